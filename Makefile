@@ -1,0 +1,39 @@
+# Build of the product library (HIP kernels + C ABI) and of the test oracle.
+#   make            -> generalized_rbda_amd/libgrbda_hip.so, oracle/_build/libgrbda_oracle.so
+#   make ref        -> oracle/_ref/libgrbda_codegen_ref.so (needs /root/reference; see oracle/Makefile)
+HIPCC ?= hipcc
+ARCH  ?= gfx950
+CSRC  := generalized_rbda_amd/csrc
+OBJ   := build/obj
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+
+LIB := generalized_rbda_amd/libgrbda_hip.so
+
+all: $(LIB) oracle
+
+$(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OBJ)/capi.o: $(CSRC)/capi.cpp $(CSRC)/plan.h $(CSRC)/devplan.h include/grbda_hip.h include/grbda_model_desc.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(OBJ)/plan.o: $(CSRC)/plan.cpp $(CSRC)/plan.h include/grbda_hip.h include/grbda_model_desc.h
+	@mkdir -p $(OBJ)
+	g++ -O2 -std=c++17 -fPIC -Wall -c $< -o $@
+$(OBJ)/urdf.o: $(CSRC)/urdf.cpp include/grbda_hip.h include/grbda_model_desc.h
+	@mkdir -p $(OBJ)
+	g++ -O2 -std=c++17 -fPIC -Wall -c $< -o $@
+
+$(LIB): $(OBJ)/kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+oracle:
+	$(MAKE) -C oracle
+
+ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -rf build $(LIB) oracle/_build oracle/_ref
+
+.PHONY: all oracle ref clean

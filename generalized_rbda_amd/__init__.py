@@ -1,0 +1,205 @@
+"""generalized_rbda_amd -- Python plumbing over the C ABI of libgrbda_hip.so.
+
+The product is the HIP library (``csrc/``) behind ``include/grbda_hip.h``; this package only loads it,
+wraps plans, and passes torch device pointers / streams through.  There is no CPU fallback:
+every dynamics call raises ``GrbdaError`` when the library or a HIP device is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from typing import Optional
+
+from . import modeldesc  # noqa: F401  (model-description builder)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrbda_hip.so")
+
+# every entry point include/grbda_hip.h declares
+C_ABI_SYMBOLS = [
+    "grbda_strerror", "grbda_last_error", "grbda_plan_from_blob", "grbda_plan_from_urdf", "grbda_urdf_to_blob",
+    "grbda_plan_free", "grbda_plan_dims", "grbda_plan_set_gravity", "grbda_plan_get_gravity", "grbda_plan_blob",
+    "grbda_plan_info", "grbda_aba_f64", "grbda_aba_f32", "grbda_rnea_f64", "grbda_rnea_f32",
+    "grbda_aba_host_f64", "grbda_rnea_host_f64", "grbda_time_kernel", "grbda_device_count",
+]
+
+
+class GrbdaError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"grbda error {code}: {detail}")
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [("n_slots", c_int), ("n_lds_slots_f32", c_int), ("n_lds_slots_f64", c_int),
+                ("lds_bytes_f32", c_size_t), ("lds_bytes_f64", c_size_t),
+                ("scratch_bytes_per_wave_f32", c_size_t), ("scratch_bytes_per_wave_f64", c_size_t),
+                ("flops_aba", c_double), ("flops_rnea", c_double),
+                ("bytes_aba_f32", c_double), ("bytes_aba_f64", c_double)]
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libgrbda_hip.so (built in-tree by ``make`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GrbdaError(-3, f"{LIB_PATH} is missing: build it with `make` (there is no CPU fallback)")
+    L = ctypes.CDLL(LIB_PATH)
+    L.grbda_strerror.restype = c_char_p
+    L.grbda_strerror.argtypes = [c_int]
+    L.grbda_last_error.restype = c_char_p
+    L.grbda_plan_from_blob.argtypes = [c_void_p, c_size_t, POINTER(c_void_p)]
+    L.grbda_plan_from_urdf.argtypes = [c_char_p, c_int, POINTER(c_void_p)]
+    L.grbda_urdf_to_blob.argtypes = [POINTER(c_char_p), c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]
+    L.grbda_plan_free.argtypes = [c_void_p]
+    L.grbda_plan_free.restype = None
+    L.grbda_plan_dims.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+    L.grbda_plan_set_gravity.argtypes = [c_void_p, POINTER(c_double)]
+    L.grbda_plan_get_gravity.argtypes = [c_void_p, POINTER(c_double)]
+    L.grbda_plan_blob.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]
+    L.grbda_plan_info.argtypes = [c_void_p, POINTER(PlanInfo)]
+    for name in ("grbda_aba_f64", "grbda_aba_f32", "grbda_rnea_f64", "grbda_rnea_f32"):
+        getattr(L, name).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                     c_void_p]
+    for name in ("grbda_aba_host_f64", "grbda_rnea_host_f64"):
+        getattr(L, name).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]
+    L.grbda_time_kernel.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                    c_void_p, c_int, POINTER(c_float)]
+    L.grbda_device_count.restype = c_int
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise GrbdaError(rc, (lib().grbda_last_error() or b"").decode() or lib().grbda_strerror(rc).decode())
+
+
+def urdf_to_blob(paths, ori_repr: str = "quaternion") -> bytes:
+    """ClusterTreeModel::buildModelFromURDF(path | vector<path>) -> model description bytes."""
+    if isinstance(paths, (str, os.PathLike)):
+        paths = [paths]
+    arr = (c_char_p * len(paths))(*[os.fspath(p).encode() for p in paths])
+    ori = 0 if ori_repr.lower().startswith("q") else 1
+    need = c_size_t(0)
+    _check(lib().grbda_urdf_to_blob(arr, len(paths), ori, None, 0, byref(need)))
+    buf = ctypes.create_string_buffer(need.value)
+    _check(lib().grbda_urdf_to_blob(arr, len(paths), ori, buf, need.value, byref(need)))
+    return buf.raw[: need.value]
+
+
+class Plan:
+    """An immutable compiled model (``grbda_plan``)."""
+
+    def __init__(self, blob: bytes):
+        self._h = c_void_p()
+        self._blob = bytes(blob)
+        _check(lib().grbda_plan_from_blob(self._blob, len(self._blob), byref(self._h)))
+        nq, nv, nb, nc = c_int(), c_int(), c_int(), c_int()
+        _check(lib().grbda_plan_dims(self._h, byref(nq), byref(nv), byref(nb), byref(nc)))
+        self.nq, self.nv, self.n_bodies, self.n_clusters = nq.value, nv.value, nb.value, nc.value
+
+    @classmethod
+    def from_model(cls, model) -> "Plan":
+        return cls(model.serialize())
+
+    @classmethod
+    def from_urdf(cls, path, ori_repr: str = "quaternion") -> "Plan":
+        return cls(urdf_to_blob(path, ori_repr))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().grbda_plan_free(self._h)
+                self._h = c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def blob(self) -> bytes:
+        p, n = c_void_p(), c_size_t()
+        _check(lib().grbda_plan_blob(self._h, byref(p), byref(n)))
+        return ctypes.string_at(p, n.value)
+
+    def set_gravity(self, g):
+        arr = (c_double * 3)(*[float(x) for x in g])
+        _check(lib().grbda_plan_set_gravity(self._h, arr))
+
+    def get_gravity(self):
+        arr = (c_double * 3)()
+        _check(lib().grbda_plan_get_gravity(self._h, arr))
+        return list(arr)
+
+    def info(self) -> PlanInfo:
+        info = PlanInfo()
+        _check(lib().grbda_plan_info(self._h, byref(info)))
+        return info
+
+    # ---- batched dynamics on torch device tensors ------------------------------------------------
+    def _launch(self, which: str, q, qd, x, out=None, stream=None):
+        import torch
+
+        if q.dtype not in (torch.float32, torch.float64):
+            raise TypeError("q must be float32 or float64")
+        if not (q.is_cuda and qd.is_cuda and x.is_cuda):
+            raise GrbdaError(-3, "inputs must be HIP device tensors (there is no CPU fallback)")
+        B = q.shape[0]
+        if q.shape != (B, self.nq) or qd.shape != (B, self.nv) or x.shape != (B, self.nv):
+            raise ValueError(f"expected q[B,{self.nq}], qd[B,{self.nv}], x[B,{self.nv}]")
+        q, qd, x = q.contiguous(), qd.contiguous(), x.contiguous()
+        if qd.dtype != q.dtype or x.dtype != q.dtype:
+            raise TypeError("dtype mismatch")
+        if out is None:
+            out = torch.empty((B, self.nv), dtype=q.dtype, device=q.device)
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_{which}_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), qd.data_ptr(), x.data_ptr(), None, out.data_ptr(), B,
+                  q.device.index or 0, c_void_p(s.cuda_stream)))
+        return out
+
+    def forward_dynamics(self, q, qd, tau, out=None, stream=None):
+        """Batched ClusterTreeModel::forwardDynamics (cluster ABA): returns ydd[B, nv]."""
+        return self._launch("aba", q, qd, tau, out, stream)
+
+    def inverse_dynamics(self, q, qd, ydd, out=None, stream=None):
+        """Batched ClusterTreeModel::inverseDynamics (cluster RNEA): returns tau[B, nv]."""
+        return self._launch("rnea", q, qd, ydd, out, stream)
+
+    def time_kernel(self, which: str, q, qd, x, out, iters: int = 20, stream=None) -> float:
+        """Average kernel duration in ms, hipEvents on the launch stream (grbda_time_kernel)."""
+        import torch
+
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        ms = c_float(0)
+        _check(lib().grbda_time_kernel(self._h, 0 if which == "aba" else 1, 32 if q.dtype == torch.float32 else 64,
+                                       q.data_ptr(), qd.data_ptr(), x.data_ptr(), out.data_ptr(), q.shape[0],
+                                       q.device.index or 0, c_void_p(s.cuda_stream), iters, byref(ms)))
+        return ms.value
+
+    # ---- host convenience (numpy, fp64) -----------------------------------------------------------
+    def forward_dynamics_host(self, q, qd, tau, device: int = 0):
+        import numpy as np
+
+        q, qd, tau = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, qd, tau))
+        out = np.empty_like(tau)
+        _check(lib().grbda_aba_host_f64(self._h, q.ctypes.data, qd.ctypes.data, tau.ctypes.data, None,
+                                        out.ctypes.data, q.shape[0], device))
+        return out
+
+    def inverse_dynamics_host(self, q, qd, ydd, device: int = 0):
+        import numpy as np
+
+        q, qd, ydd = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, qd, ydd))
+        out = np.empty_like(ydd)
+        _check(lib().grbda_rnea_host_f64(self._h, q.ctypes.data, qd.ctypes.data, ydd.ctypes.data, None,
+                                         out.ctypes.data, q.shape[0], device))
+        return out
+
+
+def device_count() -> int:
+    return lib().grbda_device_count()

@@ -1,0 +1,424 @@
+// capi.cpp -- implementation of include/grbda_hip.h on top of plan.cpp and kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/grbda_hip.h"
+#include "../../include/grbda_model_desc.h"
+#include "devplan.h"
+
+namespace grbda_hip {
+int urdf_to_blob(const char *const *paths, int n_paths, int ori_repr, std::vector<unsigned char> &blob,
+                 std::string &err);
+
+}  // namespace grbda_hip
+
+using namespace grbda_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int set_err(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+int hip_err(hipError_t e, const char *what)
+{
+    return set_err(GRBDA_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// per-(device) copies of the plan tables; per-(device, stream) scratch slabs
+struct DeviceTables {
+    Step *aba_steps = nullptr, *rnea_steps = nullptr;
+    ClusterRec *clusters = nullptr;
+    BodyRec *bodies = nullptr;
+    double *consts64 = nullptr;
+    float *consts32 = nullptr;
+    int32_t *rnea_slot_f = nullptr;
+    int n_cu = 0;
+};
+struct Scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct grbda_plan {
+    HostPlan host;
+    std::vector<unsigned char> blob;
+    mutable std::mutex mu;
+    mutable std::map<int, DeviceTables> dev;
+    mutable std::map<std::pair<int, void *>, Scratch> scratch;
+    int lds_bytes_per_wave = 16384;  // LDS budget per wavefront for the slot store
+    int waves_per_cu = 8;
+};
+
+namespace {
+
+int n_lds_slots(const grbda_plan *p, size_t elem)
+{
+    int n = static_cast<int>(p->lds_bytes_per_wave / (elem * kWave));
+    if (n > p->host.n_slots) n = p->host.n_slots;
+    return n;
+}
+
+int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return set_err(GRBDA_ENODEVICE, "no HIP device available (there is no CPU fallback)");
+    if (device < 0 || device >= count) return set_err(GRBDA_EINVAL, "device index out of range");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_err(e, "hipSetDevice");
+    std::lock_guard<std::mutex> lk(p->mu);
+    auto it = p->dev.find(device);
+    if (it != p->dev.end()) {
+        *out = &it->second;
+        return 0;
+    }
+    DeviceTables t;
+    const HostPlan &h = p->host;
+    auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
+        hipError_t e2 = hipMalloc(dst, bytes ? bytes : 16);
+        if (e2 != hipSuccess) return e2;
+        return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    std::vector<float> c32(h.consts.begin(), h.consts.end());
+    if ((e = up(h.aba_steps.data(), h.aba_steps.size() * sizeof(Step), (void **)&t.aba_steps)) != hipSuccess ||
+        (e = up(h.rnea_steps.data(), h.rnea_steps.size() * sizeof(Step), (void **)&t.rnea_steps)) != hipSuccess ||
+        (e = up(h.clusters.data(), h.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters)) != hipSuccess ||
+        (e = up(h.bodies.data(), h.bodies.size() * sizeof(BodyRec), (void **)&t.bodies)) != hipSuccess ||
+        (e = up(h.consts.data(), h.consts.size() * sizeof(double), (void **)&t.consts64)) != hipSuccess ||
+        (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess ||
+        (e = up(h.rnea_slot_f.data(), h.rnea_slot_f.size() * sizeof(int32_t), (void **)&t.rnea_slot_f)) != hipSuccess)
+        return hip_err(e, "plan upload");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_err(e, "hipGetDeviceProperties");
+    t.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = set_max_dynamic_lds()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
+    auto ins = p->dev.emplace(device, t);
+    *out = &ins.first->second;
+    return 0;
+}
+
+int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, void **out)
+{
+    std::lock_guard<std::mutex> lk(p->mu);
+    Scratch &s = p->scratch[{device, stream}];
+    if (s.bytes < bytes) {
+        if (s.ptr) {
+            hipError_t e = hipFree(s.ptr);
+            if (e != hipSuccess) return hip_err(e, "hipFree");
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+        hipError_t e = hipMalloc(&s.ptr, bytes);
+        if (e != hipSuccess) return hip_err(e, "hipMalloc(scratch)");
+        s.bytes = bytes;
+    }
+    *out = s.ptr;
+    return 0;
+}
+
+template <class T>
+DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea)
+{
+    DevPlan<T> d;
+    const HostPlan &h = p->host;
+    d.steps = rnea ? t.rnea_steps : t.aba_steps;
+    d.n_steps = static_cast<int>(rnea ? h.rnea_steps.size() : h.aba_steps.size());
+    d.clusters = t.clusters;
+    d.bodies = t.bodies;
+    d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
+    d.nq = h.nq;
+    d.nv = h.nv;
+    d.n_slots = h.n_slots;
+    d.n_lds_slots = n_lds_slots(p, sizeof(T));
+    d.ori_repr = h.ori_repr;
+    for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+    return d;
+}
+
+template <class T>
+int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, const T *f_ext, T *out, size_t B,
+        int device, void *stream)
+{
+    if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
+    if (f_ext) return set_err(GRBDA_EUNSUPPORTED, "external forces are not implemented in the HIP kernels yet");
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    DevPlan<T> d = make_dev_plan<T>(p, *t, rnea);
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    size_t grid = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->waves_per_cu);
+    if (grid > n_tiles) grid = n_tiles;
+    const size_t n_glb = static_cast<size_t>(d.n_slots - d.n_lds_slots);
+    const size_t scratch_bytes = grid * n_glb * kWave * sizeof(T) + 256;
+    void *scratch = nullptr;
+    if (int rc = ensure_scratch(p, device, stream, scratch_bytes, &scratch)) return rc;
+    const size_t lds_bytes = static_cast<size_t>(d.n_lds_slots) * kWave * sizeof(T);
+    hipError_t e;
+    if (rnea)
+        e = launch_rnea<T>(d, t->rnea_slot_f, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid),
+                           lds_bytes, static_cast<hipStream_t>(stream));
+    else
+        e = launch_aba<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
+                          static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_err(e, rnea ? "rnea launch" : "aba launch");
+    return GRBDA_OK;
+}
+
+int run_host_f64(const grbda_plan *p, bool rnea, const double *q, const double *qd, const double *x,
+                 const double *f_ext, double *out, size_t B, int device)
+{
+    if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv;
+    double *dq = nullptr, *dqd = nullptr, *dx = nullptr, *dout = nullptr;
+    hipError_t e;
+    int rc = GRBDA_OK;
+    if ((e = hipMalloc((void **)&dq, B * nq * 8)) != hipSuccess || (e = hipMalloc((void **)&dqd, B * nv * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&dx, B * nv * 8)) != hipSuccess || (e = hipMalloc((void **)&dout, B * nv * 8)) != hipSuccess) {
+        rc = hip_err(e, "hipMalloc");
+    } else if ((e = hipMemcpy(dq, q, B * nq * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+               (e = hipMemcpy(dqd, qd, B * nv * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+               (e = hipMemcpy(dx, x, B * nv * 8, hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = hip_err(e, "hipMemcpy H2D");
+    } else {
+        rc = run<double>(p, rnea, dq, dqd, dx, f_ext, dout, B, device, nullptr);
+        if (rc == GRBDA_OK) {
+            if ((e = hipDeviceSynchronize()) != hipSuccess) rc = hip_err(e, "kernel execution");
+            else if ((e = hipMemcpy(out, dout, B * nv * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_err(e, "hipMemcpy D2H");
+        }
+    }
+    if (dq) (void)hipFree(dq);
+    if (dqd) (void)hipFree(dqd);
+    if (dx) (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *grbda_strerror(int code)
+{
+    switch (code) {
+        case GRBDA_OK: return "ok";
+        case GRBDA_EINVAL: return "invalid argument or malformed model description";
+        case GRBDA_EUNSUPPORTED: return "model feature not supported by the HIP kernels";
+        case GRBDA_ENODEVICE: return "no usable HIP device";
+        case GRBDA_EHIP: return "HIP runtime error";
+        case GRBDA_ENOMEM: return "out of memory";
+        case GRBDA_EPARSE: return "URDF parse error";
+        case GRBDA_ESTATE: return "invalid spanning state";
+        default: return "unknown error";
+    }
+}
+const char *grbda_last_error(void) { return g_last_error.c_str(); }
+
+int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
+{
+    if (!out) return set_err(GRBDA_EINVAL, "null out pointer");
+    *out = nullptr;
+    std::unique_ptr<grbda_plan> p(new (std::nothrow) grbda_plan());
+    if (!p) return set_err(GRBDA_ENOMEM, "allocation failed");
+    char msg[256] = {0};
+    int rc = compile_plan(blob, bytes, p->host, msg, sizeof msg);
+    if (rc) return set_err(rc, msg);
+    p->blob.assign(static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + bytes);
+    p->lds_bytes_per_wave = env_int("GRBDA_LDS_BYTES_PER_WAVE", 16384);
+    if (p->lds_bytes_per_wave < 0) p->lds_bytes_per_wave = 0;
+    if (p->lds_bytes_per_wave > 64 * 1024) p->lds_bytes_per_wave = 64 * 1024;
+    p->waves_per_cu = env_int("GRBDA_WAVES_PER_CU", 8);
+    if (p->waves_per_cu < 1) p->waves_per_cu = 1;
+    if (p->waves_per_cu > 32) p->waves_per_cu = 32;
+    *out = p.release();
+    return GRBDA_OK;
+}
+
+int grbda_urdf_to_blob(const char *const *paths, int n_paths, int ori_repr, void *buf, size_t cap, size_t *needed)
+{
+    if (!paths || n_paths <= 0) return set_err(GRBDA_EINVAL, "no URDF path");
+    std::vector<unsigned char> blob;
+    std::string err;
+    int rc = urdf_to_blob(paths, n_paths, ori_repr, blob, err);
+    if (rc) return set_err(rc, err);
+    if (needed) *needed = blob.size();
+    if (buf) {
+        if (cap < blob.size()) return set_err(GRBDA_EINVAL, "buffer too small");
+        std::memcpy(buf, blob.data(), blob.size());
+    }
+    return GRBDA_OK;
+}
+
+int grbda_plan_from_urdf(const char *path, int ori_repr, grbda_plan **out)
+{
+    if (!path || !out) return set_err(GRBDA_EINVAL, "null argument");
+    std::vector<unsigned char> blob;
+    std::string err;
+    const char *paths[1] = {path};
+    int rc = urdf_to_blob(paths, 1, ori_repr, blob, err);
+    if (rc) return set_err(rc, err);
+    return grbda_plan_from_blob(blob.data(), blob.size(), out);
+}
+
+void grbda_plan_free(grbda_plan *p)
+{
+    if (!p) return;
+    for (auto &kv : p->dev) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        DeviceTables &t = kv.second;
+        (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.clusters); (void)hipFree(t.bodies);
+        (void)hipFree(t.consts64); (void)hipFree(t.consts32); (void)hipFree(t.rnea_slot_f);
+    }
+    for (auto &kv : p->scratch) {
+        if (hipSetDevice(kv.first.first) != hipSuccess) continue;
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    }
+    delete p;
+}
+
+int grbda_plan_dims(const grbda_plan *p, int *nq, int *nv, int *n_bodies, int *n_clusters)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    if (nq) *nq = p->host.nq;
+    if (nv) *nv = p->host.nv;
+    if (n_bodies) *n_bodies = p->host.n_bodies;
+    if (n_clusters) *n_clusters = p->host.n_clusters;
+    return GRBDA_OK;
+}
+
+int grbda_plan_set_gravity(grbda_plan *p, const double g[3])
+{
+    if (!p || !g) return set_err(GRBDA_EINVAL, "null argument");
+    for (int i = 0; i < 3; i++) p->host.gravity[3 + i] = g[i];
+    // keep the stored description in sync so that grbda_plan_blob() round-trips
+    std::memcpy(reinterpret_cast<grbda_desc_header *>(p->blob.data())->gravity, p->host.gravity, sizeof(double) * 6);
+    return GRBDA_OK;
+}
+int grbda_plan_get_gravity(const grbda_plan *p, double g[3])
+{
+    if (!p || !g) return set_err(GRBDA_EINVAL, "null argument");
+    for (int i = 0; i < 3; i++) g[i] = p->host.gravity[3 + i];
+    return GRBDA_OK;
+}
+
+int grbda_plan_blob(const grbda_plan *p, const void **blob, size_t *bytes)
+{
+    if (!p || !blob || !bytes) return set_err(GRBDA_EINVAL, "null argument");
+    *blob = p->blob.data();
+    *bytes = p->blob.size();
+    return GRBDA_OK;
+}
+
+int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
+{
+    if (!p || !info) return set_err(GRBDA_EINVAL, "null argument");
+    std::memset(info, 0, sizeof *info);
+    info->n_slots = p->host.n_slots;
+    info->n_lds_slots_f32 = n_lds_slots(p, 4);
+    info->n_lds_slots_f64 = n_lds_slots(p, 8);
+    info->lds_bytes_f32 = static_cast<size_t>(info->n_lds_slots_f32) * kWave * 4;
+    info->lds_bytes_f64 = static_cast<size_t>(info->n_lds_slots_f64) * kWave * 8;
+    info->scratch_bytes_per_wave_f32 = static_cast<size_t>(p->host.n_slots - info->n_lds_slots_f32) * kWave * 4;
+    info->scratch_bytes_per_wave_f64 = static_cast<size_t>(p->host.n_slots - info->n_lds_slots_f64) * kWave * 8;
+    info->flops_aba = p->host.flops_aba;
+    info->flops_rnea = p->host.flops_rnea;
+    info->bytes_aba_f32 = (p->host.nq + 3.0 * p->host.nv) * 4;
+    info->bytes_aba_f64 = (p->host.nq + 3.0 * p->host.nv) * 8;
+    return GRBDA_OK;
+}
+
+int grbda_aba_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, const double *f_ext,
+                  double *ydd, size_t B, int device, void *stream)
+{
+    return run<double>(p, false, q, qd, tau, f_ext, ydd, B, device, stream);
+}
+int grbda_aba_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, const float *f_ext,
+                  float *ydd, size_t B, int device, void *stream)
+{
+    return run<float>(p, false, q, qd, tau, f_ext, ydd, B, device, stream);
+}
+int grbda_rnea_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, const double *f_ext,
+                   double *tau, size_t B, int device, void *stream)
+{
+    return run<double>(p, true, q, qd, ydd, f_ext, tau, B, device, stream);
+}
+int grbda_rnea_f32(const grbda_plan *p, const float *q, const float *qd, const float *ydd, const float *f_ext,
+                   float *tau, size_t B, int device, void *stream)
+{
+    return run<float>(p, true, q, qd, ydd, f_ext, tau, B, device, stream);
+}
+
+int grbda_aba_host_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau,
+                       const double *f_ext, double *ydd, size_t B, int device)
+{
+    return run_host_f64(p, false, q, qd, tau, f_ext, ydd, B, device);
+}
+int grbda_rnea_host_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd,
+                        const double *f_ext, double *tau, size_t B, int device)
+{
+    return run_host_f64(p, true, q, qd, ydd, f_ext, tau, B, device);
+}
+
+int grbda_time_kernel(const grbda_plan *p, int kind, int precision, const void *q, const void *qd, const void *x,
+                      void *out, size_t B, int device, void *stream, int iters, float *avg_ms)
+{
+    if (!avg_ms || iters <= 0 || (precision != 32 && precision != 64) || (kind != 0 && kind != 1))
+        return set_err(GRBDA_EINVAL, "bad timing arguments");
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    hipEvent_t e0, e1;
+    hipError_t e;
+    if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return hip_err(e, "hipEventCreate");
+    auto once = [&]() -> int {
+        if (precision == 32)
+            return run<float>(p, kind == 1, static_cast<const float *>(q), static_cast<const float *>(qd),
+                              static_cast<const float *>(x), nullptr, static_cast<float *>(out), B, device, stream);
+        return run<double>(p, kind == 1, static_cast<const double *>(q), static_cast<const double *>(qd),
+                           static_cast<const double *>(x), nullptr, static_cast<double *>(out), B, device, stream);
+    };
+    int rc = once();  // warm-up: uploads tables, sizes scratch
+    if (rc == GRBDA_OK) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if ((e = hipEventRecord(e0, s)) != hipSuccess) rc = hip_err(e, "hipEventRecord");
+        for (int i = 0; i < iters && rc == GRBDA_OK; i++) rc = once();
+        if (rc == GRBDA_OK && (e = hipEventRecord(e1, s)) != hipSuccess) rc = hip_err(e, "hipEventRecord");
+        if (rc == GRBDA_OK && (e = hipEventSynchronize(e1)) != hipSuccess) rc = hip_err(e, "hipEventSynchronize");
+        float ms = 0;
+        if (rc == GRBDA_OK && (e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) rc = hip_err(e, "hipEventElapsedTime");
+        if (rc == GRBDA_OK) *avg_ms = ms / static_cast<float>(iters);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int grbda_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count < 0 ? 0 : count;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// devplan.h -- kernel argument block and launcher declarations shared by kernels.hip and capi.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+
+namespace grbda_hip {
+
+template <class T>
+struct DevPlan {
+    const Step *steps;
+    int n_steps;
+    const ClusterRec *clusters;
+    const BodyRec *bodies;
+    const T *consts;
+    int nq, nv;
+    int n_slots, n_lds_slots;
+    int ori_repr;
+    T a_root[6];  // -gravity (ClusterTreeDynamics.cpp:147)
+};
+
+template <class T>
+hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch,
+                      int grid, size_t lds_bytes, hipStream_t stream);
+template <class T>
+hipError_t launch_rnea(const DevPlan<T> &P, const int *slot_f, const T *q, const T *qd, const T *ydd, T *tau,
+                       size_t B, T *scratch, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t set_max_dynamic_lds();
+
+}  // namespace grbda_hip

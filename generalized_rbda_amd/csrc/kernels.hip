@@ -1,0 +1,1009 @@
+// kernels.hip -- batched cluster-ABA and cluster-RNEA for gfx950 (MI355X, CDNA4).
+//
+// Execution model
+//   * one robot STATE per lane, 64 states per wavefront, one wavefront per workgroup;
+//   * every lane evaluates the SAME model, so the model "program" (plan.h: steps, body and
+//     cluster records, Xtree / inertia / G constants) is wave-uniform: it is read through the
+//     scalar unit (s_load) and feeds the VALU as SGPR operands, while the 64 lanes run the
+//     per-state spatial arithmetic with no divergence and no cross-lane traffic;
+//   * per-state intermediates are "slots" laid out [slot][lane]: LDS for the first
+//     n_lds_slots (conflict-free: lane == bank), a per-wave global slab for the rest
+//     (one fully coalesced 256/512-byte row per access);
+//   * a wave walks the batch with a grid stride, so the scratch slab stays hot in L2.
+//
+// Algorithm (structured restatement of the reference's dense cluster formulation)
+//   The reference builds dense 6k x 6k cluster quantities (ClusterTreeDynamics.cpp:157-191).
+//   Here the same recursion is carried per BODY of the spanning tree, in "relative in-cluster
+//   coordinates" (S = X_intra * S_span * G, GenericJoint.cpp:426): with T = X_intra,
+//     D  = S^T IA S      = G^T (Shat^T (T^T IA T) Shat) G = G^T Hc G
+//     F  = Xup^T IA S    = sum_j fc_j G_j.          (6 x n, parent-body frame)
+//     u' = tau - S^T(pA + IA c) = tau - G^T b
+//   where Hc (k x k) is the in-cluster joint-space inertia of the composite articulated
+//   inertias, fc_j the force at the parent body per unit spanning acceleration of joint j and
+//   b_j the in-cluster bias torque.  The projected inertia / bias handed to the parent body are
+//     IA_p += sum_roots X^T IAc X - F D^-1 F^T,   pA_p += sum_roots X^T t + F D^-1 u'
+//   which equals Xup^T (IA - U D^-1 U^T) Xup and Xup^T (pA + Ia c + U D^-1 u)
+//   (ClusterTreeDynamics.cpp:120-127,181-187) whenever all in-cluster roots hang off one parent
+//   body (checked by the plan compiler).
+#include <hip/hip_runtime.h>
+
+#include "devplan.h"
+
+namespace grbda_hip {
+
+// ---------------------------------------------------------------------------------------------
+// slot store
+// ---------------------------------------------------------------------------------------------
+// The LDS array is always addressed through this symbol (never through a generic pointer), so
+// every access compiles to ds_read / ds_write and never to a flat instruction.
+extern __shared__ __attribute__((aligned(16))) unsigned char grbda_smem[];
+
+template <class T>
+struct Slots {
+    T *glb;  // wave's global slab + lane - n_lds*64 (indexable by absolute slot number)
+    int lane;
+    int n_lds;
+
+    __device__ __forceinline__ T lds_get(int s) const { return reinterpret_cast<T *>(grbda_smem)[s * kWave + lane]; }
+    __device__ __forceinline__ void lds_put(int s, T x) const { reinterpret_cast<T *>(grbda_smem)[s * kWave + lane] = x; }
+
+    template <int N>
+    __device__ __forceinline__ void ld(int s, T (&x)[N]) const
+    {
+        if (s + N <= n_lds) {
+#pragma unroll
+            for (int i = 0; i < N; i++) x[i] = lds_get(s + i);
+        } else if (s >= n_lds) {
+#pragma unroll
+            for (int i = 0; i < N; i++) x[i] = glb[(size_t)(s + i) * kWave];
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                if (s + i < n_lds) x[i] = lds_get(s + i);
+                else x[i] = glb[(size_t)(s + i) * kWave];
+            }
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ void st(int s, const T (&x)[N]) const
+    {
+        if (s + N <= n_lds) {
+#pragma unroll
+            for (int i = 0; i < N; i++) lds_put(s + i, x[i]);
+        } else if (s >= n_lds) {
+#pragma unroll
+            for (int i = 0; i < N; i++) glb[(size_t)(s + i) * kWave] = x[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                if (s + i < n_lds) lds_put(s + i, x[i]);
+                else glb[(size_t)(s + i) * kWave] = x[i];
+            }
+        }
+    }
+    // x is stored when first != 0, accumulated otherwise
+    template <int N>
+    __device__ __forceinline__ void acc(int s, const T (&x)[N], int first) const
+    {
+        if (first) {
+            st(s, x);
+        } else {
+            T y[N];
+            ld(s, y);
+#pragma unroll
+            for (int i = 0; i < N; i++) y[i] += x[i];
+            st(s, y);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// spatial algebra on (E, r) transforms -- src/Utils/SpatialTransforms.cpp:32-157
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int sidx(int i, int j)
+{  // packed upper-triangular index of a symmetric 6x6
+    return i <= j ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j));
+}
+
+// E = R_axis(theta) * Et  (ori::coordinateRotation, OrientationTools.h:46-68; XJ * Xtree)
+template <class T>
+__device__ __forceinline__ void build_E(int axis, T s, T c, const T *Et, T (&E)[9])
+{
+    if (axis == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            E[j] = Et[j];
+            E[3 + j] = c * Et[3 + j] + s * Et[6 + j];
+            E[6 + j] = c * Et[6 + j] - s * Et[3 + j];
+        }
+    } else if (axis == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            E[j] = c * Et[j] - s * Et[6 + j];
+            E[3 + j] = Et[3 + j];
+            E[6 + j] = s * Et[j] + c * Et[6 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            E[j] = c * Et[j] + s * Et[3 + j];
+            E[3 + j] = c * Et[3 + j] - s * Et[j];
+            E[6 + j] = Et[6 + j];
+        }
+    }
+}
+
+// transformMotionVector: [E w ; E (v - r x w)]
+template <class T>
+__device__ __forceinline__ void xmotion(const T (&E)[9], const T *r, const T (&m)[6], T (&o)[6])
+{
+    const T t0 = m[3] - (r[1] * m[2] - r[2] * m[1]);
+    const T t1 = m[4] - (r[2] * m[0] - r[0] * m[2]);
+    const T t2 = m[5] - (r[0] * m[1] - r[1] * m[0]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        o[i] = E[3 * i] * m[0] + E[3 * i + 1] * m[1] + E[3 * i + 2] * m[2];
+        o[3 + i] = E[3 * i] * t0 + E[3 * i + 1] * t1 + E[3 * i + 2] * t2;
+    }
+}
+
+// inverseTransformForceVector: [E^T n + r x (E^T f) ; E^T f]
+template <class T>
+__device__ __forceinline__ void xforce_inv(const T (&E)[9], const T *r, const T (&f)[6], T (&o)[6])
+{
+    T n[3], l[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        n[i] = E[i] * f[0] + E[3 + i] * f[1] + E[6 + i] * f[2];
+        l[i] = E[i] * f[3] + E[3 + i] * f[4] + E[6 + i] * f[5];
+    }
+    o[0] = n[0] + (r[1] * l[2] - r[2] * l[1]);
+    o[1] = n[1] + (r[2] * l[0] - r[0] * l[2]);
+    o[2] = n[2] + (r[0] * l[1] - r[1] * l[0]);
+    o[3] = l[0];
+    o[4] = l[1];
+    o[5] = l[2];
+}
+
+// R = E^T M E for a general 3x3 M (row-major)
+template <class T>
+__device__ __forceinline__ void rot3(const T (&E)[9], const T (&M)[9], T (&R)[9])
+{
+    T t[9];  // t = M E
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = M[3 * i] * E[j] + M[3 * i + 1] * E[3 + j] + M[3 * i + 2] * E[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R[3 * i + j] = E[i] * t[j] + E[3 + i] * t[3 + j] + E[6 + i] * t[6 + j];
+}
+
+// B = X^T A X for symmetric 6x6 A (packed), X = (E, r):
+// Transform::inverseTransformSpatialInertia (SpatialTransforms.cpp:111-135)
+template <class T>
+__device__ __forceinline__ void congruence(const T (&E)[9], const T *r, const T (&A)[21], T (&B)[21])
+{
+    T A11[9], A12[9], A22[9], R11[9], R12[9], R22[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A11[3 * i + j] = A[sidx(i, j)];
+            A12[3 * i + j] = A[sidx(i, 3 + j)];
+            A22[3 * i + j] = A[sidx(3 + i, 3 + j)];
+        }
+    rot3(E, A11, R11);
+    rot3(E, A12, R12);
+    rot3(E, A22, R22);
+    // TR = R12 + r^ R22 ; column j of r^ R22 is r x R22[:, j]
+    T TR[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        TR[j] = R12[j] + (r[1] * R22[6 + j] - r[2] * R22[3 + j]);
+        TR[3 + j] = R12[3 + j] + (r[2] * R22[j] - r[0] * R22[6 + j]);
+        TR[6 + j] = R12[6 + j] + (r[0] * R22[3 + j] - r[1] * R22[j]);
+    }
+    // N = R12 r^ (row i = R12[i,:] x r),  P = TR r^ ;  TL = R11 - N^T - P
+    T N[9], Pm[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        N[3 * i + 0] = R12[3 * i + 1] * r[2] - R12[3 * i + 2] * r[1];
+        N[3 * i + 1] = R12[3 * i + 2] * r[0] - R12[3 * i + 0] * r[2];
+        N[3 * i + 2] = R12[3 * i + 0] * r[1] - R12[3 * i + 1] * r[0];
+        Pm[3 * i + 0] = TR[3 * i + 1] * r[2] - TR[3 * i + 2] * r[1];
+        Pm[3 * i + 1] = TR[3 * i + 2] * r[0] - TR[3 * i + 0] * r[2];
+        Pm[3 * i + 2] = TR[3 * i + 0] * r[1] - TR[3 * i + 1] * r[0];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j >= i) {
+                B[sidx(i, j)] = R11[3 * i + j] - N[3 * j + i] - Pm[3 * i + j];
+                B[sidx(3 + i, 3 + j)] = R22[3 * i + j];
+            }
+            B[sidx(i, 3 + j)] = TR[3 * i + j];
+        }
+}
+
+// y = A x for packed symmetric A
+template <class T>
+__device__ __forceinline__ void symv(const T (&A)[21], const T (&x)[6], T (&y)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) s += A[sidx(i, j)] * x[j];
+        y[i] = s;
+    }
+}
+template <class T>
+__device__ __forceinline__ void symv_c(const T *A /* wave-uniform constants */, const T (&x)[6], T (&y)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) s += A[sidx(i, j)] * x[j];
+        y[i] = s;
+    }
+}
+
+// forceCrossProduct(a, b) (Spatial.h:177-188)
+template <class T>
+__device__ __forceinline__ void crf(const T (&a)[6], const T (&b)[6], T (&o)[6])
+{
+    o[0] = b[2] * a[1] - b[1] * a[2] - b[4] * a[5] + b[5] * a[4];
+    o[1] = b[0] * a[2] - b[2] * a[0] + b[3] * a[5] - b[5] * a[3];
+    o[2] = b[1] * a[0] - b[0] * a[1] - b[3] * a[4] + b[4] * a[3];
+    o[3] = b[5] * a[1] - b[4] * a[2];
+    o[4] = b[3] * a[2] - b[5] * a[0];
+    o[5] = b[4] * a[0] - b[3] * a[1];
+}
+
+// c = motionCrossProduct(v, e_axis * qd) (Spatial.h:131-143): the velocity-product
+// acceleration of a revolute joint about a coordinate axis
+template <class T>
+__device__ __forceinline__ void vxaxis(int axis, const T (&v)[6], T qd, T (&c)[6])
+{
+    if (axis == 0) {
+        c[0] = 0; c[1] = v[2] * qd; c[2] = -v[1] * qd;
+        c[3] = 0; c[4] = v[5] * qd; c[5] = -v[4] * qd;
+    } else if (axis == 1) {
+        c[0] = -v[2] * qd; c[1] = 0; c[2] = v[0] * qd;
+        c[3] = -v[5] * qd; c[4] = 0; c[5] = v[3] * qd;
+    } else {
+        c[0] = v[1] * qd; c[1] = -v[0] * qd; c[2] = 0;
+        c[3] = v[4] * qd; c[4] = -v[3] * qd; c[5] = 0;
+    }
+}
+
+template <class T>
+__device__ __forceinline__ T pick(const T (&x)[6], int axis)
+{
+    return axis == 0 ? x[0] : (axis == 1 ? x[1] : x[2]);
+}
+template <class T>
+__device__ __forceinline__ void column(const T (&A)[21], int axis, T (&h)[6])
+{
+    if (axis == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) h[i] = A[sidx(i, 0)];
+    } else if (axis == 1) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) h[i] = A[sidx(i, 1)];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) h[i] = A[sidx(i, 2)];
+    }
+}
+template <class T>
+__device__ __forceinline__ void add_axis(T (&x)[6], int axis, T val)
+{
+    if (axis == 0) x[0] += val;
+    else if (axis == 1) x[1] += val;
+    else x[2] += val;
+}
+
+__device__ __forceinline__ void sincos_t(float x, float *s, float *c) { sincosf(x, s, c); }
+__device__ __forceinline__ void sincos_t(double x, double *s, double *c) { sincos(x, s, c); }
+
+// in-place Cholesky factor + solves for an N x N SPD matrix held in registers.
+// The reference inverts D = S^T IA S with ColPivHouseholderQR (ClusterTreeNode.cpp:33-37,
+// Utilities.h:325-329); D is SPD so LL^T agrees to rounding.
+template <class T, int N>
+struct Chol {
+    T L[N][N];
+    T inv[N];
+    __device__ __forceinline__ void factor(const T (&A)[N][N])
+    {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            T d = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+            const T rs = T(1) / sqrt(d);
+            inv[j] = rs;
+            L[j][j] = d * rs;
+#pragma unroll
+            for (int i = j + 1; i < N; i++) {
+                T s = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+                L[i][j] = s * rs;
+            }
+        }
+    }
+    __device__ __forceinline__ void solve(T (&b)[N]) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            T s = b[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) s -= L[i][k] * b[k];
+            b[i] = s * inv[i];
+        }
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {
+            T s = b[i];
+#pragma unroll
+            for (int k = i + 1; k < N; k++) s -= L[k][i] * b[k];
+            b[i] = s * inv[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// per-lane view of one state of the batch
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Lane {
+    const T *q, *qd, *x;  // x: tau (ABA) or ydd (RNEA)
+    T *out;               // ydd (ABA) or tau (RNEA)
+    bool active;
+};
+
+// spanning joint value of body i: row i of G times the independent cluster coordinates
+// (LoopConstraint::Static::gamma, LoopConstraint.cpp:49-52; ClusterJoint.cpp:55-58)
+template <class T, int N>
+__device__ __forceinline__ T gdot(const T *G, const T (&y)[N])
+{
+    T s = 0;
+#pragma unroll
+    for (int a = 0; a < N; a++) s += G[a] * y[a];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ABA sweep 1: ClusterTreeNode::updateKinematics + TreeModel::forwardKinematics
+// (ClusterTreeNode.cpp:26-31, TreeModel.cpp:6-32)
+// ---------------------------------------------------------------------------------------------
+template <class T, int N>
+__device__ __forceinline__ void aba_fwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                               const Lane<T> &L)
+{
+    T y[N], yd[N];
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        y[a] = L.q[c.q_index + a];
+        yd[a] = L.qd[c.v_index + a];
+    }
+    for (int i = 0; i < c.k; i++) {
+        const BodyRec &b = P.bodies[c.first_body + i];
+        const T *C = P.consts + b.cofs;
+        const T *G = C + kBodyConstFixed;
+        const T qi = gdot<T, N>(G, y), qdi = gdot<T, N>(G, yd);
+        T sc[2];
+        sincos_t(qi, &sc[0], &sc[1]);
+        S.st(b.slot_sc, sc);
+        T E[9], v[6];
+        build_E(b.axis, sc[0], sc[1], C, E);
+        if (b.parent >= 0) {
+            T vp[6];
+            S.ld(b.parent_slot_v, vp);
+            xmotion(E, C + 9, vp, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) v[j] = 0;
+        }
+        add_axis(v, b.axis, qdi);
+        S.st(b.slot_v, v);
+    }
+}
+
+// quaternionToRotationMatrix (OrientationTools.h:251-269) / rpyToRotMat (:121-130)
+template <class T>
+__device__ __forceinline__ void free_rotation(int ori_repr, const T *o, T (&E)[9])
+{
+    if (ori_repr == 0) {
+        const T e0 = o[0], e1 = o[1], e2 = o[2], e3 = o[3];
+        E[0] = 1 - 2 * (e2 * e2 + e3 * e3); E[3] = 2 * (e1 * e2 - e0 * e3);     E[6] = 2 * (e1 * e3 + e0 * e2);
+        E[1] = 2 * (e1 * e2 + e0 * e3);     E[4] = 1 - 2 * (e1 * e1 + e3 * e3); E[7] = 2 * (e2 * e3 - e0 * e1);
+        E[2] = 2 * (e1 * e3 - e0 * e2);     E[5] = 2 * (e2 * e3 + e0 * e1);     E[8] = 1 - 2 * (e1 * e1 + e2 * e2);
+    } else {
+        T sx, cx, sy, cy, sz, cz;
+        sincos_t(o[0], &sx, &cx);
+        sincos_t(o[1], &sy, &cy);
+        sincos_t(o[2], &sz, &cz);
+        // Rx * Ry * Rz with coordinate rotations
+        const T Rxy[9] = {cy, 0, -sy, sx * sy, cx, sx * cy, cx * sy, -sx, cx * cy};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            E[3 * i + 0] = Rxy[3 * i] * cz - Rxy[3 * i + 1] * sz;
+            E[3 * i + 1] = Rxy[3 * i] * sz + Rxy[3 * i + 1] * cz;
+            E[3 * i + 2] = Rxy[3 * i + 2];
+        }
+    }
+}
+
+// Free cluster (FreeJoint.cpp:28-46, Joint.h:61-68): Xup = XJ = (R(ori), position), v = yd
+template <class T>
+__device__ __forceinline__ void fwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                         const Lane<T> &L, T (&Er)[12], T (&v)[6])
+{
+    const BodyRec &b = P.bodies[c.first_body];
+    T o[4];
+    const int nori = P.ori_repr == 0 ? 4 : 3;
+    for (int j = 0; j < 4; j++) o[j] = j < nori ? L.q[c.q_index + 3 + j] : T(0);
+    T E[9];
+    free_rotation(P.ori_repr, o, E);
+#pragma unroll
+    for (int j = 0; j < 9; j++) Er[j] = E[j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Er[9 + j] = L.q[c.q_index + j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
+    S.st(b.slot_sc, Er);
+    S.st(b.slot_v, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ABA sweep 2 (fused 2a + 2b): updateArticulatedBodies + bias back-propagation
+// (ClusterTreeDynamics.cpp:94-129,157-191; ClusterTreeNode.cpp:33-37)
+// ---------------------------------------------------------------------------------------------
+template <class T, int N>
+__device__ __forceinline__ void aba_bwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                               const Lane<T> &L)
+{
+    T yd[N], u[N], F[6][N], D[N][N];
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        yd[a] = L.qd[c.v_index + a];
+        u[a] = L.x[c.v_index + a];
+#pragma unroll
+        for (int r = 0; r < 6; r++) F[r][a] = 0;
+#pragma unroll
+        for (int bb = 0; bb < N; bb++) D[a][bb] = 0;
+    }
+
+    // in-cluster bias acceleration (the cJ part of GenericJoint.cpp:430-450), chained clusters only
+    if (c.chained) {
+        for (int i = 0; i < c.k; i++) {
+            const BodyRec &b = P.bodies[c.first_body + i];
+            const T *C = P.consts + b.cofs;
+            const T qdi = gdot<T, N>(C + kBodyConstFixed, yd);
+            T v[6], ccl[6];
+            S.ld(b.slot_v, v);
+            vxaxis(b.axis, v, qdi, ccl);
+            if (b.lam >= 0) {
+                T sc[2], E[9], cp[6], t[6];
+                S.ld(b.slot_sc, sc);
+                build_E(b.axis, sc[0], sc[1], C, E);
+                S.ld(P.bodies[b.lam].slot_ccl, cp);
+                xmotion(E, C + 9, cp, t);
+#pragma unroll
+                for (int j = 0; j < 6; j++) ccl[j] += t[j];
+            }
+            S.st(b.slot_ccl, ccl);
+        }
+    }
+
+    for (int i = c.k - 1; i >= 0; i--) {
+        const BodyRec &b = P.bodies[c.first_body + i];
+        const T *C = P.consts + b.cofs;
+        const T *G = C + kBodyConstFixed;
+        const T *Ic = C + 12;
+        T sc[2], E[9], v[6];
+        S.ld(b.slot_sc, sc);
+        S.ld(b.slot_v, v);
+        build_E(b.axis, sc[0], sc[1], C, E);
+        const T qdi = gdot<T, N>(G, yd);
+        T chat[6];
+        vxaxis(b.axis, v, qdi, chat);
+
+        // composite articulated inertia and bias of this body
+        T IA[21], psi[6];
+        {
+            T Iv[6];
+            symv_c(Ic, v, Iv);
+            crf(v, Iv, psi);  // pA = v x* (I v), ClusterTreeDynamics.cpp:95-98
+        }
+        if (b.has_child) {
+            T acc[21], pacc[6];
+            S.ld(b.slot_IA, acc);
+            S.ld(b.slot_psi, pacc);
+#pragma unroll
+            for (int j = 0; j < 21; j++) IA[j] = Ic[j] + acc[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) psi[j] += pacc[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 21; j++) IA[j] = Ic[j];
+        }
+
+        T h[6];
+        column(IA, b.axis, h);
+        const T d = pick(h, b.axis);
+        T bj = pick(psi, b.axis);
+        if (c.chained) {
+            T ccl[6];
+            S.ld(b.slot_ccl, ccl);
+#pragma unroll
+            for (int j = 0; j < 6; j++) bj += h[j] * ccl[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) bj += h[j] * chat[j];
+        }
+
+        // hand composite inertia and bias to the tree parent (in-cluster or parent cluster)
+        if (b.parent >= 0) {
+            T t[6], Ic_c[6], tp[6], Bc[21];
+            symv(IA, chat, Ic_c);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t[j] = psi[j] + Ic_c[j];
+            xforce_inv(E, C + 9, t, tp);
+            S.acc(b.parent_slot_psi, tp, b.acc_first);
+            congruence(E, C + 9, IA, Bc);
+            S.acc(b.parent_slot_IA, Bc, b.acc_first);
+        }
+
+        // joint-space terms: D += d G^T G, u -= G^T b, push h up the in-cluster chain
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            u[a] -= G[a] * bj;
+#pragma unroll
+            for (int bb = 0; bb < N; bb++) D[a][bb] += d * G[a] * G[bb];
+        }
+        T f[6];
+        xforce_inv(E, C + 9, h, f);
+        int l = b.lam;
+        while (l >= 0) {
+            const BodyRec &bl = P.bodies[l];
+            const T *Cl = P.consts + bl.cofs;
+            const T *Gl = Cl + kBodyConstFixed;
+            const T Hc = pick(f, bl.axis);
+#pragma unroll
+            for (int a = 0; a < N; a++)
+#pragma unroll
+                for (int bb = 0; bb < N; bb++) D[a][bb] += Hc * (Gl[a] * G[bb] + G[a] * Gl[bb]);
+            T scl[2], El[9], f2[6];
+            S.ld(bl.slot_sc, scl);
+            build_E(bl.axis, scl[0], scl[1], Cl, El);
+            xforce_inv(El, Cl + 9, f, f2);
+#pragma unroll
+            for (int j = 0; j < 6; j++) f[j] = f2[j];
+            l = bl.lam;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int a = 0; a < N; a++) F[r][a] += f[r] * G[a];
+    }
+
+    // D^-1 u', K = D^-1 F^T
+    Chol<T, N> ch;
+    ch.factor(D);
+    ch.solve(u);
+    T K[6 * N];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        T col[N];
+#pragma unroll
+        for (int a = 0; a < N; a++) col[a] = F[r][a];
+        ch.solve(col);
+#pragma unroll
+        for (int a = 0; a < N; a++) K[a * 6 + r] = col[a];
+    }
+    S.st(c.slot_K, K);
+    S.st(c.slot_y0, u);
+
+    // corrections on the parent body: IA_p -= F D^-1 F^T, pA_p += F D^-1 u'
+    if (c.parent_body >= 0) {
+        T dI[21], dp[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            T s = 0;
+#pragma unroll
+            for (int a = 0; a < N; a++) s += F[r][a] * u[a];
+            dp[r] = s;
+#pragma unroll
+            for (int cc = r; cc < 6; cc++) {
+                T m = 0;
+#pragma unroll
+                for (int a = 0; a < N; a++) m -= F[r][a] * K[a * 6 + cc];
+                dI[sidx(r, cc)] = m;
+            }
+        }
+        S.acc(c.parent_slot_psi, dp, 0);
+        S.acc(c.parent_slot_IA, dI, 0);
+    }
+}
+
+// Free root: S = 1, D = IA, c = 0 (FreeJoint.cpp:10-36)
+template <class T>
+__device__ __forceinline__ void aba_bwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                             const Lane<T> &L)
+{
+    const BodyRec &b = P.bodies[c.first_body];
+    const T *Ic = P.consts + b.cofs + 12;
+    T v[6], psi[6], Iv[6], IA[21];
+    S.ld(b.slot_v, v);
+    symv_c(Ic, v, Iv);
+    crf(v, Iv, psi);
+    if (b.has_child) {
+        T acc[21], pacc[6];
+        S.ld(b.slot_IA, acc);
+        S.ld(b.slot_psi, pacc);
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + acc[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi[j] += pacc[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ic[j];
+    }
+    T D[6][6], u[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        u[i] = L.x[c.v_index + i] - psi[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) D[i][j] = IA[sidx(i, j)];
+    }
+    Chol<T, 6> ch;
+    ch.factor(D);
+    ch.solve(u);
+    S.st(c.slot_y0, u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ABA sweep 3: joint accelerations (ClusterTreeDynamics.cpp:131-152)
+// ---------------------------------------------------------------------------------------------
+template <class T, int N>
+__device__ __forceinline__ void aba_acc_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                               const Lane<T> &L)
+{
+    T K[6 * N], ydd[N], yd[N], ap[6];
+    S.ld(c.slot_K, K);
+    S.ld(c.slot_y0, ydd);
+    if (c.parent_slot_a >= 0) {
+        S.ld(c.parent_slot_a, ap);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) ap[j] = P.a_root[j];
+    }
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        T s = ydd[a];
+#pragma unroll
+        for (int r = 0; r < 6; r++) s -= K[a * 6 + r] * ap[r];
+        ydd[a] = s;
+        yd[a] = L.qd[c.v_index + a];
+        if (L.active) L.out[c.v_index + a] = s;
+    }
+    for (int i = 0; i < c.k; i++) {
+        const BodyRec &b = P.bodies[c.first_body + i];
+        if (!b.has_child) continue;  // nothing downstream needs this body's acceleration
+        const T *C = P.consts + b.cofs;
+        const T *G = C + kBodyConstFixed;
+        T sc[2], E[9], v[6], a[6], api[6];
+        S.ld(b.slot_sc, sc);
+        S.ld(b.slot_v, v);
+        build_E(b.axis, sc[0], sc[1], C, E);
+        if (b.lam >= 0) {
+            S.ld(b.parent_slot_a, api);
+            xmotion(E, C + 9, api, a);
+        } else {
+            xmotion(E, C + 9, ap, a);
+        }
+        T chat[6];
+        vxaxis(b.axis, v, gdot<T, N>(G, yd), chat);
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[j] += chat[j];
+        add_axis(a, b.axis, gdot<T, N>(G, ydd));
+        S.st(b.slot_a, a);
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void aba_acc_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                             const Lane<T> &L)
+{
+    const BodyRec &b = P.bodies[c.first_body];
+    T Er[12], y0[6], ag[6], g[6], E[9];
+    S.ld(b.slot_sc, Er);
+    S.ld(c.slot_y0, y0);
+#pragma unroll
+    for (int j = 0; j < 9; j++) E[j] = Er[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
+    xmotion(E, &Er[9], g, ag);
+    // ydd = D^-1 u - D^-1 U^T a' with U = IA, D = IA  =>  ydd = y0 - a' ;  a = a' + ydd = y0
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+        if (L.active) L.out[c.v_index + j] = y0[j] - ag[j];
+    if (b.has_child) S.st(b.slot_a, y0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RNEA (TreeModel.cpp:34-57,173-212).  Force slots: slot_IA region is reused (plan.cpp).
+// ---------------------------------------------------------------------------------------------
+template <class T, int N>
+__device__ __forceinline__ void rnea_fwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                const Lane<T> &L, const int *slot_f)
+{
+    T y[N], yd[N], ydd[N];
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        y[a] = L.q[c.q_index + a];
+        yd[a] = L.qd[c.v_index + a];
+        ydd[a] = L.x[c.v_index + a];
+    }
+    for (int i = 0; i < c.k; i++) {
+        const int gb = c.first_body + i;
+        const BodyRec &b = P.bodies[gb];
+        const T *C = P.consts + b.cofs;
+        const T *G = C + kBodyConstFixed;
+        const T qi = gdot<T, N>(G, y), qdi = gdot<T, N>(G, yd), qddi = gdot<T, N>(G, ydd);
+        T sc[2], E[9], v[6], a[6];
+        sincos_t(qi, &sc[0], &sc[1]);
+        S.st(b.slot_sc, sc);
+        build_E(b.axis, sc[0], sc[1], C, E);
+        if (b.parent >= 0) {
+            T vp[6], apar[6];
+            S.ld(b.parent_slot_v, vp);
+            S.ld(b.parent_slot_a, apar);
+            xmotion(E, C + 9, vp, v);
+            xmotion(E, C + 9, apar, a);
+        } else {
+            T g[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { v[j] = 0; g[j] = P.a_root[j]; }
+            xmotion(E, C + 9, g, a);
+        }
+        add_axis(v, b.axis, qdi);
+        T chat[6];
+        vxaxis(b.axis, v, qdi, chat);
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[j] += chat[j];
+        add_axis(a, b.axis, qddi);
+        if (b.has_child) {
+            S.st(b.slot_v, v);
+            S.st(b.slot_a, a);
+        }
+        T Ia[6], Iv[6], f[6];
+        symv_c(C + 12, a, Ia);
+        symv_c(C + 12, v, Iv);
+        crf(v, Iv, f);
+#pragma unroll
+        for (int j = 0; j < 6; j++) f[j] += Ia[j];
+        S.st(slot_f[gb], f);
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void rnea_fwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                              const Lane<T> &L, const int *slot_f)
+{
+    const BodyRec &b = P.bodies[c.first_body];
+    T Er[12], v[6], a[6], g[6], E[9];
+    fwd_free(P, S, c, L, Er, v);
+#pragma unroll
+    for (int j = 0; j < 9; j++) E[j] = Er[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
+    xmotion(E, &Er[9], g, a);
+#pragma unroll
+    for (int j = 0; j < 6; j++) a[j] += L.x[c.v_index + j];
+    if (b.has_child) S.st(b.slot_a, a);
+    T Ia[6], Iv[6], f[6];
+    const T *Ic = P.consts + b.cofs + 12;
+    symv_c(Ic, a, Ia);
+    symv_c(Ic, v, Iv);
+    crf(v, Iv, f);
+#pragma unroll
+    for (int j = 0; j < 6; j++) f[j] += Ia[j];
+    S.st(slot_f[c.first_body], f);
+}
+
+template <class T, int N>
+__device__ __forceinline__ void rnea_bwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                const Lane<T> &L, const int *slot_f)
+{
+    T tau[N];
+#pragma unroll
+    for (int a = 0; a < N; a++) tau[a] = 0;
+    for (int i = c.k - 1; i >= 0; i--) {
+        const int gb = c.first_body + i;
+        const BodyRec &b = P.bodies[gb];
+        const T *C = P.consts + b.cofs;
+        const T *G = C + kBodyConstFixed;
+        T f[6];
+        S.ld(slot_f[gb], f);
+        const T t = pick(f, b.axis);
+#pragma unroll
+        for (int a = 0; a < N; a++) tau[a] += G[a] * t;
+        if (b.parent >= 0) {
+            T sc[2], E[9], fp[6];
+            S.ld(b.slot_sc, sc);
+            build_E(b.axis, sc[0], sc[1], C, E);
+            xforce_inv(E, C + 9, f, fp);
+            S.acc(slot_f[b.parent], fp, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < N; a++)
+        if (L.active) L.out[c.v_index + a] = tau[a];
+}
+
+template <class T>
+__device__ __forceinline__ void rnea_bwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                              const Lane<T> &L, const int *slot_f)
+{
+    (void)P;
+    T f[6];
+    S.ld(slot_f[c.first_body], f);
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+        if (L.active) L.out[c.v_index + j] = f[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+#define GRBDA_DISPATCH_N(n, CALL)                  \
+    switch (n) {                                   \
+        case 1: { constexpr int N_ = 1; CALL; } break; \
+        case 2: { constexpr int N_ = 2; CALL; } break; \
+        case 3: { constexpr int N_ = 3; CALL; } break; \
+        default: { constexpr int N_ = 4; CALL; } break; \
+    }
+
+template <class T>
+__global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> P, const T *__restrict__ q,
+                                                     const T *__restrict__ qd, const T *__restrict__ tau,
+                                                     T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
+{
+    const int lane = threadIdx.x;
+    const size_t n_glb = (size_t)(P.n_slots - P.n_lds_slots);
+    Slots<T> S;
+    S.lane = lane;
+    S.glb = scratch + (size_t)blockIdx.x * n_glb * kWave + lane - (size_t)P.n_lds_slots * kWave;
+    S.n_lds = P.n_lds_slots;
+
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + lane;
+        Lane<T> L;
+        L.active = r < B;
+        const size_t rr = L.active ? r : B - 1;
+        L.q = q + rr * P.nq;
+        L.qd = qd + rr * P.nv;
+        L.x = tau + rr * P.nv;
+        L.out = ydd + rr * P.nv;
+        for (int s = 0; s < P.n_steps; s++) {
+            const Step st = P.steps[s];
+            const ClusterRec &c = P.clusters[st.cluster];
+            if (st.op == OP_ABA_FWD) {
+                if (c.kind == CK_FREE) {
+                    T Er[12], v[6];
+                    fwd_free(P, S, c, L, Er, v);
+                } else {
+                    GRBDA_DISPATCH_N(c.n, (aba_fwd_static<T, N_>(P, S, c, L)))
+                }
+            } else if (st.op == OP_ABA_BWD) {
+                if (c.kind == CK_FREE) {
+                    aba_bwd_free(P, S, c, L);
+                } else {
+                    GRBDA_DISPATCH_N(c.n, (aba_bwd_static<T, N_>(P, S, c, L)))
+                }
+            } else {
+                if (c.kind == CK_FREE) {
+                    aba_acc_free(P, S, c, L);
+                } else {
+                    GRBDA_DISPATCH_N(c.n, (aba_acc_static<T, N_>(P, S, c, L)))
+                }
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave) void rnea_kernel(DevPlan<T> P, const int *__restrict__ slot_f,
+                                                      const T *__restrict__ q, const T *__restrict__ qd,
+                                                      const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
+                                                      T *__restrict__ scratch)
+{
+    const int lane = threadIdx.x;
+    const size_t n_glb = (size_t)(P.n_slots - P.n_lds_slots);
+    Slots<T> S;
+    S.lane = lane;
+    S.glb = scratch + (size_t)blockIdx.x * n_glb * kWave + lane - (size_t)P.n_lds_slots * kWave;
+    S.n_lds = P.n_lds_slots;
+
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + lane;
+        Lane<T> L;
+        L.active = r < B;
+        const size_t rr = L.active ? r : B - 1;
+        L.q = q + rr * P.nq;
+        L.qd = qd + rr * P.nv;
+        L.x = ydd + rr * P.nv;
+        L.out = tau + rr * P.nv;
+        for (int s = 0; s < P.n_steps; s++) {
+            const Step st = P.steps[s];
+            const ClusterRec &c = P.clusters[st.cluster];
+            if (st.op == OP_RNEA_FWD) {
+                if (c.kind == CK_FREE) {
+                    rnea_fwd_free(P, S, c, L, slot_f);
+                } else {
+                    GRBDA_DISPATCH_N(c.n, (rnea_fwd_static<T, N_>(P, S, c, L, slot_f)))
+                }
+            } else {
+                if (c.kind == CK_FREE) {
+                    rnea_bwd_free(P, S, c, L, slot_f);
+                } else {
+                    GRBDA_DISPATCH_N(c.n, (rnea_bwd_static<T, N_>(P, S, c, L, slot_f)))
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers (called by capi.cpp)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch,
+                      int grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(aba_kernel<T>, dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_rnea(const DevPlan<T> &P, const int *slot_f, const T *q, const T *qd, const T *ydd, T *tau,
+                       size_t B, T *scratch, int grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rnea_kernel<T>, dim3(grid), dim3(kWave), lds_bytes, stream, P, slot_f, q, qd, ydd, tau, B,
+                       scratch);
+    return hipGetLastError();
+}
+
+template hipError_t launch_aba<float>(const DevPlan<float> &, const float *, const float *, const float *, float *,
+                                      size_t, float *, int, size_t, hipStream_t);
+template hipError_t launch_aba<double>(const DevPlan<double> &, const double *, const double *, const double *,
+                                       double *, size_t, double *, int, size_t, hipStream_t);
+template hipError_t launch_rnea<float>(const DevPlan<float> &, const int *, const float *, const float *,
+                                       const float *, float *, size_t, float *, int, size_t, hipStream_t);
+template hipError_t launch_rnea<double>(const DevPlan<double> &, const int *, const double *, const double *,
+                                        const double *, double *, size_t, double *, int, size_t, hipStream_t);
+
+hipError_t set_max_dynamic_lds()
+{
+    hipError_t e;
+    const int maxb = 160 * 1024;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_kernel<float>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_kernel<double>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_kernel<float>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_kernel<double>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+}  // namespace grbda_hip

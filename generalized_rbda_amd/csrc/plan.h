@@ -1,0 +1,108 @@
+// plan.h -- the immutable device plan a ClusterTreeModel is compiled into.
+//
+// A plan is a small wave-uniform "program" for the batched dynamics kernels (kernels.hip):
+//   * steps[]     : ordered list of (op, cluster) pairs -- forward / backward / acceleration
+//                   sweeps of cluster ABA (reference: src/Dynamics/ClusterTreeDynamics.cpp:85-191)
+//                   and of cluster RNEA (src/Dynamics/TreeModel.cpp:34-57,173-212),
+//   * clusters[]  : per-cluster integer record,
+//   * bodies[]    : per-body integer record (tree topology + state-slot numbers),
+//   * consts[]    : model constants in the kernel's scalar type (Xtree, inertias, G rows),
+// All of it is wave-uniform: every lane of a wavefront evaluates a different robot state of the
+// SAME model, so the program is fetched through the scalar unit while the vector unit does the
+// per-state arithmetic.
+//
+// Per-state intermediates live in numbered "slots": slot s of lane l is element [s][l] of a
+// per-wavefront array, so a wave's access to one slot is a fully coalesced 64-element row.
+// Slots [0, n_lds_slots) are placed in LDS, the rest in a per-wave global scratch slab.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace grbda_hip {
+
+enum StepOp : int32_t {
+    OP_ABA_FWD = 0,   // velocity propagation for one cluster            (TreeModel.cpp:6-32)
+    OP_ABA_BWD = 1,   // articulated inertia + bias back-propagation     (ClusterTreeDynamics.cpp:108-129,157-191)
+    OP_ABA_ACC = 2,   // acceleration forward-propagation, writes ydd    (ClusterTreeDynamics.cpp:131-152)
+    OP_RNEA_FWD = 3,  // velocity + acceleration + body force            (TreeModel.cpp:34-57,181-186)
+    OP_RNEA_BWD = 4   // joint torque projection + force back-propagation (TreeModel.cpp:196-209)
+};
+
+enum ClusterKind : int32_t {
+    CK_STATIC = 0,  // revolute single joints, constant G (every explicit ClusterJoint type)
+    CK_FREE = 1     // floating base root (ClusterJoints::Free)
+};
+
+constexpr int kMaxClusterDof = 4;     // n of a non-free cluster handled in registers
+constexpr int kMaxClusterBodies = 8;  // k
+constexpr int kWave = 64;
+
+struct Step {
+    int32_t op;
+    int32_t cluster;
+};
+
+struct ClusterRec {
+    int32_t kind;
+    int32_t first_body;
+    int32_t k;
+    int32_t n;
+    int32_t q_index;
+    int32_t v_index;
+    int32_t parent_body;  // global index of the single body of the parent cluster all in-cluster
+                          // roots hang off, or -1 (ground)
+    int32_t slot_K;       // n x 6 : D^-1 F^T   (ABA_BWD -> ABA_ACC)
+    int32_t slot_y0;      // n     : D^-1 u'
+    int32_t parent_slot_IA;   // accumulators of parent_body (or -1)
+    int32_t parent_slot_psi;
+    int32_t parent_slot_a;    // acceleration of parent_body (or -1: use -gravity)
+    int32_t acc_first;        // 1: this cluster is the first contributor to the parent's accumulators
+    int32_t chained;          // 1: some body has an in-cluster parent
+    int32_t reserved[2];
+};
+
+struct BodyRec {
+    int32_t parent;       // global tree-parent body index or -1
+    int32_t lam;          // in-cluster parent: global body index, or -1
+    int32_t axis;         // revolute axis 0/1/2
+    int32_t jtype;        // 0 revolute, 1 free
+    int32_t has_child;    // some body (any cluster) has this body as tree parent
+    int32_t cofs;         // offset into consts[]: Et[9] rt[3] I[21] G_row[n]
+    int32_t slot_sc;      // sin, cos of the spanning joint angle (2)        [free: E (9) + r (3)]
+    int32_t slot_v;       // spatial velocity (6)
+    int32_t slot_IA;      // composite articulated inertia accumulator (21, packed upper)
+    int32_t slot_psi;     // bias force accumulator (6); RNEA: force accumulator
+    int32_t slot_a;       // spatial acceleration (6)
+    int32_t slot_ccl;     // in-cluster bias acceleration (6), chained clusters only
+    int32_t parent_slot_v;    // slot_v / slot_a / slot_IA / slot_psi of the tree parent, -1 if none
+    int32_t parent_slot_a;
+    int32_t parent_slot_IA;
+    int32_t parent_slot_psi;
+    int32_t acc_first;        // 1: first contributor to the tree parent's accumulators
+    int32_t reserved[3];
+};
+
+// number of constants per body before the G row
+constexpr int kBodyConstFixed = 9 + 3 + 21;
+
+struct HostPlan {
+    int nq = 0, nv = 0, n_bodies = 0, n_clusters = 0;
+    int ori_repr = 0;
+    double gravity[6] = {0, 0, 0, 0, 0, -9.81};
+    std::vector<Step> aba_steps;
+    std::vector<Step> rnea_steps;
+    std::vector<ClusterRec> clusters;
+    std::vector<BodyRec> bodies;
+    std::vector<double> consts;  // converted to float on upload for the f32 kernels
+    std::vector<int32_t> rnea_slot_f;  // per body: slot of the RNEA body force (6), aliases the IA region
+    int n_slots = 0;             // total per-lane slots
+    // statistics for DESIGN.md / bench.py
+    double flops_aba = 0, flops_rnea = 0;
+};
+
+// Compile a model-description blob (include/grbda_model_desc.h) into a HostPlan.
+// Returns 0 or a negative GRBDA_E* code (include/grbda_hip.h); msg receives a diagnostic.
+int compile_plan(const void *blob, size_t bytes, HostPlan &out, char *msg, size_t msg_cap);
+
+}  // namespace grbda_hip

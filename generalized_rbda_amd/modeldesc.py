@@ -1,0 +1,414 @@
+"""Model-description builder: the Python mirror of grbda::ClusterTreeModel's construction API.
+
+It produces the flat blob declared in ``include/grbda_model_desc.h`` -- the same bytes the
+C++17 facade (``generalized_rbda_amd/include/grbda``) serialises -- so tests and ``bench.py``
+can build robots programmatically.  Method names follow the reference
+(``registerBody`` / ``appendRegisteredBodiesAsCluster``: include/grbda/Dynamics/ClusterTreeModel.h:58-78,
+src/Dynamics/ClusterTreeModel.cpp:10-67); the cluster-joint helpers restate the G / K matrices of
+the reference's explicit joint types:
+
+* ``Revolute``                 src/Dynamics/ClusterJoints/RevoluteJoint.cpp:9-23
+* ``RevoluteWithRotor``        RevoluteWithRotorJoint.cpp:9-31
+* ``RevolutePairWithRotor``    RevolutePairWithRotorJoint.cpp:10-69, Transmissions.h:34-43
+* ``RevoluteTripleWithRotor``  RevoluteTripleWithRotorJoint.cpp:10-60
+* ``Generic`` + ``Static``     GenericJoint.cpp:243-287, LoopConstraint.cpp:38-52
+* ``Free``                     FreeJoint.cpp:10-26
+
+This module only describes models; all dynamics run in the HIP library.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+MAGIC = 0x44425247
+VERSION = 1
+
+JOINT_REVOLUTE, JOINT_FREE = 0, 1
+ORI_QUATERNION, ORI_RPY = 0, 1
+C_STATIC, C_FREE, C_LOOP_POSITION, C_TRIG_POLY = 0, 1, 2, 3
+
+AXIS = {"x": 0, "y": 1, "z": 2, "X": 0, "Y": 1, "Z": 2, 0: 0, 1: 1, 2: 2}
+
+
+def skew(v):
+    v = np.asarray(v, dtype=np.float64)
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], dtype=np.float64)
+
+
+def spatial_inertia(mass: float, com, inertia3) -> np.ndarray:
+    """SpatialInertia(m, c, I_c) -- include/grbda/Utils/SpatialInertia.h:74-82."""
+    c = skew(com)
+    I = np.zeros((6, 6))
+    I[:3, :3] = np.asarray(inertia3, dtype=np.float64) + mass * c @ c.T
+    I[:3, 3:] = mass * c
+    I[3:, :3] = mass * c.T
+    I[3:, 3:] = mass * np.eye(3)
+    return I
+
+
+def coordinate_rotation(axis, theta: float) -> np.ndarray:
+    """ori::coordinateRotation -- include/grbda/Utils/OrientationTools.h:46-68."""
+    s, c = np.sin(theta), np.cos(theta)
+    a = AXIS[axis]
+    if a == 0:
+        return np.array([[1, 0, 0], [0, c, s], [0, -s, c]], dtype=np.float64)
+    if a == 1:
+        return np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]], dtype=np.float64)
+    return np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]], dtype=np.float64)
+
+
+def rpy_to_rotmat(rpy) -> np.ndarray:
+    """ori::rpyToRotMat -- OrientationTools.h:121-130."""
+    return coordinate_rotation(0, rpy[0]) @ coordinate_rotation(1, rpy[1]) @ coordinate_rotation(2, rpy[2])
+
+
+def quat_to_rotmat(q) -> np.ndarray:
+    """ori::quaternionToRotationMatrix (scalar first, transposed) -- OrientationTools.h:251-269."""
+    e0, e1, e2, e3 = q
+    R = np.array([
+        [1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2)],
+        [2 * (e1 * e2 + e0 * e3), 1 - 2 * (e1 * e1 + e3 * e3), 2 * (e2 * e3 - e0 * e1)],
+        [2 * (e1 * e3 - e0 * e2), 2 * (e2 * e3 + e0 * e1), 1 - 2 * (e1 * e1 + e2 * e2)],
+    ])
+    return R.T.copy()
+
+
+def rotmat_to_quat(R) -> np.ndarray:
+    """ori::rotationMatrixToQuaternion -- OrientationTools.h:160-200 (input is the transposed
+    coordinate-transform convention of the reference)."""
+    r = np.asarray(R, dtype=np.float64).T
+    tr = np.trace(r)
+    if tr > 0:
+        S = np.sqrt(tr + 1.0) * 2.0
+        q = [0.25 * S, (r[2, 1] - r[1, 2]) / S, (r[0, 2] - r[2, 0]) / S, (r[1, 0] - r[0, 1]) / S]
+    elif r[0, 0] > r[1, 1] and r[0, 0] > r[2, 2]:
+        S = np.sqrt(1.0 + r[0, 0] - r[1, 1] - r[2, 2]) * 2.0
+        q = [(r[2, 1] - r[1, 2]) / S, 0.25 * S, (r[0, 1] + r[1, 0]) / S, (r[0, 2] + r[2, 0]) / S]
+    elif r[1, 1] > r[2, 2]:
+        S = np.sqrt(1.0 + r[1, 1] - r[0, 0] - r[2, 2]) * 2.0
+        q = [(r[0, 2] - r[2, 0]) / S, (r[0, 1] + r[1, 0]) / S, 0.25 * S, (r[1, 2] + r[2, 1]) / S]
+    else:
+        S = np.sqrt(1.0 + r[2, 2] - r[0, 0] - r[1, 1]) * 2.0
+        q = [(r[1, 0] - r[0, 1]) / S, (r[0, 2] + r[2, 0]) / S, (r[1, 2] + r[2, 1]) / S, 0.25 * S]
+    return np.array(q, dtype=np.float64)
+
+
+@dataclass
+class Body:
+    """Body<Scalar> -- include/grbda/Dynamics/Body.h:16-43."""
+    index: int
+    name: str
+    parent_index: int
+    Xtree_E: np.ndarray
+    Xtree_r: np.ndarray
+    inertia: np.ndarray
+    sub_index_within_cluster: int
+    cluster: int = -1
+    joint_type: int = JOINT_REVOLUTE
+    axis: int = 2
+
+
+@dataclass
+class Cluster:
+    name: str
+    first_body: int
+    n_bodies: int
+    parent_cluster: int
+    q_index: int
+    n_pos: int
+    v_index: int
+    n_vel: int
+    n_span_pos: int
+    n_span_vel: int
+    constraint_type: int
+    n_rows: int
+    ints: List[int] = field(default_factory=list)
+    dbls: List[float] = field(default_factory=list)
+
+
+class ClusterTreeModel:
+    """Construction half of grbda::ClusterTreeModel (ClusterTreeModel.h:24-165)."""
+
+    def __init__(self, gravity=(0.0, 0.0, -9.81), ori_repr: str = "quaternion"):
+        self.bodies: List[Body] = []
+        self.clusters: List[Cluster] = []
+        self._name_to_body: Dict[str, int] = {"ground": -1}
+        self._current: List[Body] = []
+        self.gravity6 = np.array([0, 0, 0, *gravity], dtype=np.float64)
+        self.ori_repr = ORI_QUATERNION if ori_repr.lower().startswith("q") else ORI_RPY
+        self.nq = 0
+        self.nv = 0
+
+    # -- TreeModel::setGravity (TreeModel.h:56) ------------------------------------------------
+    def setGravity(self, g):
+        self.gravity6[3:] = np.asarray(g, dtype=np.float64)
+
+    # -- registerBody (ClusterTreeModel.cpp:10-32) --------------------------------------------
+    def registerBody(self, name: str, inertia, parent: str, Xtree_E=None, Xtree_r=None) -> Body:
+        if name in self._name_to_body:
+            raise RuntimeError(f"body {name} already registered")
+        if parent not in self._name_to_body:
+            raise RuntimeError(f"unknown parent body {parent}")
+        E = np.eye(3) if Xtree_E is None else np.asarray(Xtree_E, dtype=np.float64).reshape(3, 3)
+        r = np.zeros(3) if Xtree_r is None else np.asarray(Xtree_r, dtype=np.float64).reshape(3)
+        b = Body(len(self.bodies), name, self._name_to_body[parent], E, r,
+                 np.asarray(inertia, dtype=np.float64).reshape(6, 6), len(self._current))
+        self._name_to_body[name] = b.index
+        self.bodies.append(b)
+        self._current.append(b)
+        return b
+
+    def _parent_cluster(self) -> int:
+        # getIndexOfParentClusterFromBodies + checkValidParentClusterForBodiesInCluster
+        # (ClusterTreeModel.cpp:112-126)
+        first = self._current[0].index
+        pc = None
+        for b in self._current:
+            if b.parent_index >= first:
+                continue
+            c = -1 if b.parent_index < 0 else self.bodies[b.parent_index].cluster
+            if pc is None:
+                pc = c
+            elif pc != c:
+                raise RuntimeError("The parents of all bodies in a cluster must have parents in the "
+                                   "current cluster OR in the same parent cluster")
+        if pc is None:
+            raise RuntimeError("cluster has no body attached to a parent cluster")
+        return pc
+
+    def _append(self, name, n_pos, n_vel, n_span_pos, n_span_vel, ctype, n_rows, ints=(), dbls=()):
+        if not self._current:
+            raise RuntimeError("no registered bodies")
+        cidx = len(self.clusters)
+        pc = self._parent_cluster()
+        for b in self._current:
+            b.cluster = cidx
+        cl = Cluster(name, self._current[0].index, len(self._current), pc, self.nq, n_pos, self.nv, n_vel,
+                     n_span_pos, n_span_vel, ctype, n_rows, [int(x) for x in ints], [float(x) for x in dbls])
+        self.clusters.append(cl)
+        self.nq += n_pos
+        self.nv += n_vel
+        self._current = []
+        return cl
+
+    # -- appendRegisteredBodiesAsCluster<JointT> (ClusterTreeModel.h:61-66) ---------------------
+    def appendRegisteredBodiesAsCluster(self, name: str, joint: str, **kw):
+        j = joint.lower()
+        cur = self._current
+        if j == "free":
+            if len(cur) != 1 or cur[0].parent_index >= 0:
+                raise RuntimeError("Free joint is only valid as the first joint in a tree and thus "
+                                   "cannot have a parent body")
+            cur[0].joint_type = JOINT_FREE
+            npos = 7 if self.ori_repr == ORI_QUATERNION else 6
+            return self._append(name, npos, 6, npos, 6, C_FREE, 0)
+        if j == "revolute":
+            cur[0].axis = AXIS[kw["axis"]]
+            return self._static(name, np.eye(1), np.zeros((0, 1)))
+        if j == "revolutewithrotor":
+            # bodies [link, rotor]; G = [1; N], K = [N, -1]
+            link_axis, rotor_axis, N = kw["joint_axis"], kw["rotor_axis"], float(kw["gear_ratio"])
+            cur[0].axis, cur[1].axis = AXIS[link_axis], AXIS[rotor_axis]
+            return self._static(name, np.array([[1.0], [N]]), np.array([[N, -1.0]]))
+        if j == "revolutepairwithrotor":
+            return self._pair_with_rotor(name, **kw)
+        if j == "revolutetriplewithrotor":
+            return self._triple_with_rotor(name, **kw)
+        if j == "generic":
+            for b, ax in zip(cur, kw["axes"]):
+                b.axis = AXIS[ax]
+            return self._static(name, np.asarray(kw["G"], dtype=np.float64), np.asarray(kw["K"], dtype=np.float64))
+        raise RuntimeError(f"unknown cluster joint type {joint}")
+
+    # -- appendBody<JointT> (ClusterTreeModel.h:69-78) -------------------------------------------
+    def appendBody(self, name, inertia, parent, Xtree_E=None, Xtree_r=None, joint="revolute", **kw):
+        self.registerBody(name, inertia, parent, Xtree_E, Xtree_r)
+        return self.appendRegisteredBodiesAsCluster(name, joint, **kw)
+
+    def _static(self, name, G, K):
+        k = len(self._current)
+        G = np.asarray(G, dtype=np.float64).reshape(k, -1)
+        n = G.shape[1]
+        K = np.asarray(K, dtype=np.float64).reshape(-1, k) if np.size(K) else np.zeros((0, k))
+        if K.shape[0] and np.abs(K @ G).max() > 1e-9:
+            raise RuntimeError("loop constraint is inconsistent: K G != 0")
+        return self._append(name, n, n, k, k, C_STATIC, K.shape[0], (), list(G.ravel()) + list(K.ravel()))
+
+    def _pair_with_rotor(self, name, link1, rotor1, rotor2, link2, joint_axes, rotor_axes, gear_ratios,
+                         belt_ratios_1, belt_ratios_2):
+        """RevolutePairWithRotorJoint.cpp:10-69.  link*/rotor* are Body objects of the current cluster;
+        belt_ratios_1 has one entry, belt_ratios_2 two (ParallelBeltTransmissionModule<1>, <2>)."""
+        i_l1, i_l2 = link1.sub_index_within_cluster, link2.sub_index_within_cluster
+        i_r1, i_r2 = rotor1.sub_index_within_cluster, rotor2.sub_index_within_cluster
+        link1.axis, link2.axis = AXIS[joint_axes[0]], AXIS[joint_axes[1]]
+        rotor1.axis, rotor2.axis = AXIS[rotor_axes[0]], AXIS[rotor_axes[1]]
+        # beltMatrixRowFromBeltRatios: cumulative products (Transmissions.h:34-43)
+        b1 = np.cumprod(np.asarray(belt_ratios_1, dtype=np.float64))
+        b2 = np.cumprod(np.asarray(belt_ratios_2, dtype=np.float64))
+        belt = np.array([[b1[0], 0.0], [b2[0], b2[1]]])
+        rp = np.diag(np.asarray(gear_ratios, dtype=np.float64)) @ belt
+        G = np.zeros((4, 2))
+        G[i_l1, 0] = 1.0
+        G[i_r1, 0] = rp[0, 0]
+        G[i_r2, 0] = rp[1, 0]
+        G[i_r2, 1] = rp[1, 1]
+        G[i_l2, 1] = 1.0
+        K = np.zeros((2, 4))
+        c1, c2 = int(i_r1 > i_r2), int(i_r2 > i_r1)
+        K[c1, i_r1] = -1.0
+        K[c1, i_l1] = G[i_r1, 0]
+        K[c2, i_r2] = -1.0
+        K[c2, i_l1] = G[i_r2, 0]
+        K[c2, i_l2] = G[i_r2, 1]
+        return self._static(name, G, K)
+
+    def _triple_with_rotor(self, name, joint_axes, rotor_axes, gear_ratios, belt_ratios_1, belt_ratios_2,
+                           belt_ratios_3):
+        """RevoluteTripleWithRotorJoint.cpp:10-60; bodies registered [link1, link2, link3, rotor1..3]."""
+        cur = self._current
+        for b, ax in zip(cur[:3], joint_axes):
+            b.axis = AXIS[ax]
+        for b, ax in zip(cur[3:], rotor_axes):
+            b.axis = AXIS[ax]
+        rows = [np.cumprod(np.asarray(r, dtype=np.float64)) for r in (belt_ratios_1, belt_ratios_2, belt_ratios_3)]
+        belt = np.zeros((3, 3))
+        for i, r in enumerate(rows):
+            belt[i, : i + 1] = r
+        G = np.zeros((6, 3))
+        G[:3] = np.eye(3)
+        G[3:] = np.diag(np.asarray(gear_ratios, dtype=np.float64)) @ belt
+        K = np.zeros((3, 6))
+        K[:, :3] = -G[3:]
+        K[:, 3:] = np.eye(3)
+        return self._static(name, G, K)
+
+    # -- implicit kinds ---------------------------------------------------------------------------
+    def appendLoopPositionCluster(self, name, axes, is_independent, loops):
+        """Generic cluster with the URDF+ <loop> position constraint (ClusterTreeParsing.cpp:310-376).
+        loops: list of dicts {pred: [sub...], succ: [sub...], pred_origin: (E, r), succ_origin: (E, r),
+        axis_mask: int}."""
+        cur = self._current
+        k = len(cur)
+        for b, ax in zip(cur, axes):
+            b.axis = AXIS[ax]
+        ints = [len(loops)] + [int(bool(x)) for x in is_independent]
+        dbls: List[float] = []
+        rows = 0
+        for lp in loops:
+            ints += [len(lp["pred"])] + list(lp["pred"]) + [len(lp["succ"])] + list(lp["succ"]) + [lp["axis_mask"]]
+            for key in ("pred_origin", "succ_origin"):
+                E, r = lp[key]
+                dbls += list(np.asarray(E, dtype=np.float64).ravel()) + list(np.asarray(r, dtype=np.float64).ravel())
+            rows += bin(lp["axis_mask"]).count("1")
+        n = sum(1 for x in is_independent if x)
+        if k - n != rows:
+            raise RuntimeError("number of dependent coordinates must equal the number of constraint rows")
+        return self._append(name, k, n, k, k, C_LOOP_POSITION, rows, ints, dbls)
+
+    def appendTrigPolyCluster(self, name, axes, is_independent, rows):
+        """Generic cluster with phi given as trig polynomials (hand-written lambdas of src/Robots/Tello.cpp).
+        rows: list (per constraint row) of terms (coef, [(type, weights[k], offset), ...])."""
+        cur = self._current
+        k = len(cur)
+        for b, ax in zip(cur, axes):
+            b.axis = AXIS[ax]
+        ints = [int(bool(x)) for x in is_independent]
+        dbls: List[float] = []
+        for terms in rows:
+            ints.append(len(terms))
+            for coef, factors in terms:
+                ints.append(len(factors))
+                dbls.append(coef)
+                for ftype, w, off in factors:
+                    ints.append({"lin": 0, "sin": 1, "cos": 2}[ftype])
+                    dbls += [float(x) for x in w] + [float(off)]
+        n = sum(1 for x in is_independent if x)
+        return self._append(name, k, n, k, k, C_TRIG_POLY, len(rows), ints, dbls)
+
+    # -- accessors (ClusterTreeModel.h:98,113; TreeModel.h:25-26) -----------------------------------
+    def getNumPositions(self):
+        return self.nq
+
+    def getNumDegreesOfFreedom(self):
+        return self.nv
+
+    def getNumBodies(self):
+        return len(self.bodies)
+
+    # -- serialisation ------------------------------------------------------------------------------
+    def serialize(self) -> bytes:
+        if self._current:
+            raise RuntimeError("registered bodies have not been appended as a cluster")
+        ints: List[int] = []
+        dbls: List[float] = []
+        crecs = []
+        for c in self.clusters:
+            crecs.append((c.parent_cluster, c.first_body, c.n_bodies, c.q_index, c.n_pos, c.v_index, c.n_vel,
+                          c.n_span_pos, c.n_span_vel, c.constraint_type, c.n_rows, len(ints), len(c.ints),
+                          len(dbls), len(c.dbls), 0))
+            ints += c.ints
+            dbls += c.dbls
+        names = b"".join(b.name.encode() + b"\0" for b in self.bodies) + \
+            b"".join(c.name.encode() + b"\0" for c in self.clusters)
+        names += b"\0" * ((-len(names)) % 8)
+        out = struct.pack("<II10i6d", MAGIC, VERSION, len(self.bodies), len(self.clusters), self.nq, self.nv,
+                          self.ori_repr, len(ints), len(dbls), len(names), 0, 0, *self.gravity6)
+        for b in self.bodies:
+            out += struct.pack("<8i", b.parent_index, b.cluster, b.sub_index_within_cluster, b.joint_type, b.axis,
+                               0, 0, 0)
+            out += np.asarray(b.Xtree_E, dtype="<f8").tobytes() + np.asarray(b.Xtree_r, dtype="<f8").tobytes()
+            out += np.asarray(b.inertia, dtype="<f8").tobytes()
+        for r in crecs:
+            out += struct.pack("<16i", *r)
+        if len(ints) % 2:
+            ints = ints + [0]
+        out += np.asarray(ints, dtype="<i4").tobytes()
+        out += np.asarray(dbls, dtype="<f8").tobytes()
+        out += names
+        return out
+
+
+# -------------------------------------------------------------------------------------------------
+# the reference's uniform serial chains (the models its closed-form codegen oracles describe)
+# -------------------------------------------------------------------------------------------------
+def revolute_chain_with_rotor(n_links: int, gravity=(9.81, 0.0, 0.0)) -> ClusterTreeModel:
+    """RevoluteChainWithRotor<N>::buildUniformClusterTreeModel
+    (src/Robots/SerialChains/RevoluteChainWithRotor.cpp:45-109): I=1, Irot=1e-4, m=1, l=1, c=0.5,
+    gear*belt = 6, axis Z, gravity (+9.81, 0, 0)."""
+    m = ClusterTreeModel(gravity=gravity)
+    link_I = spatial_inertia(1.0, [0.5, 0, 0], np.diag([0, 0, 1.0]))
+    rotor_I = spatial_inertia(0.0, [0, 0, 0], np.diag([0, 0, 1e-4]))
+    prev = "ground"
+    for i in range(n_links):
+        r = [0, 0, 0] if i == 0 else [1.0, 0, 0]
+        m.registerBody(f"link-{i}", link_I, prev, np.eye(3), r)
+        m.registerBody(f"rotor-{i}", rotor_I, prev, np.eye(3), r)
+        m.appendRegisteredBodiesAsCluster(f"cluster-{i}", "RevoluteWithRotor", joint_axis="z", rotor_axis="z",
+                                          gear_ratio=6.0)
+        prev = f"link-{i}"
+    return m
+
+
+def revolute_pair_chain_with_rotor(n_dof: int, gravity=(9.81, 0.0, 0.0)) -> ClusterTreeModel:
+    """RevolutePairChainWithRotor<N>::buildUniformClusterTreeModel
+    (src/Robots/SerialChains/RevolutePairChainWithRotor.cpp:62-138): bodies [linkA, rotorA, rotorB, linkB],
+    gear 2, belts {3} and {3, 1}."""
+    m = ClusterTreeModel(gravity=gravity)
+    link_I = spatial_inertia(1.0, [0.5, 0, 0], np.diag([0, 0, 1.0]))
+    rotor_I = spatial_inertia(0.0, [0, 0, 0], np.diag([0, 0, 1e-4]))
+    parent = "ground"
+    for i in range(n_dof // 2):
+        r1 = [0, 0, 0] if i == 0 else [1.0, 0, 0]
+        la = m.registerBody(f"link-A-{i}", link_I, parent, np.eye(3), r1)
+        ra = m.registerBody(f"rotor-A-{i}", rotor_I, parent, np.eye(3), r1)
+        rb = m.registerBody(f"rotor-B-{i}", rotor_I, parent, np.eye(3), r1)
+        lb = m.registerBody(f"link-B-{i}", link_I, f"link-A-{i}", np.eye(3), [1.0, 0, 0])
+        m.appendRegisteredBodiesAsCluster(f"cluster-{i}", "RevolutePairWithRotor", link1=la, rotor1=ra, rotor2=rb,
+                                          link2=lb, joint_axes="zz", rotor_axes="zz", gear_ratios=[2.0, 2.0],
+                                          belt_ratios_1=[3.0], belt_ratios_2=[3.0, 1.0])
+        parent = f"link-B-{i}"
+    return m

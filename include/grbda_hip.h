@@ -1,0 +1,134 @@
+/*
+ * grbda_hip.h -- C ABI of the MI355X batched cluster-ABA / cluster-RNEA engine.
+ *
+ * The reference (ROAM-Lab-ND/generalized_rbda) has no FFI: its boundary is the C++ class
+ * grbda::ClusterTreeModel (include/grbda/Dynamics/ClusterTreeModel.h:24-165,
+ * include/grbda/Dynamics/TreeModel.h:15-143).  Each entry point below cites the member it
+ * replaces; the C++17 facade in generalized_rbda_amd/include/grbda keeps the reference's class
+ * names and calls these functions, and INTEGRATION.md shows the few lines a maintainer of the
+ * reference would add to route ClusterTreeModel::forwardDynamics through them.
+ *
+ * Conventions
+ *   - all batched arrays are row-major: q[B][nq], qd[B][nv], tau[B][nv], ydd[B][nv];
+ *     positions are *independent* coordinates for explicit clusters and *spanning* positions
+ *     for implicit-loop clusters (GenericJoint.cpp:246-249); velocities / accelerations /
+ *     torques are always independent (TreeModel.h:83-84);
+ *   - `_f32/_f64` device entry points take DEVICE pointers on `device`, enqueue on `stream`
+ *     (a hipStream_t, may be NULL) and return without synchronising;
+ *   - the caller owns every buffer; a plan is immutable after creation and may be shared by
+ *     threads and streams (the reference model is a stateful cache and is not thread safe,
+ *     TreeModel.h:138-142);
+ *   - functions return 0 (GRBDA_OK) or a negative error code and never throw;
+ *   - there is NO CPU fallback: every compute entry point fails with GRBDA_ENODEVICE when no
+ *     HIP device is usable.
+ */
+#ifndef GRBDA_HIP_H
+#define GRBDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    GRBDA_OK = 0,
+    GRBDA_EINVAL = -1,       /* bad argument / malformed blob                                  */
+    GRBDA_EUNSUPPORTED = -2, /* model uses a topology / constraint the kernels do not cover yet */
+    GRBDA_ENODEVICE = -3,    /* no usable HIP device                                           */
+    GRBDA_EHIP = -4,         /* a HIP runtime call failed (see grbda_last_error)               */
+    GRBDA_ENOMEM = -5,
+    GRBDA_EPARSE = -6,       /* URDF+ file could not be parsed                                 */
+    GRBDA_ESTATE = -7        /* invalid spanning state (ClusterJoint.cpp:43-46,62-65)          */
+};
+
+typedef struct grbda_plan grbda_plan;
+
+/* human-readable text for an error code; thread-local detail of the last failure */
+const char *grbda_strerror(int code);
+const char *grbda_last_error(void);
+
+/* ---- model -> plan ------------------------------------------------------------------------ */
+
+/* Replaces the state held by a constructed ClusterTreeModel (ClusterTreeModel.cpp:10-67):
+ * `blob` is a model description (include/grbda_model_desc.h) written by the C++ facade
+ * (grbda::ClusterTreeModel::serialize) or by grbda_urdf_to_blob.  Host-only: needs no GPU. */
+int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out);
+
+/* Replaces ClusterTreeModel::buildModelFromURDF(path) (ClusterTreeModel.h:41-46,
+ * src/Dynamics/ClusterTreeParsing.cpp:5-440).  ori_repr: 0 quaternion, 1 roll-pitch-yaw. */
+int grbda_plan_from_urdf(const char *path, int ori_repr, grbda_plan **out);
+
+/* URDF+ file(s) -> model description blob (buildModelFromURDF(vector<path>),
+ * ClusterTreeModel.h:48-53).  Call with buf = NULL to query *needed. */
+int grbda_urdf_to_blob(const char *const *paths, int n_paths, int ori_repr, void *buf, size_t cap,
+                       size_t *needed);
+
+void grbda_plan_free(grbda_plan *plan);
+
+/* getNumPositions / getNumDegreesOfFreedom / getNumBodies / clusters().size()
+ * (TreeModel.h:25-26, ClusterTreeModel.h:98,113); any out pointer may be NULL */
+int grbda_plan_dims(const grbda_plan *plan, int *nq, int *nv, int *n_bodies, int *n_clusters);
+
+/* TreeModel::setGravity / getGravity (TreeModel.h:56-57): linear part of the gravity vector.
+ * Not thread safe against concurrent launches on the same plan. */
+int grbda_plan_set_gravity(grbda_plan *plan, const double g[3]);
+int grbda_plan_get_gravity(const grbda_plan *plan, double g[3]);
+
+/* the model description the plan was built from (for serialisation / the oracle in tests) */
+int grbda_plan_blob(const grbda_plan *plan, const void **blob, size_t *bytes);
+
+/* kernel resource / cost figures: per-state slots, LDS bytes per wave, global scratch bytes per
+ * wave, flops per forward-dynamics and inverse-dynamics evaluation (counted by the plan
+ * compiler from the operation list the kernel executes) */
+typedef struct {
+    int n_slots;
+    int n_lds_slots_f32, n_lds_slots_f64;
+    size_t lds_bytes_f32, lds_bytes_f64;
+    size_t scratch_bytes_per_wave_f32, scratch_bytes_per_wave_f64;
+    double flops_aba, flops_rnea;
+    double bytes_aba_f32, bytes_aba_f64; /* algorithmic bytes per evaluation: (nq+2nv+nv)*s */
+} grbda_plan_info_t;
+int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
+
+/* ---- batched dynamics (device pointers) ----------------------------------------------------- */
+
+/* ClusterTreeModel::setState + forwardDynamics(tau) over B independent states
+ * (ClusterTreeModel.cpp:256-308, ClusterTreeDynamics.cpp:85-191): cluster ABA.
+ * f_ext: NULL, or [B][n_bodies][6] world-frame spatial forces (TreeModel::setExternalForces,
+ * TreeModel.cpp:214-239). */
+int grbda_aba_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau,
+                  const double *f_ext, double *ydd, size_t B, int device, void *stream);
+int grbda_aba_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau,
+                  const float *f_ext, float *ydd, size_t B, int device, void *stream);
+
+/* ClusterTreeModel::setState + inverseDynamics(ydd) (ClusterTreeDynamics.cpp:79-83,
+ * TreeModel.cpp:34-57,173-212): cluster RNEA. */
+int grbda_rnea_f64(const grbda_plan *plan, const double *q, const double *qd, const double *ydd,
+                   const double *f_ext, double *tau, size_t B, int device, void *stream);
+int grbda_rnea_f32(const grbda_plan *plan, const float *q, const float *qd, const float *ydd,
+                   const float *f_ext, float *tau, size_t B, int device, void *stream);
+
+/* ---- convenience: host pointers (single-state facade calls, small batches) ------------------ */
+/* allocate, copy in, run on `device`, copy out, synchronise.  Still the HIP path. */
+int grbda_aba_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau,
+                       const double *f_ext, double *ydd, size_t B, int device);
+int grbda_rnea_host_f64(const grbda_plan *plan, const double *q, const double *qd,
+                        const double *ydd, const double *f_ext, double *tau, size_t B, int device);
+
+/* ---- measurement hook -------------------------------------------------------------------------- */
+/* Average duration in milliseconds of `iters` back-to-back launches of the ABA (kind 0) or RNEA
+ * (kind 1) kernel, measured with hipEvents recorded on `stream` around the launches (the stream
+ * the kernel runs on).  precision: 32 or 64. */
+int grbda_time_kernel(const grbda_plan *plan, int kind, int precision, const void *q, const void *qd,
+                      const void *x, void *out, size_t B, int device, void *stream, int iters,
+                      float *avg_ms);
+
+/* number of usable HIP devices (0 when there is none); never fails */
+int grbda_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRBDA_HIP_H */
