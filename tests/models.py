@@ -1,0 +1,111 @@
+"""Model zoo for the tests: the reference's uniform chains plus seeded random cluster trees that
+exercise every explicit cluster-joint type the reference has (testRigidBodyDynamicsAlgos.cpp:94-109
+uses the same families with random parameters)."""
+import numpy as np
+
+from generalized_rbda_amd import modeldesc as md
+
+
+def random_inertia(rng, massless=False):
+    """A physically valid random spatial inertia (randomBody, include/grbda/Dynamics/Body.h:45-60)."""
+    m = 0.0 if massless else rng.uniform(0.2, 2.0)
+    com = rng.uniform(-0.3, 0.3, 3)
+    A = rng.uniform(-1, 1, (3, 3))
+    I3 = A @ A.T * 0.05 + np.eye(3) * rng.uniform(1e-3, 0.05)
+    return md.spatial_inertia(m, com, I3)
+
+
+def random_xtree(rng):
+    return md.rpy_to_rotmat(rng.uniform(-1, 1, 3)), rng.uniform(-0.5, 0.5, 3)
+
+
+def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor", "pair", "triple", "generic")):
+    """Random tree of clusters.  Every cluster hangs off ONE body of an earlier cluster."""
+    rng = np.random.default_rng(seed)
+    m = md.ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    link_names = []
+    if floating:
+        m.appendBody("base", random_inertia(rng), "ground", joint="free")
+        link_names.append("base")
+    ax = lambda: "xyz"[rng.integers(3)]
+    for c in range(n_clusters):
+        parent = "ground" if not link_names else link_names[rng.integers(len(link_names))]
+        if not link_names and floating is False and c > 0:
+            parent = link_names[rng.integers(len(link_names))]
+        kind = kinds[rng.integers(len(kinds))]
+        if kind == "rev":
+            E, r = random_xtree(rng)
+            m.appendBody(f"l{c}", random_inertia(rng), parent, E, r, joint="revolute", axis=ax())
+            link_names.append(f"l{c}")
+        elif kind == "rotor":
+            E, r = random_xtree(rng)
+            m.registerBody(f"l{c}", random_inertia(rng), parent, E, r)
+            E2, r2 = random_xtree(rng)
+            m.registerBody(f"r{c}", random_inertia(rng, massless=rng.random() < 0.5), parent, E2, r2)
+            m.appendRegisteredBodiesAsCluster(f"c{c}", "RevoluteWithRotor", joint_axis=ax(), rotor_axis=ax(),
+                                              gear_ratio=rng.uniform(2, 12))
+            link_names.append(f"l{c}")
+        elif kind == "pair":
+            # MIT-humanoid knee/ankle registration order: [rotor2, link1, rotor1, link2]
+            X = [random_xtree(rng) for _ in range(4)]
+            r2 = m.registerBody(f"r2_{c}", random_inertia(rng), parent, *X[0])
+            l1 = m.registerBody(f"l1_{c}", random_inertia(rng), parent, *X[1])
+            r1 = m.registerBody(f"r1_{c}", random_inertia(rng), parent, *X[2])
+            l2 = m.registerBody(f"l2_{c}", random_inertia(rng), f"l1_{c}", *X[3])
+            m.appendRegisteredBodiesAsCluster(f"c{c}", "RevolutePairWithRotor", link1=l1, rotor1=r1, rotor2=r2,
+                                              link2=l2, joint_axes=ax() + ax(), rotor_axes=ax() + ax(),
+                                              gear_ratios=rng.uniform(2, 10, 2), belt_ratios_1=rng.uniform(1, 3, 1),
+                                              belt_ratios_2=rng.uniform(1, 3, 2))
+            link_names += [f"l1_{c}", f"l2_{c}"]
+        elif kind == "triple":
+            names = [f"t{c}_l{i}" for i in range(3)]
+            par = parent
+            for nm in names:
+                m.registerBody(nm, random_inertia(rng), par, *random_xtree(rng))
+                par = nm
+            for i in range(3):
+                m.registerBody(f"t{c}_r{i}", random_inertia(rng), parent, *random_xtree(rng))
+            m.appendRegisteredBodiesAsCluster(f"c{c}", "RevoluteTripleWithRotor", joint_axes=ax() + ax() + ax(),
+                                              rotor_axes=ax() + ax() + ax(), gear_ratios=rng.uniform(2, 8, 3),
+                                              belt_ratios_1=rng.uniform(1, 2, 1), belt_ratios_2=rng.uniform(1, 2, 2),
+                                              belt_ratios_3=rng.uniform(1, 2, 3))
+            link_names += names
+        else:  # generic static: k bodies in a random in-cluster tree, random coupling G
+            k = int(rng.integers(2, 6))
+            n = int(rng.integers(1, min(k, 4) + 1))
+            names = [f"g{c}_{i}" for i in range(k)]
+            for i, nm in enumerate(names):
+                par = parent if i == 0 or rng.random() < 0.4 else names[rng.integers(i)]
+                m.registerBody(nm, random_inertia(rng), par, *random_xtree(rng))
+            ind = sorted(rng.choice(k, size=n, replace=False).tolist())
+            dep = [i for i in range(k) if i not in ind]
+            G = np.zeros((k, n))
+            K = np.zeros((k - n, k))
+            for j, i in enumerate(ind):
+                G[i, j] = 1.0
+            for r_, i in enumerate(dep):
+                w = rng.uniform(-3, 3, n)
+                G[i] = w
+                K[r_, i] = -1.0
+                for j, ii in enumerate(ind):
+                    K[r_, ii] = w[j]
+            m.appendRegisteredBodiesAsCluster(f"c{c}", "Generic", axes=[ax() for _ in range(k)], G=G, K=K)
+            link_names += names
+    return m
+
+
+def zoo():
+    """name -> model description bytes"""
+    z = {}
+    for n in (2, 3, 4):
+        z[f"rev_rotor_chain_{n}"] = md.revolute_chain_with_rotor(n).serialize()
+    for n in (2, 4):
+        z[f"rev_pair_rotor_chain_{n}"] = md.revolute_pair_chain_with_rotor(n).serialize()
+    z["tree_rev_fixed"] = random_cluster_tree(1, 6, floating=False, kinds=("rev",)).serialize()
+    z["tree_rotor_float"] = random_cluster_tree(2, 8, floating=True, kinds=("rotor", "rev")).serialize()
+    z["tree_pair_float"] = random_cluster_tree(3, 6, floating=True, kinds=("pair", "rotor")).serialize()
+    z["tree_triple_fixed"] = random_cluster_tree(4, 4, floating=False, kinds=("triple", "rev")).serialize()
+    z["tree_generic_float"] = random_cluster_tree(5, 7, floating=True, kinds=("generic",)).serialize()
+    z["tree_mixed_float"] = random_cluster_tree(6, 12, floating=True).serialize()
+    z["tree_mixed_fixed"] = random_cluster_tree(7, 10, floating=False).serialize()
+    return z

@@ -1,0 +1,95 @@
+"""CPU tests of the C ABI: the library loads, exports every symbol include/grbda_hip.h declares,
+compiles plans on the host, reports errors by code, and refuses to compute without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import generalized_rbda_amd as G
+from generalized_rbda_amd import modeldesc as md
+from models import zoo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "grbda_hip.h")).read()
+    declared = set(re.findall(r"\b(grbda_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"grbda_plan"}
+    assert declared == set(G.C_ABI_SYMBOLS), declared ^ set(G.C_ABI_SYMBOLS)
+    L = ctypes.CDLL(G.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+@pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
+def test_plan_compiles_on_host(name, blob):
+    p = G.Plan(blob)
+    from generalized_rbda_amd.states import parse_clusters
+    m = parse_clusters(blob)
+    assert (p.nq, p.nv, p.n_bodies, p.n_clusters) == (m["nq"], m["nv"], m["nb"], m["nc"])
+    assert p.blob == blob
+    info = p.info()
+    assert info.n_slots > 0 and info.flops_aba > 0 and info.bytes_aba_f32 == (p.nq + 3 * p.nv) * 4
+
+
+def test_gravity_roundtrip():
+    p = G.Plan(md.revolute_chain_with_rotor(3).serialize())
+    assert p.get_gravity() == [9.81, 0.0, 0.0]
+    p.set_gravity([0, 0, -9.81])
+    assert p.get_gravity() == [0.0, 0.0, -9.81]
+
+
+def test_bad_blob_is_rejected():
+    with pytest.raises(G.GrbdaError) as e:
+        G.Plan(b"\0" * 200)
+    assert e.value.code == -1
+    blob = bytearray(md.revolute_chain_with_rotor(2).serialize())
+    with pytest.raises(G.GrbdaError):
+        G.Plan(bytes(blob[:300]))
+
+
+def test_cluster_with_two_parent_bodies_is_reported_unsupported():
+    m = md.ClusterTreeModel()
+    I = md.spatial_inertia(1.0, [0.1, 0, 0], np.eye(3) * 0.1)
+    m.appendBody("a", I, "ground", joint="revolute", axis="z")
+    m.registerBody("b1", I, "a")
+    m.registerBody("b2", I, "a")
+    m.appendRegisteredBodiesAsCluster("b", "Generic", axes="zz", G=[[1.0], [2.0]], K=[[2.0, -1.0]])
+    m.registerBody("c1", I, "b1")
+    m.registerBody("c2", I, "b2")
+    m.appendRegisteredBodiesAsCluster("c", "Generic", axes="zz", G=[[1.0], [2.0]], K=[[2.0, -1.0]])
+    with pytest.raises(G.GrbdaError) as e:
+        G.Plan(m.serialize())
+    assert e.value.code == -2 and "more than one body" in str(e.value)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device every compute entry point must fail loudly (GRBDA_ENODEVICE)."""
+    if G.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    p = G.Plan(md.revolute_chain_with_rotor(2).serialize())
+    z = np.zeros((1, 2))
+    with pytest.raises(G.GrbdaError) as e:
+        p.forward_dynamics_host(z, z, z)
+    assert e.value.code == -3
+    with pytest.raises(G.GrbdaError) as e:
+        p.inverse_dynamics_host(z, z, z)
+    assert e.value.code == -3
+
+
+def test_model_builder_rejects_invalid_topology():
+    m = md.ClusterTreeModel()
+    I = md.spatial_inertia(1.0, [0, 0, 0], np.eye(3))
+    m.appendBody("a", I, "ground", joint="revolute", axis="x")
+    m.appendBody("b", I, "ground", joint="revolute", axis="x")
+    m.registerBody("c1", I, "a")
+    m.registerBody("c2", I, "b")
+    with pytest.raises(RuntimeError, match="same parent cluster"):
+        m.appendRegisteredBodiesAsCluster("c", "Generic", axes="xx", G=[[1.0], [1.0]], K=[[1.0, -1.0]])
+    with pytest.raises(RuntimeError, match="Free joint"):
+        m2 = md.ClusterTreeModel()
+        m2.appendBody("a", I, "ground", joint="revolute", axis="x")
+        m2.appendBody("f", I, "a", joint="free")

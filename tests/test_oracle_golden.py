@@ -1,0 +1,68 @@
+"""CPU tests: the oracle (oracle/grbda_oracle.c) against
+ (i)   golden vectors generated from the reference's own closed-form codegen
+       (tests/golden/codegen_vectors.json, made by oracle/gen_golden.py) -- the reference's test
+       UnitTests/testReflectedInertiaAlgos.cpp:144-222 uses tol 1e-5; fp64 gives ~1e-12;
+ (ii)  the Projection identity on the spanning tree (testRigidBodyDynamicsAlgos.cpp:208-232, tol 5e-8);
+ (iii) ID(FD(tau)) == tau (testRigidBodyDynamicsAlgos.cpp:221,235)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from generalized_rbda_amd import modeldesc as md
+from generalized_rbda_amd.states import random_states
+from models import zoo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden():
+    with open(os.path.join(HERE, "golden", "codegen_vectors.json")) as f:
+        return json.load(f)["cases"]
+
+
+def _unhex(a):
+    return np.array([[float.fromhex(v) for v in row] for row in a])
+
+
+@pytest.mark.parametrize("case", _golden(), ids=lambda c: f"{c['family']}{c['n']}")
+def test_oracle_matches_reference_codegen(case):
+    build = md.revolute_chain_with_rotor if case["family"] == "rev" else md.revolute_pair_chain_with_rotor
+    blob = build(case["n"]).serialize()
+    y, yd, x = _unhex(case["y"]), _unhex(case["yd"]), _unhex(case["x"])
+    fd = O.forward_dynamics(blob, y, yd, x)
+    idd = O.inverse_dynamics(blob, y, yd, x)
+    assert np.abs(fd - _unhex(case["FD"])).max() < 1e-9 * (1 + np.abs(_unhex(case["FD"])).max())
+    assert np.abs(idd - _unhex(case["ID"])).max() < 1e-10 * (1 + np.abs(_unhex(case["ID"])).max())
+
+
+@pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
+def test_oracle_cross_algorithm_identities(name, blob):
+    q, qd, tau = random_states(blob, 20, config_index=11)
+    fd = O.forward_dynamics(blob, q, qd, tau)
+    pj = O.forward_dynamics_projection(blob, q, qd, tau)
+    scale = 1 + np.abs(fd).max()
+    assert np.abs(fd - pj).max() < 5e-8 * scale, "cluster ABA vs Projection"
+    back = O.inverse_dynamics(blob, q, qd, fd)
+    assert np.abs(back - tau).max() < 5e-8 * scale, "ID(FD(tau)) != tau"
+
+
+def test_oracle_external_forces_consistent():
+    blob = zoo()["tree_mixed_float"]
+    q, qd, tau = random_states(blob, 8, config_index=12)
+    nb = len(blob) and __import__("generalized_rbda_amd.states", fromlist=["parse_clusters"]).parse_clusters(blob)["nb"]
+    fext = np.random.default_rng(3).uniform(-1, 1, (8, nb, 6))
+    fd = O.forward_dynamics(blob, q, qd, tau, fext)
+    pj = O.forward_dynamics_projection(blob, q, qd, tau, fext)
+    assert np.abs(fd - pj).max() < 5e-8 * (1 + np.abs(fd).max())
+    back = O.inverse_dynamics(blob, q, qd, fd, fext)
+    assert np.abs(back - tau).max() < 5e-8 * (1 + np.abs(fd).max())
+    assert np.abs(fd - O.forward_dynamics(blob, q, qd, tau)).max() > 1e-3, "external forces had no effect"
+
+
+def test_oracle_mt_matches_single_thread():
+    blob = zoo()["tree_rotor_float"]
+    q, qd, tau = random_states(blob, 257, config_index=13)
+    assert np.array_equal(O.forward_dynamics(blob, q, qd, tau), O.forward_dynamics_mt(blob, q, qd, tau, 4))
