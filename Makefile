@@ -20,7 +20,7 @@ $(OBJ)/capi.o: $(CSRC)/capi.cpp $(CSRC)/plan.h $(CSRC)/devplan.h include/grbda_h
 $(OBJ)/plan.o: $(CSRC)/plan.cpp $(CSRC)/plan.h include/grbda_hip.h include/grbda_model_desc.h
 	@mkdir -p $(OBJ)
 	g++ -O2 -std=c++17 -fPIC -Wall -c $< -o $@
-$(OBJ)/urdf.o: $(CSRC)/urdf.cpp include/grbda_hip.h include/grbda_model_desc.h
+$(OBJ)/urdf.o: $(CSRC)/urdf.cpp include/grbda_hip.h include/grbda_model_desc.h generalized_rbda_amd/include/grbda/ModelDescription.h
 	@mkdir -p $(OBJ)
 	g++ -O2 -std=c++17 -fPIC -Wall -c $< -o $@
 

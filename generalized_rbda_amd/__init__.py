@@ -49,6 +49,12 @@ def lib() -> ctypes.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GrbdaError(-3, f"{LIB_PATH} is missing: build it with `make` (there is no CPU fallback)")
+    try:
+        # torch bundles its own libamdhip64; load it FIRST so that this library binds to the same
+        # HIP runtime instance (device pointers and streams are then shared with torch tensors)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     L.grbda_strerror.restype = c_char_p
     L.grbda_strerror.argtypes = [c_int]

@@ -39,11 +39,11 @@ int hip_err(hipError_t e, const char *what)
 // per-(device) copies of the plan tables; per-(device, stream) scratch slabs
 struct DeviceTables {
     Step *aba_steps = nullptr, *rnea_steps = nullptr;
-    ClusterRec *clusters = nullptr;
-    BodyRec *bodies = nullptr;
+    ClusterRec *clusters[2] = {nullptr, nullptr};      // [0] f32 layout, [1] f64 layout
+    BodyRec *bodies[2] = {nullptr, nullptr};           // ABA slots
+    BodyRec *rnea_bodies[2] = {nullptr, nullptr};      // RNEA slots
     double *consts64 = nullptr;
     float *consts32 = nullptr;
-    int32_t *rnea_slot_f = nullptr;
     int n_cu = 0;
 };
 struct Scratch {
@@ -71,13 +71,6 @@ struct grbda_plan {
 
 namespace {
 
-int n_lds_slots(const grbda_plan *p, size_t elem)
-{
-    int n = static_cast<int>(p->lds_bytes_per_wave / (elem * kWave));
-    if (n > p->host.n_slots) n = p->host.n_slots;
-    return n;
-}
-
 int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
 {
     int count = 0;
@@ -102,12 +95,16 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     std::vector<float> c32(h.consts.begin(), h.consts.end());
     if ((e = up(h.aba_steps.data(), h.aba_steps.size() * sizeof(Step), (void **)&t.aba_steps)) != hipSuccess ||
         (e = up(h.rnea_steps.data(), h.rnea_steps.size() * sizeof(Step), (void **)&t.rnea_steps)) != hipSuccess ||
-        (e = up(h.clusters.data(), h.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters)) != hipSuccess ||
-        (e = up(h.bodies.data(), h.bodies.size() * sizeof(BodyRec), (void **)&t.bodies)) != hipSuccess ||
         (e = up(h.consts.data(), h.consts.size() * sizeof(double), (void **)&t.consts64)) != hipSuccess ||
-        (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess ||
-        (e = up(h.rnea_slot_f.data(), h.rnea_slot_f.size() * sizeof(int32_t), (void **)&t.rnea_slot_f)) != hipSuccess)
+        (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess)
         return hip_err(e, "plan upload");
+    for (int w = 0; w < 2; w++) {
+        const Layout &L = w == 0 ? h.lay32 : h.lay64;
+        if ((e = up(L.clusters.data(), L.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters[w])) != hipSuccess ||
+            (e = up(L.bodies.data(), L.bodies.size() * sizeof(BodyRec), (void **)&t.bodies[w])) != hipSuccess ||
+            (e = up(L.rnea_bodies.data(), L.rnea_bodies.size() * sizeof(BodyRec), (void **)&t.rnea_bodies[w])) != hipSuccess)
+            return hip_err(e, "plan upload");
+    }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_err(e, "hipGetDeviceProperties");
     t.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -143,13 +140,15 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea)
     const HostPlan &h = p->host;
     d.steps = rnea ? t.rnea_steps : t.aba_steps;
     d.n_steps = static_cast<int>(rnea ? h.rnea_steps.size() : h.aba_steps.size());
-    d.clusters = t.clusters;
-    d.bodies = t.bodies;
+    const int w = sizeof(T) == 4 ? 0 : 1;
+    const Layout &L = w == 0 ? h.lay32 : h.lay64;
+    d.clusters = t.clusters[w];
+    d.bodies = rnea ? t.rnea_bodies[w] : t.bodies[w];
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.nq = h.nq;
     d.nv = h.nv;
-    d.n_slots = h.n_slots;
-    d.n_lds_slots = n_lds_slots(p, sizeof(T));
+    d.n_lds_slots = rnea ? L.n_lds_rnea : L.n_lds_aba;
+    d.n_glb_slots = rnea ? L.n_glb_rnea : L.n_glb_aba;
     d.ori_repr = h.ori_repr;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     return d;
@@ -168,15 +167,15 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->waves_per_cu);
     if (grid > n_tiles) grid = n_tiles;
-    const size_t n_glb = static_cast<size_t>(d.n_slots - d.n_lds_slots);
+    const size_t n_glb = static_cast<size_t>(d.n_glb_slots);
     const size_t scratch_bytes = grid * n_glb * kWave * sizeof(T) + 256;
     void *scratch = nullptr;
     if (int rc = ensure_scratch(p, device, stream, scratch_bytes, &scratch)) return rc;
     const size_t lds_bytes = static_cast<size_t>(d.n_lds_slots) * kWave * sizeof(T);
     hipError_t e;
     if (rnea)
-        e = launch_rnea<T>(d, t->rnea_slot_f, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid),
-                           lds_bytes, static_cast<hipStream_t>(stream));
+        e = launch_rnea<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
+                           static_cast<hipStream_t>(stream));
     else
         e = launch_aba<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
                           static_cast<hipStream_t>(stream));
@@ -243,12 +242,13 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     std::unique_ptr<grbda_plan> p(new (std::nothrow) grbda_plan());
     if (!p) return set_err(GRBDA_ENOMEM, "allocation failed");
     char msg[256] = {0};
-    int rc = compile_plan(blob, bytes, p->host, msg, sizeof msg);
+    p->lds_bytes_per_wave = env_int("GRBDA_LDS_BYTES_PER_WAVE", 20480);
+    if (p->lds_bytes_per_wave < 0) p->lds_bytes_per_wave = 0;
+    if (p->lds_bytes_per_wave > 160 * 1024) p->lds_bytes_per_wave = 160 * 1024;
+    int rc = compile_plan(blob, bytes, p->lds_bytes_per_wave / (4 * kWave), p->lds_bytes_per_wave / (8 * kWave), p->host,
+                          msg, sizeof msg);
     if (rc) return set_err(rc, msg);
     p->blob.assign(static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + bytes);
-    p->lds_bytes_per_wave = env_int("GRBDA_LDS_BYTES_PER_WAVE", 16384);
-    if (p->lds_bytes_per_wave < 0) p->lds_bytes_per_wave = 0;
-    if (p->lds_bytes_per_wave > 64 * 1024) p->lds_bytes_per_wave = 64 * 1024;
     p->waves_per_cu = env_int("GRBDA_WAVES_PER_CU", 8);
     if (p->waves_per_cu < 1) p->waves_per_cu = 1;
     if (p->waves_per_cu > 32) p->waves_per_cu = 32;
@@ -288,8 +288,8 @@ void grbda_plan_free(grbda_plan *p)
     for (auto &kv : p->dev) {
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
-        (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.clusters); (void)hipFree(t.bodies);
-        (void)hipFree(t.consts64); (void)hipFree(t.consts32); (void)hipFree(t.rnea_slot_f);
+        (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
+        for (int w = 0; w < 2; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto &kv : p->scratch) {
         if (hipSetDevice(kv.first.first) != hipSuccess) continue;
@@ -335,13 +335,13 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
 {
     if (!p || !info) return set_err(GRBDA_EINVAL, "null argument");
     std::memset(info, 0, sizeof *info);
-    info->n_slots = p->host.n_slots;
-    info->n_lds_slots_f32 = n_lds_slots(p, 4);
-    info->n_lds_slots_f64 = n_lds_slots(p, 8);
+    info->n_slots = p->host.lay32.n_lds_aba + p->host.lay32.n_glb_aba;
+    info->n_lds_slots_f32 = p->host.lay32.n_lds_aba;
+    info->n_lds_slots_f64 = p->host.lay64.n_lds_aba;
     info->lds_bytes_f32 = static_cast<size_t>(info->n_lds_slots_f32) * kWave * 4;
     info->lds_bytes_f64 = static_cast<size_t>(info->n_lds_slots_f64) * kWave * 8;
-    info->scratch_bytes_per_wave_f32 = static_cast<size_t>(p->host.n_slots - info->n_lds_slots_f32) * kWave * 4;
-    info->scratch_bytes_per_wave_f64 = static_cast<size_t>(p->host.n_slots - info->n_lds_slots_f64) * kWave * 8;
+    info->scratch_bytes_per_wave_f32 = static_cast<size_t>(p->host.lay32.n_glb_aba) * kWave * 4;
+    info->scratch_bytes_per_wave_f64 = static_cast<size_t>(p->host.lay64.n_glb_aba) * kWave * 8;
     info->flops_aba = p->host.flops_aba;
     info->flops_rnea = p->host.flops_rnea;
     info->bytes_aba_f32 = (p->host.nq + 3.0 * p->host.nv) * 4;

@@ -14,7 +14,7 @@ struct DevPlan {
     const BodyRec *bodies;
     const T *consts;
     int nq, nv;
-    int n_slots, n_lds_slots;
+    int n_lds_slots, n_glb_slots;
     int ori_repr;
     T a_root[6];  // -gravity (ClusterTreeDynamics.cpp:147)
 };
@@ -23,8 +23,8 @@ template <class T>
 hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch,
                       int grid, size_t lds_bytes, hipStream_t stream);
 template <class T>
-hipError_t launch_rnea(const DevPlan<T> &P, const int *slot_f, const T *q, const T *qd, const T *ydd, T *tau,
-                       size_t B, T *scratch, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch,
+                       int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t set_max_dynamic_lds();
 
 }  // namespace grbda_hip

@@ -32,7 +32,53 @@
 namespace grbda_hip {
 
 // ---------------------------------------------------------------------------------------------
-// slot store
+// plan tables live in the constant address space: uniform loads from it are scalar (s_load),
+// which also makes every branch on a plan field a scalar branch
+// ---------------------------------------------------------------------------------------------
+template <class U>
+using cptr = const U __attribute__((address_space(4))) *;
+
+// copy a plan record (all-int32 POD) out of the constant address space; unused fields fold away
+template <class U>
+__device__ __forceinline__ U load_rec(cptr<U> p)
+{
+    static_assert(sizeof(U) % 4 == 0, "plan records are arrays of int32");
+    U out;
+    cptr<int32_t> src = (cptr<int32_t>)p;
+    int32_t *dst = reinterpret_cast<int32_t *>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(U) / 4); i++) dst[i] = src[i];
+    return out;
+}
+
+template <class T>
+struct Tables {
+    cptr<Step> steps;
+    cptr<ClusterRec> clusters;
+    cptr<BodyRec> bodies;
+    cptr<T> consts;
+    int n_steps, nq, nv, ori_repr;
+    T a_root[6];
+};
+template <class T>
+__device__ __forceinline__ Tables<T> make_tables(const DevPlan<T> &P)
+{
+    Tables<T> t;
+    t.steps = (cptr<Step>)P.steps;
+    t.clusters = (cptr<ClusterRec>)P.clusters;
+    t.bodies = (cptr<BodyRec>)P.bodies;
+    t.consts = (cptr<T>)P.consts;
+    t.n_steps = P.n_steps;
+    t.nq = P.nq;
+    t.nv = P.nv;
+    t.ori_repr = P.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) t.a_root[i] = P.a_root[i];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slot store: an object is either wholly in LDS or wholly in the wave's global slab (plan.cpp)
 // ---------------------------------------------------------------------------------------------
 // The LDS array is always addressed through this symbol (never through a generic pointer), so
 // every access compiles to ds_read / ds_write and never to a flat instruction.
@@ -40,9 +86,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char grbda_smem[];
 
 template <class T>
 struct Slots {
-    T *glb;  // wave's global slab + lane - n_lds*64 (indexable by absolute slot number)
+    T *glb;  // wave's global slab + lane
     int lane;
-    int n_lds;
 
     __device__ __forceinline__ T lds_get(int s) const { return reinterpret_cast<T *>(grbda_smem)[s * kWave + lane]; }
     __device__ __forceinline__ void lds_put(int s, T x) const { reinterpret_cast<T *>(grbda_smem)[s * kWave + lane] = x; }
@@ -50,35 +95,25 @@ struct Slots {
     template <int N>
     __device__ __forceinline__ void ld(int s, T (&x)[N]) const
     {
-        if (s + N <= n_lds) {
+        if (s & kSlotGlobal) {
+            const T *p = glb + (size_t)(s & ~kSlotGlobal) * kWave;
 #pragma unroll
-            for (int i = 0; i < N; i++) x[i] = lds_get(s + i);
-        } else if (s >= n_lds) {
-#pragma unroll
-            for (int i = 0; i < N; i++) x[i] = glb[(size_t)(s + i) * kWave];
+            for (int i = 0; i < N; i++) x[i] = p[i * kWave];
         } else {
 #pragma unroll
-            for (int i = 0; i < N; i++) {
-                if (s + i < n_lds) x[i] = lds_get(s + i);
-                else x[i] = glb[(size_t)(s + i) * kWave];
-            }
+            for (int i = 0; i < N; i++) x[i] = lds_get(s + i);
         }
     }
     template <int N>
     __device__ __forceinline__ void st(int s, const T (&x)[N]) const
     {
-        if (s + N <= n_lds) {
+        if (s & kSlotGlobal) {
+            T *p = glb + (size_t)(s & ~kSlotGlobal) * kWave;
 #pragma unroll
-            for (int i = 0; i < N; i++) lds_put(s + i, x[i]);
-        } else if (s >= n_lds) {
-#pragma unroll
-            for (int i = 0; i < N; i++) glb[(size_t)(s + i) * kWave] = x[i];
+            for (int i = 0; i < N; i++) p[i * kWave] = x[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < N; i++) {
-                if (s + i < n_lds) lds_put(s + i, x[i]);
-                else glb[(size_t)(s + i) * kWave] = x[i];
-            }
+            for (int i = 0; i < N; i++) lds_put(s + i, x[i]);
         }
     }
     // x is stored when first != 0, accumulated otherwise
@@ -107,7 +142,7 @@ __host__ __device__ constexpr int sidx(int i, int j)
 
 // E = R_axis(theta) * Et  (ori::coordinateRotation, OrientationTools.h:46-68; XJ * Xtree)
 template <class T>
-__device__ __forceinline__ void build_E(int axis, T s, T c, const T *Et, T (&E)[9])
+__device__ __forceinline__ void build_E(int axis, T s, T c, cptr<T> Et, T (&E)[9])
 {
     if (axis == 0) {
 #pragma unroll
@@ -134,8 +169,8 @@ __device__ __forceinline__ void build_E(int axis, T s, T c, const T *Et, T (&E)[
 }
 
 // transformMotionVector: [E w ; E (v - r x w)]
-template <class T>
-__device__ __forceinline__ void xmotion(const T (&E)[9], const T *r, const T (&m)[6], T (&o)[6])
+template <class T, class R3>
+__device__ __forceinline__ void xmotion(const T (&E)[9], R3 r, const T (&m)[6], T (&o)[6])
 {
     const T t0 = m[3] - (r[1] * m[2] - r[2] * m[1]);
     const T t1 = m[4] - (r[2] * m[0] - r[0] * m[2]);
@@ -148,8 +183,8 @@ __device__ __forceinline__ void xmotion(const T (&E)[9], const T *r, const T (&m
 }
 
 // inverseTransformForceVector: [E^T n + r x (E^T f) ; E^T f]
-template <class T>
-__device__ __forceinline__ void xforce_inv(const T (&E)[9], const T *r, const T (&f)[6], T (&o)[6])
+template <class T, class R3>
+__device__ __forceinline__ void xforce_inv(const T (&E)[9], R3 r, const T (&f)[6], T (&o)[6])
 {
     T n[3], l[3];
 #pragma unroll
@@ -182,8 +217,8 @@ __device__ __forceinline__ void rot3(const T (&E)[9], const T (&M)[9], T (&R)[9]
 
 // B = X^T A X for symmetric 6x6 A (packed), X = (E, r):
 // Transform::inverseTransformSpatialInertia (SpatialTransforms.cpp:111-135)
-template <class T>
-__device__ __forceinline__ void congruence(const T (&E)[9], const T *r, const T (&A)[21], T (&B)[21])
+template <class T, class R3>
+__device__ __forceinline__ void congruence(const T (&E)[9], R3 r, const T (&A)[21], T (&B)[21])
 {
     T A11[9], A12[9], A22[9], R11[9], R12[9], R22[9];
 #pragma unroll
@@ -241,7 +276,7 @@ __device__ __forceinline__ void symv(const T (&A)[21], const T (&x)[6], T (&y)[6
     }
 }
 template <class T>
-__device__ __forceinline__ void symv_c(const T *A /* wave-uniform constants */, const T (&x)[6], T (&y)[6])
+__device__ __forceinline__ void symv_c(cptr<T> A /* wave-uniform constants */, const T (&x)[6], T (&y)[6])
 {
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -369,7 +404,7 @@ struct Lane {
 // spanning joint value of body i: row i of G times the independent cluster coordinates
 // (LoopConstraint::Static::gamma, LoopConstraint.cpp:49-52; ClusterJoint.cpp:55-58)
 template <class T, int N>
-__device__ __forceinline__ T gdot(const T *G, const T (&y)[N])
+__device__ __forceinline__ T gdot(cptr<T> G, const T (&y)[N])
 {
     T s = 0;
 #pragma unroll
@@ -377,29 +412,19 @@ __device__ __forceinline__ T gdot(const T *G, const T (&y)[N])
     return s;
 }
 
-// ---------------------------------------------------------------------------------------------
-// ABA sweep 1: ClusterTreeNode::updateKinematics + TreeModel::forwardKinematics
-// (ClusterTreeNode.cpp:26-31, TreeModel.cpp:6-32)
-// ---------------------------------------------------------------------------------------------
+// kinematics of one revolute body: joint transform and spatial velocity.  Bodies with children
+// were handled by the forward sweep (sin/cos and v are in their slots); leaf bodies are evaluated
+// here from the parent's stored velocity, so they never occupy a slot.
 template <class T, int N>
-__device__ __forceinline__ void aba_fwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                               const Lane<T> &L)
+__device__ __forceinline__ void body_kinematics(const Tables<T> &P, const Slots<T> &S, const BodyRec &b, cptr<T> C,
+                                                const T (&y)[N], T qdi, T (&sc)[2], T (&E)[9], T (&v)[6])
 {
-    T y[N], yd[N];
-#pragma unroll
-    for (int a = 0; a < N; a++) {
-        y[a] = L.q[c.q_index + a];
-        yd[a] = L.qd[c.v_index + a];
-    }
-    for (int i = 0; i < c.k; i++) {
-        const BodyRec &b = P.bodies[c.first_body + i];
-        const T *C = P.consts + b.cofs;
-        const T *G = C + kBodyConstFixed;
-        const T qi = gdot<T, N>(G, y), qdi = gdot<T, N>(G, yd);
-        T sc[2];
-        sincos_t(qi, &sc[0], &sc[1]);
-        S.st(b.slot_sc, sc);
-        T E[9], v[6];
+    if (b.has_child) {
+        S.ld(b.slot_sc, sc);
+        S.ld(b.slot_v, v);
+        build_E(b.axis, sc[0], sc[1], C, E);
+    } else {
+        sincos_t(gdot<T, N>(C + kBodyConstFixed, y), &sc[0], &sc[1]);
         build_E(b.axis, sc[0], sc[1], C, E);
         if (b.parent >= 0) {
             T vp[6];
@@ -410,6 +435,41 @@ __device__ __forceinline__ void aba_fwd_static(const DevPlan<T> &P, const Slots<
             for (int j = 0; j < 6; j++) v[j] = 0;
         }
         add_axis(v, b.axis, qdi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ABA sweep 1: ClusterTreeNode::updateKinematics + TreeModel::forwardKinematics
+// (ClusterTreeNode.cpp:26-31, TreeModel.cpp:6-32) -- only bodies that have children
+// ---------------------------------------------------------------------------------------------
+template <class T, int N>
+__device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                               const Lane<T> &L)
+{
+    T y[N], yd[N];
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        y[a] = L.q[c.q_index + a];
+        yd[a] = L.qd[c.v_index + a];
+    }
+    for (int i = 0; i < c.k; i++) {
+        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        if (!b.has_child) continue;
+        cptr<T> C = P.consts + b.cofs;
+        cptr<T> G = C + kBodyConstFixed;
+        T sc[2], E[9], v[6];
+        sincos_t(gdot<T, N>(G, y), &sc[0], &sc[1]);
+        S.st(b.slot_sc, sc);
+        build_E(b.axis, sc[0], sc[1], C, E);
+        if (b.parent >= 0) {
+            T vp[6];
+            S.ld(b.parent_slot_v, vp);
+            xmotion(E, C + 9, vp, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) v[j] = 0;
+        }
+        add_axis(v, b.axis, gdot<T, N>(G, yd));
         S.st(b.slot_v, v);
     }
 }
@@ -439,25 +499,22 @@ __device__ __forceinline__ void free_rotation(int ori_repr, const T *o, T (&E)[9
     }
 }
 
-// Free cluster (FreeJoint.cpp:28-46, Joint.h:61-68): Xup = XJ = (R(ori), position), v = yd
+// Free cluster (FreeJoint.cpp:28-46, Joint.h:61-68): Xup = XJ = (R(ori), position), v = yd.
+// a' = Xup * (-gravity); needs only E because -gravity has no angular part in general? No:
+// the general formula is kept.
 template <class T>
-__device__ __forceinline__ void fwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                         const Lane<T> &L, T (&Er)[12], T (&v)[6])
+__device__ __forceinline__ void free_base_accel(const Tables<T> &P, const ClusterRec &c, const Lane<T> &L, T (&ag)[6])
 {
-    const BodyRec &b = P.bodies[c.first_body];
-    T o[4];
+    T o[4], E[9], r[3], g[6];
     const int nori = P.ori_repr == 0 ? 4 : 3;
+#pragma unroll
     for (int j = 0; j < 4; j++) o[j] = j < nori ? L.q[c.q_index + 3 + j] : T(0);
-    T E[9];
     free_rotation(P.ori_repr, o, E);
 #pragma unroll
-    for (int j = 0; j < 9; j++) Er[j] = E[j];
+    for (int j = 0; j < 3; j++) r[j] = L.q[c.q_index + j];
 #pragma unroll
-    for (int j = 0; j < 3; j++) Er[9 + j] = L.q[c.q_index + j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
-    S.st(b.slot_sc, Er);
-    S.st(b.slot_v, v);
+    for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
+    xmotion(E, r, g, ag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,12 +522,13 @@ __device__ __forceinline__ void fwd_free(const DevPlan<T> &P, const Slots<T> &S,
 // (ClusterTreeDynamics.cpp:94-129,157-191; ClusterTreeNode.cpp:33-37)
 // ---------------------------------------------------------------------------------------------
 template <class T, int N>
-__device__ __forceinline__ void aba_bwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+__device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
-    T yd[N], u[N], F[6][N], D[N][N];
+    T y[N], yd[N], u[N], F[6][N], D[N][N];
 #pragma unroll
     for (int a = 0; a < N; a++) {
+        y[a] = L.q[c.q_index + a];
         yd[a] = L.qd[c.v_index + a];
         u[a] = L.x[c.v_index + a];
 #pragma unroll
@@ -482,17 +540,16 @@ __device__ __forceinline__ void aba_bwd_static(const DevPlan<T> &P, const Slots<
     // in-cluster bias acceleration (the cJ part of GenericJoint.cpp:430-450), chained clusters only
     if (c.chained) {
         for (int i = 0; i < c.k; i++) {
-            const BodyRec &b = P.bodies[c.first_body + i];
-            const T *C = P.consts + b.cofs;
+            const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+            cptr<T> C = P.consts + b.cofs;
             const T qdi = gdot<T, N>(C + kBodyConstFixed, yd);
-            T v[6], ccl[6];
-            S.ld(b.slot_v, v);
+            T sc[2], E[9], v[6], ccl[6];
+            body_kinematics<T, N>(P, S, b, C, y, qdi, sc, E, v);
             vxaxis(b.axis, v, qdi, ccl);
             if (b.lam >= 0) {
-                T sc[2], E[9], cp[6], t[6];
-                S.ld(b.slot_sc, sc);
-                build_E(b.axis, sc[0], sc[1], C, E);
-                S.ld(P.bodies[b.lam].slot_ccl, cp);
+                T cp[6], t[6];
+                const BodyRec bl = load_rec(P.bodies + (b.lam));
+                S.ld(bl.slot_ccl, cp);
                 xmotion(E, C + 9, cp, t);
 #pragma unroll
                 for (int j = 0; j < 6; j++) ccl[j] += t[j];
@@ -502,15 +559,13 @@ __device__ __forceinline__ void aba_bwd_static(const DevPlan<T> &P, const Slots<
     }
 
     for (int i = c.k - 1; i >= 0; i--) {
-        const BodyRec &b = P.bodies[c.first_body + i];
-        const T *C = P.consts + b.cofs;
-        const T *G = C + kBodyConstFixed;
-        const T *Ic = C + 12;
-        T sc[2], E[9], v[6];
-        S.ld(b.slot_sc, sc);
-        S.ld(b.slot_v, v);
-        build_E(b.axis, sc[0], sc[1], C, E);
+        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        cptr<T> C = P.consts + b.cofs;
+        cptr<T> G = C + kBodyConstFixed;
+        cptr<T> Ic = C + 12;
         const T qdi = gdot<T, N>(G, yd);
+        T sc[2], E[9], v[6];
+        body_kinematics<T, N>(P, S, b, C, y, qdi, sc, E, v);
         T chat[6];
         vxaxis(b.axis, v, qdi, chat);
 
@@ -571,9 +626,9 @@ __device__ __forceinline__ void aba_bwd_static(const DevPlan<T> &P, const Slots<
         xforce_inv(E, C + 9, h, f);
         int l = b.lam;
         while (l >= 0) {
-            const BodyRec &bl = P.bodies[l];
-            const T *Cl = P.consts + bl.cofs;
-            const T *Gl = Cl + kBodyConstFixed;
+            const BodyRec bl = load_rec(P.bodies + (l));
+            cptr<T> Cl = P.consts + bl.cofs;
+            cptr<T> Gl = Cl + kBodyConstFixed;
             const T Hc = pick(f, bl.axis);
 #pragma unroll
             for (int a = 0; a < N; a++)
@@ -634,13 +689,14 @@ __device__ __forceinline__ void aba_bwd_static(const DevPlan<T> &P, const Slots<
 
 // Free root: S = 1, D = IA, c = 0 (FreeJoint.cpp:10-36)
 template <class T>
-__device__ __forceinline__ void aba_bwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+__device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                              const Lane<T> &L)
 {
-    const BodyRec &b = P.bodies[c.first_body];
-    const T *Ic = P.consts + b.cofs + 12;
+    const BodyRec b = load_rec(P.bodies + (c.first_body));
+    cptr<T> Ic = P.consts + b.cofs + 12;
     T v[6], psi[6], Iv[6], IA[21];
-    S.ld(b.slot_v, v);
+#pragma unroll
+    for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
     symv_c(Ic, v, Iv);
     crf(v, Iv, psi);
     if (b.has_child) {
@@ -669,17 +725,18 @@ __device__ __forceinline__ void aba_bwd_free(const DevPlan<T> &P, const Slots<T>
 }
 
 // ---------------------------------------------------------------------------------------------
-// ABA sweep 3: joint accelerations (ClusterTreeDynamics.cpp:131-152)
+// ABA sweep 3: joint accelerations (ClusterTreeDynamics.cpp:131-152).  Velocities of bodies with
+// children are recomputed on the way down (cheaper than keeping them live across the sweeps).
 // ---------------------------------------------------------------------------------------------
 template <class T, int N>
-__device__ __forceinline__ void aba_acc_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+__device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
-    T K[6 * N], ydd[N], yd[N], ap[6];
+    T K[6 * N], ydd[N], ap[6];
     S.ld(c.slot_K, K);
     S.ld(c.slot_y0, ydd);
-    if (c.parent_slot_a >= 0) {
-        S.ld(c.parent_slot_a, ap);
+    if (c.parent_slot_a3 >= 0) {
+        S.ld(c.parent_slot_a3, ap);
     } else {
 #pragma unroll
         for (int j = 0; j < 6; j++) ap[j] = P.a_root[j];
@@ -690,59 +747,89 @@ __device__ __forceinline__ void aba_acc_static(const DevPlan<T> &P, const Slots<
 #pragma unroll
         for (int r = 0; r < 6; r++) s -= K[a * 6 + r] * ap[r];
         ydd[a] = s;
-        yd[a] = L.qd[c.v_index + a];
         if (L.active) L.out[c.v_index + a] = s;
     }
+    bool loaded = false;
+    T y[N], yd[N];
     for (int i = 0; i < c.k; i++) {
-        const BodyRec &b = P.bodies[c.first_body + i];
+        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         if (!b.has_child) continue;  // nothing downstream needs this body's acceleration
-        const T *C = P.consts + b.cofs;
-        const T *G = C + kBodyConstFixed;
-        T sc[2], E[9], v[6], a[6], api[6];
-        S.ld(b.slot_sc, sc);
-        S.ld(b.slot_v, v);
+        if (!loaded) {
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                y[a] = L.q[c.q_index + a];
+                yd[a] = L.qd[c.v_index + a];
+            }
+            loaded = true;
+        }
+        cptr<T> C = P.consts + b.cofs;
+        cptr<T> G = C + kBodyConstFixed;
+        T sc[2], E[9], v[6], a[6];
+        sincos_t(gdot<T, N>(G, y), &sc[0], &sc[1]);
         build_E(b.axis, sc[0], sc[1], C, E);
-        if (b.lam >= 0) {
-            S.ld(b.parent_slot_a, api);
+        if (b.parent >= 0) {
+            T vp[6], api[6];
+            S.ld(b.parent_slot_v3, vp);
+            S.ld(b.parent_slot_a3, api);
+            xmotion(E, C + 9, vp, v);
             xmotion(E, C + 9, api, a);
         } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) v[j] = 0;
             xmotion(E, C + 9, ap, a);
         }
+        const T qdi = gdot<T, N>(G, yd);
+        add_axis(v, b.axis, qdi);
         T chat[6];
-        vxaxis(b.axis, v, gdot<T, N>(G, yd), chat);
+        vxaxis(b.axis, v, qdi, chat);
 #pragma unroll
         for (int j = 0; j < 6; j++) a[j] += chat[j];
         add_axis(a, b.axis, gdot<T, N>(G, ydd));
-        S.st(b.slot_a, a);
+        S.st(b.slot_v3, v);
+        S.st(b.slot_a3, a);
     }
 }
 
 template <class T>
-__device__ __forceinline__ void aba_acc_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
+__device__ __forceinline__ void aba_acc_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                              const Lane<T> &L)
 {
-    const BodyRec &b = P.bodies[c.first_body];
-    T Er[12], y0[6], ag[6], g[6], E[9];
-    S.ld(b.slot_sc, Er);
+    const BodyRec b = load_rec(P.bodies + (c.first_body));
+    T y0[6], ag[6];
     S.ld(c.slot_y0, y0);
-#pragma unroll
-    for (int j = 0; j < 9; j++) E[j] = Er[j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
-    xmotion(E, &Er[9], g, ag);
+    free_base_accel(P, c, L, ag);
     // ydd = D^-1 u - D^-1 U^T a' with U = IA, D = IA  =>  ydd = y0 - a' ;  a = a' + ydd = y0
 #pragma unroll
     for (int j = 0; j < 6; j++)
         if (L.active) L.out[c.v_index + j] = y0[j] - ag[j];
-    if (b.has_child) S.st(b.slot_a, y0);
+    if (b.has_child) {
+        T v[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
+        S.st(b.slot_v3, v);
+        S.st(b.slot_a3, y0);
+    }
+}
+
+// free root, forward sweep: children only need its velocity
+template <class T>
+__device__ __forceinline__ void aba_fwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                             const Lane<T> &L)
+{
+    const BodyRec b = load_rec(P.bodies + (c.first_body));
+    if (!b.has_child) return;
+    T v[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
+    S.st(b.slot_v, v);
 }
 
 // ---------------------------------------------------------------------------------------------
-// RNEA (TreeModel.cpp:34-57,173-212).  Force slots: slot_IA region is reused (plan.cpp).
+// RNEA (TreeModel.cpp:34-57,173-212)
 // ---------------------------------------------------------------------------------------------
 template <class T, int N>
-__device__ __forceinline__ void rnea_fwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                                const Lane<T> &L, const int *slot_f)
+__device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                const Lane<T> &L)
 {
     T y[N], yd[N], ydd[N];
 #pragma unroll
@@ -752,19 +839,18 @@ __device__ __forceinline__ void rnea_fwd_static(const DevPlan<T> &P, const Slots
         ydd[a] = L.x[c.v_index + a];
     }
     for (int i = 0; i < c.k; i++) {
-        const int gb = c.first_body + i;
-        const BodyRec &b = P.bodies[gb];
-        const T *C = P.consts + b.cofs;
-        const T *G = C + kBodyConstFixed;
+        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        cptr<T> C = P.consts + b.cofs;
+        cptr<T> G = C + kBodyConstFixed;
         const T qi = gdot<T, N>(G, y), qdi = gdot<T, N>(G, yd), qddi = gdot<T, N>(G, ydd);
         T sc[2], E[9], v[6], a[6];
         sincos_t(qi, &sc[0], &sc[1]);
-        S.st(b.slot_sc, sc);
+        if (b.parent >= 0) S.st(b.slot_sc, sc);
         build_E(b.axis, sc[0], sc[1], C, E);
         if (b.parent >= 0) {
             T vp[6], apar[6];
             S.ld(b.parent_slot_v, vp);
-            S.ld(b.parent_slot_a, apar);
+            S.ld(b.parent_slot_a3, apar);
             xmotion(E, C + 9, vp, v);
             xmotion(E, C + 9, apar, a);
         } else {
@@ -781,7 +867,7 @@ __device__ __forceinline__ void rnea_fwd_static(const DevPlan<T> &P, const Slots
         add_axis(a, b.axis, qddi);
         if (b.has_child) {
             S.st(b.slot_v, v);
-            S.st(b.slot_a, a);
+            S.st(b.slot_a3, a);
         }
         T Ia[6], Iv[6], f[6];
         symv_c(C + 12, a, Ia);
@@ -789,49 +875,49 @@ __device__ __forceinline__ void rnea_fwd_static(const DevPlan<T> &P, const Slots
         crf(v, Iv, f);
 #pragma unroll
         for (int j = 0; j < 6; j++) f[j] += Ia[j];
-        S.st(slot_f[gb], f);
+        S.st(b.slot_f, f);
     }
 }
 
 template <class T>
-__device__ __forceinline__ void rnea_fwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                              const Lane<T> &L, const int *slot_f)
+__device__ __forceinline__ void rnea_fwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                              const Lane<T> &L)
 {
-    const BodyRec &b = P.bodies[c.first_body];
-    T Er[12], v[6], a[6], g[6], E[9];
-    fwd_free(P, S, c, L, Er, v);
+    const BodyRec b = load_rec(P.bodies + (c.first_body));
+    T v[6], a[6];
+    free_base_accel(P, c, L, a);
 #pragma unroll
-    for (int j = 0; j < 9; j++) E[j] = Er[j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
-    xmotion(E, &Er[9], g, a);
-#pragma unroll
-    for (int j = 0; j < 6; j++) a[j] += L.x[c.v_index + j];
-    if (b.has_child) S.st(b.slot_a, a);
+    for (int j = 0; j < 6; j++) {
+        v[j] = L.qd[c.v_index + j];
+        a[j] += L.x[c.v_index + j];
+    }
+    if (b.has_child) {
+        S.st(b.slot_v, v);
+        S.st(b.slot_a3, a);
+    }
     T Ia[6], Iv[6], f[6];
-    const T *Ic = P.consts + b.cofs + 12;
+    cptr<T> Ic = P.consts + b.cofs + 12;
     symv_c(Ic, a, Ia);
     symv_c(Ic, v, Iv);
     crf(v, Iv, f);
 #pragma unroll
     for (int j = 0; j < 6; j++) f[j] += Ia[j];
-    S.st(slot_f[c.first_body], f);
+    S.st(b.slot_f, f);
 }
 
 template <class T, int N>
-__device__ __forceinline__ void rnea_bwd_static(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                                const Lane<T> &L, const int *slot_f)
+__device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                const Lane<T> &L)
 {
     T tau[N];
 #pragma unroll
     for (int a = 0; a < N; a++) tau[a] = 0;
     for (int i = c.k - 1; i >= 0; i--) {
-        const int gb = c.first_body + i;
-        const BodyRec &b = P.bodies[gb];
-        const T *C = P.consts + b.cofs;
-        const T *G = C + kBodyConstFixed;
+        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        cptr<T> C = P.consts + b.cofs;
+        cptr<T> G = C + kBodyConstFixed;
         T f[6];
-        S.ld(slot_f[gb], f);
+        S.ld(b.slot_f, f);
         const T t = pick(f, b.axis);
 #pragma unroll
         for (int a = 0; a < N; a++) tau[a] += G[a] * t;
@@ -840,7 +926,7 @@ __device__ __forceinline__ void rnea_bwd_static(const DevPlan<T> &P, const Slots
             S.ld(b.slot_sc, sc);
             build_E(b.axis, sc[0], sc[1], C, E);
             xforce_inv(E, C + 9, f, fp);
-            S.acc(slot_f[b.parent], fp, 0);
+            S.acc(b.parent_slot_f, fp, 0);
         }
     }
 #pragma unroll
@@ -849,12 +935,12 @@ __device__ __forceinline__ void rnea_bwd_static(const DevPlan<T> &P, const Slots
 }
 
 template <class T>
-__device__ __forceinline__ void rnea_bwd_free(const DevPlan<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                              const Lane<T> &L, const int *slot_f)
+__device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                              const Lane<T> &L)
 {
-    (void)P;
+    const BodyRec b = load_rec(P.bodies + (c.first_body));
     T f[6];
-    S.ld(slot_f[c.first_body], f);
+    S.ld(b.slot_f, f);
 #pragma unroll
     for (int j = 0; j < 6; j++)
         if (L.active) L.out[c.v_index + j] = f[j];
@@ -872,16 +958,15 @@ __device__ __forceinline__ void rnea_bwd_free(const DevPlan<T> &P, const Slots<T
     }
 
 template <class T>
-__global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> P, const T *__restrict__ q,
+__global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                      const T *__restrict__ qd, const T *__restrict__ tau,
                                                      T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
 {
+    const Tables<T> P = make_tables(DP);
     const int lane = threadIdx.x;
-    const size_t n_glb = (size_t)(P.n_slots - P.n_lds_slots);
     Slots<T> S;
     S.lane = lane;
-    S.glb = scratch + (size_t)blockIdx.x * n_glb * kWave + lane - (size_t)P.n_lds_slots * kWave;
-    S.n_lds = P.n_lds_slots;
+    S.glb = scratch + (size_t)blockIdx.x * (size_t)DP.n_glb_slots * kWave + lane;
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -894,12 +979,11 @@ __global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> P, const T *__res
         L.x = tau + rr * P.nv;
         L.out = ydd + rr * P.nv;
         for (int s = 0; s < P.n_steps; s++) {
-            const Step st = P.steps[s];
-            const ClusterRec &c = P.clusters[st.cluster];
+            const Step st = load_rec(P.steps + s);
+            const ClusterRec c = load_rec(P.clusters + st.cluster);
             if (st.op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
-                    T Er[12], v[6];
-                    fwd_free(P, S, c, L, Er, v);
+                    aba_fwd_free(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c.n, (aba_fwd_static<T, N_>(P, S, c, L)))
                 }
@@ -921,17 +1005,15 @@ __global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> P, const T *__res
 }
 
 template <class T>
-__global__ __launch_bounds__(kWave) void rnea_kernel(DevPlan<T> P, const int *__restrict__ slot_f,
-                                                      const T *__restrict__ q, const T *__restrict__ qd,
-                                                      const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
-                                                      T *__restrict__ scratch)
+__global__ __launch_bounds__(kWave) void rnea_kernel(DevPlan<T> DP, const T *__restrict__ q,
+                                                      const T *__restrict__ qd, const T *__restrict__ ydd,
+                                                      T *__restrict__ tau, size_t B, T *__restrict__ scratch)
 {
+    const Tables<T> P = make_tables(DP);
     const int lane = threadIdx.x;
-    const size_t n_glb = (size_t)(P.n_slots - P.n_lds_slots);
     Slots<T> S;
     S.lane = lane;
-    S.glb = scratch + (size_t)blockIdx.x * n_glb * kWave + lane - (size_t)P.n_lds_slots * kWave;
-    S.n_lds = P.n_lds_slots;
+    S.glb = scratch + (size_t)blockIdx.x * (size_t)DP.n_glb_slots * kWave + lane;
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -944,19 +1026,19 @@ __global__ __launch_bounds__(kWave) void rnea_kernel(DevPlan<T> P, const int *__
         L.x = ydd + rr * P.nv;
         L.out = tau + rr * P.nv;
         for (int s = 0; s < P.n_steps; s++) {
-            const Step st = P.steps[s];
-            const ClusterRec &c = P.clusters[st.cluster];
+            const Step st = load_rec(P.steps + s);
+            const ClusterRec c = load_rec(P.clusters + st.cluster);
             if (st.op == OP_RNEA_FWD) {
                 if (c.kind == CK_FREE) {
-                    rnea_fwd_free(P, S, c, L, slot_f);
+                    rnea_fwd_free(P, S, c, L);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (rnea_fwd_static<T, N_>(P, S, c, L, slot_f)))
+                    GRBDA_DISPATCH_N(c.n, (rnea_fwd_static<T, N_>(P, S, c, L)))
                 }
             } else {
                 if (c.kind == CK_FREE) {
-                    rnea_bwd_free(P, S, c, L, slot_f);
+                    rnea_bwd_free(P, S, c, L);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (rnea_bwd_static<T, N_>(P, S, c, L, slot_f)))
+                    GRBDA_DISPATCH_N(c.n, (rnea_bwd_static<T, N_>(P, S, c, L)))
                 }
             }
         }
@@ -974,11 +1056,10 @@ hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau
     return hipGetLastError();
 }
 template <class T>
-hipError_t launch_rnea(const DevPlan<T> &P, const int *slot_f, const T *q, const T *qd, const T *ydd, T *tau,
-                       size_t B, T *scratch, int grid, size_t lds_bytes, hipStream_t stream)
+hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch,
+                       int grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(rnea_kernel<T>, dim3(grid), dim3(kWave), lds_bytes, stream, P, slot_f, q, qd, ydd, tau, B,
-                       scratch);
+    hipLaunchKernelGGL(rnea_kernel<T>, dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
 }
 
@@ -986,10 +1067,10 @@ template hipError_t launch_aba<float>(const DevPlan<float> &, const float *, con
                                       size_t, float *, int, size_t, hipStream_t);
 template hipError_t launch_aba<double>(const DevPlan<double> &, const double *, const double *, const double *,
                                        double *, size_t, double *, int, size_t, hipStream_t);
-template hipError_t launch_rnea<float>(const DevPlan<float> &, const int *, const float *, const float *,
-                                       const float *, float *, size_t, float *, int, size_t, hipStream_t);
-template hipError_t launch_rnea<double>(const DevPlan<double> &, const int *, const double *, const double *,
-                                        const double *, double *, size_t, double *, int, size_t, hipStream_t);
+template hipError_t launch_rnea<float>(const DevPlan<float> &, const float *, const float *, const float *, float *,
+                                       size_t, float *, int, size_t, hipStream_t);
+template hipError_t launch_rnea<double>(const DevPlan<double> &, const double *, const double *, const double *,
+                                        double *, size_t, double *, int, size_t, hipStream_t);
 
 hipError_t set_max_dynamic_lds()
 {

@@ -7,6 +7,7 @@
 // per-state intermediate, and emits the sweep order the kernels execute.
 #include "plan.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -56,7 +57,7 @@ int parse(const void *blob, size_t bytes, Blob &m, char *msg, size_t cap)
 
 }  // namespace
 
-int compile_plan(const void *blob, size_t bytes, HostPlan &P, char *msg, size_t cap)
+int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, HostPlan &P, char *msg, size_t cap)
 {
     Blob m;
     if (int rc = parse(blob, bytes, m, msg, cap)) return rc;
@@ -68,8 +69,8 @@ int compile_plan(const void *blob, size_t bytes, HostPlan &P, char *msg, size_t 
     P.n_clusters = nc;
     P.ori_repr = m.h->ori_repr;
     std::memcpy(P.gravity, m.h->gravity, sizeof P.gravity);
-    P.clusters.assign(nc, ClusterRec());
-    P.bodies.assign(nb, BodyRec());
+    std::vector<ClusterRec> clusters(nc, ClusterRec());
+    std::vector<BodyRec> bodies(nb, BodyRec());
 
     // ---- validation + topology ------------------------------------------------------------
     int q_end = 0, v_end = 0, b_end = 0;
@@ -86,7 +87,7 @@ int compile_plan(const void *blob, size_t bytes, HostPlan &P, char *msg, size_t 
         if (cl.n_bodies > kMaxClusterBodies)
             return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d bodies exceed the kernel limit", c, cl.n_bodies);
 
-        ClusterRec &cr = P.clusters[c];
+        ClusterRec &cr = clusters[c];
         cr.first_body = cl.first_body;
         cr.k = cl.n_bodies;
         cr.n = cl.n_vel;
@@ -122,7 +123,7 @@ int compile_plan(const void *blob, size_t bytes, HostPlan &P, char *msg, size_t 
             if (b.parent >= gb) return fail(msg, cap, GRBDA_EINVAL, "body %d: parent not earlier", gb);
             if (cr.kind == CK_STATIC && (b.joint_type != GRBDA_JOINT_REVOLUTE || b.axis < 0 || b.axis > 2))
                 return fail(msg, cap, GRBDA_EINVAL, "body %d: bad joint", gb);
-            BodyRec &br = P.bodies[gb];
+            BodyRec &br = bodies[gb];
             br.parent = b.parent;
             br.axis = b.axis;
             br.jtype = b.joint_type;
@@ -148,80 +149,13 @@ int compile_plan(const void *blob, size_t bytes, HostPlan &P, char *msg, size_t 
         return fail(msg, cap, GRBDA_EINVAL, "header totals do not match clusters");
 
     for (int b = 0; b < nb; b++)
-        if (P.bodies[b].parent >= 0) P.bodies[P.bodies[b].parent].has_child = 1;
-
-    // ---- slots ------------------------------------------------------------------------------
-    // Hot, small objects first (they land in LDS): velocities and joint sin/cos, then the
-    // accumulators, then the per-cluster solve products.
-    int slot = 0;
-    auto take = [&slot](int n) { int s = slot; slot += n; return s; };
-    for (int b = 0; b < nb; b++) {
-        BodyRec &br = P.bodies[b];
-        br.slot_sc = take(br.jtype == GRBDA_JOINT_FREE ? 12 : 2);
-        br.slot_v = take(6);
-    }
-    for (int b = 0; b < nb; b++) {
-        BodyRec &br = P.bodies[b];
-        const ClusterRec &cr = P.clusters[m.bodies[b].cluster];
-        br.slot_psi = br.has_child ? take(6) : -1;
-        br.slot_a = br.slot_psi;  // psi is dead once the body's cluster finished its backward step
-        br.slot_ccl = cr.chained ? take(6) : -1;
-    }
-    const int ia_region = slot;
-    for (int b = 0; b < nb; b++) {
-        BodyRec &br = P.bodies[b];
-        br.slot_IA = br.has_child ? take(21) : -1;
-    }
-    for (int c = 0; c < nc; c++) {
-        ClusterRec &cr = P.clusters[c];
-        cr.slot_K = take(6 * cr.n);
-        cr.slot_y0 = take(cr.n);
-    }
-    P.n_slots = slot;
-    // RNEA keeps one body force per body; it never touches the inertia accumulators or the
-    // per-cluster solve products, so the forces alias that region.
-    P.rnea_slot_f.resize(nb);
-    for (int b = 0; b < nb; b++) P.rnea_slot_f[b] = ia_region + 6 * b;
-    if (ia_region + 6 * nb > P.n_slots) P.n_slots = ia_region + 6 * nb;
-
-    // parent slots + "first contributor" flags.  Backward sweeps visit clusters in reverse index
-    // order and bodies in reverse order inside a cluster, so the first contributor to a body's
-    // accumulators is its highest-indexed tree child.
-    std::vector<int> last_child(nb, -1);
-    for (int b = 0; b < nb; b++)
-        if (P.bodies[b].parent >= 0) last_child[P.bodies[b].parent] = b;
-    for (int b = 0; b < nb; b++) {
-        BodyRec &br = P.bodies[b];
-        if (br.parent >= 0) {
-            const BodyRec &pr = P.bodies[br.parent];
-            br.parent_slot_v = pr.slot_v;
-            br.parent_slot_a = pr.slot_a;
-            br.parent_slot_IA = pr.slot_IA;
-            br.parent_slot_psi = pr.slot_psi;
-            br.acc_first = last_child[br.parent] == b;
-        } else {
-            br.parent_slot_v = br.parent_slot_a = br.parent_slot_IA = br.parent_slot_psi = -1;
-            br.acc_first = 0;
-        }
-    }
-    for (int c = 0; c < nc; c++) {
-        ClusterRec &cr = P.clusters[c];
-        if (cr.parent_body >= 0) {
-            const BodyRec &pr = P.bodies[cr.parent_body];
-            cr.parent_slot_IA = pr.slot_IA;
-            cr.parent_slot_psi = pr.slot_psi;
-            cr.parent_slot_a = pr.slot_a;
-        } else {
-            cr.parent_slot_IA = cr.parent_slot_psi = cr.parent_slot_a = -1;
-        }
-        cr.acc_first = 0;
-    }
+        if (bodies[b].parent >= 0) bodies[bodies[b].parent].has_child = 1;
 
     // ---- constants --------------------------------------------------------------------------
     for (int b = 0; b < nb; b++) {
         const grbda_desc_body &bd = m.bodies[b];
         const grbda_desc_cluster &cl = m.clusters[bd.cluster];
-        BodyRec &br = P.bodies[b];
+        BodyRec &br = bodies[b];
         br.cofs = static_cast<int>(P.consts.size());
         for (int i = 0; i < 9; i++) P.consts.push_back(bd.Xtree_E[i]);
         for (int i = 0; i < 3; i++) P.consts.push_back(bd.Xtree_r[i]);
@@ -238,30 +172,229 @@ int compile_plan(const void *blob, size_t bytes, HostPlan &P, char *msg, size_t 
         }
     }
 
-    // ---- step programs ------------------------------------------------------------------------
-    for (int c = 0; c < nc; c++) P.aba_steps.push_back({OP_ABA_FWD, c});
-    for (int c = nc - 1; c >= 0; c--) P.aba_steps.push_back({OP_ABA_BWD, c});
-    for (int c = 0; c < nc; c++) P.aba_steps.push_back({OP_ABA_ACC, c});
-    for (int c = 0; c < nc; c++) P.rnea_steps.push_back({OP_RNEA_FWD, c});
-    for (int c = nc - 1; c >= 0; c--) P.rnea_steps.push_back({OP_RNEA_BWD, c});
+    // ---- sweep schedule: depth-first, a subtree is swept forward then backward ------------------
+    std::vector<std::vector<int>> kids(nc);
+    std::vector<int> roots;
+    for (int c = 0; c < nc; c++) {
+        if (m.clusters[c].parent_cluster >= 0) kids[m.clusters[c].parent_cluster].push_back(c);
+        else roots.push_back(c);
+    }
+    std::vector<int> tF(nc, -1), tB(nc, -1), tA(nc, -1), tRF(nc, -1), tRB(nc, -1);
+    {
+        std::vector<std::pair<int, int>> stack;  // (cluster, next child)
+        for (int r : roots) {
+            stack.push_back({r, 0});
+            tF[r] = static_cast<int>(P.aba_steps.size());
+            P.aba_steps.push_back({OP_ABA_FWD, r});
+            tRF[r] = static_cast<int>(P.rnea_steps.size());
+            P.rnea_steps.push_back({OP_RNEA_FWD, r});
+            while (!stack.empty()) {
+                auto &top = stack.back();
+                const int c = top.first;
+                if (top.second < static_cast<int>(kids[c].size())) {
+                    const int ch = kids[c][top.second++];
+                    tF[ch] = static_cast<int>(P.aba_steps.size());
+                    P.aba_steps.push_back({OP_ABA_FWD, ch});
+                    tRF[ch] = static_cast<int>(P.rnea_steps.size());
+                    P.rnea_steps.push_back({OP_RNEA_FWD, ch});
+                    stack.push_back({ch, 0});
+                } else {
+                    tB[c] = static_cast<int>(P.aba_steps.size());
+                    P.aba_steps.push_back({OP_ABA_BWD, c});
+                    tRB[c] = static_cast<int>(P.rnea_steps.size());
+                    P.rnea_steps.push_back({OP_RNEA_BWD, c});
+                    stack.pop_back();
+                }
+            }
+        }
+        // acceleration sweep, depth-first pre-order
+        for (int r : roots) {
+            std::vector<int> st{r};
+            while (!st.empty()) {
+                const int c = st.back();
+                st.pop_back();
+                tA[c] = static_cast<int>(P.aba_steps.size());
+                P.aba_steps.push_back({OP_ABA_ACC, c});
+                for (int i = static_cast<int>(kids[c].size()) - 1; i >= 0; i--) st.push_back(kids[c][i]);
+            }
+        }
+    }
+
+    // ---- live ranges + interval allocation --------------------------------------------------------
+    struct Obj {
+        int *field;  // where the slot number goes (index into a flat array of fields)
+        int size, prio, birth, death, slot;
+    };
+    auto allocate = [](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb) {
+        std::vector<int> order(objs.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = static_cast<int>(i);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (objs[a].prio != objs[b].prio) return objs[a].prio < objs[b].prio;
+            return objs[a].birth < objs[b].birth;
+        });
+        std::vector<int> placed_lds, placed_glb;
+        n_lds = n_glb = 0;
+        auto first_fit = [&](const Obj &o, const std::vector<int> &placed, bool global, int limit) -> int {
+            std::vector<std::pair<int, int>> busy;
+            for (int pi : placed) {
+                const Obj &p = objs[pi];
+                if (p.death < o.birth || o.death < p.birth) continue;
+                const int off = global ? (p.slot & ~kSlotGlobal) : p.slot;
+                busy.push_back({off, off + p.size});
+            }
+            std::sort(busy.begin(), busy.end());
+            int at = 0;
+            for (auto &b : busy) {
+                if (b.first - at >= o.size) break;
+                if (b.second > at) at = b.second;
+            }
+            if (limit >= 0 && at + o.size > limit) return -1;
+            return at;
+        };
+        for (int oi : order) {
+            Obj &o = objs[oi];
+            int at = first_fit(o, placed_lds, false, lds_budget);
+            if (at >= 0) {
+                o.slot = at;
+                placed_lds.push_back(oi);
+                if (at + o.size > n_lds) n_lds = at + o.size;
+            } else {
+                at = first_fit(o, placed_glb, true, -1);
+                o.slot = kSlotGlobal | at;
+                placed_glb.push_back(oi);
+                if (at + o.size > n_glb) n_glb = at + o.size;
+            }
+            *o.field = o.slot;
+        }
+    };
+
+    auto cluster_of = [&](int b) { return m.bodies[b].cluster; };
+    auto build_layout = [&](Layout &L, int lds_budget) {
+        L.clusters = clusters;
+        L.bodies = bodies;
+        L.rnea_bodies = bodies;
+        // ---- ABA ----
+        std::vector<Obj> objs;
+        for (int b = 0; b < nb; b++) {
+            BodyRec &br = L.bodies[b];
+            const int c = cluster_of(b);
+            br.slot_sc = br.slot_v = br.slot_IA = br.slot_psi = br.slot_ccl = br.slot_v3 = br.slot_a3 = br.slot_f = -1;
+            if (br.has_child) {
+                int first_child_bwd = tB[c], last_child_acc = tA[c];
+                for (int j = b + 1; j < nb; j++)
+                    if (bodies[j].parent == b) {
+                        first_child_bwd = std::min(first_child_bwd, tB[cluster_of(j)]);
+                        last_child_acc = std::max(last_child_acc, tA[cluster_of(j)]);
+                    }
+                if (br.jtype != GRBDA_JOINT_FREE) objs.push_back({&br.slot_sc, 2, 0, tF[c], tB[c], -1});
+                objs.push_back({&br.slot_v, 6, 0, tF[c], tB[c], -1});
+                objs.push_back({&br.slot_psi, 6, 1, first_child_bwd, tB[c], -1});
+                objs.push_back({&br.slot_IA, 21, 2, first_child_bwd, tB[c], -1});
+                objs.push_back({&br.slot_v3, 6, 0, tA[c], last_child_acc, -1});
+                objs.push_back({&br.slot_a3, 6, 0, tA[c], last_child_acc, -1});
+            }
+            if (clusters[c].chained) objs.push_back({&br.slot_ccl, 6, 1, tB[c], tB[c], -1});
+        }
+        for (int c = 0; c < nc; c++) {
+            ClusterRec &cr = L.clusters[c];
+            objs.push_back({&cr.slot_y0, cr.n, 3, tB[c], tA[c], -1});
+            if (cr.kind == CK_STATIC) objs.push_back({&cr.slot_K, 6 * cr.n, 3, tB[c], tA[c], -1});
+            else cr.slot_K = -1;
+        }
+        int nl = 0, ng = 0;
+        allocate(objs, lds_budget, nl, ng);
+        L.n_lds_aba = nl;
+        L.n_glb_aba = ng;
+        // first contributor to a body's backward accumulators: earliest backward step, and inside
+        // one step the highest body index (bodies are visited in reverse order)
+        std::vector<int> first(nb, -1);
+        for (int j = 0; j < nb; j++) {
+            const int p = bodies[j].parent;
+            if (p < 0) continue;
+            if (first[p] < 0) { first[p] = j; continue; }
+            const int a = tB[cluster_of(first[p])], t = tB[cluster_of(j)];
+            if (t < a || (t == a && j > first[p])) first[p] = j;
+        }
+        for (int b = 0; b < nb; b++) {
+            BodyRec &br = L.bodies[b];
+            if (br.parent >= 0) {
+                const BodyRec &pr = L.bodies[br.parent];
+                br.parent_slot_v = pr.slot_v;
+                br.parent_slot_IA = pr.slot_IA;
+                br.parent_slot_psi = pr.slot_psi;
+                br.parent_slot_v3 = pr.slot_v3;
+                br.parent_slot_a3 = pr.slot_a3;
+                br.acc_first = first[br.parent] == b;
+            } else {
+                br.parent_slot_v = br.parent_slot_IA = br.parent_slot_psi = br.parent_slot_v3 = br.parent_slot_a3 = -1;
+                br.acc_first = 0;
+            }
+            br.parent_slot_f = -1;
+        }
+        for (int c = 0; c < nc; c++) {
+            ClusterRec &cr = L.clusters[c];
+            if (cr.parent_body >= 0) {
+                const BodyRec &pr = L.bodies[cr.parent_body];
+                cr.parent_slot_IA = pr.slot_IA;
+                cr.parent_slot_psi = pr.slot_psi;
+                cr.parent_slot_v3 = pr.slot_v3;
+                cr.parent_slot_a3 = pr.slot_a3;
+            } else {
+                cr.parent_slot_IA = cr.parent_slot_psi = cr.parent_slot_v3 = cr.parent_slot_a3 = -1;
+            }
+        }
+        // ---- RNEA ----
+        std::vector<Obj> robjs;
+        for (int b = 0; b < nb; b++) {
+            BodyRec &br = L.rnea_bodies[b];
+            const int c = cluster_of(b);
+            br.slot_sc = br.slot_v = br.slot_IA = br.slot_psi = br.slot_ccl = br.slot_v3 = br.slot_a3 = br.slot_f = -1;
+            if (br.jtype != GRBDA_JOINT_FREE && br.parent >= 0) robjs.push_back({&br.slot_sc, 2, 0, tRF[c], tRB[c], -1});
+            robjs.push_back({&br.slot_f, 6, 1, tRF[c], tRB[c], -1});
+            if (br.has_child) {
+                int last_child_fwd = tRF[c];
+                for (int j = b + 1; j < nb; j++)
+                    if (bodies[j].parent == b) last_child_fwd = std::max(last_child_fwd, tRF[cluster_of(j)]);
+                robjs.push_back({&br.slot_v, 6, 0, tRF[c], last_child_fwd, -1});
+                robjs.push_back({&br.slot_a3, 6, 0, tRF[c], last_child_fwd, -1});
+            }
+        }
+        allocate(robjs, lds_budget, nl, ng);
+        L.n_lds_rnea = nl;
+        L.n_glb_rnea = ng;
+        for (int b = 0; b < nb; b++) {
+            BodyRec &br = L.rnea_bodies[b];
+            br.acc_first = 0;
+            if (br.parent >= 0) {
+                const BodyRec &pr = L.rnea_bodies[br.parent];
+                br.parent_slot_v = pr.slot_v;
+                br.parent_slot_a3 = pr.slot_a3;
+                br.parent_slot_f = pr.slot_f;
+            } else {
+                br.parent_slot_v = br.parent_slot_a3 = br.parent_slot_f = -1;
+            }
+            br.parent_slot_IA = br.parent_slot_psi = br.parent_slot_v3 = -1;
+        }
+    };
+    build_layout(P.lay32, lds_slots32);
+    build_layout(P.lay64, lds_slots64);
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
-    // per-body costs: E build 12, motion xform 39, force xform 39, sym6*vec 66, force cross 30,
-    // congruence 470, plus per-cluster solve terms.  Kept as a model-dependent estimate; the
-    // exact figures are listed in DESIGN.md.
+    // per-body costs: sincos ~40, E build 12, motion xform 39, force xform 39, sym6*vec 66,
+    // force cross 30, congruence ~470, plus per-cluster solve terms.
     double fa = 0, fr = 0;
     for (int c = 0; c < nc; c++) {
-        const ClusterRec &cr = P.clusters[c];
+        const ClusterRec &cr = clusters[c];
         const int n = cr.n;
         for (int i = 0; i < cr.k; i++) {
-            const BodyRec &br = P.bodies[cr.first_body + i];
-            const bool fr_ee = br.jtype == GRBDA_JOINT_FREE;
-            fa += (fr_ee ? 60 : 40 + 12) + 39 + 2 * n;           // FWD: sincos, E, v, qd
-            fa += 12 + 8 + 66 + 30 + 12 + 66 + 6 + 39 * 2;        // BWD: E, c, Iv, cross, psi, IA*c, push h, t
+            const BodyRec &br = bodies[cr.first_body + i];
+            const bool is_free = br.jtype == GRBDA_JOINT_FREE;
+            fa += (is_free ? 60 : 40 + 12) + 39 + 2 * n;           // sincos, E, v, qd
+            fa += 8 + 66 + 30 + 12 + 66 + 6 + 39 * 2;             // c, Iv, cross, psi, IA*c, push h, t
             fa += br.parent >= 0 ? 470 + 39 : 0;                  // congruence + bias to parent
             fa += 6 * n * 2 + n * n * 2;                          // F, D accumulation
-            fa += 12 + 39 + 8 + 2 * n + 6;                        // ACC: E, a, c, qdd
-            fr += (fr_ee ? 60 : 52) + 39 * 2 + 8 + 2 * n * 2 + 66 * 2 + 30 + 39 + 2 * n;
+            if (br.has_child) fa += 40 + 12 + 39 * 2 + 8 + 2 * n + 6;  // acceleration sweep (recomputes v)
+            fr += (is_free ? 60 : 52) + 39 * 2 + 8 + 2 * n * 2 + 66 * 2 + 30 + 39 + 2 * n;
         }
         fa += n * n * n / 3.0 + 2.0 * n * n * 7 + 21 * 2 * n + 12 * n + 12 * n;  // solve, K, IA -= F K, psi += F y0, ydd
     }

@@ -8,12 +8,15 @@
 //   * bodies[]    : per-body integer record (tree topology + state-slot numbers),
 //   * consts[]    : model constants in the kernel's scalar type (Xtree, inertias, G rows),
 // All of it is wave-uniform: every lane of a wavefront evaluates a different robot state of the
-// SAME model, so the program is fetched through the scalar unit while the vector unit does the
-// per-state arithmetic.
+// SAME model, so the program is fetched through the scalar unit (the tables are addressed in the
+// constant address space) while the vector unit does the per-state arithmetic.
 //
 // Per-state intermediates live in numbered "slots": slot s of lane l is element [s][l] of a
 // per-wavefront array, so a wave's access to one slot is a fully coalesced 64-element row.
-// Slots [0, n_lds_slots) are placed in LDS, the rest in a per-wave global scratch slab.
+// The plan compiler schedules the sweeps depth-first (a limb is swept forward, then backward,
+// before the next limb starts), computes the live range of every intermediate and packs them
+// with an interval allocator: the hottest objects into the LDS budget, the rest into a small
+// per-wave global slab.  A slot number with kSlotGlobal set addresses the global slab.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -37,6 +40,7 @@ enum ClusterKind : int32_t {
 constexpr int kMaxClusterDof = 4;     // n of a non-free cluster handled in registers
 constexpr int kMaxClusterBodies = 8;  // k
 constexpr int kWave = 64;
+constexpr int32_t kSlotGlobal = 1 << 30;
 
 struct Step {
     int32_t op;
@@ -52,13 +56,13 @@ struct ClusterRec {
     int32_t v_index;
     int32_t parent_body;  // global index of the single body of the parent cluster all in-cluster
                           // roots hang off, or -1 (ground)
+    int32_t chained;      // 1: some body has an in-cluster parent
     int32_t slot_K;       // n x 6 : D^-1 F^T   (ABA_BWD -> ABA_ACC)
     int32_t slot_y0;      // n     : D^-1 u'
-    int32_t parent_slot_IA;   // accumulators of parent_body (or -1)
+    int32_t parent_slot_IA;   // backward-sweep accumulators of parent_body (or -1)
     int32_t parent_slot_psi;
-    int32_t parent_slot_a;    // acceleration of parent_body (or -1: use -gravity)
-    int32_t acc_first;        // 1: this cluster is the first contributor to the parent's accumulators
-    int32_t chained;          // 1: some body has an in-cluster parent
+    int32_t parent_slot_v3;   // acceleration-sweep velocity / acceleration of parent_body (or -1)
+    int32_t parent_slot_a3;
     int32_t reserved[2];
 };
 
@@ -69,22 +73,35 @@ struct BodyRec {
     int32_t jtype;        // 0 revolute, 1 free
     int32_t has_child;    // some body (any cluster) has this body as tree parent
     int32_t cofs;         // offset into consts[]: Et[9] rt[3] I[21] G_row[n]
-    int32_t slot_sc;      // sin, cos of the spanning joint angle (2)        [free: E (9) + r (3)]
-    int32_t slot_v;       // spatial velocity (6)
-    int32_t slot_IA;      // composite articulated inertia accumulator (21, packed upper)
-    int32_t slot_psi;     // bias force accumulator (6); RNEA: force accumulator
-    int32_t slot_a;       // spatial acceleration (6)
+    int32_t slot_sc;      // sin, cos of the spanning joint angle (2) [free: E (9) + r (3)]; has_child only
+    int32_t slot_v;       // spatial velocity (6), forward sweep -> backward sweep; has_child only
+    int32_t slot_IA;      // composite articulated inertia accumulator (21, packed upper); has_child only
+    int32_t slot_psi;     // bias force accumulator (6); has_child only
     int32_t slot_ccl;     // in-cluster bias acceleration (6), chained clusters only
-    int32_t parent_slot_v;    // slot_v / slot_a / slot_IA / slot_psi of the tree parent, -1 if none
-    int32_t parent_slot_a;
+    int32_t slot_v3;      // velocity (6) and acceleration (6) in the acceleration sweep; has_child only
+    int32_t slot_a3;
+    int32_t slot_f;       // RNEA: body force (6), all bodies
+    int32_t parent_slot_v;    // the tree parent's slots, -1 if none
     int32_t parent_slot_IA;
     int32_t parent_slot_psi;
-    int32_t acc_first;        // 1: first contributor to the tree parent's accumulators
+    int32_t parent_slot_v3;
+    int32_t parent_slot_a3;
+    int32_t parent_slot_f;
+    int32_t acc_first;        // 1: first contributor to the tree parent's backward accumulators
     int32_t reserved[3];
 };
 
 // number of constants per body before the G row
 constexpr int kBodyConstFixed = 9 + 3 + 21;
+
+// slot layout for one scalar width (the LDS budget in slots depends on sizeof(T))
+struct Layout {
+    std::vector<ClusterRec> clusters;
+    std::vector<BodyRec> bodies;       // ABA slots
+    std::vector<BodyRec> rnea_bodies;  // RNEA slots (slot_sc, slot_v, slot_a3, slot_f used)
+    int n_lds_aba = 0, n_glb_aba = 0;
+    int n_lds_rnea = 0, n_glb_rnea = 0;
+};
 
 struct HostPlan {
     int nq = 0, nv = 0, n_bodies = 0, n_clusters = 0;
@@ -92,17 +109,16 @@ struct HostPlan {
     double gravity[6] = {0, 0, 0, 0, 0, -9.81};
     std::vector<Step> aba_steps;
     std::vector<Step> rnea_steps;
-    std::vector<ClusterRec> clusters;
-    std::vector<BodyRec> bodies;
     std::vector<double> consts;  // converted to float on upload for the f32 kernels
-    std::vector<int32_t> rnea_slot_f;  // per body: slot of the RNEA body force (6), aliases the IA region
-    int n_slots = 0;             // total per-lane slots
+    Layout lay32, lay64;
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };
 
 // Compile a model-description blob (include/grbda_model_desc.h) into a HostPlan.
+// lds_slots32 / lds_slots64: LDS budget per wavefront in slots for the f32 / f64 kernels.
 // Returns 0 or a negative GRBDA_E* code (include/grbda_hip.h); msg receives a diagnostic.
-int compile_plan(const void *blob, size_t bytes, HostPlan &out, char *msg, size_t msg_cap);
+int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, HostPlan &out, char *msg,
+                 size_t msg_cap);
 
 }  // namespace grbda_hip
