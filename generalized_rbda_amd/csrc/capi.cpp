@@ -167,11 +167,14 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->waves_per_cu);
     if (grid > n_tiles) grid = n_tiles;
-    const size_t n_glb = static_cast<size_t>(d.n_glb_slots);
+    const size_t n_glb = static_cast<size_t>(d.n_glb_slots) + static_cast<size_t>(d.nq + 2 * d.nv);  // + staged inputs
     const size_t scratch_bytes = grid * n_glb * kWave * sizeof(T) + 256;
     void *scratch = nullptr;
     if (int rc = ensure_scratch(p, device, stream, scratch_bytes, &scratch)) return rc;
-    const size_t lds_bytes = static_cast<size_t>(d.n_lds_slots) * kWave * sizeof(T);
+    // LDS: the slot store, and at tile boundaries the staging area of the input transposition
+    size_t lds_bytes = static_cast<size_t>(d.n_lds_slots) * kWave * sizeof(T);
+    const size_t stage_bytes = static_cast<size_t>(kWave) * static_cast<size_t>((d.nq > d.nv ? d.nq : d.nv) | 1) * sizeof(T);
+    if (lds_bytes < stage_bytes) lds_bytes = stage_bytes;
     hipError_t e;
     if (rnea)
         e = launch_rnea<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,

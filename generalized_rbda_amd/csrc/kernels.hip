@@ -396,10 +396,67 @@ struct Chol {
 // ---------------------------------------------------------------------------------------------
 template <class T>
 struct Lane {
-    const T *q, *qd, *x;  // x: tau (ABA) or ydd (RNEA)
-    T *out;               // ydd (ABA) or tau (RNEA)
+    // the tile's inputs, transposed once per tile into coordinate-major rows of the wave's global
+    // slab (row j of q at in_q[j * 64], one coalesced 64-element row per coordinate)
+    const T *in_q, *in_qd, *in_x;  // x: tau (ABA) or ydd (RNEA); all already offset by the lane
+    T *out;                        // ydd (ABA) or tau (RNEA), row of this lane's state (row-major batch)
     bool active;
+    __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
+    __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
+    __device__ __forceinline__ T x(int j) const { return in_x[(size_t)j * kWave]; }
+    // the cluster's independent coordinates, fetched one step ahead (software pipelining: the
+    // strided loads of step s+1 are in flight while step s computes)
+    T y[kMaxClusterDof], yd[kMaxClusterDof], xx[kMaxClusterDof];
 };
+
+// Tile prologue: the batch is row-major ([state][coordinate], the reference's natural vector
+// layout), so one wave's 64 states are ONE contiguous block of 64 * ncols scalars.  The wave reads
+// that block with fully coalesced loads, transposes it through LDS (which holds no live slot at
+// a tile boundary) and writes coordinate-major rows into its global slab.  Every later access to
+// an input is then a coalesced 64-element row instead of a 64-line strided gather.
+template <class T>
+__device__ __forceinline__ void stage_inputs(const T *__restrict__ src, size_t tile, int rows_valid, int ncols,
+                                             T *slab_rows /* wave slab, NOT lane-offset */, int lane)
+{
+    T *stage = reinterpret_cast<T *>(grbda_smem);
+    const int pitch = ncols | 1;  // odd pitch: the transposed read is bank-conflict free
+    const T *blk = src + tile * (size_t)kWave * (size_t)ncols;
+    const int n_valid = rows_valid * ncols;
+    // element idx = it * 64 + lane of the block -> (row r, column j), advanced incrementally
+    int r = lane / ncols, j = lane - r * ncols;
+    const int dr = kWave / ncols, dj = kWave - dr * ncols;
+    for (int idx = lane; idx < kWave * ncols; idx += kWave) {
+        const int rc = r < rows_valid ? r : rows_valid - 1;  // ragged tail: replicate the last state
+        const T val = blk[idx < n_valid ? idx : rc * ncols + j];
+        stage[r * pitch + j] = val;
+        r += dr;
+        j += dj;
+        if (j >= ncols) { j -= ncols; r += 1; }
+    }
+    __syncthreads();
+    for (int c = 0; c < ncols; c++) slab_rows[(size_t)c * kWave + lane] = stage[lane * pitch + c];
+    __syncthreads();
+}
+
+// register hand-over of a cluster's projected inertia / bias to the next backward step
+template <class T>
+struct Carry {
+    T IA[21];
+    T psi[6];
+};
+
+template <class T>
+__device__ __forceinline__ void prefetch_inputs(const Lane<T> &L, const ClusterRec &c, T (&y)[kMaxClusterDof],
+                                                T (&yd)[kMaxClusterDof], T (&xx)[kMaxClusterDof])
+{
+#pragma unroll
+    for (int a = 0; a < kMaxClusterDof; a++) {
+        const bool in = a < c.n;  // wave-uniform
+        y[a] = in ? L.q(c.q_index + a) : T(0);
+        yd[a] = in ? L.qd(c.v_index + a) : T(0);
+        xx[a] = in ? L.x(c.v_index + a) : T(0);
+    }
+}
 
 // spanning joint value of body i: row i of G times the independent cluster coordinates
 // (LoopConstraint::Static::gamma, LoopConstraint.cpp:49-52; ClusterJoint.cpp:55-58)
@@ -449,8 +506,8 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
     T y[N], yd[N];
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        y[a] = L.q[c.q_index + a];
-        yd[a] = L.qd[c.v_index + a];
+        y[a] = L.y[a];
+        yd[a] = L.yd[a];
     }
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
@@ -508,10 +565,10 @@ __device__ __forceinline__ void free_base_accel(const Tables<T> &P, const Cluste
     T o[4], E[9], r[3], g[6];
     const int nori = P.ori_repr == 0 ? 4 : 3;
 #pragma unroll
-    for (int j = 0; j < 4; j++) o[j] = j < nori ? L.q[c.q_index + 3 + j] : T(0);
+    for (int j = 0; j < 4; j++) o[j] = j < nori ? L.q(c.q_index + 3 + j) : T(0);
     free_rotation(P.ori_repr, o, E);
 #pragma unroll
-    for (int j = 0; j < 3; j++) r[j] = L.q[c.q_index + j];
+    for (int j = 0; j < 3; j++) r[j] = L.q(c.q_index + j);
 #pragma unroll
     for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
     xmotion(E, r, g, ag);
@@ -523,14 +580,20 @@ __device__ __forceinline__ void free_base_accel(const Tables<T> &P, const Cluste
 // ---------------------------------------------------------------------------------------------
 template <class T, int N>
 __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                               const Lane<T> &L)
+                                               const Lane<T> &L, Carry<T> &carry)
 {
     T y[N], yd[N], u[N], F[6][N], D[N][N];
+    // contribution of this cluster to its parent body when it is handed over in registers
+    T pIA[21], ppsi[6];
+#pragma unroll
+    for (int j = 0; j < 21; j++) pIA[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) ppsi[j] = 0;
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        y[a] = L.q[c.q_index + a];
-        yd[a] = L.qd[c.v_index + a];
-        u[a] = L.x[c.v_index + a];
+        y[a] = L.y[a];
+        yd[a] = L.yd[a];
+        u[a] = L.xx[a];
 #pragma unroll
         for (int r = 0; r < 6; r++) F[r][a] = 0;
 #pragma unroll
@@ -576,7 +639,12 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             symv_c(Ic, v, Iv);
             crf(v, Iv, psi);  // pA = v x* (I v), ClusterTreeDynamics.cpp:95-98
         }
-        if (b.has_child) {
+        if (b.carry_in) {
+#pragma unroll
+            for (int j = 0; j < 21; j++) IA[j] = Ic[j] + carry.IA[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
+        } else if (b.has_child) {
             T acc[21], pacc[6];
             S.ld(b.slot_IA, acc);
             S.ld(b.slot_psi, pacc);
@@ -610,9 +678,16 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
             for (int j = 0; j < 6; j++) t[j] = psi[j] + Ic_c[j];
             xforce_inv(E, C + 9, t, tp);
-            S.acc(b.parent_slot_psi, tp, b.acc_first);
             congruence(E, C + 9, IA, Bc);
-            S.acc(b.parent_slot_IA, Bc, b.acc_first);
+            if (c.carry_out && b.lam < 0) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) ppsi[j] += tp[j];
+#pragma unroll
+                for (int j = 0; j < 21; j++) pIA[j] += Bc[j];
+            } else {
+                S.acc(b.parent_slot_psi, tp, b.acc_first);
+                S.acc(b.parent_slot_IA, Bc, b.acc_first);
+            }
         }
 
         // joint-space terms: D += d G^T G, u -= G^T b, push h up the in-cluster chain
@@ -682,24 +757,36 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
                 dI[sidx(r, cc)] = m;
             }
         }
-        S.acc(c.parent_slot_psi, dp, 0);
-        S.acc(c.parent_slot_IA, dI, 0);
+        if (c.carry_out) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) carry.psi[j] = ppsi[j] + dp[j];
+#pragma unroll
+            for (int j = 0; j < 21; j++) carry.IA[j] = pIA[j] + dI[j];
+        } else {
+            S.acc(c.parent_slot_psi, dp, 0);
+            S.acc(c.parent_slot_IA, dI, 0);
+        }
     }
 }
 
 // Free root: S = 1, D = IA, c = 0 (FreeJoint.cpp:10-36)
 template <class T>
 __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                             const Lane<T> &L)
+                                             const Lane<T> &L, const Carry<T> &carry)
 {
     const BodyRec b = load_rec(P.bodies + (c.first_body));
     cptr<T> Ic = P.consts + b.cofs + 12;
     T v[6], psi[6], Iv[6], IA[21];
 #pragma unroll
-    for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
+    for (int j = 0; j < 6; j++) v[j] = L.qd(c.v_index + j);
     symv_c(Ic, v, Iv);
     crf(v, Iv, psi);
-    if (b.has_child) {
+    if (b.carry_in) {
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + carry.IA[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
+    } else if (b.has_child) {
         T acc[21], pacc[6];
         S.ld(b.slot_IA, acc);
         S.ld(b.slot_psi, pacc);
@@ -714,7 +801,7 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
     T D[6][6], u[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        u[i] = L.x[c.v_index + i] - psi[i];
+        u[i] = L.x(c.v_index + i) - psi[i];
 #pragma unroll
         for (int j = 0; j < 6; j++) D[i][j] = IA[sidx(i, j)];
     }
@@ -757,8 +844,8 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
         if (!loaded) {
 #pragma unroll
             for (int a = 0; a < N; a++) {
-                y[a] = L.q[c.q_index + a];
-                yd[a] = L.qd[c.v_index + a];
+                y[a] = L.y[a];
+                yd[a] = L.yd[a];
             }
             loaded = true;
         }
@@ -805,7 +892,7 @@ __device__ __forceinline__ void aba_acc_free(const Tables<T> &P, const Slots<T> 
     if (b.has_child) {
         T v[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
+        for (int j = 0; j < 6; j++) v[j] = L.qd(c.v_index + j);
         S.st(b.slot_v3, v);
         S.st(b.slot_a3, y0);
     }
@@ -820,7 +907,7 @@ __device__ __forceinline__ void aba_fwd_free(const Tables<T> &P, const Slots<T> 
     if (!b.has_child) return;
     T v[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) v[j] = L.qd[c.v_index + j];
+    for (int j = 0; j < 6; j++) v[j] = L.qd(c.v_index + j);
     S.st(b.slot_v, v);
 }
 
@@ -834,9 +921,9 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
     T y[N], yd[N], ydd[N];
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        y[a] = L.q[c.q_index + a];
-        yd[a] = L.qd[c.v_index + a];
-        ydd[a] = L.x[c.v_index + a];
+        y[a] = L.y[a];
+        yd[a] = L.yd[a];
+        ydd[a] = L.xx[a];
     }
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
@@ -888,8 +975,8 @@ __device__ __forceinline__ void rnea_fwd_free(const Tables<T> &P, const Slots<T>
     free_base_accel(P, c, L, a);
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        v[j] = L.qd[c.v_index + j];
-        a[j] += L.x[c.v_index + j];
+        v[j] = L.qd(c.v_index + j);
+        a[j] += L.x(c.v_index + j);
     }
     if (b.has_child) {
         S.st(b.slot_v, v);
@@ -958,7 +1045,7 @@ __device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T>
     }
 
 template <class T>
-__global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
+__global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                      const T *__restrict__ qd, const T *__restrict__ tau,
                                                      T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
 {
@@ -966,21 +1053,50 @@ __global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> DP, const T *__re
     const int lane = threadIdx.x;
     Slots<T> S;
     S.lane = lane;
-    S.glb = scratch + (size_t)blockIdx.x * (size_t)DP.n_glb_slots * kWave + lane;
+    // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
+    S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave + lane;
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t r = tile * kWave + lane;
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        stage_inputs(q, tile, rows_valid, P.nq, slab, lane);
+        stage_inputs(qd, tile, rows_valid, P.nv, slab + (size_t)P.nq * kWave, lane);
+        stage_inputs(tau, tile, rows_valid, P.nv, slab + (size_t)(P.nq + P.nv) * kWave, lane);
         Lane<T> L;
         L.active = r < B;
         const size_t rr = L.active ? r : B - 1;
-        L.q = q + rr * P.nq;
-        L.qd = qd + rr * P.nv;
-        L.x = tau + rr * P.nv;
+        L.in_q = slab + lane;
+        L.in_qd = slab + (size_t)P.nq * kWave + lane;
+        L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.out = ydd + rr * P.nv;
+        Carry<T> carry;
+#pragma unroll
+        for (int j = 0; j < 21; j++) carry.IA[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) carry.psi[j] = 0;
+        T ny[kMaxClusterDof], nyd[kMaxClusterDof], nxx[kMaxClusterDof];
+        {
+            const Step st0 = load_rec(P.steps + 0);
+            const ClusterRec c0 = load_rec(P.clusters + st0.cluster);
+            prefetch_inputs(L, c0, ny, nyd, nxx);
+        }
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
+#pragma unroll
+            for (int a = 0; a < kMaxClusterDof; a++) {
+                L.y[a] = ny[a];
+                L.yd[a] = nyd[a];
+                L.xx[a] = nxx[a];
+            }
+            if (s + 1 < P.n_steps) {
+                const Step st1 = load_rec(P.steps + (s + 1));
+                const ClusterRec c1 = load_rec(P.clusters + st1.cluster);
+                prefetch_inputs(L, c1, ny, nyd, nxx);
+            }
             if (st.op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
@@ -989,9 +1105,9 @@ __global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> DP, const T *__re
                 }
             } else if (st.op == OP_ABA_BWD) {
                 if (c.kind == CK_FREE) {
-                    aba_bwd_free(P, S, c, L);
+                    aba_bwd_free(P, S, c, L, carry);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (aba_bwd_static<T, N_>(P, S, c, L)))
+                    GRBDA_DISPATCH_N(c.n, (aba_bwd_static<T, N_>(P, S, c, L, carry)))
                 }
             } else {
                 if (c.kind == CK_FREE) {
@@ -1005,7 +1121,7 @@ __global__ __launch_bounds__(kWave) void aba_kernel(DevPlan<T> DP, const T *__re
 }
 
 template <class T>
-__global__ __launch_bounds__(kWave) void rnea_kernel(DevPlan<T> DP, const T *__restrict__ q,
+__global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                       const T *__restrict__ qd, const T *__restrict__ ydd,
                                                       T *__restrict__ tau, size_t B, T *__restrict__ scratch)
 {
@@ -1013,21 +1129,45 @@ __global__ __launch_bounds__(kWave) void rnea_kernel(DevPlan<T> DP, const T *__r
     const int lane = threadIdx.x;
     Slots<T> S;
     S.lane = lane;
-    S.glb = scratch + (size_t)blockIdx.x * (size_t)DP.n_glb_slots * kWave + lane;
+    // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
+    S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave + lane;
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t r = tile * kWave + lane;
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        stage_inputs(q, tile, rows_valid, P.nq, slab, lane);
+        stage_inputs(qd, tile, rows_valid, P.nv, slab + (size_t)P.nq * kWave, lane);
+        stage_inputs(ydd, tile, rows_valid, P.nv, slab + (size_t)(P.nq + P.nv) * kWave, lane);
         Lane<T> L;
         L.active = r < B;
         const size_t rr = L.active ? r : B - 1;
-        L.q = q + rr * P.nq;
-        L.qd = qd + rr * P.nv;
-        L.x = ydd + rr * P.nv;
+        L.in_q = slab + lane;
+        L.in_qd = slab + (size_t)P.nq * kWave + lane;
+        L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.out = tau + rr * P.nv;
+        T ny[kMaxClusterDof], nyd[kMaxClusterDof], nxx[kMaxClusterDof];
+        {
+            const Step st0 = load_rec(P.steps + 0);
+            const ClusterRec c0 = load_rec(P.clusters + st0.cluster);
+            prefetch_inputs(L, c0, ny, nyd, nxx);
+        }
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
+#pragma unroll
+            for (int a = 0; a < kMaxClusterDof; a++) {
+                L.y[a] = ny[a];
+                L.yd[a] = nyd[a];
+                L.xx[a] = nxx[a];
+            }
+            if (s + 1 < P.n_steps) {
+                const Step st1 = load_rec(P.steps + (s + 1));
+                const ClusterRec c1 = load_rec(P.clusters + st1.cluster);
+                prefetch_inputs(L, c1, ny, nyd, nxx);
+            }
             if (st.op == OP_RNEA_FWD) {
                 if (c.kind == CK_FREE) {
                     rnea_fwd_free(P, S, c, L);

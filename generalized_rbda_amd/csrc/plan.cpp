@@ -220,6 +220,24 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
         }
     }
 
+    // ---- register hand-over along chains ------------------------------------------------------------
+    // When every tree child of body p lies in ONE cluster c and the backward step of p's cluster
+    // directly follows the backward step of c, the projected inertia / bias of c never touches a
+    // slot: it stays in registers across the two steps (carry_out on c, carry_in on p).
+    for (int c = 0; c < nc; c++) {
+        const int p = clusters[c].parent_body;
+        if (p < 0) continue;
+        bool only = true;
+        for (int j = 0; j < nb; j++)
+            if (bodies[j].parent == p && m.bodies[j].cluster != c) only = false;
+        const int next = tB[c] + 1;
+        if (only && next < static_cast<int>(P.aba_steps.size()) && P.aba_steps[next].op == OP_ABA_BWD &&
+            P.aba_steps[next].cluster == m.bodies[p].cluster) {
+            clusters[c].carry_out = 1;
+            bodies[p].carry_in = 1;
+        }
+    }
+
     // ---- live ranges + interval allocation --------------------------------------------------------
     struct Obj {
         int *field;  // where the slot number goes (index into a flat array of fields)
@@ -288,8 +306,10 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
                     }
                 if (br.jtype != GRBDA_JOINT_FREE) objs.push_back({&br.slot_sc, 2, 0, tF[c], tB[c], -1});
                 objs.push_back({&br.slot_v, 6, 0, tF[c], tB[c], -1});
-                objs.push_back({&br.slot_psi, 6, 1, first_child_bwd, tB[c], -1});
-                objs.push_back({&br.slot_IA, 21, 2, first_child_bwd, tB[c], -1});
+                if (!br.carry_in) {
+                    objs.push_back({&br.slot_psi, 6, 1, first_child_bwd, tB[c], -1});
+                    objs.push_back({&br.slot_IA, 21, 2, first_child_bwd, tB[c], -1});
+                }
                 objs.push_back({&br.slot_v3, 6, 0, tA[c], last_child_acc, -1});
                 objs.push_back({&br.slot_a3, 6, 0, tA[c], last_child_acc, -1});
             }

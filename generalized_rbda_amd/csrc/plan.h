@@ -63,7 +63,9 @@ struct ClusterRec {
     int32_t parent_slot_psi;
     int32_t parent_slot_v3;   // acceleration-sweep velocity / acceleration of parent_body (or -1)
     int32_t parent_slot_a3;
-    int32_t reserved[2];
+    int32_t carry_out;        // 1: the contribution to parent_body is handed over in registers to the
+                              //    next step (= backward step of the parent cluster) instead of slots
+    int32_t reserved[1];
 };
 
 struct BodyRec {
@@ -88,7 +90,8 @@ struct BodyRec {
     int32_t parent_slot_a3;
     int32_t parent_slot_f;
     int32_t acc_first;        // 1: first contributor to the tree parent's backward accumulators
-    int32_t reserved[3];
+    int32_t carry_in;         // 1: backward accumulators arrive in registers (single child cluster, adjacent step)
+    int32_t reserved[2];
 };
 
 // number of constants per body before the G row
