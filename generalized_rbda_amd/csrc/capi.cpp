@@ -173,8 +173,11 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     if (int rc = ensure_scratch(p, device, stream, scratch_bytes, &scratch)) return rc;
     // LDS: the slot store, and at tile boundaries the staging area of the input transposition
     size_t lds_bytes = static_cast<size_t>(d.n_lds_slots) * kWave * sizeof(T);
-    const size_t stage_bytes = static_cast<size_t>(kWave) * static_cast<size_t>((d.nq > d.nv ? d.nq : d.nv) | 1) * sizeof(T);
-    if (lds_bytes < stage_bytes) lds_bytes = stage_bytes;
+    const size_t stage_one = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq > d.nv ? d.nq : d.nv) * sizeof(T);
+    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq + 2 * d.nv) * sizeof(T);
+    if (lds_bytes < stage_one) lds_bytes = stage_one;
+    if (lds_bytes < stage_all && stage_all <= static_cast<size_t>(p->lds_bytes_per_wave)) lds_bytes = stage_all;
+    d.lds_bytes = static_cast<int>(lds_bytes);
     hipError_t e;
     if (rnea)
         e = launch_rnea<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
@@ -251,6 +254,17 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     int rc = compile_plan(blob, bytes, p->lds_bytes_per_wave / (4 * kWave), p->lds_bytes_per_wave / (8 * kWave), p->host,
                           msg, sizeof msg);
     if (rc) return set_err(rc, msg);
+    // profiling aid (results are wrong when set): GRBDA_DEBUG_SWEEPS is a bit mask of the ABA sweeps to
+    // keep -- 1 forward, 2 backward, 4 acceleration -- so that the cost of each sweep can be ablated
+    const int sweeps = env_int("GRBDA_DEBUG_SWEEPS", 7);
+    if (sweeps != 7) {
+        std::vector<Step> kept;
+        for (const Step &st : p->host.aba_steps)
+            if ((st.op == OP_ABA_FWD && (sweeps & 1)) || (st.op == OP_ABA_BWD && (sweeps & 2)) ||
+                (st.op == OP_ABA_ACC && (sweeps & 4)))
+                kept.push_back(st);
+        p->host.aba_steps = kept;
+    }
     p->blob.assign(static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + bytes);
     p->waves_per_cu = env_int("GRBDA_WAVES_PER_CU", 8);
     if (p->waves_per_cu < 1) p->waves_per_cu = 1;

@@ -15,6 +15,7 @@ struct DevPlan {
     const T *consts;
     int nq, nv;
     int n_lds_slots, n_glb_slots;
+    int lds_bytes;  // dynamic LDS actually allocated per wave (slot store / input staging area)
     int ori_repr;
     T a_root[6];  // -gravity (ClusterTreeDynamics.cpp:147)
 };

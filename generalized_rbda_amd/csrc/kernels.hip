@@ -410,32 +410,66 @@ struct Lane {
 };
 
 // Tile prologue: the batch is row-major ([state][coordinate], the reference's natural vector
-// layout), so one wave's 64 states are ONE contiguous block of 64 * ncols scalars.  The wave reads
-// that block with fully coalesced loads, transposes it through LDS (which holds no live slot at
-// a tile boundary) and writes coordinate-major rows into its global slab.  Every later access to
-// an input is then a coalesced 64-element row instead of a 64-line strided gather.
+// layout), so one wave's 64 states are ONE contiguous block of 64 * ncols scalars.  The wave copies
+// that block straight into LDS with asynchronous global->LDS loads (no VGPR round trip, all copies
+// of a tile in flight together; LDS holds no live slot at a tile boundary), then reads it back
+// transposed and writes coordinate-major rows into its global slab.  Every later access to an
+// input is a coalesced 64-element row instead of a 64-line strided gather.
 template <class T>
-__device__ __forceinline__ void stage_inputs(const T *__restrict__ src, size_t tile, int rows_valid, int ncols,
-                                             T *slab_rows /* wave slab, NOT lane-offset */, int lane)
+__device__ __forceinline__ void stage_issue(const T *__restrict__ src, size_t tile, int rows_valid, int ncols,
+                                            unsigned lds_byte_off, int lane)
 {
-    T *stage = reinterpret_cast<T *>(grbda_smem);
-    const int pitch = ncols | 1;  // odd pitch: the transposed read is bank-conflict free
-    const T *blk = src + tile * (size_t)kWave * (size_t)ncols;
-    const int n_valid = rows_valid * ncols;
-    // element idx = it * 64 + lane of the block -> (row r, column j), advanced incrementally
-    int r = lane / ncols, j = lane - r * ncols;
-    const int dr = kWave / ncols, dj = kWave - dr * ncols;
-    for (int idx = lane; idx < kWave * ncols; idx += kWave) {
-        const int rc = r < rows_valid ? r : rows_valid - 1;  // ragged tail: replicate the last state
-        const T val = blk[idx < n_valid ? idx : rc * ncols + j];
-        stage[r * pitch + j] = val;
-        r += dr;
-        j += dj;
-        if (j >= ncols) { j -= ncols; r += 1; }
+    // copy as dwords: element type does not matter for a linear copy
+    const unsigned *blk = reinterpret_cast<const unsigned *>(src + tile * (size_t)kWave * (size_t)ncols);
+    const int n_dw = kWave * ncols * (int)(sizeof(T) / 4);
+    const int n_valid = rows_valid * ncols * (int)(sizeof(T) / 4);
+    for (int base = 0; base < n_dw; base += kWave) {
+        if (base + lane < n_valid)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + lane),
+                                             (__attribute__((address_space(3))) void *)(grbda_smem + lds_byte_off + (unsigned)base * 4u),
+                                             4, 0, 0);
     }
-    __syncthreads();
-    for (int c = 0; c < ncols; c++) slab_rows[(size_t)c * kWave + lane] = stage[lane * pitch + c];
-    __syncthreads();
+}
+template <class T>
+__device__ __forceinline__ void stage_transpose(int ncols, unsigned lds_byte_off, T *slab_rows, int lane)
+{
+    const T *stage = reinterpret_cast<const T *>(grbda_smem + lds_byte_off);
+    for (int c = 0; c < ncols; c++) slab_rows[(size_t)c * kWave + lane] = stage[lane * ncols + c];
+}
+template <class T>
+__device__ __forceinline__ void stage_inputs(const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ x,
+                                             size_t tile, int rows_valid, int nq, int nv, T *slab, int lane,
+                                             int lds_bytes)
+{
+    const unsigned bq = (unsigned)(kWave * nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * nv) * (unsigned)sizeof(T);
+    if ((int)(bq + 2 * bv) <= lds_bytes) {
+        stage_issue(q, tile, rows_valid, nq, 0u, lane);
+        stage_issue(qd, tile, rows_valid, nv, bq, lane);
+        stage_issue(x, tile, rows_valid, nv, bq + bv, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage_transpose(nq, 0u, slab, lane);
+        stage_transpose(nv, bq, slab + (size_t)nq * kWave, lane);
+        stage_transpose(nv, bq + bv, slab + (size_t)(nq + nv) * kWave, lane);
+        __syncthreads();
+    } else {
+        // LDS too small for the whole tile: one array at a time (capi.cpp guarantees each one fits)
+        stage_issue(q, tile, rows_valid, nq, 0u, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage_transpose(nq, 0u, slab, lane);
+        __syncthreads();
+        stage_issue(qd, tile, rows_valid, nv, 0u, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage_transpose(nv, 0u, slab + (size_t)nq * kWave, lane);
+        __syncthreads();
+        stage_issue(x, tile, rows_valid, nv, 0u, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage_transpose(nv, 0u, slab + (size_t)(nq + nv) * kWave, lane);
+        __syncthreads();
+    }
 }
 
 // register hand-over of a cluster's projected inertia / bias to the next backward step
@@ -1062,9 +1096,7 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
         const size_t r = tile * kWave + lane;
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
-        stage_inputs(q, tile, rows_valid, P.nq, slab, lane);
-        stage_inputs(qd, tile, rows_valid, P.nv, slab + (size_t)P.nq * kWave, lane);
-        stage_inputs(tau, tile, rows_valid, P.nv, slab + (size_t)(P.nq + P.nv) * kWave, lane);
+        stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
         Lane<T> L;
         L.active = r < B;
         const size_t rr = L.active ? r : B - 1;
@@ -1138,9 +1170,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         const size_t r = tile * kWave + lane;
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
-        stage_inputs(q, tile, rows_valid, P.nq, slab, lane);
-        stage_inputs(qd, tile, rows_valid, P.nv, slab + (size_t)P.nq * kWave, lane);
-        stage_inputs(ydd, tile, rows_valid, P.nv, slab + (size_t)(P.nq + P.nv) * kWave, lane);
+        stage_inputs(q, qd, ydd, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
         Lane<T> L;
         L.active = r < B;
         const size_t rr = L.active ? r : B - 1;
