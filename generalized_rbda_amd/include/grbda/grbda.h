@@ -1,0 +1,894 @@
+// grbda.h -- C++17 facade with the reference's class names over the MI355X engine.
+//
+// A user of ROAM-Lab-ND/generalized_rbda builds a model with
+//   model.registerBody(...); model.appendRegisteredBodiesAsCluster<ClusterJoints::RevoluteWithRotor<>>(...)
+//   model.setState(...); model.forwardDynamics(tau);
+// (include/grbda/Dynamics/ClusterTreeModel.h:24-165, TreeModel.h:15-143).  This header keeps those
+// names, argument meanings and error behaviour (std::runtime_error with the reference's messages) for
+// the forward / inverse dynamics path; the model is serialised to a model description
+// (ModelDescription.h) and every dynamics call goes through the C ABI (include/grbda_hip.h) to the
+// HIP kernels -- there is no CPU implementation behind this class.
+//
+// Eigen is not available on the target image, so the few value types the API needs
+// (Vec3 / Mat3 / Mat6 / SVec / DVec / DMat) are minimal stand-ins with Eigen-like accessors.
+//
+// Not carried over (out of the hot path): contact points, Jacobians, mass matrix,
+// EFPA, and LoopConstraint::GenericImplicit built from a CasADi lambda -- use
+// LoopConstraint::LoopPosition / LoopConstraint::TrigPolynomial, the data-driven equivalents.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/grbda_hip.h"
+#include "ModelDescription.h"
+
+namespace grbda {
+
+// ------------------------------------------------------------------------------------------------
+// value types (include/grbda/Utils/cppTypes.h:17-83)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int N>
+struct Vec : std::array<T, N> {
+    Vec() { this->fill(T(0)); }
+    Vec(std::initializer_list<T> l)
+    {
+        this->fill(T(0));
+        int i = 0;
+        for (const T &x : l)
+            if (i < N) (*this)[i++] = x;
+    }
+    T &operator()(int i) { return (*this)[i]; }
+    const T &operator()(int i) const { return (*this)[i]; }
+    static Vec Zero() { return Vec(); }
+    static Vec Random()
+    {
+        Vec v;
+        for (auto &x : v) x = T(2.0 * std::rand() / RAND_MAX - 1.0);
+        return v;
+    }
+};
+template <typename T> using Vec1 = Vec<T, 1>;
+template <typename T> using Vec2 = Vec<T, 2>;
+template <typename T> using Vec3 = Vec<T, 3>;
+template <typename T> using Quat = Vec<T, 4>;
+template <typename T> using SVec = Vec<T, 6>;
+
+template <typename T, int R, int C>
+struct Mat {
+    std::array<T, R * C> d{};  // row-major
+    T &operator()(int i, int j) { return d[i * C + j]; }
+    const T &operator()(int i, int j) const { return d[i * C + j]; }
+    static Mat Zero() { return Mat(); }
+    static Mat Identity()
+    {
+        Mat m;
+        for (int i = 0; i < (R < C ? R : C); i++) m(i, i) = T(1);
+        return m;
+    }
+    Mat<T, C, R> transpose() const
+    {
+        Mat<T, C, R> t;
+        for (int i = 0; i < R; i++)
+            for (int j = 0; j < C; j++) t(j, i) = (*this)(i, j);
+        return t;
+    }
+    template <int K>
+    Mat<T, R, K> operator*(const Mat<T, C, K> &o) const
+    {
+        Mat<T, R, K> m;
+        for (int i = 0; i < R; i++)
+            for (int j = 0; j < K; j++) {
+                T s = 0;
+                for (int k = 0; k < C; k++) s += (*this)(i, k) * o(k, j);
+                m(i, j) = s;
+            }
+        return m;
+    }
+    Mat operator+(const Mat &o) const { Mat m; for (size_t i = 0; i < d.size(); i++) m.d[i] = d[i] + o.d[i]; return m; }
+    Mat operator*(T s) const { Mat m; for (size_t i = 0; i < d.size(); i++) m.d[i] = d[i] * s; return m; }
+};
+template <typename T> using Mat3 = Mat<T, 3, 3>;
+template <typename T> using Mat6 = Mat<T, 6, 6>;
+template <typename T> using RotMat = Mat3<T>;
+
+template <typename T>
+struct DVec : std::vector<T> {
+    using std::vector<T>::vector;
+    DVec() = default;
+    DVec(const std::vector<T> &v) : std::vector<T>(v) {}
+    T &operator()(int i) { return (*this)[i]; }
+    const T &operator()(int i) const { return (*this)[i]; }
+    int rows() const { return static_cast<int>(this->size()); }
+    DVec segment(int i, int n) const { return DVec(this->begin() + i, this->begin() + i + n); }
+    static DVec Zero(int n) { return DVec(static_cast<size_t>(n), T(0)); }
+    static DVec Random(int n)
+    {
+        DVec v(static_cast<size_t>(n));
+        for (auto &x : v) x = T(2.0 * std::rand() / RAND_MAX - 1.0);
+        return v;
+    }
+    DVec operator-(const DVec &o) const { DVec r(*this); for (size_t i = 0; i < r.size(); i++) r[i] -= o[i]; return r; }
+    DVec operator+(const DVec &o) const { DVec r(*this); for (size_t i = 0; i < r.size(); i++) r[i] += o[i]; return r; }
+    T norm() const { T s = 0; for (const T &x : *this) s += x * x; return std::sqrt(s); }
+};
+
+template <typename T>
+struct DMat {
+    int r = 0, c = 0;
+    std::vector<T> d;  // row-major
+    DMat() = default;
+    DMat(int rows, int cols) : r(rows), c(cols), d(static_cast<size_t>(rows) * cols, T(0)) {}
+    int rows() const { return r; }
+    int cols() const { return c; }
+    T &operator()(int i, int j) { return d[static_cast<size_t>(i) * c + j]; }
+    const T &operator()(int i, int j) const { return d[static_cast<size_t>(i) * c + j]; }
+    static DMat Zero(int rows, int cols) { return DMat(rows, cols); }
+    static DMat Identity(int rows, int cols)
+    {
+        DMat m(rows, cols);
+        for (int i = 0; i < (rows < cols ? rows : cols); i++) m(i, i) = T(1);
+        return m;
+    }
+    DMat operator*(const DMat &o) const
+    {
+        DMat m(r, o.c);
+        for (int i = 0; i < r; i++)
+            for (int j = 0; j < o.c; j++) {
+                T s = 0;
+                for (int k = 0; k < c; k++) s += (*this)(i, k) * o(k, j);
+                m(i, j) = s;
+            }
+        return m;
+    }
+    T maxAbs() const { T s = 0; for (const T &x : d) s = std::fabs(x) > s ? std::fabs(x) : s; return s; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// ori:: (include/grbda/Utils/OrientationTools.h)
+// ------------------------------------------------------------------------------------------------
+namespace ori {
+enum class CoordinateAxis { X, Y, Z };
+
+template <typename T>
+Mat3<T> vectorToSkewMat(const Vec3<T> &v)
+{
+    Mat3<T> m;
+    m(0, 1) = -v[2]; m(0, 2) = v[1]; m(1, 0) = v[2]; m(1, 2) = -v[0]; m(2, 0) = -v[1]; m(2, 1) = v[0];
+    return m;
+}
+// OrientationTools.h:46-68
+template <typename T>
+Mat3<T> coordinateRotation(CoordinateAxis axis, T theta)
+{
+    const T s = std::sin(theta), c = std::cos(theta);
+    Mat3<T> R = Mat3<T>::Identity();
+    if (axis == CoordinateAxis::X) { R(1, 1) = c; R(1, 2) = s; R(2, 1) = -s; R(2, 2) = c; }
+    else if (axis == CoordinateAxis::Y) { R(0, 0) = c; R(0, 2) = -s; R(2, 0) = s; R(2, 2) = c; }
+    else { R(0, 0) = c; R(0, 1) = s; R(1, 0) = -s; R(1, 1) = c; }
+    return R;
+}
+// OrientationTools.h:121-130
+template <typename T>
+Mat3<T> rpyToRotMat(const Vec3<T> &v)
+{
+    return coordinateRotation(CoordinateAxis::X, v[0]) * coordinateRotation(CoordinateAxis::Y, v[1]) *
+           coordinateRotation(CoordinateAxis::Z, v[2]);
+}
+// OrientationTools.h:251-269 (scalar first, transposed)
+template <typename T>
+Mat3<T> quaternionToRotationMatrix(const Quat<T> &q)
+{
+    const T e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3];
+    Mat3<T> R;
+    R(0, 0) = 1 - 2 * (e2 * e2 + e3 * e3); R(0, 1) = 2 * (e1 * e2 - e0 * e3);     R(0, 2) = 2 * (e1 * e3 + e0 * e2);
+    R(1, 0) = 2 * (e1 * e2 + e0 * e3);     R(1, 1) = 1 - 2 * (e1 * e1 + e3 * e3); R(1, 2) = 2 * (e2 * e3 - e0 * e1);
+    R(2, 0) = 2 * (e1 * e3 - e0 * e2);     R(2, 1) = 2 * (e2 * e3 + e0 * e1);     R(2, 2) = 1 - 2 * (e1 * e1 + e2 * e2);
+    return R.transpose();
+}
+// OrientationTools.h:160-200
+template <typename T>
+Quat<T> rotationMatrixToQuaternion(const Mat3<T> &r1)
+{
+    Quat<T> q;
+    const Mat3<T> r = r1.transpose();
+    const T tr = r(0, 0) + r(1, 1) + r(2, 2);
+    if (tr > 0.0) {
+        const T S = std::sqrt(tr + 1.0) * 2.0;
+        q[0] = 0.25 * S; q[1] = (r(2, 1) - r(1, 2)) / S; q[2] = (r(0, 2) - r(2, 0)) / S; q[3] = (r(1, 0) - r(0, 1)) / S;
+    } else if (r(0, 0) > r(1, 1) && r(0, 0) > r(2, 2)) {
+        const T S = std::sqrt(1.0 + r(0, 0) - r(1, 1) - r(2, 2)) * 2.0;
+        q[0] = (r(2, 1) - r(1, 2)) / S; q[1] = 0.25 * S; q[2] = (r(0, 1) + r(1, 0)) / S; q[3] = (r(0, 2) + r(2, 0)) / S;
+    } else if (r(1, 1) > r(2, 2)) {
+        const T S = std::sqrt(1.0 + r(1, 1) - r(0, 0) - r(2, 2)) * 2.0;
+        q[0] = (r(0, 2) - r(2, 0)) / S; q[1] = (r(0, 1) + r(1, 0)) / S; q[2] = 0.25 * S; q[3] = (r(1, 2) + r(2, 1)) / S;
+    } else {
+        const T S = std::sqrt(1.0 + r(2, 2) - r(0, 0) - r(1, 1)) * 2.0;
+        q[0] = (r(1, 0) - r(0, 1)) / S; q[1] = (r(0, 2) + r(2, 0)) / S; q[2] = (r(1, 2) + r(2, 1)) / S; q[3] = 0.25 * S;
+    }
+    return q;
+}
+template <typename T>
+Quat<T> rpyToQuat(const Vec3<T> &rpy) { return rotationMatrixToQuaternion(rpyToRotMat(rpy)); }
+}  // namespace ori
+
+// OrientationRepresentation.h:11-49
+namespace ori_representation {
+struct Quaternion {
+    static const int num_ori_parameter = 4;
+    static constexpr int desc_id = GRBDA_ORI_QUATERNION;
+};
+struct RollPitchYaw {
+    static const int num_ori_parameter = 3;
+    static constexpr int desc_id = GRBDA_ORI_RPY;
+};
+}  // namespace ori_representation
+
+// ------------------------------------------------------------------------------------------------
+// spatial::Transform (include/grbda/Utils/SpatialTransforms.h:13-60), SpatialInertia (SpatialInertia.h:74-116)
+// ------------------------------------------------------------------------------------------------
+namespace spatial {
+template <typename Scalar = double>
+class Transform {
+public:
+    Transform(const Mat3<Scalar> &E = Mat3<Scalar>::Identity(), const Vec3<Scalar> &r = Vec3<Scalar>::Zero()) : E_(E), r_(r) {}
+    const Mat3<Scalar> &getRotation() const { return E_; }
+    const Vec3<Scalar> &getTranslation() const { return r_; }
+    // SpatialTransforms.cpp:149-157: E = E1 E2, r = r2 + E2^T r1
+    Transform operator*(const Transform &X_in) const
+    {
+        const Mat3<Scalar> E = E_ * X_in.E_;
+        Vec3<Scalar> r = X_in.r_;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) r[i] += X_in.E_(j, i) * r_[j];
+        return Transform(E, r);
+    }
+private:
+    Mat3<Scalar> E_;
+    Vec3<Scalar> r_;
+};
+}  // namespace spatial
+
+template <typename T>
+class SpatialInertia {
+public:
+    SpatialInertia() = default;
+    SpatialInertia(T mass, const Vec3<T> &com, const Mat3<T> &inertia)
+    {
+        const Mat3<T> c = ori::vectorToSkewMat(com);
+        const Mat3<T> cct = c * c.transpose();
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                I_(i, j) = inertia(i, j) + mass * cct(i, j);
+                I_(i, j + 3) = mass * c(i, j);
+                I_(i + 3, j) = mass * c(j, i);
+                I_(i + 3, j + 3) = i == j ? mass : T(0);
+            }
+    }
+    explicit SpatialInertia(const Mat6<T> &inertia) : I_(inertia) {}
+    const Mat6<T> &getMatrix() const { return I_; }
+private:
+    Mat6<T> I_;
+};
+
+// Body (include/grbda/Dynamics/Body.h:16-43)
+template <typename Scalar = double>
+struct Body {
+    int index_ = -1;
+    std::string name_;
+    int parent_index_ = -1;
+    spatial::Transform<Scalar> Xtree_;
+    SpatialInertia<Scalar> inertia_;
+    int sub_index_within_cluster_ = 0;
+    int cluster_ancestor_index_ = -1;
+    int cluster_ancestor_sub_index_within_cluster_ = 0;
+};
+
+// StateRepresentation.h:9-80
+template <typename Scalar = double>
+class JointCoordinate : public DVec<Scalar> {
+public:
+    JointCoordinate() = default;
+    JointCoordinate(const DVec<Scalar> &vec, bool is_spanning) : DVec<Scalar>(vec), is_spanning_(is_spanning) {}
+    bool isSpanning() const { return is_spanning_; }
+private:
+    bool is_spanning_ = false;
+};
+template <typename Scalar = double>
+struct JointState {
+    JointState() = default;
+    JointState(const JointCoordinate<Scalar> &pos, const JointCoordinate<Scalar> &vel) : position(pos), velocity(vel) {}
+    JointCoordinate<Scalar> position, velocity;
+};
+template <typename Scalar = double> using ModelState = std::vector<JointState<Scalar>>;
+template <typename Scalar = double>
+struct ExternalForceAndBodyIndexPair {
+    ExternalForceAndBodyIndexPair(int index, const SVec<Scalar> &force) : index_(index), force_(force) {}
+    int index_;
+    SVec<Scalar> force_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// loop constraints (include/grbda/Dynamics/ClusterJoints/LoopConstraint.h:14-59)
+// ------------------------------------------------------------------------------------------------
+namespace LoopConstraint {
+template <typename Scalar = double>
+struct Base {
+    virtual ~Base() {}
+    int kind = GRBDA_CONSTRAINT_STATIC;
+    DMat<Scalar> G_, K_;
+    std::vector<int32_t> ints;
+    std::vector<double> dbls;
+    std::vector<bool> independent;
+    int rows = 0;
+    const DMat<Scalar> &G() const { return G_; }
+    const DMat<Scalar> &K() const { return K_; }
+    bool isExplicit() const { return kind == GRBDA_CONSTRAINT_STATIC || kind == GRBDA_CONSTRAINT_FREE; }
+};
+// LoopConstraint.cpp:38-52
+template <typename Scalar = double>
+struct Static : Base<Scalar> {
+    Static(const DMat<Scalar> &G, const DMat<Scalar> &K)
+    {
+        this->kind = GRBDA_CONSTRAINT_STATIC;
+        this->G_ = G;
+        this->K_ = K;
+        this->rows = K.rows();
+    }
+};
+template <typename Scalar = double>
+struct Free : Base<Scalar> {
+    Free() { this->kind = GRBDA_CONSTRAINT_FREE; }
+};
+// data-driven replacement of GenericImplicit for URDF+ <loop> constraints
+// (ClusterTreeParsing.cpp:310-376); see include/grbda_model_desc.h for the payload
+template <typename Scalar = double>
+struct LoopPosition : Base<Scalar> {
+    struct Loop {
+        std::vector<int> nca_to_predecessor, nca_to_successor;  // sub-indices within the cluster
+        spatial::Transform<Scalar> predecessor_origin, successor_origin;
+        int axis_mask = 7;
+    };
+    LoopPosition(const std::vector<bool> &is_coordinate_independent, const std::vector<Loop> &loops)
+    {
+        this->kind = GRBDA_CONSTRAINT_LOOP_POSITION;
+        this->independent = is_coordinate_independent;
+        this->ints.push_back(static_cast<int32_t>(loops.size()));
+        for (bool b : is_coordinate_independent) this->ints.push_back(b ? 1 : 0);
+        for (const Loop &l : loops) {
+            this->ints.push_back(static_cast<int32_t>(l.nca_to_predecessor.size()));
+            for (int s : l.nca_to_predecessor) this->ints.push_back(s);
+            this->ints.push_back(static_cast<int32_t>(l.nca_to_successor.size()));
+            for (int s : l.nca_to_successor) this->ints.push_back(s);
+            this->ints.push_back(l.axis_mask);
+            for (const auto *X : {&l.predecessor_origin, &l.successor_origin}) {
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) this->dbls.push_back(static_cast<double>(X->getRotation()(i, j)));
+                for (int i = 0; i < 3; i++) this->dbls.push_back(static_cast<double>(X->getTranslation()[i]));
+            }
+            for (int a = 0; a < 3; a++) this->rows += (l.axis_mask >> a) & 1;
+        }
+    }
+};
+// data-driven replacement of GenericImplicit for hand-written trig-polynomial phi lambdas
+// (src/Robots/Tello.cpp:139-163,237-261)
+template <typename Scalar = double>
+struct TrigPolynomial : Base<Scalar> {
+    enum Fn { Linear = 0, Sin = 1, Cos = 2 };
+    struct Factor { Fn fn; std::vector<double> w; double b; };
+    struct Term { double coef; std::vector<Factor> factors; };
+    TrigPolynomial(const std::vector<bool> &is_coordinate_independent, const std::vector<std::vector<Term>> &phi_rows)
+    {
+        this->kind = GRBDA_CONSTRAINT_TRIG_POLY;
+        this->independent = is_coordinate_independent;
+        for (bool b : is_coordinate_independent) this->ints.push_back(b ? 1 : 0);
+        for (const auto &row : phi_rows) {
+            this->ints.push_back(static_cast<int32_t>(row.size()));
+            for (const Term &t : row) {
+                this->ints.push_back(static_cast<int32_t>(t.factors.size()));
+                this->dbls.push_back(t.coef);
+                for (const Factor &f : t.factors) {
+                    this->ints.push_back(static_cast<int32_t>(f.fn));
+                    for (double w : f.w) this->dbls.push_back(w);
+                    this->dbls.push_back(f.b);
+                }
+            }
+        }
+        this->rows = static_cast<int>(phi_rows.size());
+    }
+};
+}  // namespace LoopConstraint
+
+// single joints (include/grbda/Dynamics/Joints/Joint.h:43-102)
+namespace Joints {
+template <typename Scalar = double>
+struct Base {
+    virtual ~Base() {}
+    int type = GRBDA_JOINT_REVOLUTE;
+    ori::CoordinateAxis axis = ori::CoordinateAxis::Z;
+    std::string name;
+};
+template <typename Scalar = double>
+struct Revolute : Base<Scalar> {
+    Revolute(ori::CoordinateAxis a, std::string n = "unnamed_revolute_joint") { this->type = GRBDA_JOINT_REVOLUTE; this->axis = a; this->name = n; }
+};
+template <typename Scalar = double, typename Ori = ori_representation::Quaternion>
+struct Free : Base<Scalar> {
+    Free(std::string n = "unnamed_free_joint") { this->type = GRBDA_JOINT_FREE; this->name = n; }
+};
+}  // namespace Joints
+template <typename Scalar> using JointPtr = std::shared_ptr<Joints::Base<Scalar>>;
+
+// ------------------------------------------------------------------------------------------------
+// cluster joints (include/grbda/Dynamics/ClusterJoints/*.h, Transmissions.h:11-43)
+// ------------------------------------------------------------------------------------------------
+namespace ClusterJoints {
+template <typename Scalar = double>
+struct GearedTransmissionModule {
+    Body<Scalar> body_, rotor_;
+    std::string body_joint_name_, rotor_joint_name_;
+    ori::CoordinateAxis joint_axis_, rotor_axis_;
+    Scalar gear_ratio_;
+};
+template <size_t N_belts, typename Scalar = double>
+struct ParallelBeltTransmissionModule {
+    Body<Scalar> body_, rotor_;
+    ori::CoordinateAxis joint_axis_, rotor_axis_;
+    Scalar gear_ratio_;
+    Vec<Scalar, static_cast<int>(N_belts)> belt_ratios_;
+};
+// Transmissions.h:34-43
+template <typename Scalar, int N>
+Vec<Scalar, N> beltMatrixRowFromBeltRatios(Vec<Scalar, N> ratios)
+{
+    for (int i = 1; i < N; i++) ratios[i] = ratios[i - 1] * ratios[i];
+    return ratios;
+}
+
+template <typename Scalar = double>
+class Base {
+public:
+    virtual ~Base() {}
+    int numBodies() const { return num_bodies_; }
+    int numPositions() const { return num_positions_; }
+    int numVelocities() const { return num_velocities_; }
+    const DMat<Scalar> &G() const { return loop_constraint_->G(); }
+    const DMat<Scalar> &K() const { return loop_constraint_->K(); }
+    std::shared_ptr<LoopConstraint::Base<Scalar>> cloneLoopConstraint() const { return loop_constraint_; }
+    const std::vector<JointPtr<Scalar>> &singleJoints() const { return single_joints_; }
+    // ClusterJoint.cpp:73-80
+    JointState<double> randomJointState() const
+    {
+        return JointState<double>(JointCoordinate<double>(DVec<double>::Random(num_positions_), false),
+                                  JointCoordinate<double>(DVec<double>::Random(num_velocities_), false));
+    }
+    // single joints in sub-index order (body i of the cluster <-> ordered_joints()[i])
+    std::vector<JointPtr<Scalar>> ordered_joints_;
+protected:
+    Base(int nb, int np, int nv) : num_bodies_(nb), num_positions_(np), num_velocities_(nv) {}
+    int num_bodies_, num_positions_, num_velocities_;
+    std::vector<JointPtr<Scalar>> single_joints_;
+    std::shared_ptr<LoopConstraint::Base<Scalar>> loop_constraint_;
+};
+
+// FreeJoint.cpp:10-26
+template <typename Scalar = double, typename Ori = ori_representation::Quaternion>
+class Free : public Base<Scalar> {
+public:
+    Free(const Body<Scalar> &body, std::string name = "free") : Base<Scalar>(1, Ori::num_ori_parameter + 3, 6)
+    {
+        if (body.parent_index_ >= 0)
+            throw std::runtime_error("Free joint is only valid as the first joint in a tree and thus cannot have a parent body");
+        this->single_joints_.emplace_back(new Joints::Free<Scalar, Ori>(name));
+        this->ordered_joints_ = this->single_joints_;
+        this->loop_constraint_ = std::make_shared<LoopConstraint::Free<Scalar>>();
+    }
+};
+// RevoluteJoint.cpp:9-23
+template <typename Scalar = double>
+class Revolute : public Base<Scalar> {
+public:
+    Revolute(const Body<Scalar> &, ori::CoordinateAxis joint_axis, std::string name = "revolute") : Base<Scalar>(1, 1, 1)
+    {
+        this->single_joints_.emplace_back(new Joints::Revolute<Scalar>(joint_axis, name));
+        this->ordered_joints_ = this->single_joints_;
+        this->loop_constraint_ = std::make_shared<LoopConstraint::Static<Scalar>>(DMat<Scalar>::Identity(1, 1), DMat<Scalar>::Zero(0, 1));
+    }
+};
+// RevoluteWithRotorJoint.cpp:9-31: bodies [link, rotor], G = [1; N], K = [N, -1]
+template <typename Scalar = double>
+class RevoluteWithRotor : public Base<Scalar> {
+public:
+    RevoluteWithRotor(GearedTransmissionModule<Scalar> &module) : Base<Scalar>(2, 1, 1)
+    {
+        this->single_joints_.emplace_back(new Joints::Revolute<Scalar>(module.joint_axis_, module.body_joint_name_));
+        this->single_joints_.emplace_back(new Joints::Revolute<Scalar>(module.rotor_axis_, module.rotor_joint_name_));
+        this->ordered_joints_ = this->single_joints_;
+        DMat<Scalar> G(2, 1), K(1, 2);
+        G(0, 0) = 1; G(1, 0) = module.gear_ratio_;
+        K(0, 0) = module.gear_ratio_; K(0, 1) = -1;
+        this->loop_constraint_ = std::make_shared<LoopConstraint::Static<Scalar>>(G, K);
+    }
+};
+// RevolutePairJoint.cpp: two links in series, no constraint rows (G = identity)
+template <typename Scalar = double>
+class RevolutePair : public Base<Scalar> {
+public:
+    RevolutePair(Body<Scalar> &, Body<Scalar> &, ori::CoordinateAxis a1, ori::CoordinateAxis a2) : Base<Scalar>(2, 2, 2)
+    {
+        this->single_joints_.emplace_back(new Joints::Revolute<Scalar>(a1));
+        this->single_joints_.emplace_back(new Joints::Revolute<Scalar>(a2));
+        this->ordered_joints_ = this->single_joints_;
+        this->loop_constraint_ = std::make_shared<LoopConstraint::Static<Scalar>>(DMat<Scalar>::Identity(2, 2), DMat<Scalar>::Zero(0, 2));
+    }
+};
+// RevolutePairWithRotorJoint.cpp:10-69
+template <typename Scalar = double>
+class RevolutePairWithRotor : public Base<Scalar> {
+public:
+    using ProximalTransmission = ParallelBeltTransmissionModule<1, Scalar>;
+    using DistalTransmission = ParallelBeltTransmissionModule<2, Scalar>;
+    RevolutePairWithRotor(ProximalTransmission &m1, DistalTransmission &m2) : Base<Scalar>(4, 2, 2)
+    {
+        const int l1 = m1.body_.sub_index_within_cluster_, l2 = m2.body_.sub_index_within_cluster_;
+        const int r1 = m1.rotor_.sub_index_within_cluster_, r2 = m2.rotor_.sub_index_within_cluster_;
+        this->ordered_joints_.resize(4);
+        this->ordered_joints_[l1] = std::make_shared<Joints::Revolute<Scalar>>(m1.joint_axis_);
+        this->ordered_joints_[r1] = std::make_shared<Joints::Revolute<Scalar>>(m1.rotor_axis_);
+        this->ordered_joints_[r2] = std::make_shared<Joints::Revolute<Scalar>>(m2.rotor_axis_);
+        this->ordered_joints_[l2] = std::make_shared<Joints::Revolute<Scalar>>(m2.joint_axis_);
+        this->single_joints_ = this->ordered_joints_;
+        const auto b1 = beltMatrixRowFromBeltRatios(m1.belt_ratios_);
+        const auto b2 = beltMatrixRowFromBeltRatios(m2.belt_ratios_);
+        const Scalar rp00 = m1.gear_ratio_ * b1[0], rp10 = m2.gear_ratio_ * b2[0], rp11 = m2.gear_ratio_ * b2[1];
+        DMat<Scalar> G(4, 2), K(2, 4);
+        G(l1, 0) = 1; G(r1, 0) = rp00; G(r2, 0) = rp10; G(r2, 1) = rp11; G(l2, 1) = 1;
+        const int c1 = r1 > r2, c2 = r2 > r1;
+        K(c1, r1) = -1; K(c1, l1) = G(r1, 0);
+        K(c2, r2) = -1; K(c2, l1) = G(r2, 0); K(c2, l2) = G(r2, 1);
+        this->loop_constraint_ = std::make_shared<LoopConstraint::Static<Scalar>>(G, K);
+    }
+};
+// RevoluteTripleWithRotorJoint.cpp:10-60: bodies [link1, link2, link3, rotor1, rotor2, rotor3]
+template <typename Scalar = double>
+class RevoluteTripleWithRotor : public Base<Scalar> {
+public:
+    using ProximalTransmission = ParallelBeltTransmissionModule<1, Scalar>;
+    using IntermediateTransmission = ParallelBeltTransmissionModule<2, Scalar>;
+    using DistalTransmission = ParallelBeltTransmissionModule<3, Scalar>;
+    RevoluteTripleWithRotor(const ProximalTransmission &m1, const IntermediateTransmission &m2, const DistalTransmission &m3)
+        : Base<Scalar>(6, 3, 3)
+    {
+        for (auto ax : {m1.joint_axis_, m2.joint_axis_, m3.joint_axis_}) this->single_joints_.emplace_back(new Joints::Revolute<Scalar>(ax));
+        for (auto ax : {m1.rotor_axis_, m2.rotor_axis_, m3.rotor_axis_}) this->single_joints_.emplace_back(new Joints::Revolute<Scalar>(ax));
+        this->ordered_joints_ = this->single_joints_;
+        const auto b1 = beltMatrixRowFromBeltRatios(m1.belt_ratios_);
+        const auto b2 = beltMatrixRowFromBeltRatios(m2.belt_ratios_);
+        const auto b3 = beltMatrixRowFromBeltRatios(m3.belt_ratios_);
+        DMat<Scalar> G(6, 3), K(3, 6);
+        for (int i = 0; i < 3; i++) G(i, i) = 1;
+        G(3, 0) = m1.gear_ratio_ * b1[0];
+        G(4, 0) = m2.gear_ratio_ * b2[0]; G(4, 1) = m2.gear_ratio_ * b2[1];
+        G(5, 0) = m3.gear_ratio_ * b3[0]; G(5, 1) = m3.gear_ratio_ * b3[1]; G(5, 2) = m3.gear_ratio_ * b3[2];
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) K(i, j) = -G(3 + i, j);
+            K(i, 3 + i) = 1;
+        }
+        this->loop_constraint_ = std::make_shared<LoopConstraint::Static<Scalar>>(G, K);
+    }
+};
+// GenericJoint.cpp:243-287
+template <typename Scalar = double>
+class Generic : public Base<Scalar> {
+public:
+    Generic(const std::vector<Body<Scalar>> &bodies, const std::vector<JointPtr<Scalar>> &joints,
+            std::shared_ptr<LoopConstraint::Base<Scalar>> loop_constraint)
+        : Base<Scalar>(static_cast<int>(bodies.size()), 0, 0)
+    {
+        if (bodies.size() != joints.size()) throw std::runtime_error("Generic cluster: one joint per body is required");
+        this->single_joints_ = joints;
+        this->ordered_joints_ = joints;
+        this->loop_constraint_ = loop_constraint;
+        const int k = static_cast<int>(bodies.size());
+        if (loop_constraint->isExplicit()) {
+            this->num_positions_ = this->num_velocities_ = loop_constraint->G().cols();
+        } else {
+            int n_ind = 0;
+            for (bool b : loop_constraint->independent) n_ind += b ? 1 : 0;
+            this->num_positions_ = k;  // spanning positions (GenericJoint.cpp:246-249)
+            this->num_velocities_ = n_ind;
+        }
+    }
+};
+}  // namespace ClusterJoints
+
+// ------------------------------------------------------------------------------------------------
+// TreeModel / ClusterTreeModel (TreeModel.h:15-143, ClusterTreeModel.h:24-165)
+// ------------------------------------------------------------------------------------------------
+template <typename Scalar = double>
+struct ClusterTreeNode {
+    int index_ = 0;
+    std::string name_;
+    std::vector<Body<Scalar>> bodies_;
+    std::shared_ptr<ClusterJoints::Base<Scalar>> joint_;
+    int parent_index_ = -1;
+    int position_index_ = 0, num_positions_ = 0, velocity_index_ = 0, num_velocities_ = 0;
+    JointState<Scalar> joint_state_;
+};
+template <typename Scalar> using ClusterTreeNodePtr = std::shared_ptr<ClusterTreeNode<Scalar>>;
+
+template <typename Scalar = double>
+class TreeModel {
+public:
+    TreeModel() { gravity_[5] = Scalar(-9.81); }
+    virtual ~TreeModel() {}
+    const int &getNumPositions() const { return position_index_; }
+    const int &getNumDegreesOfFreedom() const { return velocity_index_; }
+    void setGravity(const Vec3<Scalar> &g) { for (int i = 0; i < 3; i++) gravity_[3 + i] = g[i]; plan_dirty_ = true; }
+    SVec<Scalar> getGravity() const { return gravity_; }
+    virtual DVec<Scalar> forwardDynamics(const DVec<Scalar> &tau) = 0;
+    virtual DVec<Scalar> inverseDynamics(const DVec<Scalar> &qdd) = 0;
+protected:
+    SVec<Scalar> gravity_;
+    int position_index_ = 0, velocity_index_ = 0;
+    bool plan_dirty_ = true;
+};
+
+template <typename Scalar = double, typename OriTpl = ori_representation::Quaternion>
+class ClusterTreeModel : public TreeModel<Scalar> {
+public:
+    ClusterTreeModel() { body_name_to_body_index_["ground"] = -1; }
+    explicit ClusterTreeModel(const std::string &urdf_filename) : ClusterTreeModel() { buildModelFromURDF(urdf_filename); }
+    ~ClusterTreeModel() { if (plan_) grbda_plan_free(plan_); }
+    ClusterTreeModel(const ClusterTreeModel &) = delete;
+    ClusterTreeModel &operator=(const ClusterTreeModel &) = delete;
+
+    // ---- construction -------------------------------------------------------------------------
+    void buildModelFromURDF(const std::string &urdf_filename) { buildModelFromURDF(std::vector<std::string>{urdf_filename}); }
+    void buildModelFromURDF(const std::vector<std::string> &urdf_filenames)
+    {
+        std::vector<const char *> paths;
+        for (const auto &s : urdf_filenames) paths.push_back(s.c_str());
+        size_t need = 0;
+        check(grbda_urdf_to_blob(paths.data(), static_cast<int>(paths.size()), OriTpl::desc_id, nullptr, 0, &need));
+        urdf_blob_.resize(need);
+        check(grbda_urdf_to_blob(paths.data(), static_cast<int>(paths.size()), OriTpl::desc_id, urdf_blob_.data(), need, &need));
+        from_urdf_ = true;
+        const auto *h = reinterpret_cast<const grbda_desc_header *>(urdf_blob_.data());
+        this->position_index_ = h->nq;
+        this->velocity_index_ = h->nv;
+        n_bodies_urdf_ = h->n_bodies;
+        this->plan_dirty_ = true;
+    }
+
+    // ClusterTreeModel.cpp:10-32
+    Body<Scalar> registerBody(const std::string name, const SpatialInertia<Scalar> inertia, const std::string parent_name,
+                              const spatial::Transform<Scalar> Xtree)
+    {
+        if (body_name_to_body_index_.count(name)) throw std::runtime_error("Body " + name + " is already registered");
+        auto it = body_name_to_body_index_.find(parent_name);
+        if (it == body_name_to_body_index_.end()) throw std::out_of_range("map::at");  // the reference uses map::at
+        Body<Scalar> b;
+        b.index_ = static_cast<int>(bodies_.size());
+        b.name_ = name;
+        b.parent_index_ = it->second;
+        b.Xtree_ = Xtree;
+        b.inertia_ = inertia;
+        b.sub_index_within_cluster_ = static_cast<int>(bodies_in_current_cluster_.size());
+        int anc = b.parent_index_;
+        const int first = bodies_in_current_cluster_.empty() ? b.index_ : bodies_in_current_cluster_.front().index_;
+        while (anc >= first) anc = bodies_[anc].parent_index_;
+        b.cluster_ancestor_index_ = anc;
+        b.cluster_ancestor_sub_index_within_cluster_ = anc >= 0 ? bodies_[anc].sub_index_within_cluster_ : 0;
+        body_name_to_body_index_[name] = b.index_;
+        bodies_.push_back(b);
+        bodies_in_current_cluster_.push_back(b);
+        return b;
+    }
+
+    // ClusterTreeModel.h:61-66
+    template <typename ClusterJointType, typename... Args>
+    void appendRegisteredBodiesAsCluster(const std::string name, Args &&...args)
+    {
+        auto joint = std::make_shared<ClusterJointType>(args...);
+        appendRegisteredBodiesAsCluster(name, std::static_pointer_cast<ClusterJoints::Base<Scalar>>(joint));
+    }
+    // ClusterTreeModel.h:69-78
+    template <typename ClusterJointType, typename... Args>
+    void appendBody(const std::string name, const SpatialInertia<Scalar> inertia, const std::string parent_name,
+                    const spatial::Transform<Scalar> Xtree, Args &&...args)
+    {
+        Body<Scalar> body = registerBody(name, inertia, parent_name, Xtree);
+        auto joint = std::make_shared<ClusterJointType>(body, args...);
+        appendRegisteredBodiesAsCluster(name, std::static_pointer_cast<ClusterJoints::Base<Scalar>>(joint));
+    }
+    // ClusterTreeModel.cpp:34-67
+    void appendRegisteredBodiesAsCluster(const std::string name, std::shared_ptr<ClusterJoints::Base<Scalar>> joint)
+    {
+        if (bodies_in_current_cluster_.empty()) throw std::runtime_error("Cluster is empty");
+        if (static_cast<int>(bodies_in_current_cluster_.size()) != joint->numBodies())
+            throw std::runtime_error("number of registered bodies does not match the cluster joint");
+        auto node = std::make_shared<ClusterTreeNode<Scalar>>();
+        node->index_ = static_cast<int>(cluster_nodes_.size());
+        node->name_ = name;
+        node->bodies_ = bodies_in_current_cluster_;
+        node->joint_ = joint;
+        node->position_index_ = this->position_index_;
+        node->num_positions_ = joint->numPositions();
+        node->velocity_index_ = this->velocity_index_;
+        node->num_velocities_ = joint->numVelocities();
+        // checkValidParentClusterForBodiesInCluster (ClusterTreeModel.cpp:112-126)
+        const int first = node->bodies_.front().index_;
+        int parent_cluster = -2;
+        for (const auto &b : node->bodies_) {
+            if (b.parent_index_ >= first) continue;
+            const int pc = b.parent_index_ < 0 ? -1 : body_index_to_cluster_index_.at(b.parent_index_);
+            if (parent_cluster == -2) parent_cluster = pc;
+            else if (parent_cluster != pc)
+                throw std::runtime_error("The parents of all bodies in a cluster must have parents in the current cluster OR in the same parent cluster");
+        }
+        node->parent_index_ = parent_cluster;
+        for (const auto &b : node->bodies_) body_index_to_cluster_index_[b.index_] = node->index_;
+        cluster_nodes_.push_back(node);
+        this->position_index_ += joint->numPositions();
+        this->velocity_index_ += joint->numVelocities();
+        bodies_in_current_cluster_.clear();
+        this->plan_dirty_ = true;
+    }
+
+    // ---- accessors ------------------------------------------------------------------------------
+    int getNumBodies() const { return from_urdf_ ? n_bodies_urdf_ : static_cast<int>(bodies_.size()); }
+    const std::vector<Body<Scalar>> &bodies() const { return bodies_; }
+    const std::vector<ClusterTreeNodePtr<Scalar>> &clusters() const { return cluster_nodes_; }
+    ClusterTreeNodePtr<Scalar> cluster(int i) const { return cluster_nodes_.at(i); }
+    const Body<Scalar> &body(const std::string &name) const { return bodies_.at(body_name_to_body_index_.at(name)); }
+
+    // ---- state (ClusterTreeModel.cpp:256-308) -----------------------------------------------------
+    typedef std::pair<DVec<Scalar>, DVec<Scalar>> StatePair;
+    void setState(const ModelState<Scalar> &model_state)
+    {
+        DVec<Scalar> q, qd;
+        for (const auto &js : model_state) {
+            q.insert(q.end(), js.position.begin(), js.position.end());
+            qd.insert(qd.end(), js.velocity.begin(), js.velocity.end());
+        }
+        setState(StatePair{q, qd});
+    }
+    void setState(const StatePair &q_qd_pair)
+    {
+        if (static_cast<int>(q_qd_pair.first.size()) != this->position_index_ ||
+            static_cast<int>(q_qd_pair.second.size()) != this->velocity_index_)
+            throw std::runtime_error("state has the wrong dimension");
+        q_ = q_qd_pair.first;
+        qd_ = q_qd_pair.second;
+        f_ext_.clear();  // setState -> setExternalForces({}) (ClusterTreeModel.cpp:266)
+    }
+    void setState(const DVec<Scalar> &q_qd_vec)
+    {
+        setState(StatePair{q_qd_vec.segment(0, this->position_index_), q_qd_vec.segment(this->position_index_, this->velocity_index_)});
+    }
+    // TreeModel.cpp:214-239
+    void setExternalForces(const std::vector<ExternalForceAndBodyIndexPair<Scalar>> &force_and_body_index_pairs = {})
+    {
+        f_ext_ = force_and_body_index_pairs;
+    }
+
+    // ---- dynamics: the accelerated path ------------------------------------------------------------
+    DVec<Scalar> forwardDynamics(const DVec<Scalar> &tau) override { return single(false, tau); }
+    DVec<Scalar> inverseDynamics(const DVec<Scalar> &qdd) override { return single(true, qdd); }
+
+    // batched entry points on HOST arrays (row-major q[B][nq], qd[B][nv], tau[B][nv] -> ydd[B][nv])
+    void forwardDynamicsBatch(const double *q, const double *qd, const double *tau, double *ydd, size_t B, int device = 0)
+    {
+        check(grbda_aba_host_f64(plan(), q, qd, tau, nullptr, ydd, B, device));
+    }
+    void inverseDynamicsBatch(const double *q, const double *qd, const double *ydd, double *tau, size_t B, int device = 0)
+    {
+        check(grbda_rnea_host_f64(plan(), q, qd, ydd, nullptr, tau, B, device));
+    }
+    // the immutable compiled plan, for the device-pointer C ABI (grbda_aba_f32 / _f64, grbda_rnea_*)
+    const grbda_plan *plan()
+    {
+        if (this->plan_dirty_ || !plan_) {
+            if (plan_) { grbda_plan_free(plan_); plan_ = nullptr; }
+            std::vector<unsigned char> blob = serialize();
+            check(grbda_plan_from_blob(blob.data(), blob.size(), &plan_));
+            this->plan_dirty_ = false;
+        }
+        return plan_;
+    }
+
+    // model description blob (include/grbda_model_desc.h)
+    std::vector<unsigned char> serialize() const
+    {
+        if (!bodies_in_current_cluster_.empty()) throw std::runtime_error("registered bodies have not been appended as a cluster");
+        if (from_urdf_) {
+            std::vector<unsigned char> b = urdf_blob_;
+            auto *h = reinterpret_cast<grbda_desc_header *>(b.data());
+            for (int i = 0; i < 6; i++) h->gravity[i] = static_cast<double>(this->gravity_[i]);
+            return b;
+        }
+        desc::ModelDescription md;
+        md.ori_repr = OriTpl::desc_id;
+        for (int i = 0; i < 6; i++) md.gravity[i] = static_cast<double>(this->gravity_[i]);
+        for (const auto &node : cluster_nodes_) {
+            desc::ClusterDesc cd;
+            cd.name = node->name_;
+            const auto lc = node->joint_->cloneLoopConstraint();
+            const auto &joints = node->joint_->ordered_joints_;
+            int nsv = 0, nsp = 0;
+            for (size_t i = 0; i < node->bodies_.size(); i++) {
+                const Body<Scalar> &b = node->bodies_[i];
+                desc::BodyDesc bd;
+                bd.name = b.name_;
+                bd.parent = b.parent_index_;
+                bd.joint_type = joints[i]->type;
+                bd.axis = static_cast<int>(joints[i]->axis);
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) bd.E[r * 3 + c] = static_cast<double>(b.Xtree_.getRotation()(r, c));
+                for (int r = 0; r < 3; r++) bd.r[r] = static_cast<double>(b.Xtree_.getTranslation()[r]);
+                for (int r = 0; r < 6; r++)
+                    for (int c = 0; c < 6; c++) bd.inertia[r * 6 + c] = static_cast<double>(b.inertia_.getMatrix()(r, c));
+                cd.bodies.push_back(bd);
+                nsv += bd.joint_type == GRBDA_JOINT_FREE ? 6 : 1;
+                nsp += bd.joint_type == GRBDA_JOINT_FREE ? 3 + OriTpl::num_ori_parameter : 1;
+            }
+            cd.n_pos = node->num_positions_;
+            cd.n_vel = node->num_velocities_;
+            cd.n_span_pos = nsp;
+            cd.n_span_vel = nsv;
+            cd.constraint_type = lc->kind;
+            cd.n_rows = lc->rows;
+            if (lc->kind == GRBDA_CONSTRAINT_STATIC) {
+                const auto &G = lc->G();
+                const auto &K = lc->K();
+                if (G.rows() != nsv || G.cols() != cd.n_vel) throw std::runtime_error("loop constraint G has the wrong shape");
+                for (int r = 0; r < G.rows(); r++)
+                    for (int c = 0; c < G.cols(); c++) cd.dbls.push_back(static_cast<double>(G(r, c)));
+                for (int r = 0; r < K.rows(); r++)
+                    for (int c = 0; c < K.cols(); c++) cd.dbls.push_back(static_cast<double>(K(r, c)));
+            } else {
+                cd.ints = lc->ints;
+                cd.dbls = lc->dbls;
+            }
+            md.appendCluster(cd);
+        }
+        return md.serialize();
+    }
+
+private:
+    static void check(int rc)
+    {
+        if (rc != GRBDA_OK) throw std::runtime_error(std::string(grbda_strerror(rc)) + ": " + grbda_last_error());
+    }
+    DVec<Scalar> single(bool inverse, const DVec<Scalar> &x)
+    {
+        if (static_cast<int>(x.size()) != this->velocity_index_) throw std::runtime_error("input has the wrong dimension");
+        if (static_cast<int>(q_.size()) != this->position_index_) throw std::runtime_error("state has not been set");
+        if (!f_ext_.empty()) throw std::runtime_error("external forces are not supported by the HIP kernels yet");
+        std::vector<double> q(q_.begin(), q_.end()), qd(qd_.begin(), qd_.end()), in(x.begin(), x.end()), out(x.size());
+        check(inverse ? grbda_rnea_host_f64(plan(), q.data(), qd.data(), in.data(), nullptr, out.data(), 1, 0)
+                      : grbda_aba_host_f64(plan(), q.data(), qd.data(), in.data(), nullptr, out.data(), 1, 0));
+        return DVec<Scalar>(out.begin(), out.end());
+    }
+
+    std::vector<Body<Scalar>> bodies_, bodies_in_current_cluster_;
+    std::vector<ClusterTreeNodePtr<Scalar>> cluster_nodes_;
+    std::map<std::string, int> body_name_to_body_index_;
+    std::map<int, int> body_index_to_cluster_index_;
+    DVec<Scalar> q_, qd_;
+    std::vector<ExternalForceAndBodyIndexPair<Scalar>> f_ext_;
+    std::vector<unsigned char> urdf_blob_;
+    bool from_urdf_ = false;
+    int n_bodies_urdf_ = 0;
+    grbda_plan *plan_ = nullptr;
+};
+
+}  // namespace grbda

@@ -1,0 +1,138 @@
+// facade_test.cpp -- the reference's own construction code, compiled against the facade.
+//
+// The builder below is written the way src/Robots/SerialChains/RevoluteChainWithRotor.cpp:45-109 and
+// RevolutePairChainWithRotor.cpp:62-138 use the reference API (registerBody /
+// appendRegisteredBodiesAsCluster<JointT> / setState / forwardDynamics / inverseDynamics).
+//   facade_test --dump <dir>   : write model-description blobs (CPU only)
+//   facade_test --run <urdf>   : run dynamics through the HIP path and check ID(FD(tau)) == tau
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "grbda/Dynamics/ClusterTreeModel.h"
+
+using namespace grbda;
+
+template <size_t N>
+void buildRevoluteChainWithRotor(ClusterTreeModel<double> &model)
+{
+    using RevoluteWithRotor = ClusterJoints::RevoluteWithRotor<double>;
+    using TransmissionModule = ClusterJoints::GearedTransmissionModule<double>;
+    const Mat3<double> I3 = Mat3<double>::Identity();
+    const Vec3<double> z3 = Vec3<double>::Zero();
+    model.setGravity(Vec3<double>{9.81, 0., 0.});
+    const double I = 1., Irot = 1e-4, m = 1., l = 1., c = 0.5, gr = 2., br = 3.;
+    const ori::CoordinateAxis axis = ori::CoordinateAxis::Z;
+    Mat3<double> link_inertia, rotor_inertia;
+    link_inertia(2, 2) = I;
+    rotor_inertia(2, 2) = Irot;
+    const SpatialInertia<double> link_spatial_inertia(m, Vec3<double>{c, 0., 0.}, link_inertia);
+    const SpatialInertia<double> rotor_spatial_inertia(0., Vec3<double>::Zero(), rotor_inertia);
+    std::string prev_link_name = "ground";
+    for (size_t i = 0; i < N; i++) {
+        const spatial::Transform<double> Xtree = i == 0 ? spatial::Transform<double>(I3, z3)
+                                                        : spatial::Transform<double>(I3, Vec3<double>{l, 0., 0.});
+        const std::string link_name = "link-" + std::to_string(i);
+        auto link = model.registerBody(link_name, link_spatial_inertia, prev_link_name, Xtree);
+        const std::string rotor_name = "rotor-" + std::to_string(i);
+        auto rotor = model.registerBody(rotor_name, rotor_spatial_inertia, prev_link_name, Xtree);
+        TransmissionModule module{link, rotor, "link-joint-" + std::to_string(i), "rotor-joint-" + std::to_string(i),
+                                  axis, axis, gr * br};
+        model.appendRegisteredBodiesAsCluster<RevoluteWithRotor>("cluster-" + std::to_string(i), module);
+        prev_link_name = link_name;
+    }
+}
+
+template <size_t N>
+void buildRevolutePairChainWithRotor(ClusterTreeModel<double> &model)
+{
+    using RevPairRotor = ClusterJoints::RevolutePairWithRotor<double>;
+    using ProxTransModule = ClusterJoints::ParallelBeltTransmissionModule<1, double>;
+    using DistTransModule = ClusterJoints::ParallelBeltTransmissionModule<2, double>;
+    const Mat3<double> I3 = Mat3<double>::Identity();
+    model.setGravity(Vec3<double>{9.81, 0., 0.});
+    const double gr = 2., br = 3.;
+    const ori::CoordinateAxis axis = ori::CoordinateAxis::Z;
+    const spatial::Transform<double> Xtree2(I3, Vec3<double>{1., 0., 0.});
+    Mat3<double> link_inertia, rotor_inertia;
+    link_inertia(2, 2) = 1.;
+    rotor_inertia(2, 2) = 1e-4;
+    const SpatialInertia<double> link_si(1., Vec3<double>{0.5, 0., 0.}, link_inertia);
+    const SpatialInertia<double> rotor_si(0., Vec3<double>::Zero(), rotor_inertia);
+    std::string parent_name = "ground";
+    for (size_t i = 0; i < N / 2; i++) {
+        const spatial::Transform<double> Xtree1 = i == 0 ? spatial::Transform<double>(I3, Vec3<double>::Zero()) : Xtree2;
+        const std::string s = std::to_string(i);
+        auto linkA = model.registerBody("link-A-" + s, link_si, parent_name, Xtree1);
+        auto rotorA = model.registerBody("rotor-A-" + s, rotor_si, parent_name, Xtree1);
+        auto rotorB = model.registerBody("rotor-B-" + s, rotor_si, parent_name, Xtree1);
+        auto linkB = model.registerBody("link-B-" + s, link_si, "link-A-" + s, Xtree2);
+        ProxTransModule moduleA{linkA, rotorA, axis, axis, gr, Vec1<double>{br}};
+        DistTransModule moduleB{linkB, rotorB, axis, axis, gr, Vec2<double>{br, 1.}};
+        model.appendRegisteredBodiesAsCluster<RevPairRotor>("cluster-" + s, moduleA, moduleB);
+        parent_name = "link-B-" + s;
+    }
+}
+
+static void dump(const std::string &path, const std::vector<unsigned char> &blob)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(blob.data()), static_cast<std::streamsize>(blob.size()));
+}
+
+template <class Model>
+static int roundtrip(Model &model, const char *what)
+{
+    const int nq = model.getNumPositions(), nv = model.getNumDegreesOfFreedom();
+    double worst = 0;
+    for (int trial = 0; trial < 5; trial++) {
+        DVec<double> q = DVec<double>::Random(nq), qd = DVec<double>::Random(nv), tau = DVec<double>::Random(nv);
+        if (nq == nv + 1) {  // floating base: a valid unit quaternion in the last 4 of the first 7 positions
+            Quat<double> quat = ori::rpyToQuat(Vec3<double>{q[3], q[4], q[5]});
+            for (int i = 0; i < 4; i++) q[3 + i] = quat[i];
+        }
+        model.setState(std::make_pair(q, qd));
+        const DVec<double> ydd = model.forwardDynamics(tau);
+        const DVec<double> back = model.inverseDynamics(ydd);
+        worst = std::fmax(worst, (back - tau).norm());
+    }
+    std::printf("%s: nq=%d nv=%d |ID(FD(tau)) - tau| = %.3e\n", what, nq, nv, worst);
+    return worst < 5e-8 ? 0 : 1;  // tol of UnitTests/testRigidBodyDynamicsAlgos.cpp:9
+}
+
+int main(int argc, char **argv)
+{
+    const std::string mode = argc > 1 ? argv[1] : "";
+    try {
+        if (mode == "--dump" && argc > 2) {
+            const std::string dir = argv[2];
+            { ClusterTreeModel<double> m; buildRevoluteChainWithRotor<2>(m); dump(dir + "/rev2.grbd", m.serialize()); }
+            { ClusterTreeModel<double> m; buildRevoluteChainWithRotor<4>(m); dump(dir + "/rev4.grbd", m.serialize()); }
+            { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<2>(m); dump(dir + "/pair2.grbd", m.serialize()); }
+            { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<4>(m); dump(dir + "/pair4.grbd", m.serialize()); }
+            // reference error behaviour: a free joint cannot have a parent body (FreeJoint.cpp:14-15)
+            bool threw = false;
+            try {
+                ClusterTreeModel<double> m;
+                buildRevoluteChainWithRotor<2>(m);
+                m.appendBody<ClusterJoints::Free<double>>("floating", SpatialInertia<double>(), "link-1", spatial::Transform<double>());
+            } catch (const std::runtime_error &) { threw = true; }
+            std::printf("free-joint-with-parent throws: %d\n", threw ? 1 : 0);
+            return threw ? 0 : 1;
+        }
+        if (mode == "--run" && argc > 2) {
+            int rc = 0;
+            { ClusterTreeModel<double> m; buildRevoluteChainWithRotor<4>(m); rc |= roundtrip(m, "RevoluteChainWithRotor<4>"); }
+            { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<4>(m); rc |= roundtrip(m, "RevolutePairChainWithRotor<4>"); }
+            { ClusterTreeModel<double> m(argv[2]); rc |= roundtrip(m, argv[2]); }
+            std::printf(rc ? "FAILED\n" : "OK\n");
+            return rc;
+        }
+    } catch (const std::exception &e) {
+        std::printf("exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf("usage: facade_test --dump <dir> | --run <urdf>\n");
+    return 2;
+}

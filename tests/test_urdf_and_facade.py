@@ -1,0 +1,170 @@
+"""CPU tests of the two front ends of the path: the URDF+ reader and the
+C++17 facade that keeps the reference's class API."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import generalized_rbda_amd as G
+import oracle_py as O
+from generalized_rbda_amd import modeldesc as md
+from generalized_rbda_amd.states import parse_clusters, random_states
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODELS = os.path.join(ROOT, "robot-models")
+
+# (bodies, clusters, nq, nv, cluster-size histogram): SURVEY section 8 table, itself pinned by
+# UnitTests/testClusterTreeModel.cpp:149-154 and the hand-built robots of the reference
+EXPECTED = {
+    "revolute_rotor_chain": (6, 3, 3, 3, {2: 3}),
+    "mini_cheetah": (25, 13, 19, 18, {1: 1, 2: 12}),
+    "mit_humanoid": (37, 17, 25, 24, {1: 1, 2: 14, 4: 2}),
+    "mit_humanoid_leg": (10, 4, 5, 5, {2: 3, 4: 1}),
+    "jvrc1_humanoid": (58, 33, 39, 38, {1: 8, 2: 25}),
+    "four_bar": (3, 1, 3, 1, {3: 1}),
+    "six_bar": (5, 1, 5, 3, {5: 1}),
+    "planar_leg_linkage": (4, 2, 4, 2, {1: 1, 3: 1}),
+    "double_pendulum": (2, 2, 2, 2, {1: 2}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED))
+def test_urdf_model_structure(name):
+    blob = G.urdf_to_blob(os.path.join(MODELS, name + ".urdf"))
+    m = parse_clusters(blob)
+    hist = {}
+    for c in m["clusters"]:
+        hist[c[2]] = hist.get(c[2], 0) + 1
+    assert (m["nb"], m["nc"], m["nq"], m["nv"], hist) == EXPECTED[name]
+
+
+def _names(blob):
+    m = parse_clusters(blob)
+    import struct
+    n_ints, n_dbls, n_names = struct.unpack_from("<3i", blob, 28)
+    off = 96 + 416 * m["nb"] + 64 * m["nc"] + 4 * ((n_ints + 1) & ~1) + 8 * n_dbls
+    return blob[off: off + n_names].split(b"\0")[: m["nb"]]
+
+
+def test_urdf_cluster_order_matches_the_reference_hand_built_robots():
+    """MiniCheetah.cpp:29 builds legs {HR, HL, FR, FL}; MIT_Humanoid.cpp builds right leg, left leg,
+    right arm, left arm, with the knee/ankle cluster ordered [ankle_rotor, knee_link, knee_rotor,
+    ankle_link] (MIT_Humanoid.cpp:172-179); testClusterTreeModel.cpp:100-114 requires the URDF model
+    to agree cluster by cluster."""
+    mc = [n.decode() for n in _names(G.urdf_to_blob(os.path.join(MODELS, "mini_cheetah.urdf")))]
+    assert mc[0] == "Floating Base"
+    assert [n[:2] for n in mc[1::6]] == ["HR", "HL", "FR", "FL"]
+    assert mc[1:3] == ["HR_abad_link", "HR_abad_rotor"]
+    mit = [n.decode() for n in _names(G.urdf_to_blob(os.path.join(MODELS, "mit_humanoid.urdf")))]
+    assert mit[1].startswith("right_hip_rz") and mit[11].startswith("left_hip_rz")
+    assert mit[21].startswith("right_shoulder_ry") and mit[29].startswith("left_shoulder_ry")
+    assert mit[7:11] == ["right_ankle_rotor", "right_knee_link", "right_knee_rotor", "right_ankle_link"]
+
+
+def test_urdf_rotor_chain_equals_hand_built_model():
+    """URDFvsManualTests for revolute_rotor_chain.urdf vs RevoluteChainWithRotor<3>(false)
+    (testClusterTreeModel.cpp:105-106): same G/K and same dynamics.  The URDF carries link inertia
+    diag(1,1,1) while the uniform builder uses diag(0,0,1); for planar motion about z both give the
+    same dynamics."""
+    blob_u = G.urdf_to_blob(os.path.join(MODELS, "revolute_rotor_chain.urdf"))
+    p = G.Plan(blob_u)
+    p.set_gravity([9.81, 0, 0])
+    blob_u = p.blob
+    blob_m = md.revolute_chain_with_rotor(3).serialize()
+    q, qd, tau = random_states(blob_m, 25, config_index=41)
+    assert np.abs(O.forward_dynamics(blob_u, q, qd, tau) - O.forward_dynamics(blob_m, q, qd, tau)).max() < 1e-9
+    assert np.abs(O.inverse_dynamics(blob_u, q, qd, tau) - O.inverse_dynamics(blob_m, q, qd, tau)).max() < 1e-10
+    cu, cm = parse_clusters(blob_u)["clusters"], parse_clusters(blob_m)["clusters"]
+    for c in range(3):
+        Gu, _, Ku, _, _ = O.cluster_constraint(blob_u, c, q[0], qd[0], 2, 1, 1)
+        Gm, _, Km, _, _ = O.cluster_constraint(blob_m, c, q[0], qd[0], 2, 1, 1)
+        assert np.array_equal(Gu, Gm) and np.array_equal(Ku, Km) and cu[c][2] == cm[c][2]
+
+
+def test_multi_file_urdf_merge_equals_single_file():
+    """buildModelFromURDF(vector<path>) (ClusterTreeModel.h:48-53, testUrdfParser.cpp:398-445)."""
+    parts = [os.path.join(MODELS, f"mini_cheetah_{p}.urdf") for p in ("base", "fr_leg", "fl_leg", "hr_leg", "hl_leg")]
+    merged = G.urdf_to_blob(parts)
+    single = G.urdf_to_blob(os.path.join(MODELS, "mini_cheetah.urdf"))
+    a, b = parse_clusters(merged), parse_clusters(single)
+    assert (a["nb"], a["nc"], a["nq"], a["nv"]) == (b["nb"], b["nc"], b["nq"], b["nv"])
+    q, qd, tau = random_states(single, 10, config_index=42)
+    assert np.abs(O.forward_dynamics(merged, q, qd, tau) - O.forward_dynamics(single, q, qd, tau)).max() < 1e-9
+
+
+def test_urdf_errors_are_reported():
+    with pytest.raises(G.GrbdaError) as e:
+        G.urdf_to_blob("/nonexistent/robot.urdf")
+    assert e.value.code == -6
+    bad = os.path.join(ROOT, "tests", "golden", "_bad.urdf")
+    with open(bad, "w") as f:
+        f.write('<robot name="x"><link name="a"/><link name="b"/><joint name="j" type="prismatic">'
+                '<parent link="a"/><child link="b"/><axis xyz="0 0 1"/></joint></robot>')
+    try:
+        with pytest.raises(G.GrbdaError, match="not supported"):
+            G.urdf_to_blob(bad)
+    finally:
+        os.remove(bad)
+
+
+@pytest.mark.parametrize("name", ["four_bar", "six_bar", "planar_leg_linkage"])
+def test_implicit_loop_constraints_in_the_oracle(name):
+    """LoopConstraint tests of the reference (UnitTests/testLoopConstraints.cpp:195-341):
+    phi = 0 after projection, K G = 0, K g = k, and K == d phi / d q by central differences."""
+    blob = G.urdf_to_blob(os.path.join(MODELS, name + ".urdf"))
+    m = parse_clusters(blob)
+    q, qd, _ = random_states(blob, 12, config_index=43)
+    q, ok = O.project_positions(blob, q)
+    assert ok.sum() >= 6
+    q, qd = q[ok], qd[ok]
+    for ci, c in enumerate(m["clusters"]):
+        if c[9] < 2:
+            continue
+        nsv, n, rows, qi = c[8], c[6], c[10], c[3]
+        for s in range(q.shape[0]):
+            Gm, g, K, k, phi = O.cluster_constraint(blob, ci, q[s], qd[s], nsv, n, rows)
+            assert np.abs(phi).max() < 1e-8
+            assert np.abs(K @ Gm).max() < 1e-8
+            assert np.abs(K @ g - k).max() < 1e-8
+            h = 1e-6
+            Kfd = np.zeros_like(K)
+            for j in range(nsv):
+                qp, qm = q[s].copy(), q[s].copy()
+                qp[qi + j] += h
+                qm[qi + j] -= h
+                Kfd[:, j] = (O.cluster_constraint(blob, ci, qp, qd[s], nsv, n, rows)[4] -
+                             O.cluster_constraint(blob, ci, qm, qd[s], nsv, n, rows)[4]) / (2 * h)
+            assert np.abs(K - Kfd).max() < 1e-6
+            # k = -Kdot qd_span: differentiate K along the spanning velocity
+            qds = Gm @ qd[s][c[5]: c[5] + n]
+            qp, qm = q[s].copy(), q[s].copy()
+            qp[qi: qi + nsv] += h * qds
+            qm[qi: qi + nsv] -= h * qds
+            Kdot = (O.cluster_constraint(blob, ci, qp, qd[s], nsv, n, rows)[2] -
+                    O.cluster_constraint(blob, ci, qm, qd[s], nsv, n, rows)[2]) / (2 * h)
+            assert np.abs(-Kdot @ qds - k).max() < 1e-5
+
+
+@pytest.fixture(scope="module")
+def facade_binary(tmp_path_factory):
+    out = tmp_path_factory.mktemp("facade") / "facade_test"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "generalized_rbda_amd", "include"),
+                    os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-o", str(out),
+                    "-L" + os.path.join(ROOT, "generalized_rbda_amd"), "-lgrbda_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "generalized_rbda_amd")], check=True)
+    return str(out)
+
+
+def test_cpp_facade_serialises_the_same_models_as_the_python_builder(facade_binary, tmp_path):
+    r = subprocess.run([facade_binary, "--dump", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name, model in [("rev2", md.revolute_chain_with_rotor(2)), ("rev4", md.revolute_chain_with_rotor(4)),
+                        ("pair2", md.revolute_pair_chain_with_rotor(2)), ("pair4", md.revolute_pair_chain_with_rotor(4))]:
+        assert (tmp_path / f"{name}.grbd").read_bytes() == model.serialize()
+
+
+@pytest.mark.gpu
+def test_cpp_facade_runs_dynamics_on_the_gpu(facade_binary):
+    r = subprocess.run([facade_binary, "--run", os.path.join(MODELS, "mit_humanoid.urdf")], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
