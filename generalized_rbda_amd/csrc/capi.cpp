@@ -40,6 +40,8 @@ int hip_err(hipError_t e, const char *what)
 struct DeviceTables {
     Step *aba_steps = nullptr, *rnea_steps = nullptr;
     ClusterRec *clusters[2] = {nullptr, nullptr};      // [0] f32 layout, [1] f64 layout
+    ClusterRec *rnea_clusters[2] = {nullptr, nullptr};
+    int32_t *cints = nullptr;
     BodyRec *bodies[2] = {nullptr, nullptr};           // ABA slots
     BodyRec *rnea_bodies[2] = {nullptr, nullptr};      // RNEA slots
     double *consts64 = nullptr;
@@ -96,11 +98,13 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     if ((e = up(h.aba_steps.data(), h.aba_steps.size() * sizeof(Step), (void **)&t.aba_steps)) != hipSuccess ||
         (e = up(h.rnea_steps.data(), h.rnea_steps.size() * sizeof(Step), (void **)&t.rnea_steps)) != hipSuccess ||
         (e = up(h.consts.data(), h.consts.size() * sizeof(double), (void **)&t.consts64)) != hipSuccess ||
-        (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess)
+        (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess ||
+        (e = up(h.cints.data(), h.cints.size() * sizeof(int32_t), (void **)&t.cints)) != hipSuccess)
         return hip_err(e, "plan upload");
     for (int w = 0; w < 2; w++) {
         const Layout &L = w == 0 ? h.lay32 : h.lay64;
         if ((e = up(L.clusters.data(), L.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters[w])) != hipSuccess ||
+            (e = up(L.rnea_clusters.data(), L.rnea_clusters.size() * sizeof(ClusterRec), (void **)&t.rnea_clusters[w])) != hipSuccess ||
             (e = up(L.bodies.data(), L.bodies.size() * sizeof(BodyRec), (void **)&t.bodies[w])) != hipSuccess ||
             (e = up(L.rnea_bodies.data(), L.rnea_bodies.size() * sizeof(BodyRec), (void **)&t.rnea_bodies[w])) != hipSuccess)
             return hip_err(e, "plan upload");
@@ -142,7 +146,8 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea)
     d.n_steps = static_cast<int>(rnea ? h.rnea_steps.size() : h.aba_steps.size());
     const int w = sizeof(T) == 4 ? 0 : 1;
     const Layout &L = w == 0 ? h.lay32 : h.lay64;
-    d.clusters = t.clusters[w];
+    d.clusters = rnea ? t.rnea_clusters[w] : t.clusters[w];
+    d.cints = t.cints;
     d.bodies = rnea ? t.rnea_bodies[w] : t.bodies[w];
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.nq = h.nq;
@@ -306,7 +311,8 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        for (int w = 0; w < 2; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
+        (void)hipFree(t.cints);
+        for (int w = 0; w < 2; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto &kv : p->scratch) {
         if (hipSetDevice(kv.first.first) != hipSuccess) continue;

@@ -13,6 +13,7 @@ struct DevPlan {
     const ClusterRec *clusters;
     const BodyRec *bodies;
     const T *consts;
+    const int32_t *cints;  // integer payload of implicit constraints
     int nq, nv;
     int n_lds_slots, n_glb_slots;
     int lds_bytes;  // dynamic LDS actually allocated per wave (slot store / input staging area)

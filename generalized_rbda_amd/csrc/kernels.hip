@@ -57,6 +57,7 @@ struct Tables {
     cptr<ClusterRec> clusters;
     cptr<BodyRec> bodies;
     cptr<T> consts;
+    cptr<int32_t> cints;
     int n_steps, nq, nv, ori_repr;
     T a_root[6];
 };
@@ -68,6 +69,7 @@ __device__ __forceinline__ Tables<T> make_tables(const DevPlan<T> &P)
     t.clusters = (cptr<ClusterRec>)P.clusters;
     t.bodies = (cptr<BodyRec>)P.bodies;
     t.consts = (cptr<T>)P.consts;
+    t.cints = (cptr<int32_t>)P.cints;
     t.n_steps = P.n_steps;
     t.nq = P.nq;
     t.nv = P.nv;
@@ -115,6 +117,17 @@ struct Slots {
 #pragma unroll
             for (int i = 0; i < N; i++) lds_put(s + i, x[i]);
         }
+    }
+    __device__ __forceinline__ T ld1(int s) const
+    {
+        T x[1];
+        ld(s, x);
+        return x[0];
+    }
+    __device__ __forceinline__ void st1(int s, T v) const
+    {
+        const T x[1] = {v};
+        st(s, x);
     }
     // x is stored when first != 0, accumulated otherwise
     template <int N>
@@ -503,19 +516,310 @@ __device__ __forceinline__ T gdot(cptr<T> G, const T (&y)[N])
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// implicit position-loop constraints (LoopConstraint::GenericImplicit built by
+// ClusterTreeParsing.cpp:310-376; the reference evaluates CasADi functions K, G, k, g per state,
+// GenericJoint.cpp:117-129).  Here K = d phi / d q comes from the geometric Jacobian of the two
+// sub-chains NCA -> predecessor / successor, k = -Kdot qd from their velocity-product
+// accelerations, G = P [1; -Kd^-1 Ki], g = P [0; Kd^-1 k] (GenericJoint.cpp:57-90).
+// Per-step scratch block (slots, see plan.h): G rows k*(N+1) | K rows*k | qd_span k | q_span k | chain 6k
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void cross3(const T (&a)[3], const T (&b)[3], T (&o)[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// inverse of an R x R matrix held in a 3x3 array, R in {1,2,3} (wave-uniform), closed form
+template <class T>
+__device__ __forceinline__ void inv_small(int R, const T (&A)[3][3], T (&Ai)[3][3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Ai[i][j] = 0;
+    if (R == 1) {
+        Ai[0][0] = T(1) / A[0][0];
+    } else if (R == 2) {
+        const T id = T(1) / (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
+        Ai[0][0] = A[1][1] * id; Ai[0][1] = -A[0][1] * id;
+        Ai[1][0] = -A[1][0] * id; Ai[1][1] = A[0][0] * id;
+    } else {
+        const T c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+        const T c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+        const T c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+        const T id = T(1) / (A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02);
+        Ai[0][0] = c00 * id; Ai[1][0] = c01 * id; Ai[2][0] = c02 * id;
+        Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id;
+        Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id;
+        Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id;
+        Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id;
+        Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id;
+        Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id;
+    }
+}
+
+template <int N>
+struct ImpLayout {
+    int G, K, qds, qs, chain;
+    __device__ __forceinline__ ImpLayout(int base, int k, int rows)
+    {
+        G = base;
+        K = G + k * (N + 1);
+        qds = K + rows * k;
+        qs = qds + k;
+        chain = qs + k;
+    }
+};
+
+// walk one sub-chain with positions only: joint axes a_t and origins o_t (NCA coordinates) go to the
+// chain scratch, the constraint point p is returned
+template <class T>
+__device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                     cptr<int32_t> subs, int len, cptr<T> origin, int qs_slot,
+                                                     int chain_slot, T (&p)[3])
+{
+    T E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, r[3] = {0, 0, 0};
+    for (int t = 0; t < len; t++) {
+        const int sub = subs[t];
+        const BodyRec b = load_rec(P.bodies + (c.first_body + sub));
+        cptr<T> C = P.consts + b.cofs;
+        T sc[2], Eb[9], En[9];
+        sincos_t(S.ld1(qs_slot + sub), &sc[0], &sc[1]);
+        build_E(b.axis, sc[0], sc[1], C, Eb);
+        // X_new = (Eb, r_tree) * (E, r):  E_new = Eb E,  r_new = r + E^T r_tree
+#pragma unroll
+        for (int i = 0; i < 3; i++) r[i] += E[i] * C[9] + E[3 + i] * C[10] + E[6 + i] * C[11];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) En[3 * i + j] = Eb[3 * i] * E[j] + Eb[3 * i + 1] * E[3 + j] + Eb[3 * i + 2] * E[6 + j];
+#pragma unroll
+        for (int i = 0; i < 9; i++) E[i] = En[i];
+        // joint axis in NCA coordinates = row `axis` of E; joint origin = r
+        T ao[6];
+        if (b.axis == 0) { ao[0] = E[0]; ao[1] = E[1]; ao[2] = E[2]; }
+        else if (b.axis == 1) { ao[0] = E[3]; ao[1] = E[4]; ao[2] = E[5]; }
+        else { ao[0] = E[6]; ao[1] = E[7]; ao[2] = E[8]; }
+        ao[3] = r[0]; ao[4] = r[1]; ao[5] = r[2];
+        S.st(chain_slot + 6 * t, ao);
+    }
+    // constraint frame origin: p = r + E^T r_origin (the origin's own rotation does not move the point)
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = r[i] + E[i] * origin[9] + E[3 + i] * origin[10] + E[6 + i] * origin[11];
+}
+
+// G rows, g, spanning positions / velocities of an implicit-loop cluster into the scratch block
+template <class T, int N>
+__device__ __forceinline__ void eval_loop_constraint(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                     const Lane<T> &L, int base, const T (&yd)[N], bool want_bias)
+{
+    const ImpLayout<N> lay(base, c.k, c.rows);
+    const int k = c.k, rows = c.rows;
+    cptr<int32_t> ip = P.cints + c.iofs;
+    const int n_loops = ip[0];
+    const int n_ind = ip[1];
+    cptr<int32_t> ind = ip + 2;
+    cptr<int32_t> dep = ip + 3 + n_ind;
+    cptr<int32_t> loops = dep + rows;
+
+    for (int i = 0; i < k; i++) S.st1(lay.qs + i, L.q(c.q_index + i));
+    for (int i = 0; i < rows * k; i++) S.st1(lay.K + i, T(0));
+
+    // ---- K(q): geometric Jacobian of (p_pred - p_succ), enforced axes only ----------------------
+    {
+        cptr<int32_t> lp = loops;
+        int row0 = 0;
+        for (int l = 0; l < n_loops; l++) {
+            const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+            cptr<T> org = P.consts + c.dofs + 24 * l;
+            for (int side = 0; side < 2; side++) {
+                cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
+                const int len = side == 0 ? np : ns;
+                T p[3];
+                loop_chain_positions(P, S, c, subs, len, org + 12 * side, lay.qs, lay.chain, p);
+                const T sgn = side == 0 ? T(1) : T(-1);
+                for (int t = 0; t < len; t++) {
+                    T ao[6];
+                    S.ld(lay.chain + 6 * t, ao);
+                    const T a[3] = {ao[0], ao[1], ao[2]}, d[3] = {p[0] - ao[3], p[1] - ao[4], p[2] - ao[5]};
+                    T J[3];
+                    cross3(a, d, J);
+                    int row = row0;
+                    const int sub = subs[t];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++)
+                        if (mask & (1 << ax)) {
+                            S.st1(lay.K + row * k + sub, sgn * J[ax]);
+                            row++;
+                        }
+                }
+            }
+            row0 += ((mask >> 0) & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1);
+            lp += 3 + np + ns;
+        }
+    }
+
+    // ---- G = P [1; -Kd^-1 Ki] ------------------------------------------------------------------
+    T Kd[3][3], Kdi[3][3], X[3][N];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Kd[r][j] = (r < rows && j < rows) ? S.ld1(lay.K + r * k + dep[j]) : T(r == j);
+    inv_small(rows, Kd, Kdi);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            T s = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (r < rows && j < rows) s += Kdi[r][j] * S.ld1(lay.K + j * k + ind[a]);
+            X[r][a] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        T row[N + 1];
+#pragma unroll
+        for (int bb = 0; bb <= N; bb++) row[bb] = bb == a ? T(1) : T(0);
+        S.st(lay.G + ind[a] * (N + 1), row);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (r < rows) {
+            T row[N + 1];
+#pragma unroll
+            for (int a = 0; a < N; a++) row[a] = -X[r][a];
+            row[N] = 0;
+            S.st(lay.G + dep[r] * (N + 1), row);
+        }
+    // spanning velocities qd_span = G yd
+    for (int i = 0; i < k; i++) {
+        T row[N + 1];
+        S.ld(lay.G + i * (N + 1), row);
+        T s = 0;
+#pragma unroll
+        for (int a = 0; a < N; a++) s += row[a] * yd[a];
+        S.st1(lay.qds + i, s);
+    }
+    if (!want_bias) return;
+
+    // ---- k = -Kdot qd: velocity-product acceleration of the constraint point along each chain -------
+    T kv[3] = {0, 0, 0};
+    {
+        cptr<int32_t> lp = loops;
+        int row0 = 0;
+        for (int l = 0; l < n_loops; l++) {
+            const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+            cptr<T> org = P.consts + c.dofs + 24 * l;
+            T acc[3] = {0, 0, 0};
+            for (int side = 0; side < 2; side++) {
+                cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
+                const int len = side == 0 ? np : ns;
+                T p[3];
+                loop_chain_positions(P, S, c, subs, len, org + 12 * side, lay.qs, lay.chain, p);
+                T w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, ao_[3] = {0, 0, 0}, op[3] = {0, 0, 0};
+                for (int t = 0; t <= len; t++) {
+                    T a[3] = {0, 0, 0}, o[3];
+                    T qd_t = 0;
+                    if (t < len) {
+                        T rec[6];
+                        S.ld(lay.chain + 6 * t, rec);
+                        a[0] = rec[0]; a[1] = rec[1]; a[2] = rec[2];
+                        o[0] = rec[3]; o[1] = rec[4]; o[2] = rec[5];
+                        qd_t = S.ld1(lay.qds + subs[t]);
+                    } else {
+                        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+                    }
+                    // the point o is carried rigidly by the previous frame (w, al at origin op)
+                    const T d[3] = {o[0] - op[0], o[1] - op[1], o[2] - op[2]};
+                    T wd[3], wwd[3], ad[3];
+                    cross3(w, d, wd);
+                    cross3(w, wd, wwd);
+                    cross3(al, d, ad);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { ao_[i] += ad[i] + wwd[i]; op[i] = o[i]; }
+                    // then the joint adds its own rate about a (qdd = 0)
+                    const T aq[3] = {a[0] * qd_t, a[1] * qd_t, a[2] * qd_t};
+                    T waq[3];
+                    cross3(w, aq, waq);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { al[i] += waq[i]; w[i] += aq[i]; }
+                }
+                const T sgn = side == 0 ? T(1) : T(-1);
+#pragma unroll
+                for (int i = 0; i < 3; i++) acc[i] += sgn * ao_[i];
+            }
+            int row = row0;
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++)
+                if (mask & (1 << ax)) {
+                    if (row == 0) kv[0] = -acc[ax];
+                    else if (row == 1) kv[1] = -acc[ax];
+                    else kv[2] = -acc[ax];
+                    row++;
+                }
+            row0 = row;
+            lp += 3 + np + ns;
+        }
+    }
+    // g = P [0; Kd^-1 k]
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (r < rows) S.st1(lay.G + dep[r] * (N + 1) + N, Kdi[r][0] * kv[0] + Kdi[r][1] * kv[1] + Kdi[r][2] * kv[2]);
+}
+
+// coupling of body i of a revolute cluster: spanning angle, row of G, bias g_i.
+// Explicit clusters: constants (LoopConstraint::Static, LoopConstraint.cpp:38-52);
+// implicit clusters: per state, from the step's scratch block (eval_loop_constraint).
+template <class T, int N>
+__device__ __forceinline__ void body_coupling(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c, int imp_base,
+                                              int i, cptr<T> C, const T (&y)[N], T &qi, T (&Gr)[N], T &gi)
+{
+    if (c.kind == CK_LOOP) {
+        const ImpLayout<N> lay(imp_base, c.k, c.rows);
+        T row[N + 1];
+        S.ld(lay.G + i * (N + 1), row);
+#pragma unroll
+        for (int a = 0; a < N; a++) Gr[a] = row[a];
+        gi = row[N];
+        qi = S.ld1(lay.qs + i);
+    } else {
+        cptr<T> G = C + kBodyConstFixed;
+        T s = 0;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            Gr[a] = G[a];
+            s += G[a] * y[a];
+        }
+        qi = s;
+        gi = 0;
+    }
+}
+template <class T, int N>
+__device__ __forceinline__ T rdot(const T (&G)[N], const T (&y)[N])
+{
+    T s = 0;
+#pragma unroll
+    for (int a = 0; a < N; a++) s += G[a] * y[a];
+    return s;
+}
+
 // kinematics of one revolute body: joint transform and spatial velocity.  Bodies with children
 // were handled by the forward sweep (sin/cos and v are in their slots); leaf bodies are evaluated
 // here from the parent's stored velocity, so they never occupy a slot.
-template <class T, int N>
+template <class T>
 __device__ __forceinline__ void body_kinematics(const Tables<T> &P, const Slots<T> &S, const BodyRec &b, cptr<T> C,
-                                                const T (&y)[N], T qdi, T (&sc)[2], T (&E)[9], T (&v)[6])
+                                                T qi, T qdi, T (&sc)[2], T (&E)[9], T (&v)[6])
 {
     if (b.has_child) {
         S.ld(b.slot_sc, sc);
         S.ld(b.slot_v, v);
         build_E(b.axis, sc[0], sc[1], C, E);
     } else {
-        sincos_t(gdot<T, N>(C + kBodyConstFixed, y), &sc[0], &sc[1]);
+        sincos_t(qi, &sc[0], &sc[1]);
         build_E(b.axis, sc[0], sc[1], C, E);
         if (b.parent >= 0) {
             T vp[6];
@@ -543,13 +847,16 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
         y[a] = L.y[a];
         yd[a] = L.yd[a];
     }
+    const int imp = c.slot_imp_fwd;
+    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         if (!b.has_child) continue;
         cptr<T> C = P.consts + b.cofs;
-        cptr<T> G = C + kBodyConstFixed;
+        T qi, gi, Gr[N];
+        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, Gr, gi);
         T sc[2], E[9], v[6];
-        sincos_t(gdot<T, N>(G, y), &sc[0], &sc[1]);
+        sincos_t(qi, &sc[0], &sc[1]);
         S.st(b.slot_sc, sc);
         build_E(b.axis, sc[0], sc[1], C, E);
         if (b.parent >= 0) {
@@ -560,7 +867,7 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
             for (int j = 0; j < 6; j++) v[j] = 0;
         }
-        add_axis(v, b.axis, gdot<T, N>(G, yd));
+        add_axis(v, b.axis, rdot<T, N>(Gr, yd));
         S.st(b.slot_v, v);
     }
 }
@@ -634,15 +941,21 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
         for (int bb = 0; bb < N; bb++) D[a][bb] = 0;
     }
 
+    const int imp = c.slot_imp_bwd;
+    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
+
     // in-cluster bias acceleration (the cJ part of GenericJoint.cpp:430-450), chained clusters only
     if (c.chained) {
         for (int i = 0; i < c.k; i++) {
             const BodyRec b = load_rec(P.bodies + (c.first_body + i));
             cptr<T> C = P.consts + b.cofs;
-            const T qdi = gdot<T, N>(C + kBodyConstFixed, yd);
+            T qi, gi, Gr[N];
+            body_coupling<T, N>(P, S, c, imp, i, C, y, qi, Gr, gi);
+            const T qdi = rdot<T, N>(Gr, yd);
             T sc[2], E[9], v[6], ccl[6];
-            body_kinematics<T, N>(P, S, b, C, y, qdi, sc, E, v);
+            body_kinematics<T>(P, S, b, C, qi, qdi, sc, E, v);
             vxaxis(b.axis, v, qdi, ccl);
+            add_axis(ccl, b.axis, gi);  // S_implicit * g (GenericJoint.cpp:449-450)
             if (b.lam >= 0) {
                 T cp[6], t[6];
                 const BodyRec bl = load_rec(P.bodies + (b.lam));
@@ -658,13 +971,15 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
     for (int i = c.k - 1; i >= 0; i--) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
-        cptr<T> G = C + kBodyConstFixed;
         cptr<T> Ic = C + 12;
-        const T qdi = gdot<T, N>(G, yd);
+        T qi, gi, G[N];
+        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
+        const T qdi = rdot<T, N>(G, yd);
         T sc[2], E[9], v[6];
-        body_kinematics<T, N>(P, S, b, C, y, qdi, sc, E, v);
+        body_kinematics<T>(P, S, b, C, qi, qdi, sc, E, v);
         T chat[6];
         vxaxis(b.axis, v, qdi, chat);
+        add_axis(chat, b.axis, gi);
 
         // composite articulated inertia and bias of this body
         T IA[21], psi[6];
@@ -737,7 +1052,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
         while (l >= 0) {
             const BodyRec bl = load_rec(P.bodies + (l));
             cptr<T> Cl = P.consts + bl.cofs;
-            cptr<T> Gl = Cl + kBodyConstFixed;
+            T ql, gl, Gl[N];
+            body_coupling<T, N>(P, S, c, imp, l - c.first_body, Cl, y, ql, Gl, gl);
             const T Hc = pick(f, bl.axis);
 #pragma unroll
             for (int a = 0; a < N; a++)
@@ -870,23 +1186,26 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
         ydd[a] = s;
         if (L.active) L.out[c.v_index + a] = s;
     }
-    bool loaded = false;
     T y[N], yd[N];
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        y[a] = L.y[a];
+        yd[a] = L.yd[a];
+    }
+    const int imp = c.slot_imp_acc;
+    bool evaluated = false;
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         if (!b.has_child) continue;  // nothing downstream needs this body's acceleration
-        if (!loaded) {
-#pragma unroll
-            for (int a = 0; a < N; a++) {
-                y[a] = L.y[a];
-                yd[a] = L.yd[a];
-            }
-            loaded = true;
+        if (c.kind == CK_LOOP && !evaluated) {
+            eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
+            evaluated = true;
         }
         cptr<T> C = P.consts + b.cofs;
-        cptr<T> G = C + kBodyConstFixed;
+        T qi, gi, G[N];
+        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
         T sc[2], E[9], v[6], a[6];
-        sincos_t(gdot<T, N>(G, y), &sc[0], &sc[1]);
+        sincos_t(qi, &sc[0], &sc[1]);
         build_E(b.axis, sc[0], sc[1], C, E);
         if (b.parent >= 0) {
             T vp[6], api[6];
@@ -899,13 +1218,13 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
             for (int j = 0; j < 6; j++) v[j] = 0;
             xmotion(E, C + 9, ap, a);
         }
-        const T qdi = gdot<T, N>(G, yd);
+        const T qdi = rdot<T, N>(G, yd);
         add_axis(v, b.axis, qdi);
         T chat[6];
         vxaxis(b.axis, v, qdi, chat);
 #pragma unroll
         for (int j = 0; j < 6; j++) a[j] += chat[j];
-        add_axis(a, b.axis, gdot<T, N>(G, ydd));
+        add_axis(a, b.axis, rdot<T, N>(G, ydd) + gi);
         S.st(b.slot_v3, v);
         S.st(b.slot_a3, a);
     }
@@ -959,11 +1278,14 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
         yd[a] = L.yd[a];
         ydd[a] = L.xx[a];
     }
+    const int imp = c.slot_imp_fwd;
+    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
-        cptr<T> G = C + kBodyConstFixed;
-        const T qi = gdot<T, N>(G, y), qdi = gdot<T, N>(G, yd), qddi = gdot<T, N>(G, ydd);
+        T qi, gi, G[N];
+        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
+        const T qdi = rdot<T, N>(G, yd), qddi = rdot<T, N>(G, ydd) + gi;
         T sc[2], E[9], v[6], a[6];
         sincos_t(qi, &sc[0], &sc[1]);
         if (b.parent >= 0) S.st(b.slot_sc, sc);
@@ -1030,13 +1352,20 @@ template <class T, int N>
 __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                 const Lane<T> &L)
 {
-    T tau[N];
+    T tau[N], y[N], yd[N];
 #pragma unroll
-    for (int a = 0; a < N; a++) tau[a] = 0;
+    for (int a = 0; a < N; a++) {
+        tau[a] = 0;
+        y[a] = L.y[a];
+        yd[a] = L.yd[a];
+    }
+    const int imp = c.slot_imp_bwd;
+    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
     for (int i = c.k - 1; i >= 0; i--) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
-        cptr<T> G = C + kBodyConstFixed;
+        T qi, gi, G[N];
+        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
         T f[6];
         S.ld(b.slot_f, f);
         const T t = pick(f, b.axis);

@@ -111,6 +111,17 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             if (cl.n_dbl < cl.n_span_vel * cl.n_vel || cl.dbl_offset < 0 || cl.dbl_offset + cl.n_dbl > m.h->n_doubles)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: G payload missing", c);
             cr.kind = CK_STATIC;
+        } else if (cl.constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION) {
+            if (cl.n_vel < 1 || cl.n_vel > kMaxClusterDof)
+                return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d DoF exceed the kernel limit", c, cl.n_vel);
+            if (cl.n_span_vel != cl.n_bodies || cl.n_span_pos != cl.n_bodies || cl.n_pos != cl.n_bodies)
+                return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop cluster must have one revolute joint per body", c);
+            if (cl.n_constraint_rows < 1 || cl.n_constraint_rows > 3 || cl.n_constraint_rows != cl.n_bodies - cl.n_vel)
+                return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d constraint rows (1..3 supported)", c, cl.n_constraint_rows);
+            if (cl.int_offset < 0 || cl.int_offset + cl.n_int > m.h->n_ints || cl.n_int < 1 + cl.n_bodies)
+                return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop payload missing", c);
+            cr.kind = CK_LOOP;
+            cr.rows = cl.n_constraint_rows;
         } else {
             return fail(msg, cap, GRBDA_EUNSUPPORTED,
                         "cluster %d: implicit loop constraint kind %d is not covered by the HIP kernels yet", c,
@@ -121,7 +132,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             const grbda_desc_body &b = m.bodies[gb];
             if (b.cluster != c || b.sub_index != i) return fail(msg, cap, GRBDA_EINVAL, "body %d: cluster/sub index", gb);
             if (b.parent >= gb) return fail(msg, cap, GRBDA_EINVAL, "body %d: parent not earlier", gb);
-            if (cr.kind == CK_STATIC && (b.joint_type != GRBDA_JOINT_REVOLUTE || b.axis < 0 || b.axis > 2))
+            if (cr.kind != CK_FREE && (b.joint_type != GRBDA_JOINT_REVOLUTE || b.axis < 0 || b.axis > 2))
                 return fail(msg, cap, GRBDA_EINVAL, "body %d: bad joint", gb);
             BodyRec &br = bodies[gb];
             br.parent = b.parent;
@@ -170,6 +181,37 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             const double *G = m.dbls + cl.dbl_offset;  // n_span_vel x n_vel
             for (int j = 0; j < cl.n_vel; j++) P.consts.push_back(G[bd.sub_index * cl.n_vel + j]);
         }
+    }
+
+    // ---- implicit-loop payload -------------------------------------------------------------------
+    for (int c = 0; c < nc; c++) {
+        const grbda_desc_cluster &cl = m.clusters[c];
+        if (clusters[c].kind != CK_LOOP) continue;
+        const int32_t *ip = m.ints + cl.int_offset;
+        const double *dp = m.dbls + cl.dbl_offset;
+        const int k = cl.n_bodies, n_loops = ip[0];
+        clusters[c].iofs = static_cast<int>(P.cints.size());
+        clusters[c].dofs = static_cast<int>(P.consts.size());
+        P.cints.push_back(n_loops);
+        std::vector<int> ind, dep;
+        for (int i = 0; i < k; i++) (ip[1 + i] ? ind : dep).push_back(i);
+        if (static_cast<int>(ind.size()) != cl.n_vel || static_cast<int>(dep.size()) != cl.n_constraint_rows)
+            return fail(msg, cap, GRBDA_EINVAL, "cluster %d: independent/dependent coordinate counts", c);
+        P.cints.push_back(static_cast<int>(ind.size()));
+        for (int i : ind) P.cints.push_back(i);
+        P.cints.push_back(static_cast<int>(dep.size()));
+        for (int i : dep) P.cints.push_back(i);
+        const int32_t *lp = ip + 1 + k;
+        int rows = 0;
+        for (int l = 0; l < n_loops; l++) {
+            const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+            if (np < 0 || ns < 0 || np > k || ns > k) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: bad loop chain", c);
+            for (int t = 0; t < 3 + np + ns; t++) P.cints.push_back(lp[t]);
+            lp += 3 + np + ns;
+            for (int a = 0; a < 3; a++) rows += (mask >> a) & 1;
+            for (int t = 0; t < 24; t++) P.consts.push_back(dp[24 * l + t]);
+        }
+        if (rows != cl.n_constraint_rows) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop rows mismatch", c);
     }
 
     // ---- sweep schedule: depth-first, a subtree is swept forward then backward ------------------
@@ -289,6 +331,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
     auto cluster_of = [&](int b) { return m.bodies[b].cluster; };
     auto build_layout = [&](Layout &L, int lds_budget) {
         L.clusters = clusters;
+        L.rnea_clusters = clusters;
         L.bodies = bodies;
         L.rnea_bodies = bodies;
         // ---- ABA ----
@@ -318,8 +361,15 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
         for (int c = 0; c < nc; c++) {
             ClusterRec &cr = L.clusters[c];
             objs.push_back({&cr.slot_y0, cr.n, 3, tB[c], tA[c], -1});
-            if (cr.kind == CK_STATIC) objs.push_back({&cr.slot_K, 6 * cr.n, 3, tB[c], tA[c], -1});
+            if (cr.kind != CK_FREE) objs.push_back({&cr.slot_K, 6 * cr.n, 3, tB[c], tA[c], -1});
             else cr.slot_K = -1;
+            cr.slot_imp_fwd = cr.slot_imp_bwd = cr.slot_imp_acc = -1;
+            if (cr.kind == CK_LOOP) {
+                const int sz = cr.k * (cr.n + 1) + cr.rows * cr.k + cr.k + cr.k + 6 * cr.k;
+                objs.push_back({&cr.slot_imp_fwd, sz, 1, tF[c], tF[c], -1});
+                objs.push_back({&cr.slot_imp_bwd, sz, 1, tB[c], tB[c], -1});
+                objs.push_back({&cr.slot_imp_acc, sz, 1, tA[c], tA[c], -1});
+            }
         }
         int nl = 0, ng = 0;
         allocate(objs, lds_budget, nl, ng);
@@ -377,6 +427,17 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
                     if (bodies[j].parent == b) last_child_fwd = std::max(last_child_fwd, tRF[cluster_of(j)]);
                 robjs.push_back({&br.slot_v, 6, 0, tRF[c], last_child_fwd, -1});
                 robjs.push_back({&br.slot_a3, 6, 0, tRF[c], last_child_fwd, -1});
+            }
+        }
+        for (int c = 0; c < nc; c++) {
+            ClusterRec &cr = L.rnea_clusters[c];
+            cr.slot_K = cr.slot_y0 = cr.slot_imp_fwd = cr.slot_imp_bwd = cr.slot_imp_acc = -1;
+            cr.parent_slot_IA = cr.parent_slot_psi = cr.parent_slot_v3 = cr.parent_slot_a3 = -1;
+            cr.carry_out = 0;
+            if (cr.kind == CK_LOOP) {
+                const int sz = cr.k * (cr.n + 1) + cr.rows * cr.k + cr.k + cr.k + 6 * cr.k;
+                robjs.push_back({&cr.slot_imp_fwd, sz, 1, tRF[c], tRF[c], -1});
+                robjs.push_back({&cr.slot_imp_bwd, sz, 1, tRB[c], tRB[c], -1});
             }
         }
         allocate(robjs, lds_budget, nl, ng);

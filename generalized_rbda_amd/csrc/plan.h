@@ -34,7 +34,9 @@ enum StepOp : int32_t {
 
 enum ClusterKind : int32_t {
     CK_STATIC = 0,  // revolute single joints, constant G (every explicit ClusterJoint type)
-    CK_FREE = 1     // floating base root (ClusterJoints::Free)
+    CK_FREE = 1,    // floating base root (ClusterJoints::Free)
+    CK_LOOP = 2     // implicit position-loop constraint (LoopConstraint::GenericImplicit built from URDF+
+                    // <loop> elements, ClusterTreeParsing.cpp:310-376): G(q), g(q, qd) per state
 };
 
 constexpr int kMaxClusterDof = 4;     // n of a non-free cluster handled in registers
@@ -65,7 +67,12 @@ struct ClusterRec {
     int32_t parent_slot_a3;
     int32_t carry_out;        // 1: the contribution to parent_body is handed over in registers to the
                               //    next step (= backward step of the parent cluster) instead of slots
-    int32_t reserved[1];
+    int32_t rows;             // implicit clusters: number of constraint rows (= dependent coordinates)
+    // implicit clusters: per-step scratch block [G rows k*(n+1)] [K rows*k] [qd_span k] [q_span k] [chain 6k]
+    int32_t slot_imp_fwd, slot_imp_bwd, slot_imp_acc;
+    int32_t iofs;             // offset into cints[]: n_loops, n_ind, ind[], n_dep, dep[], loops...
+    int32_t dofs;             // offset into consts[]: per loop pred origin E[9] r[3], succ origin E[9] r[3]
+    int32_t reserved[3];
 };
 
 struct BodyRec {
@@ -99,7 +106,8 @@ constexpr int kBodyConstFixed = 9 + 3 + 21;
 
 // slot layout for one scalar width (the LDS budget in slots depends on sizeof(T))
 struct Layout {
-    std::vector<ClusterRec> clusters;
+    std::vector<ClusterRec> clusters;       // ABA slots
+    std::vector<ClusterRec> rnea_clusters;  // RNEA slots (slot_imp_fwd / slot_imp_bwd used)
     std::vector<BodyRec> bodies;       // ABA slots
     std::vector<BodyRec> rnea_bodies;  // RNEA slots (slot_sc, slot_v, slot_a3, slot_f used)
     int n_lds_aba = 0, n_glb_aba = 0;
@@ -113,6 +121,7 @@ struct HostPlan {
     std::vector<Step> aba_steps;
     std::vector<Step> rnea_steps;
     std::vector<double> consts;  // converted to float on upload for the f32 kernels
+    std::vector<int32_t> cints;  // integer payload of implicit constraints
     Layout lay32, lay64;
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;

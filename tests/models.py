@@ -1,6 +1,8 @@
 """Model zoo for the tests: the reference's uniform chains plus seeded random cluster trees that
 exercise every explicit cluster-joint type the reference has (testRigidBodyDynamicsAlgos.cpp:94-109
 uses the same families with random parameters)."""
+import os
+
 import numpy as np
 
 from generalized_rbda_amd import modeldesc as md
@@ -94,9 +96,37 @@ def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor"
     return m
 
 
+ROBOT_MODELS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robot-models")
+
+
+def valid_states(blob, B, config_index=0):
+    """random_states + (for implicit-loop clusters) Newton projection of the dependent positions onto
+    phi(q) = 0 with the oracle, rejecting states that do not converge (GenericJoint.cpp:289-385)."""
+    import oracle_py as O
+    from generalized_rbda_amd.states import parse_clusters, random_states
+
+    if not any(c[9] >= 2 for c in parse_clusters(blob)["clusters"]):
+        return random_states(blob, B, config_index)
+    qs, qds, taus = [], [], []
+    have, attempt = 0, 0
+    while have < B:
+        q, qd, tau = random_states(blob, max(2 * B, 16), config_index + 7919 * attempt)
+        q, ok = O.project_positions(blob, q)
+        qs.append(q[ok]); qds.append(qd[ok]); taus.append(tau[ok])
+        have += int(ok.sum())
+        attempt += 1
+        if attempt > 50:
+            raise RuntimeError("could not sample valid loop states")
+    return np.concatenate(qs)[:B], np.concatenate(qds)[:B], np.concatenate(taus)[:B]
+
+
 def zoo():
     """name -> model description bytes"""
+    import generalized_rbda_amd as G
+
     z = {}
+    for name in ("four_bar", "six_bar", "planar_leg_linkage", "mini_cheetah", "mit_humanoid"):
+        z["urdf_" + name] = G.urdf_to_blob(os.path.join(ROBOT_MODELS, name + ".urdf"))
     for n in (2, 3, 4):
         z[f"rev_rotor_chain_{n}"] = md.revolute_chain_with_rotor(n).serialize()
     for n in (2, 4):

@@ -15,7 +15,7 @@ import oracle_py as O
 import generalized_rbda_amd as G
 from generalized_rbda_amd import modeldesc as md
 from generalized_rbda_amd.states import random_states
-from models import zoo
+from models import valid_states, zoo
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,7 +44,7 @@ def test_aba_and_rnea_fp64_match_oracle(name, blob, gpu):
 
     plan = G.Plan(blob)
     for B in (1, 63, 64, 200):
-        q, qd, tau = random_states(blob, B, config_index=21)
+        q, qd, tau = valid_states(blob, B, config_index=21)
         ref = O.forward_dynamics(blob, q, qd, tau)
         got = run_gpu(plan, "aba", q, qd, tau, torch.float64, gpu)
         assert rel_err(got, ref) < TOL64, f"ABA B={B}"
@@ -58,7 +58,7 @@ def test_aba_and_rnea_fp32_match_oracle(name, blob, gpu):
     import torch
 
     plan = G.Plan(blob)
-    q, qd, tau = random_states(blob, 500, config_index=22)
+    q, qd, tau = valid_states(blob, 500, config_index=22)
     q32, qd32, tau32 = (a.astype(np.float32).astype(np.float64) for a in (q, qd, tau))
     ref = O.forward_dynamics(blob, q32, qd32, tau32)
     got = run_gpu(plan, "aba", q32, qd32, tau32, torch.float32, gpu)
@@ -91,7 +91,7 @@ def test_id_of_fd_roundtrip_large_batch(gpu):
     blob = zoo()["tree_mixed_float"]
     plan = G.Plan(blob)
     B = 100_000
-    q, qd, tau = random_states(blob, B, config_index=23)
+    q, qd, tau = valid_states(blob, B, config_index=23)
     t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=gpu)
     tq, tqd, ttau = t(q), t(qd), t(tau)
     ydd = plan.forward_dynamics(tq, tqd, ttau)
@@ -108,7 +108,7 @@ def test_id_of_fd_roundtrip_large_batch(gpu):
 def test_host_convenience_entry_points(gpu):
     blob = zoo()["rev_pair_rotor_chain_4"]
     plan = G.Plan(blob)
-    q, qd, tau = random_states(blob, 5, config_index=24)
+    q, qd, tau = valid_states(blob, 5, config_index=24)
     assert rel_err(plan.forward_dynamics_host(q, qd, tau), O.forward_dynamics(blob, q, qd, tau)) < TOL64
     assert rel_err(plan.inverse_dynamics_host(q, qd, tau), O.inverse_dynamics(blob, q, qd, tau)) < TOL64
 
@@ -118,7 +118,7 @@ def test_lds_budget_does_not_change_results(gpu, monkeypatch):
     import torch
 
     blob = zoo()["tree_mixed_float"]
-    q, qd, tau = random_states(blob, 300, config_index=25)
+    q, qd, tau = valid_states(blob, 300, config_index=25)
     outs = []
     for lds in ("0", "4096", "65536"):
         monkeypatch.setenv("GRBDA_LDS_BYTES_PER_WAVE", lds)

@@ -13,7 +13,7 @@ import pytest
 import oracle_py as O
 from generalized_rbda_amd import modeldesc as md
 from generalized_rbda_amd.states import random_states
-from models import zoo
+from models import valid_states, zoo
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -40,7 +40,7 @@ def test_oracle_matches_reference_codegen(case):
 
 @pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
 def test_oracle_cross_algorithm_identities(name, blob):
-    q, qd, tau = random_states(blob, 20, config_index=11)
+    q, qd, tau = valid_states(blob, 20, config_index=11)
     fd = O.forward_dynamics(blob, q, qd, tau)
     pj = O.forward_dynamics_projection(blob, q, qd, tau)
     scale = 1 + np.abs(fd).max()
@@ -51,7 +51,7 @@ def test_oracle_cross_algorithm_identities(name, blob):
 
 def test_oracle_external_forces_consistent():
     blob = zoo()["tree_mixed_float"]
-    q, qd, tau = random_states(blob, 8, config_index=12)
+    q, qd, tau = valid_states(blob, 8, config_index=12)
     nb = len(blob) and __import__("generalized_rbda_amd.states", fromlist=["parse_clusters"]).parse_clusters(blob)["nb"]
     fext = np.random.default_rng(3).uniform(-1, 1, (8, nb, 6))
     fd = O.forward_dynamics(blob, q, qd, tau, fext)
@@ -64,5 +64,5 @@ def test_oracle_external_forces_consistent():
 
 def test_oracle_mt_matches_single_thread():
     blob = zoo()["tree_rotor_float"]
-    q, qd, tau = random_states(blob, 257, config_index=13)
+    q, qd, tau = valid_states(blob, 257, config_index=13)
     assert np.array_equal(O.forward_dynamics(blob, q, qd, tau), O.forward_dynamics_mt(blob, q, qd, tau, 4))
