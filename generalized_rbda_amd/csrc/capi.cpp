@@ -155,6 +155,8 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea)
     d.n_lds_slots = rnea ? L.n_lds_rnea : L.n_lds_aba;
     d.n_glb_slots = rnea ? L.n_glb_rnea : L.n_glb_aba;
     d.ori_repr = h.ori_repr;
+    d.has_loop = 0;
+    for (const ClusterRec &cr : L.clusters) d.has_loop |= cr.kind == CK_LOOP;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     return d;
 }

@@ -18,6 +18,7 @@ struct DevPlan {
     int n_lds_slots, n_glb_slots;
     int lds_bytes;  // dynamic LDS actually allocated per wave (slot store / input staging area)
     int ori_repr;
+    int has_loop;  // the model contains implicit-loop clusters: launch the kernel variant that supports them
     T a_root[6];  // -gravity (ClusterTreeDynamics.cpp:147)
 };
 

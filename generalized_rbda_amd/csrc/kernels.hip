@@ -613,7 +613,7 @@ __device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const S
 
 // G rows, g, spanning positions / velocities of an implicit-loop cluster into the scratch block
 template <class T, int N>
-__device__ __forceinline__ void eval_loop_constraint(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+__device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                      const Lane<T> &L, int base, const T (&yd)[N], bool want_bias)
 {
     const ImpLayout<N> lay(base, c.k, c.rows);
@@ -772,34 +772,52 @@ __device__ __forceinline__ void eval_loop_constraint(const Tables<T> &P, const S
 }
 
 // coupling of body i of a revolute cluster: spanning angle, row of G, bias g_i.
-// Explicit clusters: constants (LoopConstraint::Static, LoopConstraint.cpp:38-52);
+// Explicit clusters: constants (LoopConstraint::Static, LoopConstraint.cpp:38-52), kept on the
+// scalar side (ConstRow: the row stays in SGPRs / the constant cache);
 // implicit clusters: per state, from the step's scratch block (eval_loop_constraint).
+template <class T>
+struct ConstRow {
+    cptr<T> p;
+    __device__ __forceinline__ T operator[](int a) const { return p[a]; }
+};
 template <class T, int N>
+struct RegRow {
+    T v[N];
+    __device__ __forceinline__ T operator[](int a) const { return v[a]; }
+};
+template <class T, int N, bool LOOP>
+struct RowSel {
+    using type = ConstRow<T>;
+};
+template <class T, int N>
+struct RowSel<T, N, true> {
+    using type = RegRow<T, N>;
+};
+
+template <class T, int N, bool LOOP>
 __device__ __forceinline__ void body_coupling(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c, int imp_base,
-                                              int i, cptr<T> C, const T (&y)[N], T &qi, T (&Gr)[N], T &gi)
+                                              int i, cptr<T> C, const T (&y)[N], T &qi,
+                                              typename RowSel<T, N, LOOP>::type &Gr, T &gi)
 {
-    if (c.kind == CK_LOOP) {
+    if constexpr (LOOP) {
         const ImpLayout<N> lay(imp_base, c.k, c.rows);
         T row[N + 1];
         S.ld(lay.G + i * (N + 1), row);
 #pragma unroll
-        for (int a = 0; a < N; a++) Gr[a] = row[a];
+        for (int a = 0; a < N; a++) Gr.v[a] = row[a];
         gi = row[N];
         qi = S.ld1(lay.qs + i);
     } else {
-        cptr<T> G = C + kBodyConstFixed;
+        Gr.p = C + kBodyConstFixed;
         T s = 0;
 #pragma unroll
-        for (int a = 0; a < N; a++) {
-            Gr[a] = G[a];
-            s += G[a] * y[a];
-        }
+        for (int a = 0; a < N; a++) s += Gr.p[a] * y[a];
         qi = s;
         gi = 0;
     }
 }
-template <class T, int N>
-__device__ __forceinline__ T rdot(const T (&G)[N], const T (&y)[N])
+template <class T, int N, class Row>
+__device__ __forceinline__ T rdot(const Row &G, const T (&y)[N])
 {
     T s = 0;
 #pragma unroll
@@ -837,7 +855,7 @@ __device__ __forceinline__ void body_kinematics(const Tables<T> &P, const Slots<
 // ABA sweep 1: ClusterTreeNode::updateKinematics + TreeModel::forwardKinematics
 // (ClusterTreeNode.cpp:26-31, TreeModel.cpp:6-32) -- only bodies that have children
 // ---------------------------------------------------------------------------------------------
-template <class T, int N>
+template <class T, int N, bool LOOP>
 __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
@@ -848,13 +866,14 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
         yd[a] = L.yd[a];
     }
     const int imp = c.slot_imp_fwd;
-    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
+    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         if (!b.has_child) continue;
         cptr<T> C = P.consts + b.cofs;
-        T qi, gi, Gr[N];
-        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, Gr, gi);
+        T qi, gi;
+        typename RowSel<T, N, LOOP>::type Gr;
+        body_coupling<T, N, LOOP>(P, S, c, imp, i, C, y, qi, Gr, gi);
         T sc[2], E[9], v[6];
         sincos_t(qi, &sc[0], &sc[1]);
         S.st(b.slot_sc, sc);
@@ -919,7 +938,7 @@ __device__ __forceinline__ void free_base_accel(const Tables<T> &P, const Cluste
 // ABA sweep 2 (fused 2a + 2b): updateArticulatedBodies + bias back-propagation
 // (ClusterTreeDynamics.cpp:94-129,157-191; ClusterTreeNode.cpp:33-37)
 // ---------------------------------------------------------------------------------------------
-template <class T, int N>
+template <class T, int N, bool LOOP>
 __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L, Carry<T> &carry)
 {
@@ -942,15 +961,16 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
     }
 
     const int imp = c.slot_imp_bwd;
-    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
+    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
 
     // in-cluster bias acceleration (the cJ part of GenericJoint.cpp:430-450), chained clusters only
     if (c.chained) {
         for (int i = 0; i < c.k; i++) {
             const BodyRec b = load_rec(P.bodies + (c.first_body + i));
             cptr<T> C = P.consts + b.cofs;
-            T qi, gi, Gr[N];
-            body_coupling<T, N>(P, S, c, imp, i, C, y, qi, Gr, gi);
+            T qi, gi;
+            typename RowSel<T, N, LOOP>::type Gr;
+            body_coupling<T, N, LOOP>(P, S, c, imp, i, C, y, qi, Gr, gi);
             const T qdi = rdot<T, N>(Gr, yd);
             T sc[2], E[9], v[6], ccl[6];
             body_kinematics<T>(P, S, b, C, qi, qdi, sc, E, v);
@@ -972,8 +992,9 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
         cptr<T> Ic = C + 12;
-        T qi, gi, G[N];
-        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
+        T qi, gi;
+        typename RowSel<T, N, LOOP>::type G;
+        body_coupling<T, N, LOOP>(P, S, c, imp, i, C, y, qi, G, gi);
         const T qdi = rdot<T, N>(G, yd);
         T sc[2], E[9], v[6];
         body_kinematics<T>(P, S, b, C, qi, qdi, sc, E, v);
@@ -1052,8 +1073,9 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
         while (l >= 0) {
             const BodyRec bl = load_rec(P.bodies + (l));
             cptr<T> Cl = P.consts + bl.cofs;
-            T ql, gl, Gl[N];
-            body_coupling<T, N>(P, S, c, imp, l - c.first_body, Cl, y, ql, Gl, gl);
+            T ql, gl;
+            typename RowSel<T, N, LOOP>::type Gl;
+            body_coupling<T, N, LOOP>(P, S, c, imp, l - c.first_body, Cl, y, ql, Gl, gl);
             const T Hc = pick(f, bl.axis);
 #pragma unroll
             for (int a = 0; a < N; a++)
@@ -1165,7 +1187,7 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
 // ABA sweep 3: joint accelerations (ClusterTreeDynamics.cpp:131-152).  Velocities of bodies with
 // children are recomputed on the way down (cheaper than keeping them live across the sweeps).
 // ---------------------------------------------------------------------------------------------
-template <class T, int N>
+template <class T, int N, bool LOOP>
 __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
@@ -1197,13 +1219,16 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         if (!b.has_child) continue;  // nothing downstream needs this body's acceleration
-        if (c.kind == CK_LOOP && !evaluated) {
-            eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
-            evaluated = true;
+        if constexpr (LOOP) {
+            if (!evaluated) {
+                eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
+                evaluated = true;
+            }
         }
         cptr<T> C = P.consts + b.cofs;
-        T qi, gi, G[N];
-        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
+        T qi, gi;
+        typename RowSel<T, N, LOOP>::type G;
+        body_coupling<T, N, LOOP>(P, S, c, imp, i, C, y, qi, G, gi);
         T sc[2], E[9], v[6], a[6];
         sincos_t(qi, &sc[0], &sc[1]);
         build_E(b.axis, sc[0], sc[1], C, E);
@@ -1267,7 +1292,7 @@ __device__ __forceinline__ void aba_fwd_free(const Tables<T> &P, const Slots<T> 
 // ---------------------------------------------------------------------------------------------
 // RNEA (TreeModel.cpp:34-57,173-212)
 // ---------------------------------------------------------------------------------------------
-template <class T, int N>
+template <class T, int N, bool LOOP>
 __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                 const Lane<T> &L)
 {
@@ -1279,12 +1304,13 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
         ydd[a] = L.xx[a];
     }
     const int imp = c.slot_imp_fwd;
-    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
+    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
-        T qi, gi, G[N];
-        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
+        T qi, gi;
+        typename RowSel<T, N, LOOP>::type G;
+        body_coupling<T, N, LOOP>(P, S, c, imp, i, C, y, qi, G, gi);
         const T qdi = rdot<T, N>(G, yd), qddi = rdot<T, N>(G, ydd) + gi;
         T sc[2], E[9], v[6], a[6];
         sincos_t(qi, &sc[0], &sc[1]);
@@ -1348,7 +1374,7 @@ __device__ __forceinline__ void rnea_fwd_free(const Tables<T> &P, const Slots<T>
     S.st(b.slot_f, f);
 }
 
-template <class T, int N>
+template <class T, int N, bool LOOP>
 __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                 const Lane<T> &L)
 {
@@ -1360,12 +1386,13 @@ __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<
         yd[a] = L.yd[a];
     }
     const int imp = c.slot_imp_bwd;
-    if (c.kind == CK_LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
+    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
     for (int i = c.k - 1; i >= 0; i--) {
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
-        T qi, gi, G[N];
-        body_coupling<T, N>(P, S, c, imp, i, C, y, qi, G, gi);
+        T qi, gi;
+        typename RowSel<T, N, LOOP>::type G;
+        body_coupling<T, N, LOOP>(P, S, c, imp, i, C, y, qi, G, gi);
         T f[6];
         S.ld(b.slot_f, f);
         const T t = pick(f, b.axis);
@@ -1399,15 +1426,28 @@ __device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T>
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define GRBDA_DISPATCH_N(n, CALL)                  \
-    switch (n) {                                   \
-        case 1: { constexpr int N_ = 1; CALL; } break; \
-        case 2: { constexpr int N_ = 2; CALL; } break; \
-        case 3: { constexpr int N_ = 3; CALL; } break; \
-        default: { constexpr int N_ = 4; CALL; } break; \
+// HAS_LOOP is a kernel template parameter: models without implicit-loop clusters run a kernel that
+// does not contain the loop-constraint code at all (code size and register pressure matter: the
+// interpreter loop must stay resident in the instruction cache)
+#define GRBDA_DISPATCH_N(c, FN, ...)                                                        \
+    if (HAS_LOOP && (c).kind == CK_LOOP) {                                                     \
+        if constexpr (HAS_LOOP) {                                                              \
+            switch ((c).n) {                                                                   \
+                case 1: FN<T, 1, true>(__VA_ARGS__); break;                                    \
+                case 2: FN<T, 2, true>(__VA_ARGS__); break;                                    \
+                default: FN<T, 3, true>(__VA_ARGS__); break;                                   \
+            }                                                                                  \
+        }                                                                                      \
+    } else {                                                                                   \
+        switch ((c).n) {                                                                       \
+            case 1: FN<T, 1, false>(__VA_ARGS__); break;                                       \
+            case 2: FN<T, 2, false>(__VA_ARGS__); break;                                       \
+            case 3: FN<T, 3, false>(__VA_ARGS__); break;                                       \
+            default: FN<T, 4, false>(__VA_ARGS__); break;                                      \
+        }                                                                                      \
     }
 
-template <class T>
+template <class T, bool HAS_LOOP>
 __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                      const T *__restrict__ qd, const T *__restrict__ tau,
                                                      T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
@@ -1462,26 +1502,26 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (aba_fwd_static<T, N_>(P, S, c, L)))
+                    GRBDA_DISPATCH_N(c, aba_fwd_static, P, S, c, L)
                 }
             } else if (st.op == OP_ABA_BWD) {
                 if (c.kind == CK_FREE) {
                     aba_bwd_free(P, S, c, L, carry);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (aba_bwd_static<T, N_>(P, S, c, L, carry)))
+                    GRBDA_DISPATCH_N(c, aba_bwd_static, P, S, c, L, carry)
                 }
             } else {
                 if (c.kind == CK_FREE) {
                     aba_acc_free(P, S, c, L);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (aba_acc_static<T, N_>(P, S, c, L)))
+                    GRBDA_DISPATCH_N(c, aba_acc_static, P, S, c, L)
                 }
             }
         }
     }
 }
 
-template <class T>
+template <class T, bool HAS_LOOP>
 __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                       const T *__restrict__ qd, const T *__restrict__ ydd,
                                                       T *__restrict__ tau, size_t B, T *__restrict__ scratch)
@@ -1531,13 +1571,13 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
                 if (c.kind == CK_FREE) {
                     rnea_fwd_free(P, S, c, L);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (rnea_fwd_static<T, N_>(P, S, c, L)))
+                    GRBDA_DISPATCH_N(c, rnea_fwd_static, P, S, c, L)
                 }
             } else {
                 if (c.kind == CK_FREE) {
                     rnea_bwd_free(P, S, c, L);
                 } else {
-                    GRBDA_DISPATCH_N(c.n, (rnea_bwd_static<T, N_>(P, S, c, L)))
+                    GRBDA_DISPATCH_N(c, rnea_bwd_static, P, S, c, L)
                 }
             }
         }
@@ -1551,14 +1591,20 @@ template <class T>
 hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch,
                       int grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(aba_kernel<T>, dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    if (P.has_loop)
+        hipLaunchKernelGGL((aba_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    else
+        hipLaunchKernelGGL((aba_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
 template <class T>
 hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch,
                        int grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(rnea_kernel<T>, dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    if (P.has_loop)
+        hipLaunchKernelGGL((rnea_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else
+        hipLaunchKernelGGL((rnea_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
 }
 
@@ -1573,16 +1619,19 @@ template hipError_t launch_rnea<double>(const DevPlan<double> &, const double *,
 
 hipError_t set_max_dynamic_lds()
 {
-    hipError_t e;
     const int maxb = 160 * 1024;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_kernel<float>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_kernel<double>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_kernel<float>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_kernel<double>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxb)) != hipSuccess) return e;
+    const void *fns[] = {reinterpret_cast<const void *>(&aba_kernel<float, false>),
+                         reinterpret_cast<const void *>(&aba_kernel<float, true>),
+                         reinterpret_cast<const void *>(&aba_kernel<double, false>),
+                         reinterpret_cast<const void *>(&aba_kernel<double, true>),
+                         reinterpret_cast<const void *>(&rnea_kernel<float, false>),
+                         reinterpret_cast<const void *>(&rnea_kernel<float, true>),
+                         reinterpret_cast<const void *>(&rnea_kernel<double, false>),
+                         reinterpret_cast<const void *>(&rnea_kernel<double, true>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+        if (e != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 
