@@ -837,7 +837,13 @@ __device__ __forceinline__ void body_kinematics(const Tables<T> &P, const Slots<
         S.ld(b.slot_v, v);
         build_E(b.axis, sc[0], sc[1], C, E);
     } else {
-        sincos_t(qi, &sc[0], &sc[1]);
+        if (b.axisym) {
+            // rotor: every quantity handed to the parent is independent of the joint angle; use q = 0
+            sc[0] = 0;
+            sc[1] = 1;
+        } else {
+            sincos_t(qi, &sc[0], &sc[1]);
+        }
         build_E(b.axis, sc[0], sc[1], C, E);
         if (b.parent >= 0) {
             T vp[6];
@@ -1026,6 +1032,11 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
             for (int j = 0; j < 21; j++) IA[j] = Ic[j];
         }
+        if (b.xofs >= 0) {  // constant inertia of the axisymmetric leaf children (rotors)
+            cptr<T> Xc = P.consts + b.xofs;
+#pragma unroll
+            for (int j = 0; j < 21; j++) IA[j] += Xc[j];
+        }
 
         T h[6];
         column(IA, b.axis, h);
@@ -1048,15 +1059,25 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
             for (int j = 0; j < 6; j++) t[j] = psi[j] + Ic_c[j];
             xforce_inv(E, C + 9, t, tp);
-            congruence(E, C + 9, IA, Bc);
-            if (c.carry_out && b.lam < 0) {
+            if (b.axisym) {
+                // X0^T I X0 is already part of the parent's constants (xofs)
+                if (c.carry_out && b.lam < 0) {
 #pragma unroll
-                for (int j = 0; j < 6; j++) ppsi[j] += tp[j];
-#pragma unroll
-                for (int j = 0; j < 21; j++) pIA[j] += Bc[j];
+                    for (int j = 0; j < 6; j++) ppsi[j] += tp[j];
+                } else {
+                    S.acc(b.parent_slot_psi, tp, b.acc_first);
+                }
             } else {
-                S.acc(b.parent_slot_psi, tp, b.acc_first);
-                S.acc(b.parent_slot_IA, Bc, b.acc_first);
+                congruence(E, C + 9, IA, Bc);
+                if (c.carry_out && b.lam < 0) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) ppsi[j] += tp[j];
+#pragma unroll
+                    for (int j = 0; j < 21; j++) pIA[j] += Bc[j];
+                } else {
+                    S.acc(b.parent_slot_psi, tp, b.acc_first);
+                    S.acc(b.parent_slot_IA, Bc, b.acc_first_IA);
+                }
             }
         }
 
@@ -1136,7 +1157,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             for (int j = 0; j < 21; j++) carry.IA[j] = pIA[j] + dI[j];
         } else {
             S.acc(c.parent_slot_psi, dp, 0);
-            S.acc(c.parent_slot_IA, dI, 0);
+            S.acc(c.parent_slot_IA, dI, c.corr_first_IA);
         }
     }
 }
@@ -1169,6 +1190,11 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
     } else {
 #pragma unroll
         for (int j = 0; j < 21; j++) IA[j] = Ic[j];
+    }
+    if (b.xofs >= 0) {
+        cptr<T> Xc = P.consts + b.xofs;
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] += Xc[j];
     }
     T D[6][6], u[6];
 #pragma unroll

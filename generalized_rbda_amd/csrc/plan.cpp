@@ -183,6 +183,70 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
         }
     }
 
+    // ---- axisymmetric leaf bodies (rotors) ------------------------------------------------------------
+    // If I is invariant under rotation about the joint axis (COM on the axis, equal transverse
+    // inertias) then X(q)^T I X(q), X(q)^T I s and X(q)^T (v x* I v) are independent of q: the body is
+    // evaluated at q = 0, and its inertia contribution to the parent is the constant X0^T I X0.
+    for (int b = 0; b < nb; b++) bodies[b].xofs = -1;
+    {
+        std::vector<std::vector<double>> extra(nb);
+        auto at = [](const double *M, int i, int j) { return M[i * 6 + j]; };
+        for (int b = 0; b < nb; b++) {
+            const grbda_desc_body &bd = m.bodies[b];
+            if (bodies[b].has_child || bd.joint_type != GRBDA_JOINT_REVOLUTE || bd.parent < 0) continue;
+            if (clusters[bd.cluster].kind == CK_LOOP) continue;
+            bool inv = true;
+            double scale = 0;
+            for (int i = 0; i < 36; i++) scale = std::max(scale, std::fabs(bd.inertia[i]));
+            for (double th : {0.7, 1.9}) {
+                // spatial rotation about the coordinate axis through the origin: blockdiag(R, R)
+                const double sn = std::sin(th), cs = std::cos(th);
+                double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                const int a1 = (bd.axis + 1) % 3, a2 = (bd.axis + 2) % 3;
+                R[a1 * 3 + a1] = cs; R[a1 * 3 + a2] = sn; R[a2 * 3 + a1] = -sn; R[a2 * 3 + a2] = cs;
+                for (int bi = 0; bi < 2 && inv; bi++)
+                    for (int bj = 0; bj < 2 && inv; bj++)
+                        for (int i = 0; i < 3 && inv; i++)
+                            for (int j = 0; j < 3; j++) {
+                                double sacc = 0;  // (R^T M R)_ij of block (bi, bj)
+                                for (int k2 = 0; k2 < 3; k2++)
+                                    for (int l2 = 0; l2 < 3; l2++)
+                                        sacc += R[k2 * 3 + i] * at(bd.inertia, 3 * bi + k2, 3 * bj + l2) * R[l2 * 3 + j];
+                                if (std::fabs(sacc - at(bd.inertia, 3 * bi + i, 3 * bj + j)) > 1e-12 * (scale + 1e-300)) { inv = false; break; }
+                            }
+            }
+            if (!inv) continue;
+            bodies[b].axisym = 1;
+            // X0 = (E_tree, r_tree): 6x6 motion transform [[E,0],[-E r^,E]]; B = X0^T I X0
+            const double *E = bd.Xtree_E, *r = bd.Xtree_r;
+            const double rh[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+            double X[36] = {0};
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    X[i * 6 + j] = E[i * 3 + j];
+                    X[(i + 3) * 6 + j + 3] = E[i * 3 + j];
+                    double er = 0;
+                    for (int k2 = 0; k2 < 3; k2++) er += E[i * 3 + k2] * rh[k2 * 3 + j];
+                    X[(i + 3) * 6 + j] = -er;
+                }
+            std::vector<double> &ex = extra[bd.parent];
+            if (ex.empty()) ex.assign(21, 0.0);
+            int idx = 0;
+            for (int i = 0; i < 6; i++)
+                for (int j = i; j < 6; j++, idx++) {
+                    double sacc = 0;
+                    for (int k2 = 0; k2 < 6; k2++)
+                        for (int l2 = 0; l2 < 6; l2++) sacc += X[k2 * 6 + i] * at(bd.inertia, k2, l2) * X[l2 * 6 + j];
+                    ex[idx] += sacc;
+                }
+        }
+        for (int b = 0; b < nb; b++)
+            if (!extra[b].empty()) {
+                bodies[b].xofs = static_cast<int>(P.consts.size());
+                P.consts.insert(P.consts.end(), extra[b].begin(), extra[b].end());
+            }
+    }
+
     // ---- implicit-loop payload -------------------------------------------------------------------
     for (int c = 0; c < nc; c++) {
         const grbda_desc_cluster &cl = m.clusters[c];
@@ -385,8 +449,30 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             const int a = tB[cluster_of(first[p])], t = tB[cluster_of(j)];
             if (t < a || (t == a && j > first[p])) first[p] = j;
         }
+        // the same for the inertia accumulator, which axisymmetric leaves never touch.  Writers of
+        // body p's inertia slot: its non-axisymmetric children (in their cluster's backward step, highest
+        // index first) and, after the bodies of a step, the cluster correction -F D^-1 F^T.
+        struct Writer { int t, phase, order, body, cluster; };
+        std::vector<Writer> firstw(nb, Writer{1 << 30, 0, 0, -1, -1});
+        auto consider = [&](int p, const Writer &w) {
+            Writer &f = firstw[p];
+            if (w.t < f.t || (w.t == f.t && (w.phase < f.phase || (w.phase == f.phase && w.order < f.order)))) f = w;
+        };
+        for (int j = 0; j < nb; j++) {
+            const int p = bodies[j].parent;
+            if (p < 0 || bodies[j].axisym) continue;
+            consider(p, Writer{tB[cluster_of(j)], 0, -j, j, -1});
+        }
+        for (int c = 0; c < nc; c++) {
+            const int p = L.clusters[c].parent_body;
+            L.clusters[c].corr_first_IA = 0;
+            if (p >= 0 && !L.clusters[c].carry_out) consider(p, Writer{tB[c], 1, c, -1, c});
+        }
+        for (int p2 = 0; p2 < nb; p2++)
+            if (firstw[p2].cluster >= 0) L.clusters[firstw[p2].cluster].corr_first_IA = 1;
         for (int b = 0; b < nb; b++) {
             BodyRec &br = L.bodies[b];
+            br.acc_first_IA = 0;
             if (br.parent >= 0) {
                 const BodyRec &pr = L.bodies[br.parent];
                 br.parent_slot_v = pr.slot_v;
@@ -395,6 +481,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
                 br.parent_slot_v3 = pr.slot_v3;
                 br.parent_slot_a3 = pr.slot_a3;
                 br.acc_first = first[br.parent] == b;
+                br.acc_first_IA = firstw[br.parent].body == b;
             } else {
                 br.parent_slot_v = br.parent_slot_IA = br.parent_slot_psi = br.parent_slot_v3 = br.parent_slot_a3 = -1;
                 br.acc_first = 0;

@@ -72,7 +72,8 @@ struct ClusterRec {
     int32_t slot_imp_fwd, slot_imp_bwd, slot_imp_acc;
     int32_t iofs;             // offset into cints[]: n_loops, n_ind, ind[], n_dep, dep[], loops...
     int32_t dofs;             // offset into consts[]: per loop pred origin E[9] r[3], succ origin E[9] r[3]
-    int32_t reserved[3];
+    int32_t corr_first_IA;    // 1: the cluster's -F D^-1 F^T term is the first inertia written to the parent's slot
+    int32_t reserved[2];
 };
 
 struct BodyRec {
@@ -98,7 +99,12 @@ struct BodyRec {
     int32_t parent_slot_f;
     int32_t acc_first;        // 1: first contributor to the tree parent's backward accumulators
     int32_t carry_in;         // 1: backward accumulators arrive in registers (single child cluster, adjacent step)
-    int32_t reserved[2];
+    int32_t axisym;           // 1: leaf body whose inertia is invariant under rotation about its joint axis
+                              //    (a rotor): X(q)^T I X(q) and X(q)^T (v x* I v) do not depend on q, so the
+                              //    body is evaluated at q = 0 and its inertia contribution is a plan constant
+    int32_t xofs;             // offset into consts[] of the 21 constants sum_children X0^T I X0 (or -1)
+    int32_t acc_first_IA;     // like acc_first, counting only children that really accumulate an inertia
+    int32_t reserved[3];
 };
 
 // number of constants per body before the G row
