@@ -37,3 +37,9 @@ clean:
 	rm -rf build $(LIB) oracle/_build oracle/_ref
 
 .PHONY: all oracle ref clean
+
+# profiling variant with in-kernel cycle accounting (tools/prof_run.py); not part of `all`
+prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+	@mkdir -p build/prof
+	$(HIPCC) $(HIPFLAGS) -DGRBDA_PROFILE -c $(CSRC)/kernels.hip -o build/prof/kernels.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/libgrbda_hip_prof.so build/prof/kernels.o $^

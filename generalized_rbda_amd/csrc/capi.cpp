@@ -371,6 +371,8 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->flops_rnea = p->host.flops_rnea;
     info->bytes_aba_f32 = (p->host.nq + 3.0 * p->host.nv) * 4;
     info->bytes_aba_f64 = (p->host.nq + 3.0 * p->host.nv) * 8;
+    for (const BodyRec &b : p->host.lay32.bodies) info->n_axisym_bodies += b.axisym;
+    for (const ClusterRec &c : p->host.lay32.clusters) info->n_carry_clusters += c.carry_out;
     return GRBDA_OK;
 }
 

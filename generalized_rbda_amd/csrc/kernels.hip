@@ -31,6 +31,28 @@
 
 namespace grbda_hip {
 
+// optional in-kernel cycle accounting (build with -DGRBDA_PROFILE, see tools/prof_run.py; never in
+// the shipped library): s_memtime deltas per phase, summed over waves into grbda_prof[]
+#ifdef GRBDA_PROFILE
+__device__ unsigned long long grbda_prof[32];
+#define PROF_T0() unsigned long long prof_t = __builtin_amdgcn_s_memtime()
+#define PROF_ARGS , unsigned long long (&prof_acc)[16], unsigned long long &prof_t
+#define PROF_PASS , prof_acc, prof_t
+#define PROF_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PROF_ADD(i)                                                    \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        prof_acc[i] += now_ - prof_t;                                  \
+        prof_t = now_;                                                 \
+    } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(i)
+#define PROF_ARGS
+#define PROF_PASS
+#define PROF_SYNC()
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // plan tables live in the constant address space: uniform loads from it are scalar (s_load),
 // which also makes every branch on a plan field a scalar branch
@@ -946,7 +968,7 @@ __device__ __forceinline__ void free_base_accel(const Tables<T> &P, const Cluste
 // ---------------------------------------------------------------------------------------------
 template <class T, int N, bool LOOP>
 __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                               const Lane<T> &L, Carry<T> &carry)
+                                               const Lane<T> &L, Carry<T> &carry PROF_ARGS)
 {
     T y[N], yd[N], u[N], F[6][N], D[N][N];
     // contribution of this cluster to its parent body when it is handed over in registers
@@ -995,7 +1017,10 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
     }
 
     for (int i = c.k - 1; i >= 0; i--) {
+        PROF_ADD(5);  // (previous body) joint-space terms + push up the in-cluster chain
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        PROF_SYNC();
+        PROF_ADD(6);  // body record round trip
         cptr<T> C = P.consts + b.cofs;
         cptr<T> Ic = C + 12;
         T qi, gi;
@@ -1004,6 +1029,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
         const T qdi = rdot<T, N>(G, yd);
         T sc[2], E[9], v[6];
         body_kinematics<T>(P, S, b, C, qi, qdi, sc, E, v);
+        PROF_SYNC();
+        PROF_ADD(7);  // constants + kinematics (LDS v / parent v)
         T chat[6];
         vxaxis(b.axis, v, qdi, chat);
         add_axis(chat, b.axis, gi);
@@ -1038,6 +1065,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             for (int j = 0; j < 21; j++) IA[j] += Xc[j];
         }
 
+        PROF_SYNC();
+        PROF_ADD(8);  // own bias + accumulator loads
         T h[6];
         column(IA, b.axis, h);
         const T d = pick(h, b.axis);
@@ -1081,6 +1110,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             }
         }
 
+        PROF_SYNC();
+        PROF_ADD(9);  // IA*c, force transform, congruence, hand-over / accumulate
         // joint-space terms: D += d G^T G, u -= G^T b, push h up the in-cluster chain
 #pragma unroll
         for (int a = 0; a < N; a++) {
@@ -1116,6 +1147,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             for (int a = 0; a < N; a++) F[r][a] += f[r] * G[a];
     }
 
+    PROF_ADD(10);
     // D^-1 u', K = D^-1 F^T
     Chol<T, N> ch;
     ch.factor(D);
@@ -1160,6 +1192,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             S.acc(c.parent_slot_IA, dI, c.corr_first_IA);
         }
     }
+    PROF_SYNC();
+    PROF_ADD(11);  // solve, K/y0 stores, parent correction
 }
 
 // Free root: S = 1, D = IA, c = 0 (FreeJoint.cpp:10-36)
@@ -1486,12 +1520,17 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
     S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave + lane;
 
+#ifdef GRBDA_PROFILE
+    unsigned long long prof_acc[16] = {0};
+#endif
+    PROF_T0();
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t r = tile * kWave + lane;
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
         stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        PROF_ADD(0);
         Lane<T> L;
         L.active = r < B;
         const size_t rr = L.active ? r : B - 1;
@@ -1524,27 +1563,35 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
                 const ClusterRec c1 = load_rec(P.clusters + st1.cluster);
                 prefetch_inputs(L, c1, ny, nyd, nxx);
             }
+            PROF_ADD(1);
             if (st.op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_fwd_static, P, S, c, L)
                 }
+                PROF_ADD(2);
             } else if (st.op == OP_ABA_BWD) {
                 if (c.kind == CK_FREE) {
                     aba_bwd_free(P, S, c, L, carry);
                 } else {
-                    GRBDA_DISPATCH_N(c, aba_bwd_static, P, S, c, L, carry)
+                    GRBDA_DISPATCH_N(c, aba_bwd_static, P, S, c, L, carry PROF_PASS)
                 }
+                PROF_ADD(3);
             } else {
                 if (c.kind == CK_FREE) {
                     aba_acc_free(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_acc_static, P, S, c, L)
                 }
+                PROF_ADD(4);
             }
         }
     }
+#ifdef GRBDA_PROFILE
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&grbda_prof[i], prof_acc[i]);
+#endif
 }
 
 template <class T, bool HAS_LOOP>
@@ -1642,6 +1689,18 @@ template hipError_t launch_rnea<float>(const DevPlan<float> &, const float *, co
                                        size_t, float *, int, size_t, hipStream_t);
 template hipError_t launch_rnea<double>(const DevPlan<double> &, const double *, const double *, const double *,
                                         double *, size_t, double *, int, size_t, hipStream_t);
+
+#ifdef GRBDA_PROFILE
+extern "C" int grbda_debug_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(grbda_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(grbda_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 hipError_t set_max_dynamic_lds()
 {

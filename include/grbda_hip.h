@@ -89,6 +89,8 @@ typedef struct {
     size_t scratch_bytes_per_wave_f32, scratch_bytes_per_wave_f64;
     double flops_aba, flops_rnea;
     double bytes_aba_f32, bytes_aba_f64; /* algorithmic bytes per evaluation: (nq+2nv+nv)*s */
+    int n_axisym_bodies;  /* leaf bodies evaluated at q = 0 (rotors), see plan.h */
+    int n_carry_clusters; /* clusters whose projected inertia is handed over in registers */
 } grbda_plan_info_t;
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 
