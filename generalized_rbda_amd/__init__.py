@@ -148,7 +148,7 @@ class Plan:
         return info
 
     # ---- batched dynamics on torch device tensors ------------------------------------------------
-    def _launch(self, which: str, q, qd, x, out=None, stream=None):
+    def _launch(self, which: str, q, qd, x, out=None, stream=None, f_ext=None):
         import torch
 
         if q.dtype not in (torch.float32, torch.float64):
@@ -163,19 +163,26 @@ class Plan:
             raise TypeError("dtype mismatch")
         if out is None:
             out = torch.empty((B, self.nv), dtype=q.dtype, device=q.device)
+        fe = None
+        if f_ext is not None:
+            if f_ext.shape != (B, self.n_bodies, 6) or f_ext.dtype != q.dtype or not f_ext.is_cuda:
+                raise ValueError(f"f_ext must be a device tensor [B,{self.n_bodies},6] of the same dtype")
+            f_ext = f_ext.contiguous()
+            fe = f_ext.data_ptr()
         s = torch.cuda.current_stream(q.device) if stream is None else stream
         fn = getattr(lib(), f"grbda_{which}_{'f32' if q.dtype == torch.float32 else 'f64'}")
-        _check(fn(self._h, q.data_ptr(), qd.data_ptr(), x.data_ptr(), None, out.data_ptr(), B,
+        _check(fn(self._h, q.data_ptr(), qd.data_ptr(), x.data_ptr(), fe, out.data_ptr(), B,
                   q.device.index or 0, c_void_p(s.cuda_stream)))
         return out
 
-    def forward_dynamics(self, q, qd, tau, out=None, stream=None):
-        """Batched ClusterTreeModel::forwardDynamics (cluster ABA): returns ydd[B, nv]."""
-        return self._launch("aba", q, qd, tau, out, stream)
+    def forward_dynamics(self, q, qd, tau, out=None, stream=None, f_ext=None):
+        """Batched ClusterTreeModel::forwardDynamics (cluster ABA): returns ydd[B, nv].
+        f_ext: optional [B, n_bodies, 6] world-frame spatial forces (TreeModel::setExternalForces)."""
+        return self._launch("aba", q, qd, tau, out, stream, f_ext)
 
-    def inverse_dynamics(self, q, qd, ydd, out=None, stream=None):
+    def inverse_dynamics(self, q, qd, ydd, out=None, stream=None, f_ext=None):
         """Batched ClusterTreeModel::inverseDynamics (cluster RNEA): returns tau[B, nv]."""
-        return self._launch("rnea", q, qd, ydd, out, stream)
+        return self._launch("rnea", q, qd, ydd, out, stream, f_ext)
 
     def time_kernel(self, which: str, q, qd, x, out, iters: int = 20, stream=None) -> float:
         """Average kernel duration in ms, hipEvents on the launch stream (grbda_time_kernel)."""
@@ -189,22 +196,24 @@ class Plan:
         return ms.value
 
     # ---- host convenience (numpy, fp64) -----------------------------------------------------------
-    def forward_dynamics_host(self, q, qd, tau, device: int = 0):
+    def forward_dynamics_host(self, q, qd, tau, device: int = 0, f_ext=None):
         import numpy as np
 
         q, qd, tau = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, qd, tau))
+        fe = None if f_ext is None else np.ascontiguousarray(f_ext, dtype=np.float64)
         out = np.empty_like(tau)
-        _check(lib().grbda_aba_host_f64(self._h, q.ctypes.data, qd.ctypes.data, tau.ctypes.data, None,
-                                        out.ctypes.data, q.shape[0], device))
+        _check(lib().grbda_aba_host_f64(self._h, q.ctypes.data, qd.ctypes.data, tau.ctypes.data,
+                                        None if fe is None else fe.ctypes.data, out.ctypes.data, q.shape[0], device))
         return out
 
-    def inverse_dynamics_host(self, q, qd, ydd, device: int = 0):
+    def inverse_dynamics_host(self, q, qd, ydd, device: int = 0, f_ext=None):
         import numpy as np
 
         q, qd, ydd = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, qd, ydd))
+        fe = None if f_ext is None else np.ascontiguousarray(f_ext, dtype=np.float64)
         out = np.empty_like(ydd)
-        _check(lib().grbda_rnea_host_f64(self._h, q.ctypes.data, qd.ctypes.data, ydd.ctypes.data, None,
-                                         out.ctypes.data, q.shape[0], device))
+        _check(lib().grbda_rnea_host_f64(self._h, q.ctypes.data, qd.ctypes.data, ydd.ctypes.data,
+                                         None if fe is None else fe.ctypes.data, out.ctypes.data, q.shape[0], device))
         return out
 
 

@@ -39,11 +39,12 @@ int hip_err(hipError_t e, const char *what)
 // per-(device) copies of the plan tables; per-(device, stream) scratch slabs
 struct DeviceTables {
     Step *aba_steps = nullptr, *rnea_steps = nullptr;
-    ClusterRec *clusters[2] = {nullptr, nullptr};      // [0] f32 layout, [1] f64 layout
-    ClusterRec *rnea_clusters[2] = {nullptr, nullptr};
+    // [0] f32, [1] f64, [2] f32 + external forces, [3] f64 + external forces
+    ClusterRec *clusters[4] = {nullptr, nullptr, nullptr, nullptr};
+    ClusterRec *rnea_clusters[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *cints = nullptr;
-    BodyRec *bodies[2] = {nullptr, nullptr};           // ABA slots
-    BodyRec *rnea_bodies[2] = {nullptr, nullptr};      // RNEA slots
+    BodyRec *bodies[4] = {nullptr, nullptr, nullptr, nullptr};       // ABA slots
+    BodyRec *rnea_bodies[4] = {nullptr, nullptr, nullptr, nullptr};  // RNEA slots
     double *consts64 = nullptr;
     float *consts32 = nullptr;
     int n_cu = 0;
@@ -101,8 +102,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess ||
         (e = up(h.cints.data(), h.cints.size() * sizeof(int32_t), (void **)&t.cints)) != hipSuccess)
         return hip_err(e, "plan upload");
-    for (int w = 0; w < 2; w++) {
-        const Layout &L = w == 0 ? h.lay32 : h.lay64;
+    for (int w = 0; w < 4; w++) {
+        const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
         if ((e = up(L.clusters.data(), L.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters[w])) != hipSuccess ||
             (e = up(L.rnea_clusters.data(), L.rnea_clusters.size() * sizeof(ClusterRec), (void **)&t.rnea_clusters[w])) != hipSuccess ||
             (e = up(L.bodies.data(), L.bodies.size() * sizeof(BodyRec), (void **)&t.bodies[w])) != hipSuccess ||
@@ -138,14 +139,14 @@ int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, 
 }
 
 template <class T>
-DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea)
+DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, bool fext)
 {
     DevPlan<T> d;
     const HostPlan &h = p->host;
     d.steps = rnea ? t.rnea_steps : t.aba_steps;
     d.n_steps = static_cast<int>(rnea ? h.rnea_steps.size() : h.aba_steps.size());
-    const int w = sizeof(T) == 4 ? 0 : 1;
-    const Layout &L = w == 0 ? h.lay32 : h.lay64;
+    const int w = (sizeof(T) == 4 ? 0 : 1) + (fext ? 2 : 0);
+    const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
     d.clusters = rnea ? t.rnea_clusters[w] : t.clusters[w];
     d.cints = t.cints;
     d.bodies = rnea ? t.rnea_bodies[w] : t.bodies[w];
@@ -155,8 +156,9 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea)
     d.n_lds_slots = rnea ? L.n_lds_rnea : L.n_lds_aba;
     d.n_glb_slots = rnea ? L.n_glb_rnea : L.n_glb_aba;
     d.ori_repr = h.ori_repr;
-    d.has_loop = 0;
-    for (const ClusterRec &cr : L.clusters) d.has_loop |= cr.kind == CK_LOOP;
+    d.general = fext ? 1 : 0;
+    for (const ClusterRec &cr : L.clusters) d.general |= cr.kind == CK_LOOP;
+    d.n_bodies = h.n_bodies;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     return d;
 }
@@ -166,11 +168,11 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
         int device, void *stream)
 {
     if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
-    if (f_ext) return set_err(GRBDA_EUNSUPPORTED, "external forces are not implemented in the HIP kernels yet");
     if (B == 0) return GRBDA_OK;
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
-    DevPlan<T> d = make_dev_plan<T>(p, *t, rnea);
+    DevPlan<T> d = make_dev_plan<T>(p, *t, rnea, f_ext != nullptr);
+    d.fext = f_ext;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->waves_per_cu);
     if (grid > n_tiles) grid = n_tiles;
@@ -204,9 +206,14 @@ int run_host_f64(const grbda_plan *p, bool rnea, const double *q, const double *
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const size_t nq = p->host.nq, nv = p->host.nv;
-    double *dq = nullptr, *dqd = nullptr, *dx = nullptr, *dout = nullptr;
+    double *dq = nullptr, *dqd = nullptr, *dx = nullptr, *dout = nullptr, *dfe = nullptr;
+    const size_t nfe = static_cast<size_t>(p->host.n_bodies) * 6;
     hipError_t e;
     int rc = GRBDA_OK;
+    if (f_ext) {
+        if ((e = hipMalloc((void **)&dfe, B * nfe * 8)) != hipSuccess) return hip_err(e, "hipMalloc");
+        if ((e = hipMemcpy(dfe, f_ext, B * nfe * 8, hipMemcpyHostToDevice)) != hipSuccess) { (void)hipFree(dfe); return hip_err(e, "hipMemcpy H2D"); }
+    }
     if ((e = hipMalloc((void **)&dq, B * nq * 8)) != hipSuccess || (e = hipMalloc((void **)&dqd, B * nv * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&dx, B * nv * 8)) != hipSuccess || (e = hipMalloc((void **)&dout, B * nv * 8)) != hipSuccess) {
         rc = hip_err(e, "hipMalloc");
@@ -215,7 +222,7 @@ int run_host_f64(const grbda_plan *p, bool rnea, const double *q, const double *
                (e = hipMemcpy(dx, x, B * nv * 8, hipMemcpyHostToDevice)) != hipSuccess) {
         rc = hip_err(e, "hipMemcpy H2D");
     } else {
-        rc = run<double>(p, rnea, dq, dqd, dx, f_ext, dout, B, device, nullptr);
+        rc = run<double>(p, rnea, dq, dqd, dx, dfe, dout, B, device, nullptr);
         if (rc == GRBDA_OK) {
             if ((e = hipDeviceSynchronize()) != hipSuccess) rc = hip_err(e, "kernel execution");
             else if ((e = hipMemcpy(out, dout, B * nv * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_err(e, "hipMemcpy D2H");
@@ -225,6 +232,7 @@ int run_host_f64(const grbda_plan *p, bool rnea, const double *q, const double *
     if (dqd) (void)hipFree(dqd);
     if (dx) (void)hipFree(dx);
     if (dout) (void)hipFree(dout);
+    if (dfe) (void)hipFree(dfe);
     return rc;
 }
 
@@ -314,7 +322,7 @@ void grbda_plan_free(grbda_plan *p)
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints);
-        for (int w = 0; w < 2; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
+        for (int w = 0; w < 4; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto &kv : p->scratch) {
         if (hipSetDevice(kv.first.first) != hipSuccess) continue;

@@ -18,7 +18,9 @@ struct DevPlan {
     int n_lds_slots, n_glb_slots;
     int lds_bytes;  // dynamic LDS actually allocated per wave (slot store / input staging area)
     int ori_repr;
-    int has_loop;  // the model contains implicit-loop clusters: launch the kernel variant that supports them
+    int general;   // launch the general kernel variant: implicit-loop clusters and / or external forces
+    int n_bodies;
+    const T *fext; // [B][n_bodies][6] world-frame spatial forces or nullptr (TreeModel::setExternalForces)
     T a_root[6];  // -gravity (ClusterTreeDynamics.cpp:147)
 };
 

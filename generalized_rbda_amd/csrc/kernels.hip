@@ -435,6 +435,7 @@ struct Lane {
     // slab (row j of q at in_q[j * 64], one coalesced 64-element row per coordinate)
     const T *in_q, *in_qd, *in_x;  // x: tau (ABA) or ydd (RNEA); all already offset by the lane
     T *out;                        // ydd (ABA) or tau (RNEA), row of this lane's state (row-major batch)
+    const T *fext;                 // this state's [n_bodies][6] world-frame external forces, or nullptr
     bool active;
     __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
     __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
@@ -847,6 +848,49 @@ __device__ __forceinline__ T rdot(const Row &G, const T (&y)[N])
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// external forces (TreeModel::setExternalForces, TreeModel.cpp:214-239): forces are given in world
+// coordinates, the bias force gets  -Xa.transformForceVector(f_ext)  (ClusterTreeDynamics.cpp:101-105,
+// SpatialTransforms.cpp:62-71,234-250) with Xa the absolute transform world -> body (TreeNode::Xa_,
+// TreeModel.cpp:20-27).  Only the general kernel variant carries this code.
+// ---------------------------------------------------------------------------------------------
+// Xa = X * Xa_parent:  E = E_i E_p,  r = r_p + E_p^T r_i   (SpatialTransforms.cpp:149-157)
+template <class T, class R3>
+__device__ __forceinline__ void compose_absolute(const Slots<T> &S, int parent_slot_Xa, const T (&E)[9], R3 r, T (&Xa)[12])
+{
+    if (parent_slot_Xa >= 0) {
+        T Xp[12];
+        S.ld(parent_slot_Xa, Xp);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Xa[3 * i + j] = E[3 * i] * Xp[j] + E[3 * i + 1] * Xp[3 + j] + E[3 * i + 2] * Xp[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++) Xa[9 + i] = Xp[9 + i] + Xp[i] * r[0] + Xp[3 + i] * r[1] + Xp[6 + i] * r[2];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) Xa[i] = E[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) Xa[9 + i] = r[i];
+    }
+}
+// f -= Xa.transformForceVector(f_ext[body])
+template <class T>
+__device__ __forceinline__ void subtract_external_force(const Lane<T> &L, int body, const T (&Xa)[12], T (&f)[6])
+{
+    T w[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) w[j] = L.fext[(size_t)body * 6 + j];
+    const T t0 = w[0] - (Xa[10] * w[5] - Xa[11] * w[4]);
+    const T t1 = w[1] - (Xa[11] * w[3] - Xa[9] * w[5]);
+    const T t2 = w[2] - (Xa[9] * w[4] - Xa[10] * w[3]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        f[i] -= Xa[3 * i] * t0 + Xa[3 * i + 1] * t1 + Xa[3 * i + 2] * t2;
+        f[3 + i] -= Xa[3 * i] * w[3] + Xa[3 * i + 1] * w[4] + Xa[3 * i + 2] * w[5];
+    }
+}
+
 // kinematics of one revolute body: joint transform and spatial velocity.  Bodies with children
 // were handled by the forward sweep (sin/cos and v are in their slots); leaf bodies are evaluated
 // here from the parent's stored velocity, so they never occupy a slot.
@@ -883,7 +927,7 @@ __device__ __forceinline__ void body_kinematics(const Tables<T> &P, const Slots<
 // ABA sweep 1: ClusterTreeNode::updateKinematics + TreeModel::forwardKinematics
 // (ClusterTreeNode.cpp:26-31, TreeModel.cpp:6-32) -- only bodies that have children
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP>
+template <class T, int N, bool LOOP, bool GEN>
 __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
@@ -916,6 +960,13 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
         }
         add_axis(v, b.axis, rdot<T, N>(Gr, yd));
         S.st(b.slot_v, v);
+        if constexpr (GEN) {
+            if (L.fext) {
+                T Xa[12];
+                compose_absolute(S, b.parent_slot_Xa, E, C + 9, Xa);
+                S.st(b.slot_Xa, Xa);
+            }
+        }
     }
 }
 
@@ -947,6 +998,21 @@ __device__ __forceinline__ void free_rotation(int ori_repr, const T *o, T (&E)[9
 // Free cluster (FreeJoint.cpp:28-46, Joint.h:61-68): Xup = XJ = (R(ori), position), v = yd.
 // a' = Xup * (-gravity); needs only E because -gravity has no angular part in general? No:
 // the general formula is kept.
+// Xa of the floating base: (R(orientation), position)
+template <class T>
+__device__ __forceinline__ void free_absolute(const Tables<T> &P, const ClusterRec &c, const Lane<T> &L, T (&Xa)[12])
+{
+    T o[4], E[9];
+    const int nori = P.ori_repr == 0 ? 4 : 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = j < nori ? L.q(c.q_index + 3 + j) : T(0);
+    free_rotation(P.ori_repr, o, E);
+#pragma unroll
+    for (int j = 0; j < 9; j++) Xa[j] = E[j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Xa[9 + j] = L.q(c.q_index + j);
+}
+
 template <class T>
 __device__ __forceinline__ void free_base_accel(const Tables<T> &P, const ClusterRec &c, const Lane<T> &L, T (&ag)[6])
 {
@@ -966,7 +1032,7 @@ __device__ __forceinline__ void free_base_accel(const Tables<T> &P, const Cluste
 // ABA sweep 2 (fused 2a + 2b): updateArticulatedBodies + bias back-propagation
 // (ClusterTreeDynamics.cpp:94-129,157-191; ClusterTreeNode.cpp:33-37)
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP>
+template <class T, int N, bool LOOP, bool GEN>
 __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L, Carry<T> &carry PROF_ARGS)
 {
@@ -1041,6 +1107,14 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             T Iv[6];
             symv_c(Ic, v, Iv);
             crf(v, Iv, psi);  // pA = v x* (I v), ClusterTreeDynamics.cpp:95-98
+        }
+        if constexpr (GEN) {
+            if (L.fext) {
+                T Xa[12];
+                if (b.has_child) S.ld(b.slot_Xa, Xa);
+                else compose_absolute(S, b.parent_slot_Xa, E, C + 9, Xa);
+                subtract_external_force(L, c.first_body + i, Xa, psi);
+            }
         }
         if (b.carry_in) {
 #pragma unroll
@@ -1208,6 +1282,11 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
     for (int j = 0; j < 6; j++) v[j] = L.qd(c.v_index + j);
     symv_c(Ic, v, Iv);
     crf(v, Iv, psi);
+    if (L.fext) {
+        T Xa[12];
+        free_absolute(P, c, L, Xa);
+        subtract_external_force(L, c.first_body, Xa, psi);
+    }
     if (b.carry_in) {
 #pragma unroll
         for (int j = 0; j < 21; j++) IA[j] = Ic[j] + carry.IA[j];
@@ -1247,7 +1326,7 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
 // ABA sweep 3: joint accelerations (ClusterTreeDynamics.cpp:131-152).  Velocities of bodies with
 // children are recomputed on the way down (cheaper than keeping them live across the sweeps).
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP>
+template <class T, int N, bool LOOP, bool GEN>
 __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
@@ -1347,12 +1426,17 @@ __device__ __forceinline__ void aba_fwd_free(const Tables<T> &P, const Slots<T> 
 #pragma unroll
     for (int j = 0; j < 6; j++) v[j] = L.qd(c.v_index + j);
     S.st(b.slot_v, v);
+    if (L.fext && b.slot_Xa >= 0) {
+        T Xa[12];
+        free_absolute(P, c, L, Xa);
+        S.st(b.slot_Xa, Xa);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // RNEA (TreeModel.cpp:34-57,173-212)
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP>
+template <class T, int N, bool LOOP, bool GEN>
 __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                 const Lane<T> &L)
 {
@@ -1404,6 +1488,14 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
         crf(v, Iv, f);
 #pragma unroll
         for (int j = 0; j < 6; j++) f[j] += Ia[j];
+        if constexpr (GEN) {
+            if (L.fext) {
+                T Xa[12];
+                compose_absolute(S, b.parent_slot_Xa, E, C + 9, Xa);
+                if (b.has_child) S.st(b.slot_Xa, Xa);
+                subtract_external_force(L, c.first_body + i, Xa, f);
+            }
+        }
         S.st(b.slot_f, f);
     }
 }
@@ -1431,10 +1523,16 @@ __device__ __forceinline__ void rnea_fwd_free(const Tables<T> &P, const Slots<T>
     crf(v, Iv, f);
 #pragma unroll
     for (int j = 0; j < 6; j++) f[j] += Ia[j];
+    if (L.fext) {
+        T Xa[12];
+        free_absolute(P, c, L, Xa);
+        if (b.has_child && b.slot_Xa >= 0) S.st(b.slot_Xa, Xa);
+        subtract_external_force(L, c.first_body, Xa, f);
+    }
     S.st(b.slot_f, f);
 }
 
-template <class T, int N, bool LOOP>
+template <class T, int N, bool LOOP, bool GEN>
 __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                                 const Lane<T> &L)
 {
@@ -1493,17 +1591,17 @@ __device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T>
     if (HAS_LOOP && (c).kind == CK_LOOP) {                                                     \
         if constexpr (HAS_LOOP) {                                                              \
             switch ((c).n) {                                                                   \
-                case 1: FN<T, 1, true>(__VA_ARGS__); break;                                    \
-                case 2: FN<T, 2, true>(__VA_ARGS__); break;                                    \
-                default: FN<T, 3, true>(__VA_ARGS__); break;                                   \
+                case 1: FN<T, 1, true, true>(__VA_ARGS__); break;                                    \
+                case 2: FN<T, 2, true, true>(__VA_ARGS__); break;                                    \
+                default: FN<T, 3, true, true>(__VA_ARGS__); break;                                   \
             }                                                                                  \
         }                                                                                      \
     } else {                                                                                   \
         switch ((c).n) {                                                                       \
-            case 1: FN<T, 1, false>(__VA_ARGS__); break;                                       \
-            case 2: FN<T, 2, false>(__VA_ARGS__); break;                                       \
-            case 3: FN<T, 3, false>(__VA_ARGS__); break;                                       \
-            default: FN<T, 4, false>(__VA_ARGS__); break;                                      \
+            case 1: FN<T, 1, false, HAS_LOOP>(__VA_ARGS__); break;                                       \
+            case 2: FN<T, 2, false, HAS_LOOP>(__VA_ARGS__); break;                                       \
+            case 3: FN<T, 3, false, HAS_LOOP>(__VA_ARGS__); break;                                       \
+            default: FN<T, 4, false, HAS_LOOP>(__VA_ARGS__); break;                                      \
         }                                                                                      \
     }
 
@@ -1538,6 +1636,7 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
         L.in_qd = slab + (size_t)P.nq * kWave + lane;
         L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.out = ydd + rr * P.nv;
+        L.fext = DP.fext ? DP.fext + rr * (size_t)DP.n_bodies * 6 : nullptr;
         Carry<T> carry;
 #pragma unroll
         for (int j = 0; j < 21; j++) carry.IA[j] = 0;
@@ -1620,6 +1719,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         L.in_qd = slab + (size_t)P.nq * kWave + lane;
         L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.out = tau + rr * P.nv;
+        L.fext = DP.fext ? DP.fext + rr * (size_t)DP.n_bodies * 6 : nullptr;
         T ny[kMaxClusterDof], nyd[kMaxClusterDof], nxx[kMaxClusterDof];
         {
             const Step st0 = load_rec(P.steps + 0);
@@ -1664,7 +1764,7 @@ template <class T>
 hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch,
                       int grid, size_t lds_bytes, hipStream_t stream)
 {
-    if (P.has_loop)
+    if (P.general)
         hipLaunchKernelGGL((aba_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     else
         hipLaunchKernelGGL((aba_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
@@ -1674,7 +1774,7 @@ template <class T>
 hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch,
                        int grid, size_t lds_bytes, hipStream_t stream)
 {
-    if (P.has_loop)
+    if (P.general)
         hipLaunchKernelGGL((rnea_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     else
         hipLaunchKernelGGL((rnea_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);

@@ -393,7 +393,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
     };
 
     auto cluster_of = [&](int b) { return m.bodies[b].cluster; };
-    auto build_layout = [&](Layout &L, int lds_budget) {
+    auto build_layout = [&](Layout &L, int lds_budget, bool with_xa) {
         L.clusters = clusters;
         L.rnea_clusters = clusters;
         L.bodies = bodies;
@@ -404,6 +404,8 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             BodyRec &br = L.bodies[b];
             const int c = cluster_of(b);
             br.slot_sc = br.slot_v = br.slot_IA = br.slot_psi = br.slot_ccl = br.slot_v3 = br.slot_a3 = br.slot_f = -1;
+            br.slot_Xa = br.parent_slot_Xa = -1;
+            if (with_xa && br.has_child) objs.push_back({&br.slot_Xa, 12, 1, tF[c], tB[c], -1});
             if (br.has_child) {
                 int first_child_bwd = tB[c], last_child_acc = tA[c];
                 for (int j = b + 1; j < nb; j++)
@@ -476,6 +478,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             if (br.parent >= 0) {
                 const BodyRec &pr = L.bodies[br.parent];
                 br.parent_slot_v = pr.slot_v;
+                br.parent_slot_Xa = pr.slot_Xa;
                 br.parent_slot_IA = pr.slot_IA;
                 br.parent_slot_psi = pr.slot_psi;
                 br.parent_slot_v3 = pr.slot_v3;
@@ -506,6 +509,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             BodyRec &br = L.rnea_bodies[b];
             const int c = cluster_of(b);
             br.slot_sc = br.slot_v = br.slot_IA = br.slot_psi = br.slot_ccl = br.slot_v3 = br.slot_a3 = br.slot_f = -1;
+            br.slot_Xa = br.parent_slot_Xa = -1;
             if (br.jtype != GRBDA_JOINT_FREE && br.parent >= 0) robjs.push_back({&br.slot_sc, 2, 0, tRF[c], tRB[c], -1});
             robjs.push_back({&br.slot_f, 6, 1, tRF[c], tRB[c], -1});
             if (br.has_child) {
@@ -514,6 +518,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
                     if (bodies[j].parent == b) last_child_fwd = std::max(last_child_fwd, tRF[cluster_of(j)]);
                 robjs.push_back({&br.slot_v, 6, 0, tRF[c], last_child_fwd, -1});
                 robjs.push_back({&br.slot_a3, 6, 0, tRF[c], last_child_fwd, -1});
+                if (with_xa) robjs.push_back({&br.slot_Xa, 12, 1, tRF[c], last_child_fwd, -1});
             }
         }
         for (int c = 0; c < nc; c++) {
@@ -538,14 +543,17 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
                 br.parent_slot_v = pr.slot_v;
                 br.parent_slot_a3 = pr.slot_a3;
                 br.parent_slot_f = pr.slot_f;
+                br.parent_slot_Xa = pr.slot_Xa;
             } else {
                 br.parent_slot_v = br.parent_slot_a3 = br.parent_slot_f = -1;
             }
             br.parent_slot_IA = br.parent_slot_psi = br.parent_slot_v3 = -1;
         }
     };
-    build_layout(P.lay32, lds_slots32);
-    build_layout(P.lay64, lds_slots64);
+    build_layout(P.lay32, lds_slots32, false);
+    build_layout(P.lay64, lds_slots64, false);
+    build_layout(P.lay32x, lds_slots32, true);
+    build_layout(P.lay64x, lds_slots64, true);
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
     // per-body costs: sincos ~40, E build 12, motion xform 39, force xform 39, sym6*vec 66,

@@ -104,7 +104,9 @@ struct BodyRec {
                               //    body is evaluated at q = 0 and its inertia contribution is a plan constant
     int32_t xofs;             // offset into consts[] of the 21 constants sum_children X0^T I X0 (or -1)
     int32_t acc_first_IA;     // like acc_first, counting only children that really accumulate an inertia
-    int32_t reserved[3];
+    int32_t slot_Xa;          // absolute transform world -> body (E 9, r 3); layouts with external forces, has_child only
+    int32_t parent_slot_Xa;
+    int32_t reserved[1];
 };
 
 // number of constants per body before the G row
@@ -128,7 +130,8 @@ struct HostPlan {
     std::vector<Step> rnea_steps;
     std::vector<double> consts;  // converted to float on upload for the f32 kernels
     std::vector<int32_t> cints;  // integer payload of implicit constraints
-    Layout lay32, lay64;
+    Layout lay32, lay64;      // fast path
+    Layout lay32x, lay64x;    // with absolute transforms kept for external forces (TreeNode::Xa_)
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };

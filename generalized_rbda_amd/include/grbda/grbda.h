@@ -872,10 +872,19 @@ private:
     {
         if (static_cast<int>(x.size()) != this->velocity_index_) throw std::runtime_error("input has the wrong dimension");
         if (static_cast<int>(q_.size()) != this->position_index_) throw std::runtime_error("state has not been set");
-        if (!f_ext_.empty()) throw std::runtime_error("external forces are not supported by the HIP kernels yet");
         std::vector<double> q(q_.begin(), q_.end()), qd(qd_.begin(), qd_.end()), in(x.begin(), x.end()), out(x.size());
-        check(inverse ? grbda_rnea_host_f64(plan(), q.data(), qd.data(), in.data(), nullptr, out.data(), 1, 0)
-                      : grbda_aba_host_f64(plan(), q.data(), qd.data(), in.data(), nullptr, out.data(), 1, 0));
+        // TreeModel::setExternalForces (TreeModel.cpp:214-239): forces on the same body add up
+        std::vector<double> fe;
+        if (!f_ext_.empty()) {
+            fe.assign(static_cast<size_t>(getNumBodies()) * 6, 0.0);
+            for (const auto &fb : f_ext_) {
+                if (fb.index_ < 0 || fb.index_ >= getNumBodies()) throw std::runtime_error("external force on an unknown body");
+                for (int i = 0; i < 6; i++) fe[static_cast<size_t>(fb.index_) * 6 + i] += static_cast<double>(fb.force_[i]);
+            }
+        }
+        const double *fp = fe.empty() ? nullptr : fe.data();
+        check(inverse ? grbda_rnea_host_f64(plan(), q.data(), qd.data(), in.data(), fp, out.data(), 1, 0)
+                      : grbda_aba_host_f64(plan(), q.data(), qd.data(), in.data(), fp, out.data(), 1, 0));
         return DVec<Scalar>(out.begin(), out.end());
     }
 

@@ -124,3 +124,31 @@ def test_lds_budget_does_not_change_results(gpu, monkeypatch):
         monkeypatch.setenv("GRBDA_LDS_BYTES_PER_WAVE", lds)
         outs.append(run_gpu(G.Plan(blob), "aba", q, qd, tau, torch.float64, gpu))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("name", ["tree_mixed_float", "tree_mixed_fixed", "urdf_mit_humanoid", "urdf_six_bar", "rev_pair_rotor_chain_4"])
+def test_external_forces_match_oracle(name, gpu):
+    """TreeModel::setExternalForces semantics (world-frame spatial force per body, TreeModel.cpp:214-239);
+    the reference's main dynamics test applies a random force to every body
+    (testRigidBodyDynamicsAlgos.cpp:189-204)."""
+    import torch
+    from generalized_rbda_amd.states import parse_clusters
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    nb = parse_clusters(blob)["nb"]
+    q, qd, tau = valid_states(blob, 130, config_index=26)
+    fext = np.random.default_rng(5).uniform(-1, 1, (q.shape[0], nb, 6))
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+    for dt, tol in ((torch.float64, TOL64), (torch.float32, TOL32)):
+        c = lambda a: a.astype(np.float32).astype(np.float64) if dt == torch.float32 else a
+        ref = O.forward_dynamics(blob, c(q), c(qd), c(tau), c(fext))
+        got = plan.forward_dynamics(t(q, dt), t(qd, dt), t(tau, dt), f_ext=t(fext, dt))
+        ref_t = O.inverse_dynamics(blob, c(q), c(qd), c(tau), c(fext))
+        got_t = plan.inverse_dynamics(t(q, dt), t(qd, dt), t(tau, dt), f_ext=t(fext, dt))
+        torch.cuda.synchronize()
+        assert rel_err(got.double().cpu().numpy(), ref) < tol, f"ABA {dt}"
+        assert rel_err(got_t.double().cpu().numpy(), ref_t) < tol, f"RNEA {dt}"
+    # forces must matter, and the host entry point takes them too
+    assert rel_err(O.forward_dynamics(blob, q, qd, tau), O.forward_dynamics(blob, q, qd, tau, fext)) > 1e-3
+    assert rel_err(plan.forward_dynamics_host(q, qd, tau, f_ext=fext), O.forward_dynamics(blob, q, qd, tau, fext)) < TOL64
