@@ -30,6 +30,8 @@ WORKLOADS = {
     "mini_cheetah": ("mini_cheetah.urdf", 65536, "f64", 1),
     "revolute_rotor_chain": ("revolute_rotor_chain.urdf", 1024, "f64", 0),
     "jvrc1_humanoid": ("jvrc1_humanoid.urdf", 1048576, "f32", 4),
+    # hand-built TelloWithArms (the URDF carries no constraints): implicit differentials
+    "tello": ("<TelloWithArms>", 1048576, "f32", 3),
 }
 
 
@@ -92,12 +94,30 @@ def main():
     if args.dtype:
         dtype_name = args.dtype
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
-    plan = G.Plan.from_urdf(os.path.join(ROOT, "robot-models", urdf))
+    if args.workload == "tello":
+        from generalized_rbda_amd.robots import tello_with_arms
+
+        plan = G.Plan.from_model(tello_with_arms())
+    else:
+        plan = G.Plan.from_urdf(os.path.join(ROOT, "robot-models", urdf))
     blob = plan.blob
     info = plan.info()
 
     # synthetic inputs: reference sampling law, counter-based RNG, distinct stream per rank
     q, qd, x = random_states(blob, B, config_index=cfg + 1000 * rank)
+    if args.workload == "tello":
+        # implicit clusters take spanning positions on the constraint manifold: Newton projection of the
+        # dependent coordinates (GenericJoint.cpp:289-385) with the CPU oracle -- input generation only;
+        # states that do not converge are replaced by converged ones
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as O
+
+        q, ok = O.project_positions(blob, q)
+        good = np.flatnonzero(ok)
+        if good.size == 0:
+            raise SystemExit("no valid Tello state could be generated")
+        bad = np.flatnonzero(~ok)
+        q[bad] = q[good[np.arange(bad.size) % good.size]]
     tq = torch.as_tensor(q, dtype=tdt, device=dev)
     tqd = torch.as_tensor(qd, dtype=tdt, device=dev)
     tx = torch.as_tensor(x, dtype=tdt, device=dev)

@@ -634,56 +634,206 @@ __device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const S
     for (int i = 0; i < 3; i++) p[i] = r[i] + E[i] * origin[9] + E[3 + i] * origin[10] + E[6 + i] * origin[11];
 }
 
-// G rows, g, spanning positions / velocities of an implicit-loop cluster into the scratch block
+// ---- K(q) and Kdot*qd of URDF+ position loops --------------------------------------------------
+template <class T, int N>
+__device__ __forceinline__ void loop_position_K(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                const ImpLayout<N> &lay, cptr<int32_t> loops, int n_loops)
+{
+    const int k = c.k;
+    cptr<int32_t> lp = loops;
+    int row0 = 0;
+    for (int l = 0; l < n_loops; l++) {
+        const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+        cptr<T> org = P.consts + c.dofs + 24 * l;
+        for (int side = 0; side < 2; side++) {
+            cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
+            const int len = side == 0 ? np : ns;
+            T p[3];
+            loop_chain_positions(P, S, c, subs, len, org + 12 * side, lay.qs, lay.chain, p);
+            const T sgn = side == 0 ? T(1) : T(-1);
+            for (int t = 0; t < len; t++) {
+                T ao[6];
+                S.ld(lay.chain + 6 * t, ao);
+                const T a[3] = {ao[0], ao[1], ao[2]}, d[3] = {p[0] - ao[3], p[1] - ao[4], p[2] - ao[5]};
+                T J[3];
+                cross3(a, d, J);
+                int row = row0;
+                const int sub = subs[t];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++)
+                    if (mask & (1 << ax)) {
+                        S.st1(lay.K + row * k + sub, sgn * J[ax]);
+                        row++;
+                    }
+            }
+        }
+        row0 += ((mask >> 0) & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1);
+        lp += 3 + np + ns;
+    }
+}
+
+// velocity-product acceleration of the constraint points: (Kdot qd)[row]
+template <class T, int N>
+__device__ __forceinline__ void loop_position_Kdqd(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                                   const ImpLayout<N> &lay, cptr<int32_t> loops, int n_loops, T (&kdq)[3])
+{
+    cptr<int32_t> lp = loops;
+    int row0 = 0;
+    for (int l = 0; l < n_loops; l++) {
+        const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+        cptr<T> org = P.consts + c.dofs + 24 * l;
+        T acc[3] = {0, 0, 0};
+        for (int side = 0; side < 2; side++) {
+            cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
+            const int len = side == 0 ? np : ns;
+            T p[3];
+            loop_chain_positions(P, S, c, subs, len, org + 12 * side, lay.qs, lay.chain, p);
+            T w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, ao_[3] = {0, 0, 0}, op[3] = {0, 0, 0};
+            for (int t = 0; t <= len; t++) {
+                T a[3] = {0, 0, 0}, o[3];
+                T qd_t = 0;
+                if (t < len) {
+                    T rec[6];
+                    S.ld(lay.chain + 6 * t, rec);
+                    a[0] = rec[0]; a[1] = rec[1]; a[2] = rec[2];
+                    o[0] = rec[3]; o[1] = rec[4]; o[2] = rec[5];
+                    qd_t = S.ld1(lay.qds + subs[t]);
+                } else {
+                    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+                }
+                // the point o is carried rigidly by the previous frame (w, al at origin op)
+                const T d[3] = {o[0] - op[0], o[1] - op[1], o[2] - op[2]};
+                T wd[3], wwd[3], ad[3];
+                cross3(w, d, wd);
+                cross3(w, wd, wwd);
+                cross3(al, d, ad);
+#pragma unroll
+                for (int i = 0; i < 3; i++) { ao_[i] += ad[i] + wwd[i]; op[i] = o[i]; }
+                // then the joint adds its own rate about a (qdd = 0)
+                const T aq[3] = {a[0] * qd_t, a[1] * qd_t, a[2] * qd_t};
+                T waq[3];
+                cross3(w, aq, waq);
+#pragma unroll
+                for (int i = 0; i < 3; i++) { al[i] += waq[i]; w[i] += aq[i]; }
+            }
+            const T sgn = side == 0 ? T(1) : T(-1);
+#pragma unroll
+            for (int i = 0; i < 3; i++) acc[i] += sgn * ao_[i];
+        }
+        int row = row0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+            if (mask & (1 << ax)) {
+                if (row == 0) kdq[0] = acc[ax];
+                else if (row == 1) kdq[1] = acc[ax];
+                else kdq[2] = acc[ax];
+                row++;
+            }
+        row0 = row;
+        lp += 3 + np + ns;
+    }
+}
+
+// ---- trig-polynomial constraints: phi_r = sum_t coef * prod_f F_f(w_f . q + b_f), F in {id, sin, cos} ----
+// (the hand-written phi lambdas of the Tello differentials, src/Robots/Tello.cpp:139-163,237-261; the
+// reference differentiates them with CasADi, here analytically).  want_K: K rows to scratch;
+// otherwise the second directional derivative along qd_span goes to kdq.
+template <class T, int N>
+__device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                               const ImpLayout<N> &lay, cptr<int32_t> prog, bool want_K, T (&kdq)[3])
+{
+    const int k = c.k;
+    cptr<int32_t> ip = prog;
+    cptr<T> dp = P.consts + c.dofs;
+    for (int r = 0; r < c.rows; r++) {
+        const int nt = *ip++;
+        T Krow[kMaxClusterBodies];
+#pragma unroll
+        for (int j = 0; j < kMaxClusterBodies; j++) Krow[j] = 0;
+        T kd = 0;
+        for (int t = 0; t < nt; t++) {
+            const int nf = *ip++;
+            const T coef = *dp++;
+            T f0[4], f1[4], f2[4], ad[4];
+            cptr<T> wv[4];
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                f0[f] = 1; f1[f] = 0; f2[f] = 0; ad[f] = 0;
+                wv[f] = dp;
+                if (f < nf) {
+                    const int type = *ip++;
+                    T a = dp[k], d = 0;
+                    for (int j = 0; j < k; j++) {
+                        const T w = dp[j];
+                        a += w * S.ld1(lay.qs + j);
+                        if (!want_K) d += w * S.ld1(lay.qds + j);
+                    }
+                    dp += k + 1;
+                    ad[f] = d;
+                    if (type == 1) { T sn, cs; sincos_t(a, &sn, &cs); f0[f] = sn; f1[f] = cs; f2[f] = -sn; }
+                    else if (type == 2) { T sn, cs; sincos_t(a, &sn, &cs); f0[f] = cs; f1[f] = -sn; f2[f] = -cs; }
+                    else { f0[f] = a; f1[f] = 1; f2[f] = 0; }
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                if (f < nf) {
+                    T others = coef;
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if (g != f) others *= f0[g];
+                    if (want_K) {
+#pragma unroll
+                        for (int j = 0; j < kMaxClusterBodies; j++)
+                            if (j < k) Krow[j] += others * f1[f] * wv[f][j];
+                    } else {
+                        kd += others * f2[f] * ad[f] * ad[f];
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+                            if (g != f && g < nf) {
+                                T rest = coef;
+#pragma unroll
+                                for (int h = 0; h < 4; h++)
+                                    if (h != f && h != g) rest *= f0[h];
+                                kd += rest * f1[f] * ad[f] * f1[g] * ad[g];
+                            }
+                    }
+                }
+            }
+        }
+        if (want_K) {
+#pragma unroll
+            for (int j = 0; j < kMaxClusterBodies; j++)
+                if (j < k) S.st1(lay.K + r * k + j, Krow[j]);
+        } else {
+            if (r == 0) kdq[0] = kd;
+            else if (r == 1) kdq[1] = kd;
+            else kdq[2] = kd;
+        }
+    }
+}
+
+// G rows, g, spanning positions / velocities of an implicit cluster into the scratch block
 template <class T, int N>
 __device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                                     const Lane<T> &L, int base, const T (&yd)[N], bool want_bias)
+                                                  const Lane<T> &L, int base, const T (&yd)[N], bool want_bias)
 {
     const ImpLayout<N> lay(base, c.k, c.rows);
     const int k = c.k, rows = c.rows;
     cptr<int32_t> ip = P.cints + c.iofs;
-    const int n_loops = ip[0];
+    const int hdr0 = ip[0];  // number of loops (position loops)
     const int n_ind = ip[1];
     cptr<int32_t> ind = ip + 2;
     cptr<int32_t> dep = ip + 3 + n_ind;
-    cptr<int32_t> loops = dep + rows;
+    cptr<int32_t> payload = dep + rows;
+    T kdq[3] = {0, 0, 0};
 
     for (int i = 0; i < k; i++) S.st1(lay.qs + i, L.q(c.q_index + i));
     for (int i = 0; i < rows * k; i++) S.st1(lay.K + i, T(0));
 
-    // ---- K(q): geometric Jacobian of (p_pred - p_succ), enforced axes only ----------------------
-    {
-        cptr<int32_t> lp = loops;
-        int row0 = 0;
-        for (int l = 0; l < n_loops; l++) {
-            const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
-            cptr<T> org = P.consts + c.dofs + 24 * l;
-            for (int side = 0; side < 2; side++) {
-                cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
-                const int len = side == 0 ? np : ns;
-                T p[3];
-                loop_chain_positions(P, S, c, subs, len, org + 12 * side, lay.qs, lay.chain, p);
-                const T sgn = side == 0 ? T(1) : T(-1);
-                for (int t = 0; t < len; t++) {
-                    T ao[6];
-                    S.ld(lay.chain + 6 * t, ao);
-                    const T a[3] = {ao[0], ao[1], ao[2]}, d[3] = {p[0] - ao[3], p[1] - ao[4], p[2] - ao[5]};
-                    T J[3];
-                    cross3(a, d, J);
-                    int row = row0;
-                    const int sub = subs[t];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++)
-                        if (mask & (1 << ax)) {
-                            S.st1(lay.K + row * k + sub, sgn * J[ax]);
-                            row++;
-                        }
-                }
-            }
-            row0 += ((mask >> 0) & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1);
-            lp += 3 + np + ns;
-        }
-    }
+    // ---- K(q) ------------------------------------------------------------------------------------
+    if (c.cons_type == 0) loop_position_K<T, N>(P, S, c, lay, payload, hdr0);
+    else trig_poly_eval<T, N>(P, S, c, lay, payload, true, kdq);
 
     // ---- G = P [1; -Kd^-1 Ki] ------------------------------------------------------------------
     T Kd[3][3], Kdi[3][3], X[3][N];
@@ -729,69 +879,12 @@ __device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const Slot
     }
     if (!want_bias) return;
 
-    // ---- k = -Kdot qd: velocity-product acceleration of the constraint point along each chain -------
-    T kv[3] = {0, 0, 0};
-    {
-        cptr<int32_t> lp = loops;
-        int row0 = 0;
-        for (int l = 0; l < n_loops; l++) {
-            const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
-            cptr<T> org = P.consts + c.dofs + 24 * l;
-            T acc[3] = {0, 0, 0};
-            for (int side = 0; side < 2; side++) {
-                cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
-                const int len = side == 0 ? np : ns;
-                T p[3];
-                loop_chain_positions(P, S, c, subs, len, org + 12 * side, lay.qs, lay.chain, p);
-                T w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, ao_[3] = {0, 0, 0}, op[3] = {0, 0, 0};
-                for (int t = 0; t <= len; t++) {
-                    T a[3] = {0, 0, 0}, o[3];
-                    T qd_t = 0;
-                    if (t < len) {
-                        T rec[6];
-                        S.ld(lay.chain + 6 * t, rec);
-                        a[0] = rec[0]; a[1] = rec[1]; a[2] = rec[2];
-                        o[0] = rec[3]; o[1] = rec[4]; o[2] = rec[5];
-                        qd_t = S.ld1(lay.qds + subs[t]);
-                    } else {
-                        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
-                    }
-                    // the point o is carried rigidly by the previous frame (w, al at origin op)
-                    const T d[3] = {o[0] - op[0], o[1] - op[1], o[2] - op[2]};
-                    T wd[3], wwd[3], ad[3];
-                    cross3(w, d, wd);
-                    cross3(w, wd, wwd);
-                    cross3(al, d, ad);
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { ao_[i] += ad[i] + wwd[i]; op[i] = o[i]; }
-                    // then the joint adds its own rate about a (qdd = 0)
-                    const T aq[3] = {a[0] * qd_t, a[1] * qd_t, a[2] * qd_t};
-                    T waq[3];
-                    cross3(w, aq, waq);
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { al[i] += waq[i]; w[i] += aq[i]; }
-                }
-                const T sgn = side == 0 ? T(1) : T(-1);
-#pragma unroll
-                for (int i = 0; i < 3; i++) acc[i] += sgn * ao_[i];
-            }
-            int row = row0;
-#pragma unroll
-            for (int ax = 0; ax < 3; ax++)
-                if (mask & (1 << ax)) {
-                    if (row == 0) kv[0] = -acc[ax];
-                    else if (row == 1) kv[1] = -acc[ax];
-                    else kv[2] = -acc[ax];
-                    row++;
-                }
-            row0 = row;
-            lp += 3 + np + ns;
-        }
-    }
-    // g = P [0; Kd^-1 k]
+    // ---- k = -Kdot qd ; g = P [0; Kd^-1 k] ----------------------------------------------------------
+    if (c.cons_type == 0) loop_position_Kdqd<T, N>(P, S, c, lay, payload, hdr0, kdq);
+    else trig_poly_eval<T, N>(P, S, c, lay, payload, false, kdq);
 #pragma unroll
     for (int r = 0; r < 3; r++)
-        if (r < rows) S.st1(lay.G + dep[r] * (N + 1) + N, Kdi[r][0] * kv[0] + Kdi[r][1] * kv[1] + Kdi[r][2] * kv[2]);
+        if (r < rows) S.st1(lay.G + dep[r] * (N + 1) + N, -(Kdi[r][0] * kdq[0] + Kdi[r][1] * kdq[1] + Kdi[r][2] * kdq[2]));
 }
 
 // coupling of body i of a revolute cluster: spanning angle, row of G, bias g_i.

@@ -111,17 +111,18 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             if (cl.n_dbl < cl.n_span_vel * cl.n_vel || cl.dbl_offset < 0 || cl.dbl_offset + cl.n_dbl > m.h->n_doubles)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: G payload missing", c);
             cr.kind = CK_STATIC;
-        } else if (cl.constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION) {
+        } else if (cl.constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION || cl.constraint_type == GRBDA_CONSTRAINT_TRIG_POLY) {
             if (cl.n_vel < 1 || cl.n_vel > kMaxClusterDof)
                 return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d DoF exceed the kernel limit", c, cl.n_vel);
             if (cl.n_span_vel != cl.n_bodies || cl.n_span_pos != cl.n_bodies || cl.n_pos != cl.n_bodies)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop cluster must have one revolute joint per body", c);
             if (cl.n_constraint_rows < 1 || cl.n_constraint_rows > 3 || cl.n_constraint_rows != cl.n_bodies - cl.n_vel)
                 return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d constraint rows (1..3 supported)", c, cl.n_constraint_rows);
-            if (cl.int_offset < 0 || cl.int_offset + cl.n_int > m.h->n_ints || cl.n_int < 1 + cl.n_bodies)
+            if (cl.int_offset < 0 || cl.int_offset + cl.n_int > m.h->n_ints || cl.n_int < cl.n_bodies)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop payload missing", c);
             cr.kind = CK_LOOP;
             cr.rows = cl.n_constraint_rows;
+            cr.cons_type = cl.constraint_type == GRBDA_CONSTRAINT_TRIG_POLY ? 1 : 0;
         } else {
             return fail(msg, cap, GRBDA_EUNSUPPORTED,
                         "cluster %d: implicit loop constraint kind %d is not covered by the HIP kernels yet", c,
@@ -253,29 +254,53 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
         if (clusters[c].kind != CK_LOOP) continue;
         const int32_t *ip = m.ints + cl.int_offset;
         const double *dp = m.dbls + cl.dbl_offset;
-        const int k = cl.n_bodies, n_loops = ip[0];
+        const int k = cl.n_bodies;
+        const bool trig = clusters[c].cons_type == 1;
+        const int32_t *flags = trig ? ip : ip + 1;
         clusters[c].iofs = static_cast<int>(P.cints.size());
         clusters[c].dofs = static_cast<int>(P.consts.size());
-        P.cints.push_back(n_loops);
+        P.cints.push_back(trig ? cl.n_constraint_rows : ip[0]);
         std::vector<int> ind, dep;
-        for (int i = 0; i < k; i++) (ip[1 + i] ? ind : dep).push_back(i);
+        for (int i = 0; i < k; i++) (flags[i] ? ind : dep).push_back(i);
         if (static_cast<int>(ind.size()) != cl.n_vel || static_cast<int>(dep.size()) != cl.n_constraint_rows)
             return fail(msg, cap, GRBDA_EINVAL, "cluster %d: independent/dependent coordinate counts", c);
         P.cints.push_back(static_cast<int>(ind.size()));
         for (int i : ind) P.cints.push_back(i);
         P.cints.push_back(static_cast<int>(dep.size()));
         for (int i : dep) P.cints.push_back(i);
-        const int32_t *lp = ip + 1 + k;
-        int rows = 0;
-        for (int l = 0; l < n_loops; l++) {
-            const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
-            if (np < 0 || ns < 0 || np > k || ns > k) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: bad loop chain", c);
-            for (int t = 0; t < 3 + np + ns; t++) P.cints.push_back(lp[t]);
-            lp += 3 + np + ns;
-            for (int a = 0; a < 3; a++) rows += (mask >> a) & 1;
-            for (int t = 0; t < 24; t++) P.consts.push_back(dp[24 * l + t]);
+        if (trig) {
+            // per row: n_terms; per term: n_factors, type[n_factors] | doubles: coef, per factor w[k], b
+            const int32_t *tp = ip + k;
+            const int32_t *tend = ip + cl.n_int;
+            int nd = 0;
+            for (int r = 0; r < cl.n_constraint_rows; r++) {
+                if (tp >= tend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly payload truncated", c);
+                const int nt = *tp++;
+                P.cints.push_back(nt);
+                for (int t = 0; t < nt; t++) {
+                    const int nf = *tp++;
+                    if (nf < 0 || nf > 4) return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: a term has %d factors (max 4)", c, nf);
+                    P.cints.push_back(nf);
+                    for (int f = 0; f < nf; f++) P.cints.push_back(*tp++);
+                    nd += 1 + nf * (k + 1);
+                }
+            }
+            if (nd > cl.n_dbl) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly doubles truncated", c);
+            for (int t = 0; t < nd; t++) P.consts.push_back(dp[t]);
+        } else {
+            const int n_loops = ip[0];
+            const int32_t *lp = ip + 1 + k;
+            int rows = 0;
+            for (int l = 0; l < n_loops; l++) {
+                const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+                if (np < 0 || ns < 0 || np > k || ns > k) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: bad loop chain", c);
+                for (int t = 0; t < 3 + np + ns; t++) P.cints.push_back(lp[t]);
+                lp += 3 + np + ns;
+                for (int a = 0; a < 3; a++) rows += (mask >> a) & 1;
+                for (int t = 0; t < 24; t++) P.consts.push_back(dp[24 * l + t]);
+            }
+            if (rows != cl.n_constraint_rows) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop rows mismatch", c);
         }
-        if (rows != cl.n_constraint_rows) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop rows mismatch", c);
     }
 
     // ---- sweep schedule: depth-first, a subtree is swept forward then backward ------------------

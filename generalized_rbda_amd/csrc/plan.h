@@ -73,7 +73,8 @@ struct ClusterRec {
     int32_t iofs;             // offset into cints[]: n_loops, n_ind, ind[], n_dep, dep[], loops...
     int32_t dofs;             // offset into consts[]: per loop pred origin E[9] r[3], succ origin E[9] r[3]
     int32_t corr_first_IA;    // 1: the cluster's -F D^-1 F^T term is the first inertia written to the parent's slot
-    int32_t reserved[2];
+    int32_t cons_type;        // implicit clusters: 0 position loops (URDF+ <loop>), 1 trig-polynomial phi
+    int32_t reserved[1];
 };
 
 struct BodyRec {

@@ -127,6 +127,9 @@ def zoo():
     z = {}
     for name in ("four_bar", "six_bar", "planar_leg_linkage", "mini_cheetah", "mit_humanoid"):
         z["urdf_" + name] = G.urdf_to_blob(os.path.join(ROBOT_MODELS, name + ".urdf"))
+    from generalized_rbda_amd.robots import tello_with_arms
+
+    z["tello_with_arms"] = tello_with_arms().serialize()
     for n in (2, 3, 4):
         z[f"rev_rotor_chain_{n}"] = md.revolute_chain_with_rotor(n).serialize()
     for n in (2, 4):
