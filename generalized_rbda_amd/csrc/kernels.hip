@@ -745,6 +745,13 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
     const int k = c.k;
     cptr<int32_t> ip = prog;
     cptr<T> dp = P.consts + c.dofs;
+    // spanning positions / velocities once into registers (k <= 8, static indexing)
+    T qv[kMaxClusterBodies], qdv[kMaxClusterBodies];
+#pragma unroll
+    for (int j = 0; j < kMaxClusterBodies; j++) {
+        qv[j] = j < k ? S.ld1(lay.qs + j) : T(0);
+        qdv[j] = (!want_K && j < k) ? S.ld1(lay.qds + j) : T(0);
+    }
     for (int r = 0; r < c.rows; r++) {
         const int nt = *ip++;
         T Krow[kMaxClusterBodies];
@@ -763,11 +770,13 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
                 if (f < nf) {
                     const int type = *ip++;
                     T a = dp[k], d = 0;
-                    for (int j = 0; j < k; j++) {
-                        const T w = dp[j];
-                        a += w * S.ld1(lay.qs + j);
-                        if (!want_K) d += w * S.ld1(lay.qds + j);
-                    }
+#pragma unroll
+                    for (int j = 0; j < kMaxClusterBodies; j++)
+                        if (j < k) {
+                            const T w = dp[j];
+                            a += w * qv[j];
+                            d += w * qdv[j];
+                        }
                     dp += k + 1;
                     ad[f] = d;
                     if (type == 1) { T sn, cs; sincos_t(a, &sn, &cs); f0[f] = sn; f1[f] = cs; f2[f] = -sn; }
