@@ -167,6 +167,16 @@ def main():
     kernel_evals_per_s = B / (kernel_ms * 1e-3)
     achieved_gbs = kernel_evals_per_s * bytes_per_eval / 1e9
     flops = info.flops_aba if args.algo == "aba" else info.flops_rnea
+    # measured HBM-side traffic of the same launch configuration, if a PMC run is committed (profiles/)
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if (e["workload"], e["algo"], e["dtype"], e["batch"]) == (args.workload, args.algo, dtype_name, B):
+                    traffic = e["bytes_per_launch"]
+                    traffic_src = "rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r1_pmc_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
     line = {
         "metric": "forward-dynamics evals/sec (batched random states), MIT Humanoid cluster model"
         if args.workload == "mit_humanoid" and args.algo == "aba"
@@ -186,8 +196,9 @@ def main():
                    "batch_per_gpu": B, "nq": plan.nq, "nv": plan.nv, "n_bodies": plan.n_bodies,
                    "n_clusters": plan.n_clusters, "parallelism": f"batch-sharded x{world}, plan replicated"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": f"{args.algo}_kernel<{'float' if dtype_name == 'f32' else 'double'}>",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": bytes_per_eval * B,
+                     "kernel": f"{args.algo}_kernel<{'float' if dtype_name == 'f32' else 'double'}, false>",
                      "kernel_ms": kernel_ms, "bytes_per_eval": bytes_per_eval,
                      "note": "algorithmic bytes; the path is VALU-bound (see valu)",
                      "valu": {"flops_per_eval": flops,
