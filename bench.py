@@ -99,7 +99,7 @@ def main():
 
         plan = G.Plan.from_model(tello_with_arms())
     else:
-        plan = G.Plan.from_urdf(os.path.join(ROOT, "robot-models", urdf))
+        plan = G.Plan.from_urdf(os.path.join(ROOT, "tests", "golden", "robot-models", urdf))
     blob = plan.blob
     info = plan.info()
 

@@ -429,6 +429,10 @@ struct Chol {
 // ---------------------------------------------------------------------------------------------
 // per-lane view of one state of the batch
 // ---------------------------------------------------------------------------------------------
+// number of independent cluster coordinates fetched one step ahead into registers; clusters with more
+// DoF (rare: triple-rotor, six-bar) load the remaining ones on demand
+constexpr int kPrefetchDof = 2;
+
 template <class T>
 struct Lane {
     // the tile's inputs, transposed once per tile into coordinate-major rows of the wave's global
@@ -440,9 +444,14 @@ struct Lane {
     __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
     __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
     __device__ __forceinline__ T x(int j) const { return in_x[(size_t)j * kWave]; }
+    // coordinate a of the current cluster: prefetched registers for a < kPrefetchDof (a is a compile-time
+    // constant at every call site), a coalesced row load otherwise
+    __device__ __forceinline__ T cy(const ClusterRec &c, int a) const { return a < kPrefetchDof ? y[a < kPrefetchDof ? a : 0] : q(c.q_index + a); }
+    __device__ __forceinline__ T cyd(const ClusterRec &c, int a) const { return a < kPrefetchDof ? yd[a < kPrefetchDof ? a : 0] : qd(c.v_index + a); }
+    __device__ __forceinline__ T cx(const ClusterRec &c, int a) const { return a < kPrefetchDof ? xx[a < kPrefetchDof ? a : 0] : x(c.v_index + a); }
     // the cluster's independent coordinates, fetched one step ahead (software pipelining: the
     // strided loads of step s+1 are in flight while step s computes)
-    T y[kMaxClusterDof], yd[kMaxClusterDof], xx[kMaxClusterDof];
+    T y[kPrefetchDof], yd[kPrefetchDof], xx[kPrefetchDof];
 };
 
 // Tile prologue: the batch is row-major ([state][coordinate], the reference's natural vector
@@ -516,11 +525,11 @@ struct Carry {
 };
 
 template <class T>
-__device__ __forceinline__ void prefetch_inputs(const Lane<T> &L, const ClusterRec &c, T (&y)[kMaxClusterDof],
-                                                T (&yd)[kMaxClusterDof], T (&xx)[kMaxClusterDof])
+__device__ __forceinline__ void prefetch_inputs(const Lane<T> &L, const ClusterRec &c, T (&y)[kPrefetchDof],
+                                                T (&yd)[kPrefetchDof], T (&xx)[kPrefetchDof])
 {
 #pragma unroll
-    for (int a = 0; a < kMaxClusterDof; a++) {
+    for (int a = 0; a < kPrefetchDof; a++) {
         const bool in = a < c.n;  // wave-uniform
         y[a] = in ? L.q(c.q_index + a) : T(0);
         yd[a] = in ? L.qd(c.v_index + a) : T(0);
@@ -1036,8 +1045,8 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
     T y[N], yd[N];
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        y[a] = L.y[a];
-        yd[a] = L.yd[a];
+        y[a] = L.cy(c, a);
+        yd[a] = L.cyd(c, a);
     }
     const int imp = c.slot_imp_fwd;
     if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
@@ -1147,9 +1156,9 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
     for (int j = 0; j < 6; j++) ppsi[j] = 0;
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        y[a] = L.y[a];
-        yd[a] = L.yd[a];
-        u[a] = L.xx[a];
+        y[a] = L.cy(c, a);
+        yd[a] = L.cyd(c, a);
+        u[a] = L.cx(c, a);
 #pragma unroll
         for (int r = 0; r < 6; r++) F[r][a] = 0;
 #pragma unroll
@@ -1452,8 +1461,8 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
     T y[N], yd[N];
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        y[a] = L.y[a];
-        yd[a] = L.yd[a];
+        y[a] = L.cy(c, a);
+        yd[a] = L.cyd(c, a);
     }
     const int imp = c.slot_imp_acc;
     bool evaluated = false;
@@ -1545,9 +1554,9 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
     T y[N], yd[N], ydd[N];
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        y[a] = L.y[a];
-        yd[a] = L.yd[a];
-        ydd[a] = L.xx[a];
+        y[a] = L.cy(c, a);
+        yd[a] = L.cyd(c, a);
+        ydd[a] = L.cx(c, a);
     }
     const int imp = c.slot_imp_fwd;
     if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
@@ -1642,8 +1651,8 @@ __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<
 #pragma unroll
     for (int a = 0; a < N; a++) {
         tau[a] = 0;
-        y[a] = L.y[a];
-        yd[a] = L.yd[a];
+        y[a] = L.cy(c, a);
+        yd[a] = L.cyd(c, a);
     }
     const int imp = c.slot_imp_bwd;
     if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
@@ -1744,7 +1753,7 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
         for (int j = 0; j < 21; j++) carry.IA[j] = 0;
 #pragma unroll
         for (int j = 0; j < 6; j++) carry.psi[j] = 0;
-        T ny[kMaxClusterDof], nyd[kMaxClusterDof], nxx[kMaxClusterDof];
+        T ny[kPrefetchDof], nyd[kPrefetchDof], nxx[kPrefetchDof];
         {
             const Step st0 = load_rec(P.steps + 0);
             const ClusterRec c0 = load_rec(P.clusters + st0.cluster);
@@ -1754,7 +1763,7 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
 #pragma unroll
-            for (int a = 0; a < kMaxClusterDof; a++) {
+            for (int a = 0; a < kPrefetchDof; a++) {
                 L.y[a] = ny[a];
                 L.yd[a] = nyd[a];
                 L.xx[a] = nxx[a];
@@ -1822,7 +1831,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.out = tau + rr * P.nv;
         L.fext = DP.fext ? DP.fext + rr * (size_t)DP.n_bodies * 6 : nullptr;
-        T ny[kMaxClusterDof], nyd[kMaxClusterDof], nxx[kMaxClusterDof];
+        T ny[kPrefetchDof], nyd[kPrefetchDof], nxx[kPrefetchDof];
         {
             const Step st0 = load_rec(P.steps + 0);
             const ClusterRec c0 = load_rec(P.clusters + st0.cluster);
@@ -1832,7 +1841,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
 #pragma unroll
-            for (int a = 0; a < kMaxClusterDof; a++) {
+            for (int a = 0; a < kPrefetchDof; a++) {
                 L.y[a] = ny[a];
                 L.yd[a] = nyd[a];
                 L.xx[a] = nxx[a];

@@ -96,7 +96,7 @@ def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor"
     return m
 
 
-ROBOT_MODELS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robot-models")
+ROBOT_MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "robot-models")
 
 
 def valid_states(blob, B, config_index=0):

@@ -12,7 +12,7 @@ from generalized_rbda_amd import modeldesc as md
 from generalized_rbda_amd.states import parse_clusters, random_states
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MODELS = os.path.join(ROOT, "robot-models")
+MODELS = os.path.join(ROOT, "tests", "golden", "robot-models")
 
 # (bodies, clusters, nq, nv, cluster-size histogram): SURVEY section 8 table, itself pinned by
 # UnitTests/testClusterTreeModel.cpp:149-154 and the hand-built robots of the reference

@@ -4,7 +4,7 @@ import torch
 import generalized_rbda_amd as G
 G.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "prof", "libgrbda_hip_prof.so")
 from generalized_rbda_amd.states import random_states
-plan = G.Plan.from_urdf("robot-models/mit_humanoid.urdf")
+plan = G.Plan.from_urdf("tests/golden/robot-models/mit_humanoid.urdf")
 B = 262144
 q, qd, tau = random_states(plan.blob, B, 2)
 dev = torch.device("cuda:0")
