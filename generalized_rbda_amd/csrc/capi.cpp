@@ -43,6 +43,7 @@ struct DeviceTables {
     ClusterRec *clusters[4] = {nullptr, nullptr, nullptr, nullptr};
     ClusterRec *rnea_clusters[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *cints = nullptr;
+    int32_t *aba_groups = nullptr, *rnea_groups = nullptr;
     BodyRec *bodies[4] = {nullptr, nullptr, nullptr, nullptr};       // ABA slots
     BodyRec *rnea_bodies[4] = {nullptr, nullptr, nullptr, nullptr};  // RNEA slots
     double *consts64 = nullptr;
@@ -100,7 +101,9 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         (e = up(h.rnea_steps.data(), h.rnea_steps.size() * sizeof(Step), (void **)&t.rnea_steps)) != hipSuccess ||
         (e = up(h.consts.data(), h.consts.size() * sizeof(double), (void **)&t.consts64)) != hipSuccess ||
         (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess ||
-        (e = up(h.cints.data(), h.cints.size() * sizeof(int32_t), (void **)&t.cints)) != hipSuccess)
+        (e = up(h.cints.data(), h.cints.size() * sizeof(int32_t), (void **)&t.cints)) != hipSuccess ||
+        (e = up(h.aba_groups.data(), h.aba_groups.size() * sizeof(int32_t), (void **)&t.aba_groups)) != hipSuccess ||
+        (e = up(h.rnea_groups.data(), h.rnea_groups.size() * sizeof(int32_t), (void **)&t.rnea_groups)) != hipSuccess)
         return hip_err(e, "plan upload");
     for (int w = 0; w < 4; w++) {
         const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
@@ -149,6 +152,7 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, 
     const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
     d.clusters = rnea ? t.rnea_clusters[w] : t.clusters[w];
     d.cints = t.cints;
+    d.groups = rnea ? t.rnea_groups : t.aba_groups;
     d.bodies = rnea ? t.rnea_bodies[w] : t.bodies[w];
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.nq = h.nq;
@@ -266,20 +270,12 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->lds_bytes_per_wave = env_int("GRBDA_LDS_BYTES_PER_WAVE", 20480);
     if (p->lds_bytes_per_wave < 0) p->lds_bytes_per_wave = 0;
     if (p->lds_bytes_per_wave > 160 * 1024) p->lds_bytes_per_wave = 160 * 1024;
-    int rc = compile_plan(blob, bytes, p->lds_bytes_per_wave / (4 * kWave), p->lds_bytes_per_wave / (8 * kWave), p->host,
-                          msg, sizeof msg);
-    if (rc) return set_err(rc, msg);
     // profiling aid (results are wrong when set): GRBDA_DEBUG_SWEEPS is a bit mask of the ABA sweeps to
     // keep -- 1 forward, 2 backward, 4 acceleration -- so that the cost of each sweep can be ablated
     const int sweeps = env_int("GRBDA_DEBUG_SWEEPS", 7);
-    if (sweeps != 7) {
-        std::vector<Step> kept;
-        for (const Step &st : p->host.aba_steps)
-            if ((st.op == OP_ABA_FWD && (sweeps & 1)) || (st.op == OP_ABA_BWD && (sweeps & 2)) ||
-                (st.op == OP_ABA_ACC && (sweeps & 4)))
-                kept.push_back(st);
-        p->host.aba_steps = kept;
-    }
+    int rc = compile_plan(blob, bytes, p->lds_bytes_per_wave / (4 * kWave), p->lds_bytes_per_wave / (8 * kWave), sweeps,
+                          p->host, msg, sizeof msg);
+    if (rc) return set_err(rc, msg);
     p->blob.assign(static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + bytes);
     p->waves_per_cu = env_int("GRBDA_WAVES_PER_CU", 8);
     if (p->waves_per_cu < 1) p->waves_per_cu = 1;
@@ -321,7 +317,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints);
+        (void)hipFree(t.cints); (void)hipFree(t.aba_groups); (void)hipFree(t.rnea_groups);
         for (int w = 0; w < 4; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto &kv : p->scratch) {

@@ -80,6 +80,7 @@ struct Tables {
     cptr<BodyRec> bodies;
     cptr<T> consts;
     cptr<int32_t> cints;
+    cptr<int32_t> groups;
     int n_steps, nq, nv, ori_repr;
     T a_root[6];
 };
@@ -92,6 +93,7 @@ __device__ __forceinline__ Tables<T> make_tables(const DevPlan<T> &P)
     t.bodies = (cptr<BodyRec>)P.bodies;
     t.consts = (cptr<T>)P.consts;
     t.cints = (cptr<int32_t>)P.cints;
+    t.groups = (cptr<int32_t>)P.groups;
     t.n_steps = P.n_steps;
     t.nq = P.nq;
     t.nv = P.nv;
@@ -429,10 +431,6 @@ struct Chol {
 // ---------------------------------------------------------------------------------------------
 // per-lane view of one state of the batch
 // ---------------------------------------------------------------------------------------------
-// number of independent cluster coordinates fetched one step ahead into registers; clusters with more
-// DoF (rare: triple-rotor, six-bar) load the remaining ones on demand
-constexpr int kPrefetchDof = 2;
-
 template <class T>
 struct Lane {
     // the tile's inputs, transposed once per tile into coordinate-major rows of the wave's global
@@ -444,14 +442,13 @@ struct Lane {
     __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
     __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
     __device__ __forceinline__ T x(int j) const { return in_x[(size_t)j * kWave]; }
-    // coordinate a of the current cluster: prefetched registers for a < kPrefetchDof (a is a compile-time
-    // constant at every call site), a coalesced row load otherwise
-    __device__ __forceinline__ T cy(const ClusterRec &c, int a) const { return a < kPrefetchDof ? y[a < kPrefetchDof ? a : 0] : q(c.q_index + a); }
-    __device__ __forceinline__ T cyd(const ClusterRec &c, int a) const { return a < kPrefetchDof ? yd[a < kPrefetchDof ? a : 0] : qd(c.v_index + a); }
-    __device__ __forceinline__ T cx(const ClusterRec &c, int a) const { return a < kPrefetchDof ? xx[a < kPrefetchDof ? a : 0] : x(c.v_index + a); }
-    // the cluster's independent coordinates, fetched one step ahead (software pipelining: the
-    // strided loads of step s+1 are in flight while step s computes)
-    T y[kPrefetchDof], yd[kPrefetchDof], xx[kPrefetchDof];
+    // coordinate a of the current step's cluster: from the staged input group in LDS
+    // ([y n][yd n][x n] at slot in_base, plan.h), or from the slab when the cluster is not staged
+    int in_base, lane;
+    __device__ __forceinline__ T staged(int s) const { return reinterpret_cast<const T *>(grbda_smem)[s * kWave + lane]; }
+    __device__ __forceinline__ T cy(const ClusterRec &c, int a) const { return in_base >= 0 ? staged(in_base + a) : q(c.q_index + a); }
+    __device__ __forceinline__ T cyd(const ClusterRec &c, int a) const { return in_base >= 0 ? staged(in_base + c.n + a) : qd(c.v_index + a); }
+    __device__ __forceinline__ T cx(const ClusterRec &c, int a) const { return in_base >= 0 ? staged(in_base + 2 * c.n + a) : x(c.v_index + a); }
 };
 
 // Tile prologue: the batch is row-major ([state][coordinate], the reference's natural vector
@@ -517,6 +514,37 @@ __device__ __forceinline__ void stage_inputs(const T *__restrict__ q, const T *_
     }
 }
 
+// Input groups: the rows of q / qd / tau the clusters of a run of steps need are copied from the wave's
+// slab into LDS slots [0, kInputSlots) with asynchronous global->LDS loads.  The region is
+// double-buffered: the copy for run g+1 is issued when run g begins, so it has a whole run of steps
+// to land and the wait at the next boundary is (almost) free.
+template <class T>
+__device__ __forceinline__ void issue_group(const Tables<T> &P, const T *slab, int group, int lane)
+{
+    cptr<int32_t> g = P.groups + group;
+    const int n_rows = g[0];
+    if (n_rows <= 0) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier reads of that half have completed
+    constexpr int kDw = (int)(sizeof(T) / 4);
+    for (int r = 0; r < n_rows; r++) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(slab + (size_t)g[1 + 2 * r] * kWave);
+        const unsigned dst = (unsigned)g[2 + 2 * r] * (unsigned)(kWave * sizeof(T));
+#pragma unroll
+        for (int h = 0; h < kDw; h++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + h * kWave + lane),
+                                             (__attribute__((address_space(3))) void *)(grbda_smem + dst + (unsigned)h * 256u),
+                                             4, 0, 0);
+    }
+}
+// a run begins: its rows (issued one run earlier) must have landed; then start fetching the next run's
+template <class T>
+__device__ __forceinline__ void begin_group(const Tables<T> &P, const T *slab, int group, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int next = group + 1 + 2 * P.groups[group];
+    if (P.groups[next] >= 0) issue_group(P, slab, next, lane);
+}
+
 // register hand-over of a cluster's projected inertia / bias to the next backward step
 template <class T>
 struct Carry {
@@ -524,18 +552,6 @@ struct Carry {
     T psi[6];
 };
 
-template <class T>
-__device__ __forceinline__ void prefetch_inputs(const Lane<T> &L, const ClusterRec &c, T (&y)[kPrefetchDof],
-                                                T (&yd)[kPrefetchDof], T (&xx)[kPrefetchDof])
-{
-#pragma unroll
-    for (int a = 0; a < kPrefetchDof; a++) {
-        const bool in = a < c.n;  // wave-uniform
-        y[a] = in ? L.q(c.q_index + a) : T(0);
-        yd[a] = in ? L.qd(c.v_index + a) : T(0);
-        xx[a] = in ? L.x(c.v_index + a) : T(0);
-    }
-}
 
 // spanning joint value of body i: row i of G times the independent cluster coordinates
 // (LoopConstraint::Static::gamma, LoopConstraint.cpp:49-52; ClusterJoint.cpp:55-58)
@@ -1051,8 +1067,8 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
     const int imp = c.slot_imp_fwd;
     if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
     for (int i = 0; i < c.k; i++) {
+        if (!((c.child_mask >> i) & 1)) continue;  // leaf bodies are evaluated inside the backward step
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
-        if (!b.has_child) continue;
         cptr<T> C = P.consts + b.cofs;
         T qi, gi;
         typename RowSel<T, N, LOOP>::type Gr;
@@ -1467,8 +1483,8 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
     const int imp = c.slot_imp_acc;
     bool evaluated = false;
     for (int i = 0; i < c.k; i++) {
+        if (!((c.child_mask >> i) & 1)) continue;  // nothing downstream needs this body's acceleration
         const BodyRec b = load_rec(P.bodies + (c.first_body + i));
-        if (!b.has_child) continue;  // nothing downstream needs this body's acceleration
         if constexpr (LOOP) {
             if (!evaluated) {
                 eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
@@ -1753,27 +1769,16 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
         for (int j = 0; j < 21; j++) carry.IA[j] = 0;
 #pragma unroll
         for (int j = 0; j < 6; j++) carry.psi[j] = 0;
-        T ny[kPrefetchDof], nyd[kPrefetchDof], nxx[kPrefetchDof];
-        {
-            const Step st0 = load_rec(P.steps + 0);
-            const ClusterRec c0 = load_rec(P.clusters + st0.cluster);
-            prefetch_inputs(L, c0, ny, nyd, nxx);
-        }
+        L.lane = lane;
+        if (DP.groups && P.groups[0] >= 0) issue_group(P, slab, 0, lane);  // first run of the tile
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
-#pragma unroll
-            for (int a = 0; a < kPrefetchDof; a++) {
-                L.y[a] = ny[a];
-                L.yd[a] = nyd[a];
-                L.xx[a] = nxx[a];
-            }
-            if (s + 1 < P.n_steps) {
-                const Step st1 = load_rec(P.steps + (s + 1));
-                const ClusterRec c1 = load_rec(P.clusters + st1.cluster);
-                prefetch_inputs(L, c1, ny, nyd, nxx);
-            }
-            PROF_ADD(1);
+            PROF_SYNC();
+            PROF_ADD(12);  // step + cluster record round trips
+            if (st.group >= 0) begin_group(P, slab, st.group, lane);
+            L.in_base = st.in_base;
+            PROF_ADD(1);   // input-group boundary: wait for the staged rows, issue the next copy
             if (st.op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
@@ -1831,26 +1836,13 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.out = tau + rr * P.nv;
         L.fext = DP.fext ? DP.fext + rr * (size_t)DP.n_bodies * 6 : nullptr;
-        T ny[kPrefetchDof], nyd[kPrefetchDof], nxx[kPrefetchDof];
-        {
-            const Step st0 = load_rec(P.steps + 0);
-            const ClusterRec c0 = load_rec(P.clusters + st0.cluster);
-            prefetch_inputs(L, c0, ny, nyd, nxx);
-        }
+        L.lane = lane;
+        if (DP.groups && P.groups[0] >= 0) issue_group(P, slab, 0, lane);  // first run of the tile
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
-#pragma unroll
-            for (int a = 0; a < kPrefetchDof; a++) {
-                L.y[a] = ny[a];
-                L.yd[a] = nyd[a];
-                L.xx[a] = nxx[a];
-            }
-            if (s + 1 < P.n_steps) {
-                const Step st1 = load_rec(P.steps + (s + 1));
-                const ClusterRec c1 = load_rec(P.clusters + st1.cluster);
-                prefetch_inputs(L, c1, ny, nyd, nxx);
-            }
+            if (st.group >= 0) begin_group(P, slab, st.group, lane);
+            L.in_base = st.in_base;
             if (st.op == OP_RNEA_FWD) {
                 if (c.kind == CK_FREE) {
                     rnea_fwd_free(P, S, c, L);

@@ -57,7 +57,8 @@ int parse(const void *blob, size_t bytes, Blob &m, char *msg, size_t cap)
 
 }  // namespace
 
-int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, HostPlan &P, char *msg, size_t cap)
+int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, int sweep_mask, HostPlan &P, char *msg,
+                 size_t cap)
 {
     Blob m;
     if (int rc = parse(blob, bytes, m, msg, cap)) return rc;
@@ -162,6 +163,8 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
 
     for (int b = 0; b < nb; b++)
         if (bodies[b].parent >= 0) bodies[bodies[b].parent].has_child = 1;
+    for (int b = 0; b < nb; b++)
+        if (bodies[b].has_child) clusters[m.bodies[b].cluster].child_mask |= 1 << m.bodies[b].sub_index;
 
     // ---- constants --------------------------------------------------------------------------
     for (int b = 0; b < nb; b++) {
@@ -316,24 +319,24 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
         for (int r : roots) {
             stack.push_back({r, 0});
             tF[r] = static_cast<int>(P.aba_steps.size());
-            P.aba_steps.push_back({OP_ABA_FWD, r});
+            P.aba_steps.push_back({OP_ABA_FWD, r, -1, -1});
             tRF[r] = static_cast<int>(P.rnea_steps.size());
-            P.rnea_steps.push_back({OP_RNEA_FWD, r});
+            P.rnea_steps.push_back({OP_RNEA_FWD, r, -1, -1});
             while (!stack.empty()) {
                 auto &top = stack.back();
                 const int c = top.first;
                 if (top.second < static_cast<int>(kids[c].size())) {
                     const int ch = kids[c][top.second++];
                     tF[ch] = static_cast<int>(P.aba_steps.size());
-                    P.aba_steps.push_back({OP_ABA_FWD, ch});
+                    P.aba_steps.push_back({OP_ABA_FWD, ch, -1, -1});
                     tRF[ch] = static_cast<int>(P.rnea_steps.size());
-                    P.rnea_steps.push_back({OP_RNEA_FWD, ch});
+                    P.rnea_steps.push_back({OP_RNEA_FWD, ch, -1, -1});
                     stack.push_back({ch, 0});
                 } else {
                     tB[c] = static_cast<int>(P.aba_steps.size());
-                    P.aba_steps.push_back({OP_ABA_BWD, c});
+                    P.aba_steps.push_back({OP_ABA_BWD, c, -1, -1});
                     tRB[c] = static_cast<int>(P.rnea_steps.size());
-                    P.rnea_steps.push_back({OP_RNEA_BWD, c});
+                    P.rnea_steps.push_back({OP_RNEA_BWD, c, -1, -1});
                     stack.pop_back();
                 }
             }
@@ -345,7 +348,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
                 const int c = st.back();
                 st.pop_back();
                 tA[c] = static_cast<int>(P.aba_steps.size());
-                P.aba_steps.push_back({OP_ABA_ACC, c});
+                P.aba_steps.push_back({OP_ABA_ACC, c, -1, -1});
                 for (int i = static_cast<int>(kids[c].size()) - 1; i >= 0; i--) st.push_back(kids[c][i]);
             }
         }
@@ -369,12 +372,71 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
         }
     }
 
+    // ---- input groups ------------------------------------------------------------------------------
+    // Greedy partition of the step sequence into runs whose clusters' inputs (3 n rows each) fit into
+    // kInputSlots LDS slots; the kernel stages a run's rows when its first step begins.
+    P.input_slots = (lds_slots32 >= 2 * kInputSlots && lds_slots64 >= 2 * kInputSlots) ? kInputSlots : 0;
+    auto build_groups = [&](std::vector<Step> &steps, std::vector<int32_t> &groups) {
+        // The region is double-buffered: group g lives in half (g & 1) and is fetched while group g-1
+        // is being processed, so its latency is hidden behind a whole run of steps.
+        groups.clear();
+        if (!P.input_slots) {
+            groups.push_back(-1);
+            return;
+        }
+        const int half = kInputSlots / 2;
+        const int nsteps = static_cast<int>(steps.size());
+        int s0 = 0, gidx = 0;
+        while (s0 < nsteps) {
+            std::vector<int> base(nc, -1);
+            std::vector<int32_t> rows;
+            const int off = (gidx & 1) * half;
+            int used = 0, s1 = s0;
+            for (; s1 < nsteps; s1++) {
+                const int c = steps[s1].cluster;
+                if (clusters[c].kind == CK_FREE || base[c] >= 0) continue;
+                const int n = clusters[c].n;
+                if (3 * n > half) { base[c] = -2; continue; }  // too large for the region: reads the slab
+                if (used + 3 * n > half) break;
+                base[c] = off + used;
+                for (int a = 0; a < n; a++) { rows.push_back(clusters[c].q_index + a); rows.push_back(off + used + a); }
+                for (int a = 0; a < n; a++) { rows.push_back(P.nq + clusters[c].v_index + a); rows.push_back(off + used + n + a); }
+                for (int a = 0; a < n; a++) { rows.push_back(P.nq + P.nv + clusters[c].v_index + a); rows.push_back(off + used + 2 * n + a); }
+                used += 3 * n;
+            }
+            if (s1 == s0) s1 = s0 + 1;
+            for (int t = s0; t < s1; t++) {
+                const int b = clusters[steps[t].cluster].kind == CK_FREE ? -1 : base[steps[t].cluster];
+                steps[t].in_base = b >= 0 ? b : -1;
+            }
+            // every run gets a group record (possibly empty) so that "next group" is simply the next record
+            steps[s0].group = static_cast<int32_t>(groups.size());
+            groups.push_back(static_cast<int32_t>(rows.size() / 2));
+            groups.insert(groups.end(), rows.begin(), rows.end());
+            gidx++;
+            s0 = s1;
+        }
+        groups.push_back(-1);  // terminator: no further group
+    };
+    if (sweep_mask != 7) {  // profiling aid: drop whole sweeps (results are then meaningless)
+        std::vector<Step> kept;
+        for (const Step &st : P.aba_steps)
+            if ((st.op == OP_ABA_FWD && (sweep_mask & 1)) || (st.op == OP_ABA_BWD && (sweep_mask & 2)) ||
+                (st.op == OP_ABA_ACC && (sweep_mask & 4)))
+                kept.push_back(st);
+        P.aba_steps = kept;
+    }
+    build_groups(P.aba_steps, P.aba_groups);
+    build_groups(P.rnea_steps, P.rnea_groups);
+
     // ---- live ranges + interval allocation --------------------------------------------------------
     struct Obj {
         int *field;  // where the slot number goes (index into a flat array of fields)
         int size, prio, birth, death, slot;
     };
-    auto allocate = [](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb) {
+    const int lds_base = P.input_slots;  // state slots start after the input staging region
+    auto allocate = [lds_base](std::vector<Obj> &objs, int lds_budget_total, int &n_lds, int &n_glb) {
+        const int lds_budget = lds_budget_total > lds_base ? lds_budget_total - lds_base : 0;
         std::vector<int> order(objs.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = static_cast<int>(i);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
@@ -382,13 +444,14 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             return objs[a].birth < objs[b].birth;
         });
         std::vector<int> placed_lds, placed_glb;
-        n_lds = n_glb = 0;
+        n_lds = lds_base;
+        n_glb = 0;
         auto first_fit = [&](const Obj &o, const std::vector<int> &placed, bool global, int limit) -> int {
             std::vector<std::pair<int, int>> busy;
             for (int pi : placed) {
                 const Obj &p = objs[pi];
                 if (p.death < o.birth || o.death < p.birth) continue;
-                const int off = global ? (p.slot & ~kSlotGlobal) : p.slot;
+                const int off = global ? (p.slot & ~kSlotGlobal) : p.slot - lds_base;
                 busy.push_back({off, off + p.size});
             }
             std::sort(busy.begin(), busy.end());
@@ -404,9 +467,9 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             Obj &o = objs[oi];
             int at = first_fit(o, placed_lds, false, lds_budget);
             if (at >= 0) {
-                o.slot = at;
+                o.slot = at + lds_base;
                 placed_lds.push_back(oi);
-                if (at + o.size > n_lds) n_lds = at + o.size;
+                if (at + o.size + lds_base > n_lds) n_lds = at + o.size + lds_base;
             } else {
                 at = first_fit(o, placed_glb, true, -1);
                 o.slot = kSlotGlobal | at;

@@ -47,7 +47,14 @@ constexpr int32_t kSlotGlobal = 1 << 30;
 struct Step {
     int32_t op;
     int32_t cluster;
+    int32_t group;    // >= 0: an input group begins at this step, offset of its row list in groups[]
+    int32_t in_base;  // LDS slot of this cluster's staged inputs [y n][yd n][x n], or -1 (read the slab)
 };
+
+// LDS slots [0, kInputSlots) hold the staged inputs of the current "input group": the independent
+// coordinates / velocities / torques of all clusters of a run of consecutive steps (typically one
+// limb), copied from the wave's slab with asynchronous global->LDS loads when the run begins.
+constexpr int kInputSlots = 16;
 
 struct ClusterRec {
     int32_t kind;
@@ -74,7 +81,8 @@ struct ClusterRec {
     int32_t dofs;             // offset into consts[]: per loop pred origin E[9] r[3], succ origin E[9] r[3]
     int32_t corr_first_IA;    // 1: the cluster's -F D^-1 F^T term is the first inertia written to the parent's slot
     int32_t cons_type;        // implicit clusters: 0 position loops (URDF+ <loop>), 1 trig-polynomial phi
-    int32_t reserved[1];
+    int32_t child_mask;       // bit i: body i of the cluster has children (forward / acceleration sweeps skip the rest
+                              // without fetching their records)
 };
 
 struct BodyRec {
@@ -129,6 +137,9 @@ struct HostPlan {
     double gravity[6] = {0, 0, 0, 0, 0, -9.81};
     std::vector<Step> aba_steps;
     std::vector<Step> rnea_steps;
+    // per group: n_rows, then n_rows x (slab input row, LDS slot)
+    std::vector<int32_t> aba_groups, rnea_groups;
+    int input_slots = 0;  // kInputSlots when input groups are in use, 0 when the LDS budget is too small
     std::vector<double> consts;  // converted to float on upload for the f32 kernels
     std::vector<int32_t> cints;  // integer payload of implicit constraints
     Layout lay32, lay64;      // fast path
@@ -140,7 +151,7 @@ struct HostPlan {
 // Compile a model-description blob (include/grbda_model_desc.h) into a HostPlan.
 // lds_slots32 / lds_slots64: LDS budget per wavefront in slots for the f32 / f64 kernels.
 // Returns 0 or a negative GRBDA_E* code (include/grbda_hip.h); msg receives a diagnostic.
-int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, HostPlan &out, char *msg,
-                 size_t msg_cap);
+int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, int sweep_mask, HostPlan &out,
+                 char *msg, size_t msg_cap);
 
 }  // namespace grbda_hip
