@@ -43,3 +43,9 @@ prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	@mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) -DGRBDA_PROFILE -c $(CSRC)/kernels.hip -o build/prof/kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/libgrbda_hip_prof.so build/prof/kernels.o $^
+
+# experiment builds: make exp NAME=foo DEFS="-DGRBDA_EXP_FOO" -> build/exp/libgrbda_foo.so
+exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+	@mkdir -p build/exp
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/kernels.hip -o build/exp/kernels_$(NAME).o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/kernels_$(NAME).o $^

@@ -69,8 +69,13 @@ struct grbda_plan {
     mutable std::mutex mu;
     mutable std::map<int, DeviceTables> dev;
     mutable std::map<std::pair<int, void *>, Scratch> scratch;
-    int lds_bytes_per_wave = 16384;  // LDS budget per wavefront for the slot store
-    int waves_per_cu = 8;
+    // launch shape per kernel, index = (rnea ? 2 : 0) + (f64 ? 1 : 0): LDS budget per wavefront for the
+    // slot store, and wavefronts launched per CU (the grid is persistent)
+    // (defaults from a sweep on MI355X over the MIT humanoid, Mini Cheetah and JVRC-1: the f32 RNEA kernel
+    // needs ~100 VGPRs and gains from 16 wavefronts per CU with little LDS each, the f64 ABA kernel is
+    // limited to 4 per CU by its registers and takes the LDS that leaves free)
+    int lds_bytes_per_wave[4] = {20480, 40960, 10240, 10240};
+    int waves_per_cu[4] = {8, 4, 16, 8};
 };
 
 namespace {
@@ -152,7 +157,7 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, 
     const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
     d.clusters = rnea ? t.rnea_clusters[w] : t.clusters[w];
     d.cints = t.cints;
-    d.groups = rnea ? t.rnea_groups : t.aba_groups;
+    d.groups = (rnea ? L.input_slots_rnea : L.input_slots_aba) ? (rnea ? t.rnea_groups : t.aba_groups) : nullptr;
     d.bodies = rnea ? t.rnea_bodies[w] : t.bodies[w];
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.nq = h.nq;
@@ -178,7 +183,8 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     DevPlan<T> d = make_dev_plan<T>(p, *t, rnea, f_ext != nullptr);
     d.fext = f_ext;
     const size_t n_tiles = (B + kWave - 1) / kWave;
-    size_t grid = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->waves_per_cu);
+    const int kid = (rnea ? 2 : 0) + (sizeof(T) == 8 ? 1 : 0);
+    size_t grid = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->waves_per_cu[kid]);
     if (grid > n_tiles) grid = n_tiles;
     const size_t n_glb = static_cast<size_t>(d.n_glb_slots) + static_cast<size_t>(d.nq + 2 * d.nv);  // + staged inputs
     const size_t scratch_bytes = grid * n_glb * kWave * sizeof(T) + 256;
@@ -189,8 +195,14 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     const size_t stage_one = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq > d.nv ? d.nq : d.nv) * sizeof(T);
     const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq + 2 * d.nv) * sizeof(T);
     if (lds_bytes < stage_one) lds_bytes = stage_one;
-    if (lds_bytes < stage_all && stage_all <= static_cast<size_t>(p->lds_bytes_per_wave)) lds_bytes = stage_all;
+    if (lds_bytes < stage_all && stage_all <= static_cast<size_t>(p->lds_bytes_per_wave[kid])) lds_bytes = stage_all;
     d.lds_bytes = static_cast<int>(lds_bytes);
+    // a CU holds 160 KiB of LDS: never launch more persistent wavefronts than can be resident at once
+    const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
+    if (fit >= 1 && fit < static_cast<size_t>(p->waves_per_cu[kid])) {
+        const size_t g2 = static_cast<size_t>(t->n_cu) * fit;
+        if (grid > g2) grid = g2;
+    }
     hipError_t e;
     if (rnea)
         e = launch_rnea<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
@@ -267,19 +279,28 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     std::unique_ptr<grbda_plan> p(new (std::nothrow) grbda_plan());
     if (!p) return set_err(GRBDA_ENOMEM, "allocation failed");
     char msg[256] = {0};
-    p->lds_bytes_per_wave = env_int("GRBDA_LDS_BYTES_PER_WAVE", 20480);
-    if (p->lds_bytes_per_wave < 0) p->lds_bytes_per_wave = 0;
-    if (p->lds_bytes_per_wave > 160 * 1024) p->lds_bytes_per_wave = 160 * 1024;
+    // tuning knobs: GRBDA_LDS_BYTES_PER_WAVE / GRBDA_WAVES_PER_CU set all four kernels, the suffixed
+    // forms (_ABA32, _ABA64, _RNEA32, _RNEA64) one of them
+    static const char *const suffix[4] = {"_ABA32", "_ABA64", "_RNEA32", "_RNEA64"};
+    for (int k = 0; k < 4; k++) {
+        int v = env_int("GRBDA_LDS_BYTES_PER_WAVE", p->lds_bytes_per_wave[k]);
+        v = env_int((std::string("GRBDA_LDS_BYTES_PER_WAVE") + suffix[k]).c_str(), v);
+        p->lds_bytes_per_wave[k] = v < 0 ? 0 : (v > 160 * 1024 ? 160 * 1024 : v);
+        int w = env_int("GRBDA_WAVES_PER_CU", p->waves_per_cu[k]);
+        w = env_int((std::string("GRBDA_WAVES_PER_CU") + suffix[k]).c_str(), w);
+        p->waves_per_cu[k] = w < 1 ? 1 : (w > 32 ? 32 : w);
+    }
+    LdsBudget lds;
+    lds.aba32 = p->lds_bytes_per_wave[0] / (4 * kWave);
+    lds.aba64 = p->lds_bytes_per_wave[1] / (8 * kWave);
+    lds.rnea32 = p->lds_bytes_per_wave[2] / (4 * kWave);
+    lds.rnea64 = p->lds_bytes_per_wave[3] / (8 * kWave);
     // profiling aid (results are wrong when set): GRBDA_DEBUG_SWEEPS is a bit mask of the ABA sweeps to
     // keep -- 1 forward, 2 backward, 4 acceleration -- so that the cost of each sweep can be ablated
     const int sweeps = env_int("GRBDA_DEBUG_SWEEPS", 7);
-    int rc = compile_plan(blob, bytes, p->lds_bytes_per_wave / (4 * kWave), p->lds_bytes_per_wave / (8 * kWave), sweeps,
-                          p->host, msg, sizeof msg);
+    int rc = compile_plan(blob, bytes, lds, sweeps, p->host, msg, sizeof msg);
     if (rc) return set_err(rc, msg);
     p->blob.assign(static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + bytes);
-    p->waves_per_cu = env_int("GRBDA_WAVES_PER_CU", 8);
-    if (p->waves_per_cu < 1) p->waves_per_cu = 1;
-    if (p->waves_per_cu > 32) p->waves_per_cu = 32;
     *out = p.release();
     return GRBDA_OK;
 }

@@ -1458,8 +1458,13 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
                                                const Lane<T> &L)
 {
     T K[6 * N], ydd[N], ap[6];
+#ifdef GRBDA_EXP_NOK
+    for (int j = 0; j < 6 * N; j++) K[j] = T(0.01) * j;
+    for (int j = 0; j < N; j++) ydd[j] = T(0.5);
+#else
     S.ld(c.slot_K, K);
     S.ld(c.slot_y0, ydd);
+#endif
     if (c.parent_slot_a3 >= 0) {
         S.ld(c.parent_slot_a3, ap);
     } else {
@@ -1776,8 +1781,8 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
             const ClusterRec c = load_rec(P.clusters + st.cluster);
             PROF_SYNC();
             PROF_ADD(12);  // step + cluster record round trips
-            if (st.group >= 0) begin_group(P, slab, st.group, lane);
-            L.in_base = st.in_base;
+            if (DP.groups && st.group >= 0) begin_group(P, slab, st.group, lane);
+            L.in_base = DP.groups ? st.in_base : -1;
             PROF_ADD(1);   // input-group boundary: wait for the staged rows, issue the next copy
             if (st.op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
@@ -1841,8 +1846,8 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
-            if (st.group >= 0) begin_group(P, slab, st.group, lane);
-            L.in_base = st.in_base;
+            if (DP.groups && st.group >= 0) begin_group(P, slab, st.group, lane);
+            L.in_base = DP.groups ? st.in_base : -1;
             if (st.op == OP_RNEA_FWD) {
                 if (c.kind == CK_FREE) {
                     rnea_fwd_free(P, S, c, L);

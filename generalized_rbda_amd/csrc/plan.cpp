@@ -57,7 +57,7 @@ int parse(const void *blob, size_t bytes, Blob &m, char *msg, size_t cap)
 
 }  // namespace
 
-int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, int sweep_mask, HostPlan &P, char *msg,
+int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep_mask, HostPlan &P, char *msg,
                  size_t cap)
 {
     Blob m;
@@ -375,15 +375,11 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
     // ---- input groups ------------------------------------------------------------------------------
     // Greedy partition of the step sequence into runs whose clusters' inputs (3 n rows each) fit into
     // kInputSlots LDS slots; the kernel stages a run's rows when its first step begins.
-    P.input_slots = (lds_slots32 >= 2 * kInputSlots && lds_slots64 >= 2 * kInputSlots) ? kInputSlots : 0;
+    // (a kernel whose LDS budget is too small for the region ignores the groups and reads the slab)
     auto build_groups = [&](std::vector<Step> &steps, std::vector<int32_t> &groups) {
         // The region is double-buffered: group g lives in half (g & 1) and is fetched while group g-1
         // is being processed, so its latency is hidden behind a whole run of steps.
         groups.clear();
-        if (!P.input_slots) {
-            groups.push_back(-1);
-            return;
-        }
         const int half = kInputSlots / 2;
         const int nsteps = static_cast<int>(steps.size());
         int s0 = 0, gidx = 0;
@@ -434,8 +430,8 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
         int *field;  // where the slot number goes (index into a flat array of fields)
         int size, prio, birth, death, slot;
     };
-    const int lds_base = P.input_slots;  // state slots start after the input staging region
-    auto allocate = [lds_base](std::vector<Obj> &objs, int lds_budget_total, int &n_lds, int &n_glb) {
+    // lds_base: state slots start after the input staging region
+    auto allocate = [](std::vector<Obj> &objs, int lds_budget_total, int lds_base, int &n_lds, int &n_glb) {
         const int lds_budget = lds_budget_total > lds_base ? lds_budget_total - lds_base : 0;
         std::vector<int> order(objs.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = static_cast<int>(i);
@@ -481,7 +477,9 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
     };
 
     auto cluster_of = [&](int b) { return m.bodies[b].cluster; };
-    auto build_layout = [&](Layout &L, int lds_budget, bool with_xa) {
+    auto build_layout = [&](Layout &L, int lds_budget, int lds_budget_rnea, bool with_xa) {
+        L.input_slots_aba = lds_budget >= 2 * kInputSlots ? kInputSlots : 0;
+        L.input_slots_rnea = lds_budget_rnea >= 2 * kInputSlots ? kInputSlots : 0;
         L.clusters = clusters;
         L.rnea_clusters = clusters;
         L.bodies = bodies;
@@ -526,7 +524,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             }
         }
         int nl = 0, ng = 0;
-        allocate(objs, lds_budget, nl, ng);
+        allocate(objs, lds_budget, L.input_slots_aba, nl, ng);
         L.n_lds_aba = nl;
         L.n_glb_aba = ng;
         // first contributor to a body's backward accumulators: earliest backward step, and inside
@@ -620,7 +618,7 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
                 robjs.push_back({&cr.slot_imp_bwd, sz, 1, tRB[c], tRB[c], -1});
             }
         }
-        allocate(robjs, lds_budget, nl, ng);
+        allocate(robjs, lds_budget_rnea, L.input_slots_rnea, nl, ng);
         L.n_lds_rnea = nl;
         L.n_glb_rnea = ng;
         for (int b = 0; b < nb; b++) {
@@ -638,10 +636,10 @@ int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots6
             br.parent_slot_IA = br.parent_slot_psi = br.parent_slot_v3 = -1;
         }
     };
-    build_layout(P.lay32, lds_slots32, false);
-    build_layout(P.lay64, lds_slots64, false);
-    build_layout(P.lay32x, lds_slots32, true);
-    build_layout(P.lay64x, lds_slots64, true);
+    build_layout(P.lay32, lds.aba32, lds.rnea32, false);
+    build_layout(P.lay64, lds.aba64, lds.rnea64, false);
+    build_layout(P.lay32x, lds.aba32, lds.rnea32, true);
+    build_layout(P.lay64x, lds.aba64, lds.rnea64, true);
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
     // per-body costs: sincos ~40, E build 12, motion xform 39, force xform 39, sym6*vec 66,

@@ -129,6 +129,14 @@ struct Layout {
     std::vector<BodyRec> rnea_bodies;  // RNEA slots (slot_sc, slot_v, slot_a3, slot_f used)
     int n_lds_aba = 0, n_glb_aba = 0;
     int n_lds_rnea = 0, n_glb_rnea = 0;
+    // kInputSlots when the kernel stages input groups in LDS, 0 when its LDS budget is too small for them
+    int input_slots_aba = 0, input_slots_rnea = 0;
+};
+
+// LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
+// wavefronts per CU and more state in the global slab; the best trade differs per kernel.
+struct LdsBudget {
+    int aba32 = 0, aba64 = 0, rnea32 = 0, rnea64 = 0;
 };
 
 struct HostPlan {
@@ -139,7 +147,6 @@ struct HostPlan {
     std::vector<Step> rnea_steps;
     // per group: n_rows, then n_rows x (slab input row, LDS slot)
     std::vector<int32_t> aba_groups, rnea_groups;
-    int input_slots = 0;  // kInputSlots when input groups are in use, 0 when the LDS budget is too small
     std::vector<double> consts;  // converted to float on upload for the f32 kernels
     std::vector<int32_t> cints;  // integer payload of implicit constraints
     Layout lay32, lay64;      // fast path
@@ -149,9 +156,8 @@ struct HostPlan {
 };
 
 // Compile a model-description blob (include/grbda_model_desc.h) into a HostPlan.
-// lds_slots32 / lds_slots64: LDS budget per wavefront in slots for the f32 / f64 kernels.
 // Returns 0 or a negative GRBDA_E* code (include/grbda_hip.h); msg receives a diagnostic.
-int compile_plan(const void *blob, size_t bytes, int lds_slots32, int lds_slots64, int sweep_mask, HostPlan &out,
+int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep_mask, HostPlan &out,
                  char *msg, size_t msg_cap);
 
 }  // namespace grbda_hip

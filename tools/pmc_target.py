@@ -1,0 +1,20 @@
+"""A few launches of one kernel on the MIT humanoid (target program of tools/pmc_run.sh)."""
+import os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import generalized_rbda_amd as G
+from generalized_rbda_amd.states import random_states
+kind = sys.argv[1] if len(sys.argv) > 1 else "aba"
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+model = sys.argv[3] if len(sys.argv) > 3 else "mit_humanoid"
+plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", model + ".urdf"))
+B = 262144
+q, qd, tau = random_states(plan.blob, B, 2)
+dt = torch.float32 if prec == 32 else torch.float64
+t = lambda a: torch.as_tensor(a, dtype=dt, device="cuda:0")
+tq, tqd, tt = t(q), t(qd), t(tau)
+out = torch.empty((B, plan.nv), dtype=dt, device="cuda:0")
+for _ in range(int(os.environ.get("PMC_LAUNCHES", "6"))):
+    (plan.forward_dynamics if kind == "aba" else plan.inverse_dynamics)(tq, tqd, tt, out=out)
+torch.cuda.synchronize()
