@@ -73,6 +73,17 @@ __device__ __forceinline__ U load_rec(cptr<U> p)
     return out;
 }
 
+// body record of the fast kernels: the plan compiler re-expresses every revolute body in a frame whose
+// z axis is the joint axis (plan.cpp, "canonical joint axes"), so the axis is a compile-time constant
+// there and every axis-dependent selection folds away.  The general kernels keep the run-time axis.
+template <bool GEN>
+__device__ __forceinline__ BodyRec load_body(cptr<BodyRec> p)
+{
+    BodyRec b = load_rec(p);
+    if constexpr (!GEN) b.axis = 2;
+    return b;
+}
+
 template <class T>
 struct Tables {
     cptr<Step> steps;
@@ -1068,7 +1079,7 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
     if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
     for (int i = 0; i < c.k; i++) {
         if (!((c.child_mask >> i) & 1)) continue;  // leaf bodies are evaluated inside the backward step
-        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
         T qi, gi;
         typename RowSel<T, N, LOOP>::type Gr;
@@ -1187,7 +1198,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
     // in-cluster bias acceleration (the cJ part of GenericJoint.cpp:430-450), chained clusters only
     if (c.chained) {
         for (int i = 0; i < c.k; i++) {
-            const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+            const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
             cptr<T> C = P.consts + b.cofs;
             T qi, gi;
             typename RowSel<T, N, LOOP>::type Gr;
@@ -1199,7 +1210,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             add_axis(ccl, b.axis, gi);  // S_implicit * g (GenericJoint.cpp:449-450)
             if (b.lam >= 0) {
                 T cp[6], t[6];
-                const BodyRec bl = load_rec(P.bodies + (b.lam));
+                const BodyRec bl = load_body<GEN>(P.bodies + (b.lam));
                 S.ld(bl.slot_ccl, cp);
                 xmotion(E, C + 9, cp, t);
 #pragma unroll
@@ -1211,7 +1222,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 
     for (int i = c.k - 1; i >= 0; i--) {
         PROF_ADD(5);  // (previous body) joint-space terms + push up the in-cluster chain
-        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
         PROF_SYNC();
         PROF_ADD(6);  // body record round trip
         cptr<T> C = P.consts + b.cofs;
@@ -1324,7 +1335,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
         xforce_inv(E, C + 9, h, f);
         int l = b.lam;
         while (l >= 0) {
-            const BodyRec bl = load_rec(P.bodies + (l));
+            const BodyRec bl = load_body<GEN>(P.bodies + (l));
             cptr<T> Cl = P.consts + bl.cofs;
             T ql, gl;
             typename RowSel<T, N, LOOP>::type Gl;
@@ -1489,7 +1500,7 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
     bool evaluated = false;
     for (int i = 0; i < c.k; i++) {
         if (!((c.child_mask >> i) & 1)) continue;  // nothing downstream needs this body's acceleration
-        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
         if constexpr (LOOP) {
             if (!evaluated) {
                 eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
@@ -1582,7 +1593,7 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
     const int imp = c.slot_imp_fwd;
     if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
     for (int i = 0; i < c.k; i++) {
-        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
         T qi, gi;
         typename RowSel<T, N, LOOP>::type G;
@@ -1678,7 +1689,7 @@ __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<
     const int imp = c.slot_imp_bwd;
     if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
     for (int i = c.k - 1; i >= 0; i--) {
-        const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+        const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
         T qi, gi;
         typename RowSel<T, N, LOOP>::type G;

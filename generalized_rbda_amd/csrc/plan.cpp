@@ -8,6 +8,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -165,6 +166,69 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         if (bodies[b].parent >= 0) bodies[bodies[b].parent].has_child = 1;
     for (int b = 0; b < nb; b++)
         if (bodies[b].has_child) clusters[m.bodies[b].cluster].child_mask |= 1 << m.bodies[b].sub_index;
+
+    // ---- canonical joint axes -------------------------------------------------------------------
+    // Models without implicit loops are re-expressed so that every revolute joint turns about the z axis
+    // of its body frame: body i's coordinates are rotated by the cyclic permutation Rc_i that maps its
+    // joint axis onto z (v_new = Rc_i v_old).  Then R_a(q) E_tree becomes R_z(q) (Rc_i E_tree Rc_p^T),
+    // the tree offset r (parent coordinates) becomes Rc_p r and the spatial inertia D I D^T with
+    // D = blockdiag(Rc_i, Rc_i).  Joint coordinates, torques and accelerations are unchanged, and
+    // world-frame external forces reach the bodies through the (equally rotated) absolute transforms.
+    // The fast kernels rely on it (kernels.hip, load_body): the joint axis is a constant there.
+    std::vector<grbda_desc_body> canon;
+    bool any_loop = false;
+    for (int c = 0; c < nc; c++) any_loop |= clusters[c].kind == CK_LOOP;
+    if (!any_loop) {
+        canon.assign(m.bodies, m.bodies + nb);
+        auto perm = [](int axis, double R[9]) {
+            for (int i = 0; i < 9; i++) R[i] = 0;
+            if (axis == 0) { R[0 * 3 + 1] = 1; R[1 * 3 + 2] = 1; R[2 * 3 + 0] = 1; }        // x -> z
+            else if (axis == 1) { R[0 * 3 + 2] = 1; R[1 * 3 + 0] = 1; R[2 * 3 + 1] = 1; }   // y -> z
+            else { R[0] = R[4] = R[8] = 1; }
+        };
+        std::vector<std::array<double, 9>> Rc(nb);
+        for (int b = 0; b < nb; b++)
+            perm(m.bodies[b].joint_type == GRBDA_JOINT_REVOLUTE ? m.bodies[b].axis : 2, Rc[b].data());
+        for (int b = 0; b < nb; b++) {
+            grbda_desc_body &bd = canon[b];
+            const double *Ri = Rc[b].data();
+            double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (bd.parent >= 0) std::memcpy(Rp, Rc[bd.parent].data(), sizeof Rp);
+            double E[9], t[9], r[3];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {  // t = Ri * E_tree
+                    double sacc = 0;
+                    for (int k2 = 0; k2 < 3; k2++) sacc += Ri[i * 3 + k2] * bd.Xtree_E[k2 * 3 + j];
+                    t[i * 3 + j] = sacc;
+                }
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {  // E = t * Rp^T
+                    double sacc = 0;
+                    for (int k2 = 0; k2 < 3; k2++) sacc += t[i * 3 + k2] * Rp[j * 3 + k2];
+                    E[i * 3 + j] = sacc;
+                }
+            for (int i = 0; i < 3; i++) r[i] = Rp[i * 3] * bd.Xtree_r[0] + Rp[i * 3 + 1] * bd.Xtree_r[1] + Rp[i * 3 + 2] * bd.Xtree_r[2];
+            std::memcpy(bd.Xtree_E, E, sizeof E);
+            std::memcpy(bd.Xtree_r, r, sizeof r);
+            double I[36];
+            for (int bi = 0; bi < 2; bi++)
+                for (int bj = 0; bj < 2; bj++)
+                    for (int i = 0; i < 3; i++)
+                        for (int j = 0; j < 3; j++) {
+                            double sacc = 0;  // Ri * block * Ri^T
+                            for (int k2 = 0; k2 < 3; k2++)
+                                for (int l2 = 0; l2 < 3; l2++)
+                                    sacc += Ri[i * 3 + k2] * bd.inertia[(3 * bi + k2) * 6 + 3 * bj + l2] * Ri[j * 3 + l2];
+                            I[(3 * bi + i) * 6 + 3 * bj + j] = sacc;
+                        }
+            std::memcpy(bd.inertia, I, sizeof I);
+            if (bd.joint_type == GRBDA_JOINT_REVOLUTE) {
+                bd.axis = 2;
+                bodies[b].axis = 2;
+            }
+        }
+        m.bodies = canon.data();
+    }
 
     // ---- constants --------------------------------------------------------------------------
     for (int b = 0; b < nb; b++) {
