@@ -1461,6 +1461,261 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Straight-line handlers of the two commonest cluster shapes (plan.h, ClusterRec::shape): a single
+// revolute body, and the reference's RevoluteWithRotor (ClusterJoints/RevoluteWithRotorJoint.h) -- a
+// link and an axisymmetric rotor leaf, both hanging off the parent body.  Same arithmetic as the generic
+// handlers with n = 1, but no body loop, no accumulate-into-zero arrays and one combined hand-over to
+// the parent, which removes most of the register shuffling the generic code needs.  Fast kernels only
+// (canonical axes: every joint turns about z).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void rotate_z(T s, T c, cptr<T> Et, T (&E)[9])
+{
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        E[j] = c * Et[j] + s * Et[3 + j];
+        E[3 + j] = c * Et[3 + j] - s * Et[j];
+        E[6 + j] = Et[6 + j];
+    }
+}
+
+template <class T, bool ROTOR>
+__device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                            const Lane<T> &L, Carry<T> &carry)
+{
+    const BodyRec b = load_rec(P.bodies + c.link_body);
+    cptr<T> C = P.consts + b.cofs;
+    const T g0 = C[kBodyConstFixed];
+    const T yd = L.cyd(c, 0);
+    const T qdi = g0 * yd;
+    const bool has_parent = c.parent_body >= 0;
+
+    // ---- link kinematics (TreeModel.cpp:6-32) ----
+    T E[9], v[6], vp[6];
+    if (b.has_child) {
+        T sc[2];
+        S.ld(b.slot_sc, sc);
+        S.ld(b.slot_v, v);
+        rotate_z(sc[0], sc[1], C, E);
+        if constexpr (ROTOR) {
+            if (has_parent) S.ld(b.parent_slot_v, vp);
+        }
+    } else {
+        T sn, cs;
+        sincos_t(g0 * L.cy(c, 0), &sn, &cs);
+        rotate_z(sn, cs, C, E);
+        if (has_parent) {
+            S.ld(b.parent_slot_v, vp);
+            xmotion(E, C + 9, vp, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) v[j] = 0;
+        }
+        v[2] += qdi;
+    }
+    T chat[6];
+    vxaxis(2, v, qdi, chat);
+
+    // ---- articulated inertia and bias of the link (ClusterTreeDynamics.cpp:93-129) ----
+    cptr<T> Ic = C + 12;
+    T IA[21], psi[6];
+    {
+        T Iv[6];
+        symv_c(Ic, v, Iv);
+        crf(v, Iv, psi);
+    }
+    if (b.carry_in) {
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + carry.IA[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
+    } else if (b.has_child) {
+        T acc[21], pacc[6];
+        S.ld(b.slot_IA, acc);
+        S.ld(b.slot_psi, pacc);
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + acc[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi[j] += pacc[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ic[j];
+    }
+    if (b.xofs >= 0) {
+        cptr<T> Xc = P.consts + b.xofs;
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] += Xc[j];
+    }
+    T h[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) h[i] = IA[sidx(i, 2)];
+    T bj = psi[2];
+#pragma unroll
+    for (int j = 0; j < 6; j++) bj += h[j] * chat[j];
+    T u = L.cx(c, 0) - g0 * bj;
+    T D = h[2] * g0 * g0;
+    T F[6];
+    xforce_inv(E, C + 9, h, F);
+#pragma unroll
+    for (int r = 0; r < 6; r++) F[r] *= g0;
+
+    T out_psi[6], out_IA[21];
+    if (has_parent) {
+        T t[6], Ic_c[6];
+        symv(IA, chat, Ic_c);
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] = psi[j] + Ic_c[j];
+        xforce_inv(E, C + 9, t, out_psi);
+        congruence(E, C + 9, IA, out_IA);
+    }
+
+    // ---- rotor: evaluated at q = 0 (plan.cpp, axisymmetric leaves) ----
+    int first_psi = b.acc_first;
+    if constexpr (ROTOR) {
+        const BodyRec rb = load_rec(P.bodies + c.rotor_body);
+        cptr<T> Cr = P.consts + rb.cofs;
+        cptr<T> Ir = Cr + 12;
+        const T gr = Cr[kBodyConstFixed];
+        const T qdr = gr * yd;
+        first_psi |= rb.acc_first;
+        T E0[9], vr[6];
+#pragma unroll
+        for (int j = 0; j < 9; j++) E0[j] = Cr[j];
+        if (has_parent) {
+            xmotion(E0, Cr + 9, vp, vr);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) vr[j] = 0;
+        }
+        vr[2] += qdr;
+        T cr[6], pr[6], hr[6];
+        vxaxis(2, vr, qdr, cr);
+        {
+            T Iv[6];
+            symv_c(Ir, vr, Iv);
+            crf(vr, Iv, pr);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) hr[i] = Ir[sidx(i, 2)];
+        T bjr = pr[2];
+#pragma unroll
+        for (int j = 0; j < 6; j++) bjr += hr[j] * cr[j];
+        u -= gr * bjr;
+        D += hr[2] * gr * gr;
+        T fr[6];
+        xforce_inv(E0, Cr + 9, hr, fr);
+#pragma unroll
+        for (int r = 0; r < 6; r++) F[r] += fr[r] * gr;
+        if (has_parent) {
+            T t[6], Ic_c[6], tp[6];
+            symv_c(Ir, cr, Ic_c);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t[j] = pr[j] + Ic_c[j];
+            xforce_inv(E0, Cr + 9, t, tp);
+#pragma unroll
+            for (int j = 0; j < 6; j++) out_psi[j] += tp[j];
+        }
+    }
+
+    // ---- D^-1 u', K = D^-1 F^T (n = 1) ----
+    const T Dinv = T(1) / D;
+    const T y0 = u * Dinv;
+    T K[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) K[r] = F[r] * Dinv;
+    S.st(c.slot_K, K);
+    S.st1(c.slot_y0, y0);
+
+    // ---- one combined hand-over to the parent body: X^T IA X - F D^-1 F^T,  X^T (pA + IA c) + F D^-1 u' ----
+    if (has_parent) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            out_psi[r] += F[r] * y0;
+#pragma unroll
+            for (int cc = r; cc < 6; cc++) out_IA[sidx(r, cc)] -= F[r] * K[cc];
+        }
+        if (c.carry_out) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) carry.psi[j] = out_psi[j];
+#pragma unroll
+            for (int j = 0; j < 21; j++) carry.IA[j] = out_IA[j];
+        } else {
+            S.acc(c.parent_slot_psi, out_psi, first_psi);
+            S.acc(c.parent_slot_IA, out_IA, b.acc_first_IA | c.corr_first_IA);
+        }
+    }
+}
+
+// acceleration sweep of the same shapes (ClusterTreeDynamics.cpp:131-152); a rotor has no children
+template <class T>
+__device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                            const Lane<T> &L)
+{
+    T K[6], ap[6];
+    S.ld(c.slot_K, K);
+    T ydd = S.ld1(c.slot_y0);
+    if (c.parent_slot_a3 >= 0) {
+        S.ld(c.parent_slot_a3, ap);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) ap[j] = P.a_root[j];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) ydd -= K[r] * ap[r];
+    if (L.active) L.out[c.v_index] = ydd;
+    if (!c.child_mask) return;
+    const BodyRec b = load_rec(P.bodies + c.link_body);
+    cptr<T> C = P.consts + b.cofs;
+    const T g0 = C[kBodyConstFixed];
+    const T qdi = g0 * L.cyd(c, 0);
+    T sn, cs, E[9], v[6], a[6];
+    sincos_t(g0 * L.cy(c, 0), &sn, &cs);
+    rotate_z(sn, cs, C, E);
+    if (b.parent >= 0) {
+        T vp[6];
+        S.ld(b.parent_slot_v3, vp);
+        xmotion(E, C + 9, vp, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) v[j] = 0;
+    }
+    xmotion(E, C + 9, ap, a);
+    v[2] += qdi;
+    T chat[6];
+    vxaxis(2, v, qdi, chat);
+#pragma unroll
+    for (int j = 0; j < 6; j++) a[j] += chat[j];
+    a[2] += g0 * ydd;
+    S.st(b.slot_v3, v);
+    S.st(b.slot_a3, a);
+}
+
+// forward sweep of the same shapes: only a link with children leaves anything behind
+template <class T>
+__device__ __forceinline__ void aba_fwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                            const Lane<T> &L)
+{
+    if (!c.child_mask) return;
+    const BodyRec b = load_rec(P.bodies + c.link_body);
+    cptr<T> C = P.consts + b.cofs;
+    const T g0 = C[kBodyConstFixed];
+    T sc[2], E[9], v[6];
+    sincos_t(g0 * L.cy(c, 0), &sc[0], &sc[1]);
+    S.st(b.slot_sc, sc);
+    rotate_z(sc[0], sc[1], C, E);
+    if (b.parent >= 0) {
+        T vp[6];
+        S.ld(b.parent_slot_v, vp);
+        xmotion(E, C + 9, vp, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) v[j] = 0;
+    }
+    v[2] += g0 * L.cyd(c, 0);
+    S.st(b.slot_v, v);
+}
+
+// ---------------------------------------------------------------------------------------------
 // ABA sweep 3: joint accelerations (ClusterTreeDynamics.cpp:131-152).  Velocities of bodies with
 // children are recomputed on the way down (cheaper than keeping them live across the sweeps).
 // ---------------------------------------------------------------------------------------------
@@ -1798,6 +2053,8 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
             if (st.op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
+                } else if (!HAS_LOOP && c.shape) {
+                    aba_fwd_rev<T>(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_fwd_static, P, S, c, L)
                 }
@@ -1805,6 +2062,10 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
             } else if (st.op == OP_ABA_BWD) {
                 if (c.kind == CK_FREE) {
                     aba_bwd_free(P, S, c, L, carry);
+                } else if (!HAS_LOOP && c.shape == SHAPE_REV) {
+                    aba_bwd_rev<T, false>(P, S, c, L, carry);
+                } else if (!HAS_LOOP && c.shape == SHAPE_REV_ROTOR) {
+                    aba_bwd_rev<T, true>(P, S, c, L, carry);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_bwd_static, P, S, c, L, carry PROF_PASS)
                 }
@@ -1812,6 +2073,8 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
             } else {
                 if (c.kind == CK_FREE) {
                     aba_acc_free(P, S, c, L);
+                } else if (!HAS_LOOP && c.shape) {
+                    aba_acc_rev<T>(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_acc_static, P, S, c, L)
                 }

@@ -315,6 +315,29 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
     }
 
+    // ---- cluster shapes with a straight-line handler (plan.h, ClusterShape) ---------------------------
+    for (int c = 0; c < nc; c++) {
+        ClusterRec &cr = clusters[c];
+        cr.shape = SHAPE_GENERIC;
+        cr.link_body = cr.rotor_body = -1;
+        if (any_loop || cr.kind != CK_STATIC || cr.n != 1 || cr.chained) continue;
+        const int f = cr.first_body;
+        if (cr.k == 1 && !bodies[f].axisym) {
+            cr.shape = SHAPE_REV;
+            cr.link_body = f;
+        } else if (cr.k == 2) {
+            for (int rot = 0; rot < 2; rot++) {
+                const int r = f + rot, l = f + 1 - rot;
+                if (bodies[r].axisym && !bodies[r].has_child && !bodies[l].axisym) {
+                    cr.shape = SHAPE_REV_ROTOR;
+                    cr.link_body = l;
+                    cr.rotor_body = r;
+                    break;
+                }
+            }
+        }
+    }
+
     // ---- implicit-loop payload -------------------------------------------------------------------
     for (int c = 0; c < nc; c++) {
         const grbda_desc_cluster &cl = m.clusters[c];

@@ -83,7 +83,15 @@ struct ClusterRec {
     int32_t cons_type;        // implicit clusters: 0 position loops (URDF+ <loop>), 1 trig-polynomial phi
     int32_t child_mask;       // bit i: body i of the cluster has children (forward / acceleration sweeps skip the rest
                               // without fetching their records)
+    int32_t shape;            // ClusterShape: clusters the fast kernels run through straight-line handlers
+    int32_t link_body;        // SHAPE_REV / SHAPE_REV_ROTOR: global index of the link ...
+    int32_t rotor_body;       // ... and of the rotor
+    int32_t reserved;
 };
+
+// Shapes with a dedicated handler.  SHAPE_REV: one revolute body, one coordinate.  SHAPE_REV_ROTOR: a link
+// and an axisymmetric leaf (rotor) driven by one coordinate, both children of the cluster's parent body.
+enum ClusterShape : int32_t { SHAPE_GENERIC = 0, SHAPE_REV = 1, SHAPE_REV_ROTOR = 2 };
 
 struct BodyRec {
     int32_t parent;       // global tree-parent body index or -1
