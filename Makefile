@@ -6,6 +6,9 @@ ARCH  ?= gfx950
 CSRC  := generalized_rbda_amd/csrc
 OBJ   := build/obj
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+# the SLP vectoriser pairs fp32 operations into v_pk_* instructions and pays for it in register moves
+# (measured: 6-10% slower f32 ABA); the kernels are scalar-per-lane code
+KERNFLAGS := -fno-slp-vectorize
 
 LIB := generalized_rbda_amd/libgrbda_hip.so
 
@@ -13,7 +16,7 @@ all: $(LIB) oracle
 
 $(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
 $(OBJ)/capi.o: $(CSRC)/capi.cpp $(CSRC)/plan.h $(CSRC)/devplan.h include/grbda_hip.h include/grbda_model_desc.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
@@ -41,11 +44,11 @@ clean:
 # profiling variant with in-kernel cycle accounting (tools/prof_run.py); not part of `all`
 prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	@mkdir -p build/prof
-	$(HIPCC) $(HIPFLAGS) -DGRBDA_PROFILE -c $(CSRC)/kernels.hip -o build/prof/kernels.o
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -DGRBDA_PROFILE -c $(CSRC)/kernels.hip -o build/prof/kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/libgrbda_hip_prof.so build/prof/kernels.o $^
 
 # experiment builds: make exp NAME=foo DEFS="-DGRBDA_EXP_FOO" -> build/exp/libgrbda_foo.so
 exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	@mkdir -p build/exp
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/kernels.hip -o build/exp/kernels_$(NAME).o
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/kernels.hip -o build/exp/kernels_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/kernels_$(NAME).o $^

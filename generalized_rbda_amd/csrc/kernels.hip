@@ -1479,16 +1479,25 @@ __device__ __forceinline__ void rotate_z(T s, T c, cptr<T> Et, T (&E)[9])
     }
 }
 
+// y = A x for packed symmetric A and a revolute-about-z velocity product x = (x0, x1, 0, x3, x4, 0)
+template <class T, class A21>
+__device__ __forceinline__ void symv_z(const A21 &A, const T (&x)[6], T (&y)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+        y[i] = A[sidx(i, 0)] * x[0] + A[sidx(i, 1)] * x[1] + A[sidx(i, 3)] * x[3] + A[sidx(i, 4)] * x[4];
+}
+
 template <class T, bool ROTOR>
 __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
                                             const Lane<T> &L, Carry<T> &carry)
 {
+    // (the plan compiler gives these shapes only to clusters with a parent body)
     const BodyRec b = load_rec(P.bodies + c.link_body);
     cptr<T> C = P.consts + b.cofs;
     const T g0 = C[kBodyConstFixed];
     const T yd = L.cyd(c, 0);
     const T qdi = g0 * yd;
-    const bool has_parent = c.parent_body >= 0;
 
     // ---- link kinematics (TreeModel.cpp:6-32) ----
     T E[9], v[6], vp[6];
@@ -1497,24 +1506,17 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
         S.ld(b.slot_sc, sc);
         S.ld(b.slot_v, v);
         rotate_z(sc[0], sc[1], C, E);
-        if constexpr (ROTOR) {
-            if (has_parent) S.ld(b.parent_slot_v, vp);
-        }
+        if constexpr (ROTOR) S.ld(b.parent_slot_v, vp);
     } else {
         T sn, cs;
         sincos_t(g0 * L.cy(c, 0), &sn, &cs);
         rotate_z(sn, cs, C, E);
-        if (has_parent) {
-            S.ld(b.parent_slot_v, vp);
-            xmotion(E, C + 9, vp, v);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 6; j++) v[j] = 0;
-        }
+        S.ld(b.parent_slot_v, vp);
+        xmotion(E, C + 9, vp, v);
         v[2] += qdi;
     }
-    T chat[6];
-    vxaxis(2, v, qdi, chat);
+    // c = v x (z qd): (v1, -v0, 0, v4, -v3, 0) qd
+    T chat[6] = {v[1] * qdi, -v[0] * qdi, 0, v[4] * qdi, -v[3] * qdi, 0};
 
     // ---- articulated inertia and bias of the link (ClusterTreeDynamics.cpp:93-129) ----
     cptr<T> Ic = C + 12;
@@ -1549,9 +1551,7 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
     T h[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) h[i] = IA[sidx(i, 2)];
-    T bj = psi[2];
-#pragma unroll
-    for (int j = 0; j < 6; j++) bj += h[j] * chat[j];
+    const T bj = psi[2] + h[0] * chat[0] + h[1] * chat[1] + h[3] * chat[3] + h[4] * chat[4];
     T u = L.cx(c, 0) - g0 * bj;
     T D = h[2] * g0 * g0;
     T F[6];
@@ -1560,11 +1560,11 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
     for (int r = 0; r < 6; r++) F[r] *= g0;
 
     T out_psi[6], out_IA[21];
-    if (has_parent) {
-        T t[6], Ic_c[6];
-        symv(IA, chat, Ic_c);
+    {
+        T t[6];
+        symv_z(IA, chat, t);
 #pragma unroll
-        for (int j = 0; j < 6; j++) t[j] = psi[j] + Ic_c[j];
+        for (int j = 0; j < 6; j++) t[j] += psi[j];
         xforce_inv(E, C + 9, t, out_psi);
         congruence(E, C + 9, IA, out_IA);
     }
@@ -1581,15 +1581,10 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
         T E0[9], vr[6];
 #pragma unroll
         for (int j = 0; j < 9; j++) E0[j] = Cr[j];
-        if (has_parent) {
-            xmotion(E0, Cr + 9, vp, vr);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 6; j++) vr[j] = 0;
-        }
+        xmotion(E0, Cr + 9, vp, vr);
         vr[2] += qdr;
-        T cr[6], pr[6], hr[6];
-        vxaxis(2, vr, qdr, cr);
+        T cr[6] = {vr[1] * qdr, -vr[0] * qdr, 0, vr[4] * qdr, -vr[3] * qdr, 0};
+        T pr[6], hr[6];
         {
             T Iv[6];
             symv_c(Ir, vr, Iv);
@@ -1597,24 +1592,20 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) hr[i] = Ir[sidx(i, 2)];
-        T bjr = pr[2];
-#pragma unroll
-        for (int j = 0; j < 6; j++) bjr += hr[j] * cr[j];
+        const T bjr = pr[2] + hr[0] * cr[0] + hr[1] * cr[1] + hr[3] * cr[3] + hr[4] * cr[4];
         u -= gr * bjr;
         D += hr[2] * gr * gr;
         T fr[6];
         xforce_inv(E0, Cr + 9, hr, fr);
 #pragma unroll
         for (int r = 0; r < 6; r++) F[r] += fr[r] * gr;
-        if (has_parent) {
-            T t[6], Ic_c[6], tp[6];
-            symv_c(Ir, cr, Ic_c);
+        T t[6], tp[6];
+        symv_z(Ir, cr, t);
 #pragma unroll
-            for (int j = 0; j < 6; j++) t[j] = pr[j] + Ic_c[j];
-            xforce_inv(E0, Cr + 9, t, tp);
+        for (int j = 0; j < 6; j++) t[j] += pr[j];
+        xforce_inv(E0, Cr + 9, t, tp);
 #pragma unroll
-            for (int j = 0; j < 6; j++) out_psi[j] += tp[j];
-        }
+        for (int j = 0; j < 6; j++) out_psi[j] += tp[j];
     }
 
     // ---- D^-1 u', K = D^-1 F^T (n = 1) ----
@@ -1627,22 +1618,20 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
     S.st1(c.slot_y0, y0);
 
     // ---- one combined hand-over to the parent body: X^T IA X - F D^-1 F^T,  X^T (pA + IA c) + F D^-1 u' ----
-    if (has_parent) {
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            out_psi[r] += F[r] * y0;
+    for (int r = 0; r < 6; r++) {
+        out_psi[r] += F[r] * y0;
 #pragma unroll
-            for (int cc = r; cc < 6; cc++) out_IA[sidx(r, cc)] -= F[r] * K[cc];
-        }
-        if (c.carry_out) {
+        for (int cc = r; cc < 6; cc++) out_IA[sidx(r, cc)] -= F[r] * K[cc];
+    }
+    if (c.carry_out) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) carry.psi[j] = out_psi[j];
+        for (int j = 0; j < 6; j++) carry.psi[j] = out_psi[j];
 #pragma unroll
-            for (int j = 0; j < 21; j++) carry.IA[j] = out_IA[j];
-        } else {
-            S.acc(c.parent_slot_psi, out_psi, first_psi);
-            S.acc(c.parent_slot_IA, out_IA, b.acc_first_IA | c.corr_first_IA);
-        }
+        for (int j = 0; j < 21; j++) carry.IA[j] = out_IA[j];
+    } else {
+        S.acc(c.parent_slot_psi, out_psi, first_psi);
+        S.acc(c.parent_slot_IA, out_IA, b.acc_first_IA | c.corr_first_IA);
     }
 }
 
@@ -1654,12 +1643,7 @@ __device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &
     T K[6], ap[6];
     S.ld(c.slot_K, K);
     T ydd = S.ld1(c.slot_y0);
-    if (c.parent_slot_a3 >= 0) {
-        S.ld(c.parent_slot_a3, ap);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 6; j++) ap[j] = P.a_root[j];
-    }
+    S.ld(c.parent_slot_a3, ap);
 #pragma unroll
     for (int r = 0; r < 6; r++) ydd -= K[r] * ap[r];
     if (L.active) L.out[c.v_index] = ydd;
@@ -1671,13 +1655,10 @@ __device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &
     T sn, cs, E[9], v[6], a[6];
     sincos_t(g0 * L.cy(c, 0), &sn, &cs);
     rotate_z(sn, cs, C, E);
-    if (b.parent >= 0) {
+    {
         T vp[6];
         S.ld(b.parent_slot_v3, vp);
         xmotion(E, C + 9, vp, v);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 6; j++) v[j] = 0;
     }
     xmotion(E, C + 9, ap, a);
     v[2] += qdi;
@@ -1703,13 +1684,10 @@ __device__ __forceinline__ void aba_fwd_rev(const Tables<T> &P, const Slots<T> &
     sincos_t(g0 * L.cy(c, 0), &sc[0], &sc[1]);
     S.st(b.slot_sc, sc);
     rotate_z(sc[0], sc[1], C, E);
-    if (b.parent >= 0) {
+    {
         T vp[6];
         S.ld(b.parent_slot_v, vp);
         xmotion(E, C + 9, vp, v);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 6; j++) v[j] = 0;
     }
     v[2] += g0 * L.cyd(c, 0);
     S.st(b.slot_v, v);

@@ -320,7 +320,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         ClusterRec &cr = clusters[c];
         cr.shape = SHAPE_GENERIC;
         cr.link_body = cr.rotor_body = -1;
-        if (any_loop || cr.kind != CK_STATIC || cr.n != 1 || cr.chained) continue;
+        if (any_loop || cr.kind != CK_STATIC || cr.n != 1 || cr.chained || cr.parent_body < 0) continue;
         const int f = cr.first_body;
         if (cr.k == 1 && !bodies[f].axisym) {
             cr.shape = SHAPE_REV;
