@@ -33,6 +33,11 @@ namespace grbda_hip {
 
 // optional in-kernel cycle accounting (build with -DGRBDA_PROFILE, see tools/prof_run.py; never in
 // the shipped library): s_memtime deltas per phase, summed over waves into grbda_prof[]
+// wavefronts per SIMD the f32 ABA kernel is register-allocated for
+#ifndef GRBDA_ABA32_WAVES
+#define GRBDA_ABA32_WAVES 2
+#endif
+
 #ifdef GRBDA_PROFILE
 __device__ unsigned long long grbda_prof[32];
 #define PROF_T0() unsigned long long prof_t = __builtin_amdgcn_s_memtime()
@@ -1958,6 +1963,106 @@ __device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T>
 }
 
 // ---------------------------------------------------------------------------------------------
+// RNEA of the revolute / revolute-with-rotor shapes (see aba_bwd_rev).  Leaves finish inside the forward
+// step: a rotor (evaluated at q = 0) and a childless link hand X^T f to the parent body and emit their
+// torque at once, so only links with children keep a force slot and get a backward step.
+// ---------------------------------------------------------------------------------------------
+template <class T, class I21>
+__device__ __forceinline__ void body_force(const I21 &Ic, const T (&v)[6], const T (&a)[6], T (&f)[6])
+{
+    T Ia[6], Iv[6];
+    symv_c(Ic, a, Ia);
+    symv_c(Ic, v, Iv);
+    crf(v, Iv, f);  // f = I a + v x* (I v), TreeModel.cpp:185-189
+#pragma unroll
+    for (int j = 0; j < 6; j++) f[j] += Ia[j];
+}
+
+template <class T, bool ROTOR>
+__device__ __forceinline__ void rnea_fwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                             const Lane<T> &L)
+{
+    const BodyRec b = load_rec(P.bodies + c.link_body);
+    cptr<T> C = P.consts + b.cofs;
+    const T g0 = C[kBodyConstFixed];
+    const T yd = L.cyd(c, 0), ydd = L.cx(c, 0);
+    const T qdi = g0 * yd;
+    T sc[2], E[9], vp[6], ap[6], v[6], a[6], f[6];
+    sincos_t(g0 * L.cy(c, 0), &sc[0], &sc[1]);
+    rotate_z(sc[0], sc[1], C, E);
+    S.ld(b.parent_slot_v, vp);
+    S.ld(b.parent_slot_a3, ap);
+    xmotion(E, C + 9, vp, v);
+    xmotion(E, C + 9, ap, a);
+    v[2] += qdi;
+    a[0] += v[1] * qdi;
+    a[1] -= v[0] * qdi;
+    a[3] += v[4] * qdi;
+    a[4] -= v[3] * qdi;
+    a[2] += g0 * ydd;
+    body_force(C + 12, v, a, f);
+
+    T tau_r = 0, fpr[6];
+    if constexpr (ROTOR) {
+        const BodyRec rb = load_rec(P.bodies + c.rotor_body);
+        cptr<T> Cr = P.consts + rb.cofs;
+        const T gr = Cr[kBodyConstFixed];
+        const T qdr = gr * yd;
+        T E0[9], vr[6], ar[6], fr[6];
+#pragma unroll
+        for (int j = 0; j < 9; j++) E0[j] = Cr[j];
+        xmotion(E0, Cr + 9, vp, vr);
+        xmotion(E0, Cr + 9, ap, ar);
+        vr[2] += qdr;
+        ar[0] += vr[1] * qdr;
+        ar[1] -= vr[0] * qdr;
+        ar[3] += vr[4] * qdr;
+        ar[4] -= vr[3] * qdr;
+        ar[2] += gr * ydd;
+        body_force(Cr + 12, vr, ar, fr);
+        tau_r = gr * fr[2];
+        xforce_inv(E0, Cr + 9, fr, fpr);
+    }
+    if (b.has_child) {
+        S.st(b.slot_sc, sc);
+        S.st(b.slot_v, v);
+        S.st(b.slot_a3, a);
+        S.st(b.slot_f, f);
+        if constexpr (ROTOR) {
+            S.acc(b.parent_slot_f, fpr, 0);
+            S.st1(c.slot_y0, tau_r);
+        }
+    } else {
+        T fp[6];
+        xforce_inv(E, C + 9, f, fp);
+        if constexpr (ROTOR) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) fp[j] += fpr[j];
+        }
+        S.acc(b.parent_slot_f, fp, 0);
+        if (L.active) L.out[c.v_index] = g0 * f[2] + tau_r;
+    }
+}
+
+// backward step of a link with children (the plan drops the step for childless links)
+template <class T, bool ROTOR>
+__device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+                                             const Lane<T> &L)
+{
+    const BodyRec b = load_rec(P.bodies + c.link_body);
+    cptr<T> C = P.consts + b.cofs;
+    T f[6], sc[2], E[9], fp[6];
+    S.ld(b.slot_f, f);
+    S.ld(b.slot_sc, sc);
+    T tau = C[kBodyConstFixed] * f[2];
+    if constexpr (ROTOR) tau += S.ld1(c.slot_y0);
+    rotate_z(sc[0], sc[1], C, E);
+    xforce_inv(E, C + 9, f, fp);
+    S.acc(b.parent_slot_f, fp, 0);
+    if (L.active) L.out[c.v_index] = tau;
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
 // HAS_LOOP is a kernel template parameter: models without implicit-loop clusters run a kernel that
@@ -1982,7 +2087,7 @@ __device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T>
     }
 
 template <class T, bool HAS_LOOP>
-__global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
+__global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                      const T *__restrict__ qd, const T *__restrict__ tau,
                                                      T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
 {
@@ -2026,9 +2131,11 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
             PROF_SYNC();
             PROF_ADD(12);  // step + cluster record round trips
             if (DP.groups && st.group >= 0) begin_group(P, slab, st.group, lane);
-            L.in_base = DP.groups ? st.in_base : -1;
             PROF_ADD(1);   // input-group boundary: wait for the staged rows, issue the next copy
-            if (st.op == OP_ABA_FWD) {
+            if (!HAS_LOOP && (st.op & kOpSkipFast)) continue;
+            const int op = st.op & kOpMask;
+            L.in_base = DP.groups ? st.in_base : -1;
+            if (op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
                 } else if (!HAS_LOOP && c.shape) {
@@ -2037,7 +2144,7 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? 2 : 1)) void aba_kernel(De
                     GRBDA_DISPATCH_N(c, aba_fwd_static, P, S, c, L)
                 }
                 PROF_ADD(2);
-            } else if (st.op == OP_ABA_BWD) {
+            } else if (op == OP_ABA_BWD) {
                 if (c.kind == CK_FREE) {
                     aba_bwd_free(P, S, c, L, carry);
                 } else if (!HAS_LOOP && c.shape == SHAPE_REV) {
@@ -2099,16 +2206,26 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
             if (DP.groups && st.group >= 0) begin_group(P, slab, st.group, lane);
+            if (!HAS_LOOP && (st.op & kOpSkipFast)) continue;
+            const int op = st.op & kOpMask;
             L.in_base = DP.groups ? st.in_base : -1;
-            if (st.op == OP_RNEA_FWD) {
+            if (op == OP_RNEA_FWD) {
                 if (c.kind == CK_FREE) {
                     rnea_fwd_free(P, S, c, L);
+                } else if (!HAS_LOOP && c.shape == SHAPE_REV) {
+                    rnea_fwd_rev<T, false>(P, S, c, L);
+                } else if (!HAS_LOOP && c.shape == SHAPE_REV_ROTOR) {
+                    rnea_fwd_rev<T, true>(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, rnea_fwd_static, P, S, c, L)
                 }
             } else {
                 if (c.kind == CK_FREE) {
                     rnea_bwd_free(P, S, c, L);
+                } else if (!HAS_LOOP && c.shape == SHAPE_REV) {
+                    rnea_bwd_rev<T, false>(P, S, c, L);
+                } else if (!HAS_LOOP && c.shape == SHAPE_REV_ROTOR) {
+                    rnea_bwd_rev<T, true>(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, rnea_bwd_static, P, S, c, L)
                 }

@@ -441,6 +441,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
     }
 
+    // steps in which the straight-line handlers have nothing to do (kOpSkipFast, plan.h)
+    for (Step &st : P.aba_steps)
+        if (st.op == OP_ABA_FWD && clusters[st.cluster].shape && !clusters[st.cluster].child_mask) st.op |= kOpSkipFast;
+    for (Step &st : P.rnea_steps)
+        if (st.op == OP_RNEA_BWD && clusters[st.cluster].shape && !clusters[st.cluster].child_mask) st.op |= kOpSkipFast;
+
     // ---- register hand-over along chains ------------------------------------------------------------
     // When every tree child of body p lies in ONE cluster c and the backward step of p's cluster
     // directly follows the backward step of c, the projected inertia / bias of c never touches a
@@ -452,7 +458,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         for (int j = 0; j < nb; j++)
             if (bodies[j].parent == p && m.bodies[j].cluster != c) only = false;
         const int next = tB[c] + 1;
-        if (only && next < static_cast<int>(P.aba_steps.size()) && P.aba_steps[next].op == OP_ABA_BWD &&
+        if (only && next < static_cast<int>(P.aba_steps.size()) && (P.aba_steps[next].op & kOpMask) == OP_ABA_BWD &&
             P.aba_steps[next].cluster == m.bodies[p].cluster) {
             clusters[c].carry_out = 1;
             bodies[p].carry_in = 1;
@@ -504,7 +510,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     if (sweep_mask != 7) {  // profiling aid: drop whole sweeps (results are then meaningless)
         std::vector<Step> kept;
         for (const Step &st : P.aba_steps)
-            if ((st.op == OP_ABA_FWD && (sweep_mask & 1)) || (st.op == OP_ABA_BWD && (sweep_mask & 2)) ||
+            if (((st.op & kOpMask) == OP_ABA_FWD && (sweep_mask & 1)) || (st.op == OP_ABA_BWD && (sweep_mask & 2)) ||
                 (st.op == OP_ABA_ACC && (sweep_mask & 4)))
                 kept.push_back(st);
         P.aba_steps = kept;
@@ -683,6 +689,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             const int c = cluster_of(b);
             br.slot_sc = br.slot_v = br.slot_IA = br.slot_psi = br.slot_ccl = br.slot_v3 = br.slot_a3 = br.slot_f = -1;
             br.slot_Xa = br.parent_slot_Xa = -1;
+            // straight-line shapes (fast layouts): a rotor and a childless link finish in the forward step
+            const bool lean = !with_xa && clusters[c].shape != SHAPE_GENERIC;
+            if (lean && !br.has_child) continue;
             if (br.jtype != GRBDA_JOINT_FREE && br.parent >= 0) robjs.push_back({&br.slot_sc, 2, 0, tRF[c], tRB[c], -1});
             robjs.push_back({&br.slot_f, 6, 1, tRF[c], tRB[c], -1});
             if (br.has_child) {
@@ -697,6 +706,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         for (int c = 0; c < nc; c++) {
             ClusterRec &cr = L.rnea_clusters[c];
             cr.slot_K = cr.slot_y0 = cr.slot_imp_fwd = cr.slot_imp_bwd = cr.slot_imp_acc = -1;
+            // rotor torque of a SHAPE_REV_ROTOR cluster whose link has children, forward -> backward step
+            if (!with_xa && cr.shape == SHAPE_REV_ROTOR && cr.child_mask) robjs.push_back({&cr.slot_y0, 1, 1, tRF[c], tRB[c], -1});
             cr.parent_slot_IA = cr.parent_slot_psi = cr.parent_slot_v3 = cr.parent_slot_a3 = -1;
             cr.carry_out = 0;
             if (cr.kind == CK_LOOP) {

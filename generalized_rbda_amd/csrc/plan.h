@@ -31,6 +31,10 @@ enum StepOp : int32_t {
     OP_RNEA_FWD = 3,  // velocity + acceleration + body force            (TreeModel.cpp:34-57,181-186)
     OP_RNEA_BWD = 4   // joint torque projection + force back-propagation (TreeModel.cpp:196-209)
 };
+// ORed into Step::op: the fast kernels have nothing to do in this step (forward ABA step / backward RNEA
+// step of a SHAPE_REV / SHAPE_REV_ROTOR cluster whose link is a leaf); the general kernels run it
+constexpr int32_t kOpSkipFast = 1 << 8;
+constexpr int32_t kOpMask = 0xff;
 
 enum ClusterKind : int32_t {
     CK_STATIC = 0,  // revolute single joints, constant G (every explicit ClusterJoint type)
