@@ -1259,9 +1259,11 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
                 subtract_external_force(L, c.first_body + i, Xa, psi);
             }
         }
+        // own inertia, plus the constant X0^T I X0 of axisymmetric leaf children (rotors) when there are any
+        cptr<T> Ib = b.xofs >= 0 ? P.consts + b.xofs : Ic;
         if (b.carry_in) {
 #pragma unroll
-            for (int j = 0; j < 21; j++) IA[j] = Ic[j] + carry.IA[j];
+            for (int j = 0; j < 21; j++) IA[j] = Ib[j] + carry.IA[j];
 #pragma unroll
             for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
         } else if (b.has_child) {
@@ -1269,17 +1271,12 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             S.ld(b.slot_IA, acc);
             S.ld(b.slot_psi, pacc);
 #pragma unroll
-            for (int j = 0; j < 21; j++) IA[j] = Ic[j] + acc[j];
+            for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
             for (int j = 0; j < 6; j++) psi[j] += pacc[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 21; j++) IA[j] = Ic[j];
-        }
-        if (b.xofs >= 0) {  // constant inertia of the axisymmetric leaf children (rotors)
-            cptr<T> Xc = P.consts + b.xofs;
-#pragma unroll
-            for (int j = 0; j < 21; j++) IA[j] += Xc[j];
+            for (int j = 0; j < 21; j++) IA[j] = Ib[j];
         }
 
         PROF_SYNC();
@@ -1430,9 +1427,11 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
         free_absolute(P, c, L, Xa);
         subtract_external_force(L, c.first_body, Xa, psi);
     }
+    // own inertia, plus the constant X0^T I X0 of axisymmetric leaf children (rotors) when there are any
+    cptr<T> Ib = b.xofs >= 0 ? P.consts + b.xofs : Ic;
     if (b.carry_in) {
 #pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + carry.IA[j];
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j] + carry.IA[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
     } else if (b.has_child) {
@@ -1440,17 +1439,12 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
         S.ld(b.slot_IA, acc);
         S.ld(b.slot_psi, pacc);
 #pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + acc[j];
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) psi[j] += pacc[j];
     } else {
 #pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] = Ic[j];
-    }
-    if (b.xofs >= 0) {
-        cptr<T> Xc = P.consts + b.xofs;
-#pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] += Xc[j];
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j];
     }
     T D[6][6], u[6];
 #pragma unroll
@@ -1531,9 +1525,11 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
         symv_c(Ic, v, Iv);
         crf(v, Iv, psi);
     }
+    // own inertia, plus the constant X0^T I X0 of axisymmetric leaf children (rotors) when there are any
+    cptr<T> Ib = b.xofs >= 0 ? P.consts + b.xofs : Ic;
     if (b.carry_in) {
 #pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + carry.IA[j];
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j] + carry.IA[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
     } else if (b.has_child) {
@@ -1541,17 +1537,12 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
         S.ld(b.slot_IA, acc);
         S.ld(b.slot_psi, pacc);
 #pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] = Ic[j] + acc[j];
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) psi[j] += pacc[j];
     } else {
 #pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] = Ic[j];
-    }
-    if (b.xofs >= 0) {
-        cptr<T> Xc = P.consts + b.xofs;
-#pragma unroll
-        for (int j = 0; j < 21; j++) IA[j] += Xc[j];
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j];
     }
     T h[6];
 #pragma unroll

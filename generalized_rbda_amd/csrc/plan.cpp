@@ -310,8 +310,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
         for (int b = 0; b < nb; b++)
             if (!extra[b].empty()) {
+                // stored as I_b + sum_children X0^T I X0: the backward step starts its accumulation from it
                 bodies[b].xofs = static_cast<int>(P.consts.size());
-                P.consts.insert(P.consts.end(), extra[b].begin(), extra[b].end());
+                for (int j = 0; j < 21; j++) P.consts.push_back(P.consts[bodies[b].cofs + 12 + j] + extra[b][j]);
             }
     }
 

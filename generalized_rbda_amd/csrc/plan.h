@@ -123,7 +123,7 @@ struct BodyRec {
     int32_t axisym;           // 1: leaf body whose inertia is invariant under rotation about its joint axis
                               //    (a rotor): X(q)^T I X(q) and X(q)^T (v x* I v) do not depend on q, so the
                               //    body is evaluated at q = 0 and its inertia contribution is a plan constant
-    int32_t xofs;             // offset into consts[] of the 21 constants sum_children X0^T I X0 (or -1)
+    int32_t xofs;             // offset into consts[] of the 21 constants I + sum_children X0^T I X0 (or -1)
     int32_t acc_first_IA;     // like acc_first, counting only children that really accumulate an inertia
     int32_t slot_Xa;          // absolute transform world -> body (E 9, r 3); layouts with external forces, has_child only
     int32_t parent_slot_Xa;
