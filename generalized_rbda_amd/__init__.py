@@ -22,6 +22,8 @@ C_ABI_SYMBOLS = [
     "grbda_plan_free", "grbda_plan_dims", "grbda_plan_set_gravity", "grbda_plan_get_gravity", "grbda_plan_blob",
     "grbda_plan_info", "grbda_aba_f64", "grbda_aba_f32", "grbda_rnea_f64", "grbda_rnea_f32",
     "grbda_aba_host_f64", "grbda_rnea_host_f64", "grbda_time_kernel", "grbda_device_count",
+    "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
+    "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
 ]
 
 
@@ -78,6 +80,13 @@ def lib() -> ctypes.CDLL:
     L.grbda_time_kernel.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                     c_void_p, c_int, POINTER(c_float)]
     L.grbda_device_count.restype = c_int
+    for sfx in ("f64", "f32"):
+        getattr(L, "grbda_bias_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                                    c_void_p]
+        getattr(L, "grbda_mass_matrix_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        getattr(L, "grbda_fd_dtau_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        getattr(L, "grbda_fd_dqd_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                      c_int, c_void_p]
     _lib = L
     return L
 
@@ -183,6 +192,44 @@ class Plan:
     def inverse_dynamics(self, q, qd, ydd, out=None, stream=None, f_ext=None):
         """Batched ClusterTreeModel::inverseDynamics (cluster RNEA): returns tau[B, nv]."""
         return self._launch("rnea", q, qd, ydd, out, stream, f_ext)
+
+    # ---- quantities derived from the two recursions (include/grbda_hip.h) ---------------------------
+    def _derived(self, name: str, q, others=(), matrix=True, stream=None, f_ext=None):
+        import torch
+
+        if not q.is_cuda or q.dtype not in (torch.float32, torch.float64):
+            raise GrbdaError(-3, "inputs must be float32/float64 HIP device tensors (there is no CPU fallback)")
+        B = q.shape[0]
+        if q.shape != (B, self.nq) or any(o.shape != (B, self.nv) or o.dtype != q.dtype or not o.is_cuda for o in others):
+            raise ValueError(f"expected q[B,{self.nq}] and [B,{self.nv}] tensors of one dtype on the device")
+        q = q.contiguous()
+        others = [o.contiguous() for o in others]
+        out = torch.empty((B, self.nv, self.nv) if matrix else (B, self.nv), dtype=q.dtype, device=q.device)
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_{name}_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        args = [self._h, q.data_ptr()] + [o.data_ptr() for o in others]
+        if name == "bias":
+            if f_ext is not None and (f_ext.shape != (B, self.n_bodies, 6) or f_ext.dtype != q.dtype or not f_ext.is_cuda):
+                raise ValueError(f"f_ext must be a device tensor [B,{self.n_bodies},6] of the same dtype")
+            args.append(None if f_ext is None else f_ext.contiguous().data_ptr())
+        _check(fn(*args, out.data_ptr(), B, q.device.index or 0, c_void_p(s.cuda_stream)))
+        return out
+
+    def bias_force(self, q, qd, stream=None, f_ext=None):
+        """Batched getBiasForceVector: C(q, qd) = RNEA(q, qd, 0), [B, nv]."""
+        return self._derived("bias", q, (qd,), matrix=False, stream=stream, f_ext=f_ext)
+
+    def mass_matrix(self, q, stream=None):
+        """Batched getMassMatrix: H(q), [B, nv, nv]."""
+        return self._derived("mass_matrix", q, stream=stream)
+
+    def fd_dtau(self, q, stream=None):
+        """d ydd / d tau = H(q)^-1 through the ABA, [B, nv, nv]."""
+        return self._derived("fd_dtau", q, stream=stream)
+
+    def fd_dqd(self, q, qd, tau, stream=None):
+        """d ydd / d qd of the forward dynamics, [B, nv, nv] (exact: the ABA is quadratic in qd)."""
+        return self._derived("fd_dqd", q, (qd, tau), stream=stream)
 
     def time_kernel(self, which: str, q, qd, x, out, iters: int = 20, stream=None) -> float:
         """Average kernel duration in ms, hipEvents on the launch stream (grbda_time_kernel)."""

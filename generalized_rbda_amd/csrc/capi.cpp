@@ -69,6 +69,7 @@ struct grbda_plan {
     mutable std::mutex mu;
     mutable std::map<int, DeviceTables> dev;
     mutable std::map<std::pair<int, void *>, Scratch> scratch;
+    mutable std::map<std::pair<int, void *>, Scratch> work;  // expanded batches of the derived quantities
     // launch shape per kernel, index = (rnea ? 2 : 0) + (f64 ? 1 : 0): LDS budget per wavefront for the
     // slot store, and wavefronts launched per CU (the grid is persistent)
     // (defaults from sweeps on MI355X over the MIT humanoid, Mini Cheetah and JVRC-1: 20 KiB and 8
@@ -252,6 +253,118 @@ int run_host_f64(const grbda_plan *p, bool rnea, const double *q, const double *
     return rc;
 }
 
+// ---- derived quantities: expanded batches over the two kernels (include/grbda_hip.h) ---------------------
+enum DerivedMode { DM_BIAS = 0, DM_MASS = 1, DM_DTAU = 2, DM_DQD = 3 };
+
+// row (b, j) of the expanded batch: state b with the j-th unit vector (or none) applied
+template <class T>
+__global__ void expand_kernel(int mode, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ tau,
+                              int nq, int nv, int R, size_t nb, T *__restrict__ qx, T *__restrict__ qdx,
+                              T *__restrict__ xx)
+{
+    const size_t rows = nb * (size_t)R;
+    const int w = nq + 2 * nv;
+    const size_t total = rows * (size_t)w;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / w;
+        const int col = (int)(i % w);
+        const size_t b = row / R;
+        const int j = (int)(row % R);
+        if (col < nq) {
+            qx[row * nq + col] = q[b * nq + col];
+        } else if (col < nq + nv) {
+            const int k = col - nq;
+            T v = 0;
+            if (mode == DM_BIAS) v = qd[b * nv + k];
+            else if (mode == DM_DQD) v = qd[b * nv + k] + ((j >> 1) == k ? ((j & 1) ? T(-1) : T(1)) : T(0));
+            qdx[row * nv + k] = v;
+        } else {
+            const int k = col - nq - nv;
+            T v = 0;
+            if (mode == DM_MASS || mode == DM_DTAU) v = (j == k) ? T(1) : T(0);
+            else if (mode == DM_DQD) v = tau[b * nv + k];
+            xx[row * nv + k] = v;
+        }
+    }
+}
+
+// out[b][i][j] from the kernel results r[(b, j)][i]
+template <class T>
+__global__ void combine_kernel(int mode, const T *__restrict__ r, int nv, int R, size_t nb, T *__restrict__ out)
+{
+    const size_t total = nb * (size_t)nv * nv;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = t / ((size_t)nv * nv);
+        const int i = (int)((t / nv) % nv), j = (int)(t % nv);
+        const T *rb = r + b * (size_t)R * nv;
+        T v;
+        if (mode == DM_DQD) v = T(0.5) * (rb[(size_t)(2 * j) * nv + i] - rb[(size_t)(2 * j + 1) * nv + i]);
+        else v = rb[(size_t)j * nv + i] - rb[(size_t)nv * nv + i];
+        out[t] = v;
+    }
+}
+
+template <class T>
+int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau, const T *f_ext, T *out, size_t B,
+            int device, void *stream)
+{
+    if (!p || !q || !out) return set_err(GRBDA_EINVAL, "null argument");
+    if ((mode == DM_BIAS || mode == DM_DQD) && !qd) return set_err(GRBDA_EINVAL, "null argument");
+    if (mode == DM_DQD && !tau) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const int nq = p->host.nq, nv = p->host.nv;
+    const int R = mode == DM_BIAS ? 1 : (mode == DM_DQD ? 2 * nv : nv + 1);
+    const size_t row_scalars = static_cast<size_t>(nq) + 3 * static_cast<size_t>(nv);  // q, qd, x, result
+    size_t chunk = (256u << 20) / (row_scalars * sizeof(T) * static_cast<size_t>(R));
+    if (chunk < 1) chunk = 1;
+    if (chunk > B) chunk = B;
+    const size_t rows = chunk * static_cast<size_t>(R);
+    void *wptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        Scratch &s = p->work[{device, stream}];
+        const size_t need = rows * row_scalars * sizeof(T) + 256;
+        if (s.bytes < need) {
+            hipError_t e;
+            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+            s.ptr = nullptr;
+            s.bytes = 0;
+            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+            s.bytes = need;
+        }
+        wptr = s.ptr;
+    }
+    T *qx = static_cast<T *>(wptr);
+    T *qdx = qx + rows * nq;
+    T *xx = qdx + rows * nv;
+    T *res = xx + rows * nv;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    const bool via_rnea = mode == DM_BIAS || mode == DM_MASS;
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t nrows = nb * static_cast<size_t>(R);
+        const size_t total = nrows * static_cast<size_t>(nq + 2 * nv);
+        int blocks = static_cast<int>((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+        hipLaunchKernelGGL((expand_kernel<T>), dim3(blocks), dim3(256), 0, hs, mode, q + b0 * nq,
+                           qd ? qd + b0 * nv : nullptr, tau ? tau + b0 * nv : nullptr, nq, nv, R, nb, qx, qdx, xx);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_err(e, "expand launch");
+        const T *fe = (mode == DM_BIAS && f_ext) ? f_ext + b0 * static_cast<size_t>(p->host.n_bodies) * 6 : nullptr;
+        T *dst = mode == DM_BIAS ? out + b0 * nv : res;
+        if (int rc = run<T>(p, via_rnea, qx, qdx, xx, fe, dst, nrows, device, stream)) return rc;
+        if (mode != DM_BIAS) {
+            const size_t tot2 = nb * static_cast<size_t>(nv) * nv;
+            blocks = static_cast<int>((tot2 + 255) / 256 < 65535 ? (tot2 + 255) / 256 : 65535);
+            hipLaunchKernelGGL((combine_kernel<T>), dim3(blocks), dim3(256), 0, hs, mode, res, nv, R, nb,
+                               out + b0 * static_cast<size_t>(nv) * nv);
+            if ((e = hipGetLastError()) != hipSuccess) return hip_err(e, "combine launch");
+        }
+    }
+    return GRBDA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -341,10 +454,11 @@ void grbda_plan_free(grbda_plan *p)
         (void)hipFree(t.cints); (void)hipFree(t.aba_groups); (void)hipFree(t.rnea_groups);
         for (int w = 0; w < 4; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
-    for (auto &kv : p->scratch) {
-        if (hipSetDevice(kv.first.first) != hipSuccess) continue;
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    }
+    for (auto *m : {&p->scratch, &p->work})
+        for (auto &kv : *m) {
+            if (hipSetDevice(kv.first.first) != hipSuccess) continue;
+            if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+        }
     delete p;
 }
 
@@ -420,6 +534,43 @@ int grbda_rnea_f32(const grbda_plan *p, const float *q, const float *qd, const f
                    float *tau, size_t B, int device, void *stream)
 {
     return run<float>(p, true, q, qd, ydd, f_ext, tau, B, device, stream);
+}
+
+int grbda_bias_f64(const grbda_plan *p, const double *q, const double *qd, const double *f_ext, double *out, size_t B,
+                   int device, void *stream)
+{
+    return derived<double>(p, DM_BIAS, q, qd, nullptr, f_ext, out, B, device, stream);
+}
+int grbda_bias_f32(const grbda_plan *p, const float *q, const float *qd, const float *f_ext, float *out, size_t B,
+                   int device, void *stream)
+{
+    return derived<float>(p, DM_BIAS, q, qd, nullptr, f_ext, out, B, device, stream);
+}
+int grbda_mass_matrix_f64(const grbda_plan *p, const double *q, double *H, size_t B, int device, void *stream)
+{
+    return derived<double>(p, DM_MASS, q, nullptr, nullptr, nullptr, H, B, device, stream);
+}
+int grbda_mass_matrix_f32(const grbda_plan *p, const float *q, float *H, size_t B, int device, void *stream)
+{
+    return derived<float>(p, DM_MASS, q, nullptr, nullptr, nullptr, H, B, device, stream);
+}
+int grbda_fd_dtau_f64(const grbda_plan *p, const double *q, double *Hinv, size_t B, int device, void *stream)
+{
+    return derived<double>(p, DM_DTAU, q, nullptr, nullptr, nullptr, Hinv, B, device, stream);
+}
+int grbda_fd_dtau_f32(const grbda_plan *p, const float *q, float *Hinv, size_t B, int device, void *stream)
+{
+    return derived<float>(p, DM_DTAU, q, nullptr, nullptr, nullptr, Hinv, B, device, stream);
+}
+int grbda_fd_dqd_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, double *J, size_t B,
+                     int device, void *stream)
+{
+    return derived<double>(p, DM_DQD, q, qd, tau, nullptr, J, B, device, stream);
+}
+int grbda_fd_dqd_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, float *J, size_t B,
+                     int device, void *stream)
+{
+    return derived<float>(p, DM_DQD, q, qd, tau, nullptr, J, B, device, stream);
 }
 
 int grbda_aba_host_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau,

@@ -784,6 +784,28 @@ public:
     DVec<Scalar> forwardDynamics(const DVec<Scalar> &tau) override { return single(false, tau); }
     DVec<Scalar> inverseDynamics(const DVec<Scalar> &qdd) override { return single(true, qdd); }
 
+    // TreeModel::updateBiasForceVector (TreeModel.cpp:162-171): C = RNEA(0), external forces included
+    DVec<Scalar> getBiasForceVector() { return single(true, DVec<Scalar>::Zero(this->velocity_index_)); }
+    // ClusterTreeModel::getMassMatrix (ClusterTreeModel.cpp:99-104).  The reference runs the CRBA; here
+    // H e_j = RNEA(q, 0, e_j) - RNEA(q, 0, 0), one batched inverse-dynamics call of nv + 1 rows.
+    DMat<Scalar> getMassMatrix()
+    {
+        const int nq = this->position_index_, nv = this->velocity_index_;
+        if (static_cast<int>(q_.size()) != nq) throw std::runtime_error("state has not been set");
+        const size_t R = static_cast<size_t>(nv) + 1;
+        std::vector<double> q(R * nq), qd(R * nv, 0.0), x(R * nv, 0.0), out(R * nv);
+        for (size_t r = 0; r < R; r++) {
+            for (int i = 0; i < nq; i++) q[r * nq + i] = static_cast<double>(q_[i]);
+            if (r < static_cast<size_t>(nv)) x[r * nv + r] = 1.0;
+        }
+        check(grbda_rnea_host_f64(plan(), q.data(), qd.data(), x.data(), nullptr, out.data(), R, 0));
+        DMat<Scalar> H(nv, nv);
+        for (int i = 0; i < nv; i++)
+            for (int j = 0; j < nv; j++)
+                H(i, j) = static_cast<Scalar>(out[static_cast<size_t>(j) * nv + i] - out[static_cast<size_t>(nv) * nv + i]);
+        return H;
+    }
+
     // batched entry points on HOST arrays (row-major q[B][nq], qd[B][nv], tau[B][nv] -> ydd[B][nv])
     void forwardDynamicsBatch(const double *q, const double *qd, const double *tau, double *ydd, size_t B, int device = 0)
     {

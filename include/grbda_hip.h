@@ -112,6 +112,38 @@ int grbda_rnea_f64(const grbda_plan *plan, const double *q, const double *qd, co
 int grbda_rnea_f32(const grbda_plan *plan, const float *q, const float *qd, const float *ydd,
                    const float *f_ext, float *tau, size_t B, int device, void *stream);
 
+/* ---- quantities derived from the two recursions ---------------------------------- */
+/* All take DEVICE pointers like grbda_aba_* / grbda_rnea_*.  They are evaluated with the same kernels over
+ * an expanded batch (one extra row per unit vector), chunked so that the work space stays below 256 MiB:
+ * RNEA is affine in ydd and ABA is affine in tau and quadratic in qd, so the differences below are exact
+ * (no step size enters), not finite-difference approximations.
+ *
+ * grbda_bias_*        C(q, qd) = RNEA(q, qd, 0)                  TreeModel::updateBiasForceVector
+ *                     out[B][nv]                                   (TreeModel.cpp:162-171), getBiasForceVector
+ *                                                                  (ClusterTreeModel.cpp:106-110)
+ * grbda_mass_matrix_* H(q) e_j = RNEA(q, 0, e_j) - RNEA(q, 0, 0) ClusterTreeModel::getMassMatrix
+ *                     out[B][nv][nv], row-major, symmetric         (ClusterTreeModel.cpp:99-104; the reference runs
+ *                                                                  the CRBA, TreeModel.cpp:115-160)
+ * grbda_fd_dtau_*     d ydd / d tau = H^-1:                       the exact identity the reference's derivative
+ *                     column j = ABA(q, 0, e_j) - ABA(q, 0, 0)     tests check (SURVEY 8c viii)
+ *                     out[B][nv][nv]
+ * grbda_fd_dqd_*      d ydd / d qd, column j =                     central difference with unit step, exact
+ *                     (ABA(qd + e_j) - ABA(qd - e_j)) / 2          because ABA is quadratic in qd
+ *                     out[B][nv][nv]                               (testRigidBodyDynamicsAlgosDerivatives.cpp:309-380)
+ */
+int grbda_bias_f64(const grbda_plan *plan, const double *q, const double *qd, const double *f_ext, double *out,
+                   size_t B, int device, void *stream);
+int grbda_bias_f32(const grbda_plan *plan, const float *q, const float *qd, const float *f_ext, float *out,
+                   size_t B, int device, void *stream);
+int grbda_mass_matrix_f64(const grbda_plan *plan, const double *q, double *H, size_t B, int device, void *stream);
+int grbda_mass_matrix_f32(const grbda_plan *plan, const float *q, float *H, size_t B, int device, void *stream);
+int grbda_fd_dtau_f64(const grbda_plan *plan, const double *q, double *Hinv, size_t B, int device, void *stream);
+int grbda_fd_dtau_f32(const grbda_plan *plan, const float *q, float *Hinv, size_t B, int device, void *stream);
+int grbda_fd_dqd_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau, double *J,
+                     size_t B, int device, void *stream);
+int grbda_fd_dqd_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, float *J,
+                     size_t B, int device, void *stream);
+
 /* ---- convenience: host pointers (single-state facade calls, small batches) ------------------ */
 /* allocate, copy in, run on `device`, copy out, synchronise.  Still the HIP path. */
 int grbda_aba_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau,

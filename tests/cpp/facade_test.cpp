@@ -96,8 +96,18 @@ static int roundtrip(Model &model, const char *what)
         const DVec<double> ydd = model.forwardDynamics(tau);
         const DVec<double> back = model.inverseDynamics(ydd);
         worst = std::fmax(worst, (back - tau).norm());
+        // H ydd + C = tau (getMassMatrix / getBiasForceVector, testRigidBodyDynamicsAlgos.cpp:208-232)
+        const DMat<double> H = model.getMassMatrix();
+        const DVec<double> C = model.getBiasForceVector();
+        double res = 0;
+        for (int i = 0; i < nv; i++) {
+            double s = C[i] - tau[i];
+            for (int j = 0; j < nv; j++) s += H(i, j) * ydd[j];
+            res += s * s;
+        }
+        worst = std::fmax(worst, std::sqrt(res));
     }
-    std::printf("%s: nq=%d nv=%d |ID(FD(tau)) - tau| = %.3e\n", what, nq, nv, worst);
+    std::printf("%s: nq=%d nv=%d max(|ID(FD(tau)) - tau|, |H ydd + C - tau|) = %.3e\n", what, nq, nv, worst);
     return worst < 5e-8 ? 0 : 1;  // tol of UnitTests/testRigidBodyDynamicsAlgos.cpp:9
 }
 

@@ -152,3 +152,74 @@ def test_external_forces_match_oracle(name, gpu):
     # forces must matter, and the host entry point takes them too
     assert rel_err(O.forward_dynamics(blob, q, qd, tau), O.forward_dynamics(blob, q, qd, tau, fext)) > 1e-3
     assert rel_err(plan.forward_dynamics_host(q, qd, tau, f_ext=fext), O.forward_dynamics(blob, q, qd, tau, fext)) < TOL64
+
+
+# ---- derived quantities (include/grbda_hip.h: bias force, mass matrix, d ydd/d tau, d ydd/d qd) ----------
+def _oracle_columns(fn, blob, q, qd, x, which, step):
+    """(fn(.. + step e_j) - fn(.. - step e_j)) / (2 step) for every j, perturbing argument `which` (1 qd, 2 x)."""
+    B, nv = x.shape
+    cols = np.empty((B, nv, nv))
+    for j in range(nv):
+        d = np.zeros_like(x)
+        d[:, j] = step
+        args_p = [q, qd + d, x] if which == 1 else [q, qd, x + d]
+        args_m = [q, qd - d, x] if which == 1 else [q, qd, x - d]
+        cols[:, :, j] = (fn(blob, *args_p) - fn(blob, *args_m)) / (2 * step)
+    return cols
+
+
+@pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
+def test_mass_matrix_bias_and_fd_derivatives_match_oracle(name, blob, gpu):
+    """getMassMatrix / getBiasForceVector (ClusterTreeModel.cpp:99-110) and the derivative identities the
+    reference tests (testRigidBodyDynamicsAlgosDerivatives.cpp:309-380; d ydd/d tau = H^-1)."""
+    import torch
+
+    plan = G.Plan(blob)
+    B = 3
+    q, qd, tau = valid_states(blob, B, config_index=23)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    nv = plan.nv
+    zero = np.zeros_like(qd)
+    H = plan.mass_matrix(t(q)).cpu().numpy()
+    C = plan.bias_force(t(q), t(qd)).cpu().numpy()
+    Hinv = plan.fd_dtau(t(q)).cpu().numpy()
+    J = plan.fd_dqd(t(q), t(qd), t(tau)).cpu().numpy()
+    # the oracle is affine in ydd / tau and quadratic in qd too: unit central differences are exact there as well
+    H_ref = _oracle_columns(O.inverse_dynamics, blob, q, zero, zero, 2, 1.0)
+    C_ref = O.inverse_dynamics(blob, q, qd, zero)
+    Hinv_ref = _oracle_columns(O.forward_dynamics, blob, q, zero, zero, 2, 1.0)
+    J_ref = _oracle_columns(O.forward_dynamics, blob, q, qd, tau, 1, 1.0)
+    scale = lambda M: 1.0 + np.abs(M).max()
+    assert np.abs(H - H_ref).max() / scale(H_ref) < TOL64
+    assert np.abs(H - H.transpose(0, 2, 1)).max() / scale(H_ref) < TOL64
+    assert rel_err(C, C_ref) < TOL64
+    assert np.abs(Hinv - Hinv_ref).max() / scale(Hinv_ref) < 1e-8
+    assert np.abs(J - J_ref).max() / scale(J_ref) < 1e-8
+    # H ydd + C = tau with ydd from the forward dynamics; H^-1 H = 1
+    ydd = run_gpu(plan, "aba", q, qd, tau, torch.float64, gpu)
+    assert rel_err(np.einsum("bij,bj->bi", H, ydd) + C, tau) < 1e-8
+    eye = np.einsum("bij,bjk->bik", Hinv, H)
+    assert np.abs(eye - np.eye(nv)).max() < 1e-7
+    # fp32 entry points
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    H32 = plan.mass_matrix(t32(q)).double().cpu().numpy()
+    assert np.abs(H32 - H_ref).max() / scale(H_ref) < TOL32
+    C32 = plan.bias_force(t32(q), t32(qd)).double().cpu().numpy()
+    assert rel_err(C32, C_ref) < TOL32
+
+
+def test_derived_quantities_chunked_large_batch(gpu):
+    """The expanded batch is processed in chunks below 256 MiB: a batch that needs several chunks gives the
+    same matrices as a small one."""
+    import torch
+
+    blob = zoo()["urdf_mini_cheetah"]
+    plan = G.Plan(blob)
+    B = 40000  # (nv + 1) * B rows of fp64 exceed one chunk
+    q, qd, tau = random_states(blob, B, 5)
+    tq = torch.as_tensor(q, dtype=torch.float64, device=gpu)
+    H = plan.mass_matrix(tq)
+    idx = torch.tensor([0, 17, B // 2, B - 1], device=gpu)
+    H_small = plan.mass_matrix(tq[idx].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(H[idx], H_small)
