@@ -41,9 +41,10 @@ namespace grbda_hip {
 #ifdef GRBDA_PROFILE
 __device__ unsigned long long grbda_prof[32];
 #define PROF_T0() unsigned long long prof_t = __builtin_amdgcn_s_memtime()
-#define PROF_ARGS , unsigned long long (&prof_acc)[16], unsigned long long &prof_t
+#define PROF_ARGS , unsigned long long (&prof_acc)[24], unsigned long long &prof_t
 #define PROF_PASS , prof_acc, prof_t
 #define PROF_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PROF_SYNCV() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define PROF_ADD(i)                                                    \
     do {                                                               \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
@@ -56,6 +57,7 @@ __device__ unsigned long long grbda_prof[32];
 #define PROF_ARGS
 #define PROF_PASS
 #define PROF_SYNC()
+#define PROF_SYNCV()
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -128,7 +130,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char grbda_smem[];
 
 template <class T>
 struct Slots {
-    T *glb;  // wave's global slab + lane
+    T *glb;  // wave's global slab (uniform: the per-lane part of an address is a 32-bit offset, which
+             // keeps the 64-bit address arithmetic to one vector add per object)
     int lane;
 
     __device__ __forceinline__ T lds_get(int s) const { return reinterpret_cast<T *>(grbda_smem)[s * kWave + lane]; }
@@ -138,7 +141,7 @@ struct Slots {
     __device__ __forceinline__ void ld(int s, T (&x)[N]) const
     {
         if (s & kSlotGlobal) {
-            const T *p = glb + (size_t)(s & ~kSlotGlobal) * kWave;
+            const T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
 #pragma unroll
             for (int i = 0; i < N; i++) x[i] = p[i * kWave];
         } else {
@@ -150,7 +153,7 @@ struct Slots {
     __device__ __forceinline__ void st(int s, const T (&x)[N]) const
     {
         if (s & kSlotGlobal) {
-            T *p = glb + (size_t)(s & ~kSlotGlobal) * kWave;
+            T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
 #pragma unroll
             for (int i = 0; i < N; i++) p[i * kWave] = x[i];
         } else {
@@ -452,7 +455,11 @@ struct Lane {
     // the tile's inputs, transposed once per tile into coordinate-major rows of the wave's global
     // slab (row j of q at in_q[j * 64], one coalesced 64-element row per coordinate)
     const T *in_q, *in_qd, *in_x;  // x: tau (ABA) or ydd (RNEA); all already offset by the lane
-    T *out;                        // ydd (ABA) or tau (RNEA), row of this lane's state (row-major batch)
+    // results (ydd of the ABA, tau of the RNEA) go to the x rows of the slab -- coordinate j's input is dead
+    // by the time its result exists -- and leave the tile through one coalesced transposition
+    // (write_outputs): a direct store would scatter every coordinate over 64 cache lines.
+    T *out_rows;
+    __device__ __forceinline__ void put(int j, T v) const { out_rows[(size_t)j * kWave] = v; }
     const T *fext;                 // this state's [n_bodies][6] world-frame external forces, or nullptr
     bool active;
     __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
@@ -528,6 +535,26 @@ __device__ __forceinline__ void stage_inputs(const T *__restrict__ q, const T *_
         stage_transpose(nv, 0u, slab + (size_t)(nq + nv) * kWave, lane);
         __syncthreads();
     }
+}
+
+// Tile epilogue: the nv result rows of the slab ([coordinate][state]) become the tile's [state][coordinate]
+// block of the output array, transposed through LDS (free again: the tile's state is dead) so that the
+// global stores are contiguous.
+template <class T>
+__device__ __forceinline__ void write_outputs(const T *rows, T *__restrict__ out, size_t tile, int rows_valid, int nv,
+                                              int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the row stores have landed
+    T *stage = reinterpret_cast<T *>(grbda_smem);
+    for (int c = 0; c < nv; c++) stage[lane * nv + c] = rows[(size_t)c * kWave + lane];
+    __syncthreads();
+    T *dst = out + tile * (size_t)kWave * (size_t)nv;
+    const int total = rows_valid * nv;
+    for (int i = 0; i < nv; i++) {
+        const int j = i * kWave + lane;
+        if (j < total) dst[j] = stage[j];
+    }
+    __syncthreads();
 }
 
 // Input groups: the rows of q / qd / tau the clusters of a run of steps need are copied from the wave's
@@ -1634,23 +1661,33 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
 // acceleration sweep of the same shapes (ClusterTreeDynamics.cpp:131-152); a rotor has no children
 template <class T>
 __device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                            const Lane<T> &L)
+                                            const Lane<T> &L PROF_ARGS)
 {
     T K[6], ap[6];
+    PROF_SYNCV();
+    PROF_ADD(13);  // drain of everything outstanding at step entry
     S.ld(c.slot_K, K);
     T ydd = S.ld1(c.slot_y0);
     S.ld(c.parent_slot_a3, ap);
+    PROF_SYNCV();
+    PROF_ADD(14);  // K, y0, parent acceleration loads
 #pragma unroll
     for (int r = 0; r < 6; r++) ydd -= K[r] * ap[r];
-    if (L.active) L.out[c.v_index] = ydd;
+    L.put(c.v_index, ydd);
+    PROF_SYNCV();
+    PROF_ADD(15);  // ydd + output store (acknowledged)
     if (!c.child_mask) return;
     const BodyRec b = load_rec(P.bodies + c.link_body);
+    PROF_SYNC();
+    PROF_ADD(16);  // body record
     cptr<T> C = P.consts + b.cofs;
     const T g0 = C[kBodyConstFixed];
     const T qdi = g0 * L.cyd(c, 0);
     T sn, cs, E[9], v[6], a[6];
     sincos_t(g0 * L.cy(c, 0), &sn, &cs);
     rotate_z(sn, cs, C, E);
+    PROF_SYNC();
+    PROF_ADD(17);  // constants, inputs, sincos, E
     {
         T vp[6];
         S.ld(b.parent_slot_v3, vp);
@@ -1717,7 +1754,7 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
 #pragma unroll
         for (int r = 0; r < 6; r++) s -= K[a * 6 + r] * ap[r];
         ydd[a] = s;
-        if (L.active) L.out[c.v_index + a] = s;
+        L.put(c.v_index + a, s);
     }
     T y[N], yd[N];
 #pragma unroll
@@ -1777,7 +1814,7 @@ __device__ __forceinline__ void aba_acc_free(const Tables<T> &P, const Slots<T> 
     // ydd = D^-1 u - D^-1 U^T a' with U = IA, D = IA  =>  ydd = y0 - a' ;  a = a' + ydd = y0
 #pragma unroll
     for (int j = 0; j < 6; j++)
-        if (L.active) L.out[c.v_index + j] = y0[j] - ag[j];
+        L.put(c.v_index + j, y0[j] - ag[j]);
     if (b.has_child) {
         T v[6];
 #pragma unroll
@@ -1938,7 +1975,7 @@ __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<
     }
 #pragma unroll
     for (int a = 0; a < N; a++)
-        if (L.active) L.out[c.v_index + a] = tau[a];
+        L.put(c.v_index + a, tau[a]);
 }
 
 template <class T>
@@ -1950,7 +1987,7 @@ __device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T>
     S.ld(b.slot_f, f);
 #pragma unroll
     for (int j = 0; j < 6; j++)
-        if (L.active) L.out[c.v_index + j] = f[j];
+        L.put(c.v_index + j, f[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2031,7 +2068,7 @@ __device__ __forceinline__ void rnea_fwd_rev(const Tables<T> &P, const Slots<T> 
             for (int j = 0; j < 6; j++) fp[j] += fpr[j];
         }
         S.acc(b.parent_slot_f, fp, 0);
-        if (L.active) L.out[c.v_index] = g0 * f[2] + tau_r;
+        L.put(c.v_index, g0 * f[2] + tau_r);
     }
 }
 
@@ -2050,7 +2087,7 @@ __device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const Slots<T> 
     rotate_z(sc[0], sc[1], C, E);
     xforce_inv(E, C + 9, f, fp);
     S.acc(b.parent_slot_f, fp, 0);
-    if (L.active) L.out[c.v_index] = tau;
+    L.put(c.v_index, tau);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2088,10 +2125,10 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
     S.lane = lane;
     // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
-    S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave + lane;
+    S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
 
 #ifdef GRBDA_PROFILE
-    unsigned long long prof_acc[16] = {0};
+    unsigned long long prof_acc[24] = {0};
 #endif
     PROF_T0();
     const size_t n_tiles = (B + kWave - 1) / kWave;
@@ -2107,7 +2144,7 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
         L.in_q = slab + lane;
         L.in_qd = slab + (size_t)P.nq * kWave + lane;
         L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
-        L.out = ydd + rr * P.nv;
+        L.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.fext = DP.fext ? DP.fext + rr * (size_t)DP.n_bodies * 6 : nullptr;
         Carry<T> carry;
 #pragma unroll
@@ -2150,17 +2187,19 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
                 if (c.kind == CK_FREE) {
                     aba_acc_free(P, S, c, L);
                 } else if (!HAS_LOOP && c.shape) {
-                    aba_acc_rev<T>(P, S, c, L);
+                    aba_acc_rev<T>(P, S, c, L PROF_PASS);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_acc_static, P, S, c, L)
                 }
                 PROF_ADD(4);
             }
         }
+        write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        PROF_ADD(18);  // tile epilogue
     }
 #ifdef GRBDA_PROFILE
     if (lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&grbda_prof[i], prof_acc[i]);
+        for (int i = 0; i < 24; i++) atomicAdd(&grbda_prof[i], prof_acc[i]);
 #endif
 }
 
@@ -2175,7 +2214,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
     S.lane = lane;
     // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
-    S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave + lane;
+    S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -2189,7 +2228,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         L.in_q = slab + lane;
         L.in_qd = slab + (size_t)P.nq * kWave + lane;
         L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
-        L.out = tau + rr * P.nv;
+        L.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.fext = DP.fext ? DP.fext + rr * (size_t)DP.n_bodies * 6 : nullptr;
         L.lane = lane;
         if (DP.groups && P.groups[0] >= 0) issue_group(P, slab, 0, lane);  // first run of the tile
@@ -2222,6 +2261,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
                 }
             }
         }
+        write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, tau, tile, rows_valid, P.nv, lane);
     }
 }
 
