@@ -43,7 +43,7 @@ struct DeviceTables {
     ClusterRec *clusters[4] = {nullptr, nullptr, nullptr, nullptr};
     ClusterRec *rnea_clusters[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *cints = nullptr;
-    int32_t *aba_groups = nullptr, *rnea_groups = nullptr;
+    int32_t *acc_k[4] = {nullptr, nullptr, nullptr, nullptr};
     BodyRec *bodies[4] = {nullptr, nullptr, nullptr, nullptr};       // ABA slots
     BodyRec *rnea_bodies[4] = {nullptr, nullptr, nullptr, nullptr};  // RNEA slots
     double *consts64 = nullptr;
@@ -107,16 +107,15 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         (e = up(h.rnea_steps.data(), h.rnea_steps.size() * sizeof(Step), (void **)&t.rnea_steps)) != hipSuccess ||
         (e = up(h.consts.data(), h.consts.size() * sizeof(double), (void **)&t.consts64)) != hipSuccess ||
         (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess ||
-        (e = up(h.cints.data(), h.cints.size() * sizeof(int32_t), (void **)&t.cints)) != hipSuccess ||
-        (e = up(h.aba_groups.data(), h.aba_groups.size() * sizeof(int32_t), (void **)&t.aba_groups)) != hipSuccess ||
-        (e = up(h.rnea_groups.data(), h.rnea_groups.size() * sizeof(int32_t), (void **)&t.rnea_groups)) != hipSuccess)
+        (e = up(h.cints.data(), h.cints.size() * sizeof(int32_t), (void **)&t.cints)) != hipSuccess)
         return hip_err(e, "plan upload");
     for (int w = 0; w < 4; w++) {
         const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
         if ((e = up(L.clusters.data(), L.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters[w])) != hipSuccess ||
             (e = up(L.rnea_clusters.data(), L.rnea_clusters.size() * sizeof(ClusterRec), (void **)&t.rnea_clusters[w])) != hipSuccess ||
             (e = up(L.bodies.data(), L.bodies.size() * sizeof(BodyRec), (void **)&t.bodies[w])) != hipSuccess ||
-            (e = up(L.rnea_bodies.data(), L.rnea_bodies.size() * sizeof(BodyRec), (void **)&t.rnea_bodies[w])) != hipSuccess)
+            (e = up(L.rnea_bodies.data(), L.rnea_bodies.size() * sizeof(BodyRec), (void **)&t.rnea_bodies[w])) != hipSuccess ||
+            (e = up(L.acc_k.data(), L.acc_k.size() * sizeof(int32_t), (void **)&t.acc_k[w])) != hipSuccess)
             return hip_err(e, "plan upload");
     }
     hipDeviceProp_t prop;
@@ -158,7 +157,7 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, 
     const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
     d.clusters = rnea ? t.rnea_clusters[w] : t.clusters[w];
     d.cints = t.cints;
-    d.groups = (rnea ? L.input_slots_rnea : L.input_slots_aba) ? (rnea ? t.rnea_groups : t.aba_groups) : nullptr;
+    d.acc_k = t.acc_k[w];
     d.bodies = rnea ? t.rnea_bodies[w] : t.bodies[w];
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.nq = h.nq;
@@ -451,8 +450,8 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.aba_groups); (void)hipFree(t.rnea_groups);
-        for (int w = 0; w < 4; w++) { (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
+        (void)hipFree(t.cints);
+        for (int w = 0; w < 4; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work})
         for (auto &kv : *m) {

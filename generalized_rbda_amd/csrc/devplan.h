@@ -14,7 +14,7 @@ struct DevPlan {
     const BodyRec *bodies;
     const T *consts;
     const int32_t *cints;  // integer payload of implicit constraints
-    const int32_t *groups; // input groups: per group n_rows, then (slab row, LDS slot) pairs
+    const int32_t *acc_k;  // ABA: per step, K block to prefetch (Layout::acc_k)
     int nq, nv;
     int n_lds_slots, n_glb_slots;
     int lds_bytes;  // dynamic LDS actually allocated per wave (slot store / input staging area)

@@ -98,7 +98,7 @@ struct Tables {
     cptr<BodyRec> bodies;
     cptr<T> consts;
     cptr<int32_t> cints;
-    cptr<int32_t> groups;
+    cptr<int32_t> acc_k;
     int n_steps, nq, nv, ori_repr;
     T a_root[6];
 };
@@ -111,7 +111,7 @@ __device__ __forceinline__ Tables<T> make_tables(const DevPlan<T> &P)
     t.bodies = (cptr<BodyRec>)P.bodies;
     t.consts = (cptr<T>)P.consts;
     t.cints = (cptr<int32_t>)P.cints;
-    t.groups = (cptr<int32_t>)P.groups;
+    t.acc_k = (cptr<int32_t>)P.acc_k;
     t.n_steps = P.n_steps;
     t.nq = P.nq;
     t.nv = P.nv;
@@ -465,13 +465,11 @@ struct Lane {
     __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
     __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
     __device__ __forceinline__ T x(int j) const { return in_x[(size_t)j * kWave]; }
-    // coordinate a of the current step's cluster: from the staged input group in LDS
-    // ([y n][yd n][x n] at slot in_base, plan.h), or from the slab when the cluster is not staged
-    int in_base, lane;
-    __device__ __forceinline__ T staged(int s) const { return reinterpret_cast<const T *>(grbda_smem)[s * kWave + lane]; }
-    __device__ __forceinline__ T cy(const ClusterRec &c, int a) const { return in_base >= 0 ? staged(in_base + a) : q(c.q_index + a); }
-    __device__ __forceinline__ T cyd(const ClusterRec &c, int a) const { return in_base >= 0 ? staged(in_base + c.n + a) : qd(c.v_index + a); }
-    __device__ __forceinline__ T cx(const ClusterRec &c, int a) const { return in_base >= 0 ? staged(in_base + 2 * c.n + a) : x(c.v_index + a); }
+    // coordinate a of the current step's cluster
+    int lane;
+    __device__ __forceinline__ T cy(const ClusterRec &c, int a) const { return q(c.q_index + a); }
+    __device__ __forceinline__ T cyd(const ClusterRec &c, int a) const { return qd(c.v_index + a); }
+    __device__ __forceinline__ T cx(const ClusterRec &c, int a) const { return x(c.v_index + a); }
 };
 
 // Tile prologue: the batch is row-major ([state][coordinate], the reference's natural vector
@@ -495,6 +493,14 @@ __device__ __forceinline__ void stage_issue(const T *__restrict__ src, size_t ti
                                              4, 0, 0);
     }
 }
+// A workgroup is one wavefront, so exchanging data between lanes through LDS needs no s_barrier (and none of
+// the memory-wide waits __syncthreads implies): LDS operations of a wave execute in order, the LDS counter
+// only has to reach zero and the compiler must not move accesses across the point.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 template <class T>
 __device__ __forceinline__ void stage_transpose(int ncols, unsigned lds_byte_off, T *slab_rows, int lane)
 {
@@ -512,28 +518,28 @@ __device__ __forceinline__ void stage_inputs(const T *__restrict__ q, const T *_
         stage_issue(qd, tile, rows_valid, nv, bq, lane);
         stage_issue(x, tile, rows_valid, nv, bq + bv, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wave_lds_fence();
         stage_transpose(nq, 0u, slab, lane);
         stage_transpose(nv, bq, slab + (size_t)nq * kWave, lane);
         stage_transpose(nv, bq + bv, slab + (size_t)(nq + nv) * kWave, lane);
-        __syncthreads();
+        wave_lds_fence();
     } else {
         // LDS too small for the whole tile: one array at a time (capi.cpp guarantees each one fits)
         stage_issue(q, tile, rows_valid, nq, 0u, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wave_lds_fence();
         stage_transpose(nq, 0u, slab, lane);
-        __syncthreads();
+        wave_lds_fence();
         stage_issue(qd, tile, rows_valid, nv, 0u, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wave_lds_fence();
         stage_transpose(nv, 0u, slab + (size_t)nq * kWave, lane);
-        __syncthreads();
+        wave_lds_fence();
         stage_issue(x, tile, rows_valid, nv, 0u, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wave_lds_fence();
         stage_transpose(nv, 0u, slab + (size_t)(nq + nv) * kWave, lane);
-        __syncthreads();
+        wave_lds_fence();
     }
 }
 
@@ -547,48 +553,16 @@ __device__ __forceinline__ void write_outputs(const T *rows, T *__restrict__ out
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the row stores have landed
     T *stage = reinterpret_cast<T *>(grbda_smem);
     for (int c = 0; c < nv; c++) stage[lane * nv + c] = rows[(size_t)c * kWave + lane];
-    __syncthreads();
+    wave_lds_fence();
     T *dst = out + tile * (size_t)kWave * (size_t)nv;
     const int total = rows_valid * nv;
     for (int i = 0; i < nv; i++) {
         const int j = i * kWave + lane;
         if (j < total) dst[j] = stage[j];
     }
-    __syncthreads();
+    wave_lds_fence();
 }
 
-// Input groups: the rows of q / qd / tau the clusters of a run of steps need are copied from the wave's
-// slab into LDS slots [0, kInputSlots) with asynchronous global->LDS loads.  The region is
-// double-buffered: the copy for run g+1 is issued when run g begins, so it has a whole run of steps
-// to land and the wait at the next boundary is (almost) free.
-template <class T>
-__device__ __forceinline__ void issue_group(const Tables<T> &P, const T *slab, int group, int lane)
-{
-    cptr<int32_t> g = P.groups + group;
-    const int n_rows = g[0];
-    if (n_rows <= 0) return;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier reads of that half have completed
-    constexpr int kDw = (int)(sizeof(T) / 4);
-    for (int r = 0; r < n_rows; r++) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(slab + (size_t)g[1 + 2 * r] * kWave);
-        const unsigned dst = (unsigned)g[2 + 2 * r] * (unsigned)(kWave * sizeof(T));
-#pragma unroll
-        for (int h = 0; h < kDw; h++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + h * kWave + lane),
-                                             (__attribute__((address_space(3))) void *)(grbda_smem + dst + (unsigned)h * 256u),
-                                             4, 0, 0);
-    }
-}
-// a run begins: its rows (issued one run earlier) must have landed; then start fetching the next run's
-template <class T>
-__device__ __forceinline__ void begin_group(const Tables<T> &P, const T *slab, int group, int lane)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int next = group + 1 + 2 * P.groups[group];
-    if (P.groups[next] >= 0) issue_group(P, slab, next, lane);
-}
-
-// register hand-over of a cluster's projected inertia / bias to the next backward step
 template <class T>
 struct Carry {
     T IA[21];
@@ -1661,13 +1635,19 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
 // acceleration sweep of the same shapes (ClusterTreeDynamics.cpp:131-152); a rotor has no children
 template <class T>
 __device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                            const Lane<T> &L PROF_ARGS)
+                                            const Lane<T> &L, const T (&kblk)[7], bool have_kblk PROF_ARGS)
 {
-    T K[6], ap[6];
+    T K[6], ap[6], ydd;
     PROF_SYNCV();
     PROF_ADD(13);  // drain of everything outstanding at step entry
-    S.ld(c.slot_K, K);
-    T ydd = S.ld1(c.slot_y0);
+    if (have_kblk) {  // [K 6][y0 1] fetched while the previous step ran
+#pragma unroll
+        for (int r = 0; r < 6; r++) K[r] = kblk[r];
+        ydd = kblk[6];
+    } else {
+        S.ld(c.slot_K, K);
+        ydd = S.ld1(c.slot_y0);
+    }
     S.ld(c.parent_slot_a3, ap);
     PROF_SYNCV();
     PROF_ADD(14);  // K, y0, parent acceleration loads
@@ -2152,17 +2132,15 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
 #pragma unroll
         for (int j = 0; j < 6; j++) carry.psi[j] = 0;
         L.lane = lane;
-        if (DP.groups && P.groups[0] >= 0) issue_group(P, slab, 0, lane);  // first run of the tile
+        T kpre[7] = {0, 0, 0, 0, 0, 0, 0};  // [K][y0] block of the next acceleration step (Layout::acc_k)
+        bool kpre_valid = false;
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
             PROF_SYNC();
             PROF_ADD(12);  // step + cluster record round trips
-            if (DP.groups && st.group >= 0) begin_group(P, slab, st.group, lane);
-            PROF_ADD(1);   // input-group boundary: wait for the staged rows, issue the next copy
             if (!HAS_LOOP && (st.op & kOpSkipFast)) continue;
             const int op = st.op & kOpMask;
-            L.in_base = DP.groups ? st.in_base : -1;
             if (op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
@@ -2184,10 +2162,25 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
                 }
                 PROF_ADD(3);
             } else {
+                if (HAS_LOOP || !c.shape) {  // generic / free step: start the prefetch chain for a following shape step
+                    if constexpr (!HAS_LOOP) {
+                        const int knext = P.acc_k[s + 1];
+                        kpre_valid = knext != -1;
+                        if (kpre_valid) S.ld(knext, kpre);
+                    }
+                }
                 if (c.kind == CK_FREE) {
                     aba_acc_free(P, S, c, L);
                 } else if (!HAS_LOOP && c.shape) {
-                    aba_acc_rev<T>(P, S, c, L PROF_PASS);
+                    T kblk[7];
+#pragma unroll
+                    for (int j = 0; j < 7; j++) kblk[j] = kpre[j];
+                    const bool have = kpre_valid;
+                    // fetch the next step's [K][y0] block now: it has this whole step to arrive
+                    const int knext = P.acc_k[s + 1];
+                    kpre_valid = knext != -1;
+                    if (kpre_valid) S.ld(knext, kpre);
+                    aba_acc_rev<T>(P, S, c, L, kblk, have PROF_PASS);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_acc_static, P, S, c, L)
                 }
@@ -2231,14 +2224,11 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         L.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
         L.fext = DP.fext ? DP.fext + rr * (size_t)DP.n_bodies * 6 : nullptr;
         L.lane = lane;
-        if (DP.groups && P.groups[0] >= 0) issue_group(P, slab, 0, lane);  // first run of the tile
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
-            if (DP.groups && st.group >= 0) begin_group(P, slab, st.group, lane);
             if (!HAS_LOOP && (st.op & kOpSkipFast)) continue;
             const int op = st.op & kOpMask;
-            L.in_base = DP.groups ? st.in_base : -1;
             if (op == OP_RNEA_FWD) {
                 if (c.kind == CK_FREE) {
                     rnea_fwd_free(P, S, c, L);

@@ -407,24 +407,24 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         for (int r : roots) {
             stack.push_back({r, 0});
             tF[r] = static_cast<int>(P.aba_steps.size());
-            P.aba_steps.push_back({OP_ABA_FWD, r, -1, -1});
+            P.aba_steps.push_back({OP_ABA_FWD, r, {0, 0}});
             tRF[r] = static_cast<int>(P.rnea_steps.size());
-            P.rnea_steps.push_back({OP_RNEA_FWD, r, -1, -1});
+            P.rnea_steps.push_back({OP_RNEA_FWD, r, {0, 0}});
             while (!stack.empty()) {
                 auto &top = stack.back();
                 const int c = top.first;
                 if (top.second < static_cast<int>(kids[c].size())) {
                     const int ch = kids[c][top.second++];
                     tF[ch] = static_cast<int>(P.aba_steps.size());
-                    P.aba_steps.push_back({OP_ABA_FWD, ch, -1, -1});
+                    P.aba_steps.push_back({OP_ABA_FWD, ch, {0, 0}});
                     tRF[ch] = static_cast<int>(P.rnea_steps.size());
-                    P.rnea_steps.push_back({OP_RNEA_FWD, ch, -1, -1});
+                    P.rnea_steps.push_back({OP_RNEA_FWD, ch, {0, 0}});
                     stack.push_back({ch, 0});
                 } else {
                     tB[c] = static_cast<int>(P.aba_steps.size());
-                    P.aba_steps.push_back({OP_ABA_BWD, c, -1, -1});
+                    P.aba_steps.push_back({OP_ABA_BWD, c, {0, 0}});
                     tRB[c] = static_cast<int>(P.rnea_steps.size());
-                    P.rnea_steps.push_back({OP_RNEA_BWD, c, -1, -1});
+                    P.rnea_steps.push_back({OP_RNEA_BWD, c, {0, 0}});
                     stack.pop_back();
                 }
             }
@@ -436,7 +436,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 const int c = st.back();
                 st.pop_back();
                 tA[c] = static_cast<int>(P.aba_steps.size());
-                P.aba_steps.push_back({OP_ABA_ACC, c, -1, -1});
+                P.aba_steps.push_back({OP_ABA_ACC, c, {0, 0}});
                 for (int i = static_cast<int>(kids[c].size()) - 1; i >= 0; i--) st.push_back(kids[c][i]);
             }
         }
@@ -466,48 +466,6 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
     }
 
-    // ---- input groups ------------------------------------------------------------------------------
-    // Greedy partition of the step sequence into runs whose clusters' inputs (3 n rows each) fit into
-    // kInputSlots LDS slots; the kernel stages a run's rows when its first step begins.
-    // (a kernel whose LDS budget is too small for the region ignores the groups and reads the slab)
-    auto build_groups = [&](std::vector<Step> &steps, std::vector<int32_t> &groups) {
-        // The region is double-buffered: group g lives in half (g & 1) and is fetched while group g-1
-        // is being processed, so its latency is hidden behind a whole run of steps.
-        groups.clear();
-        const int half = kInputSlots / 2;
-        const int nsteps = static_cast<int>(steps.size());
-        int s0 = 0, gidx = 0;
-        while (s0 < nsteps) {
-            std::vector<int> base(nc, -1);
-            std::vector<int32_t> rows;
-            const int off = (gidx & 1) * half;
-            int used = 0, s1 = s0;
-            for (; s1 < nsteps; s1++) {
-                const int c = steps[s1].cluster;
-                if (clusters[c].kind == CK_FREE || base[c] >= 0) continue;
-                const int n = clusters[c].n;
-                if (3 * n > half) { base[c] = -2; continue; }  // too large for the region: reads the slab
-                if (used + 3 * n > half) break;
-                base[c] = off + used;
-                for (int a = 0; a < n; a++) { rows.push_back(clusters[c].q_index + a); rows.push_back(off + used + a); }
-                for (int a = 0; a < n; a++) { rows.push_back(P.nq + clusters[c].v_index + a); rows.push_back(off + used + n + a); }
-                for (int a = 0; a < n; a++) { rows.push_back(P.nq + P.nv + clusters[c].v_index + a); rows.push_back(off + used + 2 * n + a); }
-                used += 3 * n;
-            }
-            if (s1 == s0) s1 = s0 + 1;
-            for (int t = s0; t < s1; t++) {
-                const int b = clusters[steps[t].cluster].kind == CK_FREE ? -1 : base[steps[t].cluster];
-                steps[t].in_base = b >= 0 ? b : -1;
-            }
-            // every run gets a group record (possibly empty) so that "next group" is simply the next record
-            steps[s0].group = static_cast<int32_t>(groups.size());
-            groups.push_back(static_cast<int32_t>(rows.size() / 2));
-            groups.insert(groups.end(), rows.begin(), rows.end());
-            gidx++;
-            s0 = s1;
-        }
-        groups.push_back(-1);  // terminator: no further group
-    };
     if (sweep_mask != 7) {  // profiling aid: drop whole sweeps (results are then meaningless)
         std::vector<Step> kept;
         for (const Step &st : P.aba_steps)
@@ -516,8 +474,6 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 kept.push_back(st);
         P.aba_steps = kept;
     }
-    build_groups(P.aba_steps, P.aba_groups);
-    build_groups(P.rnea_steps, P.rnea_groups);
 
     // ---- live ranges + interval allocation --------------------------------------------------------
     struct Obj {
@@ -572,8 +528,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
 
     auto cluster_of = [&](int b) { return m.bodies[b].cluster; };
     auto build_layout = [&](Layout &L, int lds_budget, int lds_budget_rnea, bool with_xa) {
-        L.input_slots_aba = lds_budget >= 2 * kInputSlots ? kInputSlots : 0;
-        L.input_slots_rnea = lds_budget_rnea >= 2 * kInputSlots ? kInputSlots : 0;
+
         L.clusters = clusters;
         L.rnea_clusters = clusters;
         L.bodies = bodies;
@@ -606,9 +561,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
         for (int c = 0; c < nc; c++) {
             ClusterRec &cr = L.clusters[c];
-            objs.push_back({&cr.slot_y0, cr.n, 3, tB[c], tA[c], -1});
-            if (cr.kind != CK_FREE) objs.push_back({&cr.slot_K, 6 * cr.n, 3, tB[c], tA[c], -1});
-            else cr.slot_K = -1;
+            // one block [K 6n][y0 n] per cluster (slot_y0 is derived below): the acceleration sweep fetches the
+            // block of the next step ahead of time (Layout::acc_k)
+            if (cr.kind != CK_FREE) objs.push_back({&cr.slot_K, 7 * cr.n, 3, tB[c], tA[c], -1});
+            else {
+                cr.slot_K = -1;
+                objs.push_back({&cr.slot_y0, cr.n, 3, tB[c], tA[c], -1});
+            }
             cr.slot_imp_fwd = cr.slot_imp_bwd = cr.slot_imp_acc = -1;
             if (cr.kind == CK_LOOP) {
                 const int sz = cr.k * (cr.n + 1) + cr.rows * cr.k + cr.k + cr.k + 6 * cr.k;
@@ -618,9 +577,18 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
         }
         int nl = 0, ng = 0;
-        allocate(objs, lds_budget, L.input_slots_aba, nl, ng);
+        allocate(objs, lds_budget, 0, nl, ng);
         L.n_lds_aba = nl;
         L.n_glb_aba = ng;
+        for (int c = 0; c < nc; c++)
+            if (L.clusters[c].kind != CK_FREE) L.clusters[c].slot_y0 = L.clusters[c].slot_K + 6 * L.clusters[c].n;
+        // acc_k[s]: K block of step s when it is an acceleration step of a straight-line shape, else -1
+        L.acc_k.assign(P.aba_steps.size() + 1, -1);
+        for (size_t t = 0; t < P.aba_steps.size(); t++) {
+            const Step &st = P.aba_steps[t];
+            if (st.op == OP_ABA_ACC && !with_xa && L.clusters[st.cluster].shape != SHAPE_GENERIC)
+                L.acc_k[t] = L.clusters[st.cluster].slot_K;
+        }
         // first contributor to a body's backward accumulators: earliest backward step, and inside
         // one step the highest body index (bodies are visited in reverse order)
         std::vector<int> first(nb, -1);
@@ -717,7 +685,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 robjs.push_back({&cr.slot_imp_bwd, sz, 1, tRB[c], tRB[c], -1});
             }
         }
-        allocate(robjs, lds_budget_rnea, L.input_slots_rnea, nl, ng);
+        allocate(robjs, lds_budget_rnea, 0, nl, ng);
         L.n_lds_rnea = nl;
         L.n_glb_rnea = ng;
         for (int b = 0; b < nb; b++) {

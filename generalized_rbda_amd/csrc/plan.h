@@ -51,14 +51,8 @@ constexpr int32_t kSlotGlobal = 1 << 30;
 struct Step {
     int32_t op;
     int32_t cluster;
-    int32_t group;    // >= 0: an input group begins at this step, offset of its row list in groups[]
-    int32_t in_base;  // LDS slot of this cluster's staged inputs [y n][yd n][x n], or -1 (read the slab)
+    int32_t reserved[2];
 };
-
-// LDS slots [0, kInputSlots) hold the staged inputs of the current "input group": the independent
-// coordinates / velocities / torques of all clusters of a run of consecutive steps (typically one
-// limb), copied from the wave's slab with asynchronous global->LDS loads when the run begins.
-constexpr int kInputSlots = 16;
 
 struct ClusterRec {
     int32_t kind;
@@ -141,8 +135,9 @@ struct Layout {
     std::vector<BodyRec> rnea_bodies;  // RNEA slots (slot_sc, slot_v, slot_a3, slot_f used)
     int n_lds_aba = 0, n_glb_aba = 0;
     int n_lds_rnea = 0, n_glb_rnea = 0;
-    // kInputSlots when the kernel stages input groups in LDS, 0 when its LDS budget is too small for them
-    int input_slots_aba = 0, input_slots_rnea = 0;
+    // per ABA step: slot of the [K][y0] block the step reads when it is an acceleration step of a
+    // straight-line shape, else -1; padded by one.  The kernel fetches entry s + 1 while it runs step s.
+    std::vector<int32_t> acc_k;
 };
 
 // LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
@@ -157,8 +152,6 @@ struct HostPlan {
     double gravity[6] = {0, 0, 0, 0, 0, -9.81};
     std::vector<Step> aba_steps;
     std::vector<Step> rnea_steps;
-    // per group: n_rows, then n_rows x (slab input row, LDS slot)
-    std::vector<int32_t> aba_groups, rnea_groups;
     std::vector<double> consts;  // converted to float on upload for the f32 kernels
     std::vector<int32_t> cints;  // integer payload of implicit constraints
     Layout lay32, lay64;      // fast path
