@@ -626,16 +626,20 @@ __device__ __forceinline__ void inv_small(int R, const T (&A)[3][3], T (&Ai)[3][
     }
 }
 
+// Scratch of an implicit cluster.  The constraint is evaluated ONCE per evaluation, in the first sweep that
+// visits the cluster; what the later sweeps need -- [G rows k*(n+1), last column g][qd_span k][q_span k] --
+// lives in a block kept until the last sweep (base), the work space of the evaluation itself --
+// [K rows*k][chain 6k] -- in a block that only lives during that step (tmp).
 template <int N>
 struct ImpLayout {
     int G, K, qds, qs, chain;
-    __device__ __forceinline__ ImpLayout(int base, int k, int rows)
+    __device__ __forceinline__ ImpLayout(int base, int tmp, int k, int rows)
     {
         G = base;
-        K = G + k * (N + 1);
-        qds = K + rows * k;
+        qds = G + k * (N + 1);
         qs = qds + k;
-        chain = qs + k;
+        K = tmp;
+        chain = K + rows * k;
     }
 };
 
@@ -867,9 +871,9 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
 // G rows, g, spanning positions / velocities of an implicit cluster into the scratch block
 template <class T, int N>
 __device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                                  const Lane<T> &L, int base, const T (&yd)[N], bool want_bias)
+                                                  const Lane<T> &L, const T (&yd)[N], bool want_bias)
 {
-    const ImpLayout<N> lay(base, c.k, c.rows);
+    const ImpLayout<N> lay(c.slot_imp_fwd, c.slot_imp_bwd, c.k, c.rows);
     const int k = c.k, rows = c.rows;
     cptr<int32_t> ip = P.cints + c.iofs;
     const int hdr0 = ip[0];  // number of loops (position loops)
@@ -967,7 +971,7 @@ __device__ __forceinline__ void body_coupling(const Tables<T> &P, const Slots<T>
                                               typename RowSel<T, N, LOOP>::type &Gr, T &gi)
 {
     if constexpr (LOOP) {
-        const ImpLayout<N> lay(imp_base, c.k, c.rows);
+        const ImpLayout<N> lay(imp_base, 0, c.k, c.rows);
         T row[N + 1];
         S.ld(lay.G + i * (N + 1), row);
 #pragma unroll
@@ -1082,7 +1086,7 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
         yd[a] = L.cyd(c, a);
     }
     const int imp = c.slot_imp_fwd;
-    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
+    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, yd, true);  // kept for the later sweeps
     for (int i = 0; i < c.k; i++) {
         if (!((c.child_mask >> i) & 1)) continue;  // leaf bodies are evaluated inside the backward step
         const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
@@ -1198,8 +1202,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
         for (int bb = 0; bb < N; bb++) D[a][bb] = 0;
     }
 
-    const int imp = c.slot_imp_bwd;
-    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
+    const int imp = c.slot_imp_fwd;  // evaluated by the forward step
 
     // in-cluster bias acceleration (the cJ part of GenericJoint.cpp:430-450), chained clusters only
     if (c.chained) {
@@ -1742,17 +1745,10 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
         y[a] = L.cy(c, a);
         yd[a] = L.cyd(c, a);
     }
-    const int imp = c.slot_imp_acc;
-    bool evaluated = false;
+    const int imp = c.slot_imp_fwd;  // evaluated by the forward step
     for (int i = 0; i < c.k; i++) {
         if (!((c.child_mask >> i) & 1)) continue;  // nothing downstream needs this body's acceleration
         const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
-        if constexpr (LOOP) {
-            if (!evaluated) {
-                eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
-                evaluated = true;
-            }
-        }
         cptr<T> C = P.consts + b.cofs;
         T qi, gi;
         typename RowSel<T, N, LOOP>::type G;
@@ -1837,7 +1833,7 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
         ydd[a] = L.cx(c, a);
     }
     const int imp = c.slot_imp_fwd;
-    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, true);
+    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, yd, true);  // kept for the backward step
     for (int i = 0; i < c.k; i++) {
         const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
@@ -1932,8 +1928,7 @@ __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<
         y[a] = L.cy(c, a);
         yd[a] = L.cyd(c, a);
     }
-    const int imp = c.slot_imp_bwd;
-    if constexpr (LOOP) eval_loop_constraint<T, N>(P, S, c, L, imp, yd, false);
+    const int imp = c.slot_imp_fwd;  // evaluated by the forward step
     for (int i = c.k - 1; i >= 0; i--) {
         const BodyRec b = load_body<GEN>(P.bodies + (c.first_body + i));
         cptr<T> C = P.consts + b.cofs;
@@ -2101,6 +2096,9 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
 {
     const Tables<T> P = make_tables(DP);
     const int lane = threadIdx.x;
+    // the straight-line shape handlers carry no external-force code: layouts with absolute transforms
+    // (DP.fext set) run every cluster through the generic handlers
+    const bool use_shapes = !HAS_LOOP || DP.fext == nullptr;
     Slots<T> S;
     S.lane = lane;
     // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
@@ -2139,12 +2137,12 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
             const ClusterRec c = load_rec(P.clusters + st.cluster);
             PROF_SYNC();
             PROF_ADD(12);  // step + cluster record round trips
-            if (!HAS_LOOP && (st.op & kOpSkipFast)) continue;
+            if (use_shapes && (st.op & kOpSkipFast)) continue;
             const int op = st.op & kOpMask;
             if (op == OP_ABA_FWD) {
                 if (c.kind == CK_FREE) {
                     aba_fwd_free(P, S, c, L);
-                } else if (!HAS_LOOP && c.shape) {
+                } else if (use_shapes && c.shape) {
                     aba_fwd_rev<T>(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_fwd_static, P, S, c, L)
@@ -2153,25 +2151,23 @@ __global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) vo
             } else if (op == OP_ABA_BWD) {
                 if (c.kind == CK_FREE) {
                     aba_bwd_free(P, S, c, L, carry);
-                } else if (!HAS_LOOP && c.shape == SHAPE_REV) {
+                } else if (use_shapes && c.shape == SHAPE_REV) {
                     aba_bwd_rev<T, false>(P, S, c, L, carry);
-                } else if (!HAS_LOOP && c.shape == SHAPE_REV_ROTOR) {
+                } else if (use_shapes && c.shape == SHAPE_REV_ROTOR) {
                     aba_bwd_rev<T, true>(P, S, c, L, carry);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_bwd_static, P, S, c, L, carry PROF_PASS)
                 }
                 PROF_ADD(3);
             } else {
-                if (HAS_LOOP || !c.shape) {  // generic / free step: start the prefetch chain for a following shape step
-                    if constexpr (!HAS_LOOP) {
-                        const int knext = P.acc_k[s + 1];
-                        kpre_valid = knext != -1;
-                        if (kpre_valid) S.ld(knext, kpre);
-                    }
+                if (use_shapes && !c.shape) {  // generic / free step: start the prefetch chain for a following shape step
+                    const int knext = P.acc_k[s + 1];
+                    kpre_valid = knext != -1;
+                    if (kpre_valid) S.ld(knext, kpre);
                 }
                 if (c.kind == CK_FREE) {
                     aba_acc_free(P, S, c, L);
-                } else if (!HAS_LOOP && c.shape) {
+                } else if (use_shapes && c.shape) {
                     T kblk[7];
 #pragma unroll
                     for (int j = 0; j < 7; j++) kblk[j] = kpre[j];
@@ -2203,6 +2199,9 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
 {
     const Tables<T> P = make_tables(DP);
     const int lane = threadIdx.x;
+    // the straight-line shape handlers carry no external-force code: layouts with absolute transforms
+    // (DP.fext set) run every cluster through the generic handlers
+    const bool use_shapes = !HAS_LOOP || DP.fext == nullptr;
     Slots<T> S;
     S.lane = lane;
     // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
@@ -2227,14 +2226,14 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
         for (int s = 0; s < P.n_steps; s++) {
             const Step st = load_rec(P.steps + s);
             const ClusterRec c = load_rec(P.clusters + st.cluster);
-            if (!HAS_LOOP && (st.op & kOpSkipFast)) continue;
+            if (use_shapes && (st.op & kOpSkipFast)) continue;
             const int op = st.op & kOpMask;
             if (op == OP_RNEA_FWD) {
                 if (c.kind == CK_FREE) {
                     rnea_fwd_free(P, S, c, L);
-                } else if (!HAS_LOOP && c.shape == SHAPE_REV) {
+                } else if (use_shapes && c.shape == SHAPE_REV) {
                     rnea_fwd_rev<T, false>(P, S, c, L);
-                } else if (!HAS_LOOP && c.shape == SHAPE_REV_ROTOR) {
+                } else if (use_shapes && c.shape == SHAPE_REV_ROTOR) {
                     rnea_fwd_rev<T, true>(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, rnea_fwd_static, P, S, c, L)
@@ -2242,9 +2241,9 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
             } else {
                 if (c.kind == CK_FREE) {
                     rnea_bwd_free(P, S, c, L);
-                } else if (!HAS_LOOP && c.shape == SHAPE_REV) {
+                } else if (use_shapes && c.shape == SHAPE_REV) {
                     rnea_bwd_rev<T, false>(P, S, c, L);
-                } else if (!HAS_LOOP && c.shape == SHAPE_REV_ROTOR) {
+                } else if (use_shapes && c.shape == SHAPE_REV_ROTOR) {
                     rnea_bwd_rev<T, true>(P, S, c, L);
                 } else {
                     GRBDA_DISPATCH_N(c, rnea_bwd_static, P, S, c, L)

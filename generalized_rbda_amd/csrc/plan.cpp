@@ -168,17 +168,16 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         if (bodies[b].has_child) clusters[m.bodies[b].cluster].child_mask |= 1 << m.bodies[b].sub_index;
 
     // ---- canonical joint axes -------------------------------------------------------------------
-    // Models without implicit loops are re-expressed so that every revolute joint turns about the z axis
-    // of its body frame: body i's coordinates are rotated by the cyclic permutation Rc_i that maps its
+    // The model is re-expressed so that every revolute joint turns about the z axis of its body frame
+    // (bodies of URDF+ position-loop clusters excepted: their loop origins are given in link frames): body i's coordinates are rotated by the cyclic permutation Rc_i that maps its
     // joint axis onto z (v_new = Rc_i v_old).  Then R_a(q) E_tree becomes R_z(q) (Rc_i E_tree Rc_p^T),
     // the tree offset r (parent coordinates) becomes Rc_p r and the spatial inertia D I D^T with
     // D = blockdiag(Rc_i, Rc_i).  Joint coordinates, torques and accelerations are unchanged, and
     // world-frame external forces reach the bodies through the (equally rotated) absolute transforms.
-    // The fast kernels rely on it (kernels.hip, load_body): the joint axis is a constant there.
+    // The fast kernels and the straight-line handlers rely on it (kernels.hip, load_body): the joint axis
+    // is a constant there.
     std::vector<grbda_desc_body> canon;
-    bool any_loop = false;
-    for (int c = 0; c < nc; c++) any_loop |= clusters[c].kind == CK_LOOP;
-    if (!any_loop) {
+    {
         canon.assign(m.bodies, m.bodies + nb);
         auto perm = [](int axis, double R[9]) {
             for (int i = 0; i < 9; i++) R[i] = 0;
@@ -187,8 +186,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             else { R[0] = R[4] = R[8] = 1; }
         };
         std::vector<std::array<double, 9>> Rc(nb);
-        for (int b = 0; b < nb; b++)
-            perm(m.bodies[b].joint_type == GRBDA_JOINT_REVOLUTE ? m.bodies[b].axis : 2, Rc[b].data());
+        for (int b = 0; b < nb; b++) {
+            const ClusterRec &bc = clusters[m.bodies[b].cluster];
+            const bool keep = m.bodies[b].joint_type != GRBDA_JOINT_REVOLUTE || (bc.kind == CK_LOOP && bc.cons_type == 0);
+            perm(keep ? 2 : m.bodies[b].axis, Rc[b].data());
+        }
         for (int b = 0; b < nb; b++) {
             grbda_desc_body &bd = canon[b];
             const double *Ri = Rc[b].data();
@@ -222,7 +224,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             I[(3 * bi + i) * 6 + 3 * bj + j] = sacc;
                         }
             std::memcpy(bd.inertia, I, sizeof I);
-            if (bd.joint_type == GRBDA_JOINT_REVOLUTE) {
+            const ClusterRec &bc = clusters[bd.cluster];
+            if (bd.joint_type == GRBDA_JOINT_REVOLUTE && !(bc.kind == CK_LOOP && bc.cons_type == 0)) {
                 bd.axis = 2;
                 bodies[b].axis = 2;
             }
@@ -321,7 +324,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         ClusterRec &cr = clusters[c];
         cr.shape = SHAPE_GENERIC;
         cr.link_body = cr.rotor_body = -1;
-        if (any_loop || cr.kind != CK_STATIC || cr.n != 1 || cr.chained || cr.parent_body < 0) continue;
+        if (cr.kind != CK_STATIC || cr.n != 1 || cr.chained || cr.parent_body < 0) continue;
         const int f = cr.first_body;
         if (cr.k == 1 && !bodies[f].axisym) {
             cr.shape = SHAPE_REV;
@@ -480,9 +483,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         int *field;  // where the slot number goes (index into a flat array of fields)
         int size, prio, birth, death, slot;
     };
-    // lds_base: state slots start after the input staging region
-    auto allocate = [](std::vector<Obj> &objs, int lds_budget_total, int lds_base, int &n_lds, int &n_glb) {
-        const int lds_budget = lds_budget_total > lds_base ? lds_budget_total - lds_base : 0;
+    auto allocate = [](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb) {
+        const int lds_base = 0;
         std::vector<int> order(objs.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = static_cast<int>(i);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
@@ -570,14 +572,14 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             cr.slot_imp_fwd = cr.slot_imp_bwd = cr.slot_imp_acc = -1;
             if (cr.kind == CK_LOOP) {
-                const int sz = cr.k * (cr.n + 1) + cr.rows * cr.k + cr.k + cr.k + 6 * cr.k;
-                objs.push_back({&cr.slot_imp_fwd, sz, 1, tF[c], tF[c], -1});
-                objs.push_back({&cr.slot_imp_bwd, sz, 1, tB[c], tB[c], -1});
-                objs.push_back({&cr.slot_imp_acc, sz, 1, tA[c], tA[c], -1});
+                const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + 6 * cr.k;
+                // (kernels.hip, ImpLayout) kept block: forward step -> acceleration step; work space: forward step
+                objs.push_back({&cr.slot_imp_fwd, keep, 1, tF[c], tA[c], -1});
+                objs.push_back({&cr.slot_imp_bwd, tmp, 1, tF[c], tF[c], -1});
             }
         }
         int nl = 0, ng = 0;
-        allocate(objs, lds_budget, 0, nl, ng);
+        allocate(objs, lds_budget, nl, ng);
         L.n_lds_aba = nl;
         L.n_glb_aba = ng;
         for (int c = 0; c < nc; c++)
@@ -680,12 +682,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             cr.parent_slot_IA = cr.parent_slot_psi = cr.parent_slot_v3 = cr.parent_slot_a3 = -1;
             cr.carry_out = 0;
             if (cr.kind == CK_LOOP) {
-                const int sz = cr.k * (cr.n + 1) + cr.rows * cr.k + cr.k + cr.k + 6 * cr.k;
-                robjs.push_back({&cr.slot_imp_fwd, sz, 1, tRF[c], tRF[c], -1});
-                robjs.push_back({&cr.slot_imp_bwd, sz, 1, tRB[c], tRB[c], -1});
+                const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + 6 * cr.k;
+                robjs.push_back({&cr.slot_imp_fwd, keep, 1, tRF[c], tRB[c], -1});
+                robjs.push_back({&cr.slot_imp_bwd, tmp, 1, tRF[c], tRF[c], -1});
             }
         }
-        allocate(robjs, lds_budget_rnea, 0, nl, ng);
+        allocate(robjs, lds_budget_rnea, nl, ng);
         L.n_lds_rnea = nl;
         L.n_glb_rnea = ng;
         for (int b = 0; b < nb; b++) {
@@ -709,8 +711,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     build_layout(P.lay64x, lds.aba64, lds.rnea64, true);
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
-    // per-body costs: sincos ~40, E build 12, motion xform 39, force xform 39, sym6*vec 66,
-    // force cross 30, congruence ~470, plus per-cluster solve terms.
+    // per-body costs: sincos ~40, E build 12, motion / force transform 39, sym6*vec 66 (48 against a
+    // revolute velocity product, two zero entries), force cross 30, congruence 385, plus the per-cluster
+    // solve terms.  Axisymmetric rotors are evaluated at q = 0 (no sincos, no congruence).  Checked against
+    // the executed SQ_INSTS_VALU_{FMA,MUL,ADD}_F32 counts (profiles/): 23.7e3 flop per MIT-humanoid evaluation.
     double fa = 0, fr = 0;
     for (int c = 0; c < nc; c++) {
         const ClusterRec &cr = clusters[c];
@@ -718,14 +722,20 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         for (int i = 0; i < cr.k; i++) {
             const BodyRec &br = bodies[cr.first_body + i];
             const bool is_free = br.jtype == GRBDA_JOINT_FREE;
-            fa += (is_free ? 60 : 40 + 12) + 39 + 2 * n;           // sincos, E, v, qd
-            fa += 8 + 66 + 30 + 12 + 66 + 6 + 39 * 2;             // c, Iv, cross, psi, IA*c, push h, t
-            fa += br.parent >= 0 ? 470 + 39 : 0;                  // congruence + bias to parent
-            fa += 6 * n * 2 + n * n * 2;                          // F, D accumulation
-            if (br.has_child) fa += 40 + 12 + 39 * 2 + 8 + 2 * n + 6;  // acceleration sweep (recomputes v)
-            fr += (is_free ? 60 : 52) + 39 * 2 + 8 + 2 * n * 2 + 66 * 2 + 30 + 39 + 2 * n;
+            if (is_free) {
+                fa += 60 + 66 + 30 + 21 + 6;                       // E from the quaternion, Iv, cross, IA, u
+                fr += 60 + 39 + 66 * 2 + 30 + 6;
+                continue;
+            }
+            const double kin = br.axisym ? 39 + 2 * n : 40 + 12 + 39 + 2 * n;  // (sincos, E,) v, qd
+            fa += kin + 4 + 66 + 30 + 21 + 9 + 39 + 6 * n * 2 + n * n * 2;    // c, Iv, cross, IA, b, F, D
+            if (br.parent >= 0) fa += 48 + 6 + 39 + (br.axisym ? 0 : 385);    // IA c + pA, to the parent, X^T IA X
+            if (br.lam >= 0) fa += 39 + 4 * n * n;                            // push up the in-cluster chain
+            if (br.has_child) fa += 40 + 12 + 39 * 2 + 4 + 2 * n + 6;          // acceleration sweep (recomputes v)
+            fr += kin + 39 + 4 + 2 * n + 66 * 2 + 30 + 6 + 39 + 2 * n;        // v, a, f = I a + v x* I v, tau, X^T f
         }
-        fa += n * n * n / 3.0 + 2.0 * n * n * 7 + 21 * 2 * n + 12 * n + 12 * n;  // solve, K, IA -= F K, psi += F y0, ydd
+        if (cr.kind == CK_FREE) fa += 6 * 6 * 6 / 3.0 + 2.0 * 36 + 6;        // 6x6 Cholesky + solve
+        else fa += n * n * n / 3.0 + 2.0 * n * n * 7 + 21 * 2 * n + 12 * n + 12 * n;  // solve, K, IA -= F K, psi += F y0, ydd
     }
     P.flops_aba = fa;
     P.flops_rnea = fr;

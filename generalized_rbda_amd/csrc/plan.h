@@ -73,7 +73,8 @@ struct ClusterRec {
     int32_t carry_out;        // 1: the contribution to parent_body is handed over in registers to the
                               //    next step (= backward step of the parent cluster) instead of slots
     int32_t rows;             // implicit clusters: number of constraint rows (= dependent coordinates)
-    // implicit clusters: per-step scratch block [G rows k*(n+1)] [K rows*k] [qd_span k] [q_span k] [chain 6k]
+    // implicit clusters (kernels.hip, ImpLayout): slot_imp_fwd = block kept across the sweeps
+    // [G rows k*(n+1)][qd_span k][q_span k], slot_imp_bwd = work space of the evaluation [K rows*k][chain 6k]
     int32_t slot_imp_fwd, slot_imp_bwd, slot_imp_acc;
     int32_t iofs;             // offset into cints[]: n_loops, n_ind, ind[], n_dep, dep[], loops...
     int32_t dofs;             // offset into consts[]: per loop pred origin E[9] r[3], succ origin E[9] r[3]

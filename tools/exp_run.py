@@ -10,7 +10,7 @@ def one(path):
     G.LIB_PATH = os.path.abspath(path)
     from generalized_rbda_amd.states import random_states
     res = []
-    for urdf, prec in (("mit_humanoid", 32), ("mit_humanoid", 64), ("mini_cheetah", 32), ("mini_cheetah", 64), ("jvrc1_humanoid", 32)):
+    for urdf, prec in [(m, 32) for m in os.environ.get("EXP_MODELS", "mit_humanoid,mini_cheetah,jvrc1_humanoid").split(",")] + [(m, 64) for m in os.environ.get("EXP_MODELS64", "mit_humanoid,mini_cheetah").split(",") if m]:
         plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", urdf + ".urdf"))
         B = 262144
         q, qd, tau = random_states(plan.blob, B, 2)
