@@ -107,12 +107,11 @@ def main():
     q, qd, x = random_states(blob, B, config_index=cfg + 1000 * rank)
     if args.workload == "tello":
         # implicit clusters take spanning positions on the constraint manifold: Newton projection of the
-        # dependent coordinates (GenericJoint.cpp:289-385) with the CPU oracle -- input generation only;
-        # states that do not converge are replaced by converged ones
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle_py as O
-
-        q, ok = O.project_positions(blob, q)
+        # dependent coordinates (GenericJoint.cpp:289-385) on the device (grbda_project_positions_f64) --
+        # input generation only; states that do not converge are replaced by converged ones
+        t64 = torch.as_tensor(q, dtype=torch.float64, device=dev)
+        ok = plan.project_positions(t64).cpu().numpy()
+        q = t64.cpu().numpy()
         good = np.flatnonzero(ok)
         if good.size == 0:
             raise SystemExit("no valid Tello state could be generated")

@@ -24,6 +24,8 @@ C_ABI_SYMBOLS = [
     "grbda_aba_host_f64", "grbda_rnea_host_f64", "grbda_time_kernel", "grbda_device_count",
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
     "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
+    "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
+    "grbda_spanning_f64", "grbda_spanning_f32",
 ]
 
 
@@ -87,6 +89,12 @@ def lib() -> ctypes.CDLL:
         getattr(L, "grbda_fd_dtau_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
         getattr(L, "grbda_fd_dqd_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                       c_int, c_void_p]
+    L.grbda_plan_span_dims.argtypes = [c_void_p, POINTER(c_int)]
+    for sfx in ("f64", "f32"):
+        getattr(L, "grbda_project_positions_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                                                 c_double, c_int, c_void_p]
+        getattr(L, "grbda_spanning_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                        c_size_t, c_int, c_void_p]
     _lib = L
     return L
 
@@ -230,6 +238,46 @@ class Plan:
     def fd_dqd(self, q, qd, tau, stream=None):
         """d ydd / d qd of the forward dynamics, [B, nv, nv] (exact: the ABA is quadratic in qd)."""
         return self._derived("fd_dqd", q, (qd, tau), stream=stream)
+
+    # ---- steps either side of the path ------------------------------------------------------------
+    @property
+    def n_span_vel(self) -> int:
+        n = c_int(0)
+        _check(lib().grbda_plan_span_dims(self._h, byref(n)))
+        return n.value
+
+    def project_positions(self, q, max_iter: int = 50, tol: float = 1e-8, stream=None):
+        """Newton projection of the dependent coordinates of implicit clusters onto phi(q) = 0, IN PLACE
+        (GenericJoint.cpp:289-385).  Returns a bool tensor [B]: the state converged to |phi| < tol."""
+        import torch
+
+        if not q.is_cuda or q.dtype not in (torch.float32, torch.float64) or not q.is_contiguous():
+            raise GrbdaError(-3, "q must be a contiguous float32/float64 HIP device tensor (there is no CPU fallback)")
+        B = q.shape[0]
+        if q.shape != (B, self.nq):
+            raise ValueError(f"expected q[B,{self.nq}]")
+        ok = torch.empty((B,), dtype=torch.int32, device=q.device)
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_project_positions_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), ok.data_ptr(), B, max_iter, tol, q.device.index or 0, c_void_p(s.cuda_stream)))
+        return ok.bool()
+
+    def spanning(self, q, qd, ydd, stream=None):
+        """qd_span = G yd and qdd_span = G ydd + g for every body joint: two tensors [B, n_span_vel]."""
+        import torch
+
+        B = q.shape[0]
+        if not q.is_cuda or q.shape != (B, self.nq) or qd.shape != (B, self.nv) or ydd.shape != (B, self.nv):
+            raise ValueError(f"expected device tensors q[B,{self.nq}], qd[B,{self.nv}], ydd[B,{self.nv}]")
+        q, qd, ydd = q.contiguous(), qd.contiguous(), ydd.contiguous()
+        n = self.n_span_vel
+        v = torch.empty((B, n), dtype=q.dtype, device=q.device)
+        a = torch.empty((B, n), dtype=q.dtype, device=q.device)
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_spanning_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), qd.data_ptr(), ydd.data_ptr(), v.data_ptr(), a.data_ptr(), B,
+                  q.device.index or 0, c_void_p(s.cuda_stream)))
+        return v, a
 
     def time_kernel(self, which: str, q, qd, x, out, iters: int = 20, stream=None) -> float:
         """Average kernel duration in ms, hipEvents on the launch stream (grbda_time_kernel)."""

@@ -252,6 +252,72 @@ int run_host_f64(const grbda_plan *p, bool rnea, const double *q, const double *
     return rc;
 }
 
+// ---- steps either side of the path: Newton projection, spanning recovery (kernels.hip) -----------------------
+int span_count(const grbda_plan *p)
+{
+    int n = 0;
+    for (const ClusterRec &c : p->host.lay64.clusters) n += c.kind == CK_FREE ? 6 : c.k;
+    return n;
+}
+
+// launch shape of the ABA kernel of the same precision: the auxiliary kernels use its slot layout
+template <class T>
+int aux_setup(const grbda_plan *p, size_t B, int device, void *stream, DevPlan<T> &d, T **scratch, int *grid,
+              size_t *lds_bytes)
+{
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    d = make_dev_plan<T>(p, *t, false, false);
+    const int kid = sizeof(T) == 8 ? 1 : 0;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    size_t g = static_cast<size_t>(t->n_cu) * 4;  // one wavefront per SIMD: these kernels are not register-tuned
+    if (g > n_tiles) g = n_tiles;
+    const size_t n_glb = static_cast<size_t>(d.n_glb_slots) + static_cast<size_t>(d.nq + 2 * d.nv);
+    void *sp = nullptr;
+    if (int rc = ensure_scratch(p, device, stream, g * n_glb * kWave * sizeof(T) + 256, &sp)) return rc;
+    size_t lb = static_cast<size_t>(d.n_lds_slots) * kWave * sizeof(T);
+    const size_t stage_one = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq > d.nv ? d.nq : d.nv) * sizeof(T);
+    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq + 2 * d.nv) * sizeof(T);
+    if (lb < stage_one) lb = stage_one;
+    if (lb < stage_all && stage_all <= static_cast<size_t>(p->lds_bytes_per_wave[kid])) lb = stage_all;
+    d.lds_bytes = static_cast<int>(lb);
+    *scratch = static_cast<T *>(sp);
+    *grid = static_cast<int>(g);
+    *lds_bytes = lb;
+    return GRBDA_OK;
+}
+
+template <class T>
+int project(const grbda_plan *p, T *q, int32_t *ok, size_t B, int max_iter, double tol, int device, void *stream)
+{
+    if (!p || !q || max_iter < 0) return set_err(GRBDA_EINVAL, "bad argument");
+    if (B == 0) return GRBDA_OK;
+    DevPlan<T> d;
+    T *scratch = nullptr;
+    int grid = 0;
+    size_t lds = 0;
+    if (int rc = aux_setup<T>(p, B, device, stream, d, &scratch, &grid, &lds)) return rc;
+    hipError_t e = launch_project<T>(d, p->host.n_clusters, q, ok, B, max_iter, static_cast<T>(tol), scratch, grid, lds,
+                                     static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "projection launch");
+}
+
+template <class T>
+int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_span, T *qdd_span, size_t B, int device,
+             void *stream)
+{
+    if (!p || !q || !qd || !ydd || !qdd_span) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0) return GRBDA_OK;
+    DevPlan<T> d;
+    T *scratch = nullptr;
+    int grid = 0;
+    size_t lds = 0;
+    if (int rc = aux_setup<T>(p, B, device, stream, d, &scratch, &grid, &lds)) return rc;
+    hipError_t e = launch_spanning<T>(d, p->host.n_clusters, span_count(p), q, qd, ydd, qd_span, qdd_span, B, scratch,
+                                      grid, lds, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "spanning launch");
+}
+
 // ---- derived quantities: expanded batches over the two kernels (include/grbda_hip.h) ---------------------
 enum DerivedMode { DM_BIAS = 0, DM_MASS = 1, DM_DTAU = 2, DM_DQD = 3 };
 
@@ -570,6 +636,33 @@ int grbda_fd_dqd_f32(const grbda_plan *p, const float *q, const float *qd, const
                      int device, void *stream)
 {
     return derived<float>(p, DM_DQD, q, qd, tau, nullptr, J, B, device, stream);
+}
+
+int grbda_plan_span_dims(const grbda_plan *p, int *n_span_vel)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    if (n_span_vel) *n_span_vel = span_count(p);
+    return GRBDA_OK;
+}
+int grbda_project_positions_f64(const grbda_plan *p, double *q, int32_t *ok, size_t B, int max_iter, double tol,
+                                int device, void *stream)
+{
+    return project<double>(p, q, ok, B, max_iter, tol, device, stream);
+}
+int grbda_project_positions_f32(const grbda_plan *p, float *q, int32_t *ok, size_t B, int max_iter, double tol,
+                                int device, void *stream)
+{
+    return project<float>(p, q, ok, B, max_iter, tol, device, stream);
+}
+int grbda_spanning_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, double *qd_span,
+                       double *qdd_span, size_t B, int device, void *stream)
+{
+    return spanning<double>(p, q, qd, ydd, qd_span, qdd_span, B, device, stream);
+}
+int grbda_spanning_f32(const grbda_plan *p, const float *q, const float *qd, const float *ydd, float *qd_span,
+                       float *qdd_span, size_t B, int device, void *stream)
+{
+    return spanning<float>(p, q, qd, ydd, qd_span, qdd_span, B, device, stream);
 }
 
 int grbda_aba_host_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau,

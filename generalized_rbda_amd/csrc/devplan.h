@@ -31,6 +31,13 @@ hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau
 template <class T>
 hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch,
                        int grid, size_t lds_bytes, hipStream_t stream);
+template <class T>
+hipError_t launch_project(const DevPlan<T> &P, int n_clusters, T *q, int32_t *ok, size_t B, int max_iter, T tol,
+                          T *scratch, int grid, size_t lds_bytes, hipStream_t stream);
+template <class T>
+hipError_t launch_spanning(const DevPlan<T> &P, int n_clusters, int n_span, const T *q, const T *qd, const T *ydd,
+                           T *qd_span, T *qdd_span, size_t B, T *scratch, int grid, size_t lds_bytes,
+                           hipStream_t stream);
 hipError_t set_max_dynamic_lds();
 
 }  // namespace grbda_hip

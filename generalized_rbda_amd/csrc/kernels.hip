@@ -683,8 +683,10 @@ __device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const S
 // ---- K(q) and Kdot*qd of URDF+ position loops --------------------------------------------------
 template <class T, int N>
 __device__ __forceinline__ void loop_position_K(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                                const ImpLayout<N> &lay, cptr<int32_t> loops, int n_loops)
+                                                const ImpLayout<N> &lay, cptr<int32_t> loops, int n_loops,
+                                                T *phi = nullptr /* [3]: p_pred - p_succ on the masked axes */)
 {
+    if (phi) phi[0] = phi[1] = phi[2] = 0;
     const int k = c.k;
     cptr<int32_t> lp = loops;
     int row0 = 0;
@@ -697,6 +699,17 @@ __device__ __forceinline__ void loop_position_K(const Tables<T> &P, const Slots<
             T p[3];
             loop_chain_positions(P, S, c, subs, len, org + 12 * side, lay.qs, lay.chain, p);
             const T sgn = side == 0 ? T(1) : T(-1);
+            if (phi) {
+                int row = row0;
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++)
+                    if (mask & (1 << ax)) {
+                        if (row == 0) phi[0] += sgn * p[ax];
+                        else if (row == 1) phi[1] += sgn * p[ax];
+                        else phi[2] += sgn * p[ax];
+                        row++;
+                    }
+            }
             for (int t = 0; t < len; t++) {
                 T ao[6];
                 S.ld(lay.chain + 6 * t, ao);
@@ -786,7 +799,8 @@ __device__ __forceinline__ void loop_position_Kdqd(const Tables<T> &P, const Slo
 // otherwise the second directional derivative along qd_span goes to kdq.
 template <class T, int N>
 __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
-                                               const ImpLayout<N> &lay, cptr<int32_t> prog, bool want_K, T (&kdq)[3])
+                                               const ImpLayout<N> &lay, cptr<int32_t> prog, bool want_K, T (&kdq)[3],
+                                               T *phi = nullptr /* [3]: constraint values, with want_K */)
 {
     const int k = c.k;
     cptr<int32_t> ip = prog;
@@ -803,7 +817,7 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
         T Krow[kMaxClusterBodies];
 #pragma unroll
         for (int j = 0; j < kMaxClusterBodies; j++) Krow[j] = 0;
-        T kd = 0;
+        T kd = 0, ph = 0;
         for (int t = 0; t < nt; t++) {
             const int nf = *ip++;
             const T coef = *dp++;
@@ -830,6 +844,7 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
                     else { f0[f] = a; f1[f] = 1; f2[f] = 0; }
                 }
             }
+            if (phi) ph += coef * f0[0] * f0[1] * f0[2] * f0[3];
 #pragma unroll
             for (int f = 0; f < 4; f++) {
                 if (f < nf) {
@@ -860,6 +875,11 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
 #pragma unroll
             for (int j = 0; j < kMaxClusterBodies; j++)
                 if (j < k) S.st1(lay.K + r * k + j, Krow[j]);
+            if (phi) {
+                if (r == 0) phi[0] = ph;
+                else if (r == 1) phi[1] = ph;
+                else phi[2] = ph;
+            }
         } else {
             if (r == 0) kdq[0] = kd;
             else if (r == 1) kdq[1] = kd;
@@ -2255,6 +2275,156 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Steps either side of the path: Newton projection of the dependent coordinates of implicit
+// clusters onto phi(q) = 0 (GenericJoint.cpp:289-385 -- the reference does it per state with CasADi root
+// finding when it draws random states), and recovery of the spanning velocities / accelerations
+// qd_span = G yd, qdd_span = G ydd + g (ClusterJoint.cpp:55-58; the benchmarks' pinocchioBenchmark.cpp:168-176).
+// Not hot: one state per lane, inputs read straight from the batch arrays.
+// ---------------------------------------------------------------------------------------------
+template <class T, int N>
+__device__ __forceinline__ void project_cluster(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c, T *qrow,
+                                                int max_iter, T tol, bool &good)
+{
+    const ImpLayout<N> lay(c.slot_imp_fwd, c.slot_imp_bwd, c.k, c.rows);
+    const int k = c.k, rows = c.rows;
+    cptr<int32_t> ip = P.cints + c.iofs;
+    const int hdr0 = ip[0], n_ind = ip[1];
+    cptr<int32_t> dep = ip + 3 + n_ind;
+    cptr<int32_t> payload = dep + rows;
+    for (int i = 0; i < k; i++) S.st1(lay.qs + i, qrow[c.q_index + i]);
+    T nrm = 0;
+    bool active = true;  // this lane still iterates
+    for (int it = 0; it <= max_iter; it++) {
+        for (int i = 0; i < rows * k; i++) S.st1(lay.K + i, T(0));
+        T phi[3] = {0, 0, 0}, kdq[3];
+        if (c.cons_type == 0) loop_position_K<T, N>(P, S, c, lay, payload, hdr0, phi);
+        else trig_poly_eval<T, N>(P, S, c, lay, payload, true, kdq, phi);
+        const T n2 = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
+        if (active) nrm = n2;
+        active = active && !(n2 < T(1e-12)) && it < max_iter;  // NaN keeps iterating and fails at the end
+        if (!__any(active)) break;
+        T Kd[3][3], Kdi[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Kd[r][j] = (r < rows && j < rows) ? S.ld1(lay.K + r * k + dep[j]) : T(r == j);
+        inv_small(rows, Kd, Kdi);
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (j < rows) {
+                const T dq = -(Kdi[j][0] * phi[0] + Kdi[j][1] * phi[1] + Kdi[j][2] * phi[2]);
+                const T cur = S.ld1(lay.qs + dep[j]);
+                S.st1(lay.qs + dep[j], active ? cur + dq : cur);
+            }
+    }
+    if (!(nrm < tol)) good = false;
+    for (int i = 0; i < k; i++) qrow[c.q_index + i] = S.ld1(lay.qs + i);
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void project_kernel(DevPlan<T> DP, int n_clusters, T *__restrict__ q,
+                                                           int32_t *__restrict__ ok, size_t B, int max_iter, T tol,
+                                                           T *__restrict__ scratch)
+{
+    const Tables<T> P = make_tables(DP);
+    const int lane = threadIdx.x;
+    Slots<T> S;
+    S.lane = lane;
+    S.glb = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave +
+            (size_t)(P.nq + 2 * P.nv) * kWave;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + lane;
+        const bool in_range = r < B;
+        T *qrow = q + (in_range ? r : B - 1) * (size_t)P.nq;
+        // lanes past the end of the batch redo the last state (same values, same result)
+        bool good = true;
+        for (int ci = 0; ci < n_clusters; ci++) {
+            const ClusterRec c = load_rec(P.clusters + ci);
+            if (c.kind != CK_LOOP) continue;
+            switch (c.n) {
+                case 1: project_cluster<T, 1>(P, S, c, qrow, max_iter, tol, good); break;
+                case 2: project_cluster<T, 2>(P, S, c, qrow, max_iter, tol, good); break;
+                default: project_cluster<T, 3>(P, S, c, qrow, max_iter, tol, good); break;
+            }
+        }
+        if (ok && in_range) ok[r] = good ? 1 : 0;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void spanning_kernel(DevPlan<T> DP, int n_clusters, int n_span,
+                                                            const T *__restrict__ q, const T *__restrict__ qd,
+                                                            const T *__restrict__ ydd, T *__restrict__ qd_span,
+                                                            T *__restrict__ qdd_span, size_t B, T *__restrict__ scratch)
+{
+    const Tables<T> P = make_tables(DP);
+    const int lane = threadIdx.x;
+    Slots<T> S;
+    S.lane = lane;
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
+    S.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + lane;
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        stage_inputs(q, qd, ydd, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        Lane<T> L;
+        L.active = r < B;
+        L.in_q = slab + lane;
+        L.in_qd = slab + (size_t)P.nq * kWave + lane;
+        L.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+        L.out_rows = nullptr;
+        L.fext = nullptr;
+        L.lane = lane;
+        T *ov = qd_span ? qd_span + (L.active ? r : B - 1) * (size_t)n_span : nullptr;
+        T *oa = qdd_span + (L.active ? r : B - 1) * (size_t)n_span;
+        int at = 0;
+        for (int ci = 0; ci < n_clusters; ci++) {
+            const ClusterRec c = load_rec(P.clusters + ci);
+            if (c.kind == CK_FREE) {
+                for (int j = 0; j < 6; j++) {
+                    if (ov && L.active) ov[at + j] = L.qd(c.v_index + j);
+                    if (L.active) oa[at + j] = L.x(c.v_index + j);
+                }
+                at += 6;
+                continue;
+            }
+            if (c.kind == CK_LOOP) {
+                T yd3[3];
+                for (int a = 0; a < 3; a++) yd3[a] = a < c.n ? L.qd(c.v_index + a) : T(0);
+                if (c.n == 1) { const T yd1[1] = {yd3[0]}; eval_loop_constraint<T, 1>(P, S, c, L, yd1, true); }
+                else if (c.n == 2) { const T yd2[2] = {yd3[0], yd3[1]}; eval_loop_constraint<T, 2>(P, S, c, L, yd2, true); }
+                else eval_loop_constraint<T, 3>(P, S, c, L, yd3, true);
+            }
+            for (int i = 0; i < c.k; i++) {
+                T vs = 0, as = 0;
+                if (c.kind == CK_LOOP) {
+                    const int w = c.n + 1;  // row of G with g in the last column (ImpLayout)
+                    for (int a = 0; a < c.n; a++) {
+                        const T g = S.ld1(c.slot_imp_fwd + i * w + a);
+                        vs += g * L.qd(c.v_index + a);
+                        as += g * L.x(c.v_index + a);
+                    }
+                    as += S.ld1(c.slot_imp_fwd + i * w + c.n);
+                } else {
+                    const BodyRec b = load_rec(P.bodies + (c.first_body + i));
+                    cptr<T> G = P.consts + b.cofs + kBodyConstFixed;
+                    for (int a = 0; a < c.n; a++) {
+                        vs += G[a] * L.qd(c.v_index + a);
+                        as += G[a] * L.x(c.v_index + a);
+                    }
+                }
+                if (ov && L.active) ov[at + i] = vs;
+                if (L.active) oa[at + i] = as;
+            }
+            at += c.k;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers (called by capi.cpp)
 // ---------------------------------------------------------------------------------------------
 template <class T>
@@ -2277,6 +2447,33 @@ hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *yd
         hipLaunchKernelGGL((rnea_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
 }
+
+template <class T>
+hipError_t launch_project(const DevPlan<T> &P, int n_clusters, T *q, int32_t *ok, size_t B, int max_iter, T tol,
+                          T *scratch, int grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((project_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, n_clusters, q, ok, B,
+                       max_iter, tol, scratch);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_spanning(const DevPlan<T> &P, int n_clusters, int n_span, const T *q, const T *qd, const T *ydd,
+                           T *qd_span, T *qdd_span, size_t B, T *scratch, int grid, size_t lds_bytes,
+                           hipStream_t stream)
+{
+    hipLaunchKernelGGL((spanning_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, n_clusters, n_span, q, qd,
+                       ydd, qd_span, qdd_span, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_project<float>(const DevPlan<float> &, int, float *, int32_t *, size_t, int, float, float *,
+                                          int, size_t, hipStream_t);
+template hipError_t launch_project<double>(const DevPlan<double> &, int, double *, int32_t *, size_t, int, double,
+                                           double *, int, size_t, hipStream_t);
+template hipError_t launch_spanning<float>(const DevPlan<float> &, int, int, const float *, const float *,
+                                           const float *, float *, float *, size_t, float *, int, size_t, hipStream_t);
+template hipError_t launch_spanning<double>(const DevPlan<double> &, int, int, const double *, const double *,
+                                            const double *, double *, double *, size_t, double *, int, size_t,
+                                            hipStream_t);
 
 template hipError_t launch_aba<float>(const DevPlan<float> &, const float *, const float *, const float *, float *,
                                       size_t, float *, int, size_t, hipStream_t);
@@ -2302,7 +2499,11 @@ extern "C" int grbda_debug_profile(unsigned long long *out, int reset)
 hipError_t set_max_dynamic_lds()
 {
     const int maxb = 160 * 1024;
-    const void *fns[] = {reinterpret_cast<const void *>(&aba_kernel<float, false>),
+    const void *fns[] = {reinterpret_cast<const void *>(&project_kernel<float>),
+                         reinterpret_cast<const void *>(&project_kernel<double>),
+                         reinterpret_cast<const void *>(&spanning_kernel<float>),
+                         reinterpret_cast<const void *>(&spanning_kernel<double>),
+                         reinterpret_cast<const void *>(&aba_kernel<float, false>),
                          reinterpret_cast<const void *>(&aba_kernel<float, true>),
                          reinterpret_cast<const void *>(&aba_kernel<double, false>),
                          reinterpret_cast<const void *>(&aba_kernel<double, true>),

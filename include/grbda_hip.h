@@ -144,6 +144,29 @@ int grbda_fd_dqd_f64(const grbda_plan *plan, const double *q, const double *qd, 
 int grbda_fd_dqd_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, float *J,
                      size_t B, int device, void *stream);
 
+/* ---- steps either side of the path ------------------------------------------ */
+/* Newton projection of the DEPENDENT spanning coordinates of every implicit-loop cluster onto phi(q) = 0, in
+ * place, the independent ones held fixed: q_d <- q_d - K_d^-1 phi until |phi| < 1e-12 or max_iter steps; a
+ * state is reported valid (ok[b] = 1) when every cluster ends with |phi| < tol.  This is what the reference
+ * does per state when it draws random states of a GenericImplicit joint (GenericJoint.cpp:289-385 with
+ * Utilities.h:124-140; it accepts |phi| < 1e-8) and what a simulator calls against constraint drift.
+ * q: [B][nq] device array, updated; ok: [B] device int32 or NULL.  Models without implicit clusters: no-op. */
+int grbda_project_positions_f64(const grbda_plan *plan, double *q, int32_t *ok, size_t B, int max_iter, double tol,
+                                int device, void *stream);
+int grbda_project_positions_f32(const grbda_plan *plan, float *q, int32_t *ok, size_t B, int max_iter, double tol,
+                                int device, void *stream);
+
+/* Spanning-tree velocities and accelerations of every body joint from the independent ones:
+ * qd_span = G yd, qdd_span = G ydd + g (ClusterJoint.cpp:55-58, GenericJoint.cpp:57-90; what the reference's
+ * benchmarks do with the result of forwardDynamics, pinocchioBenchmark.cpp:168-176).  Order: clusters in model
+ * order, bodies by sub-index; the free base contributes its 6 components unchanged.
+ * qd_span (may be NULL), qdd_span: [B][n_span_vel] device arrays (grbda_plan_span_dims). */
+int grbda_plan_span_dims(const grbda_plan *plan, int *n_span_vel);
+int grbda_spanning_f64(const grbda_plan *plan, const double *q, const double *qd, const double *ydd, double *qd_span,
+                       double *qdd_span, size_t B, int device, void *stream);
+int grbda_spanning_f32(const grbda_plan *plan, const float *q, const float *qd, const float *ydd, float *qd_span,
+                       float *qdd_span, size_t B, int device, void *stream);
+
 /* ---- convenience: host pointers (single-state facade calls, small batches) ------------------ */
 /* allocate, copy in, run on `device`, copy out, synchronise.  Still the HIP path. */
 int grbda_aba_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau,

@@ -223,3 +223,83 @@ def test_derived_quantities_chunked_large_batch(gpu):
     H_small = plan.mass_matrix(tq[idx].contiguous())
     torch.cuda.synchronize()
     assert torch.equal(H[idx], H_small)
+
+
+# ---- steps either side of the path: Newton projection, spanning recovery ---------------------------------
+def _implicit_models():
+    from generalized_rbda_amd.states import parse_clusters
+
+    out = []
+    for name, blob in zoo().items():
+        if any(c[9] in (2, 3) for c in parse_clusters(blob)["clusters"]):
+            out.append((name, blob))
+    return out
+
+
+@pytest.mark.parametrize("name,blob", _implicit_models(), ids=[n for n, _ in _implicit_models()])
+def test_newton_projection_matches_oracle(name, blob, gpu):
+    """grbda_project_positions against the oracle's Newton iteration (GenericJoint.cpp:289-385): same
+    converged/failed verdicts, same projected coordinates, phi = 0 at the result."""
+    import torch
+    from generalized_rbda_amd.states import parse_clusters
+
+    plan = G.Plan(blob)
+    q, qd, _ = random_states(blob, 300, config_index=31)
+    q_ref, ok_ref = O.project_positions(blob, q)
+    tq = torch.as_tensor(q, dtype=torch.float64, device=gpu)
+    ok = plan.project_positions(tq).cpu().numpy()
+    got = tq.cpu().numpy()
+    assert ok_ref.any(), "no state converged in the oracle: useless test"
+    assert (ok == ok_ref).mean() > 0.98  # borderline states may flip with the rounding of the iteration
+    both = ok & ok_ref
+    # Newton far from a root is chaotic: a few states end on another (equally valid) branch of the linkage
+    # when the iteration is rounded differently; the converged ones are all checked against phi = 0 below
+    same = np.abs(got[both] - q_ref[both]).max(axis=1) < 1e-7
+    assert same.mean() > 0.95
+    m = parse_clusters(blob)
+    for ci, c in enumerate(m["clusters"]):
+        if c[9] not in (2, 3):
+            continue
+        (pc, fb, k, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = c
+        for b in np.flatnonzero(both)[:20]:
+            phi = O.cluster_constraint(blob, ci, got[b], np.zeros(m["nv"]), nsv, nvel, rows)[4]
+            assert np.abs(phi).max() < 1e-8
+    # a model without implicit clusters is left untouched
+    plain = zoo()["urdf_mini_cheetah"]
+    p2 = G.Plan(plain)
+    q2, _, _ = random_states(plain, 70, 3)
+    t2 = torch.as_tensor(q2, dtype=torch.float64, device=gpu)
+    assert bool(p2.project_positions(t2).all()) and torch.equal(t2.cpu(), torch.as_tensor(q2))
+
+
+@pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
+def test_spanning_recovery_matches_oracle(name, blob, gpu):
+    """qd_span = G yd, qdd_span = G ydd + g (ClusterJoint.cpp:55-58, GenericJoint.cpp:57-90)."""
+    import torch
+    from generalized_rbda_amd.states import parse_clusters
+
+    plan = G.Plan(blob)
+    B = 70
+    q, qd, ydd = valid_states(blob, B, config_index=32)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    v, a = plan.spanning(t(q), t(qd), t(ydd))
+    v, a = v.cpu().numpy(), a.cpu().numpy()
+    m = parse_clusters(blob)
+    dbls_off = 96 + 416 * m["nb"] + 64 * m["nc"] + 4 * (len(m["ints"]) + (len(m["ints"]) & 1))
+    at = 0
+    for ci, c in enumerate(m["clusters"]):
+        (pc, fb, k, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = c
+        if ctype == 1:  # free
+            assert np.array_equal(v[:, at:at + 6], qd[:, vi:vi + 6]) and np.array_equal(a[:, at:at + 6], ydd[:, vi:vi + 6])
+            at += 6
+            continue
+        for b in range(B):
+            if ctype == 0:
+                Gm = np.frombuffer(blob, dtype="<f8", count=nsv * nvel, offset=dbls_off + 8 * do).reshape(nsv, nvel)
+                g = np.zeros(nsv)
+            else:
+                Gm, g = O.cluster_constraint(blob, ci, q[b], qd[b], nsv, nvel, rows)[:2]
+            assert np.abs(v[b, at:at + nsv] - Gm @ qd[b, vi:vi + nvel]).max() < 1e-9
+            assert np.abs(a[b, at:at + nsv] - (Gm @ ydd[b, vi:vi + nvel] + g)).max() < 1e-8 * (1 + np.abs(g).max())
+        at += nsv
+    assert at == plan.n_span_vel
