@@ -804,13 +804,30 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
 {
     const int k = c.k;
     cptr<int32_t> ip = prog;
-    cptr<T> dp = P.consts + c.dofs;
+    const int n_args = *ip++;
+    cptr<T> ap = P.consts + c.dofs;          // per distinct argument: w[k], b
+    cptr<T> cp = ap + n_args * (k + 1);      // per term: coef
     // spanning positions / velocities once into registers (k <= 8, static indexing)
-    T qv[kMaxClusterBodies], qdv[kMaxClusterBodies];
+    T qv[kMaxClusterBodies];
 #pragma unroll
-    for (int j = 0; j < kMaxClusterBodies; j++) {
-        qv[j] = j < k ? S.ld1(lay.qs + j) : T(0);
-        qdv[j] = (!want_K && j < k) ? S.ld1(lay.qds + j) : T(0);
+    for (int j = 0; j < kMaxClusterBodies; j++)
+        qv[j] = j < k ? S.ld1((want_K ? lay.qs : lay.qds) + j) : T(0);
+    // every distinct argument once: first pass a = w.q + b with its sine and cosine, second pass w.qd
+    // (work space [a, sin a, cos a, w.qd] per argument, in place of the position loops' chain scratch)
+    for (int i = 0; i < n_args; i++) {
+        cptr<T> w = ap + i * (k + 1);
+        T a = want_K ? w[k] : T(0);
+#pragma unroll
+        for (int j = 0; j < kMaxClusterBodies; j++)
+            if (j < k) a += w[j] * qv[j];
+        if (want_K) {
+            T sn, cs;
+            sincos_t(a, &sn, &cs);
+            const T v3[3] = {a, sn, cs};
+            S.st(lay.chain + 4 * i, v3);
+        } else {
+            S.st1(lay.chain + 4 * i + 3, a);
+        }
     }
     for (int r = 0; r < c.rows; r++) {
         const int nt = *ip++;
@@ -820,28 +837,23 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
         T kd = 0, ph = 0;
         for (int t = 0; t < nt; t++) {
             const int nf = *ip++;
-            const T coef = *dp++;
+            const T coef = *cp++;
             T f0[4], f1[4], f2[4], ad[4];
             cptr<T> wv[4];
 #pragma unroll
             for (int f = 0; f < 4; f++) {
                 f0[f] = 1; f1[f] = 0; f2[f] = 0; ad[f] = 0;
-                wv[f] = dp;
+                wv[f] = ap;
                 if (f < nf) {
-                    const int type = *ip++;
-                    T a = dp[k], d = 0;
-#pragma unroll
-                    for (int j = 0; j < kMaxClusterBodies; j++)
-                        if (j < k) {
-                            const T w = dp[j];
-                            a += w * qv[j];
-                            d += w * qdv[j];
-                        }
-                    dp += k + 1;
-                    ad[f] = d;
-                    if (type == 1) { T sn, cs; sincos_t(a, &sn, &cs); f0[f] = sn; f1[f] = cs; f2[f] = -sn; }
-                    else if (type == 2) { T sn, cs; sincos_t(a, &sn, &cs); f0[f] = cs; f1[f] = -sn; f2[f] = -cs; }
-                    else { f0[f] = a; f1[f] = 1; f2[f] = 0; }
+                    const int type = ip[0], arg = ip[1];
+                    ip += 2;
+                    wv[f] = ap + arg * (k + 1);
+                    T v4[4];
+                    S.ld(lay.chain + 4 * arg, v4);  // a, sin a, cos a, w.qd (the last one only in the second pass)
+                    ad[f] = want_K ? T(0) : v4[3];
+                    if (type == 1) { f0[f] = v4[1]; f1[f] = v4[2]; f2[f] = -v4[1]; }
+                    else if (type == 2) { f0[f] = v4[2]; f1[f] = -v4[1]; f2[f] = -v4[2]; }
+                    else { f0[f] = v4[0]; f1[f] = 1; f2[f] = 0; }
                 }
             }
             if (phi) ph += coef * f0[0] * f0[1] * f0[2] * f0[3];

@@ -343,6 +343,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     }
 
     // ---- implicit-loop payload -------------------------------------------------------------------
+    std::vector<int> trig_args(nc, 0);  // distinct factor arguments of a trig-polynomial constraint
     for (int c = 0; c < nc; c++) {
         const grbda_desc_cluster &cl = m.clusters[c];
         if (clusters[c].kind != CK_LOOP) continue;
@@ -363,24 +364,47 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         P.cints.push_back(static_cast<int>(dep.size()));
         for (int i : dep) P.cints.push_back(i);
         if (trig) {
-            // per row: n_terms; per term: n_factors, type[n_factors] | doubles: coef, per factor w[k], b
+            // blob: per row n_terms; per term n_factors, type[n_factors] | doubles: coef, per factor w[k], b.
+            // plan: the DISTINCT factor arguments a = w.q + b first (the kernel evaluates each sin/cos once:
+            // the Tello hip differential has 4 distinct angles in 30 factors) --
+            //   ints:    n_args, per row: n_terms, per term: n_factors, (type, argument index)[n_factors]
+            //   doubles: per argument w[k], b; then per term coef
             const int32_t *tp = ip + k;
             const int32_t *tend = ip + cl.n_int;
+            std::vector<std::vector<double>> args;
+            std::vector<int32_t> prog;
+            std::vector<double> coefs;
             int nd = 0;
             for (int r = 0; r < cl.n_constraint_rows; r++) {
                 if (tp >= tend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly payload truncated", c);
                 const int nt = *tp++;
-                P.cints.push_back(nt);
+                prog.push_back(nt);
                 for (int t = 0; t < nt; t++) {
                     const int nf = *tp++;
                     if (nf < 0 || nf > 4) return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: a term has %d factors (max 4)", c, nf);
-                    P.cints.push_back(nf);
-                    for (int f = 0; f < nf; f++) P.cints.push_back(*tp++);
-                    nd += 1 + nf * (k + 1);
+                    if (nd + 1 + nf * (k + 1) > cl.n_dbl) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly doubles truncated", c);
+                    prog.push_back(nf);
+                    coefs.push_back(dp[nd++]);
+                    for (int f = 0; f < nf; f++) {
+                        const std::vector<double> a(dp + nd, dp + nd + k + 1);
+                        nd += k + 1;
+                        int idx = -1;
+                        for (size_t i = 0; i < args.size(); i++)
+                            if (args[i] == a) idx = static_cast<int>(i);
+                        if (idx < 0) {
+                            idx = static_cast<int>(args.size());
+                            args.push_back(a);
+                        }
+                        prog.push_back(*tp++);
+                        prog.push_back(idx);
+                    }
                 }
             }
-            if (nd > cl.n_dbl) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly doubles truncated", c);
-            for (int t = 0; t < nd; t++) P.consts.push_back(dp[t]);
+            trig_args[c] = static_cast<int>(args.size());
+            P.cints.push_back(trig_args[c]);
+            P.cints.insert(P.cints.end(), prog.begin(), prog.end());
+            for (const auto &a : args) P.consts.insert(P.consts.end(), a.begin(), a.end());
+            P.consts.insert(P.consts.end(), coefs.begin(), coefs.end());
         } else {
             const int n_loops = ip[0];
             const int32_t *lp = ip + 1 + k;
@@ -572,7 +596,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             cr.slot_imp_fwd = cr.slot_imp_bwd = cr.slot_imp_acc = -1;
             if (cr.kind == CK_LOOP) {
-                const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + 6 * cr.k;
+                // work space: [K rows*k][chain 6k | per distinct trig argument: a, sin a, cos a, w.qd]
+                const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + std::max(6 * cr.k, 4 * trig_args[c]);
                 // (kernels.hip, ImpLayout) kept block: forward step -> acceleration step; work space: forward step
                 objs.push_back({&cr.slot_imp_fwd, keep, 1, tF[c], tA[c], -1});
                 objs.push_back({&cr.slot_imp_bwd, tmp, 1, tF[c], tF[c], -1});
@@ -682,7 +707,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             cr.parent_slot_IA = cr.parent_slot_psi = cr.parent_slot_v3 = cr.parent_slot_a3 = -1;
             cr.carry_out = 0;
             if (cr.kind == CK_LOOP) {
-                const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + 6 * cr.k;
+                // work space: [K rows*k][chain 6k | per distinct trig argument: a, sin a, cos a, w.qd]
+                const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + std::max(6 * cr.k, 4 * trig_args[c]);
                 robjs.push_back({&cr.slot_imp_fwd, keep, 1, tRF[c], tRB[c], -1});
                 robjs.push_back({&cr.slot_imp_bwd, tmp, 1, tRF[c], tRF[c], -1});
             }
