@@ -73,10 +73,10 @@ struct grbda_plan {
     // launch shape per kernel, index = (rnea ? 2 : 0) + (f64 ? 1 : 0): LDS budget per wavefront for the
     // slot store, and wavefronts launched per CU (the grid is persistent)
     // (defaults from sweeps on MI355X over the MIT humanoid, Mini Cheetah and JVRC-1 at 4096 tiles: the f32
-    // RNEA kernel needs ~100 VGPRs and gains from 16 wavefronts per CU with 10 KiB each; the f64 kernels are
-    // register-bound to 4 (ABA) / 6-8 (RNEA) wavefronts per CU and take the LDS that leaves free)
-    int lds_bytes_per_wave[4] = {20480, 32768, 10240, 26624};
-    int waves_per_cu[4] = {8, 4, 16, 6};
+    // RNEA kernel needs ~100 VGPRs and gains from 16 wavefronts per CU with 10 KiB each; the f64 RNEA kernel is
+    // register-bound to 8 per CU and prefers 6 with more LDS)
+    int lds_bytes_per_wave[4] = {20480, 20480, 10240, 26624};
+    int waves_per_cu[4] = {8, 8, 16, 6};
 };
 
 namespace {

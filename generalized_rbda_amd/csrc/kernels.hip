@@ -37,6 +37,10 @@ namespace grbda_hip {
 #ifndef GRBDA_ABA32_WAVES
 #define GRBDA_ABA32_WAVES 2
 #endif
+// (f64: two per SIMD costs ~280 spilled registers and is still 4-12 % faster than one)
+#ifndef GRBDA_ABA64_WAVES
+#define GRBDA_ABA64_WAVES 2
+#endif
 
 #ifdef GRBDA_PROFILE
 __device__ unsigned long long grbda_prof[32];
@@ -2122,7 +2126,7 @@ __device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const Slots<T> 
     }
 
 template <class T, bool HAS_LOOP>
-__global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : 1)) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
+__global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : GRBDA_ABA64_WAVES)) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                      const T *__restrict__ qd, const T *__restrict__ tau,
                                                      T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
 {
