@@ -24,6 +24,7 @@ C_ABI_SYMBOLS = [
     "grbda_aba_host_f64", "grbda_rnea_host_f64", "grbda_time_kernel", "grbda_device_count",
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
     "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
+    "grbda_fd_dq_f64", "grbda_fd_dq_f32",
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
     "grbda_spanning_f64", "grbda_spanning_f32",
 ]
@@ -90,6 +91,9 @@ def lib() -> ctypes.CDLL:
         getattr(L, "grbda_fd_dqd_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                       c_int, c_void_p]
     L.grbda_plan_span_dims.argtypes = [c_void_p, POINTER(c_int)]
+    for sfx in ("f64", "f32"):
+        getattr(L, "grbda_fd_dq_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p,
+                                                     c_size_t, c_int, c_void_p]
     for sfx in ("f64", "f32"):
         getattr(L, "grbda_project_positions_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                                                  c_double, c_int, c_void_p]
@@ -278,6 +282,22 @@ class Plan:
         _check(fn(self._h, q.data_ptr(), qd.data_ptr(), ydd.data_ptr(), v.data_ptr(), a.data_ptr(), B,
                   q.device.index or 0, c_void_p(s.cuda_stream)))
         return v, a
+
+    def fd_dq(self, q, qd, tau, step: float = 1e-6, stream=None):
+        """d ydd / d q by central differences along the reference's tangent step (testHelpers.hpp:50-112),
+        [B, nv, nv]; not exact, unlike fd_dtau / fd_dqd."""
+        import torch
+
+        B = q.shape[0]
+        if not q.is_cuda or q.shape != (B, self.nq) or qd.shape != (B, self.nv) or tau.shape != (B, self.nv):
+            raise ValueError(f"expected device tensors q[B,{self.nq}], qd[B,{self.nv}], tau[B,{self.nv}]")
+        q, qd, tau = q.contiguous(), qd.contiguous(), tau.contiguous()
+        out = torch.empty((B, self.nv, self.nv), dtype=q.dtype, device=q.device)
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_fd_dq_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), qd.data_ptr(), tau.data_ptr(), step, out.data_ptr(), B,
+                  q.device.index or 0, c_void_p(s.cuda_stream)))
+        return out
 
     def time_kernel(self, which: str, q, qd, x, out, iters: int = 20, stream=None) -> float:
         """Average kernel duration in ms, hipEvents on the launch stream (grbda_time_kernel)."""

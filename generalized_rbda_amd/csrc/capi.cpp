@@ -44,6 +44,7 @@ struct DeviceTables {
     ClusterRec *rnea_clusters[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *cints = nullptr;
     int32_t *acc_k[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *dq_map = nullptr;  // per velocity index: (kind, position index, component), see grbda_fd_dq_*
     BodyRec *bodies[4] = {nullptr, nullptr, nullptr, nullptr};       // ABA slots
     BodyRec *rnea_bodies[4] = {nullptr, nullptr, nullptr, nullptr};  // RNEA slots
     double *consts64 = nullptr;
@@ -109,6 +110,27 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         (e = up(c32.data(), c32.size() * sizeof(float), (void **)&t.consts32)) != hipSuccess ||
         (e = up(h.cints.data(), h.cints.size() * sizeof(int32_t), (void **)&t.cints)) != hipSuccess)
         return hip_err(e, "plan upload");
+    {
+        // tangent-space perturbation of the positions (UnitTests/testHelpers.hpp:50-112): kind 0 q[i] += d,
+        // 1 free-base rotation (quat += quat x (0, d e_a) / 2), 2 free-base translation (pos += R^T d e_a),
+        // 3 not differentiable here (implicit-loop cluster, roll-pitch-yaw base)
+        std::vector<int32_t> map(static_cast<size_t>(h.nv) * 3, 0);
+        for (const ClusterRec &c : h.lay64.clusters)
+            for (int a = 0; a < c.n; a++) {
+                int32_t *e = &map[static_cast<size_t>(c.v_index + a) * 3];
+                if (c.kind == CK_FREE) {
+                    e[0] = h.ori_repr == 0 ? (a < 3 ? 1 : 2) : 3;
+                    e[1] = c.q_index;
+                    e[2] = a % 3;
+                } else if (c.kind == CK_LOOP) {
+                    e[0] = 3;
+                } else {
+                    e[0] = 0;
+                    e[1] = c.q_index + a;
+                }
+            }
+        if ((e = up(map.data(), map.size() * sizeof(int32_t), (void **)&t.dq_map)) != hipSuccess) return hip_err(e, "plan upload");
+    }
     for (int w = 0; w < 4; w++) {
         const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
         if ((e = up(L.clusters.data(), L.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters[w])) != hipSuccess ||
@@ -319,13 +341,43 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
 }
 
 // ---- derived quantities: expanded batches over the two kernels (include/grbda_hip.h) ---------------------
-enum DerivedMode { DM_BIAS = 0, DM_MASS = 1, DM_DTAU = 2, DM_DQD = 3 };
+enum DerivedMode { DM_BIAS = 0, DM_MASS = 1, DM_DTAU = 2, DM_DQD = 3, DM_DQ = 4 };
 
 // row (b, j) of the expanded batch: state b with the j-th unit vector (or none) applied
+// position col of state q0 after the tangent step `d` along velocity coordinate k (testHelpers.hpp:50-112)
+template <class T>
+__device__ T perturbed_position(const T *q0, int col, const int32_t *map, int k, T d)
+{
+    const int kind = map[3 * k], qi = map[3 * k + 1], a = map[3 * k + 2];
+    const T x = q0[col];
+    if (kind == 0) return col == qi ? x + d : x;
+    if (kind == 1) {  // quat (scalar first, positions qi+3 .. qi+6) += quat x (0, d e_a) / 2
+        if (col < qi + 3 || col > qi + 6) return x;
+        const T w = q0[qi + 3], v[3] = {q0[qi + 4], q0[qi + 5], q0[qi + 6]};
+        const int i = col - qi - 3;
+        if (i == 0) return x - T(0.5) * d * v[a];
+        const int j = i - 1;  // vector component: w e_a + v x e_a
+        T p = j == a ? w : T(0);
+        if (j == (a + 1) % 3) p += v[(a + 2) % 3];   // (v x e_a)_{a+1} = v_{a+2}
+        if (j == (a + 2) % 3) p -= v[(a + 1) % 3];   // (v x e_a)_{a+2} = -v_{a+1}
+        return x + T(0.5) * d * p;
+    }
+    if (kind == 2) {  // pos += R(quat)^T d e_a: component i gets R[a][i] (OrientationTools.h:251-269)
+        if (col < qi || col > qi + 2) return x;
+        const T e0 = q0[qi + 3], e1 = q0[qi + 4], e2 = q0[qi + 5], e3 = q0[qi + 6];
+        const T M[9] = {1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2),
+                        2 * (e1 * e2 + e0 * e3), 1 - 2 * (e1 * e1 + e3 * e3), 2 * (e2 * e3 - e0 * e1),
+                        2 * (e1 * e3 - e0 * e2), 2 * (e2 * e3 + e0 * e1), 1 - 2 * (e1 * e1 + e2 * e2)};
+        const int i = col - qi;
+        return x + d * M[3 * i + a];  // R = M^T: R[a][i] = M[i][a]
+    }
+    return x;
+}
+
 template <class T>
 __global__ void expand_kernel(int mode, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ tau,
                               int nq, int nv, int R, size_t nb, T *__restrict__ qx, T *__restrict__ qdx,
-                              T *__restrict__ xx)
+                              T *__restrict__ xx, const int32_t *__restrict__ dq_map, T step)
 {
     const size_t rows = nb * (size_t)R;
     const int w = nq + 2 * nv;
@@ -336,18 +388,19 @@ __global__ void expand_kernel(int mode, const T *__restrict__ q, const T *__rest
         const size_t b = row / R;
         const int j = (int)(row % R);
         if (col < nq) {
-            qx[row * nq + col] = q[b * nq + col];
+            qx[row * nq + col] = mode == DM_DQ ? perturbed_position(q + b * nq, col, dq_map, j >> 1, (j & 1) ? -step : step)
+                                               : q[b * nq + col];
         } else if (col < nq + nv) {
             const int k = col - nq;
             T v = 0;
-            if (mode == DM_BIAS) v = qd[b * nv + k];
+            if (mode == DM_BIAS || mode == DM_DQ) v = qd[b * nv + k];
             else if (mode == DM_DQD) v = qd[b * nv + k] + ((j >> 1) == k ? ((j & 1) ? T(-1) : T(1)) : T(0));
             qdx[row * nv + k] = v;
         } else {
             const int k = col - nq - nv;
             T v = 0;
             if (mode == DM_MASS || mode == DM_DTAU) v = (j == k) ? T(1) : T(0);
-            else if (mode == DM_DQD) v = tau[b * nv + k];
+            else if (mode == DM_DQD || mode == DM_DQ) v = tau[b * nv + k];
             xx[row * nv + k] = v;
         }
     }
@@ -355,7 +408,8 @@ __global__ void expand_kernel(int mode, const T *__restrict__ q, const T *__rest
 
 // out[b][i][j] from the kernel results r[(b, j)][i]
 template <class T>
-__global__ void combine_kernel(int mode, const T *__restrict__ r, int nv, int R, size_t nb, T *__restrict__ out)
+__global__ void combine_kernel(int mode, const T *__restrict__ r, int nv, int R, size_t nb, T *__restrict__ out,
+                               T step)
 {
     const size_t total = nb * (size_t)nv * nv;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -363,7 +417,8 @@ __global__ void combine_kernel(int mode, const T *__restrict__ r, int nv, int R,
         const int i = (int)((t / nv) % nv), j = (int)(t % nv);
         const T *rb = r + b * (size_t)R * nv;
         T v;
-        if (mode == DM_DQD) v = T(0.5) * (rb[(size_t)(2 * j) * nv + i] - rb[(size_t)(2 * j + 1) * nv + i]);
+        if (mode == DM_DQD || mode == DM_DQ)
+            v = (rb[(size_t)(2 * j) * nv + i] - rb[(size_t)(2 * j + 1) * nv + i]) / (T(2) * (mode == DM_DQ ? step : T(1)));
         else v = rb[(size_t)j * nv + i] - rb[(size_t)nv * nv + i];
         out[t] = v;
     }
@@ -371,16 +426,22 @@ __global__ void combine_kernel(int mode, const T *__restrict__ r, int nv, int R,
 
 template <class T>
 int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau, const T *f_ext, T *out, size_t B,
-            int device, void *stream)
+            int device, void *stream, double step = 1.0)
 {
     if (!p || !q || !out) return set_err(GRBDA_EINVAL, "null argument");
-    if ((mode == DM_BIAS || mode == DM_DQD) && !qd) return set_err(GRBDA_EINVAL, "null argument");
-    if (mode == DM_DQD && !tau) return set_err(GRBDA_EINVAL, "null argument");
+    if ((mode == DM_BIAS || mode == DM_DQD || mode == DM_DQ) && !qd) return set_err(GRBDA_EINVAL, "null argument");
+    if ((mode == DM_DQD || mode == DM_DQ) && !tau) return set_err(GRBDA_EINVAL, "null argument");
+    if (mode == DM_DQ) {
+        if (!(step > 0)) return set_err(GRBDA_EINVAL, "step must be positive");
+        for (const ClusterRec &c : p->host.lay64.clusters)
+            if (c.kind == CK_LOOP || (c.kind == CK_FREE && p->host.ori_repr != 0))
+                return set_err(GRBDA_EUNSUPPORTED, "position derivatives: implicit-loop clusters and roll-pitch-yaw bases are not covered");
+    }
     if (B == 0) return GRBDA_OK;
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const int nq = p->host.nq, nv = p->host.nv;
-    const int R = mode == DM_BIAS ? 1 : (mode == DM_DQD ? 2 * nv : nv + 1);
+    const int R = mode == DM_BIAS ? 1 : ((mode == DM_DQD || mode == DM_DQ) ? 2 * nv : nv + 1);
     const size_t row_scalars = static_cast<size_t>(nq) + 3 * static_cast<size_t>(nv);  // q, qd, x, result
     size_t chunk = (256u << 20) / (row_scalars * sizeof(T) * static_cast<size_t>(R));
     if (chunk < 1) chunk = 1;
@@ -413,7 +474,8 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
         const size_t total = nrows * static_cast<size_t>(nq + 2 * nv);
         int blocks = static_cast<int>((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
         hipLaunchKernelGGL((expand_kernel<T>), dim3(blocks), dim3(256), 0, hs, mode, q + b0 * nq,
-                           qd ? qd + b0 * nv : nullptr, tau ? tau + b0 * nv : nullptr, nq, nv, R, nb, qx, qdx, xx);
+                           qd ? qd + b0 * nv : nullptr, tau ? tau + b0 * nv : nullptr, nq, nv, R, nb, qx, qdx, xx, t->dq_map,
+                           static_cast<T>(step));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_err(e, "expand launch");
         const T *fe = (mode == DM_BIAS && f_ext) ? f_ext + b0 * static_cast<size_t>(p->host.n_bodies) * 6 : nullptr;
@@ -423,7 +485,7 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
             const size_t tot2 = nb * static_cast<size_t>(nv) * nv;
             blocks = static_cast<int>((tot2 + 255) / 256 < 65535 ? (tot2 + 255) / 256 : 65535);
             hipLaunchKernelGGL((combine_kernel<T>), dim3(blocks), dim3(256), 0, hs, mode, res, nv, R, nb,
-                               out + b0 * static_cast<size_t>(nv) * nv);
+                               out + b0 * static_cast<size_t>(nv) * nv, static_cast<T>(step));
             if ((e = hipGetLastError()) != hipSuccess) return hip_err(e, "combine launch");
         }
     }
@@ -516,7 +578,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map);
         for (int w = 0; w < 4; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work})
@@ -638,6 +700,16 @@ int grbda_fd_dqd_f32(const grbda_plan *p, const float *q, const float *qd, const
     return derived<float>(p, DM_DQD, q, qd, tau, nullptr, J, B, device, stream);
 }
 
+int grbda_fd_dq_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, double step, double *J,
+                    size_t B, int device, void *stream)
+{
+    return derived<double>(p, DM_DQ, q, qd, tau, nullptr, J, B, device, stream, step);
+}
+int grbda_fd_dq_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, double step, float *J,
+                    size_t B, int device, void *stream)
+{
+    return derived<float>(p, DM_DQ, q, qd, tau, nullptr, J, B, device, stream, step);
+}
 int grbda_plan_span_dims(const grbda_plan *p, int *n_span_vel)
 {
     if (!p) return set_err(GRBDA_EINVAL, "null plan");

@@ -130,6 +130,12 @@ int grbda_rnea_f32(const grbda_plan *plan, const float *q, const float *qd, cons
  * grbda_fd_dqd_*      d ydd / d qd, column j =                     central difference with unit step, exact
  *                     (ABA(qd + e_j) - ABA(qd - e_j)) / 2          because ABA is quadratic in qd
  *                     out[B][nv][nv]                               (testRigidBodyDynamicsAlgosDerivatives.cpp:309-380)
+ * grbda_fd_dq_*       d ydd / d q along the tangent step the         central difference with the caller's step: NOT
+ *                     reference's derivative test uses                exact (truncation + rounding, the reference
+ *                     (testHelpers.hpp:50-112: q_i += d; free base    uses step 1e-8 in fp64 and accepts 2e-5,
+ *                     pos += R^T d, quat += quat x (0, d) / 2):       testRigidBodyDynamicsAlgosDerivatives.cpp:
+ *                     column j = (ABA(q + h e_j) - ABA(q - h e_j))    309-335).  GRBDA_EUNSUPPORTED for models with
+ *                     / (2 h), out[B][nv][nv]                         implicit-loop clusters or a roll-pitch-yaw base.
  */
 int grbda_bias_f64(const grbda_plan *plan, const double *q, const double *qd, const double *f_ext, double *out,
                    size_t B, int device, void *stream);
@@ -143,6 +149,10 @@ int grbda_fd_dqd_f64(const grbda_plan *plan, const double *q, const double *qd, 
                      size_t B, int device, void *stream);
 int grbda_fd_dqd_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, float *J,
                      size_t B, int device, void *stream);
+int grbda_fd_dq_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau, double step,
+                    double *J, size_t B, int device, void *stream);
+int grbda_fd_dq_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, double step, float *J,
+                    size_t B, int device, void *stream);
 
 /* ---- steps either side of the path ------------------------------------------ */
 /* Newton projection of the DEPENDENT spanning coordinates of every implicit-loop cluster onto phi(q) = 0, in

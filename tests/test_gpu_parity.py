@@ -303,3 +303,66 @@ def test_spanning_recovery_matches_oracle(name, blob, gpu):
             assert np.abs(a[b, at:at + nsv] - (Gm @ ydd[b, vi:vi + nvel] + g)).max() < 1e-8 * (1 + np.abs(g).max())
         at += nsv
     assert at == plan.n_span_vel
+
+
+def _reference_plus(m, q, k, d):
+    """TestHelpers::plus (UnitTests/testHelpers.hpp:50-112): state q after the tangent step d along velocity
+    coordinate k.  Free base: positions [pos 3, quat 4 scalar first], velocities [angular 3, linear 3]."""
+    q = q.copy()
+    for c in m["clusters"]:
+        (pc, fb, kk, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = c
+        if not (vi <= k < vi + nvel):
+            continue
+        a = k - vi
+        if ctype == 1:
+            quat = q[qi + 3: qi + 7].copy()
+            e0, e1, e2, e3 = quat
+            M = np.array([[1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2)],
+                          [2 * (e1 * e2 + e0 * e3), 1 - 2 * (e1 * e1 + e3 * e3), 2 * (e2 * e3 - e0 * e1)],
+                          [2 * (e1 * e3 - e0 * e2), 2 * (e2 * e3 + e0 * e1), 1 - 2 * (e1 * e1 + e2 * e2)]])
+            R = M.T  # quaternionToRotationMatrix transposes (OrientationTools.h:251-269)
+            if a < 3:
+                dv = np.zeros(3)
+                dv[a] = d
+                w, v = quat[0], quat[1:]
+                prod = np.concatenate([[-v @ dv], w * dv + np.cross(v, dv)])  # quat x (0, dv)
+                q[qi + 3: qi + 7] = quat + 0.5 * prod
+            else:
+                dp = np.zeros(3)
+                dp[a - 3] = d
+                q[qi: qi + 3] += R.T @ dp
+        else:
+            q[qi + a] += d
+    return q
+
+
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "rev_rotor_chain_4", "tree_mixed_float", "tree_triple_fixed"])
+def test_position_derivative_matches_oracle_differences(name, gpu):
+    """grbda_fd_dq: the same central differences, along the reference's tangent step, taken with the oracle."""
+    import torch
+    from generalized_rbda_amd.states import parse_clusters
+
+    z = zoo()
+    if name not in z:
+        pytest.skip(f"{name} not in the zoo")
+    blob = z[name]
+    plan = G.Plan(blob)
+    m = parse_clusters(blob)
+    B, h = 2, 1e-5
+    q, qd, tau = valid_states(blob, B, config_index=41)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    J = plan.fd_dq(t(q), t(qd), t(tau), step=h).cpu().numpy()
+    nv = plan.nv
+    J_ref = np.empty((B, nv, nv))
+    for b in range(B):
+        for k in range(nv):
+            qp = _reference_plus(m, q[b], k, +h)[None]
+            qm = _reference_plus(m, q[b], k, -h)[None]
+            J_ref[b, :, k] = (O.forward_dynamics(blob, qp, qd[b:b + 1], tau[b:b + 1])[0]
+                              - O.forward_dynamics(blob, qm, qd[b:b + 1], tau[b:b + 1])[0]) / (2 * h)
+    assert np.abs(J - J_ref).max() / (1.0 + np.abs(J_ref).max()) < 1e-5
+    # implicit-loop models are refused, not approximated
+    loop = G.Plan(z["urdf_four_bar"])
+    ql, qdl, tl = valid_states(z["urdf_four_bar"], 2, config_index=41)
+    with pytest.raises(G.GrbdaError):
+        loop.fd_dq(t(ql), t(qdl), t(tl))
