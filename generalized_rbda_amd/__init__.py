@@ -24,7 +24,8 @@ C_ABI_SYMBOLS = [
     "grbda_aba_host_f64", "grbda_rnea_host_f64", "grbda_time_kernel", "grbda_device_count",
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
     "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
-    "grbda_fd_dq_f64", "grbda_fd_dq_f32",
+    "grbda_fd_dq_f64", "grbda_fd_dq_f32", "grbda_body_poses_f64", "grbda_body_poses_f32",
+    "grbda_apply_test_force_f64", "grbda_apply_test_force_f32",
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
     "grbda_spanning_f64", "grbda_spanning_f32",
 ]
@@ -91,6 +92,10 @@ def lib() -> ctypes.CDLL:
         getattr(L, "grbda_fd_dqd_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                       c_int, c_void_p]
     L.grbda_plan_span_dims.argtypes = [c_void_p, POINTER(c_int)]
+    for sfx in ("f64", "f32"):
+        getattr(L, "grbda_body_poses_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        getattr(L, "grbda_apply_test_force_" + sfx).argtypes = [c_void_p, c_void_p, c_int, POINTER(c_double), c_void_p,
+                                                                c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     for sfx in ("f64", "f32"):
         getattr(L, "grbda_fd_dq_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p,
                                                      c_size_t, c_int, c_void_p]
@@ -282,6 +287,39 @@ class Plan:
         _check(fn(self._h, q.data_ptr(), qd.data_ptr(), ydd.data_ptr(), v.data_ptr(), a.data_ptr(), B,
                   q.device.index or 0, c_void_p(s.cuda_stream)))
         return v, a
+
+    # ---- contact side ---------------------------------------------------------------------------------
+    def body_poses(self, q, stream=None):
+        """Absolute transforms world -> body (TreeNode::Xa_): [B, n_bodies, 12] = E (9, row-major) then r (3)."""
+        import torch
+
+        B = q.shape[0]
+        if not q.is_cuda or q.shape != (B, self.nq):
+            raise ValueError(f"expected a device tensor q[B,{self.nq}]")
+        q = q.contiguous()
+        out = torch.empty((B, self.n_bodies, 12), dtype=q.dtype, device=q.device)
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_body_poses_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), out.data_ptr(), B, q.device.index or 0, c_void_p(s.cuda_stream)))
+        return out
+
+    def apply_test_force(self, q, body: int, offset, force, stream=None):
+        """Batched ClusterTreeModel::applyTestForce: world-frame force[B,3] at the body-fixed point `offset` of
+        `body`; returns (lambda_inv[B], dstate[B,nv]) = (f^T J H^-1 J^T f, H^-1 J^T f)."""
+        import torch
+
+        B = q.shape[0]
+        if not q.is_cuda or q.shape != (B, self.nq) or force.shape != (B, 3) or force.dtype != q.dtype:
+            raise ValueError(f"expected device tensors q[B,{self.nq}], force[B,3] of one dtype")
+        q, force = q.contiguous(), force.contiguous()
+        lam = torch.empty((B,), dtype=q.dtype, device=q.device)
+        ds = torch.empty((B, self.nv), dtype=q.dtype, device=q.device)
+        off = (c_double * 3)(*[float(x) for x in offset])
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_apply_test_force_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), body, off, force.data_ptr(), lam.data_ptr(), ds.data_ptr(), B,
+                  q.device.index or 0, c_void_p(s.cuda_stream)))
+        return lam, ds
 
     def fd_dq(self, q, qd, tau, step: float = 1e-6, stream=None):
         """d ydd / d q by central differences along the reference's tangent step (testHelpers.hpp:50-112),

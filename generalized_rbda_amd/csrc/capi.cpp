@@ -340,6 +340,118 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
     return e == hipSuccess ? GRBDA_OK : hip_err(e, "spanning launch");
 }
 
+// ---- contact side: body poses, test force (include/grbda_hip.h) ---------------------------------------------
+template <class T>
+int poses(const grbda_plan *p, const T *q, T *Xa, size_t B, int device, void *stream)
+{
+    if (!p || !q || !Xa) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    const size_t g = n_tiles < static_cast<size_t>(t->n_cu) * 8 ? n_tiles : static_cast<size_t>(t->n_cu) * 8;
+    hipError_t e = launch_poses<T>(d, p->host.n_clusters, q, Xa, B, static_cast<int>(g), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "poses launch");
+}
+
+// world wrench (about the world origin) of a Cartesian force at a point fixed in body `body`
+template <class T>
+__global__ void wrench_kernel(const T *__restrict__ Xa, const T *__restrict__ force, int n_bodies, int body, T ox, T oy,
+                              T oz, size_t nb, T *__restrict__ fext)
+{
+    for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < nb; b += (size_t)gridDim.x * blockDim.x) {
+        const T *X = Xa + (b * n_bodies + body) * 12;
+        // p = r + E^T offset (E: world -> body)
+        const T px = X[9] + X[0] * ox + X[3] * oy + X[6] * oz;
+        const T py = X[10] + X[1] * ox + X[4] * oy + X[7] * oz;
+        const T pz = X[11] + X[2] * ox + X[5] * oy + X[8] * oz;
+        const T fx = force[3 * b], fy = force[3 * b + 1], fz = force[3 * b + 2];
+        T *w = fext + b * (size_t)n_bodies * 6;
+        for (int i = 0; i < n_bodies * 6; i++) w[i] = 0;
+        w += (size_t)body * 6;
+        w[0] = py * fz - pz * fy;
+        w[1] = pz * fx - px * fz;
+        w[2] = px * fy - py * fx;
+        w[3] = fx;
+        w[4] = fy;
+        w[5] = fz;
+    }
+}
+// dstate = a1 - a0 ;  lambda_inv = (t0 - t1) . dstate
+template <class T>
+__global__ void test_force_finish(const T *__restrict__ a1, const T *__restrict__ a0, const T *__restrict__ t1,
+                                  const T *__restrict__ t0, int nv, size_t nb, T *__restrict__ dstate,
+                                  T *__restrict__ lambda_inv)
+{
+    for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < nb; b += (size_t)gridDim.x * blockDim.x) {
+        T s = 0;
+        for (int i = 0; i < nv; i++) {
+            const T d = a1[b * nv + i] - a0[b * nv + i];
+            dstate[b * nv + i] = d;
+            s += (t0[b * nv + i] - t1[b * nv + i]) * d;
+        }
+        lambda_inv[b] = s;
+    }
+}
+
+template <class T>
+int test_force(const grbda_plan *p, const T *q, int body, const double *offset, const T *force, T *lambda_inv, T *dstate,
+               size_t B, int device, void *stream)
+{
+    if (!p || !q || !offset || !force || !lambda_inv || !dstate) return set_err(GRBDA_EINVAL, "null argument");
+    if (body < 0 || body >= p->host.n_bodies) return set_err(GRBDA_EINVAL, "body index out of range");
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv, nbod = p->host.n_bodies;
+    const size_t per_state = nbod * 18 + 5 * nv;  // poses, wrenches, zeros, four results
+    size_t chunk = (256u << 20) / (per_state * sizeof(T));
+    if (chunk < 1) chunk = 1;
+    if (chunk > B) chunk = B;
+    void *wptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        Scratch &s = p->work[{device, stream}];
+        const size_t need = chunk * per_state * sizeof(T) + 256;
+        if (s.bytes < need) {
+            hipError_t e;
+            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+            s.ptr = nullptr;
+            s.bytes = 0;
+            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+            s.bytes = need;
+        }
+        wptr = s.ptr;
+    }
+    T *Xa = static_cast<T *>(wptr);
+    T *fext = Xa + chunk * nbod * 12;
+    T *zero = fext + chunk * nbod * 6;
+    T *a1 = zero + chunk * nv, *a0 = a1 + chunk * nv, *t1 = a0 + chunk * nv, *t0 = t1 + chunk * nv;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(zero, 0, chunk * nv * sizeof(T), hs);
+    if (e != hipSuccess) return hip_err(e, "hipMemsetAsync");
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const T *qc = q + b0 * nq;
+        if (int rc = poses<T>(p, qc, Xa, nb, device, stream)) return rc;
+        const int blocks = static_cast<int>((nb + 255) / 256 < 65535 ? (nb + 255) / 256 : 65535);
+        hipLaunchKernelGGL((wrench_kernel<T>), dim3(blocks), dim3(256), 0, hs, Xa, force + 3 * b0, static_cast<int>(nbod),
+                           body, static_cast<T>(offset[0]), static_cast<T>(offset[1]), static_cast<T>(offset[2]), nb, fext);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_err(e, "wrench launch");
+        int rc;
+        if ((rc = run<T>(p, false, qc, zero, zero, fext, a1, nb, device, stream)) ||
+            (rc = run<T>(p, false, qc, zero, zero, nullptr, a0, nb, device, stream)) ||
+            (rc = run<T>(p, true, qc, zero, zero, fext, t1, nb, device, stream)) ||
+            (rc = run<T>(p, true, qc, zero, zero, nullptr, t0, nb, device, stream)))
+            return rc;
+        hipLaunchKernelGGL((test_force_finish<T>), dim3(blocks), dim3(256), 0, hs, a1, a0, t1, t0, static_cast<int>(nv), nb,
+                           dstate + b0 * nv, lambda_inv + b0);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_err(e, "finish launch");
+    }
+    return GRBDA_OK;
+}
+
 // ---- derived quantities: expanded batches over the two kernels (include/grbda_hip.h) ---------------------
 enum DerivedMode { DM_BIAS = 0, DM_MASS = 1, DM_DTAU = 2, DM_DQD = 3, DM_DQ = 4 };
 
@@ -709,6 +821,24 @@ int grbda_fd_dq_f32(const grbda_plan *p, const float *q, const float *qd, const 
                     size_t B, int device, void *stream)
 {
     return derived<float>(p, DM_DQ, q, qd, tau, nullptr, J, B, device, stream, step);
+}
+int grbda_body_poses_f64(const grbda_plan *p, const double *q, double *Xa, size_t B, int device, void *stream)
+{
+    return poses<double>(p, q, Xa, B, device, stream);
+}
+int grbda_body_poses_f32(const grbda_plan *p, const float *q, float *Xa, size_t B, int device, void *stream)
+{
+    return poses<float>(p, q, Xa, B, device, stream);
+}
+int grbda_apply_test_force_f64(const grbda_plan *p, const double *q, int body, const double offset[3], const double *force,
+                               double *lambda_inv, double *dstate, size_t B, int device, void *stream)
+{
+    return test_force<double>(p, q, body, offset, force, lambda_inv, dstate, B, device, stream);
+}
+int grbda_apply_test_force_f32(const grbda_plan *p, const float *q, int body, const double offset[3], const float *force,
+                               float *lambda_inv, float *dstate, size_t B, int device, void *stream)
+{
+    return test_force<float>(p, q, body, offset, force, lambda_inv, dstate, B, device, stream);
 }
 int grbda_plan_span_dims(const grbda_plan *p, int *n_span_vel)
 {

@@ -38,6 +38,8 @@ template <class T>
 hipError_t launch_spanning(const DevPlan<T> &P, int n_clusters, int n_span, const T *q, const T *qd, const T *ydd,
                            T *qd_span, T *qdd_span, size_t B, T *scratch, int grid, size_t lds_bytes,
                            hipStream_t stream);
+template <class T>
+hipError_t launch_poses(const DevPlan<T> &P, int n_clusters, const T *q, T *Xa, size_t B, int grid, hipStream_t stream);
 hipError_t set_max_dynamic_lds();
 
 }  // namespace grbda_hip

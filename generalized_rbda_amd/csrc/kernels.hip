@@ -2368,6 +2368,78 @@ __global__ __launch_bounds__(kWave, 1) void project_kernel(DevPlan<T> DP, int n_
     }
 }
 
+// Absolute transforms world -> body of every body, (E 9 row-major, r 3) per body: TreeNode::Xa_
+// (TreeModel.cpp:20-27), the input of the reference's contact-point kinematics (TreeModel.cpp:59-113).
+// The poses are composed in the plan's canonical body frames and converted to the reference's frames at the
+// end (BodyRec::canon_axis).
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void poses_kernel(DevPlan<T> DP, int n_clusters, const T *__restrict__ q,
+                                                         T *__restrict__ Xa, size_t B)
+{
+    const Tables<T> P = make_tables(DP);
+    const int nb = DP.n_bodies;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + threadIdx.x;
+        if (r >= B) continue;
+        const T *qr = q + r * (size_t)P.nq;
+        T *out = Xa + r * (size_t)nb * 12;
+        for (int ci = 0; ci < n_clusters; ci++) {
+            const ClusterRec c = load_rec(P.clusters + ci);
+            for (int i = 0; i < c.k; i++) {
+                const int gb = c.first_body + i;
+                const BodyRec b = load_rec(P.bodies + gb);
+                T E[9], rr[3];
+                if (c.kind == CK_FREE) {
+                    T o[4];
+                    const int nori = P.ori_repr == 0 ? 4 : 3;
+                    for (int j = 0; j < 4; j++) o[j] = j < nori ? qr[c.q_index + 3 + j] : T(0);
+                    free_rotation(P.ori_repr, o, E);
+                    for (int j = 0; j < 3; j++) rr[j] = qr[c.q_index + j];
+                } else {
+                    cptr<T> C = P.consts + b.cofs;
+                    T qi = 0;
+                    if (c.kind == CK_LOOP) {
+                        qi = qr[c.q_index + i];
+                    } else {
+                        for (int a = 0; a < c.n; a++) qi += C[kBodyConstFixed + a] * qr[c.q_index + a];
+                    }
+                    T sn, cs, El[9];
+                    sincos_t(qi, &sn, &cs);
+                    build_E(b.axis, sn, cs, C, El);
+                    if (b.parent >= 0) {  // Xa = X * Xa_parent: E = E_l E_p, r = r_p + E_p^T r_l
+                        const T *Xp = out + (size_t)b.parent * 12;
+                        for (int u = 0; u < 3; u++)
+                            for (int w = 0; w < 3; w++)
+                                E[3 * u + w] = El[3 * u] * Xp[w] + El[3 * u + 1] * Xp[3 + w] + El[3 * u + 2] * Xp[6 + w];
+                        for (int u = 0; u < 3; u++) rr[u] = Xp[9 + u] + Xp[u] * C[9] + Xp[3 + u] * C[10] + Xp[6 + u] * C[11];
+                    } else {
+                        for (int u = 0; u < 9; u++) E[u] = El[u];
+                        for (int u = 0; u < 3; u++) rr[u] = C[9 + u];
+                    }
+                }
+                for (int u = 0; u < 9; u++) out[(size_t)gb * 12 + u] = E[u];
+                for (int u = 0; u < 3; u++) out[(size_t)gb * 12 + 9 + u] = rr[u];
+            }
+        }
+        // back to the reference's body frames: E_ref = Rc^T E, Rc = the cyclic permutation taking the axis to z
+        for (int gb = 0; gb < nb; gb++) {
+            const BodyRec b = load_rec(P.bodies + gb);
+            if (b.canon_axis == 2) continue;
+            T *e = out + (size_t)gb * 12;
+            T E[9];
+            for (int u = 0; u < 9; u++) E[u] = e[u];
+            // x -> z: Rc rows (y, z, x): row 1 <- E row 0, row 2 <- E row 1, row 0 <- E row 2;  y -> z: Rc rows (z, x, y)
+            const int to0 = b.canon_axis == 0 ? 1 : 2, to1 = b.canon_axis == 0 ? 2 : 0, to2 = b.canon_axis == 0 ? 0 : 1;
+            for (int w = 0; w < 3; w++) {
+                e[3 * to0 + w] = E[w];
+                e[3 * to1 + w] = E[3 + w];
+                e[3 * to2 + w] = E[6 + w];
+            }
+        }
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(kWave, 1) void spanning_kernel(DevPlan<T> DP, int n_clusters, int n_span,
                                                             const T *__restrict__ q, const T *__restrict__ qd,
@@ -2481,6 +2553,14 @@ hipError_t launch_spanning(const DevPlan<T> &P, int n_clusters, int n_span, cons
                        ydd, qd_span, qdd_span, B, scratch);
     return hipGetLastError();
 }
+template <class T>
+hipError_t launch_poses(const DevPlan<T> &P, int n_clusters, const T *q, T *Xa, size_t B, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((poses_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, q, Xa, B);
+    return hipGetLastError();
+}
+template hipError_t launch_poses<float>(const DevPlan<float> &, int, const float *, float *, size_t, int, hipStream_t);
+template hipError_t launch_poses<double>(const DevPlan<double> &, int, const double *, double *, size_t, int, hipStream_t);
 template hipError_t launch_project<float>(const DevPlan<float> &, int, float *, int32_t *, size_t, int, float, float *,
                                           int, size_t, hipStream_t);
 template hipError_t launch_project<double>(const DevPlan<double> &, int, double *, int32_t *, size_t, int, double,

@@ -225,7 +225,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         }
             std::memcpy(bd.inertia, I, sizeof I);
             const ClusterRec &bc = clusters[bd.cluster];
+            bodies[b].canon_axis = 2;
             if (bd.joint_type == GRBDA_JOINT_REVOLUTE && !(bc.kind == CK_LOOP && bc.cons_type == 0)) {
+                bodies[b].canon_axis = bd.axis;
                 bd.axis = 2;
                 bodies[b].axis = 2;
             }

@@ -122,7 +122,8 @@ struct BodyRec {
     int32_t acc_first_IA;     // like acc_first, counting only children that really accumulate an inertia
     int32_t slot_Xa;          // absolute transform world -> body (E 9, r 3); layouts with external forces, has_child only
     int32_t parent_slot_Xa;
-    int32_t reserved[1];
+    int32_t canon_axis;       // original joint axis when the body frame was re-expressed with the axis on z (plan.cpp,
+                              // canonical joint axes), else 2: the reference's body frame is Rc(canon_axis)^T x this one
 };
 
 // number of constants per body before the G row

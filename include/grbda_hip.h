@@ -177,6 +177,25 @@ int grbda_spanning_f64(const grbda_plan *plan, const double *q, const double *qd
 int grbda_spanning_f32(const grbda_plan *plan, const float *q, const float *qd, const float *ydd, float *qd_span,
                        float *qdd_span, size_t B, int device, void *stream);
 
+/* ---- contact side --------------------------------------------------------------------- */
+/* Absolute transform world -> body of every body, TreeNode::Xa_ after TreeModel::forwardKinematics
+ * (TreeModel.cpp:6-32): Xa[B][n_bodies][12] = rotation E (9, row-major: v_body = E v_world) then the position r
+ * of the body origin in world coordinates (spatial::Transform, SpatialTransforms.cpp:13-40).  A point fixed in
+ * the body at `offset` sits at r + E^T offset in the world (contact-point kinematics, TreeModel.cpp:59-76). */
+int grbda_body_poses_f64(const grbda_plan *plan, const double *q, double *Xa, size_t B, int device, void *stream);
+int grbda_body_poses_f32(const grbda_plan *plan, const float *q, float *Xa, size_t B, int device, void *stream);
+
+/* ClusterTreeModel::applyTestForce (ClusterTreeDynamics.cpp:194-233) for B states: a world-frame Cartesian force
+ * force[B][3] acts at the point `offset` (host, body coordinates) of body `body`;
+ * dstate[B][nv] = H^-1 J^T f and lambda_inv[B] = f^T J H^-1 J^T f.  Evaluated with the two kernels (ABA and RNEA
+ * with and without the force as an external wrench), not with the reference's force propagators. */
+int grbda_apply_test_force_f64(const grbda_plan *plan, const double *q, int body, const double offset[3],
+                               const double *force, double *lambda_inv, double *dstate, size_t B, int device,
+                               void *stream);
+int grbda_apply_test_force_f32(const grbda_plan *plan, const float *q, int body, const double offset[3],
+                               const float *force, float *lambda_inv, float *dstate, size_t B, int device,
+                               void *stream);
+
 /* ---- convenience: host pointers (single-state facade calls, small batches) ------------------ */
 /* allocate, copy in, run on `device`, copy out, synchronise.  Still the HIP path. */
 int grbda_aba_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau,

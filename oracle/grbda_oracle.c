@@ -1017,6 +1017,30 @@ static int run_batch(const void *blob, size_t bytes, const double *q, const doub
     return rc;
 }
 
+/* TreeNode::Xa_ of every body after TreeModel::forwardKinematics (TreeModel.cpp:6-32): out[B][n_bodies][12] */
+int grbda_oracle_body_poses(const void *blob, size_t bytes, const double *q, double *out, size_t B)
+{
+    model_t m;
+    int rc = parse_blob(blob, bytes, &m);
+    if (rc) return rc;
+    cws_t *W = (cws_t *)malloc(sizeof(cws_t) * (size_t)m.h->n_clusters);
+    double *zero = (double *)calloc((size_t)m.h->nv, sizeof(double));
+    if (!W || !zero) { free(W); free(zero); return GRBDA_ORACLE_ENOMEM; }
+    const int nq = m.h->nq, nb = m.h->n_bodies;
+    for (size_t s = 0; s < B && !rc; s++) {
+        rc = forward_kinematics(&m, q + s * nq, zero, NULL, W);
+        for (int c = 0; c < m.h->n_clusters && !rc; c++)
+            for (int i = 0; i < W[c].k; i++) {
+                double *o = out + (s * (size_t)nb + (size_t)(m.clusters[c].first_body + i)) * 12;
+                memcpy(o, W[c].Xa[i].E, sizeof(double) * 9);
+                memcpy(o + 9, W[c].Xa[i].r, sizeof(double) * 3);
+            }
+    }
+    free(W);
+    free(zero);
+    return rc;
+}
+
 int grbda_oracle_forward_dynamics(const void *blob, size_t bytes, const double *q, const double *qd,
                                   const double *tau, const double *f_ext, double *ydd, size_t B)
 {

@@ -64,6 +64,8 @@ int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster,
 /* Newton projection of the dependent spanning positions of every implicit cluster onto
  * phi(q) = 0 (GenericJoint.cpp:289-385); q is [B][nq], modified in place.
  * ok[B] (may be NULL) receives 1 when ||phi|| < 1e-8 was reached for every cluster. */
+/* absolute transforms world -> body (E 9 row-major, r 3) of every body: out[B][n_bodies][12] */
+int grbda_oracle_body_poses(const void *blob, size_t bytes, const double *q, double *out, size_t B);
 int grbda_oracle_project_positions(const void *blob, size_t bytes, double *q, size_t B,
                                    int max_iter, int *ok);
 

@@ -34,6 +34,7 @@ def lib():
                                                        c_size_t, c_int]
         L.grbda_oracle_cluster_constraint.argtypes = [c_void_p, c_size_t, c_int] + [c_void_p] * 7
         L.grbda_oracle_project_positions.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]
+        L.grbda_oracle_body_poses.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t]
         _lib = L
     return _lib
 
@@ -84,6 +85,15 @@ def cluster_constraint(blob, cluster, q, qd, nsv, n, rows):
     if rc:
         raise RuntimeError(f"oracle error {rc}")
     return G, g, K, k, phi
+
+
+def body_poses(blob, q, n_bodies):
+    q = _f64(q)
+    out = np.zeros((q.shape[0], n_bodies, 12))
+    rc = lib().grbda_oracle_body_poses(blob, len(blob), q.ctypes.data, out.ctypes.data, q.shape[0])
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    return out
 
 
 def project_positions(blob, q, max_iter=50):

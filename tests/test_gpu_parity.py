@@ -366,3 +366,49 @@ def test_position_derivative_matches_oracle_differences(name, gpu):
     ql, qdl, tl = valid_states(z["urdf_four_bar"], 2, config_index=41)
     with pytest.raises(G.GrbdaError):
         loop.fd_dq(t(ql), t(qdl), t(tl))
+
+
+# ---- contact side: body poses, applyTestForce -----------------------------------------------------------
+@pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
+def test_body_poses_match_oracle(name, blob, gpu):
+    """TreeNode::Xa_ (TreeModel.cpp:20-27) in the REFERENCE's body frames, although the plan works in
+    re-oriented (canonical-axis) frames internally."""
+    import torch
+
+    plan = G.Plan(blob)
+    q, _, _ = valid_states(blob, 70, config_index=51)
+    ref = O.body_poses(blob, q, plan.n_bodies)
+    got = plan.body_poses(torch.as_tensor(q, dtype=torch.float64, device=gpu)).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-11
+
+
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "tello_with_arms", "urdf_four_bar"])
+def test_apply_test_force_matches_oracle(name, gpu):
+    """applyTestForce (ClusterTreeDynamics.cpp:194-233): dstate = H^-1 J^T f, lambda_inv = f^T J H^-1 J^T f,
+    against the oracle's forward / inverse dynamics with the equivalent world wrench."""
+    import torch
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    B = 6
+    q, _, _ = valid_states(blob, B, config_index=52)
+    rng = np.random.default_rng(5)
+    force = rng.uniform(-1, 1, size=(B, 3))
+    offset = np.array([0.05, -0.02, 0.1])
+    body = plan.n_bodies - 1
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    lam, ds = plan.apply_test_force(t(q), body, offset, t(force))
+    lam, ds = lam.cpu().numpy(), ds.cpu().numpy()
+    Xa = O.body_poses(blob, q, plan.n_bodies)[:, body]
+    E, r = Xa[:, :9].reshape(B, 3, 3), Xa[:, 9:]
+    p = r + np.einsum("bji,j->bi", E, offset)  # r + E^T offset
+    fext = np.zeros((B, plan.n_bodies, 6))
+    fext[:, body, :3] = np.cross(p, force)
+    fext[:, body, 3:] = force
+    zero = np.zeros((B, plan.nv))
+    ds_ref = O.forward_dynamics(blob, q, zero, zero, f_ext=fext) - O.forward_dynamics(blob, q, zero, zero)
+    jtf = O.inverse_dynamics(blob, q, zero, zero) - O.inverse_dynamics(blob, q, zero, zero, f_ext=fext)
+    lam_ref = np.einsum("bi,bi->b", jtf, ds_ref)
+    assert rel_err(ds, ds_ref) < 1e-8
+    assert np.abs(lam - lam_ref).max() / (1 + np.abs(lam_ref).max()) < 1e-8
+    assert (lam > 0).all()  # J H^-1 J^T is positive definite along f
