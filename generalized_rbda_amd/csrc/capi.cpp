@@ -230,8 +230,9 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
         e = launch_rnea<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
                            static_cast<hipStream_t>(stream));
     else
+        // (f64 only) the two-wavefronts-per-SIMD build pays for its spills only when the grid fills them
         e = launch_aba<T>(d, q, qd, x, out, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
-                          static_cast<hipStream_t>(stream));
+                          static_cast<hipStream_t>(stream), grid > static_cast<size_t>(t->n_cu) * 4);
     if (e != hipSuccess) return hip_err(e, rnea ? "rnea launch" : "aba launch");
     return GRBDA_OK;
 }

@@ -27,7 +27,7 @@ struct DevPlan {
 
 template <class T>
 hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch,
-                      int grid, size_t lds_bytes, hipStream_t stream);
+                      int grid, size_t lds_bytes, hipStream_t stream, bool two_waves_per_simd);
 template <class T>
 hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch,
                        int grid, size_t lds_bytes, hipStream_t stream);

@@ -37,10 +37,7 @@ namespace grbda_hip {
 #ifndef GRBDA_ABA32_WAVES
 #define GRBDA_ABA32_WAVES 2
 #endif
-// (f64: two per SIMD costs ~280 spilled registers and is still 4-12 % faster than one)
-#ifndef GRBDA_ABA64_WAVES
-#define GRBDA_ABA64_WAVES 2
-#endif
+
 
 #ifdef GRBDA_PROFILE
 __device__ unsigned long long grbda_prof[32];
@@ -2125,8 +2122,11 @@ __device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const Slots<T> 
         }                                                                                      \
     }
 
-template <class T, bool HAS_LOOP>
-__global__ __launch_bounds__(kWave, (sizeof(T) == 4 ? GRBDA_ABA32_WAVES : GRBDA_ABA64_WAVES)) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
+// WPS: wavefronts per SIMD the kernel is register-allocated for.  f32: 2.  f64: the fast kernel exists for 1
+// (no spills; small batches that cannot fill two anyway) and for 2 (~280 spilled registers, still 4-12 %
+// faster once the batch fills the chip); the launcher picks.
+template <class T, bool HAS_LOOP, int WPS>
+__global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                      const T *__restrict__ qd, const T *__restrict__ tau,
                                                      T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
 {
@@ -2517,12 +2517,22 @@ __global__ __launch_bounds__(kWave, 1) void spanning_kernel(DevPlan<T> DP, int n
 // ---------------------------------------------------------------------------------------------
 template <class T>
 hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch,
-                      int grid, size_t lds_bytes, hipStream_t stream)
+                      int grid, size_t lds_bytes, hipStream_t stream, bool two_waves_per_simd)
 {
-    if (P.general)
-        hipLaunchKernelGGL((aba_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
-    else
-        hipLaunchKernelGGL((aba_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    constexpr int W32 = GRBDA_ABA32_WAVES;
+    if constexpr (sizeof(T) == 4) {
+        if (P.general)
+            hipLaunchKernelGGL((aba_kernel<T, true, W32>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+        else
+            hipLaunchKernelGGL((aba_kernel<T, false, W32>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    } else {
+        if (P.general)
+            hipLaunchKernelGGL((aba_kernel<T, true, 1>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+        else if (two_waves_per_simd)
+            hipLaunchKernelGGL((aba_kernel<T, false, 2>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+        else
+            hipLaunchKernelGGL((aba_kernel<T, false, 1>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    }
     return hipGetLastError();
 }
 template <class T>
@@ -2572,9 +2582,9 @@ template hipError_t launch_spanning<double>(const DevPlan<double> &, int, int, c
                                             hipStream_t);
 
 template hipError_t launch_aba<float>(const DevPlan<float> &, const float *, const float *, const float *, float *,
-                                      size_t, float *, int, size_t, hipStream_t);
+                                      size_t, float *, int, size_t, hipStream_t, bool);
 template hipError_t launch_aba<double>(const DevPlan<double> &, const double *, const double *, const double *,
-                                       double *, size_t, double *, int, size_t, hipStream_t);
+                                       double *, size_t, double *, int, size_t, hipStream_t, bool);
 template hipError_t launch_rnea<float>(const DevPlan<float> &, const float *, const float *, const float *, float *,
                                        size_t, float *, int, size_t, hipStream_t);
 template hipError_t launch_rnea<double>(const DevPlan<double> &, const double *, const double *, const double *,
@@ -2599,10 +2609,11 @@ hipError_t set_max_dynamic_lds()
                          reinterpret_cast<const void *>(&project_kernel<double>),
                          reinterpret_cast<const void *>(&spanning_kernel<float>),
                          reinterpret_cast<const void *>(&spanning_kernel<double>),
-                         reinterpret_cast<const void *>(&aba_kernel<float, false>),
-                         reinterpret_cast<const void *>(&aba_kernel<float, true>),
-                         reinterpret_cast<const void *>(&aba_kernel<double, false>),
-                         reinterpret_cast<const void *>(&aba_kernel<double, true>),
+                         reinterpret_cast<const void *>(&aba_kernel<float, false, GRBDA_ABA32_WAVES>),
+                         reinterpret_cast<const void *>(&aba_kernel<float, true, GRBDA_ABA32_WAVES>),
+                         reinterpret_cast<const void *>(&aba_kernel<double, false, 1>),
+                         reinterpret_cast<const void *>(&aba_kernel<double, false, 2>),
+                         reinterpret_cast<const void *>(&aba_kernel<double, true, 1>),
                          reinterpret_cast<const void *>(&rnea_kernel<float, false>),
                          reinterpret_cast<const void *>(&rnea_kernel<float, true>),
                          reinterpret_cast<const void *>(&rnea_kernel<double, false>),
