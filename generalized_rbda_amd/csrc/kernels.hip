@@ -400,7 +400,17 @@ __device__ __forceinline__ void add_axis(T (&x)[6], int axis, T val)
     else x[2] += val;
 }
 
+// f32: the hardware sine / cosine (v_sin_f32 / v_cos_f32 on x / 2 pi, 11 instructions) instead of the
+// library's sincosf (~155, with a Payne-Hanek path for huge arguments).  Measured on the MIT humanoid and
+// JVRC-1 against the fp64 oracle, joint angles up to +-20 rad: max relative error of ydd 2.5e-6 against 0.8e-6
+// (tolerance of the path: 1e-3); 3-4 % of the ABA kernel time.  The absolute error grows like |x| * 6e-8 for
+// very large angles -- callers who wind joints past ~1e4 rad use the f64 entry points
+// (-DGRBDA_PRECISE_SINCOS restores sincosf).
+#ifdef GRBDA_PRECISE_SINCOS
 __device__ __forceinline__ void sincos_t(float x, float *s, float *c) { sincosf(x, s, c); }
+#else
+__device__ __forceinline__ void sincos_t(float x, float *s, float *c) { __sincosf(x, s, c); }
+#endif
 __device__ __forceinline__ void sincos_t(double x, double *s, double *c) { sincos(x, s, c); }
 
 // in-place Cholesky factor + solves for an N x N SPD matrix held in registers.
