@@ -412,6 +412,9 @@ __device__ __forceinline__ void sincos_t(float x, float *s, float *c) { sincosf(
 __device__ __forceinline__ void sincos_t(float x, float *s, float *c) { __sincosf(x, s, c); }
 #endif
 __device__ __forceinline__ void sincos_t(double x, double *s, double *c) { sincos(x, s, c); }
+// implicit constraints always use the library functions: K_d^-1 amplifies their error near singular poses
+__device__ __forceinline__ void sincos_precise(float x, float *s, float *c) { sincosf(x, s, c); }
+__device__ __forceinline__ void sincos_precise(double x, double *s, double *c) { sincos(x, s, c); }
 
 // in-place Cholesky factor + solves for an N x N SPD matrix held in registers.
 // The reference inverts D = S^T IA S with ColPivHouseholderQR (ClusterTreeNode.cpp:33-37,
@@ -667,7 +670,7 @@ __device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const S
         const BodyRec b = load_rec(P.bodies + (c.first_body + sub));
         cptr<T> C = P.consts + b.cofs;
         T sc[2], Eb[9], En[9];
-        sincos_t(S.ld1(qs_slot + sub), &sc[0], &sc[1]);
+        sincos_precise(S.ld1(qs_slot + sub), &sc[0], &sc[1]);
         build_E(b.axis, sc[0], sc[1], C, Eb);
         // X_new = (Eb, r_tree) * (E, r):  E_new = Eb E,  r_new = r + E^T r_tree
 #pragma unroll
@@ -833,7 +836,7 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
             if (j < k) a += w[j] * qv[j];
         if (want_K) {
             T sn, cs;
-            sincos_t(a, &sn, &cs);
+            sincos_precise(a, &sn, &cs);
             const T v3[3] = {a, sn, cs};
             S.st(lay.chain + 4 * i, v3);
         } else {
