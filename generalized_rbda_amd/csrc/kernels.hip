@@ -272,6 +272,25 @@ __device__ __forceinline__ void rot3(const T (&E)[9], const T (&M)[9], T (&R)[9]
         for (int j = 0; j < 3; j++) R[3 * i + j] = E[i] * t[j] + E[3 + i] * t[3 + j] + E[6 + i] * t[6 + j];
 }
 
+// R = E^T M E for a SYMMETRIC 3x3 M: only the upper triangle of the second product is computed
+template <class T>
+__device__ __forceinline__ void rot3_sym(const T (&E)[9], const T (&M)[9], T (&R)[9])
+{
+    T t[9];  // t = M E
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = M[3 * i] * E[j] + M[3 * i + 1] * E[3 + j] + M[3 * i + 2] * E[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            const T v = E[i] * t[j] + E[3 + i] * t[3 + j] + E[6 + i] * t[6 + j];
+            R[3 * i + j] = v;
+            R[3 * j + i] = v;
+        }
+}
+
 // B = X^T A X for symmetric 6x6 A (packed), X = (E, r):
 // Transform::inverseTransformSpatialInertia (SpatialTransforms.cpp:111-135)
 template <class T, class R3>
@@ -286,9 +305,9 @@ __device__ __forceinline__ void congruence(const T (&E)[9], R3 r, const T (&A)[2
             A12[3 * i + j] = A[sidx(i, 3 + j)];
             A22[3 * i + j] = A[sidx(3 + i, 3 + j)];
         }
-    rot3(E, A11, R11);
+    rot3_sym(E, A11, R11);
     rot3(E, A12, R12);
-    rot3(E, A22, R22);
+    rot3_sym(E, A22, R22);
     // TR = R12 + r^ R22 ; column j of r^ R22 is r x R22[:, j]
     T TR[9];
 #pragma unroll
@@ -416,6 +435,13 @@ __device__ __forceinline__ void sincos_t(double x, double *s, double *c) { sinco
 __device__ __forceinline__ void sincos_precise(float x, float *s, float *c) { sincosf(x, s, c); }
 __device__ __forceinline__ void sincos_precise(double x, double *s, double *c) { sincos(x, s, c); }
 
+// reciprocal and reciprocal square root: f32 takes the hardware approximations (1 ulp; the IEEE division
+// expands to ~10 instructions), f64 the exact operations
+__device__ __forceinline__ float rcp_t(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rcp_t(double x) { return 1.0 / x; }
+__device__ __forceinline__ float rsqrt_t(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
+
 // in-place Cholesky factor + solves for an N x N SPD matrix held in registers.
 // The reference inverts D = S^T IA S with ColPivHouseholderQR (ClusterTreeNode.cpp:33-37,
 // Utilities.h:325-329); D is SPD so LL^T agrees to rounding.
@@ -430,7 +456,7 @@ struct Chol {
             T d = A[j][j];
 #pragma unroll
             for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-            const T rs = T(1) / sqrt(d);
+            const T rs = rsqrt_t(d);
             inv[j] = rs;
             L[j][j] = d * rs;
 #pragma unroll
@@ -1655,7 +1681,7 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
     }
 
     // ---- D^-1 u', K = D^-1 F^T (n = 1) ----
-    const T Dinv = T(1) / D;
+    const T Dinv = rcp_t(D);
     const T y0 = u * Dinv;
     T K[6];
 #pragma unroll
