@@ -25,7 +25,7 @@ C_ABI_SYMBOLS = [
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
     "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
     "grbda_fd_dq_f64", "grbda_fd_dq_f32", "grbda_body_poses_f64", "grbda_body_poses_f32",
-    "grbda_apply_test_force_f64", "grbda_apply_test_force_f32",
+    "grbda_apply_test_force_f64", "grbda_apply_test_force_f32", "grbda_inv_osim_f64", "grbda_inv_osim_f32",
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
     "grbda_spanning_f64", "grbda_spanning_f32",
 ]
@@ -94,6 +94,8 @@ def lib() -> ctypes.CDLL:
     L.grbda_plan_span_dims.argtypes = [c_void_p, POINTER(c_int)]
     for sfx in ("f64", "f32"):
         getattr(L, "grbda_body_poses_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        getattr(L, "grbda_inv_osim_" + sfx).argtypes = [c_void_p, c_void_p, c_int, POINTER(c_int), POINTER(c_double),
+                                                        c_void_p, c_void_p, c_size_t, c_int, c_void_p]
         getattr(L, "grbda_apply_test_force_" + sfx).argtypes = [c_void_p, c_void_p, c_int, POINTER(c_double), c_void_p,
                                                                 c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     for sfx in ("f64", "f32"):
@@ -320,6 +322,25 @@ class Plan:
         _check(fn(self._h, q.data_ptr(), body, off, force.data_ptr(), lam.data_ptr(), ds.data_ptr(), B,
                   q.device.index or 0, c_void_p(s.cuda_stream)))
         return lam, ds
+
+    def inv_osim(self, q, bodies, offsets, with_jacobian: bool = False, stream=None):
+        """Batched inverseOperationalSpaceInertiaMatrix for contact frames (body index, body-fixed offset):
+        Linv[B, 6n, 6n] (and the frame Jacobians J[B, 6n, nv] when asked)."""
+        import torch
+
+        B, n = q.shape[0], len(bodies)
+        if not q.is_cuda or q.shape != (B, self.nq):
+            raise ValueError(f"expected a device tensor q[B,{self.nq}]")
+        q = q.contiguous()
+        Linv = torch.empty((B, 6 * n, 6 * n), dtype=q.dtype, device=q.device)
+        J = torch.empty((B, 6 * n, self.nv), dtype=q.dtype, device=q.device) if with_jacobian else None
+        bod = (c_int * n)(*[int(b) for b in bodies])
+        off = (c_double * (3 * n))(*[float(x) for o in offsets for x in o])
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_inv_osim_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), n, bod, off, Linv.data_ptr(), None if J is None else J.data_ptr(), B,
+                  q.device.index or 0, c_void_p(s.cuda_stream)))
+        return (Linv, J) if with_jacobian else Linv
 
     def fd_dq(self, q, qd, tau, step: float = 1e-6, stream=None):
         """d ydd / d q by central differences along the reference's tangent step (testHelpers.hpp:50-112),

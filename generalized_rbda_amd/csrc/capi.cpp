@@ -453,6 +453,135 @@ int test_force(const grbda_plan *p, const T *q, int body, const double *offset, 
     return GRBDA_OK;
 }
 
+// ---- inverse operational-space inertia of a set of contact frames (include/grbda_hip.h) -----------------------
+constexpr int kMaxContacts = 8;
+template <class T>
+struct ContactSet {
+    int n;
+    int body[kMaxContacts];
+    T off[kMaxContacts][3];
+};
+
+// rows (b, j), j < 6 n: unit spatial force e_{j % 6} in contact frame j / 6 (body axes, origin at the contact
+// point) as a world wrench on that body; row 6 n: no force
+template <class T>
+__global__ void osim_expand_kernel(ContactSet<T> cs, const T *__restrict__ q, const T *__restrict__ Xa, int nq,
+                                   int n_bodies, size_t nb, T *__restrict__ qx, T *__restrict__ fext)
+{
+    const int R = 6 * cs.n + 1;
+    const size_t rows = nb * (size_t)R;
+    for (size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x; row < rows; row += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = row / R;
+        const int j = (int)(row % R);
+        for (int i = 0; i < nq; i++) qx[row * nq + i] = q[b * nq + i];
+        T *w = fext + row * (size_t)n_bodies * 6;
+        for (int i = 0; i < n_bodies * 6; i++) w[i] = 0;
+        if (j == R - 1) continue;
+        const int c = j / 6, k = j % 6;
+        const T *X = Xa + (b * n_bodies + cs.body[c]) * 12;
+        const T ox = cs.off[c][0], oy = cs.off[c][1], oz = cs.off[c][2];
+        const T p[3] = {X[9] + X[0] * ox + X[3] * oy + X[6] * oz, X[10] + X[1] * ox + X[4] * oy + X[7] * oz,
+                        X[11] + X[2] * ox + X[5] * oy + X[8] * oz};
+        const int a = k % 3;
+        const T e[3] = {X[3 * a], X[3 * a + 1], X[3 * a + 2]};  // E^T e_a: body axis a in world coordinates
+        w += (size_t)cs.body[c] * 6;
+        if (k < 3) {  // unit moment
+            w[0] = e[0]; w[1] = e[1]; w[2] = e[2];
+        } else {      // unit force at p
+            w[0] = p[1] * e[2] - p[2] * e[1];
+            w[1] = p[2] * e[0] - p[0] * e[2];
+            w[2] = p[0] * e[1] - p[1] * e[0];
+            w[3] = e[0]; w[4] = e[1]; w[5] = e[2];
+        }
+    }
+}
+// g_i = tau(no force) - tau(w_i) = J^T e_i,  a_j = ydd(w_j) - ydd(no force) = H^-1 J^T e_j,  Linv[i][j] = g_i . a_j
+template <class T>
+__global__ void osim_combine_kernel(const T *__restrict__ acc, const T *__restrict__ tau, int nv, int m, size_t nb,
+                                    T *__restrict__ Linv, T *__restrict__ J)
+{
+    const size_t total = nb * (size_t)m * m;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = t / ((size_t)m * m);
+        const int i = (int)((t / m) % m), j = (int)(t % m);
+        const T *ab = acc + b * (size_t)(m + 1) * nv, *tb = tau + b * (size_t)(m + 1) * nv;
+        T s = 0;
+        for (int v = 0; v < nv; v++) {
+            const T g = tb[(size_t)m * nv + v] - tb[(size_t)i * nv + v];
+            s += g * (ab[(size_t)j * nv + v] - ab[(size_t)m * nv + v]);
+            if (J && j == 0) J[(b * m + i) * nv + v] = g;
+        }
+        Linv[t] = s;
+    }
+}
+
+template <class T>
+int inv_osim(const grbda_plan *p, const T *q, int n_contacts, const int *bodies, const double *offsets, T *Linv, T *J,
+             size_t B, int device, void *stream)
+{
+    if (!p || !q || !bodies || !offsets || !Linv) return set_err(GRBDA_EINVAL, "null argument");
+    if (n_contacts < 1 || n_contacts > kMaxContacts) return set_err(GRBDA_EINVAL, "1..8 contact frames per call");
+    ContactSet<T> cs;
+    cs.n = n_contacts;
+    for (int c = 0; c < n_contacts; c++) {
+        if (bodies[c] < 0 || bodies[c] >= p->host.n_bodies) return set_err(GRBDA_EINVAL, "body index out of range");
+        cs.body[c] = bodies[c];
+        for (int i = 0; i < 3; i++) cs.off[c][i] = static_cast<T>(offsets[3 * c + i]);
+    }
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv, nbod = p->host.n_bodies;
+    const size_t m = 6 * static_cast<size_t>(n_contacts), R = m + 1;
+    const size_t per_state = nbod * 12 + R * (nq + nbod * 6 + 3 * nv);  // poses; per row q, wrenches, zeros, 2 results
+    size_t chunk = (256u << 20) / (per_state * sizeof(T));
+    if (chunk < 1) chunk = 1;
+    if (chunk > B) chunk = B;
+    void *wptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        Scratch &s = p->work[{device, stream}];
+        const size_t need = chunk * per_state * sizeof(T) + 256;
+        if (s.bytes < need) {
+            hipError_t e;
+            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+            s.ptr = nullptr;
+            s.bytes = 0;
+            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+            s.bytes = need;
+        }
+        wptr = s.ptr;
+    }
+    const size_t rows = chunk * R;
+    T *Xa = static_cast<T *>(wptr);
+    T *qx = Xa + chunk * nbod * 12;
+    T *fext = qx + rows * nq;
+    T *zero = fext + rows * nbod * 6;
+    T *acc = zero + rows * nv, *tau = acc + rows * nv;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(zero, 0, rows * nv * sizeof(T), hs);
+    if (e != hipSuccess) return hip_err(e, "hipMemsetAsync");
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t nrows = nb * R;
+        if (int rc = poses<T>(p, q + b0 * nq, Xa, nb, device, stream)) return rc;
+        int blocks = static_cast<int>((nrows + 255) / 256 < 65535 ? (nrows + 255) / 256 : 65535);
+        hipLaunchKernelGGL((osim_expand_kernel<T>), dim3(blocks), dim3(256), 0, hs, cs, q + b0 * nq, Xa, static_cast<int>(nq),
+                           static_cast<int>(nbod), nb, qx, fext);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_err(e, "expand launch");
+        int rc;
+        if ((rc = run<T>(p, false, qx, zero, zero, fext, acc, nrows, device, stream)) ||
+            (rc = run<T>(p, true, qx, zero, zero, fext, tau, nrows, device, stream)))
+            return rc;
+        const size_t tot = nb * m * m;
+        blocks = static_cast<int>((tot + 255) / 256 < 65535 ? (tot + 255) / 256 : 65535);
+        hipLaunchKernelGGL((osim_combine_kernel<T>), dim3(blocks), dim3(256), 0, hs, acc, tau, static_cast<int>(nv),
+                           static_cast<int>(m), nb, Linv + b0 * m * m, J ? J + b0 * m * nv : nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_err(e, "combine launch");
+    }
+    return GRBDA_OK;
+}
+
 // ---- derived quantities: expanded batches over the two kernels (include/grbda_hip.h) ---------------------
 enum DerivedMode { DM_BIAS = 0, DM_MASS = 1, DM_DTAU = 2, DM_DQD = 3, DM_DQ = 4 };
 
@@ -840,6 +969,16 @@ int grbda_apply_test_force_f32(const grbda_plan *p, const float *q, int body, co
                                float *lambda_inv, float *dstate, size_t B, int device, void *stream)
 {
     return test_force<float>(p, q, body, offset, force, lambda_inv, dstate, B, device, stream);
+}
+int grbda_inv_osim_f64(const grbda_plan *p, const double *q, int n_contacts, const int *bodies, const double *offsets,
+                       double *Linv, double *J, size_t B, int device, void *stream)
+{
+    return inv_osim<double>(p, q, n_contacts, bodies, offsets, Linv, J, B, device, stream);
+}
+int grbda_inv_osim_f32(const grbda_plan *p, const float *q, int n_contacts, const int *bodies, const double *offsets,
+                       float *Linv, float *J, size_t B, int device, void *stream)
+{
+    return inv_osim<float>(p, q, n_contacts, bodies, offsets, Linv, J, B, device, stream);
 }
 int grbda_plan_span_dims(const grbda_plan *p, int *n_span_vel)
 {

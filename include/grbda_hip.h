@@ -196,6 +196,19 @@ int grbda_apply_test_force_f32(const grbda_plan *plan, const float *q, int body,
                                const float *force, float *lambda_inv, float *dstate, size_t B, int device,
                                void *stream);
 
+/* ClusterTreeModel::inverseOperationalSpaceInertiaMatrix (ClusterTreeDynamics.cpp:295-435) and the contact
+ * Jacobians for B states and up to 8 contact frames per call: frame c sits on body bodies[c] (host array) at the
+ * body-fixed point offsets[c][3] (host) with the body's axes -- the frame of the reference's end-effector force
+ * propagators (createSXform(1, local_offset), :316-320).
+ *   Linv[B][6 n][6 n] = J H^-1 J^T, rows / columns ordered frame by frame, [moment 3, force 3] each;
+ *   J[B][6 n][nv] (may be NULL): the 6-D Jacobians of the frames in their own coordinates.
+ * Evaluated from unit wrenches through the ABA and RNEA kernels (6 n + 1 rows per state each), not with the
+ * reference's extended-force-propagator recursion; the results are the same matrices. */
+int grbda_inv_osim_f64(const grbda_plan *plan, const double *q, int n_contacts, const int *bodies,
+                       const double *offsets, double *Linv, double *J, size_t B, int device, void *stream);
+int grbda_inv_osim_f32(const grbda_plan *plan, const float *q, int n_contacts, const int *bodies,
+                       const double *offsets, float *Linv, float *J, size_t B, int device, void *stream);
+
 /* ---- convenience: host pointers (single-state facade calls, small batches) ------------------ */
 /* allocate, copy in, run on `device`, copy out, synchronise.  Still the HIP path. */
 int grbda_aba_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau,

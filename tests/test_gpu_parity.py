@@ -412,3 +412,55 @@ def test_apply_test_force_matches_oracle(name, gpu):
     assert rel_err(ds, ds_ref) < 1e-8
     assert np.abs(lam - lam_ref).max() / (1 + np.abs(lam_ref).max()) < 1e-8
     assert (lam > 0).all()  # J H^-1 J^T is positive definite along f
+
+
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "tello_with_arms"])
+def test_inverse_operational_space_inertia(name, gpu):
+    """inverseOperationalSpaceInertiaMatrix (ClusterTreeDynamics.cpp:295-435): J H^-1 J^T for contact frames,
+    against H and the frame Jacobians obtained from the oracle's inverse dynamics with unit wrenches, and
+    against applyTestForce."""
+    import torch
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    B = 4
+    q, _, _ = valid_states(blob, B, config_index=53)
+    nb, nv = plan.n_bodies, plan.nv
+    bodies = [nb - 1, nb // 2]
+    offsets = [[0.05, -0.02, 0.1], [0.0, 0.03, -0.2]]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    Linv, J = plan.inv_osim(t(q), bodies, offsets, with_jacobian=True)
+    Linv, J = Linv.cpu().numpy(), J.cpu().numpy()
+    # oracle: J rows from unit wrenches, H from unit accelerations
+    Xa = O.body_poses(blob, q, nb)
+    zero = np.zeros((B, nv))
+    tau0 = O.inverse_dynamics(blob, q, zero, zero)
+    J_ref = np.zeros((B, 12, nv))
+    for c, (bd, off) in enumerate(zip(bodies, offsets)):
+        E, r = Xa[:, bd, :9].reshape(B, 3, 3), Xa[:, bd, 9:]
+        p = r + np.einsum("bji,j->bi", E, np.array(off))
+        for k in range(6):
+            e = E[:, k % 3, :]  # body axis in world coordinates
+            fext = np.zeros((B, nb, 6))
+            if k < 3:
+                fext[:, bd, :3] = e
+            else:
+                fext[:, bd, :3] = np.cross(p, e)
+                fext[:, bd, 3:] = e
+            J_ref[:, 6 * c + k] = tau0 - O.inverse_dynamics(blob, q, zero, zero, f_ext=fext)
+    H = np.zeros((B, nv, nv))
+    for j in range(nv):
+        ej = np.zeros((B, nv))
+        ej[:, j] = 1
+        H[:, :, j] = O.inverse_dynamics(blob, q, zero, ej) - tau0
+    L_ref = np.einsum("bik,bkl,bjl->bij", J_ref, np.linalg.inv(H), J_ref)
+    assert np.abs(J - J_ref).max() / (1 + np.abs(J_ref).max()) < 1e-9
+    assert np.abs(Linv - L_ref).max() / (1 + np.abs(L_ref).max()) < 1e-8
+    assert np.abs(Linv - Linv.transpose(0, 2, 1)).max() / (1 + np.abs(L_ref).max()) < 1e-9
+    # applyTestForce on the first frame: lambda_inv = f_c^T Linv_ff f_c with f_c the force in body axes
+    force = np.random.default_rng(9).uniform(-1, 1, size=(B, 3))
+    lam, _ = plan.apply_test_force(t(q), bodies[0], offsets[0], t(force))
+    E0 = Xa[:, bodies[0], :9].reshape(B, 3, 3)
+    fc = np.einsum("bij,bj->bi", E0, force)
+    lam_ref = np.einsum("bi,bij,bj->b", fc, Linv[:, 3:6, 3:6], fc)
+    assert np.abs(lam.cpu().numpy() - lam_ref).max() / (1 + np.abs(lam_ref).max()) < 1e-8
