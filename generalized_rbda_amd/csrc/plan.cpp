@@ -602,7 +602,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + std::max(6 * cr.k, 4 * trig_args[c]);
                 // (kernels.hip, ImpLayout) kept block: forward step -> acceleration step; work space: forward step
                 objs.push_back({&cr.slot_imp_fwd, keep, 1, tF[c], tA[c], -1});
-                objs.push_back({&cr.slot_imp_bwd, tmp, 1, tF[c], tF[c], -1});
+                objs.push_back({&cr.slot_imp_bwd, tmp, -1, tF[c], tF[c], -1});  // first pick: it is hammered with dependent accesses
             }
         }
         int nl = 0, ng = 0;
@@ -712,7 +712,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 // work space: [K rows*k][chain 6k | per distinct trig argument: a, sin a, cos a, w.qd]
                 const int keep = cr.k * (cr.n + 1) + cr.k + cr.k, tmp = cr.rows * cr.k + std::max(6 * cr.k, 4 * trig_args[c]);
                 robjs.push_back({&cr.slot_imp_fwd, keep, 1, tRF[c], tRB[c], -1});
-                robjs.push_back({&cr.slot_imp_bwd, tmp, 1, tRF[c], tRF[c], -1});
+                robjs.push_back({&cr.slot_imp_bwd, tmp, -1, tRF[c], tRF[c], -1});
             }
         }
         allocate(robjs, lds_budget_rnea, nl, ng);

@@ -11,9 +11,20 @@ def one(path):
     from generalized_rbda_amd.states import random_states
     res = []
     for urdf, prec in [(m, 32) for m in os.environ.get("EXP_MODELS", "mit_humanoid,mini_cheetah,jvrc1_humanoid").split(",")] + [(m, 64) for m in os.environ.get("EXP_MODELS64", "mit_humanoid,mini_cheetah").split(",") if m]:
-        plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", urdf + ".urdf"))
+        if urdf == "tello":
+            from generalized_rbda_amd.robots import tello_with_arms
+            plan = G.Plan.from_model(tello_with_arms())
+        else:
+            plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", urdf + ".urdf"))
         B = 262144
         q, qd, tau = random_states(plan.blob, B, 2)
+        if urdf == "tello":  # valid spanning positions: Newton projection on the device, failures replaced
+            import numpy as np
+            t64 = torch.as_tensor(q, dtype=torch.float64, device="cuda:0")
+            ok = plan.project_positions(t64).cpu().numpy()
+            q = t64.cpu().numpy()
+            good, bad = np.flatnonzero(ok), np.flatnonzero(~ok)
+            q[bad] = q[good[np.arange(bad.size) % good.size]]
         dt = torch.float32 if prec == 32 else torch.float64
         t = lambda a: torch.as_tensor(a, dtype=dt, device="cuda:0")
         tq, tqd, tt = t(q), t(qd), t(tau)
