@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 L.grbda_debug_profile(buf, 0)
 names = ["stage", "step:group wait+issue", "fwd", "bwd(other)", "acc", "bwd:loop-top", "bwd:body-record", "bwd:consts+kinematics", "bwd:bias+acc-loads", "bwd:math+handover", "bwd:joint-terms+push", "bwd:solve+K-store", "step:records", "acc:entry drain", "acc:K/y0/ap loads", "acc:ydd+out store", "acc:body record", "acc:consts+sincos", "tile epilogue"]
 tot = sum(buf[i] for i in range(13))  # buckets >= 13 are sub-buckets of acc
-print("per-wave-per-launch ticks (s_memtime, 100MHz?):")
+print("per-wave-per-launch s_memtime ticks (shader cycles), MIT humanoid ABA f32, profiling build:")
 for i, nm in enumerate(names):
     print(f"  {nm:36s} {buf[i]/n/2048:12.0f}  {100*buf[i]/tot:5.1f}%")
 print("  total", tot / n / 2048)
