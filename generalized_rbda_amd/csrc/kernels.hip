@@ -2189,7 +2189,10 @@ __global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T 
         const size_t r = tile * kWave + lane;
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        PROF_SYNCV();
+        PROF_ADD(19);  // drain of the previous tile's result stores
         stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        PROF_SYNCV();
         PROF_ADD(0);
         Lane<T> L;
         L.active = r < B;

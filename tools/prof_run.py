@@ -21,7 +21,7 @@ n = 10
 for _ in range(n): plan.forward_dynamics(tq, tqd, tt, out=out)
 torch.cuda.synchronize()
 L.grbda_debug_profile(buf, 0)
-names = ["stage", "step:group wait+issue", "fwd", "bwd(other)", "acc", "bwd:loop-top", "bwd:body-record", "bwd:consts+kinematics", "bwd:bias+acc-loads", "bwd:math+handover", "bwd:joint-terms+push", "bwd:solve+K-store", "step:records", "acc:entry drain", "acc:K/y0/ap loads", "acc:ydd+out store", "acc:body record", "acc:consts+sincos", "tile epilogue"]
+names = ["stage", "step:group wait+issue", "fwd", "bwd(other)", "acc", "bwd:loop-top", "bwd:body-record", "bwd:consts+kinematics", "bwd:bias+acc-loads", "bwd:math+handover", "bwd:joint-terms+push", "bwd:solve+K-store", "step:records", "acc:entry drain", "acc:K/y0/ap loads", "acc:ydd+out store", "acc:body record", "acc:consts+sincos", "tile epilogue", "tile entry drain"]
 tot = sum(buf[i] for i in range(13))  # buckets >= 13 are sub-buckets of acc
 print("per-wave-per-launch s_memtime ticks (shader cycles), MIT humanoid ABA f32, profiling build:")
 for i, nm in enumerate(names):
