@@ -1051,6 +1051,50 @@ int grbda_time_kernel(const grbda_plan *p, int kind, int precision, const void *
     return rc;
 }
 
+// Experiment support (tools/spec_experiment.py): the f32 fast-path tables of a plan as C initialisers.
+int grbda_debug_dump_plan(const grbda_plan *p, const char *path)
+{
+    if (!p || !path) return set_err(GRBDA_EINVAL, "null argument");
+    FILE *f = std::fopen(path, "w");
+    if (!f) return set_err(GRBDA_EINVAL, "cannot open the dump file");
+    const HostPlan &h = p->host;
+    const Layout &L = h.lay32;
+    auto ints = [&](const char *type, const char *name, const void *data, size_t count, size_t per) {
+        const int32_t *v = static_cast<const int32_t *>(data);
+        std::fprintf(f, "__constant__ const %s %s[] = {\n", type, name);
+        for (size_t i = 0; i < count; i++) {
+            std::fprintf(f, "  {");
+            for (size_t j = 0; j < per; j++) std::fprintf(f, "%d,", v[i * per + j]);
+            std::fprintf(f, "},\n");
+        }
+        std::fprintf(f, "};\n");
+    };
+    std::fprintf(f, "constexpr int kSpecNq = %d, kSpecNv = %d, kSpecSteps = %d, kSpecLds = %d, kSpecGlb = %d, kSpecOri = %d;\n",
+                 h.nq, h.nv, (int)h.aba_steps.size(), L.n_lds_aba, L.n_glb_aba, h.ori_repr);
+    std::fprintf(f, "constexpr float kSpecARoot[6] = {");
+    for (int i = 0; i < 6; i++) std::fprintf(f, "%.9ef,", (float)-h.gravity[i]);
+    std::fprintf(f, "};\n");
+    // records as flat int initialisers (the structs are all-int32 PODs; nested arrays written as scalars)
+    std::fprintf(f, "__constant__ const int32_t kSpecStepsRaw[] = {");
+    for (const Step &st : h.aba_steps) std::fprintf(f, "%d,%d,0,0,", st.op, st.cluster);
+    std::fprintf(f, "};\n");
+    auto raw = [&](const char *name, const void *data, size_t n_ints) {
+        const int32_t *v = static_cast<const int32_t *>(data);
+        std::fprintf(f, "__constant__ const int32_t %s[] = {", name);
+        for (size_t i = 0; i < n_ints; i++) std::fprintf(f, "%d,", v[i]);
+        std::fprintf(f, "};\n");
+    };
+    raw("kSpecClustersRaw", L.clusters.data(), L.clusters.size() * sizeof(ClusterRec) / 4);
+    raw("kSpecBodiesRaw", L.bodies.data(), L.bodies.size() * sizeof(BodyRec) / 4);
+    raw("kSpecAccK", L.acc_k.data(), L.acc_k.size());
+    std::fprintf(f, "__constant__ const float kSpecConsts[] = {");
+    for (double c : h.consts) std::fprintf(f, "%.9ef,", (float)c);
+    std::fprintf(f, "};\n");
+    (void)ints;
+    std::fclose(f);
+    return GRBDA_OK;
+}
+
 int grbda_device_count(void)
 {
     int count = 0;
