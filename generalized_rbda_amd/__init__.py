@@ -24,6 +24,7 @@ C_ABI_SYMBOLS = [
     "grbda_aba_host_f64", "grbda_rnea_host_f64", "grbda_time_kernel", "grbda_device_count",
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
     "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
+    "grbda_aba_sharded_f32", "grbda_aba_sharded_f64", "grbda_rnea_sharded_f32", "grbda_rnea_sharded_f64",
     "grbda_fd_dq_f64", "grbda_fd_dq_f32", "grbda_body_poses_f64", "grbda_body_poses_f32",
     "grbda_apply_test_force_f64", "grbda_apply_test_force_f32", "grbda_inv_osim_f64", "grbda_inv_osim_f32",
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
@@ -92,6 +93,8 @@ def lib() -> ctypes.CDLL:
         getattr(L, "grbda_fd_dqd_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                       c_int, c_void_p]
     L.grbda_plan_span_dims.argtypes = [c_void_p, POINTER(c_int)]
+    for name in ("grbda_aba_sharded_f32", "grbda_aba_sharded_f64", "grbda_rnea_sharded_f32", "grbda_rnea_sharded_f64"):
+        getattr(L, name).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]
     for sfx in ("f64", "f32"):
         getattr(L, "grbda_body_poses_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
         getattr(L, "grbda_inv_osim_" + sfx).argtypes = [c_void_p, c_void_p, c_int, POINTER(c_int), POINTER(c_double),
@@ -368,6 +371,17 @@ class Plan:
                                        q.data_ptr(), qd.data_ptr(), x.data_ptr(), out.data_ptr(), q.shape[0],
                                        q.device.index or 0, c_void_p(s.cuda_stream), iters, byref(ms)))
         return ms.value
+
+    def sharded_host(self, which: str, q, qd, x, n_gpus: int):
+        """Host numpy arrays (float32 or float64), batch split over devices 0 .. n_gpus-1 in this process."""
+        import numpy as np
+
+        dt = np.float32 if q.dtype == np.float32 else np.float64
+        q, qd, x = (np.ascontiguousarray(a, dtype=dt) for a in (q, qd, x))
+        out = np.empty_like(x)
+        fn = getattr(lib(), f"grbda_{which}_sharded_{'f32' if dt == np.float32 else 'f64'}")
+        _check(fn(self._h, q.ctypes.data, qd.ctypes.data, x.ctypes.data, out.ctypes.data, q.shape[0], n_gpus))
+        return out
 
     # ---- host convenience (numpy, fp64) -----------------------------------------------------------
     def forward_dynamics_host(self, q, qd, tau, device: int = 0, f_ext=None):

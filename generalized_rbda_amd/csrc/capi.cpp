@@ -734,6 +734,68 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
     return GRBDA_OK;
 }
 
+// ---- one process, several devices: contiguous batch shards, plan replicated ------------------------
+template <class T>
+int run_sharded(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int n_gpus)
+{
+    if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return set_err(GRBDA_ENODEVICE, "no HIP device available (there is no CPU fallback)");
+    if (n_gpus < 1 || n_gpus > count) return set_err(GRBDA_EINVAL, "n_gpus out of range");
+    if (B == 0) return GRBDA_OK;
+    const size_t nq = p->host.nq, nv = p->host.nv;
+    struct Shard {
+        size_t b0 = 0, nb = 0;
+        T *dq = nullptr, *dqd = nullptr, *dx = nullptr, *dout = nullptr;
+        hipStream_t s = nullptr;
+    };
+    std::vector<Shard> sh(n_gpus);
+    int rc = GRBDA_OK;
+    hipError_t e = hipSuccess;
+    for (int g = 0; g < n_gpus && rc == GRBDA_OK; g++) {
+        Shard &S = sh[g];
+        S.b0 = B * g / n_gpus;
+        S.nb = B * (g + 1) / n_gpus - S.b0;
+        if (S.nb == 0) continue;
+        if ((e = hipSetDevice(g)) != hipSuccess || (e = hipStreamCreate(&S.s)) != hipSuccess ||
+            (e = hipMalloc((void **)&S.dq, S.nb * nq * sizeof(T))) != hipSuccess ||
+            (e = hipMalloc((void **)&S.dqd, S.nb * nv * sizeof(T))) != hipSuccess ||
+            (e = hipMalloc((void **)&S.dx, S.nb * nv * sizeof(T))) != hipSuccess ||
+            (e = hipMalloc((void **)&S.dout, S.nb * nv * sizeof(T))) != hipSuccess ||
+            (e = hipMemcpyAsync(S.dq, q + S.b0 * nq, S.nb * nq * sizeof(T), hipMemcpyHostToDevice, S.s)) != hipSuccess ||
+            (e = hipMemcpyAsync(S.dqd, qd + S.b0 * nv, S.nb * nv * sizeof(T), hipMemcpyHostToDevice, S.s)) != hipSuccess ||
+            (e = hipMemcpyAsync(S.dx, x + S.b0 * nv, S.nb * nv * sizeof(T), hipMemcpyHostToDevice, S.s)) != hipSuccess) {
+            rc = hip_err(e, "shard setup");
+            break;
+        }
+        rc = run<T>(p, rnea, S.dq, S.dqd, S.dx, nullptr, S.dout, S.nb, g, S.s);
+        if (rc == GRBDA_OK &&
+            (e = hipMemcpyAsync(out + S.b0 * nv, S.dout, S.nb * nv * sizeof(T), hipMemcpyDeviceToHost, S.s)) != hipSuccess)
+            rc = hip_err(e, "shard copy back");
+    }
+    for (int g = 0; g < n_gpus; g++) {
+        Shard &S = sh[g];
+        if (!S.s) continue;
+        (void)hipSetDevice(g);
+        if ((e = hipStreamSynchronize(S.s)) != hipSuccess && rc == GRBDA_OK) rc = hip_err(e, "shard execution");
+        if (S.dq) (void)hipFree(S.dq);
+        if (S.dqd) (void)hipFree(S.dqd);
+        if (S.dx) (void)hipFree(S.dx);
+        if (S.dout) (void)hipFree(S.dout);
+        {   // the scratch slab this call made for its private stream goes with the stream
+            std::lock_guard<std::mutex> lk(p->mu);
+            auto it = p->scratch.find({g, S.s});
+            if (it != p->scratch.end()) {
+                if (it->second.ptr) (void)hipFree(it->second.ptr);
+                p->scratch.erase(it);
+            }
+        }
+        (void)hipStreamDestroy(S.s);
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -979,6 +1041,26 @@ int grbda_inv_osim_f32(const grbda_plan *p, const float *q, int n_contacts, cons
                        float *Linv, float *J, size_t B, int device, void *stream)
 {
     return inv_osim<float>(p, q, n_contacts, bodies, offsets, Linv, J, B, device, stream);
+}
+int grbda_aba_sharded_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, float *ydd, size_t B,
+                          int n_gpus)
+{
+    return run_sharded<float>(p, false, q, qd, tau, ydd, B, n_gpus);
+}
+int grbda_aba_sharded_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, double *ydd, size_t B,
+                          int n_gpus)
+{
+    return run_sharded<double>(p, false, q, qd, tau, ydd, B, n_gpus);
+}
+int grbda_rnea_sharded_f32(const grbda_plan *p, const float *q, const float *qd, const float *ydd, float *tau, size_t B,
+                           int n_gpus)
+{
+    return run_sharded<float>(p, true, q, qd, ydd, tau, B, n_gpus);
+}
+int grbda_rnea_sharded_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, double *tau, size_t B,
+                           int n_gpus)
+{
+    return run_sharded<double>(p, true, q, qd, ydd, tau, B, n_gpus);
 }
 int grbda_plan_span_dims(const grbda_plan *p, int *n_span_vel)
 {

@@ -216,6 +216,20 @@ int grbda_aba_host_f64(const grbda_plan *plan, const double *q, const double *qd
 int grbda_rnea_host_f64(const grbda_plan *plan, const double *q, const double *qd,
                         const double *ydd, const double *f_ext, double *tau, size_t B, int device);
 
+/* ---- one process, several devices --------------------------------------------------------------- */
+/* HOST arrays, batch split into n_gpus contiguous shards on devices 0 .. n_gpus-1 (states are independent, the
+ * plan is replicated, no collective): per shard allocate, copy in, run, copy out on its own stream, all shards
+ * in flight together; returns when every shard is back.  A convenience for callers that are not one process per
+ * GPU (bench.py is: torch.distributed over RCCL); the copies cross PCIe, so this is never the benchmarked rate. */
+int grbda_aba_sharded_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, float *ydd,
+                          size_t B, int n_gpus);
+int grbda_aba_sharded_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau, double *ydd,
+                          size_t B, int n_gpus);
+int grbda_rnea_sharded_f32(const grbda_plan *plan, const float *q, const float *qd, const float *ydd, float *tau,
+                           size_t B, int n_gpus);
+int grbda_rnea_sharded_f64(const grbda_plan *plan, const double *q, const double *qd, const double *ydd, double *tau,
+                           size_t B, int n_gpus);
+
 /* ---- measurement hook -------------------------------------------------------------------------- */
 /* Average duration in milliseconds of `iters` back-to-back launches of the ABA (kind 0) or RNEA
  * (kind 1) kernel, measured with hipEvents recorded on `stream` around the launches (the stream

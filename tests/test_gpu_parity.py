@@ -464,3 +464,21 @@ def test_inverse_operational_space_inertia(name, gpu):
     fc = np.einsum("bij,bj->bi", E0, force)
     lam_ref = np.einsum("bi,bij,bj->b", fc, Linv[:, 3:6, 3:6], fc)
     assert np.abs(lam.cpu().numpy() - lam_ref).max() / (1 + np.abs(lam_ref).max()) < 1e-8
+
+
+def test_sharded_host_entry_points(gpu):
+    """grbda_*_sharded_*: host arrays over n devices in one process (here: as many as the box has)."""
+    import torch
+
+    blob = zoo()["urdf_mini_cheetah"]
+    plan = G.Plan(blob)
+    B = 1000
+    q, qd, tau = random_states(blob, B, 9)
+    n = G.device_count()
+    ref = O.forward_dynamics(blob, q, qd, tau)
+    got = plan.sharded_host("aba", q, qd, tau, n)
+    assert rel_err(got, ref) < TOL64
+    got32 = plan.sharded_host("rnea", q.astype(np.float32), qd.astype(np.float32), tau.astype(np.float32), 1)
+    assert rel_err(got32.astype(np.float64), O.inverse_dynamics(blob, q, qd, tau)) < TOL32
+    with pytest.raises(G.GrbdaError):
+        plan.sharded_host("aba", q, qd, tau, n + 1)
