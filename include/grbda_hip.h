@@ -238,6 +238,9 @@ int grbda_time_kernel(const grbda_plan *plan, int kind, int precision, const voi
                       const void *x, void *out, size_t B, int device, void *stream, int iters,
                       float *avg_ms);
 
+/* Debug aid (tools/spec_experiment.py): the f32 fast-path tables of a plan written as C initialisers. */
+int grbda_debug_dump_plan(const grbda_plan *plan, const char *path);
+
 /* number of usable HIP devices (0 when there is none); never fails */
 int grbda_device_count(void);
 
