@@ -83,10 +83,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # (BENCH_FORCE_DIST=1: take the multi-rank code path even with one rank -- a self-test of the RCCL plumbing)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL prints a version banner on the process's stdout when the communicator comes up; the contract is
+        # ONE JSON line on stdout, so file descriptor 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     urdf, B, dtype_name, cfg = WORKLOADS[args.workload]
     if args.batch:
