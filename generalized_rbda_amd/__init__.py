@@ -25,7 +25,8 @@ C_ABI_SYMBOLS = [
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
     "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
     "grbda_aba_sharded_f32", "grbda_aba_sharded_f64", "grbda_rnea_sharded_f32", "grbda_rnea_sharded_f64",
-    "grbda_debug_dump_plan", "grbda_fd_dq_f64", "grbda_fd_dq_f32", "grbda_body_poses_f64", "grbda_body_poses_f32",
+    "grbda_debug_dump_plan", "grbda_body_poses_host_f64", "grbda_apply_test_force_host_f64",
+    "grbda_inv_osim_host_f64", "grbda_fd_dq_f64", "grbda_fd_dq_f32", "grbda_body_poses_f64", "grbda_body_poses_f32",
     "grbda_apply_test_force_f64", "grbda_apply_test_force_f32", "grbda_inv_osim_f64", "grbda_inv_osim_f32",
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
     "grbda_spanning_f64", "grbda_spanning_f32",

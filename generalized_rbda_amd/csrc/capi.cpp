@@ -796,6 +796,15 @@ int run_sharded(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T
     return rc;
 }
 
+// ---- host-pointer convenience for the contact-side entry points (single-state facade calls) ----------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { hipError_t e = hipMalloc(&p, bytes ? bytes : 16); return e == hipSuccess ? 0 : hip_err(e, "hipMalloc"); }
+    int put(const void *src, size_t bytes) { hipError_t e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice); return e == hipSuccess ? 0 : hip_err(e, "hipMemcpy H2D"); }
+    int get(void *dst, size_t bytes) const { hipError_t e = hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost); return e == hipSuccess ? 0 : hip_err(e, "hipMemcpy D2H"); }
+};
+
 }  // namespace
 
 extern "C" {
@@ -1061,6 +1070,58 @@ int grbda_rnea_sharded_f64(const grbda_plan *p, const double *q, const double *q
                            int n_gpus)
 {
     return run_sharded<double>(p, true, q, qd, ydd, tau, B, n_gpus);
+}
+int grbda_body_poses_host_f64(const grbda_plan *p, const double *q, double *Xa, size_t B, int device)
+{
+    if (!p || !q || !Xa) return set_err(GRBDA_EINVAL, "null argument");
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nb = p->host.n_bodies;
+    DevBuf dq, dX;
+    int rc;
+    if ((rc = dq.alloc(B * nq * 8)) || (rc = dX.alloc(B * nb * 12 * 8)) || (rc = dq.put(q, B * nq * 8))) return rc;
+    if ((rc = poses<double>(p, static_cast<double *>(dq.p), static_cast<double *>(dX.p), B, device, nullptr))) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    return dX.get(Xa, B * nb * 12 * 8);
+}
+int grbda_apply_test_force_host_f64(const grbda_plan *p, const double *q, int body, const double offset[3],
+                                    const double *force, double *lambda_inv, double *dstate, size_t B, int device)
+{
+    if (!p || !q || !force || !lambda_inv || !dstate) return set_err(GRBDA_EINVAL, "null argument");
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv;
+    DevBuf dq, df, dl, dd;
+    int rc;
+    if ((rc = dq.alloc(B * nq * 8)) || (rc = df.alloc(B * 3 * 8)) || (rc = dl.alloc(B * 8)) || (rc = dd.alloc(B * nv * 8)) ||
+        (rc = dq.put(q, B * nq * 8)) || (rc = df.put(force, B * 3 * 8)))
+        return rc;
+    if ((rc = test_force<double>(p, static_cast<double *>(dq.p), body, offset, static_cast<double *>(df.p),
+                                 static_cast<double *>(dl.p), static_cast<double *>(dd.p), B, device, nullptr)))
+        return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    if ((rc = dl.get(lambda_inv, B * 8))) return rc;
+    return dd.get(dstate, B * nv * 8);
+}
+int grbda_inv_osim_host_f64(const grbda_plan *p, const double *q, int n_contacts, const int *bodies, const double *offsets,
+                            double *Linv, double *J, size_t B, int device)
+{
+    if (!p || !q || !Linv) return set_err(GRBDA_EINVAL, "null argument");
+    if (n_contacts < 1 || n_contacts > kMaxContacts) return set_err(GRBDA_EINVAL, "1..8 contact frames per call");
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv, m = 6 * static_cast<size_t>(n_contacts);
+    DevBuf dq, dL, dJ;
+    int rc;
+    if ((rc = dq.alloc(B * nq * 8)) || (rc = dL.alloc(B * m * m * 8)) || (J && (rc = dJ.alloc(B * m * nv * 8))) ||
+        (rc = dq.put(q, B * nq * 8)))
+        return rc;
+    if ((rc = inv_osim<double>(p, static_cast<double *>(dq.p), n_contacts, bodies, offsets, static_cast<double *>(dL.p),
+                               J ? static_cast<double *>(dJ.p) : nullptr, B, device, nullptr)))
+        return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    if ((rc = dL.get(Linv, B * m * m * 8))) return rc;
+    return J ? dJ.get(J, B * m * nv * 8) : GRBDA_OK;
 }
 int grbda_plan_span_dims(const grbda_plan *p, int *n_span_vel)
 {

@@ -315,6 +315,19 @@ struct ExternalForceAndBodyIndexPair {
     SVec<Scalar> force_;
 };
 
+// include/grbda/Dynamics/ContactPoint.h: a point fixed in a body (an end effector when flagged)
+template <typename Scalar = double>
+struct ContactPoint {
+    ContactPoint(int body_index, const Vec3<Scalar> &local_offset, const std::string &name, bool is_end_effector = false)
+        : body_index_(body_index), local_offset_(local_offset), name_(name), is_end_effector_(is_end_effector) {}
+    int body_index_;
+    Vec3<Scalar> local_offset_;
+    std::string name_;
+    bool is_end_effector_;
+    int end_effector_index_ = -1;
+    Vec3<Scalar> position_;  // world position after forwardKinematicsIncludingContactPoints()
+};
+
 // ------------------------------------------------------------------------------------------------
 // loop constraints (include/grbda/Dynamics/ClusterJoints/LoopConstraint.h:14-59)
 // ------------------------------------------------------------------------------------------------
@@ -784,6 +797,73 @@ public:
     DVec<Scalar> forwardDynamics(const DVec<Scalar> &tau) override { return single(false, tau); }
     DVec<Scalar> inverseDynamics(const DVec<Scalar> &qdd) override { return single(true, qdd); }
 
+    // ---- contact side (ClusterTreeModel.cpp:165-221, TreeModel.cpp:59-76, ClusterTreeDynamics.cpp:194-435) --------
+    void appendContactPoint(const std::string body_name, const Vec3<Scalar> &local_offset,
+                            const std::string contact_point_name, const bool is_end_effector = false)
+    {
+        contact_name_to_contact_index_[contact_point_name] = static_cast<int>(contact_points_.size());
+        contact_points_.emplace_back(body_name_to_body_index_.at(body_name), local_offset, contact_point_name, is_end_effector);
+        if (is_end_effector) contact_points_.back().end_effector_index_ = num_end_effectors_++;
+    }
+    void appendEndEffector(const std::string body_name, const Vec3<Scalar> &local_offset, const std::string end_effector_name)
+    {
+        appendContactPoint(body_name, local_offset, end_effector_name, true);
+    }
+    const std::vector<ContactPoint<Scalar>> &contactPoints() const { return contact_points_; }
+    const ContactPoint<Scalar> &contactPoint(const std::string &name) const
+    {
+        return contact_points_[contact_name_to_contact_index_.at(name)];
+    }
+    int getNumEndEffectors() const { return num_end_effectors_; }
+    // TreeModel::contactPointForwardKinematics: position_ = Xa.inverseTransformPoint(local_offset_)
+    void forwardKinematicsIncludingContactPoints()
+    {
+        const std::vector<double> q = state_q();
+        std::vector<double> Xa(static_cast<size_t>(getNumBodies()) * 12);
+        check(grbda_body_poses_host_f64(plan(), q.data(), Xa.data(), 1, 0));
+        for (auto &cp : contact_points_) {
+            const double *X = &Xa[static_cast<size_t>(cp.body_index_) * 12];
+            for (int i = 0; i < 3; i++)
+                cp.position_[i] = static_cast<Scalar>(X[9 + i] + X[i] * cp.local_offset_[0] + X[3 + i] * cp.local_offset_[1] +
+                                                      X[6 + i] * cp.local_offset_[2]);
+        }
+    }
+    // ClusterTreeModel::applyTestForce: returns f^T J H^-1 J^T f, dstate_out = H^-1 J^T f (force in world axes)
+    Scalar applyTestForce(const std::string &contact_point_name, const Vec3<Scalar> &force, DVec<Scalar> &dstate_out)
+    {
+        const ContactPoint<Scalar> &cp = contactPoint(contact_point_name);
+        const std::vector<double> q = state_q();
+        const double off[3] = {double(cp.local_offset_[0]), double(cp.local_offset_[1]), double(cp.local_offset_[2])};
+        const double f[3] = {double(force[0]), double(force[1]), double(force[2])};
+        double lam = 0;
+        std::vector<double> ds(static_cast<size_t>(this->velocity_index_));
+        check(grbda_apply_test_force_host_f64(plan(), q.data(), cp.body_index_, off, f, &lam, ds.data(), 1, 0));
+        dstate_out = DVec<Scalar>(ds.begin(), ds.end());
+        return static_cast<Scalar>(lam);
+    }
+    // ClusterTreeModel::inverseOperationalSpaceInertiaMatrix: 6 x 6 blocks of the end effectors, in the order
+    // of their end_effector_index_, each in the frame (body axes, origin at the point) of its force propagator
+    DMat<Scalar> inverseOperationalSpaceInertiaMatrix()
+    {
+        std::vector<int> bodies;
+        std::vector<double> offsets;
+        for (const auto &cp : contact_points_)
+            if (cp.is_end_effector_) {
+                bodies.push_back(cp.body_index_);
+                for (int i = 0; i < 3; i++) offsets.push_back(static_cast<double>(cp.local_offset_[i]));
+            }
+        const int m = 6 * static_cast<int>(bodies.size());
+        DMat<Scalar> L(m, m);
+        if (m == 0) return L;
+        const std::vector<double> q = state_q();
+        std::vector<double> out(static_cast<size_t>(m) * m);
+        check(grbda_inv_osim_host_f64(plan(), q.data(), static_cast<int>(bodies.size()), bodies.data(), offsets.data(),
+                                      out.data(), nullptr, 1, 0));
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < m; j++) L(i, j) = static_cast<Scalar>(out[static_cast<size_t>(i) * m + j]);
+        return L;
+    }
+
     // TreeModel::updateBiasForceVector (TreeModel.cpp:162-171): C = RNEA(0), external forces included
     DVec<Scalar> getBiasForceVector() { return single(true, DVec<Scalar>::Zero(this->velocity_index_)); }
     // ClusterTreeModel::getMassMatrix (ClusterTreeModel.cpp:99-104).  The reference runs the CRBA; here
@@ -890,6 +970,11 @@ private:
     {
         if (rc != GRBDA_OK) throw std::runtime_error(std::string(grbda_strerror(rc)) + ": " + grbda_last_error());
     }
+    std::vector<double> state_q() const
+    {
+        if (static_cast<int>(q_.size()) != this->position_index_) throw std::runtime_error("state has not been set");
+        return std::vector<double>(q_.begin(), q_.end());
+    }
     DVec<Scalar> single(bool inverse, const DVec<Scalar> &x)
     {
         if (static_cast<int>(x.size()) != this->velocity_index_) throw std::runtime_error("input has the wrong dimension");
@@ -916,6 +1001,9 @@ private:
     std::map<int, int> body_index_to_cluster_index_;
     DVec<Scalar> q_, qd_;
     std::vector<ExternalForceAndBodyIndexPair<Scalar>> f_ext_;
+    std::vector<ContactPoint<Scalar>> contact_points_;
+    std::map<std::string, int> contact_name_to_contact_index_;
+    int num_end_effectors_ = 0;
     std::vector<unsigned char> urdf_blob_;
     bool from_urdf_ = false;
     int n_bodies_urdf_ = 0;

@@ -216,6 +216,13 @@ int grbda_aba_host_f64(const grbda_plan *plan, const double *q, const double *qd
 int grbda_rnea_host_f64(const grbda_plan *plan, const double *q, const double *qd,
                         const double *ydd, const double *f_ext, double *tau, size_t B, int device);
 
+/* the same on HOST arrays (allocate, copy in, run, copy out, synchronise): single-state calls of the C++ facade */
+int grbda_body_poses_host_f64(const grbda_plan *plan, const double *q, double *Xa, size_t B, int device);
+int grbda_apply_test_force_host_f64(const grbda_plan *plan, const double *q, int body, const double offset[3],
+                                    const double *force, double *lambda_inv, double *dstate, size_t B, int device);
+int grbda_inv_osim_host_f64(const grbda_plan *plan, const double *q, int n_contacts, const int *bodies,
+                            const double *offsets, double *Linv, double *J, size_t B, int device);
+
 /* ---- one process, several devices --------------------------------------------------------------- */
 /* HOST arrays, batch split into n_gpus contiguous shards on devices 0 .. n_gpus-1 (states are independent, the
  * plan is replicated, no collective): per shard allocate, copy in, run, copy out on its own stream, all shards

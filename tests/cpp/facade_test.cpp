@@ -107,6 +107,32 @@ static int roundtrip(Model &model, const char *what)
         }
         worst = std::fmax(worst, std::sqrt(res));
     }
+    // contact side: applyTestForce against H^-1 (dstate = H^-1 J^T f is what a unit impulse does), and the
+    // end-effector operational-space inertia against it (testRigidBodyDynamicsAlgos.cpp:241-335)
+    if (!model.contactPoints().empty()) {
+        const auto &cp = model.contactPoints().front();
+        model.forwardKinematicsIncludingContactPoints();
+        const Vec3<double> f{0.3, -0.7, 0.5};
+        DVec<double> ds;
+        const double lam = model.applyTestForce(cp.name_, f, ds);
+        const DMat<double> H = model.getMassMatrix();
+        // J^T f = H dstate ; lambda = (J^T f) . dstate
+        double lam2 = 0;
+        for (int i = 0; i < nv; i++) {
+            double jtf = 0;
+            for (int j = 0; j < nv; j++) jtf += H(i, j) * ds[j];
+            lam2 += jtf * ds[i];
+        }
+        worst = std::fmax(worst, std::fabs(lam - lam2) / (1 + std::fabs(lam)));
+        const DMat<double> Linv = model.inverseOperationalSpaceInertiaMatrix();
+        if (Linv.rows() != 6 * model.getNumEndEffectors()) return 1;
+        for (int i = 0; i < Linv.rows(); i++) {
+            if (!(Linv(i, i) > -1e-12)) return 1;  // positive semi-definite: a planar chain cannot move out of its plane
+            for (int j = 0; j < Linv.cols(); j++) worst = std::fmax(worst, std::fabs(Linv(i, j) - Linv(j, i)) / (1 + std::fabs(Linv(i, i))));
+        }
+        std::printf("%s: contact point at (%.3f, %.3f, %.3f), lambda_inv = %.6f\n", what, cp.position_[0], cp.position_[1],
+                    cp.position_[2], lam);
+    }
     std::printf("%s: nq=%d nv=%d max(|ID(FD(tau)) - tau|, |H ydd + C - tau|) = %.3e\n", what, nq, nv, worst);
     return worst < 5e-8 ? 0 : 1;  // tol of UnitTests/testRigidBodyDynamicsAlgos.cpp:9
 }
@@ -133,7 +159,13 @@ int main(int argc, char **argv)
         }
         if (mode == "--run" && argc > 2) {
             int rc = 0;
-            { ClusterTreeModel<double> m; buildRevoluteChainWithRotor<4>(m); rc |= roundtrip(m, "RevoluteChainWithRotor<4>"); }
+            {
+                ClusterTreeModel<double> m;
+                buildRevoluteChainWithRotor<4>(m);
+                m.appendEndEffector("link-3", Vec3<double>{1.0, 0., 0.}, "tip");             // ClusterTreeModel.cpp:216-221
+                m.appendContactPoint("link-1", Vec3<double>{0.5, 0.1, 0.}, "mid-contact");    // :165-187
+                rc |= roundtrip(m, "RevoluteChainWithRotor<4>");
+            }
             { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<4>(m); rc |= roundtrip(m, "RevolutePairChainWithRotor<4>"); }
             { ClusterTreeModel<double> m(argv[2]); rc |= roundtrip(m, argv[2]); }
             std::printf(rc ? "FAILED\n" : "OK\n");
