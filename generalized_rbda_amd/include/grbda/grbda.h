@@ -417,6 +417,53 @@ struct TrigPolynomial : Base<Scalar> {
         this->rows = static_cast<int>(phi_rows.size());
     }
 };
+// LoopConstraint::FourBar (include/grbda/Dynamics/ClusterJoints/FourBarJoint.h:12-54, FourBarJoint.cpp:7-79): the
+// planar loop closure  phi = sum_path1 l_i [cos, sin](cumulative angle) - offset - sum_path2 l_i [cos, sin](...)
+// over spanning coordinates (q0, q2) on path 1 and (q1) on path 2 -- a trigonometric polynomial, so it is
+// handed to the engine as one (the reference differentiates the same expression by hand, :80-199).
+template <typename Scalar = double>
+struct FourBar : TrigPolynomial<Scalar> {
+    using typename TrigPolynomial<Scalar>::Term;
+    using typename TrigPolynomial<Scalar>::Factor;
+    using Fn = typename TrigPolynomial<Scalar>::Fn;
+    FourBar(std::vector<Scalar> path1_link_lengths, std::vector<Scalar> path2_link_lengths, Vec2<Scalar> offset,
+            int independent_coordinate)
+        : TrigPolynomial<Scalar>(independent_flags(path1_link_lengths, path2_link_lengths, independent_coordinate),
+                                 rows_of(path1_link_lengths, path2_link_lengths, offset)),
+          independent_coordinate_(independent_coordinate) {}
+    const int &independent_coordinate() const { return independent_coordinate_; }
+
+private:
+    static std::vector<bool> independent_flags(const std::vector<Scalar> &p1, const std::vector<Scalar> &p2, int ind)
+    {
+        if (p1.size() + p2.size() != 3) throw std::runtime_error("FourBar: Must contain 3 links");
+        if (p1.size() != 2) throw std::runtime_error("FourBar: path 1 carries spanning coordinates 0 and 2, path 2 coordinate 1");
+        if (ind < 0 || ind > 2) throw std::runtime_error("FourBar: Invalid independent coordinate");
+        std::vector<bool> f(3, false);
+        f[ind] = true;
+        return f;
+    }
+    static std::vector<std::vector<Term>> rows_of(const std::vector<Scalar> &p1, const std::vector<Scalar> &p2,
+                                                  const Vec2<Scalar> &offset)
+    {
+        std::vector<std::vector<Term>> rows(2);
+        for (int r = 0; r < 2; r++) {
+            const Fn fn = r == 0 ? TrigPolynomial<Scalar>::Cos : TrigPolynomial<Scalar>::Sin;
+            const int path1_coords[2] = {0, 2};
+            std::vector<double> w(3, 0.0);
+            for (size_t i = 0; i < p1.size(); i++) {  // cumulative angle along path 1
+                w[path1_coords[i]] = 1.0;
+                rows[r].push_back(Term{static_cast<double>(p1[i]), {Factor{fn, w, 0.0}}});
+            }
+            rows[r].push_back(Term{-static_cast<double>(offset[r]), {}});
+            std::vector<double> w2(3, 0.0);
+            w2[1] = 1.0;
+            rows[r].push_back(Term{-static_cast<double>(p2[0]), {Factor{fn, w2, 0.0}}});
+        }
+        return rows;
+    }
+    int independent_coordinate_;
+};
 }  // namespace LoopConstraint
 
 // single joints (include/grbda/Dynamics/Joints/Joint.h:43-102)
@@ -619,6 +666,14 @@ public:
             this->num_velocities_ = n_ind;
         }
     }
+};
+// ClusterJoints::FourBar (FourBarJoint.h:57-77)
+template <typename Scalar = double>
+class FourBar : public Generic<Scalar> {
+public:
+    FourBar(const std::vector<Body<Scalar>> &bodies, const std::vector<JointPtr<Scalar>> &joints,
+            std::shared_ptr<LoopConstraint::FourBar<Scalar>> loop_constraint)
+        : Generic<Scalar>(bodies, joints, loop_constraint) {}
 };
 }  // namespace ClusterJoints
 

@@ -137,6 +137,40 @@ static int roundtrip(Model &model, const char *what)
     return worst < 5e-8 ? 0 : 1;  // tol of UnitTests/testRigidBodyDynamicsAlgos.cpp:9
 }
 
+// A planar parallelogram four-bar through ClusterJoints::FourBar (FourBarJoint.h): cranks of length a on the
+// ground pivots (0,0) and (d,0), coupler of length d.  Every q = (t, t, -t) satisfies phi = 0.
+static int fourBar()
+{
+    using namespace ClusterJoints;
+    const double a = 0.4, d = 0.7;
+    const Mat3<double> I3 = Mat3<double>::Identity();
+    const SpatialInertia<double> crank(0.8, Vec3<double>{a / 2, 0., 0.}, I3 * 0.01), coupler(1.1, Vec3<double>{d / 2, 0., 0.}, I3 * 0.02);
+    ClusterTreeModel<double> m;
+    Body<double> b0 = m.registerBody("crank-1", crank, "ground", spatial::Transform<double>(I3, Vec3<double>::Zero()));
+    Body<double> b1 = m.registerBody("crank-2", crank, "ground", spatial::Transform<double>(I3, Vec3<double>{d, 0., 0.}));
+    Body<double> b2 = m.registerBody("coupler", coupler, "crank-1", spatial::Transform<double>(I3, Vec3<double>{a, 0., 0.}));
+    std::vector<JointPtr<double>> joints;
+    for (const char *n : {"j0", "j1", "j2"}) joints.emplace_back(new Joints::Revolute<double>(ori::CoordinateAxis::Z, n));
+    auto phi = std::make_shared<LoopConstraint::FourBar<double>>(std::vector<double>{a, d}, std::vector<double>{a},
+                                                                  Vec2<double>{d, 0.}, 0);
+    m.appendRegisteredBodiesAsCluster<FourBar<double>>("four-bar", std::vector<Body<double>>{b0, b1, b2}, joints, phi);
+    if (m.getNumPositions() != 3 || m.getNumDegreesOfFreedom() != 1) return 1;
+    double worst = 0;
+    for (double t : {0.3, -0.9, 1.4}) {
+        DVec<double> q(3), qd(1), tau(1);
+        q[0] = t; q[1] = t; q[2] = -t;
+        qd[0] = 0.7;
+        tau[0] = -0.4;
+        m.setState(std::make_pair(q, qd));
+        const DVec<double> ydd = m.forwardDynamics(tau);
+        worst = std::fmax(worst, (m.inverseDynamics(ydd) - tau).norm());
+        // one degree of freedom: H ydd + C = tau with the scalar mass "matrix"
+        worst = std::fmax(worst, std::fabs(m.getMassMatrix()(0, 0) * ydd[0] + m.getBiasForceVector()[0] - tau[0]));
+    }
+    std::printf("FourBar (parallelogram): nq=3 nv=1 |ID(FD(tau)) - tau| = %.3e\n", worst);
+    return worst < 5e-8 ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "";
@@ -168,6 +202,7 @@ int main(int argc, char **argv)
             }
             { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<4>(m); rc |= roundtrip(m, "RevolutePairChainWithRotor<4>"); }
             { ClusterTreeModel<double> m(argv[2]); rc |= roundtrip(m, argv[2]); }
+            rc |= fourBar();
             std::printf(rc ? "FAILED\n" : "OK\n");
             return rc;
         }
