@@ -734,6 +734,18 @@ public:
         this->velocity_index_ = h->nv;
         n_bodies_urdf_ = h->n_bodies;
         this->plan_dirty_ = true;
+        // body names (for appendContactPoint / appendEndEffector on a model read from URDF): the blob's name pool
+        // holds n_bodies + n_clusters NUL-terminated strings, bodies first (include/grbda_model_desc.h)
+        const size_t off = sizeof(grbda_desc_header) + sizeof(grbda_desc_body) * static_cast<size_t>(h->n_bodies) +
+                           sizeof(grbda_desc_cluster) * static_cast<size_t>(h->n_clusters) +
+                           4u * static_cast<size_t>(h->n_ints + (h->n_ints & 1)) + 8u * static_cast<size_t>(h->n_doubles);
+        const char *names = reinterpret_cast<const char *>(urdf_blob_.data()) + off;
+        const char *end = names + h->n_name_bytes;
+        for (int b = 0; b < h->n_bodies && names < end; b++) {
+            const std::string nm(names);
+            body_name_to_body_index_[nm] = b;
+            names += nm.size() + 1;
+        }
     }
 
     // ClusterTreeModel.cpp:10-32

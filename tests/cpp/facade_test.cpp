@@ -201,7 +201,11 @@ int main(int argc, char **argv)
                 rc |= roundtrip(m, "RevoluteChainWithRotor<4>");
             }
             { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<4>(m); rc |= roundtrip(m, "RevolutePairChainWithRotor<4>"); }
-            { ClusterTreeModel<double> m(argv[2]); rc |= roundtrip(m, argv[2]); }
+            {
+                ClusterTreeModel<double> m(argv[2]);
+                if (argc > 3) m.appendEndEffector(argv[3], Vec3<double>{0., 0., -0.1}, "urdf-ee");  // a link name of the URDF
+                rc |= roundtrip(m, argv[2]);
+            }
             rc |= fourBar();
             std::printf(rc ? "FAILED\n" : "OK\n");
             return rc;

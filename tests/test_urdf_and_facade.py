@@ -183,5 +183,6 @@ def test_cpp_facade_serialises_the_same_models_as_the_python_builder(facade_bina
 
 @pytest.mark.gpu
 def test_cpp_facade_runs_dynamics_on_the_gpu(facade_binary):
-    r = subprocess.run([facade_binary, "--run", os.path.join(MODELS, "mit_humanoid.urdf")], capture_output=True, text=True)
+    r = subprocess.run([facade_binary, "--run", os.path.join(MODELS, "mit_humanoid.urdf"), "left_elbow_link"],
+                       capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
