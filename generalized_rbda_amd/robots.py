@@ -139,3 +139,225 @@ def tello_with_arms() -> ClusterTreeModel:
                                               rotor_axis=axis, gear_ratio=ratio)
             parent = f"{side}-{link_name}"
     return m
+
+
+# -------------------------------------------------------------------------------------------------
+# Hand-built robots that ALSO exist as URDF+ files.  The reference checks its URDF reader against these
+# builders (UnitTests/testClusterTreeModel.cpp:100-114,146-229); restated here as parameter tables through
+# the same construction API so that tests/test_urdf_vs_manual.py can do the same for the product's reader.
+# -------------------------------------------------------------------------------------------------
+def _sym3(rows):
+    return np.array(rows, dtype=np.float64).reshape(3, 3)
+
+
+def _inertia_lr(mass, com, I3, flip):
+    """SpatialInertia(m, c, I) then withLeftRightSigns: the RIGHT side is the mirrored one
+    (MIT_Humanoid.hpp:214-225, MiniCheetah.hpp:125-137)."""
+    if flip:
+        mass, com, I3 = _flip_y(mass, com, I3)
+    return spatial_inertia(mass, np.asarray(com, dtype=np.float64), np.asarray(I3, dtype=np.float64))
+
+
+def mini_cheetah(ori_repr: str = "quaternion") -> ClusterTreeModel:
+    """MiniCheetah<double>::buildClusterTreeModel (src/Robots/MiniCheetah.cpp:6-139; parameters
+    include/grbda/Robots/MiniCheetah.hpp:14-84)."""
+    m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81), ori_repr=ori_repr)
+    I3 = np.eye(3)
+    RY, RX = coordinate_rotation("y", np.pi / 2), coordinate_rotation("x", np.pi / 2)
+    body_I = np.diag([11253, 36203, 42673]) * 1e-6
+    abad_I = _sym3([381, 58, 0.45, 58, 560, 0.95, 0.45, 0.95, 444]) * 1e-6
+    hip_I = _sym3([1983, 245, 13, 245, 2103, 1.5, 13, 1.5, 408]) * 1e-6
+    knee_I_rot = np.diag([6, 248, 245]) * 1e-6
+    rotor_z = np.diag([33, 33, 63]) * 1e-6
+    rotor_x, rotor_y = RY @ rotor_z @ RY.T, RX @ rotor_z @ RX.T
+    m_body, m_abad, m_hip, m_knee, m_rotor = 3.3, 0.54, 0.634, 0.064, 0.055
+    com_abad, com_hip, com_knee = [0, 0.036, 0], [0, 0.016, -0.02], [0, 0, -0.061]
+    abad_rotor_loc, abad_loc = np.array([0.125, 0.049, 0]), np.array([0.38, 0.098, 0]) * 0.5
+    hip_loc, hip_rotor_loc = np.array([0, 0.062, 0]), np.array([0, 0.04, 0])
+    knee_loc, knee_rotor_loc = np.array([0, 0, -0.209]), np.zeros(3)
+    prefix = {0: "FR_", 1: "FL_", 2: "HR_", 3: "HL_"}
+    sign = {0: (1, -1), 1: (1, 1), 2: (-1, -1), 3: (-1, 1)}  # withLegSigns (MiniCheetah.hpp:86-104)
+
+    def leg_signs(v, leg):
+        sx, sy = sign[leg]
+        return np.array([sx * v[0], sy * v[1], v[2]])
+
+    m.appendBody("Floating Base", spatial_inertia(m_body, [0, 0, 0], body_I), "ground", joint="free")
+    side = -1
+    RZ = coordinate_rotation("z", np.pi)
+    for leg in (2, 3, 0, 1):
+        p = prefix[leg]
+        flip = side == -1
+        m.registerBody(p + "abad_link", _inertia_lr(m_abad, com_abad, abad_I, flip), "Floating Base", I3, leg_signs(abad_loc, leg))
+        m.registerBody(p + "abad_rotor", _inertia_lr(m_rotor, [0, 0, 0], rotor_x, flip), "Floating Base", I3, leg_signs(abad_rotor_loc, leg))
+        m.appendRegisteredBodiesAsCluster(p + "abad", "RevoluteWithRotor", joint_axis="x", rotor_axis="x", gear_ratio=6.0)
+        m.registerBody(p + "hip_link", _inertia_lr(m_hip, com_hip, hip_I, flip), p + "abad_link", RZ, leg_signs(hip_loc, leg))
+        m.registerBody(p + "hip_rotor", _inertia_lr(m_rotor, [0, 0, 0], rotor_y, flip), p + "abad_link", RZ, leg_signs(hip_rotor_loc, leg))
+        m.appendRegisteredBodiesAsCluster(p + "hip", "RevoluteWithRotor", joint_axis="y", rotor_axis="y", gear_ratio=6.0)
+        m.registerBody(p + "knee_link", _inertia_lr(m_knee, com_knee, knee_I_rot, flip), p + "hip_link", I3, leg_signs(knee_loc, leg))
+        m.registerBody(p + "knee_rotor", _inertia_lr(m_rotor, [0, 0, 0], rotor_y, flip), p + "hip_link", I3, leg_signs(knee_rotor_loc, leg))
+        m.appendRegisteredBodiesAsCluster(p + "knee", "RevoluteWithRotor", joint_axis="y", rotor_axis="y", gear_ratio=9.33)
+        side *= -1
+    return m
+
+
+# MIT humanoid parameters (include/grbda/Robots/MIT_Humanoid.hpp:16-66,71-150)
+_MITH = dict(
+    torso=(8.52, [0.009896, 0.004771, 0.100522],
+           [0.172699, 0.001419, 0.004023, 0.001419, 0.105949, -0.001672, 0.004023, -0.001672, 0.091906]),
+    hip_rz=(0.84563, [-0.064842, -0.000036, -0.063090],
+            [0.0015373, 0.0000011, 0.0005578, 0.0000011, 0.0014252, 0.0000024, 0.0005578, 0.0000024, 0.0012028]),
+    hip_rx=(1.20868, [0.067232, -0.013018, 0.0001831],
+            [0.0017535, -0.0000063, -0.000080, -0.0000063, 0.003338, -0.000013, -0.000080, -0.000013, 0.0019927]),
+    hip_ry=(2.64093, [0.0132054, 0.0269864, -0.096021],
+            [0.0243761, 0.0000996, 0.0006548, 0.0000996, 0.0259015, 0.0026713, 0.0006548, 0.0026713, 0.0038929]),
+    knee=(0.35435, [0.00528, 0.0014762, -0.13201],
+          [0.003051, 0.000000, 0.0000873, 0.000000, 0.003033, 0.0000393, 0.0000873, 0.0000393, 0.0002529]),
+    ankle=(0.280951, [0.022623, 0.0, -0.012826],
+           [0.0000842, 0.000000, -0.0000488, 0.000000, 0.0007959, -0.000000, -0.0000488, -0.000000, 0.0007681]),
+    shoulder_ry=(0.788506, [0.009265, 0.052623, -0.0001249],
+                 [0.0013678, 0.0000266, 0.0000021, 0.0000266, 0.0007392, -0.0000012, 0.0000021, -0.0000012, 0.000884]),
+    shoulder_rx=(0.80125, [0.0006041, 0.0001221, -0.082361],
+                 [0.0011524, 0.0000007, 0.0000396, 0.0000007, 0.0011921, 0.0000014, 0.0000396, 0.0000014, 0.0012386]),
+    shoulder_rz=(0.905588, [0.0001703, -0.016797, -0.060],
+                 [0.0012713, 0.000001, -0.000008, 0.000001, 0.0017477, -0.0000225, -0.000008, -0.0000225, 0.0008191]),
+    elbow=(0.34839, [-0.0059578, 0.000111, -0.0426735],
+           [0.001570, 0.0000002, 0.0000335, 0.0000002, 0.0016167, 0.000003, 0.0000335, 0.000003, 0.0000619]),
+)
+_MITH_LOC = dict(
+    hip_rz=([-0.00565, -0.082, -0.05735], [-0.00842837, -0.082, -0.041593]),
+    hip_rx=([-0.06435, 0.0, -.07499], [-0.0827, 0.0, -0.066436]),
+    hip_ry=([0.071, 0.0018375, 0.0], [0.071, 0.024, 0.0]),
+    knee=([0.0, 0.0, -0.267], [0.013, -0.0497, -0.0178]),
+    ankle=([0.0, 0.0, -0.2785], [.01563, -.0454, -.13354]),
+    shoulder_ry=([0.01346, -0.17608, 0.24657], [0.01346, -0.16, 0.24657]),
+    shoulder_rx=([0.0, -0.0575, 0.0], [0, -0.0575, 0]),
+    shoulder_rz=([0.0, 0.0, -0.10250], [0., 0., -0.1025]),
+    elbow=([0.0, 0.0, -0.1455], [0., 0.0325, -0.06]),
+)
+_MITH_PITCH = dict(hip_rz=-0.174533, hip_rx=0.436332, hip_ry=-(0.436332 + -0.174533))
+
+
+def _mith_rotors():
+    large_z = np.diag([3.443e-4, 3.443e-4, 5.548e-4])
+    small_z = np.diag([1.084e-4, 1.084e-4, 1.6841e-4])
+    RY, RX = coordinate_rotation("y", np.pi / 2), coordinate_rotation("x", -np.pi / 2)
+    return dict(small_x=RY.T @ small_z @ RY, small_y=RX.T @ small_z @ RX, small_z=small_z,
+                large_y=RX.T @ large_z @ RX, large_z=large_z)
+
+
+def mit_humanoid(ori_repr: str = "quaternion") -> ClusterTreeModel:
+    """MIT_Humanoid<double>::buildClusterTreeModel (src/Robots/MIT_Humanoid.cpp:6-358): floating torso, then
+    right arm, right leg, left arm, left leg; legs end in a RevolutePairWithRotor knee/ankle cluster registered
+    [ankle_rotor, knee_link, knee_rotor, ankle_link] (:172-179)."""
+    m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81), ori_repr=ori_repr)
+    I3 = np.eye(3)
+    rot = _mith_rotors()
+    small_m, large_m = 0.05, 0.1
+    torso = "Floating Base"
+    m.appendBody(torso, spatial_inertia(_MITH["torso"][0], _MITH["torso"][1], _sym3(_MITH["torso"][2])), "ground", joint="free")
+
+    def lr(v, side):  # withLeftRightSigns on a location: the LEFT side (1) mirrors y (MIT_Humanoid.hpp:186-198)
+        return np.array([v[0], -v[1] if side == 1 else v[1], v[2]])
+
+    def link(key, side):
+        mass, com, I = _MITH[key]
+        return _inertia_lr(mass, com, _sym3(I), side == 0)
+
+    def rotor(mass, I, side):
+        return _inertia_lr(mass, [0, 0, 0], I, side == 0)
+
+    def rev_with_rotor(name, key, parent, side, axis, rotor_I, rotor_mass, ratio, pitch=None):
+        pre = "right_" if side == 0 else "left_"
+        E = I3 if pitch is None else coordinate_rotation("y", pitch)
+        loc, rloc = _MITH_LOC[key]
+        m.registerBody(pre + name + "_link", link(key, side), parent, E, lr(loc, side))
+        m.registerBody(pre + name + "_rotor", rotor(rotor_mass, rotor_I, side), parent, E, lr(rloc, side))
+        m.appendRegisteredBodiesAsCluster(pre + name, "RevoluteWithRotor", joint_axis=axis, rotor_axis=axis, gear_ratio=ratio)
+        return pre + name + "_link"
+
+    def leg(side):
+        pre = "right_" if side == 0 else "left_"
+        p = rev_with_rotor("hip_rz", "hip_rz", torso, side, "z", rot["small_z"], small_m, 6.0, _MITH_PITCH["hip_rz"])
+        p = rev_with_rotor("hip_rx", "hip_rx", p, side, "x", rot["small_x"], small_m, 6.0, _MITH_PITCH["hip_rx"])
+        p = rev_with_rotor("hip_ry", "hip_ry", p, side, "y", rot["large_y"], large_m, 6.0, _MITH_PITCH["hip_ry"])
+        ar = m.registerBody(pre + "ankle_rotor", rotor(small_m, rot["small_y"], side), p, I3, lr(_MITH_LOC["ankle"][1], side))
+        kl = m.registerBody(pre + "knee_link", link("knee", side), p, I3, lr(_MITH_LOC["knee"][0], side))
+        kr = m.registerBody(pre + "knee_rotor", rotor(large_m, rot["large_y"], side), p, I3, lr(_MITH_LOC["knee"][1], side))
+        al = m.registerBody(pre + "ankle_link", link("ankle", side), pre + "knee_link", I3, lr(_MITH_LOC["ankle"][0], side))
+        m.appendRegisteredBodiesAsCluster(pre + "knee_and_ankle", "RevolutePairWithRotor", link1=kl, rotor1=kr, rotor2=ar,
+                                          link2=al, joint_axes="yy", rotor_axes="yy", gear_ratios=[6.0, 6.0],
+                                          belt_ratios_1=[2.0], belt_ratios_2=[2.0, 1.0])
+
+    def arm(side):
+        p = rev_with_rotor("shoulder_ry", "shoulder_ry", torso, side, "y", rot["small_y"], small_m, 6.0)
+        p = rev_with_rotor("shoulder_rx", "shoulder_rx", p, side, "x", rot["small_x"], small_m, 6.0)
+        p = rev_with_rotor("shoulder_rz", "shoulder_rz", p, side, "z", rot["small_z"], small_m, 6.0)
+        rev_with_rotor("elbow", "elbow", p, side, "y", rot["small_y"], small_m, 9.0)
+
+    arm(0)
+    leg(0)
+    arm(1)
+    leg(1)
+    return m
+
+
+def mit_humanoid_leg() -> ClusterTreeModel:
+    """MIT_Humanoid_Leg<double>::buildClusterTreeModel (src/Robots/MIT_Humanoid_Leg.cpp:6-163): the LEFT leg's
+    parameters un-mirrored, fixed to the ground, massless rotors, knee/ankle cluster registered
+    [knee_link, ankle_rotor, knee_rotor, ankle_link] (:131-138)."""
+    m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    I3 = np.eye(3)
+    rot = _mith_rotors()
+    link = lambda key: spatial_inertia(_MITH[key][0], _MITH[key][1], _sym3(_MITH[key][2]))
+    rotor = lambda I: spatial_inertia(0.0, [0, 0, 0], I)
+    parent = "ground"
+    for name, axis, rI in (("hip_rz", "z", rot["small_z"]), ("hip_rx", "x", rot["small_x"]), ("hip_ry", "y", rot["large_y"])):
+        E = coordinate_rotation("y", _MITH_PITCH[name])
+        m.registerBody(name + "_link", link(name), parent, E, _MITH_LOC[name][0])
+        m.registerBody(name + "_rotor", rotor(rI), parent, E, _MITH_LOC[name][1])
+        m.appendRegisteredBodiesAsCluster(name, "RevoluteWithRotor", joint_axis=axis, rotor_axis=axis, gear_ratio=6.0)
+        parent = name + "_link"
+    kl = m.registerBody("knee_link", link("knee"), parent, I3, _MITH_LOC["knee"][0])
+    ar = m.registerBody("ankle_rotor", rotor(rot["small_y"]), parent, I3, _MITH_LOC["ankle"][1])
+    kr = m.registerBody("knee_rotor", rotor(rot["large_y"]), parent, I3, _MITH_LOC["knee"][1])
+    al = m.registerBody("ankle_link", link("ankle"), "knee_link", I3, _MITH_LOC["ankle"][0])
+    m.appendRegisteredBodiesAsCluster("knee_and_ankle", "RevolutePairWithRotor", link1=kl, rotor1=kr, rotor2=ar, link2=al,
+                                      joint_axes="yy", rotor_axes="yy", gear_ratios=[6.0, 6.0], belt_ratios_1=[2.0],
+                                      belt_ratios_2=[2.0, 1.0])
+    return m
+
+
+def four_bar_rows(path1_link_lengths, path2_link_lengths, offset):
+    """LoopConstraint::FourBar phi (src/Dynamics/ClusterJoints/FourBarJoint.cpp:22-49) as trig-polynomial rows:
+    spanning coordinates (q0, q2) accumulate along path 1, (q1) along path 2;
+    phi = sum_1 l_i [cos, sin](cumulative) - offset - sum_2 l_i [cos, sin](cumulative)."""
+    if len(path1_link_lengths) + len(path2_link_lengths) != 3 or len(path1_link_lengths) != 2:
+        raise RuntimeError("FourBar: Must contain 3 links (two on path 1, one on path 2)")
+    rows = []
+    for r, fn in enumerate(("cos", "sin")):
+        terms = []
+        w = [0.0, 0.0, 0.0]
+        for i, coord in enumerate((0, 2)):
+            w = list(w)
+            w[coord] = 1.0
+            terms.append((float(path1_link_lengths[i]), [(fn, w, 0.0)]))
+        terms.append((-float(offset[r]), []))
+        terms.append((-float(path2_link_lengths[0]), [(fn, [0.0, 1.0, 0.0], 0.0)]))
+        rows.append(terms)
+    return rows
+
+
+def planar_leg_linkage() -> ClusterTreeModel:
+    """PlanarLegLinkage<double>::buildClusterTreeModel (src/Robots/PlanarLegLinkage.cpp:5-93): a revolute thigh and
+    a parallelogram four-bar lower leg [shank_driver, shank_support, foot] with LoopConstraint::FourBar."""
+    m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    zz = lambda v: np.diag([0.0, 0.0, v])
+    m.appendBody("thigh", spatial_inertia(0.23, [.0364, 0, 0], zz(45.389e-6)), "ground", np.eye(3), [0, 0, 0],
+                 joint="revolute", axis="z")
+    m.registerBody("shank_driver", spatial_inertia(.004, [.048, 0, 0], zz(3.257e-6)), "thigh", np.eye(3), [.011, 0, 0])
+    m.registerBody("shank_support", spatial_inertia(0.225, [.04, 0, 0], zz(22.918e-6)), "thigh", np.eye(3), [.042, 0, 0])
+    m.registerBody("foot", spatial_inertia(.017, [.0635, 0, 0], zz(22.176e-6)), "shank_driver", np.eye(3), [.096, 0, 0])
+    p1 = [.096, .042 - .011]
+    m.appendTrigPolyCluster("lower-leg-cluster", "zzz", [True, False, False], four_bar_rows(p1, [p1[0]], [p1[1], 0.0]))
+    return m
