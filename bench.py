@@ -6,10 +6,14 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (batched cluster ABA, ClusterTreeModel::forwardDynamics)
-over one batch of B synthetic states per GPU, inputs and outputs resident in HBM.  Weak scaling:
-every rank owns its own B-state shard (states are independent, the model plan is replicated);
-there is no data-path collective inside a step -- results are gathered to rank 0 over RCCL once
-after the timed region (reported as gather_ms, not part of `value`).
+over one batch of B synthetic states per GPU, inputs and outputs resident in HBM.  Scaling: weak by
+default (every rank owns its own B-state shard); `--scaling strong` splits the workload's batch over the
+ranks (BASELINE config 4: 1 048 576 Tello states over 8 GPUs).  States are independent and the model plan is
+replicated, so there is no data-path collective inside a step; `value` times the K steps alone.  The one
+exchange the path has -- results to rank 0 over RCCL -- is measured separately: `gather_ms` for one
+blocking gather, and `end_to_end` for K steps that each gather their results, the gather of step i running
+beside the kernel of step i + 1 (two result buffers).  After the timed region a strided sample of the results is
+checked against the CPU oracle (`verified`).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -23,6 +27,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides: MI355X_MICROARCH.md chip table)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+# what a pure v_fma_f32 stream reaches on this chip (tools/valu_ubench.hip, profiles/r2_valu_ubench.txt: 1.31 ns per
+# wave-instruction per SIMD at 8 waves/SIMD, the clock sagging to ~1.9 GHz under that load; the guide quotes 103 TF)
+VALU_ATTAINABLE_TFLOPS = {"f32": 100.0}
 
 WORKLOADS = {
     # name: (urdf, batch per GPU, dtype, config index for the RNG seed)
@@ -35,23 +42,76 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(blob, q, qd, tau, budget_s=12.0):
-    """Oracle (CPU restatement of the reference algorithm) on the host cores, bounded sample."""
+def physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo; falls back to the logical count"""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(blob, q, qd, tau, budget_s=20.0, passes=5):
+    """Oracle (CPU restatement of the reference algorithm, fp64) on the host cores: single thread and all hardware
+    threads, median of `passes` passes each, on a bounded sample of the same batch."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
 
-    cores = os.cpu_count() or 1
-    n = min(q.shape[0], 2048)
-    t0 = time.perf_counter()
-    O.forward_dynamics_mt(blob, q[:n], qd[:n], tau[:n], cores)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    n2 = int(min(q.shape[0], max(n, n / dt * budget_s)))
-    t0 = time.perf_counter()
-    O.forward_dynamics_mt(blob, q[:n2], qd[:n2], tau[:n2], cores)
-    dt = time.perf_counter() - t0
-    return {"value": n2 / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"first {n2} states of the same batch, fp64 dense cluster-ABA restatement (oracle/), "
-                      f"{cores} pthreads, one pass"}
+    threads = os.cpu_count() or 1
+
+    def rate(n_threads, n):
+        t0 = time.perf_counter()
+        O.forward_dynamics_mt(blob, q[:n], qd[:n], tau[:n], n_threads)
+        return n / max(time.perf_counter() - t0, 1e-9)
+
+    def median_rate(n_threads):
+        r = rate(n_threads, min(q.shape[0], 256 * n_threads))  # sizing pass
+        n = int(min(q.shape[0], max(64 * n_threads, r * budget_s / (2 * passes))))
+        rs = sorted(rate(n_threads, n) for _ in range(passes))
+        return rs[len(rs) // 2], n
+
+    single, n1 = median_rate(1)
+    multi, nm = median_rate(threads)
+    return {"value": multi, "unit": "evals/s", "cores": threads, "physical_cores": physical_cores(), "kind": "port",
+            "single_thread": single, "per_thread_all_core": multi / threads, "passes": passes, "dtype": "f64",
+            "sample": f"first {nm} ({n1} single-thread) states of the same batch, median of {passes} passes; "
+                      f"oracle/ = DENSE 6k x 6k restatement kept as the checker, not tuned -- not representative of "
+                      f"the reference's Eigen build",
+            "reference_chart_evals_per_s_per_core": 2.0e4,
+            "reference_chart_note": "images/ForwardDynamicsBenchmark.png of the reference (C-ABA, MIT Humanoid, "
+                                    "hardware unstated), NOT re-measured: the reference cannot be built here (DESIGN.md)"}
+
+
+def verify_sample(blob, q, qd, x, out, algo, dtype_name, n=1024):
+    """strided sample of the results of the LAST timed step against the oracle (fed the inputs as the device saw them)"""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+
+    B = q.shape[0]
+    idx = np.unique(np.concatenate([np.arange(min(64, B)), np.linspace(0, B - 1, num=min(n, B), dtype=np.int64),
+                                    np.arange(max(0, B - 64), B)]))
+    c = (lambda a: a.astype(np.float32).astype(np.float64)) if dtype_name == "f32" else (lambda a: a)
+    fn = O.forward_dynamics if algo == "aba" else O.inverse_dynamics
+    if algo == "aba":
+        ref = O.forward_dynamics_mt(blob, c(q[idx]), c(qd[idx]), c(x[idx]), os.cpu_count() or 1)
+    else:
+        ref = fn(blob, c(q[idx]), c(qd[idx]), c(x[idx]))
+    got = out[idx].double().cpu().numpy()
+    err = np.abs(got - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
+    tol = 1e-3 if dtype_name == "f32" else 1e-9
+    return {"verified": bool(np.quantile(err, 0.995) < tol and np.isfinite(got).all()), "verify_states": int(idx.size),
+            "verify_max_rel_err": float(err.max()), "verify_p995_rel_err": float(np.quantile(err, 0.995)), "verify_tol": tol}
 
 
 def main():
@@ -64,6 +124,8 @@ def main():
     ap.add_argument("--dtype", default="", choices=["", "f32", "f64"])
     ap.add_argument("--algo", default="aba", choices=["aba", "rnea"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's batch per GPU; strong: the workload's batch split over the GPUs")
     args = ap.parse_args()
 
     import numpy as np
@@ -104,6 +166,8 @@ def main():
     urdf, B, dtype_name, cfg = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
+    if args.scaling == "strong":
+        B = (B + world - 1) // world  # contiguous shards of the one batch (generalized_rbda_amd/sharding.py)
     if args.dtype:
         dtype_name = args.dtype
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
@@ -158,8 +222,9 @@ def main():
     # kernel-only duration: hipEvents on the launch stream (torch's current stream here)
     kernel_ms = plan.time_kernel(args.algo, tq, tqd, tx, out, iters=max(5, min(args.steps, 50)))
 
-    # results gathered to rank 0 over RCCL (outside the timed region)
-    gather_ms = None
+    # the path's one exchange step: results to rank 0 over RCCL.  (a) one blocking gather; (b) K steps that each gather
+    # their results, the gather of step i overlapping the kernel of step i + 1 (two result buffers)
+    gather_ms, e2e_elapsed = None, None
     if dist is not None:
         bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
         barrier()
@@ -167,6 +232,25 @@ def main():
         dist.gather(out, bufs, dst=0)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        outs = [out, torch.empty_like(out)]
+        pending = [None, None]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if pending[i % 2] is not None:
+                pending[i % 2].wait()  # the gather that last read this buffer is ordered before the kernel below
+            run(tq, tqd, tx, out=outs[i % 2])
+            pending[i % 2] = dist.gather(outs[i % 2], bufs, dst=0, async_op=True)
+        for w in pending:
+            if w is not None:
+                w.wait()
+        barrier()
+        e2e_elapsed = time.perf_counter() - t0
+        t = torch.tensor([e2e_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2e_elapsed = t.item()
+        run(tq, tqd, tx, out=out)  # `out` holds the results of rank 0's own shard again for the check below
+        torch.cuda.synchronize()
 
     if rank != 0:
         if dist is not None:
@@ -181,14 +265,18 @@ def main():
     flops = info.flops_aba if args.algo == "aba" else info.flops_rnea
     # measured HBM-side traffic of the same launch configuration, if a PMC run is committed (profiles/)
     traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            for e in json.load(f)["entries"]:
-                if (e["workload"], e["algo"], e["dtype"], e["batch"]) == (args.workload, args.algo, dtype_name, B):
-                    traffic = e["bytes_per_launch"]
-                    traffic_src = "rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r1_pmc_traffic.json"
-    except (OSError, KeyError, ValueError):
-        pass
+    for fname in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                for e in json.load(f)["entries"]:
+                    if traffic is None and (e["workload"], e["algo"], e["dtype"], e["batch"]) == (args.workload, args.algo, dtype_name, B):
+                        traffic = e["bytes_per_launch"]
+                        traffic_src = f"rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/{fname}"
+        except (OSError, KeyError, ValueError):
+            pass
+    from generalized_rbda_amd.states import parse_clusters
+
+    general = any(c[9] >= 2 for c in parse_clusters(blob)["clusters"])
     line = {
         "metric": "forward-dynamics evals/sec (batched random states), MIT Humanoid cluster model"
         if args.workload == "mit_humanoid" and args.algo == "aba"
@@ -200,7 +288,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": dtype_name,
         "data": "synthetic",
@@ -210,16 +298,25 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_per_eval * B,
-                     "kernel": f"{args.algo}_kernel<{'float' if dtype_name == 'f32' else 'double'}, false>",
+                     "frac_traffic": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernel": f"grbda_hip::{args.algo}_kernel<{'float' if dtype_name == 'f32' else 'double'}, "
+                               f"{'true' if general else 'false'}>",
                      "kernel_ms": kernel_ms, "bytes_per_eval": bytes_per_eval,
-                     "note": "algorithmic bytes; the path is VALU-bound (see valu)",
+                     "note": "`achieved`/`frac` price the ALGORITHMIC bytes as the contract asks; `frac_traffic` prices the "
+                             "HBM-side bytes rocprofv3 counted; the resource that binds is VALU issue (see valu)",
                      "valu": {"flops_per_eval": flops,
                               "achieved_tflops": kernel_evals_per_s * flops / 1e12,
                               "peak_tflops": VALU_PEAK_TFLOPS[dtype_name],
-                              "frac": kernel_evals_per_s * flops / 1e12 / VALU_PEAK_TFLOPS[dtype_name]}},
+                              "frac": kernel_evals_per_s * flops / 1e12 / VALU_PEAK_TFLOPS[dtype_name],
+                              "attainable_tflops": VALU_ATTAINABLE_TFLOPS.get(dtype_name)}},
     }
+    line.update(verify_sample(blob, q, qd, x, out, args.algo, dtype_name))
     if gather_ms is not None:
         line["gather_ms"] = gather_ms
+        line["end_to_end"] = {"value": world * B * args.steps / e2e_elapsed, "unit": "evals/s",
+                              "ms_per_step": e2e_elapsed / args.steps * 1e3,
+                              "what": "K steps, each followed by the RCCL gather of its results to rank 0; the gather of "
+                                      "step i overlaps the kernel of step i + 1"}
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(blob, q, qd, x)
     elif world == 1:

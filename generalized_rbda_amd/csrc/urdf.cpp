@@ -20,9 +20,10 @@
 //   * bodies inside a cluster: ascending link name, a body only after its parent
 //     (registerBodiesInUrdfCluster, ClusterTreeParsing.cpp:260-307) -- gives the MIT-Humanoid
 //     knee/ankle order [ankle_rotor, knee_link, knee_rotor, ankle_link] (MIT_Humanoid.cpp:172-179);
-//   * child clusters: depth-first (ClusterTreeParsing.cpp:29-43), children ordered by DESCENDING
-//     name of the connecting joint -- reproduces MiniCheetah.cpp:29 ({HR, HL, FR, FL}) and
-//     MIT_Humanoid.cpp (right leg, left leg, right arm, left arm).
+//   * child clusters: depth-first (ClusterTreeParsing.cpp:29-43), the children of a cluster in REVERSE order of
+//     their first discovery by a link-level walk that follows child joints in ascending joint name and then
+//     loop links (see "cluster order" below) -- reproduces MiniCheetah.cpp:29 ({HR, HL, FR, FL}) and
+//     MIT_Humanoid.cpp:351-354 (right arm, right leg, left arm, left leg); tests/test_urdf_vs_manual.py.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -411,22 +412,53 @@ int urdf_to_blob(const char *const *paths, int n_paths, int ori_repr, std::vecto
     for (auto &kv : um.links) members[find(kv.first)].push_back(kv.first);
     if (members[find(root)].size() != 1) { err = "The root cluster may only contain one body"; return GRBDA_EPARSE; }
 
-    // depth-first cluster order
+    // cluster order.  The reference walks urdf::Cluster::child_clusters depth-first (ClusterTreeParsing.cpp:20-43); the
+    // fork fills them from a strongly-connected-components pass over the link graph whose neighbour lists are the
+    // child links in ASCENDING parent-joint name followed by the loop links (UnitTests/testUrdfParser.cpp:268-337,
+    // "the order of the neighbors matters"): components come out leaves first, the model lists them root first.
+    // Net effect: pre-order over the cluster tree, the children of a cluster in REVERSE order of their first
+    // discovery by that link-level walk.  Pinned by the hand-built robots (UnitTests/testClusterTreeModel.cpp:100-114
+    // compares cluster j of the URDF model with cluster j of MiniCheetah.cpp:29 -- {HR, HL, FR, FL} -- and
+    // MIT_Humanoid.cpp:351-354 -- right arm, right leg, left arm, left leg).
     std::vector<std::string> order;  // representatives, root cluster excluded
     {
-        std::set<std::string> visited{find(root)};
+        std::map<std::string, std::vector<const UJoint *>> child_joints;  // parent link -> joints, ascending name
+        for (auto &kv : um.joints) child_joints[kv.second.parent].push_back(&kv.second);  // std::map iterates by name
+        std::map<std::string, std::vector<std::string>> loop_links;
+        for (size_t i = 0; i < um.constraints.size(); i++) {
+            const UConstraint &c = um.constraints[i];
+            loop_links[c.pred].push_back(c.succ);
+            loop_links[c.succ].push_back(cinfo[i].pred_chain.empty() ? c.pred : cinfo[i].pred_chain.front());
+        }
+        std::map<std::string, int> discovered;  // cluster representative -> time of first visit
+        std::set<std::string> seen;
+        int clock = 0;
+        std::function<void(const std::string &)> walk = [&](const std::string &l) {
+            seen.insert(l);
+            if (!discovered.count(find(l))) discovered[find(l)] = clock++;
+            for (const UJoint *j : child_joints[l])
+                if (!seen.count(j->child)) walk(j->child);
+            for (const std::string &n : loop_links[l])
+                if (!seen.count(n)) walk(n);
+        };
+        walk(root);
+        if (discovered.size() != members.size()) { err = "URDF contains links that are not connected to the root"; return GRBDA_EPARSE; }
+        std::map<std::string, std::vector<std::string>> kids;  // parent cluster -> child clusters
+        for (auto &kv : members) {
+            if (kv.first == find(root)) continue;
+            std::string parent_cluster;
+            for (const std::string &l : kv.second) {
+                const std::string pc = find(parent_of(l));
+                if (pc != kv.first) parent_cluster = pc;
+            }
+            kids[parent_cluster].push_back(kv.first);
+        }
         std::function<void(const std::string &)> dfs = [&](const std::string &rep) {
-            // joints leaving this cluster, descending joint name
-            std::vector<const UJoint *> out;
-            for (auto &kv : um.joints)
-                if (find(kv.second.parent) == rep && find(kv.second.child) != rep) out.push_back(&kv.second);
-            std::sort(out.begin(), out.end(), [](const UJoint *a, const UJoint *b) { return a->name > b->name; });
-            for (const UJoint *j : out) {
-                const std::string cr = find(j->child);
-                if (visited.count(cr)) continue;
-                visited.insert(cr);
-                order.push_back(cr);
-                dfs(cr);
+            std::vector<std::string> &k = kids[rep];
+            std::sort(k.begin(), k.end(), [&](const std::string &a, const std::string &b) { return discovered[a] > discovered[b]; });
+            for (const std::string &c : k) {
+                order.push_back(c);
+                dfs(c);
             }
         };
         dfs(find(root));

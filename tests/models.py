@@ -21,10 +21,11 @@ def random_xtree(rng):
     return md.rpy_to_rotmat(rng.uniform(-1, 1, 3)), rng.uniform(-0.5, 0.5, 3)
 
 
-def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor", "pair", "triple", "generic")):
+def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor", "pair", "triple", "generic"),
+                        ori_repr="quaternion"):
     """Random tree of clusters.  Every cluster hangs off ONE body of an earlier cluster."""
     rng = np.random.default_rng(seed)
-    m = md.ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    m = md.ClusterTreeModel(gravity=(0.0, 0.0, -9.81), ori_repr=ori_repr)
     link_names = []
     if floating:
         m.appendBody("base", random_inertia(rng), "ground", joint="free")
@@ -125,8 +126,12 @@ def zoo():
     import generalized_rbda_amd as G
 
     z = {}
-    for name in ("four_bar", "six_bar", "planar_leg_linkage", "mini_cheetah", "mit_humanoid"):
+    for name in ("four_bar", "six_bar", "planar_leg_linkage", "mini_cheetah", "mit_humanoid", "jvrc1_humanoid",
+                 "revolute_rotor_chain", "mit_humanoid_leg"):
         z["urdf_" + name] = G.urdf_to_blob(os.path.join(ROBOT_MODELS, name + ".urdf"))
+    # ori_representation::RollPitchYaw floating bases (OrientationRepresentation.h:30-49, OrientationTools.h:121-130)
+    z["urdf_mini_cheetah_rpy"] = G.urdf_to_blob(os.path.join(ROBOT_MODELS, "mini_cheetah.urdf"), ori_repr="rpy")
+    z["tree_mixed_float_rpy"] = random_cluster_tree(8, 9, floating=True, ori_repr="rpy").serialize()
     from generalized_rbda_amd.robots import tello_with_arms
 
     z["tello_with_arms"] = tello_with_arms().serialize()

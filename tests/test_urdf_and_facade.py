@@ -48,18 +48,18 @@ def _names(blob):
 
 
 def test_urdf_cluster_order_matches_the_reference_hand_built_robots():
-    """MiniCheetah.cpp:29 builds legs {HR, HL, FR, FL}; MIT_Humanoid.cpp builds right leg, left leg,
-    right arm, left arm, with the knee/ankle cluster ordered [ankle_rotor, knee_link, knee_rotor,
+    """MiniCheetah.cpp:29 builds legs {HR, HL, FR, FL}; MIT_Humanoid.cpp:351-354 builds right arm, right leg,
+    left arm, left leg, with the knee/ankle cluster ordered [ankle_rotor, knee_link, knee_rotor,
     ankle_link] (MIT_Humanoid.cpp:172-179); testClusterTreeModel.cpp:100-114 requires the URDF model
-    to agree cluster by cluster."""
+    to agree cluster by cluster (tests/test_urdf_vs_manual.py compares the full models)."""
     mc = [n.decode() for n in _names(G.urdf_to_blob(os.path.join(MODELS, "mini_cheetah.urdf")))]
     assert mc[0] == "Floating Base"
     assert [n[:2] for n in mc[1::6]] == ["HR", "HL", "FR", "FL"]
     assert mc[1:3] == ["HR_abad_link", "HR_abad_rotor"]
     mit = [n.decode() for n in _names(G.urdf_to_blob(os.path.join(MODELS, "mit_humanoid.urdf")))]
-    assert mit[1].startswith("right_hip_rz") and mit[11].startswith("left_hip_rz")
-    assert mit[21].startswith("right_shoulder_ry") and mit[29].startswith("left_shoulder_ry")
-    assert mit[7:11] == ["right_ankle_rotor", "right_knee_link", "right_knee_rotor", "right_ankle_link"]
+    assert mit[1].startswith("right_shoulder_ry") and mit[9].startswith("right_hip_rz")
+    assert mit[19].startswith("left_shoulder_ry") and mit[27].startswith("left_hip_rz")
+    assert mit[15:19] == ["right_ankle_rotor", "right_knee_link", "right_knee_rotor", "right_ankle_link"]
 
 
 def test_urdf_rotor_chain_equals_hand_built_model():

@@ -6,7 +6,17 @@ modeldesc.py) and shares NOTHING with the product's URDF+ reader (csrc/urdf.cpp)
 different rotation / inertia conventions on the way in (rpy <origin> tags and COM-frame inertias in the URDF,
 coordinateRotation matrices and flipAlongAxis in the builders).  Equality of the two descriptions body by body
 pins the reader's conventions -- and the body data of the headline workloads -- to reference-held values; the
-dynamics comparison below then runs the oracle on both, as the reference's test runs its algorithms on both."""
+dynamics comparison below then runs the oracle on both, as the reference's test runs its algorithms on both.
+
+In-cluster body order.  The reference takes it from the link list of a urdf::Cluster of the un-vendored urdfdom
+fork (ClusterTreeParsing.cpp:260-307).  Its two hand-built robots that share one leg design disagree:
+MIT_Humanoid registers the knee/ankle cluster as [ankle_rotor, knee_link, knee_rotor, ankle_link]
+(MIT_Humanoid.cpp:172-179), MIT_Humanoid_Leg as [knee_link, ankle_rotor, knee_rotor, ankle_link]
+(MIT_Humanoid_Leg.cpp:131-138), although link, joint and constraint names of the two URDF files follow the same
+pattern -- so no rule over names or document order reproduces both (the fork presumably iterates a
+pointer-keyed container).  The product's reader orders by ascending link name (= the humanoid's order); the
+order only permutes the rows of G / spanning velocities, never the independent coordinates, so the test matches
+G rows and K columns by BODY NAME and everything state-dependent is compared as is."""
 import os
 import struct
 
@@ -82,7 +92,7 @@ def test_urdf_model_equals_hand_built_model(name, builder):
         pa = A["bodies"][a["parent"]]["name"] if a["parent"] >= 0 else "ground"
         pu = U["bodies"][u["parent"]]["name"] if u["parent"] >= 0 else "ground"
         assert pa == pu, f"{a['name']}: parent"
-        assert (a["cluster"], a["sub"], a["joint_type"]) == (u["cluster"], u["sub"], u["joint_type"]), f"{a['name']}: cluster slot"
+        assert (a["cluster"], a["joint_type"]) == (u["cluster"], u["joint_type"]), f"{a['name']}: cluster"
         if a["joint_type"] == md.JOINT_REVOLUTE:
             assert a["axis"] == u["axis"], f"{a['name']}: joint axis"
         assert np.abs(a["E"] - u["E"]).max() < TOL, f"{a['name']}: Xtree rotation"
@@ -95,12 +105,19 @@ def test_urdf_model_equals_hand_built_model(name, builder):
         ctype_u, rows_u, do_u, nd_u = cu[9], cu[10], cu[13], cu[14]
         assert rows_a == rows_u
         if ctype_a == md.C_STATIC and ctype_u == md.C_STATIC:
-            Ga, Gu = A["dbls"][do_a: do_a + nsv * nvel], U["dbls"][do_u: do_u + nsv * nvel]
+            # rows of G / columns of K belong to bodies: matched by body name (see the note on in-cluster order)
+            fb = ca[1]
+            perm = [by_name_u[A["bodies"][fb + i]["name"]]["sub"] for i in range(k)]
+            assert sorted(perm) == list(range(k))
+            Ga = A["dbls"][do_a: do_a + nsv * nvel].reshape(nsv, nvel)
+            Gu = U["dbls"][do_u: do_u + nsv * nvel].reshape(nsv, nvel)[perm]
             assert np.abs(Ga - Gu).max() < TOL, f"cluster {ci}: G"
-            Ka = A["dbls"][do_a + nsv * nvel: do_a + nd_a]
-            Ku = U["dbls"][do_u + nsv * nvel: do_u + nd_u]
+            Ka = A["dbls"][do_a + nsv * nvel: do_a + nd_a].reshape(-1, nsv)
+            Ku = U["dbls"][do_u + nsv * nvel: do_u + nd_u].reshape(-1, nsv)[:, perm]
             if Ka.size and Ku.size:
-                assert Ka.size == Ku.size and np.abs(Ka - Ku).max() < TOL, f"cluster {ci}: K"
+                # the constraint rows may be listed in another order: same row space, K G = 0 on both sides
+                assert Ka.shape == Ku.shape and np.abs(Ku @ Ga).max() < TOL and np.abs(Ka @ Ga).max() < TOL
+                assert np.linalg.matrix_rank(np.vstack([Ka, Ku]), tol=1e-9) == Ka.shape[0], f"cluster {ci}: K row space"
     # state-dependent part (:156-228): 25 random states, the reference's algorithms = the oracle on both models
     B = 25
     q, qd, tau = valid_states(manual_blob, B, config_index=61)
