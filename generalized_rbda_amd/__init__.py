@@ -45,7 +45,8 @@ class PlanInfo(ctypes.Structure):
                 ("scratch_bytes_per_wave_f32", c_size_t), ("scratch_bytes_per_wave_f64", c_size_t),
                 ("flops_aba", c_double), ("flops_rnea", c_double),
                 ("bytes_aba_f32", c_double), ("bytes_aba_f64", c_double),
-                ("n_axisym_bodies", c_int), ("n_carry_clusters", c_int)]
+                ("n_axisym_bodies", c_int), ("n_carry_clusters", c_int),
+                ("split_aba_f32", c_int), ("split_rnea_f32", c_int), ("n_lds_slots_split_f32", c_int)]
 
 
 _lib = None

@@ -39,14 +39,14 @@ int hip_err(hipError_t e, const char *what)
 // per-(device) copies of the plan tables; per-(device, stream) scratch slabs
 struct DeviceTables {
     Step *aba_steps = nullptr, *rnea_steps = nullptr;
-    // [0] f32, [1] f64, [2] f32 + external forces, [3] f64 + external forces
-    ClusterRec *clusters[4] = {nullptr, nullptr, nullptr, nullptr};
-    ClusterRec *rnea_clusters[4] = {nullptr, nullptr, nullptr, nullptr};
+    // [0] f32, [1] f64, [2] f32 + external forces, [3] f64 + external forces, [4] f32 split layout
+    ClusterRec *clusters[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ClusterRec *rnea_clusters[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t *cints = nullptr;
-    int32_t *acc_k[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *acc_k[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t *dq_map = nullptr;  // per velocity index: (kind, position index, component), see grbda_fd_dq_*
-    BodyRec *bodies[4] = {nullptr, nullptr, nullptr, nullptr};       // ABA slots
-    BodyRec *rnea_bodies[4] = {nullptr, nullptr, nullptr, nullptr};  // RNEA slots
+    BodyRec *bodies[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // ABA slots
+    BodyRec *rnea_bodies[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // RNEA slots
     double *consts64 = nullptr;
     float *consts32 = nullptr;
     int n_cu = 0;
@@ -60,6 +60,12 @@ int env_int(const char *name, int dflt)
 {
     const char *v = std::getenv(name);
     return v && *v ? std::atoi(v) : dflt;
+}
+
+constexpr int kLayouts = 5;
+const Layout &layout_of(const HostPlan &h, int w)
+{
+    return w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : (w == 3 ? h.lay64x : h.lay32s)));
 }
 
 }  // namespace
@@ -78,6 +84,7 @@ struct grbda_plan {
     // register-bound to 8 per CU and prefers 6 with more LDS)
     int lds_bytes_per_wave[4] = {20480, 20480, 10240, 26624};
     int waves_per_cu[4] = {8, 8, 16, 6};
+    bool no_split = false;
 };
 
 namespace {
@@ -131,8 +138,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             }
         if ((e = up(map.data(), map.size() * sizeof(int32_t), (void **)&t.dq_map)) != hipSuccess) return hip_err(e, "plan upload");
     }
-    for (int w = 0; w < 4; w++) {
-        const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
+    for (int w = 0; w < kLayouts; w++) {
+        const Layout &L = layout_of(h, w);
         if ((e = up(L.clusters.data(), L.clusters.size() * sizeof(ClusterRec), (void **)&t.clusters[w])) != hipSuccess ||
             (e = up(L.rnea_clusters.data(), L.rnea_clusters.size() * sizeof(ClusterRec), (void **)&t.rnea_clusters[w])) != hipSuccess ||
             (e = up(L.bodies.data(), L.bodies.size() * sizeof(BodyRec), (void **)&t.bodies[w])) != hipSuccess ||
@@ -175,8 +182,11 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, 
     const HostPlan &h = p->host;
     d.steps = rnea ? t.rnea_steps : t.aba_steps;
     d.n_steps = static_cast<int>(rnea ? h.rnea_steps.size() : h.aba_steps.size());
-    const int w = (sizeof(T) == 4 ? 0 : 1) + (fext ? 2 : 0);
-    const Layout &L = w == 0 ? h.lay32 : (w == 1 ? h.lay64 : (w == 2 ? h.lay32x : h.lay64x));
+    int w = (sizeof(T) == 4 ? 0 : 1) + (fext ? 2 : 0);
+    // f32 fast path: the split layout when it exists for this kernel (GRBDA_NO_SPLIT=1 keeps the mixed one, for A/B runs)
+    const bool split = w == 0 && (rnea ? h.lay32s.split_rnea : h.lay32s.split_aba) && !p->no_split;
+    if (split) w = 4;
+    const Layout &L = layout_of(h, w);
     d.clusters = rnea ? t.rnea_clusters[w] : t.clusters[w];
     d.cints = t.cints;
     d.acc_k = t.acc_k[w];
@@ -189,6 +199,7 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, 
     d.ori_repr = h.ori_repr;
     d.general = fext ? 1 : 0;
     for (const ClusterRec &cr : L.clusters) d.general |= cr.kind == CK_LOOP;
+    d.split = split ? 1 : 0;
     d.n_bodies = h.n_bodies;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     return d;
@@ -843,6 +854,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
         w = env_int((std::string("GRBDA_WAVES_PER_CU") + suffix[k]).c_str(), w);
         p->waves_per_cu[k] = w < 1 ? 1 : (w > 32 ? 32 : w);
     }
+    p->no_split = env_int("GRBDA_NO_SPLIT", 0) != 0;
     LdsBudget lds;
     lds.aba32 = p->lds_bytes_per_wave[0] / (4 * kWave);
     lds.aba64 = p->lds_bytes_per_wave[1] / (8 * kWave);
@@ -892,7 +904,7 @@ void grbda_plan_free(grbda_plan *p)
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map);
-        for (int w = 0; w < 4; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
+        for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work})
         for (auto &kv : *m) {
@@ -952,6 +964,9 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->bytes_aba_f64 = (p->host.nq + 3.0 * p->host.nv) * 8;
     for (const BodyRec &b : p->host.lay32.bodies) info->n_axisym_bodies += b.axisym;
     for (const ClusterRec &c : p->host.lay32.clusters) info->n_carry_clusters += c.carry_out;
+    info->split_aba_f32 = p->host.lay32s.split_aba && !p->no_split;
+    info->split_rnea_f32 = p->host.lay32s.split_rnea && !p->no_split;
+    info->n_lds_slots_split_f32 = p->host.lay32s.n_lds_aba;
     return GRBDA_OK;
 }
 

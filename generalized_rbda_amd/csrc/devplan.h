@@ -20,6 +20,7 @@ struct DevPlan {
     int lds_bytes;  // dynamic LDS actually allocated per wave (slot store / input staging area)
     int ori_repr;
     int general;   // launch the general kernel variant: implicit-loop clusters and / or external forces
+    int split;     // the layout keeps [K | y0] blocks in the global slab and everything else in LDS (Slots<T, true>)
     int n_bodies;
     const T *fext; // [B][n_bodies][6] world-frame spatial forces or nullptr (TreeModel::setExternalForces)
     T a_root[6];  // -gravity (ClusterTreeDynamics.cpp:147)

@@ -61,25 +61,7 @@ __device__ unsigned long long grbda_prof[32];
 #define PROF_SYNCV()
 #endif
 
-// ---------------------------------------------------------------------------------------------
-// plan tables live in the constant address space: uniform loads from it are scalar (s_load),
-// which also makes every branch on a plan field a scalar branch
-// ---------------------------------------------------------------------------------------------
-template <class U>
-using cptr = const U __attribute__((address_space(4))) *;
-
-// copy a plan record (all-int32 POD) out of the constant address space; unused fields fold away
-template <class U>
-__device__ __forceinline__ U load_rec(cptr<U> p)
-{
-    static_assert(sizeof(U) % 4 == 0, "plan records are arrays of int32");
-    U out;
-    cptr<int32_t> src = (cptr<int32_t>)p;
-    int32_t *dst = reinterpret_cast<int32_t *>(&out);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(U) / 4); i++) dst[i] = src[i];
-    return out;
-}
+#include "devmath.h"
 
 // body record of the fast kernels: the plan compiler re-expresses every revolute body in a frame whose
 // z axis is the joint axis (plan.cpp, "canonical joint axes"), so the axis is a compile-time constant
@@ -125,11 +107,13 @@ __device__ __forceinline__ Tables<T> make_tables(const DevPlan<T> &P)
 // ---------------------------------------------------------------------------------------------
 // slot store: an object is either wholly in LDS or wholly in the wave's global slab (plan.cpp)
 // ---------------------------------------------------------------------------------------------
-// The LDS array is always addressed through this symbol (never through a generic pointer), so
-// every access compiles to ds_read / ds_write and never to a flat instruction.
-extern __shared__ __attribute__((aligned(16))) unsigned char grbda_smem[];
 
-template <class T>
+// SPLIT policy (fast kernels, layouts with Layout::split): the [K | y0] blocks -- written once by the backward sweep,
+// read once by the acceleration sweep, 7 scalars per DoF and far too many for LDS -- and the backward accumulators of
+// branching bodies (27 scalars, touched once per child limb) ALWAYS live in the wave's global slab, every other
+// object ALWAYS in LDS.  No access then tests kSlotGlobal: the scalar branch, the
+// duplicated LDS / global code behind it and the control-flow scaffolding around both disappear from the kernel.
+template <class T, bool SPLIT = false>
 struct Slots {
     T *glb;  // wave's global slab (uniform: the per-lane part of an address is a 32-bit offset, which
              // keeps the 64-bit address arithmetic to one vector add per object)
@@ -139,12 +123,24 @@ struct Slots {
     __device__ __forceinline__ void lds_put(int s, T x) const { reinterpret_cast<T *>(grbda_smem)[s * kWave + lane] = x; }
 
     template <int N>
+    __device__ __forceinline__ void ld_glb(int s, T (&x)[N]) const
+    {
+        const T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = p[i * kWave];
+    }
+    template <int N>
+    __device__ __forceinline__ void st_glb(int s, const T (&x)[N]) const
+    {
+        T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
+#pragma unroll
+        for (int i = 0; i < N; i++) p[i * kWave] = x[i];
+    }
+    template <int N>
     __device__ __forceinline__ void ld(int s, T (&x)[N]) const
     {
-        if (s & kSlotGlobal) {
-            const T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
-#pragma unroll
-            for (int i = 0; i < N; i++) x[i] = p[i * kWave];
+        if (!SPLIT && (s & kSlotGlobal)) {
+            ld_glb(s, x);
         } else {
 #pragma unroll
             for (int i = 0; i < N; i++) x[i] = lds_get(s + i);
@@ -153,14 +149,36 @@ struct Slots {
     template <int N>
     __device__ __forceinline__ void st(int s, const T (&x)[N]) const
     {
-        if (s & kSlotGlobal) {
-            T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
-#pragma unroll
-            for (int i = 0; i < N; i++) p[i * kWave] = x[i];
+        if (!SPLIT && (s & kSlotGlobal)) {
+            st_glb(s, x);
         } else {
 #pragma unroll
             for (int i = 0; i < N; i++) lds_put(s + i, x[i]);
         }
+    }
+    // [K | y0] blocks
+    template <int N>
+    __device__ __forceinline__ void ldK(int s, T (&x)[N]) const
+    {
+        if constexpr (SPLIT) ld_glb(s, x);
+        else ld(s, x);
+    }
+    template <int N>
+    __device__ __forceinline__ void stK(int s, const T (&x)[N]) const
+    {
+        if constexpr (SPLIT) st_glb(s, x);
+        else st(s, x);
+    }
+    __device__ __forceinline__ T ldK1(int s) const
+    {
+        T x[1];
+        ldK(s, x);
+        return x[0];
+    }
+    __device__ __forceinline__ void stK1(int s, T v) const
+    {
+        const T x[1] = {v};
+        stK(s, x);
     }
     __device__ __forceinline__ T ld1(int s) const
     {
@@ -172,6 +190,20 @@ struct Slots {
     {
         const T x[1] = {v};
         st(s, x);
+    }
+    // the same for objects of the global class ([K | y0] blocks, backward accumulators)
+    template <int N>
+    __device__ __forceinline__ void accK(int s, const T (&x)[N], int first) const
+    {
+        if (first) {
+            stK(s, x);
+        } else {
+            T y[N];
+            ldK(s, y);
+#pragma unroll
+            for (int i = 0; i < N; i++) y[i] += x[i];
+            stK(s, y);
+        }
     }
     // x is stored when first != 0, accumulated otherwise
     template <int N>
@@ -185,304 +217,6 @@ struct Slots {
 #pragma unroll
             for (int i = 0; i < N; i++) y[i] += x[i];
             st(s, y);
-        }
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
-// spatial algebra on (E, r) transforms -- src/Utils/SpatialTransforms.cpp:32-157
-// ---------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int sidx(int i, int j)
-{  // packed upper-triangular index of a symmetric 6x6
-    return i <= j ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j));
-}
-
-// E = R_axis(theta) * Et  (ori::coordinateRotation, OrientationTools.h:46-68; XJ * Xtree)
-template <class T>
-__device__ __forceinline__ void build_E(int axis, T s, T c, cptr<T> Et, T (&E)[9])
-{
-    if (axis == 0) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            E[j] = Et[j];
-            E[3 + j] = c * Et[3 + j] + s * Et[6 + j];
-            E[6 + j] = c * Et[6 + j] - s * Et[3 + j];
-        }
-    } else if (axis == 1) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            E[j] = c * Et[j] - s * Et[6 + j];
-            E[3 + j] = Et[3 + j];
-            E[6 + j] = s * Et[j] + c * Et[6 + j];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            E[j] = c * Et[j] + s * Et[3 + j];
-            E[3 + j] = c * Et[3 + j] - s * Et[j];
-            E[6 + j] = Et[6 + j];
-        }
-    }
-}
-
-// transformMotionVector: [E w ; E (v - r x w)]
-template <class T, class R3>
-__device__ __forceinline__ void xmotion(const T (&E)[9], R3 r, const T (&m)[6], T (&o)[6])
-{
-    const T t0 = m[3] - (r[1] * m[2] - r[2] * m[1]);
-    const T t1 = m[4] - (r[2] * m[0] - r[0] * m[2]);
-    const T t2 = m[5] - (r[0] * m[1] - r[1] * m[0]);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        o[i] = E[3 * i] * m[0] + E[3 * i + 1] * m[1] + E[3 * i + 2] * m[2];
-        o[3 + i] = E[3 * i] * t0 + E[3 * i + 1] * t1 + E[3 * i + 2] * t2;
-    }
-}
-
-// inverseTransformForceVector: [E^T n + r x (E^T f) ; E^T f]
-template <class T, class R3>
-__device__ __forceinline__ void xforce_inv(const T (&E)[9], R3 r, const T (&f)[6], T (&o)[6])
-{
-    T n[3], l[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        n[i] = E[i] * f[0] + E[3 + i] * f[1] + E[6 + i] * f[2];
-        l[i] = E[i] * f[3] + E[3 + i] * f[4] + E[6 + i] * f[5];
-    }
-    o[0] = n[0] + (r[1] * l[2] - r[2] * l[1]);
-    o[1] = n[1] + (r[2] * l[0] - r[0] * l[2]);
-    o[2] = n[2] + (r[0] * l[1] - r[1] * l[0]);
-    o[3] = l[0];
-    o[4] = l[1];
-    o[5] = l[2];
-}
-
-// R = E^T M E for a general 3x3 M (row-major)
-template <class T>
-__device__ __forceinline__ void rot3(const T (&E)[9], const T (&M)[9], T (&R)[9])
-{
-    T t[9];  // t = M E
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) t[3 * i + j] = M[3 * i] * E[j] + M[3 * i + 1] * E[3 + j] + M[3 * i + 2] * E[6 + j];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) R[3 * i + j] = E[i] * t[j] + E[3 + i] * t[3 + j] + E[6 + i] * t[6 + j];
-}
-
-// R = E^T M E for a SYMMETRIC 3x3 M: only the upper triangle of the second product is computed
-template <class T>
-__device__ __forceinline__ void rot3_sym(const T (&E)[9], const T (&M)[9], T (&R)[9])
-{
-    T t[9];  // t = M E
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) t[3 * i + j] = M[3 * i] * E[j] + M[3 * i + 1] * E[3 + j] + M[3 * i + 2] * E[6 + j];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = i; j < 3; j++) {
-            const T v = E[i] * t[j] + E[3 + i] * t[3 + j] + E[6 + i] * t[6 + j];
-            R[3 * i + j] = v;
-            R[3 * j + i] = v;
-        }
-}
-
-// B = X^T A X for symmetric 6x6 A (packed), X = (E, r):
-// Transform::inverseTransformSpatialInertia (SpatialTransforms.cpp:111-135)
-template <class T, class R3>
-__device__ __forceinline__ void congruence(const T (&E)[9], R3 r, const T (&A)[21], T (&B)[21])
-{
-    T A11[9], A12[9], A22[9], R11[9], R12[9], R22[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            A11[3 * i + j] = A[sidx(i, j)];
-            A12[3 * i + j] = A[sidx(i, 3 + j)];
-            A22[3 * i + j] = A[sidx(3 + i, 3 + j)];
-        }
-    rot3_sym(E, A11, R11);
-    rot3(E, A12, R12);
-    rot3_sym(E, A22, R22);
-    // TR = R12 + r^ R22 ; column j of r^ R22 is r x R22[:, j]
-    T TR[9];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        TR[j] = R12[j] + (r[1] * R22[6 + j] - r[2] * R22[3 + j]);
-        TR[3 + j] = R12[3 + j] + (r[2] * R22[j] - r[0] * R22[6 + j]);
-        TR[6 + j] = R12[6 + j] + (r[0] * R22[3 + j] - r[1] * R22[j]);
-    }
-    // N = R12 r^ (row i = R12[i,:] x r),  P = TR r^ ;  TL = R11 - N^T - P
-    T N[9], Pm[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        N[3 * i + 0] = R12[3 * i + 1] * r[2] - R12[3 * i + 2] * r[1];
-        N[3 * i + 1] = R12[3 * i + 2] * r[0] - R12[3 * i + 0] * r[2];
-        N[3 * i + 2] = R12[3 * i + 0] * r[1] - R12[3 * i + 1] * r[0];
-        Pm[3 * i + 0] = TR[3 * i + 1] * r[2] - TR[3 * i + 2] * r[1];
-        Pm[3 * i + 1] = TR[3 * i + 2] * r[0] - TR[3 * i + 0] * r[2];
-        Pm[3 * i + 2] = TR[3 * i + 0] * r[1] - TR[3 * i + 1] * r[0];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            if (j >= i) {
-                B[sidx(i, j)] = R11[3 * i + j] - N[3 * j + i] - Pm[3 * i + j];
-                B[sidx(3 + i, 3 + j)] = R22[3 * i + j];
-            }
-            B[sidx(i, 3 + j)] = TR[3 * i + j];
-        }
-}
-
-// y = A x for packed symmetric A
-template <class T>
-__device__ __forceinline__ void symv(const T (&A)[21], const T (&x)[6], T (&y)[6])
-{
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        T s = 0;
-#pragma unroll
-        for (int j = 0; j < 6; j++) s += A[sidx(i, j)] * x[j];
-        y[i] = s;
-    }
-}
-template <class T>
-__device__ __forceinline__ void symv_c(cptr<T> A /* wave-uniform constants */, const T (&x)[6], T (&y)[6])
-{
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        T s = 0;
-#pragma unroll
-        for (int j = 0; j < 6; j++) s += A[sidx(i, j)] * x[j];
-        y[i] = s;
-    }
-}
-
-// forceCrossProduct(a, b) (Spatial.h:177-188)
-template <class T>
-__device__ __forceinline__ void crf(const T (&a)[6], const T (&b)[6], T (&o)[6])
-{
-    o[0] = b[2] * a[1] - b[1] * a[2] - b[4] * a[5] + b[5] * a[4];
-    o[1] = b[0] * a[2] - b[2] * a[0] + b[3] * a[5] - b[5] * a[3];
-    o[2] = b[1] * a[0] - b[0] * a[1] - b[3] * a[4] + b[4] * a[3];
-    o[3] = b[5] * a[1] - b[4] * a[2];
-    o[4] = b[3] * a[2] - b[5] * a[0];
-    o[5] = b[4] * a[0] - b[3] * a[1];
-}
-
-// c = motionCrossProduct(v, e_axis * qd) (Spatial.h:131-143): the velocity-product
-// acceleration of a revolute joint about a coordinate axis
-template <class T>
-__device__ __forceinline__ void vxaxis(int axis, const T (&v)[6], T qd, T (&c)[6])
-{
-    if (axis == 0) {
-        c[0] = 0; c[1] = v[2] * qd; c[2] = -v[1] * qd;
-        c[3] = 0; c[4] = v[5] * qd; c[5] = -v[4] * qd;
-    } else if (axis == 1) {
-        c[0] = -v[2] * qd; c[1] = 0; c[2] = v[0] * qd;
-        c[3] = -v[5] * qd; c[4] = 0; c[5] = v[3] * qd;
-    } else {
-        c[0] = v[1] * qd; c[1] = -v[0] * qd; c[2] = 0;
-        c[3] = v[4] * qd; c[4] = -v[3] * qd; c[5] = 0;
-    }
-}
-
-template <class T>
-__device__ __forceinline__ T pick(const T (&x)[6], int axis)
-{
-    return axis == 0 ? x[0] : (axis == 1 ? x[1] : x[2]);
-}
-template <class T>
-__device__ __forceinline__ void column(const T (&A)[21], int axis, T (&h)[6])
-{
-    if (axis == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) h[i] = A[sidx(i, 0)];
-    } else if (axis == 1) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) h[i] = A[sidx(i, 1)];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; i++) h[i] = A[sidx(i, 2)];
-    }
-}
-template <class T>
-__device__ __forceinline__ void add_axis(T (&x)[6], int axis, T val)
-{
-    if (axis == 0) x[0] += val;
-    else if (axis == 1) x[1] += val;
-    else x[2] += val;
-}
-
-// f32: the hardware sine / cosine (v_sin_f32 / v_cos_f32 on x / 2 pi, 11 instructions) instead of the
-// library's sincosf (~155, with a Payne-Hanek path for huge arguments).  Measured on the MIT humanoid and
-// JVRC-1 against the fp64 oracle, joint angles up to +-20 rad: max relative error of ydd 2.5e-6 against 0.8e-6
-// (tolerance of the path: 1e-3); 3-4 % of the ABA kernel time.  The absolute error grows like |x| * 6e-8 for
-// very large angles -- callers who wind joints past ~1e4 rad use the f64 entry points
-// (-DGRBDA_PRECISE_SINCOS restores sincosf).
-#ifdef GRBDA_PRECISE_SINCOS
-__device__ __forceinline__ void sincos_t(float x, float *s, float *c) { sincosf(x, s, c); }
-#else
-__device__ __forceinline__ void sincos_t(float x, float *s, float *c) { __sincosf(x, s, c); }
-#endif
-__device__ __forceinline__ void sincos_t(double x, double *s, double *c) { sincos(x, s, c); }
-// implicit constraints always use the library functions: K_d^-1 amplifies their error near singular poses
-__device__ __forceinline__ void sincos_precise(float x, float *s, float *c) { sincosf(x, s, c); }
-__device__ __forceinline__ void sincos_precise(double x, double *s, double *c) { sincos(x, s, c); }
-
-// reciprocal and reciprocal square root: f32 takes the hardware approximations (1 ulp; the IEEE division
-// expands to ~10 instructions), f64 the exact operations
-__device__ __forceinline__ float rcp_t(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double rcp_t(double x) { return 1.0 / x; }
-__device__ __forceinline__ float rsqrt_t(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double rsqrt_t(double x) { return 1.0 / sqrt(x); }
-
-// in-place Cholesky factor + solves for an N x N SPD matrix held in registers.
-// The reference inverts D = S^T IA S with ColPivHouseholderQR (ClusterTreeNode.cpp:33-37,
-// Utilities.h:325-329); D is SPD so LL^T agrees to rounding.
-template <class T, int N>
-struct Chol {
-    T L[N][N];
-    T inv[N];
-    __device__ __forceinline__ void factor(const T (&A)[N][N])
-    {
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            T d = A[j][j];
-#pragma unroll
-            for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-            const T rs = rsqrt_t(d);
-            inv[j] = rs;
-            L[j][j] = d * rs;
-#pragma unroll
-            for (int i = j + 1; i < N; i++) {
-                T s = A[i][j];
-#pragma unroll
-                for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
-                L[i][j] = s * rs;
-            }
-        }
-    }
-    __device__ __forceinline__ void solve(T (&b)[N]) const
-    {
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            T s = b[i];
-#pragma unroll
-            for (int k = 0; k < i; k++) s -= L[i][k] * b[k];
-            b[i] = s * inv[i];
-        }
-#pragma unroll
-        for (int i = N - 1; i >= 0; i--) {
-            T s = b[i];
-#pragma unroll
-            for (int k = i + 1; k < N; k++) s -= L[k][i] * b[k];
-            b[i] = s * inv[i];
         }
     }
 };
@@ -511,97 +245,6 @@ struct Lane {
     __device__ __forceinline__ T cyd(const ClusterRec &c, int a) const { return qd(c.v_index + a); }
     __device__ __forceinline__ T cx(const ClusterRec &c, int a) const { return x(c.v_index + a); }
 };
-
-// Tile prologue: the batch is row-major ([state][coordinate], the reference's natural vector
-// layout), so one wave's 64 states are ONE contiguous block of 64 * ncols scalars.  The wave copies
-// that block straight into LDS with asynchronous global->LDS loads (no VGPR round trip, all copies
-// of a tile in flight together; LDS holds no live slot at a tile boundary), then reads it back
-// transposed and writes coordinate-major rows into its global slab.  Every later access to an
-// input is a coalesced 64-element row instead of a 64-line strided gather.
-template <class T>
-__device__ __forceinline__ void stage_issue(const T *__restrict__ src, size_t tile, int rows_valid, int ncols,
-                                            unsigned lds_byte_off, int lane)
-{
-    // copy as dwords: element type does not matter for a linear copy
-    const unsigned *blk = reinterpret_cast<const unsigned *>(src + tile * (size_t)kWave * (size_t)ncols);
-    const int n_dw = kWave * ncols * (int)(sizeof(T) / 4);
-    const int n_valid = rows_valid * ncols * (int)(sizeof(T) / 4);
-    for (int base = 0; base < n_dw; base += kWave) {
-        if (base + lane < n_valid)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + lane),
-                                             (__attribute__((address_space(3))) void *)(grbda_smem + lds_byte_off + (unsigned)base * 4u),
-                                             4, 0, 0);
-    }
-}
-// A workgroup is one wavefront, so exchanging data between lanes through LDS needs no s_barrier (and none of
-// the memory-wide waits __syncthreads implies): LDS operations of a wave execute in order, the LDS counter
-// only has to reach zero and the compiler must not move accesses across the point.
-__device__ __forceinline__ void wave_lds_fence()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-template <class T>
-__device__ __forceinline__ void stage_transpose(int ncols, unsigned lds_byte_off, T *slab_rows, int lane)
-{
-    const T *stage = reinterpret_cast<const T *>(grbda_smem + lds_byte_off);
-    for (int c = 0; c < ncols; c++) slab_rows[(size_t)c * kWave + lane] = stage[lane * ncols + c];
-}
-template <class T>
-__device__ __forceinline__ void stage_inputs(const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ x,
-                                             size_t tile, int rows_valid, int nq, int nv, T *slab, int lane,
-                                             int lds_bytes)
-{
-    const unsigned bq = (unsigned)(kWave * nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * nv) * (unsigned)sizeof(T);
-    if ((int)(bq + 2 * bv) <= lds_bytes) {
-        stage_issue(q, tile, rows_valid, nq, 0u, lane);
-        stage_issue(qd, tile, rows_valid, nv, bq, lane);
-        stage_issue(x, tile, rows_valid, nv, bq + bv, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_fence();
-        stage_transpose(nq, 0u, slab, lane);
-        stage_transpose(nv, bq, slab + (size_t)nq * kWave, lane);
-        stage_transpose(nv, bq + bv, slab + (size_t)(nq + nv) * kWave, lane);
-        wave_lds_fence();
-    } else {
-        // LDS too small for the whole tile: one array at a time (capi.cpp guarantees each one fits)
-        stage_issue(q, tile, rows_valid, nq, 0u, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_fence();
-        stage_transpose(nq, 0u, slab, lane);
-        wave_lds_fence();
-        stage_issue(qd, tile, rows_valid, nv, 0u, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_fence();
-        stage_transpose(nv, 0u, slab + (size_t)nq * kWave, lane);
-        wave_lds_fence();
-        stage_issue(x, tile, rows_valid, nv, 0u, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_fence();
-        stage_transpose(nv, 0u, slab + (size_t)(nq + nv) * kWave, lane);
-        wave_lds_fence();
-    }
-}
-
-// Tile epilogue: the nv result rows of the slab ([coordinate][state]) become the tile's [state][coordinate]
-// block of the output array, transposed through LDS (free again: the tile's state is dead) so that the
-// global stores are contiguous.
-template <class T>
-__device__ __forceinline__ void write_outputs(const T *rows, T *__restrict__ out, size_t tile, int rows_valid, int nv,
-                                              int lane)
-{
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the row stores have landed
-    T *stage = reinterpret_cast<T *>(grbda_smem);
-    for (int c = 0; c < nv; c++) stage[lane * nv + c] = rows[(size_t)c * kWave + lane];
-    wave_lds_fence();
-    T *dst = out + tile * (size_t)kWave * (size_t)nv;
-    const int total = rows_valid * nv;
-    for (int i = 0; i < nv; i++) {
-        const int j = i * kWave + lane;
-        if (j < total) dst[j] = stage[j];
-    }
-    wave_lds_fence();
-}
 
 template <class T>
 struct Carry {
@@ -685,8 +328,8 @@ struct ImpLayout {
 
 // walk one sub-chain with positions only: joint axes a_t and origins o_t (NCA coordinates) go to the
 // chain scratch, the constraint point p is returned
-template <class T>
-__device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                      cptr<int32_t> subs, int len, cptr<T> origin, int qs_slot,
                                                      int chain_slot, T (&p)[3])
 {
@@ -721,8 +364,8 @@ __device__ __forceinline__ void loop_chain_positions(const Tables<T> &P, const S
 }
 
 // ---- K(q) and Kdot*qd of URDF+ position loops --------------------------------------------------
-template <class T, int N>
-__device__ __forceinline__ void loop_position_K(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, class SL>
+__device__ __forceinline__ void loop_position_K(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                 const ImpLayout<N> &lay, cptr<int32_t> loops, int n_loops,
                                                 T *phi = nullptr /* [3]: p_pred - p_succ on the masked axes */)
 {
@@ -772,8 +415,8 @@ __device__ __forceinline__ void loop_position_K(const Tables<T> &P, const Slots<
 }
 
 // velocity-product acceleration of the constraint points: (Kdot qd)[row]
-template <class T, int N>
-__device__ __forceinline__ void loop_position_Kdqd(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, class SL>
+__device__ __forceinline__ void loop_position_Kdqd(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                    const ImpLayout<N> &lay, cptr<int32_t> loops, int n_loops, T (&kdq)[3])
 {
     cptr<int32_t> lp = loops;
@@ -837,8 +480,8 @@ __device__ __forceinline__ void loop_position_Kdqd(const Tables<T> &P, const Slo
 // (the hand-written phi lambdas of the Tello differentials, src/Robots/Tello.cpp:139-163,237-261; the
 // reference differentiates them with CasADi, here analytically).  want_K: K rows to scratch;
 // otherwise the second directional derivative along qd_span goes to kdq.
-template <class T, int N>
-__device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, class SL>
+__device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                const ImpLayout<N> &lay, cptr<int32_t> prog, bool want_K, T (&kdq)[3],
                                                T *phi = nullptr /* [3]: constraint values, with want_K */)
 {
@@ -941,8 +584,8 @@ __device__ __forceinline__ void trig_poly_eval(const Tables<T> &P, const Slots<T
 }
 
 // G rows, g, spanning positions / velocities of an implicit cluster into the scratch block
-template <class T, int N>
-__device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, class SL>
+__device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                   const Lane<T> &L, const T (&yd)[N], bool want_bias)
 {
     const ImpLayout<N> lay(c.slot_imp_fwd, c.slot_imp_bwd, c.k, c.rows);
@@ -1037,8 +680,8 @@ struct RowSel<T, N, true> {
     using type = RegRow<T, N>;
 };
 
-template <class T, int N, bool LOOP>
-__device__ __forceinline__ void body_coupling(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c, int imp_base,
+template <class T, int N, bool LOOP, class SL>
+__device__ __forceinline__ void body_coupling(const Tables<T> &P, const SL &S, const ClusterRec &c, int imp_base,
                                               int i, cptr<T> C, const T (&y)[N], T &qi,
                                               typename RowSel<T, N, LOOP>::type &Gr, T &gi)
 {
@@ -1075,8 +718,8 @@ __device__ __forceinline__ T rdot(const Row &G, const T (&y)[N])
 // TreeModel.cpp:20-27).  Only the general kernel variant carries this code.
 // ---------------------------------------------------------------------------------------------
 // Xa = X * Xa_parent:  E = E_i E_p,  r = r_p + E_p^T r_i   (SpatialTransforms.cpp:149-157)
-template <class T, class R3>
-__device__ __forceinline__ void compose_absolute(const Slots<T> &S, int parent_slot_Xa, const T (&E)[9], R3 r, T (&Xa)[12])
+template <class T, class R3, class SL>
+__device__ __forceinline__ void compose_absolute(const SL &S, int parent_slot_Xa, const T (&E)[9], R3 r, T (&Xa)[12])
 {
     if (parent_slot_Xa >= 0) {
         T Xp[12];
@@ -1114,8 +757,8 @@ __device__ __forceinline__ void subtract_external_force(const Lane<T> &L, int bo
 // kinematics of one revolute body: joint transform and spatial velocity.  Bodies with children
 // were handled by the forward sweep (sin/cos and v are in their slots); leaf bodies are evaluated
 // here from the parent's stored velocity, so they never occupy a slot.
-template <class T>
-__device__ __forceinline__ void body_kinematics(const Tables<T> &P, const Slots<T> &S, const BodyRec &b, cptr<T> C,
+template <class T, class SL>
+__device__ __forceinline__ void body_kinematics(const Tables<T> &P, const SL &S, const BodyRec &b, cptr<T> C,
                                                 T qi, T qdi, T (&sc)[2], T (&E)[9], T (&v)[6])
 {
     if (b.has_child) {
@@ -1147,8 +790,8 @@ __device__ __forceinline__ void body_kinematics(const Tables<T> &P, const Slots<
 // ABA sweep 1: ClusterTreeNode::updateKinematics + TreeModel::forwardKinematics
 // (ClusterTreeNode.cpp:26-31, TreeModel.cpp:6-32) -- only bodies that have children
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP, bool GEN>
-__device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, bool LOOP, bool GEN, class SL>
+__device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
     T y[N], yd[N];
@@ -1190,31 +833,6 @@ __device__ __forceinline__ void aba_fwd_static(const Tables<T> &P, const Slots<T
     }
 }
 
-// quaternionToRotationMatrix (OrientationTools.h:251-269) / rpyToRotMat (:121-130)
-template <class T>
-__device__ __forceinline__ void free_rotation(int ori_repr, const T *o, T (&E)[9])
-{
-    if (ori_repr == 0) {
-        const T e0 = o[0], e1 = o[1], e2 = o[2], e3 = o[3];
-        E[0] = 1 - 2 * (e2 * e2 + e3 * e3); E[3] = 2 * (e1 * e2 - e0 * e3);     E[6] = 2 * (e1 * e3 + e0 * e2);
-        E[1] = 2 * (e1 * e2 + e0 * e3);     E[4] = 1 - 2 * (e1 * e1 + e3 * e3); E[7] = 2 * (e2 * e3 - e0 * e1);
-        E[2] = 2 * (e1 * e3 - e0 * e2);     E[5] = 2 * (e2 * e3 + e0 * e1);     E[8] = 1 - 2 * (e1 * e1 + e2 * e2);
-    } else {
-        T sx, cx, sy, cy, sz, cz;
-        sincos_t(o[0], &sx, &cx);
-        sincos_t(o[1], &sy, &cy);
-        sincos_t(o[2], &sz, &cz);
-        // Rx * Ry * Rz with coordinate rotations
-        const T Rxy[9] = {cy, 0, -sy, sx * sy, cx, sx * cy, cx * sy, -sx, cx * cy};
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            E[3 * i + 0] = Rxy[3 * i] * cz - Rxy[3 * i + 1] * sz;
-            E[3 * i + 1] = Rxy[3 * i] * sz + Rxy[3 * i + 1] * cz;
-            E[3 * i + 2] = Rxy[3 * i + 2];
-        }
-    }
-}
-
 // Free cluster (FreeJoint.cpp:28-46, Joint.h:61-68): Xup = XJ = (R(ori), position), v = yd.
 // a' = Xup * (-gravity); needs only E because -gravity has no angular part in general? No:
 // the general formula is kept.
@@ -1252,8 +870,8 @@ __device__ __forceinline__ void free_base_accel(const Tables<T> &P, const Cluste
 // ABA sweep 2 (fused 2a + 2b): updateArticulatedBodies + bias back-propagation
 // (ClusterTreeDynamics.cpp:94-129,157-191; ClusterTreeNode.cpp:33-37)
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP, bool GEN>
-__device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, bool LOOP, bool GEN, class SL>
+__device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                const Lane<T> &L, Carry<T> &carry PROF_ARGS)
 {
     T y[N], yd[N], u[N], F[6][N], D[N][N];
@@ -1344,8 +962,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
             for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
         } else if (b.has_child) {
             T acc[21], pacc[6];
-            S.ld(b.slot_IA, acc);
-            S.ld(b.slot_psi, pacc);
+            S.ldK(b.slot_IA, acc);
+            S.ldK(b.slot_psi, pacc);
 #pragma unroll
             for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
@@ -1384,7 +1002,7 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
                     for (int j = 0; j < 6; j++) ppsi[j] += tp[j];
                 } else {
-                    S.acc(b.parent_slot_psi, tp, b.acc_first);
+                    S.accK(b.parent_slot_psi, tp, b.acc_first);
                 }
             } else {
                 congruence(E, C + 9, IA, Bc);
@@ -1394,8 +1012,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
                     for (int j = 0; j < 21; j++) pIA[j] += Bc[j];
                 } else {
-                    S.acc(b.parent_slot_psi, tp, b.acc_first);
-                    S.acc(b.parent_slot_IA, Bc, b.acc_first_IA);
+                    S.accK(b.parent_slot_psi, tp, b.acc_first);
+                    S.accK(b.parent_slot_IA, Bc, b.acc_first_IA);
                 }
             }
         }
@@ -1452,8 +1070,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
         for (int a = 0; a < N; a++) K[a * 6 + r] = col[a];
     }
-    S.st(c.slot_K, K);
-    S.st(c.slot_y0, u);
+    S.stK(c.slot_K, K);
+    S.stK(c.slot_y0, u);
 
     // corrections on the parent body: IA_p -= F D^-1 F^T, pA_p += F D^-1 u'
     if (c.parent_body >= 0) {
@@ -1478,8 +1096,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 #pragma unroll
             for (int j = 0; j < 21; j++) carry.IA[j] = pIA[j] + dI[j];
         } else {
-            S.acc(c.parent_slot_psi, dp, 0);
-            S.acc(c.parent_slot_IA, dI, c.corr_first_IA);
+            S.accK(c.parent_slot_psi, dp, 0);
+            S.accK(c.parent_slot_IA, dI, c.corr_first_IA);
         }
     }
     PROF_SYNC();
@@ -1487,8 +1105,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const Slots<T
 }
 
 // Free root: S = 1, D = IA, c = 0 (FreeJoint.cpp:10-36)
-template <class T>
-__device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                              const Lane<T> &L, const Carry<T> &carry)
 {
     const BodyRec b = load_rec(P.bodies + (c.first_body));
@@ -1512,8 +1130,8 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
         for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
     } else if (b.has_child) {
         T acc[21], pacc[6];
-        S.ld(b.slot_IA, acc);
-        S.ld(b.slot_psi, pacc);
+        S.ldK(b.slot_IA, acc);
+        S.ldK(b.slot_psi, pacc);
 #pragma unroll
         for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
@@ -1532,7 +1150,7 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
     Chol<T, 6> ch;
     ch.factor(D);
     ch.solve(u);
-    S.st(c.slot_y0, u);
+    S.stK(c.slot_y0, u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1543,28 +1161,8 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const Slots<T> 
 // the parent, which removes most of the register shuffling the generic code needs.  Fast kernels only
 // (canonical axes: every joint turns about z).
 // ---------------------------------------------------------------------------------------------
-template <class T>
-__device__ __forceinline__ void rotate_z(T s, T c, cptr<T> Et, T (&E)[9])
-{
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        E[j] = c * Et[j] + s * Et[3 + j];
-        E[3 + j] = c * Et[3 + j] - s * Et[j];
-        E[6 + j] = Et[6 + j];
-    }
-}
-
-// y = A x for packed symmetric A and a revolute-about-z velocity product x = (x0, x1, 0, x3, x4, 0)
-template <class T, class A21>
-__device__ __forceinline__ void symv_z(const A21 &A, const T (&x)[6], T (&y)[6])
-{
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-        y[i] = A[sidx(i, 0)] * x[0] + A[sidx(i, 1)] * x[1] + A[sidx(i, 3)] * x[3] + A[sidx(i, 4)] * x[4];
-}
-
-template <class T, bool ROTOR>
-__device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, bool ROTOR, class SL>
+__device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                             const Lane<T> &L, Carry<T> &carry)
 {
     // (the plan compiler gives these shapes only to clusters with a parent body)
@@ -1573,10 +1171,11 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
     const T g0 = C[kBodyConstFixed];
     const T yd = L.cyd(c, 0);
     const T qdi = g0 * yd;
+    const bool has_child = b.has_child, carry_in = b.carry_in, carry_out = c.carry_out;
 
     // ---- link kinematics (TreeModel.cpp:6-32) ----
     T E[9], v[6], vp[6];
-    if (b.has_child) {
+    if (has_child) {
         T sc[2];
         S.ld(b.slot_sc, sc);
         S.ld(b.slot_v, v);
@@ -1603,15 +1202,15 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
     }
     // own inertia, plus the constant X0^T I X0 of axisymmetric leaf children (rotors) when there are any
     cptr<T> Ib = b.xofs >= 0 ? P.consts + b.xofs : Ic;
-    if (b.carry_in) {
+    if (carry_in) {
 #pragma unroll
         for (int j = 0; j < 21; j++) IA[j] = Ib[j] + carry.IA[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) psi[j] += carry.psi[j];
-    } else if (b.has_child) {
+    } else if (has_child) {
         T acc[21], pacc[6];
-        S.ld(b.slot_IA, acc);
-        S.ld(b.slot_psi, pacc);
+        S.ldK(b.slot_IA, acc);
+        S.ldK(b.slot_psi, pacc);
 #pragma unroll
         for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
@@ -1686,8 +1285,8 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
     T K[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) K[r] = F[r] * Dinv;
-    S.st(c.slot_K, K);
-    S.st1(c.slot_y0, y0);
+    S.stK(c.slot_K, K);
+    S.stK1(c.slot_y0, y0);
 
     // ---- one combined hand-over to the parent body: X^T IA X - F D^-1 F^T,  X^T (pA + IA c) + F D^-1 u' ----
 #pragma unroll
@@ -1696,20 +1295,20 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const Slots<T> &
 #pragma unroll
         for (int cc = r; cc < 6; cc++) out_IA[sidx(r, cc)] -= F[r] * K[cc];
     }
-    if (c.carry_out) {
+    if (carry_out) {
 #pragma unroll
         for (int j = 0; j < 6; j++) carry.psi[j] = out_psi[j];
 #pragma unroll
         for (int j = 0; j < 21; j++) carry.IA[j] = out_IA[j];
     } else {
-        S.acc(c.parent_slot_psi, out_psi, first_psi);
-        S.acc(c.parent_slot_IA, out_IA, b.acc_first_IA | c.corr_first_IA);
+        S.accK(c.parent_slot_psi, out_psi, first_psi);
+        S.accK(c.parent_slot_IA, out_IA, b.acc_first_IA | c.corr_first_IA);
     }
 }
 
 // acceleration sweep of the same shapes (ClusterTreeDynamics.cpp:131-152); a rotor has no children
-template <class T>
-__device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                             const Lane<T> &L, const T (&kblk)[7], bool have_kblk PROF_ARGS)
 {
     T K[6], ap[6], ydd;
@@ -1720,8 +1319,8 @@ __device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &
         for (int r = 0; r < 6; r++) K[r] = kblk[r];
         ydd = kblk[6];
     } else {
-        S.ld(c.slot_K, K);
-        ydd = S.ld1(c.slot_y0);
+        S.ldK(c.slot_K, K);
+        ydd = S.ldK1(c.slot_y0);
     }
     S.ld(c.parent_slot_a3, ap);
     PROF_SYNCV();
@@ -1760,8 +1359,8 @@ __device__ __forceinline__ void aba_acc_rev(const Tables<T> &P, const Slots<T> &
 }
 
 // forward sweep of the same shapes: only a link with children leaves anything behind
-template <class T>
-__device__ __forceinline__ void aba_fwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void aba_fwd_rev(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                             const Lane<T> &L)
 {
     if (!c.child_mask) return;
@@ -1785,8 +1384,8 @@ __device__ __forceinline__ void aba_fwd_rev(const Tables<T> &P, const Slots<T> &
 // ABA sweep 3: joint accelerations (ClusterTreeDynamics.cpp:131-152).  Velocities of bodies with
 // children are recomputed on the way down (cheaper than keeping them live across the sweeps).
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP, bool GEN>
-__device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, bool LOOP, bool GEN, class SL>
+__device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                const Lane<T> &L)
 {
     T K[6 * N], ydd[N], ap[6];
@@ -1794,8 +1393,8 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
     for (int j = 0; j < 6 * N; j++) K[j] = T(0.01) * j;
     for (int j = 0; j < N; j++) ydd[j] = T(0.5);
 #else
-    S.ld(c.slot_K, K);
-    S.ld(c.slot_y0, ydd);
+    S.ldK(c.slot_K, K);
+    S.ldK(c.slot_y0, ydd);
 #endif
     if (c.parent_slot_a3 >= 0) {
         S.ld(c.parent_slot_a3, ap);
@@ -1851,13 +1450,13 @@ __device__ __forceinline__ void aba_acc_static(const Tables<T> &P, const Slots<T
     }
 }
 
-template <class T>
-__device__ __forceinline__ void aba_acc_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void aba_acc_free(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                              const Lane<T> &L)
 {
     const BodyRec b = load_rec(P.bodies + (c.first_body));
     T y0[6], ag[6];
-    S.ld(c.slot_y0, y0);
+    S.ldK(c.slot_y0, y0);
     free_base_accel(P, c, L, ag);
     // ydd = D^-1 u - D^-1 U^T a' with U = IA, D = IA  =>  ydd = y0 - a' ;  a = a' + ydd = y0
 #pragma unroll
@@ -1873,8 +1472,8 @@ __device__ __forceinline__ void aba_acc_free(const Tables<T> &P, const Slots<T> 
 }
 
 // free root, forward sweep: children only need its velocity
-template <class T>
-__device__ __forceinline__ void aba_fwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void aba_fwd_free(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                              const Lane<T> &L)
 {
     const BodyRec b = load_rec(P.bodies + (c.first_body));
@@ -1893,8 +1492,8 @@ __device__ __forceinline__ void aba_fwd_free(const Tables<T> &P, const Slots<T> 
 // ---------------------------------------------------------------------------------------------
 // RNEA (TreeModel.cpp:34-57,173-212)
 // ---------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP, bool GEN>
-__device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, bool LOOP, bool GEN, class SL>
+__device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                 const Lane<T> &L)
 {
     T y[N], yd[N], ydd[N];
@@ -1957,8 +1556,8 @@ __device__ __forceinline__ void rnea_fwd_static(const Tables<T> &P, const Slots<
     }
 }
 
-template <class T>
-__device__ __forceinline__ void rnea_fwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void rnea_fwd_free(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                               const Lane<T> &L)
 {
     const BodyRec b = load_rec(P.bodies + (c.first_body));
@@ -1989,8 +1588,8 @@ __device__ __forceinline__ void rnea_fwd_free(const Tables<T> &P, const Slots<T>
     S.st(b.slot_f, f);
 }
 
-template <class T, int N, bool LOOP, bool GEN>
-__device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, int N, bool LOOP, bool GEN, class SL>
+__device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                                 const Lane<T> &L)
 {
     T tau[N], y[N], yd[N];
@@ -2025,8 +1624,8 @@ __device__ __forceinline__ void rnea_bwd_static(const Tables<T> &P, const Slots<
         L.put(c.v_index + a, tau[a]);
 }
 
-template <class T>
-__device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, class SL>
+__device__ __forceinline__ void rnea_bwd_free(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                               const Lane<T> &L)
 {
     const BodyRec b = load_rec(P.bodies + (c.first_body));
@@ -2053,8 +1652,8 @@ __device__ __forceinline__ void body_force(const I21 &Ic, const T (&v)[6], const
     for (int j = 0; j < 6; j++) f[j] += Ia[j];
 }
 
-template <class T, bool ROTOR>
-__device__ __forceinline__ void rnea_fwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, bool ROTOR, class SL>
+__device__ __forceinline__ void rnea_fwd_rev(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                              const Lane<T> &L)
 {
     const BodyRec b = load_rec(P.bodies + c.link_body);
@@ -2120,8 +1719,8 @@ __device__ __forceinline__ void rnea_fwd_rev(const Tables<T> &P, const Slots<T> 
 }
 
 // backward step of a link with children (the plan drops the step for childless links)
-template <class T, bool ROTOR>
-__device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c,
+template <class T, bool ROTOR, class SL>
+__device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const SL &S, const ClusterRec &c,
                                              const Lane<T> &L)
 {
     const BodyRec b = load_rec(P.bodies + c.link_body);
@@ -2143,6 +1742,16 @@ __device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const Slots<T> 
 // HAS_LOOP is a kernel template parameter: models without implicit-loop clusters run a kernel that
 // does not contain the loop-constraint code at all (code size and register pressure matter: the
 // interpreter loop must stay resident in the instruction cache)
+#ifdef GRBDA_EXP_NMAX2
+#define GRBDA_EXP_BIG_N(FN, ...)
+#else
+#define GRBDA_EXP_BIG_N(FN, ...)                           \
+    case 3: FN<T, 3, false, HAS_LOOP>(__VA_ARGS__); break; \
+    default: FN<T, 4, false, HAS_LOOP>(__VA_ARGS__); break;
+#endif
+#ifdef GRBDA_EXP_SHAPES_ONLY
+#define GRBDA_DISPATCH_N(c, FN, ...) {}
+#else
 #define GRBDA_DISPATCH_N(c, FN, ...)                                                        \
     if (HAS_LOOP && (c).kind == CK_LOOP) {                                                     \
         if constexpr (HAS_LOOP) {                                                              \
@@ -2156,15 +1765,15 @@ __device__ __forceinline__ void rnea_bwd_rev(const Tables<T> &P, const Slots<T> 
         switch ((c).n) {                                                                       \
             case 1: FN<T, 1, false, HAS_LOOP>(__VA_ARGS__); break;                                       \
             case 2: FN<T, 2, false, HAS_LOOP>(__VA_ARGS__); break;                                       \
-            case 3: FN<T, 3, false, HAS_LOOP>(__VA_ARGS__); break;                                       \
-            default: FN<T, 4, false, HAS_LOOP>(__VA_ARGS__); break;                                      \
+            GRBDA_EXP_BIG_N(FN, __VA_ARGS__)                                                             \
         }                                                                                      \
     }
+#endif
 
 // WPS: wavefronts per SIMD the kernel is register-allocated for.  f32: 2.  f64: the fast kernel exists for 1
 // (no spills; small batches that cannot fill two anyway) and for 2 (~280 spilled registers, still 4-12 %
 // faster once the batch fills the chip); the launcher picks.
-template <class T, bool HAS_LOOP, int WPS>
+template <class T, bool HAS_LOOP, int WPS, bool SPLIT = false>
 __global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                      const T *__restrict__ qd, const T *__restrict__ tau,
                                                      T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
@@ -2174,7 +1783,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T 
     // the straight-line shape handlers carry no external-force code: layouts with absolute transforms
     // (DP.fext set) run every cluster through the generic handlers
     const bool use_shapes = !HAS_LOOP || DP.fext == nullptr;
-    Slots<T> S;
+    Slots<T, SPLIT> S;
     S.lane = lane;
     // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
@@ -2241,7 +1850,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T 
                 if (use_shapes && !c.shape) {  // generic / free step: start the prefetch chain for a following shape step
                     const int knext = P.acc_k[s + 1];
                     kpre_valid = knext != -1;
-                    if (kpre_valid) S.ld(knext, kpre);
+                    if (kpre_valid) S.ldK(knext, kpre);
                 }
                 if (c.kind == CK_FREE) {
                     aba_acc_free(P, S, c, L);
@@ -2253,7 +1862,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T 
                     // fetch the next step's [K][y0] block now: it has this whole step to arrive
                     const int knext = P.acc_k[s + 1];
                     kpre_valid = knext != -1;
-                    if (kpre_valid) S.ld(knext, kpre);
+                    if (kpre_valid) S.ldK(knext, kpre);
                     aba_acc_rev<T>(P, S, c, L, kblk, have PROF_PASS);
                 } else {
                     GRBDA_DISPATCH_N(c, aba_acc_static, P, S, c, L)
@@ -2270,7 +1879,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T 
 #endif
 }
 
-template <class T, bool HAS_LOOP>
+template <class T, bool HAS_LOOP, bool SPLIT = false>
 __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *__restrict__ q,
                                                       const T *__restrict__ qd, const T *__restrict__ ydd,
                                                       T *__restrict__ tau, size_t B, T *__restrict__ scratch)
@@ -2280,7 +1889,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
     // the straight-line shape handlers carry no external-force code: layouts with absolute transforms
     // (DP.fext set) run every cluster through the generic handlers
     const bool use_shapes = !HAS_LOOP || DP.fext == nullptr;
-    Slots<T> S;
+    Slots<T, SPLIT> S;
     S.lane = lane;
     // wave slab: [nq + 2 nv input rows][n_glb_slots state rows], 64 scalars per row
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
@@ -2339,8 +1948,8 @@ __global__ __launch_bounds__(kWave, 2) void rnea_kernel(DevPlan<T> DP, const T *
 // qd_span = G yd, qdd_span = G ydd + g (ClusterJoint.cpp:55-58; the benchmarks' pinocchioBenchmark.cpp:168-176).
 // Not hot: one state per lane, inputs read straight from the batch arrays.
 // ---------------------------------------------------------------------------------------------
-template <class T, int N>
-__device__ __forceinline__ void project_cluster(const Tables<T> &P, const Slots<T> &S, const ClusterRec &c, T *qrow,
+template <class T, int N, class SL>
+__device__ __forceinline__ void project_cluster(const Tables<T> &P, const SL &S, const ClusterRec &c, T *qrow,
                                                 int max_iter, T tol, bool &good)
 {
     const ImpLayout<N> lay(c.slot_imp_fwd, c.slot_imp_bwd, c.k, c.rows);
@@ -2554,6 +2163,14 @@ __global__ __launch_bounds__(kWave, 1) void spanning_kernel(DevPlan<T> DP, int n
     }
 }
 
+#ifdef GRBDA_EXP_ONLY_ABA32
+// compile-time experiments (register budgets): only the fast f32 ABA kernel is instantiated
+#ifdef GRBDA_EXP_SPLIT
+template __global__ void aba_kernel<float, false, GRBDA_ABA32_WAVES, true>(DevPlan<float>, const float *, const float *, const float *, float *, size_t, float *);
+#else
+template __global__ void aba_kernel<float, false, GRBDA_ABA32_WAVES>(DevPlan<float>, const float *, const float *, const float *, float *, size_t, float *);
+#endif
+#else
 // ---------------------------------------------------------------------------------------------
 // host launchers (called by capi.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -2565,6 +2182,8 @@ hipError_t launch_aba(const DevPlan<T> &P, const T *q, const T *qd, const T *tau
     if constexpr (sizeof(T) == 4) {
         if (P.general)
             hipLaunchKernelGGL((aba_kernel<T, true, W32>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+        else if (P.split)
+            hipLaunchKernelGGL((aba_kernel<T, false, W32, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
         else
             hipLaunchKernelGGL((aba_kernel<T, false, W32>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     } else {
@@ -2583,6 +2202,8 @@ hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *yd
 {
     if (P.general)
         hipLaunchKernelGGL((rnea_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else if (sizeof(T) == 4 && P.split)
+        hipLaunchKernelGGL((rnea_kernel<T, false, sizeof(T) == 4>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     else
         hipLaunchKernelGGL((rnea_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
@@ -2632,6 +2253,8 @@ template hipError_t launch_rnea<float>(const DevPlan<float> &, const float *, co
 template hipError_t launch_rnea<double>(const DevPlan<double> &, const double *, const double *, const double *,
                                         double *, size_t, double *, int, size_t, hipStream_t);
 
+#endif  // GRBDA_EXP_ONLY_ABA32
+
 #ifdef GRBDA_PROFILE
 extern "C" int grbda_debug_profile(unsigned long long *out, int reset)
 {
@@ -2644,6 +2267,7 @@ extern "C" int grbda_debug_profile(unsigned long long *out, int reset)
 }
 #endif
 
+#ifndef GRBDA_EXP_ONLY_ABA32
 hipError_t set_max_dynamic_lds()
 {
     const int maxb = 160 * 1024;
@@ -2652,6 +2276,8 @@ hipError_t set_max_dynamic_lds()
                          reinterpret_cast<const void *>(&spanning_kernel<float>),
                          reinterpret_cast<const void *>(&spanning_kernel<double>),
                          reinterpret_cast<const void *>(&aba_kernel<float, false, GRBDA_ABA32_WAVES>),
+                         reinterpret_cast<const void *>(&aba_kernel<float, false, GRBDA_ABA32_WAVES, true>),
+                         reinterpret_cast<const void *>(&rnea_kernel<float, false, true>),
                          reinterpret_cast<const void *>(&aba_kernel<float, true, GRBDA_ABA32_WAVES>),
                          reinterpret_cast<const void *>(&aba_kernel<double, false, 1>),
                          reinterpret_cast<const void *>(&aba_kernel<double, false, 2>),
@@ -2666,5 +2292,7 @@ hipError_t set_max_dynamic_lds()
     }
     return hipSuccess;
 }
+
+#endif
 
 }  // namespace grbda_hip

@@ -495,6 +495,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
     }
 
+    for (int c = 0; c < nc; c++) {
+        ClusterRec &cr = clusters[c];
+        cr.hot = cr.shape != SHAPE_GENERIC && cr.carry_out && bodies[cr.link_body].has_child && bodies[cr.link_body].carry_in;
+    }
+
     if (sweep_mask != 7) {  // profiling aid: drop whole sweeps (results are then meaningless)
         std::vector<Step> kept;
         for (const Step &st : P.aba_steps)
@@ -508,8 +513,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     struct Obj {
         int *field;  // where the slot number goes (index into a flat array of fields)
         int size, prio, birth, death, slot;
+        int force = 0;  // split layouts: 1 must live in LDS, 2 must live in the global slab
     };
-    auto allocate = [](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb) {
+    // returns false when an object that must live in LDS does not fit the budget
+    auto allocate = [](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb) -> bool {
+        bool ok = true;
         const int lds_base = 0;
         std::vector<int> order(objs.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = static_cast<int>(i);
@@ -539,7 +547,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         };
         for (int oi : order) {
             Obj &o = objs[oi];
-            int at = first_fit(o, placed_lds, false, lds_budget);
+            int at = o.force == 2 ? -1 : first_fit(o, placed_lds, false, lds_budget);
+            if (at < 0 && o.force == 1) ok = false;
             if (at >= 0) {
                 o.slot = at + lds_base;
                 placed_lds.push_back(oi);
@@ -552,10 +561,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             *o.field = o.slot;
         }
+        return ok;
     };
 
     auto cluster_of = [&](int b) { return m.bodies[b].cluster; };
-    auto build_layout = [&](Layout &L, int lds_budget, int lds_budget_rnea, bool with_xa) {
+    auto build_layout = [&](Layout &L, int lds_budget, int lds_budget_rnea, bool with_xa, bool split = false) {
+        L.split_aba = L.split_rnea = false;
 
         L.clusters = clusters;
         L.rnea_clusters = clusters;
@@ -606,7 +617,18 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
         }
         int nl = 0, ng = 0;
-        allocate(objs, lds_budget, nl, ng);
+        if (split) {
+            // [K | y0] blocks in the global slab, everything else in LDS (kernels.hip, Slots<T, true>)
+            for (Obj &o : objs) o.force = 1;
+            for (int c = 0; c < nc; c++)
+                for (Obj &o : objs)
+                    if (o.field == &L.clusters[c].slot_K || o.field == &L.clusters[c].slot_y0) o.force = 2;
+            // ... and so do the backward accumulators of branching bodies (rarely touched, 27 scalars each)
+            for (int b = 0; b < nb; b++)
+                for (Obj &o : objs)
+                    if (o.field == &L.bodies[b].slot_IA || o.field == &L.bodies[b].slot_psi) o.force = 2;
+        }
+        L.split_aba = allocate(objs, lds_budget, nl, ng) && split;
         L.n_lds_aba = nl;
         L.n_glb_aba = ng;
         for (int c = 0; c < nc; c++)
@@ -715,7 +737,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 robjs.push_back({&cr.slot_imp_bwd, tmp, -1, tRF[c], tRF[c], -1});
             }
         }
-        allocate(robjs, lds_budget_rnea, nl, ng);
+        if (split)
+            for (Obj &o : robjs) o.force = 1;
+        L.split_rnea = allocate(robjs, lds_budget_rnea, nl, ng) && split;
         L.n_lds_rnea = nl;
         L.n_glb_rnea = ng;
         for (int b = 0; b < nb; b++) {
@@ -736,6 +760,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     build_layout(P.lay32, lds.aba32, lds.rnea32, false);
     build_layout(P.lay64, lds.aba64, lds.rnea64, false);
     build_layout(P.lay32x, lds.aba32, lds.rnea32, true);
+    // split layout of the fast f32 kernels; unusable (split_* false) when the LDS-only objects exceed the budget
+    build_layout(P.lay32s, lds.aba32, lds.rnea32, false, true);
+    for (const ClusterRec &cr : clusters)
+        if (cr.kind == CK_LOOP) P.lay32s.split_aba = P.lay32s.split_rnea = false;
     build_layout(P.lay64x, lds.aba64, lds.rnea64, true);
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------

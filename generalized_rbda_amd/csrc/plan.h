@@ -85,7 +85,8 @@ struct ClusterRec {
     int32_t shape;            // ClusterShape: clusters the fast kernels run through straight-line handlers
     int32_t link_body;        // SHAPE_REV / SHAPE_REV_ROTOR: global index of the link ...
     int32_t rotor_body;       // ... and of the rotor
-    int32_t reserved;
+    int32_t hot;              // shape clusters inside a chain: the link has children, its backward accumulators arrive in
+                              // registers and its contribution leaves in registers (kernels.hip, aba_bwd_rev<.., HOT>)
 };
 
 // Shapes with a dedicated handler.  SHAPE_REV: one revolute body, one coordinate.  SHAPE_REV_ROTOR: a link
@@ -140,6 +141,9 @@ struct Layout {
     // per ABA step: slot of the [K][y0] block the step reads when it is an acceleration step of a
     // straight-line shape, else -1; padded by one.  The kernel fetches entry s + 1 while it runs step s.
     std::vector<int32_t> acc_k;
+    // split layouts (kernels.hip, Slots<T, true>): every [K | y0] block in the global slab, every other object in LDS;
+    // false when the layout was not built that way or the LDS-only objects did not fit the budget
+    bool split_aba = false, split_rnea = false;
 };
 
 // LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
@@ -158,6 +162,7 @@ struct HostPlan {
     std::vector<int32_t> cints;  // integer payload of implicit constraints
     Layout lay32, lay64;      // fast path
     Layout lay32x, lay64x;    // with absolute transforms kept for external forces (TreeNode::Xa_)
+    Layout lay32s;            // f32 fast path, split layout (used when split_aba / split_rnea)
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };

@@ -91,6 +91,9 @@ typedef struct {
     double bytes_aba_f32, bytes_aba_f64; /* algorithmic bytes per evaluation: (nq+2nv+nv)*s */
     int n_axisym_bodies;  /* leaf bodies evaluated at q = 0 (rotors), see plan.h */
     int n_carry_clusters; /* clusters whose projected inertia is handed over in registers */
+    int split_aba_f32, split_rnea_f32; /* 1: the f32 kernel runs the split layout ([K | y0] blocks in the global slab,
+                                          every other object in LDS, plan.h Layout::split_*) */
+    int n_lds_slots_split_f32;
 } grbda_plan_info_t;
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 

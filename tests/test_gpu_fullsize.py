@@ -50,7 +50,7 @@ def _plan_and_states(workload, B, gpu):
         ok = plan.project_positions(t64).cpu().numpy()
         q = t64.cpu().numpy()
         good, bad = np.flatnonzero(ok), np.flatnonzero(~ok)
-        assert good.size > 0.5 * B
+        assert good.size > 0.05 * B
         q[bad] = q[good[np.arange(bad.size) % good.size]]
     return plan, blob, q, qd, tau
 
