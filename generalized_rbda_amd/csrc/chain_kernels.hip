@@ -1,0 +1,643 @@
+// chain_kernels.hip -- chain-structured cluster ABA for gfx950 (MI355X): the fast path of the f32 forward dynamics.
+//
+// Same execution model as kernels.hip (one robot state per lane, 64 states per wavefront, one wavefront per
+// workgroup, the model read through the scalar unit) and the same algorithm -- the structured restatement of
+// ClusterTreeModel::forwardDynamics / updateArticulatedBodies (src/Dynamics/ClusterTreeDynamics.cpp:85-191) described at
+// the top of kernels.hip -- but a different program shape.  kernels.hip interprets one (sweep, cluster) step per loop
+// iteration; every quantity that crosses a step boundary in registers (the projected inertia handed to the parent, the
+// prefetched [K | y0] block) is then loop-carried through a loop with two dozen paths, and the compiler pays for it
+// with register copies at the latch, 200+ VGPRs and control-flow scaffolding around every slot access.
+// Here the plan compiler cuts the cluster tree into CHAINS (plan.h, ChainProgram) and a sweep over a chain is one
+// tight single-path loop: velocities / accelerations going down and the articulated inertia / bias going up stay
+// in registers from link to link; what another segment needs goes through LDS; the [K | y0] blocks go to the wave's
+// global slab (written once by the backward run, read once by the acceleration run, the next link's block fetched
+// while the current link is computed).  The segment loop itself carries no vector state.
+//
+// Covered cluster types: Free root, Revolute, RevoluteWithRotor (axisymmetric rotor evaluated at q = 0, plan.cpp),
+// leaf RevolutePairWithRotor (src/Dynamics/ClusterJoints/RevolutePairWithRotorJoint.cpp).  Everything else runs on
+// the general interpreter (kernels.hip); the plan compiler decides (ChainProgram::ok).
+#include <hip/hip_runtime.h>
+
+#include "devplan.h"
+
+namespace grbda_hip {
+
+#include "devmath.h"
+
+template <class T>
+struct ChainTables {
+    cptr<ChainSeg> segs;
+    cptr<ChainLink> links;
+    cptr<ChainPair> pairs;
+    cptr<ChainFree> frees;
+    cptr<T> consts;
+    int n_segs, nq, nv, ori_repr;
+    T a_root[6];
+};
+
+// LDS slots [slot][lane]; global slab rows [slot][lane]; the tile's inputs as coordinate-major slab rows
+template <class T>
+struct ChainMem {
+    T *glb;             // wave's global slots (after the input rows)
+    const T *in_q, *in_qd, *in_x;   // already offset by the lane
+    T *out_rows;
+    int lane;
+
+    template <int N>
+    __device__ __forceinline__ void lds_ld(int s, T (&x)[N]) const
+    {
+        const T *p = reinterpret_cast<const T *>(grbda_smem) + (s * kWave + lane);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = p[i * kWave];
+    }
+    template <int N>
+    __device__ __forceinline__ void lds_st(int s, const T (&x)[N]) const
+    {
+        T *p = reinterpret_cast<T *>(grbda_smem) + (s * kWave + lane);
+#pragma unroll
+        for (int i = 0; i < N; i++) p[i * kWave] = x[i];
+    }
+    template <int N>
+    __device__ __forceinline__ void glb_ld(int s, T (&x)[N]) const
+    {
+        const T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = p[i * kWave];
+    }
+    template <int N>
+    __device__ __forceinline__ void glb_st(int s, const T (&x)[N]) const
+    {
+        T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
+#pragma unroll
+        for (int i = 0; i < N; i++) p[i * kWave] = x[i];
+    }
+    __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
+    __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
+    __device__ __forceinline__ T x(int j) const { return in_x[(size_t)j * kWave]; }
+    __device__ __forceinline__ void put(int j, T v) const { out_rows[(size_t)j * kWave] = v; }
+};
+
+// c = v x (z qd) for a joint about z: (v1, -v0, 0, v4, -v3, 0) qd   (Spatial.h:131-143)
+template <class T>
+__device__ __forceinline__ void vxz(const T (&v)[6], T qd, T (&c)[6])
+{
+    c[0] = v[1] * qd; c[1] = -v[0] * qd; c[2] = 0;
+    c[3] = v[4] * qd; c[4] = -v[3] * qd; c[5] = 0;
+}
+
+// pA = v x* (I v) for constant packed inertia (ClusterTreeDynamics.cpp:95-98)
+template <class T>
+__device__ __forceinline__ void bias_force(cptr<T> I, const T (&v)[6], T (&p)[6])
+{
+    T Iv[6];
+    symv_c(I, v, Iv);
+    crf(v, Iv, p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward run: TreeModel::forwardKinematics (TreeModel.cpp:6-32) along a chain, root side first
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
+{
+    T vp[6];
+    {
+        const ChainLink l0 = load_rec(P.links + sg.first);
+        if (l0.lds_pv >= 0) {
+            M.lds_ld(l0.lds_pv, vp);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) vp[j] = 0;
+        }
+    }
+    for (int i = 0; i < sg.count; i++) {
+        const ChainLink l = load_rec(P.links + (sg.first + i));
+        cptr<T> C = P.consts + l.cofs;
+        const T g0 = C[kBodyConstFixed];
+        T blk[8], E[9], v[6];
+        sincos_t(g0 * M.q(l.q_index), &blk[0], &blk[1]);
+        rotate_z(blk[0], blk[1], C, E);
+        xmotion(E, C + 9, vp, v);
+        v[2] += g0 * M.qd(l.v_index);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            blk[2 + j] = v[j];
+            vp[j] = v[j];
+        }
+        M.lds_st(l.lds_sv, blk);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// leaf RevolutePairWithRotor cluster, backward: bodies link1 (on the parent body P), link2 (on link1), two
+// axisymmetric rotors on P evaluated at q = 0; coordinates y = (link1 angle, link2 angle), rotor angles G_r y.
+// Per body the composite inertia / bias are pushed to the tree parent; the cluster-level terms
+//   D = sum d_i G_i^T G_i + chain terms,  F = sum f_i G_i,  u = tau - sum G_i^T b_i
+// give K = D^-1 F^T, y0 = D^-1 u and the correction -F D^-1 F^T, + F D^-1 u on P (kernels.hip, aba_bwd_static).
+// Out: (IA, psi) = what P receives (without the rotors' constant X0^T I X0, which is part of P's constants).
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainPair &pr, T (&IA)[21],
+                                         T (&psi)[6])
+{
+    cptr<T> C1 = P.consts + pr.cofs[0], C2 = P.consts + pr.cofs[1];
+    T vp[6];
+    M.lds_ld(pr.lds_pv, vp);
+    const T y1 = M.q(pr.q_index), y2 = M.q(pr.q_index + 1);
+    const T yd1 = M.qd(pr.v_index), yd2 = M.qd(pr.v_index + 1);
+    T u[2] = {M.x(pr.v_index), M.x(pr.v_index + 1)};
+    T D00 = 0, D01 = 0, D11 = 0;
+    T F0[6], F1[6];  // columns of F (force at P per unit y1dd / y2dd)
+
+    // ---- kinematics of the two links ----
+    T s1, c1, s2, c2, E1[9], E2[9], v1[6], v2[6], ch1[6], ch2[6];
+    sincos_t(y1, &s1, &c1);
+    rotate_z(s1, c1, C1, E1);
+    xmotion(E1, C1 + 9, vp, v1);
+    v1[2] += yd1;
+    vxz(v1, yd1, ch1);
+    sincos_t(y2, &s2, &c2);
+    rotate_z(s2, c2, C2, E2);
+    xmotion(E2, C2 + 9, v1, v2);
+    v2[2] += yd2;
+    vxz(v2, yd2, ch2);
+    // in-cluster bias acceleration of link2: ccl2 = ch2 + X2 ch1 (GenericJoint.cpp:430-450)
+    T ccl2[6];
+    xmotion(E2, C2 + 9, ch1, ccl2);
+#pragma unroll
+    for (int j = 0; j < 6; j++) ccl2[j] += ch2[j];
+
+    // ---- link2 (leaf): IA2 = I2 ----
+    T IA1[21], psi1[6];
+    {
+        cptr<T> I2 = C2 + 12;
+        T p2[6], h2[6];
+        bias_force(I2, v2, p2);
+#pragma unroll
+        for (int i = 0; i < 6; i++) h2[i] = I2[sidx(i, 2)];
+        T bj = p2[2];
+#pragma unroll
+        for (int j = 0; j < 6; j++) bj += h2[j] * ccl2[j];
+        u[1] -= bj;
+        D11 += h2[2];
+        // composite to link1: X2^T (p2 + I2 ch2), X2^T I2 X2
+        T t[6];
+        symv_c(I2, ch2, t);
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] += p2[j];
+        xforce_inv(E2, C2 + 9, t, psi1);
+        congruence(E2, C2 + 9, I2, IA1);
+        // joint-space coupling through the chain: f = X2^T h2 at link1, then at P
+        T f[6];
+        xforce_inv(E2, C2 + 9, h2, f);
+        D01 += f[2];  // Hc (G1 G2^T + G2 G1^T) with G1 = (1, 0), G2 = (0, 1)
+        xforce_inv(E1, C1 + 9, f, F1);
+    }
+    // ---- link1 ----
+    {
+        cptr<T> I1 = C1 + 12;
+        T p1[6];
+        bias_force(I1, v1, p1);
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA1[j] += I1[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi1[j] += p1[j];
+        T h1[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) h1[i] = IA1[sidx(i, 2)];
+        // ccl1 = ch1 = (., ., 0, ., ., 0)
+        const T bj = psi1[2] + h1[0] * ch1[0] + h1[1] * ch1[1] + h1[3] * ch1[3] + h1[4] * ch1[4];
+        u[0] -= bj;
+        D00 += h1[2];
+        T t[6];
+        symv_z(IA1, ch1, t);
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] += psi1[j];
+        xforce_inv(E1, C1 + 9, t, psi);
+        congruence(E1, C1 + 9, IA1, IA);
+        xforce_inv(E1, C1 + 9, h1, F0);
+    }
+    // ---- rotors (q = 0): bias to P, joint-space terms with their G rows ----
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        cptr<T> Cr = P.consts + pr.cofs[2 + r];
+        cptr<T> Ir = Cr + 12;
+        const T ga = Cr[kBodyConstFixed], gb = Cr[kBodyConstFixed + 1];
+        const T qdr = ga * yd1 + gb * yd2;
+        T E0[9], vr[6], cr[6], prr[6], hr[6];
+#pragma unroll
+        for (int j = 0; j < 9; j++) E0[j] = Cr[j];
+        xmotion(E0, Cr + 9, vp, vr);
+        vr[2] += qdr;
+        vxz(vr, qdr, cr);
+        bias_force(Ir, vr, prr);
+#pragma unroll
+        for (int i = 0; i < 6; i++) hr[i] = Ir[sidx(i, 2)];
+        const T bj = prr[2] + hr[0] * cr[0] + hr[1] * cr[1] + hr[3] * cr[3] + hr[4] * cr[4];
+        u[0] -= ga * bj;
+        u[1] -= gb * bj;
+        D00 += hr[2] * ga * ga;
+        D01 += hr[2] * ga * gb;
+        D11 += hr[2] * gb * gb;
+        T fr[6], t[6], tp[6];
+        xforce_inv(E0, Cr + 9, hr, fr);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            F0[j] += fr[j] * ga;
+            F1[j] += fr[j] * gb;
+        }
+        symv_z(Ir, cr, t);
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] += prr[j];
+        xforce_inv(E0, Cr + 9, t, tp);
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi[j] += tp[j];
+    }
+    // ---- D^-1 (2 x 2, SPD), K = D^-1 F^T, y0 = D^-1 u ----
+    const T idet = rcp_t(D00 * D11 - D01 * D01);
+    const T i00 = D11 * idet, i01 = -D01 * idet, i11 = D00 * idet;
+    T blk[14];  // [K row 0 (6)][K row 1 (6)][y0 (2)]
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        blk[j] = i00 * F0[j] + i01 * F1[j];
+        blk[6 + j] = i01 * F0[j] + i11 * F1[j];
+    }
+    blk[12] = i00 * u[0] + i01 * u[1];
+    blk[13] = i01 * u[0] + i11 * u[1];
+    M.glb_st(pr.glb_k, blk);
+    // ---- correction on P: IA -= F K, psi += F y0 ----
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        psi[r] += F0[r] * blk[12] + F1[r] * blk[13];
+#pragma unroll
+        for (int cc = r; cc < 6; cc++) IA[sidx(r, cc)] -= F0[r] * blk[cc] + F1[r] * blk[6 + cc];
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void pair_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainPair &pr)
+{
+    T blk[14], va[12];
+    M.glb_ld(pr.glb_k, blk);
+    M.lds_ld(pr.lds_pva, va);
+    T y0 = blk[12], y1 = blk[13];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        y0 -= blk[j] * va[6 + j];
+        y1 -= blk[6 + j] * va[6 + j];
+    }
+    M.put(pr.v_index, y0);
+    M.put(pr.v_index + 1, y1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward run: updateArticulatedBodies + bias back-propagation (ClusterTreeDynamics.cpp:94-129,157-191) along a
+// chain, leaf side first.  Per link (n = 1): D = g0^2 h_z (+ rotor), F = X^T h g0 (+ rotor), u = tau - g0 b (- rotor),
+// K = F / D, y0 = u / D, and one combined hand-over X^T IA X - F K, X^T (pA + IA c) + F y0 to the parent.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T, bool ROTOR>
+__device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
+{
+    T IAc[21], psic[6];  // what the link below handed up (register hand-over inside the run)
+    if (sg.head == HEAD_PAIR) {
+        const ChainPair pr = load_rec(P.pairs + sg.head_arg);
+        pair_bwd(P, M, pr, IAc, psic);
+    } else if (sg.head == HEAD_SLOT) {
+        T acc[27];
+        M.lds_ld(sg.head_arg, acc);
+#pragma unroll
+        for (int j = 0; j < 21; j++) IAc[j] = acc[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psic[j] = acc[21 + j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 21; j++) IAc[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) psic[j] = 0;
+    }
+    for (int i = 0; i < sg.count; i++) {
+        const ChainLink l = load_rec(P.links + (sg.first + i));
+        cptr<T> C = P.consts + l.cofs;
+        cptr<T> Ic = C + 12;
+        cptr<T> Ib = P.consts + l.iofs;
+        const T g0 = C[kBodyConstFixed];
+        const T yd = M.qd(l.v_index);
+        const T qdi = g0 * yd;
+        T blk[8], E[9], v[6];
+        M.lds_ld(l.lds_sv, blk);
+        rotate_z(blk[0], blk[1], C, E);
+#pragma unroll
+        for (int j = 0; j < 6; j++) v[j] = blk[2 + j];
+        T chat[6];
+        vxz(v, qdi, chat);
+
+        T IA[21], psi[6];
+        bias_force(Ic, v, psi);
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j] + IAc[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi[j] += psic[j];
+        T h[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) h[k] = IA[sidx(k, 2)];
+        const T bj = psi[2] + h[0] * chat[0] + h[1] * chat[1] + h[3] * chat[3] + h[4] * chat[4];
+        T u = M.x(l.v_index) - g0 * bj;
+        T D = h[2] * g0 * g0;
+        T F[6];
+        xforce_inv(E, C + 9, h, F);
+#pragma unroll
+        for (int r = 0; r < 6; r++) F[r] *= g0;
+        {
+            T t[6];
+            symv_z(IA, chat, t);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t[j] += psi[j];
+            xforce_inv(E, C + 9, t, psic);
+            congruence(E, C + 9, IA, IAc);
+        }
+        if constexpr (ROTOR) {
+            cptr<T> Cr = P.consts + l.rofs;
+            cptr<T> Ir = Cr + 12;
+            const T gr = Cr[kBodyConstFixed];
+            const T qdr = gr * yd;
+            T vp[6];
+            if (l.lds_pv >= 0) {
+                M.lds_ld(l.lds_pv, vp);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) vp[j] = 0;
+            }
+            T E0[9], vr[6], cr[6], prr[6], hr[6];
+#pragma unroll
+            for (int j = 0; j < 9; j++) E0[j] = Cr[j];
+            xmotion(E0, Cr + 9, vp, vr);
+            vr[2] += qdr;
+            vxz(vr, qdr, cr);
+            bias_force(Ir, vr, prr);
+#pragma unroll
+            for (int k = 0; k < 6; k++) hr[k] = Ir[sidx(k, 2)];
+            const T bjr = prr[2] + hr[0] * cr[0] + hr[1] * cr[1] + hr[3] * cr[3] + hr[4] * cr[4];
+            u -= gr * bjr;
+            D += hr[2] * gr * gr;
+            T fr[6], t[6], tp[6];
+            xforce_inv(E0, Cr + 9, hr, fr);
+#pragma unroll
+            for (int r = 0; r < 6; r++) F[r] += fr[r] * gr;
+            symv_z(Ir, cr, t);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t[j] += prr[j];
+            xforce_inv(E0, Cr + 9, t, tp);
+#pragma unroll
+            for (int j = 0; j < 6; j++) psic[j] += tp[j];
+        }
+        const T Dinv = rcp_t(D);
+        T kb[9];  // [K 6][y0][sin][cos]
+#pragma unroll
+        for (int r = 0; r < 6; r++) kb[r] = F[r] * Dinv;
+        kb[6] = u * Dinv;
+        kb[7] = blk[0];
+        kb[8] = blk[1];
+        M.glb_st(l.glb_k, kb);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            psic[r] += F[r] * kb[6];
+#pragma unroll
+            for (int cc = r; cc < 6; cc++) IAc[sidx(r, cc)] -= F[r] * kb[cc];
+        }
+    }
+    // hand the chain's projected inertia / bias to the body it hangs off
+    if (sg.lds_acc_out >= 0) {
+        T acc[27];
+        if (sg.acc_first) {
+#pragma unroll
+            for (int j = 0; j < 21; j++) acc[j] = IAc[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[21 + j] = psic[j];
+        } else {
+            M.lds_ld(sg.lds_acc_out, acc);
+#pragma unroll
+            for (int j = 0; j < 21; j++) acc[j] += IAc[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[21 + j] += psic[j];
+        }
+        M.lds_st(sg.lds_acc_out, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// acceleration run (ClusterTreeDynamics.cpp:131-152), root side first: ydd = y0 - K a_p; a = X a_p + c + z g0 ydd
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
+{
+    T vp[6], ap[6];
+    if (sg.lds_pva >= 0) {
+        T va[12];
+        M.lds_ld(sg.lds_pva, va);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            vp[j] = va[j];
+            ap[j] = va[6 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            vp[j] = 0;
+            ap[j] = P.a_root[j];
+        }
+    }
+    ChainLink l = load_rec(P.links + sg.first);
+    T kb[9];
+    M.glb_ld(l.glb_k, kb);
+    for (int i = 0; i < sg.count; i++) {
+        // the next link's record and [K | y0 | sin | cos] block travel while this link is computed
+        const bool more = i + 1 < sg.count;
+        const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
+        T kn[9];
+        if (more) M.glb_ld(ln.glb_k, kn);
+        T ydd = kb[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) ydd -= kb[r] * ap[r];
+        M.put(l.v_index, ydd);
+        if (l.has_child) {
+            cptr<T> C = P.consts + l.cofs;
+            const T g0 = C[kBodyConstFixed];
+            const T qdi = g0 * M.qd(l.v_index);
+            T E[9], v[6], a[6], chat[6];
+            rotate_z(kb[7], kb[8], C, E);
+            xmotion(E, C + 9, vp, v);
+            xmotion(E, C + 9, ap, a);
+            v[2] += qdi;
+            vxz(v, qdi, chat);
+#pragma unroll
+            for (int j = 0; j < 6; j++) a[j] += chat[j];
+            a[2] += g0 * ydd;
+            if (l.lds_va >= 0) {
+                T va[12];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    va[j] = v[j];
+                    va[6 + j] = a[j];
+                }
+                M.lds_st(l.lds_va, va);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                vp[j] = v[j];
+                ap[j] = a[j];
+            }
+        }
+        if (more) {
+            l = ln;
+#pragma unroll
+            for (int j = 0; j < 9; j++) kb[j] = kn[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// floating base (FreeJoint.cpp:10-46): S = 1, D = IA, c = 0
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void free_fwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
+{
+    if (f.lds_v < 0) return;
+    T v[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) v[j] = M.qd(f.v_index + j);
+    M.lds_st(f.lds_v, v);
+}
+
+template <class T>
+__device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
+{
+    cptr<T> Ic = P.consts + f.cofs + 12;
+    cptr<T> Ib = P.consts + f.iofs;
+    T v[6], psi[6], IA[21];
+#pragma unroll
+    for (int j = 0; j < 6; j++) v[j] = M.qd(f.v_index + j);
+    bias_force(Ic, v, psi);
+    if (f.lds_acc >= 0) {
+        T acc[27];
+        M.lds_ld(f.lds_acc, acc);
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi[j] += acc[21 + j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA[j] = Ib[j];
+    }
+    T D[6][6], u[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        u[i] = M.x(f.v_index + i) - psi[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) D[i][j] = IA[sidx(i, j)];
+    }
+    Chol<T, 6> ch;
+    ch.factor(D);
+    ch.solve(u);
+    M.glb_st(f.glb_y0, u);
+}
+
+template <class T>
+__device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
+{
+    T y0[6], o[4], E[9], r[3], g[6], ag[6];
+    M.glb_ld(f.glb_y0, y0);
+    const int nori = P.ori_repr == 0 ? 4 : 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = j < nori ? M.q(f.q_index + 3 + j) : T(0);
+    free_rotation(P.ori_repr, o, E);
+#pragma unroll
+    for (int j = 0; j < 3; j++) r[j] = M.q(f.q_index + j);
+#pragma unroll
+    for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
+    xmotion(E, r, g, ag);
+    // ydd = D^-1 u - D^-1 U^T a' with U = D = IA  =>  ydd = y0 - a' ;  a = a' + ydd = y0
+#pragma unroll
+    for (int j = 0; j < 6; j++) M.put(f.v_index + j, y0[j] - ag[j]);
+    if (f.lds_va >= 0) {
+        T va[12];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            va[j] = M.qd(f.v_index + j);
+            va[6 + j] = y0[j];
+        }
+        M.lds_st(f.lds_va, va);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kWave, 2) void aba_chain_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
+                                                             const T *__restrict__ tau, T *__restrict__ ydd, size_t B,
+                                                             T *__restrict__ scratch)
+{
+    ChainTables<T> P;
+    P.segs = (cptr<ChainSeg>)DP.segs;
+    P.links = (cptr<ChainLink>)DP.links;
+    P.pairs = (cptr<ChainPair>)DP.pairs;
+    P.frees = (cptr<ChainFree>)DP.frees;
+    P.consts = (cptr<T>)DP.consts;
+    P.n_segs = DP.n_segs;
+    P.nq = DP.nq;
+    P.nv = DP.nv;
+    P.ori_repr = DP.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
+    const int lane = threadIdx.x;
+    // wave slab: [nq + 2 nv input rows][n_glb_slots rows], 64 scalars per row
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
+    ChainMem<T> M;
+    M.lane = lane;
+    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q = slab + lane;
+    M.in_qd = slab + (size_t)P.nq * kWave + lane;
+    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        for (int s = 0; s < P.n_segs; s++) {
+            const ChainSeg sg = load_rec(P.segs + s);
+            switch (sg.op) {
+                case SEG_RUN_FWD: run_fwd(P, M, sg); break;
+                case SEG_RUN_BWD: {
+                    const ChainLink l0 = load_rec(P.links + sg.first);
+                    if (l0.rofs >= 0) run_bwd<T, true>(P, M, sg);
+                    else run_bwd<T, false>(P, M, sg);
+                    break;
+                }
+                case SEG_RUN_ACC: run_acc(P, M, sg); break;
+                case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
+                case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_FREE_BWD: free_bwd(P, M, load_rec(P.frees + sg.first)); break;
+                default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
+            }
+        }
+        write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+    }
+}
+
+template <class T>
+hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
+                            size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((aba_chain_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_aba_chain<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
+                                            float *, int, size_t, hipStream_t);
+
+hipError_t set_max_dynamic_lds_chain()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+}  // namespace grbda_hip

@@ -133,8 +133,8 @@ __device__ __forceinline__ void rot3_sym(const T (&E)[9], const T (&M)[9], T (&R
 
 // B = X^T A X for symmetric 6x6 A (packed), X = (E, r):
 // Transform::inverseTransformSpatialInertia (SpatialTransforms.cpp:111-135)
-template <class T, class R3>
-__device__ __forceinline__ void congruence(const T (&E)[9], R3 r, const T (&A)[21], T (&B)[21])
+template <class T, class R3, class A21>
+__device__ __forceinline__ void congruence(const T (&E)[9], R3 r, const A21 &A, T (&B)[21])
 {
     T A11[9], A12[9], A22[9], R11[9], R12[9], R22[9];
 #pragma unroll

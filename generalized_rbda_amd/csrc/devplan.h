@@ -43,4 +43,24 @@ template <class T>
 hipError_t launch_poses(const DevPlan<T> &P, int n_clusters, const T *q, T *Xa, size_t B, int grid, hipStream_t stream);
 hipError_t set_max_dynamic_lds();
 
+// kernel argument block of the chain-structured fast path (chain_kernels.hip; plan.h, ChainProgram)
+template <class T>
+struct ChainDev {
+    const ChainSeg *segs;
+    const ChainLink *links;
+    const ChainPair *pairs;
+    const ChainFree *frees;
+    const T *consts;
+    int n_segs;
+    int nq, nv;
+    int n_glb_slots;
+    int lds_bytes;
+    int ori_repr;
+    T a_root[6];
+};
+template <class T>
+hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
+                            size_t lds_bytes, hipStream_t stream);
+hipError_t set_max_dynamic_lds_chain();
+
 }  // namespace grbda_hip

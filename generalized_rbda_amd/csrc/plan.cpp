@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 
 #include "../../include/grbda_hip.h"
 #include "../../include/grbda_model_desc.h"
@@ -765,6 +766,295 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     for (const ClusterRec &cr : clusters)
         if (cr.kind == CK_LOOP) P.lay32s.split_aba = P.lay32s.split_rnea = false;
     build_layout(P.lay64x, lds.aba64, lds.rnea64, true);
+
+    // ---- chain program of the f32 fast path (plan.h, ChainProgram; chain_kernels.hip) ----------------------------
+    {
+        ChainProgram &CP = P.chain32;
+        CP = ChainProgram();
+        bool ok = sweep_mask == 7;
+        // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, -1 unsupported
+        std::vector<int> cls(nc, -1), tip(nc, -1);
+        std::vector<ChainPair> pair_of(nc);
+        for (int c = 0; c < nc && ok; c++) {
+            const ClusterRec &cr = clusters[c];
+            if (cr.kind == CK_FREE) {
+                cls[c] = 0;
+                tip[c] = cr.first_body;
+            } else if (cr.kind == CK_STATIC && cr.shape != SHAPE_GENERIC) {
+                cls[c] = cr.shape == SHAPE_REV ? 1 : 2;
+                tip[c] = cr.link_body;
+            } else if (cr.kind == CK_STATIC && cr.n == 2 && cr.k == 4 && cr.parent_body >= 0) {
+                // RevolutePairWithRotor shape: link1 and two axisymmetric rotors on the parent body, link2 on link1,
+                // coordinates = the two link angles (RevolutePairWithRotorJoint.cpp:10-69), no child clusters
+                int l1 = -1, l2 = -1, r[2] = {-1, -1}, nr = 0;
+                for (int i = 0; i < 4; i++) {
+                    const int gb = cr.first_body + i;
+                    const BodyRec &br = bodies[gb];
+                    if (br.axisym && !br.has_child && br.parent == cr.parent_body) { if (nr < 2) r[nr] = gb; nr++; }
+                    else if (br.parent == cr.parent_body && br.lam < 0) l1 = l1 < 0 ? gb : -2;
+                    else if (br.lam >= 0) l2 = l2 < 0 ? gb : -2;
+                }
+                bool good = nr == 2 && l1 >= 0 && l2 >= 0 && bodies[l2].lam == l1 && !bodies[l2].has_child && !bodies[l1].axisym &&
+                            !bodies[l2].axisym;
+                if (good)
+                    for (int j = 0; j < nb; j++)
+                        if (bodies[j].parent == l1 && j != l2) good = false;
+                if (good) {
+                    const double *g1 = &P.consts[bodies[l1].cofs + kBodyConstFixed], *g2 = &P.consts[bodies[l2].cofs + kBodyConstFixed];
+                    good = g1[0] == 1.0 && g1[1] == 0.0 && g2[0] == 0.0 && g2[1] == 1.0;
+                }
+                if (good) {
+                    cls[c] = 3;
+                    ChainPair &pr = pair_of[c];
+                    pr = ChainPair();
+                    pr.q_index = cr.q_index;
+                    pr.v_index = cr.v_index;
+                    pr.cofs[0] = bodies[l1].cofs; pr.cofs[1] = bodies[l2].cofs; pr.cofs[2] = bodies[r[0]].cofs; pr.cofs[3] = bodies[r[1]].cofs;
+                } else {
+                    ok = false;
+                }
+            } else {
+                ok = false;
+            }
+            if (cls[c] != 0 && cr.parent_body < 0) ok = false;  // fixed-base models stay on the general kernels
+        }
+        // every child cluster must hang off the tip body of its parent cluster; a pair must be an only child of a link
+        std::vector<std::vector<int>> ckids(nc);
+        for (int c = 0; c < nc && ok; c++) {
+            const int pb = clusters[c].parent_body;
+            if (pb < 0) continue;
+            const int pc = m.bodies[pb].cluster;
+            if (tip[pc] != pb) { ok = false; break; }
+            ckids[pc].push_back(c);
+        }
+        for (int c = 0; c < nc && ok; c++) {
+            // child order = the depth-first order of the general schedule (kids[])
+            ckids[c] = kids[c];
+            for (int k : ckids[c])
+                if (cls[k] == 3 && (ckids[c].size() != 1 || cls[c] == 0 || cls[c] == 3)) ok = false;
+            if (cls[c] == 3 && !ckids[c].empty()) ok = false;
+        }
+        if (ok) {
+            // per-cluster master records
+            std::vector<ChainLink> link_of(nc);
+            std::vector<ChainFree> free_of(nc);
+            std::vector<int> acc_slot(nc, -1);            // accumulator [IA 21][psi 6] of the tip body (several kid chains, or a free base)
+            std::vector<Obj> objs;
+            int n_glb = 0;
+            auto glb = [&](int size) { const int at = n_glb; n_glb += size; return at | kSlotGlobal; };
+            for (int c = 0; c < nc; c++) {
+                const ClusterRec &cr = clusters[c];
+                if (cls[c] == 0) {
+                    ChainFree &f = free_of[c];
+                    f = ChainFree();
+                    const BodyRec &br = bodies[cr.first_body];
+                    f.q_index = cr.q_index; f.v_index = cr.v_index; f.cofs = br.cofs; f.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
+                    f.lds_v = f.lds_acc = f.lds_va = -1;
+                    f.glb_y0 = glb(6);
+                } else if (cls[c] == 1 || cls[c] == 2) {
+                    ChainLink &l = link_of[c];
+                    l = ChainLink();
+                    const BodyRec &br = bodies[cr.link_body];
+                    l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = br.cofs;
+                    l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : -1;
+                    l.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
+                    l.has_child = br.has_child;
+                    l.lds_sv = l.lds_pv = l.lds_va = -1;
+                    l.glb_k = glb(9);  // [K 6][y0][sin][cos]
+                } else {
+                    pair_of[c].glb_k = glb(14);
+                    pair_of[c].lds_pv = pair_of[c].lds_pva = -1;
+                }
+            }
+            // chains: follow single link children of the same class; a single pair child becomes the head of the backward run
+            struct Chain { std::vector<int> cl; int pair = -1; std::vector<int> kid_chains; int parent_cluster = -1; };
+            std::vector<Chain> chains;
+            std::function<int(int)> make_chain = [&](int c0) -> int {
+                Chain ch;
+                ch.parent_cluster = m.bodies[clusters[c0].parent_body].cluster;
+                int c = c0;
+                for (;;) {
+                    ch.cl.push_back(c);
+                    if (ckids[c].size() == 1 && cls[ckids[c][0]] == cls[c]) { c = ckids[c][0]; continue; }
+                    break;
+                }
+                const int tipc = ch.cl.back();
+                const int id = static_cast<int>(chains.size());
+                chains.push_back(ch);
+                if (ckids[tipc].size() == 1 && cls[ckids[tipc][0]] == 3) {
+                    chains[id].pair = ckids[tipc][0];
+                } else {
+                    for (int k : ckids[tipc]) {
+                        const int kid = make_chain(k);
+                        chains[id].kid_chains.push_back(kid);
+                    }
+                }
+                return id;
+            };
+            // time stamps of segments
+            struct SegTimes { int fwd = -1, bwd = -1, acc = -1, pair_acc = -1; };
+            std::vector<SegTimes> ct;
+            std::vector<int> root_frees, free_kids_first;
+            // emission helpers work on chain ids; link records are filled after allocation, so remember (seg, cluster list)
+            struct RunRef { int seg; std::vector<int> cl; };
+            std::vector<RunRef> runs;
+            auto push_seg = [&](ChainSeg sg) { CP.segs.push_back(sg); return static_cast<int>(CP.segs.size()) - 1; };
+            std::function<void(int)> emit_fb = [&](int id) {
+                const Chain ch = chains[id];
+                {   // every link of the chain, the tip included: the backward run reads [sin, cos, v] of all of them
+                    ChainSeg sg = ChainSeg();
+                    sg.op = SEG_RUN_FWD;
+                    const int t = push_seg(sg);
+                    runs.push_back({t, ch.cl});
+                    ct[id].fwd = t;
+                }
+                for (int k : ch.kid_chains) emit_fb(k);
+                ChainSeg sg = ChainSeg();
+                sg.op = SEG_RUN_BWD;
+                const int tipc = ch.cl.back();
+                sg.head = ch.pair >= 0 ? HEAD_PAIR : (ch.kid_chains.empty() ? HEAD_LEAF : HEAD_SLOT);
+                const int t = push_seg(sg);
+                std::vector<int> rev(ch.cl.rbegin(), ch.cl.rend());
+                runs.push_back({t, rev});
+                ct[id].bwd = t;
+                (void)tipc;
+            };
+            std::function<void(int)> emit_acc = [&](int id) {
+                const Chain ch = chains[id];
+                ChainSeg sg = ChainSeg();
+                sg.op = SEG_RUN_ACC;
+                const int t = push_seg(sg);
+                runs.push_back({t, ch.cl});
+                ct[id].acc = t;
+                if (ch.pair >= 0) {
+                    ChainSeg ps = ChainSeg();
+                    ps.op = SEG_PAIR_ACC;
+                    ct[id].pair_acc = push_seg(ps);
+                }
+                for (int k : ch.kid_chains) emit_acc(k);
+            };
+            // roots
+            std::vector<std::vector<int>> free_chains(nc);
+            std::vector<int> t_free_fwd(nc, -1), t_free_bwd(nc, -1), t_free_acc(nc, -1);
+            for (int c = 0; c < nc; c++)
+                if (cls[c] == 0)
+                    for (int k : ckids[c]) free_chains[c].push_back(make_chain(k));
+            ct.assign(chains.size(), SegTimes());
+            for (int c = 0; c < nc; c++) {
+                if (cls[c] != 0) continue;
+                ChainSeg sg = ChainSeg();
+                sg.op = SEG_FREE_FWD;
+                t_free_fwd[c] = push_seg(sg);
+                for (int id : free_chains[c]) emit_fb(id);
+                sg.op = SEG_FREE_BWD;
+                t_free_bwd[c] = push_seg(sg);
+            }
+            for (int c = 0; c < nc; c++) {
+                if (cls[c] != 0) continue;
+                ChainSeg sg = ChainSeg();
+                sg.op = SEG_FREE_ACC;
+                t_free_acc[c] = push_seg(sg);
+                for (int id : free_chains[c]) emit_acc(id);
+            }
+            // ---- LDS objects and their live ranges (segment indices) ----
+            auto last_acc_of = [&](int id) {
+                std::function<int(int)> rec = [&](int i) -> int {
+                    int t = std::max(ct[i].acc, ct[i].pair_acc);
+                    for (int k : chains[i].kid_chains) t = std::max(t, rec(k));
+                    return t;
+                };
+                return rec(id);
+            };
+            for (int c = 0; c < nc; c++) {
+                if (cls[c] != 0) continue;
+                ChainFree &f = free_of[c];
+                if (free_chains[c].empty()) continue;
+                int first_bwd = 1 << 30, last_acc = t_free_acc[c];
+                for (int id : free_chains[c]) { first_bwd = std::min(first_bwd, ct[id].bwd); last_acc = std::max(last_acc, last_acc_of(id)); }
+                objs.push_back({&f.lds_v, 6, 0, t_free_fwd[c], t_free_bwd[c], -1, 1});
+                objs.push_back({&f.lds_acc, 27, 1, first_bwd, t_free_bwd[c], -1, 1});
+                objs.push_back({&f.lds_va, 12, 0, t_free_acc[c], last_acc, -1, 1});
+            }
+            for (size_t id = 0; id < chains.size(); id++) {
+                const Chain &ch = chains[id];
+                for (int c : ch.cl) objs.push_back({&link_of[c].lds_sv, 8, 0, ct[id].fwd, ct[id].bwd, -1, 1});
+                const int tipc = ch.cl.back();
+                if (!ch.kid_chains.empty()) {
+                    int first_bwd = 1 << 30, last_acc = ct[id].acc;
+                    for (int k : ch.kid_chains) { first_bwd = std::min(first_bwd, ct[k].bwd); last_acc = std::max(last_acc, last_acc_of(k)); }
+                    objs.push_back({&acc_slot[tipc], 27, 1, first_bwd, ct[id].bwd, -1, 1});
+                    objs.push_back({&link_of[tipc].lds_va, 12, 0, ct[id].acc, last_acc, -1, 1});
+                } else if (ch.pair >= 0) {
+                    objs.push_back({&link_of[tipc].lds_va, 12, 0, ct[id].acc, ct[id].pair_acc, -1, 1});
+                }
+            }
+            int n_lds = 0, n_glb_unused = 0;
+            ok = allocate(objs, lds.aba32, n_lds, n_glb_unused);
+            if (ok) {
+                CP.n_lds = n_lds;
+                CP.n_glb = n_glb;
+                // parent velocity / (v, a) slots
+                auto v_slot_of_body = [&](int b) -> int {  // LDS slot of the velocity of body b (tip of its cluster)
+                    const int c = m.bodies[b].cluster;
+                    return cls[c] == 0 ? free_of[c].lds_v : link_of[c].lds_sv + 2;
+                };
+                auto va_slot_of_body = [&](int b) -> int {
+                    const int c = m.bodies[b].cluster;
+                    return cls[c] == 0 ? free_of[c].lds_va : link_of[c].lds_va;
+                };
+                auto acc_slot_of_body = [&](int b) -> int {
+                    const int c = m.bodies[b].cluster;
+                    return cls[c] == 0 ? free_of[c].lds_acc : acc_slot[c];
+                };
+                for (int c = 0; c < nc; c++) {
+                    const int pb = clusters[c].parent_body;
+                    if (cls[c] == 1 || cls[c] == 2) link_of[c].lds_pv = v_slot_of_body(pb);
+                    if (cls[c] == 3) { pair_of[c].lds_pv = v_slot_of_body(pb); pair_of[c].lds_pva = va_slot_of_body(pb); }
+                }
+                // first writer of every accumulator slot: the kid chain whose backward run comes first
+                for (const RunRef &r : runs) {
+                    ChainSeg &sg = CP.segs[r.seg];
+                    sg.first = static_cast<int>(CP.links.size());
+                    sg.count = static_cast<int>(r.cl.size());
+                    for (int c : r.cl) CP.links.push_back(link_of[c]);
+                }
+                for (size_t id = 0; id < chains.size(); id++) {
+                    const Chain &ch = chains[id];
+                    ChainSeg &bw = CP.segs[ct[id].bwd];
+                    const int tipc = ch.cl.back(), topc = ch.cl.front();
+                    if (bw.head == HEAD_SLOT) bw.head_arg = acc_slot[tipc];
+                    if (bw.head == HEAD_PAIR) { bw.head_arg = static_cast<int>(CP.pairs.size()); }
+                    const int pb = clusters[topc].parent_body;
+                    bw.lds_acc_out = acc_slot_of_body(pb);
+                    // first writer: earliest backward run among the sibling chains
+                    bool first = true;
+                    const int pc = m.bodies[pb].cluster;
+                    int parent_chain = 0;
+                    for (size_t j = 0; j < chains.size(); j++)
+                        if (chains[j].cl.back() == pc) parent_chain = static_cast<int>(j);
+                    const std::vector<int> &sib = cls[pc] == 0 ? free_chains[pc] : chains[parent_chain].kid_chains;
+                    for (int o : sib)
+                        if (ct[o].bwd < ct[id].bwd) first = false;
+                    bw.acc_first = first ? 1 : 0;
+                    ChainSeg &ac = CP.segs[ct[id].acc];
+                    ac.lds_pva = va_slot_of_body(pb);
+                    if (ch.pair >= 0) {
+                        ChainSeg &pa = CP.segs[ct[id].pair_acc];
+                        pa.first = static_cast<int>(CP.pairs.size());
+                        CP.pairs.push_back(pair_of[ch.pair]);
+                    }
+                }
+                for (int c = 0; c < nc; c++) {
+                    if (cls[c] != 0) continue;
+                    const int fi = static_cast<int>(CP.frees.size());
+                    CP.frees.push_back(free_of[c]);
+                    CP.segs[t_free_fwd[c]].first = CP.segs[t_free_bwd[c]].first = CP.segs[t_free_acc[c]].first = fi;
+                }
+            }
+        }
+        CP.ok = ok;
+        if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); }
+    }
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
     // per-body costs: sincos ~40, E build 12, motion / force transform 39, sym6*vec 66 (48 against a

@@ -146,6 +146,83 @@ struct Layout {
     bool split_aba = false, split_rnea = false;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Chain program (chain_kernels.hip): the fast path of models made of a floating or fixed base, single revolute
+// links, RevoluteWithRotor clusters (link + axisymmetric rotor) and leaf RevolutePairWithRotor clusters -- every
+// legged robot of the reference that has a URDF.  The cluster tree is cut into CHAINS: maximal paths along which
+// every link carries exactly one child cluster.  A sweep over a chain is ONE tight loop over its links (a run):
+// the velocity / acceleration going down and the projected inertia / bias going up stay in registers from link to
+// link, and only what another segment needs goes through LDS.  Between segments everything is handed over through
+// LDS slots, so the segment loop of the kernel carries no vector state at all.
+// ---------------------------------------------------------------------------------------------------------------
+enum ChainOp : int32_t {
+    SEG_FREE_FWD = 0,   // floating base: velocity to its LDS slot
+    SEG_RUN_FWD = 1,    // links of a chain, root side first: sin / cos and velocity of every link with children
+    SEG_RUN_BWD = 2,    // leaf side first: [K | y0] of every link; (IA, psi) accumulated into the parent's slot at the end
+    SEG_FREE_BWD = 3,
+    SEG_FREE_ACC = 4,
+    SEG_RUN_ACC = 5,    // root side first: ydd of every link; (v, a) of the tip to LDS when child segments follow
+    SEG_PAIR_ACC = 6
+};
+enum ChainHead : int32_t {
+    HEAD_LEAF = 0,      // the first link of a backward run is a leaf: its accumulators start from its own inertia
+    HEAD_SLOT = 1,      // ... carries several child segments: accumulators come from its LDS slot
+    HEAD_PAIR = 2       // ... carries one leaf RevolutePairWithRotor cluster, evaluated at the start of the run
+};
+
+// one REV / REV_ROTOR cluster inside a run (16 ints: one s_load_dwordx16)
+struct ChainLink {
+    int32_t q_index, v_index;
+    int32_t cofs;       // link constants: Et[9] rt[3] I[21] g0 (consts[])
+    int32_t rofs;       // rotor constants (same layout), or -1: plain revolute cluster
+    int32_t iofs;       // the 21 constants I_link + sum over axisymmetric leaf children X0^T I X0 (BodyRec::xofs or cofs + 12)
+    int32_t lds_sv;     // LDS slot of [sin, cos, v 6], forward run -> backward run
+    int32_t lds_pv;     // LDS slot of the parent body's velocity (the v part of its lds_sv block), -1: ground
+    int32_t glb_k;      // global slab slot of [K 6][y0][sin][cos], backward run -> acceleration run
+    int32_t has_child;
+    int32_t lds_va;     // acceleration sweep: LDS slot of [v 6][a 6] when another segment reads them, else -1
+    int32_t reserved[6];
+};
+
+// a RevolutePairWithRotor-shaped leaf cluster (32 ints)
+struct ChainPair {
+    int32_t q_index, v_index;
+    int32_t cofs[4];    // constants of link1, link2, rotor1, rotor2: Et[9] rt[3] I[21] G row [2]
+    int32_t lds_pv;     // parent body's velocity
+    int32_t glb_k;      // [K 12][y0 2]
+    int32_t lds_pva;    // acceleration sweep: parent body's [v 6][a 6]
+    int32_t reserved[23];
+};
+
+struct ChainSeg {       // 16 ints
+    int32_t op;
+    int32_t first, count;   // runs: links[first .. first + count) in sweep order; pair / free: record index
+    int32_t head;           // SEG_RUN_BWD: ChainHead
+    int32_t head_arg;       // HEAD_SLOT: accumulator slot [IA 21][psi 6]; HEAD_PAIR: index into pairs[]
+    int32_t lds_acc_out;    // SEG_RUN_BWD: accumulator slot of the body the chain hangs off, -1: ground
+    int32_t acc_first;      // 1: this segment is the first writer of that slot
+    int32_t lds_pva;        // SEG_RUN_ACC: [v 6][a 6] of the body the chain hangs off, -1: ground (v = 0, a = a_root)
+    int32_t reserved[8];
+};
+
+struct ChainFree {      // 16 ints
+    int32_t q_index, v_index, cofs, iofs;
+    int32_t lds_v;      // forward: own velocity (children read it)
+    int32_t lds_acc;    // backward: accumulator slot, -1 when the base has no children
+    int32_t glb_y0;     // [y0 6]
+    int32_t lds_va;     // acceleration sweep: own [v 6][a 6], -1 when no children
+    int32_t reserved[8];
+};
+
+struct ChainProgram {
+    bool ok = false;                 // the model is covered and its LDS objects fit the budget
+    std::vector<ChainSeg> segs;
+    std::vector<ChainLink> links;    // in sweep order of each run (a cluster appears once per sweep it takes part in)
+    std::vector<ChainPair> pairs;
+    std::vector<ChainFree> frees;
+    int n_lds = 0, n_glb = 0;        // slots
+};
+
 // LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
 // wavefronts per CU and more state in the global slab; the best trade differs per kernel.
 struct LdsBudget {
@@ -163,6 +240,7 @@ struct HostPlan {
     Layout lay32, lay64;      // fast path
     Layout lay32x, lay64x;    // with absolute transforms kept for external forces (TreeNode::Xa_)
     Layout lay32s;            // f32 fast path, split layout (used when split_aba / split_rnea)
+    ChainProgram chain32;     // f32 ABA, chain-structured fast path (chain_kernels.hip)
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };

@@ -94,6 +94,8 @@ typedef struct {
     int split_aba_f32, split_rnea_f32; /* 1: the f32 kernel runs the split layout ([K | y0] blocks in the global slab,
                                           every other object in LDS, plan.h Layout::split_*) */
     int n_lds_slots_split_f32;
+    int chain_aba_f32;         /* 1: the f32 forward dynamics run the chain-structured kernel (plan.h, ChainProgram) */
+    int n_lds_slots_chain_f32, n_chain_segments;
 } grbda_plan_info_t;
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 
