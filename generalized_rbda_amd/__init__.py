@@ -47,7 +47,8 @@ class PlanInfo(ctypes.Structure):
                 ("bytes_aba_f32", c_double), ("bytes_aba_f64", c_double),
                 ("n_axisym_bodies", c_int), ("n_carry_clusters", c_int),
                 ("split_aba_f32", c_int), ("split_rnea_f32", c_int), ("n_lds_slots_split_f32", c_int),
-                ("chain_aba_f32", c_int), ("n_lds_slots_chain_f32", c_int), ("n_chain_segments", c_int)]
+                ("chain_aba_f32", c_int), ("n_lds_slots_chain_f32", c_int), ("n_chain_segments", c_int),
+                ("chain_aba_f64", c_int)]
 
 
 _lib = None

@@ -50,10 +50,11 @@ struct DeviceTables {
     double *consts64 = nullptr;
     float *consts32 = nullptr;
     // chain program of the f32 fast path (plan.h, ChainProgram)
-    ChainSeg *chain_segs = nullptr;
-    ChainLink *chain_links = nullptr;
-    ChainPair *chain_pairs = nullptr;
-    ChainFree *chain_frees = nullptr;
+    // [0] f32, two wavefronts per SIMD (HostPlan::chain32), [1] f32, four (chain32w), [2] f64 (chain64)
+    ChainSeg *chain_segs[3] = {nullptr, nullptr, nullptr};
+    ChainLink *chain_links[3] = {nullptr, nullptr, nullptr};
+    ChainPair *chain_pairs[3] = {nullptr, nullptr, nullptr};
+    ChainFree *chain_frees[3] = {nullptr, nullptr, nullptr};
     int n_cu = 0;
 };
 struct Scratch {
@@ -91,6 +92,8 @@ struct grbda_plan {
     int waves_per_cu[4] = {8, 8, 16, 6};
     bool no_split = false;
     bool no_chain = false;  // GRBDA_NO_CHAIN=1: keep the general interpreter (A/B runs, tests of the general kernels)
+    int chain_debug = 0;
+    bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
 };
 
 namespace {
@@ -153,12 +156,13 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(L.acc_k.data(), L.acc_k.size() * sizeof(int32_t), (void **)&t.acc_k[w])) != hipSuccess)
             return hip_err(e, "plan upload");
     }
-    if (h.chain32.ok) {
-        const ChainProgram &cp = h.chain32;
-        if ((e = up(cp.segs.data(), cp.segs.size() * sizeof(ChainSeg), (void **)&t.chain_segs)) != hipSuccess ||
-            (e = up(cp.links.data(), cp.links.size() * sizeof(ChainLink), (void **)&t.chain_links)) != hipSuccess ||
-            (e = up(cp.pairs.data(), cp.pairs.size() * sizeof(ChainPair), (void **)&t.chain_pairs)) != hipSuccess ||
-            (e = up(cp.frees.data(), cp.frees.size() * sizeof(ChainFree), (void **)&t.chain_frees)) != hipSuccess)
+    for (int w = 0; w < 3; w++) {
+        const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : h.chain64);
+        if (!cp.ok) continue;
+        if ((e = up(cp.segs.data(), cp.segs.size() * sizeof(ChainSeg), (void **)&t.chain_segs[w])) != hipSuccess ||
+            (e = up(cp.links.data(), cp.links.size() * sizeof(ChainLink), (void **)&t.chain_links[w])) != hipSuccess ||
+            (e = up(cp.pairs.data(), cp.pairs.size() * sizeof(ChainPair), (void **)&t.chain_pairs[w])) != hipSuccess ||
+            (e = up(cp.frees.data(), cp.frees.size() * sizeof(ChainFree), (void **)&t.chain_frees[w])) != hipSuccess)
             return hip_err(e, "plan upload");
         if ((e = set_max_dynamic_lds_chain()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
@@ -220,43 +224,60 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, 
     return d;
 }
 
-int run_chain(const grbda_plan *p, const DeviceTables &t, const float *q, const float *qd, const float *tau, float *ydd, size_t B,
+template <class T>
+bool chain_covers(const grbda_plan *p)
+{
+    if (p->no_chain) return false;
+    if (sizeof(T) == 8) return p->host.chain64.ok;
+    return p->host.chain32.ok || (p->host.chain32w.ok && p->chain_wide);
+}
+
+template <class T>
+int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *qd, const T *tau, T *ydd, size_t B,
               int device, void *stream)
 {
     const HostPlan &h = p->host;
-    const ChainProgram &cp = h.chain32;
-    ChainDev<float> d;
-    d.segs = t.chain_segs;
-    d.links = t.chain_links;
-    d.pairs = t.chain_pairs;
-    d.frees = t.chain_frees;
-    d.consts = t.consts32;
+    // f32: four wavefronts per SIMD (16 per CU, half the LDS each) once the batch fills them, when that layout exists
+    const size_t n_tiles0 = (B + kWave - 1) / kWave;
+    const bool wide = sizeof(T) == 4 && h.chain32w.ok && p->chain_wide && (!h.chain32.ok || n_tiles0 > static_cast<size_t>(t.n_cu) * 8);
+    const int w = sizeof(T) == 8 ? 2 : (wide ? 1 : 0);
+    const int kid = sizeof(T) == 8 ? 1 : 0;
+    const ChainProgram &cp = w == 2 ? h.chain64 : (wide ? h.chain32w : h.chain32);
+    const size_t waves_per_cu = wide ? 16 : static_cast<size_t>(p->waves_per_cu[kid]);
+    const size_t lds_budget = wide ? 10240 : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
+    ChainDev<T> d;
+    d.segs = t.chain_segs[w];
+    d.links = t.chain_links[w];
+    d.pairs = t.chain_pairs[w];
+    d.frees = t.chain_frees[w];
+    d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.n_segs = static_cast<int>(cp.segs.size());
     d.nq = h.nq;
     d.nv = h.nv;
     d.n_glb_slots = cp.n_glb;
     d.ori_repr = h.ori_repr;
-    for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<float>(-h.gravity[i]);
+    d.debug = p->chain_debug;
+    for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;
-    size_t grid = static_cast<size_t>(t.n_cu) * static_cast<size_t>(p->waves_per_cu[0]);
+    size_t grid = static_cast<size_t>(t.n_cu) * waves_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     // LDS: the slot store, and at tile boundaries the staging area of the input transposition
-    size_t lds_bytes = static_cast<size_t>(cp.n_lds) * kWave * sizeof(float);
-    const size_t stage_one = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq > d.nv ? d.nq : d.nv) * sizeof(float);
-    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq + 2 * d.nv) * sizeof(float);
+    size_t lds_bytes = static_cast<size_t>(cp.n_lds) * kWave * sizeof(T);
+    const size_t stage_one = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq > d.nv ? d.nq : d.nv) * sizeof(T);
+    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq + 2 * d.nv) * sizeof(T);
     if (lds_bytes < stage_one) lds_bytes = stage_one;
-    if (lds_bytes < stage_all && stage_all <= static_cast<size_t>(p->lds_bytes_per_wave[0])) lds_bytes = stage_all;
+    if (lds_bytes < stage_all && stage_all <= lds_budget) lds_bytes = stage_all;
     d.lds_bytes = static_cast<int>(lds_bytes);
     const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
-    if (fit >= 1 && fit < static_cast<size_t>(p->waves_per_cu[0])) {
+    if (fit >= 1 && fit < waves_per_cu) {
         const size_t g2 = static_cast<size_t>(t.n_cu) * fit;
         if (grid > g2) grid = g2;
     }
     const size_t n_rows = static_cast<size_t>(cp.n_glb) + static_cast<size_t>(d.nq + 2 * d.nv);
     void *scratch = nullptr;
-    if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(float) + 256, &scratch)) return rc;
-    hipError_t e = launch_aba_chain<float>(d, q, qd, tau, ydd, B, static_cast<float *>(scratch), static_cast<int>(grid), lds_bytes,
-                                           static_cast<hipStream_t>(stream));
+    if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(T) + 256, &scratch)) return rc;
+    hipError_t e = launch_aba_chain<T>(d, q, qd, tau, ydd, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
+                                           static_cast<hipStream_t>(stream), wide);
     return e == hipSuccess ? GRBDA_OK : hip_err(e, "aba chain launch");
 }
 
@@ -268,10 +289,8 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     if (B == 0) return GRBDA_OK;
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
-    if constexpr (sizeof(T) == 4) {
-        // chain-structured fast path (chain_kernels.hip): f32 forward dynamics of models the chain program covers
-        if (!rnea && !f_ext && p->host.chain32.ok && !p->no_chain) return run_chain(p, *t, q, qd, x, out, B, device, stream);
-    }
+    // chain-structured fast path (chain_kernels.hip): forward dynamics of models the chain program covers
+    if (!rnea && !f_ext && chain_covers<T>(p)) return run_chain<T>(p, *t, q, qd, x, out, B, device, stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, rnea, f_ext != nullptr);
     d.fext = f_ext;
     const size_t n_tiles = (B + kWave - 1) / kWave;
@@ -915,11 +934,14 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     }
     p->no_split = env_int("GRBDA_NO_SPLIT", 0) != 0;
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;
+    p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
+    p->chain_debug = env_int("GRBDA_CHAIN_DEBUG", 0);
     LdsBudget lds;
     lds.aba32 = p->lds_bytes_per_wave[0] / (4 * kWave);
     lds.aba64 = p->lds_bytes_per_wave[1] / (8 * kWave);
     lds.rnea32 = p->lds_bytes_per_wave[2] / (4 * kWave);
     lds.rnea64 = p->lds_bytes_per_wave[3] / (8 * kWave);
+    lds.chain32w = 10240 / (4 * kWave);
     // profiling aid (results are wrong when set): GRBDA_DEBUG_SWEEPS is a bit mask of the ABA sweeps to
     // keep -- 1 forward, 2 backward, 4 acceleration -- so that the cost of each sweep can be ablated
     const int sweeps = env_int("GRBDA_DEBUG_SWEEPS", 7);
@@ -964,7 +986,7 @@ void grbda_plan_free(grbda_plan *p)
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map);
-        (void)hipFree(t.chain_segs); (void)hipFree(t.chain_links); (void)hipFree(t.chain_pairs); (void)hipFree(t.chain_frees);
+        for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work})
@@ -1031,6 +1053,7 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->chain_aba_f32 = p->host.chain32.ok && !p->no_chain;
     info->n_lds_slots_chain_f32 = p->host.chain32.n_lds;
     info->n_chain_segments = static_cast<int>(p->host.chain32.segs.size());
+    info->chain_aba_f64 = p->host.chain64.ok && !p->no_chain;
     return GRBDA_OK;
 }
 

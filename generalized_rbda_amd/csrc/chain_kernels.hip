@@ -71,6 +71,19 @@ struct ChainMem {
 #pragma unroll
         for (int i = 0; i < N; i++) p[i * kWave] = x[i];
     }
+    // accumulators of branching bodies: LDS, or the global slab when the plan could not fit them (rare accesses)
+    template <int N>
+    __device__ __forceinline__ void acc_ld(int s, T (&x)[N]) const
+    {
+        if (s & kSlotGlobal) glb_ld(s, x);
+        else lds_ld(s, x);
+    }
+    template <int N>
+    __device__ __forceinline__ void acc_st(int s, const T (&x)[N]) const
+    {
+        if (s & kSlotGlobal) glb_st(s, x);
+        else lds_st(s, x);
+    }
     __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
     __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
     __device__ __forceinline__ T x(int j) const { return in_x[(size_t)j * kWave]; }
@@ -304,7 +317,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         pair_bwd(P, M, pr, IAc, psic);
     } else if (sg.head == HEAD_SLOT) {
         T acc[27];
-        M.lds_ld(sg.head_arg, acc);
+        M.acc_ld(sg.head_arg, acc);
 #pragma unroll
         for (int j = 0; j < 21; j++) IAc[j] = acc[j];
 #pragma unroll
@@ -406,7 +419,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         }
     }
     // hand the chain's projected inertia / bias to the body it hangs off
-    if (sg.lds_acc_out >= 0) {
+    if (sg.lds_acc_out != -1) {
         T acc[27];
         if (sg.acc_first) {
 #pragma unroll
@@ -414,13 +427,13 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
             for (int j = 0; j < 6; j++) acc[21 + j] = psic[j];
         } else {
-            M.lds_ld(sg.lds_acc_out, acc);
+            M.acc_ld(sg.lds_acc_out, acc);
 #pragma unroll
             for (int j = 0; j < 21; j++) acc[j] += IAc[j];
 #pragma unroll
             for (int j = 0; j < 6; j++) acc[21 + j] += psic[j];
         }
-        M.lds_st(sg.lds_acc_out, acc);
+        M.acc_st(sg.lds_acc_out, acc);
     }
 }
 
@@ -517,9 +530,9 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
 #pragma unroll
     for (int j = 0; j < 6; j++) v[j] = M.qd(f.v_index + j);
     bias_force(Ic, v, psi);
-    if (f.lds_acc >= 0) {
+    if (f.lds_acc != -1) {
         T acc[27];
-        M.lds_ld(f.lds_acc, acc);
+        M.acc_ld(f.lds_acc, acc);
 #pragma unroll
         for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
@@ -570,8 +583,8 @@ __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(kWave, 2) void aba_chain_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
+template <class T, int WPS>
+__global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
                                                              const T *__restrict__ tau, T *__restrict__ ydd, size_t B,
                                                              T *__restrict__ scratch)
 {
@@ -602,8 +615,10 @@ __global__ __launch_bounds__(kWave, 2) void aba_chain_kernel(ChainDev<T> DP, con
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
-        stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
-        for (int s = 0; s < P.n_segs; s++) {
+        // (DP.debug: profiling aid of tools/chain_ablate.py -- bit 0 skips the prologue, bit 1 the segments, bit 2 the
+        // epilogue; results are then meaningless)
+        if (!(DP.debug & 1)) stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        for (int s = 0; s < ((DP.debug & 2) ? 0 : P.n_segs); s++) {
             const ChainSeg sg = load_rec(P.segs + s);
             switch (sg.op) {
                 case SEG_RUN_FWD: run_fwd(P, M, sg); break;
@@ -620,23 +635,37 @@ __global__ __launch_bounds__(kWave, 2) void aba_chain_kernel(ChainDev<T> DP, con
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
-        write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        if (!(DP.debug & 4)) write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
     }
 }
 
 template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
-                            size_t lds_bytes, hipStream_t stream)
+                            size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd)
 {
-    hipLaunchKernelGGL((aba_chain_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    if constexpr (sizeof(T) == 4) {
+        if (four_waves_per_simd) {
+            hipLaunchKernelGGL((aba_chain_kernel<T, 4>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((aba_chain_kernel<T, 2>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
 template hipError_t launch_aba_chain<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
-                                            float *, int, size_t, hipStream_t);
+                                            float *, int, size_t, hipStream_t, bool);
+template hipError_t launch_aba_chain<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
+                                             size_t, double *, int, size_t, hipStream_t, bool);
 
 hipError_t set_max_dynamic_lds_chain()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<double, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float, 4>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 

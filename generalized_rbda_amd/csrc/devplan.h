@@ -56,11 +56,12 @@ struct ChainDev {
     int n_glb_slots;
     int lds_bytes;
     int ori_repr;
+    int debug;   // GRBDA_CHAIN_DEBUG: phase ablation for profiling (chain_kernels.hip)
     T a_root[6];
 };
 template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
-                            size_t lds_bytes, hipStream_t stream);
+                            size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd);
 hipError_t set_max_dynamic_lds_chain();
 
 }  // namespace grbda_hip

@@ -768,8 +768,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     build_layout(P.lay64x, lds.aba64, lds.rnea64, true);
 
     // ---- chain program of the f32 fast path (plan.h, ChainProgram; chain_kernels.hip) ----------------------------
-    {
-        ChainProgram &CP = P.chain32;
+    auto build_chain = [&](ChainProgram &CP, int lds_budget) {
         CP = ChainProgram();
         bool ok = sweep_mask == 7;
         // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, -1 unsupported
@@ -989,7 +988,17 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 }
             }
             int n_lds = 0, n_glb_unused = 0;
-            ok = allocate(objs, lds.aba32, n_lds, n_glb_unused);
+            ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
+            if (!ok) {
+                // second try: the accumulators [IA 21][psi 6] of branching bodies -- touched once per child chain -- move
+                // to the wave's global slab (their slot numbers then carry kSlotGlobal)
+                for (Obj &o : objs)
+                    if (o.size == 27) { o.force = 2; o.slot = -1; }
+                ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
+                for (Obj &o : objs)
+                    if (o.size == 27) *o.field = ((o.slot & ~kSlotGlobal) + n_glb) | kSlotGlobal;
+                n_glb += n_glb_unused;
+            }
             if (ok) {
                 CP.n_lds = n_lds;
                 CP.n_glb = n_glb;
@@ -1054,7 +1063,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
         CP.ok = ok;
         if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); }
-    }
+    };
+    build_chain(P.chain32, lds.aba32);
+    build_chain(P.chain32w, lds.chain32w);
+    build_chain(P.chain64, lds.aba64);
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
     // per-body costs: sincos ~40, E build 12, motion / force transform 39, sym6*vec 66 (48 against a

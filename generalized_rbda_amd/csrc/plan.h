@@ -198,7 +198,8 @@ struct ChainSeg {       // 16 ints
     int32_t op;
     int32_t first, count;   // runs: links[first .. first + count) in sweep order; pair / free: record index
     int32_t head;           // SEG_RUN_BWD: ChainHead
-    int32_t head_arg;       // HEAD_SLOT: accumulator slot [IA 21][psi 6]; HEAD_PAIR: index into pairs[]
+    int32_t head_arg;       // HEAD_SLOT: accumulator slot [IA 21][psi 6] (LDS, or global slab when kSlotGlobal is set);
+                            // HEAD_PAIR: index into pairs[]
     int32_t lds_acc_out;    // SEG_RUN_BWD: accumulator slot of the body the chain hangs off, -1: ground
     int32_t acc_first;      // 1: this segment is the first writer of that slot
     int32_t lds_pva;        // SEG_RUN_ACC: [v 6][a 6] of the body the chain hangs off, -1: ground (v = 0, a = a_root)
@@ -227,6 +228,7 @@ struct ChainProgram {
 // wavefronts per CU and more state in the global slab; the best trade differs per kernel.
 struct LdsBudget {
     int aba32 = 0, aba64 = 0, rnea32 = 0, rnea64 = 0;
+    int chain32w = 0;  // chain program at four wavefronts per SIMD
 };
 
 struct HostPlan {
@@ -240,7 +242,9 @@ struct HostPlan {
     Layout lay32, lay64;      // fast path
     Layout lay32x, lay64x;    // with absolute transforms kept for external forces (TreeNode::Xa_)
     Layout lay32s;            // f32 fast path, split layout (used when split_aba / split_rnea)
-    ChainProgram chain32;     // f32 ABA, chain-structured fast path (chain_kernels.hip)
+    ChainProgram chain32;     // f32 ABA, chain-structured fast path (chain_kernels.hip), two wavefronts per SIMD
+    ChainProgram chain32w;    // the same laid out for four wavefronts per SIMD (half the LDS per wavefront)
+    ChainProgram chain64;     // f64 ABA (slots are twice as large: the LDS budget holds half as many)
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };

@@ -17,6 +17,19 @@ def random_inertia(rng, massless=False):
     return md.spatial_inertia(m, com, I3)
 
 
+def axisym_rotor_inertia(rng, axis, massless=False):
+    """A rotor whose inertia is invariant under rotation about its joint axis (COM on the axis, equal transverse
+    inertias) -- what the reference's geared rotors are (MIT_Humanoid.hpp:46-66) and what the plan compiler's q = 0
+    shortcut and the chain kernels rely on."""
+    a, b = rng.uniform(1e-4, 5e-3), rng.uniform(1e-4, 5e-3)
+    I3 = np.eye(3) * a
+    k = "xyz".index(axis)
+    I3[k, k] = b
+    com = np.zeros(3)
+    com[k] = rng.uniform(-0.05, 0.05)
+    return md.spatial_inertia(0.0 if massless else rng.uniform(0.02, 0.2), com, I3)
+
+
 def random_xtree(rng):
     return md.rpy_to_rotmat(rng.uniform(-1, 1, 3)), rng.uniform(-0.5, 0.5, 3)
 
@@ -48,6 +61,33 @@ def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor"
             m.appendRegisteredBodiesAsCluster(f"c{c}", "RevoluteWithRotor", joint_axis=ax(), rotor_axis=ax(),
                                               gear_ratio=rng.uniform(2, 12))
             link_names.append(f"l{c}")
+        elif kind == "axirotor":  # RevoluteWithRotor with an axisymmetric rotor (the shape of every geared joint of the reference's robots)
+            E, r = random_xtree(rng)
+            m.registerBody(f"l{c}", random_inertia(rng), parent, E, r)
+            E2, r2 = random_xtree(rng)
+            ra = ax()
+            m.registerBody(f"r{c}", axisym_rotor_inertia(rng, ra, massless=rng.random() < 0.3), parent, E2, r2)
+            m.appendRegisteredBodiesAsCluster(f"c{c}", "RevoluteWithRotor", joint_axis=ax(), rotor_axis=ra,
+                                              gear_ratio=rng.uniform(2, 12))
+            link_names.append(f"l{c}")
+        elif kind == "axipair":  # leaf RevolutePairWithRotor with axisymmetric rotors (MIT humanoid knee / ankle)
+            X = [random_xtree(rng) for _ in range(4)]
+            ra = ax() + ax()
+            order = rng.permutation(3)  # registration order of [rotor2, link1, rotor1] varies; link2 comes after link1
+            regs = {}
+            for o in order:
+                if o == 0:
+                    regs["r2"] = m.registerBody(f"r2_{c}", axisym_rotor_inertia(rng, ra[1]), parent, *X[0])
+                elif o == 1:
+                    regs["l1"] = m.registerBody(f"l1_{c}", random_inertia(rng), parent, *X[1])
+                else:
+                    regs["r1"] = m.registerBody(f"r1_{c}", axisym_rotor_inertia(rng, ra[0]), parent, *X[2])
+            regs["l2"] = m.registerBody(f"l2_{c}", random_inertia(rng), f"l1_{c}", *X[3])
+            m.appendRegisteredBodiesAsCluster(f"c{c}", "RevolutePairWithRotor", link1=regs["l1"], rotor1=regs["r1"],
+                                              rotor2=regs["r2"], link2=regs["l2"], joint_axes=ax() + ax(), rotor_axes=ra,
+                                              gear_ratios=rng.uniform(2, 10, 2), belt_ratios_1=rng.uniform(1, 3, 1),
+                                              belt_ratios_2=rng.uniform(1, 3, 2))
+            # a leaf cluster: nothing hangs off it
         elif kind == "pair":
             # MIT-humanoid knee/ankle registration order: [rotor2, link1, rotor1, link2]
             X = [random_xtree(rng) for _ in range(4)]
@@ -94,6 +134,63 @@ def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor"
                     K[r_, ii] = w[j]
             m.appendRegisteredBodiesAsCluster(f"c{c}", "Generic", axes=[ax() for _ in range(k)], G=G, K=K)
             link_names += names
+    return m
+
+
+def chain_test_tree(seed, n_limbs=4, ori_repr="quaternion", rotors=True):
+    """A floating-base robot of the kind the chain-structured kernels cover (plan.h, ChainProgram): limbs that are
+    chains of revolute links (with axisymmetric rotors when `rotors`), some ending in a leaf RevolutePairWithRotor
+    cluster, some branching into two sub-chains half way down."""
+    rng = np.random.default_rng(seed)
+    m = md.ClusterTreeModel(gravity=(0.0, 0.0, -9.81), ori_repr=ori_repr)
+    m.appendBody("base", random_inertia(rng), "ground", joint="free")
+    ax = lambda: "xyz"[rng.integers(3)]
+    count = [0]
+
+    def link(parent):
+        c = count[0]
+        count[0] += 1
+        E, r = random_xtree(rng)
+        if rotors and rng.random() < 0.8:
+            m.registerBody(f"l{c}", random_inertia(rng), parent, E, r)
+            ra = ax()
+            m.registerBody(f"r{c}", axisym_rotor_inertia(rng, ra, massless=rng.random() < 0.3), parent, *random_xtree(rng))
+            m.appendRegisteredBodiesAsCluster(f"c{c}", "RevoluteWithRotor", joint_axis=ax(), rotor_axis=ra, gear_ratio=rng.uniform(2, 12))
+        else:
+            m.appendBody(f"l{c}", random_inertia(rng), parent, E, r, joint="revolute", axis=ax())
+        return f"l{c}"
+
+    def pair(parent):
+        c = count[0]
+        count[0] += 1
+        X = [random_xtree(rng) for _ in range(4)]
+        ra = ax() + ax()
+        regs = {}
+        for o in rng.permutation(3):
+            if o == 0:
+                regs["r2"] = m.registerBody(f"r2_{c}", axisym_rotor_inertia(rng, ra[1]), parent, *X[0])
+            elif o == 1:
+                regs["l1"] = m.registerBody(f"l1_{c}", random_inertia(rng), parent, *X[1])
+            else:
+                regs["r1"] = m.registerBody(f"r1_{c}", axisym_rotor_inertia(rng, ra[0]), parent, *X[2])
+        regs["l2"] = m.registerBody(f"l2_{c}", random_inertia(rng), f"l1_{c}", *X[3])
+        m.appendRegisteredBodiesAsCluster(f"c{c}", "RevolutePairWithRotor", link1=regs["l1"], rotor1=regs["r1"], rotor2=regs["r2"],
+                                          link2=regs["l2"], joint_axes=ax() + ax(), rotor_axes=ra, gear_ratios=rng.uniform(2, 10, 2),
+                                          belt_ratios_1=rng.uniform(1, 3, 1), belt_ratios_2=rng.uniform(1, 3, 2))
+
+    def chain(parent, length, depth):
+        p = parent
+        for i in range(length):
+            p = link(p)
+            if depth < 1 and i == length // 2 and rng.random() < 0.5:  # a branching link: two sub-chains below it
+                chain(p, int(rng.integers(1, 3)), depth + 1)
+                chain(p, int(rng.integers(1, 3)), depth + 1)
+                return
+        if rng.random() < 0.5:
+            pair(p)
+
+    for _ in range(n_limbs):
+        chain("base", int(rng.integers(1, 5)), 0)
     return m
 
 
@@ -144,6 +241,14 @@ def zoo():
     z["tree_pair_float"] = random_cluster_tree(3, 6, floating=True, kinds=("pair", "rotor")).serialize()
     z["tree_triple_fixed"] = random_cluster_tree(4, 4, floating=False, kinds=("triple", "rev")).serialize()
     z["tree_generic_float"] = random_cluster_tree(5, 7, floating=True, kinds=("generic",)).serialize()
+    # models the chain-structured kernels cover (plan.h, ChainProgram): floating base, revolute links, links with
+    # axisymmetric rotors, leaf pair clusters -- random topologies with long chains, branching links and mixed runs
+    z["tree_chain_rotor_float"] = random_cluster_tree(11, 14, floating=True, kinds=("axirotor",)).serialize()
+    z["tree_chain_rev_float"] = random_cluster_tree(14, 10, floating=True, kinds=("rev",)).serialize()
+    z["chain_tree_a"] = chain_test_tree(21, 4).serialize()
+    z["chain_tree_b"] = chain_test_tree(22, 5).serialize()
+    z["chain_tree_rpy"] = chain_test_tree(23, 3, ori_repr="rpy").serialize()
+    z["chain_tree_norotor"] = chain_test_tree(24, 4, rotors=False).serialize()
     z["tree_mixed_float"] = random_cluster_tree(6, 12, floating=True).serialize()
     z["tree_mixed_fixed"] = random_cluster_tree(7, 10, floating=False).serialize()
     return z
