@@ -107,6 +107,35 @@ __device__ __forceinline__ void bias_force(cptr<T> I, const T (&v)[6], T (&p)[6]
     crf(v, Iv, p);
 }
 
+// Axisymmetric rotor evaluated at q = 0 (plan.cpp): a body whose inertia is invariant under rotation about its joint
+// axis z has the spatial inertia  [[A,0,0,0,k,0],[0,A,0,-k,0,0],[0,0,B,0,0,0],[0,-k,0,m,0,0],[k,0,0,0,m,0],[0,0,0,0,0,m]]
+// (k = m c_z), so I v and I c cost 10 / 8 operations instead of 36 / 24, h = I[:, z] = B e_z makes the joint-space
+// bias b = pA_z, and the force per unit rotor acceleration X0^T h is a plan constant (ChainLink::rpre).
+// In: parent velocity vp, rotor rate qdr.  Out: b (bias torque about the rotor axis), tp = X0^T (pA + I c) at the parent.
+template <class T>
+__device__ __forceinline__ void rotor_terms(cptr<T> Cr, const T (&vp)[6], T qdr, T &b, T (&tp)[6])
+{
+    cptr<T> Ir = Cr + 12;
+    const T A0 = Ir[sidx(0, 0)], A1 = Ir[sidx(1, 1)], Bz = Ir[sidx(2, 2)], k04 = Ir[sidx(0, 4)], k13 = Ir[sidx(1, 3)];
+    const T m3 = Ir[sidx(3, 3)], m4 = Ir[sidx(4, 4)], m5 = Ir[sidx(5, 5)];
+    T E0[9], vr[6];
+#pragma unroll
+    for (int j = 0; j < 9; j++) E0[j] = Cr[j];
+    xmotion(E0, Cr + 9, vp, vr);
+    vr[2] += qdr;
+    // I v
+    const T Iv[6] = {A0 * vr[0] + k04 * vr[4], A1 * vr[1] + k13 * vr[3], Bz * vr[2],
+                     m3 * vr[3] + k13 * vr[1], m4 * vr[4] + k04 * vr[0], m5 * vr[5]};
+    T pA[6];
+    crf(vr, Iv, pA);
+    b = pA[2];
+    // c = v x (z qdr) = (v1, -v0, 0, v4, -v3, 0) qdr ;  t = pA + I c
+    const T c0 = vr[1] * qdr, c1 = -vr[0] * qdr, c3 = vr[4] * qdr, c4 = -vr[3] * qdr;
+    T t[6] = {pA[0] + A0 * c0 + k04 * c4, pA[1] + A1 * c1 + k13 * c3, pA[2],
+              pA[3] + m3 * c3 + k13 * c1, pA[4] + m4 * c4 + k04 * c0, pA[5]};
+    xforce_inv(E0, Cr + 9, t, tp);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward run: TreeModel::forwardKinematics (TreeModel.cpp:6-32) along a chain, root side first
 // ---------------------------------------------------------------------------------------------------------------
@@ -123,21 +152,33 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
             for (int j = 0; j < 6; j++) vp[j] = 0;
         }
     }
+    // the inputs of the next link travel (global slab rows, L2 latency) while the current link is computed
+    ChainLink l = load_rec(P.links + sg.first);
+    T qi = M.q(l.q_index), qdi_in = M.qd(l.v_index);
     for (int i = 0; i < sg.count; i++) {
-        const ChainLink l = load_rec(P.links + (sg.first + i));
+        const bool more = i + 1 < sg.count;
+        const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
+        T qn = 0, qdn = 0;
+        if (more) {
+            qn = M.q(ln.q_index);
+            qdn = M.qd(ln.v_index);
+        }
         cptr<T> C = P.consts + l.cofs;
         const T g0 = C[kBodyConstFixed];
         T blk[8], E[9], v[6];
-        sincos_t(g0 * M.q(l.q_index), &blk[0], &blk[1]);
+        sincos_t(g0 * qi, &blk[0], &blk[1]);
         rotate_z(blk[0], blk[1], C, E);
         xmotion(E, C + 9, vp, v);
-        v[2] += g0 * M.qd(l.v_index);
+        v[2] += g0 * qdi_in;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             blk[2 + j] = v[j];
             vp[j] = v[j];
         }
         M.lds_st(l.lds_sv, blk);
+        l = ln;
+        qi = qn;
+        qdi_in = qdn;
     }
 }
 
@@ -234,37 +275,21 @@ __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         cptr<T> Cr = P.consts + pr.cofs[2 + r];
-        cptr<T> Ir = Cr + 12;
+        cptr<T> Rp = P.consts + pr.rpre[r];
         const T ga = Cr[kBodyConstFixed], gb = Cr[kBodyConstFixed + 1];
-        const T qdr = ga * yd1 + gb * yd2;
-        T E0[9], vr[6], cr[6], prr[6], hr[6];
-#pragma unroll
-        for (int j = 0; j < 9; j++) E0[j] = Cr[j];
-        xmotion(E0, Cr + 9, vp, vr);
-        vr[2] += qdr;
-        vxz(vr, qdr, cr);
-        bias_force(Ir, vr, prr);
-#pragma unroll
-        for (int i = 0; i < 6; i++) hr[i] = Ir[sidx(i, 2)];
-        const T bj = prr[2] + hr[0] * cr[0] + hr[1] * cr[1] + hr[3] * cr[3] + hr[4] * cr[4];
+        T bj, tp[6];
+        rotor_terms(Cr, vp, ga * yd1 + gb * yd2, bj, tp);
         u[0] -= ga * bj;
         u[1] -= gb * bj;
-        D00 += hr[2] * ga * ga;
-        D01 += hr[2] * ga * gb;
-        D11 += hr[2] * gb * gb;
-        T fr[6], t[6], tp[6];
-        xforce_inv(E0, Cr + 9, hr, fr);
+        D00 += Rp[6] * ga * ga;
+        D01 += Rp[6] * ga * gb;
+        D11 += Rp[6] * gb * gb;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            F0[j] += fr[j] * ga;
-            F1[j] += fr[j] * gb;
+            F0[j] += Rp[j] * ga;
+            F1[j] += Rp[j] * gb;
+            psi[j] += tp[j];
         }
-        symv_z(Ir, cr, t);
-#pragma unroll
-        for (int j = 0; j < 6; j++) t[j] += prr[j];
-        xforce_inv(E0, Cr + 9, t, tp);
-#pragma unroll
-        for (int j = 0; j < 6; j++) psi[j] += tp[j];
     }
     // ---- D^-1 (2 x 2, SPD), K = D^-1 F^T, y0 = D^-1 u ----
     const T idet = rcp_t(D00 * D11 - D01 * D01);
@@ -328,13 +353,21 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
         for (int j = 0; j < 6; j++) psic[j] = 0;
     }
+    // the inputs of the next link travel (global slab rows, L2 latency) while the current link is computed
+    ChainLink l = load_rec(P.links + sg.first);
+    T yd = M.qd(l.v_index), tau_in = M.x(l.v_index);
     for (int i = 0; i < sg.count; i++) {
-        const ChainLink l = load_rec(P.links + (sg.first + i));
+        const bool more = i + 1 < sg.count;
+        const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
+        T ydn = 0, taun = 0;
+        if (more) {
+            ydn = M.qd(ln.v_index);
+            taun = M.x(ln.v_index);
+        }
         cptr<T> C = P.consts + l.cofs;
         cptr<T> Ic = C + 12;
         cptr<T> Ib = P.consts + l.iofs;
         const T g0 = C[kBodyConstFixed];
-        const T yd = M.qd(l.v_index);
         const T qdi = g0 * yd;
         T blk[8], E[9], v[6];
         M.lds_ld(l.lds_sv, blk);
@@ -354,7 +387,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
         for (int k = 0; k < 6; k++) h[k] = IA[sidx(k, 2)];
         const T bj = psi[2] + h[0] * chat[0] + h[1] * chat[1] + h[3] * chat[3] + h[4] * chat[4];
-        T u = M.x(l.v_index) - g0 * bj;
+        T u = tau_in - g0 * bj;
         T D = h[2] * g0 * g0;
         T F[6];
         xforce_inv(E, C + 9, h, F);
@@ -370,9 +403,8 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         }
         if constexpr (ROTOR) {
             cptr<T> Cr = P.consts + l.rofs;
-            cptr<T> Ir = Cr + 12;
+            cptr<T> Rp = P.consts + l.rpre;  // [X0^T h (6)][h_z]
             const T gr = Cr[kBodyConstFixed];
-            const T qdr = gr * yd;
             T vp[6];
             if (l.lds_pv >= 0) {
                 M.lds_ld(l.lds_pv, vp);
@@ -380,26 +412,12 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
                 for (int j = 0; j < 6; j++) vp[j] = 0;
             }
-            T E0[9], vr[6], cr[6], prr[6], hr[6];
-#pragma unroll
-            for (int j = 0; j < 9; j++) E0[j] = Cr[j];
-            xmotion(E0, Cr + 9, vp, vr);
-            vr[2] += qdr;
-            vxz(vr, qdr, cr);
-            bias_force(Ir, vr, prr);
-#pragma unroll
-            for (int k = 0; k < 6; k++) hr[k] = Ir[sidx(k, 2)];
-            const T bjr = prr[2] + hr[0] * cr[0] + hr[1] * cr[1] + hr[3] * cr[3] + hr[4] * cr[4];
+            T bjr, tp[6];
+            rotor_terms(Cr, vp, gr * yd, bjr, tp);
             u -= gr * bjr;
-            D += hr[2] * gr * gr;
-            T fr[6], t[6], tp[6];
-            xforce_inv(E0, Cr + 9, hr, fr);
+            D += Rp[6] * gr * gr;
 #pragma unroll
-            for (int r = 0; r < 6; r++) F[r] += fr[r] * gr;
-            symv_z(Ir, cr, t);
-#pragma unroll
-            for (int j = 0; j < 6; j++) t[j] += prr[j];
-            xforce_inv(E0, Cr + 9, t, tp);
+            for (int r = 0; r < 6; r++) F[r] += Rp[r] * gr;
 #pragma unroll
             for (int j = 0; j < 6; j++) psic[j] += tp[j];
         }
@@ -417,6 +435,9 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
             for (int cc = r; cc < 6; cc++) IAc[sidx(r, cc)] -= F[r] * kb[cc];
         }
+        l = ln;
+        yd = ydn;
+        tau_in = taun;
     }
     // hand the chain's projected inertia / bias to the body it hangs off
     if (sg.lds_acc_out != -1) {
@@ -462,12 +483,16 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
     ChainLink l = load_rec(P.links + sg.first);
     T kb[9];
     M.glb_ld(l.glb_k, kb);
+    T yd = M.qd(l.v_index);
     for (int i = 0; i < sg.count; i++) {
-        // the next link's record and [K | y0 | sin | cos] block travel while this link is computed
+        // the next link's record, [K | y0 | sin | cos] block and velocity input travel while this link is computed
         const bool more = i + 1 < sg.count;
         const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
-        T kn[9];
-        if (more) M.glb_ld(ln.glb_k, kn);
+        T kn[9], ydn = 0;
+        if (more) {
+            M.glb_ld(ln.glb_k, kn);
+            ydn = M.qd(ln.v_index);
+        }
         T ydd = kb[6];
 #pragma unroll
         for (int r = 0; r < 6; r++) ydd -= kb[r] * ap[r];
@@ -475,7 +500,7 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
         if (l.has_child) {
             cptr<T> C = P.consts + l.cofs;
             const T g0 = C[kBodyConstFixed];
-            const T qdi = g0 * M.qd(l.v_index);
+            const T qdi = g0 * yd;
             T E[9], v[6], a[6], chat[6];
             rotate_z(kb[7], kb[8], C, E);
             xmotion(E, C + 9, vp, v);
@@ -502,6 +527,7 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
         }
         if (more) {
             l = ln;
+            yd = ydn;
 #pragma unroll
             for (int j = 0; j < 9; j++) kb[j] = kn[j];
         }

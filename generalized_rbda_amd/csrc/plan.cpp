@@ -768,12 +768,36 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     build_layout(P.lay64x, lds.aba64, lds.rnea64, true);
 
     // ---- chain program of the f32 fast path (plan.h, ChainProgram; chain_kernels.hip) ----------------------------
+    // constants of every axisymmetric rotor that the kernels would otherwise recompute per state: with q = 0 the
+    // force per unit rotor acceleration at the parent body, X0^T h with h = I[:, z], does not depend on the state
+    std::vector<int> rotor_pre(nb, -1);
+    auto rotor_constants = [&](int b) {
+        if (rotor_pre[b] >= 0) return rotor_pre[b];
+        const double *C = &P.consts[bodies[b].cofs];
+        const double *E = C, *r = C + 9, *I = C + 12;
+        auto sid = [](int i, int j) { return i <= j ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j)); };
+        double h[6], n[3], l[3], f[6];
+        for (int i = 0; i < 6; i++) h[i] = I[sid(i, 2)];
+        for (int i = 0; i < 3; i++) {
+            n[i] = E[i] * h[0] + E[3 + i] * h[1] + E[6 + i] * h[2];
+            l[i] = E[i] * h[3] + E[3 + i] * h[4] + E[6 + i] * h[5];
+        }
+        f[0] = n[0] + (r[1] * l[2] - r[2] * l[1]);
+        f[1] = n[1] + (r[2] * l[0] - r[0] * l[2]);
+        f[2] = n[2] + (r[0] * l[1] - r[1] * l[0]);
+        f[3] = l[0]; f[4] = l[1]; f[5] = l[2];
+        rotor_pre[b] = static_cast<int>(P.consts.size());
+        for (int i = 0; i < 6; i++) P.consts.push_back(f[i]);
+        P.consts.push_back(h[2]);
+        return rotor_pre[b];
+    };
     auto build_chain = [&](ChainProgram &CP, int lds_budget) {
         CP = ChainProgram();
         bool ok = sweep_mask == 7;
         // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, -1 unsupported
         std::vector<int> cls(nc, -1), tip(nc, -1);
         std::vector<ChainPair> pair_of(nc);
+        std::vector<std::array<int, 2>> pair_rotors(nc, std::array<int, 2>{-1, -1});
         for (int c = 0; c < nc && ok; c++) {
             const ClusterRec &cr = clusters[c];
             if (cr.kind == CK_FREE) {
@@ -809,6 +833,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     pr.q_index = cr.q_index;
                     pr.v_index = cr.v_index;
                     pr.cofs[0] = bodies[l1].cofs; pr.cofs[1] = bodies[l2].cofs; pr.cofs[2] = bodies[r[0]].cofs; pr.cofs[3] = bodies[r[1]].cofs;
+                    pair_rotors[c] = {r[0], r[1]};
                 } else {
                     ok = false;
                 }
@@ -856,12 +881,15 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     const BodyRec &br = bodies[cr.link_body];
                     l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = br.cofs;
                     l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : -1;
+                    l.rpre = cls[c] == 2 ? rotor_constants(cr.rotor_body) : -1;
                     l.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
                     l.has_child = br.has_child;
                     l.lds_sv = l.lds_pv = l.lds_va = -1;
                     l.glb_k = glb(9);  // [K 6][y0][sin][cos]
                 } else {
                     pair_of[c].glb_k = glb(14);
+                    pair_of[c].rpre[0] = rotor_constants(pair_rotors[c][0]);
+                    pair_of[c].rpre[1] = rotor_constants(pair_rotors[c][1]);
                     pair_of[c].lds_pv = pair_of[c].lds_pva = -1;
                 }
             }

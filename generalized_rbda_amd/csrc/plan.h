@@ -181,7 +181,8 @@ struct ChainLink {
     int32_t glb_k;      // global slab slot of [K 6][y0][sin][cos], backward run -> acceleration run
     int32_t has_child;
     int32_t lds_va;     // acceleration sweep: LDS slot of [v 6][a 6] when another segment reads them, else -1
-    int32_t reserved[6];
+    int32_t rpre;       // rotor: state-independent constants [X0^T h (6)][h_z] with h = I_rotor[:, z] (plan.cpp)
+    int32_t reserved[5];
 };
 
 // a RevolutePairWithRotor-shaped leaf cluster (32 ints)
@@ -191,7 +192,8 @@ struct ChainPair {
     int32_t lds_pv;     // parent body's velocity
     int32_t glb_k;      // [K 12][y0 2]
     int32_t lds_pva;    // acceleration sweep: parent body's [v 6][a 6]
-    int32_t reserved[23];
+    int32_t rpre[2];    // rotor1, rotor2: [X0^T h (6)][h_z]
+    int32_t reserved[21];
 };
 
 struct ChainSeg {       // 16 ints
