@@ -60,13 +60,29 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def usable_cpus():
+    """hardware threads this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one
+    (a GPU box can show 256 logical CPUs and grant a handful)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(blob, q, qd, tau, budget_s=20.0, passes=5):
     """Oracle (CPU restatement of the reference algorithm, fp64) on the host cores: single thread and all hardware
     threads, median of `passes` passes each, on a bounded sample of the same batch."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
 
-    threads = os.cpu_count() or 1
+    threads = usable_cpus()
 
     def rate(n_threads, n):
         t0 = time.perf_counter()
@@ -81,11 +97,12 @@ def cpu_baseline(blob, q, qd, tau, budget_s=20.0, passes=5):
 
     single, n1 = median_rate(1)
     multi, nm = median_rate(threads)
-    return {"value": multi, "unit": "evals/s", "cores": threads, "physical_cores": physical_cores(), "kind": "port",
-            "single_thread": single, "per_thread_all_core": multi / threads, "passes": passes, "dtype": "f64",
+    return {"value": multi, "unit": "evals/s", "cores": threads, "physical_cores": physical_cores(),
+            "logical_cpus_visible": os.cpu_count(), "kind": "port",
+            "single_thread": single, "per_thread_all_core": multi / threads, "scaling_over_single_thread": multi / single,
+            "passes": passes, "dtype": "f64",
             "sample": f"first {nm} ({n1} single-thread) states of the same batch, median of {passes} passes; "
-                      f"oracle/ = DENSE 6k x 6k restatement kept as the checker, not tuned -- not representative of "
-                      f"the reference's Eigen build",
+                      f"oracle/ = dense 6k x 6k plain-C restatement of the reference algorithm (the parity checker)",
             "reference_chart_evals_per_s_per_core": 2.0e4,
             "reference_chart_note": "images/ForwardDynamicsBenchmark.png of the reference (C-ABA, MIT Humanoid, "
                                     "hardware unstated), NOT re-measured: the reference cannot be built here (DESIGN.md)"}
@@ -277,6 +294,10 @@ def main():
     from generalized_rbda_amd.states import parse_clusters
 
     general = any(c[9] >= 2 for c in parse_clusters(blob)["clusters"])
+    tname = "float" if dtype_name == "f32" else "double"
+    chain = (info.chain_aba_f32 if dtype_name == "f32" else info.chain_aba_f64) and args.algo == "aba"
+    kernel_name = (f"grbda_hip::aba_chain_kernel<{tname}, 2>" if chain
+                   else f"grbda_hip::{args.algo}_kernel<{tname}, {'true' if general else 'false'}>")
     line = {
         "metric": "forward-dynamics evals/sec (batched random states), MIT Humanoid cluster model"
         if args.workload == "mit_humanoid" and args.algo == "aba"
@@ -299,8 +320,7 @@ def main():
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_per_eval * B,
                      "frac_traffic": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "kernel": f"grbda_hip::{args.algo}_kernel<{'float' if dtype_name == 'f32' else 'double'}, "
-                               f"{'true' if general else 'false'}>",
+                     "kernel": kernel_name,
                      "kernel_ms": kernel_ms, "bytes_per_eval": bytes_per_eval,
                      "note": "`achieved`/`frac` price the ALGORITHMIC bytes as the contract asks; `frac_traffic` prices the "
                              "HBM-side bytes rocprofv3 counted; the resource that binds is VALU issue (see valu)",
