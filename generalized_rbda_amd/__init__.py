@@ -196,8 +196,12 @@ class Plan:
         q, qd, x = q.contiguous(), qd.contiguous(), x.contiguous()
         if qd.dtype != q.dtype or x.dtype != q.dtype:
             raise TypeError("dtype mismatch")
+        if qd.device != q.device or x.device != q.device:
+            raise ValueError("q, qd and x must live on one device")
         if out is None:
             out = torch.empty((B, self.nv), dtype=q.dtype, device=q.device)
+        elif (out.shape != (B, self.nv) or out.dtype != q.dtype or out.device != q.device or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous [B,{self.nv}] tensor of the inputs' dtype on the inputs' device")
         fe = None
         if f_ext is not None:
             if f_ext.shape != (B, self.n_bodies, 6) or f_ext.dtype != q.dtype or not f_ext.is_cuda:
@@ -205,6 +209,10 @@ class Plan:
             f_ext = f_ext.contiguous()
             fe = f_ext.data_ptr()
         s = torch.cuda.current_stream(q.device) if stream is None else stream
+        if stream is not None:
+            # contiguous() temporaries and `out` are used on a caller-supplied stream: tell the caching allocator
+            for tns in (q, qd, x, out) + (() if f_ext is None else (f_ext,)):
+                tns.record_stream(s)
         fn = getattr(lib(), f"grbda_{which}_{'f32' if q.dtype == torch.float32 else 'f64'}")
         _check(fn(self._h, q.data_ptr(), qd.data_ptr(), x.data_ptr(), fe, out.data_ptr(), B,
                   q.device.index or 0, c_void_p(s.cuda_stream)))
@@ -220,6 +228,18 @@ class Plan:
         return self._launch("rnea", q, qd, ydd, out, stream, f_ext)
 
     # ---- quantities derived from the two recursions (include/grbda_hip.h) ---------------------------
+    @staticmethod
+    def _floating(*tensors):
+        """every tensor: float32 or float64, one dtype, one HIP device (no silent reinterpretation of other dtypes)"""
+        import torch
+
+        t0 = tensors[0]
+        if t0.dtype not in (torch.float32, torch.float64) or not t0.is_cuda:
+            raise GrbdaError(-3, "inputs must be float32/float64 HIP device tensors (there is no CPU fallback)")
+        for t in tensors[1:]:
+            if t.dtype != t0.dtype or t.device != t0.device:
+                raise TypeError("all tensors of one call must share dtype and device")
+
     def _derived(self, name: str, q, others=(), matrix=True, stream=None, f_ext=None):
         import torch
 
@@ -284,6 +304,8 @@ class Plan:
         """qd_span = G yd and qdd_span = G ydd + g for every body joint: two tensors [B, n_span_vel]."""
         import torch
 
+        self._floating(q, qd, ydd)
+
         B = q.shape[0]
         if not q.is_cuda or q.shape != (B, self.nq) or qd.shape != (B, self.nv) or ydd.shape != (B, self.nv):
             raise ValueError(f"expected device tensors q[B,{self.nq}], qd[B,{self.nv}], ydd[B,{self.nv}]")
@@ -302,6 +324,8 @@ class Plan:
         """Absolute transforms world -> body (TreeNode::Xa_): [B, n_bodies, 12] = E (9, row-major) then r (3)."""
         import torch
 
+        self._floating(q)
+
         B = q.shape[0]
         if not q.is_cuda or q.shape != (B, self.nq):
             raise ValueError(f"expected a device tensor q[B,{self.nq}]")
@@ -316,6 +340,8 @@ class Plan:
         """Batched ClusterTreeModel::applyTestForce: world-frame force[B,3] at the body-fixed point `offset` of
         `body`; returns (lambda_inv[B], dstate[B,nv]) = (f^T J H^-1 J^T f, H^-1 J^T f)."""
         import torch
+
+        self._floating(q, force)
 
         B = q.shape[0]
         if not q.is_cuda or q.shape != (B, self.nq) or force.shape != (B, 3) or force.dtype != q.dtype:
@@ -335,6 +361,8 @@ class Plan:
         Linv[B, 6n, 6n] (and the frame Jacobians J[B, 6n, nv] when asked)."""
         import torch
 
+        self._floating(q)
+
         B, n = q.shape[0], len(bodies)
         if not q.is_cuda or q.shape != (B, self.nq):
             raise ValueError(f"expected a device tensor q[B,{self.nq}]")
@@ -351,8 +379,11 @@ class Plan:
 
     def fd_dq(self, q, qd, tau, step: float = 1e-6, stream=None):
         """d ydd / d q by central differences along the reference's tangent step (testHelpers.hpp:50-112),
-        [B, nv, nv]; not exact, unlike fd_dtau / fd_dqd."""
+        [B, nv, nv]; not exact, unlike fd_dtau / fd_dqd.  The differences are always taken in fp64 (fp32 tensors are
+        converted on the device); implicit-loop models are differentiated on the constraint manifold."""
         import torch
+
+        self._floating(q, qd, tau)
 
         B = q.shape[0]
         if not q.is_cuda or q.shape != (B, self.nq) or qd.shape != (B, self.nv) or tau.shape != (B, self.nv):
@@ -368,6 +399,8 @@ class Plan:
     def time_kernel(self, which: str, q, qd, x, out, iters: int = 20, stream=None) -> float:
         """Average kernel duration in ms, hipEvents on the launch stream (grbda_time_kernel)."""
         import torch
+
+        self._floating(q, qd, x, out)
 
         s = torch.cuda.current_stream(q.device) if stream is None else stream
         ms = c_float(0)

@@ -62,6 +62,17 @@ struct Scratch {
     size_t bytes = 0;
 };
 
+// every entry point that may switch the calling thread's HIP device puts it back on return (torch and other users of the
+// runtime in the same thread keep their current device)
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define GRBDA_CALL_SCOPE(p) DeviceGuard device_guard_; std::unique_lock<std::recursive_mutex> plan_lock_((p)->mu)
+
 int env_int(const char *name, int dflt)
 {
     const char *v = std::getenv(name);
@@ -79,10 +90,14 @@ const Layout &layout_of(const HostPlan &h, int w)
 struct grbda_plan {
     HostPlan host;
     std::vector<unsigned char> blob;
-    mutable std::mutex mu;
+    // Held from the moment a call sizes its scratch / work buffers until its last kernel is ENQUEUED: a second thread
+    // that needs a bigger buffer for the same (device, stream) can then only free the old one after the first thread's
+    // launches are in the stream (hipFree waits for them).  Recursive: the derived entry points call run().
+    mutable std::recursive_mutex mu;
     mutable std::map<int, DeviceTables> dev;
     mutable std::map<std::pair<int, void *>, Scratch> scratch;
     mutable std::map<std::pair<int, void *>, Scratch> work;  // expanded batches of the derived quantities
+    mutable std::map<std::pair<int, void *>, Scratch> work_cvt;  // fp64 copies of fp32 inputs (grbda_fd_dq_f32)
     // launch shape per kernel, index = (rnea ? 2 : 0) + (f64 ? 1 : 0): LDS budget per wavefront for the
     // slot store, and wavefronts launched per CU (the grid is persistent)
     // (defaults from sweeps on MI355X over the MIT humanoid, Mini Cheetah and JVRC-1 at 4096 tiles: the f32
@@ -106,7 +121,7 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     if (device < 0 || device >= count) return set_err(GRBDA_EINVAL, "device index out of range");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_err(e, "hipSetDevice");
-    std::lock_guard<std::mutex> lk(p->mu);
+    std::lock_guard<std::recursive_mutex> lk(p->mu);
     auto it = p->dev.find(device);
     if (it != p->dev.end()) {
         *out = &it->second;
@@ -129,17 +144,25 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     {
         // tangent-space perturbation of the positions (UnitTests/testHelpers.hpp:50-112): kind 0 q[i] += d,
         // 1 free-base rotation (quat += quat x (0, d e_a) / 2), 2 free-base translation (pos += R^T d e_a),
-        // 3 not differentiable here (implicit-loop cluster, roll-pitch-yaw base)
+        // (implicit-loop clusters: kind 0 on the independent spanning position + re-projection of the dependent ones)
         std::vector<int32_t> map(static_cast<size_t>(h.nv) * 3, 0);
         for (const ClusterRec &c : h.lay64.clusters)
             for (int a = 0; a < c.n; a++) {
                 int32_t *e = &map[static_cast<size_t>(c.v_index + a) * 3];
-                if (c.kind == CK_FREE) {
-                    e[0] = h.ori_repr == 0 ? (a < 3 ? 1 : 2) : 3;
+                if (c.kind == CK_FREE && h.ori_repr == 0) {
+                    e[0] = a < 3 ? 1 : 2;
                     e[1] = c.q_index;
                     e[2] = a % 3;
+                } else if (c.kind == CK_FREE) {
+                    // roll-pitch-yaw base: the reference's plus() only special-cases the quaternion (testHelpers.hpp:49-74);
+                    // every other position vector is q + dq
+                    e[0] = 0;
+                    e[1] = c.q_index + a;
                 } else if (c.kind == CK_LOOP) {
-                    e[0] = 3;
+                    // implicit cluster: the a-th INDEPENDENT spanning position moves, the dependent ones are put back on
+                    // phi(q) = 0 by the Newton projection (derived(), DM_DQ): the derivative on the constraint manifold
+                    e[0] = 0;
+                    e[1] = c.q_index + h.cints[c.iofs + 2 + a];
                 } else {
                     e[0] = 0;
                     e[1] = c.q_index + a;
@@ -177,7 +200,7 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
 
 int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, void **out)
 {
-    std::lock_guard<std::mutex> lk(p->mu);
+    std::lock_guard<std::recursive_mutex> lk(p->mu);
     Scratch &s = p->scratch[{device, stream}];
     if (s.bytes < bytes) {
         if (s.ptr) {
@@ -285,6 +308,8 @@ template <class T>
 int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, const T *f_ext, T *out, size_t B,
         int device, void *stream)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
     DeviceTables *t = nullptr;
@@ -329,6 +354,8 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
 int run_host_f64(const grbda_plan *p, bool rnea, const double *q, const double *qd, const double *x,
                  const double *f_ext, double *out, size_t B, int device)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
     DeviceTables *t = nullptr;
@@ -402,6 +429,8 @@ int aux_setup(const grbda_plan *p, size_t B, int device, void *stream, DevPlan<T
 template <class T>
 int project(const grbda_plan *p, T *q, int32_t *ok, size_t B, int max_iter, double tol, int device, void *stream)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || max_iter < 0) return set_err(GRBDA_EINVAL, "bad argument");
     if (B == 0) return GRBDA_OK;
     DevPlan<T> d;
@@ -418,6 +447,8 @@ template <class T>
 int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_span, T *qdd_span, size_t B, int device,
              void *stream)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !qd || !ydd || !qdd_span) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
     DevPlan<T> d;
@@ -434,6 +465,8 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
 template <class T>
 int poses(const grbda_plan *p, const T *q, T *Xa, size_t B, int device, void *stream)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !Xa) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
     DeviceTables *t = nullptr;
@@ -489,6 +522,8 @@ template <class T>
 int test_force(const grbda_plan *p, const T *q, int body, const double *offset, const T *force, T *lambda_inv, T *dstate,
                size_t B, int device, void *stream)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !offset || !force || !lambda_inv || !dstate) return set_err(GRBDA_EINVAL, "null argument");
     if (body < 0 || body >= p->host.n_bodies) return set_err(GRBDA_EINVAL, "body index out of range");
     if (B == 0) return GRBDA_OK;
@@ -501,7 +536,7 @@ int test_force(const grbda_plan *p, const T *q, int body, const double *offset, 
     if (chunk > B) chunk = B;
     void *wptr = nullptr;
     {
-        std::lock_guard<std::mutex> lk(p->mu);
+        std::lock_guard<std::recursive_mutex> lk(p->mu);
         Scratch &s = p->work[{device, stream}];
         const size_t need = chunk * per_state * sizeof(T) + 256;
         if (s.bytes < need) {
@@ -608,6 +643,8 @@ template <class T>
 int inv_osim(const grbda_plan *p, const T *q, int n_contacts, const int *bodies, const double *offsets, T *Linv, T *J,
              size_t B, int device, void *stream)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !bodies || !offsets || !Linv) return set_err(GRBDA_EINVAL, "null argument");
     if (n_contacts < 1 || n_contacts > kMaxContacts) return set_err(GRBDA_EINVAL, "1..8 contact frames per call");
     ContactSet<T> cs;
@@ -628,7 +665,7 @@ int inv_osim(const grbda_plan *p, const T *q, int n_contacts, const int *bodies,
     if (chunk > B) chunk = B;
     void *wptr = nullptr;
     {
-        std::lock_guard<std::mutex> lk(p->mu);
+        std::lock_guard<std::recursive_mutex> lk(p->mu);
         Scratch &s = p->work[{device, stream}];
         const size_t need = chunk * per_state * sizeof(T) + 256;
         if (s.bytes < need) {
@@ -737,6 +774,12 @@ __global__ void expand_kernel(int mode, const T *__restrict__ q, const T *__rest
     }
 }
 
+template <class A, class Bt>
+__global__ void convert_kernel(const A *__restrict__ src, Bt *__restrict__ dst, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = static_cast<Bt>(src[i]);
+}
+
 // out[b][i][j] from the kernel results r[(b, j)][i]
 template <class T>
 __global__ void combine_kernel(int mode, const T *__restrict__ r, int nv, int R, size_t nb, T *__restrict__ out,
@@ -759,14 +802,15 @@ template <class T>
 int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau, const T *f_ext, T *out, size_t B,
             int device, void *stream, double step = 1.0)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !out) return set_err(GRBDA_EINVAL, "null argument");
     if ((mode == DM_BIAS || mode == DM_DQD || mode == DM_DQ) && !qd) return set_err(GRBDA_EINVAL, "null argument");
     if ((mode == DM_DQD || mode == DM_DQ) && !tau) return set_err(GRBDA_EINVAL, "null argument");
+    bool reproject = false;
     if (mode == DM_DQ) {
         if (!(step > 0)) return set_err(GRBDA_EINVAL, "step must be positive");
-        for (const ClusterRec &c : p->host.lay64.clusters)
-            if (c.kind == CK_LOOP || (c.kind == CK_FREE && p->host.ori_repr != 0))
-                return set_err(GRBDA_EUNSUPPORTED, "position derivatives: implicit-loop clusters and roll-pitch-yaw bases are not covered");
+        for (const ClusterRec &c : p->host.lay64.clusters) reproject |= c.kind == CK_LOOP;
     }
     if (B == 0) return GRBDA_OK;
     DeviceTables *t = nullptr;
@@ -780,7 +824,7 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
     const size_t rows = chunk * static_cast<size_t>(R);
     void *wptr = nullptr;
     {
-        std::lock_guard<std::mutex> lk(p->mu);
+        std::lock_guard<std::recursive_mutex> lk(p->mu);
         Scratch &s = p->work[{device, stream}];
         const size_t need = rows * row_scalars * sizeof(T) + 256;
         if (s.bytes < need) {
@@ -809,6 +853,11 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
                            static_cast<T>(step));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_err(e, "expand launch");
+        if (reproject) {
+            // the perturbed states leave the constraint manifold of the implicit clusters by O(step): Newton puts the
+            // dependent coordinates back (GenericJoint.cpp:289-385), starting one step away from the solution
+            if (int rc = project<T>(p, qx, nullptr, nrows, 25, sizeof(T) == 8 ? 1e-13 : 1e-6, device, stream)) return rc;
+        }
         const T *fe = (mode == DM_BIAS && f_ext) ? f_ext + b0 * static_cast<size_t>(p->host.n_bodies) * 6 : nullptr;
         T *dst = mode == DM_BIAS ? out + b0 * nv : res;
         if (int rc = run<T>(p, via_rnea, qx, qdx, xx, fe, dst, nrows, device, stream)) return rc;
@@ -827,6 +876,8 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
 template <class T>
 int run_sharded(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int n_gpus)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -873,7 +924,7 @@ int run_sharded(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T
         if (S.dx) (void)hipFree(S.dx);
         if (S.dout) (void)hipFree(S.dout);
         {   // the scratch slab this call made for its private stream goes with the stream
-            std::lock_guard<std::mutex> lk(p->mu);
+            std::lock_guard<std::recursive_mutex> lk(p->mu);
             auto it = p->scratch.find({g, S.s});
             if (it != p->scratch.end()) {
                 if (it->second.ptr) (void)hipFree(it->second.ptr);
@@ -981,6 +1032,7 @@ int grbda_plan_from_urdf(const char *path, int ori_repr, grbda_plan **out)
 void grbda_plan_free(grbda_plan *p)
 {
     if (!p) return;
+    DeviceGuard device_guard_;
     for (auto &kv : p->dev) {
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
@@ -989,7 +1041,7 @@ void grbda_plan_free(grbda_plan *p)
         for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
-    for (auto *m : {&p->scratch, &p->work})
+    for (auto *m : {&p->scratch, &p->work, &p->work_cvt})
         for (auto &kv : *m) {
             if (hipSetDevice(kv.first.first) != hipSuccess) continue;
             if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -1123,7 +1175,42 @@ int grbda_fd_dq_f64(const grbda_plan *p, const double *q, const double *qd, cons
 int grbda_fd_dq_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, double step, float *J,
                     size_t B, int device, void *stream)
 {
-    return derived<float>(p, DM_DQ, q, qd, tau, nullptr, J, B, device, stream, step);
+    // A central difference in fp32 has no usable step (eps / h + h^2 bottoms out near 1e-2 relative): the differences
+    // are taken in fp64 on the converted inputs and the matrices converted back.
+    if (!p || !q || !qd || !tau || !J) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0) return GRBDA_OK;
+    GRBDA_CALL_SCOPE(p);
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv;
+    const size_t per_state = nq + 2 * nv + nv * nv;
+    size_t chunk = (64u << 20) / (per_state * sizeof(double));
+    if (chunk < 1) chunk = 1;
+    if (chunk > B) chunk = B;
+    Scratch &s = p->work_cvt[{device, stream}];
+    const size_t need = chunk * per_state * sizeof(double) + 256;
+    if (s.bytes < need) {
+        hipError_t e;
+        if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+        s.ptr = nullptr;
+        s.bytes = 0;
+        if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+        s.bytes = need;
+    }
+    double *q64 = static_cast<double *>(s.ptr), *qd64 = q64 + chunk * nq, *tau64 = qd64 + chunk * nv, *J64 = tau64 + chunk * nv;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    auto blocks = [](size_t n) { return static_cast<int>((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535); };
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+        hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks(nb * nq)), dim3(256), 0, hs, q + b0 * nq, q64, nb * nq);
+        hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks(nb * nv)), dim3(256), 0, hs, qd + b0 * nv, qd64, nb * nv);
+        hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks(nb * nv)), dim3(256), 0, hs, tau + b0 * nv, tau64, nb * nv);
+        if (int rc = derived<double>(p, DM_DQ, q64, qd64, tau64, nullptr, J64, nb, device, stream, step)) return rc;
+        hipLaunchKernelGGL((convert_kernel<double, float>), dim3(blocks(nb * nv * nv)), dim3(256), 0, hs, J64, J + b0 * nv * nv, nb * nv * nv);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_err(e, "convert launch");
+    }
+    return GRBDA_OK;
 }
 int grbda_body_poses_f64(const grbda_plan *p, const double *q, double *Xa, size_t B, int device, void *stream)
 {
@@ -1175,6 +1262,8 @@ int grbda_rnea_sharded_f64(const grbda_plan *p, const double *q, const double *q
 }
 int grbda_body_poses_host_f64(const grbda_plan *p, const double *q, double *Xa, size_t B, int device)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !Xa) return set_err(GRBDA_EINVAL, "null argument");
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
@@ -1189,6 +1278,8 @@ int grbda_body_poses_host_f64(const grbda_plan *p, const double *q, double *Xa, 
 int grbda_apply_test_force_host_f64(const grbda_plan *p, const double *q, int body, const double offset[3],
                                     const double *force, double *lambda_inv, double *dstate, size_t B, int device)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !force || !lambda_inv || !dstate) return set_err(GRBDA_EINVAL, "null argument");
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
@@ -1208,6 +1299,8 @@ int grbda_apply_test_force_host_f64(const grbda_plan *p, const double *q, int bo
 int grbda_inv_osim_host_f64(const grbda_plan *p, const double *q, int n_contacts, const int *bodies, const double *offsets,
                             double *Linv, double *J, size_t B, int device)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!p || !q || !Linv) return set_err(GRBDA_EINVAL, "null argument");
     if (n_contacts < 1 || n_contacts > kMaxContacts) return set_err(GRBDA_EINVAL, "1..8 contact frames per call");
     DeviceTables *t = nullptr;
@@ -1266,6 +1359,8 @@ int grbda_rnea_host_f64(const grbda_plan *p, const double *q, const double *qd, 
 int grbda_time_kernel(const grbda_plan *p, int kind, int precision, const void *q, const void *qd, const void *x,
                       void *out, size_t B, int device, void *stream, int iters, float *avg_ms)
 {
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
     if (!avg_ms || iters <= 0 || (precision != 32 && precision != 64) || (kind != 0 && kind != 1))
         return set_err(GRBDA_EINVAL, "bad timing arguments");
     DeviceTables *t = nullptr;

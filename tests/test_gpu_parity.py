@@ -336,15 +336,40 @@ def _reference_plus(m, q, k, d):
     return q
 
 
-@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "rev_rotor_chain_4", "tree_mixed_float", "tree_triple_fixed"])
+def _reference_plus_on_manifold(blob, m, q, k, d):
+    """_reference_plus, then -- for implicit-loop clusters, whose velocity coordinate k is the k-th INDEPENDENT spanning
+    position -- the dependent positions put back on phi(q) = 0 with the oracle's Newton projection."""
+    q = q.copy()
+    for c in m["clusters"]:
+        (pc, fb, kk, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = c
+        if ctype in (2, 3) and vi <= k < vi + nvel:
+            flags = m["ints"][io + 1: io + 1 + nsv] if ctype == 2 else m["ints"][io: io + nsv]
+            ind = [j for j in range(nsv) if flags[j]]
+            q[qi + ind[k - vi]] += d
+            qp, ok = O.project_positions(blob, q[None])
+            assert ok[0]
+            return qp[0]
+    if m["ori"] == 1:  # roll-pitch-yaw base: plain q + dq (testHelpers.hpp:49-74 special-cases only the quaternion)
+        for c in m["clusters"]:
+            if c[9] == 1 and c[5] <= k < c[5] + 6:
+                q[c[3] + (k - c[5])] += d
+                return q
+    return _reference_plus(m, q, k, d)
+
+
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "rev_rotor_chain_4", "tree_mixed_float", "tree_triple_fixed",
+                                  "urdf_four_bar", "urdf_six_bar", "urdf_planar_leg_linkage", "tello_with_arms", "urdf_mini_cheetah_rpy",
+                                  "urdf_jvrc1_humanoid"])
 def test_position_derivative_matches_oracle_differences(name, gpu):
-    """grbda_fd_dq: the same central differences, along the reference's tangent step, taken with the oracle."""
+    """grbda_fd_dq: the same central differences, along the reference's tangent step, taken with the oracle
+    (testRigidBodyDynamicsAlgosDerivatives.cpp:271-383: central differences of the forward dynamics are the reference's
+    own yardstick for its CasADi derivatives, tolerance 2e-5).  Implicit-loop models are differentiated ON the constraint
+    manifold: an independent position moves, the dependent ones follow.  The fp32 entry point takes its differences in
+    fp64."""
     import torch
     from generalized_rbda_amd.states import parse_clusters
 
     z = zoo()
-    if name not in z:
-        pytest.skip(f"{name} not in the zoo")
     blob = z[name]
     plan = G.Plan(blob)
     m = parse_clusters(blob)
@@ -356,16 +381,18 @@ def test_position_derivative_matches_oracle_differences(name, gpu):
     J_ref = np.empty((B, nv, nv))
     for b in range(B):
         for k in range(nv):
-            qp = _reference_plus(m, q[b], k, +h)[None]
-            qm = _reference_plus(m, q[b], k, -h)[None]
+            qp = _reference_plus_on_manifold(blob, m, q[b], k, +h)[None]
+            qm = _reference_plus_on_manifold(blob, m, q[b], k, -h)[None]
             J_ref[b, :, k] = (O.forward_dynamics(blob, qp, qd[b:b + 1], tau[b:b + 1])[0]
                               - O.forward_dynamics(blob, qm, qd[b:b + 1], tau[b:b + 1])[0]) / (2 * h)
-    assert np.abs(J - J_ref).max() / (1.0 + np.abs(J_ref).max()) < 1e-5
-    # implicit-loop models are refused, not approximated
-    loop = G.Plan(z["urdf_four_bar"])
-    ql, qdl, tl = valid_states(z["urdf_four_bar"], 2, config_index=41)
-    with pytest.raises(G.GrbdaError):
-        loop.fd_dq(t(ql), t(qdl), t(tl))
+    scale = 1.0 + np.abs(J_ref).max()
+    assert np.abs(J - J_ref).max() / scale < 2e-5
+    # fp32 in, fp32 out, differences in fp64: as good as the fp32 inputs allow
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    J32 = plan.fd_dq(t32(q), t32(qd), t32(tau), step=h).double().cpu().numpy()
+    c32 = lambda a: a.astype(np.float32).astype(np.float64)
+    J_of_32 = plan.fd_dq(t(c32(q)), t(c32(qd)), t(c32(tau)), step=h).cpu().numpy()
+    assert np.abs(J32 - J_of_32).max() / scale < 1e-5
 
 
 # ---- contact side: body poses, applyTestForce -----------------------------------------------------------
