@@ -55,6 +55,7 @@ struct DeviceTables {
     ChainLink *chain_links[3] = {nullptr, nullptr, nullptr};
     ChainPair *chain_pairs[3] = {nullptr, nullptr, nullptr};
     ChainFree *chain_frees[3] = {nullptr, nullptr, nullptr};
+    CrbaBody *crba_bodies = nullptr;
     int n_cu = 0;
 };
 struct Scratch {
@@ -108,6 +109,7 @@ struct grbda_plan {
     bool no_split = false;
     bool no_chain = false;  // GRBDA_NO_CHAIN=1: keep the general interpreter (A/B runs, tests of the general kernels)
     int chain_debug = 0;
+    bool no_crba = false;  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
 };
 
@@ -179,6 +181,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(L.acc_k.data(), L.acc_k.size() * sizeof(int32_t), (void **)&t.acc_k[w])) != hipSuccess)
             return hip_err(e, "plan upload");
     }
+    if (h.crba.ok && (e = up(h.crba.bodies.data(), h.crba.bodies.size() * sizeof(CrbaBody), (void **)&t.crba_bodies)) != hipSuccess)
+        return hip_err(e, "plan upload");
     for (int w = 0; w < 3; w++) {
         const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : h.chain64);
         if (!cp.ok) continue;
@@ -816,6 +820,21 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const int nq = p->host.nq, nv = p->host.nv;
+    if (mode == DM_MASS && p->host.crba.ok && !p->no_crba) {
+        // composite-rigid-body kernel (crba_kernels.hip): one launch instead of nv + 1 inverse-dynamics evaluations
+        DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
+        const size_t n_tiles = (B + kWave - 1) / kWave;
+        size_t grid = static_cast<size_t>(t->n_cu) * 8;
+        if (grid > n_tiles) grid = n_tiles;
+        void *scratch = nullptr;
+        if (int rc = ensure_scratch(p, device, stream, grid * static_cast<size_t>(p->host.crba.n_rows) * kWave * sizeof(T) + 256, &scratch))
+            return rc;
+        hipError_t e = hipMemsetAsync(out, 0, B * static_cast<size_t>(nv) * nv * sizeof(T), static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_err(e, "hipMemsetAsync");
+        e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q, out, B, static_cast<T *>(scratch),
+                           static_cast<int>(grid), static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? GRBDA_OK : hip_err(e, "crba launch");
+    }
     const int R = mode == DM_BIAS ? 1 : ((mode == DM_DQD || mode == DM_DQ) ? 2 * nv : nv + 1);
     const size_t row_scalars = static_cast<size_t>(nq) + 3 * static_cast<size_t>(nv);  // q, qd, x, result
     size_t chunk = (256u << 20) / (row_scalars * sizeof(T) * static_cast<size_t>(R));
@@ -987,6 +1006,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
     p->chain_debug = env_int("GRBDA_CHAIN_DEBUG", 0);
+    p->no_crba = env_int("GRBDA_NO_CRBA", 0) != 0;
     LdsBudget lds;
     lds.aba32 = p->lds_bytes_per_wave[0] / (4 * kWave);
     lds.aba64 = p->lds_bytes_per_wave[1] / (8 * kWave);
@@ -1037,7 +1057,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.dq_map);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }

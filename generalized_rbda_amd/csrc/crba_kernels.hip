@@ -1,0 +1,238 @@
+// crba_kernels.hip -- batched joint-space inertia matrix H(q) by the composite-rigid-body algorithm on the cluster
+// tree: ClusterTreeModel::getMassMatrix = TreeModel::compositeRigidBodyAlgorithm (src/Dynamics/TreeModel.cpp:115-160,
+// ClusterTreeModel.cpp:98-103).  One state per lane like the dynamics kernels.
+//
+// Structured restatement (the reference works on dense 6k x 6k cluster blocks): per BODY of the spanning tree, in
+// reverse topological order,
+//   Ic_i   = I_i + sum_children X_c^T Ic_c X_c                         composite inertia
+//   f      = Ic_i s_i                                                    force per unit spanning acceleration of joint i
+//   walk up the tree: at every ancestor joint j, H_span[i][j] = s_j^T f, then f <- X_j^T f
+// and H = G^T H_span G is accumulated on the fly: within a cluster the n x n diagonal block; at the cluster's parent
+// body the 6 x n matrix Fp = sum_i X^T f_i G_i (the composite counterpart of the F of the ABA handlers), which then
+// walks up the ancestors once for the whole cluster.  Axisymmetric rotors (plan.cpp) contribute the constant X0^T I X0
+// to their parent through the parent's precomputed inertia constants, as in the dynamics kernels.
+// Explicit (constant G) models only; models with implicit-loop clusters keep the nv + 1 inverse-dynamics evaluations of
+// capi.cpp (derived(), DM_MASS).
+#include <hip/hip_runtime.h>
+
+#include "devplan.h"
+
+namespace grbda_hip {
+
+#include "devmath.h"
+
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const CrbaBody *__restrict__ cb_, int n_clusters, int n_rows,
+                                                        const T *__restrict__ q, T *__restrict__ H, size_t B,
+                                                        T *__restrict__ scratch)
+{
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
+    cptr<T> consts = (cptr<T>)DP.consts;
+    cptr<CrbaBody> cb = (cptr<CrbaBody>)cb_;
+    const int lane = threadIdx.x, nq = DP.nq, nv = DP.nv;
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)n_rows * kWave + lane;  // row r of this lane: slab[r * kWave]
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + lane;
+        const size_t st = r < B ? r : B - 1;  // lanes past the end redo the last state and do not store
+        const bool live = r < B;
+        const T *qs = q + st * (size_t)nq;
+        T *Hs = H + st * (size_t)nv * nv;
+        // ---- pass 1: sin / cos of every revolute spanning joint; composite accumulators start at zero ----
+        for (int c = 0; c < n_clusters; c++) {
+            const ClusterRec cr = load_rec(clusters + c);
+            if (cr.kind == CK_FREE) continue;
+            for (int i = 0; i < cr.k; i++) {
+                const int gb = cr.first_body + i;
+                const BodyRec b = load_rec(bodies + gb);
+                const CrbaBody x = load_rec(cb + gb);
+                cptr<T> C = consts + b.cofs;
+                T qi = 0;
+                for (int a = 0; a < cr.n; a++) qi += C[kBodyConstFixed + a] * qs[cr.q_index + a];
+                T sn, cs;
+                if (b.axisym) { sn = 0; cs = 1; }  // rotors are evaluated at q = 0 (plan.cpp)
+                else sincos_t(qi, &sn, &cs);
+                slab[(size_t)x.sc_row * kWave] = sn;
+                slab[(size_t)(x.sc_row + 1) * kWave] = cs;
+            }
+        }
+        for (int c = 0; c < n_clusters; c++) {
+            const ClusterRec cr = load_rec(clusters + c);
+            for (int i = 0; i < cr.k; i++) {
+                const CrbaBody x = load_rec(cb + (cr.first_body + i));
+                if (x.acc_row >= 0)
+                    for (int j = 0; j < 21; j++) slab[(size_t)(x.acc_row + j) * kWave] = 0;
+            }
+        }
+        // ---- pass 2: clusters leaf side first ----
+        for (int c = n_clusters - 1; c >= 0; c--) {
+            const ClusterRec cr = load_rec(clusters + c);
+            if (cr.kind == CK_FREE) {
+                // H[base][base] = Ic of the base (S = 1)
+                const BodyRec b = load_rec(bodies + cr.first_body);
+                const CrbaBody x = load_rec(cb + cr.first_body);
+                cptr<T> Ib = b.xofs >= 0 ? consts + b.xofs : consts + b.cofs + 12;
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++) {
+                        T v = Ib[sidx(i, j)];
+                        if (x.acc_row >= 0) v += slab[(size_t)(x.acc_row + sidx(i, j)) * kWave];
+                        if (live) Hs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = v;
+                    }
+                continue;
+            }
+            const int n = cr.n;
+            T Fp[kMaxClusterDof][6];      // force at the parent body per unit acceleration of coordinate a
+            T Hcc[kMaxClusterDof][kMaxClusterDof];
+#pragma unroll
+            for (int a = 0; a < kMaxClusterDof; a++) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) Fp[a][j] = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < kMaxClusterDof; b2++) Hcc[a][b2] = 0;
+            }
+            for (int i = cr.k - 1; i >= 0; i--) {
+                const int gb = cr.first_body + i;
+                const BodyRec b = load_rec(bodies + gb);
+                const CrbaBody x = load_rec(cb + gb);
+                cptr<T> C = consts + b.cofs;
+                cptr<T> Ib = b.xofs >= 0 ? consts + b.xofs : C + 12;
+                T Ic[21];
+#pragma unroll
+                for (int j = 0; j < 21; j++) Ic[j] = Ib[j];
+                if (x.acc_row >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 21; j++) Ic[j] += slab[(size_t)(x.acc_row + j) * kWave];
+                }
+                T E[9];
+                rotate_z(slab[(size_t)x.sc_row * kWave], slab[(size_t)(x.sc_row + 1) * kWave], C, E);
+                // composite inertia to the tree parent (axisymmetric leaves are already part of the parent's constants)
+                if (b.parent >= 0 && !b.axisym) {
+                    const CrbaBody xp = load_rec(cb + b.parent);
+                    T Bc[21];
+                    congruence(E, C + 9, Ic, Bc);
+#pragma unroll
+                    for (int j = 0; j < 21; j++) slab[(size_t)(xp.acc_row + j) * kWave] += Bc[j];
+                }
+                T Gi[kMaxClusterDof];
+#pragma unroll
+                for (int a = 0; a < kMaxClusterDof; a++) Gi[a] = a < n ? C[kBodyConstFixed + a] : T(0);
+                T f[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) f[j] = Ic[sidx(j, 2)];
+#pragma unroll
+                for (int a = 0; a < kMaxClusterDof; a++)
+#pragma unroll
+                    for (int b2 = 0; b2 < kMaxClusterDof; b2++) Hcc[a][b2] += Gi[a] * Gi[b2] * f[2];
+                // up the in-cluster chain
+                T f2[6];
+                xforce_inv(E, C + 9, f, f2);
+                int l = b.lam;
+                while (l >= 0) {
+                    const BodyRec bl = load_rec(bodies + l);
+                    const CrbaBody xl = load_rec(cb + l);
+                    cptr<T> Cl = consts + bl.cofs;
+                    T Gl[kMaxClusterDof];
+#pragma unroll
+                    for (int a = 0; a < kMaxClusterDof; a++) Gl[a] = a < n ? Cl[kBodyConstFixed + a] : T(0);
+#pragma unroll
+                    for (int a = 0; a < kMaxClusterDof; a++)
+#pragma unroll
+                        for (int b2 = 0; b2 < kMaxClusterDof; b2++) Hcc[a][b2] += f2[2] * (Gi[a] * Gl[b2] + Gl[a] * Gi[b2]);
+                    T El[9], f3[6];
+                    rotate_z(slab[(size_t)xl.sc_row * kWave], slab[(size_t)(xl.sc_row + 1) * kWave], Cl, El);
+                    xforce_inv(El, Cl + 9, f2, f3);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) f2[j] = f3[j];
+                    l = bl.lam;
+                }
+#pragma unroll
+                for (int a = 0; a < kMaxClusterDof; a++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) Fp[a][j] += f2[j] * Gi[a];
+            }
+            if (live) {
+#pragma unroll
+                for (int a = 0; a < kMaxClusterDof; a++)
+#pragma unroll
+                    for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                        if (a < n && b2 < n) Hs[(size_t)(cr.v_index + a) * nv + cr.v_index + b2] = Hcc[a][b2];
+            }
+            // ---- up the ancestors: H[c][d] = Fp^T S_d, block by block ----
+            int j = cr.parent_body;
+            while (j >= 0) {
+                const BodyRec bj = load_rec(bodies + j);
+                const CrbaBody xj = load_rec(cb + j);
+                const ClusterRec cd = load_rec(clusters + xj.cluster);
+                if (cd.kind == CK_FREE) {
+                    if (live) {
+#pragma unroll
+                        for (int a = 0; a < kMaxClusterDof; a++)
+#pragma unroll
+                            for (int k6 = 0; k6 < 6; k6++)
+                                if (a < n) {
+                                    Hs[(size_t)(cr.v_index + a) * nv + cd.v_index + k6] = Fp[a][k6];
+                                    Hs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a] = Fp[a][k6];
+                                }
+                    }
+                    break;
+                }
+                // all bodies of cluster d on the path are consecutive ancestors: accumulate the block, then store it
+                T Hcd[kMaxClusterDof][kMaxClusterDof];
+#pragma unroll
+                for (int a = 0; a < kMaxClusterDof; a++)
+#pragma unroll
+                    for (int b2 = 0; b2 < kMaxClusterDof; b2++) Hcd[a][b2] = 0;
+                int jj = j;
+                int next = -1;
+                for (;;) {
+                    const BodyRec bb = load_rec(bodies + jj);
+                    const CrbaBody xb = load_rec(cb + jj);
+                    cptr<T> Cj = consts + bb.cofs;
+                    T Ej[9];
+                    rotate_z(slab[(size_t)xb.sc_row * kWave], slab[(size_t)(xb.sc_row + 1) * kWave], Cj, Ej);
+#pragma unroll
+                    for (int a = 0; a < kMaxClusterDof; a++) {
+#pragma unroll
+                        for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                            if (b2 < cd.n) Hcd[a][b2] += Fp[a][2] * Cj[kBodyConstFixed + b2];
+                        T fn[6];
+                        xforce_inv(Ej, Cj + 9, Fp[a], fn);
+#pragma unroll
+                        for (int k6 = 0; k6 < 6; k6++) Fp[a][k6] = fn[k6];
+                    }
+                    next = bb.parent;
+                    if (bb.lam < 0) break;  // left the cluster
+                    jj = bb.lam;
+                }
+                if (live) {
+#pragma unroll
+                    for (int a = 0; a < kMaxClusterDof; a++)
+#pragma unroll
+                        for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                            if (a < n && b2 < cd.n) {
+                                Hs[(size_t)(cr.v_index + a) * nv + cd.v_index + b2] = Hcd[a][b2];
+                                Hs[(size_t)(cd.v_index + b2) * nv + cr.v_index + a] = Hcd[a][b2];
+                            }
+                }
+                (void)bj;
+                j = next;
+            }
+        }
+        // entries between clusters on different branches are structural zeros of H
+    }
+}
+
+template <class T>
+hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,
+                       int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((crba_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, cb, n_clusters, n_rows, q, H, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_crba<float>(const DevPlan<float> &, const CrbaBody *, int, int, const float *, float *, size_t, float *, int,
+                                       hipStream_t);
+template hipError_t launch_crba<double>(const DevPlan<double> &, const CrbaBody *, int, int, const double *, double *, size_t,
+                                        double *, int, hipStream_t);
+
+}  // namespace grbda_hip

@@ -64,4 +64,9 @@ hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd);
 hipError_t set_max_dynamic_lds_chain();
 
+// composite-rigid-body algorithm (crba_kernels.hip)
+template <class T>
+hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,
+                       int grid, hipStream_t stream);
+
 }  // namespace grbda_hip

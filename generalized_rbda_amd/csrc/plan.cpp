@@ -1096,6 +1096,28 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     build_chain(P.chain32w, lds.chain32w);
     build_chain(P.chain64, lds.aba64);
 
+    // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
+    {
+        CrbaProgram &CR = P.crba;
+        CR = CrbaProgram();
+        CR.ok = sweep_mask == 7;
+        for (const ClusterRec &cr : clusters)
+            if (cr.kind == CK_LOOP) CR.ok = false;
+        CR.bodies.assign(nb, CrbaBody{0, -1, 0, 0});
+        int rows = 0;
+        for (int b = 0; b < nb; b++) {
+            CR.bodies[b].cluster = m.bodies[b].cluster;
+            CR.bodies[b].sc_row = rows;
+            rows += 2;
+        }
+        for (int b = 0; b < nb; b++)
+            if (bodies[b].parent >= 0 && !bodies[b].axisym && CR.bodies[bodies[b].parent].acc_row < 0) {
+                CR.bodies[bodies[b].parent].acc_row = rows;
+                rows += 21;
+            }
+        CR.n_rows = rows;
+    }
+
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
     // per-body costs: sincos ~40, E build 12, motion / force transform 39, sym6*vec 66 (48 against a
     // revolute velocity product, two zero entries), force cross 30, congruence 385, plus the per-cluster

@@ -226,6 +226,19 @@ struct ChainProgram {
     int n_lds = 0, n_glb = 0;        // slots
 };
 
+// composite-rigid-body algorithm (crba_kernels.hip): per body, where its per-state scratch rows live in the wave's slab
+struct CrbaBody {
+    int32_t cluster;  // index of the containing cluster
+    int32_t acc_row;  // first of the 21 rows of the composite-inertia accumulator (bodies with non-axisymmetric children), or -1
+    int32_t sc_row;   // rows [sin, cos] of the spanning joint angle
+    int32_t reserved;
+};
+struct CrbaProgram {
+    bool ok = false;  // explicit (constant G) clusters only
+    std::vector<CrbaBody> bodies;
+    int n_rows = 0;
+};
+
 // LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
 // wavefronts per CU and more state in the global slab; the best trade differs per kernel.
 struct LdsBudget {
@@ -247,6 +260,7 @@ struct HostPlan {
     ChainProgram chain32;     // f32 ABA, chain-structured fast path (chain_kernels.hip), two wavefronts per SIMD
     ChainProgram chain32w;    // the same laid out for four wavefronts per SIMD (half the LDS per wavefront)
     ChainProgram chain64;     // f64 ABA (slots are twice as large: the LDS budget holds half as many)
+    CrbaProgram crba;
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };
