@@ -109,7 +109,8 @@ struct grbda_plan {
     bool no_split = false;
     bool no_chain = false;  // GRBDA_NO_CHAIN=1: keep the general interpreter (A/B runs, tests of the general kernels)
     int chain_debug = 0;
-    bool no_crba = false;  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
+    bool no_crba = false;
+    bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
 };
 
@@ -643,6 +644,147 @@ __global__ void osim_combine_kernel(const T *__restrict__ acc, const T *__restri
     }
 }
 
+// Inverse OSIM by force propagation (chain_kernels.hip, osim_chain_kernel) for models the chain program covers and contact
+// frames on link / base bodies.  Returns 1 when the fast path does not apply (the caller then takes the unit-wrench path).
+template <class T>
+int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *bodies, const double *offsets, T *Linv, T *J,
+                   size_t B, int device, void *stream)
+{
+    const HostPlan &h = p->host;
+    const ChainProgram &cp = sizeof(T) == 8 ? h.chain64 : h.chain32;
+    if (p->no_chain || p->no_efpa || !cp.ok || n_contacts > kOsimMaxContacts) return 1;
+    const Layout &L = h.lay64;
+    OsimArgs<T> A;
+    std::memset(&A, 0, sizeof A);
+    A.n_contacts = n_contacts;
+    A.want_J = J ? 1 : 0;
+    std::vector<std::vector<int>> path_clusters(n_contacts);
+    int max_rows = 0;
+    for (int e = 0; e < n_contacts; e++) {
+        const int b = bodies[e];
+        int c = h.crba.bodies[b].cluster;
+        int rows = 0, len = 0;
+        bool first = true;
+        while (c >= 0) {
+            if (len >= kOsimMaxPath) return 1;
+            const ClusterRec &cr = L.clusters[c];
+            OsimStep st;
+            st.v_index = static_cast<int16_t>(cr.v_index);
+            st.w_row = static_cast<int16_t>(rows);
+            int found = -1;
+            if (cr.kind == CK_FREE) {
+                for (size_t i = 0; i < cp.frees.size(); i++)
+                    if (cp.frees[i].v_index == cr.v_index) found = static_cast<int>(i);
+                st.kind = OSIM_FREE;
+                rows += 6;
+            } else if (cr.shape != SHAPE_GENERIC) {
+                if (first && b != cr.link_body) return 1;  // a contact on a rotor
+                for (size_t i = 0; i < cp.links.size(); i++)
+                    if (cp.links[i].v_index == cr.v_index) found = static_cast<int>(i);
+                st.kind = OSIM_LINK;
+                rows += 1;
+            } else {
+                if (!first) return 1;  // pair clusters are leaves of the chain program
+                for (size_t i = 0; i < cp.pairs.size(); i++)
+                    if (cp.pairs[i].v_index == cr.v_index) found = static_cast<int>(i);
+                if (found < 0) return 1;
+                if (L.bodies[b].cofs == cp.pairs[found].cofs[0]) st.kind = OSIM_PAIR_LINK1;
+                else if (L.bodies[b].cofs == cp.pairs[found].cofs[1]) st.kind = OSIM_PAIR_LINK2;
+                else return 1;
+                rows += 2;
+            }
+            if (found < 0) return 1;
+            st.rec = static_cast<int16_t>(found);
+            A.path[e][len++] = st;
+            path_clusters[e].push_back(c);
+            first = false;
+            c = cr.parent_body >= 0 ? h.crba.bodies[cr.parent_body].cluster : -1;
+        }
+        A.path_len[e] = len;
+        A.n_rows[e] = rows;
+        if (rows > max_rows) max_rows = rows;
+        // K0: wrench on the contact body, in the PLAN's body frame (canonical joint axes, plan.cpp), per unit contact wrench
+        // given in the reference's body axes at the contact point: [n; f] -> [n + o x f; f], then the cyclic permutation
+        const double *o = offsets + 3 * e;
+        double W[36] = {0};
+        for (int j = 0; j < 3; j++) {
+            W[6 * j + j] = 1.0;            // unit moment e_j
+            W[6 * (3 + j) + 3 + j] = 1.0;  // unit force e_j ...
+        }
+        // ... and its moment about the body origin o x e_j (column 3 + j, rows 0..2)
+        W[6 * 1 + 3] = o[2];  W[6 * 2 + 3] = -o[1];   // o x e_x = (0, o_z, -o_y)
+        W[6 * 0 + 4] = -o[2]; W[6 * 2 + 4] = o[0];    // o x e_y = (-o_z, 0, o_x)
+        W[6 * 0 + 5] = o[1];  W[6 * 1 + 5] = -o[0];   // o x e_z = (o_y, -o_x, 0)
+        const int ca = L.bodies[b].canon_axis;  // v_plan = Rc v_ref: x -> z: rows (y, z, x); y -> z: rows (z, x, y)
+        const int perm[3][3] = {{1, 2, 0}, {2, 0, 1}, {0, 1, 2}};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 6; j++) {
+                A.K0[e][6 * i + j] = static_cast<T>(W[6 * perm[ca][i] + j]);
+                A.K0[e][6 * (3 + i) + j] = static_cast<T>(W[6 * (3 + perm[ca][i]) + j]);
+            }
+    }
+    for (int e1 = 0; e1 < n_contacts; e1++)
+        for (int e2 = 0; e2 < n_contacts; e2++) {
+            const std::vector<int> &a = path_clusters[e1], &b2 = path_clusters[e2];
+            int rows = 0;
+            size_t i = a.size(), j = b2.size();
+            while (i > 0 && j > 0 && a[i - 1] == b2[j - 1]) {
+                const ClusterRec &cr = L.clusters[a[i - 1]];
+                rows += cr.kind == CK_FREE ? 6 : cr.n;
+                i--;
+                j--;
+            }
+            A.common[e1][e2] = rows;
+        }
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const int w = sizeof(T) == 8 ? 2 : 0;
+    const int kid = sizeof(T) == 8 ? 1 : 0;
+    A.w_base = cp.n_glb;
+    A.w_stride = 6 * max_rows;
+    ChainDev<T> d;
+    d.segs = t->chain_segs[w];
+    d.links = t->chain_links[w];
+    d.pairs = t->chain_pairs[w];
+    d.frees = t->chain_frees[w];
+    d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t->consts32) : reinterpret_cast<const T *>(t->consts64);
+    d.n_segs = static_cast<int>(cp.segs.size());
+    d.nq = h.nq;
+    d.nv = h.nv;
+    d.n_glb_slots = cp.n_glb + n_contacts * A.w_stride;
+    d.ori_repr = h.ori_repr;
+    d.debug = 0;
+    for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    size_t grid = static_cast<size_t>(t->n_cu) * 4;  // one wavefront per SIMD: the walk kernel is not register-tuned
+    if (grid > n_tiles) grid = n_tiles;
+    size_t lds_bytes = static_cast<size_t>(cp.n_lds) * kWave * sizeof(T);
+    const size_t stage_one = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq > d.nv ? d.nq : d.nv) * sizeof(T);
+    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq + 2 * d.nv) * sizeof(T);
+    if (lds_bytes < stage_one) lds_bytes = stage_one;
+    if (lds_bytes < stage_all && stage_all <= static_cast<size_t>(p->lds_bytes_per_wave[kid])) lds_bytes = stage_all;
+    d.lds_bytes = static_cast<int>(lds_bytes);
+    const size_t n_rows = static_cast<size_t>(d.n_glb_slots) + static_cast<size_t>(d.nq + 2 * d.nv);
+    void *scratch = nullptr;
+    if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(T) + 256, &scratch)) return rc;
+    // a block of zeros stands in for the velocities and torques of every tile
+    Scratch &zs = p->work[{device, stream}];
+    const size_t zneed = B * static_cast<size_t>(h.nv) * sizeof(T) + 256;
+    hipError_t e;
+    if (zs.bytes < zneed) {
+        if (zs.ptr && (e = hipFree(zs.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+        zs.ptr = nullptr;
+        zs.bytes = 0;
+        if ((e = hipMalloc(&zs.ptr, zneed)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+        zs.bytes = zneed;
+    }
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if ((e = hipMemsetAsync(zs.ptr, 0, zneed, hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
+    e = launch_osim_chain<T>(d, A, q, static_cast<const T *>(zs.ptr), Linv, J, B, static_cast<T *>(scratch), static_cast<int>(grid),
+                             lds_bytes, hs);
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "osim chain launch");
+}
+
 template <class T>
 int inv_osim(const grbda_plan *p, const T *q, int n_contacts, const int *bodies, const double *offsets, T *Linv, T *J,
              size_t B, int device, void *stream)
@@ -659,6 +801,10 @@ int inv_osim(const grbda_plan *p, const T *q, int n_contacts, const int *bodies,
         for (int i = 0; i < 3; i++) cs.off[c][i] = static_cast<T>(offsets[3 * c + i]);
     }
     if (B == 0) return GRBDA_OK;
+    {
+        const int rc = inv_osim_chain<T>(p, q, n_contacts, bodies, offsets, Linv, J, B, device, stream);
+        if (rc != 1) return rc;
+    }
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const size_t nq = p->host.nq, nv = p->host.nv, nbod = p->host.n_bodies;
@@ -1007,6 +1153,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
     p->chain_debug = env_int("GRBDA_CHAIN_DEBUG", 0);
     p->no_crba = env_int("GRBDA_NO_CRBA", 0) != 0;
+    p->no_efpa = env_int("GRBDA_NO_EFPA", 0) != 0;
     LdsBudget lds;
     lds.aba32 = p->lds_bytes_per_wave[0] / (4 * kWave);
     lds.aba64 = p->lds_bytes_per_wave[1] / (8 * kWave);

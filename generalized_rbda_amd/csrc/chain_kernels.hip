@@ -190,7 +190,7 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
 // give K = D^-1 F^T, y0 = D^-1 u and the correction -F D^-1 F^T, + F D^-1 u on P (kernels.hip, aba_bwd_static).
 // Out: (IA, psi) = what P receives (without the rotors' constant X0^T I X0, which is part of P's constants).
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, bool OSIM>
 __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainPair &pr, T (&IA)[21],
                                          T (&psi)[6])
 {
@@ -303,6 +303,10 @@ __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem
     blk[12] = i00 * u[0] + i01 * u[1];
     blk[13] = i01 * u[0] + i11 * u[1];
     M.glb_st(pr.glb_k, blk);
+    if constexpr (OSIM) {  // what the force-propagator walk of the contact frames needs (osim_chain_kernel)
+        const T ex[7] = {i00, i01, i11, s1, c1, s2, c2};
+        M.glb_st(pr.glb_k + 14, ex);
+    }
     // ---- correction on P: IA -= F K, psi += F y0 ----
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -333,13 +337,13 @@ __device__ __forceinline__ void pair_acc(const ChainTables<T> &P, const ChainMem
 // chain, leaf side first.  Per link (n = 1): D = g0^2 h_z (+ rotor), F = X^T h g0 (+ rotor), u = tau - g0 b (- rotor),
 // K = F / D, y0 = u / D, and one combined hand-over X^T IA X - F K, X^T (pA + IA c) + F y0 to the parent.
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, bool ROTOR>
+template <class T, bool ROTOR, bool OSIM>
 __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
 {
     T IAc[21], psic[6];  // what the link below handed up (register hand-over inside the run)
     if (sg.head == HEAD_PAIR) {
         const ChainPair pr = load_rec(P.pairs + sg.head_arg);
-        pair_bwd(P, M, pr, IAc, psic);
+        pair_bwd<T, OSIM>(P, M, pr, IAc, psic);
     } else if (sg.head == HEAD_SLOT) {
         T acc[27];
         M.acc_ld(sg.head_arg, acc);
@@ -429,6 +433,10 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         kb[7] = blk[0];
         kb[8] = blk[1];
         M.glb_st(l.glb_k, kb);
+        if constexpr (OSIM) {
+            const T ex[1] = {Dinv};
+            M.glb_st(l.glb_k + 9, ex);
+        }
 #pragma unroll
         for (int r = 0; r < 6; r++) {
             psic[r] += F[r] * kb[6];
@@ -547,7 +555,7 @@ __device__ __forceinline__ void free_fwd(const ChainTables<T> &P, const ChainMem
     M.lds_st(f.lds_v, v);
 }
 
-template <class T>
+template <class T, bool OSIM>
 __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
 {
     cptr<T> Ic = P.consts + f.cofs + 12;
@@ -578,6 +586,16 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
     ch.factor(D);
     ch.solve(u);
     M.glb_st(f.glb_y0, u);
+    if constexpr (OSIM) {  // Cholesky factor of the base's articulated inertia: [L lower triangle 21][1 / diag 6]
+        T ex[27];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) ex[i * (i + 1) / 2 + j] = ch.L[i][j];
+            ex[21 + i] = ch.inv[i];
+        }
+        M.glb_st(f.glb_y0 + 6, ex);
+    }
 }
 
 template <class T>
@@ -650,20 +668,250 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                 case SEG_RUN_FWD: run_fwd(P, M, sg); break;
                 case SEG_RUN_BWD: {
                     const ChainLink l0 = load_rec(P.links + sg.first);
-                    if (l0.rofs >= 0) run_bwd<T, true>(P, M, sg);
-                    else run_bwd<T, false>(P, M, sg);
+                    if (l0.rofs >= 0) run_bwd<T, true, false>(P, M, sg);
+                    else run_bwd<T, false, false>(P, M, sg);
                     break;
                 }
                 case SEG_RUN_ACC: run_acc(P, M, sg); break;
                 case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
                 case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
-                case SEG_FREE_BWD: free_bwd(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first)); break;
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
         if (!(DP.debug & 4)) write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Inverse operational-space inertia J H^-1 J^T of contact frames by force propagation -- the recursion behind
+// ClusterTreeModel::inverseOperationalSpaceInertiaMatrix / applyTestForce (ClusterTreeDynamics.cpp:194-233,295-435:
+// ChiUp = Xup (1 - S D^-1 U^T), lambda_inv += (S^T f)^T D^-1 (S^T f), f <- ChiUp^T f).
+// After the forward and backward runs (articulated inertias, K = D^-1 F^T, D^-1 per cluster) every contact frame e walks
+// from its body to the root with the 6 x 6 matrix K_e = wrench on the current body per unit contact wrench:
+//   s = S^T K_e (n x 6),   W_e[rows of the cluster] = D^-1/2 s,   K_e <- X^T K_e - F D^-1 s
+// and Lambda^-1[e1][e2] = sum over the clusters BOTH paths visit of s1^T D^-1 s2 = W_e1^T W_e2 over the shared rows
+// (paths merge towards the root, so the shared rows are a common tail).  The Jacobians come from the same walk without
+// the articulated correction: J_e[:, cluster] = (S^T X^T...X^T K0)^T.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void k_up(const T (&E)[9], cptr<T> r, T (&K)[36])
+{  // every column through inverseTransformForceVector
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const T f[6] = {K[j], K[6 + j], K[12 + j], K[18 + j], K[24 + j], K[30 + j]};
+        T o[6];
+        xforce_inv(E, r, f, o);
+#pragma unroll
+        for (int i = 0; i < 6; i++) K[6 * i + j] = o[i];
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, OsimArgs<T> A, const T *__restrict__ q,
+                                                              const T *__restrict__ zeros, T *__restrict__ Linv,
+                                                              T *__restrict__ Jout, size_t B, T *__restrict__ scratch)
+{
+    ChainTables<T> P;
+    P.segs = (cptr<ChainSeg>)DP.segs;
+    P.links = (cptr<ChainLink>)DP.links;
+    P.pairs = (cptr<ChainPair>)DP.pairs;
+    P.frees = (cptr<ChainFree>)DP.frees;
+    P.consts = (cptr<T>)DP.consts;
+    P.n_segs = DP.n_segs;
+    P.nq = DP.nq;
+    P.nv = DP.nv;
+    P.ori_repr = DP.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
+    const int lane = threadIdx.x;
+    const int n_rows_wave = DP.n_glb_slots + P.nq + 2 * P.nv;  // DP.n_glb_slots includes the W blocks (capi.cpp)
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)n_rows_wave * kWave;
+    ChainMem<T> M;
+    M.lane = lane;
+    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q = slab + lane;
+    M.in_qd = slab + (size_t)P.nq * kWave + lane;
+    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    const int m = A.n_contacts, nv = P.nv;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        const size_t st = tile * kWave + lane;
+        const bool live = st < B;
+        // velocities and torques do not enter the articulated inertias: zeros
+        stage_inputs(q, zeros, zeros, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        for (int s = 0; s < P.n_segs; s++) {
+            const ChainSeg sg = load_rec(P.segs + s);
+            switch (sg.op) {
+                case SEG_RUN_FWD: run_fwd(P, M, sg); break;
+                case SEG_RUN_BWD: {
+                    const ChainLink l0 = load_rec(P.links + sg.first);
+                    if (l0.rofs >= 0) run_bwd<T, true, true>(P, M, sg);
+                    else run_bwd<T, false, true>(P, M, sg);
+                    break;
+                }
+                case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_FREE_BWD: free_bwd<T, true>(P, M, load_rec(P.frees + sg.first)); break;
+                default: break;  // no acceleration sweep
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the blocks written above are read back below
+        T *Js = Jout ? Jout + (live ? st : B - 1) * (size_t)(6 * m) * nv : nullptr;
+        if (Js && live)
+            for (int i = 0; i < 6 * m * nv; i++) Js[i] = 0;
+        // ---- walks ----
+        for (int e = 0; e < m; e++) {
+            T K[36], Kp[36];
+#pragma unroll
+            for (int i = 0; i < 36; i++) K[i] = Kp[i] = A.K0[e][i];
+            const int wbase = A.w_base + e * A.w_stride;
+            for (int t = 0; t < A.path_len[e]; t++) {
+                const OsimStep stp = A.path[e][t];
+                if (stp.kind == OSIM_LINK) {
+                    const ChainLink l = load_rec(P.links + stp.rec);
+                    cptr<T> C = P.consts + l.cofs;
+                    const T g0 = C[kBodyConstFixed];
+                    T kb[10], E[9];
+                    M.glb_ld(l.glb_k, kb);
+                    rotate_z(kb[7], kb[8], C, E);
+                    const T sq = sqrt(kb[9]);
+                    T srow[6], w[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        srow[j] = g0 * K[12 + j];
+                        w[j] = srow[j] * sq;
+                    }
+                    M.glb_st(wbase + stp.w_row * 6, w);
+                    if (Js && live) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) Js[(size_t)(6 * e + j) * nv + stp.v_index] = g0 * Kp[12 + j];
+                    }
+                    k_up(E, C + 9, K);
+                    if (Js) k_up(E, C + 9, Kp);
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) K[6 * i + j] -= kb[i] * srow[j];
+                } else if (stp.kind == OSIM_FREE) {
+                    const ChainFree f = load_rec(P.frees + stp.rec);
+                    T ex[27];
+                    M.glb_ld(f.glb_y0 + 6, ex);
+                    // W = L^-1 K (forward substitution per column), S = 1
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        T y[6];
+#pragma unroll
+                        for (int i = 0; i < 6; i++) {
+                            T sacc = K[6 * i + j];
+#pragma unroll
+                            for (int k2 = 0; k2 < i; k2++) sacc -= ex[i * (i + 1) / 2 + k2] * y[k2];
+                            y[i] = sacc * ex[21 + i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 6; i++) M.glb[(size_t)(wbase + (stp.w_row + i) * 6 + j) * kWave + lane] = y[i];
+                    }
+                    if (Js && live) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++)
+#pragma unroll
+                            for (int j = 0; j < 6; j++) Js[(size_t)(6 * e + j) * nv + stp.v_index + i] = Kp[6 * i + j];
+                    }
+                } else {
+                    // leaf pair cluster: the contact sits on link1 or on link2 (child of link1)
+                    const ChainPair pr = load_rec(P.pairs + stp.rec);
+                    cptr<T> C1 = P.consts + pr.cofs[0], C2 = P.consts + pr.cofs[1];
+                    T blk[21], E1[9], E2[9];
+                    M.glb_ld(pr.glb_k, blk);
+                    rotate_z(blk[17], blk[18], C1, E1);
+                    rotate_z(blk[19], blk[20], C2, E2);
+                    T s1[6], s2[6], p1[6], p2[6];
+                    if (stp.kind == OSIM_PAIR_LINK2) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) { s2[j] = K[12 + j]; p2[j] = Kp[12 + j]; }
+                        k_up(E2, C2 + 9, K);
+                        if (Js) k_up(E2, C2 + 9, Kp);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) s2[j] = p2[j] = 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { s1[j] = K[12 + j]; p1[j] = Kp[12 + j]; }
+                    // W = R [s1; s2] with R^T R = D^-1 (upper Cholesky factor of D^-1)
+                    const T r00 = sqrt(blk[14]), r01 = blk[15] / r00, r11 = sqrt(blk[16] - r01 * r01);
+                    T w1[6], w2[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        w1[j] = r00 * s1[j] + r01 * s2[j];
+                        w2[j] = r11 * s2[j];
+                    }
+                    M.glb_st(wbase + stp.w_row * 6, w1);
+                    M.glb_st(wbase + (stp.w_row + 1) * 6, w2);
+                    if (Js && live) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            Js[(size_t)(6 * e + j) * nv + stp.v_index] = p1[j];
+                            Js[(size_t)(6 * e + j) * nv + stp.v_index + 1] = p2[j];
+                        }
+                    }
+                    k_up(E1, C1 + 9, K);
+                    if (Js) k_up(E1, C1 + 9, Kp);
+                    // K <- K - F D^-1 s = K - (K_blk row 0)^T s1 - (K_blk row 1)^T s2
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) K[6 * i + j] -= blk[i] * s1[j] + blk[6 + i] * s2[j];
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- Lambda^-1 blocks: W_e1^T W_e2 over the rows the two paths share ----
+        T *Ls = Linv + (live ? st : B - 1) * (size_t)(36 * m * m);
+        for (int e1 = 0; e1 < m; e1++)
+            for (int e2 = e1; e2 < m; e2++) {
+                const int nc = A.common[e1][e2];
+                const int o1 = A.w_base + e1 * A.w_stride + (A.n_rows[e1] - nc) * 6;
+                const int o2 = A.w_base + e2 * A.w_stride + (A.n_rows[e2] - nc) * 6;
+                T acc[36];
+#pragma unroll
+                for (int i = 0; i < 36; i++) acc[i] = 0;
+                for (int t = 0; t < nc; t++) {
+                    T a[6], b[6];
+                    M.glb_ld(o1 + 6 * t, a);
+                    M.glb_ld(o2 + 6 * t, b);
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) acc[6 * i + j] += a[i] * b[j];
+                }
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            Ls[(size_t)(6 * e1 + i) * (6 * m) + 6 * e2 + j] = acc[6 * i + j];
+                            Ls[(size_t)(6 * e2 + j) * (6 * m) + 6 * e1 + i] = acc[6 * i + j];
+                        }
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <class T>
+hipError_t launch_osim_chain(const ChainDev<T> &P, const OsimArgs<T> &A, const T *q, const T *zeros, T *Linv, T *J, size_t B,
+                             T *scratch, int grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((osim_chain_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, A, q, zeros, Linv, J, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_osim_chain<float>(const ChainDev<float> &, const OsimArgs<float> &, const float *, const float *, float *,
+                                             float *, size_t, float *, int, size_t, hipStream_t);
+template hipError_t launch_osim_chain<double>(const ChainDev<double> &, const OsimArgs<double> &, const double *, const double *,
+                                              double *, double *, size_t, double *, int, size_t, hipStream_t);
 
 template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
@@ -690,6 +938,12 @@ hipError_t set_max_dynamic_lds_chain()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<double, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&osim_chain_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&osim_chain_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float, 4>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

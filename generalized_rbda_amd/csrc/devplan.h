@@ -64,6 +64,33 @@ hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd);
 hipError_t set_max_dynamic_lds_chain();
 
+// inverse operational-space inertia by force propagation along the contacts' ancestor paths (chain_kernels.hip,
+// osim_chain_kernel).  Built per call on the host (capi.cpp) and passed by value.
+constexpr int kOsimMaxContacts = 8;
+constexpr int kOsimMaxPath = 12;  // clusters between a contact body and the root
+enum OsimStepKind : int32_t { OSIM_LINK = 0, OSIM_PAIR_LINK1 = 1, OSIM_PAIR_LINK2 = 2, OSIM_FREE = 3 };
+struct OsimStep {
+    int16_t kind;
+    int16_t rec;      // index into links[] / pairs[] / frees[]
+    int16_t v_index;  // first velocity coordinate of the cluster
+    int16_t w_row;    // first of the cluster's rows in the contact's W block (n rows)
+};
+template <class T>
+struct OsimArgs {
+    int n_contacts;
+    int want_J;
+    int path_len[kOsimMaxContacts];
+    int n_rows[kOsimMaxContacts];                        // rows of W of each contact (sum of n over its path)
+    int common[kOsimMaxContacts][kOsimMaxContacts];      // number of trailing W rows two contacts share (their common ancestors)
+    OsimStep path[kOsimMaxContacts][kOsimMaxPath];       // leaf side first
+    T K0[kOsimMaxContacts][36];                          // wrench on the contact body (plan frame) per unit contact wrench, row-major
+    int w_base;                                          // first slab row (after the chain program's rows) of the W blocks
+    int w_stride;                                        // rows per contact
+};
+template <class T>
+hipError_t launch_osim_chain(const ChainDev<T> &P, const OsimArgs<T> &A, const T *q, const T *zeros, T *Linv, T *J, size_t B,
+                             T *scratch, int grid, size_t lds_bytes, hipStream_t stream);
+
 // composite-rigid-body algorithm (crba_kernels.hip)
 template <class T>
 hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,

@@ -874,7 +874,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     const BodyRec &br = bodies[cr.first_body];
                     f.q_index = cr.q_index; f.v_index = cr.v_index; f.cofs = br.cofs; f.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
                     f.lds_v = f.lds_acc = f.lds_va = -1;
-                    f.glb_y0 = glb(6);
+                    f.glb_y0 = glb(33);  // [y0 6] (+ OSIM pass: Cholesky factor of the base's articulated inertia, L 21 + 1/diag 6)
                 } else if (cls[c] == 1 || cls[c] == 2) {
                     ChainLink &l = link_of[c];
                     l = ChainLink();
@@ -885,9 +885,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     l.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
                     l.has_child = br.has_child;
                     l.lds_sv = l.lds_pv = l.lds_va = -1;
-                    l.glb_k = glb(9);  // [K 6][y0][sin][cos]
+                    l.glb_k = glb(10);  // [K 6][y0][sin][cos] (+ OSIM pass: 1 / D)
                 } else {
-                    pair_of[c].glb_k = glb(14);
+                    pair_of[c].glb_k = glb(21);  // [K 12][y0 2] (+ OSIM pass: D^-1 (3), sin / cos of the two links (4))
                     pair_of[c].rpre[0] = rotor_constants(pair_rotors[c][0]);
                     pair_of[c].rpre[1] = rotor_constants(pair_rotors[c][1]);
                     pair_of[c].lds_pv = pair_of[c].lds_pva = -1;

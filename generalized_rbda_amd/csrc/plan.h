@@ -190,7 +190,7 @@ struct ChainPair {
     int32_t q_index, v_index;
     int32_t cofs[4];    // constants of link1, link2, rotor1, rotor2: Et[9] rt[3] I[21] G row [2]
     int32_t lds_pv;     // parent body's velocity
-    int32_t glb_k;      // [K 12][y0 2]
+    int32_t glb_k;      // [K 12][y0 2] (+ 7 rows written by the OSIM pass)
     int32_t lds_pva;    // acceleration sweep: parent body's [v 6][a 6]
     int32_t rpre[2];    // rotor1, rotor2: [X0^T h (6)][h_z]
     int32_t reserved[21];

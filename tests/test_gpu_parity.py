@@ -493,6 +493,94 @@ def test_inverse_operational_space_inertia(name, gpu):
     assert np.abs(lam.cpu().numpy() - lam_ref).max() / (1 + np.abs(lam_ref).max()) < 1e-8
 
 
+def _body_index(blob, name):
+    import struct
+    from generalized_rbda_amd.states import parse_clusters
+
+    m = parse_clusters(blob)
+    n_ints, n_dbls, n_names = struct.unpack_from("<3i", blob, 28)
+    off = 96 + 416 * m["nb"] + 64 * m["nc"] + 4 * ((n_ints + 1) & ~1) + 8 * n_dbls
+    names = [n.decode() for n in blob[off: off + n_names].split(b"\0")[: m["nb"]]]
+    return names.index(name)
+
+
+OSIM_CASES = [
+    ("urdf_mini_cheetah", ["FR_knee_link", "HL_knee_link", "Floating Base", "FL_hip_link"]),
+    ("urdf_mit_humanoid", ["left_ankle_link", "right_ankle_link", "right_elbow_link", "left_knee_link", "Floating Base"]),
+    ("urdf_mini_cheetah_rpy", ["FR_knee_link", "FL_knee_link"]),
+    ("chain_tree_a", None), ("chain_tree_b", None), ("chain_tree_rpy", None), ("chain_tree_norotor", None),
+]
+
+
+@pytest.mark.parametrize("name,frames", OSIM_CASES, ids=[c[0] for c in OSIM_CASES])
+def test_inverse_osim_by_force_propagation(name, frames, gpu, monkeypatch):
+    """Chain-covered models take the in-kernel force-propagation path (osim_chain_kernel: the recursion of
+    ClusterTreeDynamics.cpp:194-233,295-435); it must give the same J H^-1 J^T and Jacobians as the oracle -- frames on
+    single links, on both links of leaf pair clusters, on the floating base, several frames sharing ancestors -- and as
+    the unit-wrench path it replaces (GRBDA_NO_EFPA=1)."""
+    import torch
+    from generalized_rbda_amd.states import parse_clusters
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    nb, nv = plan.n_bodies, plan.nv
+    if frames is None:  # every body that is not a rotor: names l<c>, l1_<c>, l2_<c>, base
+        m = parse_clusters(blob)
+        import struct
+        n_ints, n_dbls, n_names = struct.unpack_from("<3i", blob, 28)
+        off = 96 + 416 * nb + 64 * m["nc"] + 4 * ((n_ints + 1) & ~1) + 8 * n_dbls
+        names = [n.decode() for n in blob[off: off + n_names].split(b"\0")[:nb]]
+        cand = [i for i, n in enumerate(names) if not n.startswith("r")]
+        rng = np.random.default_rng(3)
+        bodies = [int(x) for x in rng.choice(cand, size=min(5, len(cand)), replace=False)]
+        pairs = [i for i, n in enumerate(names) if n.startswith("l2_") or n.startswith("l1_")]
+        if pairs:
+            bodies[0] = pairs[0]
+            bodies[-1] = pairs[-1]
+        bodies = list(dict.fromkeys(bodies))
+    else:
+        bodies = [_body_index(blob, f) for f in frames]
+    n = len(bodies)
+    offsets = np.random.default_rng(4).uniform(-0.2, 0.2, size=(n, 3))
+    B = 5
+    q, _, _ = valid_states(blob, B, config_index=54)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    Linv, J = plan.inv_osim(t(q), bodies, offsets, with_jacobian=True)
+    Linv, J = Linv.cpu().numpy(), J.cpu().numpy()
+    Xa = O.body_poses(blob, q, nb)
+    zero = np.zeros((B, nv))
+    tau0 = O.inverse_dynamics(blob, q, zero, zero)
+    J_ref = np.zeros((B, 6 * n, nv))
+    for c, (bd, off) in enumerate(zip(bodies, offsets)):
+        E, r = Xa[:, bd, :9].reshape(B, 3, 3), Xa[:, bd, 9:]
+        p = r + np.einsum("bji,j->bi", E, np.array(off))
+        for k in range(6):
+            e = E[:, k % 3, :]
+            fext = np.zeros((B, nb, 6))
+            if k < 3:
+                fext[:, bd, :3] = e
+            else:
+                fext[:, bd, :3] = np.cross(p, e)
+                fext[:, bd, 3:] = e
+            J_ref[:, 6 * c + k] = tau0 - O.inverse_dynamics(blob, q, zero, zero, f_ext=fext)
+    H = np.zeros((B, nv, nv))
+    for j in range(nv):
+        ej = np.zeros((B, nv))
+        ej[:, j] = 1
+        H[:, :, j] = O.inverse_dynamics(blob, q, zero, ej) - tau0
+    L_ref = np.einsum("bik,bkl,bjl->bij", J_ref, np.linalg.inv(H), J_ref)
+    assert np.abs(J - J_ref).max() / (1 + np.abs(J_ref).max()) < 1e-9
+    assert np.abs(Linv - L_ref).max() / (1 + np.abs(L_ref).max()) < 1e-8
+    # fp32 entry point, and the path it replaces
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    L32 = plan.inv_osim(t32(q), bodies, offsets).double().cpu().numpy()
+    assert np.abs(L32 - L_ref).max() / (1 + np.abs(L_ref).max()) < TOL32
+    monkeypatch.setenv("GRBDA_NO_EFPA", "1")
+    slow = G.Plan(blob)
+    L_slow = slow.inv_osim(t(q), bodies[:2], offsets[:2]).cpu().numpy()
+    assert np.abs(L_slow - L_ref[:, :12, :12]).max() / (1 + np.abs(L_ref).max()) < 1e-8
+
+
 def test_sharded_host_entry_points(gpu):
     """grbda_*_sharded_*: host arrays over n devices in one process (here: as many as the box has)."""
     import torch
