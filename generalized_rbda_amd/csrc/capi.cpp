@@ -56,6 +56,11 @@ struct DeviceTables {
     ChainPair *chain_pairs[3] = {nullptr, nullptr, nullptr};
     ChainFree *chain_frees[3] = {nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
+    // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64
+    RneaSeg *rchain_segs[2] = {nullptr, nullptr};
+    RneaLink *rchain_links[2] = {nullptr, nullptr};
+    RneaPair *rchain_pairs[2] = {nullptr, nullptr};
+    RneaFree *rchain_frees[2] = {nullptr, nullptr};
     int n_cu = 0;
 };
 struct Scratch {
@@ -181,6 +186,16 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(L.rnea_bodies.data(), L.rnea_bodies.size() * sizeof(BodyRec), (void **)&t.rnea_bodies[w])) != hipSuccess ||
             (e = up(L.acc_k.data(), L.acc_k.size() * sizeof(int32_t), (void **)&t.acc_k[w])) != hipSuccess)
             return hip_err(e, "plan upload");
+    }
+    for (int w = 0; w < 2; w++) {
+        const RneaChainProgram &rp = w ? h.rchain64 : h.rchain32;
+        if (!rp.ok) continue;
+        if ((e = up(rp.segs.data(), rp.segs.size() * sizeof(RneaSeg), (void **)&t.rchain_segs[w])) != hipSuccess ||
+            (e = up(rp.links.data(), rp.links.size() * sizeof(RneaLink), (void **)&t.rchain_links[w])) != hipSuccess ||
+            (e = up(rp.pairs.data(), rp.pairs.size() * sizeof(RneaPair), (void **)&t.rchain_pairs[w])) != hipSuccess ||
+            (e = up(rp.frees.data(), rp.frees.size() * sizeof(RneaFree), (void **)&t.rchain_frees[w])) != hipSuccess)
+            return hip_err(e, "plan upload");
+        if ((e = set_max_dynamic_lds_chain()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
     if (h.crba.ok && (e = up(h.crba.bodies.data(), h.crba.bodies.size() * sizeof(CrbaBody), (void **)&t.crba_bodies)) != hipSuccess)
         return hip_err(e, "plan upload");
@@ -310,6 +325,48 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
 }
 
 template <class T>
+int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *qd, const T *ydd, T *tau, size_t B, int device,
+                   void *stream)
+{
+    const HostPlan &h = p->host;
+    const int w = sizeof(T) == 8 ? 1 : 0;
+    const RneaChainProgram &rp = w ? h.rchain64 : h.rchain32;
+    RneaChainDev<T> d;
+    d.segs = t.rchain_segs[w];
+    d.links = t.rchain_links[w];
+    d.pairs = t.rchain_pairs[w];
+    d.frees = t.rchain_frees[w];
+    d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
+    d.n_segs = static_cast<int>(rp.segs.size());
+    d.nq = h.nq;
+    d.nv = h.nv;
+    d.ori_repr = h.ori_repr;
+    for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    const size_t waves_per_cu = static_cast<size_t>(p->waves_per_cu[w]);  // the ABA launch shape: 8 wavefronts per CU
+    const size_t lds_budget = static_cast<size_t>(p->lds_bytes_per_wave[w]);
+    size_t grid = static_cast<size_t>(t.n_cu) * waves_per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    size_t lds_bytes = static_cast<size_t>(rp.n_lds) * kWave * sizeof(T);
+    const size_t stage_one = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq > d.nv ? d.nq : d.nv) * sizeof(T);
+    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(d.nq + 2 * d.nv) * sizeof(T);
+    if (lds_bytes < stage_one) lds_bytes = stage_one;
+    if (lds_bytes < stage_all && stage_all <= lds_budget) lds_bytes = stage_all;
+    d.lds_bytes = static_cast<int>(lds_bytes);
+    const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
+    if (fit >= 1 && fit < waves_per_cu) {
+        const size_t g2 = static_cast<size_t>(t.n_cu) * fit;
+        if (grid > g2) grid = g2;
+    }
+    const size_t n_rows = static_cast<size_t>(d.nq + 2 * d.nv);
+    void *scratch = nullptr;
+    if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(T) + 256, &scratch)) return rc;
+    hipError_t e = launch_rnea_chain<T>(d, q, qd, ydd, tau, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
+                                        static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "rnea chain launch");
+}
+
+template <class T>
 int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, const T *f_ext, T *out, size_t B,
         int device, void *stream)
 {
@@ -321,6 +378,8 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     if (int rc = ensure_device(p, device, &t)) return rc;
     // chain-structured fast path (chain_kernels.hip): forward dynamics of models the chain program covers
     if (!rnea && !f_ext && chain_covers<T>(p)) return run_chain<T>(p, *t, q, qd, x, out, B, device, stream);
+    if (rnea && !f_ext && !p->no_chain && (sizeof(T) == 8 ? p->host.rchain64.ok : p->host.rchain32.ok))
+        return run_rnea_chain<T>(p, *t, q, qd, x, out, B, device, stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, rnea, f_ext != nullptr);
     d.fext = f_ext;
     const size_t n_tiles = (B + kWave - 1) / kWave;
@@ -1205,6 +1264,7 @@ void grbda_plan_free(grbda_plan *p)
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies);
+        for (int w = 0; w < 2; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); }
         for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
@@ -1273,6 +1333,8 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->n_lds_slots_chain_f32 = p->host.chain32.n_lds;
     info->n_chain_segments = static_cast<int>(p->host.chain32.segs.size());
     info->chain_aba_f64 = p->host.chain64.ok && !p->no_chain;
+    info->chain_rnea_f32 = p->host.rchain32.ok && !p->no_chain;
+    info->chain_rnea_f64 = p->host.rchain64.ok && !p->no_chain;
     return GRBDA_OK;
 }
 

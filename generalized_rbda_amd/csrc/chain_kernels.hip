@@ -931,6 +931,327 @@ template hipError_t launch_aba_chain<float>(const ChainDev<float> &, const float
 template hipError_t launch_aba_chain<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
                                              size_t, double *, int, size_t, hipStream_t, bool);
 
+
+// ===============================================================================================================
+// Inverse dynamics on the chains: TreeModel::recursiveNewtonEulerAlgorithm (src/Dynamics/TreeModel.cpp:34-57,173-212)
+// ===============================================================================================================
+template <class T>
+struct RneaTables {
+    cptr<RneaSeg> segs;
+    cptr<RneaLink> links;
+    cptr<RneaPair> pairs;
+    cptr<RneaFree> frees;
+    cptr<T> consts;
+    int n_segs, nq, nv, ori_repr;
+    T a_root[6];
+};
+
+// f = I a + v x* (I v)  (TreeModel.cpp:185-189), general constant inertia
+template <class T>
+__device__ __forceinline__ void body_force_c(cptr<T> I, const T (&v)[6], const T (&a)[6], T (&f)[6])
+{
+    T Ia[6], Iv[6];
+    symv_c(I, a, Ia);
+    symv_c(I, v, Iv);
+    crf(v, Iv, f);
+#pragma unroll
+    for (int j = 0; j < 6; j++) f[j] += Ia[j];
+}
+
+// axisymmetric rotor at q = 0 (see rotor_terms): torque about its axis and its force on the parent body
+template <class T>
+__device__ __forceinline__ void rotor_rnea(cptr<T> Cr, const T (&vp)[6], const T (&ap)[6], T qdr, T qddr, T &tau_z, T (&fp)[6])
+{
+    cptr<T> Ir = Cr + 12;
+    const T A0 = Ir[sidx(0, 0)], A1 = Ir[sidx(1, 1)], Bz = Ir[sidx(2, 2)], k04 = Ir[sidx(0, 4)], k13 = Ir[sidx(1, 3)];
+    const T m3 = Ir[sidx(3, 3)], m4 = Ir[sidx(4, 4)], m5 = Ir[sidx(5, 5)];
+    T E0[9], vr[6], ar[6];
+#pragma unroll
+    for (int j = 0; j < 9; j++) E0[j] = Cr[j];
+    xmotion(E0, Cr + 9, vp, vr);
+    xmotion(E0, Cr + 9, ap, ar);
+    vr[2] += qdr;
+    ar[0] += vr[1] * qdr;
+    ar[1] -= vr[0] * qdr;
+    ar[3] += vr[4] * qdr;
+    ar[4] -= vr[3] * qdr;
+    ar[2] += qddr;
+    const T Iv[6] = {A0 * vr[0] + k04 * vr[4], A1 * vr[1] + k13 * vr[3], Bz * vr[2],
+                     m3 * vr[3] + k13 * vr[1], m4 * vr[4] + k04 * vr[0], m5 * vr[5]};
+    T f[6];
+    crf(vr, Iv, f);
+    f[0] += A0 * ar[0] + k04 * ar[4];
+    f[1] += A1 * ar[1] + k13 * ar[3];
+    f[2] += Bz * ar[2];
+    f[3] += m3 * ar[3] + k13 * ar[1];
+    f[4] += m4 * ar[4] + k04 * ar[0];
+    f[5] += m5 * ar[5];
+    tau_z = f[2];
+    xforce_inv(E0, Cr + 9, f, fp);
+}
+
+template <class T>
+__device__ __forceinline__ void lds_add6(const ChainMem<T> &M, int slot, const T (&x)[6])
+{
+    T y[6];
+    M.lds_ld(slot, y);
+#pragma unroll
+    for (int j = 0; j < 6; j++) y[j] += x[j];
+    M.lds_st(slot, y);
+}
+
+template <class T, bool ROTOR>
+__device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaSeg &sg)
+{
+    T vp[6], ap[6];
+    if (sg.lds_pva >= 0) {
+        T va[12];
+        M.lds_ld(sg.lds_pva, va);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            vp[j] = va[j];
+            ap[j] = va[6 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            vp[j] = 0;
+            ap[j] = P.a_root[j];
+        }
+    }
+    RneaLink l = load_rec(P.links + sg.first);
+    T qi = M.q(l.q_index), ydi = M.qd(l.v_index), yddi = M.x(l.v_index);
+    for (int i = 0; i < sg.count; i++) {
+        const bool more = i + 1 < sg.count;
+        const RneaLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
+        T qn = 0, ydn = 0, yddn = 0;
+        if (more) {
+            qn = M.q(ln.q_index);
+            ydn = M.qd(ln.v_index);
+            yddn = M.x(ln.v_index);
+        }
+        cptr<T> C = P.consts + l.cofs;
+        const T g0 = C[kBodyConstFixed];
+        const T qdi = g0 * ydi;
+        T blk[9], E[9], v[6], a[6], f[6];
+        sincos_t(g0 * qi, &blk[6], &blk[7]);
+        rotate_z(blk[6], blk[7], C, E);
+        xmotion(E, C + 9, vp, v);
+        xmotion(E, C + 9, ap, a);
+        v[2] += qdi;
+        a[0] += v[1] * qdi;
+        a[1] -= v[0] * qdi;
+        a[3] += v[4] * qdi;
+        a[4] -= v[3] * qdi;
+        a[2] += g0 * yddi;
+        body_force_c(C + 12, v, a, f);
+        blk[8] = 0;
+        if constexpr (ROTOR) {
+            cptr<T> Cr = P.consts + l.rofs;
+            const T gr = Cr[kBodyConstFixed];
+            T tz, fpr[6];
+            rotor_rnea(Cr, vp, ap, gr * ydi, gr * yddi, tz, fpr);
+            blk[8] = gr * tz;
+            if (l.lds_pf >= 0) lds_add6(M, l.lds_pf, fpr);  // the rotor hangs off the parent body
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) blk[j] = f[j];
+        M.lds_st(l.lds_blk, blk);
+        if (l.lds_va >= 0) {
+            T va[12];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                va[j] = v[j];
+                va[6 + j] = a[j];
+            }
+            M.lds_st(l.lds_va, va);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            vp[j] = v[j];
+            ap[j] = a[j];
+        }
+        l = ln;
+        qi = qn;
+        ydi = ydn;
+        yddi = yddn;
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void rnea_run_bwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaSeg &sg)
+{
+    T fc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < sg.count; i++) {
+        const RneaLink l = load_rec(P.links + (sg.first + i));
+        cptr<T> C = P.consts + l.cofs;
+        T blk[9], E[9], ft[6];
+        M.lds_ld(l.lds_blk, blk);
+#pragma unroll
+        for (int j = 0; j < 6; j++) ft[j] = blk[j] + fc[j];
+        M.put(l.v_index, C[kBodyConstFixed] * ft[2] + blk[8]);
+        rotate_z(blk[6], blk[7], C, E);
+        xforce_inv(E, C + 9, ft, fc);
+    }
+    if (sg.lds_pf >= 0) lds_add6(M, sg.lds_pf, fc);
+}
+
+// leaf pair cluster: link1 (on P), link2 (on link1), two axisymmetric rotors on P (see pair_bwd)
+template <class T>
+__device__ __forceinline__ void rnea_pair(const RneaTables<T> &P, const ChainMem<T> &M, const RneaPair &pr)
+{
+    cptr<T> C1 = P.consts + pr.cofs[0], C2 = P.consts + pr.cofs[1];
+    T va[12], vp[6], ap[6];
+    M.lds_ld(pr.lds_pva, va);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        vp[j] = va[j];
+        ap[j] = va[6 + j];
+    }
+    const T y1 = M.q(pr.q_index), y2 = M.q(pr.q_index + 1);
+    const T yd1 = M.qd(pr.v_index), yd2 = M.qd(pr.v_index + 1);
+    const T ydd1 = M.x(pr.v_index), ydd2 = M.x(pr.v_index + 1);
+    T s1, c1, s2, c2, E1[9], E2[9], v1[6], a1[6], v2[6], a2[6], f1[6], f2[6];
+    sincos_t(y1, &s1, &c1);
+    rotate_z(s1, c1, C1, E1);
+    xmotion(E1, C1 + 9, vp, v1);
+    xmotion(E1, C1 + 9, ap, a1);
+    v1[2] += yd1;
+    a1[0] += v1[1] * yd1; a1[1] -= v1[0] * yd1; a1[3] += v1[4] * yd1; a1[4] -= v1[3] * yd1;
+    a1[2] += ydd1;
+    sincos_t(y2, &s2, &c2);
+    rotate_z(s2, c2, C2, E2);
+    xmotion(E2, C2 + 9, v1, v2);
+    xmotion(E2, C2 + 9, a1, a2);
+    v2[2] += yd2;
+    a2[0] += v2[1] * yd2; a2[1] -= v2[0] * yd2; a2[3] += v2[4] * yd2; a2[4] -= v2[3] * yd2;
+    a2[2] += ydd2;
+    body_force_c(C1 + 12, v1, a1, f1);
+    body_force_c(C2 + 12, v2, a2, f2);
+    T tau1, tau2 = f2[2], f21[6], fp[6];
+    xforce_inv(E2, C2 + 9, f2, f21);
+#pragma unroll
+    for (int j = 0; j < 6; j++) f1[j] += f21[j];
+    tau1 = f1[2];
+    xforce_inv(E1, C1 + 9, f1, fp);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        cptr<T> Cr = P.consts + pr.cofs[2 + r];
+        const T ga = Cr[kBodyConstFixed], gb = Cr[kBodyConstFixed + 1];
+        T tz, fpr[6];
+        rotor_rnea(Cr, vp, ap, ga * yd1 + gb * yd2, ga * ydd1 + gb * ydd2, tz, fpr);
+        tau1 += ga * tz;
+        tau2 += gb * tz;
+#pragma unroll
+        for (int j = 0; j < 6; j++) fp[j] += fpr[j];
+    }
+    M.put(pr.v_index, tau1);
+    M.put(pr.v_index + 1, tau2);
+    lds_add6(M, pr.lds_pf, fp);
+}
+
+template <class T>
+__device__ __forceinline__ void rnea_free_fwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaFree &f)
+{
+    T o[4], E[9], r[3], g[6], a[6], v[6], fo[6];
+    const int nori = P.ori_repr == 0 ? 4 : 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = j < nori ? M.q(f.q_index + 3 + j) : T(0);
+    free_rotation(P.ori_repr, o, E);
+#pragma unroll
+    for (int j = 0; j < 3; j++) r[j] = M.q(f.q_index + j);
+#pragma unroll
+    for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
+    xmotion(E, r, g, a);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        v[j] = M.qd(f.v_index + j);
+        a[j] += M.x(f.v_index + j);
+    }
+    body_force_c(P.consts + f.cofs + 12, v, a, fo);
+    M.lds_st(f.lds_f, fo);
+    if (f.lds_va >= 0) {
+        T va[12];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            va[j] = v[j];
+            va[6 + j] = a[j];
+        }
+        M.lds_st(f.lds_va, va);
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void rnea_free_bwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaFree &f)
+{
+    T fo[6];
+    M.lds_ld(f.lds_f, fo);
+#pragma unroll
+    for (int j = 0; j < 6; j++) M.put(f.v_index + j, fo[j]);
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
+                                                              const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
+                                                              T *__restrict__ scratch)
+{
+    RneaTables<T> P;
+    P.segs = (cptr<RneaSeg>)DP.segs;
+    P.links = (cptr<RneaLink>)DP.links;
+    P.pairs = (cptr<RneaPair>)DP.pairs;
+    P.frees = (cptr<RneaFree>)DP.frees;
+    P.consts = (cptr<T>)DP.consts;
+    P.n_segs = DP.n_segs;
+    P.nq = DP.nq;
+    P.nv = DP.nv;
+    P.ori_repr = DP.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
+    const int lane = threadIdx.x;
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(P.nq + 2 * P.nv) * kWave;  // input / result rows only
+    ChainMem<T> M;
+    M.lane = lane;
+    M.glb = slab;
+    M.in_q = slab + lane;
+    M.in_qd = slab + (size_t)P.nq * kWave + lane;
+    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        stage_inputs(q, qd, ydd, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        for (int s = 0; s < P.n_segs; s++) {
+            const RneaSeg sg = load_rec(P.segs + s);
+            switch (sg.op) {
+                case RSEG_RUN_FWD: {
+                    const RneaLink l0 = load_rec(P.links + sg.first);
+                    if (l0.rofs >= 0) rnea_run_fwd<T, true>(P, M, sg);
+                    else rnea_run_fwd<T, false>(P, M, sg);
+                    break;
+                }
+                case RSEG_RUN_BWD: rnea_run_bwd(P, M, sg); break;
+                case RSEG_PAIR: rnea_pair(P, M, load_rec(P.pairs + sg.first)); break;
+                case RSEG_FREE_FWD: rnea_free_fwd(P, M, load_rec(P.frees + sg.first)); break;
+                default: rnea_free_bwd(P, M, load_rec(P.frees + sg.first)); break;
+            }
+        }
+        write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, tau, tile, rows_valid, P.nv, lane);
+    }
+}
+
+template <class T>
+hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
+                             size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((rnea_chain_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_rnea_chain<float>(const RneaChainDev<float> &, const float *, const float *, const float *, float *, size_t,
+                                             float *, int, size_t, hipStream_t);
+template hipError_t launch_rnea_chain<double>(const RneaChainDev<double> &, const double *, const double *, const double *, double *,
+                                              size_t, double *, int, size_t, hipStream_t);
+
 hipError_t set_max_dynamic_lds_chain()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float, 2>),
@@ -938,6 +1259,12 @@ hipError_t set_max_dynamic_lds_chain()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<double, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_chain_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_chain_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&osim_chain_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);

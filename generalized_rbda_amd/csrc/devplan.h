@@ -64,6 +64,23 @@ hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd);
 hipError_t set_max_dynamic_lds_chain();
 
+template <class T>
+struct RneaChainDev {
+    const RneaSeg *segs;
+    const RneaLink *links;
+    const RneaPair *pairs;
+    const RneaFree *frees;
+    const T *consts;
+    int n_segs;
+    int nq, nv;
+    int lds_bytes;
+    int ori_repr;
+    T a_root[6];
+};
+template <class T>
+hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
+                             size_t lds_bytes, hipStream_t stream);
+
 // inverse operational-space inertia by force propagation along the contacts' ancestor paths (chain_kernels.hip,
 // osim_chain_kernel).  Built per call on the host (capi.cpp) and passed by value.
 constexpr int kOsimMaxContacts = 8;

@@ -791,7 +791,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         P.consts.push_back(h[2]);
         return rotor_pre[b];
     };
-    auto build_chain = [&](ChainProgram &CP, int lds_budget) {
+    auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget) {
         CP = ChainProgram();
         bool ok = sweep_mask == 7;
         // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, -1 unsupported
@@ -983,6 +983,119 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 t_free_acc[c] = push_seg(sg);
                 for (int id : free_chains[c]) emit_acc(id);
             }
+            // ---- the inverse-dynamics program on the same chains (plan.h, RneaChainProgram) ----
+            if (RP) {
+                RneaChainProgram &R = *RP;
+                R = RneaChainProgram();
+                std::vector<RneaLink> rl(nc);
+                std::vector<RneaPair> rp(nc);
+                std::vector<RneaFree> rf(nc);
+                std::vector<Obj> robjs;
+                struct RRun { int seg; std::vector<int> cl; };
+                std::vector<RRun> rruns;
+                std::vector<int> rt_fwd(chains.size(), -1), rt_bwd(chains.size(), -1), rt_pair(chains.size(), -1);
+                std::vector<int> rt_free_fwd(nc, -1), rt_free_bwd(nc, -1);
+                auto rpush = [&](int op) { RneaSeg sg = RneaSeg(); sg.op = op; sg.lds_pva = sg.lds_pf = -1; R.segs.push_back(sg); return static_cast<int>(R.segs.size()) - 1; };
+                std::function<int(int)> remit = [&](int id) -> int {  // returns the last forward-type segment of the subtree
+                    const Chain ch = chains[id];
+                    rt_fwd[id] = rpush(RSEG_RUN_FWD);
+                    rruns.push_back({rt_fwd[id], ch.cl});
+                    int last = rt_fwd[id];
+                    if (ch.pair >= 0) last = rt_pair[id] = rpush(RSEG_PAIR);
+                    for (int k : ch.kid_chains) last = std::max(last, remit(k));
+                    rt_bwd[id] = rpush(RSEG_RUN_BWD);
+                    std::vector<int> rev(ch.cl.rbegin(), ch.cl.rend());
+                    rruns.push_back({rt_bwd[id], rev});
+                    return last;
+                };
+                std::vector<int> last_fwd_of(chains.size(), -1);
+                for (int c = 0; c < nc; c++) {
+                    if (cls[c] != 0) continue;
+                    rt_free_fwd[c] = rpush(RSEG_FREE_FWD);
+                    for (int id : free_chains[c]) remit(id);
+                    rt_free_bwd[c] = rpush(RSEG_FREE_BWD);
+                }
+                // last segment that reads the [v, a] of a chain's tip: the forward runs / pair of its kid chains
+                for (size_t id = 0; id < chains.size(); id++) {
+                    int last = rt_fwd[id];
+                    if (chains[id].pair >= 0) last = rt_pair[id];
+                    for (int k : chains[id].kid_chains) last = std::max(last, rt_fwd[k]);
+                    last_fwd_of[id] = last;
+                }
+                for (int c = 0; c < nc; c++) {
+                    const ClusterRec &cr = clusters[c];
+                    if (cls[c] == 0) {
+                        RneaFree &f = rf[c];
+                        f = RneaFree();
+                        f.q_index = cr.q_index; f.v_index = cr.v_index; f.cofs = bodies[cr.first_body].cofs;
+                        f.lds_va = f.lds_f = -1;
+                        int last = rt_free_fwd[c];
+                        for (int id : free_chains[c]) last = std::max(last, rt_fwd[id]);
+                        if (!free_chains[c].empty()) robjs.push_back({&f.lds_va, 12, 0, rt_free_fwd[c], last, -1, 1});
+                        robjs.push_back({&f.lds_f, 6, 0, rt_free_fwd[c], rt_free_bwd[c], -1, 1});
+                    } else if (cls[c] == 1 || cls[c] == 2) {
+                        RneaLink &l = rl[c];
+                        l = RneaLink();
+                        l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = bodies[cr.link_body].cofs;
+                        l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : -1;
+                        l.lds_blk = l.lds_va = l.lds_pf = -1;
+                    } else {
+                        RneaPair &pr = rp[c];
+                        pr = RneaPair();
+                        pr.q_index = cr.q_index; pr.v_index = cr.v_index;
+                        for (int i = 0; i < 4; i++) pr.cofs[i] = pair_of[c].cofs[i];
+                        pr.lds_pva = pr.lds_pf = -1;
+                    }
+                }
+                for (size_t id = 0; id < chains.size(); id++) {
+                    const Chain &ch = chains[id];
+                    for (int c : ch.cl) robjs.push_back({&rl[c].lds_blk, 9, 0, rt_fwd[id], rt_bwd[id], -1, 1});
+                    const int tipc = ch.cl.back();
+                    if (!ch.kid_chains.empty() || ch.pair >= 0)
+                        robjs.push_back({&rl[tipc].lds_va, 12, 0, rt_fwd[id], last_fwd_of[id], -1, 1});
+                }
+                int rn_lds = 0, rn_glb = 0;
+                bool rok = allocate(robjs, rnea_budget, rn_lds, rn_glb);
+                if (rok) {
+                    auto f_slot_of_body = [&](int b) -> int {
+                        const int c = m.bodies[b].cluster;
+                        return cls[c] == 0 ? rf[c].lds_f : rl[c].lds_blk;
+                    };
+                    auto va_slot_of_body2 = [&](int b) -> int {
+                        const int c = m.bodies[b].cluster;
+                        return cls[c] == 0 ? rf[c].lds_va : rl[c].lds_va;
+                    };
+                    for (int c = 0; c < nc; c++) {
+                        const int pb = clusters[c].parent_body;
+                        if (cls[c] == 1 || cls[c] == 2) rl[c].lds_pf = f_slot_of_body(pb);
+                        if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb); }
+                    }
+                    for (const RRun &r : rruns) {
+                        RneaSeg &sg = R.segs[r.seg];
+                        sg.first = static_cast<int>(R.links.size());
+                        sg.count = static_cast<int>(r.cl.size());
+                        for (int c : r.cl) R.links.push_back(rl[c]);
+                    }
+                    for (size_t id = 0; id < chains.size(); id++) {
+                        const Chain &ch = chains[id];
+                        const int pb = clusters[ch.cl.front()].parent_body;
+                        R.segs[rt_fwd[id]].lds_pva = va_slot_of_body2(pb);
+                        R.segs[rt_bwd[id]].lds_pf = f_slot_of_body(pb);
+                        if (ch.pair >= 0) {
+                            R.segs[rt_pair[id]].first = static_cast<int>(R.pairs.size());
+                            R.pairs.push_back(rp[ch.pair]);
+                        }
+                    }
+                    for (int c = 0; c < nc; c++) {
+                        if (cls[c] != 0) continue;
+                        R.segs[rt_free_fwd[c]].first = R.segs[rt_free_bwd[c]].first = static_cast<int>(R.frees.size());
+                        R.frees.push_back(rf[c]);
+                    }
+                    R.n_lds = rn_lds;
+                }
+                R.ok = rok;
+                if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); }
+            }
             // ---- LDS objects and their live ranges (segment indices) ----
             auto last_acc_of = [&](int id) {
                 std::function<int(int)> rec = [&](int i) -> int {
@@ -1092,9 +1205,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         CP.ok = ok;
         if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); }
     };
-    build_chain(P.chain32, lds.aba32);
-    build_chain(P.chain32w, lds.chain32w);
-    build_chain(P.chain64, lds.aba64);
+    // the RNEA chain kernels run 8 wavefronts per CU like the ABA ones: the ABA budgets apply
+    build_chain(P.chain32, lds.aba32, &P.rchain32, lds.aba32);
+    build_chain(P.chain32w, lds.chain32w, nullptr, 0);
+    build_chain(P.chain64, lds.aba64, &P.rchain64, lds.aba64);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
     {

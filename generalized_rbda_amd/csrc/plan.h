@@ -217,6 +217,46 @@ struct ChainFree {      // 16 ints
     int32_t reserved[8];
 };
 
+// ---- inverse dynamics on the same chains (chain_kernels.hip, rnea_chain_kernel) ------------------------------------
+// forward run: v, a, body force f = I a + v x* I v of every link, the rotor's torque and its force on the parent body;
+// backward run: tau = S^T f, f_parent += X^T f.  A leaf pair cluster is finished in one segment of the forward pass.
+enum RneaChainOp : int32_t { RSEG_FREE_FWD = 0, RSEG_RUN_FWD = 1, RSEG_PAIR = 2, RSEG_RUN_BWD = 3, RSEG_FREE_BWD = 4 };
+struct RneaLink {       // 16 ints
+    int32_t q_index, v_index;
+    int32_t cofs, rofs;     // link / rotor constants (rofs -1: plain revolute cluster)
+    int32_t lds_blk;        // LDS slot of [f 6][sin, cos][rotor torque]  (9)
+    int32_t lds_va;         // LDS slot of [v 6][a 6] when child segments read them, else -1
+    int32_t lds_pf;         // LDS slot of the parent body's force (first 6 of its block / the base's), -1: ground
+    int32_t reserved[9];
+};
+struct RneaPair {       // 16 ints
+    int32_t q_index, v_index;
+    int32_t cofs[4];        // link1, link2, rotor1, rotor2
+    int32_t lds_pva;        // parent body's [v 6][a 6]
+    int32_t lds_pf;         // parent body's force
+    int32_t reserved[8];
+};
+struct RneaSeg {        // 8 ints
+    int32_t op, first, count;
+    int32_t lds_pva;        // RSEG_RUN_FWD: [v][a] of the body the chain hangs off, -1: ground
+    int32_t lds_pf;         // RSEG_RUN_BWD: force slot of that body, -1: ground
+    int32_t reserved[3];
+};
+struct RneaFree {       // 8 ints
+    int32_t q_index, v_index, cofs;
+    int32_t lds_va;         // own [v][a], -1 when no children
+    int32_t lds_f;          // own force (children add theirs)
+    int32_t reserved[3];
+};
+struct RneaChainProgram {
+    bool ok = false;
+    std::vector<RneaSeg> segs;
+    std::vector<RneaLink> links;
+    std::vector<RneaPair> pairs;
+    std::vector<RneaFree> frees;
+    int n_lds = 0;
+};
+
 struct ChainProgram {
     bool ok = false;                 // the model is covered and its LDS objects fit the budget
     std::vector<ChainSeg> segs;
@@ -261,6 +301,7 @@ struct HostPlan {
     ChainProgram chain32w;    // the same laid out for four wavefronts per SIMD (half the LDS per wavefront)
     ChainProgram chain64;     // f64 ABA (slots are twice as large: the LDS budget holds half as many)
     CrbaProgram crba;
+    RneaChainProgram rchain32, rchain64;  // inverse dynamics on the chains
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };

@@ -97,6 +97,7 @@ typedef struct {
     int chain_aba_f32;         /* 1: the f32 forward dynamics run the chain-structured kernel (plan.h, ChainProgram) */
     int n_lds_slots_chain_f32, n_chain_segments;
     int chain_aba_f64;
+    int chain_rnea_f32, chain_rnea_f64; /* inverse dynamics on the chains (rnea_chain_kernel) */
 } grbda_plan_info_t;
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 
