@@ -300,6 +300,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     d.n_glb_slots = cp.n_glb;
     d.ori_repr = h.ori_repr;
     d.debug = p->chain_debug;
+    d.sv_global = cp.sv_global ? 1 : 0;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t.n_cu) * waves_per_cu;
@@ -813,6 +814,7 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.n_glb_slots = cp.n_glb + n_contacts * A.w_stride;
     d.ori_repr = h.ori_repr;
     d.debug = 0;
+    d.sv_global = cp.sv_global ? 1 : 0;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t->n_cu) * 4;  // one wavefront per SIMD: the walk kernel is not register-tuned

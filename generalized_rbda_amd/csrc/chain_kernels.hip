@@ -139,14 +139,18 @@ __device__ __forceinline__ void rotor_terms(cptr<T> Cr, const T (&vp)[6], T qdr,
 // ---------------------------------------------------------------------------------------------------------------
 // forward run: TreeModel::forwardKinematics (TreeModel.cpp:6-32) along a chain, root side first
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
+// SVG: the program keeps the [sin, cos, v] blocks of the links in the wave's global slab instead of LDS (ChainProgram::
+// sv_global: chains too long for the LDS budget); a compile-time property of the run so that the common case carries
+// neither the test nor the prefetch registers.
+template <class T, bool SVG>
 __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
 {
     T vp[6];
     {
         const ChainLink l0 = load_rec(P.links + sg.first);
-        if (l0.lds_pv >= 0) {
-            M.lds_ld(l0.lds_pv, vp);
+        if (l0.lds_pv != -1) {
+            if constexpr (SVG) M.acc_ld(l0.lds_pv, vp);
+            else M.lds_ld(l0.lds_pv, vp);
         } else {
 #pragma unroll
             for (int j = 0; j < 6; j++) vp[j] = 0;
@@ -175,7 +179,8 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
             blk[2 + j] = v[j];
             vp[j] = v[j];
         }
-        M.lds_st(l.lds_sv, blk);
+        if constexpr (SVG) M.glb_st(l.lds_sv, blk);
+        else M.lds_st(l.lds_sv, blk);
         l = ln;
         qi = qn;
         qdi_in = qdn;
@@ -196,7 +201,7 @@ __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem
 {
     cptr<T> C1 = P.consts + pr.cofs[0], C2 = P.consts + pr.cofs[1];
     T vp[6];
-    M.lds_ld(pr.lds_pv, vp);
+    M.acc_ld(pr.lds_pv, vp);  // (LDS, or the global slab in programs with ChainProgram::sv_global)
     const T y1 = M.q(pr.q_index), y2 = M.q(pr.q_index + 1);
     const T yd1 = M.qd(pr.v_index), yd2 = M.qd(pr.v_index + 1);
     T u[2] = {M.x(pr.v_index), M.x(pr.v_index + 1)};
@@ -337,7 +342,10 @@ __device__ __forceinline__ void pair_acc(const ChainTables<T> &P, const ChainMem
 // chain, leaf side first.  Per link (n = 1): D = g0^2 h_z (+ rotor), F = X^T h g0 (+ rotor), u = tau - g0 b (- rotor),
 // K = F / D, y0 = u / D, and one combined hand-over X^T IA X - F K, X^T (pA + IA c) + F y0 to the parent.
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, bool ROTOR, bool OSIM>
+// Per link the rotor comes in three kinds (a wave-uniform branch on the link record, so one run may mix them): none;
+// axisymmetric (q = 0, plan constants); general leaf rotor evaluated at its own angle, whose X^T I X joins the hand-over
+// like a second body of the cluster.
+template <class T, bool OSIM, bool SVG>
 __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
 {
     T IAc[21], psic[6];  // what the link below handed up (register hand-over inside the run)
@@ -359,22 +367,30 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
     }
     // the inputs of the next link travel (global slab rows, L2 latency) while the current link is computed
     ChainLink l = load_rec(P.links + sg.first);
-    T yd = M.qd(l.v_index), tau_in = M.x(l.v_index);
+    T yd = M.qd(l.v_index), tau_in = M.x(l.v_index), y_in = M.q(l.q_index);
+    T blk[8];  // [sin, cos, v 6] of the current link; SVG: in the global slab, fetched one link ahead
+    if constexpr (SVG) M.glb_ld(l.lds_sv, blk);
     for (int i = 0; i < sg.count; i++) {
         const bool more = i + 1 < sg.count;
         const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
-        T ydn = 0, taun = 0;
+        T ydn = 0, taun = 0, yn = 0;
         if (more) {
             ydn = M.qd(ln.v_index);
             taun = M.x(ln.v_index);
+            yn = M.q(ln.q_index);
+        }
+        T blkn[8];
+        if constexpr (SVG) {
+            if (more) M.glb_ld(ln.lds_sv, blkn);
+        } else {
+            M.lds_ld(l.lds_sv, blk);
         }
         cptr<T> C = P.consts + l.cofs;
         cptr<T> Ic = C + 12;
         cptr<T> Ib = P.consts + l.iofs;
         const T g0 = C[kBodyConstFixed];
         const T qdi = g0 * yd;
-        T blk[8], E[9], v[6];
-        M.lds_ld(l.lds_sv, blk);
+        T E[9], v[6];
         rotate_z(blk[0], blk[1], C, E);
 #pragma unroll
         for (int j = 0; j < 6; j++) v[j] = blk[2 + j];
@@ -405,13 +421,53 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
             xforce_inv(E, C + 9, t, psic);
             congruence(E, C + 9, IA, IAc);
         }
-        if constexpr (ROTOR) {
+        if (l.rofs >= 0 && l.rpre < 0) {
+            cptr<T> Cr = P.consts + l.rofs;
+            cptr<T> Ir = Cr + 12;
+            const T gr = Cr[kBodyConstFixed];
+            const T qdr = gr * yd;
+            T vp[6];
+            if (l.lds_pv != -1) {
+                if constexpr (SVG) M.acc_ld(l.lds_pv, vp);
+                else M.lds_ld(l.lds_pv, vp);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) vp[j] = 0;
+            }
+            T sr, cr_, Er[9], vr[6], crv[6], prr[6], hr[6];
+            sincos_t(gr * y_in, &sr, &cr_);
+            rotate_z(sr, cr_, Cr, Er);
+            xmotion(Er, Cr + 9, vp, vr);
+            vr[2] += qdr;
+            vxz(vr, qdr, crv);
+            bias_force(Ir, vr, prr);
+#pragma unroll
+            for (int k = 0; k < 6; k++) hr[k] = Ir[sidx(k, 2)];
+            const T bjr = prr[2] + hr[0] * crv[0] + hr[1] * crv[1] + hr[3] * crv[3] + hr[4] * crv[4];
+            u -= gr * bjr;
+            D += hr[2] * gr * gr;
+            T fr[6], t[6], tp[6], Br[21];
+            xforce_inv(Er, Cr + 9, hr, fr);
+#pragma unroll
+            for (int r = 0; r < 6; r++) F[r] += fr[r] * gr;
+            symv_z(Ir, crv, t);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t[j] += prr[j];
+            xforce_inv(Er, Cr + 9, t, tp);
+#pragma unroll
+            for (int j = 0; j < 6; j++) psic[j] += tp[j];
+            congruence(Er, Cr + 9, Ir, Br);
+#pragma unroll
+            for (int j = 0; j < 21; j++) IAc[j] += Br[j];
+        }
+        if (l.rofs >= 0 && l.rpre >= 0) {
             cptr<T> Cr = P.consts + l.rofs;
             cptr<T> Rp = P.consts + l.rpre;  // [X0^T h (6)][h_z]
             const T gr = Cr[kBodyConstFixed];
             T vp[6];
-            if (l.lds_pv >= 0) {
-                M.lds_ld(l.lds_pv, vp);
+            if (l.lds_pv != -1) {
+                if constexpr (SVG) M.acc_ld(l.lds_pv, vp);
+                else M.lds_ld(l.lds_pv, vp);
             } else {
 #pragma unroll
                 for (int j = 0; j < 6; j++) vp[j] = 0;
@@ -446,6 +502,13 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         l = ln;
         yd = ydn;
         tau_in = taun;
+        y_in = yn;
+        if constexpr (SVG) {
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) blk[j] = blkn[j];
+            }
+        }
     }
     // hand the chain's projected inertia / bias to the body it hangs off
     if (sg.lds_acc_out != -1) {
@@ -665,10 +728,12 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
         for (int s = 0; s < ((DP.debug & 2) ? 0 : P.n_segs); s++) {
             const ChainSeg sg = load_rec(P.segs + s);
             switch (sg.op) {
-                case SEG_RUN_FWD: run_fwd(P, M, sg); break;
+                case SEG_RUN_FWD:
+                    if (DP.sv_global) run_fwd<T, true>(P, M, sg);
+                    else run_fwd<T, false>(P, M, sg);
+                    break;
                 case SEG_RUN_BWD: {
-                    const ChainLink l0 = load_rec(P.links + sg.first);
-                    if (l0.rofs >= 0) run_bwd<T, true, false>(P, M, sg);
+                    if (DP.sv_global) run_bwd<T, false, true>(P, M, sg);
                     else run_bwd<T, false, false>(P, M, sg);
                     break;
                 }
@@ -747,11 +812,13 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
         for (int s = 0; s < P.n_segs; s++) {
             const ChainSeg sg = load_rec(P.segs + s);
             switch (sg.op) {
-                case SEG_RUN_FWD: run_fwd(P, M, sg); break;
+                case SEG_RUN_FWD:
+                    if (DP.sv_global) run_fwd<T, true>(P, M, sg);
+                    else run_fwd<T, false>(P, M, sg);
+                    break;
                 case SEG_RUN_BWD: {
-                    const ChainLink l0 = load_rec(P.links + sg.first);
-                    if (l0.rofs >= 0) run_bwd<T, true, true>(P, M, sg);
-                    else run_bwd<T, false, true>(P, M, sg);
+                    if (DP.sv_global) run_bwd<T, true, true>(P, M, sg);
+                    else run_bwd<T, true, false>(P, M, sg);
                     break;
                 }
                 case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
@@ -1000,7 +1067,7 @@ __device__ __forceinline__ void lds_add6(const ChainMem<T> &M, int slot, const T
     M.lds_st(slot, y);
 }
 
-template <class T, bool ROTOR>
+template <class T>
 __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaSeg &sg)
 {
     T vp[6], ap[6];
@@ -1046,13 +1113,33 @@ __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const Chain
         a[2] += g0 * yddi;
         body_force_c(C + 12, v, a, f);
         blk[8] = 0;
-        if constexpr (ROTOR) {
+        if (l.rofs >= 0 && !l.general_rotor) {
             cptr<T> Cr = P.consts + l.rofs;
             const T gr = Cr[kBodyConstFixed];
             T tz, fpr[6];
             rotor_rnea(Cr, vp, ap, gr * ydi, gr * yddi, tz, fpr);
             blk[8] = gr * tz;
             if (l.lds_pf >= 0) lds_add6(M, l.lds_pf, fpr);  // the rotor hangs off the parent body
+        }
+        if (l.rofs >= 0 && l.general_rotor) {  // general rotor: a second full body of the cluster, at its own angle
+            cptr<T> Cr = P.consts + l.rofs;
+            const T gr = Cr[kBodyConstFixed];
+            const T qdr = gr * ydi;
+            T sr, cr_, Er[9], vr[6], ar[6], fr[6], fpr[6];
+            sincos_t(gr * qi, &sr, &cr_);
+            rotate_z(sr, cr_, Cr, Er);
+            xmotion(Er, Cr + 9, vp, vr);
+            xmotion(Er, Cr + 9, ap, ar);
+            vr[2] += qdr;
+            ar[0] += vr[1] * qdr;
+            ar[1] -= vr[0] * qdr;
+            ar[3] += vr[4] * qdr;
+            ar[4] -= vr[3] * qdr;
+            ar[2] += gr * yddi;
+            body_force_c(Cr + 12, vr, ar, fr);
+            blk[8] = gr * fr[2];
+            xforce_inv(Er, Cr + 9, fr, fpr);
+            if (l.lds_pf >= 0) lds_add6(M, l.lds_pf, fpr);
         }
 #pragma unroll
         for (int j = 0; j < 6; j++) blk[j] = f[j];
@@ -1224,12 +1311,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
         for (int s = 0; s < P.n_segs; s++) {
             const RneaSeg sg = load_rec(P.segs + s);
             switch (sg.op) {
-                case RSEG_RUN_FWD: {
-                    const RneaLink l0 = load_rec(P.links + sg.first);
-                    if (l0.rofs >= 0) rnea_run_fwd<T, true>(P, M, sg);
-                    else rnea_run_fwd<T, false>(P, M, sg);
-                    break;
-                }
+                case RSEG_RUN_FWD: rnea_run_fwd(P, M, sg); break;
                 case RSEG_RUN_BWD: rnea_run_bwd(P, M, sg); break;
                 case RSEG_PAIR: rnea_pair(P, M, load_rec(P.pairs + sg.first)); break;
                 case RSEG_FREE_FWD: rnea_free_fwd(P, M, load_rec(P.frees + sg.first)); break;

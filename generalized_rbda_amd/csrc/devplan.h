@@ -57,6 +57,7 @@ struct ChainDev {
     int lds_bytes;
     int ori_repr;
     int debug;   // GRBDA_CHAIN_DEBUG: phase ablation for profiling (chain_kernels.hip)
+    int sv_global;  // ChainProgram::sv_global
     T a_root[6];
 };
 template <class T>

@@ -11,6 +11,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -794,8 +795,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget) {
         CP = ChainProgram();
         bool ok = sweep_mask == 7;
-        // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, -1 unsupported
-        std::vector<int> cls(nc, -1), tip(nc, -1);
+        // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, 4 revolute + general rotor,
+        // -1 unsupported
+        std::vector<int> cls(nc, -1), tip(nc, -1), gen_rotor(nc, -1);
         std::vector<ChainPair> pair_of(nc);
         std::vector<std::array<int, 2>> pair_rotors(nc, std::array<int, 2>{-1, -1});
         for (int c = 0; c < nc && ok; c++) {
@@ -806,6 +808,17 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             } else if (cr.kind == CK_STATIC && cr.shape != SHAPE_GENERIC) {
                 cls[c] = cr.shape == SHAPE_REV ? 1 : 2;
                 tip[c] = cr.link_body;
+            } else if (cr.kind == CK_STATIC && cr.n == 1 && cr.k == 2 && !cr.chained && cr.parent_body >= 0 &&
+                       (!bodies[cr.first_body].has_child || !bodies[cr.first_body + 1].has_child)) {
+                // a link and a rotor that is NOT axisymmetric about its joint axis (JVRC-1: every rotor carries the same
+                // z-symmetric inertia whatever its axis): the rotor is evaluated at its own angle
+                cls[c] = 4;
+                const int f = cr.first_body;
+                // the rotor is the childless body; of two childless bodies the one the coordinate does not drive 1:1
+                int rot = !bodies[f].has_child ? f : f + 1;
+                if (!bodies[f].has_child && !bodies[f + 1].has_child && P.consts[bodies[f].cofs + kBodyConstFixed] == 1.0) rot = f + 1;
+                gen_rotor[c] = rot;
+                tip[c] = rot == f ? f + 1 : f;
             } else if (cr.kind == CK_STATIC && cr.n == 2 && cr.k == 4 && cr.parent_body >= 0) {
                 // RevolutePairWithRotor shape: link1 and two axisymmetric rotors on the parent body, link2 on link1,
                 // coordinates = the two link angles (RevolutePairWithRotorJoint.cpp:10-69), no child clusters
@@ -841,6 +854,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 ok = false;
             }
             if (cls[c] != 0 && cr.parent_body < 0) ok = false;  // fixed-base models stay on the general kernels
+            if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d (k %d n %d kind %d shape %d) not covered\n", c, cr.k, cr.n, cr.kind, cr.shape);
         }
         // every child cluster must hang off the tip body of its parent cluster; a pair must be an only child of a link
         std::vector<std::vector<int>> ckids(nc);
@@ -848,7 +862,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             const int pb = clusters[c].parent_body;
             if (pb < 0) continue;
             const int pc = m.bodies[pb].cluster;
-            if (tip[pc] != pb) { ok = false; break; }
+            if (tip[pc] != pb) {
+                if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d hangs off body %d, not the tip %d of cluster %d\n", c, pb, tip[pc], pc);
+                ok = false;
+                break;
+            }
             ckids[pc].push_back(c);
         }
         for (int c = 0; c < nc && ok; c++) {
@@ -875,13 +893,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     f.q_index = cr.q_index; f.v_index = cr.v_index; f.cofs = br.cofs; f.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
                     f.lds_v = f.lds_acc = f.lds_va = -1;
                     f.glb_y0 = glb(33);  // [y0 6] (+ OSIM pass: Cholesky factor of the base's articulated inertia, L 21 + 1/diag 6)
-                } else if (cls[c] == 1 || cls[c] == 2) {
+                } else if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) {
                     ChainLink &l = link_of[c];
                     l = ChainLink();
-                    const BodyRec &br = bodies[cr.link_body];
+                    const BodyRec &br = bodies[cls[c] == 4 ? tip[c] : cr.link_body];
                     l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = br.cofs;
-                    l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : -1;
-                    l.rpre = cls[c] == 2 ? rotor_constants(cr.rotor_body) : -1;
+                    l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : (cls[c] == 4 ? bodies[gen_rotor[c]].cofs : -1);
+                    l.rpre = cls[c] == 2 ? rotor_constants(cr.rotor_body) : -1;  // rofs >= 0 with rpre < 0: a general rotor
                     l.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
                     l.has_child = br.has_child;
                     l.lds_sv = l.lds_pv = l.lds_va = -1;
@@ -893,7 +911,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     pair_of[c].lds_pv = pair_of[c].lds_pva = -1;
                 }
             }
-            // chains: follow single link children of the same class; a single pair child becomes the head of the backward run
+            // chains: follow single link children; a single pair child becomes the head of the backward run
+            auto is_link = [](int k) { return k == 1 || k == 2 || k == 4; };
             struct Chain { std::vector<int> cl; int pair = -1; std::vector<int> kid_chains; int parent_cluster = -1; };
             std::vector<Chain> chains;
             std::function<int(int)> make_chain = [&](int c0) -> int {
@@ -902,7 +921,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 int c = c0;
                 for (;;) {
                     ch.cl.push_back(c);
-                    if (ckids[c].size() == 1 && cls[ckids[c][0]] == cls[c]) { c = ckids[c][0]; continue; }
+                    // (links with no rotor, an axisymmetric rotor and a general rotor may share a run: the kind is a branch on
+                    // the link record)
+                    if (ckids[c].size() == 1 && is_link(cls[ckids[c][0]])) { c = ckids[c][0]; continue; }
                     break;
                 }
                 const int tipc = ch.cl.back();
@@ -1033,11 +1054,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         for (int id : free_chains[c]) last = std::max(last, rt_fwd[id]);
                         if (!free_chains[c].empty()) robjs.push_back({&f.lds_va, 12, 0, rt_free_fwd[c], last, -1, 1});
                         robjs.push_back({&f.lds_f, 6, 0, rt_free_fwd[c], rt_free_bwd[c], -1, 1});
-                    } else if (cls[c] == 1 || cls[c] == 2) {
+                    } else if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) {
                         RneaLink &l = rl[c];
                         l = RneaLink();
-                        l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = bodies[cr.link_body].cofs;
-                        l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : -1;
+                        l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = bodies[tip[c]].cofs;
+                        l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : (cls[c] == 4 ? bodies[gen_rotor[c]].cofs : -1);
+                        l.general_rotor = cls[c] == 4;
                         l.lds_blk = l.lds_va = l.lds_pf = -1;
                     } else {
                         RneaPair &pr = rp[c];
@@ -1067,7 +1089,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     };
                     for (int c = 0; c < nc; c++) {
                         const int pb = clusters[c].parent_body;
-                        if (cls[c] == 1 || cls[c] == 2) rl[c].lds_pf = f_slot_of_body(pb);
+                        if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) rl[c].lds_pf = f_slot_of_body(pb);
                         if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb); }
                     }
                     for (const RRun &r : rruns) {
@@ -1097,20 +1119,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); }
             }
             // ---- LDS objects and their live ranges (segment indices) ----
-            auto last_acc_of = [&](int id) {
-                std::function<int(int)> rec = [&](int i) -> int {
-                    int t = std::max(ct[i].acc, ct[i].pair_acc);
-                    for (int k : chains[i].kid_chains) t = std::max(t, rec(k));
-                    return t;
-                };
-                return rec(id);
-            };
             for (int c = 0; c < nc; c++) {
                 if (cls[c] != 0) continue;
                 ChainFree &f = free_of[c];
                 if (free_chains[c].empty()) continue;
                 int first_bwd = 1 << 30, last_acc = t_free_acc[c];
-                for (int id : free_chains[c]) { first_bwd = std::min(first_bwd, ct[id].bwd); last_acc = std::max(last_acc, last_acc_of(id)); }
+                // (the [v, a] block is read when a kid chain's acceleration run STARTS: it lives until the last kid's own segment)
+                for (int id : free_chains[c]) { first_bwd = std::min(first_bwd, ct[id].bwd); last_acc = std::max(last_acc, ct[id].acc); }
                 objs.push_back({&f.lds_v, 6, 0, t_free_fwd[c], t_free_bwd[c], -1, 1});
                 objs.push_back({&f.lds_acc, 27, 1, first_bwd, t_free_bwd[c], -1, 1});
                 objs.push_back({&f.lds_va, 12, 0, t_free_acc[c], last_acc, -1, 1});
@@ -1121,7 +1136,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 const int tipc = ch.cl.back();
                 if (!ch.kid_chains.empty()) {
                     int first_bwd = 1 << 30, last_acc = ct[id].acc;
-                    for (int k : ch.kid_chains) { first_bwd = std::min(first_bwd, ct[k].bwd); last_acc = std::max(last_acc, last_acc_of(k)); }
+                    for (int k : ch.kid_chains) { first_bwd = std::min(first_bwd, ct[k].bwd); last_acc = std::max(last_acc, ct[k].acc); }
                     objs.push_back({&acc_slot[tipc], 27, 1, first_bwd, ct[id].bwd, -1, 1});
                     objs.push_back({&link_of[tipc].lds_va, 12, 0, ct[id].acc, last_acc, -1, 1});
                 } else if (ch.pair >= 0) {
@@ -1130,14 +1145,27 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             int n_lds = 0, n_glb_unused = 0;
             ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
+            if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: LDS objects need more than %d slots (got to %d)\n", lds_budget, n_lds);
             if (!ok) {
                 // second try: the accumulators [IA 21][psi 6] of branching bodies -- touched once per child chain -- move
                 // to the wave's global slab (their slot numbers then carry kSlotGlobal)
                 for (Obj &o : objs)
                     if (o.size == 27) { o.force = 2; o.slot = -1; }
                 ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
+                if (!ok) {
+                    // third try (long chains, JVRC-1's arms and legs): the [sin, cos, v] blocks of the links go there too;
+                    // the backward run fetches the next link's block while it computes the current one
+                    for (Obj &o : objs)
+                        if (o.size == 8) { o.force = 2; o.slot = -1; }
+                    ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
+                    CP.sv_global = true;
+                    if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) {
+                        std::fprintf(stderr, "chain: third try failed, n_lds %d\n", n_lds);
+                        for (const Obj &o : objs) std::fprintf(stderr, "  obj size %d force %d [%d, %d] slot %d\n", o.size, o.force, o.birth, o.death, o.slot);
+                    }
+                }
                 for (Obj &o : objs)
-                    if (o.size == 27) *o.field = ((o.slot & ~kSlotGlobal) + n_glb) | kSlotGlobal;
+                    if (o.force == 2) *o.field = ((o.slot & ~kSlotGlobal) + n_glb) | kSlotGlobal;
                 n_glb += n_glb_unused;
             }
             if (ok) {
@@ -1146,7 +1174,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 // parent velocity / (v, a) slots
                 auto v_slot_of_body = [&](int b) -> int {  // LDS slot of the velocity of body b (tip of its cluster)
                     const int c = m.bodies[b].cluster;
-                    return cls[c] == 0 ? free_of[c].lds_v : link_of[c].lds_sv + 2;
+                    return cls[c] == 0 ? free_of[c].lds_v : link_of[c].lds_sv + 2;  // (+2 keeps a kSlotGlobal flag intact)
                 };
                 auto va_slot_of_body = [&](int b) -> int {
                     const int c = m.bodies[b].cluster;
@@ -1158,7 +1186,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 };
                 for (int c = 0; c < nc; c++) {
                     const int pb = clusters[c].parent_body;
-                    if (cls[c] == 1 || cls[c] == 2) link_of[c].lds_pv = v_slot_of_body(pb);
+                    if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) link_of[c].lds_pv = v_slot_of_body(pb);
                     if (cls[c] == 3) { pair_of[c].lds_pv = v_slot_of_body(pb); pair_of[c].lds_pva = va_slot_of_body(pb); }
                 }
                 // first writer of every accumulator slot: the kid chain whose backward run comes first

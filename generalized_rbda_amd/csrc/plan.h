@@ -181,7 +181,8 @@ struct ChainLink {
     int32_t glb_k;      // global slab slot of [K 6][y0][sin][cos], backward run -> acceleration run
     int32_t has_child;
     int32_t lds_va;     // acceleration sweep: LDS slot of [v 6][a 6] when another segment reads them, else -1
-    int32_t rpre;       // rotor: state-independent constants [X0^T h (6)][h_z] with h = I_rotor[:, z] (plan.cpp)
+    int32_t rpre;       // axisymmetric rotor: state-independent constants [X0^T h (6)][h_z] with h = I_rotor[:, z] (plan.cpp);
+                        // -1 with rofs >= 0: a general rotor, evaluated at its own angle
     int32_t reserved[5];
 };
 
@@ -227,7 +228,8 @@ struct RneaLink {       // 16 ints
     int32_t lds_blk;        // LDS slot of [f 6][sin, cos][rotor torque]  (9)
     int32_t lds_va;         // LDS slot of [v 6][a 6] when child segments read them, else -1
     int32_t lds_pf;         // LDS slot of the parent body's force (first 6 of its block / the base's), -1: ground
-    int32_t reserved[9];
+    int32_t general_rotor;  // 1: the rotor is not axisymmetric about its axis and is evaluated at its own angle
+    int32_t reserved[8];
 };
 struct RneaPair {       // 16 ints
     int32_t q_index, v_index;
@@ -264,6 +266,7 @@ struct ChainProgram {
     std::vector<ChainPair> pairs;
     std::vector<ChainFree> frees;
     int n_lds = 0, n_glb = 0;        // slots
+    bool sv_global = false;          // the [sin, cos, v] blocks of the links live in the global slab (chains too long for LDS)
 };
 
 // composite-rigid-body algorithm (crba_kernels.hip): per body, where its per-state scratch rows live in the wave's slab
