@@ -174,9 +174,19 @@ def main():
         try:
             dist.init_process_group(backend="nccl", device_id=dev)
             dist.barrier()
+            warm = torch.zeros(8, device=dev)
+            dist.gather(warm, [torch.zeros(8, device=dev) for _ in range(world)] if rank == 0 else None, dst=0)
             torch.cuda.synchronize()
         finally:
+            # the banner sits in the C library's stdio buffer (fully buffered on a pipe) until someone flushes it:
+            # flush it NOW, while descriptor 1 still points at stderr
             sys.stdout.flush()
+            try:
+                import ctypes
+
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
