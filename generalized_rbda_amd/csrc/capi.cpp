@@ -55,12 +55,14 @@ struct DeviceTables {
     ChainLink *chain_links[3] = {nullptr, nullptr, nullptr};
     ChainPair *chain_pairs[3] = {nullptr, nullptr, nullptr};
     ChainFree *chain_frees[3] = {nullptr, nullptr, nullptr};
+    ChainDiff *chain_diffs[3] = {nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
     // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64
     RneaSeg *rchain_segs[2] = {nullptr, nullptr};
     RneaLink *rchain_links[2] = {nullptr, nullptr};
     RneaPair *rchain_pairs[2] = {nullptr, nullptr};
     RneaFree *rchain_frees[2] = {nullptr, nullptr};
+    RneaDiff *rchain_diffs[2] = {nullptr, nullptr};
     int n_cu = 0;
 };
 struct Scratch {
@@ -193,7 +195,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         if ((e = up(rp.segs.data(), rp.segs.size() * sizeof(RneaSeg), (void **)&t.rchain_segs[w])) != hipSuccess ||
             (e = up(rp.links.data(), rp.links.size() * sizeof(RneaLink), (void **)&t.rchain_links[w])) != hipSuccess ||
             (e = up(rp.pairs.data(), rp.pairs.size() * sizeof(RneaPair), (void **)&t.rchain_pairs[w])) != hipSuccess ||
-            (e = up(rp.frees.data(), rp.frees.size() * sizeof(RneaFree), (void **)&t.rchain_frees[w])) != hipSuccess)
+            (e = up(rp.frees.data(), rp.frees.size() * sizeof(RneaFree), (void **)&t.rchain_frees[w])) != hipSuccess ||
+            (e = up(rp.diffs.data(), rp.diffs.size() * sizeof(RneaDiff), (void **)&t.rchain_diffs[w])) != hipSuccess)
             return hip_err(e, "plan upload");
         if ((e = set_max_dynamic_lds_chain()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
@@ -205,7 +208,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         if ((e = up(cp.segs.data(), cp.segs.size() * sizeof(ChainSeg), (void **)&t.chain_segs[w])) != hipSuccess ||
             (e = up(cp.links.data(), cp.links.size() * sizeof(ChainLink), (void **)&t.chain_links[w])) != hipSuccess ||
             (e = up(cp.pairs.data(), cp.pairs.size() * sizeof(ChainPair), (void **)&t.chain_pairs[w])) != hipSuccess ||
-            (e = up(cp.frees.data(), cp.frees.size() * sizeof(ChainFree), (void **)&t.chain_frees[w])) != hipSuccess)
+            (e = up(cp.frees.data(), cp.frees.size() * sizeof(ChainFree), (void **)&t.chain_frees[w])) != hipSuccess ||
+            (e = up(cp.diffs.data(), cp.diffs.size() * sizeof(ChainDiff), (void **)&t.chain_diffs[w])) != hipSuccess)
             return hip_err(e, "plan upload");
         if ((e = set_max_dynamic_lds_chain()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
@@ -293,6 +297,8 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     d.links = t.chain_links[w];
     d.pairs = t.chain_pairs[w];
     d.frees = t.chain_frees[w];
+    d.diffs = t.chain_diffs[w];
+    d.cints = t.cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.n_segs = static_cast<int>(cp.segs.size());
     d.nq = h.nq;
@@ -337,6 +343,8 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     d.links = t.rchain_links[w];
     d.pairs = t.rchain_pairs[w];
     d.frees = t.rchain_frees[w];
+    d.diffs = t.rchain_diffs[w];
+    d.cints = t.cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.n_segs = static_cast<int>(rp.segs.size());
     d.nq = h.nq;
@@ -713,6 +721,7 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     const HostPlan &h = p->host;
     const ChainProgram &cp = sizeof(T) == 8 ? h.chain64 : h.chain32;
     if (p->no_chain || p->no_efpa || !cp.ok || n_contacts > kOsimMaxContacts) return 1;
+    if (!cp.diffs.empty()) return 1;  // differential clusters: no force-propagation walk yet, the unit-wrench route serves them
     const Layout &L = h.lay64;
     OsimArgs<T> A;
     std::memset(&A, 0, sizeof A);
@@ -807,6 +816,8 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.links = t->chain_links[w];
     d.pairs = t->chain_pairs[w];
     d.frees = t->chain_frees[w];
+    d.diffs = t->chain_diffs[w];
+    d.cints = t->cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t->consts32) : reinterpret_cast<const T *>(t->consts64);
     d.n_segs = static_cast<int>(cp.segs.size());
     d.nq = h.nq;
@@ -1266,8 +1277,8 @@ void grbda_plan_free(grbda_plan *p)
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies);
-        for (int w = 0; w < 2; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); }
-        for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); }
+        for (int w = 0; w < 2; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
+        for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work, &p->work_cvt})

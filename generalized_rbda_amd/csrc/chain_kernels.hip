@@ -30,6 +30,8 @@ struct ChainTables {
     cptr<ChainLink> links;
     cptr<ChainPair> pairs;
     cptr<ChainFree> frees;
+    cptr<ChainDiff> diffs;
+    cptr<int32_t> cints;
     cptr<T> consts;
     int n_segs, nq, nv, ori_repr;
     T a_root[6];
@@ -335,6 +337,390 @@ __device__ __forceinline__ void pair_acc(const ChainTables<T> &P, const ChainMem
     }
     M.put(pr.v_index, y0);
     M.put(pr.v_index + 1, y1);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two-rotor differential cluster (plan.h, ChainDiff): the implicit clusters of Tello (src/Robots/Tello.cpp:77-261,
+// GenericImplicit constraints; GenericJoint.cpp:380-450 for how G and g enter the recursions).
+//
+// Constraint: phi_r(q) = sum_t coef_t prod_f F_f(w_f . q + b_f), F in {sin, cos, id}; the reference differentiates its
+// phi lambdas with CasADi, here K = dphi/dq and Kdot qd come from the polynomial itself.  The plan compiler
+// (plan.cpp, emit_diff_program) lists the distinct arguments a = w . q + b and the distinct ATOMS F(a) the terms are
+// products of, and sorts the terms of every row by their number of factors, so that the loops below carry no
+// per-factor branches:
+//   pass A   per argument: a, sin a, cos a; per atom the pair (F, F') into the work space W[3 atom + {0, 1}]
+//   pass K   per term: dterm/da_f = coef F'_f prod_{g != f} F_g, K[r][:] += that * w_f        (reverse mode)
+//   X = -Kd^-1 Ki (columns: rotors independent, links dependent), link rates X yd
+//   pass A'  per atom: ad = w . qd_span; W <- second-order Taylor coefficients (F, F' ad, F'' ad^2 / 2) along qd_span
+//   pass B   per term: t^2 coefficient of the product of its atoms' series; Kdot qd = 2 * sum   (forward mode: with
+//            q(t) = q + qd t, phi'' = Kdot qd), g = -Kd^-1 Kdot qd
+// ---------------------------------------------------------------------------------------------------------------
+template <class T, class TB>
+__device__ __forceinline__ void diff_constraint(const TB &P, const ChainMem<T> &M, int tofs_i, int lds_w, const T (&qs)[4], T yd0,
+                                                T yd1, T (&X)[4], T (&g)[2], T (&qdl)[2])
+{
+    cptr<int32_t> ip = P.cints + tofs_i;
+    const int n_args = ip[0], n_atoms = ip[1];
+    cptr<T> dp = P.consts + ip[2];
+    for (int i = 0; i < n_args; i++) {
+        cptr<T> w = dp + 5 * i;
+        const T a = w[4] + w[0] * qs[0] + w[1] * qs[1] + w[2] * qs[2] + w[3] * qs[3];
+        const int as = ip[4 + 3 * i], ac = ip[5 + 3 * i], al = ip[6 + 3 * i];
+        if (as >= 0 || ac >= 0) {
+            T sn, cs;
+            sincos_t(a, &sn, &cs);
+            if (as >= 0) {
+                const T v[2] = {sn, cs};
+                M.lds_st(lds_w + as, v);
+            }
+            if (ac >= 0) {
+                const T v[2] = {cs, -sn};
+                M.lds_st(lds_w + ac, v);
+            }
+        }
+        if (al >= 0) {
+            const T v[2] = {a, T(1)};
+            M.lds_st(lds_w + al, v);
+        }
+    }
+    cptr<int32_t> tp = ip + 4 + 3 * n_args;
+    cptr<T> kp = dp + 5 * (n_args + n_atoms);
+    T K[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        T k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        const int n1 = tp[0], n2 = tp[1], n3 = tp[2];
+        tp += 3;
+        for (int t = 0; t < n1; t++) {
+            T f[2];
+            M.lds_ld(lds_w + tp[0], f);
+            const T g0 = kp[0] * f[1];
+            k0 += g0 * kp[1]; k1 += g0 * kp[2]; k2 += g0 * kp[3]; k3 += g0 * kp[4];
+            tp += 1;
+            kp += 5;
+        }
+        for (int t = 0; t < n2; t++) {
+            T f[2], h[2];
+            M.lds_ld(lds_w + tp[0], f);
+            M.lds_ld(lds_w + tp[1], h);
+            const T c = kp[0];
+            const T g0 = c * f[1] * h[0], g1 = c * f[0] * h[1];
+            k0 += g0 * kp[1] + g1 * kp[5]; k1 += g0 * kp[2] + g1 * kp[6];
+            k2 += g0 * kp[3] + g1 * kp[7]; k3 += g0 * kp[4] + g1 * kp[8];
+            tp += 2;
+            kp += 9;
+        }
+        for (int t = 0; t < n3; t++) {
+            T f[2], h[2], m[2];
+            M.lds_ld(lds_w + tp[0], f);
+            M.lds_ld(lds_w + tp[1], h);
+            M.lds_ld(lds_w + tp[2], m);
+            const T c = kp[0];
+            const T g0 = c * f[1] * h[0] * m[0], g1 = c * f[0] * h[1] * m[0], g2 = c * f[0] * h[0] * m[1];
+            k0 += g0 * kp[1] + g1 * kp[5] + g2 * kp[9]; k1 += g0 * kp[2] + g1 * kp[6] + g2 * kp[10];
+            k2 += g0 * kp[3] + g1 * kp[7] + g2 * kp[11]; k3 += g0 * kp[4] + g1 * kp[8] + g2 * kp[12];
+            tp += 3;
+            kp += 13;
+        }
+        K[r][0] = k0; K[r][1] = k1; K[r][2] = k2; K[r][3] = k3;
+    }
+    // Kd = K[:, links], Ki = K[:, rotors]
+    const T idet = rcp_t(K[0][2] * K[1][3] - K[0][3] * K[1][2]);
+    const T i00 = K[1][3] * idet, i01 = -K[0][3] * idet, i10 = -K[1][2] * idet, i11 = K[0][2] * idet;
+    X[0] = -(i00 * K[0][0] + i01 * K[1][0]);
+    X[1] = -(i00 * K[0][1] + i01 * K[1][1]);
+    X[2] = -(i10 * K[0][0] + i11 * K[1][0]);
+    X[3] = -(i10 * K[0][1] + i11 * K[1][1]);
+    qdl[0] = X[0] * yd0 + X[1] * yd1;
+    qdl[1] = X[2] * yd0 + X[3] * yd1;
+    cptr<T> ap = dp + 5 * n_args;
+    for (int at = 0; at < n_atoms; at++) {
+        cptr<T> w = ap + 5 * at;
+        const T ad = w[0] * yd0 + w[1] * yd1 + w[2] * qdl[0] + w[3] * qdl[1];
+        T f[2];
+        M.lds_ld(lds_w + 3 * at, f);
+        const T t12[2] = {f[1] * ad, w[4] * f[0] * ad * ad};
+        M.lds_st(lds_w + 3 * at + 1, t12);
+    }
+    tp = ip + 4 + 3 * n_args;
+    T kd[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        T acc = 0;
+        const int n1 = tp[0], n2 = tp[1], n3 = tp[2];
+        tp += 3;
+        for (int t = 0; t < n1; t++) {
+            T f[3];
+            M.lds_ld(lds_w + tp[0], f);
+            acc += kp[0] * f[2];
+            tp += 1;
+            kp += 1;
+        }
+        for (int t = 0; t < n2; t++) {
+            T f[3], h[3];
+            M.lds_ld(lds_w + tp[0], f);
+            M.lds_ld(lds_w + tp[1], h);
+            acc += kp[0] * (f[0] * h[2] + f[1] * h[1] + f[2] * h[0]);
+            tp += 2;
+            kp += 1;
+        }
+        for (int t = 0; t < n3; t++) {
+            T f[3], h[3], m[3];
+            M.lds_ld(lds_w + tp[0], f);
+            M.lds_ld(lds_w + tp[1], h);
+            M.lds_ld(lds_w + tp[2], m);
+            const T p0 = f[0] * h[0], p1 = f[0] * h[1] + f[1] * h[0], p2 = f[0] * h[2] + f[1] * h[1] + f[2] * h[0];
+            acc += kp[0] * (p0 * m[2] + p1 * m[1] + p2 * m[0]);
+            tp += 3;
+            kp += 1;
+        }
+        kd[r] = acc + acc;
+    }
+    g[0] = -(i00 * kd[0] + i01 * kd[1]);
+    g[1] = -(i10 * kd[0] + i11 * kd[1]);
+}
+
+// kinematics of the two links of a differential from the parent velocity: E, v, chat = v x z qd + z g
+template <class T>
+__device__ __forceinline__ void diff_links(cptr<T> C1, cptr<T> C2, const T (&sc)[4], const T (&vp)[6], T qd1, T qd2, T (&E1)[9],
+                                           T (&E2)[9], T (&v1)[6], T (&v2)[6])
+{
+    rotate_z(sc[0], sc[1], C1, E1);
+    xmotion(E1, C1 + 9, vp, v1);
+    v1[2] += qd1;
+    rotate_z(sc[2], sc[3], C2, E2);
+    xmotion(E2, C2 + 9, v1, v2);
+    v2[2] += qd2;
+}
+
+template <class T>
+__device__ __forceinline__ void diff_fwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainDiff &d)
+{
+    T qs[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) qs[i] = M.q(d.q_index + d.qpos[i]);
+    const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
+    T gx[10], qdl[2];
+    {
+        T X[4], g[2];
+        diff_constraint(P, M, d.tofs_i, d.lds_w, qs, yd0, yd1, X, g, qdl);
+#pragma unroll
+        for (int j = 0; j < 4; j++) gx[j] = X[j];
+        gx[4] = g[0];
+        gx[5] = g[1];
+    }
+    sincos_t(qs[2], &gx[6], &gx[7]);
+    sincos_t(qs[3], &gx[8], &gx[9]);
+    M.glb_st(d.glb_k + 14, gx);
+    if (d.lds_sv != -1) {
+        cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
+        T vp[6], E1[9], E2[9], v1[6], blk[8];
+        M.acc_ld(d.lds_pv, vp);
+        const T sc[4] = {gx[6], gx[7], gx[8], gx[9]};
+        T v2[6];
+        diff_links(C1, C2, sc, vp, qdl[0], qdl[1], E1, E2, v1, v2);
+        blk[0] = gx[8];
+        blk[1] = gx[9];
+#pragma unroll
+        for (int j = 0; j < 6; j++) blk[2 + j] = v2[j];
+        M.acc_st(d.lds_sv, blk);
+    }
+}
+
+// backward segment: pair_bwd with per-state G rows -- rotors (1, 0), (0, 1); links (X00, X01), (X10, X11) -- the bias
+// accelerations g of the links, and child segments on link2.
+template <class T>
+__device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainDiff &d)
+{
+    cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
+    T vp[6], gx[10];
+    M.acc_ld(d.lds_pv, vp);
+    M.glb_ld(d.glb_k + 14, gx);
+    const T X00 = gx[0], X01 = gx[1], X10 = gx[2], X11 = gx[3];
+    const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
+    T u0 = M.x(d.v_index), u1 = M.x(d.v_index + 1);
+    const T qd1 = X00 * yd0 + X01 * yd1, qd2 = X10 * yd0 + X11 * yd1;
+    T E1[9], E2[9], v1[6], v2[6], ch1[6], ch2[6], ccl2[6];
+    {
+        const T sc[4] = {gx[6], gx[7], gx[8], gx[9]};
+        diff_links(C1, C2, sc, vp, qd1, qd2, E1, E2, v1, v2);
+    }
+    vxz(v1, qd1, ch1);
+    ch1[2] += gx[4];
+    vxz(v2, qd2, ch2);
+    ch2[2] += gx[5];
+    xmotion(E2, C2 + 9, ch1, ccl2);
+#pragma unroll
+    for (int j = 0; j < 6; j++) ccl2[j] += ch2[j];
+    T D00 = 0, D01 = 0, D11 = 0, F0[6], F1[6], IA[21], psi[6];
+    T IA1[21], psi1[6];
+    {   // ---- link2 ----
+        cptr<T> Ib = P.consts + d.iofs;
+        T IA2[21], p2[6], h2[6];
+        bias_force(C2 + 12, v2, p2);
+        if (d.lds_acc != -1) {
+            T acc[27];
+            M.acc_ld(d.lds_acc, acc);
+#pragma unroll
+            for (int j = 0; j < 21; j++) IA2[j] = Ib[j] + acc[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) p2[j] += acc[21 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 21; j++) IA2[j] = Ib[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) h2[i] = IA2[sidx(i, 2)];
+        T bj = p2[2];
+#pragma unroll
+        for (int j = 0; j < 6; j++) bj += h2[j] * ccl2[j];
+        u0 -= X10 * bj;
+        u1 -= X11 * bj;
+        D00 += h2[2] * X10 * X10;
+        D01 += h2[2] * X10 * X11;
+        D11 += h2[2] * X11 * X11;
+        T t[6];
+        symv(IA2, ch2, t);
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] += p2[j];
+        xforce_inv(E2, C2 + 9, t, psi1);
+        congruence(E2, C2 + 9, IA2, IA1);
+        T f[6], Fc[6];
+        xforce_inv(E2, C2 + 9, h2, f);
+        const T Hc = f[2];  // D += Hc (G1^T G2 + G2^T G1)
+        D00 += 2 * Hc * X00 * X10;
+        D01 += Hc * (X00 * X11 + X01 * X10);
+        D11 += 2 * Hc * X01 * X11;
+        xforce_inv(E1, C1 + 9, f, Fc);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            F0[j] = Fc[j] * X10;
+            F1[j] = Fc[j] * X11;
+        }
+    }
+    {   // ---- link1 ----
+        cptr<T> I1 = C1 + 12;
+        T p1[6], h1[6];
+        bias_force(I1, v1, p1);
+#pragma unroll
+        for (int j = 0; j < 21; j++) IA1[j] += I1[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) psi1[j] += p1[j];
+#pragma unroll
+        for (int i = 0; i < 6; i++) h1[i] = IA1[sidx(i, 2)];
+        T bj = psi1[2];
+#pragma unroll
+        for (int j = 0; j < 6; j++) bj += h1[j] * ch1[j];
+        u0 -= X00 * bj;
+        u1 -= X01 * bj;
+        D00 += h1[2] * X00 * X00;
+        D01 += h1[2] * X00 * X01;
+        D11 += h1[2] * X01 * X01;
+        T t[6], Fc[6];
+        symv(IA1, ch1, t);
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] += psi1[j];
+        xforce_inv(E1, C1 + 9, t, psi);
+        congruence(E1, C1 + 9, IA1, IA);
+        xforce_inv(E1, C1 + 9, h1, Fc);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            F0[j] += Fc[j] * X00;
+            F1[j] += Fc[j] * X01;
+        }
+    }
+    {   // ---- rotors (q = 0), G rows (1, 0) and (0, 1) ----
+        T bj, tp[6];
+        cptr<T> R0 = P.consts + d.rpre[0], R1 = P.consts + d.rpre[1];
+        rotor_terms(P.consts + d.cofs[2], vp, yd0, bj, tp);
+        u0 -= bj;
+        D00 += R0[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            F0[j] += R0[j];
+            psi[j] += tp[j];
+        }
+        rotor_terms(P.consts + d.cofs[3], vp, yd1, bj, tp);
+        u1 -= bj;
+        D11 += R1[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            F1[j] += R1[j];
+            psi[j] += tp[j];
+        }
+    }
+    const T idet = rcp_t(D00 * D11 - D01 * D01);
+    const T i00 = D11 * idet, i01 = -D01 * idet, i11 = D00 * idet;
+    T blk[14];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        blk[j] = i00 * F0[j] + i01 * F1[j];
+        blk[6 + j] = i01 * F0[j] + i11 * F1[j];
+    }
+    blk[12] = i00 * u0 + i01 * u1;
+    blk[13] = i01 * u0 + i11 * u1;
+    M.glb_st(d.glb_k, blk);
+    T acc[27];
+    if (!d.acc_first) M.acc_ld(d.lds_acc_out, acc);
+    else {
+#pragma unroll
+        for (int j = 0; j < 27; j++) acc[j] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        acc[21 + r] += psi[r] + F0[r] * blk[12] + F1[r] * blk[13];
+#pragma unroll
+        for (int cc = r; cc < 6; cc++) acc[sidx(r, cc)] += IA[sidx(r, cc)] - (F0[r] * blk[cc] + F1[r] * blk[6 + cc]);
+    }
+    M.acc_st(d.lds_acc_out, acc);
+}
+
+template <class T>
+__device__ __forceinline__ void diff_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainDiff &d)
+{
+    T blk[24], va[12], vp[6], ap[6];
+    M.glb_ld(d.glb_k, blk);
+    M.lds_ld(d.lds_pva, va);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        vp[j] = va[j];
+        ap[j] = va[6 + j];
+    }
+    T ydd0 = blk[12], ydd1 = blk[13];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        ydd0 -= blk[j] * ap[j];
+        ydd1 -= blk[6 + j] * ap[j];
+    }
+    M.put(d.v_index, ydd0);
+    M.put(d.v_index + 1, ydd1);
+    if (d.lds_va >= 0) {
+        cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
+        const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
+        const T qd1 = blk[14] * yd0 + blk[15] * yd1, qd2 = blk[16] * yd0 + blk[17] * yd1;
+        const T qdd1 = blk[14] * ydd0 + blk[15] * ydd1 + blk[18], qdd2 = blk[16] * ydd0 + blk[17] * ydd1 + blk[19];
+        T E1[9], E2[9], v1[6], v2[6], a1[6], a2[6], c[6];
+        const T sc[4] = {blk[20], blk[21], blk[22], blk[23]};
+        diff_links(C1, C2, sc, vp, qd1, qd2, E1, E2, v1, v2);
+        xmotion(E1, C1 + 9, ap, a1);
+        vxz(v1, qd1, c);
+#pragma unroll
+        for (int j = 0; j < 6; j++) a1[j] += c[j];
+        a1[2] += qdd1;
+        xmotion(E2, C2 + 9, a1, a2);
+        vxz(v2, qd2, c);
+#pragma unroll
+        for (int j = 0; j < 6; j++) a2[j] += c[j];
+        a2[2] += qdd2;
+        T out[12];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            out[j] = v2[j];
+            out[6 + j] = a2[j];
+        }
+        M.lds_st(d.lds_va, out);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -700,6 +1086,8 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     P.links = (cptr<ChainLink>)DP.links;
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
+    P.diffs = (cptr<ChainDiff>)DP.diffs;
+    P.cints = (cptr<int32_t>)DP.cints;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -741,6 +1129,9 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                 case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
                 case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
                 case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_DIFF_FWD: diff_fwd(P, M, load_rec(P.diffs + sg.first)); break;
+                case SEG_DIFF_BWD: diff_bwd(P, M, load_rec(P.diffs + sg.first)); break;
+                case SEG_DIFF_ACC: diff_acc(P, M, load_rec(P.diffs + sg.first)); break;
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
@@ -783,6 +1174,8 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     P.links = (cptr<ChainLink>)DP.links;
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
+    P.diffs = (cptr<ChainDiff>)DP.diffs;
+    P.cints = (cptr<int32_t>)DP.cints;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -1008,6 +1401,8 @@ struct RneaTables {
     cptr<RneaLink> links;
     cptr<RneaPair> pairs;
     cptr<RneaFree> frees;
+    cptr<RneaDiff> diffs;
+    cptr<int32_t> cints;
     cptr<T> consts;
     int n_segs, nq, nv, ori_repr;
     T a_root[6];
@@ -1237,6 +1632,96 @@ __device__ __forceinline__ void rnea_pair(const RneaTables<T> &P, const ChainMem
     lds_add6(M, pr.lds_pf, fp);
 }
 
+
+// two-rotor differential cluster (plan.h, RneaDiff; see diff_constraint): forward segment -- G and g from the constraint,
+// v, a and the body forces of the two links, the rotors' torques and their forces on the parent body; backward segment
+// (after the child segments have added their forces to link2's) -- tau = G^T (S^T f) and the links' force to the parent.
+template <class T>
+__device__ __forceinline__ void rnea_diff_fwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaDiff &d)
+{
+    cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
+    T qs[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) qs[i] = M.q(d.q_index + d.qpos[i]);
+    const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
+    const T ydd0 = M.x(d.v_index), ydd1 = M.x(d.v_index + 1);
+    T X[4], g[2], qdl[2];
+    diff_constraint(P, M, d.tofs_i, d.lds_w, qs, yd0, yd1, X, g, qdl);
+    const T qdd1 = X[0] * ydd0 + X[1] * ydd1 + g[0], qdd2 = X[2] * ydd0 + X[3] * ydd1 + g[1];
+    T va[12], vp[6], ap[6];
+    M.lds_ld(d.lds_pva, va);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        vp[j] = va[j];
+        ap[j] = va[6 + j];
+    }
+    T sc[4], E1[9], E2[9], v1[6], v2[6], a1[6], a2[6], c[6];
+    sincos_t(qs[2], &sc[0], &sc[1]);
+    sincos_t(qs[3], &sc[2], &sc[3]);
+    diff_links(C1, C2, sc, vp, qdl[0], qdl[1], E1, E2, v1, v2);
+    xmotion(E1, C1 + 9, ap, a1);
+    vxz(v1, qdl[0], c);
+#pragma unroll
+    for (int j = 0; j < 6; j++) a1[j] += c[j];
+    a1[2] += qdd1;
+    xmotion(E2, C2 + 9, a1, a2);
+    vxz(v2, qdl[1], c);
+#pragma unroll
+    for (int j = 0; j < 6; j++) a2[j] += c[j];
+    a2[2] += qdd2;
+    T f1[6], f2[6], blk[14];
+    body_force_c(C1 + 12, v1, a1, f1);
+    body_force_c(C2 + 12, v2, a2, f2);
+    // what does not wait for the child segments goes out now: link1's own force and the rotors' to the parent body,
+    // their share of tau to the result rows (the backward segment adds link2's)
+    T tz0, tz1, fp[6], fp0[6], fp1[6];
+    rotor_rnea(P.consts + d.cofs[2], vp, ap, yd0, ydd0, tz0, fp0);
+    rotor_rnea(P.consts + d.cofs[3], vp, ap, yd1, ydd1, tz1, fp1);
+    xforce_inv(E1, C1 + 9, f1, fp);
+#pragma unroll
+    for (int j = 0; j < 6; j++) fp[j] += fp0[j] + fp1[j];
+    lds_add6(M, d.lds_pf, fp);
+    M.put(d.v_index, tz0 + X[0] * f1[2]);
+    M.put(d.v_index + 1, tz1 + X[1] * f1[2]);
+#pragma unroll
+    for (int j = 0; j < 6; j++) blk[j] = f2[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        blk[6 + j] = sc[j];
+        blk[10 + j] = X[j];
+    }
+    M.lds_st(d.lds_blk, blk);
+    if (d.lds_va >= 0) {
+        T out[12];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            out[j] = v2[j];
+            out[6 + j] = a2[j];
+        }
+        M.lds_st(d.lds_va, out);
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void rnea_diff_bwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaDiff &d)
+{
+    cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
+    T blk[14], f2[6], f21[6], fp[6], E1[9], E2[9];
+    M.lds_ld(d.lds_blk, blk);
+#pragma unroll
+    for (int j = 0; j < 6; j++) f2[j] = blk[j];
+    rotate_z(blk[6], blk[7], C1, E1);
+    rotate_z(blk[8], blk[9], C2, E2);
+    const T tl2 = f2[2];
+    xforce_inv(E2, C2 + 9, f2, f21);
+    const T tl1 = f21[2];
+    xforce_inv(E1, C1 + 9, f21, fp);
+    lds_add6(M, d.lds_pf, fp);
+    // (the result rows are the tile's third input block: M.x reads what the forward segment put there)
+    M.put(d.v_index, M.x(d.v_index) + blk[10] * tl1 + blk[12] * tl2);
+    M.put(d.v_index + 1, M.x(d.v_index + 1) + blk[11] * tl1 + blk[13] * tl2);
+}
+
 template <class T>
 __device__ __forceinline__ void rnea_free_fwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaFree &f)
 {
@@ -1287,6 +1772,8 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     P.links = (cptr<RneaLink>)DP.links;
     P.pairs = (cptr<RneaPair>)DP.pairs;
     P.frees = (cptr<RneaFree>)DP.frees;
+    P.diffs = (cptr<RneaDiff>)DP.diffs;
+    P.cints = (cptr<int32_t>)DP.cints;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -1315,6 +1802,8 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
                 case RSEG_RUN_BWD: rnea_run_bwd(P, M, sg); break;
                 case RSEG_PAIR: rnea_pair(P, M, load_rec(P.pairs + sg.first)); break;
                 case RSEG_FREE_FWD: rnea_free_fwd(P, M, load_rec(P.frees + sg.first)); break;
+                case RSEG_DIFF_FWD: rnea_diff_fwd(P, M, load_rec(P.diffs + sg.first)); break;
+                case RSEG_DIFF_BWD: rnea_diff_bwd(P, M, load_rec(P.diffs + sg.first)); break;
                 default: rnea_free_bwd(P, M, load_rec(P.frees + sg.first)); break;
             }
         }

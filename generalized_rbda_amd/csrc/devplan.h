@@ -50,6 +50,8 @@ struct ChainDev {
     const ChainLink *links;
     const ChainPair *pairs;
     const ChainFree *frees;
+    const ChainDiff *diffs;
+    const int32_t *cints;
     const T *consts;
     int n_segs;
     int nq, nv;
@@ -71,6 +73,8 @@ struct RneaChainDev {
     const RneaLink *links;
     const RneaPair *pairs;
     const RneaFree *frees;
+    const RneaDiff *diffs;
+    const int32_t *cints;
     const T *consts;
     int n_segs;
     int nq, nv;

@@ -597,13 +597,18 @@ __device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const SL &
     cptr<int32_t> dep = ip + 3 + n_ind;
     cptr<int32_t> payload = dep + rows;
     T kdq[3] = {0, 0, 0};
+#ifdef GRBDA_EXP_NO_CONSTRAINT
+    return;
+#endif
 
     for (int i = 0; i < k; i++) S.st1(lay.qs + i, L.q(c.q_index + i));
     for (int i = 0; i < rows * k; i++) S.st1(lay.K + i, T(0));
 
     // ---- K(q) ------------------------------------------------------------------------------------
     if (c.cons_type == 0) loop_position_K<T, N>(P, S, c, lay, payload, hdr0);
+#ifndef GRBDA_EXP_NO_TRIG
     else trig_poly_eval<T, N>(P, S, c, lay, payload, true, kdq);
+#endif
 
     // ---- G = P [1; -Kd^-1 Ki] ------------------------------------------------------------------
     T Kd[3][3], Kdi[3][3], X[3][N];
@@ -651,7 +656,9 @@ __device__ __noinline__ void eval_loop_constraint(const Tables<T> &P, const SL &
 
     // ---- k = -Kdot qd ; g = P [0; Kd^-1 k] ----------------------------------------------------------
     if (c.cons_type == 0) loop_position_Kdqd<T, N>(P, S, c, lay, payload, hdr0, kdq);
+#ifndef GRBDA_EXP_NO_TRIG
     else trig_poly_eval<T, N>(P, S, c, lay, payload, false, kdq);
+#endif
 #pragma unroll
     for (int r = 0; r < 3; r++)
         if (r < rows) S.st1(lay.G + dep[r] * (N + 1) + N, -(Kdi[r][0] * kdq[0] + Kdi[r][1] * kdq[1] + Kdi[r][2] * kdq[2]));

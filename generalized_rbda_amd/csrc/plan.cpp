@@ -269,7 +269,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         for (int b = 0; b < nb; b++) {
             const grbda_desc_body &bd = m.bodies[b];
             if (bodies[b].has_child || bd.joint_type != GRBDA_JOINT_REVOLUTE || bd.parent < 0) continue;
-            if (clusters[bd.cluster].kind == CK_LOOP) continue;
+            // (URDF+ position-loop clusters keep their bodies as they are: the loop origins are points of the link frames)
+            if (clusters[bd.cluster].kind == CK_LOOP && clusters[bd.cluster].cons_type == 0) continue;
             bool inv = true;
             double scale = 0;
             for (int i = 0; i < 36; i++) scale = std::max(scale, std::fabs(bd.inertia[i]));
@@ -516,14 +517,25 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         int *field;  // where the slot number goes (index into a flat array of fields)
         int size, prio, birth, death, slot;
         int force = 0;  // split layouts: 1 must live in LDS, 2 must live in the global slab
+        int tag = 0;    // chain programs: 1 = work space that never leaves LDS whatever its size
     };
     // returns false when an object that must live in LDS does not fit the budget
-    auto allocate = [](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb) -> bool {
+    // mode 0: placement order (priority, birth); 1: longest-lived first; 2: largest first (allocate_packed below)
+    auto allocate = [](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb, int mode = 0) -> bool {
         bool ok = true;
         const int lds_base = 0;
         std::vector<int> order(objs.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = static_cast<int>(i);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (mode == 1) {
+                const int la = objs[a].death - objs[a].birth, lb = objs[b].death - objs[b].birth;
+                if (la != lb) return la > lb;
+                return objs[a].size > objs[b].size;
+            }
+            if (mode == 2) {
+                if (objs[a].size != objs[b].size) return objs[a].size > objs[b].size;
+                return objs[a].birth < objs[b].birth;
+            }
             if (objs[a].prio != objs[b].prio) return objs[a].prio < objs[b].prio;
             return objs[a].birth < objs[b].birth;
         });
@@ -564,6 +576,15 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             *o.field = o.slot;
         }
         return ok;
+    };
+
+    // first-fit placement fragments: when the default order does not fit the objects that must live in LDS, try the others
+    auto allocate_packed = [&](std::vector<Obj> &objs, int lds_budget, int &n_lds, int &n_glb) -> bool {
+        for (int mode = 0; mode < 3; mode++) {
+            for (Obj &o : objs) o.slot = -1;
+            if (allocate(objs, lds_budget, n_lds, n_glb, mode)) return true;
+        }
+        return false;
     };
 
     auto cluster_of = [&](int b) { return m.bodies[b].cluster; };
@@ -792,11 +813,115 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         P.consts.push_back(h[2]);
         return rotor_pre[b];
     };
+    // ---- two-rotor differential clusters (plan.h, ChainDiff): shape test and constraint program -----------------------
+    // ints   [n_args, n_atoms, tofs_d, 0] [per argument: W offset of its sin, cos, id atom or -1]
+    //        per row: [n1, n2, n3] then the atoms' W offsets of the 1-, 2- and 3-factor terms
+    // consts [per argument: w[4], b] [per atom: w[4], kappa (-1/2 for sin / cos, 0 for id)]
+    //        K stream: per row, per term: coef, w[4] of every factor;  B stream: per row, per term: coef
+    // (w in the kernel's coordinate order rotor1, rotor2, link1, link2)
+    struct DiffShape { bool ok = false; int l1 = -1, l2 = -1, r[2] = {-1, -1}; int tofs_i = -1, n_atoms = 0; };
+    std::vector<DiffShape> diff_shape(nc);
+    for (int c = 0; c < nc; c++) {
+        const ClusterRec &cr = clusters[c];
+        const grbda_desc_cluster &cl = m.clusters[c];
+        if (cr.kind != CK_LOOP || cr.cons_type != 1 || cr.n != 2 || cr.k != 4 || cr.rows != 2 || cr.parent_body < 0) continue;
+        DiffShape ds;
+        int nr = 0;
+        for (int i = 0; i < 4; i++) {
+            const int gb = cr.first_body + i;
+            const BodyRec &br = bodies[gb];
+            if (br.axisym && !br.has_child && br.parent == cr.parent_body) { if (nr < 2) ds.r[nr] = gb; nr++; }
+            else if (br.parent == cr.parent_body && br.lam < 0) ds.l1 = ds.l1 < 0 ? gb : -2;
+            else if (br.lam >= 0) ds.l2 = ds.l2 < 0 ? gb : -2;
+        }
+        bool good = nr == 2 && ds.l1 >= 0 && ds.l2 >= 0 && bodies[ds.l2].lam == ds.l1 && !bodies[ds.l1].axisym && !bodies[ds.l2].axisym;
+        if (good)
+            for (int j = 0; j < nb; j++)
+                if (bodies[j].parent == ds.l1 && j != ds.l2) good = false;
+        const int32_t *ip = m.ints + cl.int_offset;
+        const double *dp = m.dbls + cl.dbl_offset;
+        // the rotors carry the independent coordinates
+        if (good) good = ip[ds.r[0] - cr.first_body] && ip[ds.r[1] - cr.first_body] && !ip[ds.l1 - cr.first_body] && !ip[ds.l2 - cr.first_body];
+        if (!good) continue;
+        const int order[4] = {ds.r[0] - cr.first_body, ds.r[1] - cr.first_body, ds.l1 - cr.first_body, ds.l2 - cr.first_body};
+        struct Term { double coef; std::vector<int> atoms; };
+        std::vector<std::array<double, 5>> args;
+        std::vector<std::pair<int, int>> atoms;  // (argument, type 0 id / 1 sin / 2 cos)
+        std::vector<Term> rows[2];
+        const int32_t *tp = ip + 4;
+        int nd = 0;
+        for (int r = 0; r < 2 && good; r++) {
+            const int nt = *tp++;
+            for (int t = 0; t < nt && good; t++) {
+                const int nf = *tp++;
+                Term term;
+                term.coef = dp[nd++];
+                if (nf > 3) good = false;
+                for (int f = 0; f < nf; f++) {
+                    std::array<double, 5> a;
+                    for (int j = 0; j < 4; j++) a[j] = dp[nd + order[j]];
+                    a[4] = dp[nd + 4];
+                    nd += 5;
+                    const int type = *tp++;
+                    if (type < 0 || type > 2) good = false;
+                    int ai = -1;
+                    for (size_t i = 0; i < args.size(); i++)
+                        if (args[i] == a) ai = static_cast<int>(i);
+                    if (ai < 0) { ai = static_cast<int>(args.size()); args.push_back(a); }
+                    int at = -1;
+                    for (size_t i = 0; i < atoms.size(); i++)
+                        if (atoms[i] == std::make_pair(ai, type)) at = static_cast<int>(i);
+                    if (at < 0) { at = static_cast<int>(atoms.size()); atoms.push_back({ai, type}); }
+                    term.atoms.push_back(at);
+                }
+                if (nf > 0) rows[r].push_back(term);  // constants differentiate to nothing
+            }
+        }
+        if (!good) continue;
+        ds.ok = true;
+        ds.n_atoms = static_cast<int>(atoms.size());
+        ds.tofs_i = static_cast<int>(P.cints.size());
+        const int tofs_d = static_cast<int>(P.consts.size());
+        P.cints.push_back(static_cast<int>(args.size()));
+        P.cints.push_back(ds.n_atoms);
+        P.cints.push_back(tofs_d);
+        P.cints.push_back(0);
+        for (size_t i = 0; i < args.size(); i++) {
+            int slot[3] = {-1, -1, -1};  // sin, cos, id
+            for (size_t a = 0; a < atoms.size(); a++)
+                if (atoms[a].first == static_cast<int>(i)) slot[atoms[a].second == 1 ? 0 : (atoms[a].second == 2 ? 1 : 2)] = 3 * static_cast<int>(a);
+            for (int j = 0; j < 3; j++) P.cints.push_back(slot[j]);
+            for (int j = 0; j < 5; j++) P.consts.push_back(args[i][j]);
+        }
+        for (const auto &a : atoms) {
+            for (int j = 0; j < 4; j++) P.consts.push_back(args[a.first][j]);
+            P.consts.push_back(a.second == 0 ? 0.0 : -0.5);
+        }
+        std::vector<double> bstream;
+        for (int r = 0; r < 2; r++) {
+            int cnt[4] = {0, 0, 0, 0};
+            for (const Term &t : rows[r]) cnt[t.atoms.size()]++;
+            for (int nf = 1; nf <= 3; nf++) P.cints.push_back(cnt[nf]);
+            for (size_t nf = 1; nf <= 3; nf++)
+                for (const Term &t : rows[r]) {
+                    if (t.atoms.size() != nf) continue;
+                    P.consts.push_back(t.coef);
+                    bstream.push_back(t.coef);
+                    for (int at : t.atoms) {
+                        P.cints.push_back(3 * at);
+                        for (int j = 0; j < 4; j++) P.consts.push_back(args[atoms[at].first][j]);
+                    }
+                }
+        }
+        P.consts.insert(P.consts.end(), bstream.begin(), bstream.end());
+        diff_shape[c] = ds;
+    }
+
     auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget) {
         CP = ChainProgram();
         bool ok = sweep_mask == 7;
         // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, 4 revolute + general rotor,
-        // -1 unsupported
+        // 5 two-rotor differential, -1 unsupported
         std::vector<int> cls(nc, -1), tip(nc, -1), gen_rotor(nc, -1);
         std::vector<ChainPair> pair_of(nc);
         std::vector<std::array<int, 2>> pair_rotors(nc, std::array<int, 2>{-1, -1});
@@ -850,6 +975,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 } else {
                     ok = false;
                 }
+            } else if (diff_shape[c].ok) {
+                cls[c] = 5;  // two-rotor differential (implicit), plan.h ChainDiff
+                tip[c] = diff_shape[c].l2;
             } else {
                 ok = false;
             }
@@ -873,13 +1001,14 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             // child order = the depth-first order of the general schedule (kids[])
             ckids[c] = kids[c];
             for (int k : ckids[c])
-                if (cls[k] == 3 && (ckids[c].size() != 1 || cls[c] == 0 || cls[c] == 3)) ok = false;
+                if (cls[k] == 3 && (ckids[c].size() != 1 || cls[c] == 0 || cls[c] == 3 || cls[c] == 5)) ok = false;
             if (cls[c] == 3 && !ckids[c].empty()) ok = false;
         }
         if (ok) {
             // per-cluster master records
             std::vector<ChainLink> link_of(nc);
             std::vector<ChainFree> free_of(nc);
+            std::vector<ChainDiff> diff_of(nc);
             std::vector<int> acc_slot(nc, -1);            // accumulator [IA 21][psi 6] of the tip body (several kid chains, or a free base)
             std::vector<Obj> objs;
             int n_glb = 0;
@@ -904,6 +1033,21 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     l.has_child = br.has_child;
                     l.lds_sv = l.lds_pv = l.lds_va = -1;
                     l.glb_k = glb(10);  // [K 6][y0][sin][cos] (+ OSIM pass: 1 / D)
+                } else if (cls[c] == 5) {
+                    const DiffShape &ds = diff_shape[c];
+                    ChainDiff &d = diff_of[c];
+                    d = ChainDiff();
+                    d.q_index = cr.q_index; d.v_index = cr.v_index;
+                    d.qpos[0] = ds.r[0] - cr.first_body; d.qpos[1] = ds.r[1] - cr.first_body;
+                    d.qpos[2] = ds.l1 - cr.first_body; d.qpos[3] = ds.l2 - cr.first_body;
+                    d.cofs[0] = bodies[ds.l1].cofs; d.cofs[1] = bodies[ds.l2].cofs; d.cofs[2] = bodies[ds.r[0]].cofs; d.cofs[3] = bodies[ds.r[1]].cofs;
+                    d.rpre[0] = rotor_constants(ds.r[0]);
+                    d.rpre[1] = rotor_constants(ds.r[1]);
+                    d.iofs = bodies[ds.l2].xofs >= 0 ? bodies[ds.l2].xofs : bodies[ds.l2].cofs + 12;
+                    d.lds_pv = d.lds_sv = d.lds_acc = d.lds_acc_out = d.lds_pva = d.lds_va = d.lds_w = -1;
+                    d.tofs_i = ds.tofs_i;
+                    d.tofs_d = P.cints[ds.tofs_i + 2];
+                    d.glb_k = glb(24);  // [K 12][y0 2][X 4][g 2][s1 c1 s2 c2]
                 } else {
                     pair_of[c].glb_k = glb(21);  // [K 12][y0 2] (+ OSIM pass: D^-1 (3), sin / cos of the two links (4))
                     pair_of[c].rpre[0] = rotor_constants(pair_rotors[c][0]);
@@ -913,7 +1057,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             // chains: follow single link children; a single pair child becomes the head of the backward run
             auto is_link = [](int k) { return k == 1 || k == 2 || k == 4; };
-            struct Chain { std::vector<int> cl; int pair = -1; std::vector<int> kid_chains; int parent_cluster = -1; };
+            struct Chain { std::vector<int> cl; int pair = -1; std::vector<int> kid_chains; int parent_cluster = -1; bool diff = false; };
             std::vector<Chain> chains;
             std::function<int(int)> make_chain = [&](int c0) -> int {
                 Chain ch;
@@ -923,9 +1067,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     ch.cl.push_back(c);
                     // (links with no rotor, an axisymmetric rotor and a general rotor may share a run: the kind is a branch on
                     // the link record)
-                    if (ckids[c].size() == 1 && is_link(cls[ckids[c][0]])) { c = ckids[c][0]; continue; }
+                    if (cls[c] != 5 && ckids[c].size() == 1 && is_link(cls[ckids[c][0]])) { c = ckids[c][0]; continue; }
                     break;
                 }
+                ch.diff = cls[c0] == 5;  // a differential is a chain of its own; its child clusters hang off link2
                 const int tipc = ch.cl.back();
                 const int id = static_cast<int>(chains.size());
                 chains.push_back(ch);
@@ -949,6 +1094,15 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             auto push_seg = [&](ChainSeg sg) { CP.segs.push_back(sg); return static_cast<int>(CP.segs.size()) - 1; };
             std::function<void(int)> emit_fb = [&](int id) {
                 const Chain ch = chains[id];
+                if (ch.diff) {
+                    ChainSeg sg = ChainSeg();
+                    sg.op = SEG_DIFF_FWD;
+                    ct[id].fwd = push_seg(sg);
+                    for (int k : ch.kid_chains) emit_fb(k);
+                    sg.op = SEG_DIFF_BWD;
+                    ct[id].bwd = push_seg(sg);
+                    return;
+                }
                 {   // every link of the chain, the tip included: the backward run reads [sin, cos, v] of all of them
                     ChainSeg sg = ChainSeg();
                     sg.op = SEG_RUN_FWD;
@@ -970,6 +1124,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::function<void(int)> emit_acc = [&](int id) {
                 const Chain ch = chains[id];
                 ChainSeg sg = ChainSeg();
+                if (ch.diff) {
+                    sg.op = SEG_DIFF_ACC;
+                    ct[id].acc = push_seg(sg);
+                    for (int k : ch.kid_chains) emit_acc(k);
+                    return;
+                }
                 sg.op = SEG_RUN_ACC;
                 const int t = push_seg(sg);
                 runs.push_back({t, ch.cl});
@@ -1011,6 +1171,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 std::vector<RneaLink> rl(nc);
                 std::vector<RneaPair> rp(nc);
                 std::vector<RneaFree> rf(nc);
+                std::vector<RneaDiff> rd(nc);
                 std::vector<Obj> robjs;
                 struct RRun { int seg; std::vector<int> cl; };
                 std::vector<RRun> rruns;
@@ -1019,6 +1180,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 auto rpush = [&](int op) { RneaSeg sg = RneaSeg(); sg.op = op; sg.lds_pva = sg.lds_pf = -1; R.segs.push_back(sg); return static_cast<int>(R.segs.size()) - 1; };
                 std::function<int(int)> remit = [&](int id) -> int {  // returns the last forward-type segment of the subtree
                     const Chain ch = chains[id];
+                    if (ch.diff) {
+                        int last = rt_fwd[id] = rpush(RSEG_DIFF_FWD);
+                        for (int k : ch.kid_chains) last = std::max(last, remit(k));
+                        rt_bwd[id] = rpush(RSEG_DIFF_BWD);
+                        return last;
+                    }
                     rt_fwd[id] = rpush(RSEG_RUN_FWD);
                     rruns.push_back({rt_fwd[id], ch.cl});
                     int last = rt_fwd[id];
@@ -1061,6 +1228,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : (cls[c] == 4 ? bodies[gen_rotor[c]].cofs : -1);
                         l.general_rotor = cls[c] == 4;
                         l.lds_blk = l.lds_va = l.lds_pf = -1;
+                    } else if (cls[c] == 5) {
+                        RneaDiff &d = rd[c];
+                        d = RneaDiff();
+                        d.q_index = cr.q_index; d.v_index = cr.v_index;
+                        for (int i = 0; i < 4; i++) { d.qpos[i] = diff_of[c].qpos[i]; d.cofs[i] = diff_of[c].cofs[i]; }
+                        d.lds_pva = d.lds_pf = d.lds_blk = d.lds_va = d.lds_w = -1;
+                        d.tofs_i = diff_shape[c].tofs_i;
                     } else {
                         RneaPair &pr = rp[c];
                         pr = RneaPair();
@@ -1071,26 +1245,47 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 }
                 for (size_t id = 0; id < chains.size(); id++) {
                     const Chain &ch = chains[id];
+                    if (ch.diff) {
+                        RneaDiff &d = rd[ch.cl[0]];
+                        // one object: [f2 6][sin, cos 4][X 4] then [v 6][a 6] when child segments follow; the work space of the
+                        // constraint evaluation shares it (everything else is written after the constraint is done)
+                        const int keep = 14 + (ch.kid_chains.empty() ? 0 : 12);
+                        robjs.push_back({&d.lds_blk, std::max(keep, 3 * diff_shape[ch.cl[0]].n_atoms), 0, rt_fwd[id], rt_bwd[id], -1, 1, 1});
+                        continue;
+                    }
                     for (int c : ch.cl) robjs.push_back({&rl[c].lds_blk, 9, 0, rt_fwd[id], rt_bwd[id], -1, 1});
                     const int tipc = ch.cl.back();
                     if (!ch.kid_chains.empty() || ch.pair >= 0)
                         robjs.push_back({&rl[tipc].lds_va, 12, 0, rt_fwd[id], last_fwd_of[id], -1, 1});
                 }
                 int rn_lds = 0, rn_glb = 0;
-                bool rok = allocate(robjs, rnea_budget, rn_lds, rn_glb);
+                bool rok = allocate_packed(robjs, rnea_budget, rn_lds, rn_glb);
+                if (!rok && std::getenv("GRBDA_DEBUG_CHAIN")) {
+                    std::fprintf(stderr, "chain (rnea): LDS objects need more than %d slots (got to %d)\n", rnea_budget, rn_lds);
+                    for (const Obj &o : robjs) std::fprintf(stderr, "  obj size %d [%d, %d] slot %d\n", o.size, o.birth, o.death, o.slot);
+                }
                 if (rok) {
+                    for (size_t id = 0; id < chains.size(); id++)
+                        if (chains[id].diff) {
+                            RneaDiff &d = rd[chains[id].cl[0]];
+                            d.lds_w = d.lds_blk;
+                            d.lds_va = chains[id].kid_chains.empty() ? -1 : d.lds_blk + 14;
+                        }
                     auto f_slot_of_body = [&](int b) -> int {
                         const int c = m.bodies[b].cluster;
+                        if (cls[c] == 5) return rd[c].lds_blk;
                         return cls[c] == 0 ? rf[c].lds_f : rl[c].lds_blk;
                     };
                     auto va_slot_of_body2 = [&](int b) -> int {
                         const int c = m.bodies[b].cluster;
+                        if (cls[c] == 5) return rd[c].lds_va;
                         return cls[c] == 0 ? rf[c].lds_va : rl[c].lds_va;
                     };
                     for (int c = 0; c < nc; c++) {
                         const int pb = clusters[c].parent_body;
                         if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) rl[c].lds_pf = f_slot_of_body(pb);
                         if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb); }
+                        if (cls[c] == 5) { rd[c].lds_pva = va_slot_of_body2(pb); rd[c].lds_pf = f_slot_of_body(pb); }
                     }
                     for (const RRun &r : rruns) {
                         RneaSeg &sg = R.segs[r.seg];
@@ -1103,6 +1298,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         const int pb = clusters[ch.cl.front()].parent_body;
                         R.segs[rt_fwd[id]].lds_pva = va_slot_of_body2(pb);
                         R.segs[rt_bwd[id]].lds_pf = f_slot_of_body(pb);
+                        if (ch.diff) {
+                            R.segs[rt_fwd[id]].first = R.segs[rt_bwd[id]].first = static_cast<int>(R.diffs.size());
+                            R.diffs.push_back(rd[ch.cl[0]]);
+                        }
                         if (ch.pair >= 0) {
                             R.segs[rt_pair[id]].first = static_cast<int>(R.pairs.size());
                             R.pairs.push_back(rp[ch.pair]);
@@ -1116,9 +1315,15 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     R.n_lds = rn_lds;
                 }
                 R.ok = rok;
-                if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); }
+                if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); R.diffs.clear(); }
             }
-            // ---- LDS objects and their live ranges (segment indices) ----
+            // ---- LDS objects and their live ranges ----
+            // Time runs in half steps of the segment index: an ordinary object lives from the start of its first segment to the
+            // end of its last one, [2 first, 2 last + 1].  An accumulator [IA | psi] is WRITTEN AT THE END of the first
+            // backward segment below its body and READ AT THE START of the body's own backward segment, [2 first + 1, 2 own]:
+            // the accumulator a segment consumes and the one it produces may share their slots.
+            auto B0 = [](int t) { return 2 * t; };
+            auto D1 = [](int t) { return 2 * t + 1; };
             for (int c = 0; c < nc; c++) {
                 if (cls[c] != 0) continue;
                 ChainFree &f = free_of[c];
@@ -1126,38 +1331,53 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 int first_bwd = 1 << 30, last_acc = t_free_acc[c];
                 // (the [v, a] block is read when a kid chain's acceleration run STARTS: it lives until the last kid's own segment)
                 for (int id : free_chains[c]) { first_bwd = std::min(first_bwd, ct[id].bwd); last_acc = std::max(last_acc, ct[id].acc); }
-                objs.push_back({&f.lds_v, 6, 0, t_free_fwd[c], t_free_bwd[c], -1, 1});
-                objs.push_back({&f.lds_acc, 27, 1, first_bwd, t_free_bwd[c], -1, 1});
-                objs.push_back({&f.lds_va, 12, 0, t_free_acc[c], last_acc, -1, 1});
+                objs.push_back({&f.lds_v, 6, 0, B0(t_free_fwd[c]), D1(t_free_bwd[c]), -1, 1});
+                objs.push_back({&f.lds_acc, 27, 1, B0(first_bwd) + 1, B0(t_free_bwd[c]), -1, 1});
+                objs.push_back({&f.lds_va, 12, 0, B0(t_free_acc[c]), D1(last_acc), -1, 1});
             }
             for (size_t id = 0; id < chains.size(); id++) {
                 const Chain &ch = chains[id];
-                for (int c : ch.cl) objs.push_back({&link_of[c].lds_sv, 8, 0, ct[id].fwd, ct[id].bwd, -1, 1});
+                if (ch.diff) {
+                    ChainDiff &d = diff_of[ch.cl[0]];
+                    objs.push_back({&d.lds_w, 3 * diff_shape[ch.cl[0]].n_atoms, 0, B0(ct[id].fwd), D1(ct[id].fwd), -1, 1, 1});
+                    if (!ch.kid_chains.empty()) {
+                        int first_bwd = 1 << 30, last_acc = ct[id].acc;
+                        for (int k : ch.kid_chains) { first_bwd = std::min(first_bwd, ct[k].bwd); last_acc = std::max(last_acc, ct[k].acc); }
+                        objs.push_back({&d.lds_sv, 8, 0, B0(ct[id].fwd), D1(ct[id].bwd), -1, 1});
+                        objs.push_back({&d.lds_acc, 27, 1, B0(first_bwd) + 1, B0(ct[id].bwd), -1, 1});
+                        objs.push_back({&d.lds_va, 12, 0, B0(ct[id].acc), D1(last_acc), -1, 1});
+                    }
+                    continue;
+                }
+                for (int c : ch.cl) objs.push_back({&link_of[c].lds_sv, 8, 0, B0(ct[id].fwd), D1(ct[id].bwd), -1, 1});
                 const int tipc = ch.cl.back();
                 if (!ch.kid_chains.empty()) {
                     int first_bwd = 1 << 30, last_acc = ct[id].acc;
                     for (int k : ch.kid_chains) { first_bwd = std::min(first_bwd, ct[k].bwd); last_acc = std::max(last_acc, ct[k].acc); }
-                    objs.push_back({&acc_slot[tipc], 27, 1, first_bwd, ct[id].bwd, -1, 1});
-                    objs.push_back({&link_of[tipc].lds_va, 12, 0, ct[id].acc, last_acc, -1, 1});
+                    objs.push_back({&acc_slot[tipc], 27, 1, B0(first_bwd) + 1, B0(ct[id].bwd), -1, 1});
+                    objs.push_back({&link_of[tipc].lds_va, 12, 0, B0(ct[id].acc), D1(last_acc), -1, 1});
                 } else if (ch.pair >= 0) {
-                    objs.push_back({&link_of[tipc].lds_va, 12, 0, ct[id].acc, ct[id].pair_acc, -1, 1});
+                    objs.push_back({&link_of[tipc].lds_va, 12, 0, B0(ct[id].acc), D1(ct[id].pair_acc), -1, 1});
                 }
             }
             int n_lds = 0, n_glb_unused = 0;
-            ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
-            if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: LDS objects need more than %d slots (got to %d)\n", lds_budget, n_lds);
+            ok = allocate_packed(objs, lds_budget, n_lds, n_glb_unused);
+            if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) {
+                std::fprintf(stderr, "chain: LDS objects need more than %d slots (got to %d)\n", lds_budget, n_lds);
+                for (const Obj &o : objs) std::fprintf(stderr, "  obj size %d [%d, %d] slot %d\n", o.size, o.birth, o.death, o.slot);
+            }
             if (!ok) {
                 // second try: the accumulators [IA 21][psi 6] of branching bodies -- touched once per child chain -- move
                 // to the wave's global slab (their slot numbers then carry kSlotGlobal)
                 for (Obj &o : objs)
-                    if (o.size == 27) { o.force = 2; o.slot = -1; }
-                ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
+                    if (o.size == 27 && !o.tag) { o.force = 2; o.slot = -1; }
+                ok = allocate_packed(objs, lds_budget, n_lds, n_glb_unused);
                 if (!ok) {
                     // third try (long chains, JVRC-1's arms and legs): the [sin, cos, v] blocks of the links go there too;
                     // the backward run fetches the next link's block while it computes the current one
                     for (Obj &o : objs)
-                        if (o.size == 8) { o.force = 2; o.slot = -1; }
-                    ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
+                        if (o.size == 8 && !o.tag) { o.force = 2; o.slot = -1; }
+                    ok = allocate_packed(objs, lds_budget, n_lds, n_glb_unused);
                     CP.sv_global = true;
                     if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) {
                         std::fprintf(stderr, "chain: third try failed, n_lds %d\n", n_lds);
@@ -1174,20 +1394,24 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 // parent velocity / (v, a) slots
                 auto v_slot_of_body = [&](int b) -> int {  // LDS slot of the velocity of body b (tip of its cluster)
                     const int c = m.bodies[b].cluster;
+                    if (cls[c] == 5) return diff_of[c].lds_sv + 2;
                     return cls[c] == 0 ? free_of[c].lds_v : link_of[c].lds_sv + 2;  // (+2 keeps a kSlotGlobal flag intact)
                 };
                 auto va_slot_of_body = [&](int b) -> int {
                     const int c = m.bodies[b].cluster;
+                    if (cls[c] == 5) return diff_of[c].lds_va;
                     return cls[c] == 0 ? free_of[c].lds_va : link_of[c].lds_va;
                 };
                 auto acc_slot_of_body = [&](int b) -> int {
                     const int c = m.bodies[b].cluster;
+                    if (cls[c] == 5) return diff_of[c].lds_acc;
                     return cls[c] == 0 ? free_of[c].lds_acc : acc_slot[c];
                 };
                 for (int c = 0; c < nc; c++) {
                     const int pb = clusters[c].parent_body;
                     if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) link_of[c].lds_pv = v_slot_of_body(pb);
                     if (cls[c] == 3) { pair_of[c].lds_pv = v_slot_of_body(pb); pair_of[c].lds_pva = va_slot_of_body(pb); }
+                    if (cls[c] == 5) { diff_of[c].lds_pv = v_slot_of_body(pb); diff_of[c].lds_pva = va_slot_of_body(pb); diff_of[c].lds_acc_out = acc_slot_of_body(pb); }
                 }
                 // first writer of every accumulator slot: the kid chain whose backward run comes first
                 for (const RunRef &r : runs) {
@@ -1200,6 +1424,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     const Chain &ch = chains[id];
                     ChainSeg &bw = CP.segs[ct[id].bwd];
                     const int tipc = ch.cl.back(), topc = ch.cl.front();
+                    if (ch.diff) bw.head = HEAD_LEAF;
                     if (bw.head == HEAD_SLOT) bw.head_arg = acc_slot[tipc];
                     if (bw.head == HEAD_PAIR) { bw.head_arg = static_cast<int>(CP.pairs.size()); }
                     const int pb = clusters[topc].parent_body;
@@ -1216,6 +1441,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     bw.acc_first = first ? 1 : 0;
                     ChainSeg &ac = CP.segs[ct[id].acc];
                     ac.lds_pva = va_slot_of_body(pb);
+                    if (ch.diff) {
+                        diff_of[topc].acc_first = first ? 1 : 0;
+                        CP.segs[ct[id].fwd].first = bw.first = ac.first = static_cast<int>(CP.diffs.size());
+                        CP.diffs.push_back(diff_of[topc]);
+                    }
                     if (ch.pair >= 0) {
                         ChainSeg &pa = CP.segs[ct[id].pair_acc];
                         pa.first = static_cast<int>(CP.pairs.size());
@@ -1231,7 +1461,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
         }
         CP.ok = ok;
-        if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); }
+        if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); CP.diffs.clear(); }
     };
     // the RNEA chain kernels run 8 wavefronts per CU like the ABA ones: the ABA budgets apply
     build_chain(P.chain32, lds.aba32, &P.rchain32, lds.aba32);

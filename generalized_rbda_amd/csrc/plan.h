@@ -162,7 +162,10 @@ enum ChainOp : int32_t {
     SEG_FREE_BWD = 3,
     SEG_FREE_ACC = 4,
     SEG_RUN_ACC = 5,    // root side first: ydd of every link; (v, a) of the tip to LDS when child segments follow
-    SEG_PAIR_ACC = 6
+    SEG_PAIR_ACC = 6,
+    SEG_DIFF_FWD = 7,   // two-rotor differential cluster (ChainDiff): constraint Jacobian, G, g; velocity of its tip link
+    SEG_DIFF_BWD = 8,
+    SEG_DIFF_ACC = 9
 };
 enum ChainHead : int32_t {
     HEAD_LEAF = 0,      // the first link of a backward run is a leaf: its accumulators start from its own inertia
@@ -197,6 +200,41 @@ struct ChainPair {
     int32_t reserved[21];
 };
 
+// An implicit two-rotor differential (the Tello hip and knee-ankle differentials, src/Robots/Tello.cpp:77-261 with
+// TelloDifferential / GenericImplicit constraints): link1 and two axisymmetric rotors on the parent body, link2 on link1,
+// a trig-polynomial constraint phi(q) = 0 (2 rows) that makes the two ROTOR angles the independent coordinates and the two
+// link angles the dependent ones.  Kernel coordinate order: [rotor1, rotor2, link1, link2]; G = [1; X], g = (0, 0, g1, g2)
+// with X = -Kd^-1 Ki, g = -Kd^-1 Kdot qd evaluated per state by the forward segment (32 ints).
+struct ChainDiff {
+    int32_t q_index, v_index;
+    int32_t qpos[4];    // offsets of the spanning positions of rotor1, rotor2, link1, link2 from q_index
+    int32_t cofs[4];    // constants of link1, link2, rotor1, rotor2
+    int32_t rpre[2];    // rotor1, rotor2: [X0^T h (6)][h_z]
+    int32_t iofs;       // link2: the 21 constants I + sum over axisymmetric leaf children X0^T I X0
+    int32_t lds_pv;     // parent body's velocity
+    int32_t lds_sv;     // [sin, cos, v 6] of link2 when child segments read it, else -1
+    int32_t lds_acc;    // accumulator [IA 21][psi 6] of link2 (child segments), -1: link2 is a leaf
+    int32_t lds_acc_out, acc_first;  // accumulator of the parent body; 1: this segment is its first writer
+    int32_t glb_k;      // [K 12][y0 2][X 4][g 2][s1 c1 s2 c2]
+    int32_t lds_pva;    // acceleration sweep: parent body's [v 6][a 6]
+    int32_t lds_va;     // own [v 6][a 6] of link2 when child segments follow, else -1
+    int32_t lds_w;      // work space of the constraint evaluation: 3 slots per atom (DiffProgram)
+    int32_t tofs_i, tofs_d;  // constraint program in cints[] / consts[] (plan.cpp, emit_diff_program)
+    int32_t reserved[8];
+};
+// the same cluster in the inverse-dynamics program (16 ints)
+struct RneaDiff {
+    int32_t q_index, v_index;
+    int32_t qpos[4];
+    int32_t cofs[4];
+    int32_t lds_pva;    // parent body's [v 6][a 6]
+    int32_t lds_pf;     // parent body's force
+    int32_t lds_blk;    // [f2 6][s1 c1 s2 c2][X 4]  (14), forward -> backward segment
+    int32_t lds_va;     // [v 6][a 6] of link2 for child segments (lds_blk + 14), else -1
+    int32_t lds_w;      // work space of the constraint evaluation (shares lds_blk: plan.cpp)
+    int32_t tofs_i;     // constraint program in cints[]
+};
+
 struct ChainSeg {       // 16 ints
     int32_t op;
     int32_t first, count;   // runs: links[first .. first + count) in sweep order; pair / free: record index
@@ -221,7 +259,8 @@ struct ChainFree {      // 16 ints
 // ---- inverse dynamics on the same chains (chain_kernels.hip, rnea_chain_kernel) ------------------------------------
 // forward run: v, a, body force f = I a + v x* I v of every link, the rotor's torque and its force on the parent body;
 // backward run: tau = S^T f, f_parent += X^T f.  A leaf pair cluster is finished in one segment of the forward pass.
-enum RneaChainOp : int32_t { RSEG_FREE_FWD = 0, RSEG_RUN_FWD = 1, RSEG_PAIR = 2, RSEG_RUN_BWD = 3, RSEG_FREE_BWD = 4 };
+enum RneaChainOp : int32_t { RSEG_FREE_FWD = 0, RSEG_RUN_FWD = 1, RSEG_PAIR = 2, RSEG_RUN_BWD = 3, RSEG_FREE_BWD = 4,
+                             RSEG_DIFF_FWD = 5, RSEG_DIFF_BWD = 6 };
 struct RneaLink {       // 16 ints
     int32_t q_index, v_index;
     int32_t cofs, rofs;     // link / rotor constants (rofs -1: plain revolute cluster)
@@ -256,6 +295,7 @@ struct RneaChainProgram {
     std::vector<RneaLink> links;
     std::vector<RneaPair> pairs;
     std::vector<RneaFree> frees;
+    std::vector<RneaDiff> diffs;
     int n_lds = 0;
 };
 
@@ -265,6 +305,7 @@ struct ChainProgram {
     std::vector<ChainLink> links;    // in sweep order of each run (a cluster appears once per sweep it takes part in)
     std::vector<ChainPair> pairs;
     std::vector<ChainFree> frees;
+    std::vector<ChainDiff> diffs;
     int n_lds = 0, n_glb = 0;        // slots
     bool sv_global = false;          // the [sin, cos, v] blocks of the links live in the global slab (chains too long for LDS)
 };

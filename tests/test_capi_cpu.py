@@ -98,14 +98,15 @@ def test_model_builder_rejects_invalid_topology():
 def test_chain_program_covers_the_headline_models():
     """The chain-structured fast path (plan.h, ChainProgram) must be what runs the floating-base robots made of
     revolute links, geared rotors and leaf pair clusters -- the BASELINE workloads mini_cheetah / mit_humanoid -- and
-    the random models of the zoo that exercise its run / branch / pair / roll-pitch-yaw code; everything else stays on
-    the general interpreter."""
+    the random models of the zoo that exercise its run / branch / pair / roll-pitch-yaw code -- and TelloWithArms, whose
+    implicit differentials are a segment type of their own; everything else stays on the general interpreter."""
     z = zoo()
     for name in ("urdf_mini_cheetah", "urdf_mit_humanoid", "urdf_jvrc1_humanoid", "urdf_mini_cheetah_rpy", "tree_chain_rotor_float", "tree_chain_rev_float", "tree_rotor_float",
-                 "chain_tree_a", "chain_tree_b", "chain_tree_rpy", "chain_tree_norotor"):
+                 "chain_tree_a", "chain_tree_b", "chain_tree_rpy", "chain_tree_norotor", "tello_with_arms"):
         info = G.Plan(z[name]).info()
         assert info.chain_aba_f32 == 1 and info.n_chain_segments > 0, name
     for name in ("urdf_mini_cheetah", "urdf_mit_humanoid", "chain_tree_b", "chain_tree_norotor"):
         assert G.Plan(z[name]).info().chain_aba_f64 == 1, name
-    for name in ("urdf_four_bar", "tello_with_arms", "tree_generic_float", "rev_rotor_chain_3"):
+    assert G.Plan(z["tello_with_arms"]).info().chain_rnea_f32 == 1
+    for name in ("urdf_four_bar", "tree_generic_float", "rev_rotor_chain_3"):
         assert G.Plan(z[name]).info().chain_aba_f32 == 0, name
