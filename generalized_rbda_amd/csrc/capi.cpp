@@ -276,7 +276,7 @@ bool chain_covers(const grbda_plan *p)
 {
     if (p->no_chain) return false;
     if (sizeof(T) == 8) return p->host.chain64.ok;
-    return p->host.chain32.ok || (p->host.chain32w.ok && p->chain_wide);
+    return p->host.chain32.ok || (p->host.chain32w.ok && p->host.chain32w.diffs.empty() && p->chain_wide);
 }
 
 template <class T>
@@ -286,7 +286,8 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     const HostPlan &h = p->host;
     // f32: four wavefronts per SIMD (16 per CU, half the LDS each) once the batch fills them, when that layout exists
     const size_t n_tiles0 = (B + kWave - 1) / kWave;
-    const bool wide = sizeof(T) == 4 && h.chain32w.ok && p->chain_wide && (!h.chain32.ok || n_tiles0 > static_cast<size_t>(t.n_cu) * 8);
+    const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && p->chain_wide &&
+                      (!h.chain32.ok || n_tiles0 > static_cast<size_t>(t.n_cu) * 8);
     const int w = sizeof(T) == 8 ? 2 : (wide ? 1 : 0);
     const int kid = sizeof(T) == 8 ? 1 : 0;
     const ChainProgram &cp = w == 2 ? h.chain64 : (wide ? h.chain32w : h.chain32);
@@ -298,6 +299,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     d.pairs = t.chain_pairs[w];
     d.frees = t.chain_frees[w];
     d.diffs = t.chain_diffs[w];
+    d.n_diffs = static_cast<int>(cp.diffs.size());
     d.cints = t.cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.n_segs = static_cast<int>(cp.segs.size());
@@ -344,6 +346,7 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     d.pairs = t.rchain_pairs[w];
     d.frees = t.rchain_frees[w];
     d.diffs = t.rchain_diffs[w];
+    d.n_diffs = static_cast<int>(rp.diffs.size());
     d.cints = t.cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.n_segs = static_cast<int>(rp.segs.size());
@@ -817,6 +820,7 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.pairs = t->chain_pairs[w];
     d.frees = t->chain_frees[w];
     d.diffs = t->chain_diffs[w];
+    d.n_diffs = 0;
     d.cints = t->cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t->consts32) : reinterpret_cast<const T *>(t->consts64);
     d.n_segs = static_cast<int>(cp.segs.size());

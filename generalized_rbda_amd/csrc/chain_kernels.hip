@@ -1076,7 +1076,9 @@ __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, int WPS>
+// DIFF: the program has differential clusters (ChainDiff).  A kernel variant of its own, so that the models without them
+// (every URDF robot of the reference) keep the register allocation of the plain run / pair / free code.
+template <class T, int WPS, bool DIFF>
 __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
                                                              const T *__restrict__ tau, T *__restrict__ ydd, size_t B,
                                                              T *__restrict__ scratch)
@@ -1086,8 +1088,8 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     P.links = (cptr<ChainLink>)DP.links;
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
-    P.diffs = (cptr<ChainDiff>)DP.diffs;
-    P.cints = (cptr<int32_t>)DP.cints;
+    P.diffs = DIFF ? (cptr<ChainDiff>)DP.diffs : nullptr;
+    P.cints = DIFF ? (cptr<int32_t>)DP.cints : nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -1129,9 +1131,15 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                 case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
                 case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
                 case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first)); break;
-                case SEG_DIFF_FWD: diff_fwd(P, M, load_rec(P.diffs + sg.first)); break;
-                case SEG_DIFF_BWD: diff_bwd(P, M, load_rec(P.diffs + sg.first)); break;
-                case SEG_DIFF_ACC: diff_acc(P, M, load_rec(P.diffs + sg.first)); break;
+                case SEG_DIFF_FWD:
+                    if constexpr (DIFF) diff_fwd(P, M, load_rec(P.diffs + sg.first));
+                    break;
+                case SEG_DIFF_BWD:
+                    if constexpr (DIFF) diff_bwd(P, M, load_rec(P.diffs + sg.first));
+                    break;
+                case SEG_DIFF_ACC:
+                    if constexpr (DIFF) diff_acc(P, M, load_rec(P.diffs + sg.first));
+                    break;
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
@@ -1174,8 +1182,8 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     P.links = (cptr<ChainLink>)DP.links;
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
-    P.diffs = (cptr<ChainDiff>)DP.diffs;
-    P.cints = (cptr<int32_t>)DP.cints;
+    P.diffs = nullptr;
+    P.cints = nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -1377,13 +1385,18 @@ template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd)
 {
+    if (P.n_diffs > 0) {
+        if (four_waves_per_simd) return hipErrorInvalidValue;  // (capi.cpp keeps such programs at two wavefronts per SIMD)
+        hipLaunchKernelGGL((aba_chain_kernel<T, 2, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+        return hipGetLastError();
+    }
     if constexpr (sizeof(T) == 4) {
         if (four_waves_per_simd) {
-            hipLaunchKernelGGL((aba_chain_kernel<T, 4>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+            hipLaunchKernelGGL((aba_chain_kernel<T, 4, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((aba_chain_kernel<T, 2>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    hipLaunchKernelGGL((aba_chain_kernel<T, 2, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
 template hipError_t launch_aba_chain<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
@@ -1762,7 +1775,7 @@ __device__ __forceinline__ void rnea_free_bwd(const RneaTables<T> &P, const Chai
     for (int j = 0; j < 6; j++) M.put(f.v_index + j, fo[j]);
 }
 
-template <class T>
+template <class T, bool DIFF>
 __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
                                                               const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
                                                               T *__restrict__ scratch)
@@ -1772,8 +1785,8 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     P.links = (cptr<RneaLink>)DP.links;
     P.pairs = (cptr<RneaPair>)DP.pairs;
     P.frees = (cptr<RneaFree>)DP.frees;
-    P.diffs = (cptr<RneaDiff>)DP.diffs;
-    P.cints = (cptr<int32_t>)DP.cints;
+    P.diffs = DIFF ? (cptr<RneaDiff>)DP.diffs : nullptr;
+    P.cints = DIFF ? (cptr<int32_t>)DP.cints : nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -1802,8 +1815,12 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
                 case RSEG_RUN_BWD: rnea_run_bwd(P, M, sg); break;
                 case RSEG_PAIR: rnea_pair(P, M, load_rec(P.pairs + sg.first)); break;
                 case RSEG_FREE_FWD: rnea_free_fwd(P, M, load_rec(P.frees + sg.first)); break;
-                case RSEG_DIFF_FWD: rnea_diff_fwd(P, M, load_rec(P.diffs + sg.first)); break;
-                case RSEG_DIFF_BWD: rnea_diff_bwd(P, M, load_rec(P.diffs + sg.first)); break;
+                case RSEG_DIFF_FWD:
+                    if constexpr (DIFF) rnea_diff_fwd(P, M, load_rec(P.diffs + sg.first));
+                    break;
+                case RSEG_DIFF_BWD:
+                    if constexpr (DIFF) rnea_diff_bwd(P, M, load_rec(P.diffs + sg.first));
+                    break;
                 default: rnea_free_bwd(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
@@ -1815,7 +1832,8 @@ template <class T>
 hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
                              size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((rnea_chain_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    if (P.n_diffs > 0) hipLaunchKernelGGL((rnea_chain_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else hipLaunchKernelGGL((rnea_chain_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
 }
 template hipError_t launch_rnea_chain<float>(const RneaChainDev<float> &, const float *, const float *, const float *, float *, size_t,
@@ -1825,26 +1843,18 @@ template hipError_t launch_rnea_chain<double>(const RneaChainDev<double> &, cons
 
 hipError_t set_max_dynamic_lds_chain()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<double, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_chain_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rnea_chain_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&osim_chain_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&osim_chain_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&aba_chain_kernel<float, 4>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void *const kernels[] = {
+        reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, false>), reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, true>),
+        reinterpret_cast<const void *>(&aba_chain_kernel<float, 4, false>),
+        reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, false>), reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, true>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<float, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<double, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true>),
+        reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>)};
+    for (const void *k : kernels) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace grbda_hip

@@ -51,6 +51,7 @@ struct ChainDev {
     const ChainPair *pairs;
     const ChainFree *frees;
     const ChainDiff *diffs;
+    int n_diffs;
     const int32_t *cints;
     const T *consts;
     int n_segs;
@@ -74,6 +75,7 @@ struct RneaChainDev {
     const RneaPair *pairs;
     const RneaFree *frees;
     const RneaDiff *diffs;
+    int n_diffs;
     const int32_t *cints;
     const T *consts;
     int n_segs;
