@@ -23,6 +23,9 @@ $(OBJ)/chain_kernels.o: $(CSRC)/chain_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan
 $(OBJ)/crba_kernels.o: $(CSRC)/crba_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
+$(OBJ)/deriv_kernels.o: $(CSRC)/deriv_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
 $(OBJ)/capi.o: $(CSRC)/capi.cpp $(CSRC)/plan.h $(CSRC)/devplan.h include/grbda_hip.h include/grbda_model_desc.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
@@ -33,7 +36,7 @@ $(OBJ)/urdf.o: $(CSRC)/urdf.cpp include/grbda_hip.h include/grbda_model_desc.h g
 	@mkdir -p $(OBJ)
 	g++ -O2 -std=c++17 -fPIC -Wall -c $< -o $@
 
-$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 oracle:
@@ -48,13 +51,19 @@ clean:
 .PHONY: all oracle ref clean
 
 # profiling variant with in-kernel cycle accounting (tools/prof_run.py); not part of `all`
-prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/crba_kernels.o
+prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
 	@mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -DGRBDA_PROFILE -c $(CSRC)/kernels.hip -o build/prof/kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/libgrbda_hip_prof.so build/prof/kernels.o $^
 
 # experiment builds: make exp NAME=foo DEFS="-DGRBDA_EXP_FOO" -> build/exp/libgrbda_foo.so
-exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/crba_kernels.o
+exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/kernels.hip -o build/exp/kernels_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/kernels_$(NAME).o $^
+
+# experiment builds of the derivative kernels: make expd NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
+expd: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+	@mkdir -p build/exp
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/deriv_kernels.hip -o build/exp/deriv_$(NAME).o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/deriv_$(NAME).o $^

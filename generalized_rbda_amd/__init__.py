@@ -29,7 +29,7 @@ C_ABI_SYMBOLS = [
     "grbda_inv_osim_host_f64", "grbda_fd_dq_f64", "grbda_fd_dq_f32", "grbda_body_poses_f64", "grbda_body_poses_f32",
     "grbda_apply_test_force_f64", "grbda_apply_test_force_f32", "grbda_inv_osim_f64", "grbda_inv_osim_f32",
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
-    "grbda_spanning_f64", "grbda_spanning_f32",
+    "grbda_spanning_f64", "grbda_spanning_f32", "grbda_fd_derivatives_f64", "grbda_fd_derivatives_f32",
 ]
 
 
@@ -108,6 +108,9 @@ def lib() -> ctypes.CDLL:
     for sfx in ("f64", "f32"):
         getattr(L, "grbda_fd_dq_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p,
                                                      c_size_t, c_int, c_void_p]
+    for sfx in ("f64", "f32"):
+        getattr(L, "grbda_fd_derivatives_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                              c_void_p, c_size_t, c_int, c_void_p]
     for sfx in ("f64", "f32"):
         getattr(L, "grbda_project_positions_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                                                  c_double, c_int, c_void_p]
@@ -377,10 +380,29 @@ class Plan:
                   q.device.index or 0, c_void_p(s.cuda_stream)))
         return (Linv, J) if with_jacobian else Linv
 
+    def fd_derivatives(self, q, qd, tau, want=("dq", "dqd", "dtau"), stream=None):
+        """d ydd / d q, d ydd / d qd, d ydd / d tau of the forward dynamics in one pass (grbda_fd_derivatives_*): a dict
+        of [B, nv, nv] tensors for the names in `want`.  Explicit models get the analytic recursion + one SPD solve per
+        state (deriv_kernels.hip); the others fall back to fd_dtau / fd_dqd / fd_dq."""
+        import torch
+
+        self._floating(q, qd, tau)
+        B = q.shape[0]
+        if q.shape != (B, self.nq) or qd.shape != (B, self.nv) or tau.shape != (B, self.nv):
+            raise ValueError(f"expected device tensors q[B,{self.nq}], qd[B,{self.nv}], tau[B,{self.nv}]")
+        q, qd, tau = q.contiguous(), qd.contiguous(), tau.contiguous()
+        out = {k: torch.empty((B, self.nv, self.nv), dtype=q.dtype, device=q.device) for k in ("dq", "dqd", "dtau") if k in want}
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_fd_derivatives_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        ptr = lambda k: out[k].data_ptr() if k in out else None
+        _check(fn(self._h, q.data_ptr(), qd.data_ptr(), tau.data_ptr(), ptr("dq"), ptr("dqd"), ptr("dtau"), B,
+                  q.device.index or 0, c_void_p(s.cuda_stream)))
+        return out
+
     def fd_dq(self, q, qd, tau, step: float = 1e-6, stream=None):
-        """d ydd / d q by central differences along the reference's tangent step (testHelpers.hpp:50-112),
-        [B, nv, nv]; not exact, unlike fd_dtau / fd_dqd.  The differences are always taken in fp64 (fp32 tensors are
-        converted on the device); implicit-loop models are differentiated on the constraint manifold."""
+        """d ydd / d q along the reference's tangent step (testHelpers.hpp:50-112), [B, nv, nv].  Explicit models:
+        analytic (`step` unused).  Models with implicit loops or a roll-pitch-yaw base: central differences, always taken
+        in fp64 (fp32 tensors are converted on the device), on the constraint manifold."""
         import torch
 
         self._floating(q, qd, tau)

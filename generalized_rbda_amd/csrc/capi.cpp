@@ -57,6 +57,7 @@ struct DeviceTables {
     ChainFree *chain_frees[3] = {nullptr, nullptr, nullptr};
     ChainDiff *chain_diffs[3] = {nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
+    DerivBody *deriv_bodies = nullptr;
     // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64
     RneaSeg *rchain_segs[2] = {nullptr, nullptr};
     RneaLink *rchain_links[2] = {nullptr, nullptr};
@@ -117,6 +118,9 @@ struct grbda_plan {
     bool no_chain = false;  // GRBDA_NO_CHAIN=1: keep the general interpreter (A/B runs, tests of the general kernels)
     int chain_debug = 0;
     bool no_crba = false;
+    bool no_analytic = false;  // GRBDA_NO_ANALYTIC=1: derivatives by the unit-vector / central-difference batches only
+    bool solve_f64 = false;    // GRBDA_SOLVE_F64=1: the SPD solve of the f32 derivative entry points computes in f64
+    int deriv_waves = 4;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel
     bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
 };
@@ -202,6 +206,11 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     }
     if (h.crba.ok && (e = up(h.crba.bodies.data(), h.crba.bodies.size() * sizeof(CrbaBody), (void **)&t.crba_bodies)) != hipSuccess)
         return hip_err(e, "plan upload");
+    if (h.deriv.ok) {
+        if ((e = up(h.deriv.bodies.data(), h.deriv.bodies.size() * sizeof(DerivBody), (void **)&t.deriv_bodies)) != hipSuccess)
+            return hip_err(e, "plan upload");
+        if ((e = set_max_dynamic_lds_deriv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
+    }
     for (int w = 0; w < 3; w++) {
         const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : h.chain64);
         if (!cp.ok) continue;
@@ -1113,6 +1122,93 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
     return GRBDA_OK;
 }
 
+// ---- analytic first-order derivatives of the forward dynamics (deriv_kernels.hip) ---------------------------------
+// d ydd / d tau = H^-1, d ydd / d q = -H^-1 dID/dq, d ydd / d qd = -H^-1 dID/dqd at ydd = FD(q, qd, tau); any of the three
+// outputs may be null.  Returns 1 when the model is not covered (implicit loops, roll-pitch-yaw base, nv > 64): the
+// callers then fall back to the unit-vector / central-difference batches of derived().
+template <class T>
+bool analytic_covers(const grbda_plan *p)
+{
+    return p->host.deriv.ok && p->host.crba.ok && !p->no_analytic && !p->no_crba && p->host.nv <= kWave;
+}
+template <class T>
+int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, T *dq, T *dqd, T *dtau, size_t B, int device,
+                    void *stream)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!analytic_covers<T>(p)) return 1;
+    if (!q || ((dq || dqd) && (!qd || !tau))) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0 || (!dq && !dqd && !dtau)) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
+    const bool need_d = dq || dqd;
+    const size_t per_state = nn + (need_d ? 2 * nn + nv : 0);
+    size_t chunk = (512u << 20) / (per_state * sizeof(T));
+    if (chunk < 1) chunk = 1;
+    if (chunk > B) chunk = B;
+    void *wptr = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lk(p->mu);
+        Scratch &s = p->work[{device, stream}];
+        const size_t need = chunk * per_state * sizeof(T) + 256;
+        if (s.bytes < need) {
+            hipError_t e;
+            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+            s.ptr = nullptr;
+            s.bytes = 0;
+            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+            s.bytes = need;
+        }
+        wptr = s.ptr;
+    }
+    T *H = static_cast<T *>(wptr), *Dq = H + chunk * nn, *Dqd = Dq + chunk * nn, *ydd = Dqd + chunk * nn;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t n_tiles = (nb + kWave - 1) / kWave;
+        hipError_t e = hipMemsetAsync(H, 0, nb * nn * (need_d ? 3 : 1) * sizeof(T), hs);
+        if (e != hipSuccess) return hip_err(e, "hipMemsetAsync");
+        if (need_d)
+            if (int rc = run<T>(p, false, q + b0 * nq, qd + b0 * nv, tau + b0 * nv, nullptr, ydd, nb, device, stream)) return rc;
+        size_t grid = static_cast<size_t>(t->n_cu) * 8;
+        if (grid > n_tiles) grid = n_tiles;
+        const size_t rows = std::max(p->host.crba.n_rows, need_d ? p->host.deriv.n_rows : 0);
+        const size_t slabs = std::max(grid, static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->deriv_waves));
+        void *scratch = nullptr;
+        if (int rc = ensure_scratch(p, device, stream, slabs * rows * kWave * sizeof(T) + 256, &scratch)) return rc;
+        e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, H, nb, static_cast<T *>(scratch),
+                           static_cast<int>(grid), hs);
+        if (e != hipSuccess) return hip_err(e, "crba launch");
+        if (need_d) {
+            size_t g2 = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->deriv_waves);
+            if (g2 > n_tiles) g2 = n_tiles;
+            e = launch_rnea_deriv<T>(d, t->deriv_bodies, p->host.n_clusters, p->host.deriv.n_rows, q + b0 * nq, qd + b0 * nv, ydd, Dq, Dqd,
+                                     nb, static_cast<T *>(scratch), static_cast<int>(g2), hs);
+            if (e != hipSuccess) return hip_err(e, "rnea derivative launch");
+        }
+        // one wavefront per state; as many as the LDS of a CU holds
+        const bool wide = sizeof(T) == 4 && p->solve_f64;
+        const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), wide ? 8 : sizeof(T));
+        size_t per_cu = lds ? (160u * 1024u) / lds : 16;
+        if (per_cu > 16) per_cu = 16;
+        if (per_cu < 1) per_cu = 1;
+        size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
+        if (g3 > nb) g3 = nb;
+        T *o1 = dq ? dq + b0 * nn : nullptr, *o2 = dqd ? dqd + b0 * nn : nullptr, *o3 = dtau ? dtau + b0 * nn : nullptr;
+        if constexpr (sizeof(T) == 4) {
+            if (wide) e = launch_spd_solve<float, double>(H, dq ? Dq : nullptr, dqd ? Dqd : nullptr, o3, o1, o2, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
+            else e = launch_spd_solve<float, float>(H, dq ? Dq : nullptr, dqd ? Dqd : nullptr, o3, o1, o2, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
+        } else {
+            e = launch_spd_solve<double, double>(H, dq ? Dq : nullptr, dqd ? Dqd : nullptr, o3, o1, o2, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
+        }
+        if (e != hipSuccess) return hip_err(e, "spd solve launch");
+    }
+    return GRBDA_OK;
+}
+
 // ---- one process, several devices: contiguous batch shards, plan replicated ------------------------
 template <class T>
 int run_sharded(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int n_gpus)
@@ -1229,6 +1325,10 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
     p->chain_debug = env_int("GRBDA_CHAIN_DEBUG", 0);
     p->no_crba = env_int("GRBDA_NO_CRBA", 0) != 0;
+    p->no_analytic = env_int("GRBDA_NO_ANALYTIC", 0) != 0;
+    p->solve_f64 = env_int("GRBDA_SOLVE_F64", 0) != 0;
+    p->deriv_waves = env_int("GRBDA_DERIV_WAVES_PER_CU", 4);
+    if (p->deriv_waves < 1) p->deriv_waves = 1;
     p->no_efpa = env_int("GRBDA_NO_EFPA", 0) != 0;
     LdsBudget lds;
     lds.aba32 = p->lds_bytes_per_wave[0] / (4 * kWave);
@@ -1280,7 +1380,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies);
         for (int w = 0; w < 2; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
         for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
@@ -1396,26 +1496,36 @@ int grbda_mass_matrix_f32(const grbda_plan *p, const float *q, float *H, size_t 
 }
 int grbda_fd_dtau_f64(const grbda_plan *p, const double *q, double *Hinv, size_t B, int device, void *stream)
 {
+    if (p && q && Hinv)
+        if (const int rc = analytic_derivs<double>(p, q, nullptr, nullptr, nullptr, nullptr, Hinv, B, device, stream); rc != 1) return rc;
     return derived<double>(p, DM_DTAU, q, nullptr, nullptr, nullptr, Hinv, B, device, stream);
 }
 int grbda_fd_dtau_f32(const grbda_plan *p, const float *q, float *Hinv, size_t B, int device, void *stream)
 {
+    if (p && q && Hinv)
+        if (const int rc = analytic_derivs<float>(p, q, nullptr, nullptr, nullptr, nullptr, Hinv, B, device, stream); rc != 1) return rc;
     return derived<float>(p, DM_DTAU, q, nullptr, nullptr, nullptr, Hinv, B, device, stream);
 }
 int grbda_fd_dqd_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, double *J, size_t B,
                      int device, void *stream)
 {
+    if (p && q && qd && tau && J)
+        if (const int rc = analytic_derivs<double>(p, q, qd, tau, nullptr, J, nullptr, B, device, stream); rc != 1) return rc;
     return derived<double>(p, DM_DQD, q, qd, tau, nullptr, J, B, device, stream);
 }
 int grbda_fd_dqd_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, float *J, size_t B,
                      int device, void *stream)
 {
+    if (p && q && qd && tau && J)
+        if (const int rc = analytic_derivs<float>(p, q, qd, tau, nullptr, J, nullptr, B, device, stream); rc != 1) return rc;
     return derived<float>(p, DM_DQD, q, qd, tau, nullptr, J, B, device, stream);
 }
 
 int grbda_fd_dq_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, double step, double *J,
                     size_t B, int device, void *stream)
 {
+    if (p && q && qd && tau && J && step > 0)
+        if (const int rc = analytic_derivs<double>(p, q, qd, tau, J, nullptr, nullptr, B, device, stream); rc != 1) return rc;
     return derived<double>(p, DM_DQ, q, qd, tau, nullptr, J, B, device, stream, step);
 }
 int grbda_fd_dq_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, double step, float *J,
@@ -1425,6 +1535,8 @@ int grbda_fd_dq_f32(const grbda_plan *p, const float *q, const float *qd, const 
     // are taken in fp64 on the converted inputs and the matrices converted back.
     if (!p || !q || !qd || !tau || !J) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
+    if (step > 0)
+        if (const int rc = analytic_derivs<float>(p, q, qd, tau, J, nullptr, nullptr, B, device, stream); rc != 1) return rc;
     GRBDA_CALL_SCOPE(p);
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
@@ -1456,6 +1568,28 @@ int grbda_fd_dq_f32(const grbda_plan *p, const float *q, const float *qd, const 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_err(e, "convert launch");
     }
+    return GRBDA_OK;
+}
+int grbda_fd_derivatives_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, double *dq, double *dqd,
+                             double *dtau, size_t B, int device, void *stream)
+{
+    if (!p || !q || !qd || !tau) return set_err(GRBDA_EINVAL, "null argument");
+    const int rc = analytic_derivs<double>(p, q, qd, tau, dq, dqd, dtau, B, device, stream);
+    if (rc != 1) return rc;
+    if (dtau) if (const int r2 = grbda_fd_dtau_f64(p, q, dtau, B, device, stream)) return r2;
+    if (dqd) if (const int r2 = grbda_fd_dqd_f64(p, q, qd, tau, dqd, B, device, stream)) return r2;
+    if (dq) if (const int r2 = grbda_fd_dq_f64(p, q, qd, tau, 1e-6, dq, B, device, stream)) return r2;
+    return GRBDA_OK;
+}
+int grbda_fd_derivatives_f32(const grbda_plan *p, const float *q, const float *qd, const float *tau, float *dq, float *dqd, float *dtau,
+                             size_t B, int device, void *stream)
+{
+    if (!p || !q || !qd || !tau) return set_err(GRBDA_EINVAL, "null argument");
+    const int rc = analytic_derivs<float>(p, q, qd, tau, dq, dqd, dtau, B, device, stream);
+    if (rc != 1) return rc;
+    if (dtau) if (const int r2 = grbda_fd_dtau_f32(p, q, dtau, B, device, stream)) return r2;
+    if (dqd) if (const int r2 = grbda_fd_dqd_f32(p, q, qd, tau, dqd, B, device, stream)) return r2;
+    if (dq) if (const int r2 = grbda_fd_dq_f32(p, q, qd, tau, 1e-6, dq, B, device, stream)) return r2;
     return GRBDA_OK;
 }
 int grbda_body_poses_f64(const grbda_plan *p, const double *q, double *Xa, size_t B, int device, void *stream)

@@ -1,0 +1,718 @@
+// deriv_kernels.hip -- first-order derivatives of the cluster dynamics (BASELINE config 5: d ydd / d q, d qd, d tau).
+//
+// The reference has no derivative ALGORITHM: it differentiates CasADi graphs of its forward dynamics and validates them
+// against central differences (UnitTests/testForwardDynamicsDerivatives.cpp, testHelpers.hpp:50-112).  Here:
+//   ydd = FD(q, qd, tau)                                              (chain_kernels.hip / kernels.hip)
+//   Dq = d ID / d q, Dqd = d ID / d qd at (q, qd, ydd)                 rnea_deriv_kernel, analytic, one state per lane
+//   H                                                                 crba_kernels.hip
+//   d ydd / d tau = H^-1,  d ydd / d q = -H^-1 Dq,  d ydd / d qd = -H^-1 Dqd      spd_solve_kernel, one state per wavefront
+// (ID(q, qd, FD(q, qd, tau)) = tau differentiated).  Explicit (constant G) clusters only; models with implicit loops keep
+// the central differences of capi.cpp.
+//
+// Inverse-dynamics derivatives.  The recursion is the spatial-vector form of the RNEA derivatives (Carpentier & Mansard,
+// RSS 2018; Singh, Russell & Wensing, RA-L 2022) applied to the SPANNING tree, every body a 1-DoF revolute joint (plus
+// the free base), and then projected with the clusters' constant G:  d tau_y / d y = G^T (d tau_span / d q_span) G.
+// All spatial quantities are expressed in ONE inertial frame F that coincides with the floating base at this instant
+// (the world for fixed-base models), so composite quantities add without transforms and an entry of the result is a dot
+// product of a descendant-side and an ancestor-side 6-vector.  With S_j the joint axis, Sd_j = v_j x S_j,
+// Pd_j = v_parent x S_j (= Sd_j for a revolute joint), Pdd_j = a_parent x S_j + v_parent x Pd_j and, per body,
+// B_i = (v x*) I - I (v x) + (I v) xbar*,  Ic / Bc / Fc the sums of I, B, f = I a + v x* I v over the subtree:
+//    j ancestor of or equal to k:  d tau_k / d q_j  = Pd_j . (Bc_k^T S_k) + Pdd_j . (Ic_k S_k)
+//                                  d tau_k / d qd_j = S_j . (Bc_k^T S_k) + (Sd_j + Pd_j) . (Ic_k S_k)
+//    k strict ancestor of j:       d tau_k / d q_j  = S_k . (S_j x* Fc_j + Bc_j Pd_j + Ic_j Pdd_j)
+//                                  d tau_k / d qd_j = S_k . (Bc_j S_j + Ic_j (Sd_j + Pd_j))
+// The columns of the free base are the body-frame twists of the reference's tangent step (pos += R^T d,
+// quat += quat (x) (0, d) / 2): S = 1, Sd = v x 1, Pd = 0, Pdd = a_0 x 1 with a_0 = -gravity seen from the base.
+// tools/proto_rnea_derivs.py is the numpy statement of the same recursion, checked against differences of the oracle.
+#include <hip/hip_runtime.h>
+
+#include "devplan.h"
+
+namespace grbda_hip {
+
+#include "devmath.h"
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// spatial helpers in the common frame
+// ---------------------------------------------------------------------------------------------------------------
+// motion cross product a x b
+template <class T>
+__device__ __forceinline__ void crm(const T (&a)[6], const T (&b)[6], T (&o)[6])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+    o[3] = a[1] * b[5] - a[2] * b[4] + a[4] * b[2] - a[5] * b[1];
+    o[4] = a[2] * b[3] - a[0] * b[5] + a[5] * b[0] - a[3] * b[2];
+    o[5] = a[0] * b[4] - a[1] * b[3] + a[3] * b[1] - a[4] * b[0];
+}
+template <class T>
+__device__ __forceinline__ T dot6(const T (&a)[6], const T (&b)[6])
+{
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+// y = M x, y = M^T x for a row-major 6 x 6
+template <class T>
+__device__ __forceinline__ void mv6(const T (&M)[36], const T (&x)[6], T (&y)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) s += M[6 * i + j] * x[j];
+        y[i] = s;
+    }
+}
+template <class T>
+__device__ __forceinline__ void mtv6(const T (&M)[36], const T (&x)[6], T (&y)[6])
+{
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        T s = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) s += M[6 * i + j] * x[i];
+        y[j] = s;
+    }
+}
+// B = (v x*) I - I (v x) + (I v) xbar*, column by column: B e_j = v x* (I e_j) - I (v x e_j) + e_j x* (I v)
+template <class T>
+__device__ __forceinline__ void body_B(const T (&I)[21], const T (&v)[6], const T (&h)[6], T (&Bm)[36])
+{
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        T e[6], col[6], c1[6], ve[6], c2[6], c3[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            e[i] = i == j ? T(1) : T(0);
+            col[i] = I[sidx(i, j)];
+        }
+        crf(v, col, c1);
+        crm(v, e, ve);
+        symv(I, ve, c2);
+        crf(e, h, c3);
+#pragma unroll
+        for (int i = 0; i < 6; i++) Bm[6 * i + j] = c1[i] - c2[i] + c3[i];
+    }
+}
+
+// slab rows of one lane
+template <class T>
+struct Rows {
+    T *p;  // slab + lane
+    template <int N>
+    __device__ __forceinline__ void ld(int row, T (&x)[N]) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = p[(size_t)(row + i) * kWave];
+    }
+    template <int N>
+    __device__ __forceinline__ void st(int row, const T (&x)[N]) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++) p[(size_t)(row + i) * kWave] = x[i];
+    }
+};
+
+// kinematics of a revolute body in F from its parent's: E, p (F -> body), v, a, S, Sd = v x S, Pdd = a_p x S + v_p x Sd
+template <class T>
+__device__ __forceinline__ void deriv_kin(cptr<T> C, bool axisym, T qi, T qdi, T qddi, const T (&Ep)[9], const T (&pp)[3],
+                                          const T (&vp)[6], const T (&ap)[6], T (&E)[9], T (&p)[3], T (&v)[6], T (&a)[6], T (&S)[6],
+                                          T (&Sd)[6], T (&Pdd)[6])
+{
+    T sn = 0, cs = 1, El[9];
+    if (!axisym) sincos_t(qi, &sn, &cs);   // a rotor's inertia, axis and velocity in F do not depend on its own angle
+    rotate_z(sn, cs, C, El);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) E[3 * i + j] = El[3 * i] * Ep[j] + El[3 * i + 1] * Ep[3 + j] + El[3 * i + 2] * Ep[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = pp[i] + Ep[i] * C[9] + Ep[3 + i] * C[10] + Ep[6 + i] * C[11];
+    // joint axis: the body's z axis seen from F, through the body origin
+    S[0] = E[6]; S[1] = E[7]; S[2] = E[8];
+    S[3] = p[1] * S[2] - p[2] * S[1];
+    S[4] = p[2] * S[0] - p[0] * S[2];
+    S[5] = p[0] * S[1] - p[1] * S[0];
+    crm(vp, S, Sd);
+    T t[6];
+    crm(ap, S, Pdd);
+    crm(vp, Sd, t);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        Pdd[j] += t[j];
+        v[j] = vp[j] + S[j] * qdi;
+        a[j] = ap[j] + S[j] * qddi + Sd[j] * qdi;
+    }
+}
+
+#ifndef GRBDA_DERIV_WAVES
+#define GRBDA_DERIV_WAVES 1
+#endif
+template <class T>
+__global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
+                                                              const T *__restrict__ q, const T *__restrict__ qd,
+                                                              const T *__restrict__ ydd, T *__restrict__ Dq, T *__restrict__ Dqd,
+                                                              size_t B, T *__restrict__ scratch)
+{
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
+    cptr<T> consts = (cptr<T>)DP.consts;
+    cptr<DerivBody> db = (cptr<DerivBody>)db_;
+    const int lane = threadIdx.x, nq = DP.nq, nv = DP.nv;
+    Rows<T> R;
+    R.p = scratch + (size_t)blockIdx.x * (size_t)n_rows * kWave + lane;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + lane;
+        const size_t st = r < B ? r : B - 1;  // lanes past the end redo the last state and do not store
+#ifdef GRBDA_EXP_NO_STORE
+        const bool live = r < B && DP.nq < 0;
+#else
+        const bool live = r < B;
+#endif
+        const T *qs = q + st * (size_t)nq, *qds = qd + st * (size_t)nv, *ydds = ydd + st * (size_t)nv;
+        T *Dqs = Dq + st * (size_t)nv * nv, *Dqds = Dqd + st * (size_t)nv * nv;
+        // gravity as the acceleration of the frame F (TreeModel.cpp:40-43: a_root = -gravity), base velocity
+        T a0[6], vb[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            a0[j] = DP.a_root[j];
+            vb[j] = 0;
+        }
+        // ---- pass 1, root side first: kinematics in F of every body that has children ----
+        for (int c = 0; c < n_clusters; c++) {
+            const ClusterRec cr = load_rec(clusters + c);
+            if (cr.kind == CK_FREE) {
+                T o[4], Eb[9], rb[3], g[6], kin[24];
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = qs[cr.q_index + 3 + j];
+                free_rotation(0, o, Eb);
+#pragma unroll
+                for (int j = 0; j < 3; j++) rb[j] = qs[cr.q_index + j];
+#pragma unroll
+                for (int j = 0; j < 6; j++) g[j] = DP.a_root[j];
+                xmotion(Eb, rb, g, a0);
+#pragma unroll
+                for (int j = 0; j < 9; j++) kin[j] = (j % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+                for (int j = 0; j < 3; j++) kin[9 + j] = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    vb[j] = qds[cr.v_index + j];
+                    kin[12 + j] = vb[j];
+                    kin[18 + j] = a0[j] + ydds[cr.v_index + j];
+                }
+                const DerivBody x = load_rec(db + cr.first_body);
+                if (x.kin_row >= 0) R.st(x.kin_row, kin);
+                continue;
+            }
+            for (int i = 0; i < cr.k; i++) {
+                if (!((cr.child_mask >> i) & 1)) continue;
+                const int gb = cr.first_body + i;
+                const BodyRec b = load_rec(bodies + gb);
+                const DerivBody x = load_rec(db + gb);
+                cptr<T> C = consts + b.cofs;
+                T qi = 0, qdi = 0, qddi = 0;
+                for (int a2 = 0; a2 < cr.n; a2++) {
+                    const T g = C[kBodyConstFixed + a2];
+                    qi += g * qs[cr.q_index + a2];
+                    qdi += g * qds[cr.v_index + a2];
+                    qddi += g * ydds[cr.v_index + a2];
+                }
+                T kp[24];
+                if (b.parent >= 0) {
+                    const DerivBody xp = load_rec(db + b.parent);
+                    R.ld(xp.kin_row, kp);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 9; j++) kp[j] = (j % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+                    for (int j = 9; j < 18; j++) kp[j] = 0;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) kp[18 + j] = a0[j];
+                }
+                T Ep[9], pp[3], vp[6], ap[6], kin[24], anc[18];
+#pragma unroll
+                for (int j = 0; j < 9; j++) Ep[j] = kp[j];
+#pragma unroll
+                for (int j = 0; j < 3; j++) pp[j] = kp[9 + j];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    vp[j] = kp[12 + j];
+                    ap[j] = kp[18 + j];
+                }
+                T E[9], p3[3], v[6], a[6], S[6], Sd[6], Pdd[6];
+                deriv_kin(C, false, qi, qdi, qddi, Ep, pp, vp, ap, E, p3, v, a, S, Sd, Pdd);
+#pragma unroll
+                for (int j = 0; j < 9; j++) kin[j] = E[j];
+#pragma unroll
+                for (int j = 0; j < 3; j++) kin[9 + j] = p3[j];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    kin[12 + j] = v[j];
+                    kin[18 + j] = a[j];
+                    anc[j] = S[j];
+                    anc[6 + j] = Sd[j];
+                    anc[12 + j] = Pdd[j];
+                }
+                R.st(x.kin_row, kin);
+                R.st(x.anc_row, anc);
+            }
+        }
+        // ---- pass 2, leaf side first ----
+        for (int c = n_clusters - 1; c >= 0; c--) {
+            const ClusterRec cr = load_rec(clusters + c);
+            if (cr.kind == CK_FREE) {
+                // base: E = 1, p = 0; S = 1, Sd = v x 1, Pd = 0, Pdd = a0 x 1; every pair of its columns counts as "ancestor or equal"
+                const BodyRec b = load_rec(bodies + cr.first_body);
+                const DerivBody x = load_rec(db + cr.first_body);
+                cptr<T> Ib = consts + b.cofs + 12;
+                T Ic[21], Bc[36], h[6];
+#pragma unroll
+                for (int j = 0; j < 21; j++) Ic[j] = Ib[j];
+                symv(Ic, vb, h);
+                body_B(Ic, vb, h, Bc);
+                if (x.acc_row >= 0) {
+                    T acc[57];
+                    R.ld(x.acc_row, acc);
+#pragma unroll
+                    for (int j = 0; j < 21; j++) Ic[j] += acc[j];
+#pragma unroll
+                    for (int j = 0; j < 36; j++) Bc[j] += acc[21 + j];
+                }
+                // d tau_b / d q_b = Ic crm(a0), d tau_b / d qd_b = Bc + Ic crm(vb)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    T e[6], c1[6], c2[6], y1[6], y2[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) e[i] = i == j ? T(1) : T(0);
+                    crm(a0, e, c1);
+                    crm(vb, e, c2);
+                    symv(Ic, c1, y1);
+                    symv(Ic, c2, y2);
+                    if (live) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++) {
+                            Dqs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = y1[i];
+                            Dqds[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Bc[6 * i + j] + y2[i];
+                        }
+                    }
+                }
+                continue;
+            }
+            const int n = cr.n;
+            // cluster-level descendant-side vectors and the contribution to the parent body's accumulator
+            T T1[kMaxClusterDof][6], T2[kMaxClusterDof][6], T3[kMaxClusterDof][6], T4[kMaxClusterDof][6];
+            T Cq[kMaxClusterDof][kMaxClusterDof], Cqd[kMaxClusterDof][kMaxClusterDof];
+            T part[63];
+#pragma unroll
+            for (int j = 0; j < 63; j++) part[j] = 0;
+#pragma unroll
+            for (int a2 = 0; a2 < kMaxClusterDof; a2++) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) T1[a2][j] = T2[a2][j] = T3[a2][j] = T4[a2][j] = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < kMaxClusterDof; b2++) Cq[a2][b2] = Cqd[a2][b2] = 0;
+            }
+            for (int i = cr.k - 1; i >= 0; i--) {
+                const int gb = cr.first_body + i;
+                const BodyRec b = load_rec(bodies + gb);
+                const DerivBody x = load_rec(db + gb);
+                cptr<T> C = consts + b.cofs;
+                T Gi[kMaxClusterDof];
+#pragma unroll
+                for (int a2 = 0; a2 < kMaxClusterDof; a2++) Gi[a2] = a2 < n ? C[kBodyConstFixed + a2] : T(0);
+                T E[9], p3[3], v[6], a[6], S[6], Sd[6], Pdd[6];
+                if (x.kin_row >= 0) {
+                    T kin[24], anc[18];
+                    R.ld(x.kin_row, kin);
+                    R.ld(x.anc_row, anc);
+#pragma unroll
+                    for (int j = 0; j < 9; j++) E[j] = kin[j];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) p3[j] = kin[9 + j];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        v[j] = kin[12 + j];
+                        a[j] = kin[18 + j];
+                        S[j] = anc[j];
+                        Sd[j] = anc[6 + j];
+                        Pdd[j] = anc[12 + j];
+                    }
+                } else {
+                    T qi = 0, qdi = 0, qddi = 0;
+#pragma unroll
+                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                        if (a2 < n) {
+                            qi += Gi[a2] * qs[cr.q_index + a2];
+                            qdi += Gi[a2] * qds[cr.v_index + a2];
+                            qddi += Gi[a2] * ydds[cr.v_index + a2];
+                        }
+                    T kp[24];
+                    if (b.parent >= 0) {
+                        const DerivBody xp = load_rec(db + b.parent);
+                        R.ld(xp.kin_row, kp);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 9; j++) kp[j] = (j % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+                        for (int j = 9; j < 18; j++) kp[j] = 0;
+#pragma unroll
+                        for (int j = 0; j < 6; j++) kp[18 + j] = a0[j];
+                    }
+                    T Ep[9], pp[3], vp[6], ap[6];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) Ep[j] = kp[j];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) pp[j] = kp[9 + j];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        vp[j] = kp[12 + j];
+                        ap[j] = kp[18 + j];
+                    }
+                    deriv_kin(C, b.axisym != 0, qi, qdi, qddi, Ep, pp, vp, ap, E, p3, v, a, S, Sd, Pdd);
+                }
+                // body inertia, force and B in F; composites
+                T Ic[21], Bc[36], Fc[6], h[6];
+                congruence(E, p3, C + 12, Ic);
+                symv(Ic, v, h);
+                {
+                    T Ia[6], vh[6];
+                    symv(Ic, a, Ia);
+                    crf(v, h, vh);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) Fc[j] = Ia[j] + vh[j];
+                }
+                body_B(Ic, v, h, Bc);
+                if (x.acc_row >= 0) {
+                    T acc[63];
+                    R.ld(x.acc_row, acc);
+#pragma unroll
+                    for (int j = 0; j < 21; j++) Ic[j] += acc[j];
+#pragma unroll
+                    for (int j = 0; j < 36; j++) Bc[j] += acc[21 + j];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) Fc[j] += acc[57 + j];
+                }
+                // descendant-side vectors of this joint (Pd = Sd for a revolute joint)
+                T t1[6], t2[6], t3[6], t4[6];
+                mtv6(Bc, S, t1);
+                symv(Ic, S, t2);
+                {
+                    T u1[6], u2[6], u3[6], u4[6];
+                    mv6(Bc, S, u1);
+                    symv(Ic, Sd, u2);
+                    crf(S, Fc, u3);
+                    mv6(Bc, Sd, u4);
+                    T u5[6];
+                    symv(Ic, Pdd, u5);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        t3[j] = u1[j] + 2 * u2[j];
+                        t4[j] = u3[j] + u4[j] + u5[j];
+                    }
+                }
+                // the joint with itself
+                {
+                    const T sq = dot6(Sd, t1) + dot6(Pdd, t2), sqd = dot6(S, t1) + 2 * dot6(Sd, t2);
+#pragma unroll
+                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+#pragma unroll
+                        for (int b2 = 0; b2 < kMaxClusterDof; b2++) {
+                            Cq[a2][b2] += Gi[a2] * Gi[b2] * sq;
+                            Cqd[a2][b2] += Gi[a2] * Gi[b2] * sqd;
+                        }
+                }
+                // in-cluster ancestors
+                int l = b.lam;
+                while (l >= 0) {
+                    const BodyRec bl = load_rec(bodies + l);
+                    const DerivBody xl = load_rec(db + l);
+                    cptr<T> Cl = consts + bl.cofs;
+                    T anc[18], Sl[6], Sdl[6], Pddl[6], Gl[kMaxClusterDof];
+                    R.ld(xl.anc_row, anc);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        Sl[j] = anc[j];
+                        Sdl[j] = anc[6 + j];
+                        Pddl[j] = anc[12 + j];
+                    }
+#pragma unroll
+                    for (int a2 = 0; a2 < kMaxClusterDof; a2++) Gl[a2] = a2 < n ? Cl[kBodyConstFixed + a2] : T(0);
+                    const T kq = dot6(Sdl, t1) + dot6(Pddl, t2), kqd = dot6(Sl, t1) + 2 * dot6(Sdl, t2);  // (k = this body, j = l)
+                    const T lq = dot6(Sl, t4), lqd = dot6(Sl, t3);                                          // (k = l, j = this body)
+#pragma unroll
+                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+#pragma unroll
+                        for (int b2 = 0; b2 < kMaxClusterDof; b2++) {
+                            Cq[a2][b2] += Gi[a2] * Gl[b2] * kq + Gl[a2] * Gi[b2] * lq;
+                            Cqd[a2][b2] += Gi[a2] * Gl[b2] * kqd + Gl[a2] * Gi[b2] * lqd;
+                        }
+                    l = bl.lam;
+                }
+#pragma unroll
+                for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        T1[a2][j] += Gi[a2] * t1[j];
+                        T2[a2][j] += Gi[a2] * t2[j];
+                        T3[a2][j] += Gi[a2] * t3[j];
+                        T4[a2][j] += Gi[a2] * t4[j];
+                    }
+                // composites to the tree parent
+                if (b.lam >= 0) {
+                    const DerivBody xl = load_rec(db + b.lam);
+                    T acc[63];
+                    if (x.acc_first) {
+#pragma unroll
+                        for (int j = 0; j < 63; j++) acc[j] = 0;
+                    } else {
+                        R.ld(xl.acc_row, acc);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 21; j++) acc[j] += Ic[j];
+#pragma unroll
+                    for (int j = 0; j < 36; j++) acc[21 + j] += Bc[j];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) acc[57 + j] += Fc[j];
+                    R.st(xl.acc_row, acc);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 21; j++) part[j] += Ic[j];
+#pragma unroll
+                    for (int j = 0; j < 36; j++) part[21 + j] += Bc[j];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) part[57 + j] += Fc[j];
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+#pragma unroll
+                    for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                        if (a2 < n && b2 < n) {
+                            Dqs[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cq[a2][b2];
+                            Dqds[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cqd[a2][b2];
+                        }
+            }
+#ifdef GRBDA_EXP_NO_ACC
+            if (cr.parent_body >= 0 && nq < 0) {
+#else
+            if (cr.parent_body >= 0) {
+#endif
+                const DerivBody xf = load_rec(db + cr.first_body);
+                const DerivBody xp = load_rec(db + cr.parent_body);
+                if (!xf.cluster_acc_first) {
+                    T acc[63];
+                    R.ld(xp.acc_row, acc);
+#pragma unroll
+                    for (int j = 0; j < 63; j++) part[j] += acc[j];
+                }
+                R.st(xp.acc_row, part);
+            }
+            // ---- up the ancestors outside the cluster, block by block ----
+#ifdef GRBDA_EXP_NO_WALK
+            int j = -1;
+#else
+            int j = cr.parent_body;
+#endif
+            while (j >= 0) {
+                const DerivBody xj = load_rec(db + j);
+                const ClusterRec cd = load_rec(clusters + xj.cluster);
+                if (cd.kind == CK_FREE) {
+#pragma unroll
+                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                        if (a2 < n) {
+                            T w1[6], w2[6];
+                            crf(a0, T2[a2], w1);   // (a0 x e_k) . t = -(a0 x* t)_k
+                            crf(vb, T2[a2], w2);
+                            if (live) {
+#pragma unroll
+                                for (int k6 = 0; k6 < 6; k6++) {
+                                    Dqs[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = -w1[k6];
+                                    Dqds[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = T1[a2][k6] - w2[k6];
+                                    Dqs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T4[a2][k6];
+                                    Dqds[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T3[a2][k6];
+                                }
+                            }
+                        }
+                    break;
+                }
+                T Bq[kMaxClusterDof][kMaxClusterDof], Bqd[kMaxClusterDof][kMaxClusterDof];   // [c][d]
+                T Uq[kMaxClusterDof][kMaxClusterDof], Uqd[kMaxClusterDof][kMaxClusterDof];   // [d][c]
+#pragma unroll
+                for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+#pragma unroll
+                    for (int b2 = 0; b2 < kMaxClusterDof; b2++) Bq[a2][b2] = Bqd[a2][b2] = Uq[a2][b2] = Uqd[a2][b2] = 0;
+                int jj = j, next = -1;
+                for (;;) {
+                    const BodyRec bb = load_rec(bodies + jj);
+                    const DerivBody xb = load_rec(db + jj);
+                    cptr<T> Cj = consts + bb.cofs;
+                    T anc[18], Sj[6], Sdj[6], Pddj[6];
+                    R.ld(xb.anc_row, anc);
+#pragma unroll
+                    for (int i2 = 0; i2 < 6; i2++) {
+                        Sj[i2] = anc[i2];
+                        Sdj[i2] = anc[6 + i2];
+                        Pddj[i2] = anc[12 + i2];
+                    }
+#pragma unroll
+                    for (int a2 = 0; a2 < kMaxClusterDof; a2++) {
+                        const T eq = dot6(Sdj, T1[a2]) + dot6(Pddj, T2[a2]), eqd = dot6(Sj, T1[a2]) + 2 * dot6(Sdj, T2[a2]);
+                        const T uq = dot6(Sj, T4[a2]), uqd = dot6(Sj, T3[a2]);
+#pragma unroll
+                        for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                            if (b2 < cd.n) {
+                                const T g = Cj[kBodyConstFixed + b2];
+                                Bq[a2][b2] += eq * g;
+                                Bqd[a2][b2] += eqd * g;
+                                Uq[b2][a2] += uq * g;
+                                Uqd[b2][a2] += uqd * g;
+                            }
+                    }
+                    next = bb.parent;
+                    if (bb.lam < 0) break;  // left the cluster
+                    jj = bb.lam;
+                }
+                if (live) {
+#pragma unroll
+                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+#pragma unroll
+                        for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                            if (a2 < n && b2 < cd.n) {
+                                Dqs[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bq[a2][b2];
+                                Dqds[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bqd[a2][b2];
+                                Dqs[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Uq[b2][a2];
+                                Dqds[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Uqd[b2][a2];
+                            }
+                }
+                j = next;
+            }
+        }
+        // entries between clusters on different branches are structural zeros (the arrays are cleared by the caller)
+    }
+}
+
+template <class T>
+hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, const T *q, const T *qd, const T *ydd,
+                             T *Dq, T *Dqd, size_t B, T *scratch, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((rnea_deriv_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq, Dqd, B,
+                       scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_rnea_deriv<float>(const DevPlan<float> &, const DerivBody *, int, int, const float *, const float *,
+                                             const float *, float *, float *, size_t, float *, int, hipStream_t);
+template hipError_t launch_rnea_deriv<double>(const DevPlan<double> &, const DerivBody *, int, int, const double *, const double *,
+                                              const double *, double *, double *, size_t, double *, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched SPD solve, one state per wavefront, entirely in registers.  Lane i holds row i of H, then of its Cholesky
+// factor L (left-looking by columns: the entry L[k][m] another row needs comes from lane k by v_readlane, a scalar
+// operand); for the triangular solves every lane carries one right-hand-side column and the factor is again read
+// through v_readlane, so neither LDS nor shuffles are involved.  NV is the compile-time size the loops are unrolled
+// for (nv <= NV <= 64; H is padded with the identity).  Right-hand sides: the nv columns of R1, of R2 and of the
+// identity (H^-1), each optional, 64 columns per pass; results are scaled by -1 for R1 / R2 (-H^-1 D).
+// Global traffic: every matrix read / written once, rows contiguous.  TIO: array element type; TC: arithmetic type.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_value(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+__device__ __forceinline__ double lane_value(double x, int l)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <class TIO, class TC, int NV>
+__global__ __launch_bounds__(kWave) void spd_solve_kernel(const TIO *__restrict__ H, const TIO *__restrict__ R1, const TIO *__restrict__ R2,
+                                                         TIO *__restrict__ Hinv, TIO *__restrict__ X1, TIO *__restrict__ X2, int nv,
+                                                         size_t B)
+{
+    const int lane = threadIdx.x;
+    const size_t nn = (size_t)nv * nv;
+    for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
+        TC Lr[NV], dinv[NV];
+        {
+            const TIO *row = H + s * nn + (size_t)(lane < nv ? lane : 0) * nv;
+#pragma unroll
+            for (int j = 0; j < NV; j++) Lr[j] = (lane < nv && j < nv) ? (TC)row[j < nv ? j : 0] : (lane == j ? TC(1) : TC(0));
+        }
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            TC sum = Lr[k];
+#pragma unroll
+            for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
+            const TC d = lane_value(sum, k);
+            const TC r = TC(1) / sqrt(d);
+            Lr[k] = sum * r;
+            dinv[k] = r;
+        }
+        const int n1 = R1 ? nv : 0, n2 = R2 ? nv : 0, n3 = Hinv ? nv : 0;
+        for (int c0 = 0; c0 < n1 + n2 + n3; c0 += kWave) {
+            const int col = c0 + lane;
+            const TIO *src = nullptr;
+            TIO *dst = nullptr;
+            int j = 0;
+            TC scale = 1;
+            if (col < n1) { src = R1 + s * nn; dst = X1 + s * nn; j = col; scale = -1; }
+            else if (col < n1 + n2) { src = R2 + s * nn; dst = X2 + s * nn; j = col - n1; scale = -1; }
+            else if (col < n1 + n2 + n3) { dst = Hinv + s * nn; j = col - n1 - n2; }
+            TC x[NV];
+#pragma unroll
+            for (int i = 0; i < NV; i++) x[i] = (dst && i < nv) ? (src ? (TC)src[(size_t)i * nv + j] : (i == j ? TC(1) : TC(0))) : TC(0);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                TC acc = x[i];
+#pragma unroll
+                for (int m2 = 0; m2 < i; m2++) acc -= lane_value(Lr[m2], i) * x[m2];
+                x[i] = acc * dinv[i];
+            }
+#pragma unroll
+            for (int i = NV - 1; i >= 0; i--) {
+                TC acc = x[i];
+#pragma unroll
+                for (int m2 = i + 1; m2 < NV; m2++) acc -= lane_value(Lr[i], m2) * x[m2];
+                x[i] = acc * dinv[i];
+            }
+            if (dst) {
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+                    if (i < nv) dst[(size_t)i * nv + j] = (TIO)(scale * x[i]);
+            }
+        }
+    }
+}
+
+template <class TIO, class TC, int NV>
+static hipError_t launch_spd_solve_n(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
+                                     hipStream_t stream)
+{
+    hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV>), dim3(grid), dim3(kWave), 0, stream, H, R1, R2, Hinv, X1, X2, nv, B);
+    return hipGetLastError();
+}
+template <class TIO, class TC>
+hipError_t launch_spd_solve(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
+                            hipStream_t stream)
+{
+    if (nv <= 16) return launch_spd_solve_n<TIO, TC, 16>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
+    if (nv <= 24) return launch_spd_solve_n<TIO, TC, 24>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
+    if (nv <= 32) return launch_spd_solve_n<TIO, TC, 32>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
+    if (nv <= 40) return launch_spd_solve_n<TIO, TC, 40>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
+    if (nv <= 48) return launch_spd_solve_n<TIO, TC, 48>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
+    if (nv <= 64) return launch_spd_solve_n<TIO, TC, 64>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
+    return hipErrorInvalidValue;
+}
+template hipError_t launch_spd_solve<float, float>(const float *, const float *, const float *, float *, float *, float *, int, size_t, int,
+                                                   hipStream_t);
+template hipError_t launch_spd_solve<float, double>(const float *, const float *, const float *, float *, float *, float *, int, size_t, int,
+                                                    hipStream_t);
+template hipError_t launch_spd_solve<double, double>(const double *, const double *, const double *, double *, double *, double *, int,
+                                                     size_t, int, hipStream_t);
+
+size_t spd_solve_lds_bytes(int, size_t) { return 0; }
+
+hipError_t set_max_dynamic_lds_deriv() { return hipSuccess; }
+
+}  // namespace grbda_hip

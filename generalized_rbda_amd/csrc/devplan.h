@@ -120,4 +120,14 @@ template <class T>
 hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,
                        int grid, hipStream_t stream);
 
+// inverse-dynamics derivatives and the batched SPD solve behind d ydd / d (q, qd, tau) (deriv_kernels.hip)
+template <class T>
+hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, const T *q, const T *qd, const T *ydd,
+                             T *Dq, T *Dqd, size_t B, T *scratch, int grid, hipStream_t stream);
+template <class TIO, class TC>
+hipError_t launch_spd_solve(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
+                            hipStream_t stream);
+size_t spd_solve_lds_bytes(int nv, size_t elem);
+hipError_t set_max_dynamic_lds_deriv();
+
 }  // namespace grbda_hip

@@ -1490,6 +1490,56 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         CR.n_rows = rows;
     }
 
+    // ---- inverse-dynamics derivative program (deriv_kernels.hip) -----------------------------------------------------
+    {
+        DerivProgram &DV = P.deriv;
+        DV = DerivProgram();
+        DV.ok = sweep_mask == 7;
+        for (const ClusterRec &cr : clusters) {
+            if (cr.kind == CK_LOOP) DV.ok = false;
+            if (cr.kind == CK_FREE && (P.ori_repr != GRBDA_ORI_QUATERNION || cr.first_body != 0)) DV.ok = false;
+        }
+        DV.bodies.assign(nb, DerivBody{0, -1, -1, -1, 0, 0, {0, 0}});
+        int rows = 0;
+        for (int b = 0; b < nb; b++) {
+            DV.bodies[b].cluster = m.bodies[b].cluster;
+            if (!bodies[b].has_child) continue;
+            DV.bodies[b].kin_row = rows;
+            rows += 24;
+            if (bodies[b].jtype != GRBDA_JOINT_FREE) {
+                DV.bodies[b].anc_row = rows;
+                rows += 18;
+            }
+        }
+        // accumulators: written by the child clusters (one combined write each, highest cluster first) and by in-cluster
+        // children, read when the body itself is processed; rows are shared between accumulators that are never live together
+        std::vector<int> birth(nb, -1), death(nb, -1);
+        int step = 0;
+        for (int c = nc - 1; c >= 0; c--) {
+            const ClusterRec &cr = clusters[c];
+            for (int i = cr.k - 1; i >= 0; i--, step++) {
+                const int b = cr.first_body + i;
+                death[b] = step;
+                if (bodies[b].lam >= 0 && birth[bodies[b].lam] < 0) {
+                    birth[bodies[b].lam] = step;
+                    DV.bodies[b].acc_first = 1;
+                }
+            }
+            if (cr.parent_body >= 0 && birth[cr.parent_body] < 0) {
+                birth[cr.parent_body] = step - 1;
+                DV.bodies[cr.first_body].cluster_acc_first = 1;
+            }
+        }
+        std::vector<Obj> aobjs;
+        for (int b = 0; b < nb; b++)
+            if (bodies[b].has_child) aobjs.push_back({&DV.bodies[b].acc_row, 63, 0, birth[b], death[b], -1, 1});
+        int n_acc = 0, n_unused = 0;
+        allocate(aobjs, 1 << 28, n_acc, n_unused);
+        for (int b = 0; b < nb; b++)
+            if (DV.bodies[b].acc_row >= 0) DV.bodies[b].acc_row += rows;
+        DV.n_rows = rows + n_acc;
+    }
+
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------
     // per-body costs: sincos ~40, E build 12, motion / force transform 39, sym6*vec 66 (48 against a
     // revolute velocity product, two zero entries), force cross 30, congruence 385, plus the per-cluster

@@ -323,6 +323,22 @@ struct CrbaProgram {
     int n_rows = 0;
 };
 
+// inverse-dynamics derivatives (deriv_kernels.hip): per body, where its per-state rows live in the wave's slab
+struct DerivBody {     // 8 ints
+    int32_t cluster;
+    int32_t kin_row;    // bodies with children: 24 rows [E 9][p 3][v 6][a 6], transform from / motion in the common frame F; else -1
+    int32_t anc_row;    // revolute bodies with children: 18 rows [S 6][Sd 6][Pdd 6]; else -1
+    int32_t acc_row;    // bodies with children: 63 rows [Ic 21][Bc 36][Fc 6], composite sums over the descendants; else -1
+    int32_t acc_first;  // this body is the first writer of the accumulator of its in-cluster parent
+    int32_t cluster_acc_first;  // (first body of a cluster) the cluster is the first writer of the accumulator of its parent body
+    int32_t reserved[2];
+};
+struct DerivProgram {
+    bool ok = false;  // explicit (constant G) clusters, quaternion or no floating base
+    std::vector<DerivBody> bodies;
+    int n_rows = 0;
+};
+
 // LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
 // wavefronts per CU and more state in the global slab; the best trade differs per kernel.
 struct LdsBudget {
@@ -345,6 +361,7 @@ struct HostPlan {
     ChainProgram chain32w;    // the same laid out for four wavefronts per SIMD (half the LDS per wavefront)
     ChainProgram chain64;     // f64 ABA (slots are twice as large: the LDS budget holds half as many)
     CrbaProgram crba;
+    DerivProgram deriv;
     RneaChainProgram rchain32, rchain64;  // inverse dynamics on the chains
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;

@@ -143,6 +143,14 @@ int grbda_rnea_f32(const grbda_plan *plan, const float *q, const float *qd, cons
  *                     pos += R^T d, quat += quat x (0, d) / 2):       testRigidBodyDynamicsAlgosDerivatives.cpp:
  *                     column j = (ABA(q + h e_j) - ABA(q - h e_j))    309-335).  GRBDA_EUNSUPPORTED for models with
  *                     / (2 h), out[B][nv][nv]                         implicit-loop clusters or a roll-pitch-yaw base.
+ *
+ * Models made of explicit (constant G) clusters with a quaternion or no floating base and nv <= 64 -- every URDF robot of
+ * the reference without <loop> elements -- do not go through those batches: the mass matrix comes from the
+ * composite-rigid-body kernel, and the three derivatives from the ANALYTIC recursion of deriv_kernels.hip
+ * (d ID / d q and d ID / d qd of the spanning tree projected with G, then one batched SPD solve per state:
+ * d ydd / d tau = H^-1, d ydd / d q = -H^-1 dID/dq, d ydd / d qd = -H^-1 dID/dqd at ydd = FD(q, qd, tau)); `step` is then
+ * not used.  grbda_fd_derivatives_* returns any subset of the three matrices from ONE pass (NULL = not wanted) and falls
+ * back to the three entry points above for the other models.
  */
 int grbda_bias_f64(const grbda_plan *plan, const double *q, const double *qd, const double *f_ext, double *out,
                    size_t B, int device, void *stream);
@@ -160,6 +168,10 @@ int grbda_fd_dq_f64(const grbda_plan *plan, const double *q, const double *qd, c
                     double *J, size_t B, int device, void *stream);
 int grbda_fd_dq_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, double step, float *J,
                     size_t B, int device, void *stream);
+int grbda_fd_derivatives_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau, double *dydd_dq,
+                             double *dydd_dqd, double *dydd_dtau, size_t B, int device, void *stream);
+int grbda_fd_derivatives_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, float *dydd_dq,
+                             float *dydd_dqd, float *dydd_dtau, size_t B, int device, void *stream);
 
 /* ---- steps either side of the path ------------------------------------------ */
 /* Newton projection of the DEPENDENT spanning coordinates of every implicit-loop cluster onto phi(q) = 0, in
