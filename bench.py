@@ -306,7 +306,10 @@ def main():
     general = any(c[9] >= 2 for c in parse_clusters(blob)["clusters"])
     tname = "float" if dtype_name == "f32" else "double"
     chain = (info.chain_aba_f32 if dtype_name == "f32" else info.chain_aba_f64) and args.algo == "aba"
-    kernel_name = (f"grbda_hip::aba_chain_kernel<{tname}, 2>" if chain
+    rchain = (info.chain_rnea_f32 if dtype_name == "f32" else info.chain_rnea_f64) and args.algo == "rnea"
+    # (differential clusters -- TelloWithArms -- are the `true` variants of the chain kernels, chain_kernels.hip)
+    kernel_name = (f"grbda_hip::aba_chain_kernel<{tname}, 2, {'true' if general else 'false'}>" if chain
+                   else f"grbda_hip::rnea_chain_kernel<{tname}, {'true' if general else 'false'}>" if rchain
                    else f"grbda_hip::{args.algo}_kernel<{tname}, {'true' if general else 'false'}>")
     line = {
         "metric": "forward-dynamics evals/sec (batched random states), MIT Humanoid cluster model"
