@@ -120,7 +120,7 @@ struct grbda_plan {
     bool no_crba = false;
     bool no_analytic = false;  // GRBDA_NO_ANALYTIC=1: derivatives by the unit-vector / central-difference batches only
     bool solve_f64 = false;    // GRBDA_SOLVE_F64=1: the SPD solve of the f32 derivative entry points computes in f64
-    int deriv_waves = 4;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel
+    int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 4)
     bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
 };
@@ -1176,18 +1176,21 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         size_t grid = static_cast<size_t>(t->n_cu) * 8;
         if (grid > n_tiles) grid = n_tiles;
         const size_t rows = std::max(p->host.crba.n_rows, need_d ? p->host.deriv.n_rows : 0);
-        const size_t slabs = std::max(grid, static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->deriv_waves));
+        const size_t deriv_waves = p->deriv_waves ? static_cast<size_t>(p->deriv_waves) : 4;
+        const size_t slabs = std::max(grid, static_cast<size_t>(t->n_cu) * deriv_waves);
         void *scratch = nullptr;
         if (int rc = ensure_scratch(p, device, stream, slabs * rows * kWave * sizeof(T) + 256, &scratch)) return rc;
-        e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, H, nb, static_cast<T *>(scratch),
-                           static_cast<int>(grid), hs);
-        if (e != hipSuccess) return hip_err(e, "crba launch");
         if (need_d) {
-            size_t g2 = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->deriv_waves);
+            // (the derivative recursion carries the composite inertias in a common frame: H comes out of the same launch)
+            size_t g2 = static_cast<size_t>(t->n_cu) * deriv_waves;
             if (g2 > n_tiles) g2 = n_tiles;
-            e = launch_rnea_deriv<T>(d, t->deriv_bodies, p->host.n_clusters, p->host.deriv.n_rows, q + b0 * nq, qd + b0 * nv, ydd, Dq, Dqd,
-                                     nb, static_cast<T *>(scratch), static_cast<int>(g2), hs);
+            e = launch_rnea_deriv<T>(d, t->deriv_bodies, p->host.n_clusters, p->host.deriv.n_rows, p->host.deriv.n_max, q + b0 * nq,
+                                     qd + b0 * nv, ydd, Dq, Dqd, H, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs);
             if (e != hipSuccess) return hip_err(e, "rnea derivative launch");
+        } else {
+            e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, H, nb, static_cast<T *>(scratch),
+                               static_cast<int>(grid), hs);
+            if (e != hipSuccess) return hip_err(e, "crba launch");
         }
         // one wavefront per state; as many as the LDS of a CU holds
         const bool wide = sizeof(T) == 4 && p->solve_f64;
@@ -1327,8 +1330,8 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->no_crba = env_int("GRBDA_NO_CRBA", 0) != 0;
     p->no_analytic = env_int("GRBDA_NO_ANALYTIC", 0) != 0;
     p->solve_f64 = env_int("GRBDA_SOLVE_F64", 0) != 0;
-    p->deriv_waves = env_int("GRBDA_DERIV_WAVES_PER_CU", 4);
-    if (p->deriv_waves < 1) p->deriv_waves = 1;
+    p->deriv_waves = env_int("GRBDA_DERIV_WAVES_PER_CU", 0);
+    if (p->deriv_waves < 0) p->deriv_waves = 0;
     p->no_efpa = env_int("GRBDA_NO_EFPA", 0) != 0;
     LdsBudget lds;
     lds.aba32 = p->lds_bytes_per_wave[0] / (4 * kWave);

@@ -26,12 +26,13 @@
 // tools/proto_rnea_derivs.py is the numpy statement of the same recursion, checked against differences of the oracle.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "devplan.h"
 
 namespace grbda_hip {
 
 #include "devmath.h"
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // spatial helpers in the common frame
@@ -146,14 +147,14 @@ __device__ __forceinline__ void deriv_kin(cptr<T> C, bool axisym, T qi, T qdi, T
     }
 }
 
-#ifndef GRBDA_DERIV_WAVES
-#define GRBDA_DERIV_WAVES 1
-#endif
-template <class T>
-__global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
+// NMAX: the largest number of coordinates of a cluster of the model (1, 2 or NMAX).  The cluster-level
+// vectors are sized by it, and with them the register budget (the kernel runs one wavefront per SIMD: it is bound by
+// the traffic of its slab rows, two wavefronts per SIMD measured no faster).
+template <class T, int NMAX>
+__global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
                                                               const T *__restrict__ q, const T *__restrict__ qd,
                                                               const T *__restrict__ ydd, T *__restrict__ Dq, T *__restrict__ Dqd,
-                                                              size_t B, T *__restrict__ scratch)
+                                                              T *__restrict__ H, size_t B, T *__restrict__ scratch)
 {
     cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
     cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
@@ -173,6 +174,9 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
 #endif
         const T *qs = q + st * (size_t)nq, *qds = qd + st * (size_t)nv, *ydds = ydd + st * (size_t)nv;
         T *Dqs = Dq + st * (size_t)nv * nv, *Dqds = Dqd + st * (size_t)nv * nv;
+        // the joint-space inertia matrix falls out of the same composites: H[k][j] = S_j . (Ic_k S_k) for j ancestor of or
+        // equal to k (the CRBA in the common frame); written when the caller wants it
+        T *Hs = H ? H + st * (size_t)nv * nv : nullptr;
         // gravity as the acceleration of the frame F (TreeModel.cpp:40-43: a_root = -gravity), base velocity
         T a0[6], vb[6];
 #pragma unroll
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                         for (int i = 0; i < 6; i++) {
                             Dqs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = y1[i];
                             Dqds[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Bc[6 * i + j] + y2[i];
+                            if (Hs) Hs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Ic[sidx(i, j)];
                         }
                     }
                 }
@@ -303,26 +308,26 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
             }
             const int n = cr.n;
             // cluster-level descendant-side vectors and the contribution to the parent body's accumulator
-            T T1[kMaxClusterDof][6], T2[kMaxClusterDof][6], T3[kMaxClusterDof][6], T4[kMaxClusterDof][6];
-            T Cq[kMaxClusterDof][kMaxClusterDof], Cqd[kMaxClusterDof][kMaxClusterDof];
-            T part[63];
+            T T1[NMAX][6], T2[NMAX][6], T3[NMAX][6], T4[NMAX][6];
+            T Cq[NMAX][NMAX], Cqd[NMAX][NMAX], Ch[NMAX][NMAX];
+            T part[63];  // what the in-cluster roots hand to the parent body: one read-modify-write per cluster
 #pragma unroll
             for (int j = 0; j < 63; j++) part[j] = 0;
 #pragma unroll
-            for (int a2 = 0; a2 < kMaxClusterDof; a2++) {
+            for (int a2 = 0; a2 < NMAX; a2++) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) T1[a2][j] = T2[a2][j] = T3[a2][j] = T4[a2][j] = 0;
 #pragma unroll
-                for (int b2 = 0; b2 < kMaxClusterDof; b2++) Cq[a2][b2] = Cqd[a2][b2] = 0;
+                for (int b2 = 0; b2 < NMAX; b2++) Cq[a2][b2] = Cqd[a2][b2] = Ch[a2][b2] = 0;
             }
             for (int i = cr.k - 1; i >= 0; i--) {
                 const int gb = cr.first_body + i;
                 const BodyRec b = load_rec(bodies + gb);
                 const DerivBody x = load_rec(db + gb);
                 cptr<T> C = consts + b.cofs;
-                T Gi[kMaxClusterDof];
+                T Gi[NMAX];
 #pragma unroll
-                for (int a2 = 0; a2 < kMaxClusterDof; a2++) Gi[a2] = a2 < n ? C[kBodyConstFixed + a2] : T(0);
+                for (int a2 = 0; a2 < NMAX; a2++) Gi[a2] = a2 < n ? C[kBodyConstFixed + a2] : T(0);
                 T E[9], p3[3], v[6], a[6], S[6], Sd[6], Pdd[6];
                 if (x.kin_row >= 0) {
                     T kin[24], anc[18];
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                 } else {
                     T qi = 0, qdi = 0, qddi = 0;
 #pragma unroll
-                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                    for (int a2 = 0; a2 < NMAX; a2++)
                         if (a2 < n) {
                             qi += Gi[a2] * qs[cr.q_index + a2];
                             qdi += Gi[a2] * qds[cr.v_index + a2];
@@ -415,13 +420,14 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                 }
                 // the joint with itself
                 {
-                    const T sq = dot6(Sd, t1) + dot6(Pdd, t2), sqd = dot6(S, t1) + 2 * dot6(Sd, t2);
+                    const T sq = dot6(Sd, t1) + dot6(Pdd, t2), sqd = dot6(S, t1) + 2 * dot6(Sd, t2), sh = dot6(S, t2);
 #pragma unroll
-                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                    for (int a2 = 0; a2 < NMAX; a2++)
 #pragma unroll
-                        for (int b2 = 0; b2 < kMaxClusterDof; b2++) {
+                        for (int b2 = 0; b2 < NMAX; b2++) {
                             Cq[a2][b2] += Gi[a2] * Gi[b2] * sq;
                             Cqd[a2][b2] += Gi[a2] * Gi[b2] * sqd;
+                            Ch[a2][b2] += Gi[a2] * Gi[b2] * sh;
                         }
                 }
                 // in-cluster ancestors
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                     const BodyRec bl = load_rec(bodies + l);
                     const DerivBody xl = load_rec(db + l);
                     cptr<T> Cl = consts + bl.cofs;
-                    T anc[18], Sl[6], Sdl[6], Pddl[6], Gl[kMaxClusterDof];
+                    T anc[18], Sl[6], Sdl[6], Pddl[6], Gl[NMAX];
                     R.ld(xl.anc_row, anc);
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
@@ -439,20 +445,22 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                         Pddl[j] = anc[12 + j];
                     }
 #pragma unroll
-                    for (int a2 = 0; a2 < kMaxClusterDof; a2++) Gl[a2] = a2 < n ? Cl[kBodyConstFixed + a2] : T(0);
+                    for (int a2 = 0; a2 < NMAX; a2++) Gl[a2] = a2 < n ? Cl[kBodyConstFixed + a2] : T(0);
                     const T kq = dot6(Sdl, t1) + dot6(Pddl, t2), kqd = dot6(Sl, t1) + 2 * dot6(Sdl, t2);  // (k = this body, j = l)
                     const T lq = dot6(Sl, t4), lqd = dot6(Sl, t3);                                          // (k = l, j = this body)
+                    const T lh = dot6(Sl, t2);
 #pragma unroll
-                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                    for (int a2 = 0; a2 < NMAX; a2++)
 #pragma unroll
-                        for (int b2 = 0; b2 < kMaxClusterDof; b2++) {
+                        for (int b2 = 0; b2 < NMAX; b2++) {
                             Cq[a2][b2] += Gi[a2] * Gl[b2] * kq + Gl[a2] * Gi[b2] * lq;
                             Cqd[a2][b2] += Gi[a2] * Gl[b2] * kqd + Gl[a2] * Gi[b2] * lqd;
+                            Ch[a2][b2] += (Gi[a2] * Gl[b2] + Gl[a2] * Gi[b2]) * lh;
                         }
                     l = bl.lam;
                 }
 #pragma unroll
-                for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                for (int a2 = 0; a2 < NMAX; a2++)
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
                         T1[a2][j] += Gi[a2] * t1[j];
@@ -460,23 +468,23 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                         T3[a2][j] += Gi[a2] * t3[j];
                         T4[a2][j] += Gi[a2] * t4[j];
                     }
-                // composites to the tree parent
+                // composites to the tree parent: in-cluster parents through their accumulator rows (the first writer stores,
+                // the others add), the parent body of the cluster through `part`
                 if (b.lam >= 0) {
                     const DerivBody xl = load_rec(db + b.lam);
-                    T acc[63];
-                    if (x.acc_first) {
-#pragma unroll
-                        for (int j = 0; j < 63; j++) acc[j] = 0;
-                    } else {
+                    if (!x.acc_first) {
+                        T acc[63];
                         R.ld(xl.acc_row, acc);
+#pragma unroll
+                        for (int j = 0; j < 21; j++) Ic[j] += acc[j];
+#pragma unroll
+                        for (int j = 0; j < 36; j++) Bc[j] += acc[21 + j];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) Fc[j] += acc[57 + j];
                     }
-#pragma unroll
-                    for (int j = 0; j < 21; j++) acc[j] += Ic[j];
-#pragma unroll
-                    for (int j = 0; j < 36; j++) acc[21 + j] += Bc[j];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) acc[57 + j] += Fc[j];
-                    R.st(xl.acc_row, acc);
+                    R.st(xl.acc_row, Ic);
+                    R.st(xl.acc_row + 21, Bc);
+                    R.st(xl.acc_row + 57, Fc);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 21; j++) part[j] += Ic[j];
@@ -486,21 +494,7 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                     for (int j = 0; j < 6; j++) part[57 + j] += Fc[j];
                 }
             }
-            if (live) {
-#pragma unroll
-                for (int a2 = 0; a2 < kMaxClusterDof; a2++)
-#pragma unroll
-                    for (int b2 = 0; b2 < kMaxClusterDof; b2++)
-                        if (a2 < n && b2 < n) {
-                            Dqs[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cq[a2][b2];
-                            Dqds[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cqd[a2][b2];
-                        }
-            }
-#ifdef GRBDA_EXP_NO_ACC
-            if (cr.parent_body >= 0 && nq < 0) {
-#else
             if (cr.parent_body >= 0) {
-#endif
                 const DerivBody xf = load_rec(db + cr.first_body);
                 const DerivBody xp = load_rec(db + cr.parent_body);
                 if (!xf.cluster_acc_first) {
@@ -510,6 +504,17 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                     for (int j = 0; j < 63; j++) part[j] += acc[j];
                 }
                 R.st(xp.acc_row, part);
+            }
+            if (live) {
+#pragma unroll
+                for (int a2 = 0; a2 < NMAX; a2++)
+#pragma unroll
+                    for (int b2 = 0; b2 < NMAX; b2++)
+                        if (a2 < n && b2 < n) {
+                            Dqs[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cq[a2][b2];
+                            Dqds[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cqd[a2][b2];
+                            if (Hs) Hs[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Ch[a2][b2];
+                        }
             }
             // ---- up the ancestors outside the cluster, block by block ----
 #ifdef GRBDA_EXP_NO_WALK
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                 const ClusterRec cd = load_rec(clusters + xj.cluster);
                 if (cd.kind == CK_FREE) {
 #pragma unroll
-                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                    for (int a2 = 0; a2 < NMAX; a2++)
                         if (a2 < n) {
                             T w1[6], w2[6];
                             crf(a0, T2[a2], w1);   // (a0 x e_k) . t = -(a0 x* t)_k
@@ -534,17 +539,22 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                                     Dqds[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = T1[a2][k6] - w2[k6];
                                     Dqs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T4[a2][k6];
                                     Dqds[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T3[a2][k6];
+                                    if (Hs) {
+                                        Hs[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = T2[a2][k6];
+                                        Hs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T2[a2][k6];
+                                    }
                                 }
                             }
                         }
                     break;
                 }
-                T Bq[kMaxClusterDof][kMaxClusterDof], Bqd[kMaxClusterDof][kMaxClusterDof];   // [c][d]
-                T Uq[kMaxClusterDof][kMaxClusterDof], Uqd[kMaxClusterDof][kMaxClusterDof];   // [d][c]
+                T Bq[NMAX][NMAX], Bqd[NMAX][NMAX];   // [c][d]
+                T Uq[NMAX][NMAX], Uqd[NMAX][NMAX];   // [d][c]
+                T Bh[NMAX][NMAX];
 #pragma unroll
-                for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                for (int a2 = 0; a2 < NMAX; a2++)
 #pragma unroll
-                    for (int b2 = 0; b2 < kMaxClusterDof; b2++) Bq[a2][b2] = Bqd[a2][b2] = Uq[a2][b2] = Uqd[a2][b2] = 0;
+                    for (int b2 = 0; b2 < NMAX; b2++) Bq[a2][b2] = Bqd[a2][b2] = Uq[a2][b2] = Uqd[a2][b2] = Bh[a2][b2] = 0;
                 int jj = j, next = -1;
                 for (;;) {
                     const BodyRec bb = load_rec(bodies + jj);
@@ -559,17 +569,18 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                         Pddj[i2] = anc[12 + i2];
                     }
 #pragma unroll
-                    for (int a2 = 0; a2 < kMaxClusterDof; a2++) {
+                    for (int a2 = 0; a2 < NMAX; a2++) {
                         const T eq = dot6(Sdj, T1[a2]) + dot6(Pddj, T2[a2]), eqd = dot6(Sj, T1[a2]) + 2 * dot6(Sdj, T2[a2]);
-                        const T uq = dot6(Sj, T4[a2]), uqd = dot6(Sj, T3[a2]);
+                        const T uq = dot6(Sj, T4[a2]), uqd = dot6(Sj, T3[a2]), hh = dot6(Sj, T2[a2]);
 #pragma unroll
-                        for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                        for (int b2 = 0; b2 < NMAX; b2++)
                             if (b2 < cd.n) {
                                 const T g = Cj[kBodyConstFixed + b2];
                                 Bq[a2][b2] += eq * g;
                                 Bqd[a2][b2] += eqd * g;
                                 Uq[b2][a2] += uq * g;
                                 Uqd[b2][a2] += uqd * g;
+                                Bh[a2][b2] += hh * g;
                             }
                     }
                     next = bb.parent;
@@ -578,14 +589,18 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
                 }
                 if (live) {
 #pragma unroll
-                    for (int a2 = 0; a2 < kMaxClusterDof; a2++)
+                    for (int a2 = 0; a2 < NMAX; a2++)
 #pragma unroll
-                        for (int b2 = 0; b2 < kMaxClusterDof; b2++)
+                        for (int b2 = 0; b2 < NMAX; b2++)
                             if (a2 < n && b2 < cd.n) {
                                 Dqs[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bq[a2][b2];
                                 Dqds[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bqd[a2][b2];
                                 Dqs[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Uq[b2][a2];
                                 Dqds[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Uqd[b2][a2];
+                                if (Hs) {
+                                    Hs[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bh[a2][b2];
+                                    Hs[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Bh[a2][b2];
+                                }
                             }
                 }
                 j = next;
@@ -596,17 +611,24 @@ __global__ __launch_bounds__(kWave, GRBDA_DERIV_WAVES) void rnea_deriv_kernel(De
 }
 
 template <class T>
-hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, const T *q, const T *qd, const T *ydd,
-                             T *Dq, T *Dqd, size_t B, T *scratch, int grid, hipStream_t stream)
+hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
+                             const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((rnea_deriv_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq, Dqd, B,
-                       scratch);
+    if (n_max <= 1)
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, 1>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq, Dqd, H,
+                           B, scratch);
+    else if (n_max <= 2)
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, 2>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq, Dqd, H,
+                           B, scratch);
+    else
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd,
+                           Dq, Dqd, H, B, scratch);
     return hipGetLastError();
 }
-template hipError_t launch_rnea_deriv<float>(const DevPlan<float> &, const DerivBody *, int, int, const float *, const float *,
-                                             const float *, float *, float *, size_t, float *, int, hipStream_t);
-template hipError_t launch_rnea_deriv<double>(const DevPlan<double> &, const DerivBody *, int, int, const double *, const double *,
-                                              const double *, double *, double *, size_t, double *, int, hipStream_t);
+template hipError_t launch_rnea_deriv<float>(const DevPlan<float> &, const DerivBody *, int, int, int, const float *, const float *,
+                                             const float *, float *, float *, float *, size_t, float *, int, hipStream_t);
+template hipError_t launch_rnea_deriv<double>(const DevPlan<double> &, const DerivBody *, int, int, int, const double *, const double *,
+                                              const double *, double *, double *, double *, size_t, double *, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Batched SPD solve, one state per wavefront, entirely in registers.  Lane i holds row i of H, then of its Cholesky
@@ -625,7 +647,7 @@ __device__ __forceinline__ double lane_value(double x, int l)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <class TIO, class TC, int NV>
+template <class TIO, class TC, int NV, int KC>
 __global__ __launch_bounds__(kWave) void spd_solve_kernel(const TIO *__restrict__ H, const TIO *__restrict__ R1, const TIO *__restrict__ R2,
                                                          TIO *__restrict__ Hinv, TIO *__restrict__ X1, TIO *__restrict__ X2, int nv,
                                                          size_t B)
@@ -633,7 +655,7 @@ __global__ __launch_bounds__(kWave) void spd_solve_kernel(const TIO *__restrict_
     const int lane = threadIdx.x;
     const size_t nn = (size_t)nv * nv;
     for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
-        TC Lr[NV], dinv[NV];
+        TC Lr[NV];  // row `lane` of H, then of L; the diagonal entry holds 1 / L[k][k]
         {
             const TIO *row = H + s * nn + (size_t)(lane < nv ? lane : 0) * nv;
 #pragma unroll
@@ -646,41 +668,67 @@ __global__ __launch_bounds__(kWave) void spd_solve_kernel(const TIO *__restrict_
             for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
             const TC d = lane_value(sum, k);
             const TC r = TC(1) / sqrt(d);
-            Lr[k] = sum * r;
-            dinv[k] = r;
+            Lr[k] = lane == k ? r : sum * r;
         }
+        // right-hand sides: KC columns per lane and pass (two when more than 64 columns are wanted: the factor entries
+        // read through v_readlane then serve both)
         const int n1 = R1 ? nv : 0, n2 = R2 ? nv : 0, n3 = Hinv ? nv : 0;
-        for (int c0 = 0; c0 < n1 + n2 + n3; c0 += kWave) {
-            const int col = c0 + lane;
-            const TIO *src = nullptr;
-            TIO *dst = nullptr;
-            int j = 0;
-            TC scale = 1;
-            if (col < n1) { src = R1 + s * nn; dst = X1 + s * nn; j = col; scale = -1; }
-            else if (col < n1 + n2) { src = R2 + s * nn; dst = X2 + s * nn; j = col - n1; scale = -1; }
-            else if (col < n1 + n2 + n3) { dst = Hinv + s * nn; j = col - n1 - n2; }
-            TC x[NV];
+        for (int c0 = 0; c0 < n1 + n2 + n3; c0 += KC * kWave) {
+            const TIO *src[KC];
+            TIO *dst[KC];
+            int jc[KC];
+            TC scale[KC], x[KC][NV];
 #pragma unroll
-            for (int i = 0; i < NV; i++) x[i] = (dst && i < nv) ? (src ? (TC)src[(size_t)i * nv + j] : (i == j ? TC(1) : TC(0))) : TC(0);
+            for (int u = 0; u < KC; u++) {
+                const int col = c0 + u * kWave + lane;
+                src[u] = nullptr;
+                dst[u] = nullptr;
+                jc[u] = 0;
+                scale[u] = 1;
+                if (col < n1) { src[u] = R1 + s * nn; dst[u] = X1 + s * nn; jc[u] = col; scale[u] = -1; }
+                else if (col < n1 + n2) { src[u] = R2 + s * nn; dst[u] = X2 + s * nn; jc[u] = col - n1; scale[u] = -1; }
+                else if (col < n1 + n2 + n3) { dst[u] = Hinv + s * nn; jc[u] = col - n1 - n2; }
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+                    x[u][i] = (dst[u] && i < nv) ? (src[u] ? (TC)src[u][(size_t)i * nv + jc[u]] : (i == jc[u] ? TC(1) : TC(0))) : TC(0);
+            }
 #pragma unroll
             for (int i = 0; i < NV; i++) {
-                TC acc = x[i];
+                TC acc[KC];
 #pragma unroll
-                for (int m2 = 0; m2 < i; m2++) acc -= lane_value(Lr[m2], i) * x[m2];
-                x[i] = acc * dinv[i];
+                for (int u = 0; u < KC; u++) acc[u] = x[u][i];
+#pragma unroll
+                for (int m2 = 0; m2 < i; m2++) {
+                    const TC l = lane_value(Lr[m2], i);
+#pragma unroll
+                    for (int u = 0; u < KC; u++) acc[u] -= l * x[u][m2];
+                }
+                const TC di = lane_value(Lr[i], i);
+#pragma unroll
+                for (int u = 0; u < KC; u++) x[u][i] = acc[u] * di;
             }
 #pragma unroll
             for (int i = NV - 1; i >= 0; i--) {
-                TC acc = x[i];
+                TC acc[KC];
 #pragma unroll
-                for (int m2 = i + 1; m2 < NV; m2++) acc -= lane_value(Lr[i], m2) * x[m2];
-                x[i] = acc * dinv[i];
-            }
-            if (dst) {
+                for (int u = 0; u < KC; u++) acc[u] = x[u][i];
 #pragma unroll
-                for (int i = 0; i < NV; i++)
-                    if (i < nv) dst[(size_t)i * nv + j] = (TIO)(scale * x[i]);
+                for (int m2 = i + 1; m2 < NV; m2++) {
+                    const TC l = lane_value(Lr[i], m2);
+#pragma unroll
+                    for (int u = 0; u < KC; u++) acc[u] -= l * x[u][m2];
+                }
+                const TC di = lane_value(Lr[i], i);
+#pragma unroll
+                for (int u = 0; u < KC; u++) x[u][i] = acc[u] * di;
             }
+#pragma unroll
+            for (int u = 0; u < KC; u++)
+                if (dst[u]) {
+#pragma unroll
+                    for (int i = 0; i < NV; i++)
+                        if (i < nv) dst[u][(size_t)i * nv + jc[u]] = (TIO)(scale[u] * x[u][i]);
+                }
         }
     }
 }
@@ -689,7 +737,16 @@ template <class TIO, class TC, int NV>
 static hipError_t launch_spd_solve_n(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
                                      hipStream_t stream)
 {
-    hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV>), dim3(grid), dim3(kWave), 0, stream, H, R1, R2, Hinv, X1, X2, nv, B);
+    // two columns per lane: f32 arithmetic and more than one pass of 64 columns (register budget: 4 NV values per lane)
+    const int ncols = (R1 ? nv : 0) + (R2 ? nv : 0) + (Hinv ? nv : 0);
+    static const int kc_env = [] { const char *e = std::getenv("GRBDA_SOLVE_KC"); return e ? std::atoi(e) : 0; }();
+    if constexpr (sizeof(TC) == 4 && NV == 40) {  // (measured: it pays for JVRC-1's 114 columns only)
+        if (kc_env != 1 && (ncols > kWave || kc_env == 2)) {
+            hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 2>), dim3(grid), dim3(kWave), 0, stream, H, R1, R2, Hinv, X1, X2, nv, B);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 1>), dim3(grid), dim3(kWave), 0, stream, H, R1, R2, Hinv, X1, X2, nv, B);
     return hipGetLastError();
 }
 template <class TIO, class TC>

@@ -122,8 +122,8 @@ hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, 
 
 // inverse-dynamics derivatives and the batched SPD solve behind d ydd / d (q, qd, tau) (deriv_kernels.hip)
 template <class T>
-hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, const T *q, const T *qd, const T *ydd,
-                             T *Dq, T *Dqd, size_t B, T *scratch, int grid, hipStream_t stream);
+hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
+                             const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream);
 template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
                             hipStream_t stream);

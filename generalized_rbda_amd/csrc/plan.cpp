@@ -1511,6 +1511,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 rows += 18;
             }
         }
+        for (const ClusterRec &cr : clusters)
+            if (cr.kind != CK_FREE) DV.n_max = std::max(DV.n_max, cr.n);
         // accumulators: written by the child clusters (one combined write each, highest cluster first) and by in-cluster
         // children, read when the body itself is processed; rows are shared between accumulators that are never live together
         std::vector<int> birth(nb, -1), death(nb, -1);

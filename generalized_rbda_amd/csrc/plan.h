@@ -337,6 +337,7 @@ struct DerivProgram {
     bool ok = false;  // explicit (constant G) clusters, quaternion or no floating base
     std::vector<DerivBody> bodies;
     int n_rows = 0;
+    int n_max = 1;    // largest number of coordinates of a cluster
 };
 
 // LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
