@@ -1455,6 +1455,8 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->chain_aba_f64 = p->host.chain64.ok && !p->no_chain;
     info->chain_rnea_f32 = p->host.rchain32.ok && !p->no_chain;
     info->chain_rnea_f64 = p->host.rchain64.ok && !p->no_chain;
+    info->analytic_derivatives = analytic_covers<double>(p) ? 1 : 0;
+    info->n_chain_differentials = p->no_chain ? 0 : static_cast<int>(p->host.chain32.diffs.size());
     return GRBDA_OK;
 }
 

@@ -23,7 +23,7 @@
 //                                  d tau_k / d qd_j = S_k . (Bc_j S_j + Ic_j (Sd_j + Pd_j))
 // The columns of the free base are the body-frame twists of the reference's tangent step (pos += R^T d,
 // quat += quat (x) (0, d) / 2): S = 1, Sd = v x 1, Pd = 0, Pdd = a_0 x 1 with a_0 = -gravity seen from the base.
-// tools/proto_rnea_derivs.py is the numpy statement of the same recursion, checked against differences of the oracle.
+// tests/deriv_recursion_numpy.py is the numpy statement of the same recursion, checked against differences of the oracle.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

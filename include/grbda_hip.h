@@ -98,6 +98,8 @@ typedef struct {
     int n_lds_slots_chain_f32, n_chain_segments;
     int chain_aba_f64;
     int chain_rnea_f32, chain_rnea_f64; /* inverse dynamics on the chains (rnea_chain_kernel) */
+    int analytic_derivatives;           /* grbda_fd_d* / grbda_fd_derivatives_* take the analytic route (deriv_kernels.hip) */
+    int n_chain_differentials;          /* implicit two-rotor differential clusters inside the f32 chain program */
 } grbda_plan_info_t;
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 

@@ -1,4 +1,4 @@
-"""Prototype (numpy, one state) of the analytic first-order derivatives of cluster inverse dynamics that
+"""Test infrastructure: numpy statement (one state) of the analytic first-order derivatives of cluster inverse dynamics that
 `deriv_kernels.hip` implements, checked against central differences of the CPU oracle.  Explicit (constant G) models.
 
 All spatial quantities are expressed in ONE inertial frame F that coincides with the floating base at this instant, so
@@ -9,7 +9,7 @@ Pdd_j = a_parent x S_j + v_parent x Pd_j and, per body, B_i = (v x*) I - I (v x)
     k <  j:                        dtau_k/dq_j  = S_k . (S_j x* Fc_j + Bc_j Pd_j + Ic_j Pdd_j)
                                    dtau_k/dqd_j = S_k . (Bc_j S_j + Ic_j (Sd_j + Pd_j))
 (Ic, Bc, Fc: sums over the subtree), then  d tau_y / d y = G^T (.) G.
-usage: python tools/proto_rnea_derivs.py"""
+usage: python tests/deriv_recursion_numpy.py"""
 import os, struct, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
