@@ -361,6 +361,7 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     d.n_segs = static_cast<int>(rp.segs.size());
     d.nq = h.nq;
     d.nv = h.nv;
+    d.n_glb_slots = rp.n_glb;
     d.ori_repr = h.ori_repr;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;
@@ -379,7 +380,7 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
         const size_t g2 = static_cast<size_t>(t.n_cu) * fit;
         if (grid > g2) grid = g2;
     }
-    const size_t n_rows = static_cast<size_t>(d.nq + 2 * d.nv);
+    const size_t n_rows = static_cast<size_t>(d.nq + 2 * d.nv) + static_cast<size_t>(rp.n_glb);
     void *scratch = nullptr;
     if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(T) + 256, &scratch)) return rc;
     hipError_t e = launch_rnea_chain<T>(d, q, qd, ydd, tau, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,

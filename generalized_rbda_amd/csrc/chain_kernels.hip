@@ -141,7 +141,7 @@ __device__ __forceinline__ void rotor_terms(cptr<T> Cr, const T (&vp)[6], T qdr,
 // ---------------------------------------------------------------------------------------------------------------
 // forward run: TreeModel::forwardKinematics (TreeModel.cpp:6-32) along a chain, root side first
 // ---------------------------------------------------------------------------------------------------------------
-// SVG: the program keeps the [sin, cos, v] blocks of the links in the wave's global slab instead of LDS (ChainProgram::
+// SVG: the program keeps SOME of the [sin, cos, v] blocks of the links in the wave's global slab instead of LDS (ChainProgram::
 // sv_global: chains too long for the LDS budget); a compile-time property of the run so that the common case carries
 // neither the test nor the prefetch registers.
 template <class T, bool SVG>
@@ -181,7 +181,7 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
             blk[2 + j] = v[j];
             vp[j] = v[j];
         }
-        if constexpr (SVG) M.glb_st(l.lds_sv, blk);
+        if constexpr (SVG) M.acc_st(l.lds_sv, blk);
         else M.lds_st(l.lds_sv, blk);
         l = ln;
         qi = qn;
@@ -755,7 +755,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
     ChainLink l = load_rec(P.links + sg.first);
     T yd = M.qd(l.v_index), tau_in = M.x(l.v_index), y_in = M.q(l.q_index);
     T blk[8];  // [sin, cos, v 6] of the current link; SVG: in the global slab, fetched one link ahead
-    if constexpr (SVG) M.glb_ld(l.lds_sv, blk);
+    if constexpr (SVG) M.acc_ld(l.lds_sv, blk);
     for (int i = 0; i < sg.count; i++) {
         const bool more = i + 1 < sg.count;
         const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
@@ -767,7 +767,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         }
         T blkn[8];
         if constexpr (SVG) {
-            if (more) M.glb_ld(ln.lds_sv, blkn);
+            if (more) M.acc_ld(ln.lds_sv, blkn);
         } else {
             M.lds_ld(l.lds_sv, blk);
         }
@@ -1465,17 +1465,22 @@ __device__ __forceinline__ void rotor_rnea(cptr<T> Cr, const T (&vp)[6], const T
     xforce_inv(E0, Cr + 9, f, fp);
 }
 
-template <class T>
-__device__ __forceinline__ void lds_add6(const ChainMem<T> &M, int slot, const T (&x)[6])
+// GLB: the program keeps some of the links' [f | sin, cos | rotor torque] blocks in the wave's global slab (RneaChainProgram::
+// n_glb > 0: chains too long for the LDS budget, JVRC-1); a compile-time property of the kernel so that the common case
+// carries no test of where a block lives.
+template <class T, bool GLB>
+__device__ __forceinline__ void add6(const ChainMem<T> &M, int slot, const T (&x)[6])
 {
     T y[6];
-    M.lds_ld(slot, y);
+    if constexpr (GLB) M.acc_ld(slot, y);
+    else M.lds_ld(slot, y);
 #pragma unroll
     for (int j = 0; j < 6; j++) y[j] += x[j];
-    M.lds_st(slot, y);
+    if constexpr (GLB) M.acc_st(slot, y);
+    else M.lds_st(slot, y);
 }
 
-template <class T>
+template <class T, bool GLB>
 __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaSeg &sg)
 {
     T vp[6], ap[6];
@@ -1527,7 +1532,7 @@ __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const Chain
             T tz, fpr[6];
             rotor_rnea(Cr, vp, ap, gr * ydi, gr * yddi, tz, fpr);
             blk[8] = gr * tz;
-            if (l.lds_pf >= 0) lds_add6(M, l.lds_pf, fpr);  // the rotor hangs off the parent body
+            if (l.lds_pf >= 0) add6<T, GLB>(M, l.lds_pf, fpr);  // the rotor hangs off the parent body
         }
         if (l.rofs >= 0 && l.general_rotor) {  // general rotor: a second full body of the cluster, at its own angle
             cptr<T> Cr = P.consts + l.rofs;
@@ -1547,11 +1552,12 @@ __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const Chain
             body_force_c(Cr + 12, vr, ar, fr);
             blk[8] = gr * fr[2];
             xforce_inv(Er, Cr + 9, fr, fpr);
-            if (l.lds_pf >= 0) lds_add6(M, l.lds_pf, fpr);
+            if (l.lds_pf >= 0) add6<T, GLB>(M, l.lds_pf, fpr);
         }
 #pragma unroll
         for (int j = 0; j < 6; j++) blk[j] = f[j];
-        M.lds_st(l.lds_blk, blk);
+        if constexpr (GLB) M.acc_st(l.lds_blk, blk);
+        else M.lds_st(l.lds_blk, blk);
         if (l.lds_va >= 0) {
             T va[12];
 #pragma unroll
@@ -1573,7 +1579,7 @@ __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const Chain
     }
 }
 
-template <class T>
+template <class T, bool GLB>
 __device__ __forceinline__ void rnea_run_bwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaSeg &sg)
 {
     T fc[6] = {0, 0, 0, 0, 0, 0};
@@ -1581,18 +1587,19 @@ __device__ __forceinline__ void rnea_run_bwd(const RneaTables<T> &P, const Chain
         const RneaLink l = load_rec(P.links + (sg.first + i));
         cptr<T> C = P.consts + l.cofs;
         T blk[9], E[9], ft[6];
-        M.lds_ld(l.lds_blk, blk);
+        if constexpr (GLB) M.acc_ld(l.lds_blk, blk);
+        else M.lds_ld(l.lds_blk, blk);
 #pragma unroll
         for (int j = 0; j < 6; j++) ft[j] = blk[j] + fc[j];
         M.put(l.v_index, C[kBodyConstFixed] * ft[2] + blk[8]);
         rotate_z(blk[6], blk[7], C, E);
         xforce_inv(E, C + 9, ft, fc);
     }
-    if (sg.lds_pf >= 0) lds_add6(M, sg.lds_pf, fc);
+    if (sg.lds_pf >= 0) add6<T, GLB>(M, sg.lds_pf, fc);
 }
 
 // leaf pair cluster: link1 (on P), link2 (on link1), two axisymmetric rotors on P (see pair_bwd)
-template <class T>
+template <class T, bool GLB>
 __device__ __forceinline__ void rnea_pair(const RneaTables<T> &P, const ChainMem<T> &M, const RneaPair &pr)
 {
     cptr<T> C1 = P.consts + pr.cofs[0], C2 = P.consts + pr.cofs[1];
@@ -1642,14 +1649,14 @@ __device__ __forceinline__ void rnea_pair(const RneaTables<T> &P, const ChainMem
     }
     M.put(pr.v_index, tau1);
     M.put(pr.v_index + 1, tau2);
-    lds_add6(M, pr.lds_pf, fp);
+    add6<T, GLB>(M, pr.lds_pf, fp);
 }
 
 
 // two-rotor differential cluster (plan.h, RneaDiff; see diff_constraint): forward segment -- G and g from the constraint,
 // v, a and the body forces of the two links, the rotors' torques and their forces on the parent body; backward segment
 // (after the child segments have added their forces to link2's) -- tau = G^T (S^T f) and the links' force to the parent.
-template <class T>
+template <class T, bool GLB>
 __device__ __forceinline__ void rnea_diff_fwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaDiff &d)
 {
     cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
@@ -1693,7 +1700,7 @@ __device__ __forceinline__ void rnea_diff_fwd(const RneaTables<T> &P, const Chai
     xforce_inv(E1, C1 + 9, f1, fp);
 #pragma unroll
     for (int j = 0; j < 6; j++) fp[j] += fp0[j] + fp1[j];
-    lds_add6(M, d.lds_pf, fp);
+    add6<T, GLB>(M, d.lds_pf, fp);
     M.put(d.v_index, tz0 + X[0] * f1[2]);
     M.put(d.v_index + 1, tz1 + X[1] * f1[2]);
 #pragma unroll
@@ -1715,7 +1722,7 @@ __device__ __forceinline__ void rnea_diff_fwd(const RneaTables<T> &P, const Chai
     }
 }
 
-template <class T>
+template <class T, bool GLB>
 __device__ __forceinline__ void rnea_diff_bwd(const RneaTables<T> &P, const ChainMem<T> &M, const RneaDiff &d)
 {
     cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
@@ -1729,7 +1736,7 @@ __device__ __forceinline__ void rnea_diff_bwd(const RneaTables<T> &P, const Chai
     xforce_inv(E2, C2 + 9, f2, f21);
     const T tl1 = f21[2];
     xforce_inv(E1, C1 + 9, f21, fp);
-    lds_add6(M, d.lds_pf, fp);
+    add6<T, GLB>(M, d.lds_pf, fp);
     // (the result rows are the tile's third input block: M.x reads what the forward segment put there)
     M.put(d.v_index, M.x(d.v_index) + blk[10] * tl1 + blk[12] * tl2);
     M.put(d.v_index + 1, M.x(d.v_index + 1) + blk[11] * tl1 + blk[13] * tl2);
@@ -1775,7 +1782,7 @@ __device__ __forceinline__ void rnea_free_bwd(const RneaTables<T> &P, const Chai
     for (int j = 0; j < 6; j++) M.put(f.v_index + j, fo[j]);
 }
 
-template <class T, bool DIFF>
+template <class T, bool DIFF, bool GLB>
 __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
                                                               const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
                                                               T *__restrict__ scratch)
@@ -1795,10 +1802,11 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
 #pragma unroll
     for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
     const int lane = threadIdx.x;
-    T *slab = scratch + (size_t)blockIdx.x * (size_t)(P.nq + 2 * P.nv) * kWave;  // input / result rows only
+    // wave slab: [nq + 2 nv input / result rows][n_glb_slots rows]
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(P.nq + 2 * P.nv + DP.n_glb_slots) * kWave;
     ChainMem<T> M;
     M.lane = lane;
-    M.glb = slab;
+    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q = slab + lane;
     M.in_qd = slab + (size_t)P.nq * kWave + lane;
     M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
@@ -1811,15 +1819,15 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
         for (int s = 0; s < P.n_segs; s++) {
             const RneaSeg sg = load_rec(P.segs + s);
             switch (sg.op) {
-                case RSEG_RUN_FWD: rnea_run_fwd(P, M, sg); break;
-                case RSEG_RUN_BWD: rnea_run_bwd(P, M, sg); break;
-                case RSEG_PAIR: rnea_pair(P, M, load_rec(P.pairs + sg.first)); break;
+                case RSEG_RUN_FWD: rnea_run_fwd<T, GLB>(P, M, sg); break;
+                case RSEG_RUN_BWD: rnea_run_bwd<T, GLB>(P, M, sg); break;
+                case RSEG_PAIR: rnea_pair<T, GLB>(P, M, load_rec(P.pairs + sg.first)); break;
                 case RSEG_FREE_FWD: rnea_free_fwd(P, M, load_rec(P.frees + sg.first)); break;
                 case RSEG_DIFF_FWD:
-                    if constexpr (DIFF) rnea_diff_fwd(P, M, load_rec(P.diffs + sg.first));
+                    if constexpr (DIFF) rnea_diff_fwd<T, GLB>(P, M, load_rec(P.diffs + sg.first));
                     break;
                 case RSEG_DIFF_BWD:
-                    if constexpr (DIFF) rnea_diff_bwd(P, M, load_rec(P.diffs + sg.first));
+                    if constexpr (DIFF) rnea_diff_bwd<T, GLB>(P, M, load_rec(P.diffs + sg.first));
                     break;
                 default: rnea_free_bwd(P, M, load_rec(P.frees + sg.first)); break;
             }
@@ -1832,8 +1840,11 @@ template <class T>
 hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
                              size_t lds_bytes, hipStream_t stream)
 {
-    if (P.n_diffs > 0) hipLaunchKernelGGL((rnea_chain_kernel<T, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
-    else hipLaunchKernelGGL((rnea_chain_kernel<T, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    const bool glb = P.n_glb_slots > 0;
+    if (P.n_diffs > 0 && glb) hipLaunchKernelGGL((rnea_chain_kernel<T, true, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else if (P.n_diffs > 0) hipLaunchKernelGGL((rnea_chain_kernel<T, true, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else if (glb) hipLaunchKernelGGL((rnea_chain_kernel<T, false, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else hipLaunchKernelGGL((rnea_chain_kernel<T, false, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
 }
 template hipError_t launch_rnea_chain<float>(const RneaChainDev<float> &, const float *, const float *, const float *, float *, size_t,
@@ -1847,8 +1858,10 @@ hipError_t set_max_dynamic_lds_chain()
         reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, false>), reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, true>),
         reinterpret_cast<const void *>(&aba_chain_kernel<float, 4, false>),
         reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, false>), reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, true>),
-        reinterpret_cast<const void *>(&rnea_chain_kernel<float, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true>),
-        reinterpret_cast<const void *>(&rnea_chain_kernel<double, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, false>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, false>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, true>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, true>),
         reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>)};
     for (const void *k : kernels) {
         const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

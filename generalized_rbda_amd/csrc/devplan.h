@@ -80,6 +80,7 @@ struct RneaChainDev {
     const T *consts;
     int n_segs;
     int nq, nv;
+    int n_glb_slots;  // RneaChainProgram::n_glb
     int lds_bytes;
     int ori_repr;
     T a_root[6];

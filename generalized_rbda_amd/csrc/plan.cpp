@@ -1260,6 +1260,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 }
                 int rn_lds = 0, rn_glb = 0;
                 bool rok = allocate_packed(robjs, rnea_budget, rn_lds, rn_glb);
+                if (!rok) {
+                    // second try: the links' [f | sin, cos | rotor torque] blocks take what LDS the other objects leave
+                    // and otherwise go to the wave's global slab
+                    for (Obj &o : robjs)
+                        if (o.size == 9 && !o.tag) { o.force = 0; o.prio = 1; o.slot = -1; }
+                    rok = allocate(robjs, rnea_budget, rn_lds, rn_glb);
+                }
                 if (!rok && std::getenv("GRBDA_DEBUG_CHAIN")) {
                     std::fprintf(stderr, "chain (rnea): LDS objects need more than %d slots (got to %d)\n", rnea_budget, rn_lds);
                     for (const Obj &o : robjs) std::fprintf(stderr, "  obj size %d [%d, %d] slot %d\n", o.size, o.birth, o.death, o.slot);
@@ -1313,6 +1320,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         R.frees.push_back(rf[c]);
                     }
                     R.n_lds = rn_lds;
+                    R.n_glb = rn_glb;
                 }
                 R.ok = rok;
                 if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); R.diffs.clear(); }
@@ -1367,17 +1375,19 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 for (const Obj &o : objs) std::fprintf(stderr, "  obj size %d [%d, %d] slot %d\n", o.size, o.birth, o.death, o.slot);
             }
             if (!ok) {
-                // second try: the accumulators [IA 21][psi 6] of branching bodies -- touched once per child chain -- move
-                // to the wave's global slab (their slot numbers then carry kSlotGlobal)
+                // second try: the accumulators [IA 21][psi 6] of branching bodies -- touched once per child chain -- take
+                // what LDS the other objects leave and otherwise move to the wave's global slab (their slot numbers then
+                // carry kSlotGlobal)
                 for (Obj &o : objs)
-                    if (o.size == 27 && !o.tag) { o.force = 2; o.slot = -1; }
-                ok = allocate_packed(objs, lds_budget, n_lds, n_glb_unused);
+                    if (o.size == 27 && !o.tag) { o.force = 0; o.slot = -1; }
+                ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
                 if (!ok) {
-                    // third try (long chains, JVRC-1's arms and legs): the [sin, cos, v] blocks of the links go there too;
-                    // the backward run fetches the next link's block while it computes the current one
+                    // third try (long chains, JVRC-1's arms and legs): the [sin, cos, v] blocks of the links likewise, after
+                    // everything that must stay in LDS; the backward run fetches the next link's block while it computes the
+                    // current one
                     for (Obj &o : objs)
-                        if (o.size == 8 && !o.tag) { o.force = 2; o.slot = -1; }
-                    ok = allocate_packed(objs, lds_budget, n_lds, n_glb_unused);
+                        if (o.size == 8 && !o.tag) { o.force = 0; o.prio = 1; o.slot = -1; }
+                    ok = allocate(objs, lds_budget, n_lds, n_glb_unused);
                     CP.sv_global = true;
                     if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) {
                         std::fprintf(stderr, "chain: third try failed, n_lds %d\n", n_lds);
@@ -1385,7 +1395,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     }
                 }
                 for (Obj &o : objs)
-                    if (o.force == 2) *o.field = ((o.slot & ~kSlotGlobal) + n_glb) | kSlotGlobal;
+                    if (o.slot & kSlotGlobal) *o.field = ((o.slot & ~kSlotGlobal) + n_glb) | kSlotGlobal;
                 n_glb += n_glb_unused;
             }
             if (ok) {

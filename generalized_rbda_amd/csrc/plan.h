@@ -297,6 +297,7 @@ struct RneaChainProgram {
     std::vector<RneaFree> frees;
     std::vector<RneaDiff> diffs;
     int n_lds = 0;
+    int n_glb = 0;  // > 0: some link blocks live in the wave's global slab (their slot numbers carry kSlotGlobal)
 };
 
 struct ChainProgram {

@@ -1,4 +1,5 @@
-"""A few launches of one kernel on the MIT humanoid (target program of tools/pmc_run.sh)."""
+"""A few launches of one kernel (target program of tools/pmc_run.sh / tools/profile_round.sh).
+usage: pmc_target.py aba|rnea 32|64 [model]   env: PMC_BATCH, PMC_LAUNCHES"""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -8,9 +9,20 @@ from generalized_rbda_amd.states import random_states
 kind = sys.argv[1] if len(sys.argv) > 1 else "aba"
 prec = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 model = sys.argv[3] if len(sys.argv) > 3 else "mit_humanoid"
-plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", model + ".urdf"))
-B = 262144
+if model == "tello":
+    from generalized_rbda_amd.robots import tello_with_arms
+    plan = G.Plan.from_model(tello_with_arms())
+else:
+    plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", model + ".urdf"))
+B = int(os.environ.get("PMC_BATCH", "262144"))
 q, qd, tau = random_states(plan.blob, B, 2)
+if model == "tello":  # valid spanning positions (Newton projection on the device), failures replaced
+    import numpy as np
+    t64 = torch.as_tensor(q, dtype=torch.float64, device="cuda:0")
+    ok = plan.project_positions(t64).cpu().numpy()
+    q = t64.cpu().numpy()
+    good, bad = np.flatnonzero(ok), np.flatnonzero(~ok)
+    q[bad] = q[good[np.arange(bad.size) % good.size]]
 dt = torch.float32 if prec == 32 else torch.float64
 t = lambda a: torch.as_tensor(a, dtype=dt, device="cuda:0")
 tq, tqd, tt = t(q), t(qd), t(tau)
