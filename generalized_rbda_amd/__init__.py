@@ -30,6 +30,7 @@ C_ABI_SYMBOLS = [
     "grbda_apply_test_force_f64", "grbda_apply_test_force_f32", "grbda_inv_osim_f64", "grbda_inv_osim_f32",
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
     "grbda_spanning_f64", "grbda_spanning_f32", "grbda_fd_derivatives_f64", "grbda_fd_derivatives_f32",
+    "grbda_mass_matrix_host_f64", "grbda_fd_derivatives_host_f64",
 ]
 
 

@@ -1704,6 +1704,42 @@ int grbda_inv_osim_host_f64(const grbda_plan *p, const double *q, int n_contacts
     if ((rc = dL.get(Linv, B * m * m * 8))) return rc;
     return J ? dJ.get(J, B * m * nv * 8) : GRBDA_OK;
 }
+// host arrays: mass matrix and the derivatives of the forward dynamics (facade: getMassMatrix, forwardDynamicsDerivativesBatch)
+int grbda_mass_matrix_host_f64(const grbda_plan *p, const double *q, double *H, size_t B, int device)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!q || !H) return set_err(GRBDA_EINVAL, "null argument");
+    const size_t nq = p->host.nq, nv = p->host.nv;
+    DevBuf dq, dH;
+    int rc;
+    if ((rc = dq.alloc(B * nq * 8)) || (rc = dH.alloc(B * nv * nv * 8)) || (rc = dq.put(q, B * nq * 8))) return rc;
+    if ((rc = grbda_mass_matrix_f64(p, static_cast<double *>(dq.p), static_cast<double *>(dH.p), B, device, nullptr))) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    return dH.get(H, B * nv * nv * 8);
+}
+int grbda_fd_derivatives_host_f64(const grbda_plan *p, const double *q, const double *qd, const double *tau, double *dq, double *dqd,
+                                  double *dtau, size_t B, int device)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!q || !qd || !tau) return set_err(GRBDA_EINVAL, "null argument");
+    const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
+    DevBuf bq, bqd, bt, b1, b2, b3;
+    int rc;
+    if ((rc = bq.alloc(B * nq * 8)) || (rc = bqd.alloc(B * nv * 8)) || (rc = bt.alloc(B * nv * 8)) || (dq && (rc = b1.alloc(B * nn * 8))) ||
+        (dqd && (rc = b2.alloc(B * nn * 8))) || (dtau && (rc = b3.alloc(B * nn * 8))) || (rc = bq.put(q, B * nq * 8)) ||
+        (rc = bqd.put(qd, B * nv * 8)) || (rc = bt.put(tau, B * nv * 8)))
+        return rc;
+    if ((rc = grbda_fd_derivatives_f64(p, static_cast<double *>(bq.p), static_cast<double *>(bqd.p), static_cast<double *>(bt.p),
+                                       dq ? static_cast<double *>(b1.p) : nullptr, dqd ? static_cast<double *>(b2.p) : nullptr,
+                                       dtau ? static_cast<double *>(b3.p) : nullptr, B, device, nullptr)))
+        return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    if (dq && (rc = b1.get(dq, B * nn * 8))) return rc;
+    if (dqd && (rc = b2.get(dqd, B * nn * 8))) return rc;
+    return dtau ? b3.get(dtau, B * nn * 8) : GRBDA_OK;
+}
 int grbda_plan_span_dims(const grbda_plan *p, int *n_span_vel)
 {
     if (!p) return set_err(GRBDA_EINVAL, "null plan");

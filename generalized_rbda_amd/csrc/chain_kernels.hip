@@ -44,6 +44,7 @@ struct ChainMem {
     const T *in_q, *in_qd, *in_x;   // already offset by the lane
     T *out_rows;
     int lane;
+    int gmul;  // 1; 0 under GRBDA_CHAIN_DEBUG bit 3: every global slot aliases row 0 (same instructions, no slab traffic)
 
     template <int N>
     __device__ __forceinline__ void lds_ld(int s, T (&x)[N]) const
@@ -62,14 +63,14 @@ struct ChainMem {
     template <int N>
     __device__ __forceinline__ void glb_ld(int s, T (&x)[N]) const
     {
-        const T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
+        const T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave + lane);
 #pragma unroll
         for (int i = 0; i < N; i++) x[i] = p[i * kWave];
     }
     template <int N>
     __device__ __forceinline__ void glb_st(int s, const T (&x)[N]) const
     {
-        T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * kWave + lane);
+        T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave + lane);
 #pragma unroll
         for (int i = 0; i < N; i++) p[i * kWave] = x[i];
     }
@@ -1102,6 +1103,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
     ChainMem<T> M;
     M.lane = lane;
+    M.gmul = (DP.debug & 8) ? 0 : 1;
     M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q = slab + lane;
     M.in_qd = slab + (size_t)P.nq * kWave + lane;
@@ -1196,6 +1198,7 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     T *slab = scratch + (size_t)blockIdx.x * (size_t)n_rows_wave * kWave;
     ChainMem<T> M;
     M.lane = lane;
+    M.gmul = 1;
     M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q = slab + lane;
     M.in_qd = slab + (size_t)P.nq * kWave + lane;
@@ -1806,6 +1809,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(P.nq + 2 * P.nv + DP.n_glb_slots) * kWave;
     ChainMem<T> M;
     M.lane = lane;
+    M.gmul = 1;
     M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q = slab + lane;
     M.in_qd = slab + (size_t)P.nq * kWave + lane;

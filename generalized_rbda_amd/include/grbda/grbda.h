@@ -933,24 +933,27 @@ public:
 
     // TreeModel::updateBiasForceVector (TreeModel.cpp:162-171): C = RNEA(0), external forces included
     DVec<Scalar> getBiasForceVector() { return single(true, DVec<Scalar>::Zero(this->velocity_index_)); }
-    // ClusterTreeModel::getMassMatrix (ClusterTreeModel.cpp:99-104).  The reference runs the CRBA; here
-    // H e_j = RNEA(q, 0, e_j) - RNEA(q, 0, 0), one batched inverse-dynamics call of nv + 1 rows.
+    // ClusterTreeModel::getMassMatrix (ClusterTreeModel.cpp:99-104): the batched cluster CRBA kernel (crba_kernels.hip;
+    // models with implicit-loop clusters: unit-acceleration inverse-dynamics columns), one state
     DMat<Scalar> getMassMatrix()
     {
-        const int nq = this->position_index_, nv = this->velocity_index_;
-        if (static_cast<int>(q_.size()) != nq) throw std::runtime_error("state has not been set");
-        const size_t R = static_cast<size_t>(nv) + 1;
-        std::vector<double> q(R * nq), qd(R * nv, 0.0), x(R * nv, 0.0), out(R * nv);
-        for (size_t r = 0; r < R; r++) {
-            for (int i = 0; i < nq; i++) q[r * nq + i] = static_cast<double>(q_[i]);
-            if (r < static_cast<size_t>(nv)) x[r * nv + r] = 1.0;
-        }
-        check(grbda_rnea_host_f64(plan(), q.data(), qd.data(), x.data(), nullptr, out.data(), R, 0));
+        const int nv = this->velocity_index_;
+        const std::vector<double> q = state_q();
+        std::vector<double> out(static_cast<size_t>(nv) * nv);
+        check(grbda_mass_matrix_host_f64(plan(), q.data(), out.data(), 1, 0));
         DMat<Scalar> H(nv, nv);
         for (int i = 0; i < nv; i++)
-            for (int j = 0; j < nv; j++)
-                H(i, j) = static_cast<Scalar>(out[static_cast<size_t>(j) * nv + i] - out[static_cast<size_t>(nv) * nv + i]);
+            for (int j = 0; j < nv; j++) H(i, j) = static_cast<Scalar>(out[static_cast<size_t>(i) * nv + j]);
         return H;
+    }
+
+    // d ydd / d q, d ydd / d qd, d ydd / d tau of forwardDynamics for B states on HOST arrays, each [B][nv][nv] row-major, any
+    // of them may be null (grbda_fd_derivatives_*: analytic for explicit models).  The reference obtains these matrices by
+    // instantiating its templated algorithms with casadi::SX (UnitTests/testRigidBodyDynamicsAlgosDerivatives.cpp:271-383).
+    void forwardDynamicsDerivativesBatch(const double *q, const double *qd, const double *tau, double *dydd_dq, double *dydd_dqd,
+                                         double *dydd_dtau, size_t B, int device = 0)
+    {
+        check(grbda_fd_derivatives_host_f64(plan(), q, qd, tau, dydd_dq, dydd_dqd, dydd_dtau, B, device));
     }
 
     // batched entry points on HOST arrays (row-major q[B][nq], qd[B][nv], tau[B][nv] -> ydd[B][nv])

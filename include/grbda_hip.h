@@ -174,6 +174,10 @@ int grbda_fd_derivatives_f64(const grbda_plan *plan, const double *q, const doub
                              double *dydd_dqd, double *dydd_dtau, size_t B, int device, void *stream);
 int grbda_fd_derivatives_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, float *dydd_dq,
                              float *dydd_dqd, float *dydd_dtau, size_t B, int device, void *stream);
+/* host-array variants (allocate, copy and synchronise per call: for the facade's single-state calls and small batches) */
+int grbda_mass_matrix_host_f64(const grbda_plan *plan, const double *q, double *H, size_t B, int device);
+int grbda_fd_derivatives_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau, double *dydd_dq,
+                                  double *dydd_dqd, double *dydd_dtau, size_t B, int device);
 
 /* ---- steps either side of the path ------------------------------------------ */
 /* Newton projection of the DEPENDENT spanning coordinates of every implicit-loop cluster onto phi(q) = 0, in

@@ -106,6 +106,29 @@ static int roundtrip(Model &model, const char *what)
             res += s * s;
         }
         worst = std::fmax(worst, std::sqrt(res));
+        // derivatives of the forward dynamics (forwardDynamicsDerivativesBatch): H (d ydd / d tau) = 1, and
+        // d ydd / d qd against the exact unit central difference (the forward dynamics is quadratic in qd)
+        std::vector<double> qv(q.data(), q.data() + nq), qdv(qd.data(), qd.data() + nv), tv(tau.data(), tau.data() + nv);
+        std::vector<double> dtau(static_cast<size_t>(nv) * nv), dqd(static_cast<size_t>(nv) * nv);
+        model.forwardDynamicsDerivativesBatch(qv.data(), qdv.data(), tv.data(), nullptr, dqd.data(), dtau.data(), 1);
+        for (int i = 0; i < nv; i++)
+            for (int j = 0; j < nv; j++) {
+                double s = i == j ? -1.0 : 0.0;
+                for (int k = 0; k < nv; k++) s += H(i, k) * dtau[static_cast<size_t>(k) * nv + j];
+                worst = std::fmax(worst, std::fabs(s));
+            }
+        {
+            DVec<double> qp = qd, qm = qd;
+            qp[nv - 1] += 1.0;
+            qm[nv - 1] -= 1.0;
+            model.setState(std::make_pair(q, qp));
+            const DVec<double> yp = model.forwardDynamics(tau);
+            model.setState(std::make_pair(q, qm));
+            const DVec<double> ym = model.forwardDynamics(tau);
+            model.setState(std::make_pair(q, qd));
+            for (int i = 0; i < nv; i++)
+                worst = std::fmax(worst, std::fabs(0.5 * (yp[i] - ym[i]) - dqd[static_cast<size_t>(i) * nv + nv - 1]) / (1 + std::fabs(yp[i])));
+        }
     }
     // contact side: applyTestForce against H^-1 (dstate = H^-1 J^T f is what a unit impulse does), and the
     // end-effector operational-space inertia against it (testRigidBodyDynamicsAlgos.cpp:241-335)

@@ -21,7 +21,8 @@ if __name__ == "__main__":
     if len(sys.argv) == 3 and sys.argv[1] == "--one":
         one(int(sys.argv[2]))
     else:
-        for dbg, name in ((0, "full"), (1, "no prologue"), (4, "no epilogue"), (5, "segments only"), (2, "prologue+epilogue only"), (6, "prologue only"), (3, "epilogue only")):
+        for dbg, name in ((0, "full"), (1, "no prologue"), (4, "no epilogue"), (5, "segments only"), (2, "prologue+epilogue only"), (6, "prologue only"), (3, "epilogue only"),
+                          (8, "full, slab rows aliased"), (13, "segments only, aliased")):
             print(f"{name:24s}", end=" ", flush=True)
             for B in (131072, 262144, 524288, 1048576):
                 env = dict(os.environ, GRBDA_CHAIN_DEBUG=str(dbg))
