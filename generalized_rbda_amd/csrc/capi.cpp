@@ -734,7 +734,6 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     const HostPlan &h = p->host;
     const ChainProgram &cp = sizeof(T) == 8 ? h.chain64 : h.chain32;
     if (p->no_chain || p->no_efpa || !cp.ok || n_contacts > kOsimMaxContacts) return 1;
-    if (!cp.diffs.empty()) return 1;  // differential clusters: no force-propagation walk yet, the unit-wrench route serves them
     const Layout &L = h.lay64;
     OsimArgs<T> A;
     std::memset(&A, 0, sizeof A);
@@ -765,6 +764,15 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
                     if (cp.links[i].v_index == cr.v_index) found = static_cast<int>(i);
                 st.kind = OSIM_LINK;
                 rows += 1;
+            } else if (cr.kind == CK_LOOP) {
+                // two-rotor differential: the path enters at link1 (a contact on it) or at link2 (a contact on it or below)
+                for (size_t i = 0; i < cp.diffs.size(); i++)
+                    if (cp.diffs[i].v_index == cr.v_index) found = static_cast<int>(i);
+                if (found < 0) return 1;
+                if (!first || L.bodies[b].cofs == cp.diffs[found].cofs[1]) st.kind = OSIM_DIFF_LINK2;
+                else if (L.bodies[b].cofs == cp.diffs[found].cofs[0]) st.kind = OSIM_DIFF_LINK1;
+                else return 1;  // a contact on a rotor
+                rows += 2;
             } else {
                 if (!first) return 1;  // pair clusters are leaves of the chain program
                 for (size_t i = 0; i < cp.pairs.size(); i++)
@@ -830,7 +838,7 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.pairs = t->chain_pairs[w];
     d.frees = t->chain_frees[w];
     d.diffs = t->chain_diffs[w];
-    d.n_diffs = 0;
+    d.n_diffs = static_cast<int>(cp.diffs.size());
     d.cints = t->cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t->consts32) : reinterpret_cast<const T *>(t->consts64);
     d.n_segs = static_cast<int>(cp.segs.size());

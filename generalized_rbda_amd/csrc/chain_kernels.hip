@@ -531,7 +531,7 @@ __device__ __forceinline__ void diff_fwd(const ChainTables<T> &P, const ChainMem
 
 // backward segment: pair_bwd with per-state G rows -- rotors (1, 0), (0, 1); links (X00, X01), (X10, X11) -- the bias
 // accelerations g of the links, and child segments on link2.
-template <class T>
+template <class T, bool OSIM>
 __device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainDiff &d)
 {
     cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
@@ -662,6 +662,10 @@ __device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem
     blk[12] = i00 * u0 + i01 * u1;
     blk[13] = i01 * u0 + i11 * u1;
     M.glb_st(d.glb_k, blk);
+    if constexpr (OSIM) {  // D^-1 for the force-propagator walk of the contact frames (osim_chain_kernel)
+        const T ex[3] = {i00, i01, i11};
+        M.glb_st(d.glb_k + 24, ex);
+    }
     T acc[27];
     if (!d.acc_first) M.acc_ld(d.lds_acc_out, acc);
     else {
@@ -1137,7 +1141,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                     if constexpr (DIFF) diff_fwd(P, M, load_rec(P.diffs + sg.first));
                     break;
                 case SEG_DIFF_BWD:
-                    if constexpr (DIFF) diff_bwd(P, M, load_rec(P.diffs + sg.first));
+                    if constexpr (DIFF) diff_bwd<T, false>(P, M, load_rec(P.diffs + sg.first));
                     break;
                 case SEG_DIFF_ACC:
                     if constexpr (DIFF) diff_acc(P, M, load_rec(P.diffs + sg.first));
@@ -1184,8 +1188,8 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     P.links = (cptr<ChainLink>)DP.links;
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
-    P.diffs = nullptr;
-    P.cints = nullptr;
+    P.diffs = (cptr<ChainDiff>)DP.diffs;
+    P.cints = (cptr<int32_t>)DP.cints;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -1227,6 +1231,8 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
                 }
                 case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
                 case SEG_FREE_BWD: free_bwd<T, true>(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_DIFF_FWD: diff_fwd(P, M, load_rec(P.diffs + sg.first)); break;
+                case SEG_DIFF_BWD: diff_bwd<T, true>(P, M, load_rec(P.diffs + sg.first)); break;
                 default: break;  // no acceleration sweep
             }
         }
@@ -1291,6 +1297,58 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
 #pragma unroll
                             for (int j = 0; j < 6; j++) Js[(size_t)(6 * e + j) * nv + stp.v_index + i] = Kp[6 * i + j];
                     }
+                } else if (stp.kind == OSIM_DIFF_LINK1 || stp.kind == OSIM_DIFF_LINK2) {
+                    // two-rotor differential (ChainDiff): the path enters at link1 (a contact on it) or at link2 (a contact
+                    // on it or anything below it).  S^T K = G_l1^T (z^T K at link1) + G_l2^T (z^T K at link2), G rows (X00,
+                    // X01) and (X10, X11) of the state's constraint Jacobian; the rotors see nothing of the wrench
+                    const ChainDiff df = load_rec(P.diffs + stp.rec);
+                    cptr<T> C1 = P.consts + df.cofs[0], C2 = P.consts + df.cofs[1];
+                    T blk[27], E1[9], E2[9];
+                    M.glb_ld(df.glb_k, blk);
+                    rotate_z(blk[20], blk[21], C1, E1);
+                    rotate_z(blk[22], blk[23], C2, E2);
+                    T z1[6], z2[6], y1[6], y2[6];
+                    if (stp.kind == OSIM_DIFF_LINK2) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) { z2[j] = K[12 + j]; y2[j] = Kp[12 + j]; }
+                        k_up(E2, C2 + 9, K);
+                        if (Js) k_up(E2, C2 + 9, Kp);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) z2[j] = y2[j] = 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { z1[j] = K[12 + j]; y1[j] = Kp[12 + j]; }
+                    T s0[6], s1[6], p0[6], p1[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        s0[j] = blk[14] * z1[j] + blk[16] * z2[j];
+                        s1[j] = blk[15] * z1[j] + blk[17] * z2[j];
+                        p0[j] = blk[14] * y1[j] + blk[16] * y2[j];
+                        p1[j] = blk[15] * y1[j] + blk[17] * y2[j];
+                    }
+                    const T r00 = sqrt(blk[24]), r01 = blk[25] / r00, r11 = sqrt(blk[26] - r01 * r01);
+                    T w1[6], w2[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        w1[j] = r00 * s0[j] + r01 * s1[j];
+                        w2[j] = r11 * s1[j];
+                    }
+                    M.glb_st(wbase + stp.w_row * 6, w1);
+                    M.glb_st(wbase + (stp.w_row + 1) * 6, w2);
+                    if (Js && live) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            Js[(size_t)(6 * e + j) * nv + stp.v_index] = p0[j];
+                            Js[(size_t)(6 * e + j) * nv + stp.v_index + 1] = p1[j];
+                        }
+                    }
+                    k_up(E1, C1 + 9, K);
+                    if (Js) k_up(E1, C1 + 9, Kp);
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 6; j++) K[6 * i + j] -= blk[i] * s0[j] + blk[6 + i] * s1[j];
                 } else {
                     // leaf pair cluster: the contact sits on link1 or on link2 (child of link1)
                     const ChainPair pr = load_rec(P.pairs + stp.rec);

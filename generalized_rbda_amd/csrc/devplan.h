@@ -93,7 +93,7 @@ hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, 
 // osim_chain_kernel).  Built per call on the host (capi.cpp) and passed by value.
 constexpr int kOsimMaxContacts = 8;
 constexpr int kOsimMaxPath = 12;  // clusters between a contact body and the root
-enum OsimStepKind : int32_t { OSIM_LINK = 0, OSIM_PAIR_LINK1 = 1, OSIM_PAIR_LINK2 = 2, OSIM_FREE = 3 };
+enum OsimStepKind : int32_t { OSIM_LINK = 0, OSIM_PAIR_LINK1 = 1, OSIM_PAIR_LINK2 = 2, OSIM_FREE = 3, OSIM_DIFF_LINK1 = 4, OSIM_DIFF_LINK2 = 5 };
 struct OsimStep {
     int16_t kind;
     int16_t rec;      // index into links[] / pairs[] / frees[]

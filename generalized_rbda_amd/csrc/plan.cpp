@@ -1047,7 +1047,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     d.lds_pv = d.lds_sv = d.lds_acc = d.lds_acc_out = d.lds_pva = d.lds_va = d.lds_w = -1;
                     d.tofs_i = ds.tofs_i;
                     d.tofs_d = P.cints[ds.tofs_i + 2];
-                    d.glb_k = glb(24);  // [K 12][y0 2][X 4][g 2][s1 c1 s2 c2]
+                    d.glb_k = glb(27);  // [K 12][y0 2][X 4][g 2][s1 c1 s2 c2] (+ OSIM pass: D^-1 (3))
                 } else {
                     pair_of[c].glb_k = glb(21);  // [K 12][y0 2] (+ OSIM pass: D^-1 (3), sin / cos of the two links (4))
                     pair_of[c].rpre[0] = rotor_constants(pair_rotors[c][0]);

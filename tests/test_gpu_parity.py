@@ -549,6 +549,8 @@ OSIM_CASES = [
     ("urdf_mit_humanoid", ["left_ankle_link", "right_ankle_link", "right_elbow_link", "left_knee_link", "Floating Base"]),
     ("urdf_mini_cheetah_rpy", ["FR_knee_link", "FL_knee_link"]),
     ("chain_tree_a", None), ("chain_tree_b", None), ("chain_tree_rpy", None), ("chain_tree_norotor", None),
+    # implicit differentials: frames on link 2 / link 1 of the leaf (knee-ankle) and of the inner (hip) differential, an arm, the base
+    ("tello_with_arms", ["left-foot", "right-shin", "left-gimbal", "right-thigh", "left-elbow-link", "torso"]),
 ]
 
 
@@ -556,7 +558,8 @@ OSIM_CASES = [
 def test_inverse_osim_by_force_propagation(name, frames, gpu, monkeypatch):
     """Chain-covered models take the in-kernel force-propagation path (osim_chain_kernel: the recursion of
     ClusterTreeDynamics.cpp:194-233,295-435); it must give the same J H^-1 J^T and Jacobians as the oracle -- frames on
-    single links, on both links of leaf pair clusters, on the floating base, several frames sharing ancestors -- and as
+    single links, on both links of leaf pair clusters and of Tello's implicit differentials (leaf and inner), on the
+    floating base, several frames sharing ancestors -- and as
     the unit-wrench path it replaces (GRBDA_NO_EFPA=1)."""
     import torch
     from generalized_rbda_amd.states import parse_clusters
