@@ -403,7 +403,7 @@ class Plan:
 
     def fd_dq(self, q, qd, tau, step: float = 1e-6, stream=None):
         """d ydd / d q along the reference's tangent step (testHelpers.hpp:50-112), [B, nv, nv].  Explicit models:
-        analytic (`step` unused).  Models with implicit loops or a roll-pitch-yaw base: central differences, always taken
+        analytic (`step` unused).  Models with implicit loops: central differences, always taken
         in fp64 (fp32 tensors are converted on the device), on the constraint manifold."""
         import torch
 

@@ -1133,7 +1133,7 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
 
 // ---- analytic first-order derivatives of the forward dynamics (deriv_kernels.hip) ---------------------------------
 // d ydd / d tau = H^-1, d ydd / d q = -H^-1 dID/dq, d ydd / d qd = -H^-1 dID/dqd at ydd = FD(q, qd, tau); any of the three
-// outputs may be null.  Returns 1 when the model is not covered (implicit loops, roll-pitch-yaw base, nv > 64): the
+// outputs may be null.  Returns 1 when the model is not covered (implicit loops, nv > 64): the
 // callers then fall back to the unit-vector / central-difference batches of derived().
 template <class T>
 bool analytic_covers(const grbda_plan *p)

@@ -150,6 +150,21 @@ __device__ __forceinline__ void deriv_kin(cptr<T> C, bool axisym, T qi, T qdi, T
 // NMAX: the largest number of coordinates of a cluster of the model (1, 2 or NMAX).  The cluster-level
 // vectors are sized by it, and with them the register budget (the kernel runs one wavefront per SIMD: it is bound by
 // the traffic of its slab rows, two wavefronts per SIMD measured no faster).
+// a row of the six base columns of d tau / d q: from body-twist columns [rotation; translation] to the columns of the
+// roll-pitch-yaw coordinates [position; angles] (see the kernel)
+template <class T>
+__device__ __forceinline__ void rpy_columns(const T (&Rb)[9], const T (&Tb)[9], T (&row)[6])
+{
+    T out[6];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        out[a] = row[3] * Rb[a] + row[4] * Rb[3 + a] + row[5] * Rb[6 + a];
+        out[3 + a] = row[0] * Tb[a] + row[1] * Tb[3 + a] + row[2] * Tb[6 + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) row[a] = out[a];
+}
+
 template <class T, int NMAX>
 __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
                                                               const T *__restrict__ q, const T *__restrict__ qd,
@@ -184,14 +199,31 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
             a0[j] = DP.a_root[j];
             vb[j] = 0;
         }
+        // roll-pitch-yaw base: the reference's tangent step is plain q + dq there (position in world coordinates, then the
+        // angles), so the base's body-twist columns [rotation; translation] of d tau / d q go through
+        // d(twist) / d(pos, rpy) = [[0, Tb], [Rb, 0]]: Rb the base rotation, Tb the body angular velocity per unit angle rate
+        T Rb[9], Tb[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) Rb[j] = Tb[j] = (j % 4 == 0) ? T(1) : T(0);
+        const bool rpy = DP.ori_repr == 1;
         // ---- pass 1, root side first: kinematics in F of every body that has children ----
         for (int c = 0; c < n_clusters; c++) {
             const ClusterRec cr = load_rec(clusters + c);
             if (cr.kind == CK_FREE) {
                 T o[4], Eb[9], rb[3], g[6], kin[24];
 #pragma unroll
-                for (int j = 0; j < 4; j++) o[j] = qs[cr.q_index + 3 + j];
-                free_rotation(0, o, Eb);
+                for (int j = 0; j < 4; j++) o[j] = (rpy && j == 3) ? T(0) : qs[cr.q_index + 3 + j];
+                free_rotation(DP.ori_repr, o, Eb);
+                if (rpy) {
+                    T sx, cx, sy, cy;
+                    sincos_t(o[0], &sx, &cx);
+                    sincos_t(o[1], &sy, &cy);
+                    Tb[0] = 1; Tb[1] = 0; Tb[2] = -sy;
+                    Tb[3] = 0; Tb[4] = cx; Tb[5] = sx * cy;
+                    Tb[6] = 0; Tb[7] = -sx; Tb[8] = cx * cy;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) Rb[j] = Eb[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 3; j++) rb[j] = qs[cr.q_index + j];
 #pragma unroll
@@ -286,6 +318,7 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                     for (int j = 0; j < 36; j++) Bc[j] += acc[21 + j];
                 }
                 // d tau_b / d q_b = Ic crm(a0), d tau_b / d qd_b = Bc + Ic crm(vb)
+                T Mq[36];
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
                     T e[6], c1[6], c2[6], y1[6], y2[6];
@@ -295,11 +328,23 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                     crm(vb, e, c2);
                     symv(Ic, c1, y1);
                     symv(Ic, c2, y2);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        Mq[6 * i + j] = y1[i];
+                        Bc[6 * i + j] += y2[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    T row[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) row[j] = Mq[6 * i + j];
+                    if (rpy) rpy_columns(Rb, Tb, row);
                     if (live) {
 #pragma unroll
-                        for (int i = 0; i < 6; i++) {
-                            Dqs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = y1[i];
-                            Dqds[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Bc[6 * i + j] + y2[i];
+                        for (int j = 0; j < 6; j++) {
+                            Dqs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = row[j];
+                            Dqds[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Bc[6 * i + j];
                             if (Hs) Hs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Ic[sidx(i, j)];
                         }
                     }
@@ -532,10 +577,13 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                             T w1[6], w2[6];
                             crf(a0, T2[a2], w1);   // (a0 x e_k) . t = -(a0 x* t)_k
                             crf(vb, T2[a2], w2);
+#pragma unroll
+                            for (int k6 = 0; k6 < 6; k6++) w1[k6] = -w1[k6];
+                            if (rpy) rpy_columns(Rb, Tb, w1);
                             if (live) {
 #pragma unroll
                                 for (int k6 = 0; k6 < 6; k6++) {
-                                    Dqs[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = -w1[k6];
+                                    Dqs[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = w1[k6];
                                     Dqds[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = T1[a2][k6] - w2[k6];
                                     Dqs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T4[a2][k6];
                                     Dqds[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T3[a2][k6];

@@ -1507,7 +1507,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         DV.ok = sweep_mask == 7;
         for (const ClusterRec &cr : clusters) {
             if (cr.kind == CK_LOOP) DV.ok = false;
-            if (cr.kind == CK_FREE && (P.ori_repr != GRBDA_ORI_QUATERNION || cr.first_body != 0)) DV.ok = false;
+            if (cr.kind == CK_FREE && cr.first_body != 0) DV.ok = false;
         }
         DV.bodies.assign(nb, DerivBody{0, -1, -1, -1, 0, 0, {0, 0}});
         int rows = 0;

@@ -335,7 +335,7 @@ struct DerivBody {     // 8 ints
     int32_t reserved[2];
 };
 struct DerivProgram {
-    bool ok = false;  // explicit (constant G) clusters, quaternion or no floating base
+    bool ok = false;  // explicit (constant G) clusters
     std::vector<DerivBody> bodies;
     int n_rows = 0;
     int n_max = 1;    // largest number of coordinates of a cluster

@@ -143,10 +143,11 @@ int grbda_rnea_f32(const grbda_plan *plan, const float *q, const float *qd, cons
  *                     reference's derivative test uses                exact (truncation + rounding, the reference
  *                     (testHelpers.hpp:50-112: q_i += d; free base    uses step 1e-8 in fp64 and accepts 2e-5,
  *                     pos += R^T d, quat += quat x (0, d) / 2):       testRigidBodyDynamicsAlgosDerivatives.cpp:
- *                     column j = (ABA(q + h e_j) - ABA(q - h e_j))    309-335).  GRBDA_EUNSUPPORTED for models with
- *                     / (2 h), out[B][nv][nv]                         implicit-loop clusters or a roll-pitch-yaw base.
+ *                     column j = (ABA(q + h e_j) - ABA(q - h e_j))    309-335).  Implicit-loop models: an INDEPENDENT
+ *                     / (2 h), out[B][nv][nv]                         position moves, the dependent ones are re-projected
+ *                                                                     onto phi(q) = 0; a roll-pitch-yaw base: plain q + dq.
  *
- * Models made of explicit (constant G) clusters with a quaternion or no floating base and nv <= 64 -- every URDF robot of
+ * Models made of explicit (constant G) clusters with nv <= 64 -- every URDF robot of
  * the reference without <loop> elements -- do not go through those batches: the mass matrix comes from the
  * composite-rigid-body kernel, and the three derivatives from the ANALYTIC recursion of deriv_kernels.hip
  * (d ID / d q and d ID / d qd of the spanning tree projected with G, then one batched SPD solve per state:

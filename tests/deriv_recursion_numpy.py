@@ -148,6 +148,17 @@ def rnea_derivs(m, q, qd, ydd):
                         dq[np.ix_(ij, ik)] += np.outer(gj, gk) * (Sj @ t4)
                         dqd[np.ix_(ij, ik)] += np.outer(gj, gk) * (Sj @ t3)
                 j = bodies[j]["parent"]
+    if base is not None and m["ori"] == 1:
+        # roll-pitch-yaw base: the reference's tangent step is plain q + dq there (position in world coordinates, then the
+        # three angles), so the base's body-twist columns [rotation; translation] are mapped through
+        # d(twist) / d(pos, rpy) = [[0, T], [R, 0]], T = body angular velocity per unit rate of (roll, pitch, yaw)
+        fb, qi, vi = base
+        r, p_ = q[qi + 3], q[qi + 4]
+        sx, cx, sy, cy = np.sin(r), np.cos(r), np.sin(p_), np.cos(p_)
+        T = np.array([[1, 0, -sy], [0, cx, sx * cy], [0, -sx, cx * cy]])
+        R = rpy_to_rotmat(q[qi + 3:qi + 6])
+        J6 = np.block([[np.zeros((3, 3)), T], [R, np.zeros((3, 3))]])
+        dq[:, vi:vi + 6] = dq[:, vi:vi + 6] @ J6
     return tau, dq, dqd
 
 

@@ -109,9 +109,9 @@ def test_chain_program_covers_the_headline_models():
         assert G.Plan(z[name]).info().chain_aba_f64 == 1, name
     ti = G.Plan(z["tello_with_arms"]).info()
     assert ti.chain_rnea_f32 == 1 and ti.n_chain_differentials == 4
-    # analytic derivatives (deriv_kernels.hip): explicit clusters with a quaternion or no floating base
+    # analytic derivatives (deriv_kernels.hip): explicit clusters
     for name, want in (("urdf_jvrc1_humanoid", 1), ("urdf_mit_humanoid", 1), ("tree_mixed_fixed", 1), ("tree_generic_float", 1),
-                       ("tello_with_arms", 0), ("urdf_four_bar", 0), ("urdf_mini_cheetah_rpy", 0)):
+                       ("tello_with_arms", 0), ("urdf_four_bar", 0), ("urdf_mini_cheetah_rpy", 1)):
         assert G.Plan(z[name]).info().analytic_derivatives == want, name
     for name in ("urdf_four_bar", "tree_generic_float", "rev_rotor_chain_3"):
         assert G.Plan(z[name]).info().chain_aba_f32 == 0, name

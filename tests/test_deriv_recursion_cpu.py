@@ -19,7 +19,7 @@ from models import valid_states, zoo  # noqa: E402
 
 
 @pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_revolute_rotor_chain", "tree_pair_float", "tree_triple_fixed",
-                                  "tree_generic_float", "rev_pair_rotor_chain_4"])
+                                  "tree_generic_float", "rev_pair_rotor_chain_4", "urdf_mini_cheetah_rpy", "chain_tree_rpy"])
 def test_recursion_matches_differences_of_the_oracle(name):
     blob = zoo()[name]
     m = P.parse(blob)

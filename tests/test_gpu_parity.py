@@ -394,7 +394,7 @@ def test_position_derivative_matches_oracle_differences(name, gpu):
     J32 = plan.fd_dq(t32(q), t32(qd), t32(tau), step=h).double().cpu().numpy()
     c32 = lambda a: a.astype(np.float32).astype(np.float64)
     J_of_32 = plan.fd_dq(t(c32(q)), t(c32(qd)), t(c32(tau)), step=h).cpu().numpy()
-    analytic = not any(c[9] >= 2 for c in m["clusters"]) and m["ori"] == 0
+    analytic = not any(c[9] >= 2 for c in m["clusters"])
     assert np.abs(J32 - J_of_32).max() / scale < (2e-4 if analytic else 1e-5)
 
 
@@ -406,7 +406,7 @@ def test_fd_derivatives_analytic_against_difference_batches(name, gpu, monkeypat
     the same model with GRBDA_NO_ANALYTIC=1 takes the unit-vector / central-difference batches through the ABA kernel,
     which the tests above pin to the oracle.  d ydd/d tau and d ydd/d qd are exact on both routes; d ydd/d q is compared
     within the reference's own tolerance for its derivative test (2e-5).  130 states: two full tiles and a ragged one.
-    Models with implicit loops or a roll-pitch-yaw base fall back to the batches on both plans."""
+    Models with implicit loops fall back to the batches on both plans."""
     import torch
 
     blob = zoo()[name]
