@@ -356,10 +356,25 @@ __device__ __forceinline__ void wave_lds_fence()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
+// The staged block is the row-major [state][column] copy of the inputs; lane l reads its own row.  With an even number of
+// columns a column-at-a-time read hits the same LDS banks from many lanes (24 columns: 8-way conflicts, measured as 39 %
+// of the LDS-active cycles of the forward dynamics); 16-byte reads of the lane's own row (rows are 16-byte aligned when
+// the row size is a multiple of 16 bytes) conflict at most 2-way.
 template <class T>
 __device__ __forceinline__ void stage_transpose(int ncols, unsigned lds_byte_off, T *slab_rows, int lane)
 {
     const T *stage = reinterpret_cast<const T *>(grbda_smem + lds_byte_off);
+    constexpr int V = 16 / (int)sizeof(T);  // elements per 16-byte read
+    if ((ncols % V) == 0 && (lds_byte_off % 16u) == 0) {
+        struct alignas(16) Vec { T v[V]; };
+        const Vec *rows = reinterpret_cast<const Vec *>(stage + lane * ncols);
+        for (int c = 0; c < ncols; c += V) {
+            const Vec x = rows[c / V];
+#pragma unroll
+            for (int k = 0; k < V; k++) slab_rows[(size_t)(c + k) * kWave + lane] = x.v[k];
+        }
+        return;
+    }
     for (int c = 0; c < ncols; c++) slab_rows[(size_t)c * kWave + lane] = stage[lane * ncols + c];
 }
 template <class T>
@@ -407,7 +422,19 @@ __device__ __forceinline__ void write_outputs(const T *rows, T *__restrict__ out
 {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the row stores have landed
     T *stage = reinterpret_cast<T *>(grbda_smem);
-    for (int c = 0; c < nv; c++) stage[lane * nv + c] = rows[(size_t)c * kWave + lane];
+    constexpr int V = 16 / (int)sizeof(T);
+    if ((nv % V) == 0) {  // 16-byte writes of the lane's own row (see stage_transpose)
+        struct alignas(16) Vec { T v[V]; };
+        Vec *mine = reinterpret_cast<Vec *>(stage + lane * nv);
+        for (int c = 0; c < nv; c += V) {
+            Vec x;
+#pragma unroll
+            for (int k = 0; k < V; k++) x.v[k] = rows[(size_t)(c + k) * kWave + lane];
+            mine[c / V] = x;
+        }
+    } else {
+        for (int c = 0; c < nv; c++) stage[lane * nv + c] = rows[(size_t)c * kWave + lane];
+    }
     wave_lds_fence();
     T *dst = out + tile * (size_t)kWave * (size_t)nv;
     const int total = rows_valid * nv;

@@ -5,8 +5,8 @@ acc = defaultdict(list)
 for f in glob.glob(os.path.join(sys.argv[1], "p*", "**", "*counter_collection.csv"), recursive=True):
     per = defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if "grbda" not in r["Kernel_Name"]:
-            continue
+        if "grbda" not in r["Kernel_Name"] or not ("aba" in r["Kernel_Name"] or "rnea" in r["Kernel_Name"]):
+            continue  # (input generation runs project_kernel on TelloWithArms: not the kernel under study)
         per[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (d, name), v in per.items():
         acc[name].append(v)
