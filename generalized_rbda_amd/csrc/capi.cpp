@@ -58,12 +58,12 @@ struct DeviceTables {
     ChainDiff *chain_diffs[3] = {nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
-    // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64
-    RneaSeg *rchain_segs[2] = {nullptr, nullptr};
-    RneaLink *rchain_links[2] = {nullptr, nullptr};
-    RneaPair *rchain_pairs[2] = {nullptr, nullptr};
-    RneaFree *rchain_frees[2] = {nullptr, nullptr};
-    RneaDiff *rchain_diffs[2] = {nullptr, nullptr};
+    // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w)
+    RneaSeg *rchain_segs[3] = {nullptr, nullptr, nullptr};
+    RneaLink *rchain_links[3] = {nullptr, nullptr, nullptr};
+    RneaPair *rchain_pairs[3] = {nullptr, nullptr, nullptr};
+    RneaFree *rchain_frees[3] = {nullptr, nullptr, nullptr};
+    RneaDiff *rchain_diffs[3] = {nullptr, nullptr, nullptr};
     int n_cu = 0;
 };
 struct Scratch {
@@ -118,6 +118,7 @@ struct grbda_plan {
     bool no_chain = false;  // GRBDA_NO_CHAIN=1: keep the general interpreter (A/B runs, tests of the general kernels)
     int chain_debug = 0;
     bool no_crba = false;
+    bool rnea_narrow = false;  // GRBDA_RNEA_NARROW=1: the inverse-dynamics chain kernel stays at two wavefronts per SIMD
     bool no_analytic = false;  // GRBDA_NO_ANALYTIC=1: derivatives by the unit-vector / central-difference batches only
     bool solve_f64 = false;    // GRBDA_SOLVE_F64=1: the SPD solve of the f32 derivative entry points computes in f64
     int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 4)
@@ -193,8 +194,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(L.acc_k.data(), L.acc_k.size() * sizeof(int32_t), (void **)&t.acc_k[w])) != hipSuccess)
             return hip_err(e, "plan upload");
     }
-    for (int w = 0; w < 2; w++) {
-        const RneaChainProgram &rp = w ? h.rchain64 : h.rchain32;
+    for (int w = 0; w < 3; w++) {
+        const RneaChainProgram &rp = w == 0 ? h.rchain32 : (w == 1 ? h.rchain64 : h.rchain32w);
         if (!rp.ok) continue;
         if ((e = up(rp.segs.data(), rp.segs.size() * sizeof(RneaSeg), (void **)&t.rchain_segs[w])) != hipSuccess ||
             (e = up(rp.links.data(), rp.links.size() * sizeof(RneaLink), (void **)&t.rchain_links[w])) != hipSuccess ||
@@ -347,8 +348,16 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
                    void *stream)
 {
     const HostPlan &h = p->host;
-    const int w = sizeof(T) == 8 ? 1 : 0;
-    const RneaChainProgram &rp = w ? h.rchain64 : h.rchain32;
+    const int kid = sizeof(T) == 8 ? 1 : 0;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    // f32: the inverse-dynamics kernel needs 109 VGPRs, so four wavefronts per SIMD fit; models whose blocks all fit the
+    // LDS of the two-per-SIMD shape (no global-slab fallback) run the program laid out for half the LDS per wavefront
+    // once the batch fills 16 wavefronts per CU (MIT humanoid 0.105 -> 0.095 ms, Mini Cheetah 0.079 -> 0.070 ms; JVRC-1,
+    // whose blocks spill already, loses)
+    const bool wide = sizeof(T) == 4 && !p->rnea_narrow && h.rchain32w.ok && h.rchain32.ok && h.rchain32.n_glb == 0 &&
+                      n_tiles > static_cast<size_t>(t.n_cu) * 8;
+    const int w = wide ? 2 : kid;
+    const RneaChainProgram &rp = wide ? h.rchain32w : (kid ? h.rchain64 : h.rchain32);
     RneaChainDev<T> d;
     d.segs = t.rchain_segs[w];
     d.links = t.rchain_links[w];
@@ -364,9 +373,8 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     d.n_glb_slots = rp.n_glb;
     d.ori_repr = h.ori_repr;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
-    const size_t n_tiles = (B + kWave - 1) / kWave;
-    const size_t waves_per_cu = static_cast<size_t>(p->waves_per_cu[w]);  // the ABA launch shape: 8 wavefronts per CU
-    const size_t lds_budget = static_cast<size_t>(p->lds_bytes_per_wave[w]);
+    const size_t waves_per_cu = wide ? 16 : static_cast<size_t>(p->waves_per_cu[kid]);  // the ABA launch shape: 8 wavefronts per CU
+    const size_t lds_budget = wide ? 10240 : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
     size_t grid = static_cast<size_t>(t.n_cu) * waves_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     size_t lds_bytes = static_cast<size_t>(rp.n_lds) * kWave * sizeof(T);
@@ -1337,6 +1345,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
     p->chain_debug = env_int("GRBDA_CHAIN_DEBUG", 0);
     p->no_crba = env_int("GRBDA_NO_CRBA", 0) != 0;
+    p->rnea_narrow = env_int("GRBDA_RNEA_NARROW", 0) != 0;
     p->no_analytic = env_int("GRBDA_NO_ANALYTIC", 0) != 0;
     p->solve_f64 = env_int("GRBDA_SOLVE_F64", 0) != 0;
     p->deriv_waves = env_int("GRBDA_DERIV_WAVES_PER_CU", 0);
@@ -1393,7 +1402,7 @@ void grbda_plan_free(grbda_plan *p)
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies);
-        for (int w = 0; w < 2; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
+        for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
         for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }

@@ -1475,7 +1475,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     };
     // the RNEA chain kernels run 8 wavefronts per CU like the ABA ones: the ABA budgets apply
     build_chain(P.chain32, lds.aba32, &P.rchain32, lds.aba32);
-    build_chain(P.chain32w, lds.chain32w, nullptr, 0);
+    build_chain(P.chain32w, lds.chain32w, &P.rchain32w, lds.chain32w);
     build_chain(P.chain64, lds.aba64, &P.rchain64, lds.aba64);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------

@@ -365,6 +365,7 @@ struct HostPlan {
     CrbaProgram crba;
     DerivProgram deriv;
     RneaChainProgram rchain32, rchain64;  // inverse dynamics on the chains
+    RneaChainProgram rchain32w;           // f32 laid out for four wavefronts per SIMD (half the LDS per wavefront)
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };
