@@ -435,6 +435,60 @@ def test_fd_derivatives_analytic_against_difference_batches(name, gpu, monkeypat
         assert np.abs(a - b).max() / (1.0 + np.abs(b).max()) < TOL32, k
 
 
+def _sweep_models():
+    """Random models beyond the fixed zoo: chain-structured robots (branching links, leaf pairs, long limbs, with and
+    without rotors, both base orientations) and random cluster trees of every explicit type, floating and fixed."""
+    from models import chain_test_tree, random_cluster_tree
+
+    out = []
+    for seed in range(101, 109):
+        out.append((f"chain{seed}", lambda s=seed: chain_test_tree(s, n_limbs=2 + s % 4, ori_repr="rpy" if s % 3 == 0 else "quaternion",
+                                                                   rotors=s % 4 != 1)))
+    for seed in range(201, 207):
+        out.append((f"tree{seed}", lambda s=seed: random_cluster_tree(s, n_clusters=5 + s % 6, floating=s % 2 == 0,
+                                                                      ori_repr="rpy" if s % 5 == 0 else "quaternion")))
+    return out
+
+
+@pytest.mark.parametrize("name,build", _sweep_models(), ids=[m[0] for m in _sweep_models()])
+def test_random_model_sweep_dynamics_and_derivatives(name, build, gpu):
+    """Forward / inverse dynamics, mass matrix and the three derivative matrices of freshly drawn random models against the
+    oracle (derivatives: central differences of the oracle along the reference's tangent step), fp64 and fp32, 70 states
+    (one full tile and a ragged one).  Whatever program shape the plan compiler picks for a model is what gets tested."""
+    import torch
+
+    blob = build().serialize()
+    plan = G.Plan(blob)
+    B = 70
+    q, qd, tau = valid_states(blob, B, config_index=77)
+    for dt, tol in ((torch.float64, TOL64), (torch.float32, TOL32)):
+        c = (lambda a: a) if dt == torch.float64 else (lambda a: a.astype(np.float32).astype(np.float64))
+        ydd = run_gpu(plan, "aba", q, qd, tau, dt, gpu)
+        assert rel_err(ydd, O.forward_dynamics(blob, c(q), c(qd), c(tau))) < tol
+        t_ = run_gpu(plan, "rnea", q, qd, tau, dt, gpu)
+        assert rel_err(t_, O.inverse_dynamics(blob, c(q), c(qd), c(tau))) < tol
+    from generalized_rbda_amd.states import parse_clusters
+
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    d = plan.fd_derivatives(t(q[:3]), t(qd[:3]), t(tau[:3]))
+    m = parse_clusters(blob)
+    nv, h = plan.nv, 1e-6
+    for b in range(3):
+        J_q, J_qd, J_tau = np.empty((nv, nv)), np.empty((nv, nv)), np.empty((nv, nv))
+        for k in range(nv):
+            e = np.zeros(nv)
+            e[k] = 1.0
+            qp, qm = _reference_plus_on_manifold(blob, m, q[b], k, +h)[None], _reference_plus_on_manifold(blob, m, q[b], k, -h)[None]
+            J_q[:, k] = (O.forward_dynamics(blob, qp, qd[b:b + 1], tau[b:b + 1])[0] - O.forward_dynamics(blob, qm, qd[b:b + 1], tau[b:b + 1])[0]) / (2 * h)
+            J_qd[:, k] = (O.forward_dynamics(blob, q[b:b + 1], (qd[b] + e)[None], tau[b:b + 1])[0]
+                          - O.forward_dynamics(blob, q[b:b + 1], (qd[b] - e)[None], tau[b:b + 1])[0]) / 2
+            J_tau[:, k] = (O.forward_dynamics(blob, q[b:b + 1], qd[b:b + 1], (tau[b] + e)[None])[0]
+                           - O.forward_dynamics(blob, q[b:b + 1], qd[b:b + 1], (tau[b] - e)[None])[0]) / 2
+        for key, ref, tol in (("dq", J_q, 2e-5), ("dqd", J_qd, 1e-8), ("dtau", J_tau, 1e-8)):
+            got = d[key][b].cpu().numpy()
+            assert np.abs(got - ref).max() / (1.0 + np.abs(ref).max()) < tol, (key, b)
+
+
 # ---- contact side: body poses, applyTestForce -----------------------------------------------------------
 @pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
 def test_body_poses_match_oracle(name, blob, gpu):
