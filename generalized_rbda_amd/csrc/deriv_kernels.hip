@@ -297,6 +297,10 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
             }
         }
         // ---- pass 2, leaf side first ----
+        T part[63];  // what the in-cluster roots of a cluster hand to the parent body: one read-modify-write per cluster, or
+                     // no memory traffic at all along chains (DerivBody::carry_out: it stays here for the next cluster)
+#pragma unroll
+        for (int j = 0; j < 63; j++) part[j] = 0;
         for (int c = n_clusters - 1; c >= 0; c--) {
             const ClusterRec cr = load_rec(clusters + c);
             if (cr.kind == CK_FREE) {
@@ -355,9 +359,12 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
             // cluster-level descendant-side vectors and the contribution to the parent body's accumulator
             T T1[NMAX][6], T2[NMAX][6], T3[NMAX][6], T4[NMAX][6];
             T Cq[NMAX][NMAX], Cqd[NMAX][NMAX], Ch[NMAX][NMAX];
-            T part[63];  // what the in-cluster roots hand to the parent body: one read-modify-write per cluster
+            const DerivBody xf = load_rec(db + cr.first_body);
+            const int first_i = xf.carry_body >= 0 ? xf.carry_body - cr.first_body : -1;
+            if (first_i < 0) {
 #pragma unroll
-            for (int j = 0; j < 63; j++) part[j] = 0;
+                for (int j = 0; j < 63; j++) part[j] = 0;
+            }
 #pragma unroll
             for (int a2 = 0; a2 < NMAX; a2++) {
 #pragma unroll
@@ -365,7 +372,13 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
 #pragma unroll
                 for (int b2 = 0; b2 < NMAX; b2++) Cq[a2][b2] = Cqd[a2][b2] = Ch[a2][b2] = 0;
             }
-            for (int i = cr.k - 1; i >= 0; i--) {
+            // (the body that receives carried composites comes first, the others last body first)
+            for (int step = first_i >= 0 ? -1 : 0; step < cr.k; step++) {
+                int i = first_i;
+                if (step >= 0) {
+                    i = cr.k - 1 - step;
+                    if (i == first_i) continue;
+                }
                 const int gb = cr.first_body + i;
                 const BodyRec b = load_rec(bodies + gb);
                 const DerivBody x = load_rec(db + gb);
@@ -435,7 +448,16 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                     for (int j = 0; j < 6; j++) Fc[j] = Ia[j] + vh[j];
                 }
                 body_B(Ic, v, h, Bc);
-                if (x.acc_row >= 0) {
+                if (step < 0) {  // the composites of the subtree arrived in registers
+#pragma unroll
+                    for (int j = 0; j < 21; j++) Ic[j] += part[j];
+#pragma unroll
+                    for (int j = 0; j < 36; j++) Bc[j] += part[21 + j];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) Fc[j] += part[57 + j];
+#pragma unroll
+                    for (int j = 0; j < 63; j++) part[j] = 0;
+                } else if (x.acc_row >= 0) {
                     T acc[63];
                     R.ld(x.acc_row, acc);
 #pragma unroll
@@ -539,8 +561,7 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                     for (int j = 0; j < 6; j++) part[57 + j] += Fc[j];
                 }
             }
-            if (cr.parent_body >= 0) {
-                const DerivBody xf = load_rec(db + cr.first_body);
+            if (cr.parent_body >= 0 && !xf.carry_out) {
                 const DerivBody xp = load_rec(db + cr.parent_body);
                 if (!xf.cluster_acc_first) {
                     T acc[63];

@@ -1509,7 +1509,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             if (cr.kind == CK_LOOP) DV.ok = false;
             if (cr.kind == CK_FREE && cr.first_body != 0) DV.ok = false;
         }
-        DV.bodies.assign(nb, DerivBody{0, -1, -1, -1, 0, 0, {0, 0}});
+        DV.bodies.assign(nb, DerivBody{0, -1, -1, -1, 0, 0, 0, -1});
         int rows = 0;
         for (int b = 0; b < nb; b++) {
             DV.bodies[b].cluster = m.bodies[b].cluster;
@@ -1523,6 +1523,24 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
         for (const ClusterRec &cr : clusters)
             if (cr.kind != CK_FREE) DV.n_max = std::max(DV.n_max, cr.n);
+        // register hand-over along chains: a cluster that is the only contributor to its parent body, directly before that
+        // body's cluster in the processing order, leaves its composites in registers; the receiving body (no in-cluster
+        // children) is processed first in its cluster
+        std::vector<char> carried(nb, 0);
+        for (int c = nc - 1; c >= 1; c--) {
+            const ClusterRec &cr = clusters[c];
+            const int pb = cr.parent_body;
+            if (pb < 0 || m.bodies[pb].cluster != c - 1 || bodies[pb].jtype == GRBDA_JOINT_FREE || bodies[pb].lam >= 0) continue;
+            int contributors = 0;
+            for (int c2 = 0; c2 < nc; c2++)
+                if (clusters[c2].parent_body == pb) contributors++;
+            for (int b = 0; b < nb; b++)
+                if (bodies[b].lam == pb) contributors += 2;
+            if (contributors != 1) continue;
+            DV.bodies[cr.first_body].carry_out = 1;
+            DV.bodies[clusters[c - 1].first_body].carry_body = pb;
+            carried[pb] = 1;
+        }
         // accumulators: written by the child clusters (one combined write each, highest cluster first) and by in-cluster
         // children, read when the body itself is processed; rows are shared between accumulators that are never live together
         std::vector<int> birth(nb, -1), death(nb, -1);
@@ -1544,7 +1562,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
         std::vector<Obj> aobjs;
         for (int b = 0; b < nb; b++)
-            if (bodies[b].has_child) aobjs.push_back({&DV.bodies[b].acc_row, 63, 0, birth[b], death[b], -1, 1});
+            if (bodies[b].has_child && !carried[b]) aobjs.push_back({&DV.bodies[b].acc_row, 63, 0, birth[b], death[b], -1, 1});
         int n_acc = 0, n_unused = 0;
         allocate(aobjs, 1 << 28, n_acc, n_unused);
         for (int b = 0; b < nb; b++)

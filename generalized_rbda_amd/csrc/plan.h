@@ -332,7 +332,9 @@ struct DerivBody {     // 8 ints
     int32_t acc_row;    // bodies with children: 63 rows [Ic 21][Bc 36][Fc 6], composite sums over the descendants; else -1
     int32_t acc_first;  // this body is the first writer of the accumulator of its in-cluster parent
     int32_t cluster_acc_first;  // (first body of a cluster) the cluster is the first writer of the accumulator of its parent body
-    int32_t reserved[2];
+    int32_t carry_out;  // (first body of a cluster) the cluster is the only contributor to its parent body and that body's
+                        // cluster is processed next: the composites stay in registers instead of going through the slab
+    int32_t carry_body; // (first body of a cluster) the body that receives them (processed first in its cluster), or -1
 };
 struct DerivProgram {
     bool ok = false;  // explicit (constant G) clusters
