@@ -933,8 +933,14 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             } else if (cr.kind == CK_STATIC && cr.shape != SHAPE_GENERIC) {
                 cls[c] = cr.shape == SHAPE_REV ? 1 : 2;
                 tip[c] = cr.link_body;
-            } else if (cr.kind == CK_STATIC && cr.n == 1 && cr.k == 2 && !cr.chained && cr.parent_body >= 0 &&
+            } else if (cr.kind == CK_STATIC && cr.n == 1 && cr.k == 1 && cr.parent_body < 0) {
+                // a single revolute link on the ground (the straight-line shapes of the interpreter need a parent body; the
+                // runs do not)
+                cls[c] = 1;
+                tip[c] = cr.first_body;
+            } else if (cr.kind == CK_STATIC && cr.n == 1 && cr.k == 2 && !cr.chained &&
                        (!bodies[cr.first_body].has_child || !bodies[cr.first_body + 1].has_child)) {
+                // (also: a link and any rotor on the ground -- rotors there are not folded into a parent's constants)
                 // a link and a rotor that is NOT axisymmetric about its joint axis (JVRC-1: every rotor carries the same
                 // z-symmetric inertia whatever its axis): the rotor is evaluated at its own angle
                 cls[c] = 4;
@@ -981,7 +987,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             } else {
                 ok = false;
             }
-            if (cls[c] != 0 && cr.parent_body < 0) ok = false;  // fixed-base models stay on the general kernels
+            // (links may hang off the ground -- fixed-base models: the runs then start from v = 0, a = -gravity and hand
+            // their inertia to nobody; pair and differential clusters need a parent body)
+            if ((cls[c] == 3 || cls[c] == 5) && cr.parent_body < 0) ok = false;
             if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d (k %d n %d kind %d shape %d) not covered\n", c, cr.k, cr.n, cr.kind, cr.shape);
         }
         // every child cluster must hang off the tip body of its parent cluster; a pair must be an only child of a link
@@ -1025,7 +1033,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 } else if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) {
                     ChainLink &l = link_of[c];
                     l = ChainLink();
-                    const BodyRec &br = bodies[cls[c] == 4 ? tip[c] : cr.link_body];
+                    const BodyRec &br = bodies[tip[c]];
                     l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = br.cofs;
                     l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : (cls[c] == 4 ? bodies[gen_rotor[c]].cofs : -1);
                     l.rpre = cls[c] == 2 ? rotor_constants(cr.rotor_body) : -1;  // rofs >= 0 with rpre < 0: a general rotor
@@ -1061,7 +1069,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::vector<Chain> chains;
             std::function<int(int)> make_chain = [&](int c0) -> int {
                 Chain ch;
-                ch.parent_cluster = m.bodies[clusters[c0].parent_body].cluster;
+                ch.parent_cluster = clusters[c0].parent_body >= 0 ? m.bodies[clusters[c0].parent_body].cluster : -1;
                 int c = c0;
                 for (;;) {
                     ch.cl.push_back(c);
@@ -1144,10 +1152,15 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             // roots
             std::vector<std::vector<int>> free_chains(nc);
             std::vector<int> t_free_fwd(nc, -1), t_free_bwd(nc, -1), t_free_acc(nc, -1);
-            for (int c = 0; c < nc; c++)
+            std::vector<int> ground_chains;  // chains whose first link hangs off the ground
+            for (int c = 0; c < nc; c++) {
                 if (cls[c] == 0)
                     for (int k : ckids[c]) free_chains[c].push_back(make_chain(k));
+                else if (clusters[c].parent_body < 0)
+                    ground_chains.push_back(make_chain(c));
+            }
             ct.assign(chains.size(), SegTimes());
+            for (int id : ground_chains) emit_fb(id);
             for (int c = 0; c < nc; c++) {
                 if (cls[c] != 0) continue;
                 ChainSeg sg = ChainSeg();
@@ -1164,6 +1177,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 t_free_acc[c] = push_seg(sg);
                 for (int id : free_chains[c]) emit_acc(id);
             }
+            for (int id : ground_chains) emit_acc(id);
             // ---- the inverse-dynamics program on the same chains (plan.h, RneaChainProgram) ----
             if (RP) {
                 RneaChainProgram &R = *RP;
@@ -1197,6 +1211,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     return last;
                 };
                 std::vector<int> last_fwd_of(chains.size(), -1);
+                for (int id : ground_chains) remit(id);
                 for (int c = 0; c < nc; c++) {
                     if (cls[c] != 0) continue;
                     rt_free_fwd[c] = rpush(RSEG_FREE_FWD);
@@ -1279,11 +1294,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             d.lds_va = chains[id].kid_chains.empty() ? -1 : d.lds_blk + 14;
                         }
                     auto f_slot_of_body = [&](int b) -> int {
+                        if (b < 0) return -1;  // ground
                         const int c = m.bodies[b].cluster;
                         if (cls[c] == 5) return rd[c].lds_blk;
                         return cls[c] == 0 ? rf[c].lds_f : rl[c].lds_blk;
                     };
                     auto va_slot_of_body2 = [&](int b) -> int {
+                        if (b < 0) return -1;
                         const int c = m.bodies[b].cluster;
                         if (cls[c] == 5) return rd[c].lds_va;
                         return cls[c] == 0 ? rf[c].lds_va : rl[c].lds_va;
@@ -1402,17 +1419,20 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 CP.n_lds = n_lds;
                 CP.n_glb = n_glb;
                 // parent velocity / (v, a) slots
-                auto v_slot_of_body = [&](int b) -> int {  // LDS slot of the velocity of body b (tip of its cluster)
+                auto v_slot_of_body = [&](int b) -> int {  // LDS slot of the velocity of body b (tip of its cluster); -1: ground
+                    if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
                     if (cls[c] == 5) return diff_of[c].lds_sv + 2;
                     return cls[c] == 0 ? free_of[c].lds_v : link_of[c].lds_sv + 2;  // (+2 keeps a kSlotGlobal flag intact)
                 };
                 auto va_slot_of_body = [&](int b) -> int {
+                    if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
                     if (cls[c] == 5) return diff_of[c].lds_va;
                     return cls[c] == 0 ? free_of[c].lds_va : link_of[c].lds_va;
                 };
                 auto acc_slot_of_body = [&](int b) -> int {
+                    if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
                     if (cls[c] == 5) return diff_of[c].lds_acc;
                     return cls[c] == 0 ? free_of[c].lds_acc : acc_slot[c];
@@ -1441,13 +1461,15 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     bw.lds_acc_out = acc_slot_of_body(pb);
                     // first writer: earliest backward run among the sibling chains
                     bool first = true;
-                    const int pc = m.bodies[pb].cluster;
-                    int parent_chain = 0;
-                    for (size_t j = 0; j < chains.size(); j++)
-                        if (chains[j].cl.back() == pc) parent_chain = static_cast<int>(j);
-                    const std::vector<int> &sib = cls[pc] == 0 ? free_chains[pc] : chains[parent_chain].kid_chains;
-                    for (int o : sib)
-                        if (ct[o].bwd < ct[id].bwd) first = false;
+                    if (pb >= 0) {
+                        const int pc = m.bodies[pb].cluster;
+                        int parent_chain = 0;
+                        for (size_t j = 0; j < chains.size(); j++)
+                            if (chains[j].cl.back() == pc) parent_chain = static_cast<int>(j);
+                        const std::vector<int> &sib = cls[pc] == 0 ? free_chains[pc] : chains[parent_chain].kid_chains;
+                        for (int o : sib)
+                            if (ct[o].bwd < ct[id].bwd) first = false;
+                    }
                     bw.acc_first = first ? 1 : 0;
                     ChainSeg &ac = CP.segs[ct[id].acc];
                     ac.lds_pva = va_slot_of_body(pb);

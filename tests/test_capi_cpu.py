@@ -113,5 +113,9 @@ def test_chain_program_covers_the_headline_models():
     for name, want in (("urdf_jvrc1_humanoid", 1), ("urdf_mit_humanoid", 1), ("tree_mixed_fixed", 1), ("tree_generic_float", 1),
                        ("tello_with_arms", 0), ("urdf_four_bar", 0), ("urdf_mini_cheetah_rpy", 1)):
         assert G.Plan(z[name]).info().analytic_derivatives == want, name
-    for name in ("urdf_four_bar", "tree_generic_float", "rev_rotor_chain_3"):
+    # fixed-base chains of links (the reference's RevoluteChainWithRotor family, config 1's URDF) start their runs on the ground
+    for name in ("rev_rotor_chain_3", "urdf_revolute_rotor_chain", "tree_rev_fixed"):
+        info = G.Plan(z[name]).info()
+        assert info.chain_aba_f32 == 1 and info.chain_rnea_f32 == 1 and info.chain_aba_f64 == 1, name
+    for name in ("urdf_four_bar", "tree_generic_float", "rev_pair_rotor_chain_4"):
         assert G.Plan(z[name]).info().chain_aba_f32 == 0, name
