@@ -17,9 +17,13 @@ all: $(LIB) oracle
 $(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
+# The chain kernels may re-associate sums (no signed zeros, no traps; NOT reciprocal / finite-math-only / approximate
+# functions): lone multiplies and adds of the spatial products fold into FMAs, 10 % fewer floating-point instructions
+# (MIT humanoid fp32 ABA 0.173 -> 0.170 ms, JVRC-1 and TelloWithArms 3-4 %); parity tolerances unchanged.
+CHAINFLAGS := -fassociative-math -fno-signed-zeros -fno-trapping-math
 $(OBJ)/chain_kernels.o: $(CSRC)/chain_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -c $< -o $@
 $(OBJ)/crba_kernels.o: $(CSRC)/crba_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
