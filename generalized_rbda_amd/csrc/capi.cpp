@@ -613,6 +613,10 @@ __global__ void test_force_finish(const T *__restrict__ a1, const T *__restrict_
 }
 
 template <class T>
+int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *bodies, const double *offsets, T *Linv, T *J,
+                   size_t B, int device, void *stream, const T *tf_force, T *tf_lambda, T *tf_dstate);
+
+template <class T>
 int test_force(const grbda_plan *p, const T *q, int body, const double *offset, const T *force, T *lambda_inv, T *dstate,
                size_t B, int device, void *stream)
 {
@@ -621,6 +625,10 @@ int test_force(const grbda_plan *p, const T *q, int body, const double *offset, 
     if (!p || !q || !offset || !force || !lambda_inv || !dstate) return set_err(GRBDA_EINVAL, "null argument");
     if (body < 0 || body >= p->host.n_bodies) return set_err(GRBDA_EINVAL, "body index out of range");
     if (B == 0) return GRBDA_OK;
+    {   // models the chain program covers: one launch of the force-propagation kernel (osim_chain_kernel, applyTestForce mode)
+        const int rc = inv_osim_chain<T>(p, q, 1, &body, offset, nullptr, nullptr, B, device, stream, force, lambda_inv, dstate);
+        if (rc != 1) return rc;
+    }
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const size_t nq = p->host.nq, nv = p->host.nv, nbod = p->host.n_bodies;
@@ -737,7 +745,7 @@ __global__ void osim_combine_kernel(const T *__restrict__ acc, const T *__restri
 // frames on link / base bodies.  Returns 1 when the fast path does not apply (the caller then takes the unit-wrench path).
 template <class T>
 int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *bodies, const double *offsets, T *Linv, T *J,
-                   size_t B, int device, void *stream)
+                   size_t B, int device, void *stream, const T *tf_force, T *tf_lambda, T *tf_dstate)
 {
     const HostPlan &h = p->host;
     const ChainProgram &cp = sizeof(T) == 8 ? h.chain64 : h.chain32;
@@ -747,6 +755,11 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     std::memset(&A, 0, sizeof A);
     A.n_contacts = n_contacts;
     A.want_J = J ? 1 : 0;
+    A.test_force = tf_force ? 1 : 0;
+    A.force = tf_force;
+    A.lambda_inv = tf_lambda;
+    A.dstate = tf_dstate;
+    if (tf_force && n_contacts != 1) return 1;
     std::vector<std::vector<int>> path_clusters(n_contacts);
     int max_rows = 0;
     for (int e = 0; e < n_contacts; e++) {
@@ -815,6 +828,8 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
         W[6 * 0 + 5] = o[1];  W[6 * 1 + 5] = -o[0];   // o x e_z = (o_y, -o_x, 0)
         const int ca = L.bodies[b].canon_axis;  // v_plan = Rc v_ref: x -> z: rows (y, z, x); y -> z: rows (z, x, y)
         const int perm[3][3] = {{1, 2, 0}, {2, 0, 1}, {0, 1, 2}};
+        if (e == 0)
+            for (int i = 0; i < 3; i++) A.perm[i] = perm[ca][i];
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 6; j++) {
                 A.K0[e][6 * i + j] = static_cast<T>(W[6 * perm[ca][i] + j]);
@@ -856,7 +871,8 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.ori_repr = h.ori_repr;
     d.debug = 0;
     d.sv_global = cp.sv_global ? 1 : 0;
-    for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+    // (gravity enters the acceleration sweep only, which runs in applyTestForce mode alone -- there without it)
+    for (int i = 0; i < 6; i++) d.a_root[i] = tf_force ? T(0) : static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t->n_cu) * 4;  // one wavefront per SIMD: the walk kernel is not register-tuned
     if (grid > n_tiles) grid = n_tiles;
@@ -904,7 +920,7 @@ int inv_osim(const grbda_plan *p, const T *q, int n_contacts, const int *bodies,
     }
     if (B == 0) return GRBDA_OK;
     {
-        const int rc = inv_osim_chain<T>(p, q, n_contacts, bodies, offsets, Linv, J, B, device, stream);
+        const int rc = inv_osim_chain<T>(p, q, n_contacts, bodies, offsets, Linv, J, B, device, stream, nullptr, nullptr, nullptr);
         if (rc != 1) return rc;
     }
     DeviceTables *t = nullptr;

@@ -1179,6 +1179,12 @@ __device__ __forceinline__ void k_up(const T (&E)[9], cptr<T> r, T (&K)[36])
 }
 
 template <class T>
+__device__ __forceinline__ T dot6w(const T (&a)[6], const T (&b)[6])
+{
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+
+template <class T>
 __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, OsimArgs<T> A, const T *__restrict__ q,
                                                               const T *__restrict__ zeros, T *__restrict__ Linv,
                                                               T *__restrict__ Jout, size_t B, T *__restrict__ scratch)
@@ -1241,6 +1247,18 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
         if (Js && live)
             for (int i = 0; i < 6 * m * nv; i++) Js[i] = 0;
         // ---- walks ----
+        T Etot[9];  // applyTestForce mode: rotation world -> contact body (plan frames), built up along the path
+#pragma unroll
+        for (int i = 0; i < 9; i++) Etot[i] = (i % 4 == 0) ? T(1) : T(0);
+        auto turn = [&](const T(&E)[9]) {  // Etot <- Etot E
+            T R[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) R[3 * i + j] = Etot[3 * i] * E[j] + Etot[3 * i + 1] * E[3 + j] + Etot[3 * i + 2] * E[6 + j];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Etot[i] = R[i];
+        };
         for (int e = 0; e < m; e++) {
             T K[36], Kp[36];
 #pragma unroll
@@ -1255,6 +1273,7 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
                     T kb[10], E[9];
                     M.glb_ld(l.glb_k, kb);
                     rotate_z(kb[7], kb[8], C, E);
+                    if (A.test_force) turn(E);
                     const T sq = sqrt(kb[9]);
                     T srow[6], w[6];
 #pragma unroll
@@ -1277,6 +1296,14 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
                     const ChainFree f = load_rec(P.frees + stp.rec);
                     T ex[27];
                     M.glb_ld(f.glb_y0 + 6, ex);
+                    if (A.test_force) {
+                        T o[4], Eb[9];
+                        const int nori = P.ori_repr == 0 ? 4 : 3;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) o[j] = j < nori ? M.q(f.q_index + 3 + j) : T(0);
+                        free_rotation(P.ori_repr, o, Eb);
+                        turn(Eb);
+                    }
                     // W = L^-1 K (forward substitution per column), S = 1
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
@@ -1307,6 +1334,10 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
                     M.glb_ld(df.glb_k, blk);
                     rotate_z(blk[20], blk[21], C1, E1);
                     rotate_z(blk[22], blk[23], C2, E2);
+                    if (A.test_force) {
+                        if (stp.kind == OSIM_DIFF_LINK2) turn(E2);
+                        turn(E1);
+                    }
                     T z1[6], z2[6], y1[6], y2[6];
                     if (stp.kind == OSIM_DIFF_LINK2) {
 #pragma unroll
@@ -1357,6 +1388,10 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
                     M.glb_ld(pr.glb_k, blk);
                     rotate_z(blk[17], blk[18], C1, E1);
                     rotate_z(blk[19], blk[20], C2, E2);
+                    if (A.test_force) {
+                        if (stp.kind == OSIM_PAIR_LINK2) turn(E2);
+                        turn(E1);
+                    }
                     T s1[6], s2[6], p1[6], p2[6];
                     if (stp.kind == OSIM_PAIR_LINK2) {
 #pragma unroll
@@ -1397,6 +1432,91 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (A.test_force) {
+            // ---- applyTestForce (ClusterTreeDynamics.cpp:194-233): the contact force in the contact body's axes, then per
+            // cluster of the path y0 = D^-1 S^T K_e f (from the W rows: W = D^-1/2 S^T K_e), lambda_inv = |W f|^2, and the
+            // acceleration sweep of the whole model with these y0 and no gravity gives dstate = H^-1 J^T f
+            const size_t sf = live ? st : B - 1;
+            const T fw[3] = {A.force[sf * 3], A.force[sf * 3 + 1], A.force[sf * 3 + 2]};
+            T f6[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const T fp = Etot[3 * i] * fw[0] + Etot[3 * i + 1] * fw[1] + Etot[3 * i + 2] * fw[2];
+                if (A.perm[i] == 0) f6[3] = fp;
+                else if (A.perm[i] == 1) f6[4] = fp;
+                else f6[5] = fp;
+            }
+            T lam = 0;
+            const int wbase = A.w_base;
+            for (int t = 0; t < A.path_len[0]; t++) {
+                const OsimStep stp = A.path[0][t];
+                if (stp.kind == OSIM_LINK) {
+                    const ChainLink l = load_rec(P.links + stp.rec);
+                    T w[6], dv[1];
+                    M.glb_ld(wbase + stp.w_row * 6, w);
+                    M.glb_ld(l.glb_k + 9, dv);
+                    const T a = dot6w(w, f6);
+                    lam += a * a;
+                    const T y0[1] = {sqrt(dv[0]) * a};
+                    M.glb_st(l.glb_k + 6, y0);
+                } else if (stp.kind == OSIM_FREE) {
+                    const ChainFree f = load_rec(P.frees + stp.rec);
+                    T ex[27], y[6];
+                    M.glb_ld(f.glb_y0 + 6, ex);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        T w[6];
+                        M.glb_ld(wbase + (stp.w_row + i) * 6, w);
+                        y[i] = dot6w(w, f6);
+                        lam += y[i] * y[i];
+                    }
+                    // L^T x = y
+#pragma unroll
+                    for (int i = 5; i >= 0; i--) {
+                        T sacc = y[i];
+#pragma unroll
+                        for (int k2 = i + 1; k2 < 6; k2++) sacc -= ex[k2 * (k2 + 1) / 2 + i] * y[k2];
+                        y[i] = sacc * ex[21 + i];
+                    }
+                    M.glb_st(f.glb_y0, y);
+                } else {
+                    // pair / differential: two rows, R^T R = D^-1 with R = [[r00, r01], [0, r11]]
+                    int gk;
+                    T dinv[3];
+                    if (stp.kind == OSIM_DIFF_LINK1 || stp.kind == OSIM_DIFF_LINK2) {
+                        const ChainDiff df = load_rec(P.diffs + stp.rec);
+                        gk = df.glb_k;
+                        M.glb_ld(gk + 24, dinv);
+                    } else {
+                        const ChainPair pr = load_rec(P.pairs + stp.rec);
+                        gk = pr.glb_k;
+                        M.glb_ld(gk + 14, dinv);
+                    }
+                    T w1[6], w2[6];
+                    M.glb_ld(wbase + stp.w_row * 6, w1);
+                    M.glb_ld(wbase + (stp.w_row + 1) * 6, w2);
+                    const T a = dot6w(w1, f6), b = dot6w(w2, f6);
+                    lam += a * a + b * b;
+                    const T r00 = sqrt(dinv[0]), r01 = dinv[1] / r00, r11 = sqrt(dinv[2] - r01 * r01);
+                    const T y0[2] = {r00 * a, r01 * a + r11 * b};
+                    M.glb_st(gk + 12, y0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int s2 = 0; s2 < P.n_segs; s2++) {
+                const ChainSeg sg = load_rec(P.segs + s2);
+                switch (sg.op) {
+                    case SEG_RUN_ACC: run_acc(P, M, sg); break;
+                    case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
+                    case SEG_DIFF_ACC: diff_acc(P, M, load_rec(P.diffs + sg.first)); break;
+                    case SEG_FREE_ACC: free_acc(P, M, load_rec(P.frees + sg.first)); break;
+                    default: break;
+                }
+            }
+            if (live) A.lambda_inv[st] = lam;
+            write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, A.dstate, tile, rows_valid, P.nv, lane);
+            continue;
+        }
         // ---- Lambda^-1 blocks: W_e1^T W_e2 over the rows the two paths share ----
         T *Ls = Linv + (live ? st : B - 1) * (size_t)(36 * m * m);
         for (int e1 = 0; e1 < m; e1++)

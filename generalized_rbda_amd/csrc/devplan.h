@@ -111,6 +111,14 @@ struct OsimArgs {
     T K0[kOsimMaxContacts][36];                          // wrench on the contact body (plan frame) per unit contact wrench, row-major
     int w_base;                                          // first slab row (after the chain program's rows) of the W blocks
     int w_stride;                                        // rows per contact
+    // applyTestForce mode (one contact): a force per state, given in world coordinates at the contact point; results
+    // lambda_inv[B] = f^T (J H^-1 J^T) f and dstate[B][nv] = H^-1 J^T f.  perm: plan-frame axis i of the contact body is the
+    // reference's axis perm[i] (canonical joint axes, plan.cpp)
+    int test_force;
+    int perm[3];
+    const T *force;
+    T *lambda_inv;
+    T *dstate;
 };
 template <class T>
 hipError_t launch_osim_chain(const ChainDev<T> &P, const OsimArgs<T> &A, const T *q, const T *zeros, T *Linv, T *J, size_t B,

@@ -503,7 +503,9 @@ def test_body_poses_match_oracle(name, blob, gpu):
     assert np.abs(got - ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "tello_with_arms", "urdf_four_bar"])
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "tello_with_arms", "urdf_four_bar",
+                                  "urdf_mini_cheetah_rpy", "chain_tree_a", "chain_tree_b", "urdf_jvrc1_humanoid", "rev_rotor_chain_4",
+                                  "tree_rev_fixed"])
 def test_apply_test_force_matches_oracle(name, gpu):
     """applyTestForce (ClusterTreeDynamics.cpp:194-233): dstate = H^-1 J^T f, lambda_inv = f^T J H^-1 J^T f,
     against the oracle's forward / inverse dynamics with the equivalent world wrench."""
@@ -516,7 +518,11 @@ def test_apply_test_force_matches_oracle(name, gpu):
     rng = np.random.default_rng(5)
     force = rng.uniform(-1, 1, size=(B, 3))
     offset = np.array([0.05, -0.02, 0.1])
-    body = plan.n_bodies - 1
+    # a link deep in a limb where the model has named ones (chain-covered models then take the one-launch force-propagation
+    # route: osim_chain_kernel in applyTestForce mode), else the last body
+    named = {"urdf_mini_cheetah": "HL_knee_link", "urdf_mit_humanoid": "left_ankle_link", "tello_with_arms": "left-foot",
+             "urdf_mini_cheetah_rpy": "FR_knee_link", "urdf_revolute_rotor_chain": None}
+    body = _body_index(blob, named[name]) if named.get(name) else plan.n_bodies - 1
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
     lam, ds = plan.apply_test_force(t(q), body, offset, t(force))
     lam, ds = lam.cpu().numpy(), ds.cpu().numpy()
@@ -533,6 +539,11 @@ def test_apply_test_force_matches_oracle(name, gpu):
     assert rel_err(ds, ds_ref) < 1e-8
     assert np.abs(lam - lam_ref).max() / (1 + np.abs(lam_ref).max()) < 1e-8
     assert (lam > 0).all()  # J H^-1 J^T is positive definite along f
+    # fp32 entry point
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    lam32, ds32 = plan.apply_test_force(t32(q), body, offset, t32(force))
+    assert rel_err(ds32.double().cpu().numpy(), ds_ref) < TOL32
+    assert np.abs(lam32.double().cpu().numpy() - lam_ref).max() / (1 + np.abs(lam_ref).max()) < TOL32
 
 
 @pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "tello_with_arms"])
