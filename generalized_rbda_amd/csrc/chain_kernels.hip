@@ -13,9 +13,12 @@
 // global slab (written once by the backward run, read once by the acceleration run, the next link's block fetched
 // while the current link is computed).  The segment loop itself carries no vector state.
 //
-// Covered cluster types: Free root, Revolute, RevoluteWithRotor (axisymmetric rotor evaluated at q = 0, plan.cpp),
-// leaf RevolutePairWithRotor (src/Dynamics/ClusterJoints/RevolutePairWithRotorJoint.cpp).  Everything else runs on
-// the general interpreter (kernels.hip); the plan compiler decides (ChainProgram::ok).
+// Covered cluster types: Free root or links on the ground, Revolute, RevoluteWithRotor (axisymmetric rotor evaluated at
+// q = 0, plan.cpp; any other rotor at its own angle), leaf RevolutePairWithRotor
+// (src/Dynamics/ClusterJoints/RevolutePairWithRotorJoint.cpp), and the implicit two-rotor differentials of Tello
+// (GenericImplicit clusters of src/Robots/Tello.cpp; ChainDiff below).  Everything else runs on the general interpreter
+// (kernels.hip); the plan compiler decides (ChainProgram::ok).  The same file holds the inverse dynamics on the chains
+// (rnea_chain_kernel) and the force-propagation kernel of the contact side (osim_chain_kernel).
 #include <hip/hip_runtime.h>
 
 #include "devplan.h"
