@@ -225,6 +225,30 @@ def test_derived_quantities_chunked_large_batch(gpu):
     assert torch.equal(H[idx], H_small)
 
 
+def test_analytic_derivatives_chunked_large_batch(gpu):
+    """The analytic derivative pipeline works through the batch in chunks of its 512 MiB work space (H, dID/dq, dID/dqd,
+    ydd per state): a batch that needs several chunks gives, at the chunk seams and the ragged end, the matrices of a small
+    batch of the same states."""
+    import torch
+
+    blob = zoo()["urdf_mini_cheetah"]
+    plan = G.Plan(blob)
+    assert plan.info().analytic_derivatives == 1
+    nv = plan.nv
+    per_state = (3 * nv * nv + nv) * 4
+    chunk = (512 << 20) // per_state
+    B = 2 * chunk + 77
+    q, qd, tau = random_states(blob, B, 6)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=gpu)
+    tq, tqd, tt = t(q), t(qd), t(tau)
+    d = plan.fd_derivatives(tq, tqd, tt, want=("dq", "dtau"))
+    idx = torch.tensor([0, 63, chunk - 1, chunk, chunk + 1, 2 * chunk - 1, 2 * chunk, B - 1], device=gpu)
+    small = plan.fd_derivatives(tq[idx].contiguous(), tqd[idx].contiguous(), tt[idx].contiguous(), want=("dq", "dtau"))
+    torch.cuda.synchronize()
+    for k in ("dq", "dtau"):
+        assert torch.equal(d[k][idx], small[k]), k
+
+
 # ---- steps either side of the path: Newton projection, spanning recovery ---------------------------------
 def _implicit_models():
     from generalized_rbda_amd.states import parse_clusters
