@@ -394,6 +394,8 @@ class Plan:
             raise ValueError(f"expected device tensors q[B,{self.nq}], qd[B,{self.nv}], tau[B,{self.nv}]")
         q, qd, tau = q.contiguous(), qd.contiguous(), tau.contiguous()
         out = {k: torch.empty((B, self.nv, self.nv), dtype=q.dtype, device=q.device) for k in ("dq", "dqd", "dtau") if k in want}
+        if B == 0:
+            return out
         s = torch.cuda.current_stream(q.device) if stream is None else stream
         fn = getattr(lib(), f"grbda_fd_derivatives_{'f32' if q.dtype == torch.float32 else 'f64'}")
         ptr = lambda k: out[k].data_ptr() if k in out else None

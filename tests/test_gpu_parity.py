@@ -225,6 +225,36 @@ def test_derived_quantities_chunked_large_batch(gpu):
     assert torch.equal(H[idx], H_small)
 
 
+def test_derivative_entry_points_edge_cases(gpu):
+    """One state; an empty batch; a model with more coordinates than the SPD solve's 64 lanes (nv = 66: the plan reports
+    no analytic route and the difference batches serve it) -- every case through grbda_fd_derivatives_*."""
+    import torch
+    from models import random_cluster_tree
+
+    blob = zoo()["urdf_mit_humanoid"]
+    plan = G.Plan(blob)
+    q, qd, tau = random_states(blob, 1, 8)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    d1 = plan.fd_derivatives(t(q), t(qd), t(tau))
+    Hinv = d1["dtau"][0].cpu().numpy()
+    H = plan.mass_matrix(t(q))[0].cpu().numpy()
+    assert np.abs(Hinv @ H - np.eye(plan.nv)).max() < 1e-8
+    d0 = plan.fd_derivatives(t(q[:0]), t(qd[:0]), t(tau[:0]))
+    assert all(v.shape == (0, plan.nv, plan.nv) for v in d0.values())
+    big = random_cluster_tree(301, n_clusters=60, floating=True, kinds=("rev", "rotor")).serialize()
+    pb = G.Plan(big)
+    assert pb.nv > 64 and pb.info().analytic_derivatives == 0
+    q, qd, tau = random_states(big, 2, 9)
+    db = pb.fd_derivatives(t(q), t(qd), t(tau), want=("dtau", "dqd"))
+    Hb = pb.mass_matrix(t(q)).cpu().numpy()
+    assert np.abs(np.einsum("bij,bjk->bik", db["dtau"].cpu().numpy(), Hb) - np.eye(pb.nv)).max() < 1e-7
+    k = pb.nv - 1
+    e = np.zeros_like(qd)
+    e[:, k] = 1.0
+    col = (O.forward_dynamics(big, q, qd + e, tau) - O.forward_dynamics(big, q, qd - e, tau)) / 2
+    assert np.abs(db["dqd"][:, :, k].cpu().numpy() - col).max() / (1 + np.abs(col).max()) < 1e-8
+
+
 def test_analytic_derivatives_chunked_large_batch(gpu):
     """The analytic derivative pipeline works through the batch in chunks of its 512 MiB work space (H, dID/dq, dID/dqd,
     ydd per state): a batch that needs several chunks gives, at the chunk seams and the ragged end, the matrices of a small
