@@ -785,8 +785,13 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
                     if (cp.links[i].v_index == cr.v_index) found = static_cast<int>(i);
                 st.kind = OSIM_LINK;
                 rows += 1;
-            } else if (cr.kind == CK_LOOP) {
-                // two-rotor differential: the path enters at link1 (a contact on it) or at link2 (a contact on it or below)
+            } else if (cr.kind == CK_LOOP || [&] {
+                           for (const ChainDiff &df : cp.diffs)
+                               if (df.v_index == cr.v_index) return true;
+                           return false;
+                       }()) {
+                // two-rotor differential, or an explicit pair that runs through its segments: the path enters at link1 (a
+                // contact on it) or at link2 (a contact on it or below)
                 for (size_t i = 0; i < cp.diffs.size(); i++)
                     if (cp.diffs[i].v_index == cr.v_index) found = static_cast<int>(i);
                 if (found < 0) return 1;

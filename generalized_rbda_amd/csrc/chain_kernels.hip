@@ -506,13 +506,18 @@ __device__ __forceinline__ void diff_fwd(const ChainTables<T> &P, const ChainMem
     for (int i = 0; i < 4; i++) qs[i] = M.q(d.q_index + d.qpos[i]);
     const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
     T gx[10], qdl[2];
-    {
+    if (d.tofs_i >= 0) {
         T X[4], g[2];
         diff_constraint(P, M, d.tofs_i, d.lds_w, qs, yd0, yd1, X, g, qdl);
 #pragma unroll
         for (int j = 0; j < 4; j++) gx[j] = X[j];
         gx[4] = g[0];
         gx[5] = g[1];
+    } else {  // explicit pair: the link angles are the coordinates
+        gx[0] = 1; gx[1] = 0; gx[2] = 0; gx[3] = 1;
+        gx[4] = gx[5] = 0;
+        qdl[0] = yd0;
+        qdl[1] = yd1;
     }
     sincos_t(qs[2], &gx[6], &gx[7]);
     sincos_t(qs[3], &gx[8], &gx[9]);
@@ -520,7 +525,12 @@ __device__ __forceinline__ void diff_fwd(const ChainTables<T> &P, const ChainMem
     if (d.lds_sv != -1) {
         cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
         T vp[6], E1[9], E2[9], v1[6], blk[8];
-        M.acc_ld(d.lds_pv, vp);
+        if (d.lds_pv != -1) {
+            M.acc_ld(d.lds_pv, vp);
+        } else {  // the cluster hangs off the ground
+#pragma unroll
+            for (int j = 0; j < 6; j++) vp[j] = 0;
+        }
         const T sc[4] = {gx[6], gx[7], gx[8], gx[9]};
         T v2[6];
         diff_links(C1, C2, sc, vp, qdl[0], qdl[1], E1, E2, v1, v2);
@@ -539,7 +549,12 @@ __device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem
 {
     cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
     T vp[6], gx[10];
-    M.acc_ld(d.lds_pv, vp);
+    if (d.lds_pv != -1) {
+        M.acc_ld(d.lds_pv, vp);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) vp[j] = 0;
+    }
     M.glb_ld(d.glb_k + 14, gx);
     const T X00 = gx[0], X01 = gx[1], X10 = gx[2], X11 = gx[3];
     const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
@@ -634,23 +649,22 @@ __device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem
             F1[j] += Fc[j] * X01;
         }
     }
-    {   // ---- rotors (q = 0), G rows (1, 0) and (0, 1) ----
+    // ---- rotors (q = 0); their G rows are (1, 0), (0, 1) in a differential, the gear / belt products in an explicit pair ----
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
         T bj, tp[6];
-        cptr<T> R0 = P.consts + d.rpre[0], R1 = P.consts + d.rpre[1];
-        rotor_terms(P.consts + d.cofs[2], vp, yd0, bj, tp);
-        u0 -= bj;
-        D00 += R0[6];
+        cptr<T> Rp = P.consts + d.rpre[r];
+        const T ga = P.consts[d.gofs + 2 * r], gb = P.consts[d.gofs + 2 * r + 1];
+        rotor_terms(P.consts + d.cofs[2 + r], vp, ga * yd0 + gb * yd1, bj, tp);
+        u0 -= ga * bj;
+        u1 -= gb * bj;
+        D00 += Rp[6] * ga * ga;
+        D01 += Rp[6] * ga * gb;
+        D11 += Rp[6] * gb * gb;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            F0[j] += R0[j];
-            psi[j] += tp[j];
-        }
-        rotor_terms(P.consts + d.cofs[3], vp, yd1, bj, tp);
-        u1 -= bj;
-        D11 += R1[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            F1[j] += R1[j];
+            F0[j] += Rp[j] * ga;
+            F1[j] += Rp[j] * gb;
             psi[j] += tp[j];
         }
     }
@@ -669,6 +683,7 @@ __device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem
         const T ex[3] = {i00, i01, i11};
         M.glb_st(d.glb_k + 24, ex);
     }
+    if (d.lds_acc_out == -1) return;  // on the ground: nobody to hand the projected inertia to
     T acc[27];
     if (!d.acc_first) M.acc_ld(d.lds_acc_out, acc);
     else {
@@ -687,13 +702,22 @@ __device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem
 template <class T>
 __device__ __forceinline__ void diff_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainDiff &d)
 {
-    T blk[24], va[12], vp[6], ap[6];
+    T blk[24], vp[6], ap[6];
     M.glb_ld(d.glb_k, blk);
-    M.lds_ld(d.lds_pva, va);
+    if (d.lds_pva >= 0) {
+        T va[12];
+        M.lds_ld(d.lds_pva, va);
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        vp[j] = va[j];
-        ap[j] = va[6 + j];
+        for (int j = 0; j < 6; j++) {
+            vp[j] = va[j];
+            ap[j] = va[6 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            vp[j] = 0;
+            ap[j] = P.a_root[j];
+        }
     }
     T ydd0 = blk[12], ydd1 = blk[13];
 #pragma unroll
@@ -1850,14 +1874,30 @@ __device__ __forceinline__ void rnea_diff_fwd(const RneaTables<T> &P, const Chai
     const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
     const T ydd0 = M.x(d.v_index), ydd1 = M.x(d.v_index + 1);
     T X[4], g[2], qdl[2];
-    diff_constraint(P, M, d.tofs_i, d.lds_w, qs, yd0, yd1, X, g, qdl);
+    if (d.tofs_i >= 0) {
+        diff_constraint(P, M, d.tofs_i, d.lds_w, qs, yd0, yd1, X, g, qdl);
+    } else {  // explicit pair: the link angles are the coordinates
+        X[0] = 1; X[1] = 0; X[2] = 0; X[3] = 1;
+        g[0] = g[1] = 0;
+        qdl[0] = yd0;
+        qdl[1] = yd1;
+    }
     const T qdd1 = X[0] * ydd0 + X[1] * ydd1 + g[0], qdd2 = X[2] * ydd0 + X[3] * ydd1 + g[1];
-    T va[12], vp[6], ap[6];
-    M.lds_ld(d.lds_pva, va);
+    T vp[6], ap[6];
+    if (d.lds_pva >= 0) {
+        T va[12];
+        M.lds_ld(d.lds_pva, va);
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        vp[j] = va[j];
-        ap[j] = va[6 + j];
+        for (int j = 0; j < 6; j++) {
+            vp[j] = va[j];
+            ap[j] = va[6 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            vp[j] = 0;
+            ap[j] = P.a_root[j];
+        }
     }
     T sc[4], E1[9], E2[9], v1[6], v2[6], a1[6], a2[6], c[6];
     sincos_t(qs[2], &sc[0], &sc[1]);
@@ -1879,14 +1919,15 @@ __device__ __forceinline__ void rnea_diff_fwd(const RneaTables<T> &P, const Chai
     // what does not wait for the child segments goes out now: link1's own force and the rotors' to the parent body,
     // their share of tau to the result rows (the backward segment adds link2's)
     T tz0, tz1, fp[6], fp0[6], fp1[6];
-    rotor_rnea(P.consts + d.cofs[2], vp, ap, yd0, ydd0, tz0, fp0);
-    rotor_rnea(P.consts + d.cofs[3], vp, ap, yd1, ydd1, tz1, fp1);
+    const T g00 = P.consts[d.gofs], g01 = P.consts[d.gofs + 1], g10 = P.consts[d.gofs + 2], g11 = P.consts[d.gofs + 3];
+    rotor_rnea(P.consts + d.cofs[2], vp, ap, g00 * yd0 + g01 * yd1, g00 * ydd0 + g01 * ydd1, tz0, fp0);
+    rotor_rnea(P.consts + d.cofs[3], vp, ap, g10 * yd0 + g11 * yd1, g10 * ydd0 + g11 * ydd1, tz1, fp1);
     xforce_inv(E1, C1 + 9, f1, fp);
 #pragma unroll
     for (int j = 0; j < 6; j++) fp[j] += fp0[j] + fp1[j];
-    add6<T, GLB>(M, d.lds_pf, fp);
-    M.put(d.v_index, tz0 + X[0] * f1[2]);
-    M.put(d.v_index + 1, tz1 + X[1] * f1[2]);
+    if (d.lds_pf >= 0) add6<T, GLB>(M, d.lds_pf, fp);
+    M.put(d.v_index, g00 * tz0 + g10 * tz1 + X[0] * f1[2]);
+    M.put(d.v_index + 1, g01 * tz0 + g11 * tz1 + X[1] * f1[2]);
 #pragma unroll
     for (int j = 0; j < 6; j++) blk[j] = f2[j];
 #pragma unroll
@@ -1920,7 +1961,7 @@ __device__ __forceinline__ void rnea_diff_bwd(const RneaTables<T> &P, const Chai
     xforce_inv(E2, C2 + 9, f2, f21);
     const T tl1 = f21[2];
     xforce_inv(E1, C1 + 9, f21, fp);
-    add6<T, GLB>(M, d.lds_pf, fp);
+    if (d.lds_pf >= 0) add6<T, GLB>(M, d.lds_pf, fp);
     // (the result rows are the tile's third input block: M.x reads what the forward segment put there)
     M.put(d.v_index, M.x(d.v_index) + blk[10] * tl1 + blk[12] * tl2);
     M.put(d.v_index + 1, M.x(d.v_index + 1) + blk[11] * tl1 + blk[13] * tl2);

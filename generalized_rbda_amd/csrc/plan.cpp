@@ -268,7 +268,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         auto at = [](const double *M, int i, int j) { return M[i * 6 + j]; };
         for (int b = 0; b < nb; b++) {
             const grbda_desc_body &bd = m.bodies[b];
-            if (bodies[b].has_child || bd.joint_type != GRBDA_JOINT_REVOLUTE || bd.parent < 0) continue;
+            if (bodies[b].has_child || bd.joint_type != GRBDA_JOINT_REVOLUTE) continue;
             // (URDF+ position-loop clusters keep their bodies as they are: the loop origins are points of the link frames)
             if (clusters[bd.cluster].kind == CK_LOOP && clusters[bd.cluster].cons_type == 0) continue;
             bool inv = true;
@@ -305,6 +305,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     for (int k2 = 0; k2 < 3; k2++) er += E[i * 3 + k2] * rh[k2 * 3 + j];
                     X[(i + 3) * 6 + j] = -er;
                 }
+            if (bd.parent < 0) continue;  // a rotor on the ground: nobody to hand X0^T I X0 to
             std::vector<double> &ex = extra[bd.parent];
             if (ex.empty()) ex.assign(21, 0.0);
             int idx = 0;
@@ -920,9 +921,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget) {
         CP = ChainProgram();
         bool ok = sweep_mask == 7;
-        // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair, 4 revolute + general rotor,
-        // 5 two-rotor differential, -1 unsupported
+        // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair (head of its parent link's backward
+        // run), 4 revolute + general rotor, 5 two-rotor differential, 6 explicit pair with child clusters on link2 or in a
+        // place class 3 does not cover (runs through the differential's segments with constant G), -1 unsupported
         std::vector<int> cls(nc, -1), tip(nc, -1), gen_rotor(nc, -1);
+        auto is_diff = [&](int c) { return cls[c] == 5 || cls[c] == 6; };
         std::vector<ChainPair> pair_of(nc);
         std::vector<std::array<int, 2>> pair_rotors(nc, std::array<int, 2>{-1, -1});
         for (int c = 0; c < nc && ok; c++) {
@@ -950,7 +953,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 if (!bodies[f].has_child && !bodies[f + 1].has_child && P.consts[bodies[f].cofs + kBodyConstFixed] == 1.0) rot = f + 1;
                 gen_rotor[c] = rot;
                 tip[c] = rot == f ? f + 1 : f;
-            } else if (cr.kind == CK_STATIC && cr.n == 2 && cr.k == 4 && cr.parent_body >= 0) {
+            } else if (cr.kind == CK_STATIC && cr.n == 2 && cr.k == 4) {
                 // RevolutePairWithRotor shape: link1 and two axisymmetric rotors on the parent body, link2 on link1,
                 // coordinates = the two link angles (RevolutePairWithRotorJoint.cpp:10-69), no child clusters
                 int l1 = -1, l2 = -1, r[2] = {-1, -1}, nr = 0;
@@ -961,8 +964,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     else if (br.parent == cr.parent_body && br.lam < 0) l1 = l1 < 0 ? gb : -2;
                     else if (br.lam >= 0) l2 = l2 < 0 ? gb : -2;
                 }
-                bool good = nr == 2 && l1 >= 0 && l2 >= 0 && bodies[l2].lam == l1 && !bodies[l2].has_child && !bodies[l1].axisym &&
-                            !bodies[l2].axisym;
+                bool good = nr == 2 && l1 >= 0 && l2 >= 0 && bodies[l2].lam == l1 && !bodies[l1].axisym && !bodies[l2].axisym;
                 if (good)
                     for (int j = 0; j < nb; j++)
                         if (bodies[j].parent == l1 && j != l2) good = false;
@@ -971,7 +973,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     good = g1[0] == 1.0 && g1[1] == 0.0 && g2[0] == 0.0 && g2[1] == 1.0;
                 }
                 if (good) {
-                    cls[c] = 3;
+                    // (the shape in the differential's terms too: class 6, decided here when link2 carries child clusters,
+                    // below when a leaf pair sits where the head of a backward run cannot be)
+                    DiffShape ds;
+                    ds.ok = true; ds.l1 = l1; ds.l2 = l2; ds.r[0] = r[0]; ds.r[1] = r[1]; ds.tofs_i = -1; ds.n_atoms = 0;
+                    diff_shape[c] = ds;
+                    cls[c] = (bodies[l2].has_child || cr.parent_body < 0) ? 6 : 3;
+                    if (cls[c] == 6) tip[c] = l2;
                     ChainPair &pr = pair_of[c];
                     pr = ChainPair();
                     pr.q_index = cr.q_index;
@@ -1009,8 +1017,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             // child order = the depth-first order of the general schedule (kids[])
             ckids[c] = kids[c];
             for (int k : ckids[c])
-                if (cls[k] == 3 && (ckids[c].size() != 1 || cls[c] == 0 || cls[c] == 3 || cls[c] == 5)) ok = false;
-            if (cls[c] == 3 && !ckids[c].empty()) ok = false;
+                if (cls[k] == 3 && (ckids[c].size() != 1 || cls[c] == 0 || cls[c] == 3 || is_diff(c))) {
+                    cls[k] = 6;  // a leaf pair next to siblings, or on the base / a pair / a differential: standalone segments
+                    tip[k] = diff_shape[k].l2;
+                }
         }
         if (ok) {
             // per-cluster master records
@@ -1041,20 +1051,29 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     l.has_child = br.has_child;
                     l.lds_sv = l.lds_pv = l.lds_va = -1;
                     l.glb_k = glb(10);  // [K 6][y0][sin][cos] (+ OSIM pass: 1 / D)
-                } else if (cls[c] == 5) {
+                } else if (is_diff(c)) {
                     const DiffShape &ds = diff_shape[c];
                     ChainDiff &d = diff_of[c];
                     d = ChainDiff();
                     d.q_index = cr.q_index; d.v_index = cr.v_index;
-                    d.qpos[0] = ds.r[0] - cr.first_body; d.qpos[1] = ds.r[1] - cr.first_body;
-                    d.qpos[2] = ds.l1 - cr.first_body; d.qpos[3] = ds.l2 - cr.first_body;
+                    if (cls[c] == 5) {
+                        d.qpos[0] = ds.r[0] - cr.first_body; d.qpos[1] = ds.r[1] - cr.first_body;
+                        d.qpos[2] = ds.l1 - cr.first_body; d.qpos[3] = ds.l2 - cr.first_body;
+                    } else {  // the coordinates ARE the link angles (G rows (1, 0), (0, 1) checked above)
+                        d.qpos[0] = d.qpos[1] = 0;
+                        d.qpos[2] = 0; d.qpos[3] = 1;
+                    }
+                    d.gofs = static_cast<int>(P.consts.size());
+                    for (int r2 = 0; r2 < 2; r2++)
+                        for (int a = 0; a < 2; a++)
+                            P.consts.push_back(cls[c] == 5 ? (r2 == a ? 1.0 : 0.0) : P.consts[bodies[ds.r[r2]].cofs + kBodyConstFixed + a]);
                     d.cofs[0] = bodies[ds.l1].cofs; d.cofs[1] = bodies[ds.l2].cofs; d.cofs[2] = bodies[ds.r[0]].cofs; d.cofs[3] = bodies[ds.r[1]].cofs;
                     d.rpre[0] = rotor_constants(ds.r[0]);
                     d.rpre[1] = rotor_constants(ds.r[1]);
                     d.iofs = bodies[ds.l2].xofs >= 0 ? bodies[ds.l2].xofs : bodies[ds.l2].cofs + 12;
                     d.lds_pv = d.lds_sv = d.lds_acc = d.lds_acc_out = d.lds_pva = d.lds_va = d.lds_w = -1;
                     d.tofs_i = ds.tofs_i;
-                    d.tofs_d = P.cints[ds.tofs_i + 2];
+                    d.tofs_d = ds.tofs_i >= 0 ? P.cints[ds.tofs_i + 2] : 0;
                     d.glb_k = glb(27);  // [K 12][y0 2][X 4][g 2][s1 c1 s2 c2] (+ OSIM pass: D^-1 (3))
                 } else {
                     pair_of[c].glb_k = glb(21);  // [K 12][y0 2] (+ OSIM pass: D^-1 (3), sin / cos of the two links (4))
@@ -1075,10 +1094,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     ch.cl.push_back(c);
                     // (links with no rotor, an axisymmetric rotor and a general rotor may share a run: the kind is a branch on
                     // the link record)
-                    if (cls[c] != 5 && ckids[c].size() == 1 && is_link(cls[ckids[c][0]])) { c = ckids[c][0]; continue; }
+                    if (!is_diff(c) && ckids[c].size() == 1 && is_link(cls[ckids[c][0]])) { c = ckids[c][0]; continue; }
                     break;
                 }
-                ch.diff = cls[c0] == 5;  // a differential is a chain of its own; its child clusters hang off link2
+                ch.diff = is_diff(c0);  // a differential is a chain of its own; its child clusters hang off link2
                 const int tipc = ch.cl.back();
                 const int id = static_cast<int>(chains.size());
                 chains.push_back(ch);
@@ -1243,13 +1262,14 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : (cls[c] == 4 ? bodies[gen_rotor[c]].cofs : -1);
                         l.general_rotor = cls[c] == 4;
                         l.lds_blk = l.lds_va = l.lds_pf = -1;
-                    } else if (cls[c] == 5) {
+                    } else if (is_diff(c)) {
                         RneaDiff &d = rd[c];
                         d = RneaDiff();
                         d.q_index = cr.q_index; d.v_index = cr.v_index;
                         for (int i = 0; i < 4; i++) { d.qpos[i] = diff_of[c].qpos[i]; d.cofs[i] = diff_of[c].cofs[i]; }
                         d.lds_pva = d.lds_pf = d.lds_blk = d.lds_va = d.lds_w = -1;
                         d.tofs_i = diff_shape[c].tofs_i;
+                        d.gofs = diff_of[c].gofs;
                     } else {
                         RneaPair &pr = rp[c];
                         pr = RneaPair();
@@ -1296,20 +1316,20 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     auto f_slot_of_body = [&](int b) -> int {
                         if (b < 0) return -1;  // ground
                         const int c = m.bodies[b].cluster;
-                        if (cls[c] == 5) return rd[c].lds_blk;
+                        if (is_diff(c)) return rd[c].lds_blk;
                         return cls[c] == 0 ? rf[c].lds_f : rl[c].lds_blk;
                     };
                     auto va_slot_of_body2 = [&](int b) -> int {
                         if (b < 0) return -1;
                         const int c = m.bodies[b].cluster;
-                        if (cls[c] == 5) return rd[c].lds_va;
+                        if (is_diff(c)) return rd[c].lds_va;
                         return cls[c] == 0 ? rf[c].lds_va : rl[c].lds_va;
                     };
                     for (int c = 0; c < nc; c++) {
                         const int pb = clusters[c].parent_body;
                         if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) rl[c].lds_pf = f_slot_of_body(pb);
                         if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb); }
-                        if (cls[c] == 5) { rd[c].lds_pva = va_slot_of_body2(pb); rd[c].lds_pf = f_slot_of_body(pb); }
+                        if (is_diff(c)) { rd[c].lds_pva = va_slot_of_body2(pb); rd[c].lds_pf = f_slot_of_body(pb); }
                     }
                     for (const RRun &r : rruns) {
                         RneaSeg &sg = R.segs[r.seg];
@@ -1364,7 +1384,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 const Chain &ch = chains[id];
                 if (ch.diff) {
                     ChainDiff &d = diff_of[ch.cl[0]];
-                    objs.push_back({&d.lds_w, 3 * diff_shape[ch.cl[0]].n_atoms, 0, B0(ct[id].fwd), D1(ct[id].fwd), -1, 1, 1});
+                    if (diff_shape[ch.cl[0]].n_atoms > 0)
+                        objs.push_back({&d.lds_w, 3 * diff_shape[ch.cl[0]].n_atoms, 0, B0(ct[id].fwd), D1(ct[id].fwd), -1, 1, 1});
                     if (!ch.kid_chains.empty()) {
                         int first_bwd = 1 << 30, last_acc = ct[id].acc;
                         for (int k : ch.kid_chains) { first_bwd = std::min(first_bwd, ct[k].bwd); last_acc = std::max(last_acc, ct[k].acc); }
@@ -1422,26 +1443,26 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 auto v_slot_of_body = [&](int b) -> int {  // LDS slot of the velocity of body b (tip of its cluster); -1: ground
                     if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
-                    if (cls[c] == 5) return diff_of[c].lds_sv + 2;
+                    if (is_diff(c)) return diff_of[c].lds_sv + 2;
                     return cls[c] == 0 ? free_of[c].lds_v : link_of[c].lds_sv + 2;  // (+2 keeps a kSlotGlobal flag intact)
                 };
                 auto va_slot_of_body = [&](int b) -> int {
                     if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
-                    if (cls[c] == 5) return diff_of[c].lds_va;
+                    if (is_diff(c)) return diff_of[c].lds_va;
                     return cls[c] == 0 ? free_of[c].lds_va : link_of[c].lds_va;
                 };
                 auto acc_slot_of_body = [&](int b) -> int {
                     if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
-                    if (cls[c] == 5) return diff_of[c].lds_acc;
+                    if (is_diff(c)) return diff_of[c].lds_acc;
                     return cls[c] == 0 ? free_of[c].lds_acc : acc_slot[c];
                 };
                 for (int c = 0; c < nc; c++) {
                     const int pb = clusters[c].parent_body;
                     if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) link_of[c].lds_pv = v_slot_of_body(pb);
                     if (cls[c] == 3) { pair_of[c].lds_pv = v_slot_of_body(pb); pair_of[c].lds_pva = va_slot_of_body(pb); }
-                    if (cls[c] == 5) { diff_of[c].lds_pv = v_slot_of_body(pb); diff_of[c].lds_pva = va_slot_of_body(pb); diff_of[c].lds_acc_out = acc_slot_of_body(pb); }
+                    if (is_diff(c)) { diff_of[c].lds_pv = v_slot_of_body(pb); diff_of[c].lds_pva = va_slot_of_body(pb); diff_of[c].lds_acc_out = acc_slot_of_body(pb); }
                 }
                 // first writer of every accumulator slot: the kid chain whose backward run comes first
                 for (const RunRef &r : runs) {

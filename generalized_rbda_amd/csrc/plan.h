@@ -219,10 +219,13 @@ struct ChainDiff {
     int32_t lds_pva;    // acceleration sweep: parent body's [v 6][a 6]
     int32_t lds_va;     // own [v 6][a 6] of link2 when child segments follow, else -1
     int32_t lds_w;      // work space of the constraint evaluation: 3 slots per atom (DiffProgram)
-    int32_t tofs_i, tofs_d;  // constraint program in cints[] / consts[] (plan.cpp, emit_diff_program)
-    int32_t reserved[8];
+    int32_t tofs_i, tofs_d;  // constraint program in cints[] / consts[] (plan.cpp, emit_diff_program); tofs_i = -1: an EXPLICIT
+                             // cluster of the same shape -- RevolutePairWithRotor with child clusters on link2 or in a place the
+                             // leaf-pair head of a run does not cover: the link angles are the coordinates (X = 1, g = 0)
+    int32_t gofs;            // consts[]: G rows of the two rotors, (1, 0, 0, 1) for a differential
+    int32_t reserved[7];
 };
-// the same cluster in the inverse-dynamics program (16 ints)
+// the same cluster in the inverse-dynamics program (20 ints)
 struct RneaDiff {
     int32_t q_index, v_index;
     int32_t qpos[4];
@@ -232,7 +235,9 @@ struct RneaDiff {
     int32_t lds_blk;    // [f2 6][s1 c1 s2 c2][X 4]  (14), forward -> backward segment
     int32_t lds_va;     // [v 6][a 6] of link2 for child segments (lds_blk + 14), else -1
     int32_t lds_w;      // work space of the constraint evaluation (shares lds_blk: plan.cpp)
-    int32_t tofs_i;     // constraint program in cints[]
+    int32_t tofs_i;     // constraint program in cints[], -1: explicit pair (see ChainDiff)
+    int32_t gofs;       // consts[]: G rows of the two rotors
+    int32_t reserved[3];
 };
 
 struct ChainSeg {       // 16 ints

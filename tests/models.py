@@ -137,10 +137,12 @@ def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor"
     return m
 
 
-def chain_test_tree(seed, n_limbs=4, ori_repr="quaternion", rotors=True):
+def chain_test_tree(seed, n_limbs=4, ori_repr="quaternion", rotors=True, deep_pairs=False):
     """A floating-base robot of the kind the chain-structured kernels cover (plan.h, ChainProgram): limbs that are
     chains of revolute links (with axisymmetric rotors when `rotors`), some ending in a leaf RevolutePairWithRotor
-    cluster, some branching into two sub-chains half way down."""
+    cluster, some branching into two sub-chains half way down.  deep_pairs: pair clusters also sit in the middle of a limb
+    (child clusters on their second link) and directly on the base -- the explicit pairs that run through the
+    differential's segments (plan.cpp, class 6)."""
     rng = np.random.default_rng(seed)
     m = md.ClusterTreeModel(gravity=(0.0, 0.0, -9.81), ori_repr=ori_repr)
     m.appendBody("base", random_inertia(rng), "ground", joint="free")
@@ -177,10 +179,14 @@ def chain_test_tree(seed, n_limbs=4, ori_repr="quaternion", rotors=True):
         m.appendRegisteredBodiesAsCluster(f"c{c}", "RevolutePairWithRotor", link1=regs["l1"], rotor1=regs["r1"], rotor2=regs["r2"],
                                           link2=regs["l2"], joint_axes=ax() + ax(), rotor_axes=ra, gear_ratios=rng.uniform(2, 10, 2),
                                           belt_ratios_1=rng.uniform(1, 3, 1), belt_ratios_2=rng.uniform(1, 3, 2))
+        return f"l2_{c}"
 
     def chain(parent, length, depth):
         p = parent
         for i in range(length):
+            if deep_pairs and rng.random() < 0.3:
+                p = pair(p)  # a pair in the middle of the limb (or on the base): the limb goes on below its second link
+                continue
             p = link(p)
             if depth < 1 and i == length // 2 and rng.random() < 0.5:  # a branching link: two sub-chains below it
                 chain(p, int(rng.integers(1, 3)), depth + 1)

@@ -114,8 +114,10 @@ def test_chain_program_covers_the_headline_models():
                        ("tello_with_arms", 0), ("urdf_four_bar", 0), ("urdf_mini_cheetah_rpy", 1)):
         assert G.Plan(z[name]).info().analytic_derivatives == want, name
     # fixed-base chains of links (the reference's RevoluteChainWithRotor family, config 1's URDF) start their runs on the ground
-    for name in ("rev_rotor_chain_3", "urdf_revolute_rotor_chain", "tree_rev_fixed"):
+    for name in ("rev_rotor_chain_3", "urdf_revolute_rotor_chain", "tree_rev_fixed", "rev_pair_rotor_chain_4"):
         info = G.Plan(z[name]).info()
         assert info.chain_aba_f32 == 1 and info.chain_rnea_f32 == 1 and info.chain_aba_f64 == 1, name
-    for name in ("urdf_four_bar", "tree_generic_float", "rev_pair_rotor_chain_4"):
+    # (pairs in series -- the reference's RevolutePairChainWithRotor -- run through the differential's segments with constant G)
+    assert G.Plan(z["rev_pair_rotor_chain_4"]).info().n_chain_differentials == 2
+    for name in ("urdf_four_bar", "tree_generic_float", "tree_triple_fixed"):
         assert G.Plan(z[name]).info().chain_aba_f32 == 0, name

@@ -497,7 +497,7 @@ def _sweep_models():
     out = []
     for seed in range(101, 109):
         out.append((f"chain{seed}", lambda s=seed: chain_test_tree(s, n_limbs=2 + s % 4, ori_repr="rpy" if s % 3 == 0 else "quaternion",
-                                                                   rotors=s % 4 != 1)))
+                                                                   rotors=s % 4 != 1, deep_pairs=s % 2 == 0)))
     for seed in range(201, 207):
         out.append((f"tree{seed}", lambda s=seed: random_cluster_tree(s, n_clusters=5 + s % 6, floating=s % 2 == 0,
                                                                       ori_repr="rpy" if s % 5 == 0 else "quaternion")))

@@ -18,7 +18,8 @@ shapes = {}
 for seed in range(1000, 1000 + n):
     for kind in ("chain", "tree_float", "tree_fixed", "chain_fixed_like"):
         if kind == "chain":
-            m = chain_test_tree(seed, n_limbs=1 + seed % 5, ori_repr="rpy" if seed % 4 == 0 else "quaternion", rotors=seed % 3 != 0)
+            m = chain_test_tree(seed, n_limbs=1 + seed % 5, ori_repr="rpy" if seed % 4 == 0 else "quaternion", rotors=seed % 3 != 0,
+                                deep_pairs=seed % 2 == 1)
         elif kind == "tree_float":
             m = random_cluster_tree(seed, n_clusters=3 + seed % 9, floating=True, ori_repr="rpy" if seed % 7 == 0 else "quaternion")
         elif kind == "tree_fixed":
@@ -29,7 +30,7 @@ for seed in range(1000, 1000 + n):
         os.environ.pop("GRBDA_NO_ANALYTIC", None); os.environ.pop("GRBDA_NO_EFPA", None)
         plan = G.Plan(blob)
         info = plan.info()
-        key = (kind, info.chain_aba_f32, info.chain_rnea_f32, info.analytic_derivatives)
+        key = (kind, info.chain_aba_f32, info.chain_rnea_f32, info.analytic_derivatives, "diffs>0" if info.n_chain_differentials else "")
         shapes[key] = shapes.get(key, 0) + 1
         B = 70
         q, qd, tau = valid_states(blob, B, config_index=seed)
@@ -58,4 +59,4 @@ for seed in range(1000, 1000 + n):
             print("FAIL", kind, seed, {k: f"{v[0]:.2e}" for k, v in fails.items()}, "info", key, flush=True)
 print("models", 4 * n, "failures", bad)
 for k, v in sorted(shapes.items()):
-    print("  (kind, chain_aba_f32, chain_rnea_f32, analytic):", k, "x", v)
+    print("  (kind, chain_aba_f32, chain_rnea_f32, analytic, explicit pairs as differentials):", k, "x", v)
