@@ -58,6 +58,7 @@ struct DeviceTables {
     ChainDiff *chain_diffs[3] = {nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
+    uint64_t *deriv_related = nullptr;  // DerivProgram::related
     // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w)
     RneaSeg *rchain_segs[3] = {nullptr, nullptr, nullptr};
     RneaLink *rchain_links[3] = {nullptr, nullptr, nullptr};
@@ -121,7 +122,7 @@ struct grbda_plan {
     bool rnea_narrow = false;  // GRBDA_RNEA_NARROW=1: the inverse-dynamics chain kernel stays at two wavefronts per SIMD
     bool no_analytic = false;  // GRBDA_NO_ANALYTIC=1: derivatives by the unit-vector / central-difference batches only
     bool solve_f64 = false;    // GRBDA_SOLVE_F64=1: the SPD solve of the f32 derivative entry points computes in f64
-    int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 4)
+    int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 3)
     bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
 };
@@ -209,6 +210,9 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         return hip_err(e, "plan upload");
     if (h.deriv.ok) {
         if ((e = up(h.deriv.bodies.data(), h.deriv.bodies.size() * sizeof(DerivBody), (void **)&t.deriv_bodies)) != hipSuccess)
+            return hip_err(e, "plan upload");
+        if (!h.deriv.related.empty() &&
+            (e = up(h.deriv.related.data(), h.deriv.related.size() * sizeof(uint64_t), (void **)&t.deriv_related)) != hipSuccess)
             return hip_err(e, "plan upload");
         if ((e = set_max_dynamic_lds_deriv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
@@ -1182,8 +1186,10 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     if (int rc = ensure_device(p, device, &t)) return rc;
     const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
     const bool need_d = dq || dqd;
-    const size_t per_state = nn + (need_d ? 2 * nn + nv : 0);
-    size_t chunk = (512u << 20) / (per_state * sizeof(T));
+    // H is built in the caller's d/dtau array when that is wanted (the factor is out of it before H^-1 goes in); dID/dq and
+    // dID/dqd in rnea_deriv_kernel's packed layout, the H nobody asked for, and ydd take workspace
+    const size_t per_state = (dtau ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
+    size_t chunk = (2048ull << 20) / (per_state ? per_state * sizeof(T) : 1);
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     void *wptr = nullptr;
@@ -1201,20 +1207,31 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         }
         wptr = s.ptr;
     }
-    T *H = static_cast<T *>(wptr), *Dq = H + chunk * nn, *Dqd = Dq + chunk * nn, *ydd = Dqd + chunk * nn;
+    T *wnext = static_cast<T *>(wptr);
+    auto take = [&](bool wanted) -> T * {
+        if (!wanted) return nullptr;
+        T *r = wnext;
+        wnext += chunk * nn;
+        return r;
+    };
+    T *wH = take(!dtau), *Dq = take(need_d), *Dqd = take(need_d);
+    T *ydd = wnext;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
     for (size_t b0 = 0; b0 < B; b0 += chunk) {
         const size_t nb = B - b0 < chunk ? B - b0 : chunk;
         const size_t n_tiles = (nb + kWave - 1) / kWave;
-        hipError_t e = hipMemsetAsync(H, 0, nb * nn * (need_d ? 3 : 1) * sizeof(T), hs);
-        if (e != hipSuccess) return hip_err(e, "hipMemsetAsync");
+        T *H = dtau ? dtau + b0 * nn : wH;
+        hipError_t e = hipSuccess;
+        // (the CRBA kernel leaves the structural zeros of H to the caller; the derivative kernel's outputs are read through
+        // DerivProgram::related and need no clearing)
+        if (!need_d && (e = hipMemsetAsync(H, 0, nb * nn * sizeof(T), hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
         if (need_d)
             if (int rc = run<T>(p, false, q + b0 * nq, qd + b0 * nv, tau + b0 * nv, nullptr, ydd, nb, device, stream)) return rc;
         size_t grid = static_cast<size_t>(t->n_cu) * 8;
         if (grid > n_tiles) grid = n_tiles;
         const size_t rows = std::max(p->host.crba.n_rows, need_d ? p->host.deriv.n_rows : 0);
-        const size_t deriv_waves = p->deriv_waves ? static_cast<size_t>(p->deriv_waves) : 4;
+        const size_t deriv_waves = p->deriv_waves ? static_cast<size_t>(p->deriv_waves) : 3;
         const size_t slabs = std::max(grid, static_cast<size_t>(t->n_cu) * deriv_waves);
         void *scratch = nullptr;
         if (int rc = ensure_scratch(p, device, stream, slabs * rows * kWave * sizeof(T) + 256, &scratch)) return rc;
@@ -1239,11 +1256,14 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
         if (g3 > nb) g3 = nb;
         T *o1 = dq ? dq + b0 * nn : nullptr, *o2 = dqd ? dqd + b0 * nn : nullptr, *o3 = dtau ? dtau + b0 * nn : nullptr;
+        const T *r1 = dq ? Dq : nullptr, *r2 = dqd ? Dqd : nullptr;
+        const uint64_t *rel = t->deriv_related;
+        const int nvi = static_cast<int>(nv), g3i = static_cast<int>(g3), hp = need_d ? 1 : 0;
         if constexpr (sizeof(T) == 4) {
-            if (wide) e = launch_spd_solve<float, double>(H, dq ? Dq : nullptr, dqd ? Dqd : nullptr, o3, o1, o2, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
-            else e = launch_spd_solve<float, float>(H, dq ? Dq : nullptr, dqd ? Dqd : nullptr, o3, o1, o2, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
+            if (wide) e = launch_spd_solve<float, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs);
+            else e = launch_spd_solve<float, float>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs);
         } else {
-            e = launch_spd_solve<double, double>(H, dq ? Dq : nullptr, dqd ? Dqd : nullptr, o3, o1, o2, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
+            e = launch_spd_solve<double, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs);
         }
         if (e != hipSuccess) return hip_err(e, "spd solve launch");
     }
@@ -1422,7 +1442,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
         for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }

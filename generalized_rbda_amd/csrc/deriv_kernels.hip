@@ -188,10 +188,22 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
         const bool live = r < B;
 #endif
         const T *qs = q + st * (size_t)nq, *qds = qd + st * (size_t)nv, *ydds = ydd + st * (size_t)nv;
+        // output layout, per state and matrix nv^2 entries: coordinate r owns the run [r^2, (r + 1)^2): first d tau_r / d x_c
+        // for c = 0 .. r, then d tau_c / d x_r for c = 0 .. r-1.  Every store of a coordinate's pass (its own cluster, then
+        // ancestor by ancestor) lands in that coordinate's run, so a cache line is completed by consecutive instructions
+        // instead of being revisited from every descendant (the scattered transposed stores of the plain layout cost 2 of
+        // 6.6 ms on JVRC-1); spd_solve_kernel reads column c as entry c of the runs r >= c, and the second half of run c.
         T *Dqs = Dq + st * (size_t)nv * nv, *Dqds = Dqd + st * (size_t)nv * nv;
         // the joint-space inertia matrix falls out of the same composites: H[k][j] = S_j . (Ic_k S_k) for j ancestor of or
-        // equal to k (the CRBA in the common frame); written when the caller wants it
+        // equal to k (the CRBA in the common frame); the rows of its lower triangle, back to back, when the caller wants it
         T *Hs = H ? H + st * (size_t)nv * nv : nullptr;
+        auto put = [&](T *P, int r, int c, T v) {
+            if (c <= r) P[r * r + c] = v;
+            else P[c * c + c + 1 + r] = v;
+        };
+        auto put_h = [&](int r, int c, T v) {
+            if (Hs && c <= r) Hs[r * (r + 1) / 2 + c] = v;
+        };
         // gravity as the acceleration of the frame F (TreeModel.cpp:40-43: a_root = -gravity), base velocity
         T a0[6], vb[6];
 #pragma unroll
@@ -347,9 +359,9 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                     if (live) {
 #pragma unroll
                         for (int j = 0; j < 6; j++) {
-                            Dqs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = row[j];
-                            Dqds[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Bc[6 * i + j];
-                            if (Hs) Hs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = Ic[sidx(i, j)];
+                            put(Dqs, cr.v_index + i, cr.v_index + j, row[j]);
+                            put(Dqds, cr.v_index + i, cr.v_index + j, Bc[6 * i + j]);
+                            put_h(cr.v_index + i, cr.v_index + j, Ic[sidx(i, j)]);
                         }
                     }
                 }
@@ -577,9 +589,9 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
 #pragma unroll
                     for (int b2 = 0; b2 < NMAX; b2++)
                         if (a2 < n && b2 < n) {
-                            Dqs[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cq[a2][b2];
-                            Dqds[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Cqd[a2][b2];
-                            if (Hs) Hs[(size_t)(cr.v_index + a2) * nv + cr.v_index + b2] = Ch[a2][b2];
+                            put(Dqs, cr.v_index + a2, cr.v_index + b2, Cq[a2][b2]);
+                            put(Dqds, cr.v_index + a2, cr.v_index + b2, Cqd[a2][b2]);
+                            put_h(cr.v_index + a2, cr.v_index + b2, Ch[a2][b2]);
                         }
             }
             // ---- up the ancestors outside the cluster, block by block ----
@@ -604,14 +616,11 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                             if (live) {
 #pragma unroll
                                 for (int k6 = 0; k6 < 6; k6++) {
-                                    Dqs[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = w1[k6];
-                                    Dqds[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = T1[a2][k6] - w2[k6];
-                                    Dqs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T4[a2][k6];
-                                    Dqds[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T3[a2][k6];
-                                    if (Hs) {
-                                        Hs[(size_t)(cr.v_index + a2) * nv + cd.v_index + k6] = T2[a2][k6];
-                                        Hs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a2] = T2[a2][k6];
-                                    }
+                                    put(Dqs, cr.v_index + a2, cd.v_index + k6, w1[k6]);
+                                    put(Dqds, cr.v_index + a2, cd.v_index + k6, T1[a2][k6] - w2[k6]);
+                                    put(Dqs, cd.v_index + k6, cr.v_index + a2, T4[a2][k6]);
+                                    put(Dqds, cd.v_index + k6, cr.v_index + a2, T3[a2][k6]);
+                                    put_h(cr.v_index + a2, cd.v_index + k6, T2[a2][k6]);
                                 }
                             }
                         }
@@ -662,20 +671,18 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
 #pragma unroll
                         for (int b2 = 0; b2 < NMAX; b2++)
                             if (a2 < n && b2 < cd.n) {
-                                Dqs[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bq[a2][b2];
-                                Dqds[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bqd[a2][b2];
-                                Dqs[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Uq[b2][a2];
-                                Dqds[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Uqd[b2][a2];
-                                if (Hs) {
-                                    Hs[(size_t)(cr.v_index + a2) * nv + cd.v_index + b2] = Bh[a2][b2];
-                                    Hs[(size_t)(cd.v_index + b2) * nv + cr.v_index + a2] = Bh[a2][b2];
-                                }
+                                put(Dqs, cr.v_index + a2, cd.v_index + b2, Bq[a2][b2]);
+                                put(Dqds, cr.v_index + a2, cd.v_index + b2, Bqd[a2][b2]);
+                                put(Dqs, cd.v_index + b2, cr.v_index + a2, Uq[b2][a2]);
+                                put(Dqds, cd.v_index + b2, cr.v_index + a2, Uqd[b2][a2]);
+                                put_h(cr.v_index + a2, cd.v_index + b2, Bh[a2][b2]);
                             }
                 }
                 j = next;
             }
         }
-        // entries between clusters on different branches are structural zeros (the arrays are cleared by the caller)
+        // entries between clusters on different branches are structural zeros: never written, and never read by the solve
+        // (DerivProgram::related)
     }
 }
 
@@ -700,13 +707,17 @@ template hipError_t launch_rnea_deriv<double>(const DevPlan<double> &, const Der
                                               const double *, double *, double *, double *, size_t, double *, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------------------
-// Batched SPD solve, one state per wavefront, entirely in registers.  Lane i holds row i of H, then of its Cholesky
-// factor L (left-looking by columns: the entry L[k][m] another row needs comes from lane k by v_readlane, a scalar
-// operand); for the triangular solves every lane carries one right-hand-side column and the factor is again read
-// through v_readlane, so neither LDS nor shuffles are involved.  NV is the compile-time size the loops are unrolled
-// for (nv <= NV <= 64; H is padded with the identity).  Right-hand sides: the nv columns of R1, of R2 and of the
-// identity (H^-1), each optional, 64 columns per pass; results are scaled by -1 for R1 / R2 (-H^-1 D).
-// Global traffic: every matrix read / written once, rows contiguous.  TIO: array element type; TC: arithmetic type.
+// Batched SPD solve, one state per wavefront.  Lane i holds row i of H, then of its Cholesky factor L (left-looking by
+// columns: the entry L[k][m] another row needs comes from lane k by v_readlane, a scalar operand); each finished column
+// of L is also written to LDS as a row of L^T.  For the triangular solves every lane carries one or two right-hand-side
+// columns in registers and reads the factor row by row from LDS, every lane the same address (a 16-byte broadcast read,
+// on the LDS port rather than the VALU's): forward substitution by columns of L, backward by rows of L^T -- both are
+// rows of the stored L^T.  With two columns per lane the f32 updates are packed (v_pk_fma_f32).  NV is the compile-time
+// size the loops are unrolled for (nv <= NV <= 64; H is padded with the identity).  Right-hand sides: the nv columns of
+// P1, of P2 (rnea_deriv_kernel's packed layout) and of the identity (H^-1), each optional; results, in plain row-major
+// layout, are scaled by -1 for P1 / P2 (-H^-1 D).  Hinv may be H: the factor is in registers / LDS before H^-1 is stored.
+// `related` (DerivProgram::related, may be null): the entries that are not structural zeros; the others are not used,
+// whatever the arrays hold.  Global traffic: every matrix read / written once.  TIO: array element type; TC: arithmetic.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lane_value(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 __device__ __forceinline__ double lane_value(double x, int l)
@@ -716,37 +727,93 @@ __device__ __forceinline__ double lane_value(double x, int l)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <class TIO, class TC, int NV, int KC>
-__global__ __launch_bounds__(kWave) void spd_solve_kernel(const TIO *__restrict__ H, const TIO *__restrict__ R1, const TIO *__restrict__ R2,
-                                                         TIO *__restrict__ Hinv, TIO *__restrict__ X1, TIO *__restrict__ X2, int nv,
-                                                         size_t B)
+// 1 / sqrt(d): the hardware estimate refined by Newton steps (y <- y (1.5 - 0.5 d y^2)) to working precision, a fraction
+// of the instructions of the IEEE division and square root
+__device__ __forceinline__ float inv_sqrt(float d)
 {
+    const float y = __builtin_amdgcn_rsqf(d);
+    return y * (1.5f - 0.5f * d * y * y);
+}
+__device__ __forceinline__ double inv_sqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y * (1.5 - 0.5 * d * y * y);
+}
+
+template <class TIO, class TC, int NV, int KC>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(KC == 2 ? 2 : 1, KC == 2 ? 2 : 8)))
+void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2,
+                      const uint64_t *__restrict__ related, int nv, size_t B)
+{
+    constexpr int V = 16 / (int)sizeof(TC);
+    typedef TC Vec __attribute__((ext_vector_type(V)));
+    typedef TC XV __attribute__((ext_vector_type(KC)));
+    static_assert(NV % V == 0, "rows of the factor are read as 16-byte vectors");
+    __shared__ __attribute__((aligned(16))) TC Lt[NV * NV];  // Lt[k][i] = L[i][k], i >= k; Lt[k][k] = 1 / L[k][k]
     const int lane = threadIdx.x;
     const size_t nn = (size_t)nv * nv;
+    // row k of Lt from entry `from` on, every lane the same address (an LDS broadcast, no bank conflicts)
+    auto factor_row = [&](int k, int from, TC(&l)[NV]) {
+#pragma unroll
+        for (int i = (from / V) * V; i < NV; i += V) {
+            const Vec v = *reinterpret_cast<const Vec *>(&Lt[k * NV + i]);
+#pragma unroll
+            for (int e = 0; e < V; e++) l[i + e] = v[e];
+        }
+    };
+    // a lane's own run of n consecutive entries at `row` (n wave-uniform): 16-byte loads where they stay inside the run
+    auto read_row = [&](const TIO *row, int n, TIO(&out)[NV]) {
+        constexpr int W = 16 / (int)sizeof(TIO);
+        typedef TIO VIO __attribute__((ext_vector_type(W)));
+#pragma unroll
+        for (int i = 0; i < NV; i += W) {
+            if (i + W <= n) {
+                VIO v;
+                __builtin_memcpy(&v, row + i, sizeof v);
+#pragma unroll
+                for (int e = 0; e < W; e++) out[i + e] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; e++) out[i + e] = (i + e < n) ? row[i + e] : TIO(0);
+            }
+        }
+    };
+    const uint64_t rel_mine = related ? related[lane < nv ? lane : 0] : ~uint64_t(0);
     for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
-        TC Lr[NV];  // row `lane` of H, then of L; the diagonal entry holds 1 / L[k][k]
         {
-            const TIO *row = H + s * nn + (size_t)(lane < nv ? lane : 0) * nv;
+            TC Lr[NV];  // row `lane` of H, then of L; the diagonal entry holds 1 / L[k][k]
+            // (only the lower triangle of H is read, and of that only the entries between coordinates on one root path;
+            // h_packed: rows of the lower triangle back to back, as rnea_deriv_kernel writes them)
+            const size_t lrow = lane < nv ? lane : 0;
+            TIO hrow[NV];
+            read_row(H + s * nn + (h_packed ? lrow * (lrow + 1) / 2 : lrow * nv), nv, hrow);
 #pragma unroll
-            for (int j = 0; j < NV; j++) Lr[j] = (lane < nv && j < nv) ? (TC)row[j < nv ? j : 0] : (lane == j ? TC(1) : TC(0));
+            for (int j = 0; j < NV; j++)
+                Lr[j] = (lane < nv && j < nv) ? ((j <= lane && ((rel_mine >> j) & 1)) ? (TC)hrow[j] : TC(0)) : (lane == j ? TC(1) : TC(0));
+            __syncthreads();  // the previous state's solves are done with Lt
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                TC sum = Lr[k];
+#pragma unroll
+                for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
+                const TC d = lane_value(sum, k);
+                const TC r = inv_sqrt(d);
+                Lr[k] = lane == k ? r : sum * r;
+                if (lane >= k && lane < NV) Lt[k * NV + lane] = Lr[k];
+            }
+            __syncthreads();
         }
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-            TC sum = Lr[k];
-#pragma unroll
-            for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
-            const TC d = lane_value(sum, k);
-            const TC r = TC(1) / sqrt(d);
-            Lr[k] = lane == k ? r : sum * r;
-        }
-        // right-hand sides: KC columns per lane and pass (two when more than 64 columns are wanted: the factor entries
-        // read through v_readlane then serve both)
-        const int n1 = R1 ? nv : 0, n2 = R2 ? nv : 0, n3 = Hinv ? nv : 0;
+        // right-hand sides: KC columns per lane and pass; forward substitution by columns of L, backward by rows of L^T,
+        // both of which are rows of Lt
+        const int n1 = P1 ? nv : 0, n2 = P2 ? nv : 0, n3 = Hinv ? nv : 0;
         for (int c0 = 0; c0 < n1 + n2 + n3; c0 += KC * kWave) {
+            asm volatile("" ::: "memory");  // the factor is re-read from LDS every pass, not kept in NV^2/2 registers
             const TIO *src[KC];
             TIO *dst[KC];
             int jc[KC];
-            TC scale[KC], x[KC][NV];
+            TC scale[KC];
+            XV x[NV];  // x[i][u]: entry i of this lane's u-th column (a register pair when KC == 2: packed f32 arithmetic)
 #pragma unroll
             for (int u = 0; u < KC; u++) {
                 const int col = c0 + u * kWave + lane;
@@ -754,88 +821,107 @@ __global__ __launch_bounds__(kWave) void spd_solve_kernel(const TIO *__restrict_
                 dst[u] = nullptr;
                 jc[u] = 0;
                 scale[u] = 1;
-                if (col < n1) { src[u] = R1 + s * nn; dst[u] = X1 + s * nn; jc[u] = col; scale[u] = -1; }
-                else if (col < n1 + n2) { src[u] = R2 + s * nn; dst[u] = X2 + s * nn; jc[u] = col - n1; scale[u] = -1; }
+                if (col < n1) { src[u] = P1 + s * nn; dst[u] = X1 + s * nn; jc[u] = col; scale[u] = -1; }
+                else if (col < n1 + n2) { src[u] = P2 + s * nn; dst[u] = X2 + s * nn; jc[u] = col - n1; scale[u] = -1; }
                 else if (col < n1 + n2 + n3) { dst[u] = Hinv + s * nn; jc[u] = col - n1 - n2; }
+                // column c of a packed right-hand side (rnea_deriv_kernel): the entries on and below the diagonal sit at
+                // r^2 + c of the runs r >= c (across lanes: consecutive addresses), the ones above it are the second half of
+                // run c, c^2 + c + 1 + r.  Structural zeros are never written, and not used here.
+                const uint64_t rel = related ? related[jc[u]] : ~uint64_t(0);
+                if (src[u]) {
+                    TIO urow[NV];
+                    read_row(src[u] + (size_t)jc[u] * jc[u] + jc[u] + 1, nv - 1, urow);
 #pragma unroll
-                for (int i = 0; i < NV; i++)
-                    x[u][i] = (dst[u] && i < nv) ? (src[u] ? (TC)src[u][(size_t)i * nv + jc[u]] : (i == jc[u] ? TC(1) : TC(0))) : TC(0);
-            }
+                    for (int i = 0; i < NV; i++) {
+                        const size_t r = i < nv ? i : 0;
+                        const TIO v = src[u][r * r + (jc[u] <= (int)r ? jc[u] : 0)];
+                        x[i][u] = (i < nv && ((rel >> i) & 1)) ? (TC)(i < jc[u] ? urow[i] : v) : TC(0);
+                    }
+                } else {
 #pragma unroll
-            for (int i = 0; i < NV; i++) {
-                TC acc[KC];
-#pragma unroll
-                for (int u = 0; u < KC; u++) acc[u] = x[u][i];
-#pragma unroll
-                for (int m2 = 0; m2 < i; m2++) {
-                    const TC l = lane_value(Lr[m2], i);
-#pragma unroll
-                    for (int u = 0; u < KC; u++) acc[u] -= l * x[u][m2];
+                    for (int i = 0; i < NV; i++) x[i][u] = (dst[u] && i == jc[u]) ? TC(1) : TC(0);
                 }
-                const TC di = lane_value(Lr[i], i);
+            }
+            // (the row after the current one is in flight while this one is used; the clobbers and scheduling barriers keep
+            // the compiler from hoisting every LDS read of the unrolled loop to the top, which spills)
+            TC l[NV], ln[NV];
+            factor_row(0, 0, l);
 #pragma unroll
-                for (int u = 0; u < KC; u++) x[u][i] = acc[u] * di;
+            for (int m2 = 0; m2 < NV; m2++) {
+                factor_row(m2 + 1 < NV ? m2 + 1 : NV - 1, m2 + 1 < NV ? m2 + 1 : NV - 1, ln);
+                x[m2] *= l[m2];
+#pragma unroll
+                for (int i = m2 + 1; i < NV; i++) x[i] -= l[i] * x[m2];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NV; i++) l[i] = ln[i];
             }
 #pragma unroll
             for (int i = NV - 1; i >= 0; i--) {
-                TC acc[KC];
+                if (i > 0) factor_row(i - 1, i - 1, ln);
+                XV acc = x[i];
 #pragma unroll
-                for (int u = 0; u < KC; u++) acc[u] = x[u][i];
+                for (int m2 = i + 1; m2 < NV; m2++) acc -= l[m2] * x[m2];
+                x[i] = acc * l[i];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m2 = i + 1; m2 < NV; m2++) {
-                    const TC l = lane_value(Lr[i], m2);
-#pragma unroll
-                    for (int u = 0; u < KC; u++) acc[u] -= l * x[u][m2];
-                }
-                const TC di = lane_value(Lr[i], i);
-#pragma unroll
-                for (int u = 0; u < KC; u++) x[u][i] = acc[u] * di;
+                for (int j = 0; j < NV; j++) l[j] = ln[j];
             }
 #pragma unroll
             for (int u = 0; u < KC; u++)
                 if (dst[u]) {
 #pragma unroll
                     for (int i = 0; i < NV; i++)
-                        if (i < nv) dst[u][(size_t)i * nv + jc[u]] = (TIO)(scale[u] * x[u][i]);
+                        if (i < nv) dst[u][(size_t)i * nv + jc[u]] = (TIO)(scale[u] * x[i][u]);
                 }
+            // a use of the solution outside the conditional stores: without it the compiler sinks the whole substitution
+            // into the store block, below the LDS reads, and every factor row stays live (spills)
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+#pragma unroll
+                for (int u = 0; u < KC; u++) asm volatile("" ::"v"(x[i][u]));
         }
     }
 }
 
 template <class TIO, class TC, int NV>
-static hipError_t launch_spd_solve_n(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
-                                     hipStream_t stream)
+static hipError_t launch_spd_solve_n(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2,
+                                     const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
 {
     // two columns per lane: f32 arithmetic and more than one pass of 64 columns (register budget: 4 NV values per lane)
-    const int ncols = (R1 ? nv : 0) + (R2 ? nv : 0) + (Hinv ? nv : 0);
+    const int ncols = (P1 ? nv : 0) + (P2 ? nv : 0) + (Hinv ? nv : 0);
     static const int kc_env = [] { const char *e = std::getenv("GRBDA_SOLVE_KC"); return e ? std::atoi(e) : 0; }();
     if constexpr (sizeof(TC) == 4 && NV == 40) {  // (measured: it pays for JVRC-1's 114 columns only)
         if (kc_env != 1 && (ncols > kWave || kc_env == 2)) {
-            hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 2>), dim3(grid), dim3(kWave), 0, stream, H, R1, R2, Hinv, X1, X2, nv, B);
+            hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 2>), dim3(grid), dim3(kWave), 0, stream, H, h_packed, P1, P2, Hinv, X1, X2,
+                               related, nv, B);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 1>), dim3(grid), dim3(kWave), 0, stream, H, R1, R2, Hinv, X1, X2, nv, B);
+    hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 1>), dim3(grid), dim3(kWave), 0, stream, H, h_packed, P1, P2, Hinv, X1, X2, related, nv,
+                       B);
     return hipGetLastError();
 }
 template <class TIO, class TC>
-hipError_t launch_spd_solve(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
-                            hipStream_t stream)
+hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
+                            int nv, size_t B, int grid, hipStream_t stream)
 {
-    if (nv <= 16) return launch_spd_solve_n<TIO, TC, 16>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
-    if (nv <= 24) return launch_spd_solve_n<TIO, TC, 24>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
-    if (nv <= 32) return launch_spd_solve_n<TIO, TC, 32>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
-    if (nv <= 40) return launch_spd_solve_n<TIO, TC, 40>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
-    if (nv <= 48) return launch_spd_solve_n<TIO, TC, 48>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
-    if (nv <= 64) return launch_spd_solve_n<TIO, TC, 64>(H, R1, R2, Hinv, X1, X2, nv, B, grid, stream);
+    if (nv <= 16) return launch_spd_solve_n<TIO, TC, 16>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 24) return launch_spd_solve_n<TIO, TC, 24>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 32) return launch_spd_solve_n<TIO, TC, 32>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 40) return launch_spd_solve_n<TIO, TC, 40>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 48) return launch_spd_solve_n<TIO, TC, 48>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 64) return launch_spd_solve_n<TIO, TC, 64>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
     return hipErrorInvalidValue;
 }
-template hipError_t launch_spd_solve<float, float>(const float *, const float *, const float *, float *, float *, float *, int, size_t, int,
-                                                   hipStream_t);
-template hipError_t launch_spd_solve<float, double>(const float *, const float *, const float *, float *, float *, float *, int, size_t, int,
-                                                    hipStream_t);
-template hipError_t launch_spd_solve<double, double>(const double *, const double *, const double *, double *, double *, double *, int,
-                                                     size_t, int, hipStream_t);
+template hipError_t launch_spd_solve<float, float>(const float *, int, const float *, const float *, float *, float *, float *, const uint64_t *,
+                                                   int, size_t, int, hipStream_t);
+template hipError_t launch_spd_solve<float, double>(const float *, int, const float *, const float *, float *, float *, float *,
+                                                    const uint64_t *, int, size_t, int, hipStream_t);
+template hipError_t launch_spd_solve<double, double>(const double *, int, const double *, const double *, double *, double *, double *,
+                                                     const uint64_t *, int, size_t, int, hipStream_t);
 
 size_t spd_solve_lds_bytes(int, size_t) { return 0; }
 

@@ -134,8 +134,8 @@ template <class T>
 hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
                              const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream);
 template <class TIO, class TC>
-hipError_t launch_spd_solve(const TIO *H, const TIO *R1, const TIO *R2, TIO *Hinv, TIO *X1, TIO *X2, int nv, size_t B, int grid,
-                            hipStream_t stream);
+hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
+                            int nv, size_t B, int grid, hipStream_t stream);
 size_t spd_solve_lds_bytes(int nv, size_t elem);
 hipError_t set_max_dynamic_lds_deriv();
 

@@ -1611,6 +1611,21 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         for (int b = 0; b < nb; b++)
             if (DV.bodies[b].acc_row >= 0) DV.bodies[b].acc_row += rows;
         DV.n_rows = rows + n_acc;
+        if (P.nv <= 64) {
+            DV.related.assign(P.nv, 0);
+            for (int c = 0; c < nc; c++) {
+                int a = c;  // c and its ancestor clusters
+                for (;;) {
+                    for (int i = 0; i < clusters[c].n; i++)
+                        for (int j = 0; j < clusters[a].n; j++) {
+                            DV.related[clusters[c].v_index + i] |= uint64_t(1) << (clusters[a].v_index + j);
+                            DV.related[clusters[a].v_index + j] |= uint64_t(1) << (clusters[c].v_index + i);
+                        }
+                    if (clusters[a].parent_body < 0) break;
+                    a = m.bodies[clusters[a].parent_body].cluster;
+                }
+            }
+        }
     }
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------

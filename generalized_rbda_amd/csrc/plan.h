@@ -346,6 +346,9 @@ struct DerivProgram {
     std::vector<DerivBody> bodies;
     int n_rows = 0;
     int n_max = 1;    // largest number of coordinates of a cluster
+    // (nv <= 64) bit i of related[j]: velocity coordinates i and j are on one root path (same cluster, ancestor or
+    // descendant) -- the only entries of H, dID/dq and dID/dqd that are not structural zeros
+    std::vector<uint64_t> related;
 };
 
 // LDS budget per wavefront, in slots, of each kernel (ABA / RNEA x f32 / f64).  Few slots mean more
