@@ -489,6 +489,36 @@ def test_fd_derivatives_analytic_against_difference_batches(name, gpu, monkeypat
         assert np.abs(a - b).max() / (1.0 + np.abs(b).max()) < TOL32, k
 
 
+@pytest.mark.parametrize("n_clusters,seed", [(40, 31), (57, 32)])
+def test_fd_derivatives_wide_models(n_clusters, seed, gpu, monkeypatch):
+    """The SPD solve is compiled for 16 / 24 / 32 / 40 / 48 / 64 coordinates; the robots of the zoo stop at 38.  Random
+    floating-base trees of revolute and rotor clusters with 46 and 63 coordinates: analytic route against the
+    unit-vector / central-difference batches, fp64, and fp32 against fp64."""
+    import torch
+    from models import random_cluster_tree
+
+    blob = random_cluster_tree(seed, n_clusters, floating=True, kinds=("rev", "rotor")).serialize()
+    plan = G.Plan(blob)
+    assert plan.info().analytic_derivatives and plan.nv == n_clusters + 6
+    monkeypatch.setenv("GRBDA_NO_ANALYTIC", "1")
+    plan_fd = G.Plan(blob)
+    monkeypatch.delenv("GRBDA_NO_ANALYTIC")
+    B = 70
+    q, qd, tau = valid_states(blob, B, config_index=91)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    d = plan.fd_derivatives(t(q), t(qd), t(tau))
+    ref = {"dtau": plan_fd.fd_dtau(t(q)), "dqd": plan_fd.fd_dqd(t(q), t(qd), t(tau)), "dq": plan_fd.fd_dq(t(q), t(qd), t(tau), step=1e-6)}
+    for k, tol in (("dtau", 1e-8), ("dqd", 1e-8), ("dq", 2e-5)):
+        a, b = d[k].cpu().numpy(), ref[k].cpu().numpy()
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() / (1.0 + np.abs(b).max()) < tol, k
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    d32 = plan.fd_derivatives(t32(q), t32(qd), t32(tau))
+    for k in ("dtau", "dqd", "dq"):
+        a, b = d32[k].double().cpu().numpy(), d[k].cpu().numpy()
+        assert np.abs(a - b).max() / (1.0 + np.abs(b).max()) < 10 * TOL32, k
+
+
 def _sweep_models():
     """Random models beyond the fixed zoo: chain-structured robots (branching links, leaf pairs, long limbs, with and
     without rotors, both base orientations) and random cluster trees of every explicit type, floating and fixed."""
