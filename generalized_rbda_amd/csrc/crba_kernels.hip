@@ -24,7 +24,7 @@ namespace grbda_hip {
 template <class T>
 __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const CrbaBody *__restrict__ cb_, int n_clusters, int n_rows,
                                                         const T *__restrict__ q, T *__restrict__ H, size_t B,
-                                                        T *__restrict__ scratch)
+                                                        T *__restrict__ scratch, int packed)
 {
     cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
     cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
@@ -39,6 +39,14 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
         const bool live = r < B;
         const T *qs = q + st * (size_t)nq;
         T *Hs = H + st * (size_t)nv * nv;
+        // packed: the rows of the lower triangle back to back (entry (r, c <= r) at r (r + 1) / 2 + c), every store of a
+        // coordinate's pass in that coordinate's own row -- what spd_solve_kernel and unpack_symmetric_kernel read; the
+        // transposed stores of the plain layout revisit every ancestor's row from every descendant.  Plain: the full
+        // symmetric nv x nv matrix, structural zeros left to the caller.
+        auto put = [&](int r, int c, T v) {
+            if (!packed) Hs[(size_t)r * nv + c] = v;
+            else if (c <= r) Hs[r * (r + 1) / 2 + c] = v;
+        };
         // ---- pass 1: sin / cos of every revolute spanning joint; composite accumulators start at zero ----
         for (int c = 0; c < n_clusters; c++) {
             const ClusterRec cr = load_rec(clusters + c);
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
                     for (int j = 0; j < 6; j++) {
                         T v = Ib[sidx(i, j)];
                         if (x.acc_row >= 0) v += slab[(size_t)(x.acc_row + sidx(i, j)) * kWave];
-                        if (live) Hs[(size_t)(cr.v_index + i) * nv + cr.v_index + j] = v;
+                        if (live) put(cr.v_index + i, cr.v_index + j, v);
                     }
                 continue;
             }
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
                 for (int a = 0; a < kMaxClusterDof; a++)
 #pragma unroll
                     for (int b2 = 0; b2 < kMaxClusterDof; b2++)
-                        if (a < n && b2 < n) Hs[(size_t)(cr.v_index + a) * nv + cr.v_index + b2] = Hcc[a][b2];
+                        if (a < n && b2 < n) put(cr.v_index + a, cr.v_index + b2, Hcc[a][b2]);
             }
             // ---- up the ancestors: H[c][d] = Fp^T S_d, block by block ----
             int j = cr.parent_body;
@@ -171,8 +179,8 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
 #pragma unroll
                             for (int k6 = 0; k6 < 6; k6++)
                                 if (a < n) {
-                                    Hs[(size_t)(cr.v_index + a) * nv + cd.v_index + k6] = Fp[a][k6];
-                                    Hs[(size_t)(cd.v_index + k6) * nv + cr.v_index + a] = Fp[a][k6];
+                                    put(cr.v_index + a, cd.v_index + k6, Fp[a][k6]);
+                                    put(cd.v_index + k6, cr.v_index + a, Fp[a][k6]);
                                 }
                     }
                     break;
@@ -211,8 +219,8 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
 #pragma unroll
                         for (int b2 = 0; b2 < kMaxClusterDof; b2++)
                             if (a < n && b2 < cd.n) {
-                                Hs[(size_t)(cr.v_index + a) * nv + cd.v_index + b2] = Hcd[a][b2];
-                                Hs[(size_t)(cd.v_index + b2) * nv + cr.v_index + a] = Hcd[a][b2];
+                                put(cr.v_index + a, cd.v_index + b2, Hcd[a][b2]);
+                                put(cd.v_index + b2, cr.v_index + a, Hcd[a][b2]);
                             }
                 }
                 (void)bj;
@@ -225,14 +233,53 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
 
 template <class T>
 hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,
-                       int grid, hipStream_t stream)
+                       int grid, hipStream_t stream, bool packed)
 {
-    hipLaunchKernelGGL((crba_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, cb, n_clusters, n_rows, q, H, B, scratch);
+    hipLaunchKernelGGL((crba_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, cb, n_clusters, n_rows, q, H, B, scratch, packed ? 1 : 0);
     return hipGetLastError();
 }
 template hipError_t launch_crba<float>(const DevPlan<float> &, const CrbaBody *, int, int, const float *, float *, size_t, float *, int,
-                                       hipStream_t);
+                                       hipStream_t, bool);
 template hipError_t launch_crba<double>(const DevPlan<double> &, const CrbaBody *, int, int, const double *, double *, size_t,
-                                        double *, int, hipStream_t);
+                                        double *, int, hipStream_t, bool);
+
+// Packed lower triangle -> full symmetric matrix, in place (the packed rows occupy the first nv (nv + 1) / 2 entries of each
+// state's nv x nv block).  One state per wavefront: the packed block is read into LDS with consecutive lanes on
+// consecutive addresses, then the nv^2 entries are written the same way; entries between coordinates that are not on
+// one root path (DerivProgram::related) are written as zeros, whatever the packed block holds there.  nv <= 64.
+template <class T>
+__global__ __launch_bounds__(kWave) void unpack_symmetric_kernel(T *__restrict__ H, const uint64_t *__restrict__ related, int nv, size_t B)
+{
+    __shared__ T tri[kWave * (kWave + 1) / 2];
+    const int lane = threadIdx.x, nn = nv * nv, nt = nv * (nv + 1) / 2;
+    const int step_r = kWave / nv, step_c = kWave % nv;
+    for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
+        T *Hs = H + s * (size_t)nn;
+        __syncthreads();
+        for (int i = lane; i < nt; i += kWave) tri[i] = Hs[i];
+        __syncthreads();
+        int r = lane / nv, c = lane % nv;
+        for (int i = lane; i < nn; i += kWave) {
+            const int lo = c <= r ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r;
+            const bool rel = (related[r] >> c) & 1;
+            Hs[i] = rel ? tri[lo] : T(0);
+            r += step_r;
+            c += step_c;
+            if (c >= nv) {
+                c -= nv;
+                r++;
+            }
+        }
+    }
+}
+template <class T>
+hipError_t launch_unpack_symmetric(T *H, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
+{
+    if (nv > kWave || !related) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((unpack_symmetric_kernel<T>), dim3(grid), dim3(kWave), 0, stream, H, related, nv, B);
+    return hipGetLastError();
+}
+template hipError_t launch_unpack_symmetric<float>(float *, const uint64_t *, int, size_t, int, hipStream_t);
+template hipError_t launch_unpack_symmetric<double>(double *, const uint64_t *, int, size_t, int, hipStream_t);
 
 }  // namespace grbda_hip

@@ -127,7 +127,9 @@ hipError_t launch_osim_chain(const ChainDev<T> &P, const OsimArgs<T> &A, const T
 // composite-rigid-body algorithm (crba_kernels.hip)
 template <class T>
 hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,
-                       int grid, hipStream_t stream);
+                       int grid, hipStream_t stream, bool packed);
+template <class T>
+hipError_t launch_unpack_symmetric(T *H, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream);
 
 // inverse-dynamics derivatives and the batched SPD solve behind d ydd / d (q, qd, tau) (deriv_kernels.hip)
 template <class T>
