@@ -153,7 +153,9 @@ int grbda_rnea_f32(const grbda_plan *plan, const float *q, const float *qd, cons
  * (d ID / d q and d ID / d qd of the spanning tree projected with G, then one batched SPD solve per state:
  * d ydd / d tau = H^-1, d ydd / d q = -H^-1 dID/dq, d ydd / d qd = -H^-1 dID/dqd at ydd = FD(q, qd, tau)); `step` is then
  * not used.  grbda_fd_derivatives_* returns any subset of the three matrices from ONE pass (NULL = not wanted) and falls
- * back to the three entry points above for the other models.
+ * back to the three entry points above for the other models.  The analytic route keeps its intermediate matrices in a
+ * device workspace owned by the plan, one per (device, stream), of at most 2 GiB (the batch goes through in chunks of that
+ * size); the output arrays must not overlap the inputs or each other.
  */
 int grbda_bias_f64(const grbda_plan *plan, const double *q, const double *qd, const double *f_ext, double *out,
                    size_t B, int device, void *stream);
