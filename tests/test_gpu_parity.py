@@ -192,6 +192,14 @@ def test_mass_matrix_bias_and_fd_derivatives_match_oracle(name, blob, gpu):
     scale = lambda M: 1.0 + np.abs(M).max()
     assert np.abs(H - H_ref).max() / scale(H_ref) < TOL64
     assert np.abs(H - H.transpose(0, 2, 1)).max() / scale(H_ref) < TOL64
+    # fp32: explicit models write packed rows of the lower triangle and unpack them in place (crba_kernels.hip); 67 states:
+    # a full tile and a ragged one
+    q67 = valid_states(blob, 67, config_index=24)[0]
+    H32 = plan.mass_matrix(torch.as_tensor(np.ascontiguousarray(q67), dtype=torch.float32, device=gpu)).double().cpu().numpy()
+    H67 = plan.mass_matrix(t(q67.astype(np.float32).astype(np.float64))).cpu().numpy()
+    assert np.isfinite(H32).all() and np.abs(H32 - H67).max() / scale(H67) < TOL32
+    if plan.info().analytic_derivatives:  # (models with implicit loops go through nv + 1 inverse-dynamics evaluations)
+        assert (H32 == H32.transpose(0, 2, 1)).all() and ((H32 == 0) == (H67 == 0)).all()
     assert rel_err(C, C_ref) < TOL64
     assert np.abs(Hinv - Hinv_ref).max() / scale(Hinv_ref) < 1e-8
     assert np.abs(J - J_ref).max() / scale(J_ref) < 1e-8

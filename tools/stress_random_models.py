@@ -45,6 +45,17 @@ for seed in range(1000, 1000 + n):
         errs["dtau"] = (rel(d["dtau"].cpu().numpy(), slow.fd_dtau(t(q[:6])).cpu().numpy()), 1e-8)
         errs["dqd"] = (rel(d["dqd"].cpu().numpy(), slow.fd_dqd(t(q[:6]), t(qd[:6]), t(tau[:6])).cpu().numpy()), 1e-8)
         errs["dq"] = (rel(d["dq"].cpu().numpy(), slow.fd_dq(t(q[:6]), t(qd[:6]), t(tau[:6]), step=1e-6).cpu().numpy()), 2e-5)
+        # mass matrix: fp64 (plain CRBA) against the oracle, fp32 (packed rows + in-place unpack) against fp64
+        H64 = plan.mass_matrix(t(q[:66])).cpu().numpy()
+        z4 = np.zeros((4, plan.nv))
+        c0 = O.inverse_dynamics(blob, q[:4], z4, z4)
+        Href = np.stack([O.inverse_dynamics(blob, q[:4], z4, np.tile(np.eye(plan.nv)[k], (4, 1))) - c0 for k in range(plan.nv)], axis=2)
+        errs["H64"] = (rel(H64[:4], Href), 1e-9)
+        errs["H32"] = (rel(plan.mass_matrix(t(q[:66], torch.float32)).double().cpu().numpy(), H64), 1e-4)
+        if info.analytic_derivatives:
+            d32 = plan.fd_derivatives(t(q[:66], torch.float32), t(qd[:66], torch.float32), t(tau[:66], torch.float32))
+            d64 = plan.fd_derivatives(t(q[:66]), t(qd[:66]), t(tau[:66]))
+            errs["dtau32"] = (rel(d32["dtau"].double().cpu().numpy(), d64["dtau"].cpu().numpy()), 2e-2)
         names = [b.name for b in m.bodies]
         cand = [i for i, nm in enumerate(names) if not nm.startswith("r")]
         rng = np.random.default_rng(seed)
