@@ -211,7 +211,6 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     if (h.deriv.ok) {
         if ((e = up(h.deriv.bodies.data(), h.deriv.bodies.size() * sizeof(DerivBody), (void **)&t.deriv_bodies)) != hipSuccess)
             return hip_err(e, "plan upload");
-        if ((e = set_max_dynamic_lds_deriv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
     if (!h.deriv.related.empty() &&
         (e = up(h.deriv.related.data(), h.deriv.related.size() * sizeof(uint64_t), (void **)&t.deriv_related)) != hipSuccess)

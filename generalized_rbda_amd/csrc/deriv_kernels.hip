@@ -923,8 +923,11 @@ template hipError_t launch_spd_solve<float, double>(const float *, int, const fl
 template hipError_t launch_spd_solve<double, double>(const double *, int, const double *, const double *, double *, double *, double *,
                                                      const uint64_t *, int, size_t, int, hipStream_t);
 
-size_t spd_solve_lds_bytes(int, size_t) { return 0; }
-
-hipError_t set_max_dynamic_lds_deriv() { return hipSuccess; }
+// static LDS of one spd_solve_kernel workgroup: the factor, at the compile-time size the launch picks for nv
+size_t spd_solve_lds_bytes(int nv, size_t elem)
+{
+    const int nvb = nv <= 16 ? 16 : (nv <= 24 ? 24 : (nv <= 32 ? 32 : (nv <= 40 ? 40 : (nv <= 48 ? 48 : 64))));
+    return static_cast<size_t>(nvb) * nvb * elem;
+}
 
 }  // namespace grbda_hip

@@ -139,6 +139,5 @@ template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
                             int nv, size_t B, int grid, hipStream_t stream);
 size_t spd_solve_lds_bytes(int nv, size_t elem);
-hipError_t set_max_dynamic_lds_deriv();
 
 }  // namespace grbda_hip
