@@ -165,6 +165,26 @@ __device__ __forceinline__ void rpy_columns(const T (&Rb)[9], const T (&Tb)[9], 
     for (int a = 0; a < 6; a++) row[a] = out[a];
 }
 
+extern __shared__ __attribute__((aligned(16))) unsigned char deriv_smem[];
+
+// The 63 composites [I | B | f] a cluster hands to its parent body.  fp32: registers.  fp64: LDS, entry j of lane l at
+// [j][l] -- the fp64 kernel is far beyond its 512 registers, and what does not fit goes to scratch memory.
+template <class T, bool IN_LDS>
+struct PartStore {
+    T r[IN_LDS ? 1 : 63];
+    T *lds;  // (IN_LDS) the wave's block, already offset by the lane
+    __device__ __forceinline__ T get(int j) const
+    {
+        if constexpr (IN_LDS) return lds[j * kWave];
+        else return r[j];
+    }
+    __device__ __forceinline__ void set(int j, T v)
+    {
+        if constexpr (IN_LDS) lds[j * kWave] = v;
+        else r[j] = v;
+    }
+};
+
 template <class T, int NMAX>
 __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
                                                               const T *__restrict__ q, const T *__restrict__ qd,
@@ -309,10 +329,11 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
             }
         }
         // ---- pass 2, leaf side first ----
-        T part[63];  // what the in-cluster roots of a cluster hand to the parent body: one read-modify-write per cluster, or
+        PartStore<T, sizeof(T) == 8> part;  // what the in-cluster roots of a cluster hand to the parent body: one read-modify-write per cluster, or
                      // no memory traffic at all along chains (DerivBody::carry_out: it stays here for the next cluster)
+        part.lds = reinterpret_cast<T *>(deriv_smem) + lane;
 #pragma unroll
-        for (int j = 0; j < 63; j++) part[j] = 0;
+        for (int j = 0; j < 63; j++) part.set(j, T(0));
         for (int c = n_clusters - 1; c >= 0; c--) {
             const ClusterRec cr = load_rec(clusters + c);
             if (cr.kind == CK_FREE) {
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
             const int first_i = xf.carry_body >= 0 ? xf.carry_body - cr.first_body : -1;
             if (first_i < 0) {
 #pragma unroll
-                for (int j = 0; j < 63; j++) part[j] = 0;
+                for (int j = 0; j < 63; j++) part.set(j, T(0));
             }
 #pragma unroll
             for (int a2 = 0; a2 < NMAX; a2++) {
@@ -462,13 +483,13 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                 body_B(Ic, v, h, Bc);
                 if (step < 0) {  // the composites of the subtree arrived in registers
 #pragma unroll
-                    for (int j = 0; j < 21; j++) Ic[j] += part[j];
+                    for (int j = 0; j < 21; j++) Ic[j] += part.get(j);
 #pragma unroll
-                    for (int j = 0; j < 36; j++) Bc[j] += part[21 + j];
+                    for (int j = 0; j < 36; j++) Bc[j] += part.get(21 + j);
 #pragma unroll
-                    for (int j = 0; j < 6; j++) Fc[j] += part[57 + j];
+                    for (int j = 0; j < 6; j++) Fc[j] += part.get(57 + j);
 #pragma unroll
-                    for (int j = 0; j < 63; j++) part[j] = 0;
+                    for (int j = 0; j < 63; j++) part.set(j, T(0));
                 } else if (x.acc_row >= 0) {
                     T acc[63];
                     R.ld(x.acc_row, acc);
@@ -566,22 +587,25 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
                     R.st(xl.acc_row + 57, Fc);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 21; j++) part[j] += Ic[j];
+                    for (int j = 0; j < 21; j++) part.set(j, part.get(j) + Ic[j]);
 #pragma unroll
-                    for (int j = 0; j < 36; j++) part[21 + j] += Bc[j];
+                    for (int j = 0; j < 36; j++) part.set(21 + j, part.get(21 + j) + Bc[j]);
 #pragma unroll
-                    for (int j = 0; j < 6; j++) part[57 + j] += Fc[j];
+                    for (int j = 0; j < 6; j++) part.set(57 + j, part.get(57 + j) + Fc[j]);
                 }
             }
             if (cr.parent_body >= 0 && !xf.carry_out) {
                 const DerivBody xp = load_rec(db + cr.parent_body);
+                T out[63];
+#pragma unroll
+                for (int j = 0; j < 63; j++) out[j] = part.get(j);
                 if (!xf.cluster_acc_first) {
                     T acc[63];
                     R.ld(xp.acc_row, acc);
 #pragma unroll
-                    for (int j = 0; j < 63; j++) part[j] += acc[j];
+                    for (int j = 0; j < 63; j++) out[j] += acc[j];
                 }
-                R.st(xp.acc_row, part);
+                R.st(xp.acc_row, out);
             }
             if (live) {
 #pragma unroll
@@ -690,15 +714,16 @@ template <class T>
 hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
                              const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream)
 {
+    const size_t part_lds = sizeof(T) == 8 ? 63 * kWave * sizeof(T) : 0;  // PartStore
     if (n_max <= 1)
-        hipLaunchKernelGGL((rnea_deriv_kernel<T, 1>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq, Dqd, H,
-                           B, scratch);
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, 1>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
+                           Dqd, H, B, scratch);
     else if (n_max <= 2)
-        hipLaunchKernelGGL((rnea_deriv_kernel<T, 2>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq, Dqd, H,
-                           B, scratch);
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, 2>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
+                           Dqd, H, B, scratch);
     else
-        hipLaunchKernelGGL((rnea_deriv_kernel<T, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, db, n_clusters, n_rows, q, qd, ydd,
-                           Dq, Dqd, H, B, scratch);
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, kMaxClusterDof>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd,
+                           ydd, Dq, Dqd, H, B, scratch);
     return hipGetLastError();
 }
 template hipError_t launch_rnea_deriv<float>(const DevPlan<float> &, const DerivBody *, int, int, int, const float *, const float *,
@@ -742,7 +767,8 @@ __device__ __forceinline__ double inv_sqrt(double d)
 }
 
 template <class TIO, class TC, int NV, int KC>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(KC == 2 ? 2 : 1, KC == 2 ? 2 : 8)))
+__global__ __launch_bounds__(kWave)
+__attribute__((amdgpu_waves_per_eu((KC == 2 || (sizeof(TC) == 8 && NV <= 48)) ? 2 : 1, KC == 2 ? 2 : 8)))
 void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2,
                       const uint64_t *__restrict__ related, int nv, size_t B)
 {
@@ -844,30 +870,42 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
             }
             // (the row after the current one is in flight while this one is used; the clobbers and scheduling barriers keep
             // the compiler from hoisting every LDS read of the unrolled loop to the top, which spills)
-            TC l[NV], ln[NV];
-            factor_row(0, 0, l);
+            // (fp64: no row in flight -- the registers it would take are what keeps a second wavefront off the SIMD, and that
+            // wavefront hides the LDS latency better)
+            constexpr bool AHEAD = sizeof(TC) == 4;
+            TC l[NV], ln[AHEAD ? NV : 1];
+            if constexpr (AHEAD) factor_row(0, 0, l);
 #pragma unroll
             for (int m2 = 0; m2 < NV; m2++) {
-                factor_row(m2 + 1 < NV ? m2 + 1 : NV - 1, m2 + 1 < NV ? m2 + 1 : NV - 1, ln);
+                if constexpr (AHEAD) factor_row(m2 + 1 < NV ? m2 + 1 : NV - 1, m2 + 1 < NV ? m2 + 1 : NV - 1, ln);
+                else factor_row(m2, m2, l);
                 x[m2] *= l[m2];
 #pragma unroll
                 for (int i = m2 + 1; i < NV; i++) x[i] -= l[i] * x[m2];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (AHEAD) {
 #pragma unroll
-                for (int i = 0; i < NV; i++) l[i] = ln[i];
+                    for (int i = 0; i < NV; i++) l[i] = ln[i];
+                }
             }
 #pragma unroll
             for (int i = NV - 1; i >= 0; i--) {
-                if (i > 0) factor_row(i - 1, i - 1, ln);
+                if constexpr (AHEAD) {
+                    if (i > 0) factor_row(i - 1, i - 1, ln);
+                } else {
+                    factor_row(i, i, l);
+                }
                 XV acc = x[i];
 #pragma unroll
                 for (int m2 = i + 1; m2 < NV; m2++) acc -= l[m2] * x[m2];
                 x[i] = acc * l[i];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (AHEAD) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) l[j] = ln[j];
+                    for (int j = 0; j < NV; j++) l[j] = ln[j];
+                }
             }
 #pragma unroll
             for (int u = 0; u < KC; u++)
