@@ -84,23 +84,26 @@ def cpu_baseline(blob, q, qd, tau, budget_s=20.0, passes=5):
 
     threads = usable_cpus()
 
-    def rate(n_threads, n):
+    def rate(fn, n_threads, n):
         t0 = time.perf_counter()
-        O.forward_dynamics_mt(blob, q[:n], qd[:n], tau[:n], n_threads)
+        fn(blob, q[:n], qd[:n], tau[:n], n_threads)
         return n / max(time.perf_counter() - t0, 1e-9)
 
-    def median_rate(n_threads):
-        r = rate(n_threads, min(q.shape[0], 256 * n_threads))  # sizing pass
-        n = int(min(q.shape[0], max(64 * n_threads, r * budget_s / (2 * passes))))
-        rs = sorted(rate(n_threads, n) for _ in range(passes))
+    def median_rate(fn, n_threads, budget):
+        r = rate(fn, n_threads, min(q.shape[0], 256 * n_threads))  # sizing pass
+        n = int(min(q.shape[0], max(64 * n_threads, r * budget / (2 * passes))))
+        rs = sorted(rate(fn, n_threads, n) for _ in range(passes))
         return rs[len(rs) // 2], n
 
-    single, n1 = median_rate(1)
-    multi, nm = median_rate(threads)
+    single, n1 = median_rate(O.forward_dynamics_mt, 1, budget_s)
+    multi, nm = median_rate(O.forward_dynamics_mt, threads, budget_s)
+    # the same restatement compiled in single precision (oracle/Makefile), a shorter sample
+    single32, _ = median_rate(O.forward_dynamics_mt_f32, 1, budget_s / 3)
+    multi32, _ = median_rate(O.forward_dynamics_mt_f32, threads, budget_s / 3)
     return {"value": multi, "unit": "evals/s", "cores": threads, "physical_cores": physical_cores(),
             "logical_cpus_visible": os.cpu_count(), "kind": "port",
             "single_thread": single, "per_thread_all_core": multi / threads, "scaling_over_single_thread": multi / single,
-            "passes": passes, "dtype": "f64",
+            "passes": passes, "dtype": "f64", "f32": {"value": multi32, "single_thread": single32},
             "sample": f"first {nm} ({n1} single-thread) states of the same batch, median of {passes} passes; "
                       f"oracle/ = dense 6k x 6k plain-C restatement of the reference algorithm (the parity checker)",
             "reference_chart_evals_per_s_per_core": 2.0e4,

@@ -1,7 +1,8 @@
 /*
  * grbda_oracle.c -- TEST INFRASTRUCTURE ONLY (see grbda_oracle.h).
  *
- * Dense, fp64, single-state-at-a-time restatement of the reference's cluster-ABA / RNEA.
+ * Dense, single-state-at-a-time restatement (fp64 as the parity checker; see grbda_oracle.h for the fp32 build)
+ *  of the reference's cluster-ABA / RNEA.
  * It deliberately follows the reference's *dense* formulation (6k x 6k cluster inertias,
  * X_intra / X_intra_ring matrices, GeneralizedTransform block loops), not the structured
  * per-body formulation the HIP product uses, so the two are independent derivations.
@@ -11,6 +12,8 @@
  */
 #include "grbda_oracle.h"
 #include "../include/grbda_model_desc.h"
+
+typedef grbda_real real;  /* working precision; the model description stays double (md_copy) */
 
 #include <math.h>
 #include <pthread.h>
@@ -26,34 +29,39 @@
 /* ------------------------------------------------------------------------------------------ */
 /* small dense helpers (row-major)                                                            */
 /* ------------------------------------------------------------------------------------------ */
-static void mm(const double *A, const double *B, double *C, int m, int k, int n)
+/* model-description doubles -> working precision */
+static void md_copy(real *dst, const double *src, int n)
+{
+    for (int i = 0; i < n; i++) dst[i] = (real)src[i];
+}
+static void mm(const real *A, const real *B, real *C, int m, int k, int n)
 { /* C[m x n] = A[m x k] B[k x n] */
     for (int i = 0; i < m; i++)
         for (int j = 0; j < n; j++) {
-            double s = 0;
+            real s = 0;
             for (int l = 0; l < k; l++) s += A[i * k + l] * B[l * n + j];
             C[i * n + j] = s;
         }
 }
-static void mtm(const double *A, const double *B, double *C, int m, int k, int n)
+static void mtm(const real *A, const real *B, real *C, int m, int k, int n)
 { /* C[k x n] = A^T B, A is m x k, B is m x n */
     for (int i = 0; i < k; i++)
         for (int j = 0; j < n; j++) {
-            double s = 0;
+            real s = 0;
             for (int l = 0; l < m; l++) s += A[l * k + i] * B[l * n + j];
             C[i * n + j] = s;
         }
 }
-static void m3mul(const double *A, const double *B, double *C) { mm(A, B, C, 3, 3, 3); }
-static void m3tv(const double *A, const double *v, double *o)
+static void m3mul(const real *A, const real *B, real *C) { mm(A, B, C, 3, 3, 3); }
+static void m3tv(const real *A, const real *v, real *o)
 { /* o = A^T v */
     for (int i = 0; i < 3; i++) o[i] = A[0 + i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
 }
-static void m3v(const double *A, const double *v, double *o)
+static void m3v(const real *A, const real *v, real *o)
 {
     for (int i = 0; i < 3; i++) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
 }
-static void cross3(const double *a, const double *b, double *o)
+static void cross3(const real *a, const real *b, real *o)
 {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
@@ -63,20 +71,20 @@ static void cross3(const double *a, const double *b, double *o)
 /* LU with partial pivoting, solves A X = Bm in place (A n x n, Bm n x m).  The reference uses
  * Eigen::ColPivHouseholderQR (include/grbda/Utils/Utilities.h:325-329); any backward-stable
  * solve agrees to rounding. */
-static int lu_solve(double *A, double *Bm, int n, int m)
+static int lu_solve(real *A, real *Bm, int n, int m)
 {
     for (int c = 0; c < n; c++) {
         int p = c;
-        double best = fabs(A[c * n + c]);
+        real best = fabs(A[c * n + c]);
         for (int r = c + 1; r < n; r++)
             if (fabs(A[r * n + c]) > best) { best = fabs(A[r * n + c]); p = r; }
         if (best == 0.0 || best != best) return GRBDA_ORACLE_ESINGULAR;
         if (p != c) {
-            for (int j = 0; j < n; j++) { double t = A[c * n + j]; A[c * n + j] = A[p * n + j]; A[p * n + j] = t; }
-            for (int j = 0; j < m; j++) { double t = Bm[c * m + j]; Bm[c * m + j] = Bm[p * m + j]; Bm[p * m + j] = t; }
+            for (int j = 0; j < n; j++) { real t = A[c * n + j]; A[c * n + j] = A[p * n + j]; A[p * n + j] = t; }
+            for (int j = 0; j < m; j++) { real t = Bm[c * m + j]; Bm[c * m + j] = Bm[p * m + j]; Bm[p * m + j] = t; }
         }
         for (int r = c + 1; r < n; r++) {
-            double f = A[r * n + c] / A[c * n + c];
+            real f = A[r * n + c] / A[c * n + c];
             if (f == 0.0) continue;
             for (int j = c; j < n; j++) A[r * n + j] -= f * A[c * n + j];
             for (int j = 0; j < m; j++) Bm[r * m + j] -= f * Bm[c * m + j];
@@ -84,7 +92,7 @@ static int lu_solve(double *A, double *Bm, int n, int m)
     }
     for (int c = n - 1; c >= 0; c--)
         for (int j = 0; j < m; j++) {
-            double s = Bm[c * m + j];
+            real s = Bm[c * m + j];
             for (int l = c + 1; l < n; l++) s -= A[c * n + l] * Bm[l * m + j];
             Bm[c * m + j] = s / A[c * n + c];
         }
@@ -94,7 +102,7 @@ static int lu_solve(double *A, double *Bm, int n, int m)
 /* ------------------------------------------------------------------------------------------ */
 /* spatial::Transform (src/Utils/SpatialTransforms.cpp:13-197)                                */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { double E[9]; double r[3]; } xf_t;
+typedef struct { real E[9]; real r[3]; } xf_t;
 
 static void xf_identity(xf_t *X)
 {
@@ -106,19 +114,19 @@ static void xf_mul(const xf_t *A, const xf_t *B, xf_t *C)
 {
     xf_t o;
     m3mul(A->E, B->E, o.E);
-    double t[3];
+    real t[3];
     m3tv(B->E, A->r, t);
     for (int i = 0; i < 3; i++) o.r[i] = B->r[i] + t[i];
     *C = o;
 }
 /* toMatrix (SpatialTransforms.cpp:32-40): [[E,0],[-E r^, E]] */
-static void xf_matrix(const xf_t *X, double *M)
+static void xf_matrix(const xf_t *X, real *M)
 {
-    const double *E = X->E, *r = X->r;
-    double rh[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
-    double Er[9];
+    const real *E = X->E, *r = X->r;
+    real rh[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+    real Er[9];
     m3mul(E, rh, Er);
-    memset(M, 0, 36 * sizeof(double));
+    memset(M, 0, 36 * sizeof(real));
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
             M[i * 6 + j] = E[i * 3 + j];
@@ -127,34 +135,34 @@ static void xf_matrix(const xf_t *X, double *M)
         }
 }
 /* transformMotionVector (SpatialTransforms.cpp:42-50) */
-static void xf_motion(const xf_t *X, const double *m, double *o)
+static void xf_motion(const xf_t *X, const real *m, real *o)
 {
-    double t[3], c[3];
+    real t[3], c[3];
     m3v(X->E, m, o);
     cross3(X->r, m, c);
     for (int i = 0; i < 3; i++) t[i] = m[3 + i] - c[i];
     m3v(X->E, t, o + 3);
 }
 /* inverseTransformForceVector (SpatialTransforms.cpp:73-82) */
-static void xf_inv_force(const xf_t *X, const double *f, double *o)
+static void xf_inv_force(const xf_t *X, const real *f, real *o)
 {
-    double n[3], l[3], c[3];
+    real n[3], l[3], c[3];
     m3tv(X->E, f, n);
     m3tv(X->E, f + 3, l);
     cross3(X->r, l, c);
     for (int i = 0; i < 3; i++) { o[i] = n[i] + c[i]; o[3 + i] = l[i]; }
 }
 /* transformForceVector (SpatialTransforms.cpp:62-71) */
-static void xf_force(const xf_t *X, const double *f, double *o)
+static void xf_force(const xf_t *X, const real *f, real *o)
 {
-    double c[3], t[3];
+    real c[3], t[3];
     cross3(X->r, f + 3, c);
     for (int i = 0; i < 3; i++) t[i] = f[i] - c[i];
     m3v(X->E, t, o);
     m3v(X->E, f + 3, o + 3);
 }
 /* motionCrossProduct / forceCrossProduct (include/grbda/Utils/Spatial.h:131-143,177-188) */
-static void crm(const double *a, const double *b, double *o)
+static void crm(const real *a, const real *b, real *o)
 {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
@@ -163,7 +171,7 @@ static void crm(const double *a, const double *b, double *o)
     o[4] = a[2] * b[3] - a[0] * b[5] - a[3] * b[2] + a[5] * b[0];
     o[5] = a[0] * b[4] - a[1] * b[3] + a[3] * b[1] - a[4] * b[0];
 }
-static void crf(const double *a, const double *b, double *o)
+static void crf(const real *a, const real *b, real *o)
 {
     o[0] = b[2] * a[1] - b[1] * a[2] - b[4] * a[5] + b[5] * a[4];
     o[1] = b[0] * a[2] - b[2] * a[0] + b[3] * a[5] - b[5] * a[3];
@@ -173,11 +181,11 @@ static void crf(const double *a, const double *b, double *o)
     o[5] = b[4] * a[0] - b[3] * a[1];
 }
 /* motionCrossMatrix (Spatial.h:54-66) */
-static void crm_matrix(const double *v, double *M)
+static void crm_matrix(const real *v, real *M)
 {
-    memset(M, 0, 36 * sizeof(double));
-    double w[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
-    double l[9] = {0, -v[5], v[4], v[5], 0, -v[3], -v[4], v[3], 0};
+    memset(M, 0, 36 * sizeof(real));
+    real w[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    real l[9] = {0, -v[5], v[4], v[5], 0, -v[3], -v[4], v[3], 0};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
             M[i * 6 + j] = w[i * 3 + j];
@@ -186,27 +194,27 @@ static void crm_matrix(const double *v, double *M)
         }
 }
 /* ori::coordinateRotation (include/grbda/Utils/OrientationTools.h:46-68) */
-static void coord_rotation(int axis, double th, double *R)
+static void coord_rotation(int axis, real th, real *R)
 {
-    double s = sin(th), c = cos(th);
-    if (axis == 0) { double t[9] = {1, 0, 0, 0, c, s, 0, -s, c}; memcpy(R, t, sizeof t); }
-    else if (axis == 1) { double t[9] = {c, 0, -s, 0, 1, 0, s, 0, c}; memcpy(R, t, sizeof t); }
-    else { double t[9] = {c, s, 0, -s, c, 0, 0, 0, 1}; memcpy(R, t, sizeof t); }
+    real s = sin(th), c = cos(th);
+    if (axis == 0) { real t[9] = {1, 0, 0, 0, c, s, 0, -s, c}; memcpy(R, t, sizeof t); }
+    else if (axis == 1) { real t[9] = {c, 0, -s, 0, 1, 0, s, 0, c}; memcpy(R, t, sizeof t); }
+    else { real t[9] = {c, s, 0, -s, c, 0, 0, 0, 1}; memcpy(R, t, sizeof t); }
 }
 /* ori::quaternionToRotationMatrix (OrientationTools.h:251-269): scalar first, result transposed */
-static void quat_to_rot(const double *q, double *R)
+static void quat_to_rot(const real *q, real *R)
 {
-    double e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3];
-    double M[9] = {1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2),
+    real e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3];
+    real M[9] = {1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2),
                    2 * (e1 * e2 + e0 * e3), 1 - 2 * (e1 * e1 + e3 * e3), 2 * (e2 * e3 - e0 * e1),
                    2 * (e1 * e3 - e0 * e2), 2 * (e2 * e3 + e0 * e1), 1 - 2 * (e1 * e1 + e2 * e2)};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) R[i * 3 + j] = M[j * 3 + i];
 }
 /* ori::rpyToRotMat (OrientationTools.h:121-130): Rx Ry Rz coordinate rotations */
-static void rpy_to_rot(const double *rpy, double *R)
+static void rpy_to_rot(const real *rpy, real *R)
 {
-    double Rx[9], Ry[9], Rz[9], T[9];
+    real Rx[9], Ry[9], Rz[9], T[9];
     coord_rotation(0, rpy[0], Rx);
     coord_rotation(1, rpy[1], Ry);
     coord_rotation(2, rpy[2], Rz);
@@ -228,18 +236,18 @@ typedef struct {
 typedef struct {
     int k, n, dim, nsp, nsv, rows;
     /* ClusterJoints::Base state (ClusterJoint.h:33-98) */
-    double qs[MAXSP], qds[MAXD];       /* spanning position / velocity */
-    double G[MAXD * MAXN], g[MAXD];    /* nsv x n, nsv */
-    double K[MAXROWS * MAXD], kb[MAXROWS], phi[MAXROWS];
-    double S[MAXD * MAXN], vJ[MAXD], cJ[MAXD];
+    real qs[MAXSP], qds[MAXD];       /* spanning position / velocity */
+    real G[MAXD * MAXN], g[MAXD];    /* nsv x n, nsv */
+    real K[MAXROWS * MAXD], kb[MAXROWS], phi[MAXROWS];
+    real S[MAXD * MAXN], vJ[MAXD], cJ[MAXD];
     xf_t XJ[MAXK];  /* single-joint transform * Xtree */
     /* TreeNode / ClusterTreeNode state (TreeNode.h:48-74, ClusterTreeNode.h:39-55) */
     xf_t Xup[MAXK], Xa[MAXK];
     int anc_sub[MAXK]; /* sub-index (in parent cluster) of the nearest ancestor outside the cluster */
     int lam[MAXK];     /* in-cluster tree parent sub-index or -1 */
-    double v[MAXD], a[MAXD], avp[MAXD], f[MAXD], fext[MAXD];
-    double I[MAXD * MAXD], IA[MAXD * MAXD], Ia[MAXD * MAXD];
-    double pA[MAXD], U[MAXD * MAXN], DinvUT[MAXN * MAXD], u[MAXN], Dinvu[MAXN];
+    real v[MAXD], a[MAXD], avp[MAXD], f[MAXD], fext[MAXD];
+    real I[MAXD * MAXD], IA[MAXD * MAXD], Ia[MAXD * MAXD];
+    real pA[MAXD], U[MAXD * MAXN], DinvUT[MAXN * MAXD], u[MAXN], Dinvu[MAXN];
     int has_ext;
 } cws_t;
 
@@ -296,11 +304,11 @@ static int span_pos_offset(const model_t *m, const grbda_desc_cluster *cl, int i
 typedef struct {
     int n;
     int sub[MAXK];
-    double a[MAXK][3], o[MAXK][3], p[3];
+    real a[MAXK][3], o[MAXK][3], p[3];
 } chain_t;
 
 static void chain_eval(const model_t *m, const grbda_desc_cluster *cl, const int32_t *subs, int n,
-                       const double *origin /* E[9] r[3] */, const double *qs, chain_t *ch)
+                       const double *origin /* E[9] r[3] */, const real *qs, chain_t *ch)
 {
     xf_t X;
     xf_identity(&X);
@@ -309,8 +317,8 @@ static void chain_eval(const model_t *m, const grbda_desc_cluster *cl, const int
         const int sub = subs[t];
         const grbda_desc_body *b = &m->bodies[cl->first_body + sub];
         xf_t Xt, XJ, Xb;
-        memcpy(Xt.E, b->Xtree_E, sizeof Xt.E);
-        memcpy(Xt.r, b->Xtree_r, sizeof Xt.r);
+        md_copy(Xt.E, b->Xtree_E, 9);
+        md_copy(Xt.r, b->Xtree_r, 3);
         xf_identity(&XJ);
         coord_rotation(b->axis, qs[sub], XJ.E);
         xf_mul(&XJ, &Xt, &Xb);
@@ -321,18 +329,18 @@ static void chain_eval(const model_t *m, const grbda_desc_cluster *cl, const int
         for (int i = 0; i < 3; i++) { ch->o[t][i] = X.r[i]; ch->a[t][i] = X.E[b->axis * 3 + i]; }
     }
     xf_t Xo, Xf;
-    memcpy(Xo.E, origin, 9 * sizeof(double));
-    memcpy(Xo.r, origin + 9, 3 * sizeof(double));
+    md_copy(Xo.E, origin, 9);
+    md_copy(Xo.r, origin + 9, 3);
     xf_mul(&Xo, &X, &Xf);
     for (int i = 0; i < 3; i++) ch->p[i] = Xf.r[i];
 }
 
 /* d p / d q_b = a_b x (p - o_b);  d2 p / dq_b dq_c (b before c) = a_b x (a_c x (p - o_c)) */
-static void chain_accumulate(const chain_t *ch, double sign, const double *qds, double *Krow3 /* 3 x nsv */,
-                             int nsv, double *Kdqd3 /* 3 */)
+static void chain_accumulate(const chain_t *ch, real sign, const real *qds, real *Krow3 /* 3 x nsv */,
+                             int nsv, real *Kdqd3 /* 3 */)
 {
     for (int t = 0; t < ch->n; t++) {
-        double d[3], J[3];
+        real d[3], J[3];
         for (int i = 0; i < 3; i++) d[i] = ch->p[i] - ch->o[t][i];
         cross3(ch->a[t], d, J);
         for (int i = 0; i < 3; i++) Krow3[i * nsv + ch->sub[t]] += sign * J[i];
@@ -341,11 +349,11 @@ static void chain_accumulate(const chain_t *ch, double sign, const double *qds, 
     for (int b = 0; b < ch->n; b++)
         for (int c = 0; c < ch->n; c++) {
             const int lo = b < c ? b : c, hi = b < c ? c : b;
-            double d[3], t1[3], t2[3];
+            real d[3], t1[3], t2[3];
             for (int i = 0; i < 3; i++) d[i] = ch->p[i] - ch->o[hi][i];
             cross3(ch->a[hi], d, t1);
             cross3(ch->a[lo], t1, t2);
-            const double w = qds[ch->sub[b]] * qds[ch->sub[c]];
+            const real w = qds[ch->sub[b]] * qds[ch->sub[c]];
             for (int i = 0; i < 3; i++) Kdqd3[i] += sign * w * t2[i];
         }
 }
@@ -356,45 +364,45 @@ static void chain_accumulate(const chain_t *ch, double sign, const double *qds, 
  * knee-ankle differentials (src/Robots/Tello.cpp:139-163,237-261); the reference obtains
  * K = dphi/dq and Kdot via CasADi (GenericJoint.cpp:51-64), here they are differentiated
  * analytically.  K_dot*qd is the second directional derivative of phi along qd. */
-static void trig_f(int type, double a, double *f0, double *f1, double *f2)
+static void trig_f(int type, real a, real *f0, real *f1, real *f2)
 {
     if (type == 1) { *f0 = sin(a); *f1 = cos(a); *f2 = -sin(a); }
     else if (type == 2) { *f0 = cos(a); *f1 = -sin(a); *f2 = -cos(a); }
     else { *f0 = a; *f1 = 1.0; *f2 = 0.0; }
 }
-static int trigpoly_eval(const int32_t *ip, const double *dp, int nsp, int rows, const double *q,
-                         const double *qd, double *K, double *Kdqd, double *phi)
+static int trigpoly_eval(const int32_t *ip, const double *dp, int nsp, int rows, const real *q,
+                         const real *qd, real *K, real *Kdqd, real *phi)
 {
     for (int r = 0; r < rows; r++) {
         const int nt = *ip++;
-        double ph = 0, kd = 0;
+        real ph = 0, kd = 0;
         if (K) for (int j = 0; j < nsp; j++) K[r * nsp + j] = 0;
         for (int t = 0; t < nt; t++) {
             const int nf = *ip++;
             if (nf > 8) return GRBDA_ORACLE_EUNSUPPORTED;
-            const double coef = *dp++;
-            double f0[8], f1[8], f2[8], ad[8];
+            const real coef = (real)*dp++;
+            real f0[8], f1[8], f2[8], ad[8];
             const double *wv[8];
             for (int f = 0; f < nf; f++) {
                 const int type = *ip++;
                 wv[f] = dp;
-                double a = dp[nsp], d = 0;
-                for (int j = 0; j < nsp; j++) { a += dp[j] * q[j]; if (qd) d += dp[j] * qd[j]; }
+                real a = (real)dp[nsp], d = 0;
+                for (int j = 0; j < nsp; j++) { a += (real)dp[j] * q[j]; if (qd) d += (real)dp[j] * qd[j]; }
                 dp += nsp + 1;
                 ad[f] = d;
                 trig_f(type, a, &f0[f], &f1[f], &f2[f]);
             }
-            double prod = coef;
+            real prod = coef;
             for (int f = 0; f < nf; f++) prod *= f0[f];
             ph += prod;
             for (int f = 0; f < nf; f++) {
-                double others = coef;
+                real others = coef;
                 for (int g = 0; g < nf; g++) if (g != f) others *= f0[g];
-                if (K) for (int j = 0; j < nsp; j++) K[r * nsp + j] += others * f1[f] * wv[f][j];
+                if (K) for (int j = 0; j < nsp; j++) K[r * nsp + j] += others * f1[f] * (real)wv[f][j];
                 kd += others * f2[f] * ad[f] * ad[f];
                 for (int g = 0; g < nf; g++) {
                     if (g == f) continue;
-                    double rest = coef;
+                    real rest = coef;
                     for (int h = 0; h < nf; h++) if (h != f && h != g) rest *= f0[h];
                     kd += rest * f1[f] * ad[f] * f1[g] * ad[g];
                 }
@@ -409,15 +417,15 @@ static int trigpoly_eval(const int32_t *ip, const double *dp, int nsp, int rows,
 /* LoopConstraint evaluation: fills G, g (and K, k, phi) for cluster c given the cluster's
  * input coordinates.  y = positions as given to the model (independent for explicit kinds,
  * spanning for implicit kinds), yd = independent velocities. */
-static int constraint_eval(const model_t *m, int c, const double *y, const double *yd, cws_t *w)
+static int constraint_eval(const model_t *m, int c, const real *y, const real *yd, cws_t *w)
 {
     const grbda_desc_cluster *cl = &m->clusters[c];
     const int n = cl->n_vel, nsv = cl->n_span_vel, nsp = cl->n_span_pos;
     w->rows = cl->n_constraint_rows;
-    memset(w->g, 0, sizeof(double) * (size_t)nsv);
+    memset(w->g, 0, sizeof(real) * (size_t)nsv);
     memset(w->kb, 0, sizeof w->kb);
     memset(w->phi, 0, sizeof w->phi);
-    memset(w->K, 0, sizeof(double) * (size_t)(MAXROWS * MAXD));
+    memset(w->K, 0, sizeof(real) * (size_t)(MAXROWS * MAXD));
 
     if (cl->constraint_type == GRBDA_CONSTRAINT_FREE) {
         /* ClusterJoints::Free (FreeJoint.cpp:10-36): identity */
@@ -431,11 +439,11 @@ static int constraint_eval(const model_t *m, int c, const double *y, const doubl
         /* Static::gamma = G y, qd_span = G yd (LoopConstraint.cpp:38-52, ClusterJoint.cpp:22-71) */
         const double *G = m->dbls + cl->dbl_offset;
         const double *K = G + nsv * n;
-        memcpy(w->G, G, sizeof(double) * (size_t)(nsv * n));
+        md_copy(w->G, G, nsv * n);
         for (int r = 0; r < cl->n_constraint_rows; r++)
             for (int j = 0; j < nsv; j++) w->K[r * nsv + j] = K[r * nsv + j];
         for (int i = 0; i < nsv; i++) {
-            double sq = 0, sv = 0;
+            real sq = 0, sv = 0;
             for (int j = 0; j < n; j++) { sq += G[i * n + j] * y[j]; sv += G[i * n + j] * yd[j]; }
             w->qs[i] = sq;
             w->qds[i] = sv;
@@ -448,7 +456,7 @@ static int constraint_eval(const model_t *m, int c, const double *y, const doubl
     const double *dp = m->dbls + cl->dbl_offset;
     const int rows = cl->n_constraint_rows;
     const int32_t *is_ind;
-    double Kdqd[MAXROWS];
+    real Kdqd[MAXROWS];
     memset(Kdqd, 0, sizeof Kdqd);
     for (int i = 0; i < nsp; i++) w->qs[i] = y[i];
 
@@ -468,7 +476,7 @@ static int constraint_eval(const model_t *m, int c, const double *y, const doubl
             chain_t cp, cs;
             chain_eval(m, cl, ps, np, dp + 24 * l, w->qs, &cp);
             chain_eval(m, cl, ss, ns, dp + 24 * l + 12, w->qs, &cs);
-            double K3[3 * MAXD];
+            real K3[3 * MAXD];
             memset(K3, 0, sizeof K3);
             chain_accumulate(&cp, +1.0, NULL, K3, nsv, NULL);
             chain_accumulate(&cs, -1.0, NULL, K3, nsv, NULL);
@@ -494,22 +502,22 @@ static int constraint_eval(const model_t *m, int c, const double *y, const doubl
         if (is_ind[i]) ind[ni++] = i; else dep[nd++] = i;
     }
     if (ni != n || nd != rows) return GRBDA_ORACLE_EBADBLOB;
-    double Kd[MAXROWS * MAXROWS], Ki[MAXROWS * MAXN];
+    real Kd[MAXROWS * MAXROWS], Ki[MAXROWS * MAXN];
     for (int r = 0; r < rows; r++) {
         for (int j = 0; j < nd; j++) Kd[r * nd + j] = w->K[r * nsv + dep[j]];
         for (int j = 0; j < ni; j++) Ki[r * ni + j] = w->K[r * nsv + ind[j]];
     }
-    double Kd1[MAXROWS * MAXROWS];
+    real Kd1[MAXROWS * MAXROWS];
     memcpy(Kd1, Kd, sizeof Kd);
     int rc = lu_solve(Kd1, Ki, nd, ni); /* Ki <- Kd^-1 Ki */
     if (rc) return rc;
-    memset(w->G, 0, sizeof(double) * (size_t)(nsv * n));
+    memset(w->G, 0, sizeof(real) * (size_t)(nsv * n));
     for (int j = 0; j < ni; j++) w->G[ind[j] * n + j] = 1.0;
     for (int r = 0; r < nd; r++)
         for (int j = 0; j < ni; j++) w->G[dep[r] * n + j] = -Ki[r * ni + j];
     /* qd_span = G yd */
     for (int i = 0; i < nsv; i++) {
-        double s = 0;
+        real s = 0;
         for (int j = 0; j < n; j++) s += w->G[i * n + j] * yd[j];
         w->qds[i] = s;
     }
@@ -528,7 +536,7 @@ static int constraint_eval(const model_t *m, int c, const double *y, const doubl
             chain_t cp, cs;
             chain_eval(m, cl, ps, np, dp + 24 * l, w->qs, &cp);
             chain_eval(m, cl, ss, ns, dp + 24 * l + 12, w->qs, &cs);
-            double K3[3 * MAXD], a3[3] = {0, 0, 0};
+            real K3[3 * MAXD], a3[3] = {0, 0, 0};
             memset(K3, 0, sizeof K3);
             chain_accumulate(&cp, +1.0, w->qds, K3, nsv, a3);
             chain_accumulate(&cs, -1.0, w->qds, K3, nsv, a3);
@@ -541,7 +549,7 @@ static int constraint_eval(const model_t *m, int c, const double *y, const doubl
     }
     for (int r = 0; r < rows; r++) w->kb[r] = -Kdqd[r];
     /* g = P [0; Kd^-1 k] (GenericJoint.cpp:85-88) */
-    double kk[MAXROWS];
+    real kk[MAXROWS];
     memcpy(kk, w->kb, sizeof kk);
     memcpy(Kd1, Kd, sizeof Kd);
     rc = lu_solve(Kd1, kk, nd, 1);
@@ -557,7 +565,7 @@ static int constraint_eval(const model_t *m, int c, const double *y, const doubl
 /* is the Generic formula (src/Dynamics/ClusterJoints/GenericJoint.cpp:387-469) with a         */
 /* Static constraint; Free is FreeJoint.cpp:28-46.                                             */
 /* ------------------------------------------------------------------------------------------ */
-static int cluster_kinematics(const model_t *m, int c, const double *q, const double *qd, cws_t *w)
+static int cluster_kinematics(const model_t *m, int c, const real *q, const real *qd, cws_t *w)
 {
     const grbda_desc_cluster *cl = &m->clusters[c];
     const int k = cl->n_bodies, n = cl->n_vel, nsv = cl->n_span_vel, dim = 6 * k;
@@ -567,13 +575,13 @@ static int cluster_kinematics(const model_t *m, int c, const double *q, const do
     if (rc) return rc;
 
     /* single joints (include/grbda/Dynamics/Joints/Joint.h:61-68,95-98) */
-    double S_span[MAXD * MAXD];
-    memset(S_span, 0, sizeof(double) * (size_t)(dim * nsv));
+    real S_span[MAXD * MAXD];
+    memset(S_span, 0, sizeof(real) * (size_t)(dim * nsv));
     for (int i = 0; i < k; i++) {
         const grbda_desc_body *b = &m->bodies[cl->first_body + i];
         xf_t XJ, Xt;
-        memcpy(Xt.E, b->Xtree_E, sizeof Xt.E);
-        memcpy(Xt.r, b->Xtree_r, sizeof Xt.r);
+        md_copy(Xt.E, b->Xtree_E, 9);
+        md_copy(Xt.r, b->Xtree_r, 3);
         xf_identity(&XJ);
         const int so = span_vel_offset(m, cl, i), po = span_pos_offset(m, cl, i);
         if (b->joint_type == GRBDA_JOINT_FREE) {
@@ -601,15 +609,15 @@ static int cluster_kinematics(const model_t *m, int c, const double *q, const do
         else w->Xup[i] = w->XJ[i];
     }
     /* X_intra (GenericJoint.cpp:406-424) */
-    double X_intra[MAXD * MAXD], X_ring[MAXD * MAXD];
-    memset(X_intra, 0, sizeof(double) * (size_t)(dim * dim));
-    memset(X_ring, 0, sizeof(double) * (size_t)(dim * dim));
+    real X_intra[MAXD * MAXD], X_ring[MAXD * MAXD];
+    memset(X_intra, 0, sizeof(real) * (size_t)(dim * dim));
+    memset(X_ring, 0, sizeof(real) * (size_t)(dim * dim));
     for (int i = 0; i < dim; i++) X_intra[i * dim + i] = 1.0;
     for (int i = 0; i < k; i++) {
         int kk = i;
         int j = w->lam[i];
         while (j >= 0) {
-            double prev[36], Xint[36], prod[36];
+            real prev[36], Xint[36], prod[36];
             for (int r = 0; r < 6; r++)
                 for (int cc = 0; cc < 6; cc++) prev[r * 6 + cc] = X_intra[(6 * i + r) * dim + 6 * kk + cc];
             xf_matrix(&w->XJ[kk], Xint);
@@ -621,7 +629,7 @@ static int cluster_kinematics(const model_t *m, int c, const double *q, const do
         }
     }
     /* S = X_intra S_span G ; vJ = X_intra S_span qd (GenericJoint.cpp:426-428) */
-    double S_impl[MAXD * MAXD];
+    real S_impl[MAXD * MAXD];
     mm(X_intra, S_span, S_impl, dim, dim, nsv);
     mm(S_impl, w->G, w->S, dim, nsv, n);
     mm(S_impl, w->qds, w->vJ, dim, nsv, 1);
@@ -629,7 +637,7 @@ static int cluster_kinematics(const model_t *m, int c, const double *q, const do
     for (int i = 0; i < k; i++) {
         int j = w->lam[i];
         while (j >= 0) {
-            double Xup[36], vp[6], vrel[6], cm[36], prod[36];
+            real Xup[36], vp[6], vrel[6], cm[36], prod[36];
             for (int r = 0; r < 6; r++)
                 for (int cc = 0; cc < 6; cc++) Xup[r * 6 + cc] = X_intra[(6 * i + r) * dim + 6 * j + cc];
             mm(Xup, w->vJ + 6 * j, vp, 6, 6, 1);
@@ -642,13 +650,13 @@ static int cluster_kinematics(const model_t *m, int c, const double *q, const do
         }
     }
     /* cJ = X_ring S_span qd + S_impl g (GenericJoint.cpp:449-450) */
-    double t1[MAXD], t2[MAXD], t3[MAXD];
+    real t1[MAXD], t2[MAXD], t3[MAXD];
     mm(S_span, w->qds, t1, dim, nsv, 1);
     mm(X_ring, t1, t2, dim, dim, 1);
     mm(S_impl, w->g, t3, dim, nsv, 1);
     for (int i = 0; i < dim; i++) w->cJ[i] = t2[i] + t3[i];
     /* block-diagonal I (ClusterTreeNode.cpp:17-23) */
-    memset(w->I, 0, sizeof(double) * (size_t)(dim * dim));
+    memset(w->I, 0, sizeof(real) * (size_t)(dim * dim));
     for (int i = 0; i < k; i++) {
         const grbda_desc_body *b = &m->bodies[cl->first_body + i];
         for (int r = 0; r < 6; r++)
@@ -658,7 +666,7 @@ static int cluster_kinematics(const model_t *m, int c, const double *q, const do
 }
 
 /* TreeModel::forwardKinematics (src/Dynamics/TreeModel.cpp:6-32) */
-static int forward_kinematics(const model_t *m, const double *q, const double *qd, const double *fext,
+static int forward_kinematics(const model_t *m, const real *q, const real *qd, const real *fext,
                               cws_t *W)
 {
     for (int c = 0; c < m->h->n_clusters; c++) {
@@ -669,7 +677,7 @@ static int forward_kinematics(const model_t *m, const double *q, const double *q
         for (int i = 0; i < w->k; i++) {
             if (cl->parent_cluster >= 0) {
                 const cws_t *p = &W[cl->parent_cluster];
-                double t[6];
+                real t[6];
                 xf_motion(&w->Xup[i], p->v + 6 * w->anc_sub[i], t);
                 for (int r = 0; r < 6; r++) w->v[6 * i + r] = t[r] + w->vJ[6 * i + r];
                 xf_mul(&w->Xup[i], &p->Xa[w->anc_sub[i]], &w->Xa[i]);
@@ -694,13 +702,13 @@ static int forward_kinematics(const model_t *m, const double *q, const double *q
 
 /* GeneralizedTransform::inverseTransformSpatialInertia (SpatialTransforms.cpp:364-369,415-477):
  * M_out[p(a), p(b)] += X_a^T M[a,b] X_b */
-static void add_inverse_transformed_inertia(const cws_t *w, const double *Ia, cws_t *p)
+static void add_inverse_transformed_inertia(const cws_t *w, const real *Ia, cws_t *p)
 {
-    double Xm[MAXK][36];
+    real Xm[MAXK][36];
     for (int i = 0; i < w->k; i++) xf_matrix(&w->Xup[i], Xm[i]);
     for (int a = 0; a < w->k; a++)
         for (int b = 0; b < w->k; b++) {
-            double blk[36], t[36], o[36];
+            real blk[36], t[36], o[36];
             for (int r = 0; r < 6; r++)
                 for (int c = 0; c < 6; c++) blk[r * 6 + c] = Ia[(6 * a + r) * w->dim + 6 * b + c];
             mm(blk, Xm[b], t, 6, 6, 6);
@@ -711,17 +719,17 @@ static void add_inverse_transformed_inertia(const cws_t *w, const double *Ia, cw
         }
 }
 
-static void bias_force(const model_t *m, cws_t *w, double *out /* dim */)
+static void bias_force(const model_t *m, cws_t *w, real *out /* dim */)
 {
     /* generalForceCrossProduct(v, I v) (Spatial.h:196-215) minus external forces
      * (ClusterTreeDynamics.cpp:95-105, SpatialTransforms.cpp:234-250) */
     (void)m;
-    double Iv[MAXD];
+    real Iv[MAXD];
     mm(w->I, w->v, Iv, w->dim, w->dim, 1);
     for (int i = 0; i < w->k; i++) crf(w->v + 6 * i, Iv + 6 * i, out + 6 * i);
     if (w->has_ext)
         for (int i = 0; i < w->k; i++) {
-            double t[6];
+            real t[6];
             xf_force(&w->Xa[i], w->fext + 6 * i, t);
             for (int r = 0; r < 6; r++) out[6 * i + r] -= t[r];
         }
@@ -729,27 +737,27 @@ static void bias_force(const model_t *m, cws_t *w, double *out /* dim */)
 
 /* ClusterTreeModel::forwardDynamics + updateArticulatedBodies
  * (src/Dynamics/ClusterTreeDynamics.cpp:85-191) */
-static int aba_one(const model_t *m, const double *q, const double *qd, const double *tau,
-                   const double *fext, double *ydd, cws_t *W)
+static int aba_one(const model_t *m, const real *q, const real *qd, const real *tau,
+                   const real *fext, real *ydd, cws_t *W)
 {
     const int nc = m->h->n_clusters;
     int rc = forward_kinematics(m, q, qd, fext, W);
     if (rc) return rc;
-    for (int c = 0; c < nc; c++) memcpy(W[c].IA, W[c].I, sizeof(double) * (size_t)(W[c].dim * W[c].dim));
+    for (int c = 0; c < nc; c++) memcpy(W[c].IA, W[c].I, sizeof(real) * (size_t)(W[c].dim * W[c].dim));
     /* updateArticulatedBodies backward pass (:171-188) */
     for (int c = nc - 1; c >= 0; c--) {
         cws_t *w = &W[c];
         const int dim = w->dim, n = w->n;
-        double D[MAXN * MAXN], UT[MAXN * MAXD];
+        real D[MAXN * MAXN], UT[MAXN * MAXD];
         mm(w->IA, w->S, w->U, dim, dim, n);
         mtm(w->S, w->U, D, dim, n, n);
         for (int i = 0; i < n; i++)
             for (int j = 0; j < dim; j++) UT[i * dim + j] = w->U[j * n + i];
         rc = lu_solve(D, UT, n, dim);
         if (rc) return rc;
-        memcpy(w->DinvUT, UT, sizeof(double) * (size_t)(n * dim));
+        memcpy(w->DinvUT, UT, sizeof(real) * (size_t)(n * dim));
         if (m->clusters[c].parent_cluster >= 0) {
-            double UD[MAXD * MAXD];
+            real UD[MAXD * MAXD];
             mm(w->U, w->DinvUT, UD, dim, n, dim);
             for (int i = 0; i < dim * dim; i++) w->Ia[i] = w->IA[i] - UD[i];
             add_inverse_transformed_inertia(w, w->Ia, &W[m->clusters[c].parent_cluster]);
@@ -762,24 +770,24 @@ static int aba_one(const model_t *m, const double *q, const double *qd, const do
         cws_t *w = &W[c];
         const grbda_desc_cluster *cl = &m->clusters[c];
         const int dim = w->dim, n = w->n;
-        double STp[MAXN];
+        real STp[MAXN];
         mtm(w->S, w->pA, STp, dim, n, 1);
         for (int i = 0; i < n; i++) w->u[i] = tau[cl->v_index + i] - STp[i];
         /* D_inv_u = D^-1 u: recompute D (the reference keeps the factorisation) */
-        double D[MAXN * MAXN];
+        real D[MAXN * MAXN];
         mtm(w->S, w->U, D, dim, n, n);
-        memcpy(w->Dinvu, w->u, sizeof(double) * (size_t)n);
+        memcpy(w->Dinvu, w->u, sizeof(real) * (size_t)n);
         rc = lu_solve(D, w->Dinvu, n, 1);
         if (rc) return rc;
         if (cl->parent_cluster >= 0) {
             cws_t *p = &W[cl->parent_cluster];
-            double cv[MAXD], t1[MAXD], t2[MAXD], pa[MAXD];
+            real cv[MAXD], t1[MAXD], t2[MAXD], pa[MAXD];
             for (int i = 0; i < dim; i++) cv[i] = w->cJ[i] + w->avp[i];
             mm(w->Ia, cv, t1, dim, dim, 1);
             mm(w->U, w->Dinvu, t2, dim, n, 1);
             for (int i = 0; i < dim; i++) pa[i] = w->pA[i] + t1[i] + t2[i];
             for (int i = 0; i < w->k; i++) {
-                double t[6];
+                real t[6];
                 xf_inv_force(&w->Xup[i], pa + 6 * i, t);
                 for (int r = 0; r < 6; r++) p->pA[6 * w->anc_sub[i] + r] += t[r];
             }
@@ -790,9 +798,9 @@ static int aba_one(const model_t *m, const double *q, const double *qd, const do
         cws_t *w = &W[c];
         const grbda_desc_cluster *cl = &m->clusters[c];
         const int dim = w->dim, n = w->n;
-        double at[MAXD], t[MAXN], Sq[MAXD];
+        real at[MAXD], t[MAXN], Sq[MAXD];
         for (int i = 0; i < w->k; i++) {
-            double ap[6], x[6];
+            real ap[6], x[6];
             if (cl->parent_cluster >= 0)
                 memcpy(ap, W[cl->parent_cluster].a + 6 * w->anc_sub[i], sizeof ap);
             else
@@ -810,8 +818,8 @@ static int aba_one(const model_t *m, const double *q, const double *qd, const do
 
 /* TreeModel::forwardAccelerationKinematics + recursiveNewtonEulerAlgorithm
  * (src/Dynamics/TreeModel.cpp:34-57,173-212) */
-static int rnea_one(const model_t *m, const double *q, const double *qd, const double *ydd,
-                    const double *fext, double *tau, cws_t *W)
+static int rnea_one(const model_t *m, const real *q, const real *qd, const real *ydd,
+                    const real *fext, real *tau, cws_t *W)
 {
     const int nc = m->h->n_clusters;
     int rc = forward_kinematics(m, q, qd, fext, W);
@@ -819,10 +827,10 @@ static int rnea_one(const model_t *m, const double *q, const double *qd, const d
     for (int c = 0; c < nc; c++) {
         cws_t *w = &W[c];
         const grbda_desc_cluster *cl = &m->clusters[c];
-        double Sq[MAXD], Ia[MAXD], b[MAXD];
+        real Sq[MAXD], Ia[MAXD], b[MAXD];
         mm(w->S, ydd + cl->v_index, Sq, w->dim, w->n, 1);
         for (int i = 0; i < w->k; i++) {
-            double ap[6], x[6];
+            real ap[6], x[6];
             if (cl->parent_cluster >= 0)
                 memcpy(ap, W[cl->parent_cluster].a + 6 * w->anc_sub[i], sizeof ap);
             else
@@ -842,7 +850,7 @@ static int rnea_one(const model_t *m, const double *q, const double *qd, const d
         if (cl->parent_cluster >= 0) {
             cws_t *p = &W[cl->parent_cluster];
             for (int i = 0; i < w->k; i++) {
-                double t[6];
+                real t[6];
                 xf_inv_force(&w->Xup[i], w->f + 6 * i, t);
                 for (int r = 0; r < 6; r++) p->f[6 * w->anc_sub[i] + r] += t[r];
             }
@@ -855,8 +863,8 @@ static int rnea_one(const model_t *m, const double *q, const double *qd, const d
 /* Independent check: spanning tree CRBA + RNEA + Projection                                  */
 /* (RigidBodyTreeDynamics.cpp:86-97; TreeModel.cpp:115-171 restated per body)                 */
 /* ------------------------------------------------------------------------------------------ */
-static int projection_one(const model_t *m, const double *q, const double *qd, const double *tau,
-                          const double *fext, double *ydd, cws_t *W)
+static int projection_one(const model_t *m, const real *q, const real *qd, const real *tau,
+                          const real *fext, real *ydd, cws_t *W)
 {
     const int nb = m->h->n_bodies, nc = m->h->n_clusters, nv = m->h->nv;
     /* constraints + single-joint transforms come from the same kinematics call; everything
@@ -873,25 +881,25 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
         ns += ndof[b];
     }
     voff[nb] = ns;
-    double *H = (double *)calloc((size_t)ns * ns, sizeof(double));
-    double *C = (double *)calloc((size_t)ns, sizeof(double));
-    double *Gf = (double *)calloc((size_t)ns * nv, sizeof(double));
-    double *gf = (double *)calloc((size_t)ns, sizeof(double));
-    double *Ic = (double *)malloc(sizeof(double) * 36 * (size_t)nb);
-    double *vb = (double *)malloc(sizeof(double) * 6 * (size_t)nb);
-    double *ab = (double *)malloc(sizeof(double) * 6 * (size_t)nb);
-    double *fb = (double *)malloc(sizeof(double) * 6 * (size_t)nb);
+    real *H = (real *)calloc((size_t)ns * ns, sizeof(real));
+    real *C = (real *)calloc((size_t)ns, sizeof(real));
+    real *Gf = (real *)calloc((size_t)ns * nv, sizeof(real));
+    real *gf = (real *)calloc((size_t)ns, sizeof(real));
+    real *Ic = (real *)malloc(sizeof(real) * 36 * (size_t)nb);
+    real *vb = (real *)malloc(sizeof(real) * 6 * (size_t)nb);
+    real *ab = (real *)malloc(sizeof(real) * 6 * (size_t)nb);
+    real *fb = (real *)malloc(sizeof(real) * 6 * (size_t)nb);
     xf_t *Xb = (xf_t *)malloc(sizeof(xf_t) * (size_t)nb);
     xf_t *Xab = (xf_t *)malloc(sizeof(xf_t) * (size_t)nb);
-    double *A = (double *)malloc(sizeof(double) * (size_t)nv * nv);
-    double *rhs = (double *)malloc(sizeof(double) * (size_t)nv);
-    double *HG = (double *)malloc(sizeof(double) * (size_t)ns * nv);
-    double *tmp = (double *)malloc(sizeof(double) * (size_t)ns);
+    real *A = (real *)malloc(sizeof(real) * (size_t)nv * nv);
+    real *rhs = (real *)malloc(sizeof(real) * (size_t)nv);
+    real *HG = (real *)malloc(sizeof(real) * (size_t)ns * nv);
+    real *tmp = (real *)malloc(sizeof(real) * (size_t)ns);
     if (!H || !C || !Gf || !gf || !Ic || !vb || !ab || !fb || !Xb || !Xab || !A || !rhs || !HG || !tmp)
         return GRBDA_ORACLE_ENOMEM;
 
     /* assemble block-diagonal G, stacked g, per-body joint velocity */
-    double *qds_b = (double *)calloc((size_t)ns, sizeof(double));
+    real *qds_b = (real *)calloc((size_t)ns, sizeof(real));
     for (int c = 0; c < nc; c++) {
         const grbda_desc_cluster *cl = &m->clusters[c];
         const cws_t *w = &W[c];
@@ -906,10 +914,10 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
     /* RNEA on the spanning tree with qdd_span = 0 -> C; body velocities */
     for (int b = 0; b < nb; b++) {
         const grbda_desc_body *bd = &m->bodies[b];
-        double vj[6] = {0, 0, 0, 0, 0, 0};
+        real vj[6] = {0, 0, 0, 0, 0, 0};
         if (bd->joint_type == GRBDA_JOINT_FREE) for (int r = 0; r < 6; r++) vj[r] = qds_b[voff[b] + r];
         else vj[bd->axis] = qds_b[voff[b]];
-        double ap[6], vp[6] = {0, 0, 0, 0, 0, 0}, x[6], cr[6];
+        real ap[6], vp[6] = {0, 0, 0, 0, 0, 0}, x[6], cr[6];
         if (bd->parent >= 0) {
             memcpy(ap, ab + 6 * bd->parent, sizeof ap);
             memcpy(vp, vb + 6 * bd->parent, sizeof vp);
@@ -923,24 +931,26 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
         crm(vb + 6 * b, vj, cr);
         xf_motion(&Xb[b], ap, x);
         for (int r = 0; r < 6; r++) ab[6 * b + r] = x[r] + cr[r];
-        double Ia[6], Iv[6], cf[6];
-        mm(bd->inertia, ab + 6 * b, Ia, 6, 6, 1);
-        mm(bd->inertia, vb + 6 * b, Iv, 6, 6, 1);
+        real Ia[6], Iv[6], cf[6];
+        real Ib[36];
+        md_copy(Ib, bd->inertia, 36);
+        mm(Ib, ab + 6 * b, Ia, 6, 6, 1);
+        mm(Ib, vb + 6 * b, Iv, 6, 6, 1);
         crf(vb + 6 * b, Iv, cf);
         for (int r = 0; r < 6; r++) fb[6 * b + r] = Ia[r] + cf[r];
         if (fext) {
-            double t[6];
+            real t[6];
             xf_force(&Xab[b], fext + 6 * (size_t)b, t);
             for (int r = 0; r < 6; r++) fb[6 * b + r] -= t[r];
         }
-        memcpy(Ic + 36 * b, bd->inertia, sizeof(double) * 36);
+        md_copy(Ic + 36 * b, bd->inertia, 36);
     }
     for (int b = nb - 1; b >= 0; b--) {
         const grbda_desc_body *bd = &m->bodies[b];
         if (bd->joint_type == GRBDA_JOINT_FREE) for (int r = 0; r < 6; r++) C[voff[b] + r] = fb[6 * b + r];
         else C[voff[b]] = fb[6 * b + bd->axis];
         if (bd->parent >= 0) {
-            double t[6];
+            real t[6];
             xf_inv_force(&Xb[b], fb + 6 * b, t);
             for (int r = 0; r < 6; r++) fb[6 * bd->parent + r] += t[r];
         }
@@ -949,7 +959,7 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
     for (int b = nb - 1; b >= 0; b--) {
         const grbda_desc_body *bd = &m->bodies[b];
         if (bd->parent >= 0) {
-            double Xm[36], t[36], o[36];
+            real Xm[36], t[36], o[36];
             xf_matrix(&Xb[b], Xm);
             mm(Ic + 36 * b, Xm, t, 6, 6, 6);
             mtm(Xm, t, o, 6, 6, 6);
@@ -959,7 +969,7 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
     for (int b = 0; b < nb; b++) {
         const grbda_desc_body *bd = &m->bodies[b];
         for (int d = 0; d < ndof[b]; d++) {
-            double s[6] = {0, 0, 0, 0, 0, 0}, F[6];
+            real s[6] = {0, 0, 0, 0, 0, 0}, F[6];
             s[bd->joint_type == GRBDA_JOINT_FREE ? d : bd->axis] = 1.0;
             mm(Ic + 36 * b, s, F, 6, 6, 1);
             /* own block */
@@ -969,7 +979,7 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
             }
             int j = b;
             while (m->bodies[j].parent >= 0) {
-                double t[6];
+                real t[6];
                 xf_inv_force(&Xb[j], F, t);
                 memcpy(F, t, sizeof F);
                 j = m->bodies[j].parent;
@@ -990,7 +1000,7 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
     mtm(Gf, tmp, rhs, ns, nv, 1);
     for (int i = 0; i < nv; i++) rhs[i] = tau[i] - rhs[i];
     rc = lu_solve(A, rhs, nv, 1);
-    if (!rc) memcpy(ydd, rhs, sizeof(double) * (size_t)nv);
+    if (!rc) memcpy(ydd, rhs, sizeof(real) * (size_t)nv);
     free(voff); free(ndof); free(H); free(C); free(Gf); free(gf); free(Ic); free(vb); free(ab);
     free(fb); free(Xb); free(Xab); free(A); free(rhs); free(HG); free(tmp); free(qds_b);
     return rc;
@@ -999,11 +1009,11 @@ static int projection_one(const model_t *m, const double *q, const double *qd, c
 /* ------------------------------------------------------------------------------------------ */
 /* batch drivers                                                                              */
 /* ------------------------------------------------------------------------------------------ */
-typedef int (*one_fn)(const model_t *, const double *, const double *, const double *, const double *,
-                      double *, cws_t *);
+typedef int (*one_fn)(const model_t *, const real *, const real *, const real *, const real *,
+                      real *, cws_t *);
 
-static int run_batch(const void *blob, size_t bytes, const double *q, const double *qd, const double *x,
-                     const double *fext, double *out, size_t B, one_fn fn)
+static int run_batch(const void *blob, size_t bytes, const real *q, const real *qd, const real *x,
+                     const real *fext, real *out, size_t B, one_fn fn)
 {
     model_t m;
     int rc = parse_blob(blob, bytes, &m);
@@ -1018,22 +1028,22 @@ static int run_batch(const void *blob, size_t bytes, const double *q, const doub
 }
 
 /* TreeNode::Xa_ of every body after TreeModel::forwardKinematics (TreeModel.cpp:6-32): out[B][n_bodies][12] */
-int grbda_oracle_body_poses(const void *blob, size_t bytes, const double *q, double *out, size_t B)
+int grbda_oracle_body_poses(const void *blob, size_t bytes, const real *q, real *out, size_t B)
 {
     model_t m;
     int rc = parse_blob(blob, bytes, &m);
     if (rc) return rc;
     cws_t *W = (cws_t *)malloc(sizeof(cws_t) * (size_t)m.h->n_clusters);
-    double *zero = (double *)calloc((size_t)m.h->nv, sizeof(double));
+    real *zero = (real *)calloc((size_t)m.h->nv, sizeof(real));
     if (!W || !zero) { free(W); free(zero); return GRBDA_ORACLE_ENOMEM; }
     const int nq = m.h->nq, nb = m.h->n_bodies;
     for (size_t s = 0; s < B && !rc; s++) {
         rc = forward_kinematics(&m, q + s * nq, zero, NULL, W);
         for (int c = 0; c < m.h->n_clusters && !rc; c++)
             for (int i = 0; i < W[c].k; i++) {
-                double *o = out + (s * (size_t)nb + (size_t)(m.clusters[c].first_body + i)) * 12;
-                memcpy(o, W[c].Xa[i].E, sizeof(double) * 9);
-                memcpy(o + 9, W[c].Xa[i].r, sizeof(double) * 3);
+                real *o = out + (s * (size_t)nb + (size_t)(m.clusters[c].first_body + i)) * 12;
+                memcpy(o, W[c].Xa[i].E, sizeof(real) * 9);
+                memcpy(o + 9, W[c].Xa[i].r, sizeof(real) * 3);
             }
     }
     free(W);
@@ -1041,25 +1051,25 @@ int grbda_oracle_body_poses(const void *blob, size_t bytes, const double *q, dou
     return rc;
 }
 
-int grbda_oracle_forward_dynamics(const void *blob, size_t bytes, const double *q, const double *qd,
-                                  const double *tau, const double *f_ext, double *ydd, size_t B)
+int grbda_oracle_forward_dynamics(const void *blob, size_t bytes, const real *q, const real *qd,
+                                  const real *tau, const real *f_ext, real *ydd, size_t B)
 {
     return run_batch(blob, bytes, q, qd, tau, f_ext, ydd, B, aba_one);
 }
-int grbda_oracle_inverse_dynamics(const void *blob, size_t bytes, const double *q, const double *qd,
-                                  const double *ydd, const double *f_ext, double *tau, size_t B)
+int grbda_oracle_inverse_dynamics(const void *blob, size_t bytes, const real *q, const real *qd,
+                                  const real *ydd, const real *f_ext, real *tau, size_t B)
 {
     return run_batch(blob, bytes, q, qd, ydd, f_ext, tau, B, rnea_one);
 }
-int grbda_oracle_forward_dynamics_projection(const void *blob, size_t bytes, const double *q,
-                                             const double *qd, const double *tau,
-                                             const double *f_ext, double *ydd, size_t B)
+int grbda_oracle_forward_dynamics_projection(const void *blob, size_t bytes, const real *q,
+                                             const real *qd, const real *tau,
+                                             const real *f_ext, real *ydd, size_t B)
 {
     return run_batch(blob, bytes, q, qd, tau, f_ext, ydd, B, projection_one);
 }
 
 typedef struct {
-    const void *blob; size_t bytes; const double *q, *qd, *tau; double *ydd; size_t lo, hi; int nq, nv, rc;
+    const void *blob; size_t bytes; const real *q, *qd, *tau; real *ydd; size_t lo, hi; int nq, nv, rc;
 } mt_arg_t;
 static void *mt_worker(void *p)
 {
@@ -1069,8 +1079,8 @@ static void *mt_worker(void *p)
                                           a->hi - a->lo);
     return NULL;
 }
-int grbda_oracle_forward_dynamics_mt(const void *blob, size_t bytes, const double *q,
-                                     const double *qd, const double *tau, double *ydd, size_t B,
+int grbda_oracle_forward_dynamics_mt(const void *blob, size_t bytes, const real *q,
+                                     const real *qd, const real *tau, real *ydd, size_t B,
                                      int n_threads)
 {
     model_t m;
@@ -1093,9 +1103,9 @@ int grbda_oracle_forward_dynamics_mt(const void *blob, size_t bytes, const doubl
     return rc;
 }
 
-int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster, const double *q,
-                                    const double *qd, double *G, double *g, double *K, double *k,
-                                    double *phi)
+int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster, const real *q,
+                                    const real *qd, real *G, real *g, real *K, real *k,
+                                    real *phi)
 {
     model_t m;
     int rc = parse_blob(blob, bytes, &m);
@@ -1107,17 +1117,17 @@ int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster,
     rc = constraint_eval(&m, cluster, q + cl->q_index, qd + cl->v_index, w);
     if (!rc) {
         const int nsv = cl->n_span_vel, n = cl->n_vel, rows = cl->n_constraint_rows;
-        if (G) memcpy(G, w->G, sizeof(double) * (size_t)(nsv * n));
-        if (g) memcpy(g, w->g, sizeof(double) * (size_t)nsv);
-        if (K) for (int r = 0; r < rows; r++) memcpy(K + r * nsv, w->K + r * nsv, sizeof(double) * (size_t)nsv);
-        if (k) memcpy(k, w->kb, sizeof(double) * (size_t)rows);
-        if (phi) memcpy(phi, w->phi, sizeof(double) * (size_t)rows);
+        if (G) memcpy(G, w->G, sizeof(real) * (size_t)(nsv * n));
+        if (g) memcpy(g, w->g, sizeof(real) * (size_t)nsv);
+        if (K) for (int r = 0; r < rows; r++) memcpy(K + r * nsv, w->K + r * nsv, sizeof(real) * (size_t)nsv);
+        if (k) memcpy(k, w->kb, sizeof(real) * (size_t)rows);
+        if (phi) memcpy(phi, w->phi, sizeof(real) * (size_t)rows);
     }
     free(w);
     return rc;
 }
 
-int grbda_oracle_project_positions(const void *blob, size_t bytes, double *q, size_t B,
+int grbda_oracle_project_positions(const void *blob, size_t bytes, real *q, size_t B,
                                    int max_iter, int *ok)
 {
     model_t m;
@@ -1125,7 +1135,7 @@ int grbda_oracle_project_positions(const void *blob, size_t bytes, double *q, si
     if (rc) return rc;
     cws_t *w = (cws_t *)malloc(sizeof(cws_t));
     if (!w) return GRBDA_ORACLE_ENOMEM;
-    double zeros[MAXN] = {0};
+    real zeros[MAXN] = {0};
     for (size_t s = 0; s < B; s++) {
         int good = 1;
         for (int c = 0; c < m.h->n_clusters; c++) {
@@ -1134,11 +1144,11 @@ int grbda_oracle_project_positions(const void *blob, size_t bytes, double *q, si
                 continue;
             const int32_t *ip = m.ints + cl->int_offset;
             const int32_t *is_ind = cl->constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION ? ip + 1 : ip;
-            double *y = q + s * m.h->nq + cl->q_index;
+            real *y = q + s * m.h->nq + cl->q_index;
             const int nsv = cl->n_span_vel, rows = cl->n_constraint_rows;
             int dep[MAXD], nd = 0;
             for (int i = 0; i < nsv; i++) if (!is_ind[i]) dep[nd++] = i;
-            double nrm = 1e30;
+            real nrm = 1e30;
             for (int it = 0; it <= max_iter; it++) {
                 rc = constraint_eval(&m, c, y, zeros, w);
                 if (rc == GRBDA_ORACLE_ESINGULAR) { rc = 0; break; }
@@ -1147,7 +1157,7 @@ int grbda_oracle_project_positions(const void *blob, size_t bytes, double *q, si
                 for (int r = 0; r < rows; r++) nrm += w->phi[r] * w->phi[r];
                 nrm = sqrt(nrm);
                 if (nrm < 1e-12 || it == max_iter) break;
-                double Kd[MAXROWS * MAXROWS], dq[MAXROWS];
+                real Kd[MAXROWS * MAXROWS], dq[MAXROWS];
                 for (int r = 0; r < rows; r++) {
                     for (int j = 0; j < nd; j++) Kd[r * nd + j] = w->K[r * nsv + dep[j]];
                     dq[r] = -w->phi[r];

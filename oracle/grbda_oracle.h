@@ -22,6 +22,14 @@
 
 #include <stddef.h>
 
+/* Scalar type of the state arrays and of all arithmetic.  double: the parity checker (the only build tests/ and smoke()
+ * use).  float (-DGRBDA_ORACLE_REAL=float, _build/libgrbda_oracle_f32.so): the same code as a single-precision CPU
+ * baseline for bench.py.  The model-description blob holds doubles in both builds. */
+#ifndef GRBDA_ORACLE_REAL
+#define GRBDA_ORACLE_REAL double
+#endif
+typedef GRBDA_ORACLE_REAL grbda_real;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -36,37 +44,37 @@ enum {
 };
 
 /* cluster ABA: ClusterTreeModel::forwardDynamics (src/Dynamics/ClusterTreeDynamics.cpp:85-191) */
-int grbda_oracle_forward_dynamics(const void *blob, size_t bytes, const double *q, const double *qd,
-                                  const double *tau, const double *f_ext, double *ydd, size_t B);
+int grbda_oracle_forward_dynamics(const void *blob, size_t bytes, const grbda_real *q, const grbda_real *qd,
+                                  const grbda_real *tau, const grbda_real *f_ext, grbda_real *ydd, size_t B);
 
 /* cluster RNEA: TreeModel::recursiveNewtonEulerAlgorithm (src/Dynamics/TreeModel.cpp:173-212) */
-int grbda_oracle_inverse_dynamics(const void *blob, size_t bytes, const double *q, const double *qd,
-                                  const double *ydd, const double *f_ext, double *tau, size_t B);
+int grbda_oracle_inverse_dynamics(const void *blob, size_t bytes, const grbda_real *q, const grbda_real *qd,
+                                  const grbda_real *ydd, const grbda_real *f_ext, grbda_real *tau, size_t B);
 
 /* independent check: spanning-tree CRBA + RNEA + Projection
  * (RigidBodyTreeDynamics.cpp:86-97, TreeModel.cpp:115-171); returns independent ydd */
-int grbda_oracle_forward_dynamics_projection(const void *blob, size_t bytes, const double *q,
-                                             const double *qd, const double *tau,
-                                             const double *f_ext, double *ydd, size_t B);
+int grbda_oracle_forward_dynamics_projection(const void *blob, size_t bytes, const grbda_real *q,
+                                             const grbda_real *qd, const grbda_real *tau,
+                                             const grbda_real *f_ext, grbda_real *ydd, size_t B);
 
 /* same algorithm as grbda_oracle_forward_dynamics, batch statically partitioned over
  * n_threads pthreads (cpu_baseline leg of bench.py) */
-int grbda_oracle_forward_dynamics_mt(const void *blob, size_t bytes, const double *q,
-                                     const double *qd, const double *tau, double *ydd, size_t B,
+int grbda_oracle_forward_dynamics_mt(const void *blob, size_t bytes, const grbda_real *q,
+                                     const grbda_real *qd, const grbda_real *tau, grbda_real *ydd, size_t B,
                                      int n_threads);
 
 /* loop-constraint quantities of cluster c for one state (tests of K G = 0, K g = k):
  * G[n_span_vel*n_vel], g[n_span_vel], K[rows*n_span_vel], k[rows], phi[rows] (any may be NULL) */
-int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster, const double *q,
-                                    const double *qd, double *G, double *g, double *K, double *k,
-                                    double *phi);
+int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster, const grbda_real *q,
+                                    const grbda_real *qd, grbda_real *G, grbda_real *g, grbda_real *K, grbda_real *k,
+                                    grbda_real *phi);
 
 /* Newton projection of the dependent spanning positions of every implicit cluster onto
  * phi(q) = 0 (GenericJoint.cpp:289-385); q is [B][nq], modified in place.
  * ok[B] (may be NULL) receives 1 when ||phi|| < 1e-8 was reached for every cluster. */
 /* absolute transforms world -> body (E 9 row-major, r 3) of every body: out[B][n_bodies][12] */
-int grbda_oracle_body_poses(const void *blob, size_t bytes, const double *q, double *out, size_t B);
-int grbda_oracle_project_positions(const void *blob, size_t bytes, double *q, size_t B,
+int grbda_oracle_body_poses(const void *blob, size_t bytes, const grbda_real *q, grbda_real *out, size_t B);
+int grbda_oracle_project_positions(const void *blob, size_t bytes, grbda_real *q, size_t B,
                                    int max_iter, int *ok);
 
 #ifdef __cplusplus

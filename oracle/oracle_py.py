@@ -76,6 +76,29 @@ def forward_dynamics_mt(blob, q, qd, tau, n_threads):
     return out
 
 
+_lib32 = None
+
+
+def forward_dynamics_mt_f32(blob, q, qd, tau, n_threads):
+    """The same restatement compiled in single precision (_build/libgrbda_oracle_f32.so): the fp32 CPU baseline of
+    bench.py.  Not a parity checker."""
+    global _lib32
+    if _lib32 is None:
+        path = os.path.join(_HERE, "_build", "libgrbda_oracle_f32.so")
+        if not os.path.exists(path):
+            build()
+        _lib32 = ctypes.CDLL(path)
+        _lib32.grbda_oracle_forward_dynamics_mt.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                            c_size_t, c_int]
+    q, qd, tau = (np.ascontiguousarray(a, dtype=np.float32) for a in (q, qd, tau))
+    out = np.empty_like(tau)
+    rc = _lib32.grbda_oracle_forward_dynamics_mt(blob, len(blob), q.ctypes.data, qd.ctypes.data, tau.ctypes.data,
+                                                 out.ctypes.data, q.shape[0], n_threads)
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    return out
+
+
 def cluster_constraint(blob, cluster, q, qd, nsv, n, rows):
     q, qd = _f64(q), _f64(qd)
     G, g = np.zeros((nsv, n)), np.zeros(nsv)

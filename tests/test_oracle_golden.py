@@ -66,3 +66,17 @@ def test_oracle_mt_matches_single_thread():
     blob = zoo()["tree_rotor_float"]
     q, qd, tau = valid_states(blob, 257, config_index=13)
     assert np.array_equal(O.forward_dynamics(blob, q, qd, tau), O.forward_dynamics_mt(blob, q, qd, tau, 4))
+
+
+def test_oracle_single_precision_build_tracks_the_checker():
+    """oracle/_build/libgrbda_oracle_f32.so is the same source compiled with float arithmetic: bench.py's fp32 CPU
+    baseline, never a checker.  It has to stay a valid statement of the algorithm: fp32-class agreement with the fp64
+    build on the headline model and on a model with rotors and pairs."""
+    for name in ("urdf_mit_humanoid", "tree_pair_float"):
+        blob = zoo()[name]
+        q, qd, tau = valid_states(blob, 130, config_index=19)
+        a = O.forward_dynamics_mt(blob, q, qd, tau, 2)
+        b = O.forward_dynamics_mt_f32(blob, q, qd, tau, 2).astype(np.float64)
+        assert np.isfinite(b).all()
+        err = np.abs(a - b).max(axis=1) / (1.0 + np.abs(a).max(axis=1))
+        assert np.quantile(err, 0.99) < 1e-4
