@@ -497,6 +497,28 @@ def test_fd_derivatives_analytic_against_difference_batches(name, gpu, monkeypat
         assert np.abs(a - b).max() / (1.0 + np.abs(b).max()) < TOL32, k
 
 
+@pytest.mark.parametrize("name", ["urdf_mit_humanoid", "urdf_jvrc1_humanoid"])
+def test_fd_derivatives_fp32_with_fp64_solve(name, gpu, monkeypatch):
+    """GRBDA_SOLVE_F64=1: the fp32 derivative entry points keep fp32 arrays and run the SPD solve in fp64 arithmetic
+    (spd_solve_kernel<float, double>).  Same results as the all-fp32 route to fp32 accuracy, against the fp64 route."""
+    import torch
+
+    blob = zoo()[name]
+    monkeypatch.setenv("GRBDA_SOLVE_F64", "1")
+    plan = G.Plan(blob)
+    monkeypatch.delenv("GRBDA_SOLVE_F64")
+    q, qd, tau = valid_states(blob, 70, config_index=58)
+    c32 = lambda a: a.astype(np.float32).astype(np.float64)
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    t64 = lambda a: torch.as_tensor(np.ascontiguousarray(c32(a)), dtype=torch.float64, device=gpu)
+    d32 = plan.fd_derivatives(t32(q), t32(qd), t32(tau))
+    d64 = plan.fd_derivatives(t64(q), t64(qd), t64(tau))
+    for k in ("dtau", "dqd", "dq"):
+        a, b = d32[k].double().cpu().numpy(), d64[k].cpu().numpy()
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() / (1.0 + np.abs(b).max()) < TOL32, k
+
+
 @pytest.mark.parametrize("n_clusters,seed", [(40, 31), (57, 32)])
 def test_fd_derivatives_wide_models(n_clusters, seed, gpu, monkeypatch):
     """The SPD solve is compiled for 16 / 24 / 32 / 40 / 48 / 64 coordinates; the robots of the zoo stop at 38.  Random
