@@ -45,5 +45,6 @@ def test_bench_multi_rank_path_on_one_rank(gpu):
                 "--batch", "131072")
     assert line["verified"] is True
     assert line["gather_ms"] > 0 and line["end_to_end"]["value"] > 0
-    # (the two figures come from separate timed loops of 6 steps: a sanity bound, not a measurement)
-    assert line["end_to_end"]["value"] <= line["value"] * 1.5
+    # (the two figures come from separate timed loops of 6 steps each; either can catch a stall of the box, so they are
+    # not compared -- that assertion failed once in 30 runs with the compute-only loop 5 x slower than usual)
+    assert line["value"] > 0
