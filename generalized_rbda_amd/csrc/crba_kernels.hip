@@ -251,8 +251,10 @@ template <class T>
 __global__ __launch_bounds__(kWave) void unpack_symmetric_kernel(T *__restrict__ H, const uint64_t *__restrict__ related, int nv, size_t B)
 {
     __shared__ T tri[kWave * (kWave + 1) / 2];
+    __shared__ uint64_t rel_rows[kWave];  // the masks, once per workgroup (a global load per entry otherwise)
     const int lane = threadIdx.x, nn = nv * nv, nt = nv * (nv + 1) / 2;
     const int step_r = kWave / nv, step_c = kWave % nv;
+    rel_rows[lane] = lane < nv ? related[lane] : 0;
     for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
         T *Hs = H + s * (size_t)nn;
         __syncthreads();
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(kWave) void unpack_symmetric_kernel(T *__restrict__
         int r = lane / nv, c = lane % nv;
         for (int i = lane; i < nn; i += kWave) {
             const int lo = c <= r ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r;
-            const bool rel = (related[r] >> c) & 1;
+            const bool rel = (rel_rows[r] >> c) & 1;
             Hs[i] = rel ? tri[lo] : T(0);
             r += step_r;
             c += step_c;
