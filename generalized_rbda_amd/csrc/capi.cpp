@@ -1103,9 +1103,9 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
             return rc;
         hipStream_t hs = static_cast<hipStream_t>(stream);
         hipError_t e;
-        if (t->deriv_related && sizeof(T) == 4) {
+        if (t->deriv_related) {
             // the lower triangle in packed rows (row-local stores), then unpacked in place, one wavefront per state
-            // (JVRC-1, 131 072 states: 1.27 against 1.65 ms; in f64 the two launches measured slower than the plain one)
+            // (JVRC-1, 131 072 states, f32: 1.10 against 1.65 ms for the plain layout; f64 about even)
             e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q, out, B, static_cast<T *>(scratch),
                                static_cast<int>(grid), hs, true);
             if (e != hipSuccess) return hip_err(e, "crba launch");
