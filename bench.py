@@ -13,7 +13,11 @@ replicated, so there is no data-path collective inside a step; `value` times the
 exchange the path has -- results to rank 0 over RCCL -- is measured separately: `gather_ms` for one
 blocking gather, and `end_to_end` for K steps that each gather their results, the gather of step i running
 beside the kernel of step i + 1 (two result buffers).  After the timed region a strided sample of the results is
-checked against the CPU oracle (`verified`).
+checked against the CPU oracle (`verified`: max error of the sample under the tolerance).
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (torch.distributed.run as a child
+process, before this process touches a GPU) and relays rank 0's line and the children's exit code.
+The K steps are timed `--replays` times (default 7), every repetition bracketed by barrier + synchronize; `value` is
+the MEDIAN repetition, `spread` carries min / max.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -39,6 +43,9 @@ WORKLOADS = {
     "jvrc1_humanoid": ("jvrc1_humanoid.urdf", 1048576, "f32", 4),
     # hand-built TelloWithArms (the URDF carries no constraints): implicit differentials
     "tello": ("<TelloWithArms>", 1048576, "f32", 3),
+    # BASELINE config 5's URDF+ loop clusters
+    "four_bar": ("four_bar.urdf", 1048576, "f32", 5),
+    "six_bar": ("six_bar.urdf", 1048576, "f32", 6),
 }
 
 
@@ -130,8 +137,50 @@ def verify_sample(blob, q, qd, x, out, algo, dtype_name, n=1024):
     got = out[idx].double().cpu().numpy()
     err = np.abs(got - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
     tol = 1e-3 if dtype_name == "f32" else 1e-9
-    return {"verified": bool(np.quantile(err, 0.995) < tol and np.isfinite(got).all()), "verify_states": int(idx.size),
-            "verify_max_rel_err": float(err.max()), "verify_p995_rel_err": float(np.quantile(err, 0.995)), "verify_tol": tol}
+    return {"verified": bool(err.max() < tol and np.isfinite(got).all()), "verify_states": int(idx.size),
+            "verify_max_rel_err": float(err.max()), "verify_states_over_tol": int((err >= tol).sum()), "verify_tol": tol}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children of THIS process (which has not touched
+    a GPU and does not: no torch.cuda call before or after), relay rank 0's JSON line, exit with the children's code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(f"bench: {n}-rank run failed (exit code {p.returncode}, {len(lines)} result lines)\n")
+        sys.stderr.write(p.stdout[-2000:])
+        raise SystemExit(p.returncode or 1)
+    print(lines[0])
+    raise SystemExit(0)
+
+
+def spawn_selftest():
+    """BENCH_SPAWN_SELFTEST=1 (tests/test_bench_spawn_cpu.py): the ranks only rendezvous over gloo and sum their ranks --
+    checks the self-spawn / relay plumbing where there is no GPU.  Never taken by a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    if os.environ.get("BENCH_SPAWN_SELFTEST") == "fail" and rank == world - 1:
+        raise SystemExit(3)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": t.item()}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -147,20 +196,26 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time a plain loop of K launches instead of one hipGraph replay")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's batch per GPU; strong: the workload's batch split over the GPUs")
+    ap.add_argument("--replays", type=int, default=7, help="repetitions of the K timed steps (median reported)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])  # does not return
+    if os.environ.get("BENCH_SPAWN_SELFTEST"):
+        return spawn_selftest()
 
     import numpy as np
     import torch
 
     import generalized_rbda_amd as G
-    from generalized_rbda_amd.states import random_states
+    from generalized_rbda_amd.sharding import shard_range
+    from generalized_rbda_amd.states import valid_random_states_device
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -197,8 +252,7 @@ def main():
     urdf, B, dtype_name, cfg = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
-    if args.scaling == "strong":
-        B = (B + world - 1) // world  # contiguous shards of the one batch (generalized_rbda_amd/sharding.py)
+    B_global = B if args.scaling == "strong" else B * world
     if args.dtype:
         dtype_name = args.dtype
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
@@ -211,20 +265,19 @@ def main():
     blob = plan.blob
     info = plan.info()
 
-    # synthetic inputs: reference sampling law, counter-based RNG, distinct stream per rank
-    q, qd, x = random_states(blob, B, config_index=cfg + 1000 * rank)
-    if args.workload == "tello":
-        # implicit clusters take spanning positions on the constraint manifold: Newton projection of the
-        # dependent coordinates (GenericJoint.cpp:289-385) on the device (grbda_project_positions_f64) --
-        # input generation only; states that do not converge are replaced by converged ones
-        t64 = torch.as_tensor(q, dtype=torch.float64, device=dev)
-        ok = plan.project_positions(t64).cpu().numpy()
-        q = t64.cpu().numpy()
-        good = np.flatnonzero(ok)
-        if good.size == 0:
-            raise SystemExit("no valid Tello state could be generated")
-        bad = np.flatnonzero(~ok)
-        q[bad] = q[good[np.arange(bad.size) % good.size]]
+    # Synthetic inputs: reference sampling law, counter-based RNG (generalized_rbda_amd/states.py).  Implicit clusters take
+    # spanning positions on the constraint manifold: Newton projection of the dependent coordinates (GenericJoint.cpp:289-385)
+    # on the device, then the conditioning gate of states.py; rejected states are replaced by accepted ones (input
+    # generation only, outside the timed region).
+    if args.scaling == "strong":
+        # ONE global batch, the same on every rank; this rank computes its contiguous slab (sharding.shard_range)
+        q, qd, x, n_distinct = valid_random_states_device(plan, B_global, cfg, dev)
+        lo, hi = shard_range(B_global, rank, world)
+        q, qd, x = q[lo:hi], qd[lo:hi], x[lo:hi]
+        B = hi - lo
+    else:
+        # weak: every rank owns its own B-state shard of a world * B batch, drawn from its own RNG stream
+        q, qd, x, n_distinct = valid_random_states_device(plan, B, cfg + 1000 * rank, dev)
     tq = torch.as_tensor(q, dtype=tdt, device=dev)
     tqd = torch.as_tensor(qd, dtype=tdt, device=dev)
     tx = torch.as_tensor(x, dtype=tdt, device=dev)
@@ -265,19 +318,25 @@ def main():
             sys.stderr.write(f"bench: hipGraph capture failed ({e}); timing the plain launch loop\n")
             graph = None
             torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
-            run(tq, tqd, tx, out=out)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    # R repetitions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced with MAX over the
+    # ranks; `value` is the median repetition
+    reps = []
+    for _ in range(max(1, args.replays)):
+        barrier()
+        t0 = time.perf_counter()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                run(tq, tqd, tx, out=out)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        reps.append(el)
+    elapsed = sorted(reps)[len(reps) // 2]
 
     # kernel-only duration: hipEvents on the launch stream (torch's current stream here)
     kernel_ms = plan.time_kernel(args.algo, tq, tqd, tx, out, iters=max(5, min(args.steps, 50)))
@@ -319,13 +378,14 @@ def main():
 
     elem = 4 if dtype_name == "f32" else 8
     bytes_per_eval = (plan.nq + 3 * plan.nv) * elem  # q, qd, tau in + ydd out
-    evals_per_s = world * B * args.steps / elapsed
+    total_states = B_global if args.scaling == "strong" else world * B
+    evals_per_s = total_states * args.steps / elapsed
     kernel_evals_per_s = B / (kernel_ms * 1e-3)
     achieved_gbs = kernel_evals_per_s * bytes_per_eval / 1e9
     flops = info.flops_aba if args.algo == "aba" else info.flops_rnea
     # measured HBM-side traffic of the same launch configuration, if a PMC run is committed (profiles/)
     traffic, traffic_src = None, None
-    for fname in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for fname in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fname)) as f:
                 for e in json.load(f)["entries"]:
@@ -334,6 +394,16 @@ def main():
                         traffic_src = f"rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/{fname}"
         except (OSError, KeyError, ValueError):
             pass
+    # executed floating-point operations per evaluation from the committed instruction counters of the same launch
+    # configuration (2 x FMA + ADD + MUL + TRANS, x 64 lanes / batch), beside the plan compiler's operation model
+    flops_pmc, flops_pmc_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r3_pmc_flops.json")) as f:
+            for e in json.load(f)["entries"]:
+                if (e["workload"], e["algo"], e["dtype"]) == (args.workload, args.algo, dtype_name):
+                    flops_pmc, flops_pmc_src = e["flops_per_eval"], "profiles/r3_pmc_flops.json: " + e["source"]
+    except (OSError, KeyError, ValueError):
+        pass
     from generalized_rbda_amd.states import parse_clusters
 
     general = any(c[9] >= 2 for c in parse_clusters(blob)["clusters"])
@@ -361,7 +431,7 @@ def main():
         "data": "synthetic",
         "launch": launch,
         "config": {"workload": f"{urdf} cluster-{'ABA' if args.algo == 'aba' else 'RNEA'}, {B} random states per GPU",
-                   "batch_per_gpu": B, "nq": plan.nq, "nv": plan.nv, "n_bodies": plan.n_bodies,
+                   "batch_per_gpu": B, "batch_global": total_states, "nq": plan.nq, "nv": plan.nv, "n_bodies": plan.n_bodies,
                    "n_clusters": plan.n_clusters, "parallelism": f"batch-sharded x{world}, plan replicated"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -371,16 +441,25 @@ def main():
                      "kernel_ms": kernel_ms, "bytes_per_eval": bytes_per_eval,
                      "note": "`achieved`/`frac` price the ALGORITHMIC bytes as the contract asks; `frac_traffic` prices the "
                              "HBM-side bytes rocprofv3 counted; the resource that binds is VALU issue (see valu)",
-                     "valu": {"flops_per_eval": flops,
-                              "achieved_tflops": kernel_evals_per_s * flops / 1e12,
+                     "valu": {"flops_model": flops, "flops_pmc": flops_pmc, "flops_pmc_source": flops_pmc_src,
+                              "flops_per_eval": flops_pmc if flops_pmc is not None else flops,
+                              "achieved_tflops": kernel_evals_per_s * (flops_pmc if flops_pmc is not None else flops) / 1e12,
                               "peak_tflops": VALU_PEAK_TFLOPS[dtype_name],
-                              "frac": kernel_evals_per_s * flops / 1e12 / VALU_PEAK_TFLOPS[dtype_name],
-                              "attainable_tflops": VALU_ATTAINABLE_TFLOPS.get(dtype_name)}},
+                              "frac": kernel_evals_per_s * (flops_pmc if flops_pmc is not None else flops) / 1e12
+                              / VALU_PEAK_TFLOPS[dtype_name],
+                              "attainable_tflops": VALU_ATTAINABLE_TFLOPS.get(dtype_name),
+                              "note": "flops_model = the plan compiler's operation count; flops_pmc = executed, from the "
+                                      "committed SQ_INSTS_VALU_* counters; achieved_tflops / frac use flops_pmc when present"}},
+        "spread": {"replays": len(reps), "ms_per_step_min": min(reps) / max(args.steps, 1) * 1e3,
+                   "ms_per_step_median": elapsed / max(args.steps, 1) * 1e3, "ms_per_step_max": max(reps) / max(args.steps, 1) * 1e3,
+                   "value_min": total_states * args.steps / max(reps), "value_max": total_states * args.steps / min(reps)},
+        "inputs": {"distinct_states": n_distinct, "gate": "implicit clusters: max |Kd^-1 Ki| < 50 and |q_span| < 32 rad "
+                                                          "(generalized_rbda_amd/states.py)" if general else None},
     }
     line.update(verify_sample(blob, q, qd, x, out, args.algo, dtype_name))
     if gather_ms is not None:
         line["gather_ms"] = gather_ms
-        line["end_to_end"] = {"value": world * B * args.steps / e2e_elapsed, "unit": "evals/s",
+        line["end_to_end"] = {"value": total_states * args.steps / e2e_elapsed, "unit": "evals/s",
                               "ms_per_step": e2e_elapsed / args.steps * 1e3,
                               "what": "K steps, each followed by the RCCL gather of its results to rank 0; the gather of "
                                       "step i overlaps the kernel of step i + 1"}

@@ -31,6 +31,8 @@ C_ABI_SYMBOLS = [
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
     "grbda_spanning_f64", "grbda_spanning_f32", "grbda_fd_derivatives_f64", "grbda_fd_derivatives_f32",
     "grbda_mass_matrix_host_f64", "grbda_fd_derivatives_host_f64",
+    "grbda_state_input_dims", "grbda_state_to_independent_f64", "grbda_state_to_independent_f32",
+    "grbda_state_to_independent_host_f64",
 ]
 
 
@@ -118,6 +120,13 @@ def lib() -> ctypes.CDLL:
                                                                  c_double, c_int, c_void_p]
         getattr(L, "grbda_spanning_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                         c_size_t, c_int, c_void_p]
+    L.grbda_state_input_dims.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int)]
+    for sfx in ("f64", "f32"):
+        getattr(L, "grbda_state_to_independent_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                                    c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_int,
+                                                                    c_void_p]
+    L.grbda_state_to_independent_host_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_size_t, c_double, c_int]
     _lib = L
     return L
 
@@ -304,6 +313,53 @@ class Plan:
         fn = getattr(lib(), f"grbda_project_positions_{'f32' if q.dtype == torch.float32 else 'f64'}")
         _check(fn(self._h, q.data_ptr(), ok.data_ptr(), B, max_iter, tol, q.device.index or 0, c_void_p(s.cuda_stream)))
         return ok.bool()
+
+    @staticmethod
+    def _flag_bytes(flags, n):
+        if flags is None:
+            return None
+        if len(flags) != n:
+            raise ValueError(f"expected one flag per cluster ({n})")
+        return (ctypes.c_uint8 * n)(*[1 if f else 0 for f in flags])
+
+    def state_input_dims(self, pos_is_spanning=None, vel_is_spanning=None):
+        """Row widths (in_nq, in_nv) of a batch whose clusters give spanning / independent coordinates as flagged."""
+        a, b = c_int(0), c_int(0)
+        _check(lib().grbda_state_input_dims(self._h, self._flag_bytes(pos_is_spanning, self.n_clusters),
+                                            self._flag_bytes(vel_is_spanning, self.n_clusters), byref(a), byref(b)))
+        return a.value, b.value
+
+    def state_to_independent(self, q_in, qd_in=None, pos_is_spanning=None, vel_is_spanning=None, tol: float = 1e-8,
+                             want_gmax: bool = False, stream=None):
+        """ClusterTreeModel::setState(ModelState) for a batch (ClusterJoint.cpp:22-71): per-cluster spanning or independent
+        coordinates -> the engine's (q[B,nq], qd[B,nv]) plus status[B] (0 = valid; code + 256 * cluster otherwise) and,
+        optionally, cond[B, 2] = (max |K_d^-1 K_i|, max |K_d|_F |K_d^-1|_F) over the implicit clusters."""
+        import torch
+
+        self._floating(*([q_in] if qd_in is None else [q_in, qd_in]))
+        B = q_in.shape[0]
+        wq, wv = self.state_input_dims(pos_is_spanning, vel_is_spanning)
+        if q_in.shape != (B, wq) or (qd_in is not None and qd_in.shape != (B, wv)):
+            raise ValueError(f"expected q_in[B,{wq}], qd_in[B,{wv}]")
+        q_in = q_in.contiguous()
+        qd_in = None if qd_in is None else qd_in.contiguous()
+        q = torch.empty((B, self.nq), dtype=q_in.dtype, device=q_in.device)
+        qd = None if qd_in is None else torch.empty((B, self.nv), dtype=q_in.dtype, device=q_in.device)
+        status = torch.empty((B,), dtype=torch.int32, device=q_in.device)
+        gmax = torch.empty((B, 2), dtype=q_in.dtype, device=q_in.device) if want_gmax else None
+        s = torch.cuda.current_stream(q_in.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_state_to_independent_{'f32' if q_in.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, self._flag_bytes(pos_is_spanning, self.n_clusters), self._flag_bytes(vel_is_spanning, self.n_clusters),
+                  q_in.data_ptr(), None if qd_in is None else qd_in.data_ptr(), q.data_ptr(),
+                  None if qd is None else qd.data_ptr(), status.data_ptr(), None if gmax is None else gmax.data_ptr(), B, tol,
+                  q_in.device.index or 0, c_void_p(s.cuda_stream)))
+        return (q, qd, status, gmax) if want_gmax else (q, qd, status)
+
+    def constraint_gain(self, q, tol: float = 1e-8, stream=None):
+        """(gmax[B], kcond[B], status[B]) of engine-coordinate positions q[B,nq]: max |K_d^-1 K_i| and max |K_d|_F |K_d^-1|_F
+        over the implicit clusters, and the validity status of the positions (|phi| < tol)."""
+        _, _, status, cond = self.state_to_independent(q, None, None, None, tol=tol, want_gmax=True, stream=stream)
+        return cond[:, 0].contiguous(), cond[:, 1].contiguous(), status
 
     def spanning(self, q, qd, ydd, stream=None):
         """qd_span = G yd and qdd_span = G ydd + g for every body joint: two tensors [B, n_span_vel]."""

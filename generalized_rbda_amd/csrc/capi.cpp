@@ -240,6 +240,13 @@ int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, 
     std::lock_guard<std::recursive_mutex> lk(p->mu);
     Scratch &s = p->scratch[{device, stream}];
     if (s.bytes < bytes) {
+        // A stream under capture must not see hipFree / hipMalloc, and a graph captured earlier on this (device, stream)
+        // holds the slab's address: growing is refused while the stream captures (reserve with one eager call of the
+        // largest batch first, include/grbda_hip.h "Graph capture")
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return set_err(GRBDA_EINVAL, "the per-stream scratch slab would have to grow during stream capture: run the largest "
+                                         "batch once on this stream before capturing");
         if (s.ptr) {
             hipError_t e = hipFree(s.ptr);
             if (e != hipSuccess) return hip_err(e, "hipFree");
@@ -556,6 +563,53 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
     hipError_t e = launch_spanning<T>(d, p->host.n_clusters, span_count(p), q, qd, ydd, qd_span, qdd_span, B, scratch,
                                       grid, lds, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? GRBDA_OK : hip_err(e, "spanning launch");
+}
+
+// ---- state input in the reference's conventions (kernels.hip, state_kernel) ----------------------------------
+// widths of the caller's rows for the given per-cluster flags; GRBDA_ESTATE for independent positions of an implicit cluster
+int state_widths(const grbda_plan *p, const uint8_t *pos_sp, const uint8_t *vel_sp, StateFlags *F, int *in_nq, int *in_nv)
+{
+    const auto &cl = p->host.lay64.clusters;
+    if (cl.size() > static_cast<size_t>(64 * kStateFlagWords)) return set_err(GRBDA_EUNSUPPORTED, "more than 256 clusters");
+    StateFlags f{};
+    int wq = 0, wv = 0;
+    const int npos_free = p->host.ori_repr == GRBDA_ORI_QUATERNION ? 7 : 6;
+    for (size_t c = 0; c < cl.size(); c++) {
+        const ClusterRec &r = cl[c];
+        const bool ps = pos_sp ? pos_sp[c] != 0 : r.kind == CK_LOOP, vs = vel_sp ? vel_sp[c] != 0 : false;
+        if (r.kind == CK_LOOP && !ps)
+            return set_err(GRBDA_ESTATE, "cluster " + std::to_string(c) +
+                                             ": Independent positions cannot be converted to spanning positions when the constraint is implicit.");
+        if (ps) f.pos[c >> 6] |= 1ull << (c & 63);
+        if (vs) f.vel[c >> 6] |= 1ull << (c & 63);
+        wq += r.kind == CK_FREE ? npos_free : (ps ? r.k : r.n);
+        wv += r.kind == CK_FREE ? 6 : (vs ? r.k : r.n);
+    }
+    if (F) *F = f;
+    if (in_nq) *in_nq = wq;
+    if (in_nv) *in_nv = wv;
+    return GRBDA_OK;
+}
+
+template <class T>
+int state_convert(const grbda_plan *p, const uint8_t *pos_sp, const uint8_t *vel_sp, const T *q_in, const T *qd_in, T *q, T *qd,
+                  int32_t *status, T *cond, size_t B, double tol, int device, void *stream)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!q_in || (qd && !qd_in)) return set_err(GRBDA_EINVAL, "null argument");
+    StateFlags F;
+    int in_nq = 0, in_nv = 0;
+    if (int rc = state_widths(p, pos_sp, vel_sp, &F, &in_nq, &in_nv)) return rc;
+    if (B == 0) return GRBDA_OK;
+    DevPlan<T> d;
+    T *scratch = nullptr;
+    int grid = 0;
+    size_t lds = 0;
+    if (int rc = aux_setup<T>(p, B, device, stream, d, &scratch, &grid, &lds)) return rc;
+    hipError_t e = launch_state<T>(d, p->host.n_clusters, F, q_in, qd_in, in_nq, in_nv, q, qd, status, cond, B, static_cast<T>(tol),
+                                   scratch, grid, lds, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "state conversion launch");
 }
 
 // ---- contact side: body poses, test force (include/grbda_hip.h) ---------------------------------------------
@@ -1779,6 +1833,8 @@ int grbda_mass_matrix_host_f64(const grbda_plan *p, const double *q, double *H, 
     if (!p) return set_err(GRBDA_EINVAL, "null plan");
     GRBDA_CALL_SCOPE(p);
     if (!q || !H) return set_err(GRBDA_EINVAL, "null argument");
+    DeviceTables *t = nullptr;
+    if (int rc0 = ensure_device(p, device, &t)) return rc0;  // `device` current before anything is allocated on it
     const size_t nq = p->host.nq, nv = p->host.nv;
     DevBuf dq, dH;
     int rc;
@@ -1793,6 +1849,8 @@ int grbda_fd_derivatives_host_f64(const grbda_plan *p, const double *q, const do
     if (!p) return set_err(GRBDA_EINVAL, "null plan");
     GRBDA_CALL_SCOPE(p);
     if (!q || !qd || !tau) return set_err(GRBDA_EINVAL, "null argument");
+    DeviceTables *t = nullptr;
+    if (int rc0 = ensure_device(p, device, &t)) return rc0;  // `device` current before anything is allocated on it
     const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
     DevBuf bq, bqd, bt, b1, b2, b3;
     int rc;
@@ -1824,6 +1882,56 @@ int grbda_project_positions_f32(const grbda_plan *p, float *q, int32_t *ok, size
                                 int device, void *stream)
 {
     return project<float>(p, q, ok, B, max_iter, tol, device, stream);
+}
+int grbda_state_input_dims(const grbda_plan *p, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning, int *in_nq, int *in_nv)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    return state_widths(p, pos_is_spanning, vel_is_spanning, nullptr, in_nq, in_nv);
+}
+int grbda_state_to_independent_f64(const grbda_plan *p, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning, const double *q_in,
+                                   const double *qd_in, double *q, double *qd, int32_t *status, double *cond, size_t B, double tol,
+                                   int device, void *stream)
+{
+    return state_convert<double>(p, pos_is_spanning, vel_is_spanning, q_in, qd_in, q, qd, status, cond, B, tol, device, stream);
+}
+int grbda_state_to_independent_f32(const grbda_plan *p, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning, const float *q_in,
+                                   const float *qd_in, float *q, float *qd, int32_t *status, float *cond, size_t B, double tol,
+                                   int device, void *stream)
+{
+    return state_convert<float>(p, pos_is_spanning, vel_is_spanning, q_in, qd_in, q, qd, status, cond, B, tol, device, stream);
+}
+int grbda_state_to_independent_host_f64(const grbda_plan *p, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning,
+                                        const double *q_in, const double *qd_in, double *q, double *qd, size_t B, double tol, int device)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!q_in || !qd_in || !q || !qd) return set_err(GRBDA_EINVAL, "null argument");
+    int in_nq = 0, in_nv = 0;
+    if (int rc = state_widths(p, pos_is_spanning, vel_is_spanning, nullptr, &in_nq, &in_nv)) return rc;
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv;
+    DevBuf bqi, bvi, bq, bv, bs;
+    int rc;
+    if ((rc = bqi.alloc(B * in_nq * 8)) || (rc = bvi.alloc(B * in_nv * 8)) || (rc = bq.alloc(B * nq * 8)) || (rc = bv.alloc(B * nv * 8)) ||
+        (rc = bs.alloc(B * 4)) || (rc = bqi.put(q_in, B * in_nq * 8)) || (rc = bvi.put(qd_in, B * in_nv * 8)))
+        return rc;
+    if ((rc = state_convert<double>(p, pos_is_spanning, vel_is_spanning, static_cast<const double *>(bqi.p), static_cast<const double *>(bvi.p),
+                                    static_cast<double *>(bq.p), static_cast<double *>(bv.p), static_cast<int32_t *>(bs.p), nullptr, B, tol,
+                                    device, nullptr)))
+        return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    std::vector<int32_t> st(B);
+    if ((rc = bs.get(st.data(), B * 4)) || (rc = bq.get(q, B * nq * 8)) || (rc = bv.get(qd, B * nv * 8))) return rc;
+    for (size_t b = 0; b < B; b++)
+        if (st[b]) {
+            const int code = st[b] & 255, cluster = st[b] >> 8;
+            return set_err(GRBDA_ESTATE, "state " + std::to_string(b) + ", cluster " + std::to_string(cluster) + ": " +
+                                             (code == 1 ? "Spanning position is not valid" : "Spanning velocity is not valid"));
+        }
+    return GRBDA_OK;
 }
 int grbda_spanning_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, double *qd_span,
                        double *qdd_span, size_t B, int device, void *stream)

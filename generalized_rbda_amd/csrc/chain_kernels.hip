@@ -373,7 +373,11 @@ __device__ __forceinline__ void diff_constraint(const TB &P, const ChainMem<T> &
         const int as = ip[4 + 3 * i], ac = ip[5 + 3 * i], al = ip[6 + 3 * i];
         if (as >= 0 || ac >= 0) {
             T sn, cs;
+#ifdef GRBDA_EXP_DIFF_PRECISE
+            sincos_precise(a, &sn, &cs);
+#else
             sincos_t(a, &sn, &cs);
+#endif
             if (as >= 0) {
                 const T v[2] = {sn, cs};
                 M.lds_st(lds_w + as, v);
@@ -430,7 +434,13 @@ __device__ __forceinline__ void diff_constraint(const TB &P, const ChainMem<T> &
         K[r][0] = k0; K[r][1] = k1; K[r][2] = k2; K[r][3] = k3;
     }
     // Kd = K[:, links], Ki = K[:, rotors]
+#ifdef GRBDA_EXP_DIFF_DIV
+    const T idet = T(1) / (K[0][2] * K[1][3] - K[0][3] * K[1][2]);
+#elif defined(GRBDA_EXP_DIFF_F64DET)
+    const T idet = T(1.0 / ((double)K[0][2] * (double)K[1][3] - (double)K[0][3] * (double)K[1][2]));
+#else
     const T idet = rcp_t(K[0][2] * K[1][3] - K[0][3] * K[1][2]);
+#endif
     const T i00 = K[1][3] * idet, i01 = -K[0][3] * idet, i10 = -K[1][2] * idet, i11 = K[0][2] * idet;
     X[0] = -(i00 * K[0][0] + i01 * K[1][0]);
     X[1] = -(i00 * K[0][1] + i01 * K[1][1]);

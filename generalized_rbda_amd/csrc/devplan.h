@@ -35,6 +35,15 @@ hipError_t launch_rnea(const DevPlan<T> &P, const T *q, const T *qd, const T *yd
 template <class T>
 hipError_t launch_project(const DevPlan<T> &P, int n_clusters, T *q, int32_t *ok, size_t B, int max_iter, T tol,
                           T *scratch, int grid, size_t lds_bytes, hipStream_t stream);
+// bit c of pos / vel: cluster c's positions / velocities are given as SPANNING coordinates (state_kernel)
+constexpr int kStateFlagWords = 4;
+struct StateFlags {
+    uint64_t pos[kStateFlagWords], vel[kStateFlagWords];
+};
+template <class T>
+hipError_t launch_state(const DevPlan<T> &P, int n_clusters, const StateFlags &F, const T *q_in, const T *qd_in, int in_nq, int in_nv,
+                        T *q_out, T *qd_out, int32_t *status, T *gmax, size_t B, T tol, T *scratch, int grid, size_t lds_bytes,
+                        hipStream_t stream);
 template <class T>
 hipError_t launch_spanning(const DevPlan<T> &P, int n_clusters, int n_span, const T *q, const T *qd, const T *ydd,
                            T *qd_span, T *qdd_span, size_t B, T *scratch, int grid, size_t lds_bytes,

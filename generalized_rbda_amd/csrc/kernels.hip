@@ -2026,6 +2026,179 @@ __global__ __launch_bounds__(kWave, 1) void project_kernel(DevPlan<T> DP, int n_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// State input in the reference's conventions (ClusterJoints::Base::toSpanningTreeState, ClusterJoint.cpp:22-71;
+// ClusterTreeModel::setState(ModelState), ClusterTreeModel.cpp:256-276): per cluster the caller's positions and
+// velocities are either independent or SPANNING coordinates (JointCoordinate::isSpanning()).  The engine's own
+// coordinates are independent ones for explicit clusters and spanning positions for implicit ones, so:
+//   explicit, spanning positions   y = G+ q_span           (the reference keeps q_span as it is: same state)
+//   implicit, spanning positions   valid iff |phi(q)| < tol (LoopConstraint::Base::isValidSpanningPosition,
+//                                  LoopConstraint.cpp:15-19, nearZero: 2-norm, Utilities.h:124-130)
+//   spanning velocities            valid iff |K qd_span| < tol (isValidSpanningVelocity, LoopConstraint.cpp:22-26);
+//                                  yd = the independent entries (G+ qd_span for explicit clusters)
+// status[b] = 0, or (1 = "Spanning position is not valid", 2 = "Spanning velocity is not valid") + 256 * cluster for
+// the first failure in cluster order, as the reference throws.  cond[b][2] (optional), both maxima over the implicit
+// clusters: [0] = max |Kd^-1 Ki|, the entries of G that depend on the state, i.e. how strongly the constraint amplifies
+// rates; [1] = |Kd|_F |Kd^-1|_F, the condition number of the block that is inverted (large next to change points of a
+// linkage, where [0] stays finite) -- the measures behind the fp32 accuracy gate of generalized_rbda_amd/states.py.
+// Not hot: one state per lane, rows read straight from the batch arrays.
+// ---------------------------------------------------------------------------------------------
+template <class T, int N, class SL>
+__device__ __forceinline__ void state_loop_cluster(const Tables<T> &P, const SL &S, const ClusterRec &c, const T *qi,
+                                                   const T *vi, bool vel_span, T *qo, T *vo, bool wq, bool wv, T tol,
+                                                   int ci, int &st, T &gm, T &kc)
+{
+    const ImpLayout<N> lay(c.slot_imp_fwd, c.slot_imp_bwd, c.k, c.rows);
+    const int k = c.k, rows = c.rows;
+    cptr<int32_t> ip = P.cints + c.iofs;
+    const int hdr0 = ip[0], n_ind = ip[1];
+    cptr<int32_t> ind = ip + 2;
+    cptr<int32_t> dep = ip + 3 + n_ind;
+    cptr<int32_t> payload = dep + rows;
+    for (int i = 0; i < k; i++) {
+        const T v = qi[i];
+        S.st1(lay.qs + i, v);
+        if (wq) qo[i] = v;
+    }
+    for (int i = 0; i < rows * k; i++) S.st1(lay.K + i, T(0));
+    T phi[3] = {0, 0, 0}, kdq[3];
+    if (c.cons_type == 0) loop_position_K<T, N>(P, S, c, lay, payload, hdr0, phi);
+    else trig_poly_eval<T, N>(P, S, c, lay, payload, true, kdq, phi);
+    const T n2 = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
+    if (!(n2 < tol) && st == 0) st = 1 + 256 * ci;
+    if (vi) {
+        if (vel_span) {
+            T s2 = 0;
+            for (int r = 0; r < rows; r++) {
+                T sacc = 0;
+                for (int i = 0; i < k; i++) sacc += S.ld1(lay.K + r * k + i) * vi[i];
+                s2 += sacc * sacc;
+            }
+            if (!(sqrt(s2) < tol) && st == 0) st = 2 + 256 * ci;
+        }
+        for (int a = 0; a < N; a++) {
+            const T v = vi[vel_span ? ind[a] : a];
+            if (wv) vo[a] = v;
+        }
+    }
+    T Kd[3][3], Kdi[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Kd[r][j] = (r < rows && j < rows) ? S.ld1(lay.K + r * k + dep[j]) : T(r == j);
+    inv_small(rows, Kd, Kdi);
+    T f1 = 0, f2 = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (r < rows && j < rows) {
+                f1 += Kd[r][j] * Kd[r][j];
+                f2 += Kdi[r][j] * Kdi[r][j];
+            }
+    const T cn = sqrt(f1 * f2);
+    kc = (cn > kc || cn != cn) ? cn : kc;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            T x = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (r < rows && j < rows) x += Kdi[r][j] * S.ld1(lay.K + j * k + ind[a]);
+            x = fabs(x);
+            gm = (x > gm || x != x) ? x : gm;  // NaN (singular Kd) sticks
+        }
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void state_kernel(DevPlan<T> DP, int n_clusters, StateFlags F, const T *__restrict__ q_in,
+                                                         const T *__restrict__ qd_in, int in_nq, int in_nv, T *__restrict__ q_out,
+                                                         T *__restrict__ qd_out, int32_t *__restrict__ status,
+                                                         T *__restrict__ gmax, size_t B, T tol, T *__restrict__ scratch)
+{
+    const Tables<T> P = make_tables(DP);
+    const int lane = threadIdx.x;
+    Slots<T> S;
+    S.lane = lane;
+    S.glb = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave +
+            (size_t)(P.nq + 2 * P.nv) * kWave;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + lane;
+        const bool write = r < B;
+        const size_t row = write ? r : B - 1;  // lanes past the end redo the last state and write nothing
+        const T *qi = q_in + row * (size_t)in_nq;
+        const T *vi = qd_in ? qd_in + row * (size_t)in_nv : nullptr;
+        T *qo = q_out ? q_out + row * (size_t)P.nq : nullptr;
+        T *vo = qd_out ? qd_out + row * (size_t)P.nv : nullptr;
+        int st = 0;
+        T gm = 0, kc = 0;
+        for (int ci = 0; ci < n_clusters; ci++) {
+            const ClusterRec c = load_rec(P.clusters + ci);
+            const bool ps = (F.pos[ci >> 6] >> (ci & 63)) & 1, vs = (F.vel[ci >> 6] >> (ci & 63)) & 1;
+            T *qoc = qo ? qo + c.q_index : nullptr, *voc = vo ? vo + c.v_index : nullptr;
+            if (c.kind == CK_FREE) {
+                const int npos = P.ori_repr == 0 ? 7 : 6;
+                if (qoc && write)
+                    for (int j = 0; j < npos; j++) qoc[j] = qi[j];
+                if (vi && voc && write)
+                    for (int j = 0; j < 6; j++) voc[j] = vi[j];
+                qi += npos;
+                if (vi) vi += 6;
+            } else if (c.kind == CK_LOOP) {
+                const bool wq = write && qoc, wv = write && voc;
+                switch (c.n) {
+                    case 1: state_loop_cluster<T, 1>(P, S, c, qi, vi, vs, qoc, voc, wq, wv, tol, ci, st, gm, kc); break;
+                    case 2: state_loop_cluster<T, 2>(P, S, c, qi, vi, vs, qoc, voc, wq, wv, tol, ci, st, gm, kc); break;
+                    default: state_loop_cluster<T, 3>(P, S, c, qi, vi, vs, qoc, voc, wq, wv, tol, ci, st, gm, kc); break;
+                }
+                qi += c.k;
+                if (vi) vi += vs ? c.k : c.n;
+            } else {  // explicit: consts[dofs] = K (rows x k), then G+ (n x k)  (plan.cpp)
+                cptr<T> Kc = P.consts + c.dofs;
+                cptr<T> Gp = Kc + c.rows * c.k;
+                for (int a = 0; a < c.n; a++) {
+                    T y = 0;
+                    if (ps) {
+                        for (int i = 0; i < c.k; i++) y += Gp[a * c.k + i] * qi[i];
+                    } else {
+                        y = qi[a];
+                    }
+                    if (qoc && write) qoc[a] = y;
+                }
+                qi += ps ? c.k : c.n;
+                if (vi) {
+                    if (vs) {
+                        T s2 = 0;
+                        for (int rr = 0; rr < c.rows; rr++) {
+                            T sacc = 0;
+                            for (int i = 0; i < c.k; i++) sacc += Kc[rr * c.k + i] * vi[i];
+                            s2 += sacc * sacc;
+                        }
+                        if (!(sqrt(s2) < tol) && st == 0) st = 2 + 256 * ci;
+                    }
+                    for (int a = 0; a < c.n; a++) {
+                        T y = 0;
+                        if (vs) {
+                            for (int i = 0; i < c.k; i++) y += Gp[a * c.k + i] * vi[i];
+                        } else {
+                            y = vi[a];
+                        }
+                        if (voc && write) voc[a] = y;
+                    }
+                    vi += vs ? c.k : c.n;
+                }
+            }
+        }
+        if (status && write) status[r] = st;
+        if (gmax && write) {
+            gmax[2 * r] = gm;
+            gmax[2 * r + 1] = kc;
+        }
+    }
+}
+
 // Absolute transforms world -> body of every body, (E 9 row-major, r 3) per body: TreeNode::Xa_
 // (TreeModel.cpp:20-27), the input of the reference's contact-point kinematics (TreeModel.cpp:59-113).
 // The poses are composed in the plan's canonical body frames and converted to the reference's frames at the
@@ -2225,6 +2398,19 @@ hipError_t launch_project(const DevPlan<T> &P, int n_clusters, T *q, int32_t *ok
     return hipGetLastError();
 }
 template <class T>
+hipError_t launch_state(const DevPlan<T> &P, int n_clusters, const StateFlags &F, const T *q_in, const T *qd_in, int in_nq, int in_nv,
+                        T *q_out, T *qd_out, int32_t *status, T *gmax, size_t B, T tol, T *scratch, int grid, size_t lds_bytes,
+                        hipStream_t stream)
+{
+    hipLaunchKernelGGL((state_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, n_clusters, F, q_in, qd_in, in_nq, in_nv,
+                       q_out, qd_out, status, gmax, B, tol, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_state<float>(const DevPlan<float> &, int, const StateFlags &, const float *, const float *, int, int, float *,
+                                        float *, int32_t *, float *, size_t, float, float *, int, size_t, hipStream_t);
+template hipError_t launch_state<double>(const DevPlan<double> &, int, const StateFlags &, const double *, const double *, int, int,
+                                         double *, double *, int32_t *, double *, size_t, double, double *, int, size_t, hipStream_t);
+template <class T>
 hipError_t launch_spanning(const DevPlan<T> &P, int n_clusters, int n_span, const T *q, const T *qd, const T *ydd,
                            T *qd_span, T *qdd_span, size_t B, T *scratch, int grid, size_t lds_bytes,
                            hipStream_t stream)
@@ -2280,6 +2466,8 @@ hipError_t set_max_dynamic_lds()
     const int maxb = 160 * 1024;
     const void *fns[] = {reinterpret_cast<const void *>(&project_kernel<float>),
                          reinterpret_cast<const void *>(&project_kernel<double>),
+                         reinterpret_cast<const void *>(&state_kernel<float>),
+                         reinterpret_cast<const void *>(&state_kernel<double>),
                          reinterpret_cast<const void *>(&spanning_kernel<float>),
                          reinterpret_cast<const void *>(&spanning_kernel<double>),
                          reinterpret_cast<const void *>(&aba_kernel<float, false, GRBDA_ABA32_WAVES>),

@@ -258,6 +258,91 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
     }
 
+    // ---- explicit clusters: K and a left inverse of G for spanning-state input (kernels.hip, state_kernel) -------
+    // ClusterJoints::Base::toSpanningTreeState (ClusterJoint.cpp:22-71) accepts spanning positions / velocities; the
+    // engine's coordinates are the independent ones, y = G+ q_span.  consts[dofs]: K (rows x k) then G+ (n x k).  G+ picks
+    // the rows of G that are unit vectors (every cluster joint of the reference has them: link coordinates), and is the
+    // least-squares inverse (G^T G)^-1 G^T otherwise.  A description without K gets an orthonormal basis of null(G^T).
+    for (int c = 0; c < nc; c++) {
+        const grbda_desc_cluster &cl = m.clusters[c];
+        if (clusters[c].kind != CK_STATIC) continue;
+        const int k = cl.n_bodies, n = cl.n_vel, rows = k - n;
+        const double *G = m.dbls + cl.dbl_offset;
+        clusters[c].rows = rows;
+        clusters[c].dofs = static_cast<int>(P.consts.size());
+        std::vector<double> Gp(static_cast<size_t>(n) * k, 0.0);
+        bool picked = true;
+        for (int a = 0; a < n && picked; a++) {
+            int row = -1;
+            for (int i = 0; i < k && row < 0; i++) {
+                bool unit = true;
+                for (int b2 = 0; b2 < n; b2++) unit = unit && G[i * n + b2] == (b2 == a ? 1.0 : 0.0);
+                if (unit) row = i;
+            }
+            if (row < 0) picked = false;
+            else Gp[static_cast<size_t>(a) * k + row] = 1.0;
+        }
+        if (!picked) {  // (G^T G)^-1 G^T by Gauss-Jordan with partial pivoting, n <= 4
+            std::vector<double> A(static_cast<size_t>(n) * (n + k), 0.0);
+            for (int a = 0; a < n; a++) {
+                for (int b2 = 0; b2 < n; b2++)
+                    for (int i = 0; i < k; i++) A[a * (n + k) + b2] += G[i * n + a] * G[i * n + b2];
+                for (int i = 0; i < k; i++) A[a * (n + k) + n + i] = G[i * n + a];
+            }
+            for (int col = 0; col < n; col++) {
+                int piv = col;
+                for (int r = col + 1; r < n; r++)
+                    if (std::fabs(A[r * (n + k) + col]) > std::fabs(A[piv * (n + k) + col])) piv = r;
+                if (std::fabs(A[piv * (n + k) + col]) < 1e-300) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: G is rank deficient", c);
+                for (int j = 0; j < n + k; j++) std::swap(A[col * (n + k) + j], A[piv * (n + k) + j]);
+                const double d = 1.0 / A[col * (n + k) + col];
+                for (int j = 0; j < n + k; j++) A[col * (n + k) + j] *= d;
+                for (int r = 0; r < n; r++) {
+                    if (r == col) continue;
+                    const double f = A[r * (n + k) + col];
+                    for (int j = 0; j < n + k; j++) A[r * (n + k) + j] -= f * A[col * (n + k) + j];
+                }
+            }
+            for (int a = 0; a < n; a++)
+                for (int i = 0; i < k; i++) Gp[static_cast<size_t>(a) * k + i] = A[a * (n + k) + n + i];
+        }
+        if (cl.n_dbl >= k * n + rows * k && cl.n_constraint_rows == rows) {
+            const double *K = G + k * n;
+            for (int i = 0; i < rows * k; i++) P.consts.push_back(K[i]);
+        } else {  // orthonormal complement of range(G): Gram-Schmidt over the unit vectors
+            std::vector<std::vector<double>> basis;  // orthonormal
+            auto orthonormalise = [&](std::vector<double> &v) {
+                for (int pass = 0; pass < 2; pass++)
+                    for (const auto &bv : basis) {
+                        double dot = 0;
+                        for (int i = 0; i < k; i++) dot += v[i] * bv[i];
+                        for (int i = 0; i < k; i++) v[i] -= dot * bv[i];
+                    }
+                double nn = 0;
+                for (int i = 0; i < k; i++) nn += v[i] * v[i];
+                if (nn < 1e-20) return false;
+                for (int i = 0; i < k; i++) v[i] /= std::sqrt(nn);
+                return true;
+            };
+            for (int a = 0; a < n; a++) {
+                std::vector<double> v(k);
+                for (int i = 0; i < k; i++) v[i] = G[i * n + a];
+                if (orthonormalise(v)) basis.push_back(v);
+            }
+            int have = 0;
+            for (int e = 0; e < k; e++) {
+                std::vector<double> v(k, 0.0);
+                v[e] = 1.0;
+                if (!orthonormalise(v)) continue;
+                basis.push_back(v);
+                if (have < rows) for (int i = 0; i < k; i++) P.consts.push_back(v[i]);
+                have++;
+            }
+            if (have != rows) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: G is rank deficient", c);
+        }
+        P.consts.insert(P.consts.end(), Gp.begin(), Gp.end());
+    }
+
     // ---- axisymmetric leaf bodies (rotors) ------------------------------------------------------------
     // If I is invariant under rotation about the joint axis (COM on the axis, equal transverse
     // inertias) then X(q)^T I X(q), X(q)^T I s and X(q)^T (v x* I v) are independent of q: the body is

@@ -832,14 +832,32 @@ public:
 
     // ---- state (ClusterTreeModel.cpp:256-308) -----------------------------------------------------
     typedef std::pair<DVec<Scalar>, DVec<Scalar>> StatePair;
+    // One JointState per cluster, each position / velocity flagged independent or spanning
+    // (JointCoordinate::isSpanning()).  ClusterJoints::Base::toSpanningTreeState (ClusterJoint.cpp:22-71) decides per
+    // cluster what is accepted; the same rules run in the library (grbda_state_to_independent_host_f64) and invalid
+    // spanning positions / velocities throw std::runtime_error with the reference's messages.
     void setState(const ModelState<Scalar> &model_state)
     {
-        DVec<Scalar> q, qd;
-        for (const auto &js : model_state) {
+        const grbda_plan *pl = plan();
+        int nq = 0, nv = 0, nb = 0, nc = 0;
+        check(grbda_plan_dims(pl, &nq, &nv, &nb, &nc));
+        if (static_cast<int>(model_state.size()) != nc) throw std::runtime_error("model state must hold one joint state per cluster");
+        std::vector<uint8_t> ps(nc), vs(nc);
+        std::vector<double> q, qd;
+        for (int c = 0; c < nc; c++) {
+            const auto &js = model_state[c];
+            ps[c] = js.position.isSpanning();
+            vs[c] = js.velocity.isSpanning();
             q.insert(q.end(), js.position.begin(), js.position.end());
             qd.insert(qd.end(), js.velocity.begin(), js.velocity.end());
         }
-        setState(StatePair{q, qd});
+        int in_nq = 0, in_nv = 0;
+        check(grbda_state_input_dims(pl, ps.data(), vs.data(), &in_nq, &in_nv));
+        if (static_cast<int>(q.size()) != in_nq || static_cast<int>(qd.size()) != in_nv)
+            throw std::runtime_error("state has the wrong dimension");
+        std::vector<double> qo(nq), vo(nv);
+        check(grbda_state_to_independent_host_f64(pl, ps.data(), vs.data(), q.data(), qd.data(), qo.data(), vo.data(), 1, 1e-8, 0));
+        setState(StatePair{DVec<Scalar>(qo.begin(), qo.end()), DVec<Scalar>(vo.begin(), vo.end())});
     }
     void setState(const StatePair &q_qd_pair)
     {

@@ -361,3 +361,103 @@ def planar_leg_linkage() -> ClusterTreeModel:
     p1 = [.096, .042 - .011]
     m.appendTrigPolyCluster("lower-leg-cluster", "zzz", [True, False, False], four_bar_rows(p1, [p1[0]], [p1[1], 0.0]))
     return m
+
+
+# -------------------------------------------------------------------------------------------------
+# JVRC-1 humanoid, hand-built (src/Robots/JVRC1_Humanoid.cpp:6-771; parameters include/grbda/Robots/JVRC1_Humanoid.hpp:16-275).
+# Every joint of the hand-built robot is a RevoluteWithRotor cluster (gear ratio 6, one rotor design, rotor and link
+# share their tree transform, all tree rotations are the identity); robot-models/jvrc1_humanoid.urdf -- the model
+# BASELINE config 5 names -- describes the same links but gives no rotor to the neck (3 joints) and the wrists (4): 58
+# bodies against 65.  `urdf_variant=True` builds the hand-built robot WITHOUT those seven rotors and with the URDF's link
+# names, so that tests/test_urdf_vs_manual.py can pin the URDF reader's JVRC-1 (body data, coordinate order, dynamics)
+# to the values the reference's header holds.
+# -------------------------------------------------------------------------------------------------
+_JVRC1_LINK = dict(   # design: (mass, CoM, diag of the rotational inertia at the CoM)      JVRC1_Humanoid.hpp:181-269
+    pelvis=(10.0, [-0.01, 0.0, 0.034], [0.089583, 0.089583, 0.1125]),
+    hip_p=(1.0, [0.0, 0.0, 0.0], [0.00196, 0.00196, 0.00196]),
+    hip_r=(1.0, [0.0, 0.0, 0.0], [0.00196, 0.00196, 0.00196]),
+    hip_y=(3.0, [0.01, 0.0, -0.22], [0.031925, 0.034525, 0.00865]),
+    knee=(3.0, [0.04, 0.0, -0.16], [0.031925, 0.034525, 0.00865]),
+    ankle_r=(1.0, [0.0, 0.0, 0.0], [0.00064, 0.00064, 0.00064]),
+    ankle_p=(1.5, [0.03, 0.0, -0.07], [0.001417, 0.005617, 0.006217]),
+    waist_y=(1.0, [0.0, 0.0, -0.07], [0.00173, 0.00173, 0.0032]),
+    waist_p=(1.0, [0.0, 0.0, 0.0], [0.002425, 0.002425, 0.002425]),
+    waist_r=(10.0, [0.02, 0.0, 0.24], [0.157083, 0.101083, 0.1367]),
+    neck_y=(0.5, [0.0, 0.0, -0.05], [0.000729167, 0.000729167, 0.000625]),
+    neck_r=(0.5, [0.0, 0.0, 0.0], [0.0005, 0.0005, 0.0005]),
+    neck_p=(2.0, [0.01, 0.0, 0.11], [0.00968, 0.00968, 0.00968]),
+    shoulder_p=(1.0, [0.0, 0.0, 0.0], [0.00196, 0.00196, 0.00196]),
+    shoulder_r=(1.0, [0.0, 0.0, 0.0], [0.00196, 0.00196, 0.00196]),
+    shoulder_y=(2.0, [-0.01, 0.0, -0.19], [0.01365, 0.0146, 0.00635]),
+    elbow_p=(1.0, [-0.02, 0.0, -0.1], [0.010675, 0.010675, 0.0027]),
+    elbow_y=(1.0, [0.0, 0.0, 0.0], [0.00064, 0.00064, 0.00064]),
+    wrist_r=(0.5, [0.0, 0.0, 0.0], [0.00032, 0.00032, 0.00032]),
+    left_wrist_y=(0.5, [0.0, -0.01, -0.06], [0.0004625, 0.0007625, 0.0004625]),
+    right_wrist_y=(0.5, [0.0, 0.01, -0.06], [0.0004625, 0.0007625, 0.0004625]),
+)
+_JVRC1_ROTOR = (0.07, [0.0, 0.0, 0.0], [2e-5, 2e-5, 5e-5])   # JVRC1_Humanoid.hpp:176-179
+_JVRC1_POS = dict(    # tree translations p_* (all R_* are the identity)                      JVRC1_Humanoid.hpp:19-172
+    left_hip_p=[0.0, 0.096, 0.0], left_hip_r=[0.0, -2.77e-17, 0.0], left_hip_y=[0.0, -2.77e-17, 0.0],
+    left_knee=[-0.02, -2.77e-17, -0.389], left_ankle_r=[0.04, 1.52e-16, -0.357], left_ankle_p=[-4.86e-17, 3.61e-16, -2.22e-16],
+    right_hip_p=[0.0, -0.096, 0.0], right_hip_r=[0.0, 2.77e-17, 0.0], right_hip_y=[0.0, 2.77e-17, 0.0],
+    right_knee=[-0.02, 2.77e-17, -0.389], right_ankle_r=[0.04, 1.11e-16, -0.357], right_ankle_p=[-1.734e-17, -4.44e-16, -1.11e-16],
+    waist_y=[0.0, 0.0, 0.192], waist_p=[0.0, 0.0, -1.11e-16], waist_r=[0.0, 0.0, -1.11e-16],
+    neck_y=[-0.003, 0.0, 0.453], neck_r=[8.24e-18, 0.0, 2.22e-16], neck_p=[8.24e-18, 0.0, 2.22e-16],
+    left_shoulder_p=[0.0, 0.24, 0.33], left_shoulder_r=[0.0, 2.78e-17, -5.55e-16], left_shoulder_y=[0.0, 2.78e-17, -5.55e-16],
+    left_elbow_p=[0.004, -2.78e-17, -0.305], left_elbow_y=[-0.004, 3.89e-16, -0.239], left_wrist_r=[0.0, -2.78e-16, -1.8e-16],
+    left_wrist_y=[0.0, -2.78e-16, -1.8e-16],
+    right_shoulder_p=[0.0, -0.24, 0.33], right_shoulder_r=[0.0, -2.78e-17, -7.77e-16], right_shoulder_y=[0.0, -2.78e-17, -7.77e-16],
+    right_elbow_p=[0.004, 2.78e-17, -0.305], right_elbow_y=[-0.004, -5e-16, -0.239], right_wrist_r=[0.0, 2.78e-16, -1.8e-16],
+    right_wrist_y=[0.0, 2.78e-16, -1.8e-16],
+)
+# (joint, parent, axis) in the order the reference appends the clusters (JVRC1_Humanoid.cpp:22-755); {s} = left / right
+_JVRC1_TRUNK = [("waist_y", "pelvis", "z"), ("waist_p", "waist_y", "y"), ("waist_r", "waist_p", "x"),
+                ("neck_y", "waist_r", "z"), ("neck_r", "neck_y", "x"), ("neck_p", "neck_r", "y")]
+_JVRC1_LEG = [("hip_p", "pelvis", "y"), ("hip_r", "{s}_hip_p", "x"), ("hip_y", "{s}_hip_r", "z"), ("knee", "{s}_hip_y", "y"),
+              ("ankle_r", "{s}_knee", "x"), ("ankle_p", "{s}_ankle_r", "y")]
+_JVRC1_ARM = [("shoulder_p", "waist_r", "y"), ("shoulder_r", "{s}_shoulder_p", "x"), ("shoulder_y", "{s}_shoulder_r", "z"),
+              ("elbow_p", "{s}_shoulder_y", "y"), ("elbow_y", "{s}_elbow_p", "z"), ("wrist_r", "{s}_elbow_y", "x")]
+_JVRC1_NO_ROTOR_IN_URDF = ("neck_y", "neck_r", "neck_p", "wrist_r", "wrist_y")
+# The ONE number on which the reference's two descriptions of the robot disagree: the URDF puts the right hip 87 mm below
+# the pelvis frame (robot-models/jvrc1_humanoid.urdf:378,392: xyz="0.0 -0.096 -87e-03"), the header does not
+# (JVRC1_Humanoid.hpp:52: p_right_hip_p = {0., -0.096, 0.}; the left hip is at z = 0 in both).  The URDF variant takes
+# the file's value -- the file is what BASELINE config 5 names.
+_JVRC1_URDF_POS = dict(right_hip_p=[0.0, -0.096, -87e-03])
+_JVRC1_URDF_WORD = dict(p="pitch", r="roll", y="yaw")
+
+
+def jvrc1_urdf_link_name(name: str) -> str:
+    """'left_hip_p' -> 'left-hip-pitch', 'left_knee' -> 'left-knee' (the link names of robot-models/jvrc1_humanoid.urdf)."""
+    parts = name.split("_")
+    if parts[-1] in _JVRC1_URDF_WORD and len(parts) > 1:
+        parts[-1] = _JVRC1_URDF_WORD[parts[-1]]
+    return "-".join(parts)
+
+
+def jvrc1_humanoid(urdf_variant: bool = False) -> ClusterTreeModel:
+    """JVRC1_Humanoid::buildClusterTreeModel (src/Robots/JVRC1_Humanoid.cpp:6-771)."""
+    m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    I3 = np.eye(3)
+    nm = jvrc1_urdf_link_name if urdf_variant else (lambda s: s)
+    si = lambda d: spatial_inertia(d[0], np.array(d[1], dtype=np.float64), np.diag(d[2]))
+    m.appendBody(nm("pelvis"), si(_JVRC1_LINK["pelvis"]), "ground", joint="free")
+
+    def joint(name, design, parent, axis):
+        has_rotor = not (urdf_variant and any(name.endswith(t) for t in _JVRC1_NO_ROTOR_IN_URDF))
+        pos = _JVRC1_URDF_POS.get(name, _JVRC1_POS[name]) if urdf_variant else _JVRC1_POS[name]
+        if not has_rotor:
+            m.appendBody(nm(name), si(_JVRC1_LINK[design]), nm(parent), I3, pos, joint="revolute", axis=axis)
+            return
+        m.registerBody(nm(name), si(_JVRC1_LINK[design]), nm(parent), I3, pos)
+        m.registerBody(nm(name) + ("-rotor" if urdf_variant else "_rotor"), si(_JVRC1_ROTOR), nm(parent), I3, pos)
+        m.appendRegisteredBodiesAsCluster(nm(name), "RevoluteWithRotor", joint_axis=axis, rotor_axis=axis, gear_ratio=6.0)
+
+    for name, parent, axis in _JVRC1_TRUNK:
+        joint(name, name, parent, axis)
+    for table in (_JVRC1_LEG, _JVRC1_ARM):
+        for s in ("left", "right"):
+            for name, parent, axis in table:
+                joint(f"{s}_{name}", name, parent.format(s=s), axis)
+    for s in ("left", "right"):   # JVRC1_Humanoid.cpp:692-755: the wrist yaw joints come last
+        joint(f"{s}_wrist_y", f"{s}_wrist_y", f"{s}_wrist_r", "z")
+    return m

@@ -7,6 +7,26 @@
 * implicit-loop clusters: independent positions U(-1,1), dependent guess U(-0.1,0.1); the caller
   projects them onto phi(q) = 0 (GenericJoint.cpp:289-348).
 Counter-based RNG (Philox), seed = 0x67726264 + config_index.
+
+Conditioning gate of the implicit-loop models (``accept``): the reference's sampler keeps whatever root its Newton
+solver lands on (CasADi ``rootfinder('newton')`` from a guess in U(-0.1, 0.1), GenericJoint.cpp:289-385; the only test
+is |phi| < 1e-8).  About 3 % of the roots it finds for the Tello differentials are poses no mechanism reaches: the
+solver has wandered tens to 10^5 radians away, or sits next to a singular pose of the linkage where the transmission
+``X = -K_d^-1 K_i`` (normally ~N = 6) is 10^2 ... 10^3 and the bias acceleration ``g`` 10^5 ... 10^7 rad/s^2.  Such
+states amplify ANY rounding by ``|X|`` (velocities) and ``|X|^2`` (velocity products); they are valid inputs and the fp64
+path reproduces the oracle on them to 1e-9, but no single-precision evaluation -- the reference's own ``float``
+instantiation included -- can promise 1e-3 there.  The synthetic workloads therefore accept a state iff, for every
+implicit cluster,
+
+    max |K_d^-1 K_i| < GATE_GMAX = 50,     |K_d|_F |K_d^-1|_F < GATE_KCOND = 1000,     max |q_span| < GATE_QMAX = 32 rad
+
+(an fp32 angle of magnitude a carries an absolute error ~6e-8 a; times the gain 50 and the ~10 terms of a constraint
+row this stays under 1e-3 up to a ~ 32.  The condition number catches what the gain does not: next to a CHANGE POINT of
+a linkage -- the flat pose of four_bar.urdf's parallelogram -- K_d^-1 K_i stays at its regular value, 3, while K_d
+itself becomes singular; 0.1 % of the four-bar states have cond > 1000 and fp32 errors up to 6e-3.)  Measured on 1 048 576 TelloWithArms states (tools/tello_acc.py): 96.5 %
+accepted; fp32 vs fp64 over the accepted ones max 2.5e-4 (ABA), 1.8e-5 (RNEA); over the rejected ones up to 0.18.
+ONE definition, used by the oracle-side sampler of the tests (tests/models.py), the device-side sampler below, the
+full-size tests and bench.py alike; explicit models are not affected (no state-dependent G).
 """
 from __future__ import annotations
 
@@ -17,6 +37,9 @@ import numpy as np
 from .modeldesc import C_FREE, C_LOOP_POSITION, C_STATIC, C_TRIG_POLY, ORI_QUATERNION, rotmat_to_quat, rpy_to_rotmat
 
 SEED_BASE = 0x67726264
+GATE_GMAX = 50.0
+GATE_KCOND = 1000.0
+GATE_QMAX = 32.0
 
 
 def rpy_to_quat_batch(rpy: np.ndarray) -> np.ndarray:
@@ -37,7 +60,7 @@ def rpy_to_quat_batch(rpy: np.ndarray) -> np.ndarray:
     c1 = ~c0 & (r[:, 0, 0] > r[:, 1, 1]) & (r[:, 0, 0] > r[:, 2, 2])
     c2 = ~c0 & ~c1 & (r[:, 1, 1] > r[:, 2, 2])
     c3 = ~c0 & ~c1 & ~c2
-    with np.errstate(invalid="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore"):
         S = np.sqrt(np.maximum(tr + 1.0, 0)) * 2.0
         q[c0] = np.stack([0.25 * S, (r[:, 2, 1] - r[:, 1, 2]) / S, (r[:, 0, 2] - r[:, 2, 0]) / S,
                           (r[:, 1, 0] - r[:, 0, 1]) / S], axis=1)[c0]
@@ -80,3 +103,43 @@ def random_states(blob: bytes, B: int, config_index: int = 0, dtype=np.float64):
                 if not ind[j]:
                     q[:, qi + j] *= 0.1
     return q.astype(dtype), qd.astype(dtype), tau.astype(dtype)
+
+
+def accept(blob: bytes, q: np.ndarray, gmax: np.ndarray, kcond: np.ndarray) -> np.ndarray:
+    """The conditioning gate (module docstring): bool[B].  gmax[B] = max |K_d^-1 K_i| and kcond[B] = max |K_d|_F |K_d^-1|_F
+    over the implicit clusters, from the product (``Plan.constraint_gain``) or from the oracle
+    (``oracle_py.spanning_state``)."""
+    m = parse_clusters(blob)
+    ok = np.isfinite(gmax) & (np.asarray(gmax) < GATE_GMAX) & np.isfinite(kcond) & (np.asarray(kcond) < GATE_KCOND)
+    for c in m["clusters"]:
+        (pc, fb, k, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = c
+        if ctype in (C_LOOP_POSITION, C_TRIG_POLY):
+            ok &= np.abs(q[:, qi: qi + npos]).max(axis=1) < GATE_QMAX
+    return ok
+
+
+def has_implicit_clusters(blob: bytes) -> bool:
+    return any(c[9] in (C_LOOP_POSITION, C_TRIG_POLY) for c in parse_clusters(blob)["clusters"])
+
+
+def valid_random_states_device(plan, B: int, config_index: int, device, dtype=np.float64):
+    """random_states, and for models with implicit clusters: Newton projection ON THE DEVICE (grbda_project_positions),
+    the conditioning gate on the device's own gain (grbda_state_to_independent), rejected states replaced by accepted
+    ones in order.  Returns (q, qd, tau, n_distinct)."""
+    import torch
+
+    blob = plan.blob
+    q, qd, tau = random_states(blob, B, config_index)
+    n_distinct = B
+    if has_implicit_clusters(blob):
+        t64 = torch.as_tensor(q, dtype=torch.float64, device=device)
+        ok = plan.project_positions(t64).cpu().numpy()
+        gmax, kcond, status = plan.constraint_gain(t64)
+        q = t64.cpu().numpy()
+        ok &= (status.cpu().numpy() == 0) & accept(blob, q, gmax.cpu().numpy(), kcond.cpu().numpy())
+        good, bad = np.flatnonzero(ok), np.flatnonzero(~ok)
+        if good.size == 0:
+            raise RuntimeError("no random state passed the Newton projection and the conditioning gate")
+        q[bad] = q[good[np.arange(bad.size) % good.size]]
+        n_distinct = int(good.size)
+    return q.astype(dtype), qd.astype(dtype), tau.astype(dtype), n_distinct

@@ -194,6 +194,42 @@ int grbda_project_positions_f64(const grbda_plan *plan, double *q, int32_t *ok, 
 int grbda_project_positions_f32(const grbda_plan *plan, float *q, int32_t *ok, size_t B, int max_iter, double tol,
                                 int device, void *stream);
 
+/* State input in the reference's conventions: ClusterJoints::Base::toSpanningTreeState (ClusterJoint.cpp:22-71) behind
+ * ClusterTreeModel::setState(const ModelState&) (ClusterTreeModel.cpp:256-276).  Every JointState of a ModelState flags
+ * its position and its velocity as independent or SPANNING coordinates (JointCoordinate::isSpanning(),
+ * StateRepresentation.h:10-36); half of the reference's dynamics tests feed spanning states
+ * (testRigidBodyDynamicsAlgos.cpp:45-72,195-196).  The compute entry points take the engine's own coordinates --
+ * independent ones for explicit clusters, spanning POSITIONS for implicit clusters, independent velocities -- and these
+ * calls convert a batch to them, with the reference's validity checks:
+ *   pos_is_spanning[c], vel_is_spanning[c]  (n_clusters bytes each; NULL = the engine's convention / all independent)
+ *   q_in  [B][in_nq], qd_in [B][in_nv]      the clusters' segments back to back, each n or k entries wide
+ *                                           (free base: 7 or 6 positions, 6 velocities); widths: grbda_state_input_dims
+ *   q [B][nq], qd [B][nv]                   engine coordinates (either may be NULL; qd_in may be NULL with qd)
+ *   status[B]                               0, or code + 256 * cluster of the first failure in cluster order:
+ *                                           1 "Spanning position is not valid"  (implicit cluster, |phi(q)|_2 >= tol;
+ *                                             LoopConstraint.cpp:15-19.  Explicit clusters are taken as they are, like
+ *                                             the reference: ClusterJoint.cpp:37-41),
+ *                                           2 "Spanning velocity is not valid"  (|K qd_span|_2 >= tol, LoopConstraint.cpp:22-26)
+ *   cond[B][2] (or NULL)                    maxima over the implicit clusters of [0] |K_d^-1 K_i| (the state-dependent
+ *                                           entries of G: how strongly the loop amplifies rates) and [1] |K_d|_F |K_d^-1|_F
+ *                                           (condition number of the inverted block; NaN where K_d is singular) -- what
+ *                                           the synthetic-state generator gates on
+ *   tol                                     the reference's nearZero tolerance is 1e-8 (Utilities.h:124-130)
+ * Independent positions for an implicit cluster are refused with GRBDA_ESTATE before anything is launched
+ * (ClusterJoint.cpp:32-35).  Device arrays; the _host_ variant takes host arrays, synchronises and returns GRBDA_ESTATE
+ * with the reference's message in grbda_last_error() if any state is invalid (what the facade's setState throws). */
+int grbda_state_input_dims(const grbda_plan *plan, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning, int *in_nq,
+                           int *in_nv);
+int grbda_state_to_independent_f64(const grbda_plan *plan, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning,
+                                   const double *q_in, const double *qd_in, double *q, double *qd, int32_t *status, double *cond,
+                                   size_t B, double tol, int device, void *stream);
+int grbda_state_to_independent_f32(const grbda_plan *plan, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning,
+                                   const float *q_in, const float *qd_in, float *q, float *qd, int32_t *status, float *cond,
+                                   size_t B, double tol, int device, void *stream);
+int grbda_state_to_independent_host_f64(const grbda_plan *plan, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning,
+                                        const double *q_in, const double *qd_in, double *q, double *qd, size_t B, double tol,
+                                        int device);
+
 /* Spanning-tree velocities and accelerations of every body joint from the independent ones:
  * qd_span = G yd, qdd_span = G ydd + g (ClusterJoint.cpp:55-58, GenericJoint.cpp:57-90; what the reference's
  * benchmarks do with the result of forwardDynamics, pinocchioBenchmark.cpp:168-176).  Order: clusters in model

@@ -1127,6 +1127,65 @@ int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster,
     return rc;
 }
 
+/* Spanning state of every cluster, cluster after cluster: ClusterJoints::Base::toSpanningTreeState
+ * (ClusterJoint.cpp:22-71) -- q_span = gamma(y) = G y for explicit constraints (LoopConstraint.cpp:38-52), the given
+ * spanning positions for implicit ones, qd_span = G yd -- i.e. what the reference's tests hand to setState when
+ * use_spanning_state is set (testRigidBodyDynamicsAlgos.cpp:45-72).  gmax[b] (may be NULL): largest |G| entry in the
+ * dependent rows of the implicit clusters (G = P [1; -Kd^-1 Ki], GenericJoint.cpp:75-83); kcond[b] (may be NULL): largest
+ * Frobenius condition number |Kd|_F |Kd^-1|_F of their dependent blocks. */
+int grbda_oracle_spanning_state(const void *blob, size_t bytes, const real *q, const real *qd, real *q_span,
+                                real *qd_span, real *gmax, real *kcond, size_t B)
+{
+    model_t m;
+    int rc = parse_blob(blob, bytes, &m);
+    if (rc) return rc;
+    cws_t *w = (cws_t *)malloc(sizeof(cws_t));
+    if (!w) return GRBDA_ORACLE_ENOMEM;
+    int nsp = 0, nsv = 0;
+    for (int c = 0; c < m.h->n_clusters; c++) { nsp += m.clusters[c].n_span_pos; nsv += m.clusters[c].n_span_vel; }
+    for (size_t b = 0; b < B && !rc; b++) {
+        const real *qb = q + b * (size_t)m.h->nq, *vb = qd + b * (size_t)m.h->nv;
+        real *qo = q_span ? q_span + b * (size_t)nsp : NULL, *vo = qd_span ? qd_span + b * (size_t)nsv : NULL;
+        real gm = 0, kc = 0;
+        for (int c = 0; c < m.h->n_clusters && !rc; c++) {
+            const grbda_desc_cluster *cl = &m.clusters[c];
+            rc = constraint_eval(&m, c, qb + cl->q_index, vb + cl->v_index, w);
+            if (rc) break;
+            if (qo) { memcpy(qo, w->qs, sizeof(real) * (size_t)cl->n_span_pos); qo += cl->n_span_pos; }
+            if (vo) { memcpy(vo, w->qds, sizeof(real) * (size_t)cl->n_span_vel); vo += cl->n_span_vel; }
+            if (cl->constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION || cl->constraint_type == GRBDA_CONSTRAINT_TRIG_POLY) {
+                const int32_t *is_ind = m.ints + cl->int_offset + (cl->constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION ? 1 : 0);
+                for (int i = 0; i < cl->n_span_vel; i++)
+                    if (!is_ind[i])
+                        for (int a = 0; a < cl->n_vel; a++) {
+                            const real x = fabs(w->G[i * cl->n_vel + a]);
+                            if (x > gm || x != x) gm = x;
+                        }
+                /* Kd = K[:, dependent]; its inverse by LU on the identity */
+                const int rows = cl->n_constraint_rows, nsv = cl->n_span_vel;
+                real Kd[MAXROWS * MAXROWS], Ki[MAXROWS * MAXROWS], f1 = 0, f2 = 0;
+                int dcol = 0;
+                for (int i = 0; i < nsv; i++)
+                    if (!is_ind[i]) {
+                        for (int r = 0; r < rows; r++) Kd[r * rows + dcol] = w->K[r * nsv + i];
+                        dcol++;
+                    }
+                for (int i = 0; i < rows * rows; i++) { f1 += Kd[i] * Kd[i]; Ki[i] = (i / rows == i % rows); }
+                if (dcol != rows || lu_solve(Kd, Ki, rows, rows)) { kc = NAN; }
+                else {
+                    for (int i = 0; i < rows * rows; i++) f2 += Ki[i] * Ki[i];
+                    const real cn = sqrt(f1 * f2);
+                    if (cn > kc || cn != cn) kc = cn;
+                }
+            }
+        }
+        if (gmax) gmax[b] = gm;
+        if (kcond) kcond[b] = kc;
+    }
+    free(w);
+    return rc;
+}
+
 int grbda_oracle_project_positions(const void *blob, size_t bytes, real *q, size_t B,
                                    int max_iter, int *ok)
 {

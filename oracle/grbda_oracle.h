@@ -69,6 +69,12 @@ int grbda_oracle_cluster_constraint(const void *blob, size_t bytes, int cluster,
                                     const grbda_real *qd, grbda_real *G, grbda_real *g, grbda_real *K, grbda_real *k,
                                     grbda_real *phi);
 
+/* spanning state of every cluster, cluster after cluster (ClusterJoint.cpp:22-71): q_span[B][sum n_span_pos],
+ * qd_span[B][sum n_span_vel]; gmax[B]: largest |G| entry of the dependent rows of the implicit clusters; kcond[B]: largest
+ * |Kd|_F |Kd^-1|_F of their dependent blocks.  Any output may be NULL. */
+int grbda_oracle_spanning_state(const void *blob, size_t bytes, const grbda_real *q, const grbda_real *qd,
+                                grbda_real *q_span, grbda_real *qd_span, grbda_real *gmax, grbda_real *kcond, size_t B);
+
 /* Newton projection of the dependent spanning positions of every implicit cluster onto
  * phi(q) = 0 (GenericJoint.cpp:289-385); q is [B][nq], modified in place.
  * ok[B] (may be NULL) receives 1 when ||phi|| < 1e-8 was reached for every cluster. */

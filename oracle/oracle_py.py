@@ -119,6 +119,25 @@ def body_poses(blob, q, n_bodies):
     return out
 
 
+def spanning_state(blob, q, qd):
+    """(q_span[B, sum n_span_pos], qd_span[B, sum n_span_vel], gmax[B], kcond[B]) -- toSpanningTreeState of every cluster."""
+    import struct
+    q, qd = _f64(q), _f64(qd)
+    nb, nc = struct.unpack_from("<ii", blob, 8)
+    off = 96 + 416 * nb
+    nsp = sum(struct.unpack_from("<16i", blob, off + 64 * c)[7] for c in range(nc))
+    nsv = sum(struct.unpack_from("<16i", blob, off + 64 * c)[8] for c in range(nc))
+    B = q.shape[0]
+    qs, vs, gm, kc = np.zeros((B, nsp)), np.zeros((B, nsv)), np.zeros(B), np.zeros(B)
+    L = lib()
+    L.grbda_oracle_spanning_state.argtypes = [c_void_p, c_size_t] + [c_void_p] * 6 + [c_size_t]
+    rc = L.grbda_oracle_spanning_state(blob, len(blob), q.ctypes.data, qd.ctypes.data, qs.ctypes.data, vs.ctypes.data,
+                                       gm.ctypes.data, kc.ctypes.data, B)
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    return qs, vs, gm, kc
+
+
 def project_positions(blob, q, max_iter=50):
     q = _f64(q).copy()
     ok = np.zeros(q.shape[0], dtype=np.int32)

@@ -194,6 +194,47 @@ static int fourBar()
     return worst < 5e-8 ? 0 : 1;
 }
 
+// setState(ModelState) with spanning joint states (testRigidBodyDynamicsAlgos.cpp:45-72: use_spanning_state): every
+// cluster hands over q_span = G y, qd_span = G yd flagged as spanning; the dynamics must not change.  An invalid spanning
+// velocity throws "Spanning velocity is not valid" (ClusterJoint.cpp:62-65).
+static int spanningStates()
+{
+    ClusterTreeModel<double> m;
+    buildRevolutePairChainWithRotor<4>(m);
+    const int nv = m.getNumDegreesOfFreedom();
+    const DVec<double> tau = DVec<double>::Random(nv);
+    ModelState<double> independent, spanning, broken;
+    for (const auto &cluster : m.clusters()) {
+        const auto &joint = cluster->joint_;
+        const DVec<double> y = DVec<double>::Random(joint->numPositions()), yd = DVec<double>::Random(joint->numVelocities());
+        const DMat<double> &G = joint->G();
+        DVec<double> qs = DVec<double>::Zero(G.rows()), vs = DVec<double>::Zero(G.rows());
+        for (int i = 0; i < G.rows(); i++)
+            for (int j = 0; j < G.cols(); j++) {
+                qs[i] += G(i, j) * y[j];
+                vs[i] += G(i, j) * yd[j];
+            }
+        independent.emplace_back(JointCoordinate<double>(y, false), JointCoordinate<double>(yd, false));
+        spanning.emplace_back(JointCoordinate<double>(qs, true), JointCoordinate<double>(vs, true));
+        DVec<double> bad = vs;
+        bad[0] += 1e-3;
+        broken.emplace_back(JointCoordinate<double>(qs, true), JointCoordinate<double>(bad, true));
+    }
+    m.setState(independent);
+    const DVec<double> a = m.forwardDynamics(tau);
+    m.setState(spanning);
+    const DVec<double> b = m.forwardDynamics(tau);
+    const double diff = (a - b).norm();
+    bool threw = false;
+    try {
+        m.setState(broken);
+    } catch (const std::runtime_error &e) {
+        threw = std::string(e.what()).find("Spanning velocity is not valid") != std::string::npos;
+    }
+    std::printf("spanning vs independent joint states: |dydd| = %.3e, invalid spanning velocity throws: %d\n", diff, threw ? 1 : 0);
+    return diff < 1e-9 && threw ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "";
@@ -230,6 +271,7 @@ int main(int argc, char **argv)
                 rc |= roundtrip(m, argv[2]);
             }
             rc |= fourBar();
+            rc |= spanningStates();
             std::printf(rc ? "FAILED\n" : "OK\n");
             return rc;
         }

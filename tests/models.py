@@ -205,9 +205,10 @@ ROBOT_MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"
 
 def valid_states(blob, B, config_index=0):
     """random_states + (for implicit-loop clusters) Newton projection of the dependent positions onto
-    phi(q) = 0 with the oracle, rejecting states that do not converge (GenericJoint.cpp:289-385)."""
+    phi(q) = 0 with the oracle, rejecting states that do not converge (GenericJoint.cpp:289-385) or that fail the
+    conditioning gate of generalized_rbda_amd/states.py (evaluated on the ORACLE's constraint Jacobian here)."""
     import oracle_py as O
-    from generalized_rbda_amd.states import parse_clusters, random_states
+    from generalized_rbda_amd.states import accept, parse_clusters, random_states
 
     if not any(c[9] >= 2 for c in parse_clusters(blob)["clusters"]):
         return random_states(blob, B, config_index)
@@ -216,6 +217,7 @@ def valid_states(blob, B, config_index=0):
     while have < B:
         q, qd, tau = random_states(blob, max(2 * B, 16), config_index + 7919 * attempt)
         q, ok = O.project_positions(blob, q)
+        ok &= accept(blob, q, *O.spanning_state(blob, q, qd)[2:])
         qs.append(q[ok]); qds.append(qd[ok]); taus.append(tau[ok])
         have += int(ok.sum())
         attempt += 1
@@ -238,6 +240,9 @@ def zoo():
     from generalized_rbda_amd.robots import tello_with_arms
 
     z["tello_with_arms"] = tello_with_arms().serialize()
+    from generalized_rbda_amd.robots import jvrc1_humanoid
+
+    z["jvrc1_hand_built"] = jvrc1_humanoid().serialize()  # the reference's JVRC1_Humanoid: 32 rotor clusters, 65 bodies
     for n in (2, 3, 4):
         z[f"rev_rotor_chain_{n}"] = md.revolute_chain_with_rotor(n).serialize()
     for n in (2, 4):

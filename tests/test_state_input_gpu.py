@@ -1,0 +1,92 @@
+"""Spanning-state input through the C ABI (ClusterJoints::Base::toSpanningTreeState, ClusterJoint.cpp:22-71;
+ClusterTreeModel::setState(ModelState), ClusterTreeModel.cpp:256-276).  The reference's dynamics tests feed every
+other robot SPANNING joint states (testRigidBodyDynamicsAlgos.cpp:45-72,195-196: use_spanning_state = i % 2 == 0) and
+require the same results; here every zoo model goes through both conventions and through a per-cluster mix."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+import generalized_rbda_amd as G
+from generalized_rbda_amd.states import parse_clusters
+from generalized_rbda_amd.modeldesc import C_FREE, C_LOOP_POSITION, C_TRIG_POLY
+from models import valid_states, zoo
+
+pytestmark = pytest.mark.gpu
+
+
+ZOO = zoo()
+
+
+def _rows(m, q, qd, qs, vs, pos_sp, vel_sp):
+    """the caller's rows for the given per-cluster flags: spanning segments from (qs, vs), independent ones from (q, qd)"""
+    cq, cv = [], []
+    sp = sv = 0
+    for c, cl in enumerate(m["clusters"]):
+        (pc, fb, k, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = cl
+        cq.append(qs[:, sp:sp + nsp] if pos_sp[c] else q[:, qi:qi + npos])
+        cv.append(vs[:, sv:sv + nsv] if vel_sp[c] else qd[:, vi:vi + nvel])
+        sp += nsp
+        sv += nsv
+    return np.concatenate(cq, axis=1), np.concatenate(cv, axis=1)
+
+
+@pytest.mark.parametrize("name", sorted(ZOO))
+def test_spanning_and_independent_states_give_the_same_dynamics(name, gpu):
+    import torch
+
+    blob = ZOO[name]
+    plan = G.Plan(blob)
+    m = parse_clusters(blob)
+    q, qd, tau = valid_states(blob, 70, config_index=11)
+    qs, vs, _, _ = O.spanning_state(blob, q, qd)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=gpu)
+    implicit = [cl[9] in (C_LOOP_POSITION, C_TRIG_POLY) for cl in m["clusters"]]
+    ref = plan.forward_dynamics(t(q), t(qd), t(tau))
+    nc = len(m["clusters"])
+    for pos_sp, vel_sp in (([True] * nc, [True] * nc),                                   # use_spanning_state
+                           (implicit, [False] * nc),                                     # the engine's own convention
+                           ([imp or c % 2 == 0 for c, imp in enumerate(implicit)], [c % 3 != 0 for c in range(nc)])):
+        q_in, qd_in = _rows(m, q, qd, qs, vs, pos_sp, vel_sp)
+        assert plan.state_input_dims(pos_sp, vel_sp) == (q_in.shape[1], qd_in.shape[1])
+        q2, qd2, status = plan.state_to_independent(t(q_in), t(qd_in), pos_sp, vel_sp, tol=1e-8)
+        assert int(status.abs().sum().item()) == 0
+        assert np.abs(q2.cpu().numpy() - q).max() < 1e-12 and np.abs(qd2.cpu().numpy() - qd).max() < 1e-11
+        ydd = plan.forward_dynamics(q2, qd2, t(tau))
+        assert (ydd - ref).abs().max().item() <= 1e-9 * (1 + ref.abs().max().item())
+    # ---- invalid spanning velocity: off range(G) in the last multi-body cluster ("Spanning velocity is not valid") --
+    multi = [c for c, cl in enumerate(m["clusters"]) if cl[9] != C_FREE and cl[8] > cl[6]]
+    if multi:
+        c = multi[-1]
+        q_in, qd_in = _rows(m, q, qd, qs, vs, [True] * nc, [True] * nc)
+        sv = sum(cl[8] for cl in m["clusters"][:c])
+        bad = qd_in.copy()
+        bad[3, sv] += 1e-3
+        _, _, status = plan.state_to_independent(t(q_in), t(bad), [True] * nc, [True] * nc)
+        st = status.cpu().numpy()
+        assert st[3] == 2 + 256 * c and (np.delete(st, 3) == 0).all()
+    # ---- invalid spanning position of an implicit cluster ("Spanning position is not valid") ----------------------
+    imp = [c for c, f in enumerate(implicit) if f]
+    if imp:
+        c = imp[0]
+        q_in, qd_in = _rows(m, q, qd, qs, vs, [True] * nc, [True] * nc)
+        sp = sum(cl[7] for cl in m["clusters"][:c])
+        bad = q_in.copy()
+        bad[1, sp + m["clusters"][c][7] - 1] += 1e-3
+        _, _, status = plan.state_to_independent(t(bad), t(qd_in), [True] * nc, [True] * nc)
+        assert status.cpu().numpy()[1] == 1 + 256 * c
+        with pytest.raises(G.GrbdaError, match="Independent positions cannot be converted"):
+            plan.state_input_dims([False] * nc, None)
+
+
+@pytest.mark.parametrize("name", ["tello_with_arms", "urdf_four_bar", "urdf_six_bar"])
+def test_constraint_gain_matches_oracle(name, gpu):
+    import torch
+
+    blob = ZOO[name]
+    plan = G.Plan(blob)
+    q, qd, _ = valid_states(blob, 300, config_index=5)
+    _, _, gm, kc = O.spanning_state(blob, q, qd)
+    gmax, kcond, status = plan.constraint_gain(torch.as_tensor(q, dtype=torch.float64, device=gpu))
+    assert int(status.abs().sum().item()) == 0
+    assert np.abs(gmax.cpu().numpy() - gm).max() <= 1e-8 * (1 + gm.max())
+    assert (np.abs(kcond.cpu().numpy() - kc) / kc).max() <= 1e-7

@@ -6,14 +6,17 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${1:-bench}
 mkdir -p $OUT
 cd $ROOT
-python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+FAILED=0
+python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { echo "bench.py (headline) failed: rc $?" >&2; FAILED=1; }
 : > $OUT/bench_other_workloads.jsonl
 for spec in "mit_humanoid rnea" "mit_humanoid aba --dtype f64" "mit_humanoid rnea --dtype f64" "mini_cheetah aba" "mini_cheetah rnea" \
             "jvrc1_humanoid aba" "jvrc1_humanoid rnea" "tello aba" "tello rnea" "revolute_rotor_chain aba"; do
   set -- $spec
   w=$1; a=$2; shift 2
-  python3 bench.py --workload $w --algo $a "$@" --steps 30 --warmup 3 --no-cpu-baseline >> $OUT/bench_other_workloads.jsonl 2>> $OUT/bench_other.err
+  python3 bench.py --workload $w --algo $a "$@" --steps 30 --warmup 3 --no-cpu-baseline >> $OUT/bench_other_workloads.jsonl 2>> $OUT/bench_other.err \
+    || { echo "bench.py $w $a $* failed: rc $?" >&2; FAILED=1; }
 done
 python3 tools/time_derivs.py jvrc1_humanoid 1048576 > $OUT/derivatives_timing.txt 2>/dev/null
 python3 tools/time_derivs.py mit_humanoid 262144 >> $OUT/derivatives_timing.txt 2>/dev/null
 python3 tools/time_derivs.py mini_cheetah 65536 >> $OUT/derivatives_timing.txt 2>/dev/null
+exit $FAILED

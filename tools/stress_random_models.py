@@ -71,3 +71,4 @@ for seed in range(1000, 1000 + n):
 print("models", 4 * n, "failures", bad)
 for k, v in sorted(shapes.items()):
     print("  (kind, chain_aba_f32, chain_rnea_f32, analytic, explicit pairs as differentials):", k, "x", v)
+sys.exit(1 if bad else 0)
