@@ -1314,7 +1314,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         }
         // one wavefront per state; as many as the LDS of a CU holds
         const bool wide = sizeof(T) == 4 && p->solve_f64;
-        const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), wide ? 8 : sizeof(T));
+        const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), wide ? 8 : sizeof(T), (dq ? 1 : 0) + (dqd ? 1 : 0));
         size_t per_cu = lds ? (160u * 1024u) / lds : 16;
         if (per_cu > 16) per_cu = 16;
         if (per_cu < 1) per_cu = 1;

@@ -744,6 +744,14 @@ template hipError_t launch_rnea_deriv<double>(const DevPlan<double> &, const Der
 // `related` (DerivProgram::related, may be null): the entries that are not structural zeros; the others are not used,
 // whatever the arrays hold.  Global traffic: every matrix read / written once.  TIO: array element type; TC: arithmetic.
 // ---------------------------------------------------------------------------------------------------------------
+// f32 solves run on the matrix cores (spd_mfma_kernel) unless GRBDA_SOLVE_VALU=1 keeps the triangular solves (A/B runs)
+bool spd_solve_on_mfma(size_t elem)
+{
+    static const bool valu = [] { const char *e = std::getenv("GRBDA_SOLVE_VALU"); return e && std::atoi(e) != 0; }();
+    return elem == 4 && !valu;
+}
+size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
+
 __device__ __forceinline__ float lane_value(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 __device__ __forceinline__ double lane_value(double x, int l)
 {
@@ -924,6 +932,239 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same solve on the matrix cores (f32): one state per wavefront.
+//   1. Cholesky factor of H as above (row i in lane i, v_readlane), rows of L^T to LDS;
+//   2. W = L^-1 by forward substitution on the identity (column j in lane j), written to LDS;
+//   3. H^-1 = W^T W              v_mfma_f32_16x16x4_f32, NT x NT tiles of 16 x 16, W lower triangular: tile (mt, nt) only
+//                                sums over rows >= 16 max(mt, nt);
+//   4. [X1 | X2] = -H^-1 [P1 | P2]   the same instruction; A fragments from the H^-1 tile in LDS (symmetric: read by rows),
+//                                B fragments gathered from the PACKED right-hand sides (rnea_deriv_kernel's runs), which an
+//                                asynchronous global -> LDS copy put next to it while 1. - 3. ran; structural zeros
+//                                (DerivProgram::related) and the padding are masked to 0 at the gather.
+// 2 nv^2 (nv + n_rhs) flops per state go through 16 x 16 x 4 tiles (JVRC-1: 38 + 150 MFMAs) instead of ~5 000 VALU
+// instructions of triangular solves; what stays on the VALU is the factorisation and the inversion of the factor
+// (~nv^2 FMAs + nv^2 / 2 v_readlane).  Fragment maps (cdna_hip_programming.md 3): A[l & 15][l >> 4], B[l >> 4][l & 15],
+// D: column l & 15, rows 4 (l >> 4) + 0..3.  LDS rows have a stride of WS floats with WS = 16 (mod 32) so that the four
+// 16-lane groups of a fragment read (rows 4k .. 4k + 3) fall into different banks.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NVV>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NVV > 48 ? 1 : 2, 2)))
+void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float *P2, float *Hinv, float *X1, float *X2,
+                     const uint64_t *__restrict__ related, int nv, size_t B)
+{
+    constexpr int NT = (NVV + 15) / 16;               // row / column tiles of H^-1
+    constexpr int WS = NT == 1 ? 16 : (NT <= 3 ? 48 : 80);
+    constexpr int NCT = (2 * NVV + 15) / 16;          // column tiles of [P1 | P2]
+    constexpr int KS = NVV / 4;                       // k steps
+    static_assert(NVV % 8 == 0 && NT * 16 <= WS, "sizes");
+    float *A = reinterpret_cast<float *>(grbda_smem);  // [NT * 16][WS]: rows of L^T, then W = L^-1, then H^-1
+    float *Pk = A + NT * 16 * WS;                      // packed right-hand sides, n_mat * nv * nv
+    const int lane = threadIdx.x, g = lane >> 4, c16 = lane & 15;
+    const int nn = nv * nv;
+    const float *src[2] = {P1 ? P1 : P2, P1 ? P2 : nullptr};
+    float *dst[2] = {P1 ? X1 : X2, P1 ? X2 : nullptr};
+    const int n_mat = (P1 ? 1 : 0) + (P2 ? 1 : 0);
+    const int n_cols = n_mat * nv, nct = (n_cols + 15) / 16;
+    auto factor_row = [&](int k, int from, float(&l)[NVV]) {
+#pragma unroll
+        for (int i = (from / 4) * 4; i < NVV; i += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(&A[k * WS + i]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) l[i + e] = v[e];
+        }
+    };
+    // per column tile of the right-hand sides: where this lane's column lives in the packed copy
+    int lo_base[NCT], hi_base[NCT], ccol[NCT], mat[NCT];
+    uint64_t rel[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; t++) {
+        const int c = 16 * t + c16;
+        const bool valid = c < n_cols;
+        const int m = (valid && c >= nv) ? 1 : 0, cc = valid ? c - m * nv : 0;
+        mat[t] = valid ? m : -1;
+        ccol[t] = cc;
+        lo_base[t] = m * nn + cc;
+        hi_base[t] = m * nn + cc * cc + cc + 1;
+        rel[t] = valid ? (related ? related[cc] : ~uint64_t(0)) : uint64_t(0);
+    }
+    const uint64_t rel_mine = related ? related[lane < nv ? lane : 0] : ~uint64_t(0);
+    for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
+        // ---- 0. the packed right-hand sides on their way to LDS (nobody reads Pk before step 4) ----
+        wave_lds_fence();  // the previous state's fragment reads are done
+        for (int m = 0; m < n_mat; m++) {
+            const unsigned *blk = reinterpret_cast<const unsigned *>(src[m] + s * (size_t)nn);
+            for (int base = 0; base < nn; base += kWave)
+                if (base + lane < nn)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + lane),
+                                                     (__attribute__((address_space(3))) void *)(Pk + m * nn + base), 4, 0, 0);
+        }
+        // ---- 1. Cholesky: row `lane` of H, then of L; the diagonal entry holds 1 / L[k][k] ----
+        {
+            float Lr[NVV];
+            const size_t lrow = lane < nv ? lane : 0;
+            const float *hp = H + s * (size_t)nn + (h_packed ? lrow * (lrow + 1) / 2 : lrow * nv);
+            float hrow[NVV];  // (16-byte loads; a packed row runs on into the next rows: masked below)
+#pragma unroll
+            for (int i = 0; i < NVV; i += 4) {
+                if (i + 4 <= nv) {
+                    f32x4 v;
+                    __builtin_memcpy(&v, hp + i, sizeof v);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) hrow[i + e] = v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) hrow[i + e] = (i + e < nv) ? hp[i + e] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NVV; j++)
+                Lr[j] = (lane < nv && j < nv) ? ((j <= lane && ((rel_mine >> j) & 1)) ? hrow[j] : 0.0f) : (lane == j ? 1.0f : 0.0f);
+#pragma unroll
+            for (int k = 0; k < NVV; k++) {
+                float sum = Lr[k];
+#pragma unroll
+                for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
+                const float d = lane_value(sum, k);
+                const float r = inv_sqrt(d);
+                Lr[k] = lane == k ? r : sum * r;
+                if (lane >= k && lane < NVV) A[k * WS + lane] = Lr[k];
+            }
+        }
+        wave_lds_fence();
+        // ---- 2. W = L^-1: column `lane`, forward substitution by columns of L (rows of the stored L^T) ----
+        {
+            float x[NVV], l[NVV];
+#pragma unroll
+            for (int i = 0; i < NVV; i++) x[i] = lane == i ? 1.0f : 0.0f;
+#pragma unroll
+            for (int m2 = 0; m2 < NVV; m2++) {
+                factor_row(m2, m2, l);
+                x[m2] *= l[m2];
+#pragma unroll
+                for (int i = m2 + 1; i < NVV; i++) x[i] -= l[i] * x[m2];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (a use of the solution outside the conditional stores: without it the compiler sinks the whole substitution
+            // into the store block, below the LDS reads, and every factor row stays live)
+#pragma unroll
+            for (int i = 0; i < NVV; i++) asm volatile("" ::"v"(x[i]));
+            wave_lds_fence();  // every row of L^T has been read: W goes over it
+            if (lane < NT * 16) {
+#pragma unroll
+                for (int i = 0; i < NT * 16; i++) A[i * WS + lane] = i < NVV ? (lane < NVV ? x[i < NVV ? i : 0] : 0.0f) : 0.0f;
+            }
+        }
+        wave_lds_fence();
+        // ---- 3. H^-1 = W^T W ----
+        f32x4 hi[NT][NT];
+#pragma unroll
+        for (int a = 0; a < NT; a++)
+#pragma unroll
+            for (int b = 0; b < NT; b++) hi[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            float w[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) w[t] = (16 * t <= 4 * k + 3) ? A[(4 * k + g) * WS + 16 * t + c16] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < NT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++)
+                    if (16 * (a > b ? a : b) <= 4 * k + 3) hi[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a], w[b], hi[a][b], 0, 0, 0);
+        }
+        // the packed right-hand sides have long arrived; waiting for them HERE, before the H^-1 stores are issued, keeps the
+        // wait from also draining those stores (loads and stores share the counter)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_fence();  // W has been read: H^-1 goes over it
+#pragma unroll
+        for (int a = 0; a < NT; a++)
+#pragma unroll
+            for (int b = 0; b < NT; b++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = 16 * a + 4 * g + j, col = 16 * b + c16;
+                    A[row * WS + col] = hi[a][b][j];
+                    if (Hinv && row < nv && col < nv) Hinv[s * (size_t)nn + (size_t)row * nv + col] = hi[a][b][j];
+                }
+        if (n_mat == 0) continue;
+        wave_lds_fence();
+        // ---- 4. X = -H^-1 [P1 | P2] ----
+        f32x4 acc[NT][NCT];
+#pragma unroll
+        for (int a = 0; a < NT; a++)
+#pragma unroll
+            for (int t = 0; t < NCT; t++) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            int r = 4 * k + g;
+            asm volatile("" : "+v"(r));  // (the gather addresses and masks do not depend on the state: left to itself the
+                                         // compiler computes all NCT * KS of them before the loop and spills them)
+            const int r2 = r * r;
+            float av[NT], bv[NCT];
+#pragma unroll
+            for (int a = 0; a < NT; a++) av[a] = A[r * WS + 16 * a + c16];  // H^-1[a][r] = H^-1[r][a]
+#pragma unroll
+            for (int t = 0; t < NCT; t++) {
+                if (t < nct) {
+                    const bool ok = (rel[t] >> r) & 1;  // bit r of related[column]: r < nv, the column exists, not a structural zero
+                    const int addr = ccol[t] <= r ? r2 + lo_base[t] : r + hi_base[t];
+                    const float v = Pk[ok ? addr : 0];
+                    bv[t] = ok ? v : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NCT; t++)
+                if (t < nct) {
+#pragma unroll
+                    for (int a = 0; a < NT; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NCT; t++)
+            if (t < nct && mat[t] >= 0) {
+                float *out = dst[mat[t]] + s * (size_t)nn + ccol[t];
+#pragma unroll
+                for (int a = 0; a < NT; a++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int row = 16 * a + 4 * g + j;
+                        if (row < nv) out[(size_t)row * nv] = -acc[a][t][j];
+                    }
+            }
+    }
+}
+
+template <int NVV>
+static hipError_t launch_spd_mfma_n(const float *H, int h_packed, const float *P1, const float *P2, float *Hinv, float *X1, float *X2,
+                                    const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
+{
+    const size_t lds = spd_solve_lds_bytes(nv, 4, (P1 ? 1 : 0) + (P2 ? 1 : 0));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_mfma_kernel<NVV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((spd_mfma_kernel<NVV>), dim3(grid), dim3(kWave), lds, stream, H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B);
+    return hipGetLastError();
+}
+static hipError_t launch_spd_mfma(const float *H, int h_packed, const float *P1, const float *P2, float *Hinv, float *X1, float *X2,
+                                  const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
+{
+    if (nv <= 16) return launch_spd_mfma_n<16>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 24) return launch_spd_mfma_n<24>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 32) return launch_spd_mfma_n<32>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 40) return launch_spd_mfma_n<40>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 48) return launch_spd_mfma_n<48>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 64) return launch_spd_mfma_n<64>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    return hipErrorInvalidValue;
+}
+
 template <class TIO, class TC, int NV>
 static hipError_t launch_spd_solve_n(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2,
                                      const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
@@ -946,6 +1187,9 @@ template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
                             int nv, size_t B, int grid, hipStream_t stream)
 {
+    if constexpr (sizeof(TIO) == 4 && sizeof(TC) == 4) {
+        if (spd_solve_on_mfma(4)) return launch_spd_mfma(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    }
     if (nv <= 16) return launch_spd_solve_n<TIO, TC, 16>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
     if (nv <= 24) return launch_spd_solve_n<TIO, TC, 24>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
     if (nv <= 32) return launch_spd_solve_n<TIO, TC, 32>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
@@ -961,10 +1205,15 @@ template hipError_t launch_spd_solve<float, double>(const float *, int, const fl
 template hipError_t launch_spd_solve<double, double>(const double *, int, const double *, const double *, double *, double *, double *,
                                                      const uint64_t *, int, size_t, int, hipStream_t);
 
-// static LDS of one spd_solve_kernel workgroup: the factor, at the compile-time size the launch picks for nv
-size_t spd_solve_lds_bytes(int nv, size_t elem)
+// LDS of one workgroup of the solve: the factor at the compile-time size the launch picks for nv (VALU kernel), or the
+// [16 NT][WS] matrix tile plus the packed right-hand sides (matrix-core kernel)
+size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs)
 {
     const int nvb = nv <= 16 ? 16 : (nv <= 24 ? 24 : (nv <= 32 ? 32 : (nv <= 40 ? 40 : (nv <= 48 ? 48 : 64))));
+    if (spd_solve_on_mfma(elem)) {
+        const int nt = (nvb + 15) / 16, ws = nt == 1 ? 16 : (nt <= 3 ? 48 : 80);
+        return (static_cast<size_t>(nt) * 16 * ws + static_cast<size_t>(n_rhs) * nv * nv) * 4;
+    }
     return static_cast<size_t>(nvb) * nvb * elem;
 }
 

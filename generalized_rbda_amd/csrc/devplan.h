@@ -147,6 +147,7 @@ hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clu
 template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
                             int nv, size_t B, int grid, hipStream_t stream);
-size_t spd_solve_lds_bytes(int nv, size_t elem);
+size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
+bool spd_solve_on_mfma(size_t elem);
 
 }  // namespace grbda_hip
