@@ -949,6 +949,12 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
 // 16-lane groups of a fragment read (rows 4k .. 4k + 3) fall into different banks.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef GRBDA_EXP_MF_PROF
+__device__ unsigned long long mf_prof[8];
+#define MF_STAMP(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += now_ - prof_t; prof_t = now_; }
+#else
+#define MF_STAMP(i)
+#endif
 
 template <int NVV>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NVV > 48 ? 1 : 2, 2)))
@@ -991,16 +997,27 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
         rel[t] = valid ? (related ? related[cc] : ~uint64_t(0)) : uint64_t(0);
     }
     const uint64_t rel_mine = related ? related[lane < nv ? lane : 0] : ~uint64_t(0);
+#ifdef GRBDA_EXP_MF_PROF
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
     for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
         // ---- 0. the packed right-hand sides on their way to LDS (nobody reads Pk before step 4) ----
         wave_lds_fence();  // the previous state's fragment reads are done
         for (int m = 0; m < n_mat; m++) {
             const unsigned *blk = reinterpret_cast<const unsigned *>(src[m] + s * (size_t)nn);
-            for (int base = 0; base < nn; base += kWave)
-                if (base + lane < nn)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + lane),
-                                                     (__attribute__((address_space(3))) void *)(Pk + m * nn + base), 4, 0, 0);
+            if ((nn & 3) == 0) {  // 16 bytes per lane and instruction (1 KiB per wave instruction): nv even
+                for (int base = 0; base < nn; base += 4 * kWave)
+                    if (base + 4 * lane < nn)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + 4 * lane),
+                                                         (__attribute__((address_space(3))) void *)(Pk + m * nn + base), 16, 0, 0);
+            } else {
+                for (int base = 0; base < nn; base += kWave)
+                    if (base + lane < nn)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + lane),
+                                                         (__attribute__((address_space(3))) void *)(Pk + m * nn + base), 4, 0, 0);
+            }
         }
+        MF_STAMP(0)  // fence + DMA issue
         // ---- 1. Cholesky: row `lane` of H, then of L; the diagonal entry holds 1 / L[k][k] ----
         {
             float Lr[NVV];
@@ -1022,6 +1039,10 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
 #pragma unroll
             for (int j = 0; j < NVV; j++)
                 Lr[j] = (lane < nv && j < nv) ? ((j <= lane && ((rel_mine >> j) & 1)) ? hrow[j] : 0.0f) : (lane == j ? 1.0f : 0.0f);
+#ifdef GRBDA_EXP_MF_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MF_STAMP(1)  // H row load
+#endif
 #pragma unroll
             for (int k = 0; k < NVV; k++) {
                 float sum = Lr[k];
@@ -1034,6 +1055,7 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
             }
         }
         wave_lds_fence();
+        MF_STAMP(2)  // Cholesky
         // ---- 2. W = L^-1: column `lane`, forward substitution by columns of L (rows of the stored L^T) ----
         {
             float x[NVV], l[NVV];
@@ -1059,6 +1081,7 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
             }
         }
         wave_lds_fence();
+        MF_STAMP(3)  // L^-1
         // ---- 3. H^-1 = W^T W ----
         f32x4 hi[NT][NT];
 #pragma unroll
@@ -1090,6 +1113,7 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
                     A[row * WS + col] = hi[a][b][j];
                     if (Hinv && row < nv && col < nv) Hinv[s * (size_t)nn + (size_t)row * nv + col] = hi[a][b][j];
                 }
+        MF_STAMP(4)  // GEMM 1, wait for the copy, H^-1 to LDS and to global
         if (n_mat == 0) continue;
         wave_lds_fence();
         // ---- 4. X = -H^-1 [P1 | P2] ----
@@ -1123,6 +1147,7 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
                     for (int a = 0; a < NT; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
                 }
         }
+        MF_STAMP(5)  // GEMM 2
 #pragma unroll
         for (int t = 0; t < NCT; t++)
             if (t < nct && mat[t] >= 0) {
@@ -1135,8 +1160,24 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
                         if (row < nv) out[(size_t)row * nv] = -acc[a][t][j];
                     }
             }
+        MF_STAMP(6)  // result stores (issue)
     }
+#ifdef GRBDA_EXP_MF_PROF
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&mf_prof[i], prof_acc[i]);
+#endif
 }
+#ifdef GRBDA_EXP_MF_PROF
+extern "C" int grbda_debug_mf_prof(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mf_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mf_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 template <int NVV>
 static hipError_t launch_spd_mfma_n(const float *H, int h_packed, const float *P1, const float *P2, float *Hinv, float *X1, float *X2,

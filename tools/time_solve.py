@@ -23,3 +23,17 @@ def timed(fn, n=5):
 res = {"fd_dtau": timed(lambda: plan.fd_dtau(tq)), "dqd only": timed(lambda: plan.fd_derivatives(tq, tqd, tt, want=("dqd",))),
        "all three": timed(lambda: plan.fd_derivatives(tq, tqd, tt))}
 print(os.path.basename(G.LIB_PATH), model, B, "  ".join(f"{k}={v:.3f}ms" for k, v in res.items()), flush=True)
+
+try:
+    import ctypes
+    L = G.lib()
+    L.grbda_debug_mf_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = (ctypes.c_ulonglong * 8)()
+    L.grbda_debug_mf_prof(buf, 1)
+    plan.fd_derivatives(tq, tqd, tt); torch.cuda.synchronize()
+    L.grbda_debug_mf_prof(buf, 0)
+    names = ["fence + copy issue", "H row load", "Cholesky", "L^-1", "GEMM1 + copy wait + H^-1 stores", "GEMM2", "result stores"]
+    tot = sum(buf[:7])
+    print("s_memtime ticks per state (all three):", "  ".join(f"{n}={buf[i] / B:.0f} ({100 * buf[i] / tot:.0f}%)" for i, n in enumerate(names)), " total", tot / B)
+except AttributeError:
+    pass
