@@ -77,3 +77,13 @@ expc: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/deriv_kernels.o $(OBJ)/cr
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(DEFS) -c $(CSRC)/chain_kernels.hip -o build/exp/chain_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/chain_$(NAME).o $^
+
+# AddressSanitizer + UBSan build of the HOST-side code (CPU only: GPU sanitizers are not available on this pool): the plan
+# compiler, the URDF+ reader and the oracle, driven by tools/asan_driver.cpp over every robot URDF and a serialised model.
+#   make asan && build/asan/asan_driver tests/golden/robot-models/*.urdf
+asan:
+	@mkdir -p build/asan
+	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -Wall \
+	    -DGRBDA_ASAN_DRIVER -I include -I generalized_rbda_amd/include tools/asan_driver.cpp $(CSRC)/plan.cpp $(CSRC)/urdf.cpp \
+	    -x c oracle/grbda_oracle.c -x none -lm -lpthread -o build/asan/asan_driver
+.PHONY: asan

@@ -438,6 +438,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     for (int c = 0; c < nc; c++) {
         const grbda_desc_cluster &cl = m.clusters[c];
         if (clusters[c].kind != CK_LOOP) continue;
+        if (cl.dbl_offset < 0 || cl.n_dbl < 0 || cl.dbl_offset + cl.n_dbl > m.h->n_doubles)
+            return fail(msg, cap, GRBDA_EINVAL, "cluster %d: constraint doubles outside the blob", c);
         const int32_t *ip = m.ints + cl.int_offset;
         const double *dp = m.dbls + cl.dbl_offset;
         const int k = cl.n_bodies;
@@ -470,9 +472,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 if (tp >= tend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly payload truncated", c);
                 const int nt = *tp++;
                 prog.push_back(nt);
+                if (nt < 0 || nt > cl.n_int) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly term count", c);
                 for (int t = 0; t < nt; t++) {
+                    if (tp >= tend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly payload truncated", c);
                     const int nf = *tp++;
                     if (nf < 0 || nf > 4) return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: a term has %d factors (max 4)", c, nf);
+                    if (tp + nf > tend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly payload truncated", c);
                     if (nd + 1 + nf * (k + 1) > cl.n_dbl) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly doubles truncated", c);
                     prog.push_back(nf);
                     coefs.push_back(dp[nd++]);
@@ -486,6 +491,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             idx = static_cast<int>(args.size());
                             args.push_back(a);
                         }
+                        if (*tp < 0 || *tp > 2) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: trig-poly factor type %d", c, *tp);
                         prog.push_back(*tp++);
                         prog.push_back(idx);
                     }
@@ -499,10 +505,22 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         } else {
             const int n_loops = ip[0];
             const int32_t *lp = ip + 1 + k;
+            const int32_t *lend = ip + cl.n_int;
             int rows = 0;
+            if (n_loops < 1 || n_loops > 3 || cl.n_int < 1 + k || cl.n_dbl < 24 * n_loops)
+                return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop payload truncated", c);
             for (int l = 0; l < n_loops; l++) {
-                const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
-                if (np < 0 || ns < 0 || np > k || ns > k) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: bad loop chain", c);
+                // (every index is checked against the end of the cluster's integer payload before it is used)
+                if (lp + 1 > lend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop payload truncated", c);
+                const int np = lp[0];
+                if (np < 0 || np > k || lp + 2 + np > lend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: bad loop chain", c);
+                const int ns = lp[1 + np];
+                if (ns < 0 || ns > k || lp + 3 + np + ns > lend) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: bad loop chain", c);
+                const int mask = lp[2 + np + ns];
+                for (int t = 0; t < np + ns; t++) {
+                    const int sub = lp[t < np ? 1 + t : 2 + t];
+                    if (sub < 0 || sub >= k) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop chain names body %d", c, sub);
+                }
                 for (int t = 0; t < 3 + np + ns; t++) P.cints.push_back(lp[t]);
                 lp += 3 + np + ns;
                 for (int a = 0; a < 3; a++) rows += (mask >> a) & 1;

@@ -15,14 +15,8 @@ if model == "tello":
 else:
     plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", model + ".urdf"))
 B = int(os.environ.get("PMC_BATCH", "262144"))
-q, qd, tau = random_states(plan.blob, B, 2)
-if model == "tello":  # valid spanning positions (Newton projection on the device), failures replaced
-    import numpy as np
-    t64 = torch.as_tensor(q, dtype=torch.float64, device="cuda:0")
-    ok = plan.project_positions(t64).cpu().numpy()
-    q = t64.cpu().numpy()
-    good, bad = np.flatnonzero(ok), np.flatnonzero(~ok)
-    q[bad] = q[good[np.arange(bad.size) % good.size]]
+from generalized_rbda_amd.states import valid_random_states_device
+q, qd, tau, _ = valid_random_states_device(plan, B, 2, "cuda:0")  # (implicit models: projected + gated, as bench.py)
 dt = torch.float32 if prec == 32 else torch.float64
 t = lambda a: torch.as_tensor(a, dtype=dt, device="cuda:0")
 tq, tqd, tt = t(q), t(qd), t(tau)
