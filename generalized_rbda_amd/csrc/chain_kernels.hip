@@ -910,16 +910,14 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
             for (int j = 0; j < 6; j++) psic[j] += tp[j];
         }
         const T Dinv = rcp_t(D);
-        T kb[9];  // [K 6][y0][sin][cos]
+        T kb[7];  // [K 6][y0]: what the acceleration run needs (it recomputes sin / cos from q: two slab rows less per link)
 #pragma unroll
         for (int r = 0; r < 6; r++) kb[r] = F[r] * Dinv;
         kb[6] = u * Dinv;
-        kb[7] = blk[0];
-        kb[8] = blk[1];
         M.glb_st(l.glb_k, kb);
-        if constexpr (OSIM) {
-            const T ex[1] = {Dinv};
-            M.glb_st(l.glb_k + 9, ex);
+        if constexpr (OSIM) {  // the force-propagator walk (osim_chain_kernel) reads [sin][cos][1 / D] behind the block
+            const T ex[3] = {blk[0], blk[1], Dinv};
+            M.glb_st(l.glb_k + 7, ex);
         }
 #pragma unroll
         for (int r = 0; r < 6; r++) {
@@ -980,17 +978,19 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
         }
     }
     ChainLink l = load_rec(P.links + sg.first);
-    T kb[9];
+    T kb[7];
     M.glb_ld(l.glb_k, kb);
-    T yd = M.qd(l.v_index);
+    T yd = M.qd(l.v_index), yq = l.has_child ? M.q(l.q_index) : T(0);
     for (int i = 0; i < sg.count; i++) {
-        // the next link's record, [K | y0 | sin | cos] block and velocity input travel while this link is computed
+        // the next link's record, [K | y0] block and inputs travel while this link is computed (the joint angle only for
+        // links with children: the others need no transform here)
         const bool more = i + 1 < sg.count;
         const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
-        T kn[9], ydn = 0;
+        T kn[7], ydn = 0, yqn = 0;
         if (more) {
             M.glb_ld(ln.glb_k, kn);
             ydn = M.qd(ln.v_index);
+            if (ln.has_child) yqn = M.q(ln.q_index);
         }
         T ydd = kb[6];
 #pragma unroll
@@ -1000,8 +1000,9 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
             cptr<T> C = P.consts + l.cofs;
             const T g0 = C[kBodyConstFixed];
             const T qdi = g0 * yd;
-            T E[9], v[6], a[6], chat[6];
-            rotate_z(kb[7], kb[8], C, E);
+            T E[9], v[6], a[6], chat[6], sn, cs;
+            sincos_t(g0 * yq, &sn, &cs);
+            rotate_z(sn, cs, C, E);
             xmotion(E, C + 9, vp, v);
             xmotion(E, C + 9, ap, a);
             v[2] += qdi;
@@ -1027,8 +1028,9 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
         if (more) {
             l = ln;
             yd = ydn;
+            yq = yqn;
 #pragma unroll
-            for (int j = 0; j < 9; j++) kb[j] = kn[j];
+            for (int j = 0; j < 7; j++) kb[j] = kn[j];
         }
     }
 }
