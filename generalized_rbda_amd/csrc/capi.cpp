@@ -1254,10 +1254,17 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const bool need_d = dq || dqd;
     // H is built in the caller's d/dtau array when that is wanted (the factor is out of it before H^-1 goes in); dID/dq and
     // dID/dqd in rnea_deriv_kernel's packed layout, the H nobody asked for, and ydd take workspace
-    const size_t per_state = (dtau ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
+    const bool h_in_place = dtau && (B % kDerivGroup) == 0;
+    const size_t per_state = (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
     size_t chunk = (2048ull << 20) / (per_state ? per_state * sizeof(T) : 1);
-    if (chunk < 1) chunk = 1;
-    if (chunk > B) chunk = B;
+    chunk &= ~static_cast<size_t>(kWave - 1);  // whole tiles, whole groups of the interleaved workspace
+    if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
+    if (chunk > B) chunk = (B + kDerivGroup - 1) / kDerivGroup * kDerivGroup;  // (the last group of the workspace is allocated whole)
+    // f32 with the matrix-core solve: the recursion writes H, dID/dq, dID/dqd interleaved by groups of kDerivGroup states
+    // (deriv_kernels.hip); every other combination keeps the state-major layout
+    const bool wide0 = sizeof(T) == 4 && p->solve_f64;
+    const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
+    const int il = (need_d && !wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
     void *wptr = nullptr;
     {
         std::lock_guard<std::recursive_mutex> lk(p->mu);
@@ -1280,14 +1287,16 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         wnext += chunk * nn;
         return r;
     };
-    T *wH = take(!dtau), *Dq = take(need_d), *Dqd = take(need_d);
+    T *wH = take(!h_in_place), *Dq = take(need_d), *Dqd = take(need_d);
     T *ydd = wnext;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
     for (size_t b0 = 0; b0 < B; b0 += chunk) {
         const size_t nb = B - b0 < chunk ? B - b0 : chunk;
         const size_t n_tiles = (nb + kWave - 1) / kWave;
-        T *H = dtau ? dtau + b0 * nn : wH;
+        // (an interleaved H block spans the slots of a whole group: when the batch does not end on a group boundary the last
+        // group would reach past the caller's d/dtau array, so that H goes to the workspace)
+        T *H = (dtau && !(il > 1 && (B % kDerivGroup) != 0)) ? dtau + b0 * nn : wH;
         hipError_t e = hipSuccess;
         // (both kernels write H as packed rows of its lower triangle; the solve reads it through DerivProgram::related, so
         // nothing is cleared)
@@ -1296,7 +1305,8 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         size_t grid = static_cast<size_t>(t->n_cu) * 8;
         if (grid > n_tiles) grid = n_tiles;
         const size_t rows = std::max(p->host.crba.n_rows, need_d ? p->host.deriv.n_rows : 0);
-        const size_t deriv_waves = p->deriv_waves ? static_cast<size_t>(p->deriv_waves) : 3;
+        // (state-major results: three wavefronts per CU -- a fourth only adds open cache lines; interleaved: one per SIMD)
+        const size_t deriv_waves = p->deriv_waves ? static_cast<size_t>(p->deriv_waves) : (il > 1 ? 4 : 3);
         const size_t slabs = std::max(grid, static_cast<size_t>(t->n_cu) * deriv_waves);
         void *scratch = nullptr;
         if (int rc = ensure_scratch(p, device, stream, slabs * rows * kWave * sizeof(T) + 256, &scratch)) return rc;
@@ -1305,7 +1315,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             size_t g2 = static_cast<size_t>(t->n_cu) * deriv_waves;
             if (g2 > n_tiles) g2 = n_tiles;
             e = launch_rnea_deriv<T>(d, t->deriv_bodies, p->host.n_clusters, p->host.deriv.n_rows, p->host.deriv.n_max, q + b0 * nq,
-                                     qd + b0 * nv, ydd, Dq, Dqd, H, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs);
+                                     qd + b0 * nv, ydd, Dq, Dqd, H, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, il);
             if (e != hipSuccess) return hip_err(e, "rnea derivative launch");
         } else {
             e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, H, nb, static_cast<T *>(scratch),
@@ -1316,19 +1326,23 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         const bool wide = sizeof(T) == 4 && p->solve_f64;
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), wide ? 8 : sizeof(T), (dq ? 1 : 0) + (dqd ? 1 : 0));
         size_t per_cu = lds ? (160u * 1024u) / lds : 16;
-        if (per_cu > 16) per_cu = 16;
+        const bool mfma = !wide && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs);
+        if (per_cu > (mfma ? 2u : 16u)) per_cu = mfma ? 2 : 16;  // (matrix-core kernel: workgroups of four wavefronts, two wavefronts per SIMD)
         if (per_cu < 1) per_cu = 1;
         size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
-        if (g3 > nb) g3 = nb;
+        const size_t units = mfma ? (nb + kDerivGroup - 1) / kDerivGroup : nb;
+        if (g3 > units) g3 = units;
         T *o1 = dq ? dq + b0 * nn : nullptr, *o2 = dqd ? dqd + b0 * nn : nullptr, *o3 = dtau ? dtau + b0 * nn : nullptr;
         const T *r1 = dq ? Dq : nullptr, *r2 = dqd ? Dqd : nullptr;
         const uint64_t *rel = t->deriv_related;
         const int nvi = static_cast<int>(nv), g3i = static_cast<int>(g3), hp = 1;
+        // (H comes from the CRBA kernel, state-major, when no right-hand side is wanted)
+        const int sil = need_d ? il : 1;
         if constexpr (sizeof(T) == 4) {
-            if (wide) e = launch_spd_solve<float, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs);
-            else e = launch_spd_solve<float, float>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs);
+            if (wide) e = launch_spd_solve<float, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, 1);
+            else e = launch_spd_solve<float, float>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, sil);
         } else {
-            e = launch_spd_solve<double, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs);
+            e = launch_spd_solve<double, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, 1);
         }
         if (e != hipSuccess) return hip_err(e, "spd solve launch");
     }

@@ -185,7 +185,14 @@ struct PartStore {
     }
 };
 
-template <class T, int NMAX>
+// IL: interleave factor of the result workspace.  1: state-major, [state][entry].  kDerivGroup (= 4): [group of 4 states][entry][4]
+// -- what the matrix-core solve reads.  With one state per lane a store instruction of the state-major layout opens 64 cache
+// lines per result stream, 192 per wavefront; they do not survive in L2 until their other 31 entries arrive, are written back
+// partially and fetched again: 35 KB written and 30 KB fetched per JVRC-1 state for 14.4 KB of results, 3.9 TB/s -- the kernel
+// was bound by that (round 3, calibrated FETCH_SIZE / WRITE_SIZE).  Interleaving four states makes every store a run of
+// 16-byte pieces, a quarter of the open lines (measured 2.2 -> 1.45 ms per 131 072 states at four wavefronts per CU;
+// factors 8, 16 and 64 add 2-4 % more and cost the solve its cooperative 4-wavefront copy).
+template <class T, int NMAX, int IL>
 __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
                                                               const T *__restrict__ q, const T *__restrict__ qd,
                                                               const T *__restrict__ ydd, T *__restrict__ Dq, T *__restrict__ Dqd,
@@ -213,16 +220,18 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
         // ancestor by ancestor) lands in that coordinate's run, so a cache line is completed by consecutive instructions
         // instead of being revisited from every descendant (the scattered transposed stores of the plain layout cost 2 of
         // 6.6 ms on JVRC-1); spd_solve_kernel reads column c as entry c of the runs r >= c, and the second half of run c.
-        T *Dqs = Dq + st * (size_t)nv * nv, *Dqds = Dqd + st * (size_t)nv * nv;
+        // (interleaved: state r sits at sub-position r % IL of group r / IL; groups are IL * nv^2 entries apart)
+        const size_t grp_of = st / IL, sub_of = st % IL;
+        T *Dqs = Dq + grp_of * (size_t)nv * nv * IL + sub_of, *Dqds = Dqd + grp_of * (size_t)nv * nv * IL + sub_of;
         // the joint-space inertia matrix falls out of the same composites: H[k][j] = S_j . (Ic_k S_k) for j ancestor of or
         // equal to k (the CRBA in the common frame); the rows of its lower triangle, back to back, when the caller wants it
-        T *Hs = H ? H + st * (size_t)nv * nv : nullptr;
+        T *Hs = H ? H + grp_of * (size_t)nv * nv * IL + sub_of : nullptr;
         auto put = [&](T *P, int r, int c, T v) {
-            if (c <= r) P[r * r + c] = v;
-            else P[c * c + c + 1 + r] = v;
+            if (c <= r) P[(size_t)(r * r + c) * IL] = v;
+            else P[(size_t)(c * c + c + 1 + r) * IL] = v;
         };
         auto put_h = [&](int r, int c, T v) {
-            if (Hs && c <= r) Hs[r * (r + 1) / 2 + c] = v;
+            if (Hs && c <= r) Hs[(size_t)(r * (r + 1) / 2 + c) * IL] = v;
         };
         // gravity as the acceleration of the frame F (TreeModel.cpp:40-43: a_root = -gravity), base velocity
         T a0[6], vb[6];
@@ -710,26 +719,37 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
     }
 }
 
-template <class T>
-hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
-                             const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream)
+template <class T, int IL>
+static hipError_t launch_rnea_deriv_il(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q,
+                                       const T *qd, const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream)
 {
     const size_t part_lds = sizeof(T) == 8 ? 63 * kWave * sizeof(T) : 0;  // PartStore
     if (n_max <= 1)
-        hipLaunchKernelGGL((rnea_deriv_kernel<T, 1>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, IL>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
     else if (n_max <= 2)
-        hipLaunchKernelGGL((rnea_deriv_kernel<T, 2>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, 2, IL>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
     else
-        hipLaunchKernelGGL((rnea_deriv_kernel<T, kMaxClusterDof>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd,
-                           ydd, Dq, Dqd, H, B, scratch);
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, kMaxClusterDof, IL>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q,
+                           qd, ydd, Dq, Dqd, H, B, scratch);
     return hipGetLastError();
 }
+template <class T>
+hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
+                             const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream, int interleave)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (interleave == kDerivGroup)
+            return launch_rnea_deriv_il<T, kDerivGroup>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
+    }
+    if (interleave != 1) return hipErrorInvalidValue;
+    return launch_rnea_deriv_il<T, 1>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
+}
 template hipError_t launch_rnea_deriv<float>(const DevPlan<float> &, const DerivBody *, int, int, int, const float *, const float *,
-                                             const float *, float *, float *, float *, size_t, float *, int, hipStream_t);
+                                             const float *, float *, float *, float *, size_t, float *, int, hipStream_t, int);
 template hipError_t launch_rnea_deriv<double>(const DevPlan<double> &, const DerivBody *, int, int, int, const double *, const double *,
-                                              const double *, double *, double *, double *, size_t, double *, int, hipStream_t);
+                                              const double *, double *, double *, double *, size_t, double *, int, hipStream_t, int);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Batched SPD solve, one state per wavefront.  Lane i holds row i of H, then of its Cholesky factor L (left-looking by
@@ -744,11 +764,19 @@ template hipError_t launch_rnea_deriv<double>(const DevPlan<double> &, const Der
 // `related` (DerivProgram::related, may be null): the entries that are not structural zeros; the others are not used,
 // whatever the arrays hold.  Global traffic: every matrix read / written once.  TIO: array element type; TC: arithmetic.
 // ---------------------------------------------------------------------------------------------------------------
-// f32 solves run on the matrix cores (spd_mfma_kernel) unless GRBDA_SOLVE_VALU=1 keeps the triangular solves (A/B runs)
-bool spd_solve_on_mfma(size_t elem)
+// f32 solves run on the matrix cores (spd_mfma_kernel) when a workgroup's tiles and right-hand sides fit the LDS of a CU (nv <= 48
+// with two right-hand sides) and GRBDA_SOLVE_VALU=1 does not keep the triangular solves (A/B runs)
+static size_t spd_mfma_lds_bytes(int nv, int n_rhs)
+{
+    const int nvb = nv <= 16 ? 16 : (nv <= 24 ? 24 : (nv <= 32 ? 32 : (nv <= 40 ? 40 : (nv <= 48 ? 48 : 64))));
+    const int nt = (nvb + 15) / 16, ws = nt == 1 ? 16 : (nt <= 3 ? 48 : 80);
+    // per WORKGROUP of kDerivGroup wavefronts; the H block is staged where the right-hand sides go
+    return static_cast<size_t>(kDerivGroup) * (static_cast<size_t>(nvb) * ws + static_cast<size_t>(n_rhs > 1 ? n_rhs : 1) * nv * nv) * 4;
+}
+bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs)
 {
     static const bool valu = [] { const char *e = std::getenv("GRBDA_SOLVE_VALU"); return e && std::atoi(e) != 0; }();
-    return elem == 4 && !valu;
+    return elem == 4 && !valu && nv <= kWave && spd_mfma_lds_bytes(nv, n_rhs) <= 160u * 1024u;
 }
 size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
 
@@ -933,20 +961,26 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same solve on the matrix cores (f32): one state per wavefront.
+// The same solve on the matrix cores (f32).  A workgroup is kDerivGroup = 4 wavefronts and takes one GROUP of four states at
+// a time, one state per wavefront; the group's inputs are one contiguous block of memory -- [entry][4] when the derivative
+// recursion wrote them (interleaved workspace, see rnea_deriv_kernel), [state][entry] when H comes from the CRBA kernel or
+// the caller -- which the four wavefronts copy into LDS together, 16 bytes per lane and instruction, fully coalesced.
+// Per wavefront:
 //   1. Cholesky factor of H as above (row i in lane i, v_readlane), rows of L^T to LDS;
 //   2. W = L^-1 by forward substitution on the identity (column j in lane j), written to LDS;
 //   3. H^-1 = W^T W              v_mfma_f32_16x16x4_f32, NT x NT tiles of 16 x 16, W lower triangular: tile (mt, nt) only
 //                                sums over rows >= 16 max(mt, nt);
 //   4. [X1 | X2] = -H^-1 [P1 | P2]   the same instruction; A fragments from the H^-1 tile in LDS (symmetric: read by rows),
-//                                B fragments gathered from the PACKED right-hand sides (rnea_deriv_kernel's runs), which an
-//                                asynchronous global -> LDS copy put next to it while 1. - 3. ran; structural zeros
-//                                (DerivProgram::related) and the padding are masked to 0 at the gather.
-// 2 nv^2 (nv + n_rhs) flops per state go through 16 x 16 x 4 tiles (JVRC-1: 38 + 150 MFMAs) instead of ~5 000 VALU
-// instructions of triangular solves; what stays on the VALU is the factorisation and the inversion of the factor
-// (~nv^2 FMAs + nv^2 / 2 v_readlane).  Fragment maps (cdna_hip_programming.md 3): A[l & 15][l >> 4], B[l >> 4][l & 15],
-// D: column l & 15, rows 4 (l >> 4) + 0..3.  LDS rows have a stride of WS floats with WS = 16 (mod 32) so that the four
-// 16-lane groups of a fragment read (rows 4k .. 4k + 3) fall into different banks.
+//                                B fragments gathered from the group's PACKED right-hand sides (rnea_deriv_kernel's runs) in
+//                                LDS; structural zeros (DerivProgram::related) and the padding are masked to 0 at the gather.
+// The group's H block is staged in the LDS region of the right-hand sides first (every lane takes its row from there), then
+// the right-hand sides are copied over it while steps 1 - 3 run.  2 nv^2 (nv + n_rhs) flops per state go through 16 x 16 x 4
+// tiles (JVRC-1: 38 + 150 MFMAs) instead of ~5 000 VALU instructions of triangular solves; what stays on the VALU is the
+// factorisation and the inversion of the factor (~nv^2 FMAs + nv^2 / 2 v_readlane).  Fragment maps
+// (cdna_hip_programming.md 3): A[l & 15][l >> 4], B[l >> 4][l & 15], D: column l & 15, rows 4 (l >> 4) + 0..3.  LDS rows of
+// the tile have a stride of WS floats with WS = 16 (mod 32): the four 16-lane groups of a fragment read (rows 4k .. 4k + 3)
+// fall into different banks.  LDS per workgroup: 4 NVV WS floats of tiles + 4 n_rhs nv^2 of right-hand sides (JVRC-1:
+// 30.7 + 46.2 KB, two workgroups per CU).
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef GRBDA_EXP_MF_PROF
@@ -957,23 +991,27 @@ __device__ unsigned long long mf_prof[8];
 #endif
 
 template <int NVV>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NVV > 48 ? 1 : 2, 2)))
-void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float *P2, float *Hinv, float *X1, float *X2,
+__global__ __launch_bounds__(kWave * kDerivGroup) __attribute__((amdgpu_waves_per_eu(NVV > 48 ? 1 : 2, 2)))
+void spd_mfma_kernel(const float *H, int h_packed, int h_il, const float *P1, const float *P2, int p_il, float *Hinv, float *X1, float *X2,
                      const uint64_t *__restrict__ related, int nv, size_t B)
 {
     constexpr int NT = (NVV + 15) / 16;               // row / column tiles of H^-1
     constexpr int WS = NT == 1 ? 16 : (NT <= 3 ? 48 : 80);
     constexpr int NCT = (2 * NVV + 15) / 16;          // column tiles of [P1 | P2]
     constexpr int KS = NVV / 4;                       // k steps
+    constexpr int G = kDerivGroup;
     static_assert(NVV % 8 == 0 && NT * 16 <= WS, "sizes");
-    float *A = reinterpret_cast<float *>(grbda_smem);  // [NT * 16][WS]: rows of L^T, then W = L^-1, then H^-1
-    float *Pk = A + NT * 16 * WS;                      // packed right-hand sides, n_mat * nv * nv
-    const int lane = threadIdx.x, g = lane >> 4, c16 = lane & 15;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     const int nn = nv * nv;
+    float *A = reinterpret_cast<float *>(grbda_smem) + wave * (NVV * WS);  // this wavefront's tile: rows of L^T, then W, then H^-1
+    float *Pg = reinterpret_cast<float *>(grbda_smem) + G * (NVV * WS);   // the group's H block, then its right-hand sides
     const float *src[2] = {P1 ? P1 : P2, P1 ? P2 : nullptr};
     float *dst[2] = {P1 ? X1 : X2, P1 ? X2 : nullptr};
     const int n_mat = (P1 ? 1 : 0) + (P2 ? 1 : 0);
     const int n_cols = n_mat * nv, nct = (n_cols + 15) / 16;
+    // element e of this wavefront's state inside a group block: interleaved [entry][G] or state-major [state][entry]
+    const int h_es = h_il == G ? G : 1, h_ss = h_il == G ? 1 : nn;
+    const int p_es = p_il == G ? G : 1, p_ss = p_il == G ? 1 : nn;
     auto factor_row = [&](int k, int from, float(&l)[NVV]) {
 #pragma unroll
         for (int i = (from / 4) * 4; i < NVV; i += 4) {
@@ -982,7 +1020,23 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
             for (int e = 0; e < 4; e++) l[i + e] = v[e];
         }
     };
-    // per column tile of the right-hand sides: where this lane's column lives in the packed copy
+    // the four wavefronts copy `count` floats from `from` (16-byte aligned when count % 4 == 0 and the block is) to LDS at `to`
+    auto group_copy = [&](const float *from, float *to, int count) {
+        const unsigned *blk = reinterpret_cast<const unsigned *>(from);
+        if ((count & 3) == 0 && (reinterpret_cast<uintptr_t>(from) & 15) == 0) {
+            for (int base = wave * 4 * kWave; base < count; base += G * 4 * kWave)
+                if (base + 4 * lane < count)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + 4 * lane),
+                                                     (__attribute__((address_space(3))) void *)(to + base), 16, 0, 0);
+        } else {
+            for (int base = wave * kWave; base < count; base += G * kWave)
+                if (base + lane < count)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + lane),
+                                                     (__attribute__((address_space(3))) void *)(to + base), 4, 0, 0);
+        }
+    };
+    // per column tile of the right-hand sides: where this lane's column lives in the packed copy (entry index, before the
+    // layout's element stride)
     int lo_base[NCT], hi_base[NCT], ccol[NCT], mat[NCT];
     uint64_t rel[NCT];
 #pragma unroll
@@ -992,70 +1046,52 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
         const int m = (valid && c >= nv) ? 1 : 0, cc = valid ? c - m * nv : 0;
         mat[t] = valid ? m : -1;
         ccol[t] = cc;
-        lo_base[t] = m * nn + cc;
-        hi_base[t] = m * nn + cc * cc + cc + 1;
+        lo_base[t] = cc;
+        hi_base[t] = cc * cc + cc + 1;
         rel[t] = valid ? (related ? related[cc] : ~uint64_t(0)) : uint64_t(0);
     }
     const uint64_t rel_mine = related ? related[lane < nv ? lane : 0] : ~uint64_t(0);
+    const size_t n_groups = (B + G - 1) / G;
 #ifdef GRBDA_EXP_MF_PROF
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
 #endif
-    for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
-        // ---- 0. the packed right-hand sides on their way to LDS (nobody reads Pk before step 4) ----
-        wave_lds_fence();  // the previous state's fragment reads are done
-        for (int m = 0; m < n_mat; m++) {
-            const unsigned *blk = reinterpret_cast<const unsigned *>(src[m] + s * (size_t)nn);
-            if ((nn & 3) == 0) {  // 16 bytes per lane and instruction (1 KiB per wave instruction): nv even
-                for (int base = 0; base < nn; base += 4 * kWave)
-                    if (base + 4 * lane < nn)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + 4 * lane),
-                                                         (__attribute__((address_space(3))) void *)(Pk + m * nn + base), 16, 0, 0);
-            } else {
-                for (int base = 0; base < nn; base += kWave)
-                    if (base + lane < nn)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + base + lane),
-                                                         (__attribute__((address_space(3))) void *)(Pk + m * nn + base), 4, 0, 0);
+    for (size_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const size_t s = grp * G + wave;
+        const bool live = s < B;  // (a wavefront past the end of the batch works on whatever LDS holds and stores nothing)
+        const int n_valid = (int)(B - grp * G < (size_t)G ? B - grp * G : (size_t)G);
+        // ---- 0. the group's H block into LDS; every lane takes its row of H ----
+        __syncthreads();  // the previous group's fragment reads are done
+        // (interleaved blocks are whole by construction of the workspace; a state-major block ends with the batch)
+        group_copy(H + grp * (size_t)G * nn, Pg, (h_il == G ? G : n_valid) * nn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        MF_STAMP(0)
+        float Lr[NVV];  // row `lane` of H, then of L; the diagonal entry holds 1 / L[k][k]
+        {
+            const int lrow = lane < nv ? lane : 0;
+            const float *hrow = Pg + (size_t)(h_packed ? lrow * (lrow + 1) / 2 : lrow * nv) * h_es + wave * h_ss;
+#pragma unroll
+            for (int j = 0; j < NVV; j++) {
+                const float h = (j < nv && j <= lrow) ? hrow[j * h_es] : 0.0f;
+                Lr[j] = (lane < nv && j < nv) ? ((j <= lane && ((rel_mine >> j) & 1)) ? h : 0.0f) : (lane == j ? 1.0f : 0.0f);
             }
         }
-        MF_STAMP(0)  // fence + DMA issue
-        // ---- 1. Cholesky: row `lane` of H, then of L; the diagonal entry holds 1 / L[k][k] ----
-        {
-            float Lr[NVV];
-            const size_t lrow = lane < nv ? lane : 0;
-            const float *hp = H + s * (size_t)nn + (h_packed ? lrow * (lrow + 1) / 2 : lrow * nv);
-            float hrow[NVV];  // (16-byte loads; a packed row runs on into the next rows: masked below)
+        __syncthreads();  // every wavefront has its H: the right-hand sides may land over the block
+        for (int m = 0; m < n_mat; m++) group_copy(src[m] + grp * (size_t)G * nn, Pg + (size_t)m * G * nn, (p_il == G ? G : n_valid) * nn);
+        MF_STAMP(1)
+        // ---- 1. Cholesky ----
 #pragma unroll
-            for (int i = 0; i < NVV; i += 4) {
-                if (i + 4 <= nv) {
-                    f32x4 v;
-                    __builtin_memcpy(&v, hp + i, sizeof v);
+        for (int k = 0; k < NVV; k++) {
+            float sum = Lr[k];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) hrow[i + e] = v[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) hrow[i + e] = (i + e < nv) ? hp[i + e] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NVV; j++)
-                Lr[j] = (lane < nv && j < nv) ? ((j <= lane && ((rel_mine >> j) & 1)) ? hrow[j] : 0.0f) : (lane == j ? 1.0f : 0.0f);
-#ifdef GRBDA_EXP_MF_PROF
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            MF_STAMP(1)  // H row load
-#endif
-#pragma unroll
-            for (int k = 0; k < NVV; k++) {
-                float sum = Lr[k];
-#pragma unroll
-                for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
-                const float d = lane_value(sum, k);
-                const float r = inv_sqrt(d);
-                Lr[k] = lane == k ? r : sum * r;
-                if (lane >= k && lane < NVV) A[k * WS + lane] = Lr[k];
-            }
+            for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
+            const float d = lane_value(sum, k);
+            const float r = inv_sqrt(d);
+            Lr[k] = lane == k ? r : sum * r;
+            if (lane >= k && lane < NVV) A[k * WS + lane] = Lr[k];
         }
         wave_lds_fence();
-        MF_STAMP(2)  // Cholesky
+        MF_STAMP(2)
         // ---- 2. W = L^-1: column `lane`, forward substitution by columns of L (rows of the stored L^T) ----
         {
             float x[NVV], l[NVV];
@@ -1077,12 +1113,12 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
             wave_lds_fence();  // every row of L^T has been read: W goes over it
             if (lane < NT * 16) {
 #pragma unroll
-                for (int i = 0; i < NT * 16; i++) A[i * WS + lane] = i < NVV ? (lane < NVV ? x[i < NVV ? i : 0] : 0.0f) : 0.0f;
+                for (int i = 0; i < NVV; i++) A[i * WS + lane] = lane < NVV ? x[i] : 0.0f;
             }
         }
         wave_lds_fence();
-        MF_STAMP(3)  // L^-1
-        // ---- 3. H^-1 = W^T W ----
+        MF_STAMP(3)
+        // ---- 3. H^-1 = W^T W (rows and columns NVV .. 16 NT - 1 of the tile are padding: never stored, read as zero) ----
         f32x4 hi[NT][NT];
 #pragma unroll
         for (int a = 0; a < NT; a++)
@@ -1099,8 +1135,8 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
                 for (int b = 0; b < NT; b++)
                     if (16 * (a > b ? a : b) <= 4 * k + 3) hi[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a], w[b], hi[a][b], 0, 0, 0);
         }
-        // the packed right-hand sides have long arrived; waiting for them HERE, before the H^-1 stores are issued, keeps the
-        // wait from also draining those stores (loads and stores share the counter)
+        // the right-hand sides have long arrived; waiting for them HERE, before the H^-1 stores are issued, keeps the wait from
+        // also draining those stores (loads and stores share the counter)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_fence();  // W has been read: H^-1 goes over it
 #pragma unroll
@@ -1110,18 +1146,19 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int row = 16 * a + 4 * g + j, col = 16 * b + c16;
-                    A[row * WS + col] = hi[a][b][j];
-                    if (Hinv && row < nv && col < nv) Hinv[s * (size_t)nn + (size_t)row * nv + col] = hi[a][b][j];
+                    if (row < NVV) A[row * WS + col] = hi[a][b][j];
+                    if (Hinv && live && row < nv && col < nv) Hinv[s * (size_t)nn + (size_t)row * nv + col] = hi[a][b][j];
                 }
-        MF_STAMP(4)  // GEMM 1, wait for the copy, H^-1 to LDS and to global
+        MF_STAMP(4)
         if (n_mat == 0) continue;
-        wave_lds_fence();
+        __syncthreads();  // every wavefront's part of the copy has landed (and this wavefront's H^-1 is in LDS)
         // ---- 4. X = -H^-1 [P1 | P2] ----
         f32x4 acc[NT][NCT];
 #pragma unroll
         for (int a = 0; a < NT; a++)
 #pragma unroll
             for (int t = 0; t < NCT; t++) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *Pw = Pg + wave * p_ss;
 #pragma unroll
         for (int k = 0; k < KS; k++) {
             int r = 4 * k + g;
@@ -1135,8 +1172,8 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
             for (int t = 0; t < NCT; t++) {
                 if (t < nct) {
                     const bool ok = (rel[t] >> r) & 1;  // bit r of related[column]: r < nv, the column exists, not a structural zero
-                    const int addr = ccol[t] <= r ? r2 + lo_base[t] : r + hi_base[t];
-                    const float v = Pk[ok ? addr : 0];
+                    const int idx = ccol[t] <= r ? r2 + lo_base[t] : r + hi_base[t];
+                    const float v = Pw[ok ? (mat[t] * G * nn + idx * p_es) : 0];
                     bv[t] = ok ? v : 0.0f;
                 }
             }
@@ -1147,10 +1184,10 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
                     for (int a = 0; a < NT; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
                 }
         }
-        MF_STAMP(5)  // GEMM 2
+        MF_STAMP(5)
 #pragma unroll
         for (int t = 0; t < NCT; t++)
-            if (t < nct && mat[t] >= 0) {
+            if (t < nct && mat[t] >= 0 && live) {
                 float *out = dst[mat[t]] + s * (size_t)nn + ccol[t];
 #pragma unroll
                 for (int a = 0; a < NT; a++)
@@ -1160,7 +1197,7 @@ void spd_mfma_kernel(const float *H, int h_packed, const float *P1, const float 
                         if (row < nv) out[(size_t)row * nv] = -acc[a][t][j];
                     }
             }
-        MF_STAMP(6)  // result stores (issue)
+        MF_STAMP(6)
     }
 #ifdef GRBDA_EXP_MF_PROF
     if (lane == 0)
@@ -1180,10 +1217,10 @@ extern "C" int grbda_debug_mf_prof(unsigned long long *out, int reset)
 #endif
 
 template <int NVV>
-static hipError_t launch_spd_mfma_n(const float *H, int h_packed, const float *P1, const float *P2, float *Hinv, float *X1, float *X2,
-                                    const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
+static hipError_t launch_spd_mfma_n(const float *H, int h_packed, int h_il, const float *P1, const float *P2, int p_il, float *Hinv, float *X1,
+                                    float *X2, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
 {
-    const size_t lds = spd_solve_lds_bytes(nv, 4, (P1 ? 1 : 0) + (P2 ? 1 : 0));
+    const size_t lds = spd_mfma_lds_bytes(nv, (P1 ? 1 : 0) + (P2 ? 1 : 0));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_mfma_kernel<NVV>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1191,18 +1228,19 @@ static hipError_t launch_spd_mfma_n(const float *H, int h_packed, const float *P
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((spd_mfma_kernel<NVV>), dim3(grid), dim3(kWave), lds, stream, H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B);
+    hipLaunchKernelGGL((spd_mfma_kernel<NVV>), dim3(grid), dim3(kWave * kDerivGroup), lds, stream, H, h_packed, h_il, P1, P2, p_il, Hinv, X1,
+                       X2, related, nv, B);
     return hipGetLastError();
 }
-static hipError_t launch_spd_mfma(const float *H, int h_packed, const float *P1, const float *P2, float *Hinv, float *X1, float *X2,
-                                  const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
+static hipError_t launch_spd_mfma(const float *H, int h_packed, int h_il, const float *P1, const float *P2, int p_il, float *Hinv, float *X1,
+                                  float *X2, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
 {
-    if (nv <= 16) return launch_spd_mfma_n<16>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
-    if (nv <= 24) return launch_spd_mfma_n<24>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
-    if (nv <= 32) return launch_spd_mfma_n<32>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
-    if (nv <= 40) return launch_spd_mfma_n<40>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
-    if (nv <= 48) return launch_spd_mfma_n<48>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
-    if (nv <= 64) return launch_spd_mfma_n<64>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 16) return launch_spd_mfma_n<16>(H, h_packed, h_il, P1, P2, p_il, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 24) return launch_spd_mfma_n<24>(H, h_packed, h_il, P1, P2, p_il, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 32) return launch_spd_mfma_n<32>(H, h_packed, h_il, P1, P2, p_il, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 40) return launch_spd_mfma_n<40>(H, h_packed, h_il, P1, P2, p_il, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 48) return launch_spd_mfma_n<48>(H, h_packed, h_il, P1, P2, p_il, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 64) return launch_spd_mfma_n<64>(H, h_packed, h_il, P1, P2, p_il, Hinv, X1, X2, related, nv, B, grid, stream);
     return hipErrorInvalidValue;
 }
 
@@ -1224,13 +1262,16 @@ static hipError_t launch_spd_solve_n(const TIO *H, int h_packed, const TIO *P1, 
                        B);
     return hipGetLastError();
 }
+// interleave: layout of H, P1, P2 -- 1 state-major, kDerivGroup the interleaved workspace of rnea_deriv_kernel (matrix-core kernel only)
 template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
-                            int nv, size_t B, int grid, hipStream_t stream)
+                            int nv, size_t B, int grid, hipStream_t stream, int interleave)
 {
     if constexpr (sizeof(TIO) == 4 && sizeof(TC) == 4) {
-        if (spd_solve_on_mfma(4)) return launch_spd_mfma(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+        if (spd_solve_on_mfma(4, nv, (P1 ? 1 : 0) + (P2 ? 1 : 0)))
+            return launch_spd_mfma(H, h_packed, interleave, P1, P2, interleave, Hinv, X1, X2, related, nv, B, grid, stream);
     }
+    if (interleave != 1) return hipErrorInvalidValue;
     if (nv <= 16) return launch_spd_solve_n<TIO, TC, 16>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
     if (nv <= 24) return launch_spd_solve_n<TIO, TC, 24>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
     if (nv <= 32) return launch_spd_solve_n<TIO, TC, 32>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
@@ -1240,21 +1281,18 @@ hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO
     return hipErrorInvalidValue;
 }
 template hipError_t launch_spd_solve<float, float>(const float *, int, const float *, const float *, float *, float *, float *, const uint64_t *,
-                                                   int, size_t, int, hipStream_t);
+                                                   int, size_t, int, hipStream_t, int);
 template hipError_t launch_spd_solve<float, double>(const float *, int, const float *, const float *, float *, float *, float *,
-                                                    const uint64_t *, int, size_t, int, hipStream_t);
+                                                    const uint64_t *, int, size_t, int, hipStream_t, int);
 template hipError_t launch_spd_solve<double, double>(const double *, int, const double *, const double *, double *, double *, double *,
-                                                     const uint64_t *, int, size_t, int, hipStream_t);
+                                                     const uint64_t *, int, size_t, int, hipStream_t, int);
 
-// LDS of one workgroup of the solve: the factor at the compile-time size the launch picks for nv (VALU kernel), or the
-// [16 NT][WS] matrix tile plus the packed right-hand sides (matrix-core kernel)
+// LDS of one workgroup of the solve: the [NVV][WS] tiles of its four wavefronts plus the group's right-hand sides (matrix-core
+// kernel), or the factor at the compile-time size the launch picks for nv (VALU kernel, one wavefront)
 size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs)
 {
+    if (spd_solve_on_mfma(elem, nv, n_rhs)) return spd_mfma_lds_bytes(nv, n_rhs);
     const int nvb = nv <= 16 ? 16 : (nv <= 24 ? 24 : (nv <= 32 ? 32 : (nv <= 40 ? 40 : (nv <= 48 ? 48 : 64))));
-    if (spd_solve_on_mfma(elem)) {
-        const int nt = (nvb + 15) / 16, ws = nt == 1 ? 16 : (nt <= 3 ? 48 : 80);
-        return (static_cast<size_t>(nt) * 16 * ws + static_cast<size_t>(n_rhs) * nv * nv) * 4;
-    }
     return static_cast<size_t>(nvb) * nvb * elem;
 }
 

@@ -141,13 +141,16 @@ template <class T>
 hipError_t launch_unpack_symmetric(T *H, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream);
 
 // inverse-dynamics derivatives and the batched SPD solve behind d ydd / d (q, qd, tau) (deriv_kernels.hip)
+// states per group of the interleaved derivative workspace ([group][entry][kDerivGroup]) = wavefronts per workgroup of the
+// matrix-core solve (deriv_kernels.hip)
+constexpr int kDerivGroup = 4;
 template <class T>
 hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
-                             const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream);
+                             const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream, int interleave);
 template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
-                            int nv, size_t B, int grid, hipStream_t stream);
+                            int nv, size_t B, int grid, hipStream_t stream, int interleave);
 size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
-bool spd_solve_on_mfma(size_t elem);
+bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
 
 }  // namespace grbda_hip
