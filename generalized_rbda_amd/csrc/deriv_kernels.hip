@@ -1006,7 +1006,7 @@ void spd_mfma_kernel(const float *H, int h_packed, int h_il, const float *P1, co
     float *A = reinterpret_cast<float *>(grbda_smem) + wave * (NVV * WS);  // this wavefront's tile: rows of L^T, then W, then H^-1
     float *Pg = reinterpret_cast<float *>(grbda_smem) + G * (NVV * WS);   // the group's H block, then its right-hand sides
     const float *src[2] = {P1 ? P1 : P2, P1 ? P2 : nullptr};
-    float *dst[2] = {P1 ? X1 : X2, P1 ? X2 : nullptr};
+    float *const dst0 = P1 ? X1 : X2, *const dst1 = P1 ? X2 : nullptr;
     const int n_mat = (P1 ? 1 : 0) + (P2 ? 1 : 0);
     const int n_cols = n_mat * nv, nct = (n_cols + 15) / 16;
     // element e of this wavefront's state inside a group block: interleaved [entry][G] or state-major [state][entry]
@@ -1147,8 +1147,27 @@ void spd_mfma_kernel(const float *H, int h_packed, int h_il, const float *P1, co
                 for (int j = 0; j < 4; j++) {
                     const int row = 16 * a + 4 * g + j, col = 16 * b + c16;
                     if (row < NVV) A[row * WS + col] = hi[a][b][j];
-                    if (Hinv && live && row < nv && col < nv) Hinv[s * (size_t)nn + (size_t)row * nv + col] = hi[a][b][j];
                 }
+        if (Hinv && live) {
+            // H^-1 is symmetric: the four values a lane holds of tile (a, b) -- rows 16 a + 4 g + 0..3 of column 16 b + c16 -- are
+            // also columns 16 a + 4 g + 0..3 of ROW 16 b + c16: one 16-byte store instead of four 4-byte ones
+            float *hout = Hinv + s * (size_t)nn;
+#pragma unroll
+            for (int a = 0; a < NT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++) {
+                    const int row = 16 * b + c16, col0 = 16 * a + 4 * g;
+                    if (row < nv) {
+                        if (col0 + 3 < nv) {
+                            __builtin_memcpy(hout + (size_t)row * nv + col0, &hi[a][b], 16);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (col0 + j < nv) hout[(size_t)row * nv + col0 + j] = hi[a][b][j];
+                        }
+                    }
+                }
+        }
         MF_STAMP(4)
         if (n_mat == 0) continue;
         __syncthreads();  // every wavefront's part of the copy has landed (and this wavefront's H^-1 is in LDS)
@@ -1181,22 +1200,41 @@ void spd_mfma_kernel(const float *H, int h_packed, int h_il, const float *P1, co
             for (int t = 0; t < NCT; t++)
                 if (t < nct) {
 #pragma unroll
-                    for (int a = 0; a < NT; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+                    for (int a = 0; a < NT; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t], av[a], acc[a][t], 0, 0, 0);
                 }
         }
         MF_STAMP(5)
+        // The product was taken transposed, (P^T H^-1)^T: with the right-hand-side fragment as the A operand a lane's four
+        // accumulator values of tile (a, t) are X[16 a + c16][16 t + 4 g + 0..3] -- four consecutive entries of a row of the
+        // result: one 16-byte store (two 8-byte ones at the odd alignment of an odd row when nv = 2 mod 4) instead of four.
+        if (live) {
 #pragma unroll
-        for (int t = 0; t < NCT; t++)
-            if (t < nct && mat[t] >= 0 && live) {
-                float *out = dst[mat[t]] + s * (size_t)nn + ccol[t];
+            for (int t = 0; t < NCT; t++)
+                if (t < nct) {
+                    const int c0 = 16 * t + 4 * g;  // first of this lane's four columns of [X1 | X2]
 #pragma unroll
-                for (int a = 0; a < NT; a++)
+                    for (int a = 0; a < NT; a++) {
+                        const int row = 16 * a + c16;
+                        if (row >= nv) continue;
+                        const f32x4 v = -acc[a][t];
+                        const bool second = c0 >= nv;
+                        const int cc0 = second ? c0 - nv : c0;
+                        float *o0 = (second ? dst1 : dst0) + s * (size_t)nn + (size_t)row * nv + cc0;
+                        if (c0 + 3 < n_cols && cc0 + 3 < nv) {  // all four in one matrix
+                            __builtin_memcpy(o0, &v, 16);
+                        } else {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int row = 16 * a + 4 * g + j;
-                        if (row < nv) out[(size_t)row * nv] = -acc[a][t][j];
+                            for (int j = 0; j < 4; j++) {
+                                const int c = c0 + j;
+                                if (c < n_cols) {
+                                    if (c >= nv && !second) dst1[s * (size_t)nn + (size_t)row * nv + (c - nv)] = v[j];
+                                    else o0[j] = v[j];
+                                }
+                            }
+                        }
                     }
-            }
+                }
+        }
         MF_STAMP(6)
     }
 #ifdef GRBDA_EXP_MF_PROF

@@ -32,7 +32,7 @@ try:
     L.grbda_debug_mf_prof(buf, 1)
     plan.fd_derivatives(tq, tqd, tt); torch.cuda.synchronize()
     L.grbda_debug_mf_prof(buf, 0)
-    names = ["fence + copy issue", "H row load", "Cholesky", "L^-1", "GEMM1 + copy wait + H^-1 stores", "GEMM2", "result stores"]
+    names = ["H block copy + wait", "H row from LDS + rhs copy issue", "Cholesky", "L^-1", "GEMM1 + copy wait + H^-1 stores", "barrier + GEMM2", "result stores"]
     tot = sum(buf[:7])
     print("s_memtime ticks per state (all three):", "  ".join(f"{n}={buf[i] / B:.0f} ({100 * buf[i] / tot:.0f}%)" for i, n in enumerate(names)), " total", tot / B)
 except AttributeError:
