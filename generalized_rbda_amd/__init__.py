@@ -52,7 +52,8 @@ class PlanInfo(ctypes.Structure):
                 ("split_aba_f32", c_int), ("split_rnea_f32", c_int), ("n_lds_slots_split_f32", c_int),
                 ("chain_aba_f32", c_int), ("n_lds_slots_chain_f32", c_int), ("n_chain_segments", c_int),
                 ("chain_aba_f64", c_int), ("chain_rnea_f32", c_int), ("chain_rnea_f64", c_int),
-                ("analytic_derivatives", c_int), ("n_chain_differentials", c_int)]
+                ("analytic_derivatives", c_int), ("n_chain_differentials", c_int),
+                ("latency_mode_f32", c_int), ("latency_mode_f64", c_int)]
 
 
 _lib = None

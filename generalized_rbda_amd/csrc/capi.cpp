@@ -51,11 +51,12 @@ struct DeviceTables {
     float *consts32 = nullptr;
     // chain program of the f32 fast path (plan.h, ChainProgram)
     // [0] f32, two wavefronts per SIMD (HostPlan::chain32), [1] f32, four (chain32w), [2] f64 (chain64)
-    ChainSeg *chain_segs[3] = {nullptr, nullptr, nullptr};
-    ChainLink *chain_links[3] = {nullptr, nullptr, nullptr};
-    ChainPair *chain_pairs[3] = {nullptr, nullptr, nullptr};
-    ChainFree *chain_frees[3] = {nullptr, nullptr, nullptr};
-    ChainDiff *chain_diffs[3] = {nullptr, nullptr, nullptr};
+    // chain programs: 0 f32, 1 f32 at four wavefronts per SIMD, 2 f64, 3 / 4 latency mode f32 / f64 (ChainProgram::n_waves = 2)
+    ChainSeg *chain_segs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainLink *chain_links[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainPair *chain_pairs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainFree *chain_frees[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainDiff *chain_diffs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
@@ -122,6 +123,7 @@ struct grbda_plan {
     bool rnea_narrow = false;  // GRBDA_RNEA_NARROW=1: the inverse-dynamics chain kernel stays at two wavefronts per SIMD
     bool no_analytic = false;  // GRBDA_NO_ANALYTIC=1: derivatives by the unit-vector / central-difference batches only
     bool solve_f64 = false;    // GRBDA_SOLVE_F64=1: the SPD solve of the f32 derivative entry points computes in f64
+    bool no_latency_mode = false;  // GRBDA_NO_LATENCY_MODE=1: small batches keep the one-wavefront-per-tile kernel
     int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 3)
     bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
@@ -215,8 +217,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     if (!h.deriv.related.empty() &&
         (e = up(h.deriv.related.data(), h.deriv.related.size() * sizeof(uint64_t), (void **)&t.deriv_related)) != hipSuccess)
         return hip_err(e, "plan upload");
-    for (int w = 0; w < 3; w++) {
-        const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : h.chain64);
+    for (int w = 0; w < 5; w++) {
+        const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : h.chain64p)));
         if (!cp.ok) continue;
         if ((e = up(cp.segs.data(), cp.segs.size() * sizeof(ChainSeg), (void **)&t.chain_segs[w])) != hipSuccess ||
             (e = up(cp.links.data(), cp.links.size() * sizeof(ChainLink), (void **)&t.chain_links[w])) != hipSuccess ||
@@ -304,8 +306,45 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
               int device, void *stream)
 {
     const HostPlan &h = p->host;
-    // f32: four wavefronts per SIMD (16 per CU, half the LDS each) once the batch fills them, when that layout exists
     const size_t n_tiles0 = (B + kWave - 1) / kWave;
+    // Latency mode: a batch of at most one tile per SIMD would leave every SIMD with a single wavefront; a tile then goes
+    // to a workgroup of two wavefronts that split its limbs (chain_kernels.hip, aba_chain_lm_kernel).  GRBDA_NO_LATENCY_MODE=1
+    // keeps the ordinary kernel (A/B runs); results are bit-identical either way.
+    {
+        const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
+        const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
+        size_t lds_lm = static_cast<size_t>(lp.n_lds) * kWave * sizeof(T);
+        if (lds_lm < stage_all) lds_lm = stage_all;
+        if (lp.ok && !p->no_latency_mode && !p->chain_debug && n_tiles0 <= static_cast<size_t>(t.n_cu) * 4 && n_tiles0 > 0 && lds_lm <= 40960) {
+            const int w = sizeof(T) == 8 ? 4 : 3;
+            ChainDev<T> d;
+            d.segs = t.chain_segs[w];
+            d.links = t.chain_links[w];
+            d.pairs = t.chain_pairs[w];
+            d.frees = t.chain_frees[w];
+            d.diffs = nullptr;
+            d.n_diffs = 0;
+            d.cints = t.cints;
+            d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
+            d.n_segs = static_cast<int>(lp.segs.size());
+            d.nq = h.nq;
+            d.nv = h.nv;
+            d.n_glb_slots = lp.n_glb;
+            d.ori_repr = h.ori_repr;
+            d.debug = 0;
+            d.sv_global = 0;
+            d.lds_bytes = static_cast<int>(lds_lm);
+            for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+            const size_t grid = n_tiles0;  // (<= 4 workgroups per CU: all resident)
+            const size_t n_rows = static_cast<size_t>(lp.n_glb) + static_cast<size_t>(d.nq + 2 * d.nv);
+            void *scratch = nullptr;
+            if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(T) + 256, &scratch)) return rc;
+            hipError_t e = launch_aba_chain_lm<T>(d, q, qd, tau, ydd, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_lm,
+                                                  static_cast<hipStream_t>(stream));
+            return e == hipSuccess ? GRBDA_OK : hip_err(e, "aba chain launch (latency mode)");
+        }
+    }
+    // f32: four wavefronts per SIMD (16 per CU, half the LDS each) once the batch fills them, when that layout exists
     const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && p->chain_wide &&
                       (!h.chain32.ok || n_tiles0 > static_cast<size_t>(t.n_cu) * 8);
     const int w = sizeof(T) == 8 ? 2 : (wide ? 1 : 0);
@@ -1462,6 +1501,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     }
     p->no_split = env_int("GRBDA_NO_SPLIT", 0) != 0;
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;
+    p->no_latency_mode = env_int("GRBDA_NO_LATENCY_MODE", 0) != 0;
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
     p->chain_debug = env_int("GRBDA_CHAIN_DEBUG", 0);
     p->no_crba = env_int("GRBDA_NO_CRBA", 0) != 0;
@@ -1523,7 +1563,7 @@ void grbda_plan_free(grbda_plan *p)
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
-        for (int w = 0; w < 3; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); }
+        for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work, &p->work_cvt})
@@ -1595,6 +1635,8 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->chain_rnea_f64 = p->host.rchain64.ok && !p->no_chain;
     info->analytic_derivatives = analytic_covers<double>(p) ? 1 : 0;
     info->n_chain_differentials = p->no_chain ? 0 : static_cast<int>(p->host.chain32.diffs.size());
+    info->latency_mode_f32 = p->host.chain32p.ok && !p->no_chain && !p->no_latency_mode;
+    info->latency_mode_f64 = p->host.chain64p.ok && !p->no_chain && !p->no_latency_mode;
     return GRBDA_OK;
 }
 

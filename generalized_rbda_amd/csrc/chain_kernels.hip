@@ -1064,6 +1064,13 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
         for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) psi[j] += acc[21 + j];
+        if (f.lds_acc2 != -1) {  // latency-mode programs: what the second wavefront's limbs handed up
+            M.acc_ld(f.lds_acc2, acc);
+#pragma unroll
+            for (int j = 0; j < 21; j++) IA[j] += acc[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) psi[j] += acc[21 + j];
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 21; j++) IA[j] = Ib[j];
@@ -1192,6 +1199,102 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Latency mode (plan.h, ChainProgram::n_waves = 2): a tile of 64 states is run by a WORKGROUP of two wavefronts.  The limbs
+// below the floating base are dealt to the two wavefronts (ChainSeg::owner), the base's own segments run on wavefront 0,
+// SEG_BARRIER segments order the hand-overs: base velocity (LDS) -> limbs, limb accumulators (global slab) -> base, base
+// acceleration (LDS) -> limbs.  The tile prologue is shared too: wavefront 0 stages q, wavefront 1 stages qd and tau.
+// For batches that do not fill the chip -- fewer tiles than SIMDs, BASELINE config 2: 65 536 Mini-Cheetah states = 1 024 tiles
+// on 1 024 SIMDs -- the ordinary kernel leaves every SIMD with ONE wavefront, which issues an instruction every ~4.1 ns
+// whatever it depends on; two wavefronts with half the stream each issue at 2.1 ns per SIMD.  This is
+// north_star's "robot per several waves" where it pays: not to parallelise a 6 x 6 product, but to shorten the stream.
+// Same device functions, same arithmetic per state as aba_chain_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ tau,
+                         T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
+{
+    ChainTables<T> P;
+    P.segs = (cptr<ChainSeg>)DP.segs;
+    P.links = (cptr<ChainLink>)DP.links;
+    P.pairs = (cptr<ChainPair>)DP.pairs;
+    P.frees = (cptr<ChainFree>)DP.frees;
+    P.diffs = nullptr;
+    P.cints = nullptr;
+    P.consts = (cptr<T>)DP.consts;
+    P.n_segs = DP.n_segs;
+    P.nq = DP.nq;
+    P.nv = DP.nv;
+    P.ori_repr = DP.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
+    ChainMem<T> M;
+    M.lane = lane;
+    M.gmul = 1;
+    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q = slab + lane;
+    M.in_qd = slab + (size_t)P.nq * kWave + lane;
+    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    const unsigned bq = (unsigned)(kWave * P.nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * P.nv) * (unsigned)sizeof(T);
+
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        // prologue: each wavefront stages its arrays through its own part of LDS (capi.cpp sizes LDS for all three at once)
+        if (wave == 0) {
+            stage_issue(q, tile, rows_valid, P.nq, 0u, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            stage_transpose(P.nq, 0u, slab, lane);
+        } else {
+            stage_issue(qd, tile, rows_valid, P.nv, bq, lane);
+            stage_issue(tau, tile, rows_valid, P.nv, bq + bv, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            stage_transpose(P.nv, bq, slab + (size_t)P.nq * kWave, lane);
+            stage_transpose(P.nv, bq + bv, slab + (size_t)(P.nq + P.nv) * kWave, lane);
+        }
+        __syncthreads();  // (drains the slab stores of both wavefronts: the rows are visible to either)
+        for (int s = 0; s < P.n_segs; s++) {
+            const ChainSeg sg = load_rec(P.segs + s);
+            if (sg.op == SEG_BARRIER) {
+                __syncthreads();
+                continue;
+            }
+            if (sg.owner != wave) continue;
+            switch (sg.op) {
+                case SEG_RUN_FWD: run_fwd<T, false>(P, M, sg); break;
+                case SEG_RUN_BWD: run_bwd<T, false, false>(P, M, sg); break;
+                case SEG_RUN_ACC: run_acc(P, M, sg); break;
+                case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
+                case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first)); break;
+                default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
+            }
+        }
+        __syncthreads();  // every result row is in the slab
+        if (wave == 0) write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        __syncthreads();  // LDS and the slab are free for the next tile
+    }
+}
+
+template <class T>
+hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
+                               size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((aba_chain_lm_kernel<T>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_aba_chain_lm<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
+                                               float *, int, size_t, hipStream_t);
+template hipError_t launch_aba_chain_lm<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
+                                                size_t, double *, int, size_t, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Inverse operational-space inertia J H^-1 J^T of contact frames by force propagation -- the recursion behind
@@ -2100,7 +2203,8 @@ hipError_t set_max_dynamic_lds_chain()
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, false>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, true>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, true>),
-        reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>)};
+        reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>),
+        reinterpret_cast<const void *>(&aba_chain_lm_kernel<float>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<double>)};
     for (const void *k : kernels) {
         const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

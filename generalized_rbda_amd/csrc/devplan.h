@@ -75,6 +75,10 @@ struct ChainDev {
 template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd);
+// latency mode: a tile per workgroup of two wavefronts (chain_kernels.hip, aba_chain_lm_kernel)
+template <class T>
+hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
+                               size_t lds_bytes, hipStream_t stream);
 hipError_t set_max_dynamic_lds_chain();
 
 template <class T>

@@ -622,6 +622,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         int size, prio, birth, death, slot;
         int force = 0;  // split layouts: 1 must live in LDS, 2 must live in the global slab
         int tag = 0;    // chain programs: 1 = work space that never leaves LDS whatever its size
+        // latency-mode chain programs: the wavefront whose limb the object belongs to (-1: the base's, ordered against
+        // everything by the barriers) and the phase it lives in (0: forward / backward runs, 1: acceleration runs).  Limbs of
+        // different wavefronts run concurrently inside a phase: their objects never share slots, whatever the segment order says.
+        int owner = -1, phase = 0;
     };
     // returns false when an object that must live in LDS does not fit the budget
     // mode 0: placement order (priority, birth); 1: longest-lived first; 2: largest first (allocate_packed below)
@@ -650,7 +654,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::vector<std::pair<int, int>> busy;
             for (int pi : placed) {
                 const Obj &p = objs[pi];
-                if (p.death < o.birth || o.death < p.birth) continue;
+                const bool concurrent = p.owner >= 0 && o.owner >= 0 && p.owner != o.owner && p.phase == o.phase;
+                if (!concurrent && (p.death < o.birth || o.death < p.birth)) continue;
                 const int off = global ? (p.slot & ~kSlotGlobal) : p.slot - lds_base;
                 busy.push_back({off, off + p.size});
             }
@@ -1021,8 +1026,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         diff_shape[c] = ds;
     }
 
-    auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget) {
+    auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget, int n_waves = 1) {
         CP = ChainProgram();
+        CP.n_waves = n_waves;
+        const bool lm = n_waves > 1;  // latency mode (plan.h, ChainProgram::n_waves)
         bool ok = sweep_mask == 7;
         // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair (head of its parent link's backward
         // run), 4 revolute + general rotor, 5 two-rotor differential, 6 explicit pair with child clusters on link2 or in a
@@ -1141,7 +1148,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     f = ChainFree();
                     const BodyRec &br = bodies[cr.first_body];
                     f.q_index = cr.q_index; f.v_index = cr.v_index; f.cofs = br.cofs; f.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
-                    f.lds_v = f.lds_acc = f.lds_va = -1;
+                    f.lds_v = f.lds_acc = f.lds_va = f.lds_acc2 = -1;
                     f.glb_y0 = glb(33);  // [y0 6] (+ OSIM pass: Cholesky factor of the base's articulated inertia, L 21 + 1/diag 6)
                 } else if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) {
                     ChainLink &l = link_of[c];
@@ -1221,14 +1228,18 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             // emission helpers work on chain ids; link records are filled after allocation, so remember (seg, cluster list)
             struct RunRef { int seg; std::vector<int> cl; };
             std::vector<RunRef> runs;
-            auto push_seg = [&](ChainSeg sg) { CP.segs.push_back(sg); return static_cast<int>(CP.segs.size()) - 1; };
+            std::vector<int> owner_of;  // latency mode: the wavefront that runs the chain (limbs below the base are dealt out)
+            int cur_owner = 0;
+            auto push_seg = [&](ChainSeg sg) { sg.owner = cur_owner; CP.segs.push_back(sg); return static_cast<int>(CP.segs.size()) - 1; };
             std::function<void(int)> emit_fb = [&](int id) {
                 const Chain ch = chains[id];
+                cur_owner = owner_of[id];
                 if (ch.diff) {
                     ChainSeg sg = ChainSeg();
                     sg.op = SEG_DIFF_FWD;
                     ct[id].fwd = push_seg(sg);
                     for (int k : ch.kid_chains) emit_fb(k);
+                    cur_owner = owner_of[id];
                     sg.op = SEG_DIFF_BWD;
                     ct[id].bwd = push_seg(sg);
                     return;
@@ -1241,6 +1252,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     ct[id].fwd = t;
                 }
                 for (int k : ch.kid_chains) emit_fb(k);
+                cur_owner = owner_of[id];
                 ChainSeg sg = ChainSeg();
                 sg.op = SEG_RUN_BWD;
                 const int tipc = ch.cl.back();
@@ -1253,6 +1265,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             };
             std::function<void(int)> emit_acc = [&](int id) {
                 const Chain ch = chains[id];
+                cur_owner = owner_of[id];
                 ChainSeg sg = ChainSeg();
                 if (ch.diff) {
                     sg.op = SEG_DIFF_ACC;
@@ -1282,21 +1295,65 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     ground_chains.push_back(make_chain(c));
             }
             ct.assign(chains.size(), SegTimes());
+            owner_of.assign(chains.size(), 0);
+            if (lm) {
+                // one floating base with at least two limbs, nothing on the ground, no differential segments (their work space
+                // and per-state G rows are not sized for concurrent limbs); the limbs are dealt to the wavefronts by link count
+                int n_free = 0, base = -1;
+                for (int c = 0; c < nc; c++)
+                    if (cls[c] == 0) { n_free++; base = c; }
+                bool any_diff = false;
+                for (const Chain &ch : chains) any_diff = any_diff || ch.diff;
+                if (n_free != 1 || !ground_chains.empty() || any_diff || free_chains[base].size() < 2) {
+                    ok = false;
+                } else {
+                    std::function<int(int)> weight = [&](int id) {
+                        int w = static_cast<int>(chains[id].cl.size()) + (chains[id].pair >= 0 ? 2 : 0);
+                        for (int k : chains[id].kid_chains) w += weight(k);
+                        return w;
+                    };
+                    std::function<void(int, int)> give = [&](int id, int o) {
+                        owner_of[id] = o;
+                        for (int k : chains[id].kid_chains) give(k, o);
+                    };
+                    std::vector<int> load(n_waves, 0);
+                    for (int id : free_chains[base]) {
+                        int o = 0;
+                        for (int w2 = 1; w2 < n_waves; w2++)
+                            if (load[w2] < load[o]) o = w2;
+                        give(id, o);
+                        load[o] += weight(id);
+                    }
+                }
+            }
+            auto barrier = [&]() {
+                if (!lm) return;
+                cur_owner = 0;
+                ChainSeg sg = ChainSeg();
+                sg.op = SEG_BARRIER;
+                push_seg(sg);
+            };
             for (int id : ground_chains) emit_fb(id);
             for (int c = 0; c < nc; c++) {
                 if (cls[c] != 0) continue;
                 ChainSeg sg = ChainSeg();
                 sg.op = SEG_FREE_FWD;
+                cur_owner = 0;
                 t_free_fwd[c] = push_seg(sg);
+                barrier();  // the base's velocity is in LDS: the limbs may start
                 for (int id : free_chains[c]) emit_fb(id);
+                barrier();  // every limb has handed its inertia / bias to the base's accumulators
                 sg.op = SEG_FREE_BWD;
+                cur_owner = 0;
                 t_free_bwd[c] = push_seg(sg);
             }
             for (int c = 0; c < nc; c++) {
                 if (cls[c] != 0) continue;
                 ChainSeg sg = ChainSeg();
                 sg.op = SEG_FREE_ACC;
+                cur_owner = 0;
                 t_free_acc[c] = push_seg(sg);
+                barrier();  // the base's acceleration is in LDS
                 for (int id : free_chains[c]) emit_acc(id);
             }
             for (int id : ground_chains) emit_acc(id);
@@ -1480,11 +1537,31 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 // (the [v, a] block is read when a kid chain's acceleration run STARTS: it lives until the last kid's own segment)
                 for (int id : free_chains[c]) { first_bwd = std::min(first_bwd, ct[id].bwd); last_acc = std::max(last_acc, ct[id].acc); }
                 objs.push_back({&f.lds_v, 6, 0, B0(t_free_fwd[c]), D1(t_free_bwd[c]), -1, 1});
-                objs.push_back({&f.lds_acc, 27, 1, B0(first_bwd) + 1, B0(t_free_bwd[c]), -1, 1});
+                if (!lm) {
+                    objs.push_back({&f.lds_acc, 27, 1, B0(first_bwd) + 1, B0(t_free_bwd[c]), -1, 1});
+                } else {
+                    // one accumulator per wavefront, in the global slab (two read-modify-writes per limb; LDS is what limits
+                    // how many tiles a CU holds in this mode)
+                    for (int o = 0; o < n_waves && o < 2; o++) {
+                        int fb = 1 << 30;
+                        for (int id : free_chains[c])
+                            if (owner_of[id] == o) fb = std::min(fb, ct[id].bwd);
+                        if (fb == 1 << 30) continue;
+                        objs.push_back({o == 0 ? &f.lds_acc : &f.lds_acc2, 27, 1, B0(fb) + 1, B0(t_free_bwd[c]), -1, 2});
+                    }
+                }
                 objs.push_back({&f.lds_va, 12, 0, B0(t_free_acc[c]), D1(last_acc), -1, 1});
             }
+            int t_acc_phase = 1 << 30;  // first acceleration segment: objects born from there on live in phase 1
+            for (int c = 0; c < nc; c++)
+                if (cls[c] == 0) t_acc_phase = std::min(t_acc_phase, t_free_acc[c]);
             for (size_t id = 0; id < chains.size(); id++) {
                 const Chain &ch = chains[id];
+                const size_t o_begin = objs.size();
+                struct OwnerTag {  // on leaving the iteration: the objects pushed for this chain belong to its wavefront
+                    std::vector<Obj> &v; size_t from; int owner; int t_acc; bool on;
+                    ~OwnerTag() { if (on) for (size_t i = from; i < v.size(); i++) { v[i].owner = owner; v[i].phase = v[i].birth >= 2 * t_acc ? 1 : 0; } }
+                } owner_tag{objs, o_begin, owner_of[id], t_acc_phase, lm};
                 if (ch.diff) {
                     ChainDiff &d = diff_of[ch.cl[0]];
                     if (diff_shape[ch.cl[0]].n_atoms > 0)
@@ -1510,12 +1587,20 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 }
             }
             int n_lds = 0, n_glb_unused = 0;
-            ok = allocate_packed(objs, lds_budget, n_lds, n_glb_unused);
+            const bool pre_ok = ok;
+            ok = allocate_packed(objs, lds_budget, n_lds, n_glb_unused) && pre_ok;
+            if (lm) {
+                // no second tries in this mode (they move link blocks to the slab: latency on the critical path); the base's
+                // accumulators are global by construction: number them behind the [K | y0] blocks
+                for (Obj &o : objs)
+                    if (o.slot >= 0 && (o.slot & kSlotGlobal)) *o.field = ((o.slot & ~kSlotGlobal) + n_glb) | kSlotGlobal;
+                n_glb += n_glb_unused;
+            }
             if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) {
                 std::fprintf(stderr, "chain: LDS objects need more than %d slots (got to %d)\n", lds_budget, n_lds);
                 for (const Obj &o : objs) std::fprintf(stderr, "  obj size %d [%d, %d] slot %d\n", o.size, o.birth, o.death, o.slot);
             }
-            if (!ok) {
+            if (!ok && !lm) {
                 // second try: the accumulators [IA 21][psi 6] of branching bodies -- touched once per child chain -- take
                 // what LDS the other objects leave and otherwise move to the wave's global slab (their slot numbers then
                 // carry kSlotGlobal)
@@ -1555,11 +1640,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     if (is_diff(c)) return diff_of[c].lds_va;
                     return cls[c] == 0 ? free_of[c].lds_va : link_of[c].lds_va;
                 };
-                auto acc_slot_of_body = [&](int b) -> int {
+                auto acc_slot_of_body = [&](int b, int owner = 0) -> int {
                     if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
                     if (is_diff(c)) return diff_of[c].lds_acc;
-                    return cls[c] == 0 ? free_of[c].lds_acc : acc_slot[c];
+                    return cls[c] == 0 ? (lm && owner == 1 ? free_of[c].lds_acc2 : free_of[c].lds_acc) : acc_slot[c];
                 };
                 for (int c = 0; c < nc; c++) {
                     const int pb = clusters[c].parent_body;
@@ -1582,7 +1667,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     if (bw.head == HEAD_SLOT) bw.head_arg = acc_slot[tipc];
                     if (bw.head == HEAD_PAIR) { bw.head_arg = static_cast<int>(CP.pairs.size()); }
                     const int pb = clusters[topc].parent_body;
-                    bw.lds_acc_out = acc_slot_of_body(pb);
+                    bw.lds_acc_out = acc_slot_of_body(pb, owner_of[id]);
                     // first writer: earliest backward run among the sibling chains
                     bool first = true;
                     if (pb >= 0) {
@@ -1592,7 +1677,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             if (chains[j].cl.back() == pc) parent_chain = static_cast<int>(j);
                         const std::vector<int> &sib = cls[pc] == 0 ? free_chains[pc] : chains[parent_chain].kid_chains;
                         for (int o : sib)
-                            if (ct[o].bwd < ct[id].bwd) first = false;
+                            if (ct[o].bwd < ct[id].bwd && (!lm || cls[pc] != 0 || owner_of[o] == owner_of[id])) first = false;
                     }
                     bw.acc_first = first ? 1 : 0;
                     ChainSeg &ac = CP.segs[ct[id].acc];
@@ -1623,6 +1708,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     build_chain(P.chain32, lds.aba32, &P.rchain32, lds.aba32);
     build_chain(P.chain32w, lds.chain32w, &P.rchain32w, lds.chain32w);
     build_chain(P.chain64, lds.aba64, &P.rchain64, lds.aba64);
+    // latency mode serves batches of at most one tile per SIMD, i.e. four tiles per CU: 40 KiB of LDS per tile
+    build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2);
+    build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
     {

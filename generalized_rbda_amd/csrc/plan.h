@@ -165,7 +165,8 @@ enum ChainOp : int32_t {
     SEG_PAIR_ACC = 6,
     SEG_DIFF_FWD = 7,   // two-rotor differential cluster (ChainDiff): constraint Jacobian, G, g; velocity of its tip link
     SEG_DIFF_BWD = 8,
-    SEG_DIFF_ACC = 9
+    SEG_DIFF_ACC = 9,
+    SEG_BARRIER = 10    // latency-mode programs (ChainProgram::n_waves > 1): every wavefront of the workgroup meets here
 };
 enum ChainHead : int32_t {
     HEAD_LEAF = 0,      // the first link of a backward run is a leaf: its accumulators start from its own inertia
@@ -249,7 +250,8 @@ struct ChainSeg {       // 16 ints
     int32_t lds_acc_out;    // SEG_RUN_BWD: accumulator slot of the body the chain hangs off, -1: ground
     int32_t acc_first;      // 1: this segment is the first writer of that slot
     int32_t lds_pva;        // SEG_RUN_ACC: [v 6][a 6] of the body the chain hangs off, -1: ground (v = 0, a = a_root)
-    int32_t reserved[8];
+    int32_t owner;          // latency-mode programs: the wavefront of the workgroup that runs this segment (base segments: 0)
+    int32_t reserved[7];
 };
 
 struct ChainFree {      // 16 ints
@@ -258,7 +260,8 @@ struct ChainFree {      // 16 ints
     int32_t lds_acc;    // backward: accumulator slot, -1 when the base has no children
     int32_t glb_y0;     // [y0 6]
     int32_t lds_va;     // acceleration sweep: own [v 6][a 6], -1 when no children
-    int32_t reserved[8];
+    int32_t lds_acc2;   // latency-mode programs: the accumulator the SECOND wavefront's limbs add into (-1: none)
+    int32_t reserved[7];
 };
 
 // ---- inverse dynamics on the same chains (chain_kernels.hip, rnea_chain_kernel) ------------------------------------
@@ -314,6 +317,12 @@ struct ChainProgram {
     std::vector<ChainDiff> diffs;
     int n_lds = 0, n_glb = 0;        // slots
     bool sv_global = false;          // the [sin, cos, v] blocks of the links live in the global slab (chains too long for LDS)
+    // Latency mode (n_waves = 2): a tile is run by a WORKGROUP of two wavefronts -- the limbs below the floating base are
+    // dealt to the two, the base's own segments run on wavefront 0, SEG_BARRIER segments order the hand-overs (base velocity
+    // -> limbs, limb accumulators -> base, base acceleration -> limbs).  For batches that do not fill the chip (fewer tiles
+    // than SIMDs: BASELINE config 2) this halves the instruction stream a SIMD sees per tile.  LDS objects of limbs that run
+    // on different wavefronts never share slots (separate pools); the base's accumulators live in the global slab.
+    int n_waves = 1;
 };
 
 // composite-rigid-body algorithm (crba_kernels.hip): per body, where its per-state scratch rows live in the wave's slab
@@ -372,6 +381,7 @@ struct HostPlan {
     ChainProgram chain32;     // f32 ABA, chain-structured fast path (chain_kernels.hip), two wavefronts per SIMD
     ChainProgram chain32w;    // the same laid out for four wavefronts per SIMD (half the LDS per wavefront)
     ChainProgram chain64;     // f64 ABA (slots are twice as large: the LDS budget holds half as many)
+    ChainProgram chain32p, chain64p;  // latency mode: two wavefronts per tile (ChainProgram::n_waves)
     CrbaProgram crba;
     DerivProgram deriv;
     RneaChainProgram rchain32, rchain64;  // inverse dynamics on the chains
