@@ -309,7 +309,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     const size_t n_tiles0 = (B + kWave - 1) / kWave;
     // Latency mode: a batch of at most one tile per SIMD would leave every SIMD with a single wavefront; a tile then goes
     // to a workgroup of two wavefronts that split its limbs (chain_kernels.hip, aba_chain_lm_kernel).  GRBDA_NO_LATENCY_MODE=1
-    // keeps the ordinary kernel (A/B runs); results are bit-identical either way.
+    // keeps the ordinary kernel (A/B runs); results agree to rounding (the base sums one partial inertia per wavefront).
     {
         const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
         const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);

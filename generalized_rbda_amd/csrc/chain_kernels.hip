@@ -1209,7 +1209,8 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
 // on 1 024 SIMDs -- the ordinary kernel leaves every SIMD with ONE wavefront, which issues an instruction every ~4.1 ns
 // whatever it depends on; two wavefronts with half the stream each issue at 2.1 ns per SIMD.  This is
 // north_star's "robot per several waves" where it pays: not to parallelise a 6 x 6 product, but to shorten the stream.
-// Same device functions, same arithmetic per state as aba_chain_kernel: results are bit-identical.
+// Same device functions and operations per state as aba_chain_kernel; the limbs' inertias reach the base as one partial sum per
+// wavefront, so results agree with it to rounding (tests/test_gpu_parity.py, test_latency_mode_matches_the_one_wavefront_kernel).
 // ---------------------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))

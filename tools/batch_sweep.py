@@ -1,5 +1,5 @@
-"""Kernel time of the f32 forward dynamics over a sweep of batch sizes (startup cost vs steady-state rounds).
-usage: python tools/batch_sweep.py [model]"""
+"""Kernel time of the forward dynamics over a sweep of batch sizes (startup cost vs steady-state rounds; latency mode below
+one tile per SIMD: GRBDA_NO_LATENCY_MODE=1 switches it off).   usage: python tools/batch_sweep.py [model] [f32|f64]"""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -9,12 +9,13 @@ if os.environ.get("GRBDA_LIB"):
     G.LIB_PATH = os.path.abspath(os.environ["GRBDA_LIB"])
 from generalized_rbda_amd.states import random_states
 model = sys.argv[1] if len(sys.argv) > 1 else "mit_humanoid"
+dt = torch.float64 if (len(sys.argv) > 2 and sys.argv[2] == "f64") else torch.float32
 plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", model + ".urdf"))
-for B in (64, 4096, 16384, 65536, 131072, 196608, 262144, 393216, 524288, 1048576, 2097152):
+for B in (64, 4096, 16384, 32768, 49152, 65536, 65600, 98304, 131072, 196608, 262144, 393216, 524288, 1048576, 2097152):
     q, qd, tau = random_states(plan.blob, B, 2)
-    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda:0")
+    t = lambda a: torch.as_tensor(a, dtype=dt, device="cuda:0")
     tq, tqd, tt = t(q), t(qd), t(tau)
-    out = torch.empty((B, plan.nv), dtype=torch.float32, device="cuda:0")
+    out = torch.empty((B, plan.nv), dtype=dt, device="cuda:0")
     plan.time_kernel("aba", tq, tqd, tt, out, iters=5)
     ms = min(plan.time_kernel("aba", tq, tqd, tt, out, iters=30) for _ in range(3))
     tiles = (B + 63) // 64
