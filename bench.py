@@ -411,7 +411,11 @@ def main():
     chain = (info.chain_aba_f32 if dtype_name == "f32" else info.chain_aba_f64) and args.algo == "aba"
     rchain = (info.chain_rnea_f32 if dtype_name == "f32" else info.chain_rnea_f64) and args.algo == "rnea"
     # (differential clusters -- TelloWithArms -- are the `true` variants of the chain kernels, chain_kernels.hip)
-    kernel_name = (f"grbda_hip::aba_chain_kernel<{tname}, 2, {'true' if general else 'false'}>" if chain
+    # (batches of at most one tile per SIMD: the latency-mode kernel, a tile per workgroup of two wavefronts)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    lm = (info.latency_mode_f32 if dtype_name == "f32" else info.latency_mode_f64) and args.algo == "aba" and (B + 63) // 64 <= 4 * n_cu
+    kernel_name = (f"grbda_hip::aba_chain_lm_kernel<{tname}>" if lm
+                   else f"grbda_hip::aba_chain_kernel<{tname}, 2, {'true' if general else 'false'}>" if chain
                    else f"grbda_hip::rnea_chain_kernel<{tname}, {'true' if general else 'false'}>" if rchain
                    else f"grbda_hip::{args.algo}_kernel<{tname}, {'true' if general else 'false'}>")
     line = {

@@ -1265,7 +1265,13 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
         for (int s = 0; s < P.n_segs; s++) {
             const ChainSeg sg = load_rec(P.segs + s);
             if (sg.op == SEG_BARRIER) {
-                __syncthreads();
+                if (sg.head) {
+                    __syncthreads();  // drains the global stores: the limbs' accumulators went through the slab
+                } else {  // LDS hand-over only: the [K | y0] stores in flight need not land first
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
                 continue;
             }
             if (sg.owner != wave) continue;
@@ -1281,7 +1287,11 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
         }
         __syncthreads();  // every result row is in the slab
         if (wave == 0) write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
-        __syncthreads();  // LDS and the slab are free for the next tile
+        // LDS and the slab are free for the next tile once wavefront 0 has READ the result rows (its own output stores may still
+        // be in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 }
 

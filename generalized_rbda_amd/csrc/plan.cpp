@@ -1326,11 +1326,14 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     }
                 }
             }
-            auto barrier = [&]() {
+            // global: what crosses the barrier went through the global slab (the limbs' accumulators), so the stores must have
+            // landed; otherwise it is LDS only and the wavefronts need not drain their [K | y0] stores
+            auto barrier = [&](bool global) {
                 if (!lm) return;
                 cur_owner = 0;
                 ChainSeg sg = ChainSeg();
                 sg.op = SEG_BARRIER;
+                sg.head = global ? 1 : 0;
                 push_seg(sg);
             };
             for (int id : ground_chains) emit_fb(id);
@@ -1340,9 +1343,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 sg.op = SEG_FREE_FWD;
                 cur_owner = 0;
                 t_free_fwd[c] = push_seg(sg);
-                barrier();  // the base's velocity is in LDS: the limbs may start
+                barrier(false);  // the base's velocity is in LDS: the limbs may start
                 for (int id : free_chains[c]) emit_fb(id);
-                barrier();  // every limb has handed its inertia / bias to the base's accumulators
+                barrier(true);  // every limb has handed its inertia / bias to the base's accumulators (global slab)
                 sg.op = SEG_FREE_BWD;
                 cur_owner = 0;
                 t_free_bwd[c] = push_seg(sg);
@@ -1353,7 +1356,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 sg.op = SEG_FREE_ACC;
                 cur_owner = 0;
                 t_free_acc[c] = push_seg(sg);
-                barrier();  // the base's acceleration is in LDS
+                barrier(false);  // the base's acceleration is in LDS
                 for (int id : free_chains[c]) emit_acc(id);
             }
             for (int id : ground_chains) emit_acc(id);
