@@ -105,6 +105,13 @@ typedef struct {
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 
 /* ---- batched dynamics (device pointers) ----------------------------------------------------- */
+/* The device entry points only enqueue work on the stream they are given and may be captured into a hipGraph as they are.
+ * The library keeps one scratch slab per (device, stream) and grows it on demand (hipFree + hipMalloc): a captured launch
+ * holds the slab's address, so (i) call once with the largest batch on that stream BEFORE capturing -- a call that would have
+ * to grow the slab while its stream is capturing returns GRBDA_EINVAL -- and (ii) do not make a larger eager call on the same
+ * (device, stream) while the graph is alive.
+ * Batches of at most one 64-state tile per SIMD (4 x the CU count) take the latency-mode forward-dynamics kernel when the
+ * plan has one (grbda_plan_info: latency_mode_f32 / _f64): same results to rounding, 20-35 % less time per call. */
 
 /* ClusterTreeModel::setState + forwardDynamics(tau) over B independent states
  * (ClusterTreeModel.cpp:256-308, ClusterTreeDynamics.cpp:85-191): cluster ABA.
@@ -156,7 +163,10 @@ int grbda_rnea_f32(const grbda_plan *plan, const float *q, const float *qd, cons
  * not used.  grbda_fd_derivatives_* returns any subset of the three matrices from ONE pass (NULL = not wanted) and falls
  * back to the three entry points above for the other models.  The analytic route keeps its intermediate matrices in a
  * device workspace owned by the plan, one per (device, stream), of at most 2 GiB (the batch goes through in chunks of that
- * size); the output arrays must not overlap the inputs or each other.
+ * size); the output arrays must not overlap the inputs or each other.  The f32 analytic route factors H per state by Cholesky
+ * on the matrix-core kernel: a state whose H is not positive definite in single precision (massless chains, garbage input)
+ * gets NaN / Inf in its three matrices while the call returns GRBDA_OK -- check the outputs, or use the _f64 entry points
+ * (GRBDA_SOLVE_F64=1 keeps fp32 storage with an fp64 solve).
  */
 int grbda_bias_f64(const grbda_plan *plan, const double *q, const double *qd, const double *f_ext, double *out,
                    size_t B, int device, void *stream);
