@@ -1563,7 +1563,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 const size_t o_begin = objs.size();
                 struct OwnerTag {  // on leaving the iteration: the objects pushed for this chain belong to its wavefront
                     std::vector<Obj> &v; size_t from; int owner; int t_acc; bool on;
-                    ~OwnerTag() { if (on) for (size_t i = from; i < v.size(); i++) { v[i].owner = owner; v[i].phase = v[i].birth >= 2 * t_acc ? 1 : 0; } }
+                    ~OwnerTag() { if (on) for (size_t i = from; i < v.size(); i++) { v[i].owner = owner; v[i].phase = v[i].birth / 2 >= t_acc ? 1 : 0; } }
                 } owner_tag{objs, o_begin, owner_of[id], t_acc_phase, lm};
                 if (ch.diff) {
                     ChainDiff &d = diff_of[ch.cl[0]];
