@@ -43,10 +43,11 @@ struct ChainTables {
 // LDS slots [slot][lane]; global slab rows [slot][lane]; the tile's inputs as coordinate-major slab rows
 template <class T>
 struct ChainMem {
-    T *glb;             // wave's global slots (after the input rows)
-    const T *in_q, *in_qd, *in_x;   // already offset by the lane
-    T *out_rows;
+    T *glb_u;           // wave's global slots (after the input rows): wave-uniform base
+    const T *in_q_u, *in_qd_u, *in_x_u;   // the tile's input rows in the slab: wave-uniform bases
+    T *out_u;
     int lane;
+    unsigned lane_b;  // lane * sizeof(T): the byte offset every slab access adds to its wave-uniform row address
     int gmul;  // 1; 0 under GRBDA_CHAIN_DEBUG bit 3: every global slot aliases row 0 (same instructions, no slab traffic)
 
     template <int N>
@@ -63,19 +64,21 @@ struct ChainMem {
 #pragma unroll
         for (int i = 0; i < N; i++) p[i * kWave] = x[i];
     }
+    // (row base: wave-uniform, so the 64-bit address arithmetic stays on the scalar unit; the lane enters as a 32-bit offset
+    // that is the same register for every access of the kernel, the row number as an immediate)
     template <int N>
     __device__ __forceinline__ void glb_ld(int s, T (&x)[N]) const
     {
-        const T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave + lane);
+        const char *p = reinterpret_cast<const char *>(glb_u + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave));
 #pragma unroll
-        for (int i = 0; i < N; i++) x[i] = p[i * kWave];
+        for (int i = 0; i < N; i++) x[i] = *reinterpret_cast<const T *>(p + i * (kWave * (int)sizeof(T)) + (size_t)lane_b);
     }
     template <int N>
     __device__ __forceinline__ void glb_st(int s, const T (&x)[N]) const
     {
-        T *p = glb + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave + lane);
+        char *p = reinterpret_cast<char *>(glb_u + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave));
 #pragma unroll
-        for (int i = 0; i < N; i++) p[i * kWave] = x[i];
+        for (int i = 0; i < N; i++) *reinterpret_cast<T *>(p + i * (kWave * (int)sizeof(T)) + (size_t)lane_b) = x[i];
     }
     // accumulators of branching bodies: LDS, or the global slab when the plan could not fit them (rare accesses)
     template <int N>
@@ -90,10 +93,17 @@ struct ChainMem {
         if (s & kSlotGlobal) glb_st(s, x);
         else lds_st(s, x);
     }
-    __device__ __forceinline__ T q(int j) const { return in_q[(size_t)j * kWave]; }
-    __device__ __forceinline__ T qd(int j) const { return in_qd[(size_t)j * kWave]; }
-    __device__ __forceinline__ T x(int j) const { return in_x[(size_t)j * kWave]; }
-    __device__ __forceinline__ void put(int j, T v) const { out_rows[(size_t)j * kWave] = v; }
+    __device__ __forceinline__ T row_ld(const T *base_u, int j) const
+    {
+        return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b);
+    }
+    __device__ __forceinline__ T q(int j) const { return row_ld(in_q_u, j); }
+    __device__ __forceinline__ T qd(int j) const { return row_ld(in_qd_u, j); }
+    __device__ __forceinline__ T x(int j) const { return row_ld(in_x_u, j); }
+    __device__ __forceinline__ void put(int j, T v) const
+    {
+        *reinterpret_cast<T *>(reinterpret_cast<char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b) = v;
+    }
 };
 
 // c = v x (z qd) for a joint about z: (v1, -v0, 0, v4, -v3, 0) qd   (Spatial.h:131-143)
@@ -1153,12 +1163,13 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
     ChainMem<T> M;
     M.lane = lane;
+    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = (DP.debug & 8) ? 0 : 1;
-    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
-    M.in_q = slab + lane;
-    M.in_qd = slab + (size_t)P.nq * kWave + lane;
-    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
-    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q_u = slab;
+    M.in_qd_u = slab + (size_t)P.nq * kWave;
+    M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1235,12 +1246,13 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
     ChainMem<T> M;
     M.lane = lane;
+    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
-    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
-    M.in_q = slab + lane;
-    M.in_qd = slab + (size_t)P.nq * kWave + lane;
-    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
-    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q_u = slab;
+    M.in_qd_u = slab + (size_t)P.nq * kWave;
+    M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
     const unsigned bq = (unsigned)(kWave * P.nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * P.nv) * (unsigned)sizeof(T);
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
@@ -1361,12 +1373,13 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     T *slab = scratch + (size_t)blockIdx.x * (size_t)n_rows_wave * kWave;
     ChainMem<T> M;
     M.lane = lane;
+    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
-    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
-    M.in_q = slab + lane;
-    M.in_qd = slab + (size_t)P.nq * kWave + lane;
-    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
-    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q_u = slab;
+    M.in_qd_u = slab + (size_t)P.nq * kWave;
+    M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
     const int m = A.n_contacts, nv = P.nv;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1469,7 +1482,7 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
                             y[i] = sacc * ex[21 + i];
                         }
 #pragma unroll
-                        for (int i = 0; i < 6; i++) M.glb[(size_t)(wbase + (stp.w_row + i) * 6 + j) * kWave + lane] = y[i];
+                        for (int i = 0; i < 6; i++) M.glb_u[(size_t)(wbase + (stp.w_row + i) * 6 + j) * kWave + lane] = y[i];
                     }
                     if (Js && live) {
 #pragma unroll
@@ -2157,12 +2170,13 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(P.nq + 2 * P.nv + DP.n_glb_slots) * kWave;
     ChainMem<T> M;
     M.lane = lane;
+    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
-    M.glb = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
-    M.in_q = slab + lane;
-    M.in_qd = slab + (size_t)P.nq * kWave + lane;
-    M.in_x = slab + (size_t)(P.nq + P.nv) * kWave + lane;
-    M.out_rows = slab + (size_t)(P.nq + P.nv) * kWave + lane;
+    M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q_u = slab;
+    M.in_qd_u = slab + (size_t)P.nq * kWave;
+    M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t left = B - tile * kWave;
