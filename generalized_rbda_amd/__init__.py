@@ -14,7 +14,8 @@ from typing import Optional
 from . import modeldesc  # noqa: F401  (model-description builder)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrbda_hip.so")
+# GRBDA_HIP_LIB: another build of the same library (kernel build variants, `make variant`); development A/B runs only
+LIB_PATH = os.environ.get("GRBDA_HIP_LIB") or os.path.join(_HERE, "libgrbda_hip.so")
 
 # every entry point include/grbda_hip.h declares
 C_ABI_SYMBOLS = [

@@ -19,9 +19,44 @@
 // (GenericImplicit clusters of src/Robots/Tello.cpp; ChainDiff below).  Everything else runs on the general interpreter
 // (kernels.hip); the plan compiler decides (ChainProgram::ok).  The same file holds the inverse dynamics on the chains
 // (rnea_chain_kernel) and the force-propagation kernel of the contact side (osim_chain_kernel).
+//
+// Two translation units are built from this file (Makefile).  GRBDA_CHAIN_UNIT == 1 carries the two fp64 kernels with the deepest
+// register pressure -- aba_chain_lm_kernel<double> and aba_chain_kernel<double, 2, true> (the program with differentials); unit 0
+// is everything else.  Both fp64 kernels spill, and how much depends on what else the compiler sees in the unit: measured in
+// one run against the single-unit build (tools/ab3.sh), Mini Cheetah fp64 at 65 536 states 0.0727 -> 0.0664 ms and TelloWithArms
+// fp64 3.60 -> 2.61 ms, every other kernel unchanged.  (Scheduler strategies were tried on top -- make variant
+// U1FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp": same figures for these two, fp32 kernels as fast or faster with the default.)
 #include <hip/hip_runtime.h>
 
 #include "devplan.h"
+
+#ifndef GRBDA_CHAIN_UNIT
+#define GRBDA_CHAIN_UNIT 0
+#endif
+// Which code paths use the permutation-structured transforms of devmath.h (rzp_*).  The defaults are what the same-run A/B
+// (tools/ab3.sh, library variants of `make variant VFLAGS=-DGRBDA_PERM_...`) kept: links, general rotors and pairs of the fp32
+// forward dynamics (JVRC-1 1.234 -> 1.178 ms per 2^20 states, TelloWithArms 0.801 -> 0.789, MIT Humanoid unchanged at 0.1495 --
+// its limbs are short and the time is not in the transforms); NOT the acceleration run, the inverse dynamics (JVRC-1 fp32
+// 0.665 -> 0.715 ms with them: the switch costs more than the products save) and the fp64 kernels (they spill; Tello fp64
+// 2.6 -> 3.7 ms with them).
+#ifndef GRBDA_PERM_LINK
+#define GRBDA_PERM_LINK 1
+#endif
+#ifndef GRBDA_PERM_ACC
+#define GRBDA_PERM_ACC 0
+#endif
+#ifndef GRBDA_PERM_ROTOR
+#define GRBDA_PERM_ROTOR 1
+#endif
+#ifndef GRBDA_PERM_PAIR
+#define GRBDA_PERM_PAIR 1
+#endif
+#ifndef GRBDA_PERM_RNEA
+#define GRBDA_PERM_RNEA 0
+#endif
+#ifndef GRBDA_PERM_F64
+#define GRBDA_PERM_F64 0
+#endif
 
 namespace grbda_hip {
 
@@ -49,6 +84,7 @@ struct ChainMem {
     int lane;
     unsigned lane_b;  // lane * sizeof(T): the byte offset every slab access adds to its wave-uniform row address
     int gmul;  // 1; 0 under GRBDA_CHAIN_DEBUG bit 3: every global slot aliases row 0 (same instructions, no slab traffic)
+    int amask; // ~0; kSlotGlobal under GRBDA_CHAIN_DEBUG bit 4: the slots that overflowed the LDS alias row 0, the [K | y0] blocks stay
 
     template <int N>
     __device__ __forceinline__ void lds_ld(int s, T (&x)[N]) const
@@ -84,13 +120,13 @@ struct ChainMem {
     template <int N>
     __device__ __forceinline__ void acc_ld(int s, T (&x)[N]) const
     {
-        if (s & kSlotGlobal) glb_ld(s, x);
+        if (s & kSlotGlobal) glb_ld(s & amask, x);
         else lds_ld(s, x);
     }
     template <int N>
     __device__ __forceinline__ void acc_st(int s, const T (&x)[N]) const
     {
-        if (s & kSlotGlobal) glb_st(s, x);
+        if (s & kSlotGlobal) glb_st(s & amask, x);
         else lds_st(s, x);
     }
     __device__ __forceinline__ T row_ld(const T *base_u, int j) const
@@ -115,8 +151,8 @@ __device__ __forceinline__ void vxz(const T (&v)[6], T qd, T (&c)[6])
 }
 
 // pA = v x* (I v) for constant packed inertia (ClusterTreeDynamics.cpp:95-98)
-template <class T>
-__device__ __forceinline__ void bias_force(cptr<T> I, const T (&v)[6], T (&p)[6])
+template <class T, class I21>
+__device__ __forceinline__ void bias_force(const I21 &I, const T (&v)[6], T (&p)[6])
 {
     T Iv[6];
     symv_c(I, v, Iv);
@@ -152,12 +188,96 @@ __device__ __forceinline__ void rotor_terms(cptr<T> Cr, const T (&vp)[6], T qdr,
     xforce_inv(E0, Cr + 9, t, tp);
 }
 
+// E-dependent part of one link of the backward run: F = X^T h, psic = X^T t, IAc = X^T IA X.  perm >= 0: the tree rotation is the
+// cyclic permutation P_perm (devmath.h, rzp_*), wave-uniform switch; otherwise the general rotation E = Rz Et.
+template <class T, int K, class A21, class R3>
+__device__ __forceinline__ void link_up_p(T s, T c, const R3 &r, const T (&h)[6], const T (&t)[6], const A21 &IA, T (&F)[6],
+                                          T (&psic)[6], T (&IAc)[21])
+{
+    xforce_inv_p<T, K>(s, c, r, h, F);
+    xforce_inv_p<T, K>(s, c, r, t, psic);
+    congruence_p<T, K>(s, c, r, IA, IAc);
+}
+template <class T>
+__device__ __forceinline__ int perm_if(bool on, int perm)
+{
+    return on && (GRBDA_PERM_F64 || sizeof(T) == 4) ? perm : -1;
+}
+template <class T, class A21>
+__device__ __forceinline__ void link_up(int perm, T s, T c, cptr<T> C, const T (&h)[6], const T (&t)[6], const A21 &IA,
+                                        T (&F)[6], T (&psic)[6], T (&IAc)[21])
+{
+    if (perm < 0) {
+        T E[9];
+        rotate_z(s, c, C, E);
+        xforce_inv(E, C + 9, h, F);
+        xforce_inv(E, C + 9, t, psic);
+        congruence(E, C + 9, IA, IAc);
+    } else if (perm == 0) {
+        link_up_p<T, 0, A21>(s, c, C + 9, h, t, IA, F, psic, IAc);
+    } else if (perm == 1) {
+        link_up_p<T, 1, A21>(s, c, C + 9, h, t, IA, F, psic, IAc);
+    } else {
+        link_up_p<T, 2, A21>(s, c, C + 9, h, t, IA, F, psic, IAc);
+    }
+}
+template <class T>
+__device__ __forceinline__ void link_down(int perm, T s, T c, cptr<T> C, const T (&vp)[6], T (&v)[6])
+{
+    if (perm < 0) {
+        T E[9];
+        rotate_z(s, c, C, E);
+        xmotion(E, C + 9, vp, v);
+    } else if (perm == 0) {
+        xmotion_p<T, 0>(s, c, C + 9, vp, v);
+    } else if (perm == 1) {
+        xmotion_p<T, 1>(s, c, C + 9, vp, v);
+    } else {
+        xmotion_p<T, 2>(s, c, C + 9, vp, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward run: TreeModel::forwardKinematics (TreeModel.cpp:6-32) along a chain, root side first
 // ---------------------------------------------------------------------------------------------------------------
 // SVG: the program keeps SOME of the [sin, cos, v] blocks of the links in the wave's global slab instead of LDS (ChainProgram::
 // sv_global: chains too long for the LDS budget); a compile-time property of the run so that the common case carries
 // neither the test nor the prefetch registers.
+template <class T>
+__device__ __forceinline__ void link_down2(int perm, T s, T c, cptr<T> C, const T (&vp)[6], const T (&ap)[6], T (&v)[6], T (&a)[6])
+{
+    if (perm < 0) {
+        T E[9];
+        rotate_z(s, c, C, E);
+        xmotion(E, C + 9, vp, v);
+        xmotion(E, C + 9, ap, a);
+    } else if (perm == 0) {
+        xmotion_p<T, 0>(s, c, C + 9, vp, v);
+        xmotion_p<T, 0>(s, c, C + 9, ap, a);
+    } else if (perm == 1) {
+        xmotion_p<T, 1>(s, c, C + 9, vp, v);
+        xmotion_p<T, 1>(s, c, C + 9, ap, a);
+    } else {
+        xmotion_p<T, 2>(s, c, C + 9, vp, v);
+        xmotion_p<T, 2>(s, c, C + 9, ap, a);
+    }
+}
+template <class T>
+__device__ __forceinline__ void link_force_up(int perm, T s, T c, cptr<T> C, const T (&f)[6], T (&o)[6])
+{
+    if (perm < 0) {
+        T E[9];
+        rotate_z(s, c, C, E);
+        xforce_inv(E, C + 9, f, o);
+    } else if (perm == 0) {
+        xforce_inv_p<T, 0>(s, c, C + 9, f, o);
+    } else if (perm == 1) {
+        xforce_inv_p<T, 1>(s, c, C + 9, f, o);
+    } else {
+        xforce_inv_p<T, 2>(s, c, C + 9, f, o);
+    }
+}
+
 template <class T, bool SVG>
 __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
 {
@@ -185,10 +305,9 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
         }
         cptr<T> C = P.consts + l.cofs;
         const T g0 = C[kBodyConstFixed];
-        T blk[8], E[9], v[6];
+        T blk[8], v[6];
         sincos_t(g0 * qi, &blk[0], &blk[1]);
-        rotate_z(blk[0], blk[1], C, E);
-        xmotion(E, C + 9, vp, v);
+        link_down(perm_if<T>(GRBDA_PERM_LINK, l.perm), blk[0], blk[1], C, vp, v);
         v[2] += g0 * qdi_in;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -211,9 +330,29 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
 // give K = D^-1 F^T, y0 = D^-1 u and the correction -F D^-1 F^T, + F D^-1 u on P (kernels.hip, aba_bwd_static).
 // Out: (IA, psi) = what P receives (without the rotors' constant X0^T I X0, which is part of P's constants).
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, bool OSIM>
-__device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainPair &pr, T (&IA)[21],
-                                         T (&psi)[6])
+template <class T, int K>
+__device__ __forceinline__ void xmotion_k(T s, T c, const T (&E)[9], cptr<T> C, const T (&m)[6], T (&o)[6])
+{
+    if constexpr (K < 0) xmotion(E, C + 9, m, o);
+    else xmotion_p<T, K>(s, c, C + 9, m, o);
+}
+template <class T, int K>
+__device__ __forceinline__ void xforce_inv_k(T s, T c, const T (&E)[9], cptr<T> C, const T (&f)[6], T (&o)[6])
+{
+    if constexpr (K < 0) xforce_inv(E, C + 9, f, o);
+    else xforce_inv_p<T, K>(s, c, C + 9, f, o);
+}
+template <class T, int K, class A21>
+__device__ __forceinline__ void congruence_k(T s, T c, const T (&E)[9], cptr<T> C, const A21 &A, T (&B)[21])
+{
+    if constexpr (K < 0) congruence(E, C + 9, A, B);
+    else congruence_p<T, K>(s, c, C + 9, A, B);
+}
+
+// K1, K2: compile-time ChainPair::perm of the two links (-1: general rotation)
+template <class T, bool OSIM, int K1, int K2>
+__device__ __forceinline__ void pair_bwd_k(const ChainTables<T> &P, const ChainMem<T> &M, const ChainPair &pr, T (&IA)[21],
+                                           T (&psi)[6])
 {
     cptr<T> C1 = P.consts + pr.cofs[0], C2 = P.consts + pr.cofs[1];
     T vp[6];
@@ -227,18 +366,18 @@ __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem
     // ---- kinematics of the two links ----
     T s1, c1, s2, c2, E1[9], E2[9], v1[6], v2[6], ch1[6], ch2[6];
     sincos_t(y1, &s1, &c1);
-    rotate_z(s1, c1, C1, E1);
-    xmotion(E1, C1 + 9, vp, v1);
+    if constexpr (K1 < 0) rotate_z(s1, c1, C1, E1);
+    xmotion_k<T, K1>(s1, c1, E1, C1, vp, v1);
     v1[2] += yd1;
     vxz(v1, yd1, ch1);
     sincos_t(y2, &s2, &c2);
-    rotate_z(s2, c2, C2, E2);
-    xmotion(E2, C2 + 9, v1, v2);
+    if constexpr (K2 < 0) rotate_z(s2, c2, C2, E2);
+    xmotion_k<T, K2>(s2, c2, E2, C2, v1, v2);
     v2[2] += yd2;
     vxz(v2, yd2, ch2);
     // in-cluster bias acceleration of link2: ccl2 = ch2 + X2 ch1 (GenericJoint.cpp:430-450)
     T ccl2[6];
-    xmotion(E2, C2 + 9, ch1, ccl2);
+    xmotion_k<T, K2>(s2, c2, E2, C2, ch1, ccl2);
 #pragma unroll
     for (int j = 0; j < 6; j++) ccl2[j] += ch2[j];
 
@@ -260,13 +399,13 @@ __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem
         symv_c(I2, ch2, t);
 #pragma unroll
         for (int j = 0; j < 6; j++) t[j] += p2[j];
-        xforce_inv(E2, C2 + 9, t, psi1);
-        congruence(E2, C2 + 9, I2, IA1);
+        xforce_inv_k<T, K2>(s2, c2, E2, C2, t, psi1);
+        congruence_k<T, K2>(s2, c2, E2, C2, I2, IA1);
         // joint-space coupling through the chain: f = X2^T h2 at link1, then at P
         T f[6];
-        xforce_inv(E2, C2 + 9, h2, f);
+        xforce_inv_k<T, K2>(s2, c2, E2, C2, h2, f);
         D01 += f[2];  // Hc (G1 G2^T + G2 G1^T) with G1 = (1, 0), G2 = (0, 1)
-        xforce_inv(E1, C1 + 9, f, F1);
+        xforce_inv_k<T, K1>(s1, c1, E1, C1, f, F1);
     }
     // ---- link1 ----
     {
@@ -288,9 +427,9 @@ __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem
         symv_z(IA1, ch1, t);
 #pragma unroll
         for (int j = 0; j < 6; j++) t[j] += psi1[j];
-        xforce_inv(E1, C1 + 9, t, psi);
-        congruence(E1, C1 + 9, IA1, IA);
-        xforce_inv(E1, C1 + 9, h1, F0);
+        xforce_inv_k<T, K1>(s1, c1, E1, C1, t, psi);
+        congruence_k<T, K1>(s1, c1, E1, C1, IA1, IA);
+        xforce_inv_k<T, K1>(s1, c1, E1, C1, h1, F0);
     }
     // ---- rotors (q = 0): bias to P, joint-space terms with their G rows ----
 #pragma unroll
@@ -335,6 +474,14 @@ __device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem
 #pragma unroll
         for (int cc = r; cc < 6; cc++) IA[sidx(r, cc)] -= F0[r] * blk[cc] + F1[r] * blk[6 + cc];
     }
+}
+template <class T, bool OSIM>
+__device__ __forceinline__ void pair_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainPair &pr, T (&IA)[21],
+                                         T (&psi)[6])
+{
+    // (the knee-ankle pairs of the MIT Humanoid: both tree rotations the identity)
+    if (perm_if<T>(GRBDA_PERM_PAIR, pr.perm[0]) == 0 && pr.perm[1] == 0) pair_bwd_k<T, OSIM, 0, 0>(P, M, pr, IA, psi);
+    else pair_bwd_k<T, OSIM, -1, -1>(P, M, pr, IA, psi);
 }
 
 template <class T>
@@ -828,8 +975,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         cptr<T> Ib = P.consts + l.iofs;
         const T g0 = C[kBodyConstFixed];
         const T qdi = g0 * yd;
-        T E[9], v[6];
-        rotate_z(blk[0], blk[1], C, E);
+        T v[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) v[j] = blk[2 + j];
         T chat[6];
@@ -848,17 +994,15 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         T u = tau_in - g0 * bj;
         T D = h[2] * g0 * g0;
         T F[6];
-        xforce_inv(E, C + 9, h, F);
-#pragma unroll
-        for (int r = 0; r < 6; r++) F[r] *= g0;
         {
             T t[6];
             symv_z(IA, chat, t);
 #pragma unroll
             for (int j = 0; j < 6; j++) t[j] += psi[j];
-            xforce_inv(E, C + 9, t, psic);
-            congruence(E, C + 9, IA, IAc);
+            link_up(perm_if<T>(GRBDA_PERM_LINK, l.perm), blk[0], blk[1], C, h, t, IA, F, psic, IAc);
         }
+#pragma unroll
+        for (int r = 0; r < 6; r++) F[r] *= g0;
         if (l.rofs >= 0 && l.rpre < 0) {
             cptr<T> Cr = P.consts + l.rofs;
             cptr<T> Ir = Cr + 12;
@@ -872,10 +1016,9 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
                 for (int j = 0; j < 6; j++) vp[j] = 0;
             }
-            T sr, cr_, Er[9], vr[6], crv[6], prr[6], hr[6];
+            T sr, cr_, vr[6], crv[6], prr[6], hr[6];
             sincos_t(gr * y_in, &sr, &cr_);
-            rotate_z(sr, cr_, Cr, Er);
-            xmotion(Er, Cr + 9, vp, vr);
+            link_down(perm_if<T>(GRBDA_PERM_ROTOR, l.rperm), sr, cr_, Cr, vp, vr);
             vr[2] += qdr;
             vxz(vr, qdr, crv);
             bias_force(Ir, vr, prr);
@@ -885,16 +1028,14 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
             u -= gr * bjr;
             D += hr[2] * gr * gr;
             T fr[6], t[6], tp[6], Br[21];
-            xforce_inv(Er, Cr + 9, hr, fr);
-#pragma unroll
-            for (int r = 0; r < 6; r++) F[r] += fr[r] * gr;
             symv_z(Ir, crv, t);
 #pragma unroll
             for (int j = 0; j < 6; j++) t[j] += prr[j];
-            xforce_inv(Er, Cr + 9, t, tp);
+            link_up(perm_if<T>(GRBDA_PERM_ROTOR, l.rperm), sr, cr_, Cr, hr, t, Ir, fr, tp, Br);
+#pragma unroll
+            for (int r = 0; r < 6; r++) F[r] += fr[r] * gr;
 #pragma unroll
             for (int j = 0; j < 6; j++) psic[j] += tp[j];
-            congruence(Er, Cr + 9, Ir, Br);
 #pragma unroll
             for (int j = 0; j < 21; j++) IAc[j] += Br[j];
         }
@@ -1010,11 +1151,9 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
             cptr<T> C = P.consts + l.cofs;
             const T g0 = C[kBodyConstFixed];
             const T qdi = g0 * yd;
-            T E[9], v[6], a[6], chat[6], sn, cs;
+            T v[6], a[6], chat[6], sn, cs;
             sincos_t(g0 * yq, &sn, &cs);
-            rotate_z(sn, cs, C, E);
-            xmotion(E, C + 9, vp, v);
-            xmotion(E, C + 9, ap, a);
+            link_down2(perm_if<T>(GRBDA_PERM_ACC, l.perm), sn, cs, C, vp, ap, v, a);
             v[2] += qdi;
             vxz(v, qdi, chat);
 #pragma unroll
@@ -1165,6 +1304,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = (DP.debug & 8) ? 0 : 1;
+    M.amask = (DP.debug & 16) ? kSlotGlobal : ~0;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -1248,6 +1388,7 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
+    M.amask = ~0;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -1314,10 +1455,13 @@ hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, co
     hipLaunchKernelGGL((aba_chain_lm_kernel<T>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
+#if GRBDA_CHAIN_UNIT == 0
 template hipError_t launch_aba_chain_lm<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
                                                float *, int, size_t, hipStream_t);
+#else
 template hipError_t launch_aba_chain_lm<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
                                                 size_t, double *, int, size_t, hipStream_t);
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Inverse operational-space inertia J H^-1 J^T of contact frames by force propagation -- the recursion behind
@@ -1375,6 +1519,7 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
+    M.amask = ~0;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -1723,19 +1868,27 @@ hipError_t launch_osim_chain(const ChainDev<T> &P, const OsimArgs<T> &A, const T
     hipLaunchKernelGGL((osim_chain_kernel<T>), dim3(grid), dim3(kWave), lds_bytes, stream, P, A, q, zeros, Linv, J, B, scratch);
     return hipGetLastError();
 }
+#if GRBDA_CHAIN_UNIT == 0
 template hipError_t launch_osim_chain<float>(const ChainDev<float> &, const OsimArgs<float> &, const float *, const float *, float *,
                                              float *, size_t, float *, int, size_t, hipStream_t);
 template hipError_t launch_osim_chain<double>(const ChainDev<double> &, const OsimArgs<double> &, const double *, const double *,
                                               double *, double *, size_t, double *, int, size_t, hipStream_t);
+#endif
 
+hipError_t launch_aba_chain_diff_f64(const ChainDev<double> &P, const double *q, const double *qd, const double *tau, double *ydd, size_t B,
+                                     double *scratch, int grid, size_t lds_bytes, hipStream_t stream);
 template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd)
 {
     if (P.n_diffs > 0) {
         if (four_waves_per_simd) return hipErrorInvalidValue;  // (capi.cpp keeps such programs at two wavefronts per SIMD)
-        hipLaunchKernelGGL((aba_chain_kernel<T, 2, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
-        return hipGetLastError();
+        if constexpr (sizeof(T) == 8) {
+            return launch_aba_chain_diff_f64(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream);  // (unit 1, below)
+        } else {
+            hipLaunchKernelGGL((aba_chain_kernel<T, 2, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+            return hipGetLastError();
+        }
     }
     if constexpr (sizeof(T) == 4) {
         if (four_waves_per_simd) {
@@ -1746,10 +1899,19 @@ hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const
     hipLaunchKernelGGL((aba_chain_kernel<T, 2, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
+#if GRBDA_CHAIN_UNIT == 0
 template hipError_t launch_aba_chain<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
                                             float *, int, size_t, hipStream_t, bool);
 template hipError_t launch_aba_chain<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
                                              size_t, double *, int, size_t, hipStream_t, bool);
+#else
+hipError_t launch_aba_chain_diff_f64(const ChainDev<double> &P, const double *q, const double *qd, const double *tau, double *ydd, size_t B,
+                                     double *scratch, int grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((aba_chain_kernel<double, 2, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    return hipGetLastError();
+}
+#endif
 
 
 // ===============================================================================================================
@@ -1860,11 +2022,9 @@ __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const Chain
         cptr<T> C = P.consts + l.cofs;
         const T g0 = C[kBodyConstFixed];
         const T qdi = g0 * ydi;
-        T blk[9], E[9], v[6], a[6], f[6];
+        T blk[9], v[6], a[6], f[6];
         sincos_t(g0 * qi, &blk[6], &blk[7]);
-        rotate_z(blk[6], blk[7], C, E);
-        xmotion(E, C + 9, vp, v);
-        xmotion(E, C + 9, ap, a);
+        link_down2(perm_if<T>(GRBDA_PERM_RNEA, l.perm), blk[6], blk[7], C, vp, ap, v, a);
         v[2] += qdi;
         a[0] += v[1] * qdi;
         a[1] -= v[0] * qdi;
@@ -1885,11 +2045,9 @@ __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const Chain
             cptr<T> Cr = P.consts + l.rofs;
             const T gr = Cr[kBodyConstFixed];
             const T qdr = gr * ydi;
-            T sr, cr_, Er[9], vr[6], ar[6], fr[6], fpr[6];
+            T sr, cr_, vr[6], ar[6], fr[6], fpr[6];
             sincos_t(gr * qi, &sr, &cr_);
-            rotate_z(sr, cr_, Cr, Er);
-            xmotion(Er, Cr + 9, vp, vr);
-            xmotion(Er, Cr + 9, ap, ar);
+            link_down2(perm_if<T>(GRBDA_PERM_RNEA, l.rperm), sr, cr_, Cr, vp, ap, vr, ar);
             vr[2] += qdr;
             ar[0] += vr[1] * qdr;
             ar[1] -= vr[0] * qdr;
@@ -1898,7 +2056,7 @@ __device__ __forceinline__ void rnea_run_fwd(const RneaTables<T> &P, const Chain
             ar[2] += gr * yddi;
             body_force_c(Cr + 12, vr, ar, fr);
             blk[8] = gr * fr[2];
-            xforce_inv(Er, Cr + 9, fr, fpr);
+            link_force_up(perm_if<T>(GRBDA_PERM_RNEA, l.rperm), sr, cr_, Cr, fr, fpr);
             if (l.lds_pf >= 0) add6<T, GLB>(M, l.lds_pf, fpr);
         }
 #pragma unroll
@@ -1933,14 +2091,13 @@ __device__ __forceinline__ void rnea_run_bwd(const RneaTables<T> &P, const Chain
     for (int i = 0; i < sg.count; i++) {
         const RneaLink l = load_rec(P.links + (sg.first + i));
         cptr<T> C = P.consts + l.cofs;
-        T blk[9], E[9], ft[6];
+        T blk[9], ft[6];
         if constexpr (GLB) M.acc_ld(l.lds_blk, blk);
         else M.lds_ld(l.lds_blk, blk);
 #pragma unroll
         for (int j = 0; j < 6; j++) ft[j] = blk[j] + fc[j];
         M.put(l.v_index, C[kBodyConstFixed] * ft[2] + blk[8]);
-        rotate_z(blk[6], blk[7], C, E);
-        xforce_inv(E, C + 9, ft, fc);
+        link_force_up(perm_if<T>(GRBDA_PERM_RNEA, l.perm), blk[6], blk[7], C, ft, fc);
     }
     if (sg.lds_pf >= 0) add6<T, GLB>(M, sg.lds_pf, fc);
 }
@@ -2172,6 +2329,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
+    M.amask = ~0;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -2213,28 +2371,45 @@ hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, 
     else hipLaunchKernelGGL((rnea_chain_kernel<T, false, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
 }
+#if GRBDA_CHAIN_UNIT == 0
 template hipError_t launch_rnea_chain<float>(const RneaChainDev<float> &, const float *, const float *, const float *, float *, size_t,
                                              float *, int, size_t, hipStream_t);
 template hipError_t launch_rnea_chain<double>(const RneaChainDev<double> &, const double *, const double *, const double *, double *,
                                               size_t, double *, int, size_t, hipStream_t);
+#endif
 
+static hipError_t set_max_dynamic_lds(const void *const *kernels, int n)
+{
+    for (int i = 0; i < n; i++) {
+        const hipError_t e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t set_max_dynamic_lds_chain_unit1();
+#if GRBDA_CHAIN_UNIT == 0
 hipError_t set_max_dynamic_lds_chain()
 {
     const void *const kernels[] = {
         reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, false>), reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, true>),
         reinterpret_cast<const void *>(&aba_chain_kernel<float, 4, false>),
-        reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, false>), reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, true>),
+        reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, false>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, false>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, false>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, true>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, true>),
         reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>),
-        reinterpret_cast<const void *>(&aba_chain_lm_kernel<float>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<double>)};
-    for (const void *k : kernels) {
-        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+        reinterpret_cast<const void *>(&aba_chain_lm_kernel<float>)};
+    const hipError_t e = set_max_dynamic_lds(kernels, static_cast<int>(sizeof(kernels) / sizeof(kernels[0])));
+    return e != hipSuccess ? e : set_max_dynamic_lds_chain_unit1();
 }
+#else
+hipError_t set_max_dynamic_lds_chain_unit1()
+{
+    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, true>),
+                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<double>)};
+    return set_max_dynamic_lds(kernels, 2);
+}
+#endif
 
 }  // namespace grbda_hip

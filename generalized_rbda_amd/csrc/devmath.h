@@ -191,8 +191,8 @@ __device__ __forceinline__ void symv(const T (&A)[21], const T (&x)[6], T (&y)[6
         y[i] = s;
     }
 }
-template <class T>
-__device__ __forceinline__ void symv_c(cptr<T> A /* wave-uniform constants */, const T (&x)[6], T (&y)[6])
+template <class T, class A21>
+__device__ __forceinline__ void symv_c(const A21 &A /* wave-uniform constants */, const T (&x)[6], T (&y)[6])
 {
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -470,8 +470,8 @@ __device__ __forceinline__ void free_rotation(int ori_repr, const T *o, T (&E)[9
     }
 }
 
-template <class T>
-__device__ __forceinline__ void rotate_z(T s, T c, cptr<T> Et, T (&E)[9])
+template <class T, class E9>
+__device__ __forceinline__ void rotate_z(T s, T c, const E9 &Et, T (&E)[9])
 {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -479,6 +479,128 @@ __device__ __forceinline__ void rotate_z(T s, T c, cptr<T> Et, T (&E)[9])
         E[3 + j] = c * Et[3 + j] - s * Et[j];
         E[6 + j] = Et[6 + j];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Links whose tree rotation is a cyclic permutation of the axes (plan.cpp: Et in {1, C, C^2} after the canonical joint axes -- every
+// joint of JVRC-1, every joint of the other robots whose URDF <origin> carries no rotation): E = Rz(q) P_K with
+// (P_K x)_i = x_((i + K) % 3).  The products with E then cost 4 multiply-adds per 3-vector instead of 9 and a 3 x 3 block congruence
+// 22-24 instead of 45-54; the permutation is compile-time re-indexing.  K is wave-uniform (ChainLink::perm): the callers switch.
+// ---------------------------------------------------------------------------------------------
+template <class T, int K>
+__device__ __forceinline__ void rzp_apply(T s, T c, const T (&x)[3], T (&o)[3])  // o = Rz P_K x
+{
+    const T w0 = x[K % 3], w1 = x[(1 + K) % 3], w2 = x[(2 + K) % 3];
+    o[0] = c * w0 + s * w1;
+    o[1] = c * w1 - s * w0;
+    o[2] = w2;
+}
+template <class T, int K>
+__device__ __forceinline__ void rzp_apply_t(T s, T c, const T (&y)[3], T (&o)[3])  // o = P_K^T Rz^T y
+{
+    o[K % 3] = c * y[0] - s * y[1];
+    o[(1 + K) % 3] = s * y[0] + c * y[1];
+    o[(2 + K) % 3] = y[2];
+}
+template <class T, int K, class R3>
+__device__ __forceinline__ void xmotion_p(T s, T c, R3 r, const T (&m)[6], T (&o)[6])
+{
+    const T w[3] = {m[0], m[1], m[2]};
+    const T t[3] = {m[3] - (r[1] * m[2] - r[2] * m[1]), m[4] - (r[2] * m[0] - r[0] * m[2]), m[5] - (r[0] * m[1] - r[1] * m[0])};
+    T a[3], b[3];
+    rzp_apply<T, K>(s, c, w, a);
+    rzp_apply<T, K>(s, c, t, b);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        o[i] = a[i];
+        o[3 + i] = b[i];
+    }
+}
+template <class T, int K, class R3>
+__device__ __forceinline__ void xforce_inv_p(T s, T c, R3 r, const T (&f)[6], T (&o)[6])
+{
+    const T fa[3] = {f[0], f[1], f[2]}, fl[3] = {f[3], f[4], f[5]};
+    T n[3], l[3];
+    rzp_apply_t<T, K>(s, c, fa, n);
+    rzp_apply_t<T, K>(s, c, fl, l);
+    o[0] = n[0] + (r[1] * l[2] - r[2] * l[1]);
+    o[1] = n[1] + (r[2] * l[0] - r[0] * l[2]);
+    o[2] = n[2] + (r[0] * l[1] - r[1] * l[0]);
+    o[3] = l[0];
+    o[4] = l[1];
+    o[5] = l[2];
+}
+// R = E^T M E for E = Rz P_K: M' = Rz^T M Rz (rows and columns 0, 1 mix), then R[a][b] = M'[sigma^-1(a)][sigma^-1(b)]
+template <class T, int K, bool SYM>
+__device__ __forceinline__ void rot3_p(T s, T c, const T (&M)[9], T (&R)[9])
+{
+    T t[9], m[9];  // t = M Rz ; m = Rz^T t
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        t[3 * i] = c * M[3 * i] - s * M[3 * i + 1];
+        t[3 * i + 1] = s * M[3 * i] + c * M[3 * i + 1];
+        t[3 * i + 2] = M[3 * i + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (!SYM || j >= 0) m[j] = c * t[j] - s * t[3 + j];
+        if (!SYM || j >= 1) m[3 + j] = s * t[j] + c * t[3 + j];
+        m[6 + j] = t[6 + j];
+    }
+    if (SYM) {
+        m[3] = m[1];
+        m[6] = m[2];
+        m[7] = m[5];
+    }
+    // sigma(i) = (i + K) % 3 maps an index of the permuted vector to the original one: (P x)_i = x_sigma(i); E^T M E = P^T M' P,
+    // (P^T M' P)[sigma(i)][sigma(j)] = M'[i][j]
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R[3 * ((i + K) % 3) + (j + K) % 3] = m[3 * i + j];
+}
+template <class T, int K, class R3, class A21>
+__device__ __forceinline__ void congruence_p(T s, T c, R3 r, const A21 &A, T (&B)[21])
+{
+    T A11[9], A12[9], A22[9], R11[9], R12[9], R22[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A11[3 * i + j] = A[sidx(i, j)];
+            A12[3 * i + j] = A[sidx(i, 3 + j)];
+            A22[3 * i + j] = A[sidx(3 + i, 3 + j)];
+        }
+    rot3_p<T, K, true>(s, c, A11, R11);
+    rot3_p<T, K, false>(s, c, A12, R12);
+    rot3_p<T, K, true>(s, c, A22, R22);
+    T TR[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        TR[j] = R12[j] + (r[1] * R22[6 + j] - r[2] * R22[3 + j]);
+        TR[3 + j] = R12[3 + j] + (r[2] * R22[j] - r[0] * R22[6 + j]);
+        TR[6 + j] = R12[6 + j] + (r[0] * R22[3 + j] - r[1] * R22[j]);
+    }
+    T N[9], Pm[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        N[3 * i + 0] = R12[3 * i + 1] * r[2] - R12[3 * i + 2] * r[1];
+        N[3 * i + 1] = R12[3 * i + 2] * r[0] - R12[3 * i + 0] * r[2];
+        N[3 * i + 2] = R12[3 * i + 0] * r[1] - R12[3 * i + 1] * r[0];
+        Pm[3 * i + 0] = TR[3 * i + 1] * r[2] - TR[3 * i + 2] * r[1];
+        Pm[3 * i + 1] = TR[3 * i + 2] * r[0] - TR[3 * i + 0] * r[2];
+        Pm[3 * i + 2] = TR[3 * i + 0] * r[1] - TR[3 * i + 1] * r[0];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j >= i) {
+                B[sidx(i, j)] = R11[3 * i + j] - N[3 * j + i] - Pm[3 * i + j];
+                B[sidx(3 + i, 3 + j)] = R22[3 * i + j];
+            }
+            B[sidx(i, 3 + j)] = TR[3 * i + j];
+        }
 }
 
 // y = A x for packed symmetric A and a revolute-about-z velocity product x = (x0, x1, 0, x3, x4, 0)

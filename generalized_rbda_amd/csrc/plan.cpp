@@ -19,6 +19,21 @@
 #include "../../include/grbda_model_desc.h"
 
 namespace grbda_hip {
+// Is the tree rotation Et (row-major at consts[cofs]) a cyclic permutation of the axes, (Et x)_i = x_((i + k) % 3), to rounding (1e-14)?
+// Returns the shift k, or -1.  The chain kernels then use the permutation-structured transforms (devmath.h, rzp_*).
+// GRBDA_NO_PERM_LINKS: A/B switch, every link on the general rotation path.
+static int cyclic_shift(const std::vector<double> &consts, int cofs)
+{
+    if (std::getenv("GRBDA_NO_PERM_LINKS")) return -1;
+    for (int k = 0; k < 3; k++) {
+        bool is = true;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) is = is && std::fabs(consts[cofs + 3 * i + j] - (j == (i + k) % 3 ? 1.0 : 0.0)) < 1e-14;
+        if (is) return k;
+    }
+    return -1;
+}
+
 
 namespace {
 
@@ -1096,6 +1111,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     pr.v_index = cr.v_index;
                     pr.cofs[0] = bodies[l1].cofs; pr.cofs[1] = bodies[l2].cofs; pr.cofs[2] = bodies[r[0]].cofs; pr.cofs[3] = bodies[r[1]].cofs;
                     pair_rotors[c] = {r[0], r[1]};
+                    pr.perm[0] = cyclic_shift(P.consts, pr.cofs[0]);
+                    pr.perm[1] = cyclic_shift(P.consts, pr.cofs[1]);
+                    if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d pair perms %d %d\n", c, pr.perm[0], pr.perm[1]);
                 } else {
                     ok = false;
                 }
@@ -1161,6 +1179,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     l.has_child = br.has_child;
                     l.lds_sv = l.lds_pv = l.lds_va = -1;
                     l.glb_k = glb(10);  // [K 6][y0][sin][cos] (+ OSIM pass: 1 / D)
+                    l.perm = cyclic_shift(P.consts, br.cofs);
+                    l.rperm = l.rofs >= 0 && l.rpre < 0 ? cyclic_shift(P.consts, l.rofs) : -1;
+                    if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d class %d perm %d rotor perm %d\n", c, cls[c], l.perm, l.rperm);
                 } else if (is_diff(c)) {
                     const DiffShape &ds = diff_shape[c];
                     ChainDiff &d = diff_of[c];
@@ -1424,6 +1445,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         l.q_index = cr.q_index; l.v_index = cr.v_index; l.cofs = bodies[tip[c]].cofs;
                         l.rofs = cls[c] == 2 ? bodies[cr.rotor_body].cofs : (cls[c] == 4 ? bodies[gen_rotor[c]].cofs : -1);
                         l.general_rotor = cls[c] == 4;
+                        l.perm = link_of[c].perm; l.rperm = link_of[c].rperm;
                         l.lds_blk = l.lds_va = l.lds_pf = -1;
                     } else if (is_diff(c)) {
                         RneaDiff &d = rd[c];

@@ -187,7 +187,10 @@ struct ChainLink {
     int32_t lds_va;     // acceleration sweep: LDS slot of [v 6][a 6] when another segment reads them, else -1
     int32_t rpre;       // axisymmetric rotor: state-independent constants [X0^T h (6)][h_z] with h = I_rotor[:, z] (plan.cpp);
                         // -1 with rofs >= 0: a general rotor, evaluated at its own angle
-    int32_t reserved[5];
+    int32_t perm;       // 0, 1, 2: the tree rotation Et is the cyclic axis permutation (Et x)_i = x_((i + perm) % 3), the kernels use
+                        // the permutation-structured transforms (devmath.h, rzp_*); -1: general rotation
+    int32_t rperm;      // the same for the tree rotation of a general rotor (rofs >= 0, rpre < 0)
+    int32_t reserved[3];
 };
 
 // a RevolutePairWithRotor-shaped leaf cluster (32 ints)
@@ -198,7 +201,8 @@ struct ChainPair {
     int32_t glb_k;      // [K 12][y0 2] (+ 7 rows written by the OSIM pass)
     int32_t lds_pva;    // acceleration sweep: parent body's [v 6][a 6]
     int32_t rpre[2];    // rotor1, rotor2: [X0^T h (6)][h_z]
-    int32_t reserved[21];
+    int32_t perm[2];    // link1, link2: ChainLink::perm
+    int32_t reserved[19];
 };
 
 // An implicit two-rotor differential (the Tello hip and knee-ankle differentials, src/Robots/Tello.cpp:77-261 with
@@ -276,7 +280,8 @@ struct RneaLink {       // 16 ints
     int32_t lds_va;         // LDS slot of [v 6][a 6] when child segments read them, else -1
     int32_t lds_pf;         // LDS slot of the parent body's force (first 6 of its block / the base's), -1: ground
     int32_t general_rotor;  // 1: the rotor is not axisymmetric about its axis and is evaluated at its own angle
-    int32_t reserved[8];
+    int32_t perm, rperm;    // ChainLink::perm / rperm
+    int32_t reserved[6];
 };
 struct RneaPair {       // 16 ints
     int32_t q_index, v_index;
