@@ -151,6 +151,8 @@ struct DMat {
     T maxAbs() const { T s = 0; for (const T &x : d) s = std::fabs(x) > s ? std::fabs(x) : s; return s; }
 };
 
+template <typename T> using D6Mat = DMat<T>;  // 6 x n (cppTypes.h)
+
 // ------------------------------------------------------------------------------------------------
 // ori:: (include/grbda/Utils/OrientationTools.h)
 // ------------------------------------------------------------------------------------------------
@@ -326,6 +328,8 @@ struct ContactPoint {
     bool is_end_effector_;
     int end_effector_index_ = -1;
     Vec3<Scalar> position_;  // world position after forwardKinematicsIncludingContactPoints()
+    Vec3<Scalar> velocity_;  // world-axes linear velocity of the point, the same call
+    DMat<Scalar> jacobian_;  // 6 x nv, world axes at the point [angular; linear] (contactJacobianWorldFrame)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -829,9 +833,50 @@ public:
     const std::vector<ClusterTreeNodePtr<Scalar>> &clusters() const { return cluster_nodes_; }
     ClusterTreeNodePtr<Scalar> cluster(int i) const { return cluster_nodes_.at(i); }
     const Body<Scalar> &body(const std::string &name) const { return bodies_.at(body_name_to_body_index_.at(name)); }
+    const Body<Scalar> &body(int index) const { return bodies_.at(index); }
+    const Body<Scalar> &getBody(int index) const { return bodies_.at(index); }
+    // cluster bookkeeping queries (ClusterTreeModel.h:97-121, ClusterTreeModel.cpp:408-470)
+    int getNumClusters() const { return static_cast<int>(cluster_nodes_.size()); }
+    int getSubIndexWithinClusterForBody(int body_index) const { return body_index >= 0 ? bodies_.at(body_index).sub_index_within_cluster_ : 0; }
+    int getSubIndexWithinClusterForBody(const Body<Scalar> &b) const { return getSubIndexWithinClusterForBody(b.index_); }
+    int getSubIndexWithinClusterForBody(const std::string &body_name) const { return body(body_name).sub_index_within_cluster_; }
+    int getNumBodiesInCluster(int cluster_index) const
+    {
+        return cluster_index >= 0 ? static_cast<int>(cluster_nodes_.at(cluster_index)->bodies_.size()) : 0;
+    }
+    int getNumBodiesInCluster(const ClusterTreeNodePtr<Scalar> &cluster) const { return static_cast<int>(cluster->bodies_.size()); }
+    int getNumBodiesInCluster(const std::string &cluster_name) const
+    {
+        for (const auto &c : cluster_nodes_)
+            if (c->name_ == cluster_name) return static_cast<int>(c->bodies_.size());
+        throw std::runtime_error("no cluster named " + cluster_name);
+    }
+    int getIndexOfClusterContainingBody(int body_index) const { return body_index_to_cluster_index_.at(body_index); }
+    int getIndexOfClusterContainingBody(const Body<Scalar> &b) const { return body_index_to_cluster_index_.at(b.index_); }
+    int getIndexOfClusterContainingBody(const std::string &body_name) const { return body_index_to_cluster_index_.at(body(body_name).index_); }
+    ClusterTreeNodePtr<Scalar> getClusterContainingBody(int body_index) const { return cluster_nodes_.at(getIndexOfClusterContainingBody(body_index)); }
+    ClusterTreeNodePtr<Scalar> getClusterContainingBody(const Body<Scalar> &b) const { return getClusterContainingBody(b.index_); }
+    ClusterTreeNodePtr<Scalar> getClusterContainingBody(const std::string &body_name) const { return getClusterContainingBody(body(body_name).index_); }
+    // the nearest body at or above `body_index` that already belongs to a cluster (-1: the ground)
+    int getClusterAncestorIndexFromParent(int body_index) const
+    {
+        int j = body_index;
+        while (j != -1 && !body_index_to_cluster_index_.count(j)) j = bodies_.at(j).parent_index_;
+        return j;
+    }
 
     // ---- state (ClusterTreeModel.cpp:256-308) -----------------------------------------------------
     typedef std::pair<DVec<Scalar>, DVec<Scalar>> StatePair;
+    // independent coordinates only (ClusterTreeModel.cpp:287-308)
+    ModelState<Scalar> stateVectorToModelState(const StatePair &q_qd_pair) const
+    {
+        ModelState<Scalar> state;
+        for (const auto &c : cluster_nodes_)
+            state.push_back(JointState<Scalar>(
+                JointCoordinate<Scalar>(q_qd_pair.first.segment(c->position_index_, c->num_positions_), false),
+                JointCoordinate<Scalar>(q_qd_pair.second.segment(c->velocity_index_, c->num_velocities_), false)));
+        return state;
+    }
     // One JointState per cluster, each position / velocity flagged independent or spanning
     // (JointCoordinate::isSpanning()).  ClusterJoints::Base::toSpanningTreeState (ClusterJoint.cpp:22-71) decides per
     // cluster what is accepted; the same rules run in the library (grbda_state_to_independent_host_f64) and invalid
@@ -900,18 +945,63 @@ public:
         return contact_points_[contact_name_to_contact_index_.at(name)];
     }
     int getNumEndEffectors() const { return num_end_effectors_; }
-    // TreeModel::contactPointForwardKinematics: position_ = Xa.inverseTransformPoint(local_offset_)
+    // TreeModel::contactPointForwardKinematics (TreeModel.cpp:59-76): position_ = Xa.inverseTransformPoint(local_offset_),
+    // velocity_ = the point's linear velocity in world axes (= the linear rows of the world-frame Jacobian times qd)
     void forwardKinematicsIncludingContactPoints()
     {
-        const std::vector<double> q = state_q();
-        std::vector<double> Xa(static_cast<size_t>(getNumBodies()) * 12);
-        check(grbda_body_poses_host_f64(plan(), q.data(), Xa.data(), 1, 0));
+        const std::vector<double> Xa = bodyPoses();
         for (auto &cp : contact_points_) {
-            const double *X = &Xa[static_cast<size_t>(cp.body_index_) * 12];
-            for (int i = 0; i < 3; i++)
-                cp.position_[i] = static_cast<Scalar>(X[9 + i] + X[i] * cp.local_offset_[0] + X[3 + i] * cp.local_offset_[1] +
-                                                      X[6 + i] * cp.local_offset_[2]);
+            cp.position_ = pointInWorld(Xa, cp.body_index_, cp.local_offset_);
+            const DMat<Scalar> J = jacobianAt(cp.body_index_, cp.local_offset_, &Xa);
+            for (int i = 0; i < 3; i++) {
+                Scalar s = 0;
+                for (int k = 0; k < this->velocity_index_; k++) s += J(3 + i, k) * qd_[k];
+                cp.velocity_[i] = s;
+            }
         }
+    }
+    // ClusterTreeModel::contactJacobianBodyFrame (ClusterTreeDynamics.cpp:47-79): 6 x nv, [angular; linear] in the body's axes at
+    // the contact point (the frame of the end-effector force propagators)
+    D6Mat<Scalar> contactJacobianBodyFrame(const std::string &cp_name)
+    {
+        const ContactPoint<Scalar> &cp = contactPoint(cp_name);
+        return jacobianAt(cp.body_index_, cp.local_offset_, nullptr);
+    }
+    // ClusterTreeModel::contactJacobianWorldFrame (ClusterTreeDynamics.cpp:10-45): the same rows turned into world axes; kept in
+    // ContactPoint::jacobian_ as the reference does
+    const D6Mat<Scalar> &contactJacobianWorldFrame(const std::string &cp_name)
+    {
+        ContactPoint<Scalar> &cp = contact_points_[contact_name_to_contact_index_.at(cp_name)];
+        const std::vector<double> Xa = bodyPoses();
+        cp.jacobian_ = jacobianAt(cp.body_index_, cp.local_offset_, &Xa);
+        return cp.jacobian_;
+    }
+    // TreeModel::updateContactPointJacobians (TreeModel.cpp:101-112)
+    void updateContactPointJacobians()
+    {
+        for (auto &cp : contact_points_) contactJacobianWorldFrame(cp.name_);
+    }
+    // body kinematics in the world (ClusterTreeModel.cpp:320-375)
+    Vec3<Scalar> getPosition(const std::string &body_name, const Vec3<Scalar> &offset = Vec3<Scalar>::Zero())
+    {
+        return pointInWorld(bodyPoses(), body_name_to_body_index_.at(body_name), offset);
+    }
+    Mat3<Scalar> getOrientation(const std::string &body_name)  // body axes -> world axes
+    {
+        const std::vector<double> Xa = bodyPoses();
+        const double *X = &Xa[static_cast<size_t>(body_name_to_body_index_.at(body_name)) * 12];
+        Mat3<Scalar> R;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) R(i, j) = static_cast<Scalar>(X[3 * j + i]);
+        return R;
+    }
+    Vec3<Scalar> getLinearVelocity(const std::string &body_name, const Vec3<Scalar> &offset = Vec3<Scalar>::Zero())
+    {
+        return twistRows(body_name_to_body_index_.at(body_name), offset, 3);
+    }
+    Vec3<Scalar> getAngularVelocity(const std::string &body_name)
+    {
+        return twistRows(body_name_to_body_index_.at(body_name), Vec3<Scalar>::Zero(), 0);
     }
     // ClusterTreeModel::applyTestForce: returns f^T J H^-1 J^T f, dstate_out = H^-1 J^T f (force in world axes)
     Scalar applyTestForce(const std::string &contact_point_name, const Vec3<Scalar> &force, DVec<Scalar> &dstate_out)
@@ -1062,6 +1152,59 @@ private:
     {
         if (static_cast<int>(q_.size()) != this->position_index_) throw std::runtime_error("state has not been set");
         return std::vector<double>(q_.begin(), q_.end());
+    }
+    // Xa[n_bodies][12] of the current state: rotation world -> body (row-major), origin in the world (grbda_body_poses_*)
+    std::vector<double> bodyPoses()
+    {
+        const std::vector<double> q = state_q();
+        std::vector<double> Xa(static_cast<size_t>(getNumBodies()) * 12);
+        check(grbda_body_poses_host_f64(plan(), q.data(), Xa.data(), 1, 0));
+        return Xa;
+    }
+    static Vec3<Scalar> pointInWorld(const std::vector<double> &Xa, int body_index, const Vec3<Scalar> &offset)
+    {
+        const double *X = &Xa[static_cast<size_t>(body_index) * 12];
+        Vec3<Scalar> p;
+        for (int i = 0; i < 3; i++)
+            p[i] = static_cast<Scalar>(X[9 + i] + X[i] * offset[0] + X[3 + i] * offset[1] + X[6 + i] * offset[2]);
+        return p;
+    }
+    // 6 x nv Jacobian of the frame (body axes, origin at `offset`) on a body, from the force-propagation kernel
+    // (grbda_inv_osim_*: J next to the operational-space inertia); with poses: rows turned into world axes
+    DMat<Scalar> jacobianAt(int body_index, const Vec3<Scalar> &offset, const std::vector<double> *Xa)
+    {
+        const int nv = this->velocity_index_;
+        const std::vector<double> q = state_q();
+        const double off[3] = {double(offset[0]), double(offset[1]), double(offset[2])};
+        std::vector<double> L(36), Jb(static_cast<size_t>(6) * nv);
+        check(grbda_inv_osim_host_f64(plan(), q.data(), 1, &body_index, off, L.data(), Jb.data(), 1, 0));
+        DMat<Scalar> J(6, nv);
+        for (int half = 0; half < 2; half++)
+            for (int i = 0; i < 3; i++)
+                for (int k = 0; k < nv; k++) {
+                    double s = 0;
+                    if (Xa) {  // world axes: E^T on each 3-row half
+                        const double *X = &(*Xa)[static_cast<size_t>(body_index) * 12];
+                        for (int m = 0; m < 3; m++) s += X[3 * m + i] * Jb[static_cast<size_t>(3 * half + m) * nv + k];
+                    } else {
+                        s = Jb[static_cast<size_t>(3 * half + i) * nv + k];
+                    }
+                    J(3 * half + i, k) = static_cast<Scalar>(s);
+                }
+        return J;
+    }
+    // rows first .. first + 2 of (world-frame Jacobian at the point) x qd: 0 -> angular velocity, 3 -> linear velocity
+    Vec3<Scalar> twistRows(int body_index, const Vec3<Scalar> &offset, int first)
+    {
+        const std::vector<double> Xa = bodyPoses();
+        const DMat<Scalar> J = jacobianAt(body_index, offset, &Xa);
+        Vec3<Scalar> v;
+        for (int i = 0; i < 3; i++) {
+            Scalar s = 0;
+            for (int k = 0; k < this->velocity_index_; k++) s += J(first + i, k) * qd_[k];
+            v[i] = s;
+        }
+        return v;
     }
     DVec<Scalar> single(bool inverse, const DVec<Scalar> &x)
     {

@@ -82,10 +82,11 @@ static void dump(const std::string &path, const std::vector<unsigned char> &blob
 }
 
 template <class Model>
-static int roundtrip(Model &model, const char *what)
+static int roundtrip(Model &model, const char *what, const std::string &cp_body_name = "")
 {
     const int nq = model.getNumPositions(), nv = model.getNumDegreesOfFreedom();
     double worst = 0;
+    DVec<double> last_q, last_qd;
     for (int trial = 0; trial < 5; trial++) {
         DVec<double> q = DVec<double>::Random(nq), qd = DVec<double>::Random(nv), tau = DVec<double>::Random(nv);
         if (nq == nv + 1) {  // floating base: a valid unit quaternion in the last 4 of the first 7 positions
@@ -93,6 +94,8 @@ static int roundtrip(Model &model, const char *what)
             for (int i = 0; i < 4; i++) q[3 + i] = quat[i];
         }
         model.setState(std::make_pair(q, qd));
+        last_q = q;
+        last_qd = qd;
         const DVec<double> ydd = model.forwardDynamics(tau);
         const DVec<double> back = model.inverseDynamics(ydd);
         worst = std::fmax(worst, (back - tau).norm());
@@ -155,6 +158,49 @@ static int roundtrip(Model &model, const char *what)
         }
         std::printf("%s: contact point at (%.3f, %.3f, %.3f), lambda_inv = %.6f\n", what, cp.position_[0], cp.position_[1],
                     cp.position_[2], lam);
+        // contact Jacobians (ClusterTreeDynamics.cpp:10-79): J_world = diag(R, R) J_body with R = getOrientation; its linear rows
+        // give J^T f = H dstate of applyTestForce and the point's velocity; on fixed-base models the velocity is also the
+        // central difference of the point's position along qd
+        const DMat<double> Jw = model.contactJacobianWorldFrame(cp.name_);
+        const DMat<double> Jb = model.contactJacobianBodyFrame(cp.name_);
+        if (Jw.rows() != 6 || Jw.cols() != nv || Jb.rows() != 6 || Jb.cols() != nv) return 1;
+        const DVec<double> H_ds = [&] { DVec<double> r = DVec<double>::Zero(nv); for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) r[i] += H(i, j) * ds[j]; return r; }();
+        for (int k = 0; k < nv; k++) {
+            double jtf = 0;
+            for (int i = 0; i < 3; i++) jtf += Jw(3 + i, k) * f[i];
+            worst = std::fmax(worst, std::fabs(jtf - H_ds[k]) / (1 + std::fabs(jtf)));
+        }
+        model.updateContactPointJacobians();
+        const auto &cp2 = model.contactPoint(cp.name_);
+        double v_from_J[3] = {0, 0, 0}, w_from_J[3] = {0, 0, 0};
+        for (int i = 0; i < 3; i++)
+            for (int k = 0; k < nv; k++) {
+                v_from_J[i] += cp2.jacobian_(3 + i, k) * last_qd[k];
+                w_from_J[i] += cp2.jacobian_(i, k) * last_qd[k];
+            }
+        for (int i = 0; i < 3; i++) worst = std::fmax(worst, std::fabs(v_from_J[i] - cp2.velocity_[i]));
+        if (nq == nv && !cp_body_name.empty()) {  // (hand-built fixed-base chains: the test knows the body's name)
+            const Mat3<double> R = model.getOrientation(cp_body_name);
+            for (int half = 0; half < 2; half++)
+                for (int i = 0; i < 3; i++)
+                    for (int k = 0; k < nv; k++) {
+                        double s = 0;
+                        for (int m2 = 0; m2 < 3; m2++) s += R(i, m2) * Jb(3 * half + m2, k);
+                        worst = std::fmax(worst, std::fabs(s - Jw(3 * half + i, k)));
+                    }
+            const Vec3<double> vl = model.getLinearVelocity(cp_body_name, cp.local_offset_), wl = model.getAngularVelocity(cp_body_name);
+            for (int i = 0; i < 3; i++) worst = std::fmax(worst, std::fmax(std::fabs(vl[i] - v_from_J[i]), std::fabs(wl[i] - w_from_J[i])));
+            const double h = 1e-6;
+            DVec<double> qp = last_q, qm = last_q;
+            for (int k = 0; k < nv; k++) { qp[k] += h * last_qd[k]; qm[k] -= h * last_qd[k]; }
+            model.setState(std::make_pair(qp, last_qd));
+            const Vec3<double> pp = model.getPosition(cp_body_name, cp.local_offset_);
+            model.setState(std::make_pair(qm, last_qd));
+            const Vec3<double> pm = model.getPosition(cp_body_name, cp.local_offset_);
+            model.setState(std::make_pair(last_q, last_qd));
+            for (int i = 0; i < 3; i++) worst = std::fmax(worst, std::fabs((pp[i] - pm[i]) / (2 * h) - v_from_J[i]) * 1e-2);  // O(h^2) + rounding / h
+            std::printf("%s: contact velocity (%.4f, %.4f, %.4f) = J qd = d position / dt\n", what, v_from_J[0], v_from_J[1], v_from_J[2]);
+        }
     }
     std::printf("%s: nq=%d nv=%d max(|ID(FD(tau)) - tau|, |H ydd + C - tau|) = %.3e\n", what, nq, nv, worst);
     return worst < 5e-8 ? 0 : 1;  // tol of UnitTests/testRigidBodyDynamicsAlgos.cpp:9
@@ -262,7 +308,13 @@ int main(int argc, char **argv)
                 buildRevoluteChainWithRotor<4>(m);
                 m.appendEndEffector("link-3", Vec3<double>{1.0, 0., 0.}, "tip");             // ClusterTreeModel.cpp:216-221
                 m.appendContactPoint("link-1", Vec3<double>{0.5, 0.1, 0.}, "mid-contact");    // :165-187
-                rc |= roundtrip(m, "RevoluteChainWithRotor<4>");
+                rc |= roundtrip(m, "RevoluteChainWithRotor<4>", "link-3");
+                // cluster bookkeeping queries (ClusterTreeModel.h:97-121)
+                if (m.getIndexOfClusterContainingBody("link-3") != 3 || m.getNumBodiesInCluster(3) != 2 ||
+                    m.getSubIndexWithinClusterForBody("link-3") != 0 || m.getClusterContainingBody("link-3")->bodies_.size() != 2 ||
+                    m.getBody(m.body("link-3").index_).name_ != "link-3" || m.getClusterAncestorIndexFromParent(m.body("link-3").index_) != m.body("link-3").index_ ||
+                    m.stateVectorToModelState(std::make_pair(DVec<double>::Zero(4), DVec<double>::Zero(4))).size() != 4)
+                    rc |= 1;
             }
             { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<4>(m); rc |= roundtrip(m, "RevolutePairChainWithRotor<4>"); }
             {
