@@ -32,6 +32,7 @@ C_ABI_SYMBOLS = [
     "grbda_project_positions_f64", "grbda_project_positions_f32", "grbda_plan_span_dims",
     "grbda_spanning_f64", "grbda_spanning_f32", "grbda_fd_derivatives_f64", "grbda_fd_derivatives_f32",
     "grbda_mass_matrix_host_f64", "grbda_fd_derivatives_host_f64",
+    "grbda_body_twists_f64", "grbda_body_twists_f32", "grbda_body_twists_host_f64",
     "grbda_state_input_dims", "grbda_state_to_independent_f64", "grbda_state_to_independent_f32",
     "grbda_state_to_independent_host_f64",
 ]
@@ -107,6 +108,7 @@ def lib() -> ctypes.CDLL:
         getattr(L, name).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]
     for sfx in ("f64", "f32"):
         getattr(L, "grbda_body_poses_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        getattr(L, "grbda_body_twists_" + sfx).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
         getattr(L, "grbda_inv_osim_" + sfx).argtypes = [c_void_p, c_void_p, c_int, POINTER(c_int), POINTER(c_double),
                                                         c_void_p, c_void_p, c_size_t, c_int, c_void_p]
         getattr(L, "grbda_apply_test_force_" + sfx).argtypes = [c_void_p, c_void_p, c_int, POINTER(c_double), c_void_p,
@@ -397,6 +399,24 @@ class Plan:
         s = torch.cuda.current_stream(q.device) if stream is None else stream
         fn = getattr(lib(), f"grbda_body_poses_{'f32' if q.dtype == torch.float32 else 'f64'}")
         _check(fn(self._h, q.data_ptr(), out.data_ptr(), B, q.device.index or 0, c_void_p(s.cuda_stream)))
+        return out
+
+    def body_twists(self, q, qd, ydd, stream=None):
+        """Spatial velocity and acceleration of every body in its own coordinates (TreeNode::v_ / a_ after
+        forwardAccelerationKinematics): [B, n_bodies, 12] = v (6) then a (6), each [angular; linear]; the acceleration
+        carries the base's -gravity as in the reference."""
+        import torch
+
+        self._floating(q, qd, ydd)
+        B = q.shape[0]
+        if not q.is_cuda or q.shape != (B, self.nq) or qd.shape != (B, self.nv) or ydd.shape != (B, self.nv):
+            raise ValueError(f"expected device tensors q[B,{self.nq}], qd[B,{self.nv}], ydd[B,{self.nv}]")
+        q, qd, ydd = q.contiguous(), qd.contiguous(), ydd.contiguous()
+        out = torch.empty((B, self.n_bodies, 12), dtype=q.dtype, device=q.device)
+        s = torch.cuda.current_stream(q.device) if stream is None else stream
+        fn = getattr(lib(), f"grbda_body_twists_{'f32' if q.dtype == torch.float32 else 'f64'}")
+        _check(fn(self._h, q.data_ptr(), qd.data_ptr(), ydd.data_ptr(), out.data_ptr(), B, q.device.index or 0,
+                  c_void_p(s.cuda_stream)))
         return out
 
     def apply_test_force(self, q, body: int, offset, force, stream=None):

@@ -668,6 +668,43 @@ int poses(const grbda_plan *p, const T *q, T *Xa, size_t B, int device, void *st
     return e == hipSuccess ? GRBDA_OK : hip_err(e, "poses launch");
 }
 
+// spatial velocity / acceleration of every body: the spanning rates (spanning_kernel) into the plan's per-(device, stream)
+// workspace, then the tree walk (twists_kernel)
+template <class T>
+int twists(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *V, size_t B, int device, void *stream)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!q || !qd || !ydd || !V) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t ns = static_cast<size_t>(span_count(p));
+    void *wptr = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lk(p->mu);
+        Scratch &s = p->work[{device, stream}];
+        const size_t need = 2 * B * ns * sizeof(T) + 256;
+        if (s.bytes < need) {
+            hipError_t e;
+            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+            s.ptr = nullptr;
+            s.bytes = 0;
+            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+            s.bytes = need;
+        }
+        wptr = s.ptr;
+    }
+    T *vs = static_cast<T *>(wptr), *as = vs + B * ns;
+    if (int rc = spanning<T>(p, q, qd, ydd, vs, as, B, device, stream)) return rc;
+    DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    const size_t g = n_tiles < static_cast<size_t>(t->n_cu) * 8 ? n_tiles : static_cast<size_t>(t->n_cu) * 8;
+    hipError_t e = launch_twists<T>(d, p->host.n_clusters, static_cast<int>(ns), q, vs, as, V, B, static_cast<int>(g),
+                                    static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "twists launch");
+}
+
 // world wrench (about the world origin) of a Cartesian force at a point fixed in body `body`
 template <class T>
 __global__ void wrench_kernel(const T *__restrict__ Xa, const T *__restrict__ force, int n_bodies, int body, T ox, T oy,
@@ -1777,6 +1814,16 @@ int grbda_fd_derivatives_f32(const grbda_plan *p, const float *q, const float *q
     if (dq) if (const int r2 = grbda_fd_dq_f32(p, q, qd, tau, 1e-6, dq, B, device, stream)) return r2;
     return GRBDA_OK;
 }
+int grbda_body_twists_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, double *V, size_t B, int device,
+                          void *stream)
+{
+    return twists<double>(p, q, qd, ydd, V, B, device, stream);
+}
+int grbda_body_twists_f32(const grbda_plan *p, const float *q, const float *qd, const float *ydd, float *V, size_t B, int device,
+                          void *stream)
+{
+    return twists<float>(p, q, qd, ydd, V, B, device, stream);
+}
 int grbda_body_poses_f64(const grbda_plan *p, const double *q, double *Xa, size_t B, int device, void *stream)
 {
     return poses<double>(p, q, Xa, B, device, stream);
@@ -1839,6 +1886,25 @@ int grbda_body_poses_host_f64(const grbda_plan *p, const double *q, double *Xa, 
     if ((rc = poses<double>(p, static_cast<double *>(dq.p), static_cast<double *>(dX.p), B, device, nullptr))) return rc;
     if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
     return dX.get(Xa, B * nb * 12 * 8);
+}
+int grbda_body_twists_host_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, double *V, size_t B, int device)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!q || !qd || !ydd || !V) return set_err(GRBDA_EINVAL, "null argument");
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv, nb = p->host.n_bodies;
+    DevBuf dq, dqd, dy, dV;
+    int rc;
+    if ((rc = dq.alloc(B * nq * 8)) || (rc = dqd.alloc(B * nv * 8)) || (rc = dy.alloc(B * nv * 8)) || (rc = dV.alloc(B * nb * 12 * 8)) ||
+        (rc = dq.put(q, B * nq * 8)) || (rc = dqd.put(qd, B * nv * 8)) || (rc = dy.put(ydd, B * nv * 8)))
+        return rc;
+    if ((rc = twists<double>(p, static_cast<double *>(dq.p), static_cast<double *>(dqd.p), static_cast<double *>(dy.p),
+                             static_cast<double *>(dV.p), B, device, nullptr)))
+        return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    return dV.get(V, B * nb * 12 * 8);
 }
 int grbda_apply_test_force_host_f64(const grbda_plan *p, const double *q, int body, const double offset[3],
                                     const double *force, double *lambda_inv, double *dstate, size_t B, int device)

@@ -50,6 +50,9 @@ hipError_t launch_spanning(const DevPlan<T> &P, int n_clusters, int n_span, cons
                            hipStream_t stream);
 template <class T>
 hipError_t launch_poses(const DevPlan<T> &P, int n_clusters, const T *q, T *Xa, size_t B, int grid, hipStream_t stream);
+template <class T>
+hipError_t launch_twists(const DevPlan<T> &P, int n_clusters, int n_span, const T *q, const T *qd_span, const T *qdd_span, T *V, size_t B,
+                         int grid, hipStream_t stream);
 hipError_t set_max_dynamic_lds();
 
 // kernel argument block of the chain-structured fast path (chain_kernels.hip; plan.h, ChainProgram)

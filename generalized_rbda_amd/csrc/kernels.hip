@@ -2271,6 +2271,105 @@ __global__ __launch_bounds__(kWave, 1) void poses_kernel(DevPlan<T> DP, int n_cl
     }
 }
 
+// Spatial velocity and acceleration of every body in its own coordinates, V[B][n_bodies][12] = [v 6 | a 6] ([angular 3; linear 3]
+// each): TreeNode::v_ / a_ after TreeModel::forwardAccelerationKinematics (TreeModel.cpp:6-57), the input of the reference's
+// contact-point velocities and accelerations (TreeModel.cpp:59-99) and of ClusterTreeModel::getLinearAcceleration
+// (ClusterTreeModel.cpp:376-404).  As there, the acceleration is the one the recursions carry: the base starts from -gravity.
+// Spanning-tree form: v_i = X_i v_parent + S_i qd_i, a_i = X_i a_parent + S_i qdd_i + v_i x S_i qd_i with the spanning rates
+// qd_span = G yd, qdd_span = G ydd + g of spanning_kernel (identical to the cluster form: cJ = Xdot S qd + X S g).
+// One state per lane, parents read back from the output row; canonical body frames until the end (see poses_kernel).
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void twists_kernel(DevPlan<T> DP, int n_clusters, int n_span, const T *__restrict__ q,
+                                                          const T *__restrict__ qd_span, const T *__restrict__ qdd_span,
+                                                          T *__restrict__ V, size_t B)
+{
+    const Tables<T> P = make_tables(DP);
+    const int nb = DP.n_bodies;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r = tile * kWave + threadIdx.x;
+        if (r >= B) continue;
+        const T *qr = q + r * (size_t)P.nq;
+        const T *vs = qd_span + r * (size_t)n_span, *as = qdd_span + r * (size_t)n_span;
+        T *out = V + r * (size_t)nb * 12;
+        int at = 0;
+        for (int ci = 0; ci < n_clusters; ci++) {
+            const ClusterRec c = load_rec(P.clusters + ci);
+            for (int i = 0; i < c.k; i++) {
+                const int gb = c.first_body + i;
+                const BodyRec b = load_rec(P.bodies + gb);
+                T v[6], a[6];
+                if (c.kind == CK_FREE) {  // S = 1, the rates are the base twist; a = X (-gravity) + ydd
+                    T o[4], E[9];
+                    const int nori = P.ori_repr == 0 ? 4 : 3;
+                    for (int j = 0; j < 4; j++) o[j] = j < nori ? qr[c.q_index + 3 + j] : T(0);
+                    free_rotation(P.ori_repr, o, E);
+                    for (int j = 0; j < 6; j++) {
+                        v[j] = vs[at + j];
+                        a[j] = as[at + j];
+                    }
+                    for (int u = 0; u < 3; u++) {
+                        a[u] += E[3 * u] * P.a_root[0] + E[3 * u + 1] * P.a_root[1] + E[3 * u + 2] * P.a_root[2];
+                        a[3 + u] += E[3 * u] * P.a_root[3] + E[3 * u + 1] * P.a_root[4] + E[3 * u + 2] * P.a_root[5];
+                    }
+                } else {
+                    cptr<T> C = P.consts + b.cofs;
+                    T qi = 0;
+                    if (c.kind == CK_LOOP) {
+                        qi = qr[c.q_index + i];
+                    } else {
+                        for (int k2 = 0; k2 < c.n; k2++) qi += C[kBodyConstFixed + k2] * qr[c.q_index + k2];
+                    }
+                    T sn, cs, El[9], vp[6], ap[6];
+                    sincos_t(qi, &sn, &cs);
+                    build_E(b.axis, sn, cs, C, El);
+                    if (b.parent >= 0) {
+                        const T *Vp = out + (size_t)b.parent * 12;
+                        for (int j = 0; j < 6; j++) {
+                            vp[j] = Vp[j];
+                            ap[j] = Vp[6 + j];
+                        }
+                    } else {
+                        for (int j = 0; j < 6; j++) {
+                            vp[j] = 0;
+                            ap[j] = P.a_root[j];
+                        }
+                    }
+                    xmotion(El, C + 9, vp, v);
+                    xmotion(El, C + 9, ap, a);
+                    const T qdi = vs[at + i], qddi = as[at + i];
+                    add_axis(v, b.axis, qdi);
+                    // v x (S qdi), S the unit angular axis e: [w x e; v_lin x e] qdi
+                    const int e0 = b.axis, e1 = (b.axis + 1) % 3, e2 = (b.axis + 2) % 3;
+                    a[e1] += v[e2] * qdi;
+                    a[e2] -= v[e1] * qdi;
+                    a[3 + e1] += v[3 + e2] * qdi;
+                    a[3 + e2] -= v[3 + e1] * qdi;
+                    add_axis(a, e0, qddi);
+                }
+                for (int j = 0; j < 6; j++) {
+                    out[(size_t)gb * 12 + j] = v[j];
+                    out[(size_t)gb * 12 + 6 + j] = a[j];
+                }
+            }
+            at += c.kind == CK_FREE ? 6 : c.k;
+        }
+        // back to the reference's body frames (x_ref = Rc^T x_canon on each 3-vector, the row permutation of poses_kernel)
+        for (int gb = 0; gb < nb; gb++) {
+            const BodyRec b = load_rec(P.bodies + gb);
+            if (b.canon_axis == 2) continue;
+            T *e = out + (size_t)gb * 12;
+            const int to0 = b.canon_axis == 0 ? 1 : 2, to1 = b.canon_axis == 0 ? 2 : 0, to2 = b.canon_axis == 0 ? 0 : 1;
+            for (int h = 0; h < 4; h++) {
+                const T x0 = e[3 * h], x1 = e[3 * h + 1], x2 = e[3 * h + 2];
+                e[3 * h + to0] = x0;
+                e[3 * h + to1] = x1;
+                e[3 * h + to2] = x2;
+            }
+        }
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(kWave, 1) void spanning_kernel(DevPlan<T> DP, int n_clusters, int n_span,
                                                             const T *__restrict__ q, const T *__restrict__ qd,
@@ -2425,6 +2524,17 @@ hipError_t launch_poses(const DevPlan<T> &P, int n_clusters, const T *q, T *Xa, 
     hipLaunchKernelGGL((poses_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, q, Xa, B);
     return hipGetLastError();
 }
+template <class T>
+hipError_t launch_twists(const DevPlan<T> &P, int n_clusters, int n_span, const T *q, const T *qd_span, const T *qdd_span, T *V, size_t B,
+                         int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((twists_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, n_span, q, qd_span, qdd_span, V, B);
+    return hipGetLastError();
+}
+template hipError_t launch_twists<float>(const DevPlan<float> &, int, int, const float *, const float *, const float *, float *, size_t, int,
+                                         hipStream_t);
+template hipError_t launch_twists<double>(const DevPlan<double> &, int, int, const double *, const double *, const double *, double *, size_t,
+                                          int, hipStream_t);
 template hipError_t launch_poses<float>(const DevPlan<float> &, int, const float *, float *, size_t, int, hipStream_t);
 template hipError_t launch_poses<double>(const DevPlan<double> &, int, const double *, double *, size_t, int, hipStream_t);
 template hipError_t launch_project<float>(const DevPlan<float> &, int, float *, int32_t *, size_t, int, float, float *,

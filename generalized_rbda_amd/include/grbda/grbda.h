@@ -329,6 +329,7 @@ struct ContactPoint {
     int end_effector_index_ = -1;
     Vec3<Scalar> position_;  // world position after forwardKinematicsIncludingContactPoints()
     Vec3<Scalar> velocity_;  // world-axes linear velocity of the point, the same call
+    Vec3<Scalar> acceleration_;  // classical acceleration of the point in world axes (forwardAccelerationKinematicsIncludingContactPoints)
     DMat<Scalar> jacobian_;  // 6 x nv, world axes at the point [angular; linear] (contactJacobianWorldFrame)
 };
 
@@ -1003,6 +1004,34 @@ public:
     {
         return twistRows(body_name_to_body_index_.at(body_name), Vec3<Scalar>::Zero(), 0);
     }
+    // ClusterTreeModel::getLinearAcceleration / getAngularAcceleration (ClusterTreeModel.cpp:376-404): the body's spatial
+    // acceleration after forwardAccelerationKinematics(qdd) -- the recursion's, with the base's -gravity -- at the point, in
+    // world axes: Rai * spatialToLinearAcceleration(a, v, offset) (Spatial.h:420-437)
+    Vec3<Scalar> getLinearAcceleration(const DVec<Scalar> &qdd, const std::string &body_name,
+                                       const Vec3<Scalar> &offset = Vec3<Scalar>::Zero())
+    {
+        const int b = body_name_to_body_index_.at(body_name);
+        const std::vector<double> Xa = bodyPoses(), V = bodyTwists(qdd);
+        return toWorld(Xa, b, pointAcceleration(&V[static_cast<size_t>(b) * 12], offset));
+    }
+    Vec3<Scalar> getAngularAcceleration(const DVec<Scalar> &qdd, const std::string &body_name)
+    {
+        const int b = body_name_to_body_index_.at(body_name);
+        const std::vector<double> Xa = bodyPoses(), V = bodyTwists(qdd);
+        const double *a = &V[static_cast<size_t>(b) * 12 + 6];
+        return toWorld(Xa, b, Vec3<Scalar>{Scalar(a[0]), Scalar(a[1]), Scalar(a[2])});
+    }
+    // TreeModel::forwardAccelerationKinematicsIncludingContactPoints (TreeModel.h:70-74, TreeModel.cpp:78-99): positions,
+    // velocities and the classical accelerations of the contact points (gravity added back to the recursion's acceleration)
+    void forwardAccelerationKinematicsIncludingContactPoints(const DVec<Scalar> &qdd)
+    {
+        forwardKinematicsIncludingContactPoints();
+        const std::vector<double> Xa = bodyPoses(), V = bodyTwists(qdd);
+        for (auto &cp : contact_points_) {
+            const Vec3<Scalar> a = toWorld(Xa, cp.body_index_, pointAcceleration(&V[static_cast<size_t>(cp.body_index_) * 12], cp.local_offset_));
+            for (int i = 0; i < 3; i++) cp.acceleration_[i] = a[i] + this->gravity_[3 + i];
+        }
+    }
     // ClusterTreeModel::applyTestForce: returns f^T J H^-1 J^T f, dstate_out = H^-1 J^T f (force in world axes)
     Scalar applyTestForce(const std::string &contact_point_name, const Vec3<Scalar> &force, DVec<Scalar> &dstate_out)
     {
@@ -1160,6 +1189,39 @@ private:
         std::vector<double> Xa(static_cast<size_t>(getNumBodies()) * 12);
         check(grbda_body_poses_host_f64(plan(), q.data(), Xa.data(), 1, 0));
         return Xa;
+    }
+    // [v 6 | a 6] of every body in its own coordinates for the current state and the given accelerations (grbda_body_twists_*)
+    std::vector<double> bodyTwists(const DVec<Scalar> &qdd)
+    {
+        if (static_cast<int>(qdd.size()) != this->velocity_index_) throw std::runtime_error("input has the wrong dimension");
+        const std::vector<double> q = state_q(), qd(qd_.begin(), qd_.end()), ydd(qdd.begin(), qdd.end());
+        std::vector<double> V(static_cast<size_t>(getNumBodies()) * 12);
+        check(grbda_body_twists_host_f64(plan(), q.data(), qd.data(), ydd.data(), V.data(), 1, 0));
+        return V;
+    }
+    // spatialToLinearAcceleration(a, v, x): (a_lin + alpha x x) + omega x (v_lin + omega x x), body coordinates
+    static Vec3<Scalar> pointAcceleration(const double *va, const Vec3<Scalar> &x)
+    {
+        const double *v = va, *a = va + 6;
+        const double xs[3] = {double(x[0]), double(x[1]), double(x[2])};
+        auto cross = [](const double *p, const double *r, double *o) {
+            o[0] = p[1] * r[2] - p[2] * r[1];
+            o[1] = p[2] * r[0] - p[0] * r[2];
+            o[2] = p[0] * r[1] - p[1] * r[0];
+        };
+        double ax[3], wx[3], vl[3], wv[3];
+        cross(a, xs, ax);
+        cross(v, xs, wx);
+        for (int i = 0; i < 3; i++) vl[i] = v[3 + i] + wx[i];
+        cross(v, vl, wv);
+        return Vec3<Scalar>{Scalar(a[3] + ax[0] + wv[0]), Scalar(a[4] + ax[1] + wv[1]), Scalar(a[5] + ax[2] + wv[2])};
+    }
+    static Vec3<Scalar> toWorld(const std::vector<double> &Xa, int body_index, const Vec3<Scalar> &x)  // E^T x
+    {
+        const double *X = &Xa[static_cast<size_t>(body_index) * 12];
+        Vec3<Scalar> w;
+        for (int i = 0; i < 3; i++) w[i] = static_cast<Scalar>(X[i] * x[0] + X[3 + i] * x[1] + X[6 + i] * x[2]);
+        return w;
     }
     static Vec3<Scalar> pointInWorld(const std::vector<double> &Xa, int body_index, const Vec3<Scalar> &offset)
     {

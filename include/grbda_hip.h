@@ -260,6 +260,18 @@ int grbda_spanning_f32(const grbda_plan *plan, const float *q, const float *qd, 
 int grbda_body_poses_f64(const grbda_plan *plan, const double *q, double *Xa, size_t B, int device, void *stream);
 int grbda_body_poses_f32(const grbda_plan *plan, const float *q, float *Xa, size_t B, int device, void *stream);
 
+/* Spatial velocity and acceleration of every body in its own coordinates, TreeNode::v_ / a_ after
+ * TreeModel::forwardAccelerationKinematics(ydd) (TreeModel.cpp:6-57): V[B][n_bodies][12] = [v 6 | a 6], each [angular 3;
+ * linear 3].  As in the reference the acceleration is the one the recursions carry -- the base starts from -gravity, so a
+ * body at rest has a = X (0, 0, 0, 0, 0, 9.81) -- which is what ClusterTreeModel::getLinearAcceleration /
+ * getAngularAcceleration (ClusterTreeModel.cpp:376-404) rotate into world axes and what
+ * TreeModel::contactPointForwardAccelerationKinematics (TreeModel.cpp:78-99) adds gravity back to.  q, qd, ydd as for the
+ * inverse dynamics (implicit clusters: spanning positions on the manifold). */
+int grbda_body_twists_f64(const grbda_plan *plan, const double *q, const double *qd, const double *ydd, double *V, size_t B,
+                          int device, void *stream);
+int grbda_body_twists_f32(const grbda_plan *plan, const float *q, const float *qd, const float *ydd, float *V, size_t B,
+                          int device, void *stream);
+
 /* ClusterTreeModel::applyTestForce (ClusterTreeDynamics.cpp:194-233) for B states: a world-frame Cartesian force
  * force[B][3] acts at the point `offset` (host, body coordinates) of body `body`;
  * dstate[B][nv] = H^-1 J^T f and lambda_inv[B] = f^T J H^-1 J^T f.  Evaluated with the two kernels (ABA and RNEA
@@ -293,6 +305,8 @@ int grbda_rnea_host_f64(const grbda_plan *plan, const double *q, const double *q
 
 /* the same on HOST arrays (allocate, copy in, run, copy out, synchronise): single-state calls of the C++ facade */
 int grbda_body_poses_host_f64(const grbda_plan *plan, const double *q, double *Xa, size_t B, int device);
+int grbda_body_twists_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *ydd, double *V, size_t B,
+                               int device);
 int grbda_apply_test_force_host_f64(const grbda_plan *plan, const double *q, int body, const double offset[3],
                                     const double *force, double *lambda_inv, double *dstate, size_t B, int device);
 int grbda_inv_osim_host_f64(const grbda_plan *plan, const double *q, int n_contacts, const int *bodies,

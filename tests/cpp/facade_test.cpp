@@ -200,6 +200,31 @@ static int roundtrip(Model &model, const char *what, const std::string &cp_body_
             model.setState(std::make_pair(last_q, last_qd));
             for (int i = 0; i < 3; i++) worst = std::fmax(worst, std::fabs((pp[i] - pm[i]) / (2 * h) - v_from_J[i]) * 1e-2);  // O(h^2) + rounding / h
             std::printf("%s: contact velocity (%.4f, %.4f, %.4f) = J qd = d position / dt\n", what, v_from_J[0], v_from_J[1], v_from_J[2]);
+            // contact acceleration (TreeModel.cpp:78-99): the second central difference of the point's position along
+            // q(t) = q + qd t + qdd t^2 / 2 is its classical acceleration; getLinearAcceleration is the same without gravity
+            const DVec<double> qdd = DVec<double>::Random(nv);
+            model.forwardAccelerationKinematicsIncludingContactPoints(qdd);
+            const Vec3<double> acc = model.contactPoint(cp.name_).acceleration_;
+            const Vec3<double> lin = model.getLinearAcceleration(qdd, cp_body_name, cp.local_offset_);
+            const double h2 = 1e-4;
+            DVec<double> q2p = last_q, q2m = last_q;
+            for (int k = 0; k < nv; k++) {
+                q2p[k] += h2 * last_qd[k] + 0.5 * h2 * h2 * qdd[k];
+                q2m[k] += -h2 * last_qd[k] + 0.5 * h2 * h2 * qdd[k];
+            }
+            const Vec3<double> p0 = model.getPosition(cp_body_name, cp.local_offset_);
+            model.setState(std::make_pair(q2p, last_qd));
+            const Vec3<double> p2p = model.getPosition(cp_body_name, cp.local_offset_);
+            model.setState(std::make_pair(q2m, last_qd));
+            const Vec3<double> p2m = model.getPosition(cp_body_name, cp.local_offset_);
+            model.setState(std::make_pair(last_q, last_qd));
+            const SVec<double> grav = model.getGravity();
+            for (int i = 0; i < 3; i++) {
+                const double fd = (p2p[i] - 2 * p0[i] + p2m[i]) / (h2 * h2);
+                worst = std::fmax(worst, std::fabs(fd - acc[i]) * 1e-3);  // (second difference: rounding 1e-16 / h^2 = 1e-8, O(h^2) truncation)
+                worst = std::fmax(worst, std::fabs(lin[i] + grav[3 + i] - acc[i]));
+            }
+            std::printf("%s: contact acceleration (%.4f, %.4f, %.4f) = d^2 position / dt^2\n", what, acc[0], acc[1], acc[2]);
         }
     }
     std::printf("%s: nq=%d nv=%d max(|ID(FD(tau)) - tau|, |H ydd + C - tau|) = %.3e\n", what, nq, nv, worst);

@@ -620,6 +620,65 @@ def test_body_poses_match_oracle(name, blob, gpu):
     assert np.abs(got - ref).max() < 1e-11
 
 
+@pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
+def test_body_twists_are_the_derivatives_of_the_motion(name, blob, gpu):
+    """grbda_body_twists_*: TreeNode::v_ / a_ after forwardAccelerationKinematics (TreeModel.cpp:6-57).  Checked without a
+    second implementation of the recursion: (1) a spatial acceleration in BODY coordinates is the componentwise time derivative
+    of the body-coordinate velocity (v x v = 0), so along q(t) = q + qd_span t + qdd_span t^2 / 2, yd(t) = yd + ydd t the central
+    difference of v reproduces a minus the base's -gravity carried down the tree (E_i (0, 0, 9.81) on the linear part); the
+    body-coordinate velocities do not depend on the base pose, and the spanning rates keep implicit clusters on their manifold
+    to O(t^3); (2) v of a body is its contact Jacobian (force-propagation kernel, checked against the oracle elsewhere) times yd."""
+    import torch
+
+    from generalized_rbda_amd.states import C_FREE, C_LOOP_POSITION, C_TRIG_POLY, parse_clusters
+
+    plan = G.Plan(blob)
+    m = parse_clusters(blob)
+    B = 5
+    q, qd, tau = valid_states(blob, B, config_index=57)
+    ydd = O.forward_dynamics(blob, q, qd, tau)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    V = plan.body_twists(t(q), t(qd), t(ydd)).cpu().numpy()
+    assert np.isfinite(V).all()
+    vs, as_ = (x.cpu().numpy() for x in plan.spanning(t(q), t(qd), t(ydd)))
+
+    def moved(h):
+        """joint coordinates and rates a time h later; the base pose is left where it is"""
+        q2, qd2 = q.copy(), qd + h * ydd
+        at = 0
+        for (pc, fb, k, qi, npos, vi, n, nsp, nsv, ctype, rows, io, ni, do, nd, _) in m["clusters"]:
+            if ctype == C_FREE:
+                at += 6
+                continue
+            if ctype in (C_LOOP_POSITION, C_TRIG_POLY):  # implicit: spanning positions
+                q2[:, qi:qi + k] += h * vs[:, at:at + k] + 0.5 * h * h * as_[:, at:at + k]
+            else:  # independent coordinates
+                q2[:, qi:qi + n] += h * qd[:, vi:vi + n] + 0.5 * h * h * ydd[:, vi:vi + n]
+            at += k
+        return q2, qd2
+
+    h = 1e-5
+    qp, qdp = moved(+h)
+    qm, qdm = moved(-h)
+    Vp = plan.body_twists(t(qp), t(qdp), t(ydd)).cpu().numpy()
+    Vm = plan.body_twists(t(qm), t(qdm), t(ydd)).cpu().numpy()
+    a_fd = (Vp[:, :, :6] - Vm[:, :, :6]) / (2 * h)
+    Xa = O.body_poses(blob, q, plan.n_bodies)
+    E = Xa[:, :, :9].reshape(B, plan.n_bodies, 3, 3)
+    g = np.asarray(plan.get_gravity(), dtype=np.float64)[-3:]
+    a_ref = V[:, :, 6:].copy()
+    a_ref[:, :, 3:] -= np.einsum("bnij,j->bni", E, -g)
+    scale = 1.0 + np.abs(a_ref).max()
+    assert np.abs(a_fd - a_ref).max() / scale < 2e-6, np.abs(a_fd - a_ref).max() / scale
+
+    bodies = sorted({0, plan.n_bodies // 2, plan.n_bodies - 1})
+    _, J = plan.inv_osim(t(q), bodies, np.zeros((len(bodies), 3)), with_jacobian=True)
+    J = J.cpu().numpy().reshape(B, len(bodies), 6, plan.nv)
+    v_from_J = np.einsum("bnij,bj->bni", J, qd)
+    got = V[:, bodies, :6]
+    assert np.abs(v_from_J - got).max() / (1.0 + np.abs(got).max()) < 1e-9
+
+
 @pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "tello_with_arms", "urdf_four_bar",
                                   "urdf_mini_cheetah_rpy", "chain_tree_a", "chain_tree_b", "urdf_jvrc1_humanoid", "rev_rotor_chain_4",
                                   "tree_rev_fixed"])
