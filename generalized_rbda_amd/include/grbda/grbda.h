@@ -940,6 +940,19 @@ public:
     {
         appendContactPoint(body_name, local_offset, end_effector_name, true);
     }
+    // the eight corners of a box centred on the body frame, named as the reference names them (ClusterTreeModel.cpp:200-213)
+    void appendContactBox(const std::string body_name, const Vec3<Scalar> &box_dimensions)
+    {
+        int n = 0;
+        for (int sz = 1; sz >= -1; sz -= 2)
+            for (int sy = 1; sy >= -1; sy -= 2)
+                for (int sx = 1; sx >= -1; sx -= 2)
+                    appendContactPoint(body_name,
+                                       Vec3<Scalar>{Scalar(sx) * box_dimensions[0] / 2, Scalar(sy) * box_dimensions[1] / 2,
+                                                    Scalar(sz) * box_dimensions[2] / 2},
+                                       "torso-contact-" + std::to_string(++n));
+    }
+    const ContactPoint<Scalar> &contactPoint(int index) const { return contact_points_.at(index); }
     const std::vector<ContactPoint<Scalar>> &contactPoints() const { return contact_points_; }
     const ContactPoint<Scalar> &contactPoint(const std::string &name) const
     {

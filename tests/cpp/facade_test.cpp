@@ -340,6 +340,13 @@ int main(int argc, char **argv)
                     m.getBody(m.body("link-3").index_).name_ != "link-3" || m.getClusterAncestorIndexFromParent(m.body("link-3").index_) != m.body("link-3").index_ ||
                     m.stateVectorToModelState(std::make_pair(DVec<double>::Zero(4), DVec<double>::Zero(4))).size() != 4)
                     rc |= 1;
+                // appendContactBox (ClusterTreeModel.cpp:200-213): eight corners, the reference's names and order
+                const size_t before = m.contactPoints().size();
+                m.appendContactBox("link-2", Vec3<double>{0.2, 0.4, 0.6});
+                if (m.contactPoints().size() != before + 8 || m.contactPoint("torso-contact-2").local_offset_[0] != -0.1 ||
+                    m.contactPoint("torso-contact-3").local_offset_[1] != -0.2 || m.contactPoint("torso-contact-5").local_offset_[2] != -0.3 ||
+                    m.contactPoint(static_cast<int>(before)).name_ != "torso-contact-1")
+                    rc |= 1;
             }
             { ClusterTreeModel<double> m; buildRevolutePairChainWithRotor<4>(m); rc |= roundtrip(m, "RevolutePairChainWithRotor<4>"); }
             {

@@ -1,4 +1,5 @@
-// Issue rate of v_fma_f32 against v_pk_fma_f32 on one SIMD at one and two wavefronts (is two states per lane worth it?).
+// Issue rate of v_fma_f32, v_pk_fma_f32 and v_fma_f64 on one SIMD at one, two and four wavefronts, with 1-8 independent accumulators
+// per wavefront (dependent-issue latency against throughput; is two states per lane in packed registers worth it?).
 // hipcc --offload-arch=gfx950 -O3 tools/pk_rate.hip -o build/tools/pk_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,27 +27,28 @@ void run(const char *name, int waves_per_simd)
     T *out;
     const int n_cu = 256;
     const int blocks = n_cu * 4 * waves_per_simd;
-    hipMalloc(&out, blocks * 64 * sizeof(T));
+    (void)hipMalloc(&out, blocks * 64 * sizeof(T));
     const int iters = 20000;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k<T, NACC><<<blocks, 64>>>(out, 1.0001f, 0.5f, 10);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
     k<T, NACC><<<blocks, 64>>>(out, 1.0001f, 0.5f, iters);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double instr = double(iters) * 8 * NACC * waves_per_simd;  // per SIMD
     std::printf("%-10s acc %2d waves/SIMD %d: %.3f ms, %.2f cycles per instruction and SIMD at 2.4 GHz\n", name, NACC, waves_per_simd, ms,
                 ms * 1e-3 * 2.4e9 / instr);
-    hipFree(out);
+    (void)hipFree(out);
 }
 int main()
 {
-    for (int w = 1; w <= 2; w++) {
+    for (int w = 1; w <= 4; w *= 2) {
         run<float, 1>("fma", w); run<float, 2>("fma", w); run<float, 4>("fma", w); run<float, 8>("fma", w);
         run<f2, 1>("pk_fma", w); run<f2, 2>("pk_fma", w); run<f2, 4>("pk_fma", w); run<f2, 8>("pk_fma", w);
+        run<double, 1>("fma_f64", w); run<double, 2>("fma_f64", w); run<double, 4>("fma_f64", w); run<double, 8>("fma_f64", w);
     }
     return 0;
 }
