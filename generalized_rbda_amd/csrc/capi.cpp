@@ -333,6 +333,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.ori_repr = h.ori_repr;
             d.debug = 0;
             d.sv_global = 0;
+            d.out_lds = lp.out_lds;
             d.lds_bytes = static_cast<int>(lds_lm);
             for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
             const size_t grid = n_tiles0;  // (<= 4 workgroups per CU: all resident)
@@ -368,6 +369,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     d.ori_repr = h.ori_repr;
     d.debug = p->chain_debug;
     d.sv_global = cp.sv_global ? 1 : 0;
+    d.out_lds = cp.out_lds;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t.n_cu) * waves_per_cu;
@@ -1009,6 +1011,7 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.ori_repr = h.ori_repr;
     d.debug = 0;
     d.sv_global = cp.sv_global ? 1 : 0;
+    d.out_lds = -1;  // (the force-propagation kernel keeps its result rows in the slab)
     // (gravity enters the acceleration sweep only, which runs in applyTestForce mode alone -- there without it)
     for (int i = 0; i < 6; i++) d.a_root[i] = tf_force ? T(0) : static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;

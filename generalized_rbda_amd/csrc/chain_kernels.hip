@@ -136,9 +136,11 @@ struct ChainMem {
     __device__ __forceinline__ T q(int j) const { return row_ld(in_q_u, j); }
     __device__ __forceinline__ T qd(int j) const { return row_ld(in_qd_u, j); }
     __device__ __forceinline__ T x(int j) const { return row_ld(in_x_u, j); }
+    int out_row;  // >= 0: the result rows [coordinate][lane] live in LDS from this row on (ChainProgram::out_lds); -1: in the slab
     __device__ __forceinline__ void put(int j, T v) const
     {
-        *reinterpret_cast<T *>(reinterpret_cast<char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b) = v;
+        if (out_row >= 0) reinterpret_cast<T *>(grbda_smem)[(out_row + j) * kWave + lane] = v;
+        else *reinterpret_cast<T *>(reinterpret_cast<char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b) = v;
     }
 };
 
@@ -1305,6 +1307,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = (DP.debug & 8) ? 0 : 1;
     M.amask = (DP.debug & 16) ? kSlotGlobal : ~0;
+    M.out_row = DP.out_lds;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -1346,7 +1349,10 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
-        if (!(DP.debug & 4)) write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        if (!(DP.debug & 4)) {
+            if (M.out_row >= 0) write_outputs_lds<T>(M.out_row, ydd, tile, rows_valid, P.nv, lane);
+            else write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        }
     }
 }
 
@@ -1389,6 +1395,7 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
     M.amask = ~0;
+    M.out_row = DP.out_lds;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -1438,8 +1445,11 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
-        __syncthreads();  // every result row is in the slab
-        if (wave == 0) write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        __syncthreads();  // every result row is in the slab (or in LDS: ChainProgram::out_lds)
+        if (wave == 0) {
+            if (M.out_row >= 0) write_outputs_lds<T>(M.out_row, ydd, tile, rows_valid, P.nv, lane);
+            else write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        }
         // LDS and the slab are free for the next tile once wavefront 0 has READ the result rows (its own output stores may still
         // be in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1520,6 +1530,7 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
     M.amask = ~0;
+    M.out_row = -1;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -2330,6 +2341,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
     M.amask = ~0;
+    M.out_row = -1;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;

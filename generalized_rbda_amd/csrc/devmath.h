@@ -445,6 +445,38 @@ __device__ __forceinline__ void write_outputs(const T *rows, T *__restrict__ out
     wave_lds_fence();
 }
 
+// The same with the result rows in LDS ([coordinate][lane] from row `out_row` on, written by the acceleration run): no slab
+// round trip and no wait for global stores.  The state-major staging block is the first nv rows of LDS when the result rows sit
+// above them, else the nv rows behind the result rows (the plan compiler reserved them).
+template <class T>
+__device__ __forceinline__ void write_outputs_lds(int out_row, T *__restrict__ out, size_t tile, int rows_valid, int nv, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const T *rows = reinterpret_cast<const T *>(grbda_smem) + out_row * kWave;
+    T *stage = reinterpret_cast<T *>(grbda_smem) + (out_row >= nv ? 0 : (out_row + nv) * kWave);
+    constexpr int V = 16 / (int)sizeof(T);
+    if ((nv % V) == 0) {
+        struct alignas(16) Vec { T v[V]; };
+        Vec *mine = reinterpret_cast<Vec *>(stage + lane * nv);
+        for (int c = 0; c < nv; c += V) {
+            Vec x;
+#pragma unroll
+            for (int k = 0; k < V; k++) x.v[k] = rows[(c + k) * kWave + lane];
+            mine[c / V] = x;
+        }
+    } else {
+        for (int c = 0; c < nv; c++) stage[lane * nv + c] = rows[c * kWave + lane];
+    }
+    wave_lds_fence();
+    T *dst = out + tile * (size_t)kWave * (size_t)nv;
+    const int total = rows_valid * nv;
+    for (int i = 0; i < nv; i++) {
+        const int j = i * kWave + lane;
+        if (j < total) dst[j] = stage[j];
+    }
+    wave_lds_fence();
+}
+
 // quaternionToRotationMatrix (OrientationTools.h:251-269) / rpyToRotMat (:121-130)
 template <class T>
 __device__ __forceinline__ void free_rotation(int ori_repr, const T *o, T (&E)[9])

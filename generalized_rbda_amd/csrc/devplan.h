@@ -73,6 +73,7 @@ struct ChainDev {
     int ori_repr;
     int debug;   // GRBDA_CHAIN_DEBUG: phase ablation for profiling (chain_kernels.hip)
     int sv_global;  // ChainProgram::sv_global
+    int out_lds;    // ChainProgram::out_lds
     T a_root[6];
 };
 template <class T>

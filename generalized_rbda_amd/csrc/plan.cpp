@@ -1650,6 +1650,38 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 n_glb += n_glb_unused;
             }
             if (ok) {
+                // The result rows ydd[coordinate][lane] of the acceleration sweep go to LDS when nv free rows exist from the first
+                // acceleration segment to the end of the tile (ChainProgram::out_lds; else to the slab: one more global round trip and
+                // a drain of the store queue before the epilogue, 2.5-4 % of the kernel).  The epilogue transposes them through a
+                // second block of nv rows -- rows [0, nv) when the result rows sit above them, else the rows behind the result rows;
+                // nothing else is alive then.
+                CP.out_lds = -1;
+                {
+                    int t_first = -1;
+                    for (size_t t2 = 0; t2 < CP.segs.size(); t2++) {
+                        const int op = CP.segs[t2].op;
+                        if (op == SEG_FREE_ACC || op == SEG_RUN_ACC || op == SEG_PAIR_ACC || op == SEG_DIFF_ACC) { t_first = static_cast<int>(t2); break; }
+                    }
+                    const int nvr = P.nv;
+                    if (t_first >= 0 && nvr > 0 && !std::getenv("GRBDA_NO_LDS_RESULTS")) {
+                        std::vector<char> busy(static_cast<size_t>(lds_budget) + 1, 0);
+                        for (const Obj &o : objs) {
+                            if (o.slot < 0 || (o.slot & kSlotGlobal) || o.death < B0(t_first)) continue;
+                            for (int r = o.slot; r < o.slot + o.size && r < lds_budget; r++) busy[r] = 1;
+                        }
+                        for (int r = 0; r + nvr <= lds_budget; r++) {
+                            bool is_free = true;
+                            for (int k2 = 0; k2 < nvr && is_free; k2++) is_free = !busy[r + k2];
+                            if (!is_free) continue;
+                            const int stage = r >= nvr ? 0 : r + nvr;
+                            if (stage + nvr > lds_budget) continue;
+                            CP.out_lds = r;
+                            n_lds = std::max(n_lds, std::max(r + nvr, stage + nvr));
+                            break;
+                        }
+                    }
+                }
+                if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: result rows at LDS row %d (nv %d, %d rows in use of %d)\n", CP.out_lds, P.nv, n_lds, lds_budget);
                 CP.n_lds = n_lds;
                 CP.n_glb = n_glb;
                 // parent velocity / (v, a) slots

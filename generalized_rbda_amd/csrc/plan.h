@@ -321,6 +321,7 @@ struct ChainProgram {
     std::vector<ChainFree> frees;
     std::vector<ChainDiff> diffs;
     int n_lds = 0, n_glb = 0;        // slots
+    int out_lds = -1;                // first of the nv LDS rows the acceleration sweep writes its results to (-1: slab rows)
     bool sv_global = false;          // the [sin, cos, v] blocks of the links live in the global slab (chains too long for LDS)
     // Latency mode (n_waves = 2): a tile is run by a WORKGROUP of two wavefronts -- the limbs below the floating base are
     // dealt to the two, the base's own segments run on wavefront 0, SEG_BARRIER segments order the hand-overs (base velocity
