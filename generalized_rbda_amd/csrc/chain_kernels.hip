@@ -137,6 +137,12 @@ struct ChainMem {
     __device__ __forceinline__ T qd(int j) const { return row_ld(in_qd_u, j); }
     __device__ __forceinline__ T x(int j) const { return row_ld(in_x_u, j); }
     int out_row;  // >= 0: the result rows [coordinate][lane] live in LDS from this row on (ChainProgram::out_lds); -1: in the slab
+    // a result row read back (the differential's forward segment leaves a partial torque its backward segment completes)
+    __device__ __forceinline__ T got(int j) const
+    {
+        if (out_row >= 0) return reinterpret_cast<const T *>(grbda_smem)[(out_row + j) * kWave + lane];
+        return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b);
+    }
     __device__ __forceinline__ void put(int j, T v) const
     {
         if (out_row >= 0) reinterpret_cast<T *>(grbda_smem)[(out_row + j) * kWave + lane] = v;
@@ -2269,9 +2275,9 @@ __device__ __forceinline__ void rnea_diff_bwd(const RneaTables<T> &P, const Chai
     const T tl1 = f21[2];
     xforce_inv(E1, C1 + 9, f21, fp);
     if (d.lds_pf >= 0) add6<T, GLB>(M, d.lds_pf, fp);
-    // (the result rows are the tile's third input block: M.x reads what the forward segment put there)
-    M.put(d.v_index, M.x(d.v_index) + blk[10] * tl1 + blk[12] * tl2);
-    M.put(d.v_index + 1, M.x(d.v_index + 1) + blk[11] * tl1 + blk[13] * tl2);
+    // (the forward segment put the partial torques into the result rows)
+    M.put(d.v_index, M.got(d.v_index) + blk[10] * tl1 + blk[12] * tl2);
+    M.put(d.v_index + 1, M.got(d.v_index + 1) + blk[11] * tl1 + blk[13] * tl2);
 }
 
 template <class T>
@@ -2341,7 +2347,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
     M.amask = ~0;
-    M.out_row = -1;
+    M.out_row = -1;  // (the torque rows stay in the slab: LDS rows measured no faster here, and the branch in put() cost TelloWithArms 10 %)
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;

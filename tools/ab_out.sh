@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the result rows in LDS (GRBDA_NO_LDS_RESULTS=1: in the slab, as before)
 cd ${GRAFT_REPO_ROOT:-.}
-for a in "--workload mit_humanoid" "--workload jvrc1_humanoid" "--workload tello" "--workload mini_cheetah" "--workload mini_cheetah --dtype f32 --batch 262144" "--workload mit_humanoid --batch 65536"; do
+for a in "$@"; do
 for cfg in "A=1" "GRBDA_NO_LDS_RESULTS=1" "A=1" "GRBDA_NO_LDS_RESULTS=1"; do
   env $cfg python bench.py --steps 50 --warmup 5 --no-cpu-baseline $a 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a', '[$cfg]', '%.4g evals/s' % d['value'], 'kernel %.4f ms' % d['roofline']['kernel_ms'], d.get('verified'))"
 done; done
