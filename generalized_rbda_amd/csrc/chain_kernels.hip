@@ -140,13 +140,20 @@ struct ChainMem {
     // a result row read back (the differential's forward segment leaves a partial torque its backward segment completes)
     __device__ __forceinline__ T got(int j) const
     {
-        if (out_row >= 0) return reinterpret_cast<const T *>(grbda_smem)[(out_row + j) * kWave + lane];
         return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b);
+    }
+    // (forward dynamics: rows in LDS or in the slab)
+    __device__ __forceinline__ void put_f(int j, T v) const { out_f[j * kWave + lane] = v; }
+    // the result rows through ONE generic pointer (flat stores reach LDS and the slab alike): no branch per store
+    T *out_f;
+    __device__ __forceinline__ void set_out(int row)
+    {
+        out_row = row;
+        out_f = row >= 0 ? reinterpret_cast<T *>(grbda_smem) + row * kWave : out_u;
     }
     __device__ __forceinline__ void put(int j, T v) const
     {
-        if (out_row >= 0) reinterpret_cast<T *>(grbda_smem)[(out_row + j) * kWave + lane] = v;
-        else *reinterpret_cast<T *>(reinterpret_cast<char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b) = v;
+        *reinterpret_cast<T *>(reinterpret_cast<char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b) = v;
     }
 };
 
@@ -504,8 +511,8 @@ __device__ __forceinline__ void pair_acc(const ChainTables<T> &P, const ChainMem
         y0 -= blk[j] * va[6 + j];
         y1 -= blk[6 + j] * va[6 + j];
     }
-    M.put(pr.v_index, y0);
-    M.put(pr.v_index + 1, y1);
+    M.put_f(pr.v_index, y0);
+    M.put_f(pr.v_index + 1, y1);
 }
 
 
@@ -900,8 +907,8 @@ __device__ __forceinline__ void diff_acc(const ChainTables<T> &P, const ChainMem
         ydd0 -= blk[j] * ap[j];
         ydd1 -= blk[6 + j] * ap[j];
     }
-    M.put(d.v_index, ydd0);
-    M.put(d.v_index + 1, ydd1);
+    M.put_f(d.v_index, ydd0);
+    M.put_f(d.v_index + 1, ydd1);
     if (d.lds_va >= 0) {
         cptr<T> C1 = P.consts + d.cofs[0], C2 = P.consts + d.cofs[1];
         const T yd0 = M.qd(d.v_index), yd1 = M.qd(d.v_index + 1);
@@ -1154,7 +1161,7 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
         T ydd = kb[6];
 #pragma unroll
         for (int r = 0; r < 6; r++) ydd -= kb[r] * ap[r];
-        M.put(l.v_index, ydd);
+        M.put_f(l.v_index, ydd);
         if (l.has_child) {
             cptr<T> C = P.consts + l.cofs;
             const T g0 = C[kBodyConstFixed];
@@ -1271,7 +1278,7 @@ __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem
     xmotion(E, r, g, ag);
     // ydd = D^-1 u - D^-1 U^T a' with U = D = IA  =>  ydd = y0 - a' ;  a = a' + ydd = y0
 #pragma unroll
-    for (int j = 0; j < 6; j++) M.put(f.v_index + j, y0[j] - ag[j]);
+    for (int j = 0; j < 6; j++) M.put_f(f.v_index + j, y0[j] - ag[j]);
     if (f.lds_va >= 0) {
         T va[12];
 #pragma unroll
@@ -1313,12 +1320,12 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = (DP.debug & 8) ? 0 : 1;
     M.amask = (DP.debug & 16) ? kSlotGlobal : ~0;
-    M.out_row = DP.out_lds;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_out(DP.out_lds);
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1401,12 +1408,12 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
     M.amask = ~0;
-    M.out_row = DP.out_lds;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_out(DP.out_lds);
     const unsigned bq = (unsigned)(kWave * P.nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * P.nv) * (unsigned)sizeof(T);
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
@@ -1536,12 +1543,12 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
     M.amask = ~0;
-    M.out_row = -1;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_out(-1);
     const int m = A.n_contacts, nv = P.nv;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -2347,12 +2354,13 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
     M.amask = ~0;
-    M.out_row = -1;  // (the torque rows stay in the slab: LDS rows measured no faster here, and the branch in put() cost TelloWithArms 10 %)
+    // (the torque rows stay in the slab: LDS rows measured no faster here)
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_out(-1);
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t left = B - tile * kWave;
