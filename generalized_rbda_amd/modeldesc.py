@@ -412,3 +412,107 @@ def revolute_pair_chain_with_rotor(n_dof: int, gravity=(9.81, 0.0, 0.0)) -> Clus
                                           belt_ratios_1=[3.0], belt_ratios_2=[3.0, 1.0])
         parent = f"link-B-{i}"
     return m
+
+
+# -------------------------------------------------------------------------------------------------
+# the reference's RANDOM serial chains (what its unit tests instantiate: UnitTests/testClusterTreeModel.cpp:26-37,
+# testRigidBodyDynamicsAlgos.cpp:94-109).  Same structure, registration order and sampling laws; the numbers come from a
+# seeded numpy generator instead of rand().
+# -------------------------------------------------------------------------------------------------
+def _ref_random_inertia(rng, scaling: float = 1.0) -> np.ndarray:
+    """SpatialInertia::createRandomInertia (include/grbda/Utils/SpatialInertia.h:144-151)."""
+    mass = scaling * rng.uniform(0.0, 1.0)
+    com = scaling * rng.uniform(-1.0, 1.0, 3)
+    A = rng.uniform(-1.0, 1.0, (3, 3))
+    return spatial_inertia(mass, com, scaling * (A @ A.T))
+
+
+def _ref_random_xtree(rng):
+    """spatial::randomSpatialRotation (include/grbda/Utils/Spatial.h:43-48): E = rpyToRotMat(Random), r = Random."""
+    r = rng.uniform(-1.0, 1.0, 3)
+    return rpy_to_rotmat(rng.uniform(-1.0, 1.0, 3)), r
+
+
+def _ref_axis(rng) -> str:
+    return "xyz"[int(rng.integers(3))]  # ori::randomCoordinateAxis (OrientationTools.h:95-104)
+
+
+def _ref_ratio(rng, n: int = 0):
+    """SerialChain::randomGearRatio / randomBeltRatios<N> (SerialChain.hpp:41-55): rand() % 5 + 1."""
+    return float(rng.integers(1, 6)) if n == 0 else [float(x) for x in rng.integers(1, 6, n)]
+
+
+def revolute_chain_with_and_without_rotor(n_with: int, n_without: int, seed: int = 0, gravity=(0.0, 0.0, -9.81)) -> ClusterTreeModel:
+    """RevoluteChainWithAndWithoutRotor<N, M>::buildRandomClusterTreeModel
+    (src/Robots/SerialChains/RevoluteChainWithAndWithoutRotor.cpp:7-52): N RevoluteWithRotor clusters, then M plain links."""
+    rng = np.random.default_rng(seed)
+    m = ClusterTreeModel(gravity=gravity)
+    prev = "ground"
+    for i in range(n_with):
+        E, r = _ref_random_xtree(rng)
+        I = _ref_random_inertia(rng)
+        link_axis = _ref_axis(rng)
+        m.registerBody(f"link-{i}", I, prev, E, r)
+        E, r = _ref_random_xtree(rng)
+        I = _ref_random_inertia(rng, 1e-4)
+        rotor_axis = _ref_axis(rng)
+        m.registerBody(f"rotor-{i}", I, prev, E, r)
+        m.appendRegisteredBodiesAsCluster(f"cluster-{i}", "RevoluteWithRotor", joint_axis=link_axis, rotor_axis=rotor_axis,
+                                          gear_ratio=_ref_ratio(rng))
+        prev = f"link-{i}"
+    for i in range(n_with, n_with + n_without):
+        E, r = _ref_random_xtree(rng)
+        m.appendBody(f"link-{i}", _ref_random_inertia(rng), prev, E, r, joint="revolute", axis=_ref_axis(rng))
+        prev = f"link-{i}"
+    return m
+
+
+def revolute_pair_chain(n_dof: int, seed: int = 0, gravity=(0.0, 0.0, -9.81)) -> ClusterTreeModel:
+    """RevolutePairChain<N>::buildRandomClusterTreeModel (src/Robots/SerialChains/RevolutePairChain.cpp): clusters of two links
+    in series, no rotors, G = 1 (ClusterJoints::RevolutePair, RevolutePairJoint.cpp)."""
+    rng = np.random.default_rng(seed)
+    m = ClusterTreeModel(gravity=gravity)
+    parent = "ground"
+    for i in range(n_dof // 2):
+        E, r = _ref_random_xtree(rng)
+        IA = _ref_random_inertia(rng)
+        axA = _ref_axis(rng)
+        m.registerBody(f"link-A-{i}", IA, parent, E, r)
+        E, r = _ref_random_xtree(rng)
+        IB = _ref_random_inertia(rng)
+        axB = _ref_axis(rng)
+        m.registerBody(f"link-B-{i}", IB, f"link-A-{i}", E, r)
+        m.appendRegisteredBodiesAsCluster(f"cluster-{i}", "generic", axes=axA + axB, G=np.eye(2), K=np.zeros((0, 2)))
+        parent = f"link-B-{i}"
+    return m
+
+
+def revolute_triple_chain_with_rotor(n_dof: int, seed: int = 0, gravity=(0.0, 0.0, -9.81)) -> ClusterTreeModel:
+    """RevoluteTripleChainWithRotor<N>::buildRandomClusterTreeModel
+    (src/Robots/SerialChains/RevoluteTripleChainWithRotor.cpp:7-80): per cluster links A, B, C in series and their three rotors on
+    the cluster's parent body, registered [A, B, C, rotor A, rotor B, rotor C]; proximal / intermediate / distal
+    parallel-belt transmissions with 1 / 2 / 3 belt ratios."""
+    rng = np.random.default_rng(seed)
+    m = ClusterTreeModel(gravity=gravity)
+    parent = "ground"
+    for i in range(n_dof // 3):
+        axes, rotor_axes = "", ""
+        par = parent
+        for tag in "ABC":
+            E, r = _ref_random_xtree(rng)
+            I = _ref_random_inertia(rng)
+            axes += _ref_axis(rng)
+            m.registerBody(f"link-{tag}-{i}", I, par, E, r)
+            par = f"link-{tag}-{i}"
+        for tag in "ABC":
+            E, r = _ref_random_xtree(rng)
+            I = _ref_random_inertia(rng, 1e-4)
+            rotor_axes += _ref_axis(rng)
+            m.registerBody(f"rotor-{tag}-{i}", I, parent, E, r)
+        gears = [_ref_ratio(rng) for _ in range(3)]
+        m.appendRegisteredBodiesAsCluster(f"cluster-{i}", "RevoluteTripleWithRotor", joint_axes=axes, rotor_axes=rotor_axes,
+                                          gear_ratios=gears, belt_ratios_1=_ref_ratio(rng, 1), belt_ratios_2=_ref_ratio(rng, 2),
+                                          belt_ratios_3=_ref_ratio(rng, 3))
+        parent = f"link-C-{i}"
+    return m
+

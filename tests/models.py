@@ -247,6 +247,12 @@ def zoo():
         z[f"rev_rotor_chain_{n}"] = md.revolute_chain_with_rotor(n).serialize()
     for n in (2, 4):
         z[f"rev_pair_rotor_chain_{n}"] = md.revolute_pair_chain_with_rotor(n).serialize()
+    # the random serial chains of the reference's unit tests (testRigidBodyDynamicsAlgos.cpp:94-109)
+    for n in (3, 6):
+        z[f"rev_triple_rotor_chain_{n}"] = md.revolute_triple_chain_with_rotor(n, seed=n).serialize()
+    for a, b in ((0, 8), (4, 4), (8, 0)):
+        z[f"rev_chain_{a}_with_{b}_without_rotor"] = md.revolute_chain_with_and_without_rotor(a, b, seed=10 * a + b).serialize()
+    z["rev_pair_chain_4"] = md.revolute_pair_chain(4, seed=4).serialize()
     z["tree_rev_fixed"] = random_cluster_tree(1, 6, floating=False, kinds=("rev",)).serialize()
     z["tree_rotor_float"] = random_cluster_tree(2, 8, floating=True, kinds=("rotor", "rev")).serialize()
     z["tree_pair_float"] = random_cluster_tree(3, 6, floating=True, kinds=("pair", "rotor")).serialize()
