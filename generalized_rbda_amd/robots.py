@@ -69,7 +69,13 @@ def _tello_knee_ankle_phi(N=6.0):
     return [row0, row1]
 
 
-def tello_with_arms() -> ClusterTreeModel:
+def tello() -> ClusterTreeModel:
+    """Tello<double>::buildClusterTreeModel (src/Robots/Tello.cpp:6-277): floating torso and the two legs (hip clamp, hip
+    differential, knee-ankle differential each)."""
+    return tello_with_arms(arms=False)
+
+
+def tello_with_arms(arms: bool = True) -> ClusterTreeModel:
     """TelloWithArms<double>::buildClusterTreeModel (TelloWithArms.cpp:6-170 on top of Tello.cpp:6-277)."""
     m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
     I3 = np.eye(3)
@@ -109,6 +115,8 @@ def tello_with_arms() -> ClusterTreeModel:
         m.appendTrigPolyCluster(f"{side}-knee-ankle-differential", "zzyy", [True, True, False, False],
                                 _tello_knee_ankle_phi())
 
+    if not arms:
+        return m
     # arms (TelloWithArms.cpp:13-164, TelloWithArms.hpp:14-89); armID 0 = left, 1 = right (mirrored in y)
     rotor_z = np.diag([1.084e-4, 1.084e-4, 1.6841e-4])
     RY, RX = coordinate_rotation("y", np.pi / 2), coordinate_rotation("x", -np.pi / 2)
@@ -302,6 +310,50 @@ def mit_humanoid(ori_repr: str = "quaternion") -> ClusterTreeModel:
     return m
 
 
+def mit_humanoid_no_rotors(ori_repr: str = "quaternion") -> ClusterTreeModel:
+    """MIT_Humanoid_no_rotors<double>::buildClusterTreeModel (src/Robots/MIT_Humanoid_no_rotors.cpp:6-199): the MIT Humanoid's
+    links with its parameters (the class derives from MIT_Humanoid), plain Revolute clusters, the knee and ankle links of a
+    leg as one RevolutePair cluster (:112-113; G = 1), arm / leg / arm / leg as in the model with rotors (:192-195)."""
+    m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81), ori_repr=ori_repr)
+    I3 = np.eye(3)
+    torso = "Floating Base"
+    m.appendBody(torso, spatial_inertia(_MITH["torso"][0], _MITH["torso"][1], _sym3(_MITH["torso"][2])), "ground", joint="free")
+
+    def lr(v, side):
+        return np.array([v[0], -v[1] if side == 1 else v[1], v[2]])
+
+    def link(key, side):
+        mass, com, I = _MITH[key]
+        return _inertia_lr(mass, com, _sym3(I), side == 0)
+
+    def rev(key, parent, side, axis, pitch=None):
+        name = ("right_" if side == 0 else "left_") + key + "_link"
+        E = I3 if pitch is None else coordinate_rotation("y", pitch)
+        m.appendBody(name, link(key, side), parent, E, lr(_MITH_LOC[key][0], side), joint="revolute", axis=axis)
+        return name
+
+    def leg(side):
+        pre = "right_" if side == 0 else "left_"
+        p = rev("hip_rz", torso, side, "z", _MITH_PITCH["hip_rz"])
+        p = rev("hip_rx", p, side, "x", _MITH_PITCH["hip_rx"])
+        p = rev("hip_ry", p, side, "y", _MITH_PITCH["hip_ry"])
+        m.registerBody(pre + "knee_link", link("knee", side), p, I3, lr(_MITH_LOC["knee"][0], side))
+        m.registerBody(pre + "ankle_link", link("ankle", side), pre + "knee_link", I3, lr(_MITH_LOC["ankle"][0], side))
+        m.appendRegisteredBodiesAsCluster(pre + "knee_ankle_cluster", "generic", axes="yy", G=np.eye(2), K=np.zeros((0, 2)))
+
+    def arm(side):
+        p = rev("shoulder_ry", torso, side, "y")
+        p = rev("shoulder_rx", p, side, "x")
+        p = rev("shoulder_rz", p, side, "z")
+        rev("elbow", p, side, "y")
+
+    arm(0)
+    leg(0)
+    arm(1)
+    leg(1)
+    return m
+
+
 def mit_humanoid_leg() -> ClusterTreeModel:
     """MIT_Humanoid_Leg<double>::buildClusterTreeModel (src/Robots/MIT_Humanoid_Leg.cpp:6-163): the LEFT leg's
     parameters un-mirrored, fixed to the ground, massless rotors, knee/ankle cluster registered
@@ -461,3 +513,65 @@ def jvrc1_humanoid(urdf_variant: bool = False) -> ClusterTreeModel:
     for s in ("left", "right"):   # JVRC1_Humanoid.cpp:692-755: the wrist yaw joints come last
         joint(f"{s}_wrist_y", f"{s}_wrist_y", f"{s}_wrist_r", "z")
     return m
+
+
+# -------------------------------------------------------------------------------------------------
+# TeleopArm (src/Robots/TeleopArm.cpp, include/grbda/Robots/TeleopArm.hpp): fixed base, three RevoluteWithRotor clusters,
+# one RevoluteTripleWithRotor cluster (upper link, wrist pitch, wrist roll and their three rotors on the shoulder link) and
+# the gripper.  Values as the reference holds them (TeleopArm.cpp:167-266), its rotor arithmetic included: the "small" rotor
+# inertia is 1e-3 times the ALREADY scaled large one (:173-177), and the X / Y variants are R I R^T with R = Ry(pi/2) / Rx(+pi/2).
+# -------------------------------------------------------------------------------------------------
+_TELEOP = {  # mass, com, rotational inertia rows (about the COM)
+    "base": (0.996728196, [-1.32E-07, -0.001991858, 0.042209332],
+             [[0.003411721, -2.78E-09, -1.45E-09], [-2.78E-09, 0.003047159, -0.000609866], [-1.45E-09, -0.000609866, 0.003412964]]),
+    "shoulder-rx-link": (0.4796, [-4.96E-10, -0.004546817, 0.045690967],
+                         [[0.001190777, 3.21E-12, 2.07E-11], [3.21E-12, 0.001028401, 0.00022441], [2.07E-11, 0.00022441, 0.001459421]]),
+    "shoulder-ry-link": (1.670980082, [0.000482465, -0.000659857, 0.168192061],
+                         [[0.016496934, 2.23E-07, 7.79E-05], [2.23E-07, 0.018757685, 0.000273553], [7.79E-05, 0.000273553, 0.003224214]]),
+    "upper-link": (0.4617247, [3.99E-08, 0.003531916, 0.130185501],
+                   [[0.006286029, -1.39E-10, -3.25E-09], [-1.39E-10, 0.006437035, 6.24E-06], [-3.25E-09, 6.24E-06, 0.00020455]]),
+    "wrist-pitch-link": (0.063603259, [-1.70E-09, 0.004167466, 0.01683806],
+                         [[1.73E-05, -2.13E-12, -3.11E-13], [-2.13E-12, 1.42E-05, -4.98E-07], [-3.11E-13, -4.98E-07, 2.03E-05]]),
+    "wrist-roll-link": (0.167365855, [-0.001177177, 0.004697849, 0.040664076],
+                        [[0.000182127, 2.15E-06, -1.57E-06], [2.15E-06, 8.28E-05, -9.44E-06], [-1.57E-06, -9.44E-06, 0.00011452]]),
+    "gripper": (0.170943071, [0.000564355, -0.003238555, 0.105873754],
+                [[6.20E-05, 5.26E-09, 1.04E-06], [5.26E-09, 6.64E-05, 8.69E-07], [1.04E-06, 8.69E-07, 1.81E-05]]),
+}
+_TELEOP_LOC = {"base": [0, 0, 0.051], "shoulder-rx-link": [0, 0, 0.106], "shoulder-ry-link": [0, 0, 0.071],
+               "upper-link": [0, -0.0095, 0.3855], "wrist-pitch-link": [0, 0, 0.362], "wrist-roll-link": [0, 0.004, 0.03574],
+               "gripper": [0.0004, 0.0375, 0.070995]}
+
+
+def teleop_arm() -> ClusterTreeModel:
+    """TeleopArm::buildClusterTreeModel (src/Robots/TeleopArm.cpp:6-165)."""
+    m = ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    I3 = np.eye(3)
+    large_z = 1e-3 * np.diag([1.052, 1.046, 1.811])
+    small_z = 1e-3 * large_z
+    RY, RX = coordinate_rotation("y", np.pi / 2), coordinate_rotation("x", np.pi / 2)
+    rot = {("small", "x"): RY @ small_z @ RY.T, ("small", "y"): RX @ small_z @ RX.T, ("small", "z"): small_z,
+           ("large", "x"): RY @ large_z @ RY.T, ("large", "y"): RX @ large_z @ RX.T, ("large", "z"): large_z}
+    rotor = lambda size, axis: spatial_inertia(0.055 if size == "small" else 1.081, [0, 0, 0], rot[(size, axis)])
+    link = lambda name: spatial_inertia(_TELEOP[name][0], _TELEOP[name][1], np.asarray(_TELEOP[name][2]))
+    zero = [0.0, 0.0, 0.0]
+
+    def rev_with_rotor(cluster, name, rotor_name, parent, axis, size, ratio):
+        m.registerBody(name, link(name), parent, I3, _TELEOP_LOC[name])
+        m.registerBody(rotor_name, rotor(size, axis), parent, I3, zero)
+        m.appendRegisteredBodiesAsCluster(cluster, "RevoluteWithRotor", joint_axis=axis, rotor_axis=axis, gear_ratio=ratio)
+
+    rev_with_rotor("base-cluster", "base", "base-rotor", "ground", "z", "large", 6.0)
+    rev_with_rotor("shoulder-rx-cluster", "shoulder-rx-link", "shoulder-rx-rotor", "base", "x", "large", 6.0)
+    rev_with_rotor("shoulder-ry-cluster", "shoulder-ry-link", "shoulder-ry-rotor", "shoulder-rx-link", "y", "large", 6.0)
+    par = "shoulder-ry-link"
+    for name in ("upper-link", "wrist-pitch-link", "wrist-roll-link"):
+        m.registerBody(name, link(name), par, I3, _TELEOP_LOC[name])
+        par = name
+    for name, size, axis in (("elbow-rotor", "large", "y"), ("wrist-pitch-rotor", "small", "y"), ("wrist-roll-rotor", "small", "z")):
+        m.registerBody(name, rotor(size, axis), "shoulder-ry-link", I3, zero)
+    m.appendRegisteredBodiesAsCluster("upper-arm-cluster", "RevoluteTripleWithRotor", joint_axes="yyz", rotor_axes="yyz",
+                                      gear_ratios=[6.0, 6.0, 6.0], belt_ratios_1=[1.0], belt_ratios_2=[1.0, 1.0],
+                                      belt_ratios_3=[-1.0, 1.0, -1.0])
+    rev_with_rotor("gripper-cluster", "gripper", "gripper-rotor", "wrist-roll-link", "x", "small", 2.0)
+    return m
+

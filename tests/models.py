@@ -240,6 +240,11 @@ def zoo():
     from generalized_rbda_amd.robots import tello_with_arms
 
     z["tello_with_arms"] = tello_with_arms().serialize()
+    # the other hand-built robots of the reference's unit tests (testClusterTreeModel.cpp:26-37)
+    from generalized_rbda_amd.robots import mit_humanoid_no_rotors, teleop_arm, tello
+    z["tello"] = tello().serialize()
+    z["teleop_arm"] = teleop_arm().serialize()
+    z["mit_humanoid_no_rotors"] = mit_humanoid_no_rotors().serialize()
     from generalized_rbda_amd.robots import jvrc1_humanoid
 
     z["jvrc1_hand_built"] = jvrc1_humanoid().serialize()  # the reference's JVRC1_Humanoid: 32 rotor clusters, 65 bodies
