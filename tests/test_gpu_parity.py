@@ -671,6 +671,11 @@ def test_body_twists_are_the_derivatives_of_the_motion(name, blob, gpu):
     scale = 1.0 + np.abs(a_ref).max()
     assert np.abs(a_fd - a_ref).max() / scale < 2e-6, np.abs(a_fd - a_ref).max() / scale
 
+    # fp32 entry point against the fp64 one
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    V32 = plan.body_twists(t32(q), t32(qd), t32(ydd)).double().cpu().numpy()
+    assert np.abs(V32 - V).max() / (1.0 + np.abs(V).max()) < TOL32
+
     bodies = sorted({0, plan.n_bodies // 2, plan.n_bodies - 1})
     _, J = plan.inv_osim(t(q), bodies, np.zeros((len(bodies), 3)), with_jacobian=True)
     J = J.cpu().numpy().reshape(B, len(bodies), 6, plan.nv)
