@@ -21,13 +21,17 @@ $(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/d
 # functions): lone multiplies and adds of the spatial products fold into FMAs, 10 % fewer floating-point instructions
 # (MIT humanoid fp32 ABA 0.173 -> 0.170 ms, JVRC-1 and TelloWithArms 3-4 %); parity tolerances unchanged.
 CHAINFLAGS := -fassociative-math -fno-signed-zeros -fno-trapping-math
-$(OBJ)/chain_kernels.o: $(CSRC)/chain_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+$(OBJ)/chain_kernels.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -c $< -o $@
 # second unit of the same source: the two fp64 kernels with the deepest register pressure (see the head of chain_kernels.hip)
-$(OBJ)/chain_kernels_u1.o: $(CSRC)/chain_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+$(OBJ)/chain_kernels_u1.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -DGRBDA_CHAIN_UNIT=1 -c $< -o $@
+# third unit: the kernels of chain programs with generic clusters (gen_segments.h)
+$(OBJ)/chain_kernels_u2.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -DGRBDA_CHAIN_UNIT=2 $(U2FLAGS) -c $< -o $@
 $(OBJ)/crba_kernels.o: $(CSRC)/crba_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
@@ -49,13 +53,14 @@ $(OBJ)/urdf.o: $(CSRC)/urdf.cpp include/grbda_hip.h include/grbda_model_desc.h g
 VARIANT ?= v
 VFLAGS ?=
 U1FLAGS ?=
-variant: $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+U2FLAGS ?=
+variant: $(OBJ)/chain_kernels_u2.o $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	@mkdir -p build/variants
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_$(VARIANT).o
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -DGRBDA_CHAIN_UNIT=1 $(U1FLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_u1_$(VARIANT).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/libgrbda_hip_$(VARIANT).so build/variants/chain_kernels_$(VARIANT).o build/variants/chain_kernels_u1_$(VARIANT).o $^
 
-$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 oracle:
@@ -70,25 +75,25 @@ clean:
 .PHONY: all oracle ref clean
 
 # profiling variant with in-kernel cycle accounting (tools/prof_run.py); not part of `all`
-prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
+prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
 	@mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -DGRBDA_PROFILE -c $(CSRC)/kernels.hip -o build/prof/kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/libgrbda_hip_prof.so build/prof/kernels.o $^
 
 # experiment builds: make exp NAME=foo DEFS="-DGRBDA_EXP_FOO" -> build/exp/libgrbda_foo.so
-exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
+exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/kernels.hip -o build/exp/kernels_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/kernels_$(NAME).o $^
 
 # experiment builds of the derivative kernels: make expd NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expd: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expd: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/deriv_kernels.hip -o build/exp/deriv_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/deriv_$(NAME).o $^
 
 # experiment builds of the chain kernels: make expc NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expc: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels_u1.o $(OBJ)/deriv_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expc: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/deriv_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(DEFS) -c $(CSRC)/chain_kernels.hip -o build/exp/chain_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/chain_$(NAME).o $^

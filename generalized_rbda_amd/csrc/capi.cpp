@@ -57,6 +57,8 @@ struct DeviceTables {
     ChainPair *chain_pairs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     ChainFree *chain_frees[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     ChainDiff *chain_diffs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGen *chain_gens[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGenBody *chain_gbodies[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
@@ -224,7 +226,9 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(cp.links.data(), cp.links.size() * sizeof(ChainLink), (void **)&t.chain_links[w])) != hipSuccess ||
             (e = up(cp.pairs.data(), cp.pairs.size() * sizeof(ChainPair), (void **)&t.chain_pairs[w])) != hipSuccess ||
             (e = up(cp.frees.data(), cp.frees.size() * sizeof(ChainFree), (void **)&t.chain_frees[w])) != hipSuccess ||
-            (e = up(cp.diffs.data(), cp.diffs.size() * sizeof(ChainDiff), (void **)&t.chain_diffs[w])) != hipSuccess)
+            (e = up(cp.diffs.data(), cp.diffs.size() * sizeof(ChainDiff), (void **)&t.chain_diffs[w])) != hipSuccess ||
+            (e = up(cp.gens.data(), cp.gens.size() * sizeof(ChainGen), (void **)&t.chain_gens[w])) != hipSuccess ||
+            (e = up(cp.gbodies.data(), cp.gbodies.size() * sizeof(ChainGenBody), (void **)&t.chain_gbodies[w])) != hipSuccess)
             return hip_err(e, "plan upload");
         if ((e = set_max_dynamic_lds_chain()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
@@ -298,7 +302,7 @@ bool chain_covers(const grbda_plan *p)
 {
     if (p->no_chain) return false;
     if (sizeof(T) == 8) return p->host.chain64.ok;
-    return p->host.chain32.ok || (p->host.chain32w.ok && p->host.chain32w.diffs.empty() && p->chain_wide);
+    return p->host.chain32.ok || (p->host.chain32w.ok && p->host.chain32w.diffs.empty() && p->host.chain32w.gens.empty() && p->chain_wide);
 }
 
 template <class T>
@@ -324,6 +328,9 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.frees = t.chain_frees[w];
             d.diffs = nullptr;
             d.n_diffs = 0;
+            d.gens = nullptr;
+            d.gbodies = nullptr;
+            d.n_gens = 0;
             d.cints = t.cints;
             d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
             d.n_segs = static_cast<int>(lp.segs.size());
@@ -346,7 +353,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
         }
     }
     // f32: four wavefronts per SIMD (16 per CU, half the LDS each) once the batch fills them, when that layout exists
-    const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && p->chain_wide &&
+    const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && h.chain32w.gens.empty() && p->chain_wide &&
                       (!h.chain32.ok || n_tiles0 > static_cast<size_t>(t.n_cu) * 8);
     const int w = sizeof(T) == 8 ? 2 : (wide ? 1 : 0);
     const int kid = sizeof(T) == 8 ? 1 : 0;
@@ -360,6 +367,9 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     d.frees = t.chain_frees[w];
     d.diffs = t.chain_diffs[w];
     d.n_diffs = static_cast<int>(cp.diffs.size());
+    d.gens = t.chain_gens[w];
+    d.gbodies = t.chain_gbodies[w];
+    d.n_gens = static_cast<int>(cp.gens.size());
     d.cints = t.cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.n_segs = static_cast<int>(cp.segs.size());
@@ -884,7 +894,8 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
 {
     const HostPlan &h = p->host;
     const ChainProgram &cp = sizeof(T) == 8 ? h.chain64 : h.chain32;
-    if (p->no_chain || p->no_efpa || !cp.ok || n_contacts > kOsimMaxContacts) return 1;
+    // (programs with generic clusters -- plan.h, ChainGen -- have no walk steps in the force-propagation kernel: unit-wrench path)
+    if (p->no_chain || p->no_efpa || !cp.ok || !cp.gens.empty() || n_contacts > kOsimMaxContacts) return 1;
     const Layout &L = h.lay64;
     OsimArgs<T> A;
     std::memset(&A, 0, sizeof A);
@@ -1002,6 +1013,9 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.frees = t->chain_frees[w];
     d.diffs = t->chain_diffs[w];
     d.n_diffs = static_cast<int>(cp.diffs.size());
+    d.gens = nullptr;
+    d.gbodies = nullptr;
+    d.n_gens = 0;
     d.cints = t->cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t->consts32) : reinterpret_cast<const T *>(t->consts64);
     d.n_segs = static_cast<int>(cp.segs.size());
@@ -1603,7 +1617,7 @@ void grbda_plan_free(grbda_plan *p)
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
-        for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); }
+        for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work, &p->work_cvt})
@@ -1677,6 +1691,7 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->n_chain_differentials = p->no_chain ? 0 : static_cast<int>(p->host.chain32.diffs.size());
     info->latency_mode_f32 = p->host.chain32p.ok && !p->no_chain && !p->no_latency_mode;
     info->latency_mode_f64 = p->host.chain64p.ok && !p->no_chain && !p->no_latency_mode;
+    info->n_chain_generic = p->no_chain ? 0 : static_cast<int>(p->host.chain32.gens.size());
     return GRBDA_OK;
 }
 

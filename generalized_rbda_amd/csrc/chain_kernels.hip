@@ -20,7 +20,8 @@
 // (kernels.hip); the plan compiler decides (ChainProgram::ok).  The same file holds the inverse dynamics on the chains
 // (rnea_chain_kernel) and the force-propagation kernel of the contact side (osim_chain_kernel).
 //
-// Two translation units are built from this file (Makefile).  GRBDA_CHAIN_UNIT == 1 carries the two fp64 kernels with the deepest
+// Three translation units are built from this file (Makefile).  GRBDA_CHAIN_UNIT == 2 carries the kernels of programs with
+// generic clusters (gen_segments.h: aba_chain_kernel<T, 2, 2>), GRBDA_CHAIN_UNIT == 1 carries the two fp64 kernels with the deepest
 // register pressure -- aba_chain_lm_kernel<double> and aba_chain_kernel<double, 2, true> (the program with differentials); unit 0
 // is everything else.  Both fp64 kernels spill, and how much depends on what else the compiler sees in the unit: measured in
 // one run against the single-unit build (tools/ab3.sh), Mini Cheetah fp64 at 65 536 states 0.0727 -> 0.0664 ms and TelloWithArms
@@ -69,6 +70,8 @@ struct ChainTables {
     cptr<ChainPair> pairs;
     cptr<ChainFree> frees;
     cptr<ChainDiff> diffs;
+    cptr<ChainGen> gens;
+    cptr<ChainGenBody> gbodies;
     cptr<int32_t> cints;
     cptr<T> consts;
     int n_segs, nq, nv, ori_repr;
@@ -1290,20 +1293,26 @@ __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem
     }
 }
 
+#include "gen_segments.h"
+
 // ---------------------------------------------------------------------------------------------------------------
-// DIFF: the program has differential clusters (ChainDiff).  A kernel variant of its own, so that the models without them
-// (every URDF robot of the reference) keep the register allocation of the plain run / pair / free code.
-template <class T, int WPS, bool DIFF>
+// MODE 1: the program has differential clusters (ChainDiff).  A kernel variant of its own, so that the models without them
+// (every URDF robot of the reference) keep the register allocation of the plain run / pair / free code.  MODE 2: the program
+// has generic clusters (ChainGen; gen_segments.h) and possibly differentials: translation unit 2.
+template <class T, int WPS, int MODE>
 __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
                                                              const T *__restrict__ tau, T *__restrict__ ydd, size_t B,
                                                              T *__restrict__ scratch)
 {
+    constexpr bool DIFF = MODE >= 1, GEN = MODE == 2;
     ChainTables<T> P;
     P.segs = (cptr<ChainSeg>)DP.segs;
     P.links = (cptr<ChainLink>)DP.links;
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
     P.diffs = DIFF ? (cptr<ChainDiff>)DP.diffs : nullptr;
+    P.gens = GEN ? (cptr<ChainGen>)DP.gens : nullptr;
+    P.gbodies = GEN ? (cptr<ChainGenBody>)DP.gbodies : nullptr;
     P.cints = DIFF ? (cptr<int32_t>)DP.cints : nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
@@ -1359,6 +1368,15 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                 case SEG_DIFF_ACC:
                     if constexpr (DIFF) diff_acc(P, M, load_rec(P.diffs + sg.first));
                     break;
+                case SEG_GEN_FWD:
+                    if constexpr (GEN) gen_segment<T, 0>(P, M, load_rec(P.gens + sg.first));
+                    break;
+                case SEG_GEN_BWD:
+                    if constexpr (GEN) gen_segment<T, 1>(P, M, load_rec(P.gens + sg.first));
+                    break;
+                case SEG_GEN_ACC:
+                    if constexpr (GEN) gen_segment<T, 2>(P, M, load_rec(P.gens + sg.first));
+                    break;
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
@@ -1393,6 +1411,8 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
     P.diffs = nullptr;
+    P.gens = nullptr;
+    P.gbodies = nullptr;
     P.cints = nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
@@ -1481,7 +1501,7 @@ hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, co
 #if GRBDA_CHAIN_UNIT == 0
 template hipError_t launch_aba_chain_lm<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
                                                float *, int, size_t, hipStream_t);
-#else
+#elif GRBDA_CHAIN_UNIT == 1
 template hipError_t launch_aba_chain_lm<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
                                                 size_t, double *, int, size_t, hipStream_t);
 #endif
@@ -1527,6 +1547,8 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
     P.diffs = (cptr<ChainDiff>)DP.diffs;
+    P.gens = nullptr;
+    P.gbodies = nullptr;
     P.cints = (cptr<int32_t>)DP.cints;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
@@ -1902,25 +1924,32 @@ template hipError_t launch_osim_chain<double>(const ChainDev<double> &, const Os
 hipError_t launch_aba_chain_diff_f64(const ChainDev<double> &P, const double *q, const double *qd, const double *tau, double *ydd, size_t B,
                                      double *scratch, int grid, size_t lds_bytes, hipStream_t stream);
 template <class T>
+hipError_t launch_aba_chain_gen(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
+                                size_t lds_bytes, hipStream_t stream);
+template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd)
 {
+    if (P.n_gens > 0) {
+        if (four_waves_per_simd) return hipErrorInvalidValue;
+        return launch_aba_chain_gen<T>(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream);  // (unit 2)
+    }
     if (P.n_diffs > 0) {
         if (four_waves_per_simd) return hipErrorInvalidValue;  // (capi.cpp keeps such programs at two wavefronts per SIMD)
         if constexpr (sizeof(T) == 8) {
             return launch_aba_chain_diff_f64(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream);  // (unit 1, below)
         } else {
-            hipLaunchKernelGGL((aba_chain_kernel<T, 2, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+            hipLaunchKernelGGL((aba_chain_kernel<T, 2, 1>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
             return hipGetLastError();
         }
     }
     if constexpr (sizeof(T) == 4) {
         if (four_waves_per_simd) {
-            hipLaunchKernelGGL((aba_chain_kernel<T, 4, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+            hipLaunchKernelGGL((aba_chain_kernel<T, 4, 0>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((aba_chain_kernel<T, 2, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    hipLaunchKernelGGL((aba_chain_kernel<T, 2, 0>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
 #if GRBDA_CHAIN_UNIT == 0
@@ -1928,13 +1957,25 @@ template hipError_t launch_aba_chain<float>(const ChainDev<float> &, const float
                                             float *, int, size_t, hipStream_t, bool);
 template hipError_t launch_aba_chain<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
                                              size_t, double *, int, size_t, hipStream_t, bool);
-#else
+#elif GRBDA_CHAIN_UNIT == 1
 hipError_t launch_aba_chain_diff_f64(const ChainDev<double> &P, const double *q, const double *qd, const double *tau, double *ydd, size_t B,
                                      double *scratch, int grid, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((aba_chain_kernel<double, 2, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    hipLaunchKernelGGL((aba_chain_kernel<double, 2, 1>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
+#else
+template <class T>
+hipError_t launch_aba_chain_gen(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
+                                size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((aba_chain_kernel<T, 2, 2>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_aba_chain_gen<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
+                                                float *, int, size_t, hipStream_t);
+template hipError_t launch_aba_chain_gen<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
+                                                 size_t, double *, int, size_t, hipStream_t);
 #endif
 
 
@@ -2413,13 +2454,14 @@ static hipError_t set_max_dynamic_lds(const void *const *kernels, int n)
     return hipSuccess;
 }
 hipError_t set_max_dynamic_lds_chain_unit1();
+hipError_t set_max_dynamic_lds_chain_unit2();
 #if GRBDA_CHAIN_UNIT == 0
 hipError_t set_max_dynamic_lds_chain()
 {
     const void *const kernels[] = {
-        reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, false>), reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, true>),
-        reinterpret_cast<const void *>(&aba_chain_kernel<float, 4, false>),
-        reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, false>),
+        reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, 0>), reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, 1>),
+        reinterpret_cast<const void *>(&aba_chain_kernel<float, 4, 0>),
+        reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 0>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, false>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, false>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, true>),
@@ -2427,13 +2469,22 @@ hipError_t set_max_dynamic_lds_chain()
         reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>),
         reinterpret_cast<const void *>(&aba_chain_lm_kernel<float>)};
     const hipError_t e = set_max_dynamic_lds(kernels, static_cast<int>(sizeof(kernels) / sizeof(kernels[0])));
-    return e != hipSuccess ? e : set_max_dynamic_lds_chain_unit1();
+    if (e != hipSuccess) return e;
+    const hipError_t e1 = set_max_dynamic_lds_chain_unit1();
+    return e1 != hipSuccess ? e1 : set_max_dynamic_lds_chain_unit2();
 }
-#else
+#elif GRBDA_CHAIN_UNIT == 1
 hipError_t set_max_dynamic_lds_chain_unit1()
 {
-    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, true>),
+    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 1>),
                                    reinterpret_cast<const void *>(&aba_chain_lm_kernel<double>)};
+    return set_max_dynamic_lds(kernels, 2);
+}
+#else
+hipError_t set_max_dynamic_lds_chain_unit2()
+{
+    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, 2>),
+                                   reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 2>)};
     return set_max_dynamic_lds(kernels, 2);
 }
 #endif

@@ -64,6 +64,9 @@ struct ChainDev {
     const ChainFree *frees;
     const ChainDiff *diffs;
     int n_diffs;
+    const ChainGen *gens;          // generic clusters (plan.h, ChainGen; gen_segments.h)
+    const ChainGenBody *gbodies;
+    int n_gens;
     const int32_t *cints;
     const T *consts;
     int n_segs;

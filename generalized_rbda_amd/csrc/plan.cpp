@@ -1049,8 +1049,16 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         // cluster classes: 0 free, 1 revolute, 2 revolute + axisymmetric rotor, 3 leaf pair (head of its parent link's backward
         // run), 4 revolute + general rotor, 5 two-rotor differential, 6 explicit pair with child clusters on link2 or in a
         // place class 3 does not cover (runs through the differential's segments with constant G), -1 unsupported
+        // 7 generic cluster (plan.h, ChainGen): any other explicit cluster, URDF+ position loops, trig-polynomial constraints that
+        // are not in the differential's shape; child clusters may hang off any of its bodies (tip = -2)
         std::vector<int> cls(nc, -1), tip(nc, -1), gen_rotor(nc, -1);
+        const bool no_gen = std::getenv("GRBDA_NO_CHAIN_GEN") != nullptr;  // A/B switch: such models keep the interpreter
         auto is_diff = [&](int c) { return cls[c] == 5 || cls[c] == 6; };
+        auto make_gen = [&](int c) {
+            if (no_gen) { ok = false; return; }
+            cls[c] = 7;
+            tip[c] = -2;
+        };
         std::vector<ChainPair> pair_of(nc);
         std::vector<std::array<int, 2>> pair_rotors(nc, std::array<int, 2>{-1, -1});
         for (int c = 0; c < nc && ok; c++) {
@@ -1115,17 +1123,17 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     pr.perm[1] = cyclic_shift(P.consts, pr.cofs[1]);
                     if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d pair perms %d %d\n", c, pr.perm[0], pr.perm[1]);
                 } else {
-                    ok = false;
+                    make_gen(c);
                 }
             } else if (diff_shape[c].ok) {
                 cls[c] = 5;  // two-rotor differential (implicit), plan.h ChainDiff
                 tip[c] = diff_shape[c].l2;
             } else {
-                ok = false;
+                make_gen(c);
             }
             // (links may hang off the ground -- fixed-base models: the runs then start from v = 0, a = -gravity and hand
             // their inertia to nobody; pair and differential clusters need a parent body)
-            if ((cls[c] == 3 || cls[c] == 5) && cr.parent_body < 0) ok = false;
+            if ((cls[c] == 3 || cls[c] == 5) && cr.parent_body < 0) make_gen(c);
             if (!ok && std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d (k %d n %d kind %d shape %d) not covered\n", c, cr.k, cr.n, cr.kind, cr.shape);
         }
         // every child cluster must hang off the tip body of its parent cluster; a pair must be an only child of a link
@@ -1134,10 +1142,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             const int pb = clusters[c].parent_body;
             if (pb < 0) continue;
             const int pc = m.bodies[pb].cluster;
-            if (tip[pc] != pb) {
+            if (tip[pc] != pb && tip[pc] != -2) {
+                // (a child cluster on a rotor, on the first link of a pair, ...: the parent runs as a generic cluster)
                 if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d hangs off body %d, not the tip %d of cluster %d\n", c, pb, tip[pc], pc);
-                ok = false;
-                break;
+                if (cls[pc] == 0) { ok = false; break; }
+                make_gen(pc);
+                if (!ok) break;
             }
             ckids[pc].push_back(c);
         }
@@ -1145,7 +1155,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             // child order = the depth-first order of the general schedule (kids[])
             ckids[c] = kids[c];
             for (int k : ckids[c])
-                if (cls[k] == 3 && (ckids[c].size() != 1 || cls[c] == 0 || cls[c] == 3 || is_diff(c))) {
+                if (cls[k] == 3 && (ckids[c].size() != 1 || cls[c] == 0 || cls[c] == 3 || cls[c] == 7 || is_diff(c))) {
                     cls[k] = 6;  // a leaf pair next to siblings, or on the base / a pair / a differential: standalone segments
                     tip[k] = diff_shape[k].l2;
                 }
@@ -1155,6 +1165,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::vector<ChainLink> link_of(nc);
             std::vector<ChainFree> free_of(nc);
             std::vector<ChainDiff> diff_of(nc);
+            std::vector<ChainGen> gen_of(nc);
+            std::vector<std::vector<ChainGenBody>> gbody_of(nc);
+            std::vector<int> gen_w_size(nc, 0);
             std::vector<int> acc_slot(nc, -1);            // accumulator [IA 21][psi 6] of the tip body (several kid chains, or a free base)
             std::vector<Obj> objs;
             int n_glb = 0;
@@ -1206,6 +1219,78 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     d.tofs_i = ds.tofs_i;
                     d.tofs_d = ds.tofs_i >= 0 ? P.cints[ds.tofs_i + 2] : 0;
                     d.glb_k = glb(27);  // [K 12][y0 2][X 4][g 2][s1 c1 s2 c2] (+ OSIM pass: D^-1 (3))
+                } else if (cls[c] == 7) {
+                    ChainGen &g = gen_of[c];
+                    g = ChainGen();
+                    const int k = cr.k, n = cr.n;
+                    g.q_index = cr.q_index; g.v_index = cr.v_index;
+                    g.k = k; g.n = n; g.rows = cr.rows;
+                    g.kind = cr.kind == CK_LOOP ? (cr.cons_type == 1 ? 2 : 1) : 0;
+                    g.iofs = cr.iofs; g.dofs = cr.dofs;
+                    g.has_parent = cr.parent_body >= 0;
+                    g.lds_pv = g.lds_acc_out = g.lds_pva = g.lds_w = g.lds_wf = g.keep = -1;
+                    g.glb_k = glb(7 * n);
+                    std::vector<ChainGenBody> &gb = gbody_of[c];
+                    gb.assign(k, ChainGenBody());
+                    bool kids_here = false;
+                    for (int i = 0; i < k; i++) {
+                        const BodyRec &br = bodies[cr.first_body + i];
+                        ChainGenBody &b = gb[i];
+                        b.cofs = br.cofs;
+                        b.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
+                        b.lam = br.lam >= 0 ? br.lam - cr.first_body : -1;
+                        b.axis = br.axis;
+                        b.axisym = br.axisym;
+                        b.acc_w = b.up_w = b.lds_acc = b.lds_va = b.pva = b.ind_a = b.dep_r = b.lds_v = -1;
+                        for (int j = 0; j < nb; j++)
+                            if (bodies[j].parent == cr.first_body + i && m.bodies[j].cluster != c) kids_here = true;
+                    }
+                    // scratch of the constraint evaluation (gen_segments.h): K [rows x k], then per loop side 6 slots per joint of
+                    // its path + 3, or 4 slots per distinct argument of a trig-polynomial constraint
+                    int scratch = 0;
+                    if (g.kind) {  // cints[iofs]: header, n_ind, ind[], n_dep, dep[]
+                        const int32_t *ip = &P.cints[cr.iofs];
+                        for (int a = 0; a < ip[1]; a++) gb[ip[2 + a]].ind_a = a;
+                        for (int r = 0; r < cr.rows; r++) gb[ip[3 + ip[1] + r]].dep_r = r;
+                    }
+                    if (g.kind == 1) {
+                        const int32_t *ip = &P.cints[cr.iofs];
+                        const int32_t *lp = ip + 3 + ip[1] + cr.rows;
+                        scratch = cr.rows * k;
+                        for (int l = 0; l < ip[0]; l++) {
+                            const int np = lp[0], ns = lp[1 + np];
+                            scratch += 6 * (np + ns) + 6;
+                            lp += 3 + np + ns;
+                        }
+                    } else if (g.kind == 2) {
+                        scratch = cr.rows * k + 4 * trig_args[c];
+                    }
+                    int w = 2 * k + std::max(6 * k, scratch);
+                    // (IA, psi) inside the cluster: to the body right before in registers, else through an accumulator of the work area
+                    for (int i = k - 1; i >= 0; i--) {
+                        ChainGenBody &b = gb[i];
+                        if (b.lam < 0) continue;
+                        if (b.lam == i - 1) {
+                            b.carry_up = 1;
+                            gb[i - 1].carry_in = 1;
+                            continue;
+                        }
+                        ChainGenBody &pl = gb[b.lam];
+                        if (pl.acc_w < 0) {
+                            pl.acc_w = w;
+                            w += 27;
+                            b.up_first = 1;
+                        }
+                        b.up_w = pl.acc_w;
+                    }
+                    if (g.kind && !kids_here) {  // the kept block of a childless implicit cluster lives inside the work area
+                        g.keep = -2 - w;          // (resolved against lds_w after allocation)
+                        w += cr.rows * (n + 2);
+                    } else if (g.kind) {
+                        g.keep = glb(cr.rows * (n + 2));
+                    }
+                    g.has_fwd = kids_here ? 1 : 0;
+                    gen_w_size[c] = w;
                 } else {
                     pair_of[c].glb_k = glb(21);  // [K 12][y0 2] (+ OSIM pass: D^-1 (3), sin / cos of the two links (4))
                     pair_of[c].rpre[0] = rotor_constants(pair_rotors[c][0]);
@@ -1215,7 +1300,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             // chains: follow single link children; a single pair child becomes the head of the backward run
             auto is_link = [](int k) { return k == 1 || k == 2 || k == 4; };
-            struct Chain { std::vector<int> cl; int pair = -1; std::vector<int> kid_chains; int parent_cluster = -1; bool diff = false; };
+            struct Chain { std::vector<int> cl; int pair = -1; std::vector<int> kid_chains; int parent_cluster = -1; bool diff = false; bool gen = false; };
             std::vector<Chain> chains;
             std::function<int(int)> make_chain = [&](int c0) -> int {
                 Chain ch;
@@ -1225,10 +1310,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     ch.cl.push_back(c);
                     // (links with no rotor, an axisymmetric rotor and a general rotor may share a run: the kind is a branch on
                     // the link record)
-                    if (!is_diff(c) && ckids[c].size() == 1 && is_link(cls[ckids[c][0]])) { c = ckids[c][0]; continue; }
+                    if (!is_diff(c) && cls[c] != 7 && ckids[c].size() == 1 && is_link(cls[ckids[c][0]])) { c = ckids[c][0]; continue; }
                     break;
                 }
                 ch.diff = is_diff(c0);  // a differential is a chain of its own; its child clusters hang off link2
+                ch.gen = cls[c0] == 7;  // so is a generic cluster; its child clusters hang off any of its bodies
                 const int tipc = ch.cl.back();
                 const int id = static_cast<int>(chains.size());
                 chains.push_back(ch);
@@ -1255,6 +1341,19 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::function<void(int)> emit_fb = [&](int id) {
                 const Chain ch = chains[id];
                 cur_owner = owner_of[id];
+                if (ch.gen) {
+                    ChainSeg sg = ChainSeg();
+                    if (gen_of[ch.cl[0]].has_fwd) {
+                        sg.op = SEG_GEN_FWD;
+                        ct[id].fwd = push_seg(sg);
+                    }
+                    for (int k : ch.kid_chains) emit_fb(k);
+                    cur_owner = owner_of[id];
+                    sg.op = SEG_GEN_BWD;
+                    ct[id].bwd = push_seg(sg);
+                    if (ct[id].fwd < 0) ct[id].fwd = ct[id].bwd;
+                    return;
+                }
                 if (ch.diff) {
                     ChainSeg sg = ChainSeg();
                     sg.op = SEG_DIFF_FWD;
@@ -1288,8 +1387,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 const Chain ch = chains[id];
                 cur_owner = owner_of[id];
                 ChainSeg sg = ChainSeg();
-                if (ch.diff) {
-                    sg.op = SEG_DIFF_ACC;
+                if (ch.diff || ch.gen) {
+                    sg.op = ch.gen ? SEG_GEN_ACC : SEG_DIFF_ACC;
                     ct[id].acc = push_seg(sg);
                     for (int k : ch.kid_chains) emit_acc(k);
                     return;
@@ -1324,7 +1423,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 for (int c = 0; c < nc; c++)
                     if (cls[c] == 0) { n_free++; base = c; }
                 bool any_diff = false;
-                for (const Chain &ch : chains) any_diff = any_diff || ch.diff;
+                for (const Chain &ch : chains) any_diff = any_diff || ch.diff || ch.gen;
                 if (n_free != 1 || !ground_chains.empty() || any_diff || free_chains[base].size() < 2) {
                     ok = false;
                 } else {
@@ -1382,7 +1481,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             for (int id : ground_chains) emit_acc(id);
             // ---- the inverse-dynamics program on the same chains (plan.h, RneaChainProgram) ----
-            if (RP) {
+            bool any_gen = false;
+            for (const Chain &ch : chains) any_gen = any_gen || ch.gen;
+            if (RP) *RP = RneaChainProgram();
+            if (RP && !any_gen) {
                 RneaChainProgram &R = *RP;
                 R = RneaChainProgram();
                 std::vector<RneaLink> rl(nc);
@@ -1587,6 +1689,35 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     std::vector<Obj> &v; size_t from; int owner; int t_acc; bool on;
                     ~OwnerTag() { if (on) for (size_t i = from; i < v.size(); i++) { v[i].owner = owner; v[i].phase = v[i].birth / 2 >= t_acc ? 1 : 0; } }
                 } owner_tag{objs, o_begin, owner_of[id], t_acc_phase, lm};
+                if (ch.gen) {
+                    const int c = ch.cl[0];
+                    ChainGen &g = gen_of[c];
+                    std::vector<ChainGenBody> &gb = gbody_of[c];
+                    // (the forward segment's work area needs no in-cluster accumulators; the sizes are the same for simplicity)
+                    objs.push_back({&g.lds_w, gen_w_size[c], 0, B0(ct[id].bwd), D1(ct[id].bwd), -1, 1, 1});
+                    if (g.has_fwd) objs.push_back({&g.lds_wf, gen_w_size[c], 0, B0(ct[id].fwd), D1(ct[id].fwd), -1, 1, 1});
+                    std::vector<int> va_until(g.k, -1);
+                    for (int i = 0; i < g.k; i++) {
+                        const int body = clusters[c].first_body + i;
+                        int first_bwd = 1 << 30, last_acc = -1;
+                        for (int k : ch.kid_chains)
+                            if (clusters[chains[k].cl.front()].parent_body == body) {
+                                first_bwd = std::min(first_bwd, ct[k].bwd);
+                                last_acc = std::max(last_acc, ct[k].acc);
+                            }
+                        if (last_acc < 0) continue;
+                        objs.push_back({&gb[i].lds_acc, 27, 1, B0(first_bwd) + 1, B0(ct[id].bwd), -1, 1});
+                        objs.push_back({&gb[i].lds_v, 6, 0, B0(ct[id].fwd), D1(ct[id].bwd), -1, 1, 1});
+                        // (v, a) of the body and of its in-cluster ancestors, until the last child segment below them has started
+                        for (int j = i; j >= 0; j = gb[j].lam) va_until[j] = std::max(va_until[j], last_acc);
+                    }
+                    for (int i = 0; i < g.k; i++)
+                        if (va_until[i] >= 0) {
+                            objs.push_back({&gb[i].lds_va, 12, 0, B0(ct[id].acc), D1(va_until[i]), -1, 1});
+                            g.need_acc = 1;
+                        }
+                    continue;
+                }
                 if (ch.diff) {
                     ChainDiff &d = diff_of[ch.cl[0]];
                     if (diff_shape[ch.cl[0]].n_atoms > 0)
@@ -1660,7 +1791,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     int t_first = -1;
                     for (size_t t2 = 0; t2 < CP.segs.size(); t2++) {
                         const int op = CP.segs[t2].op;
-                        if (op == SEG_FREE_ACC || op == SEG_RUN_ACC || op == SEG_PAIR_ACC || op == SEG_DIFF_ACC) { t_first = static_cast<int>(t2); break; }
+                        if (op == SEG_FREE_ACC || op == SEG_RUN_ACC || op == SEG_PAIR_ACC || op == SEG_DIFF_ACC || op == SEG_GEN_ACC) { t_first = static_cast<int>(t2); break; }
                     }
                     const int nvr = P.nv;
                     if (t_first >= 0 && nvr > 0 && !std::getenv("GRBDA_NO_LDS_RESULTS")) {
@@ -1689,18 +1820,21 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
                     if (is_diff(c)) return diff_of[c].lds_sv + 2;
+                    if (cls[c] == 7) return gbody_of[c][b - clusters[c].first_body].lds_v;
                     return cls[c] == 0 ? free_of[c].lds_v : link_of[c].lds_sv + 2;  // (+2 keeps a kSlotGlobal flag intact)
                 };
                 auto va_slot_of_body = [&](int b) -> int {
                     if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
                     if (is_diff(c)) return diff_of[c].lds_va;
+                    if (cls[c] == 7) return gbody_of[c][b - clusters[c].first_body].lds_va;
                     return cls[c] == 0 ? free_of[c].lds_va : link_of[c].lds_va;
                 };
                 auto acc_slot_of_body = [&](int b, int owner = 0) -> int {
                     if (b < 0) return -1;
                     const int c = m.bodies[b].cluster;
                     if (is_diff(c)) return diff_of[c].lds_acc;
+                    if (cls[c] == 7) return gbody_of[c][b - clusters[c].first_body].lds_acc;
                     return cls[c] == 0 ? (lm && owner == 1 ? free_of[c].lds_acc2 : free_of[c].lds_acc) : acc_slot[c];
                 };
                 for (int c = 0; c < nc; c++) {
@@ -1708,6 +1842,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) link_of[c].lds_pv = v_slot_of_body(pb);
                     if (cls[c] == 3) { pair_of[c].lds_pv = v_slot_of_body(pb); pair_of[c].lds_pva = va_slot_of_body(pb); }
                     if (is_diff(c)) { diff_of[c].lds_pv = v_slot_of_body(pb); diff_of[c].lds_pva = va_slot_of_body(pb); diff_of[c].lds_acc_out = acc_slot_of_body(pb); }
+                    if (cls[c] == 7) {
+                        ChainGen &g = gen_of[c];
+                        g.lds_pv = v_slot_of_body(pb); g.lds_pva = va_slot_of_body(pb); g.lds_acc_out = acc_slot_of_body(pb);
+                        if (g.keep < -1) g.keep = g.lds_w + (-g.keep - 2);
+                        for (ChainGenBody &b : gbody_of[c]) b.pva = b.lam >= 0 ? gbody_of[c][b.lam].lds_va : -1;
+                    }
                 }
                 // first writer of every accumulator slot: the kid chain whose backward run comes first
                 for (const RunRef &r : runs) {
@@ -1720,7 +1860,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     const Chain &ch = chains[id];
                     ChainSeg &bw = CP.segs[ct[id].bwd];
                     const int tipc = ch.cl.back(), topc = ch.cl.front();
-                    if (ch.diff) bw.head = HEAD_LEAF;
+                    if (ch.diff || ch.gen) bw.head = HEAD_LEAF;
                     if (bw.head == HEAD_SLOT) bw.head_arg = acc_slot[tipc];
                     if (bw.head == HEAD_PAIR) { bw.head_arg = static_cast<int>(CP.pairs.size()); }
                     const int pb = clusters[topc].parent_body;
@@ -1728,13 +1868,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     // first writer: earliest backward run among the sibling chains
                     bool first = true;
                     if (pb >= 0) {
+                        // the sibling chains: those that hang off the same BODY (a generic cluster carries children on several)
                         const int pc = m.bodies[pb].cluster;
-                        int parent_chain = 0;
-                        for (size_t j = 0; j < chains.size(); j++)
-                            if (chains[j].cl.back() == pc) parent_chain = static_cast<int>(j);
-                        const std::vector<int> &sib = cls[pc] == 0 ? free_chains[pc] : chains[parent_chain].kid_chains;
-                        for (int o : sib)
-                            if (ct[o].bwd < ct[id].bwd && (!lm || cls[pc] != 0 || owner_of[o] == owner_of[id])) first = false;
+                        for (size_t o = 0; o < chains.size(); o++)
+                            if (o != id && clusters[chains[o].cl.front()].parent_body == pb && ct[o].bwd < ct[id].bwd &&
+                                (!lm || cls[pc] != 0 || owner_of[o] == owner_of[id]))
+                                first = false;
                     }
                     bw.acc_first = first ? 1 : 0;
                     ChainSeg &ac = CP.segs[ct[id].acc];
@@ -1743,6 +1882,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         diff_of[topc].acc_first = first ? 1 : 0;
                         CP.segs[ct[id].fwd].first = bw.first = ac.first = static_cast<int>(CP.diffs.size());
                         CP.diffs.push_back(diff_of[topc]);
+                    }
+                    if (ch.gen) {
+                        gen_of[topc].acc_first = first ? 1 : 0;
+                        gen_of[topc].first = static_cast<int>(CP.gbodies.size());
+                        CP.gbodies.insert(CP.gbodies.end(), gbody_of[topc].begin(), gbody_of[topc].end());
+                        CP.segs[ct[id].fwd].first = bw.first = ac.first = static_cast<int>(CP.gens.size());
+                        CP.gens.push_back(gen_of[topc]);
                     }
                     if (ch.pair >= 0) {
                         ChainSeg &pa = CP.segs[ct[id].pair_acc];
@@ -1759,12 +1905,16 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
         }
         CP.ok = ok;
-        if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); CP.diffs.clear(); }
+        if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); CP.diffs.clear(); CP.gens.clear(); CP.gbodies.clear(); }
     };
     // the RNEA chain kernels run 8 wavefronts per CU like the ABA ones: the ABA budgets apply
     build_chain(P.chain32, lds.aba32, &P.rchain32, lds.aba32);
     build_chain(P.chain32w, lds.chain32w, &P.rchain32w, lds.chain32w);
     build_chain(P.chain64, lds.aba64, &P.rchain64, lds.aba64);
+    // Generic clusters (plan.h, ChainGen) keep their work area in LDS: large ones get a program laid out for twice the LDS per
+    // wavefront (the launch then holds fewer wavefronts per CU, capi.cpp: still several times the interpreter's rate)
+    if (!P.chain32.ok) build_chain(P.chain32, 2 * lds.aba32, P.rchain32.ok ? nullptr : &P.rchain32, 2 * lds.aba32);
+    if (!P.chain64.ok) build_chain(P.chain64, 2 * lds.aba64, P.rchain64.ok ? nullptr : &P.rchain64, 2 * lds.aba64);
     // latency mode serves batches of at most one tile per SIMD, i.e. four tiles per CU: 40 KiB of LDS per tile
     build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2);
     build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);

@@ -166,7 +166,10 @@ enum ChainOp : int32_t {
     SEG_DIFF_FWD = 7,   // two-rotor differential cluster (ChainDiff): constraint Jacobian, G, g; velocity of its tip link
     SEG_DIFF_BWD = 8,
     SEG_DIFF_ACC = 9,
-    SEG_BARRIER = 10    // latency-mode programs (ChainProgram::n_waves > 1): every wavefront of the workgroup meets here
+    SEG_BARRIER = 10,   // latency-mode programs (ChainProgram::n_waves > 1): every wavefront of the workgroup meets here
+    SEG_GEN_FWD = 11,   // generic cluster (ChainGen): constraint Jacobian / G / g of an implicit cluster, velocities of its bodies
+    SEG_GEN_BWD = 12,   // ... articulated inertia / bias of its bodies, [K | y0], hand-over to the parent body
+    SEG_GEN_ACC = 13    // ... ydd; (v, a) of the bodies that carry child clusters
 };
 enum ChainHead : int32_t {
     HEAD_LEAF = 0,      // the first link of a backward run is a leaf: its accumulators start from its own inertia
@@ -230,6 +233,55 @@ struct ChainDiff {
     int32_t gofs;            // consts[]: G rows of the two rotors, (1, 0, 0, 1) for a differential
     int32_t reserved[7];
 };
+// ---------------------------------------------------------------------------------------------------------------
+// Generic cluster inside a chain program (chain_kernels.hip, gen_segments.h): k <= 8 revolute bodies in any in-cluster tree,
+// n <= 4 independent coordinates, and either a constant G (every explicit ClusterJoint type that has no segment type of
+// its own: RevoluteTripleWithRotor, Generic + LoopConstraint::Static, pairs and rotors in unusual places) or an implicit
+// constraint evaluated per state -- URDF+ position loops (ClusterTreeParsing.cpp:310-376: four-bar, six-bar, planar leg
+// linkage) and trig-polynomial phi that is not the two-rotor differential's shape (GenericJoint.cpp:57-90,387-469).
+// Child clusters may hang off ANY of its bodies.  One body of the cluster (16 ints):
+struct ChainGenBody {
+    int32_t cofs;       // Et[9] rt[3] I[21] (+ G row [n] for explicit clusters)
+    int32_t iofs;       // the 21 constants I + sum over axisymmetric leaf children X0^T I X0 (BodyRec::xofs or cofs + 12)
+    int32_t lam;        // in-cluster parent: index within the cluster, or -1 (the body hangs off the cluster's parent body)
+    int32_t axis;       // joint axis 0 / 1 / 2 (bodies of position-loop clusters keep the reference's frames)
+    int32_t axisym;     // axisymmetric leaf (rotor): evaluated at q = 0, X0^T I X0 is part of the parent's constants
+    int32_t carry_up;   // 1: lam is the body right before this one and (IA, psi) go up in registers
+    int32_t carry_in;   // 1: the body right behind this one hands its (IA, psi) up in registers
+    int32_t acc_w;      // work-area offset of the accumulator [IA 21][psi 6] in-cluster children without carry_up add into, or -1
+    int32_t up_w;       // (no carry_up, lam >= 0) work-area offset of lam's accumulator ...
+    int32_t up_first;   // ... and 1 when this body is its first writer
+    int32_t lds_acc;    // accumulator [IA 21][psi 6] the child CLUSTERS of this body add into (LDS / global slab), or -1
+    int32_t lds_va;     // acceleration sweep: [v 6][a 6] of this body (it or an in-cluster descendant carries child clusters), or -1
+    int32_t pva;        // acceleration sweep: lds_va of lam (lam >= 0)
+    int32_t ind_a;      // implicit clusters: this body carries independent coordinate ind_a (G row = unit vector, g = 0), or -1
+    int32_t dep_r;      // implicit clusters: this body is dependent coordinate dep_r (its [G row n][g][qd_span] is row dep_r of the kept block), or -1
+    int32_t lds_v;      // [v 6] of this body for the segments of its child clusters (forward segment -> backward segment), or -1
+};
+// the cluster (32 ints)
+struct ChainGen {
+    int32_t q_index, v_index;
+    int32_t k, n, rows;
+    int32_t kind;       // 0 explicit (constant G rows behind the bodies' constants), 1 URDF+ position loops, 2 trig-polynomial phi
+    int32_t first;      // gbodies[first .. first + k)
+    int32_t iofs, dofs; // implicit: constraint payload in cints[] / consts[] (ClusterRec::iofs / dofs)
+    int32_t lds_pv;     // velocity of the parent body, -1: ground
+    int32_t has_parent; // the cluster hangs off a body (0: off the ground -- nobody to hand the projected inertia to)
+    int32_t lds_acc_out, acc_first;  // accumulator of the parent body; 1: this segment is its first writer
+    int32_t lds_pva;    // acceleration sweep: [v 6][a 6] of the parent body, -1: ground
+    int32_t glb_k;      // [K 6 n][y0 n]
+    int32_t keep;       // implicit: per DEPENDENT body [G row n][g][qd_span], forward / backward segment -> acceleration segment (LDS inside
+                        // the work area for a cluster without child clusters, else the global slab)
+    int32_t lds_w;      // work area of the backward segment (LDS): [sin, cos] x k | [v 6] x k (the constraint evaluation's scratch
+                        // aliases it) | in-cluster accumulators | kept block of a childless implicit cluster
+    int32_t has_fwd;    // 1: a SEG_GEN_FWD segment exists (child clusters need the velocities): it evaluates the constraint (kept block in
+                        // the slab) and leaves the velocities of the bodies with child clusters in their lds_v; the backward segment
+                        // repeats the downward pass without the constraint -- no work area stays alive across the child segments
+    int32_t need_acc;   // 1: some body has lds_va >= 0
+    int32_t lds_wf;     // work area of the forward segment (has_fwd)
+    int32_t reserved[12];
+};
+
 // the same cluster in the inverse-dynamics program (20 ints)
 struct RneaDiff {
     int32_t q_index, v_index;
@@ -320,6 +372,8 @@ struct ChainProgram {
     std::vector<ChainPair> pairs;
     std::vector<ChainFree> frees;
     std::vector<ChainDiff> diffs;
+    std::vector<ChainGen> gens;
+    std::vector<ChainGenBody> gbodies;
     int n_lds = 0, n_glb = 0;        // slots
     int out_lds = -1;                // first of the nv LDS rows the acceleration sweep writes its results to (-1: slab rows)
     bool sv_global = false;          // the [sin, cos, v] blocks of the links live in the global slab (chains too long for LDS)

@@ -101,6 +101,7 @@ typedef struct {
     int analytic_derivatives;           /* grbda_fd_d* / grbda_fd_derivatives_* take the analytic route (deriv_kernels.hip) */
     int n_chain_differentials;          /* implicit two-rotor differential clusters inside the f32 chain program */
     int latency_mode_f32, latency_mode_f64; /* 1: batches of at most one tile per SIMD run a tile on two wavefronts (plan.h, ChainProgram::n_waves) */
+    int n_chain_generic;                /* generic clusters inside the f32 chain program (plan.h, ChainGen): URDF+ position loops, triple / Generic clusters */
 } grbda_plan_info_t;
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 

@@ -99,7 +99,7 @@ def test_chain_program_covers_the_headline_models():
     """The chain-structured fast path (plan.h, ChainProgram) must be what runs the floating-base robots made of
     revolute links, geared rotors and leaf pair clusters -- the BASELINE workloads mini_cheetah / mit_humanoid -- and
     the random models of the zoo that exercise its run / branch / pair / roll-pitch-yaw code -- and TelloWithArms, whose
-    implicit differentials are a segment type of their own; everything else stays on the general interpreter."""
+    implicit differentials are a segment type of their own; every other cluster type is a generic segment (ChainGen)."""
     z = zoo()
     for name in ("urdf_mini_cheetah", "urdf_mit_humanoid", "urdf_jvrc1_humanoid", "urdf_mini_cheetah_rpy", "tree_chain_rotor_float", "tree_chain_rev_float", "tree_rotor_float",
                  "chain_tree_a", "chain_tree_b", "chain_tree_rpy", "chain_tree_norotor", "tello_with_arms"):
@@ -119,5 +119,11 @@ def test_chain_program_covers_the_headline_models():
         assert info.chain_aba_f32 == 1 and info.chain_rnea_f32 == 1 and info.chain_aba_f64 == 1, name
     # (pairs in series -- the reference's RevolutePairChainWithRotor -- run through the differential's segments with constant G)
     assert G.Plan(z["rev_pair_rotor_chain_4"]).info().n_chain_differentials == 2
-    for name in ("urdf_four_bar", "tree_generic_float", "tree_triple_fixed"):
-        assert G.Plan(z[name]).info().chain_aba_f32 == 0, name
+    # generic clusters (plan.h, ChainGen): URDF+ position loops, RevoluteTripleWithRotor, Generic + Static clusters run inside
+    # chain programs too -- nothing of the zoo is left on the interpreter for the fp32 forward dynamics
+    for name in ("urdf_four_bar", "urdf_six_bar", "urdf_planar_leg_linkage", "teleop_arm", "tree_generic_float", "tree_triple_fixed",
+                 "tree_mixed_float", "tree_mixed_fixed", "rev_triple_rotor_chain_6"):
+        info = G.Plan(z[name]).info()
+        assert info.chain_aba_f32 == 1 and info.n_chain_generic >= 1, name
+    for name, blob in z.items():
+        assert G.Plan(blob).info().chain_aba_f32 == 1, name

@@ -120,6 +120,7 @@ def test_lds_budget_does_not_change_results(gpu, monkeypatch):
     blob = zoo()["tree_mixed_float"]
     q, qd, tau = valid_states(blob, 300, config_index=25)
     outs = []
+    monkeypatch.setenv("GRBDA_NO_CHAIN", "1")  # the interpreter's slot store is what has the two homes
     for lds in ("0", "4096", "65536"):
         monkeypatch.setenv("GRBDA_LDS_BYTES_PER_WAVE", lds)
         outs.append(run_gpu(G.Plan(blob), "aba", q, qd, tau, torch.float64, gpu))
