@@ -311,6 +311,35 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
 {
     const HostPlan &h = p->host;
     const size_t n_tiles0 = (B + kWave - 1) / kWave;
+    {   // single-cluster programs: the fused, slab-free kernel (chain_kernels.hip, aba_gen1_kernel)
+        const int w1 = sizeof(T) == 8 ? 2 : 0;
+        const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
+        const size_t work = static_cast<size_t>(sp.n_lds) * kWave * sizeof(T);
+        const size_t lds_total = work + 2 * static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);  // two input buffers
+        if (sp.ok && sp.single_gen && !p->chain_debug && lds_total <= 65536) {
+            ChainDev<T> d;
+            std::memset(&d, 0, sizeof d);
+            d.gens = t.chain_gens[w1];
+            d.gbodies = t.chain_gbodies[w1];
+            d.n_gens = 1;
+            d.cints = t.cints;
+            d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
+            d.nq = h.nq;
+            d.nv = h.nv;
+            d.ori_repr = h.ori_repr;
+            d.out_lds = -1;
+            d.lds_bytes = static_cast<int>(work);
+            for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+            size_t per_cu = static_cast<size_t>(gen1_waves_per_simd<T>(sp.gens[0].n)) * 4;
+            const size_t fit = (160u * 1024u) / lds_total;
+            if (fit < per_cu) per_cu = fit;
+            size_t grid = static_cast<size_t>(t.n_cu) * per_cu;
+            if (grid > n_tiles0) grid = n_tiles0;
+            hipError_t e = launch_aba_gen1<T>(d, sp.gens[0].n, sp.gens[0].kind != 0, q, qd, tau, ydd, B, static_cast<int>(grid), lds_total,
+                                              static_cast<hipStream_t>(stream));
+            return e == hipSuccess ? GRBDA_OK : hip_err(e, "aba single-cluster launch");
+        }
+    }
     // Latency mode: a batch of at most one tile per SIMD would leave every SIMD with a single wavefront; a tile then goes
     // to a workgroup of two wavefronts that split its limbs (chain_kernels.hip, aba_chain_lm_kernel).  GRBDA_NO_LATENCY_MODE=1
     // keeps the ordinary kernel (A/B runs); results agree to rounding (the base sums one partial inertia per wavefront).

@@ -1295,6 +1295,132 @@ __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem
 
 #include "gen_segments.h"
 
+#if GRBDA_CHAIN_UNIT == 2
+// ---------------------------------------------------------------------------------------------------------------
+// Single-cluster programs (ChainProgram::single_gen): ONE generic cluster on the ground and nothing else -- the URDF+ loop
+// mechanisms of BASELINE config 5 (four_bar.urdf, six_bar.urdf), a triple cluster on a bench.  The whole forward dynamics is the
+// cluster's downward pass, its upward pass and ydd = y0 - K a_root, so the kernel is specialised on (n, implicit?) at compile time
+// and touches no slab at all: the tile's inputs stay in LDS as the asynchronous copy left them (row-major [state][column] blocks,
+// every lane reads its own row), results go straight to the caller's array.  With 3-5 input columns per state the tile is bound by
+// the latency of its few dependent memory round trips, not by instructions: small register footprints (N = 1: four wavefronts
+// per SIMD) and no global round trip inside the tile are what count.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+struct ChainMemL : ChainMem<T> {
+    int in_q, in_qd, in_x;  // element offsets of the staged blocks in LDS
+    int ncq, ncv;
+    T *out_g;               // this lane's result row (nullptr: a lane beyond the batch)
+    __device__ __forceinline__ T q(int j) const { return reinterpret_cast<const T *>(grbda_smem)[in_q + this->lane * ncq + j]; }
+    __device__ __forceinline__ T qd(int j) const { return reinterpret_cast<const T *>(grbda_smem)[in_qd + this->lane * ncv + j]; }
+    __device__ __forceinline__ T x(int j) const { return reinterpret_cast<const T *>(grbda_smem)[in_x + this->lane * ncv + j]; }
+    __device__ __forceinline__ void put_f(int j, T v) const
+    {
+        if (out_g) out_g[j] = v;
+    }
+};
+
+template <class T, int N, bool LOOP, int WPS>
+__global__ __launch_bounds__(kWave, WPS) void aba_gen1_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
+                                                            const T *__restrict__ tau, T *__restrict__ ydd, size_t B)
+{
+    ChainTables<T> P;
+    P.segs = nullptr;
+    P.links = nullptr;
+    P.pairs = nullptr;
+    P.frees = nullptr;
+    P.diffs = nullptr;
+    P.gens = (cptr<ChainGen>)DP.gens;
+    P.gbodies = (cptr<ChainGenBody>)DP.gbodies;
+    P.cints = (cptr<int32_t>)DP.cints;
+    P.consts = (cptr<T>)DP.consts;
+    P.n_segs = 0;
+    P.nq = DP.nq;
+    P.nv = DP.nv;
+    P.ori_repr = DP.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
+    const ChainGen g = load_rec(P.gens);
+    const int lane = threadIdx.x;
+    ChainMemL<T> M;
+    M.lane = lane;
+    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
+    M.gmul = 1;
+    M.amask = ~0;
+    M.glb_u = nullptr;
+    M.in_q_u = M.in_qd_u = M.in_x_u = nullptr;
+    M.out_u = nullptr;
+    M.out_row = -1;
+    M.out_f = nullptr;
+    // LDS: [work area: DP.lds_bytes][2 x (q block | qd block | tau block)]: the next tile's inputs are copied while this one computes
+    const unsigned off0 = (unsigned)DP.lds_bytes;
+    const unsigned bq = (unsigned)(kWave * P.nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * P.nv) * (unsigned)sizeof(T);
+    const unsigned blk = bq + 2 * bv;
+    M.ncq = P.nq;
+    M.ncv = P.nv;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    auto issue = [&](size_t tile, unsigned off) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        stage_issue(q, tile, rows_valid, P.nq, off, lane);
+        stage_issue(qd, tile, rows_valid, P.nv, off + bq, lane);
+        stage_issue(tau, tile, rows_valid, P.nv, off + bq + bv, lane);
+    };
+    unsigned par = 0;
+    if ((size_t)blockIdx.x < n_tiles) issue(blockIdx.x, off0);
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_fence();  // this tile's inputs are in LDS; the previous tile's reads of the other buffer are done
+        const unsigned off = off0 + par * blk;
+        if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x, off0 + (par ^ 1u) * blk);
+        M.in_q = (int)(off / sizeof(T));
+        M.in_qd = (int)((off + bq) / sizeof(T));
+        M.in_x = (int)((off + bq + bv) / sizeof(T));
+        M.out_g = lane < rows_valid ? ydd + (tile * kWave + lane) * (size_t)P.nv : nullptr;
+        gen_down<T, N, LOOP>(P, M, g, g.lds_w, true, false);
+        gen_up<T, N, LOOP, true>(P, M, g);
+        par ^= 1u;
+    }
+}
+
+template <class T, int N, bool LOOP>
+static hipError_t launch_gen1(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, int grid, size_t lds_bytes,
+                              hipStream_t stream)
+{
+    // wavefronts per SIMD the register footprint allows (checked against the code object: no scratch)
+    constexpr int WPS = sizeof(T) == 4 ? (N <= 2 ? 3 : 2) : (N == 1 ? 2 : 1);
+    hipLaunchKernelGGL((aba_gen1_kernel<T, N, LOOP, WPS>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B);
+    return hipGetLastError();
+}
+template <class T>
+int gen1_waves_per_simd(int n)
+{
+    return sizeof(T) == 4 ? (n <= 2 ? 3 : 2) : (n == 1 ? 2 : 1);
+}
+template int gen1_waves_per_simd<float>(int);
+template int gen1_waves_per_simd<double>(int);
+template <class T>
+hipError_t launch_aba_gen1(const ChainDev<T> &P, int n, int implicit, const T *q, const T *qd, const T *tau, T *ydd, size_t B, int grid,
+                           size_t lds_bytes, hipStream_t stream)
+{
+    if (implicit) {
+        if (n == 1) return launch_gen1<T, 1, true>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+        if (n == 2) return launch_gen1<T, 2, true>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+        if (n == 3) return launch_gen1<T, 3, true>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+        return launch_gen1<T, 4, true>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+    }
+    if (n == 1) return launch_gen1<T, 1, false>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+    if (n == 2) return launch_gen1<T, 2, false>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+    if (n == 3) return launch_gen1<T, 3, false>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+    return launch_gen1<T, 4, false>(P, q, qd, tau, ydd, B, grid, lds_bytes, stream);
+}
+template hipError_t launch_aba_gen1<float>(const ChainDev<float> &, int, int, const float *, const float *, const float *, float *, size_t, int,
+                                           size_t, hipStream_t);
+template hipError_t launch_aba_gen1<double>(const ChainDev<double> &, int, int, const double *, const double *, const double *, double *,
+                                            size_t, int, size_t, hipStream_t);
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // MODE 1: the program has differential clusters (ChainDiff).  A kernel variant of its own, so that the models without them
 // (every URDF robot of the reference) keep the register allocation of the plain run / pair / free code.  MODE 2: the program
@@ -2485,7 +2611,7 @@ hipError_t set_max_dynamic_lds_chain_unit2()
 {
     const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, 2>),
                                    reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 2>)};
-    return set_max_dynamic_lds(kernels, 2);
+    return set_max_dynamic_lds(kernels, 2);  // (the single-cluster kernels stay below the 64 KiB default: capi.cpp)
 }
 #endif
 

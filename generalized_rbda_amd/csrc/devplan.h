@@ -87,6 +87,13 @@ template <class T>
 hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                                size_t lds_bytes, hipStream_t stream);
 hipError_t set_max_dynamic_lds_chain();
+// single-cluster programs (ChainProgram::single_gen; chain_kernels.hip, aba_gen1_kernel): P.lds_bytes = the work area, lds_bytes = work
+// area + two sets of the three staged input blocks
+template <class T>
+hipError_t launch_aba_gen1(const ChainDev<T> &P, int n, int implicit, const T *q, const T *qd, const T *tau, T *ydd, size_t B, int grid,
+                           size_t lds_bytes, hipStream_t stream);
+template <class T>
+int gen1_waves_per_simd(int n);
 
 template <class T>
 struct RneaChainDev {

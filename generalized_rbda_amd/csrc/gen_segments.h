@@ -63,35 +63,53 @@ __device__ __forceinline__ void gen_inv_small(int R, const T (&A)[3][3], T (&Ai)
 }
 
 // single LDS slot
-template <class T>
-__device__ __forceinline__ T gen_ld1(const ChainMem<T> &M, int s)
+template <class T, class MM>
+__device__ __forceinline__ T gen_ld1(const MM &M, int s)
 {
     return reinterpret_cast<const T *>(grbda_smem)[s * kWave + M.lane];
 }
-template <class T>
-__device__ __forceinline__ void gen_st1(const ChainMem<T> &M, int s, T v)
+template <class T, class MM>
+__device__ __forceinline__ void gen_st1(const MM &M, int s, T v)
 {
     reinterpret_cast<T *>(grbda_smem)[s * kWave + M.lane] = v;
 }
 
 // sin / cos of a joint angle of an implicit cluster.  The hardware approximations (devmath.h, sincos_t) unless
 // GRBDA_GEN_PRECISE: K and the body transforms use the SAME values, so phi's Jacobian is consistent with the kinematics.
-template <class T>
-__device__ __forceinline__ void gen_sincos(T x, T *s, T *c)
+// f32: Cody-Waite reduction to [-pi/4, pi/4] (two fused steps) and the cephes minimax polynomials, ~25 instructions and ~1 ulp
+// for |x| < 1e4 -- the hardware v_sin_f32 / v_cos_f32 behind sincos_t are ten times less accurate (|x| 6e-8 from the 1 / 2 pi scaling
+// alone) and Kd^-1 amplifies that by the constraint's condition number; the library's sincosf costs ~155 instructions.
+__device__ __forceinline__ void gen_sincos(float x, float *s, float *c)
 {
 #ifdef GRBDA_GEN_PRECISE
     sincos_precise(x, s, c);
-#else
+#elif defined(GRBDA_GEN_HW_SINCOS)
     sincos_t(x, s, c);
+#else
+    const float k = __builtin_rintf(x * 0.636619772f);
+    float r = __builtin_fmaf(-k, 1.57079637f, x);
+    r = __builtin_fmaf(-k, -4.37113883e-8f, r);
+    const float z = r * r;
+    float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(z, sp, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(r * z, sp, r);
+    float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int n = (int)k;
+    const float a = (n & 1) ? cs : sn, b = (n & 1) ? sn : cs;
+    *s = (n & 2) ? -a : a;
+    *c = ((n + 1) & 2) ? -b : b;
 #endif
 }
+__device__ __forceinline__ void gen_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // URDF+ position loops.  Scratch (LDS slots from `scr`): K [rows x k] | per loop side: [a 3][o 3] per joint of its path
 // (axis and origin in the coordinates of the nearest common ancestor), then the constraint point [p 3].
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
-__device__ __forceinline__ void gen_loop_K(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g, int sc0, int scr,
+template <class T, class MM>
+__device__ __forceinline__ void gen_loop_K(const ChainTables<T> &P, const MM &M, const ChainGen &g, int sc0, int scr,
                                            cptr<int32_t> loops, int n_loops)
 {
     const int k = g.k;
@@ -111,7 +129,7 @@ __device__ __forceinline__ void gen_loop_K(const ChainTables<T> &P, const ChainM
                 cptr<T> C = P.consts + b.cofs;
                 T sc[2], Eb[9], En[9];
                 M.lds_ld(sc0 + 2 * sub, sc);
-                build_E(b.axis, sc[0], sc[1], C, Eb);
+                rotate_z(sc[0], sc[1], C, Eb);
                 // X_new = (Eb, r_tree) * (E, r):  E_new = Eb E,  r_new = r + E^T r_tree
 #pragma unroll
                 for (int i = 0; i < 3; i++) r[i] += E[i] * C[9] + E[3 + i] * C[10] + E[6 + i] * C[11];
@@ -121,11 +139,7 @@ __device__ __forceinline__ void gen_loop_K(const ChainTables<T> &P, const ChainM
                     for (int j = 0; j < 3; j++) En[3 * i + j] = Eb[3 * i] * E[j] + Eb[3 * i + 1] * E[3 + j] + Eb[3 * i + 2] * E[6 + j];
 #pragma unroll
                 for (int i = 0; i < 9; i++) E[i] = En[i];
-                T ao[6];
-                if (b.axis == 0) { ao[0] = E[0]; ao[1] = E[1]; ao[2] = E[2]; }
-                else if (b.axis == 1) { ao[0] = E[3]; ao[1] = E[4]; ao[2] = E[5]; }
-                else { ao[0] = E[6]; ao[1] = E[7]; ao[2] = E[8]; }
-                ao[3] = r[0]; ao[4] = r[1]; ao[5] = r[2];
+                const T ao[6] = {E[6], E[7], E[8], r[0], r[1], r[2]};  // the joint axis is the body's z axis (canonical joint axes, plan.cpp)
                 M.lds_st(rec + 6 * t, ao);
             }
             T p[3];
@@ -157,8 +171,8 @@ __device__ __forceinline__ void gen_loop_K(const ChainTables<T> &P, const ChainM
 }
 
 // velocity-product acceleration of the constraint points, (Kdot qd)[row]; qd0: the k spanning rates (LDS scratch)
-template <class T>
-__device__ __forceinline__ void gen_loop_Kdqd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g, int scr, int qd0,
+template <class T, class MM>
+__device__ __forceinline__ void gen_loop_Kdqd(const ChainTables<T> &P, const MM &M, const ChainGen &g, int scr, int qd0,
                                               cptr<int32_t> loops, int n_loops, T (&kdq)[3])
 {
     const int k = g.k;
@@ -225,8 +239,8 @@ __device__ __forceinline__ void gen_loop_Kdqd(const ChainTables<T> &P, const Cha
 // [per distinct argument w[k], b][per term coef]).  Scratch: K [rows x k] | per argument [a, sin a, cos a, w . qd_span].
 // want_K: rows of K to the scratch; otherwise the second directional derivative along qd_span goes to kdq.
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
-__device__ __forceinline__ void gen_trig_eval(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g, int scr, int qd0,
+template <class T, class MM>
+__device__ __forceinline__ void gen_trig_eval(const ChainTables<T> &P, const MM &M, const ChainGen &g, int scr, int qd0,
                                               cptr<int32_t> prog, bool want_K, T (&kdq)[3])
 {
     const int k = g.k;
@@ -243,7 +257,7 @@ __device__ __forceinline__ void gen_trig_eval(const ChainTables<T> &P, const Cha
             if (want_K) {
                 qv[j] = M.q(g.q_index + j);
             } else {
-                qv[j] = gen_ld1(M, qd0 + j);
+                qv[j] = gen_ld1<T>(M, qd0 + j);
             }
         }
     }
@@ -329,8 +343,8 @@ __device__ __forceinline__ void gen_trig_eval(const ChainTables<T> &P, const Cha
 
 // G rows, g and the spanning rates of the DEPENDENT bodies of an implicit cluster into the kept block: row r = [G row N][g][qd_span]
 // of dependent coordinate r (an independent body's row of G is a unit vector, its g is 0 and its rate is yd: gen_coupling)
-template <class T, int N>
-__device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g, int sc0, int scr,
+template <class T, int N, class MM>
+__device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const MM &M, const ChainGen &g, int sc0, int scr,
                                                const T (&yd)[N])
 {
     constexpr int ks = N + 2;
@@ -350,7 +364,7 @@ __device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const Ch
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) Kd[r][j] = (r < rows && j < rows) ? gen_ld1(M, scr + r * k + dep[j]) : T(r == j);
+        for (int j = 0; j < 3; j++) Kd[r][j] = (r < rows && j < rows) ? gen_ld1<T>(M, scr + r * k + dep[j]) : T(r == j);
     gen_inv_small(rows, Kd, Kdi);
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -359,7 +373,7 @@ __device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const Ch
             T s = 0;
 #pragma unroll
             for (int j = 0; j < 3; j++)
-                if (r < rows && j < rows) s += Kdi[r][j] * gen_ld1(M, scr + j * k + ind[a]);
+                if (r < rows && j < rows) s += Kdi[r][j] * gen_ld1<T>(M, scr + j * k + ind[a]);
             X[r][a] = s;
         }
     // the spanning rates of all k bodies take the place of K's first row (K is not needed any more)
@@ -392,8 +406,8 @@ __device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const Ch
 }
 
 // coupling of a body: G row (registers), g_i, qd_i
-template <class T, int N, bool LOOP>
-__device__ __forceinline__ void gen_coupling(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g, const ChainGenBody &b,
+template <class T, int N, bool LOOP, class MM>
+__device__ __forceinline__ void gen_coupling(const ChainTables<T> &P, const MM &M, const ChainGen &g, const ChainGenBody &b,
                                              cptr<T> C, const T (&yd)[N], T (&Gr)[N], T &gi, T &qdi)
 {
     if constexpr (LOOP) {
@@ -432,8 +446,8 @@ __device__ __forceinline__ void gen_coupling(const ChainTables<T> &P, const Chai
 // ---------------------------------------------------------------------------------------------------------------
 // w: work area; constraint: evaluate it (else the kept block is valid already); publish: velocities of the bodies with child clusters
 // to their lds_v
-template <class T, int N, bool LOOP>
-__device__ __forceinline__ void gen_down(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g, int w, bool constraint, bool publish)
+template <class T, int N, bool LOOP, class MM>
+__device__ __forceinline__ void gen_down(const ChainTables<T> &P, const MM &M, const ChainGen &g, int w, bool constraint, bool publish)
 {
     const int k = g.k;
     const int sc0 = w, v0 = w + 2 * k;
@@ -477,7 +491,7 @@ __device__ __forceinline__ void gen_down(const ChainTables<T> &P, const ChainMem
         T Gr[N], gi, qdi, sc[2], E[9], v[6];
         gen_coupling<T, N, LOOP>(P, M, g, b, C, yd, Gr, gi, qdi);
         M.lds_ld(sc0 + 2 * i, sc);
-        build_E(b.axis, sc[0], sc[1], C, E);
+        rotate_z(sc[0], sc[1], C, E);
         if (b.lam >= 0) {
             T vl[6];
             M.lds_ld(v0 + 6 * b.lam, vl);
@@ -485,7 +499,7 @@ __device__ __forceinline__ void gen_down(const ChainTables<T> &P, const ChainMem
         } else {
             xmotion(E, C + 9, vp, v);
         }
-        add_axis(v, b.axis, qdi);
+        v[2] += qdi;
         M.lds_st(v0 + 6 * i, v);
         if (publish && b.lds_v != -1) M.acc_st(b.lds_v, v);
     }
@@ -494,8 +508,10 @@ __device__ __forceinline__ void gen_down(const ChainTables<T> &P, const ChainMem
 // ---------------------------------------------------------------------------------------------------------------
 // upward pass: updateArticulatedBodies + bias back-propagation (ClusterTreeDynamics.cpp:94-129,157-191) of one cluster
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP>
-__device__ __forceinline__ void gen_up(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g)
+// FUSE: the cluster hangs off the ground and has no child clusters (single-cluster programs, aba_gen1_kernel): the acceleration
+// pass is two lines -- ydd = y0 - K a_root goes straight to the results, no [K | y0] block leaves the registers
+template <class T, int N, bool LOOP, bool FUSE, class MM>
+__device__ __forceinline__ void gen_up(const ChainTables<T> &P, const MM &M, const ChainGen &g)
 {
     const int k = g.k;
     const int sc0 = g.lds_w, v0 = g.lds_w + 2 * k;
@@ -523,9 +539,9 @@ __device__ __forceinline__ void gen_up(const ChainTables<T> &P, const ChainMem<T
         gen_coupling<T, N, LOOP>(P, M, g, b, C, yd, G, gi, qdi);
         M.lds_ld(sc0 + 2 * i, sc);
         M.lds_ld(v0 + 6 * i, v);
-        build_E(b.axis, sc[0], sc[1], C, E);
-        vxaxis(b.axis, v, qdi, chat);
-        add_axis(chat, b.axis, gi);  // S_implicit g (GenericJoint.cpp:449-450)
+        rotate_z(sc[0], sc[1], C, E);
+        vxz(v, qdi, chat);
+        chat[2] += gi;  // S_implicit g (GenericJoint.cpp:449-450)
 
         T IA[21], psi[6];
         bias_force(Ic, v, psi);  // pA = v x* (I v), ClusterTreeDynamics.cpp:95-98
@@ -555,9 +571,10 @@ __device__ __forceinline__ void gen_up(const ChainTables<T> &P, const ChainMem<T
             for (int j = 0; j < 6; j++) psi[j] += acc[21 + j];
         }
         T h[6];
-        column(IA, b.axis, h);
-        const T d = pick(h, b.axis);
-        T bj = pick(psi, b.axis);
+        #pragma unroll
+        for (int j = 0; j < 6; j++) h[j] = IA[sidx(j, 2)];
+        const T d = h[2];
+        T bj = psi[2];
 #pragma unroll
         for (int j = 0; j < 6; j++) bj += h[j] * chat[j];
 
@@ -615,16 +632,16 @@ __device__ __forceinline__ void gen_up(const ChainTables<T> &P, const ChainMem<T
             gen_coupling<T, N, LOOP>(P, M, g, bl, Cl, yd, Gl, gl, qdl);
             M.lds_ld(sc0 + 2 * l, scl);
             M.lds_ld(v0 + 6 * l, vl);
-            vxaxis(bl.axis, vl, qdl, cl);
-            add_axis(cl, bl.axis, gl);
+            vxz(vl, qdl, cl);
+            cl[2] += gl;
 #pragma unroll
             for (int j = 0; j < 6; j++) bj += f[j] * cl[j];
-            const T Hc = pick(f, bl.axis);
+            const T Hc = f[2];
 #pragma unroll
             for (int a = 0; a < N; a++)
 #pragma unroll
                 for (int bb = 0; bb < N; bb++) D[a][bb] += Hc * (Gl[a] * G[bb] + G[a] * Gl[bb]);
-            build_E(bl.axis, scl[0], scl[1], Cl, El);
+            rotate_z(scl[0], scl[1], Cl, El);
             xforce_inv(El, Cl + 9, f, f2);
 #pragma unroll
             for (int j = 0; j < 6; j++) f[j] = f2[j];
@@ -654,7 +671,18 @@ __device__ __forceinline__ void gen_up(const ChainTables<T> &P, const ChainMem<T
     }
 #pragma unroll
     for (int a = 0; a < N; a++) blk[6 * N + a] = u[a];
-    M.glb_st(g.glb_k, blk);
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            T ydd = u[a];
+#pragma unroll
+            for (int r = 0; r < 6; r++) ydd -= blk[a * 6 + r] * P.a_root[r];
+            M.put_f(g.v_index + a, ydd);
+        }
+        return;
+    } else {
+        M.glb_st(g.glb_k, blk);
+    }
 
     // the parent body receives sum X^T IA X - F D^-1 F^T and sum X^T (pA + IA c) + F D^-1 u'
     if (g.lds_acc_out != -1) {
@@ -686,8 +714,8 @@ __device__ __forceinline__ void gen_up(const ChainTables<T> &P, const ChainMem<T
 // ---------------------------------------------------------------------------------------------------------------
 // acceleration pass (ClusterTreeDynamics.cpp:131-152): ydd = y0 - K a_p; (v, a) of the bodies child clusters hang off
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP>
-__device__ __forceinline__ void gen_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g)
+template <class T, int N, bool LOOP, class MM>
+__device__ __forceinline__ void gen_acc(const ChainTables<T> &P, const MM &M, const ChainGen &g)
 {
     T blk[7 * N], vp[6], ap[6], ydd[N];
     M.glb_ld(g.glb_k, blk);
@@ -737,7 +765,7 @@ __device__ __forceinline__ void gen_acc(const ChainTables<T> &P, const ChainMem<
         T sc[2], E[9], v[6], a6[6], chat[6];
         if constexpr (LOOP) gen_sincos(qi, &sc[0], &sc[1]);
         else sincos_t(qi, &sc[0], &sc[1]);
-        build_E(b.axis, sc[0], sc[1], C, E);
+        rotate_z(sc[0], sc[1], C, E);
         if (b.lam >= 0) {
             T va[12], vl[6], al[6];
             M.lds_ld(b.pva, va);
@@ -752,14 +780,14 @@ __device__ __forceinline__ void gen_acc(const ChainTables<T> &P, const ChainMem<
             xmotion(E, C + 9, vp, v);
             xmotion(E, C + 9, ap, a6);
         }
-        add_axis(v, b.axis, qdi);
-        vxaxis(b.axis, v, qdi, chat);
+        v[2] += qdi;
+        vxz(v, qdi, chat);
 #pragma unroll
         for (int j = 0; j < 6; j++) a6[j] += chat[j];
         T qddi = gi;
 #pragma unroll
         for (int a = 0; a < N; a++) qddi += G[a] * ydd[a];
-        add_axis(a6, b.axis, qddi);
+        a6[2] += qddi;
         T out[12];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -771,20 +799,20 @@ __device__ __forceinline__ void gen_acc(const ChainTables<T> &P, const ChainMem<
 }
 
 // OP: 0 forward segment, 1 backward segment, 2 acceleration segment
-template <class T, int N, bool LOOP, int OP>
-__device__ __forceinline__ void gen_run(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g)
+template <class T, int N, bool LOOP, int OP, class MM>
+__device__ __forceinline__ void gen_run(const ChainTables<T> &P, const MM &M, const ChainGen &g)
 {
     if constexpr (OP == 0) {
         gen_down<T, N, LOOP>(P, M, g, g.lds_wf, true, true);
     } else if constexpr (OP == 1) {
         gen_down<T, N, LOOP>(P, M, g, g.lds_w, !g.has_fwd, false);
-        gen_up<T, N, LOOP>(P, M, g);
+        gen_up<T, N, LOOP, false>(P, M, g);
     } else {
         gen_acc<T, N, LOOP>(P, M, g);
     }
 }
-template <class T, int OP>
-__device__ __forceinline__ void gen_segment(const ChainTables<T> &P, const ChainMem<T> &M, const ChainGen &g)
+template <class T, int OP, class MM>
+__device__ __forceinline__ void gen_segment(const ChainTables<T> &P, const MM &M, const ChainGen &g)
 {
     if (g.kind) {
         if (g.n == 1) gen_run<T, 1, true, OP>(P, M, g);

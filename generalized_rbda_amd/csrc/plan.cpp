@@ -186,7 +186,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
 
     // ---- canonical joint axes -------------------------------------------------------------------
     // The model is re-expressed so that every revolute joint turns about the z axis of its body frame
-    // (bodies of URDF+ position-loop clusters excepted: their loop origins are given in link frames): body i's coordinates are rotated by the cyclic permutation Rc_i that maps its
+    // (bodies of URDF+ position-loop clusters included since round 4: their loop origins -- points of the link frames -- and the axis
+    // masks of their constraint rows -- axes of the nearest common ancestor -- are rotated with the frames where the loop
+    // payload is emitted below): body i's coordinates are rotated by the cyclic permutation Rc_i that maps its
     // joint axis onto z (v_new = Rc_i v_old).  Then R_a(q) E_tree becomes R_z(q) (Rc_i E_tree Rc_p^T),
     // the tree offset r (parent coordinates) becomes Rc_p r and the spatial inertia D I D^T with
     // D = blockdiag(Rc_i, Rc_i).  Joint coordinates, torques and accelerations are unchanged, and
@@ -194,6 +196,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     // The fast kernels and the straight-line handlers rely on it (kernels.hip, load_body): the joint axis
     // is a constant there.
     std::vector<grbda_desc_body> canon;
+    std::vector<std::array<double, 9>> Rc(nb);
+    std::vector<int> canon_shift(nb, 0);  // v_new[i] = v_old[(i + shift) % 3]
     {
         canon.assign(m.bodies, m.bodies + nb);
         auto perm = [](int axis, double R[9]) {
@@ -202,11 +206,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             else if (axis == 1) { R[0 * 3 + 2] = 1; R[1 * 3 + 0] = 1; R[2 * 3 + 1] = 1; }   // y -> z
             else { R[0] = R[4] = R[8] = 1; }
         };
-        std::vector<std::array<double, 9>> Rc(nb);
         for (int b = 0; b < nb; b++) {
-            const ClusterRec &bc = clusters[m.bodies[b].cluster];
-            const bool keep = m.bodies[b].joint_type != GRBDA_JOINT_REVOLUTE || (bc.kind == CK_LOOP && bc.cons_type == 0);
+            const bool keep = m.bodies[b].joint_type != GRBDA_JOINT_REVOLUTE;
             perm(keep ? 2 : m.bodies[b].axis, Rc[b].data());
+            canon_shift[b] = keep ? 0 : (m.bodies[b].axis == 0 ? 1 : (m.bodies[b].axis == 1 ? 2 : 0));
         }
         for (int b = 0; b < nb; b++) {
             grbda_desc_body &bd = canon[b];
@@ -241,9 +244,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             I[(3 * bi + i) * 6 + 3 * bj + j] = sacc;
                         }
             std::memcpy(bd.inertia, I, sizeof I);
-            const ClusterRec &bc = clusters[bd.cluster];
             bodies[b].canon_axis = 2;
-            if (bd.joint_type == GRBDA_JOINT_REVOLUTE && !(bc.kind == CK_LOOP && bc.cons_type == 0)) {
+            if (bd.joint_type == GRBDA_JOINT_REVOLUTE) {
                 bodies[b].canon_axis = bd.axis;
                 bd.axis = 2;
                 bodies[b].axis = 2;
@@ -369,7 +371,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         for (int b = 0; b < nb; b++) {
             const grbda_desc_body &bd = m.bodies[b];
             if (bodies[b].has_child || bd.joint_type != GRBDA_JOINT_REVOLUTE) continue;
-            // (URDF+ position-loop clusters keep their bodies as they are: the loop origins are points of the link frames)
+            // (bodies of URDF+ position-loop clusters are always evaluated at their own angle: they carry constraint points)
             if (clusters[bd.cluster].kind == CK_LOOP && clusters[bd.cluster].cons_type == 0) continue;
             bool inv = true;
             double scale = 0;
@@ -536,10 +538,32 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     const int sub = lp[t < np ? 1 + t : 2 + t];
                     if (sub < 0 || sub >= k) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop chain names body %d", c, sub);
                 }
-                for (int t = 0; t < 3 + np + ns; t++) P.cints.push_back(lp[t]);
+                // canonical joint axes: the constraint rows are components along the axes of the nearest common ancestor (the tree
+                // parent of the first joint of either sub-chain, or the ground), the origins are points of the predecessor / successor
+                // link (the last body of each sub-chain, or the ancestor itself when the sub-chain is empty)
+                const int fb = cl.first_body;
+                const int nca = np > 0 ? canon[fb + lp[1]].parent : (ns > 0 ? canon[fb + lp[2 + np]].parent : -1);
+                const int sh = nca >= 0 ? canon_shift[nca] : 0;
+                int mask2 = 0;
+                for (int i = 0; i < 3; i++)
+                    if ((mask >> ((i + sh) % 3)) & 1) mask2 |= 1 << i;
+                for (int t = 0; t < 2 + np + ns; t++) P.cints.push_back(lp[t]);
+                P.cints.push_back(mask2);
+                const int link[2] = {np > 0 ? fb + lp[np] : nca, ns > 0 ? fb + lp[1 + np + ns] : nca};
                 lp += 3 + np + ns;
                 for (int a = 0; a < 3; a++) rows += (mask >> a) & 1;
-                for (int t = 0; t < 24; t++) P.consts.push_back(dp[24 * l + t]);
+                for (int side = 0; side < 2; side++) {
+                    const double *o = dp + 24 * l + 12 * side;
+                    double Ri[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                    if (link[side] >= 0) std::memcpy(Ri, Rc[link[side]].data(), sizeof Ri);
+                    for (int i = 0; i < 3; i++)
+                        for (int j = 0; j < 3; j++) {  // E_new = E Ri^T
+                            double acc2 = 0;
+                            for (int k2 = 0; k2 < 3; k2++) acc2 += o[3 * i + k2] * Ri[3 * j + k2];
+                            P.consts.push_back(acc2);
+                        }
+                    for (int i = 0; i < 3; i++) P.consts.push_back(Ri[3 * i] * o[9] + Ri[3 * i + 1] * o[10] + Ri[3 * i + 2] * o[11]);
+                }
             }
             if (rows != cl.n_constraint_rows) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop rows mismatch", c);
         }
@@ -1905,6 +1929,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
         }
         CP.ok = ok;
+        CP.single_gen = ok && CP.gens.size() == 1 && CP.segs.size() == 2 && CP.links.empty() && CP.pairs.empty() && CP.frees.empty() &&
+                        CP.diffs.empty() && !CP.gens[0].has_parent && !std::getenv("GRBDA_NO_GEN1");
         if (!ok) { CP.segs.clear(); CP.links.clear(); CP.pairs.clear(); CP.frees.clear(); CP.diffs.clear(); CP.gens.clear(); CP.gbodies.clear(); }
     };
     // the RNEA chain kernels run 8 wavefronts per CU like the ABA ones: the ABA budgets apply

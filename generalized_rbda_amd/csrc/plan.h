@@ -244,7 +244,7 @@ struct ChainGenBody {
     int32_t cofs;       // Et[9] rt[3] I[21] (+ G row [n] for explicit clusters)
     int32_t iofs;       // the 21 constants I + sum over axisymmetric leaf children X0^T I X0 (BodyRec::xofs or cofs + 12)
     int32_t lam;        // in-cluster parent: index within the cluster, or -1 (the body hangs off the cluster's parent body)
-    int32_t axis;       // joint axis 0 / 1 / 2 (bodies of position-loop clusters keep the reference's frames)
+    int32_t axis;       // joint axis: always 2 (canonical joint axes, plan.cpp); kept for the record
     int32_t axisym;     // axisymmetric leaf (rotor): evaluated at q = 0, X0^T I X0 is part of the parent's constants
     int32_t carry_up;   // 1: lam is the body right before this one and (IA, psi) go up in registers
     int32_t carry_in;   // 1: the body right behind this one hands its (IA, psi) up in registers
@@ -374,6 +374,7 @@ struct ChainProgram {
     std::vector<ChainDiff> diffs;
     std::vector<ChainGen> gens;
     std::vector<ChainGenBody> gbodies;
+    bool single_gen = false;         // the whole model is ONE generic cluster on the ground: aba_gen1_kernel (no slab, fused sweeps)
     int n_lds = 0, n_glb = 0;        // slots
     int out_lds = -1;                // first of the nv LDS rows the acceleration sweep writes its results to (-1: slab rows)
     bool sv_global = false;          // the [sin, cos, v] blocks of the links live in the global slab (chains too long for LDS)
