@@ -38,6 +38,9 @@ $(OBJ)/crba_kernels.o: $(CSRC)/crba_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h
 $(OBJ)/deriv_kernels.o: $(CSRC)/deriv_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
+$(OBJ)/manifold_kernels.o: $(CSRC)/manifold_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
 $(OBJ)/capi.o: $(CSRC)/capi.cpp $(CSRC)/plan.h $(CSRC)/devplan.h include/grbda_hip.h include/grbda_model_desc.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
@@ -54,13 +57,13 @@ VARIANT ?= v
 VFLAGS ?=
 U1FLAGS ?=
 U2FLAGS ?=
-variant: $(OBJ)/chain_kernels_u2.o $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+variant: $(OBJ)/chain_kernels_u2.o $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	@mkdir -p build/variants
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_$(VARIANT).o
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -DGRBDA_CHAIN_UNIT=1 $(U1FLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_u1_$(VARIANT).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/libgrbda_hip_$(VARIANT).so build/variants/chain_kernels_$(VARIANT).o build/variants/chain_kernels_u1_$(VARIANT).o $^
 
-$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 oracle:
@@ -75,25 +78,25 @@ clean:
 .PHONY: all oracle ref clean
 
 # profiling variant with in-kernel cycle accounting (tools/prof_run.py); not part of `all`
-prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
+prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o
 	@mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -DGRBDA_PROFILE -c $(CSRC)/kernels.hip -o build/prof/kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/libgrbda_hip_prof.so build/prof/kernels.o $^
 
 # experiment builds: make exp NAME=foo DEFS="-DGRBDA_EXP_FOO" -> build/exp/libgrbda_foo.so
-exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o
+exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/kernels.hip -o build/exp/kernels_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/kernels_$(NAME).o $^
 
 # experiment builds of the derivative kernels: make expd NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expd: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expd: $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/deriv_kernels.hip -o build/exp/deriv_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/deriv_$(NAME).o $^
 
 # experiment builds of the chain kernels: make expc NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expc: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/deriv_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expc: $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/deriv_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(DEFS) -c $(CSRC)/chain_kernels.hip -o build/exp/chain_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/chain_$(NAME).o $^

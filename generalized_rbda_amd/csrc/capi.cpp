@@ -62,6 +62,7 @@ struct DeviceTables {
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
+    int32_t *span_q = nullptr, *span_v = nullptr, *crow = nullptr;  // grbda_plan::span_q / span_v / crow
     // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w)
     RneaSeg *rchain_segs[3] = {nullptr, nullptr, nullptr};
     RneaLink *rchain_links[3] = {nullptr, nullptr, nullptr};
@@ -129,6 +130,14 @@ struct grbda_plan {
     int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 3)
     bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
+    // Models with implicit clusters: the spanning-tree model as a plan of its own (plan.cpp, make_spanning_blob) -- the analytic
+    // derivatives and the mass matrix are taken on it and projected with the per-state G (manifold_kernels.hip).  span_q / span_v:
+    // spanning position / velocity index of every body; crow: first row of every implicit cluster in the coupling slab.
+    grbda_plan *span = nullptr;
+    ~grbda_plan() { if (span) grbda_plan_free(span); }
+    std::vector<int32_t> span_q, span_v, crow;
+    int n_cpl_rows = 0;
+    bool no_manifold = false;  // GRBDA_NO_MANIFOLD=1: implicit models keep the difference batches (A/B runs)
 };
 
 namespace {
@@ -231,6 +240,12 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(cp.gbodies.data(), cp.gbodies.size() * sizeof(ChainGenBody), (void **)&t.chain_gbodies[w])) != hipSuccess)
             return hip_err(e, "plan upload");
         if ((e = set_max_dynamic_lds_chain()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
+    }
+    if (p->span) {
+        if ((e = up(p->span_q.data(), p->span_q.size() * sizeof(int32_t), (void **)&t.span_q)) != hipSuccess ||
+            (e = up(p->span_v.data(), p->span_v.size() * sizeof(int32_t), (void **)&t.span_v)) != hipSuccess ||
+            (e = up(p->crow.data(), p->crow.size() * sizeof(int32_t), (void **)&t.crow)) != hipSuccess)
+            return hip_err(e, "plan upload");
     }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_err(e, "hipGetDeviceProperties");
@@ -1361,13 +1376,139 @@ bool analytic_covers(const grbda_plan *p)
 {
     return p->host.deriv.ok && p->host.crba.ok && !p->no_analytic && !p->no_crba && p->host.nv <= kWave;
 }
+// Models with implicit clusters (manifold_kernels.hip): ydd = FD; spanning state and the first-order parts of G, g per state;
+// tau_s and (A_q, A_v, H_s) of the spanning tree from its own plan; projection with the per-state G; the same SPD solve.
+// H only (dq == dqd == nullptr): qd and tau may be null.
+template <class T>
+bool manifold_covers(const grbda_plan *p)
+{
+    return p->span && !p->no_manifold && !p->no_analytic && p->host.nv <= kWave && p->host.deriv.related.size() == static_cast<size_t>(p->host.nv);
+}
+template <class T>
+int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, T *dq, T *dqd, T *dtau, T *Hout, size_t B, int device,
+                    void *stream)
+{
+    if (!q || ((dq || dqd) && (!qd || !tau))) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0 || (!dq && !dqd && !dtau && !Hout)) return GRBDA_OK;
+    DeviceTables *t = nullptr, *ts = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const grbda_plan *sp = p->span;
+    if (int rc = ensure_device(sp, device, &ts)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
+    const size_t nq_s = sp->host.nq, nv_s = sp->host.nv, nn_s = nv_s * nv_s;
+    const bool need_d = dq || dqd;
+    const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
+    const bool solve = need_d || dtau;
+    const int il = (need_d && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
+    // workspace per state: spanning state (q_s, qd_s, qdd_s, tau_s), zeros for a missing qd, coupling rows, the three spanning
+    // matrices, the three projected matrices, ydd
+    const size_t per_state = nq_s + 3 * nv_s + nv + static_cast<size_t>(p->n_cpl_rows) + 3 * nn_s + 3 * nn + nv;
+    size_t chunk = (1024ull << 20) / (per_state * sizeof(T));
+    chunk &= ~static_cast<size_t>(kWave - 1);
+    if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
+    const size_t b_round = (B + kWave - 1) / kWave * kWave;
+    if (chunk > b_round) chunk = b_round;
+    void *wptr = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lk(p->mu);
+        Scratch &s = p->work[{device, stream}];
+        const size_t need = chunk * per_state * sizeof(T) + 256;
+        if (s.bytes < need) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return set_err(GRBDA_EINVAL, "the derivative workspace would have to grow during stream capture: run the largest batch once first");
+            hipError_t e;
+            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+            s.ptr = nullptr;
+            s.bytes = 0;
+            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
+            s.bytes = need;
+        }
+        wptr = s.ptr;
+    }
+    T *w = static_cast<T *>(wptr);
+    auto take = [&](size_t per) { T *r = w; w += chunk * per; return r; };
+    T *q_s = take(nq_s), *qd_s = take(nv_s), *qdd_s = take(nv_s), *tau_s = take(nv_s), *zeros = take(nv), *cpl = take(p->n_cpl_rows);
+    T *Aq = take(nn_s), *Av = take(nn_s), *Hs = take(nn_s), *Dq = take(nn), *Dqd = take(nn), *Hw = take(nn), *ydd = take(nv);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
+    DevPlan<T> ds = make_dev_plan<T>(sp, *ts, false, false);
+    hipError_t e;
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t n_tiles = (nb + kWave - 1) / kWave;
+        const T *qc = q + b0 * nq, *qdc = qd ? qd + b0 * nv : zeros, *yddc = nullptr;
+        if (!qd && (e = hipMemsetAsync(zeros, 0, nb * nv * sizeof(T), hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
+        if (need_d) {
+            if (int rc = run<T>(p, false, qc, qdc, tau + b0 * nv, nullptr, ydd, nb, device, stream)) return rc;
+            yddc = ydd;
+        } else {
+            // H only: the recursion runs at zero velocity and acceleration (its H does not depend on them)
+            if ((e = hipMemsetAsync(qd_s, 0, 2 * chunk * nv_s * sizeof(T), hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
+        }
+        size_t grid = static_cast<size_t>(t->n_cu) * 4;
+        if (grid > n_tiles) grid = n_tiles;
+        e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
+                                          p->n_cpl_rows, need_d ? 1 : 0, qc, qdc, yddc, q_s, qd_s, need_d ? qdd_s : nullptr, cpl, nb,
+                                          static_cast<int>(grid), hs);
+        if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
+        if (!need_d && (e = hipMemsetAsync(qd_s, 0, chunk * nv_s * sizeof(T), hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
+        if (need_d)
+            if (int rc = run<T>(sp, true, q_s, qd_s, qdd_s, nullptr, tau_s, nb, device, stream)) return rc;
+        {
+            const size_t deriv_waves = 4;
+            size_t g2 = static_cast<size_t>(ts->n_cu) * deriv_waves;
+            if (g2 > n_tiles) g2 = n_tiles;
+            void *scratch = nullptr;
+            if (int rc = ensure_scratch(sp, device, stream, g2 * static_cast<size_t>(sp->host.deriv.n_rows) * kWave * sizeof(T) + 256, &scratch))
+                return rc;
+            e = launch_rnea_deriv<T>(ds, ts->deriv_bodies, sp->host.n_clusters, sp->host.deriv.n_rows, sp->host.deriv.n_max, q_s, qd_s, qdd_s, Aq,
+                                     Av, Hs, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, kWave);
+            if (e != hipSuccess) return hip_err(e, "spanning derivative launch");
+        }
+        // the projected H goes to the caller's array when no solve follows, or (state-major layouts, whole groups) to d/dtau
+        T *H = !solve ? Hout + b0 * nn : ((dtau && !(il > 1 && (B % kDerivGroup) != 0)) ? dtau + b0 * nn : Hw);
+        e = launch_manifold_project<T>(d, p->host.n_clusters, t->span_v, t->crow, t->deriv_related, ts->deriv_related, static_cast<int>(nv_s),
+                                       p->n_cpl_rows, need_d ? 0 : 1, Aq, Av, Hs, tau_s, cpl, need_d ? Dq : nullptr, need_d ? Dqd : nullptr, H,
+                                       nb, static_cast<int>(grid), hs, solve ? il : 1);
+        if (e != hipSuccess) return hip_err(e, "manifold projection launch");
+        if (!solve) {
+            // packed lower rows -> the full symmetric matrix, in place
+            size_t g4 = static_cast<size_t>(t->n_cu) * 16;
+            if (g4 > nb) g4 = nb;
+            e = launch_unpack_symmetric<T>(H, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g4), hs);
+            if (e != hipSuccess) return hip_err(e, "unpack launch");
+            continue;
+        }
+        const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), sizeof(T), n_rhs);
+        size_t per_cu = lds ? (160u * 1024u) / lds : 16;
+        const bool mfma = need_d && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs);
+        if (per_cu > (mfma ? 2u : 16u)) per_cu = mfma ? 2 : 16;
+        if (per_cu < 1) per_cu = 1;
+        size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
+        const size_t units = mfma ? (nb + kDerivGroup - 1) / kDerivGroup : nb;
+        if (g3 > units) g3 = units;
+        T *o1 = dq ? dq + b0 * nn : nullptr, *o2 = dqd ? dqd + b0 * nn : nullptr, *o3 = dtau ? dtau + b0 * nn : nullptr;
+        const T *r1 = dq ? Dq : nullptr, *r2 = dqd ? Dqd : nullptr;
+        if constexpr (sizeof(T) == 4)
+            e = launch_spd_solve<float, float>(H, 1, r1, r2, o3, o1, o2, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g3), hs, il);
+        else
+            e = launch_spd_solve<double, double>(H, 1, r1, r2, o3, o1, o2, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g3), hs, 1);
+        if (e != hipSuccess) return hip_err(e, "spd solve launch");
+    }
+    return GRBDA_OK;
+}
+
 template <class T>
 int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, T *dq, T *dqd, T *dtau, size_t B, int device,
                     void *stream)
 {
     if (!p) return set_err(GRBDA_EINVAL, "null plan");
     GRBDA_CALL_SCOPE(p);
-    if (!analytic_covers<T>(p)) return 1;
+    if (!analytic_covers<T>(p)) {
+        if (manifold_covers<T>(p)) return manifold_derivs<T>(p, q, qd, tau, dq, dqd, dtau, nullptr, B, device, stream);
+        return 1;
+    }
     if (!q || ((dq || dqd) && (!qd || !tau))) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0 || (!dq && !dqd && !dtau)) return GRBDA_OK;
     DeviceTables *t = nullptr;
@@ -1469,6 +1610,16 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         if (e != hipSuccess) return hip_err(e, "spd solve launch");
     }
     return GRBDA_OK;
+}
+
+template <class T>
+int manifold_mass(const grbda_plan *p, const T *q, T *H, size_t B, int device, void *stream)
+{
+    // models with implicit clusters: H = G^T H_s G through the spanning tree (manifold_kernels.hip) instead of nv + 1 inverse dynamics
+    if (!p || !q || !H || p->no_crba) return 1;
+    GRBDA_CALL_SCOPE(p);
+    if (!manifold_covers<T>(p)) return 1;
+    return manifold_derivs<T>(p, q, nullptr, nullptr, nullptr, nullptr, nullptr, H, B, device, stream);
 }
 
 // ---- one process, several devices: contiguous batch shards, plan replicated ------------------------
@@ -1606,6 +1757,33 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     int rc = compile_plan(blob, bytes, lds, sweeps, p->host, msg, sizeof msg);
     if (rc) return set_err(rc, msg);
     p->blob.assign(static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + bytes);
+    p->no_manifold = env_int("GRBDA_NO_MANIFOLD", 0) != 0;
+    bool implicit = false;
+    for (const ClusterRec &cr : p->host.lay64.clusters) implicit = implicit || cr.kind == CK_LOOP;
+    if (implicit && p->host.nv <= kWave) {
+        // the spanning-tree model for the derivatives on the constraint manifold (at most 64 spanning velocities: the masks of
+        // DerivProgram::related)
+        std::vector<unsigned char> sb;
+        if (make_spanning_blob(blob, bytes, sb, p->span_q, p->span_v, msg, sizeof msg) == 0) {
+            grbda_plan *sp = nullptr;
+            if (grbda_plan_from_blob(sb.data(), sb.size(), &sp) == GRBDA_OK) {
+                if (sp->host.nv <= kWave && sp->host.deriv.ok) {
+                    p->span = sp;
+                    std::memcpy(sp->host.gravity, p->host.gravity, sizeof sp->host.gravity);
+                    p->crow.assign(p->host.n_clusters, 0);
+                    int rows = 0;
+                    for (int c = 0; c < p->host.n_clusters; c++) {
+                        const ClusterRec &cr = p->host.lay64.clusters[c];
+                        p->crow[c] = rows;
+                        if (cr.kind == CK_LOOP) rows += cr.k * cr.n * (4 + cr.n);
+                    }
+                    p->n_cpl_rows = rows;
+                } else {
+                    grbda_plan_free(sp);
+                }
+            }
+        }
+    }
     *out = p.release();
     return GRBDA_OK;
 }
@@ -1645,6 +1823,7 @@ void grbda_plan_free(grbda_plan *p)
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related);
+        (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
         for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
@@ -1671,6 +1850,7 @@ int grbda_plan_set_gravity(grbda_plan *p, const double g[3])
 {
     if (!p || !g) return set_err(GRBDA_EINVAL, "null argument");
     for (int i = 0; i < 3; i++) p->host.gravity[3 + i] = g[i];
+    if (p->span) grbda_plan_set_gravity(p->span, g);
     // keep the stored description in sync so that grbda_plan_blob() round-trips
     std::memcpy(reinterpret_cast<grbda_desc_header *>(p->blob.data())->gravity, p->host.gravity, sizeof(double) * 6);
     return GRBDA_OK;
@@ -1716,7 +1896,7 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->chain_aba_f64 = p->host.chain64.ok && !p->no_chain;
     info->chain_rnea_f32 = p->host.rchain32.ok && !p->no_chain;
     info->chain_rnea_f64 = p->host.rchain64.ok && !p->no_chain;
-    info->analytic_derivatives = analytic_covers<double>(p) ? 1 : 0;
+    info->analytic_derivatives = (analytic_covers<double>(p) || manifold_covers<double>(p)) ? 1 : 0;
     info->n_chain_differentials = p->no_chain ? 0 : static_cast<int>(p->host.chain32.diffs.size());
     info->latency_mode_f32 = p->host.chain32p.ok && !p->no_chain && !p->no_latency_mode;
     info->latency_mode_f64 = p->host.chain64p.ok && !p->no_chain && !p->no_latency_mode;
@@ -1757,10 +1937,12 @@ int grbda_bias_f32(const grbda_plan *p, const float *q, const float *qd, const f
 }
 int grbda_mass_matrix_f64(const grbda_plan *p, const double *q, double *H, size_t B, int device, void *stream)
 {
+    if (const int rc = manifold_mass<double>(p, q, H, B, device, stream); rc != 1) return rc;
     return derived<double>(p, DM_MASS, q, nullptr, nullptr, nullptr, H, B, device, stream);
 }
 int grbda_mass_matrix_f32(const grbda_plan *p, const float *q, float *H, size_t B, int device, void *stream)
 {
+    if (const int rc = manifold_mass<float>(p, q, H, B, device, stream); rc != 1) return rc;
     return derived<float>(p, DM_MASS, q, nullptr, nullptr, nullptr, H, B, device, stream);
 }
 int grbda_fd_dtau_f64(const grbda_plan *p, const double *q, double *Hinv, size_t B, int device, void *stream)

@@ -743,6 +743,14 @@ hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clu
         if (interleave == kDerivGroup)
             return launch_rnea_deriv_il<T, kDerivGroup>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
     }
+    if (interleave == kWave && n_max <= 1) {
+        // tile-interleaved results [tile][entry][lane]: what a one-state-per-lane consumer reads as coalesced rows (the
+        // spanning-tree pass of manifold_kernels.hip; single-body clusters only)
+        const size_t part_lds = sizeof(T) == 8 ? 63 * kWave * sizeof(T) : 0;
+        hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, kWave>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
+                           Dqd, H, B, scratch);
+        return hipGetLastError();
+    }
     if (interleave != 1) return hipErrorInvalidValue;
     return launch_rnea_deriv_il<T, 1>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
 }

@@ -169,6 +169,16 @@ template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
                             int nv, size_t B, int grid, hipStream_t stream, int interleave);
 size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
+
+// analytic derivatives of models with implicit clusters through the spanning tree (manifold_kernels.hip)
+template <class T>
+hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
+                                      int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream);
+template <class T>
+hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
+                                   const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
+                                   const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave);
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
 
 }  // namespace grbda_hip

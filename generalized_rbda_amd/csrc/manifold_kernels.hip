@@ -1,0 +1,627 @@
+// manifold_kernels.hip -- analytic first-order derivatives of the cluster dynamics for models with IMPLICIT clusters
+// (BASELINE config 5 names "four_bar / six_bar loop clusters"; Tello's differentials are the other user).
+//
+// The reference differentiates CasADi graphs through G(q), g(q, qd) of its GenericImplicit clusters
+// (src/Dynamics/ClusterJoints/GenericJoint.cpp:57-90; yardstick UnitTests/testRigidBodyDynamicsAlgosDerivatives.cpp:271-383).
+// Here the inverse dynamics in the independent coordinates y is written through the SPANNING tree,
+//     tau(y, yd, ydd) = G^T tau_s(q_s, qd_s, qdd_s),   qd_s = G yd,   qdd_s = G ydd + g,   d q_s / d y = G,
+// so, with A_q = d tau_s / d q_s, A_v = d tau_s / d qd_s, H_s = d tau_s / d qdd_s of the spanning tree (an explicit model:
+// rnea_deriv_kernel on the spanning plan, plan.cpp make_spanning_blob) and G_a' = d G / d y_a along the manifold,
+//     d tau / d y_a  = G^T [A_q G e_a + A_v (G_a' yd) + H_s (G_a' ydd + d g / d y_a)] + G_a'^T tau_s
+//     d tau / d yd_a = G^T [A_v G e_a + H_s (d g / d yd_a)]
+//     H              = G^T H_s G
+// and d ydd / d (y, yd, tau) = -H^-1 (...), H^-1 by the same batched SPD solve as the explicit models.
+//
+// Derivatives of the constraint quantities (manifold_constraint_kernel, one state per lane).  With K = d phi / d q split into
+// dependent / independent columns, K G = 0 and Kd g_dep = -kappa, kappa = D^2 phi [qd_s, qd_s] (= Kdot qd_s); along the
+// direction d = G e_a of the manifold, K' = D K [d]:
+//     G_a'(dep rows) = -Kd^-1 K' G,        d g_dep / d yd_a = -2 Kd^-1 K' qd_s,
+//     d g_dep / d y_a = -Kd^-1 (kappa' + K'_d g_dep),   kappa' = D^3 phi [d, qd_s, qd_s] + 2 D^2 phi [qd_s, G_a' yd].
+// K' and kappa' come from evaluating K and kappa in DUAL numbers (value + first-order part along d): the same templated code
+// that computes K and kappa -- the point Jacobians / velocity-product accelerations of the two sub-chains of a URDF+ <loop>
+// (ClusterTreeParsing.cpp:310-376), term-by-term differentiation of a trig-polynomial phi -- runs once with plain numbers and once per
+// independent coordinate with duals.  No finite differences, no re-projection.
+#include <hip/hip_runtime.h>
+
+#include "devplan.h"
+
+namespace grbda_hip {
+
+#include "devmath.h"
+
+// ---- dual numbers ------------------------------------------------------------------------------------------------
+template <class T>
+struct Du {
+    T v, d;
+    __device__ __forceinline__ Du() : v(0), d(0) {}
+    __device__ __forceinline__ Du(T x) : v(x), d(0) {}
+    __device__ __forceinline__ Du(T x, T y) : v(x), d(y) {}
+};
+template <class T> __device__ __forceinline__ Du<T> operator+(Du<T> a, Du<T> b) { return Du<T>(a.v + b.v, a.d + b.d); }
+template <class T> __device__ __forceinline__ Du<T> operator-(Du<T> a, Du<T> b) { return Du<T>(a.v - b.v, a.d - b.d); }
+template <class T> __device__ __forceinline__ Du<T> operator-(Du<T> a) { return Du<T>(-a.v, -a.d); }
+template <class T> __device__ __forceinline__ Du<T> operator*(Du<T> a, Du<T> b) { return Du<T>(a.v * b.v, a.v * b.d + a.d * b.v); }
+template <class T> __device__ __forceinline__ Du<T> operator*(Du<T> a, T b) { return Du<T>(a.v * b, a.d * b); }
+template <class T> __device__ __forceinline__ Du<T> operator*(T a, Du<T> b) { return Du<T>(a * b.v, a * b.d); }
+template <class T> __device__ __forceinline__ Du<T> &operator+=(Du<T> &a, Du<T> b) { a.v += b.v; a.d += b.d; return a; }
+template <class T> __device__ __forceinline__ Du<T> &operator-=(Du<T> &a, Du<T> b) { a.v -= b.v; a.d -= b.d; return a; }
+// sine and cosine of an angle given with its first-order part
+template <class T> __device__ __forceinline__ void sc_of(T x, T &s, T &c) { sincos_precise(x, &s, &c); }
+template <class T> __device__ __forceinline__ void sc_of(Du<T> x, Du<T> &s, Du<T> &c)
+{
+    T sn, cs;
+    sincos_precise(x.v, &sn, &cs);
+    s = Du<T>(sn, cs * x.d);
+    c = Du<T>(cs, -sn * x.d);
+}
+
+constexpr int kMB = kMaxClusterBodies;  // 8
+constexpr int kMR = 3;                  // constraint rows
+constexpr int kMN = kMaxClusterDof;     // 4
+
+template <class S>
+__device__ __forceinline__ void cross_s(const S (&a)[3], const S (&b)[3], S (&o)[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// ---- URDF+ position loops: K (want_K) or kappa = Kdot qd (otherwise), in the scalar type S ------------------------------
+// sn / cs: sine and cosine of the k spanning angles; qd: the k spanning rates
+template <class T, class S>
+__device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
+                                   const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][kMB], S (&kap)[kMR])
+{
+    cptr<int32_t> lp = loops;
+    int row0 = 0;
+    for (int l = 0; l < n_loops; l++) {
+        const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+        cptr<T> org = consts + c.dofs + 24 * l;
+        S acc[3] = {S(T(0)), S(T(0)), S(T(0))};
+        for (int side = 0; side < 2; side++) {
+            cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
+            const int len = side == 0 ? np : ns;
+            const T sgn = side == 0 ? T(1) : T(-1);
+            S E[9], r[3], A[kMB][3], O[kMB][3];
+#pragma unroll
+            for (int i = 0; i < 9; i++) E[i] = S(i % 4 == 0 ? T(1) : T(0));
+#pragma unroll
+            for (int i = 0; i < 3; i++) r[i] = S(T(0));
+            for (int t = 0; t < len; t++) {
+                const int sub = subs[t];
+                const BodyRec b = load_rec(bodies + (c.first_body + sub));
+                cptr<T> C = consts + b.cofs;
+                S Eb[9], En[9];
+                const S s = sn[sub], co = cs[sub];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {  // Rz(q) Et (canonical joint axes, plan.cpp)
+                    Eb[j] = co * C[j] + s * C[3 + j];
+                    Eb[3 + j] = co * C[3 + j] - s * C[j];
+                    Eb[6 + j] = S(C[6 + j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) r[i] += E[i] * C[9] + E[3 + i] * C[10] + E[6 + i] * C[11];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) En[3 * i + j] = Eb[3 * i] * E[j] + Eb[3 * i + 1] * E[3 + j] + Eb[3 * i + 2] * E[6 + j];
+#pragma unroll
+                for (int i = 0; i < 9; i++) E[i] = En[i];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    A[t][i] = E[6 + i];
+                    O[t][i] = r[i];
+                }
+            }
+            S p[3];
+            cptr<T> og = org + 12 * side;
+#pragma unroll
+            for (int i = 0; i < 3; i++) p[i] = r[i] + E[i] * og[9] + E[3 + i] * og[10] + E[6 + i] * og[11];
+            if (want_K) {
+                for (int t = 0; t < len; t++) {
+                    const S a[3] = {A[t][0], A[t][1], A[t][2]}, d[3] = {p[0] - O[t][0], p[1] - O[t][1], p[2] - O[t][2]};
+                    S J[3];
+                    cross_s(a, d, J);
+                    int row = row0;
+                    for (int ax = 0; ax < 3; ax++)
+                        if (mask & (1 << ax)) {
+                            K[row][subs[t]] = sgn * J[ax];
+                            row++;
+                        }
+                }
+            } else {
+                S w[3], al[3], ao[3], op[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) w[i] = al[i] = ao[i] = op[i] = S(T(0));
+                for (int t = 0; t <= len; t++) {
+                    S a[3], o[3], qd_t = S(T(0));
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        a[i] = t < len ? A[t][i] : S(T(0));
+                        o[i] = t < len ? O[t][i] : p[i];
+                    }
+                    if (t < len) qd_t = qd[subs[t]];
+                    const S d[3] = {o[0] - op[0], o[1] - op[1], o[2] - op[2]};
+                    S wd[3], wwd[3], ad[3];
+                    cross_s(w, d, wd);
+                    cross_s(w, wd, wwd);
+                    cross_s(al, d, ad);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        ao[i] += ad[i] + wwd[i];
+                        op[i] = o[i];
+                    }
+                    const S aq[3] = {a[0] * qd_t, a[1] * qd_t, a[2] * qd_t};
+                    S waq[3];
+                    cross_s(w, aq, waq);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        al[i] += waq[i];
+                        w[i] += aq[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) acc[i] += sgn * ao[i];
+            }
+        }
+        int row = row0;
+        for (int ax = 0; ax < 3; ax++)
+            if (mask & (1 << ax)) {
+                if (!want_K) kap[row] = acc[ax];
+                row++;
+            }
+        row0 = row;
+        lp += 3 + np + ns;
+    }
+}
+
+// ---- trig-polynomial phi (plan.cpp: ints [n_args, per row: n_terms, per term: n_factors, (type, argument)...], constants
+// [per distinct argument w[k], b][per term coef]) ---------------------------------------------------------------------------
+template <class T, class S>
+__device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32_t> prog, const S *q, const S *qd, bool want_K,
+                                 S (&K)[kMR][kMB], S (&kap)[kMR])
+{
+    const int k = c.k;
+    cptr<int32_t> ip = prog;
+    const int n_args = *ip++;
+    cptr<T> ap = consts + c.dofs;
+    cptr<T> cp = ap + n_args * (k + 1);
+    for (int r = 0; r < c.rows; r++) {
+        const int nt = *ip++;
+        S Krow[kMB], kd = S(T(0));
+#pragma unroll
+        for (int j = 0; j < kMB; j++) Krow[j] = S(T(0));
+        for (int t = 0; t < nt; t++) {
+            const int nf = *ip++;
+            const T coef = *cp++;
+            S f0[4], f1[4], f2[4], ad[4];
+            cptr<T> wv[4];
+            for (int f = 0; f < 4; f++) {
+                f0[f] = S(T(1)); f1[f] = S(T(0)); f2[f] = S(T(0)); ad[f] = S(T(0));
+                wv[f] = ap;
+                if (f < nf) {
+                    const int type = ip[0], arg = ip[1];
+                    ip += 2;
+                    cptr<T> w = ap + arg * (k + 1);
+                    wv[f] = w;
+                    S a = S(w[k]), adot = S(T(0));
+                    for (int j = 0; j < k; j++) {
+                        a += q[j] * w[j];
+                        adot += qd[j] * w[j];
+                    }
+                    ad[f] = adot;
+                    S sn, cs;
+                    sc_of(a, sn, cs);
+                    if (type == 1) { f0[f] = sn; f1[f] = cs; f2[f] = -sn; }
+                    else if (type == 2) { f0[f] = cs; f1[f] = -sn; f2[f] = -cs; }
+                    else { f0[f] = a; f1[f] = S(T(1)); f2[f] = S(T(0)); }
+                }
+            }
+            for (int f = 0; f < nf; f++) {
+                S others = S(coef);
+                for (int h = 0; h < 4; h++)
+                    if (h != f) others = others * f0[h];
+                if (want_K) {
+                    for (int j = 0; j < k; j++) Krow[j] += others * f1[f] * wv[f][j];
+                } else {
+                    kd += others * f2[f] * ad[f] * ad[f];
+                    for (int h = 0; h < nf; h++)
+                        if (h != f) {
+                            S rest = S(coef);
+                            for (int m2 = 0; m2 < 4; m2++)
+                                if (m2 != f && m2 != h) rest = rest * f0[m2];
+                            kd += rest * f1[f] * ad[f] * f1[h] * ad[h];
+                        }
+                }
+            }
+        }
+        if (want_K) {
+            for (int j = 0; j < k; j++) K[r][j] = Krow[j];
+        } else {
+            kap[r] = kd;
+        }
+    }
+}
+
+// K or kappa of an implicit cluster at the spanning state (q, qd), scalar type S
+template <class T, class S>
+__device__ void constraint_eval(cptr<T> consts, cptr<BodyRec> bodies, cptr<int32_t> cints, const ClusterRec &c, const S *q, const S *qd,
+                                bool want_K, S (&K)[kMR][kMB], S (&kap)[kMR])
+{
+    cptr<int32_t> ip = cints + c.iofs;
+    const int hdr0 = ip[0], n_ind = ip[1];
+    cptr<int32_t> payload = ip + 3 + n_ind + c.rows;
+    if (c.cons_type == 0) {
+        S sn[kMB], cs[kMB];
+        for (int j = 0; j < c.k; j++) sc_of(q[j], sn[j], cs[j]);
+        loop_position_eval<T, S>(consts, bodies, c, payload, hdr0, sn, cs, qd, want_K, K, kap);
+    } else {
+        trig_poly_eval_s<T, S>(consts, c, payload, q, qd, want_K, K, kap);
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void inv_rows(int R, const T (&A)[kMR][kMR], T (&Ai)[kMR][kMR])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Ai[i][j] = 0;
+    if (R == 1) {
+        Ai[0][0] = T(1) / A[0][0];
+    } else if (R == 2) {
+        const T id = T(1) / (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
+        Ai[0][0] = A[1][1] * id; Ai[0][1] = -A[0][1] * id;
+        Ai[1][0] = -A[1][0] * id; Ai[1][1] = A[0][0] * id;
+    } else {
+        const T c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+        const T c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+        const T c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+        const T id = T(1) / (A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02);
+        Ai[0][0] = c00 * id; Ai[1][0] = c01 * id; Ai[2][0] = c02 * id;
+        Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id;
+        Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id;
+        Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id;
+        Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id;
+        Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id;
+        Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel 1: spanning state and coupling of every cluster, one state per lane.
+//   q_s [B][nq_s], qd_s / qdd_s [B][nv_s]: the state of the spanning model (row-major: what its kernels take)
+//   cpl [tile][row][lane]: per implicit cluster, from row crow[c], per body i (stride n (4 + n)):
+//       [G row n][(G_a' yd)_i, a < n][(G_a' ydd + d g / d y_a)_i][(d g / d yd_a)_i][G_a'[i][b], a-major]
+// span_q / span_v: first spanning position / velocity index of every body; want_d = 0: G rows only (mass matrix)
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_q_,
+                                                                     const int32_t *__restrict__ span_v_, const int32_t *__restrict__ crow_,
+                                                                     int nq_s, int nv_s, int n_cpl_rows, int want_d,
+                                                                     const T *__restrict__ q, const T *__restrict__ qd,
+                                                                     const T *__restrict__ ydd, T *__restrict__ q_s, T *__restrict__ qd_s,
+                                                                     T *__restrict__ qdd_s, T *__restrict__ cpl, size_t B)
+{
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
+    cptr<T> consts = (cptr<T>)DP.consts;
+    cptr<int32_t> cints = (cptr<int32_t>)DP.cints;
+    cptr<int32_t> span_q = (cptr<int32_t>)span_q_, span_v = (cptr<int32_t>)span_v_, crow = (cptr<int32_t>)crow_;
+    const int lane = threadIdx.x, nq = DP.nq, nv = DP.nv;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r0 = tile * kWave + lane;
+        const bool live = r0 < B;
+        const size_t st = live ? r0 : B - 1;
+        const T *qs = q + st * (size_t)nq, *qds = qd + st * (size_t)nv, *ydds = ydd ? ydd + st * (size_t)nv : nullptr;
+        T *oq = q_s + st * (size_t)nq_s, *ov = qd_s + st * (size_t)nv_s, *oa = qdd_s ? qdd_s + st * (size_t)nv_s : nullptr;
+        T *cp = cpl + (tile * (size_t)n_cpl_rows) * kWave + lane;
+        for (int c = 0; c < n_clusters; c++) {
+            const ClusterRec cr = load_rec(clusters + c);
+            const int sq0 = span_q[cr.first_body], sv0 = span_v[cr.first_body];
+            if (cr.kind == CK_FREE) {
+                const int npos = DP.ori_repr == 0 ? 7 : 6;
+                if (live) {
+                    for (int j = 0; j < npos; j++) oq[sq0 + j] = qs[cr.q_index + j];
+                    for (int j = 0; j < 6; j++) {
+                        ov[sv0 + j] = qds[cr.v_index + j];
+                        if (oa) oa[sv0 + j] = ydds[cr.v_index + j];
+                    }
+                }
+                continue;
+            }
+            const int k = cr.k, n = cr.n;
+            if (cr.kind == CK_STATIC) {
+                for (int i = 0; i < k; i++) {
+                    const BodyRec b = load_rec(bodies + (cr.first_body + i));
+                    cptr<T> G = consts + b.cofs + kBodyConstFixed;
+                    T a = 0, v = 0, w = 0;
+                    for (int j = 0; j < n; j++) {
+                        a += G[j] * qs[cr.q_index + j];
+                        v += G[j] * qds[cr.v_index + j];
+                        if (ydds) w += G[j] * ydds[cr.v_index + j];
+                    }
+                    if (live) {
+                        oq[span_q[cr.first_body + i]] = a;
+                        ov[span_v[cr.first_body + i]] = v;
+                        if (oa) oa[span_v[cr.first_body + i]] = w;
+                    }
+                }
+                continue;
+            }
+            // ---- implicit cluster ----
+            cptr<int32_t> ip = cints + cr.iofs;
+            const int n_ind = ip[1], rows = cr.rows;
+            cptr<int32_t> ind = ip + 2, dep = ip + 3 + n_ind;
+            T qv[kMB], yd[kMN], yddv[kMN];
+            for (int j = 0; j < kMB; j++) qv[j] = j < k ? qs[cr.q_index + j] : T(0);
+            for (int a = 0; a < kMN; a++) {
+                yd[a] = a < n ? qds[cr.v_index + a] : T(0);
+                yddv[a] = (a < n && ydds) ? ydds[cr.v_index + a] : T(0);
+            }
+            T K[kMR][kMB], kap[kMR], zero[kMB];
+            for (int r = 0; r < kMR; r++) {
+                kap[r] = 0;
+                for (int j = 0; j < kMB; j++) K[r][j] = 0;
+            }
+            for (int j = 0; j < kMB; j++) zero[j] = 0;
+            constraint_eval<T, T>(consts, bodies, cints, cr, qv, zero, true, K, kap);
+            T Kd[kMR][kMR], Kdi[kMR][kMR], G[kMB][kMN], qdv[kMB], gv[kMB];
+            for (int r = 0; r < kMR; r++)
+                for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
+            inv_rows(rows, Kd, Kdi);
+            for (int i = 0; i < kMB; i++) {
+                gv[i] = 0;
+                for (int a = 0; a < kMN; a++) G[i][a] = 0;
+            }
+            for (int a = 0; a < n; a++) G[ind[a]][a] = 1;
+            for (int r = 0; r < rows; r++)
+                for (int a = 0; a < n; a++) {
+                    T s = 0;
+                    for (int j = 0; j < rows; j++) s += Kdi[r][j] * K[j][ind[a]];
+                    G[dep[r]][a] = -s;
+                }
+            for (int i = 0; i < k; i++) {
+                T s = 0;
+                for (int a = 0; a < n; a++) s += G[i][a] * yd[a];
+                qdv[i] = s;
+            }
+            constraint_eval<T, T>(consts, bodies, cints, cr, qv, qdv, false, K, kap);  // (K is not touched: want_K false)
+            for (int r = 0; r < rows; r++) {
+                T s = 0;
+                for (int j = 0; j < rows; j++) s += Kdi[r][j] * kap[j];
+                gv[dep[r]] = -s;
+            }
+            if (live) {
+                for (int i = 0; i < k; i++) {
+                    oq[span_q[cr.first_body + i]] = qv[i];
+                    ov[span_v[cr.first_body + i]] = qdv[i];
+                    if (oa) {
+                        T s = gv[i];
+                        for (int a = 0; a < n; a++) s += G[i][a] * yddv[a];
+                        oa[span_v[cr.first_body + i]] = s;
+                    }
+                }
+            }
+            const int stride = n * (4 + n);
+            T *cc = cp + (size_t)crow[c] * kWave;
+            for (int i = 0; i < k; i++)
+                for (int a = 0; a < n; a++) cc[(size_t)(i * stride + a) * kWave] = G[i][a];
+            if (!want_d) continue;
+            // ---- first-order parts along every independent coordinate ----
+            for (int i = 0; i < k; i++)
+                for (int j = n; j < stride; j++) cc[(size_t)(i * stride + j) * kWave] = 0;
+            for (int a = 0; a < n; a++) {
+                Du<T> qD[kMB], qdD[kMB], KD[kMR][kMB], kapD[kMR];
+                for (int j = 0; j < kMB; j++) {
+                    qD[j] = Du<T>(qv[j], j < k ? G[j][a] : T(0));
+                    qdD[j] = Du<T>(T(0));
+                }
+                for (int r = 0; r < kMR; r++) {
+                    kapD[r] = Du<T>(T(0));
+                    for (int j = 0; j < kMB; j++) KD[r][j] = Du<T>(T(0));
+                }
+                constraint_eval<T, Du<T>>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD);
+                // G' (dependent rows) = -Kd^-1 K' G ;  d g / d yd_a = -2 Kd^-1 K' qd_s
+                T Gp[kMR][kMN], KpQd[kMR], qdp[kMB];
+                for (int r = 0; r < rows; r++) {
+                    T s = 0;
+                    for (int j = 0; j < k; j++) s += KD[r][j].d * qdv[j];
+                    KpQd[r] = s;
+                }
+                for (int j = 0; j < kMB; j++) qdp[j] = 0;
+                for (int r = 0; r < rows; r++)
+                    for (int b2 = 0; b2 < n; b2++) {
+                        T s = 0;
+                        for (int r2 = 0; r2 < rows; r2++) {
+                            T kg = 0;  // (K' G)[r2][b2]
+                            for (int j = 0; j < k; j++) kg += KD[r2][j].d * G[j][b2];
+                            s += Kdi[r][r2] * kg;
+                        }
+                        Gp[r][b2] = -s;
+                        qdp[dep[r]] += -s * yd[b2];
+                    }
+                for (int j = 0; j < kMB; j++) qdD[j] = Du<T>(j < k ? qdv[j] : T(0), qdp[j]);
+                constraint_eval<T, Du<T>>(consts, bodies, cints, cr, qD, qdD, false, KD, kapD);  // (KD is not touched)
+                for (int r = 0; r < rows; r++) {
+                    const int i = dep[r];
+                    T gy = 0, gyd = 0, ay = 0, by = 0;
+                    for (int r2 = 0; r2 < rows; r2++) {
+                        T kdg = 0;  // (K'_d g_dep)[r2]
+                        for (int j = 0; j < rows; j++) kdg += KD[r2][dep[j]].d * gv[dep[j]];
+                        gy += Kdi[r][r2] * (kapD[r2].d + kdg);
+                        gyd += Kdi[r][r2] * KpQd[r2];
+                    }
+                    gy = -gy;
+                    gyd = T(-2) * gyd;
+                    for (int b2 = 0; b2 < n; b2++) {
+                        ay += Gp[r][b2] * yd[b2];
+                        by += Gp[r][b2] * yddv[b2];
+                        cc[(size_t)(i * stride + 4 * n + a * n + b2) * kWave] = Gp[r][b2];
+                    }
+                    cc[(size_t)(i * stride + n + a) * kWave] = ay;
+                    cc[(size_t)(i * stride + 2 * n + a) * kWave] = by + gy;
+                    cc[(size_t)(i * stride + 3 * n + a) * kWave] = gyd;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel 2: projection onto the independent coordinates, one state per lane.
+//   Aq, Av: d tau_s / d q_s, d tau_s / d qd_s of the spanning model, Hs: its joint-space inertia -- rnea_deriv_kernel's packed
+//   layout interleaved by 64: [tile][entry][lane]; tau_s [B][nv_s]; rel_s: DerivProgram::related of the spanning model
+//   outputs Dq, Dqd, H in the layout spd_solve reads for the model's own nv (packed runs / packed lower rows, interleaved by IL)
+// mode 0: all three; mode 1: H only (Aq, Av, tau_s unused)
+// ---------------------------------------------------------------------------------------------------------------
+template <class T, int IL>
+__global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_v_,
+                                                                  const int32_t *__restrict__ crow_, const uint64_t *__restrict__ rel_,
+                                                                  const uint64_t *__restrict__ rel_s_, int nv_s, int n_cpl_rows, int mode,
+                                                                  const T *__restrict__ Aq, const T *__restrict__ Av,
+                                                                  const T *__restrict__ Hs, const T *__restrict__ tau_s,
+                                                                  const T *__restrict__ cpl, T *__restrict__ Dq, T *__restrict__ Dqd,
+                                                                  T *__restrict__ H, size_t B)
+{
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
+    cptr<T> consts = (cptr<T>)DP.consts;
+    cptr<int32_t> span_v = (cptr<int32_t>)span_v_, crow = (cptr<int32_t>)crow_;
+    cptr<uint64_t> rel = (cptr<uint64_t>)rel_, rel_s = (cptr<uint64_t>)rel_s_;
+    const int lane = threadIdx.x, nv = DP.nv;
+    const size_t nn_s = (size_t)nv_s * nv_s, nn = (size_t)nv * nv;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r0 = tile * kWave + lane;
+        const bool live = r0 < B;
+        const size_t st = live ? r0 : B - 1;
+        const T *aq = Aq ? Aq + tile * nn_s * kWave + lane : nullptr, *av = Av ? Av + tile * nn_s * kWave + lane : nullptr;
+        const T *hs = Hs + tile * nn_s * kWave + lane;
+        const T *ts = tau_s ? tau_s + st * (size_t)nv_s : nullptr;
+        const T *cp = cpl + (tile * (size_t)n_cpl_rows) * kWave + lane;
+        const size_t grp = st / IL, sub = st % IL;
+        T *Dqs = Dq ? Dq + grp * nn * IL + sub : nullptr, *Dqds = Dqd ? Dqd + grp * nn * IL + sub : nullptr;
+        T *Hout = H + grp * nn * IL + sub;
+        auto packed = [](int r, int c) -> size_t { return c <= r ? (size_t)(r * r + c) : (size_t)(c * c + c + 1 + r); };
+        auto sym = [](int r, int c) -> size_t { return r >= c ? (size_t)(r * (r + 1) / 2 + c) : (size_t)(c * (c + 1) / 2 + r); };
+        for (int cJ = 0; cJ < n_clusters; cJ++) {
+            const ClusterRec J = load_rec(clusters + cJ);
+            const int nJ = J.kind == CK_FREE ? 6 : J.n, kJ = J.kind == CK_FREE ? 6 : J.k;
+            const int strideJ = J.kind == CK_LOOP ? J.n * (4 + J.n) : 0;
+            const T *cJp = cp + (size_t)(J.kind == CK_LOOP ? crow[cJ] : 0) * kWave;
+            for (int a = 0; a < nJ; a++) {
+                // column data over the spanning coordinates of cluster J: G e_a, G_a' yd, G_a' ydd + dg/dy_a, dg/dyd_a
+                T gJ[kMB], ayJ[kMB], byJ[kMB], bvJ[kMB];
+                int svJ[kMB];
+                for (int s = 0; s < kMB; s++) {
+                    gJ[s] = ayJ[s] = byJ[s] = bvJ[s] = 0;
+                    svJ[s] = 0;
+                    if (s >= kJ) continue;
+                    if (J.kind == CK_FREE) {
+                        svJ[s] = span_v[J.first_body] + s;
+                        gJ[s] = s == a ? T(1) : T(0);
+                    } else if (J.kind == CK_STATIC) {
+                        svJ[s] = span_v[J.first_body + s];
+                        gJ[s] = consts[load_rec(bodies + (J.first_body + s)).cofs + kBodyConstFixed + a];
+                    } else {
+                        svJ[s] = span_v[J.first_body + s];
+                        gJ[s] = cJp[(size_t)(s * strideJ + a) * kWave];
+                        if (mode == 0) {
+                            ayJ[s] = cJp[(size_t)(s * strideJ + J.n + a) * kWave];
+                            byJ[s] = cJp[(size_t)(s * strideJ + 2 * J.n + a) * kWave];
+                            bvJ[s] = cJp[(size_t)(s * strideJ + 3 * J.n + a) * kWave];
+                        }
+                    }
+                }
+                const int vJ = J.v_index + a;
+                for (int cI = 0; cI < n_clusters; cI++) {
+                    const ClusterRec I = load_rec(clusters + cI);
+                    if (!((rel[I.v_index] >> J.v_index) & 1)) continue;  // clusters on different branches: structural zeros
+                    const int nI = I.kind == CK_FREE ? 6 : I.n, kI = I.kind == CK_FREE ? 6 : I.k;
+                    const int strideI = I.kind == CK_LOOP ? I.n * (4 + I.n) : 0;
+                    const T *cIp = cp + (size_t)(I.kind == CK_LOOP ? crow[cI] : 0) * kWave;
+                    T oq[kMN + 2], ov[kMN + 2], oh[kMN + 2];
+                    for (int b2 = 0; b2 < kMN + 2; b2++) oq[b2] = ov[b2] = oh[b2] = 0;
+                    for (int ri = 0; ri < kI; ri++) {
+                        const int r = I.kind == CK_FREE ? span_v[I.first_body] + ri : span_v[I.first_body + ri];
+                        const uint64_t rr = rel_s[r];
+                        T colq = 0, colv = 0, colh = 0;
+                        for (int s = 0; s < kJ; s++) {
+                            const int sv = svJ[s];
+                            if (!((rr >> sv) & 1)) continue;
+                            const T h = hs[sym(r, sv) * kWave];
+                            colh += h * gJ[s];
+                            if (mode == 0) {
+                                const T x = aq[packed(r, sv) * kWave], y = av[packed(r, sv) * kWave];
+                                colq += x * gJ[s] + y * ayJ[s] + h * byJ[s];
+                                colv += y * gJ[s] + h * bvJ[s];
+                            }
+                        }
+                        for (int b2 = 0; b2 < nI; b2++) {
+                            T g;
+                            if (I.kind == CK_FREE) g = ri == b2 ? T(1) : T(0);
+                            else if (I.kind == CK_STATIC) g = consts[load_rec(bodies + (I.first_body + ri)).cofs + kBodyConstFixed + b2];
+                            else g = cIp[(size_t)(ri * strideI + b2) * kWave];
+                            oq[b2] += g * colq;
+                            ov[b2] += g * colv;
+                            oh[b2] += g * colh;
+                        }
+                        // (d G^T / d y_a) tau_s: own cluster only, dependent bodies carry the rows of G_a'
+                        if (mode == 0 && cI == cJ && I.kind == CK_LOOP) {
+                            const T tr = ts[r];
+                            for (int b2 = 0; b2 < nI; b2++) oq[b2] += cIp[(size_t)(ri * strideI + 4 * I.n + a * I.n + b2) * kWave] * tr;
+                        }
+                    }
+                    if (live) {
+                        for (int b2 = 0; b2 < nI; b2++) {
+                            const int vI = I.v_index + b2;
+                            if (mode == 0) {
+                                Dqs[packed(vI, vJ) * IL] = oq[b2];
+                                Dqds[packed(vI, vJ) * IL] = ov[b2];
+                            }
+                            if (vJ <= vI) Hout[sym(vI, vJ) * IL] = oh[b2];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <class T>
+hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
+                                      int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((manifold_constraint_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_q, span_v, crow, nq_s, nv_s,
+                       n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
+                                   const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
+                                   const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave)
+{
+    if (interleave == kDerivGroup)
+        hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, rel, rel_s,
+                           nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
+    else
+        hipLaunchKernelGGL((manifold_project_kernel<T, 1>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, rel, rel_s, nv_s,
+                           n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
+    return hipGetLastError();
+}
+template hipError_t launch_manifold_constraint<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const int32_t *, int, int, int,
+                                                      int, const float *, const float *, const float *, float *, float *, float *, float *,
+                                                      size_t, int, hipStream_t);
+template hipError_t launch_manifold_constraint<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const int32_t *, int, int,
+                                                       int, int, const double *, const double *, const double *, double *, double *, double *,
+                                                       double *, size_t, int, hipStream_t);
+template hipError_t launch_manifold_project<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const uint64_t *,
+                                                   const uint64_t *, int, int, int, const float *, const float *, const float *, const float *,
+                                                   const float *, float *, float *, float *, size_t, int, hipStream_t, int);
+template hipError_t launch_manifold_project<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const uint64_t *,
+                                                    const uint64_t *, int, int, int, const double *, const double *, const double *,
+                                                    const double *, const double *, double *, double *, double *, size_t, int, hipStream_t, int);
+
+}  // namespace grbda_hip

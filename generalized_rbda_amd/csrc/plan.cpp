@@ -2085,3 +2085,67 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
 }
 
 }  // namespace grbda_hip
+
+// ---------------------------------------------------------------------------------------------------------------
+// Spanning-tree model of a cluster tree model: every revolute body a cluster of its own (Revolute, G = 1), the floating base
+// as it is.  The analytic derivatives of models with implicit clusters are taken on it (capi.cpp, manifold_derivs;
+// manifold_kernels.hip): tau = G^T tau_span(q_span, G yd, G ydd + g), so d tau / d y needs d tau_span / d (q, qd)_span and
+// H_span of the spanning tree -- which is an explicit model the inverse-dynamics derivative recursion covers -- and the
+// derivatives of G and g.  span_q / span_v: per body of the model, its first position / velocity index in the spanning model.
+// ---------------------------------------------------------------------------------------------------------------
+namespace grbda_hip {
+int make_spanning_blob(const void *blob, size_t bytes, std::vector<unsigned char> &out, std::vector<int32_t> &span_q,
+                       std::vector<int32_t> &span_v, char *msg, size_t cap)
+{
+    Blob m;
+    if (int rc = parse(blob, bytes, m, msg, cap)) return rc;
+    const int nb = m.h->n_bodies;
+    grbda_desc_header h = *m.h;
+    std::vector<grbda_desc_body> bodies(m.bodies, m.bodies + nb);
+    std::vector<grbda_desc_cluster> clusters(nb);
+    std::vector<double> dbls;
+    span_q.assign(nb, 0);
+    span_v.assign(nb, 0);
+    int nq = 0, nv = 0;
+    for (int b = 0; b < nb; b++) {
+        grbda_desc_cluster &c = clusters[b];
+        std::memset(&c, 0, sizeof c);
+        const bool is_free = bodies[b].joint_type == GRBDA_JOINT_FREE;
+        c.parent_cluster = bodies[b].parent;  // one cluster per body: cluster index = body index
+        c.first_body = b;
+        c.n_bodies = 1;
+        c.q_index = nq;
+        c.v_index = nv;
+        c.n_pos = is_free ? (h.ori_repr == GRBDA_ORI_QUATERNION ? 7 : 6) : 1;
+        c.n_vel = is_free ? 6 : 1;
+        c.n_span_pos = c.n_pos;
+        c.n_span_vel = c.n_vel;
+        c.constraint_type = is_free ? GRBDA_CONSTRAINT_FREE : GRBDA_CONSTRAINT_STATIC;
+        c.n_constraint_rows = 0;
+        c.int_offset = 0;
+        c.n_int = 0;
+        c.dbl_offset = static_cast<int32_t>(dbls.size());
+        c.n_dbl = is_free ? 0 : 1;
+        if (!is_free) dbls.push_back(1.0);
+        span_q[b] = nq;
+        span_v[b] = nv;
+        nq += c.n_pos;
+        nv += c.n_vel;
+        bodies[b].cluster = b;
+        bodies[b].sub_index = 0;
+    }
+    h.n_clusters = nb;
+    h.nq = nq;
+    h.nv = nv;
+    h.n_ints = 0;
+    h.n_doubles = static_cast<int32_t>(dbls.size());
+    h.n_name_bytes = 0;
+    out.clear();
+    auto put = [&](const void *p, size_t n) { const auto *c = static_cast<const unsigned char *>(p); out.insert(out.end(), c, c + n); };
+    put(&h, sizeof h);
+    put(bodies.data(), sizeof(grbda_desc_body) * bodies.size());
+    put(clusters.data(), sizeof(grbda_desc_cluster) * clusters.size());
+    put(dbls.data(), sizeof(double) * dbls.size());
+    return 0;
+}
+}  // namespace grbda_hip

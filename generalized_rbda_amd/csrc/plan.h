@@ -456,4 +456,9 @@ struct HostPlan {
 int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep_mask, HostPlan &out,
                  char *msg, size_t msg_cap);
 
+// The spanning-tree model (every revolute body its own Revolute cluster) as a model-description blob; span_q / span_v: per body,
+// its first position / velocity index in that model (plan.cpp; capi.cpp manifold_derivs).
+int make_spanning_blob(const void *blob, size_t bytes, std::vector<unsigned char> &out, std::vector<int32_t> &span_q,
+                       std::vector<int32_t> &span_v, char *msg, size_t msg_cap);
+
 }  // namespace grbda_hip

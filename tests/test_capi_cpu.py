@@ -109,10 +109,11 @@ def test_chain_program_covers_the_headline_models():
         assert G.Plan(z[name]).info().chain_aba_f64 == 1, name
     ti = G.Plan(z["tello_with_arms"]).info()
     assert ti.chain_rnea_f32 == 1 and ti.n_chain_differentials == 4
-    # analytic derivatives (deriv_kernels.hip): explicit clusters
-    for name, want in (("urdf_jvrc1_humanoid", 1), ("urdf_mit_humanoid", 1), ("tree_mixed_fixed", 1), ("tree_generic_float", 1),
-                       ("tello_with_arms", 0), ("urdf_four_bar", 0), ("urdf_mini_cheetah_rpy", 1)):
-        assert G.Plan(z[name]).info().analytic_derivatives == want, name
+    # analytic derivatives: explicit clusters by the recursion of deriv_kernels.hip, implicit ones on the constraint manifold through
+    # the spanning tree (manifold_kernels.hip) -- nothing of the zoo takes differences
+    for name in ("urdf_jvrc1_humanoid", "urdf_mit_humanoid", "tree_mixed_fixed", "tree_generic_float", "tello_with_arms", "tello", "urdf_four_bar",
+                 "urdf_six_bar", "urdf_planar_leg_linkage", "urdf_mini_cheetah_rpy"):
+        assert G.Plan(z[name]).info().analytic_derivatives == 1, name
     # fixed-base chains of links (the reference's RevoluteChainWithRotor family, config 1's URDF) start their runs on the ground
     for name in ("rev_rotor_chain_3", "urdf_revolute_rotor_chain", "tree_rev_fixed", "rev_pair_rotor_chain_4"):
         info = G.Plan(z[name]).info()
