@@ -457,8 +457,8 @@ def main():
         "spread": {"replays": len(reps), "ms_per_step_min": min(reps) / max(args.steps, 1) * 1e3,
                    "ms_per_step_median": elapsed / max(args.steps, 1) * 1e3, "ms_per_step_max": max(reps) / max(args.steps, 1) * 1e3,
                    "value_min": total_states * args.steps / max(reps), "value_max": total_states * args.steps / min(reps)},
-        "inputs": {"distinct_states": n_distinct, "gate": "implicit clusters: max |Kd^-1 Ki| < 50 and |q_span| < 32 rad "
-                                                          "(generalized_rbda_amd/states.py)" if general else None},
+        "inputs": {"distinct_states": n_distinct, "gate": "implicit clusters: max |Kd^-1 Ki| < 150, cond(Kd) < 3000 and |q_span| < 32 rad "
+                                                          "(generalized_rbda_amd/states.py; profiles/r4_gate_f32_oracle.txt)" if general else None},
     }
     line.update(verify_sample(blob, q, qd, x, out, args.algo, dtype_name))
     if gather_ms is not None:

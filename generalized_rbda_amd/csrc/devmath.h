@@ -275,6 +275,30 @@ __device__ __forceinline__ void sincos_t(double x, double *s, double *c) { sinco
 __device__ __forceinline__ void sincos_precise(float x, float *s, float *c) { sincosf(x, s, c); }
 __device__ __forceinline__ void sincos_precise(double x, double *s, double *c) { sincos(x, s, c); }
 
+// Implicit constraints in fp32: Cody-Waite reduction to [-pi/4, pi/4] (two fused steps) and the cephes minimax polynomials, ~25
+// instructions and ~1 ulp for |x| < 1e4.  The hardware v_sin_f32 / v_cos_f32 behind sincos_t are about ten times less accurate
+// (|x| 6e-8 from the 1 / 2 pi scaling alone) and K_d^-1 amplifies that by the constraint's condition number -- measured against the
+// oracle compiled in `float` (profiles/r4_gate_f32_oracle.txt): with sincos_t the differential segments were 10x less accurate than
+// the dense float restatement, with these they match it; the library's sincosf costs ~155 instructions.
+__device__ __forceinline__ void sincos_cw(float x, float *s, float *c)
+{
+    const float k = __builtin_rintf(x * 0.636619772f);
+    float r = __builtin_fmaf(-k, 1.57079637f, x);
+    r = __builtin_fmaf(-k, -4.37113883e-8f, r);
+    const float z = r * r;
+    float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(z, sp, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(r * z, sp, r);
+    float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int n = (int)k;
+    const float a = (n & 1) ? cs : sn, b = (n & 1) ? sn : cs;
+    *s = (n & 2) ? -a : a;
+    *c = ((n + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ void sincos_cw(double x, double *s, double *c) { sincos(x, s, c); }
+
 // reciprocal and reciprocal square root: f32 takes the hardware approximations (1 ulp; the IEEE division
 // expands to ~10 instructions), f64 the exact operations
 __device__ __forceinline__ float rcp_t(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -74,11 +74,7 @@ __device__ __forceinline__ void gen_st1(const MM &M, int s, T v)
     reinterpret_cast<T *>(grbda_smem)[s * kWave + M.lane] = v;
 }
 
-// sin / cos of a joint angle of an implicit cluster.  The hardware approximations (devmath.h, sincos_t) unless
-// GRBDA_GEN_PRECISE: K and the body transforms use the SAME values, so phi's Jacobian is consistent with the kinematics.
-// f32: Cody-Waite reduction to [-pi/4, pi/4] (two fused steps) and the cephes minimax polynomials, ~25 instructions and ~1 ulp
-// for |x| < 1e4 -- the hardware v_sin_f32 / v_cos_f32 behind sincos_t are ten times less accurate (|x| 6e-8 from the 1 / 2 pi scaling
-// alone) and Kd^-1 amplifies that by the constraint's condition number; the library's sincosf costs ~155 instructions.
+// sin / cos of the joint angles of an implicit cluster: K and the body transforms use the SAME values (devmath.h, sincos_cw)
 __device__ __forceinline__ void gen_sincos(float x, float *s, float *c)
 {
 #ifdef GRBDA_GEN_PRECISE
@@ -86,20 +82,7 @@ __device__ __forceinline__ void gen_sincos(float x, float *s, float *c)
 #elif defined(GRBDA_GEN_HW_SINCOS)
     sincos_t(x, s, c);
 #else
-    const float k = __builtin_rintf(x * 0.636619772f);
-    float r = __builtin_fmaf(-k, 1.57079637f, x);
-    r = __builtin_fmaf(-k, -4.37113883e-8f, r);
-    const float z = r * r;
-    float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
-    sp = __builtin_fmaf(z, sp, -1.6666654611e-1f);
-    const float sn = __builtin_fmaf(r * z, sp, r);
-    float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
-    const float cs = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
-    const int n = (int)k;
-    const float a = (n & 1) ? cs : sn, b = (n & 1) ? sn : cs;
-    *s = (n & 2) ? -a : a;
-    *c = ((n + 1) & 2) ? -b : b;
+    sincos_cw(x, s, c);
 #endif
 }
 __device__ __forceinline__ void gen_sincos(double x, double *s, double *c) { sincos(x, s, c); }

@@ -10,21 +10,28 @@ Counter-based RNG (Philox), seed = 0x67726264 + config_index.
 
 Conditioning gate of the implicit-loop models (``accept``): the reference's sampler keeps whatever root its Newton
 solver lands on (CasADi ``rootfinder('newton')`` from a guess in U(-0.1, 0.1), GenericJoint.cpp:289-385; the only test
-is |phi| < 1e-8).  About 3 % of the roots it finds for the Tello differentials are poses no mechanism reaches: the
+is |phi| < 1e-8).  A few per cent of the roots it finds for the Tello differentials are poses no mechanism reaches: the
 solver has wandered tens to 10^5 radians away, or sits next to a singular pose of the linkage where the transmission
 ``X = -K_d^-1 K_i`` (normally ~N = 6) is 10^2 ... 10^3 and the bias acceleration ``g`` 10^5 ... 10^7 rad/s^2.  Such
 states amplify ANY rounding by ``|X|`` (velocities) and ``|X|^2`` (velocity products); they are valid inputs and the fp64
-path reproduces the oracle on them to 1e-9, but no single-precision evaluation -- the reference's own ``float``
-instantiation included -- can promise 1e-3 there.  The synthetic workloads therefore accept a state iff, for every
-implicit cluster,
+path reproduces the oracle on them to 1e-9 (tests/test_gpu_parity.py::test_ungated_implicit_states_fp64), but single
+precision cannot promise 1e-3 there.  That claim is MEASURED since round 4 (tools/gate_f32_oracle.py ->
+profiles/r4_gate_f32_oracle.txt): the oracle -- the dense restatement of the reference's algorithm -- compiled in ``float``
+is run beside the fp32 kernels on every state the gate rejects, both against the fp64 oracle.  Round 3's gate (gain < 50,
+cond < 1000) did NOT stand: the float oracle stayed below 1e-3 up to five times those limits while the kernels did not -- the
+kernels' closed-form 2 x 2 inverse of D = G^T Hc G (adjugate / determinant) cancelled when D is nearly rank one; with the
+factorisation that replaced it (chain_kernels.hip, diff_bwd / pair_bwd_k) the kernels match the float oracle (max error over
+60 000 gated Tello states 2.4e-5 both) and the gate is three times wider:
 
-    max |K_d^-1 K_i| < GATE_GMAX = 50,     |K_d|_F |K_d^-1|_F < GATE_KCOND = 1000,     max |q_span| < GATE_QMAX = 32 rad
+    max |K_d^-1 K_i| < GATE_GMAX = 150,     |K_d|_F |K_d^-1|_F < GATE_KCOND = 3000,     max |q_span| < GATE_QMAX = 32 rad
 
-(an fp32 angle of magnitude a carries an absolute error ~6e-8 a; times the gain 50 and the ~10 terms of a constraint
-row this stays under 1e-3 up to a ~ 32.  The condition number catches what the gain does not: next to a CHANGE POINT of
-a linkage -- the flat pose of four_bar.urdf's parallelogram -- K_d^-1 K_i stays at its regular value, 3, while K_d
-itself becomes singular; 0.1 % of the four-bar states have cond > 1000 and fp32 errors up to 6e-3.)  Measured on 1 048 576 TelloWithArms states (tools/tello_acc.py): 96.5 %
-accepted; fp32 vs fp64 over the accepted ones max 2.5e-4 (ABA), 1.8e-5 (RNEA); over the rejected ones up to 0.18.
+Up to five times round 3's limits the fp32 kernels stay below 7.4e-4 on 143 362 converged Tello draws and 7.7e-4 on 1 047 690
+four-bar draws (the float oracle: 3.2e-4 / 3.0e-4); a full batch of 1 048 576 DISTINCT accepted Tello states at five times reached
+1.2e-3 on one state, hence three; between 5 and 10 times the FLOAT ORACLE ITSELF reaches 1.2e-3 (Tello) / 1.1e-3 (four_bar), beyond
+it 3e-3 and more, and past |q| = 32 rad 2.4e-2 (an fp32 angle of magnitude a carries an absolute error ~6e-8 a): far outside the
+gate single precision is the limit, not a kernel.  The condition number catches what the gain does not: next to a CHANGE POINT of a
+linkage -- the flat pose of four_bar.urdf's parallelogram -- K_d^-1 K_i stays at its regular value, 3, while K_d itself becomes
+singular.  With the wider gate ~99 % of the converged Tello roots and 99.8 % of the four-bar roots are accepted.
 ONE definition, used by the oracle-side sampler of the tests (tests/models.py), the device-side sampler below, the
 full-size tests and bench.py alike; explicit models are not affected (no state-dependent G).
 """
@@ -37,8 +44,8 @@ import numpy as np
 from .modeldesc import C_FREE, C_LOOP_POSITION, C_STATIC, C_TRIG_POLY, ORI_QUATERNION, rotmat_to_quat, rpy_to_rotmat
 
 SEED_BASE = 0x67726264
-GATE_GMAX = 50.0
-GATE_KCOND = 1000.0
+GATE_GMAX = 150.0
+GATE_KCOND = 3000.0
 GATE_QMAX = 32.0
 
 
@@ -123,23 +130,30 @@ def has_implicit_clusters(blob: bytes) -> bool:
 
 
 def valid_random_states_device(plan, B: int, config_index: int, device, dtype=np.float64):
-    """random_states, and for models with implicit clusters: Newton projection ON THE DEVICE (grbda_project_positions),
-    the conditioning gate on the device's own gain (grbda_state_to_independent), rejected states replaced by accepted
-    ones in order.  Returns (q, qd, tau, n_distinct)."""
+    """random_states, and for models with implicit clusters: Newton projection ON THE DEVICE (grbda_project_positions) and the
+    conditioning gate on the device's own gain (grbda_state_to_independent); states that do not converge or do not pass are
+    REPLACED BY FRESH DRAWS (further Philox streams, seed + 7919 per round) until B distinct accepted states exist.
+    Returns (q, qd, tau, n_distinct) with n_distinct == B."""
     import torch
 
     blob = plan.blob
-    q, qd, tau = random_states(blob, B, config_index)
-    n_distinct = B
-    if has_implicit_clusters(blob):
+    if not has_implicit_clusters(blob):
+        q, qd, tau = random_states(blob, B, config_index)
+        return q.astype(dtype), qd.astype(dtype), tau.astype(dtype), B
+    qs, qds, taus, have = [], [], [], 0
+    for attempt in range(200):
+        n_draw = B if attempt == 0 else max(min(B, 2 * (B - have) * max(1, attempt)), 4096)
+        q, qd, tau = random_states(blob, n_draw, config_index + 7919 * attempt)
         t64 = torch.as_tensor(q, dtype=torch.float64, device=device)
         ok = plan.project_positions(t64).cpu().numpy()
         gmax, kcond, status = plan.constraint_gain(t64)
         q = t64.cpu().numpy()
         ok &= (status.cpu().numpy() == 0) & accept(blob, q, gmax.cpu().numpy(), kcond.cpu().numpy())
-        good, bad = np.flatnonzero(ok), np.flatnonzero(~ok)
-        if good.size == 0:
-            raise RuntimeError("no random state passed the Newton projection and the conditioning gate")
-        q[bad] = q[good[np.arange(bad.size) % good.size]]
-        n_distinct = int(good.size)
-    return q.astype(dtype), qd.astype(dtype), tau.astype(dtype), n_distinct
+        qs.append(q[ok]); qds.append(qd[ok]); taus.append(tau[ok])
+        have += int(ok.sum())
+        if have >= B:
+            break
+    if have < B:
+        raise RuntimeError(f"only {have} of {B} random states passed the Newton projection and the conditioning gate")
+    q, qd, tau = np.concatenate(qs)[:B], np.concatenate(qds)[:B], np.concatenate(taus)[:B]
+    return q.astype(dtype), qd.astype(dtype), tau.astype(dtype), B
