@@ -57,11 +57,14 @@ VARIANT ?= v
 VFLAGS ?=
 U1FLAGS ?=
 U2FLAGS ?=
-variant: $(OBJ)/chain_kernels_u2.o $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+# (VFLAGS=-DGRBDA_EXP also compiles the ablation switches GRBDA_CHAIN_DEBUG / GRBDA_DEBUG_SWEEPS into the variant: the product
+# library ignores them)
+variant: $(OBJ)/chain_kernels_u2.o $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	@mkdir -p build/variants
+	$(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/capi.cpp -o build/variants/capi_$(VARIANT).o
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_$(VARIANT).o
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -DGRBDA_CHAIN_UNIT=1 $(U1FLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_u1_$(VARIANT).o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/libgrbda_hip_$(VARIANT).so build/variants/chain_kernels_$(VARIANT).o build/variants/chain_kernels_u1_$(VARIANT).o $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/libgrbda_hip_$(VARIANT).so build/variants/chain_kernels_$(VARIANT).o build/variants/chain_kernels_u1_$(VARIANT).o build/variants/capi_$(VARIANT).o $^
 
 $(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^

@@ -49,6 +49,19 @@ WORKLOADS = {
 }
 
 
+def kernel_sources_sha():
+    """sha256 (16 hex digits) over the device-side sources of the library: the PMC files under profiles/ carry the value they were
+    taken on (tools/collect_profiles.py), and counters of other sources are refused below instead of printed next to a fresh time."""
+    import glob, hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "generalized_rbda_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def physical_cores():
     """distinct (package, core) pairs of /proc/cpuinfo; falls back to the logical count"""
     try:
@@ -270,8 +283,19 @@ def main():
     # on the device, then the conditioning gate of states.py; rejected states are replaced by accepted ones (input
     # generation only, outside the timed region).
     if args.scaling == "strong":
-        # ONE global batch, the same on every rank; this rank computes its contiguous slab (sharding.shard_range)
-        q, qd, x, n_distinct = valid_random_states_device(plan, B_global, cfg, dev)
+        # ONE global batch; rank 0 draws (and Newton-projects) it, the others receive it; this rank computes its contiguous slab
+        # (sharding.shard_range)
+        import numpy as np
+
+        if rank == 0 or dist is None:
+            q, qd, x, n_distinct = valid_random_states_device(plan, B_global, cfg, dev)
+        else:
+            q, qd, x, n_distinct = np.empty((B_global, plan.nq)), np.empty((B_global, plan.nv)), np.empty((B_global, plan.nv)), B_global
+        if dist is not None and world > 1:
+            for a in (q, qd, x):
+                tb = torch.as_tensor(a, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.broadcast(tb, src=0)
+                a[...] = tb.cpu().numpy()
         lo, hi = shard_range(B_global, rank, world)
         q, qd, x = q[lo:hi], qd[lo:hi], x[lo:hi]
         B = hi - lo
@@ -384,40 +408,43 @@ def main():
     achieved_gbs = kernel_evals_per_s * bytes_per_eval / 1e9
     flops = info.flops_aba if args.algo == "aba" else info.flops_rnea
     # measured HBM-side traffic of the same launch configuration, if a PMC run is committed (profiles/)
-    traffic, traffic_src = None, None
-    for fname in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    # (only counters taken on THESE kernel sources: a file records the sha of the sources it was measured on)
+    sha = kernel_sources_sha()
+    traffic, traffic_src, stale = None, None, []
+    for fname in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fname)) as f:
-                for e in json.load(f)["entries"]:
-                    if traffic is None and (e["workload"], e["algo"], e["dtype"], e["batch"]) == (args.workload, args.algo, dtype_name, B):
-                        traffic = e["bytes_per_launch"]
-                        traffic_src = f"rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/{fname}"
+                doc = json.load(f)
+            if doc.get("kernel_sources_sha") != sha:
+                stale.append(fname)
+                continue
+            for e in doc["entries"]:
+                if traffic is None and (e["workload"], e["algo"], e["dtype"], e["batch"]) == (args.workload, args.algo, dtype_name, B):
+                    traffic = e["bytes_per_launch"]
+                    traffic_src = f"rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/{fname} (kernel sources {sha})"
         except (OSError, KeyError, ValueError):
             pass
+    if traffic is None and stale:
+        traffic_src = f"no counters for kernel sources {sha}: {', '.join('profiles/' + x for x in stale)} were taken on other sources (refused)"
     # executed floating-point operations per evaluation from the committed instruction counters of the same launch
     # configuration (2 x FMA + ADD + MUL + TRANS, x 64 lanes / batch), beside the plan compiler's operation model
     flops_pmc, flops_pmc_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r3_pmc_flops.json")) as f:
-            for e in json.load(f)["entries"]:
-                if (e["workload"], e["algo"], e["dtype"]) == (args.workload, args.algo, dtype_name):
-                    flops_pmc, flops_pmc_src = e["flops_per_eval"], "profiles/r3_pmc_flops.json: " + e["source"]
-    except (OSError, KeyError, ValueError):
-        pass
+    for fname in ("r4_pmc_flops.json", "r3_pmc_flops.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                doc = json.load(f)
+            if doc.get("kernel_sources_sha") != sha:
+                continue
+            for e in doc["entries"]:
+                if flops_pmc is None and (e["workload"], e["algo"], e["dtype"]) == (args.workload, args.algo, dtype_name):
+                    flops_pmc, flops_pmc_src = e["flops_per_eval"], f"profiles/{fname}: " + e["source"]
+        except (OSError, KeyError, ValueError):
+            pass
     from generalized_rbda_amd.states import parse_clusters
 
     general = any(c[9] >= 2 for c in parse_clusters(blob)["clusters"])
-    tname = "float" if dtype_name == "f32" else "double"
-    chain = (info.chain_aba_f32 if dtype_name == "f32" else info.chain_aba_f64) and args.algo == "aba"
-    rchain = (info.chain_rnea_f32 if dtype_name == "f32" else info.chain_rnea_f64) and args.algo == "rnea"
-    # (differential clusters -- TelloWithArms -- are the `true` variants of the chain kernels, chain_kernels.hip)
-    # (batches of at most one tile per SIMD: the latency-mode kernel, a tile per workgroup of two wavefronts)
-    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    lm = (info.latency_mode_f32 if dtype_name == "f32" else info.latency_mode_f64) and args.algo == "aba" and (B + 63) // 64 <= 4 * n_cu
-    kernel_name = (f"grbda_hip::aba_chain_lm_kernel<{tname}>" if lm
-                   else f"grbda_hip::aba_chain_kernel<{tname}, 2, {'true' if general else 'false'}>" if chain
-                   else f"grbda_hip::rnea_chain_kernel<{tname}, {'true' if general else 'false'}>" if rchain
-                   else f"grbda_hip::{args.algo}_kernel<{tname}, {'true' if general else 'false'}>")
+    # the kernel this batch ran on, from the library's own selection (grbda_kernel_name)
+    kernel_name = plan.kernel_name(args.algo, dtype_name, B, dev.index or 0)
     line = {
         "metric": "forward-dynamics evals/sec (batched random states), MIT Humanoid cluster model"
         if args.workload == "mit_humanoid" and args.algo == "aba"

@@ -34,7 +34,7 @@ C_ABI_SYMBOLS = [
     "grbda_mass_matrix_host_f64", "grbda_fd_derivatives_host_f64",
     "grbda_body_twists_f64", "grbda_body_twists_f32", "grbda_body_twists_host_f64",
     "grbda_state_input_dims", "grbda_state_to_independent_f64", "grbda_state_to_independent_f32",
-    "grbda_state_to_independent_host_f64",
+    "grbda_state_to_independent_host_f64", "grbda_spd_bad_pivots", "grbda_kernel_name",
 ]
 
 
@@ -199,6 +199,12 @@ class Plan:
         info = PlanInfo()
         _check(lib().grbda_plan_info(self._h, byref(info)))
         return info
+
+    def kernel_name(self, algo: str, dtype: str, B: int, device: int = 0) -> str:
+        """The kernel forward ("aba") / inverse ("rnea") dynamics launch for B states in "f32" / "f64" (grbda_kernel_name)."""
+        buf = ctypes.create_string_buffer(256)
+        _check(lib().grbda_kernel_name(self._h, 0 if algo == "aba" else 1, 32 if dtype == "f32" else 64, ctypes.c_size_t(B), int(device), buf, 256))
+        return buf.value.decode()
 
     # ---- batched dynamics on torch device tensors ------------------------------------------------
     def _launch(self, which: str, q, qd, x, out=None, stream=None, f_ext=None):
@@ -548,3 +554,11 @@ class Plan:
 
 def device_count() -> int:
     return lib().grbda_device_count()
+
+
+def spd_bad_pivots(device: int = 0, reset: bool = True) -> int:
+    """States whose joint-space inertia was not positive definite in the SPD solves of the derivative entry points since the
+    last reset (their results are NaN / Inf); synchronises the device (grbda_spd_bad_pivots)."""
+    n = ctypes.c_ulonglong(0)
+    _check(lib().grbda_spd_bad_pivots(int(device), ctypes.byref(n), 1 if reset else 0))
+    return int(n.value)

@@ -251,6 +251,7 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_err(e, "hipGetDeviceProperties");
     t.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = set_max_dynamic_lds()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
+    if ((e = set_max_dynamic_lds_deriv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     auto ins = p->dev.emplace(device, t);
     *out = &ins.first->second;
     return 0;
@@ -276,6 +277,28 @@ int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, 
         }
         hipError_t e = hipMalloc(&s.ptr, bytes);
         if (e != hipSuccess) return hip_err(e, "hipMalloc(scratch)");
+        s.bytes = bytes;
+    }
+    *out = s.ptr;
+    return 0;
+}
+
+// The per-(device, stream) work slab of the derived quantities, grown on demand under the same rule as ensure_scratch: never
+// while the stream captures (a graph captured earlier holds the old address).
+int ensure_work(const grbda_plan *p, std::map<std::pair<int, void *>, Scratch> &pool, int device, void *stream, size_t bytes, void **out)
+{
+    std::lock_guard<std::recursive_mutex> lk(p->mu);
+    Scratch &s = pool[{device, stream}];
+    if (s.bytes < bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return set_err(GRBDA_EINVAL, "a per-stream work buffer would have to grow during stream capture: run the largest batch once on "
+                                         "this stream before capturing");
+        hipError_t e;
+        if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
+        s.ptr = nullptr;
+        s.bytes = 0;
+        if ((e = hipMalloc(&s.ptr, bytes)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
         s.bytes = bytes;
     }
     *out = s.ptr;
@@ -320,18 +343,54 @@ bool chain_covers(const grbda_plan *p)
     return p->host.chain32.ok || (p->host.chain32w.ok && p->host.chain32w.diffs.empty() && p->host.chain32w.gens.empty() && p->chain_wide);
 }
 
+// which forward-dynamics kernel a batch of B states runs on a device with n_cu compute units: ONE definition, used by the launch
+// path below and by grbda_kernel_name (bench.py prints the name next to the roofline figures)
+enum AbaPath { ABA_GEN1, ABA_LM, ABA_CHAIN_WIDE, ABA_CHAIN, ABA_INTERPRETER };
+template <class T>
+size_t lm_lds_bytes(const grbda_plan *p)
+{
+    const HostPlan &h = p->host;
+    const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
+    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
+    const size_t lds_lm = static_cast<size_t>(lp.n_lds) * kWave * sizeof(T);
+    return lds_lm < stage_all ? stage_all : lds_lm;
+}
+template <class T>
+size_t gen1_lds_bytes(const grbda_plan *p)
+{
+    const HostPlan &h = p->host;
+    const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
+    return static_cast<size_t>(sp.n_lds) * kWave * sizeof(T) + 2 * static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
+}
+template <class T>
+AbaPath choose_aba(const grbda_plan *p, int n_cu, size_t B, bool f_ext)
+{
+    const HostPlan &h = p->host;
+    if (f_ext || !chain_covers<T>(p)) return ABA_INTERPRETER;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
+    if (sp.ok && sp.single_gen && !p->chain_debug && gen1_lds_bytes<T>(p) <= 65536) return ABA_GEN1;
+    const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
+    if (lp.ok && !p->no_latency_mode && !p->chain_debug && n_tiles <= static_cast<size_t>(n_cu) * 4 && n_tiles > 0 && lm_lds_bytes<T>(p) <= 40960)
+        return ABA_LM;
+    const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && h.chain32w.gens.empty() && p->chain_wide &&
+                      (!h.chain32.ok || n_tiles > static_cast<size_t>(n_cu) * 8);
+    return wide ? ABA_CHAIN_WIDE : ABA_CHAIN;
+}
+
 template <class T>
 int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *qd, const T *tau, T *ydd, size_t B,
               int device, void *stream)
 {
     const HostPlan &h = p->host;
     const size_t n_tiles0 = (B + kWave - 1) / kWave;
+    const AbaPath path = choose_aba<T>(p, t.n_cu, B, false);
     {   // single-cluster programs: the fused, slab-free kernel (chain_kernels.hip, aba_gen1_kernel)
         const int w1 = sizeof(T) == 8 ? 2 : 0;
         const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
         const size_t work = static_cast<size_t>(sp.n_lds) * kWave * sizeof(T);
-        const size_t lds_total = work + 2 * static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);  // two input buffers
-        if (sp.ok && sp.single_gen && !p->chain_debug && lds_total <= 65536) {
+        const size_t lds_total = gen1_lds_bytes<T>(p);  // work area + two input buffers
+        if (path == ABA_GEN1) {
             ChainDev<T> d;
             std::memset(&d, 0, sizeof d);
             d.gens = t.chain_gens[w1];
@@ -360,10 +419,8 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     // keeps the ordinary kernel (A/B runs); results agree to rounding (the base sums one partial inertia per wavefront).
     {
         const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
-        const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
-        size_t lds_lm = static_cast<size_t>(lp.n_lds) * kWave * sizeof(T);
-        if (lds_lm < stage_all) lds_lm = stage_all;
-        if (lp.ok && !p->no_latency_mode && !p->chain_debug && n_tiles0 <= static_cast<size_t>(t.n_cu) * 4 && n_tiles0 > 0 && lds_lm <= 40960) {
+        const size_t lds_lm = lm_lds_bytes<T>(p);
+        if (path == ABA_LM) {
             const int w = sizeof(T) == 8 ? 4 : 3;
             ChainDev<T> d;
             d.segs = t.chain_segs[w];
@@ -397,8 +454,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
         }
     }
     // f32: four wavefronts per SIMD (16 per CU, half the LDS each) once the batch fills them, when that layout exists
-    const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && h.chain32w.gens.empty() && p->chain_wide &&
-                      (!h.chain32.ok || n_tiles0 > static_cast<size_t>(t.n_cu) * 8);
+    const bool wide = path == ABA_CHAIN_WIDE;
     const int w = sizeof(T) == 8 ? 2 : (wide ? 1 : 0);
     const int kid = sizeof(T) == 8 ? 1 : 0;
     const ChainProgram &cp = w == 2 ? h.chain64 : (wide ? h.chain32w : h.chain32);
@@ -737,20 +793,7 @@ int twists(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *V, siz
     if (int rc = ensure_device(p, device, &t)) return rc;
     const size_t ns = static_cast<size_t>(span_count(p));
     void *wptr = nullptr;
-    {
-        std::lock_guard<std::recursive_mutex> lk(p->mu);
-        Scratch &s = p->work[{device, stream}];
-        const size_t need = 2 * B * ns * sizeof(T) + 256;
-        if (s.bytes < need) {
-            hipError_t e;
-            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
-            s.ptr = nullptr;
-            s.bytes = 0;
-            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
-            s.bytes = need;
-        }
-        wptr = s.ptr;
-    }
+    if (int rc = ensure_work(p, p->work, device, stream, 2 * B * ns * sizeof(T) + 256, &wptr)) return rc;
     T *vs = static_cast<T *>(wptr), *as = vs + B * ns;
     if (int rc = spanning<T>(p, q, qd, ydd, vs, as, B, device, stream)) return rc;
     DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
@@ -826,20 +869,7 @@ int test_force(const grbda_plan *p, const T *q, int body, const double *offset, 
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     void *wptr = nullptr;
-    {
-        std::lock_guard<std::recursive_mutex> lk(p->mu);
-        Scratch &s = p->work[{device, stream}];
-        const size_t need = chunk * per_state * sizeof(T) + 256;
-        if (s.bytes < need) {
-            hipError_t e;
-            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
-            s.ptr = nullptr;
-            s.bytes = 0;
-            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
-            s.bytes = need;
-        }
-        wptr = s.ptr;
-    }
+    if (int rc = ensure_work(p, p->work, device, stream, chunk * per_state * sizeof(T) + 256, &wptr)) return rc;
     T *Xa = static_cast<T *>(wptr);
     T *fext = Xa + chunk * nbod * 12;
     T *zero = fext + chunk * nbod * 6;
@@ -1131,20 +1161,7 @@ int inv_osim(const grbda_plan *p, const T *q, int n_contacts, const int *bodies,
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     void *wptr = nullptr;
-    {
-        std::lock_guard<std::recursive_mutex> lk(p->mu);
-        Scratch &s = p->work[{device, stream}];
-        const size_t need = chunk * per_state * sizeof(T) + 256;
-        if (s.bytes < need) {
-            hipError_t e;
-            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
-            s.ptr = nullptr;
-            s.bytes = 0;
-            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
-            s.bytes = need;
-        }
-        wptr = s.ptr;
-    }
+    if (int rc = ensure_work(p, p->work, device, stream, chunk * per_state * sizeof(T) + 256, &wptr)) return rc;
     const size_t rows = chunk * R;
     T *Xa = static_cast<T *>(wptr);
     T *qx = Xa + chunk * nbod * 12;
@@ -1318,20 +1335,7 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
     if (chunk > B) chunk = B;
     const size_t rows = chunk * static_cast<size_t>(R);
     void *wptr = nullptr;
-    {
-        std::lock_guard<std::recursive_mutex> lk(p->mu);
-        Scratch &s = p->work[{device, stream}];
-        const size_t need = rows * row_scalars * sizeof(T) + 256;
-        if (s.bytes < need) {
-            hipError_t e;
-            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
-            s.ptr = nullptr;
-            s.bytes = 0;
-            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
-            s.bytes = need;
-        }
-        wptr = s.ptr;
-    }
+    if (int rc = ensure_work(p, p->work, device, stream, rows * row_scalars * sizeof(T) + 256, &wptr)) return rc;
     T *qx = static_cast<T *>(wptr);
     T *qdx = qx + rows * nq;
     T *xx = qdx + rows * nv;
@@ -1409,23 +1413,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const size_t b_round = (B + kWave - 1) / kWave * kWave;
     if (chunk > b_round) chunk = b_round;
     void *wptr = nullptr;
-    {
-        std::lock_guard<std::recursive_mutex> lk(p->mu);
-        Scratch &s = p->work[{device, stream}];
-        const size_t need = chunk * per_state * sizeof(T) + 256;
-        if (s.bytes < need) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-                return set_err(GRBDA_EINVAL, "the derivative workspace would have to grow during stream capture: run the largest batch once first");
-            hipError_t e;
-            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
-            s.ptr = nullptr;
-            s.bytes = 0;
-            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
-            s.bytes = need;
-        }
-        wptr = s.ptr;
-    }
+    if (int rc = ensure_work(p, p->work, device, stream, chunk * per_state * sizeof(T) + 256, &wptr)) return rc;
     T *w = static_cast<T *>(wptr);
     auto take = [&](size_t per) { T *r = w; w += chunk * per; return r; };
     T *q_s = take(nq_s), *qd_s = take(nv_s), *qdd_s = take(nv_s), *tau_s = take(nv_s), *zeros = take(nv), *cpl = take(p->n_cpl_rows);
@@ -1517,32 +1505,20 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const bool need_d = dq || dqd;
     // H is built in the caller's d/dtau array when that is wanted (the factor is out of it before H^-1 goes in); dID/dq and
     // dID/dqd in rnea_deriv_kernel's packed layout, the H nobody asked for, and ydd take workspace
-    const bool h_in_place = dtau && (B % kDerivGroup) == 0;
+    const bool wide0 = sizeof(T) == 4 && p->solve_f64;
+    const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
+    const int il = (need_d && !wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
+    // (only an INTERLEAVED H block can reach past the caller's array: the state-major layouts always build H in place)
+    const bool h_in_place = dtau && (il == 1 || (B % kDerivGroup) == 0);
     const size_t per_state = (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
     size_t chunk = (2048ull << 20) / (per_state ? per_state * sizeof(T) : 1);
     chunk &= ~static_cast<size_t>(kWave - 1);  // whole tiles, whole groups of the interleaved workspace
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     if (chunk > B) chunk = (B + kDerivGroup - 1) / kDerivGroup * kDerivGroup;  // (the last group of the workspace is allocated whole)
     // f32 with the matrix-core solve: the recursion writes H, dID/dq, dID/dqd interleaved by groups of kDerivGroup states
-    // (deriv_kernels.hip); every other combination keeps the state-major layout
-    const bool wide0 = sizeof(T) == 4 && p->solve_f64;
-    const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
-    const int il = (need_d && !wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
+    // (deriv_kernels.hip); every other combination keeps the state-major layout (il, above)
     void *wptr = nullptr;
-    {
-        std::lock_guard<std::recursive_mutex> lk(p->mu);
-        Scratch &s = p->work[{device, stream}];
-        const size_t need = chunk * per_state * sizeof(T) + 256;
-        if (s.bytes < need) {
-            hipError_t e;
-            if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
-            s.ptr = nullptr;
-            s.bytes = 0;
-            if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
-            s.bytes = need;
-        }
-        wptr = s.ptr;
-    }
+    if (int rc = ensure_work(p, p->work, device, stream, chunk * per_state * sizeof(T) + 256, &wptr)) return rc;
     T *wnext = static_cast<T *>(wptr);
     auto take = [&](bool wanted) -> T * {
         if (!wanted) return nullptr;
@@ -1559,7 +1535,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         const size_t n_tiles = (nb + kWave - 1) / kWave;
         // (an interleaved H block spans the slots of a whole group: when the batch does not end on a group boundary the last
         // group would reach past the caller's d/dtau array, so that H goes to the workspace)
-        T *H = (dtau && !(il > 1 && (B % kDerivGroup) != 0)) ? dtau + b0 * nn : wH;
+        T *H = h_in_place ? dtau + b0 * nn : wH;
         hipError_t e = hipSuccess;
         // (both kernels write H as packed rows of its lower triangle; the solve reads it through DerivProgram::related, so
         // nothing is cleared)
@@ -1620,6 +1596,43 @@ int manifold_mass(const grbda_plan *p, const T *q, T *H, size_t B, int device, v
     GRBDA_CALL_SCOPE(p);
     if (!manifold_covers<T>(p)) return 1;
     return manifold_derivs<T>(p, q, nullptr, nullptr, nullptr, nullptr, nullptr, H, B, device, stream);
+}
+
+template <class T>
+static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_t B)
+{
+    const HostPlan &h = p->host;
+    const char *tn = sizeof(T) == 4 ? "float" : "double";
+    char buf[160];
+    if (kind == 0) {
+        const ChainProgram &cp = sizeof(T) == 8 ? h.chain64 : h.chain32;
+        switch (choose_aba<T>(p, n_cu, B, false)) {
+            case ABA_GEN1:
+                std::snprintf(buf, sizeof buf, "grbda_hip::aba_gen1_kernel<%s, %d, %s, %d>", tn, cp.gens[0].n, cp.gens[0].kind ? "true" : "false",
+                              gen1_waves_per_simd<T>(cp.gens[0].n));
+                return buf;
+            case ABA_LM: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s>", tn); return buf;
+            case ABA_CHAIN_WIDE: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, 4, 0>", tn); return buf;
+            case ABA_CHAIN:
+                std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, 2, %d>", tn, !cp.gens.empty() ? 2 : (!cp.diffs.empty() ? 1 : 0));
+                return buf;
+            default: break;
+        }
+        bool loop = false;
+        for (const ClusterRec &cr : h.lay64.clusters) loop = loop || cr.kind == CK_LOOP;
+        std::snprintf(buf, sizeof buf, "grbda_hip::aba_kernel<%s, %s>", tn, loop ? "true" : "false");
+        return buf;
+    }
+    const bool chain = !p->no_chain && (sizeof(T) == 8 ? h.rchain64.ok : h.rchain32.ok);
+    if (chain) {
+        const RneaChainProgram &rp = sizeof(T) == 8 ? h.rchain64 : h.rchain32;
+        std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_kernel<%s, %s, %s>", tn, rp.diffs.empty() ? "false" : "true", rp.n_glb > 0 ? "true" : "false");
+        return buf;
+    }
+    bool loop = false;
+    for (const ClusterRec &cr : h.lay64.clusters) loop = loop || cr.kind == CK_LOOP;
+    std::snprintf(buf, sizeof buf, "grbda_hip::rnea_kernel<%s, %s>", tn, loop ? "true" : "false");
+    return buf;
 }
 
 // ---- one process, several devices: contiguous batch shards, plan replicated ------------------------
@@ -1737,7 +1750,13 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;
     p->no_latency_mode = env_int("GRBDA_NO_LATENCY_MODE", 0) != 0;
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
+#ifdef GRBDA_EXP
+    // ablation switches of tools/chain_ablate.py: results are WRONG when set, so the product library does not read them -- only
+    // the experiment builds do (make variant VFLAGS=-DGRBDA_EXP)
     p->chain_debug = env_int("GRBDA_CHAIN_DEBUG", 0);
+#else
+    p->chain_debug = 0;
+#endif
     p->no_crba = env_int("GRBDA_NO_CRBA", 0) != 0;
     p->rnea_narrow = env_int("GRBDA_RNEA_NARROW", 0) != 0;
     p->no_analytic = env_int("GRBDA_NO_ANALYTIC", 0) != 0;
@@ -1753,7 +1772,11 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     lds.chain32w = 10240 / (4 * kWave);
     // profiling aid (results are wrong when set): GRBDA_DEBUG_SWEEPS is a bit mask of the ABA sweeps to
     // keep -- 1 forward, 2 backward, 4 acceleration -- so that the cost of each sweep can be ablated
+#ifdef GRBDA_EXP
     const int sweeps = env_int("GRBDA_DEBUG_SWEEPS", 7);
+#else
+    const int sweeps = 7;
+#endif
     int rc = compile_plan(blob, bytes, lds, sweeps, p->host, msg, sizeof msg);
     if (rc) return set_err(rc, msg);
     p->blob.assign(static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + bytes);
@@ -1996,17 +2019,9 @@ int grbda_fd_dq_f32(const grbda_plan *p, const float *q, const float *qd, const 
     size_t chunk = (64u << 20) / (per_state * sizeof(double));
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
-    Scratch &s = p->work_cvt[{device, stream}];
-    const size_t need = chunk * per_state * sizeof(double) + 256;
-    if (s.bytes < need) {
-        hipError_t e;
-        if (s.ptr && (e = hipFree(s.ptr)) != hipSuccess) return hip_err(e, "hipFree");
-        s.ptr = nullptr;
-        s.bytes = 0;
-        if ((e = hipMalloc(&s.ptr, need)) != hipSuccess) return hip_err(e, "hipMalloc(work)");
-        s.bytes = need;
-    }
-    double *q64 = static_cast<double *>(s.ptr), *qd64 = q64 + chunk * nq, *tau64 = qd64 + chunk * nv, *J64 = tau64 + chunk * nv;
+    void *cvt = nullptr;
+    if (int rc = ensure_work(p, p->work_cvt, device, stream, chunk * per_state * sizeof(double) + 256, &cvt)) return rc;
+    double *q64 = static_cast<double *>(cvt), *qd64 = q64 + chunk * nq, *tau64 = qd64 + chunk * nv, *J64 = tau64 + chunk * nv;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     auto blocks = [](size_t n) { return static_cast<int>((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535); };
     for (size_t b0 = 0; b0 < B; b0 += chunk) {
@@ -2042,6 +2057,27 @@ int grbda_fd_derivatives_f32(const grbda_plan *p, const float *q, const float *q
     if (dqd) if (const int r2 = grbda_fd_dqd_f32(p, q, qd, tau, dqd, B, device, stream)) return r2;
     if (dq) if (const int r2 = grbda_fd_dq_f32(p, q, qd, tau, 1e-6, dq, B, device, stream)) return r2;
     return GRBDA_OK;
+}
+int grbda_kernel_name(const grbda_plan *p, int kind, int precision, size_t B, int device, char *buf, size_t cap)
+{
+    if (!p || !buf || cap == 0 || (kind != 0 && kind != 1) || (precision != 32 && precision != 64)) return set_err(GRBDA_EINVAL, "bad argument");
+    GRBDA_CALL_SCOPE(p);
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const std::string name = precision == 32 ? kernel_name_of<float>(p, kind, t->n_cu, B) : kernel_name_of<double>(p, kind, t->n_cu, B);
+    std::snprintf(buf, cap, "%s", name.c_str());
+    return GRBDA_OK;
+}
+int grbda_spd_bad_pivots(int device, unsigned long long *count, int reset)
+{
+    if (!count) return set_err(GRBDA_EINVAL, "null argument");
+    DeviceGuard device_guard_;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(GRBDA_ENODEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return set_err(GRBDA_EINVAL, "device index out of range");
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = spd_bad_pivots(count, reset);
+    return e == hipSuccess ? GRBDA_OK : hip_err(e, "grbda_spd_bad_pivots");
 }
 int grbda_body_twists_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, double *V, size_t B, int device,
                           void *stream)

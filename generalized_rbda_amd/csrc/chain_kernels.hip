@@ -1490,8 +1490,13 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     ChainMem<T> M;
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
-    M.gmul = (DP.debug & 8) ? 0 : 1;
-    M.amask = (DP.debug & 16) ? kSlotGlobal : ~0;
+#ifdef GRBDA_EXP  // ablation builds only (make variant VFLAGS=-DGRBDA_EXP): the product kernels carry no wrong-result switches
+    const int dbg = DP.debug;
+#else
+    constexpr int dbg = 0;
+#endif
+    M.gmul = (dbg & 8) ? 0 : 1;
+    M.amask = (dbg & 16) ? kSlotGlobal : ~0;
     M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
     M.in_q_u = slab;
     M.in_qd_u = slab + (size_t)P.nq * kWave;
@@ -1505,8 +1510,8 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
         // (DP.debug: profiling aid of tools/chain_ablate.py -- bit 0 skips the prologue, bit 1 the segments, bit 2 the
         // epilogue; results are then meaningless)
-        if (!(DP.debug & 1)) stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
-        for (int s = 0; s < ((DP.debug & 2) ? 0 : P.n_segs); s++) {
+        if (!(dbg & 1)) stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        for (int s = 0; s < ((dbg & 2) ? 0 : P.n_segs); s++) {
             const ChainSeg sg = load_rec(P.segs + s);
             switch (sg.op) {
                 case SEG_RUN_FWD:
@@ -1543,7 +1548,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
-        if (!(DP.debug & 4)) {
+        if (!(dbg & 4)) {
             if (M.out_row >= 0) write_outputs_lds<T>(M.out_row, ydd, tile, rows_valid, P.nv, lane);
             else write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
         }

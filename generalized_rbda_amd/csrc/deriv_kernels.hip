@@ -796,6 +796,20 @@ __device__ __forceinline__ double lane_value(double x, int l)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// States whose joint-space inertia is not positive definite to working precision (a pivot of the factorisation <= 0 or not finite:
+// massless chains, a singular pose of an implicit cluster): their results are NaN / Inf, and the solve kernels count them here so
+// that a caller can ASK (grbda_spd_bad_pivots, include/grbda_hip.h) instead of scanning nv^2 numbers per state.
+__device__ unsigned long long grbda_spd_bad_count = 0;
+hipError_t spd_bad_pivots(unsigned long long *count, int reset)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(count, HIP_SYMBOL(grbda_spd_bad_count), sizeof *count);
+    if (e != hipSuccess || !reset) return e;
+    const unsigned long long z = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(grbda_spd_bad_count), &z, sizeof z);
+}
+
 // 1 / sqrt(d): the hardware estimate refined by Newton steps (y <- y (1.5 - 0.5 d y^2)) to working precision, a fraction
 // of the instructions of the IEEE division and square root
 __device__ __forceinline__ float inv_sqrt(float d)
@@ -862,16 +876,19 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
             for (int j = 0; j < NV; j++)
                 Lr[j] = (lane < nv && j < nv) ? ((j <= lane && ((rel_mine >> j) & 1)) ? (TC)hrow[j] : TC(0)) : (lane == j ? TC(1) : TC(0));
             __syncthreads();  // the previous state's solves are done with Lt
+            bool bad = false;
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 TC sum = Lr[k];
 #pragma unroll
                 for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
                 const TC d = lane_value(sum, k);
+                bad = bad || !(d > TC(0)) || !(d < TC(3e38));
                 const TC r = inv_sqrt(d);
                 Lr[k] = lane == k ? r : sum * r;
                 if (lane >= k && lane < NV) Lt[k * NV + lane] = Lr[k];
             }
+            if (bad && lane == 0) atomicAdd(&grbda_spd_bad_count, 1ull);
             __syncthreads();
         }
         // right-hand sides: KC columns per lane and pass; forward substitution by columns of L, backward by rows of L^T,
@@ -1088,16 +1105,19 @@ void spd_mfma_kernel(const float *H, int h_packed, int h_il, const float *P1, co
         for (int m = 0; m < n_mat; m++) group_copy(src[m] + grp * (size_t)G * nn, Pg + (size_t)m * G * nn, (p_il == G ? G : n_valid) * nn);
         MF_STAMP(1)
         // ---- 1. Cholesky ----
+        bool bad = false;
 #pragma unroll
         for (int k = 0; k < NVV; k++) {
             float sum = Lr[k];
 #pragma unroll
             for (int m2 = 0; m2 < k; m2++) sum -= Lr[m2] * lane_value(Lr[m2], k);
             const float d = lane_value(sum, k);
+            bad = bad || !(d > 0.0f) || !(d < 3e38f);
             const float r = inv_sqrt(d);
             Lr[k] = lane == k ? r : sum * r;
             if (lane >= k && lane < NVV) A[k * WS + lane] = Lr[k];
         }
+        if (bad && lane == 0 && live) atomicAdd(&grbda_spd_bad_count, 1ull);
         wave_lds_fence();
         MF_STAMP(2)
         // ---- 2. W = L^-1: column `lane`, forward substitution by columns of L (rows of the stored L^T) ----
@@ -1266,17 +1286,22 @@ template <int NVV>
 static hipError_t launch_spd_mfma_n(const float *H, int h_packed, int h_il, const float *P1, const float *P2, int p_il, float *Hinv, float *X1,
                                     float *X2, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
 {
-    const size_t lds = spd_mfma_lds_bytes(nv, (P1 ? 1 : 0) + (P2 ? 1 : 0));
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_mfma_kernel<NVV>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    const size_t lds = spd_mfma_lds_bytes(nv, (P1 ? 1 : 0) + (P2 ? 1 : 0));  // (above the 64 KiB default: set_max_dynamic_lds_deriv, per device)
     hipLaunchKernelGGL((spd_mfma_kernel<NVV>), dim3(grid), dim3(kWave * kDerivGroup), lds, stream, H, h_packed, h_il, P1, P2, p_il, Hinv, X1,
                        X2, related, nv, B);
     return hipGetLastError();
+}
+// the matrix-core solve needs up to 160 KiB of dynamic LDS: raised per device by capi.cpp's ensure_device, like every other kernel
+hipError_t set_max_dynamic_lds_deriv()
+{
+    const void *fns[] = {reinterpret_cast<const void *>(&spd_mfma_kernel<16>), reinterpret_cast<const void *>(&spd_mfma_kernel<24>),
+                         reinterpret_cast<const void *>(&spd_mfma_kernel<32>), reinterpret_cast<const void *>(&spd_mfma_kernel<40>),
+                         reinterpret_cast<const void *>(&spd_mfma_kernel<48>), reinterpret_cast<const void *>(&spd_mfma_kernel<64>)};
+    for (const void *f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 static hipError_t launch_spd_mfma(const float *H, int h_packed, int h_il, const float *P1, const float *P2, int p_il, float *Hinv, float *X1,
                                   float *X2, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)

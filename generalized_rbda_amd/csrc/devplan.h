@@ -180,5 +180,7 @@ hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const in
                                    const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
                                    const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave);
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
+hipError_t set_max_dynamic_lds_deriv();
+hipError_t spd_bad_pivots(unsigned long long *count, int reset);
 
 }  // namespace grbda_hip

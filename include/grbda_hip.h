@@ -189,6 +189,17 @@ int grbda_fd_derivatives_f64(const grbda_plan *plan, const double *q, const doub
                              double *dydd_dqd, double *dydd_dtau, size_t B, int device, void *stream);
 int grbda_fd_derivatives_f32(const grbda_plan *plan, const float *q, const float *qd, const float *tau, float *dydd_dq,
                              float *dydd_dqd, float *dydd_dtau, size_t B, int device, void *stream);
+/* States whose joint-space inertia matrix H was not positive definite to working precision in the SPD solves behind
+ * grbda_fd_dtau_* / grbda_fd_dq_* / grbda_fd_dqd_* / grbda_fd_derivatives_* (a pivot of the factorisation <= 0 or not finite: massless
+ * chains, a singular pose of an implicit cluster) get NaN / Inf results; the reference's ColPivHouseholderQR would return some
+ * least-squares answer there (src/Dynamics/ClusterTreeNode.cpp:33-37).  The solve kernels COUNT such states per device: this call
+ * synchronises the device, returns the count since the last reset and (reset != 0) clears it. */
+int grbda_spd_bad_pivots(int device, unsigned long long *count, int reset);
+/* The name of the kernel grbda_aba_* (kind 0) / grbda_rnea_* (kind 1) launches for a batch of B states in this precision (32 | 64) on
+ * this device, without external forces -- as rocprofv3 prints it (template arguments included; the chain kernels' inverse dynamics
+ * may append a wave-count variant).  bench.py reports it next to the roofline figures instead of re-deriving the selection. */
+int grbda_kernel_name(const grbda_plan *plan, int kind, int precision, size_t B, int device, char *buf, size_t cap);
+
 /* host-array variants (allocate, copy and synchronise per call: for the facade's single-state calls and small batches) */
 int grbda_mass_matrix_host_f64(const grbda_plan *plan, const double *q, double *H, size_t B, int device);
 int grbda_fd_derivatives_host_f64(const grbda_plan *plan, const double *q, const double *qd, const double *tau, double *dydd_dq,

@@ -15,7 +15,7 @@ import oracle_py as O
 import generalized_rbda_amd as G
 from generalized_rbda_amd import modeldesc as md
 from generalized_rbda_amd.states import random_states
-from models import valid_states, zoo
+from models import random_inertia, random_xtree, valid_states, zoo
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -951,3 +951,27 @@ def test_ungated_implicit_states_fp64(name, gpu):
     assert e.max() < 1e-6 and e_id.max() < 1e-6, (e.max(), e_id.max(), int(outside.sum()))
     if name in ("tello_with_arms", "tello", "urdf_four_bar"):
         assert outside.sum() > 0  # the sample really holds states the gate rejects
+
+
+def test_singular_mass_matrix_is_counted(gpu):
+    """A model whose joint-space inertia is singular (a massless, inertia-less distal link): the SPD solves behind the derivative
+    entry points return NaN / Inf for such states and COUNT them (grbda_spd_bad_pivots) -- a caller can ask instead of scanning
+    the matrices; a regular model leaves the counter at zero."""
+    import torch
+
+    m = md.ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    rng = np.random.default_rng(5)
+    m.appendBody("l0", random_inertia(rng), "ground", *random_xtree(rng), joint="revolute", axis="z")
+    m.appendBody("l1", md.spatial_inertia(0.0, np.zeros(3), np.zeros((3, 3))), "l0", *random_xtree(rng), joint="revolute", axis="y")
+    plan = G.Plan(m.serialize())
+    B = 130
+    q = torch.as_tensor(rng.uniform(-1, 1, (B, 2)), dtype=torch.float64, device=gpu)
+    G.spd_bad_pivots(0, reset=True)
+    for dt in (torch.float64, torch.float32):
+        Hinv = plan.fd_dtau(q.to(dt))
+        assert G.spd_bad_pivots(0, reset=True) == B
+        assert not torch.isfinite(Hinv).all()
+    good = G.Plan(zoo()["urdf_mini_cheetah"])
+    qg, _, _ = valid_states(good.blob, 70, config_index=3)
+    good.fd_dtau(torch.as_tensor(qg, dtype=torch.float32, device=gpu))
+    assert G.spd_bad_pivots(0, reset=True) == 0

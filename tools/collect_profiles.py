@@ -3,6 +3,8 @@ usage: python tools/collect_profiles.py r3 gpurun_out/r3b"""
 import glob, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha  # the counters are valid for these device sources only (bench.py refuses others)
 rnd, src = sys.argv[1], sys.argv[2]
 P = os.path.join(ROOT, "profiles")
 
@@ -24,6 +26,11 @@ cp("prof/derivs_under_rocprof.txt", "derivatives_under_rocprofv3.txt")
 cp("prof/stats/**/*kernel_stats.csv", "rocprofv3_kernel_stats.csv")
 cp("prof/stats_derivs/**/*kernel_stats.csv", "rocprofv3_kernel_stats_derivatives.csv")
 cp("pmc_flops.json", "pmc_flops.json")
+fl = os.path.join(P, f"{rnd}_pmc_flops.json")
+if os.path.exists(fl):
+    doc = json.load(open(fl))
+    doc["kernel_sources_sha"] = kernel_sources_sha()
+    json.dump(doc, open(fl, "w"), indent=1)
 cp("traffic_calibration.txt", "traffic_calibration.txt")
 cp("prof/traffic.txt", "pmc_traffic_raw.txt")
 for tag, name in (("pmc_mit_aba32", "mit_aba32"), ("pmc_mit_rnea32", "mit_rnea32"), ("pmc_tello_aba32", "tello_aba32"),
@@ -45,5 +52,5 @@ if os.path.exists(raw):
                         "bytes_per_launch": total, "bytes_per_state": round(total / batch, 1), "kernel": kern})
     old = os.path.join(P, f"{rnd}_pmc_traffic.json")
     comment = json.load(open(old))["_comment"] if os.path.exists(old) else "bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
-    json.dump({"_comment": comment, "entries": entries}, open(old, "w"), indent=1)
+    json.dump({"_comment": comment, "kernel_sources_sha": kernel_sources_sha(), "entries": entries}, open(old, "w"), indent=1)
     print(f"{rnd}_pmc_traffic.json  <-  prof/traffic.txt ({len(entries)} entries)")
