@@ -55,7 +55,7 @@ class PlanInfo(ctypes.Structure):
                 ("chain_aba_f32", c_int), ("n_lds_slots_chain_f32", c_int), ("n_chain_segments", c_int),
                 ("chain_aba_f64", c_int), ("chain_rnea_f32", c_int), ("chain_rnea_f64", c_int),
                 ("analytic_derivatives", c_int), ("n_chain_differentials", c_int),
-                ("latency_mode_f32", c_int), ("latency_mode_f64", c_int), ("n_chain_generic", c_int)]
+                ("latency_mode_f32", c_int), ("latency_mode_f64", c_int), ("n_chain_generic", c_int), ("spanning_tree_route", c_int)]
 
 
 _lib = None

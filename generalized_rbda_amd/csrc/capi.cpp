@@ -112,6 +112,7 @@ struct grbda_plan {
     mutable std::map<std::pair<int, void *>, Scratch> scratch;
     mutable std::map<std::pair<int, void *>, Scratch> work;  // expanded batches of the derived quantities
     mutable std::map<std::pair<int, void *>, Scratch> work_cvt;  // fp64 copies of fp32 inputs (grbda_fd_dq_f32)
+    mutable std::map<std::pair<int, void *>, Scratch> work_proj; // projection_run (called from inside the users of `work`)
     // launch shape per kernel, index = (rnea ? 2 : 0) + (f64 ? 1 : 0): LDS budget per wavefront for the
     // slot store, and wavefronts launched per CU (the grid is persistent)
     // (defaults from sweeps on MI355X over the MIT humanoid, Mini Cheetah and JVRC-1 at 4096 tiles: the f32
@@ -558,6 +559,9 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
 }
 
 template <class T>
+int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int device, void *stream);
+
+template <class T>
 int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, const T *f_ext, T *out, size_t B,
         int device, void *stream)
 {
@@ -565,6 +569,10 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     GRBDA_CALL_SCOPE(p);
     if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
+    if (p->host.projection_only) {
+        if (f_ext) return set_err(GRBDA_EUNSUPPORTED, "external forces are not supported for models on the spanning-tree route");
+        return projection_run<T>(p, rnea, q, qd, x, out, B, device, stream);
+    }
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     // chain-structured fast path (chain_kernels.hip): forward dynamics of models the chain program covers
@@ -1380,6 +1388,82 @@ bool analytic_covers(const grbda_plan *p)
 {
     return p->host.deriv.ok && p->host.crba.ok && !p->no_analytic && !p->no_crba && p->host.nv <= kWave;
 }
+// Forward / inverse dynamics through the spanning tree (HostPlan::projection_only; the reference's Projection-method cross-check,
+// RigidBodyTreeDynamics.cpp:86-97):  tau = G^T ID_s(q_s, G yd, G ydd + g);  ydd = (G^T H_s G)^-1 (tau - G^T ID_s(q_s, G yd, g)).
+template <class T>
+int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int device, void *stream)
+{
+    if (!p->span) return set_err(GRBDA_EUNSUPPORTED, "the model needs the spanning-tree route, which covers at most 64 spanning velocities");
+    DeviceTables *t = nullptr, *ts = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const grbda_plan *sp = p->span;
+    if (int rc = ensure_device(sp, device, &ts)) return rc;
+    const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
+    const size_t nq_s = sp->host.nq, nv_s = sp->host.nv, nn_s = nv_s * nv_s;
+    const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : 3 * nn_s + 2 * nn);
+    size_t chunk = (1024ull << 20) / (per_state * sizeof(T));
+    chunk &= ~static_cast<size_t>(kWave - 1);
+    if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
+    const size_t b_round = (B + kWave - 1) / kWave * kWave;
+    if (chunk > b_round) chunk = b_round;
+    void *wptr = nullptr;
+    if (int rc = ensure_work(p, p->work_proj, device, stream, chunk * per_state * sizeof(T) + 256, &wptr)) return rc;
+    T *w = static_cast<T *>(wptr);
+    auto take = [&](size_t per) { T *r = w; w += chunk * per; return r; };
+    T *q_s = take(nq_s), *qd_s = take(nv_s), *qdd_s = take(nv_s), *x_s = take(nv_s), *cpl = take(p->n_cpl_rows);
+    T *Aq = rnea ? nullptr : take(nn_s), *Av = rnea ? nullptr : take(nn_s), *Hs = rnea ? nullptr : take(nn_s);
+    T *Hw = rnea ? nullptr : take(nn), *Hinv = rnea ? nullptr : take(nn);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
+    DevPlan<T> ds = make_dev_plan<T>(sp, *ts, false, false);
+    hipError_t e;
+    for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t n_tiles = (nb + kWave - 1) / kWave;
+        size_t grid = static_cast<size_t>(t->n_cu) * 4;
+        if (grid > n_tiles) grid = n_tiles;
+        // inverse dynamics: qdd_s = G ydd + g; forward dynamics: qdd_s = g (the bias of the spanning tree with the constraint's own acceleration)
+        e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
+                                          p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, rnea ? x + b0 * nv : nullptr, q_s, qd_s, qdd_s, cpl, nb,
+                                          static_cast<int>(grid), hs);
+        if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
+        if (int rc = run<T>(sp, true, q_s, qd_s, qdd_s, nullptr, x_s, nb, device, stream)) return rc;
+        if (rnea) {
+            e = launch_manifold_apply<T>(d, p->host.n_clusters, t->span_v, t->crow, static_cast<int>(nv_s), p->n_cpl_rows, 0, x_s, nullptr, nullptr,
+                                         cpl, out + b0 * nv, nb, static_cast<int>(grid), hs);
+            if (e != hipSuccess) return hip_err(e, "manifold apply launch");
+            continue;
+        }
+        size_t g2 = static_cast<size_t>(ts->n_cu) * 4;
+        if (g2 > n_tiles) g2 = n_tiles;
+        void *scratch = nullptr;
+        if (int rc = ensure_scratch(sp, device, stream, g2 * static_cast<size_t>(sp->host.deriv.n_rows) * kWave * sizeof(T) + 256, &scratch)) return rc;
+        e = launch_rnea_deriv<T>(ds, ts->deriv_bodies, sp->host.n_clusters, sp->host.deriv.n_rows, sp->host.deriv.n_max, q_s, qd_s, qdd_s, Aq, Av, Hs,
+                                 nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, kWave);
+        if (e != hipSuccess) return hip_err(e, "spanning derivative launch");
+        e = launch_manifold_project<T>(d, p->host.n_clusters, t->span_v, t->crow, t->deriv_related, ts->deriv_related, static_cast<int>(nv_s),
+                                       p->n_cpl_rows, 1, nullptr, nullptr, Hs, nullptr, cpl, nullptr, nullptr, Hw, nb, static_cast<int>(grid), hs, 1);
+        if (e != hipSuccess) return hip_err(e, "manifold projection launch");
+        const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), sizeof(T), 0);
+        size_t per_cu = lds ? (160u * 1024u) / lds : 16;
+        if (per_cu > 16) per_cu = 16;
+        if (per_cu < 1) per_cu = 1;
+        size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
+        if (g3 > nb) g3 = nb;
+        if constexpr (sizeof(T) == 4)
+            e = launch_spd_solve<float, float>(Hw, 1, nullptr, nullptr, Hinv, nullptr, nullptr, t->deriv_related, static_cast<int>(nv), nb,
+                                               static_cast<int>(g3), hs, 1);
+        else
+            e = launch_spd_solve<double, double>(Hw, 1, nullptr, nullptr, Hinv, nullptr, nullptr, t->deriv_related, static_cast<int>(nv), nb,
+                                                 static_cast<int>(g3), hs, 1);
+        if (e != hipSuccess) return hip_err(e, "spd solve launch");
+        e = launch_manifold_apply<T>(d, p->host.n_clusters, t->span_v, t->crow, static_cast<int>(nv_s), p->n_cpl_rows, 1, x_s, x + b0 * nv, Hinv, cpl,
+                                     out + b0 * nv, nb, static_cast<int>(grid), hs);
+        if (e != hipSuccess) return hip_err(e, "manifold apply launch");
+    }
+    return GRBDA_OK;
+}
+
 // Models with implicit clusters (manifold_kernels.hip): ydd = FD; spanning state and the first-order parts of G, g per state;
 // tau_s and (A_q, A_v, H_s) of the spanning tree from its own plan; projection with the per-state G; the same SPD solve.
 // H only (dq == dqd == nullptr): qd and tau may be null.
@@ -1783,7 +1867,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->no_manifold = env_int("GRBDA_NO_MANIFOLD", 0) != 0;
     bool implicit = false;
     for (const ClusterRec &cr : p->host.lay64.clusters) implicit = implicit || cr.kind == CK_LOOP;
-    if (implicit && p->host.nv <= kWave) {
+    if ((implicit || p->host.projection_only) && p->host.nv <= kWave) {
         // the spanning-tree model for the derivatives on the constraint manifold (at most 64 spanning velocities: the masks of
         // DerivProgram::related)
         std::vector<unsigned char> sb;
@@ -1851,7 +1935,7 @@ void grbda_plan_free(grbda_plan *p)
         for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
-    for (auto *m : {&p->scratch, &p->work, &p->work_cvt})
+    for (auto *m : {&p->scratch, &p->work, &p->work_cvt, &p->work_proj})
         for (auto &kv : *m) {
             if (hipSetDevice(kv.first.first) != hipSuccess) continue;
             if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -1924,6 +2008,7 @@ int grbda_plan_info(const grbda_plan *p, grbda_plan_info_t *info)
     info->latency_mode_f32 = p->host.chain32p.ok && !p->no_chain && !p->no_latency_mode;
     info->latency_mode_f64 = p->host.chain64p.ok && !p->no_chain && !p->no_latency_mode;
     info->n_chain_generic = p->no_chain ? 0 : static_cast<int>(p->host.chain32.gens.size());
+    info->spanning_tree_route = p->host.projection_only ? 1 : 0;
     return GRBDA_OK;
 }
 

@@ -176,6 +176,9 @@ hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const
                                       int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
                                       T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream);
 template <class T>
+hipError_t launch_manifold_apply(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, int nv_s, int n_cpl_rows, int mode,
+                                 const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream);
+template <class T>
 hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
                                    const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
                                    const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave);

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                     for (int j = 0; j < npos; j++) oq[sq0 + j] = qs[cr.q_index + j];
                     for (int j = 0; j < 6; j++) {
                         ov[sv0 + j] = qds[cr.v_index + j];
-                        if (oa) oa[sv0 + j] = ydds[cr.v_index + j];
+                        if (oa) oa[sv0 + j] = ydds ? ydds[cr.v_index + j] : T(0);
                     }
                 }
                 continue;
@@ -588,6 +588,76 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel 3: between the independent coordinates and the spanning tree, one state per lane (capi.cpp, projection_run).
+//   mode 0 (inverse dynamics):  out = G^T x_s                                   x_s = tau_s(q_s, G yd, G ydd + g)
+//   mode 1 (forward dynamics):  out = Hinv (tau - G^T x_s)                      x_s = C_s + H_s g,  Hinv = (G^T H_s G)^-1 [B][nv][nv]
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_v_,
+                                                                const int32_t *__restrict__ crow_, int nv_s, int n_cpl_rows, int mode,
+                                                                const T *__restrict__ x_s, const T *__restrict__ tau,
+                                                                const T *__restrict__ Hinv, const T *__restrict__ cpl, T *__restrict__ out,
+                                                                size_t B)
+{
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
+    cptr<T> consts = (cptr<T>)DP.consts;
+    cptr<int32_t> span_v = (cptr<int32_t>)span_v_, crow = (cptr<int32_t>)crow_;
+    const int lane = threadIdx.x, nv = DP.nv;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r0 = tile * kWave + lane;
+        const bool live = r0 < B;
+        const size_t st = live ? r0 : B - 1;
+        const T *xs = x_s + st * (size_t)nv_s;
+        const T *cp = cpl + (tile * (size_t)n_cpl_rows) * kWave + lane;
+        T rhs[kWave];
+        for (int c = 0; c < n_clusters; c++) {
+            const ClusterRec cr = load_rec(clusters + c);
+            const int n = cr.kind == CK_FREE ? 6 : cr.n, k = cr.kind == CK_FREE ? 6 : cr.k;
+            const int stride = cr.kind == CK_LOOP ? cr.n * (4 + cr.n) : 0;
+            const T *cc = cp + (size_t)(cr.kind == CK_LOOP ? crow[c] : 0) * kWave;
+            for (int a = 0; a < n; a++) {
+                T s = 0;
+                for (int i = 0; i < k; i++) {
+                    T g;
+                    int sv;
+                    if (cr.kind == CK_FREE) { g = i == a ? T(1) : T(0); sv = span_v[cr.first_body] + i; }
+                    else if (cr.kind == CK_STATIC) { g = consts[load_rec(bodies + (cr.first_body + i)).cofs + kBodyConstFixed + a]; sv = span_v[cr.first_body + i]; }
+                    else { g = cc[(size_t)(i * stride + a) * kWave]; sv = span_v[cr.first_body + i]; }
+                    s += g * xs[sv];
+                }
+                rhs[cr.v_index + a] = mode == 0 ? s : tau[st * (size_t)nv + cr.v_index + a] - s;
+            }
+        }
+        if (!live) continue;
+        T *o = out + st * (size_t)nv;
+        if (mode == 0) {
+            for (int i = 0; i < nv; i++) o[i] = rhs[i];
+        } else {
+            const T *Hi = Hinv + st * (size_t)nv * nv;
+            for (int i = 0; i < nv; i++) {
+                T s = 0;
+                for (int j = 0; j < nv; j++) s += Hi[(size_t)i * nv + j] * rhs[j];
+                o[i] = s;
+            }
+        }
+    }
+}
+template <class T>
+hipError_t launch_manifold_apply(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, int nv_s, int n_cpl_rows, int mode,
+                                 const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((manifold_apply_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, nv_s, n_cpl_rows, mode, x_s,
+                       tau, Hinv, cpl, out, B);
+    return hipGetLastError();
+}
+template hipError_t launch_manifold_apply<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, int, int, int, const float *,
+                                                 const float *, const float *, const float *, float *, size_t, int, hipStream_t);
+template hipError_t launch_manifold_apply<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, int, int, int, const double *,
+                                                  const double *, const double *, const double *, double *, size_t, int, hipStream_t);
 
 template <class T>
 hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,

@@ -169,9 +169,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 if (b.parent < 0 && cl.parent_cluster >= 0)
                     return fail(msg, cap, GRBDA_EINVAL, "body %d: ground parent in a non-root cluster", gb);
                 if (cr.parent_body == -2) cr.parent_body = b.parent;
-                else if (cr.parent_body != b.parent)
-                    return fail(msg, cap, GRBDA_EUNSUPPORTED,
-                                "cluster %d attaches to more than one body of its parent cluster (body %d)", c, gb);
+                else if (cr.parent_body != b.parent) {
+                    // several parent bodies: the structured recursions do not apply (plan.h, HostPlan::projection_only)
+                    if (std::getenv("GRBDA_NO_PROJECTION"))
+                        return fail(msg, cap, GRBDA_EUNSUPPORTED,
+                                    "cluster %d attaches to more than one body of its parent cluster (body %d)", c, gb);
+                    P.projection_only = true;
+                }
             }
         }
         if (cr.parent_body == -2) return fail(msg, cap, GRBDA_EINVAL, "cluster %d has no root body", c);
@@ -567,6 +571,29 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             if (rows != cl.n_constraint_rows) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop rows mismatch", c);
         }
+    }
+
+    if (P.projection_only) {
+        // tables for the spanning-tree route only (manifold_kernels.hip reads clusters / bodies / consts / cints); the coordinates two
+        // clusters share a root path on -- the entries of H and of the derivative matrices that are not structural zeros
+        for (Layout *L : {&P.lay32, &P.lay64, &P.lay32x, &P.lay64x, &P.lay32s}) {
+            L->clusters = clusters;
+            L->rnea_clusters = clusters;
+            L->bodies = bodies;
+            L->rnea_bodies = bodies;
+            L->acc_k.assign(1, -1);
+        }
+        if (P.nv <= 64) {
+            P.deriv.related.assign(P.nv, 0);
+            for (int c = 0; c < nc; c++)
+                for (int a = c; a >= 0; a = m.clusters[a].parent_cluster)
+                    for (int i = 0; i < m.clusters[c].n_vel; i++)
+                        for (int j = 0; j < m.clusters[a].n_vel; j++) {
+                            P.deriv.related[m.clusters[c].v_index + i] |= uint64_t(1) << (m.clusters[a].v_index + j);
+                            P.deriv.related[m.clusters[a].v_index + j] |= uint64_t(1) << (m.clusters[c].v_index + i);
+                        }
+        }
+        return 0;
     }
 
     // ---- sweep schedule: depth-first, a subtree is swept forward then backward ------------------

@@ -431,6 +431,11 @@ struct LdsBudget {
 struct HostPlan {
     int nq = 0, nv = 0, n_bodies = 0, n_clusters = 0;
     int ori_repr = 0;
+    // The cluster recursions do not cover this model (a cluster attached to several bodies of its parent cluster: the projected
+    // inertia then couples those bodies, SpatialTransforms.cpp:312-344): forward / inverse dynamics, mass matrix and derivatives
+    // run through the SPANNING TREE and the per-state G instead -- H = G^T H_s G, ydd = H^-1 (tau - G^T (C_s + H_s g)), the
+    // reference's own cross-check (RigidBodyTreeDynamics.cpp:86-97) -- capi.cpp projection_run; no sweep programs are built.
+    bool projection_only = false;
     double gravity[6] = {0, 0, 0, 0, 0, -9.81};
     std::vector<Step> aba_steps;
     std::vector<Step> rnea_steps;

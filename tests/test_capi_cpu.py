@@ -51,18 +51,41 @@ def test_bad_blob_is_rejected():
         G.Plan(bytes(blob[:300]))
 
 
-def test_cluster_with_two_parent_bodies_is_reported_unsupported():
+def two_parent_model():
+    """A cluster whose two bodies hang off DIFFERENT bodies of the parent cluster (per-body parent_subindex of the reference's
+    GeneralizedTransform, SpatialTransforms.cpp:312-344,415-477): the projected inertia of cluster c couples b1 and b2."""
     m = md.ClusterTreeModel()
-    I = md.spatial_inertia(1.0, [0.1, 0, 0], np.eye(3) * 0.1)
-    m.appendBody("a", I, "ground", joint="revolute", axis="z")
-    m.registerBody("b1", I, "a")
-    m.registerBody("b2", I, "a")
-    m.appendRegisteredBodiesAsCluster("b", "Generic", axes="zz", G=[[1.0], [2.0]], K=[[2.0, -1.0]])
-    m.registerBody("c1", I, "b1")
-    m.registerBody("c2", I, "b2")
-    m.appendRegisteredBodiesAsCluster("c", "Generic", axes="zz", G=[[1.0], [2.0]], K=[[2.0, -1.0]])
+    rng = np.random.default_rng(12)
+    I = lambda: md.spatial_inertia(rng.uniform(0.5, 2.0), rng.uniform(-0.2, 0.2, 3), np.eye(3) * rng.uniform(0.02, 0.1))
+    X = lambda: (md.rpy_to_rotmat(rng.uniform(-1, 1, 3)), rng.uniform(-0.4, 0.4, 3))
+    m.appendBody("a", I(), "ground", *X(), joint="revolute", axis="z")
+    m.registerBody("b1", I(), "a", *X())
+    m.registerBody("b2", I(), "a", *X())
+    m.appendRegisteredBodiesAsCluster("b", "Generic", axes="zy", G=[[1.0], [2.0]], K=[[2.0, -1.0]])
+    m.registerBody("c1", I(), "b1", *X())
+    m.registerBody("c2", I(), "b2", *X())
+    m.appendRegisteredBodiesAsCluster("c", "Generic", axes="xz", G=[[1.0], [-1.5]], K=[[1.5, 1.0]])
+    m.appendBody("d", I(), "c2", *X(), joint="revolute", axis="y")
+    return m
+
+
+def test_cluster_with_two_parent_bodies_takes_the_spanning_tree_route(monkeypatch):
+    """Rounds 1-3 refused such models (GRBDA_EUNSUPPORTED); they now compile to a plan whose entry points run through the
+    spanning tree (plan.h, HostPlan::projection_only) -- GPU parity in tests/test_gpu_parity.py.  The oracle's dense 6k x 6k
+    formulation covers the shape directly and agrees with its own Projection-method restatement."""
+    import oracle_py as O
+
+    blob = two_parent_model().serialize()
+    info = G.Plan(blob).info()
+    assert info.spanning_tree_route == 1 and info.analytic_derivatives == 1 and info.chain_aba_f32 == 0
+    rng = np.random.default_rng(3)
+    q, qd, tau = rng.uniform(-1, 1, (20, 4)), rng.uniform(-1, 1, (20, 4)), rng.uniform(-1, 1, (20, 4))
+    a = O.forward_dynamics(blob, q, qd, tau)
+    b = O.forward_dynamics_projection(blob, q, qd, tau)
+    assert np.abs(a - b).max() / (1 + np.abs(a).max()) < 5e-8
+    monkeypatch.setenv("GRBDA_NO_PROJECTION", "1")  # (A/B switch: the old refusal)
     with pytest.raises(G.GrbdaError) as e:
-        G.Plan(m.serialize())
+        G.Plan(blob)
     assert e.value.code == -2 and "more than one body" in str(e.value)
 
 

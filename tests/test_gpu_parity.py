@@ -975,3 +975,45 @@ def test_singular_mass_matrix_is_counted(gpu):
     qg, _, _ = valid_states(good.blob, 70, config_index=3)
     good.fd_dtau(torch.as_tensor(qg, dtype=torch.float32, device=gpu))
     assert G.spd_bad_pivots(0, reset=True) == 0
+
+
+def test_cluster_on_two_parent_bodies_spanning_tree_route(gpu):
+    """A cluster attached to two bodies of its parent cluster (tests/test_capi_cpu.py::two_parent_model) runs through the spanning
+    tree (capi.cpp, projection_run): forward / inverse dynamics, mass matrix and the three derivative matrices against the oracle's
+    dense cluster recursion (fp64 1e-9; fp32 1e-3)."""
+    import torch
+    from test_capi_cpu import two_parent_model
+    from generalized_rbda_amd.states import parse_clusters
+
+    blob = two_parent_model().serialize()
+    plan = G.Plan(blob)
+    assert plan.info().spanning_tree_route == 1
+    B, nv = 200, plan.nv
+    q, qd, tau = random_states(blob, B, config_index=91)
+    ref = O.forward_dynamics(blob, q, qd, tau)
+    ref_id = O.inverse_dynamics(blob, q, qd, tau)
+    for dt, tol in ((torch.float64, 1e-9), (torch.float32, 1e-3)):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+        ydd = plan.forward_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
+        tid = plan.inverse_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
+        assert np.abs(ydd - ref).max() / (1 + np.abs(ref).max()) < tol
+        assert np.abs(tid - ref_id).max() / (1 + np.abs(ref_id).max()) < tol
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    H = plan.mass_matrix(t(q)).cpu().numpy()
+    e = np.eye(nv)
+    z = np.zeros_like(qd)
+    C = O.inverse_dynamics(blob, q, z, z)
+    for k in range(nv):
+        col = O.inverse_dynamics(blob, q, z, np.tile(e[k], (B, 1))) - C
+        assert np.abs(H[:, :, k] - col).max() < 1e-9 * (1 + np.abs(col).max())
+    d = plan.fd_derivatives(t(q[:16]), t(qd[:16]), t(tau[:16]))
+    m = parse_clusters(blob)
+    h = 1e-6
+    for b in range(16):
+        for k in range(nv):
+            qp, qm = _reference_plus(m, q[b], k, +h)[None], _reference_plus(m, q[b], k, -h)[None]
+            col = (O.forward_dynamics(blob, qp, qd[b:b + 1], tau[b:b + 1])[0] - O.forward_dynamics(blob, qm, qd[b:b + 1], tau[b:b + 1])[0]) / (2 * h)
+            got = d["dq"][b, :, k].cpu().numpy()
+            assert np.abs(got - col).max() / (1 + np.abs(col).max()) < 2e-5
+            col_t = O.forward_dynamics(blob, q[b:b + 1], qd[b:b + 1], tau[b:b + 1] + e[k])[0] - ref[b]
+            assert np.abs(d["dtau"][b, :, k].cpu().numpy() - col_t).max() / (1 + np.abs(col_t).max()) < 1e-8
