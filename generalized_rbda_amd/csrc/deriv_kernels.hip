@@ -1334,10 +1334,85 @@ static hipError_t launch_spd_solve_n(const TIO *H, int h_packed, const TIO *P1, 
     return hipGetLastError();
 }
 // interleave: layout of H, P1, P2 -- 1 state-major, kDerivGroup the interleaved workspace of rnea_deriv_kernel (matrix-core kernel only)
+// ---------------------------------------------------------------------------------------------------------------
+// Tiny systems (nv <= 6: four_bar.urdf, six_bar.urdf, a leg on a bench): one state per LANE, everything in registers -- the
+// one-state-per-wavefront kernels above pad such a system to 16 x 16 and spend their time on barriers and identity rows (six_bar,
+// nv = 3: 0.70 ms per 262 144 states on the matrix-core kernel against 0.06 ms for the whole forward dynamics).  Same inputs
+// (packed lower rows of H, packed runs of the right-hand sides, any interleave factor IL), same outputs.
+// ---------------------------------------------------------------------------------------------------------------
+template <class TIO, class TC, int NV>
+__global__ __launch_bounds__(kWave) void spd_small_kernel(const TIO *__restrict__ H, int il, const TIO *__restrict__ P1, const TIO *__restrict__ P2,
+                                                        TIO *__restrict__ Hinv, TIO *__restrict__ X1, TIO *__restrict__ X2,
+                                                        const uint64_t *__restrict__ related, int nv, size_t B)
+{
+    const size_t nn = (size_t)nv * nv;
+    for (size_t st = (size_t)blockIdx.x * kWave + threadIdx.x; st < B; st += (size_t)gridDim.x * kWave) {
+        const size_t base = (st / il) * nn * il + st % il;
+        TC D[NV][NV];
+#pragma unroll
+        for (int r = 0; r < NV; r++)
+#pragma unroll
+            for (int c = 0; c < NV; c++) {
+                D[r][c] = r == c ? TC(1) : TC(0);
+                if (r < nv && c <= r) {
+                    const bool rel = !related || ((related[r] >> c) & 1);
+                    const TC v = rel ? (TC)H[base + (size_t)(r * (r + 1) / 2 + c) * il] : TC(0);
+                    D[r][c] = v;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < NV; r++)
+#pragma unroll
+            for (int c = r + 1; c < NV; c++) D[r][c] = D[c][r];
+        Chol<TC, NV> ch;
+        ch.factor(D);
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < NV; j++) bad = bad || !(ch.inv[j] > TC(0)) || !(ch.inv[j] < TC(1e30));
+        if (bad) atomicAdd(&grbda_spd_bad_count, 1ull);
+        for (int m = 0; m < 3; m++) {
+            const TIO *P = m == 0 ? P1 : (m == 1 ? P2 : nullptr);
+            TIO *X = m == 0 ? X1 : (m == 1 ? X2 : Hinv);
+            if (!X || (m < 2 && !P)) continue;
+            for (int c = 0; c < nv; c++) {
+                TC b[NV];
+#pragma unroll
+                for (int r = 0; r < NV; r++) {
+                    b[r] = 0;
+                    if (r < nv) {
+                        if (m == 2) {
+                            b[r] = r == c ? TC(1) : TC(0);
+                        } else if (!related || ((related[r] >> c) & 1)) {
+                            const size_t e = c <= r ? (size_t)(r * r + c) : (size_t)(c * c + c + 1 + r);
+                            b[r] = -(TC)P[base + e * il];
+                        }
+                    }
+                }
+                ch.solve(b);
+#pragma unroll
+                for (int r = 0; r < NV; r++)
+                    if (r < nv) X[st * nn + (size_t)r * nv + c] = (TIO)b[r];
+            }
+        }
+    }
+}
+template <class TIO, class TC>
+static hipError_t launch_spd_small(const TIO *H, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related, int nv, size_t B,
+                                   hipStream_t stream, int il)
+{
+    size_t grid = (B + kWave - 1) / kWave;
+    if (grid > 65535u * 4u) grid = 65535u * 4u;
+    if (nv <= 2) hipLaunchKernelGGL((spd_small_kernel<TIO, TC, 2>), dim3(grid), dim3(kWave), 0, stream, H, il, P1, P2, Hinv, X1, X2, related, nv, B);
+    else if (nv <= 4) hipLaunchKernelGGL((spd_small_kernel<TIO, TC, 4>), dim3(grid), dim3(kWave), 0, stream, H, il, P1, P2, Hinv, X1, X2, related, nv, B);
+    else hipLaunchKernelGGL((spd_small_kernel<TIO, TC, 6>), dim3(grid), dim3(kWave), 0, stream, H, il, P1, P2, Hinv, X1, X2, related, nv, B);
+    return hipGetLastError();
+}
+
 template <class TIO, class TC>
 hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2, const uint64_t *related,
                             int nv, size_t B, int grid, hipStream_t stream, int interleave)
 {
+    if (nv <= 6 && h_packed) return launch_spd_small<TIO, TC>(H, P1, P2, Hinv, X1, X2, related, nv, B, stream, interleave);
     if constexpr (sizeof(TIO) == 4 && sizeof(TC) == 4) {
         if (spd_solve_on_mfma(4, nv, (P1 ? 1 : 0) + (P2 ? 1 : 0)))
             return launch_spd_mfma(H, h_packed, interleave, P1, P2, interleave, Hinv, X1, X2, related, nv, B, grid, stream);
