@@ -21,15 +21,15 @@ $(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/d
 # functions): lone multiplies and adds of the spatial products fold into FMAs, 10 % fewer floating-point instructions
 # (MIT humanoid fp32 ABA 0.173 -> 0.170 ms, JVRC-1 and TelloWithArms 3-4 %); parity tolerances unchanged.
 CHAINFLAGS := -fassociative-math -fno-signed-zeros -fno-trapping-math
-$(OBJ)/chain_kernels.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+$(OBJ)/chain_kernels.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/gen_rnea_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -c $< -o $@
 # second unit of the same source: the two fp64 kernels with the deepest register pressure (see the head of chain_kernels.hip)
-$(OBJ)/chain_kernels_u1.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+$(OBJ)/chain_kernels_u1.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/gen_rnea_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -DGRBDA_CHAIN_UNIT=1 -c $< -o $@
 # third unit: the kernels of chain programs with generic clusters (gen_segments.h)
-$(OBJ)/chain_kernels_u2.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+$(OBJ)/chain_kernels_u2.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/gen_rnea_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -DGRBDA_CHAIN_UNIT=2 $(U2FLAGS) -c $< -o $@
 $(OBJ)/crba_kernels.o: $(CSRC)/crba_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h

@@ -69,6 +69,8 @@ struct DeviceTables {
     RneaPair *rchain_pairs[3] = {nullptr, nullptr, nullptr};
     RneaFree *rchain_frees[3] = {nullptr, nullptr, nullptr};
     RneaDiff *rchain_diffs[3] = {nullptr, nullptr, nullptr};
+    ChainGen *rchain_gens[3] = {nullptr, nullptr, nullptr};
+    ChainGenBody *rchain_gbodies[3] = {nullptr, nullptr, nullptr};
     int n_cu = 0;
 };
 struct Scratch {
@@ -216,7 +218,9 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(rp.links.data(), rp.links.size() * sizeof(RneaLink), (void **)&t.rchain_links[w])) != hipSuccess ||
             (e = up(rp.pairs.data(), rp.pairs.size() * sizeof(RneaPair), (void **)&t.rchain_pairs[w])) != hipSuccess ||
             (e = up(rp.frees.data(), rp.frees.size() * sizeof(RneaFree), (void **)&t.rchain_frees[w])) != hipSuccess ||
-            (e = up(rp.diffs.data(), rp.diffs.size() * sizeof(RneaDiff), (void **)&t.rchain_diffs[w])) != hipSuccess)
+            (e = up(rp.diffs.data(), rp.diffs.size() * sizeof(RneaDiff), (void **)&t.rchain_diffs[w])) != hipSuccess ||
+            (e = up(rp.gens.data(), rp.gens.size() * sizeof(ChainGen), (void **)&t.rchain_gens[w])) != hipSuccess ||
+            (e = up(rp.gbodies.data(), rp.gbodies.size() * sizeof(ChainGenBody), (void **)&t.rchain_gbodies[w])) != hipSuccess)
             return hip_err(e, "plan upload");
         if ((e = set_max_dynamic_lds_chain()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     }
@@ -516,7 +520,7 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     // LDS of the two-per-SIMD shape (no global-slab fallback) run the program laid out for half the LDS per wavefront
     // once the batch fills 16 wavefronts per CU (MIT humanoid 0.105 -> 0.095 ms, Mini Cheetah 0.079 -> 0.070 ms; JVRC-1,
     // whose blocks spill already, loses)
-    const bool wide = sizeof(T) == 4 && !p->rnea_narrow && h.rchain32w.ok && h.rchain32.ok && h.rchain32.n_glb == 0 &&
+    const bool wide = sizeof(T) == 4 && !p->rnea_narrow && h.rchain32w.ok && h.rchain32.ok && h.rchain32.n_glb == 0 && h.rchain32.gens.empty() &&
                       n_tiles > static_cast<size_t>(t.n_cu) * 8;
     const int w = wide ? 2 : kid;
     const RneaChainProgram &rp = wide ? h.rchain32w : (kid ? h.rchain64 : h.rchain32);
@@ -527,6 +531,9 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     d.frees = t.rchain_frees[w];
     d.diffs = t.rchain_diffs[w];
     d.n_diffs = static_cast<int>(rp.diffs.size());
+    d.gens = t.rchain_gens[w];
+    d.gbodies = t.rchain_gbodies[w];
+    d.n_gens = static_cast<int>(rp.gens.size());
     d.cints = t.cints;
     d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
     d.n_segs = static_cast<int>(rp.segs.size());
@@ -1710,7 +1717,7 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
     const bool chain = !p->no_chain && (sizeof(T) == 8 ? h.rchain64.ok : h.rchain32.ok);
     if (chain) {
         const RneaChainProgram &rp = sizeof(T) == 8 ? h.rchain64 : h.rchain32;
-        std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_kernel<%s, %s, %s>", tn, rp.diffs.empty() ? "false" : "true", rp.n_glb > 0 ? "true" : "false");
+        std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_kernel<%s, %d, %s>", tn, !rp.gens.empty() ? 2 : (rp.diffs.empty() ? 0 : 1), rp.n_glb > 0 ? "true" : "false");
         return buf;
     }
     bool loop = false;
@@ -1931,7 +1938,7 @@ void grbda_plan_free(grbda_plan *p)
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
-        for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); }
+        for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
         for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }

@@ -2157,6 +2157,8 @@ struct RneaTables {
     cptr<RneaPair> pairs;
     cptr<RneaFree> frees;
     cptr<RneaDiff> diffs;
+    cptr<ChainGen> gens;          // generic clusters (gen_rnea_segments.h)
+    cptr<ChainGenBody> gbodies;
     cptr<int32_t> cints;
     cptr<T> consts;
     int n_segs, nq, nv, ori_repr;
@@ -2536,17 +2538,23 @@ __device__ __forceinline__ void rnea_free_bwd(const RneaTables<T> &P, const Chai
     for (int j = 0; j < 6; j++) M.put(f.v_index + j, fo[j]);
 }
 
-template <class T, bool DIFF, bool GLB>
+#include "gen_rnea_segments.h"
+
+// MODE 0: runs, pairs, bases; 1: + differential clusters; 2: + generic clusters (translation unit 2)
+template <class T, int MODE, bool GLB>
 __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
                                                               const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
                                                               T *__restrict__ scratch)
 {
+    constexpr bool DIFF = MODE >= 1, GEN = MODE == 2;
     RneaTables<T> P;
     P.segs = (cptr<RneaSeg>)DP.segs;
     P.links = (cptr<RneaLink>)DP.links;
     P.pairs = (cptr<RneaPair>)DP.pairs;
     P.frees = (cptr<RneaFree>)DP.frees;
     P.diffs = DIFF ? (cptr<RneaDiff>)DP.diffs : nullptr;
+    P.gens = GEN ? (cptr<ChainGen>)DP.gens : nullptr;
+    P.gbodies = GEN ? (cptr<ChainGenBody>)DP.gbodies : nullptr;
     P.cints = DIFF ? (cptr<int32_t>)DP.cints : nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
@@ -2588,6 +2596,12 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
                 case RSEG_DIFF_BWD:
                     if constexpr (DIFF) rnea_diff_bwd<T, GLB>(P, M, load_rec(P.diffs + sg.first));
                     break;
+                case RSEG_GEN_FWD:
+                    if constexpr (GEN) gen_rnea_segment<T, 0, GLB>(P, M, load_rec(P.gens + sg.first));
+                    break;
+                case RSEG_GEN_BWD:
+                    if constexpr (GEN) gen_rnea_segment<T, 1, GLB>(P, M, load_rec(P.gens + sg.first));
+                    break;
                 default: rnea_free_bwd(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
@@ -2596,14 +2610,32 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
 }
 
 template <class T>
+hipError_t launch_rnea_chain_gen(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
+                                 size_t lds_bytes, hipStream_t stream);
+#if GRBDA_CHAIN_UNIT == 2
+template <class T>
+hipError_t launch_rnea_chain_gen(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
+                                 size_t lds_bytes, hipStream_t stream)
+{
+    if (P.n_glb_slots > 0) hipLaunchKernelGGL((rnea_chain_kernel<T, 2, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else hipLaunchKernelGGL((rnea_chain_kernel<T, 2, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    return hipGetLastError();
+}
+template hipError_t launch_rnea_chain_gen<float>(const RneaChainDev<float> &, const float *, const float *, const float *, float *, size_t,
+                                                 float *, int, size_t, hipStream_t);
+template hipError_t launch_rnea_chain_gen<double>(const RneaChainDev<double> &, const double *, const double *, const double *, double *,
+                                                  size_t, double *, int, size_t, hipStream_t);
+#endif
+template <class T>
 hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
                              size_t lds_bytes, hipStream_t stream)
 {
     const bool glb = P.n_glb_slots > 0;
-    if (P.n_diffs > 0 && glb) hipLaunchKernelGGL((rnea_chain_kernel<T, true, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
-    else if (P.n_diffs > 0) hipLaunchKernelGGL((rnea_chain_kernel<T, true, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
-    else if (glb) hipLaunchKernelGGL((rnea_chain_kernel<T, false, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
-    else hipLaunchKernelGGL((rnea_chain_kernel<T, false, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    if (P.n_gens > 0) return launch_rnea_chain_gen<T>(P, q, qd, ydd, tau, B, scratch, grid, lds_bytes, stream);  // (unit 2)
+    if (P.n_diffs > 0 && glb) hipLaunchKernelGGL((rnea_chain_kernel<T, 1, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else if (P.n_diffs > 0) hipLaunchKernelGGL((rnea_chain_kernel<T, 1, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else if (glb) hipLaunchKernelGGL((rnea_chain_kernel<T, 0, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else hipLaunchKernelGGL((rnea_chain_kernel<T, 0, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     return hipGetLastError();
 }
 #if GRBDA_CHAIN_UNIT == 0
@@ -2630,10 +2662,10 @@ hipError_t set_max_dynamic_lds_chain()
         reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, 0>), reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, 1>),
         reinterpret_cast<const void *>(&aba_chain_kernel<float, 4, 0>),
         reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 0>),
-        reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, false>),
-        reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, false>),
-        reinterpret_cast<const void *>(&rnea_chain_kernel<float, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, true, true>),
-        reinterpret_cast<const void *>(&rnea_chain_kernel<double, false, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, true, true>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<float, 0, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, 1, false>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<double, 0, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, 1, false>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<float, 0, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, 1, true>),
+        reinterpret_cast<const void *>(&rnea_chain_kernel<double, 0, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, 1, true>),
         reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>),
         reinterpret_cast<const void *>(&aba_chain_lm_kernel<float>)};
     const hipError_t e = set_max_dynamic_lds(kernels, static_cast<int>(sizeof(kernels) / sizeof(kernels[0])));
@@ -2652,8 +2684,12 @@ hipError_t set_max_dynamic_lds_chain_unit1()
 hipError_t set_max_dynamic_lds_chain_unit2()
 {
     const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_kernel<float, 2, 2>),
-                                   reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 2>)};
-    return set_max_dynamic_lds(kernels, 2);  // (the single-cluster kernels stay below the 64 KiB default: capi.cpp)
+                                   reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 2>),
+                                   reinterpret_cast<const void *>(&rnea_chain_kernel<float, 2, false>),
+                                   reinterpret_cast<const void *>(&rnea_chain_kernel<float, 2, true>),
+                                   reinterpret_cast<const void *>(&rnea_chain_kernel<double, 2, false>),
+                                   reinterpret_cast<const void *>(&rnea_chain_kernel<double, 2, true>)};
+    return set_max_dynamic_lds(kernels, 6);  // (the single-cluster kernels stay below the 64 KiB default: capi.cpp)
 }
 #endif
 

@@ -103,6 +103,9 @@ struct RneaChainDev {
     const RneaFree *frees;
     const RneaDiff *diffs;
     int n_diffs;
+    const ChainGen *gens;          // generic clusters (gen_rnea_segments.h)
+    const ChainGenBody *gbodies;
+    int n_gens;
     const int32_t *cints;
     const T *consts;
     int n_segs;

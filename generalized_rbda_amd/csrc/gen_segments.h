@@ -91,8 +91,8 @@ __device__ __forceinline__ void gen_sincos(double x, double *s, double *c) { sin
 // URDF+ position loops.  Scratch (LDS slots from `scr`): K [rows x k] | per loop side: [a 3][o 3] per joint of its path
 // (axis and origin in the coordinates of the nearest common ancestor), then the constraint point [p 3].
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, class MM>
-__device__ __forceinline__ void gen_loop_K(const ChainTables<T> &P, const MM &M, const ChainGen &g, int sc0, int scr,
+template <class T, class MM, class TB>
+__device__ __forceinline__ void gen_loop_K(const TB &P, const MM &M, const ChainGen &g, int sc0, int scr,
                                            cptr<int32_t> loops, int n_loops)
 {
     const int k = g.k;
@@ -154,8 +154,8 @@ __device__ __forceinline__ void gen_loop_K(const ChainTables<T> &P, const MM &M,
 }
 
 // velocity-product acceleration of the constraint points, (Kdot qd)[row]; qd0: the k spanning rates (LDS scratch)
-template <class T, class MM>
-__device__ __forceinline__ void gen_loop_Kdqd(const ChainTables<T> &P, const MM &M, const ChainGen &g, int scr, int qd0,
+template <class T, class MM, class TB>
+__device__ __forceinline__ void gen_loop_Kdqd(const TB &P, const MM &M, const ChainGen &g, int scr, int qd0,
                                               cptr<int32_t> loops, int n_loops, T (&kdq)[3])
 {
     const int k = g.k;
@@ -222,8 +222,8 @@ __device__ __forceinline__ void gen_loop_Kdqd(const ChainTables<T> &P, const MM 
 // [per distinct argument w[k], b][per term coef]).  Scratch: K [rows x k] | per argument [a, sin a, cos a, w . qd_span].
 // want_K: rows of K to the scratch; otherwise the second directional derivative along qd_span goes to kdq.
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, class MM>
-__device__ __forceinline__ void gen_trig_eval(const ChainTables<T> &P, const MM &M, const ChainGen &g, int scr, int qd0,
+template <class T, class MM, class TB>
+__device__ __forceinline__ void gen_trig_eval(const TB &P, const MM &M, const ChainGen &g, int scr, int qd0,
                                               cptr<int32_t> prog, bool want_K, T (&kdq)[3])
 {
     const int k = g.k;
@@ -326,8 +326,8 @@ __device__ __forceinline__ void gen_trig_eval(const ChainTables<T> &P, const MM 
 
 // G rows, g and the spanning rates of the DEPENDENT bodies of an implicit cluster into the kept block: row r = [G row N][g][qd_span]
 // of dependent coordinate r (an independent body's row of G is a unit vector, its g is 0 and its rate is yd: gen_coupling)
-template <class T, int N, class MM>
-__device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const MM &M, const ChainGen &g, int sc0, int scr,
+template <class T, int N, class MM, class TB>
+__device__ __forceinline__ void gen_constraint(const TB &P, const MM &M, const ChainGen &g, int sc0, int scr,
                                                const T (&yd)[N])
 {
     constexpr int ks = N + 2;
@@ -340,7 +340,7 @@ __device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const MM
     cptr<int32_t> payload = dep + rows;
     T kdq[3] = {0, 0, 0};
     for (int i = 0; i < rows * k; i++) gen_st1(M, scr + i, T(0));
-    if (g.kind == 1) gen_loop_K(P, M, g, sc0, scr, payload, hdr0);
+    if (g.kind == 1) gen_loop_K<T>(P, M, g, sc0, scr, payload, hdr0);
     else gen_trig_eval(P, M, g, scr, scr, payload, true, kdq);
 
     T Kd[3][3], Kdi[3][3], X[3][N];
@@ -389,8 +389,8 @@ __device__ __forceinline__ void gen_constraint(const ChainTables<T> &P, const MM
 }
 
 // coupling of a body: G row (registers), g_i, qd_i
-template <class T, int N, bool LOOP, class MM>
-__device__ __forceinline__ void gen_coupling(const ChainTables<T> &P, const MM &M, const ChainGen &g, const ChainGenBody &b,
+template <class T, int N, bool LOOP, class MM, class TB>
+__device__ __forceinline__ void gen_coupling(const TB &P, const MM &M, const ChainGen &g, const ChainGenBody &b,
                                              cptr<T> C, const T (&yd)[N], T (&Gr)[N], T &gi, T &qdi)
 {
     if constexpr (LOOP) {
@@ -429,8 +429,8 @@ __device__ __forceinline__ void gen_coupling(const ChainTables<T> &P, const MM &
 // ---------------------------------------------------------------------------------------------------------------
 // w: work area; constraint: evaluate it (else the kept block is valid already); publish: velocities of the bodies with child clusters
 // to their lds_v
-template <class T, int N, bool LOOP, class MM>
-__device__ __forceinline__ void gen_down(const ChainTables<T> &P, const MM &M, const ChainGen &g, int w, bool constraint, bool publish)
+template <class T, int N, bool LOOP, class MM, class TB>
+__device__ __forceinline__ void gen_down(const TB &P, const MM &M, const ChainGen &g, int w, bool constraint, bool publish)
 {
     const int k = g.k;
     const int sc0 = w, v0 = w + 2 * k;
@@ -493,8 +493,8 @@ __device__ __forceinline__ void gen_down(const ChainTables<T> &P, const MM &M, c
 // ---------------------------------------------------------------------------------------------------------------
 // FUSE: the cluster hangs off the ground and has no child clusters (single-cluster programs, aba_gen1_kernel): the acceleration
 // pass is two lines -- ydd = y0 - K a_root goes straight to the results, no [K | y0] block leaves the registers
-template <class T, int N, bool LOOP, bool FUSE, class MM>
-__device__ __forceinline__ void gen_up(const ChainTables<T> &P, const MM &M, const ChainGen &g)
+template <class T, int N, bool LOOP, bool FUSE, class MM, class TB>
+__device__ __forceinline__ void gen_up(const TB &P, const MM &M, const ChainGen &g)
 {
     const int k = g.k;
     const int sc0 = g.lds_w, v0 = g.lds_w + 2 * k;
@@ -697,8 +697,8 @@ __device__ __forceinline__ void gen_up(const ChainTables<T> &P, const MM &M, con
 // ---------------------------------------------------------------------------------------------------------------
 // acceleration pass (ClusterTreeDynamics.cpp:131-152): ydd = y0 - K a_p; (v, a) of the bodies child clusters hang off
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, int N, bool LOOP, class MM>
-__device__ __forceinline__ void gen_acc(const ChainTables<T> &P, const MM &M, const ChainGen &g)
+template <class T, int N, bool LOOP, class MM, class TB>
+__device__ __forceinline__ void gen_acc(const TB &P, const MM &M, const ChainGen &g)
 {
     T blk[7 * N], vp[6], ap[6], ydd[N];
     M.glb_ld(g.glb_k, blk);
@@ -782,8 +782,8 @@ __device__ __forceinline__ void gen_acc(const ChainTables<T> &P, const MM &M, co
 }
 
 // OP: 0 forward segment, 1 backward segment, 2 acceleration segment
-template <class T, int N, bool LOOP, int OP, class MM>
-__device__ __forceinline__ void gen_run(const ChainTables<T> &P, const MM &M, const ChainGen &g)
+template <class T, int N, bool LOOP, int OP, class MM, class TB>
+__device__ __forceinline__ void gen_run(const TB &P, const MM &M, const ChainGen &g)
 {
     if constexpr (OP == 0) {
         gen_down<T, N, LOOP>(P, M, g, g.lds_wf, true, true);
@@ -794,8 +794,8 @@ __device__ __forceinline__ void gen_run(const ChainTables<T> &P, const MM &M, co
         gen_acc<T, N, LOOP>(P, M, g);
     }
 }
-template <class T, int OP, class MM>
-__device__ __forceinline__ void gen_segment(const ChainTables<T> &P, const MM &M, const ChainGen &g)
+template <class T, int OP, class MM, class TB>
+__device__ __forceinline__ void gen_segment(const TB &P, const MM &M, const ChainGen &g)
 {
     if (g.kind) {
         if (g.n == 1) gen_run<T, 1, true, OP>(P, M, g);

@@ -1218,7 +1218,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::vector<ChainDiff> diff_of(nc);
             std::vector<ChainGen> gen_of(nc);
             std::vector<std::vector<ChainGenBody>> gbody_of(nc);
-            std::vector<int> gen_w_size(nc, 0);
+            std::vector<int> gen_w_size(nc, 0), gen_scratch(nc, 0);
             std::vector<int> acc_slot(nc, -1);            // accumulator [IA 21][psi 6] of the tip body (several kid chains, or a free base)
             std::vector<Obj> objs;
             int n_glb = 0;
@@ -1316,6 +1316,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     } else if (g.kind == 2) {
                         scratch = cr.rows * k + 4 * trig_args[c];
                     }
+                    gen_scratch[c] = scratch;
                     int w = 2 * k + std::max(6 * k, scratch);
                     // (IA, psi) inside the cluster: to the body right before in registers, else through an accumulator of the work area
                     for (int i = k - 1; i >= 0; i--) {
@@ -1534,14 +1535,16 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             // ---- the inverse-dynamics program on the same chains (plan.h, RneaChainProgram) ----
             bool any_gen = false;
             for (const Chain &ch : chains) any_gen = any_gen || ch.gen;
-            if (RP) *RP = RneaChainProgram();
-            if (RP && !any_gen) {
+            (void)any_gen;
+            if (RP) {
                 RneaChainProgram &R = *RP;
                 R = RneaChainProgram();
                 std::vector<RneaLink> rl(nc);
                 std::vector<RneaPair> rp(nc);
                 std::vector<RneaFree> rf(nc);
                 std::vector<RneaDiff> rd(nc);
+                std::vector<ChainGen> rg(nc);                      // generic clusters: the field use of gen_rnea_segments.h
+                std::vector<std::vector<ChainGenBody>> rgb(nc);
                 std::vector<Obj> robjs;
                 struct RRun { int seg; std::vector<int> cl; };
                 std::vector<RRun> rruns;
@@ -1550,10 +1553,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 auto rpush = [&](int op) { RneaSeg sg = RneaSeg(); sg.op = op; sg.lds_pva = sg.lds_pf = -1; R.segs.push_back(sg); return static_cast<int>(R.segs.size()) - 1; };
                 std::function<int(int)> remit = [&](int id) -> int {  // returns the last forward-type segment of the subtree
                     const Chain ch = chains[id];
-                    if (ch.diff) {
-                        int last = rt_fwd[id] = rpush(RSEG_DIFF_FWD);
+                    if (ch.diff || ch.gen) {
+                        int last = rt_fwd[id] = rpush(ch.gen ? RSEG_GEN_FWD : RSEG_DIFF_FWD);
                         for (int k : ch.kid_chains) last = std::max(last, remit(k));
-                        rt_bwd[id] = rpush(RSEG_DIFF_BWD);
+                        rt_bwd[id] = rpush(ch.gen ? RSEG_GEN_BWD : RSEG_DIFF_BWD);
                         return last;
                     }
                     rt_fwd[id] = rpush(RSEG_RUN_FWD);
@@ -1600,6 +1603,21 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         l.general_rotor = cls[c] == 4;
                         l.perm = link_of[c].perm; l.rperm = link_of[c].rperm;
                         l.lds_blk = l.lds_va = l.lds_pf = -1;
+                    } else if (cls[c] == 7) {
+                        rg[c] = gen_of[c];
+                        rg[c].lds_pv = rg[c].lds_acc_out = rg[c].lds_pva = rg[c].lds_w = rg[c].lds_wf = rg[c].keep = rg[c].glb_k = -1;
+                        rg[c].has_fwd = 1;
+                        rg[c].need_acc = 0;
+                        rgb[c] = gbody_of[c];
+                        for (ChainGenBody &b : rgb[c]) b.lds_acc = b.lds_va = b.pva = b.lds_v = b.acc_w = b.up_w = -1;
+                        {   // [v 6][a 6] of the bodies with in-cluster children, behind the [sin, cos] rows of the work area
+                            int w = 2 * rg[c].k;
+                            for (ChainGenBody &b : rgb[c])
+                                if (b.lam >= 0 && rgb[c][b.lam].acc_w < 0) { rgb[c][b.lam].acc_w = w; w += 12; }
+                            for (ChainGenBody &b : rgb[c])
+                                if (b.lam >= 0) b.up_w = rgb[c][b.lam].acc_w;
+                            rg[c].reserved[0] = w - 2 * rg[c].k;  // slots of those pairs
+                        }
                     } else if (is_diff(c)) {
                         RneaDiff &d = rd[c];
                         d = RneaDiff();
@@ -1618,6 +1636,22 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 }
                 for (size_t id = 0; id < chains.size(); id++) {
                     const Chain &ch = chains[id];
+                    if (ch.gen) {
+                        const int c = ch.cl[0];
+                        ChainGen &g = rg[c];
+                        const int k = g.k;
+                        robjs.push_back({&g.lds_w, 2 * k + std::max(g.reserved[0], gen_scratch[c]), 0, rt_fwd[id], rt_fwd[id], -1, 1, 1});
+                        robjs.push_back({&g.glb_k, 8 * k, 0, rt_fwd[id], rt_bwd[id], -1, 1, 1});
+                        if (g.kind) robjs.push_back({&g.keep, g.rows * (g.n + 2), 0, rt_fwd[id], rt_bwd[id], -1, 1, 1});
+                        for (int i = 0; i < k; i++) {
+                            const int body = clusters[c].first_body + i;
+                            int last = -1;
+                            for (int kc : ch.kid_chains)
+                                if (clusters[chains[kc].cl.front()].parent_body == body) last = std::max(last, rt_fwd[kc]);
+                            if (last >= 0) robjs.push_back({&rgb[c][i].lds_va, 12, 0, rt_fwd[id], last, -1, 1, 1});
+                        }
+                        continue;
+                    }
                     if (ch.diff) {
                         RneaDiff &d = rd[ch.cl[0]];
                         // one object: [f2 6][sin, cos 4][X 4] then [v 6][a 6] when child segments follow; the work space of the
@@ -1655,16 +1689,19 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         if (b < 0) return -1;  // ground
                         const int c = m.bodies[b].cluster;
                         if (is_diff(c)) return rd[c].lds_blk;
+                        if (cls[c] == 7) return rg[c].glb_k + 8 * (b - clusters[c].first_body);
                         return cls[c] == 0 ? rf[c].lds_f : rl[c].lds_blk;
                     };
                     auto va_slot_of_body2 = [&](int b) -> int {
                         if (b < 0) return -1;
                         const int c = m.bodies[b].cluster;
                         if (is_diff(c)) return rd[c].lds_va;
+                        if (cls[c] == 7) return rgb[c][b - clusters[c].first_body].lds_va;
                         return cls[c] == 0 ? rf[c].lds_va : rl[c].lds_va;
                     };
                     for (int c = 0; c < nc; c++) {
                         const int pb = clusters[c].parent_body;
+                        if (cls[c] == 7) { rg[c].lds_pva = va_slot_of_body2(pb); rg[c].lds_acc_out = f_slot_of_body(pb); }
                         if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) rl[c].lds_pf = f_slot_of_body(pb);
                         if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb); }
                         if (is_diff(c)) { rd[c].lds_pva = va_slot_of_body2(pb); rd[c].lds_pf = f_slot_of_body(pb); }
@@ -1684,6 +1721,19 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             R.segs[rt_fwd[id]].first = R.segs[rt_bwd[id]].first = static_cast<int>(R.diffs.size());
                             R.diffs.push_back(rd[ch.cl[0]]);
                         }
+                        if (ch.gen) {
+                            if (std::getenv("GRBDA_DEBUG_CHAIN")) {
+                                const ChainGen &g = rg[ch.cl[0]];
+                                std::fprintf(stderr, "rnea gen cluster %d: k %d n %d kind %d lds_w %d blk %d keep %d pva %d pf %d segs %d/%d\n", ch.cl[0], g.k, g.n, g.kind,
+                                             g.lds_w, g.glb_k, g.keep, g.lds_pva, g.lds_acc_out, rt_fwd[id], rt_bwd[id]);
+                                for (const ChainGenBody &b : rgb[ch.cl[0]])
+                                    std::fprintf(stderr, "   body lam %d axisym %d acc_w %d up_w %d lds_va %d ind %d dep %d\n", b.lam, b.axisym, b.acc_w, b.up_w, b.lds_va, b.ind_a, b.dep_r);
+                            }
+                            rg[ch.cl[0]].first = static_cast<int>(R.gbodies.size());
+                            R.gbodies.insert(R.gbodies.end(), rgb[ch.cl[0]].begin(), rgb[ch.cl[0]].end());
+                            R.segs[rt_fwd[id]].first = R.segs[rt_bwd[id]].first = static_cast<int>(R.gens.size());
+                            R.gens.push_back(rg[ch.cl[0]]);
+                        }
                         if (ch.pair >= 0) {
                             R.segs[rt_pair[id]].first = static_cast<int>(R.pairs.size());
                             R.pairs.push_back(rp[ch.pair]);
@@ -1698,7 +1748,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     R.n_glb = rn_glb;
                 }
                 R.ok = rok;
-                if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); R.diffs.clear(); }
+                if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); R.diffs.clear(); R.gens.clear(); R.gbodies.clear(); }
             }
             // ---- LDS objects and their live ranges ----
             // Time runs in half steps of the segment index: an ordinary object lives from the start of its first segment to the
@@ -1968,6 +2018,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     // wavefront (the launch then holds fewer wavefronts per CU, capi.cpp: still several times the interpreter's rate)
     if (!P.chain32.ok) build_chain(P.chain32, 2 * lds.aba32, P.rchain32.ok ? nullptr : &P.rchain32, 2 * lds.aba32);
     if (!P.chain64.ok) build_chain(P.chain64, 2 * lds.aba64, P.rchain64.ok ? nullptr : &P.rchain64, 2 * lds.aba64);
+    // (the same for an inverse-dynamics program that did not fit: its generic clusters keep [f | sin, cos] of every body from the
+    // forward to the backward segment)
+    {
+        ChainProgram scratch_cp;
+        if (!P.rchain32.ok) build_chain(scratch_cp, 2 * lds.aba32, &P.rchain32, 2 * lds.aba32);
+        if (!P.rchain64.ok) build_chain(scratch_cp, 2 * lds.aba64, &P.rchain64, 2 * lds.aba64);
+    }
     // latency mode serves batches of at most one tile per SIMD, i.e. four tiles per CU: 40 KiB of LDS per tile
     build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2);
     build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);

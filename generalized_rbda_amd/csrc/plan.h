@@ -324,7 +324,7 @@ struct ChainFree {      // 16 ints
 // forward run: v, a, body force f = I a + v x* I v of every link, the rotor's torque and its force on the parent body;
 // backward run: tau = S^T f, f_parent += X^T f.  A leaf pair cluster is finished in one segment of the forward pass.
 enum RneaChainOp : int32_t { RSEG_FREE_FWD = 0, RSEG_RUN_FWD = 1, RSEG_PAIR = 2, RSEG_RUN_BWD = 3, RSEG_FREE_BWD = 4,
-                             RSEG_DIFF_FWD = 5, RSEG_DIFF_BWD = 6 };
+                             RSEG_DIFF_FWD = 5, RSEG_DIFF_BWD = 6, RSEG_GEN_FWD = 7, RSEG_GEN_BWD = 8 };
 struct RneaLink {       // 16 ints
     int32_t q_index, v_index;
     int32_t cofs, rofs;     // link / rotor constants (rofs -1: plain revolute cluster)
@@ -361,6 +361,8 @@ struct RneaChainProgram {
     std::vector<RneaPair> pairs;
     std::vector<RneaFree> frees;
     std::vector<RneaDiff> diffs;
+    std::vector<ChainGen> gens;          // generic clusters: the records of the forward-dynamics program with the field use of
+    std::vector<ChainGenBody> gbodies;   // gen_rnea_segments.h
     int n_lds = 0;
     int n_glb = 0;  // > 0: some link blocks live in the wave's global slab (their slot numbers carry kSlotGlobal)
 };
