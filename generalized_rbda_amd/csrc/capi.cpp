@@ -1329,18 +1329,30 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
         if (t->deriv_related) {
             // the lower triangle in packed rows (row-local stores), then unpacked in place, one wavefront per state
             // (JVRC-1, 131 072 states, f32: 1.10 against 1.65 ms for the plain layout; f64 about even)
-            e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q, out, B, static_cast<T *>(scratch),
-                               static_cast<int>(grid), hs, true);
-            if (e != hipSuccess) return hip_err(e, "crba launch");
-            size_t g2 = static_cast<size_t>(t->n_cu) * 16;
-            if (g2 > B) g2 = B;
-            e = launch_unpack_symmetric<T>(out, t->deriv_related, nv, B, static_cast<int>(g2), hs);
-            return e == hipSuccess ? GRBDA_OK : hip_err(e, "unpack launch");
+            // whole groups of kDerivGroup states interleaved (crba_kernels.hip: a quarter of the open cache lines per store), the tail
+            // of the batch state-major
+            const int il = unpack_symmetric_lds_bytes(nv, sizeof(T), kDerivGroup) <= 60 * 1024 && !env_int("GRBDA_CRBA_STATE_MAJOR", 0) ? kDerivGroup : 1;
+            const size_t Bg = il > 1 ? B / il * il : 0;
+            for (int part = 0; part < 2; part++) {
+                const size_t b0 = part == 0 ? 0 : Bg, nbp = part == 0 ? Bg : B - Bg;
+                if (nbp == 0) continue;
+                const int ilp = part == 0 ? il : 1;
+                size_t gp = static_cast<size_t>(t->n_cu) * 8;
+                if (gp > (nbp + kWave - 1) / kWave) gp = (nbp + kWave - 1) / kWave;
+                e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, out + b0 * static_cast<size_t>(nv) * nv, nbp,
+                                   static_cast<T *>(scratch), static_cast<int>(gp), hs, true, ilp);
+                if (e != hipSuccess) return hip_err(e, "crba launch");
+                size_t g2 = static_cast<size_t>(t->n_cu) * 16;
+                if (g2 > nbp / ilp) g2 = nbp / ilp;
+                e = launch_unpack_symmetric<T>(out + b0 * static_cast<size_t>(nv) * nv, t->deriv_related, nv, nbp, static_cast<int>(g2), hs, ilp);
+                if (e != hipSuccess) return hip_err(e, "unpack launch");
+            }
+            return GRBDA_OK;
         }
         e = hipMemsetAsync(out, 0, B * static_cast<size_t>(nv) * nv * sizeof(T), hs);
         if (e != hipSuccess) return hip_err(e, "hipMemsetAsync");
         e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q, out, B, static_cast<T *>(scratch),
-                           static_cast<int>(grid), hs, false);
+                           static_cast<int>(grid), hs, false, 1);
         return e == hipSuccess ? GRBDA_OK : hip_err(e, "crba launch");
     }
     const int R = mode == DM_BIAS ? 1 : ((mode == DM_DQD || mode == DM_DQ) ? 2 * nv : nv + 1);
@@ -1555,7 +1567,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             // packed lower rows -> the full symmetric matrix, in place
             size_t g4 = static_cast<size_t>(t->n_cu) * 16;
             if (g4 > nb) g4 = nb;
-            e = launch_unpack_symmetric<T>(H, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g4), hs);
+            e = launch_unpack_symmetric<T>(H, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g4), hs, 1);
             if (e != hipSuccess) return hip_err(e, "unpack launch");
             continue;
         }
@@ -1598,7 +1610,8 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     // dID/dqd in rnea_deriv_kernel's packed layout, the H nobody asked for, and ydd take workspace
     const bool wide0 = sizeof(T) == 4 && p->solve_f64;
     const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
-    const int il = (need_d && !wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
+    // (d / d tau alone: the CRBA kernel writes the same interleaved H and the matrix-core solve inverts it)
+    const int il = (!wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
     // (only an INTERLEAVED H block can reach past the caller's array: the state-major layouts always build H in place)
     const bool h_in_place = dtau && (il == 1 || (B % kDerivGroup) == 0);
     const size_t per_state = (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
@@ -1649,7 +1662,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             if (e != hipSuccess) return hip_err(e, "rnea derivative launch");
         } else {
             e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, H, nb, static_cast<T *>(scratch),
-                               static_cast<int>(grid), hs, true);
+                               static_cast<int>(grid), hs, true, il);
             if (e != hipSuccess) return hip_err(e, "crba launch");
         }
         // one wavefront per state; as many as the LDS of a CU holds
@@ -1666,8 +1679,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         const T *r1 = dq ? Dq : nullptr, *r2 = dqd ? Dqd : nullptr;
         const uint64_t *rel = t->deriv_related;
         const int nvi = static_cast<int>(nv), g3i = static_cast<int>(g3), hp = 1;
-        // (H comes from the CRBA kernel, state-major, when no right-hand side is wanted)
-        const int sil = need_d ? il : 1;
+        const int sil = il;
         if constexpr (sizeof(T) == 4) {
             if (wide) e = launch_spd_solve<float, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, 1);
             else e = launch_spd_solve<float, float>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, sil);

@@ -21,7 +21,10 @@ namespace grbda_hip {
 
 #include "devmath.h"
 
-template <class T>
+// IL: interleave factor of the PACKED result ([group of IL states][entry][IL], as rnea_deriv_kernel's workspace: with one state per
+// lane a store of the state-major layout opens 64 cache lines that do not survive in L2 until their other entries arrive --
+// deriv_kernels.hip; the matrix-core solve and unpack_symmetric_kernel read the interleaved form)
+template <class T, int IL>
 __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const CrbaBody *__restrict__ cb_, int n_clusters, int n_rows,
                                                         const T *__restrict__ q, T *__restrict__ H, size_t B,
                                                         T *__restrict__ scratch, int packed)
@@ -38,14 +41,14 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
         const size_t st = r < B ? r : B - 1;  // lanes past the end redo the last state and do not store
         const bool live = r < B;
         const T *qs = q + st * (size_t)nq;
-        T *Hs = H + st * (size_t)nv * nv;
+        T *Hs = H + (st / IL) * (size_t)nv * nv * IL + st % IL;
         // packed: the rows of the lower triangle back to back (entry (r, c <= r) at r (r + 1) / 2 + c), every store of a
         // coordinate's pass in that coordinate's own row -- what spd_solve_kernel and unpack_symmetric_kernel read; the
         // transposed stores of the plain layout revisit every ancestor's row from every descendant.  Plain: the full
         // symmetric nv x nv matrix, structural zeros left to the caller.
         auto put = [&](int r, int c, T v) {
-            if (!packed) Hs[(size_t)r * nv + c] = v;
-            else if (c <= r) Hs[r * (r + 1) / 2 + c] = v;
+            if (!packed) Hs[(size_t)r * nv + c] = v;  // (IL == 1)
+            else if (c <= r) Hs[(size_t)(r * (r + 1) / 2 + c) * IL] = v;
         };
         // ---- pass 1: sin / cos of every revolute spanning joint; composite accumulators start at zero ----
         for (int c = 0; c < n_clusters; c++) {
@@ -233,55 +236,68 @@ __global__ __launch_bounds__(kWave, 1) void crba_kernel(DevPlan<T> DP, const Crb
 
 template <class T>
 hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,
-                       int grid, hipStream_t stream, bool packed)
+                       int grid, hipStream_t stream, bool packed, int interleave)
 {
-    hipLaunchKernelGGL((crba_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, cb, n_clusters, n_rows, q, H, B, scratch, packed ? 1 : 0);
+    if (interleave == kDerivGroup && packed)
+        hipLaunchKernelGGL((crba_kernel<T, kDerivGroup>), dim3(grid), dim3(kWave), 0, stream, P, cb, n_clusters, n_rows, q, H, B, scratch, 1);
+    else if (interleave == 1)
+        hipLaunchKernelGGL((crba_kernel<T, 1>), dim3(grid), dim3(kWave), 0, stream, P, cb, n_clusters, n_rows, q, H, B, scratch, packed ? 1 : 0);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 template hipError_t launch_crba<float>(const DevPlan<float> &, const CrbaBody *, int, int, const float *, float *, size_t, float *, int,
-                                       hipStream_t, bool);
+                                       hipStream_t, bool, int);
 template hipError_t launch_crba<double>(const DevPlan<double> &, const CrbaBody *, int, int, const double *, double *, size_t,
-                                        double *, int, hipStream_t, bool);
+                                        double *, int, hipStream_t, bool, int);
 
 // Packed lower triangle -> full symmetric matrix, in place (the packed rows occupy the first nv (nv + 1) / 2 entries of each
-// state's nv x nv block).  One state per wavefront: the packed block is read into LDS with consecutive lanes on
-// consecutive addresses, then the nv^2 entries are written the same way; entries between coordinates that are not on
-// one root path (DerivProgram::related) are written as zeros, whatever the packed block holds there.  nv <= 64.
+// state's nv x nv block; interleaved by il: the first il nv (nv + 1) / 2 entries of each GROUP's il nv^2 block -- B a multiple of
+// il).  One group per wavefront: the packed block is read into LDS with consecutive lanes on consecutive addresses, then the
+// il nv^2 entries are written the same way; entries between coordinates that are not on one root path (DerivProgram::related) are
+// written as zeros, whatever the packed block holds there.  nv <= 64.
 template <class T>
-__global__ __launch_bounds__(kWave) void unpack_symmetric_kernel(T *__restrict__ H, const uint64_t *__restrict__ related, int nv, size_t B)
+__global__ __launch_bounds__(kWave) void unpack_symmetric_kernel(T *__restrict__ H, const uint64_t *__restrict__ related, int nv, size_t B, int il)
 {
-    __shared__ T tri[kWave * (kWave + 1) / 2];
+    T *tri = reinterpret_cast<T *>(grbda_smem);  // [il * nt], as it lies in memory
     __shared__ uint64_t rel_rows[kWave];  // the masks, once per workgroup (a global load per entry otherwise)
     const int lane = threadIdx.x, nn = nv * nv, nt = nv * (nv + 1) / 2;
     const int step_r = kWave / nv, step_c = kWave % nv;
     rel_rows[lane] = lane < nv ? related[lane] : 0;
-    for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
-        T *Hs = H + s * (size_t)nn;
+    const size_t n_groups = B / il;
+    for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        T *Hg = H + g * (size_t)nn * il;
         __syncthreads();
-        for (int i = lane; i < nt; i += kWave) tri[i] = Hs[i];
+        for (int i = lane; i < nt * il; i += kWave) tri[i] = Hg[i];
         __syncthreads();
-        int r = lane / nv, c = lane % nv;
-        for (int i = lane; i < nn; i += kWave) {
-            const int lo = c <= r ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r;
-            const bool rel = (rel_rows[r] >> c) & 1;
-            Hs[i] = rel ? tri[lo] : T(0);
-            r += step_r;
-            c += step_c;
-            if (c >= nv) {
-                c -= nv;
-                r++;
+        for (int s = 0; s < il; s++) {
+            T *Hs = Hg + (size_t)s * nn;
+            int r = lane / nv, c = lane % nv;
+            for (int i = lane; i < nn; i += kWave) {
+                const int lo = c <= r ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r;
+                const bool rel = (rel_rows[r] >> c) & 1;
+                Hs[i] = rel ? tri[lo * il + s] : T(0);
+                r += step_r;
+                c += step_c;
+                if (c >= nv) {
+                    c -= nv;
+                    r++;
+                }
             }
         }
     }
 }
+size_t unpack_symmetric_lds_bytes(int nv, size_t elem, int il) { return static_cast<size_t>(il) * nv * (nv + 1) / 2 * elem; }
 template <class T>
-hipError_t launch_unpack_symmetric(T *H, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
+hipError_t launch_unpack_symmetric(T *H, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream, int il)
 {
-    if (nv > kWave || !related) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((unpack_symmetric_kernel<T>), dim3(grid), dim3(kWave), 0, stream, H, related, nv, B);
+    if (nv > kWave || !related || il < 1 || B % il != 0) return hipErrorInvalidValue;
+    const size_t lds = unpack_symmetric_lds_bytes(nv, sizeof(T), il);
+    if (lds > 60 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((unpack_symmetric_kernel<T>), dim3(grid), dim3(kWave), lds, stream, H, related, nv, B, il);
     return hipGetLastError();
 }
-template hipError_t launch_unpack_symmetric<float>(float *, const uint64_t *, int, size_t, int, hipStream_t);
-template hipError_t launch_unpack_symmetric<double>(double *, const uint64_t *, int, size_t, int, hipStream_t);
+template hipError_t launch_unpack_symmetric<float>(float *, const uint64_t *, int, size_t, int, hipStream_t, int);
+template hipError_t launch_unpack_symmetric<double>(double *, const uint64_t *, int, size_t, int, hipStream_t, int);
 
 }  // namespace grbda_hip

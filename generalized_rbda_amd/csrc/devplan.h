@@ -157,9 +157,11 @@ hipError_t launch_osim_chain(const ChainDev<T> &P, const OsimArgs<T> &A, const T
 // composite-rigid-body algorithm (crba_kernels.hip)
 template <class T>
 hipError_t launch_crba(const DevPlan<T> &P, const CrbaBody *cb, int n_clusters, int n_rows, const T *q, T *H, size_t B, T *scratch,
-                       int grid, hipStream_t stream, bool packed);
+                       int grid, hipStream_t stream, bool packed, int interleave);
+// (in place; B a multiple of il; il nv (nv + 1) / 2 elements of LDS: unpack_symmetric_lds_bytes <= 60 KiB)
 template <class T>
-hipError_t launch_unpack_symmetric(T *H, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream);
+hipError_t launch_unpack_symmetric(T *H, const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream, int il);
+size_t unpack_symmetric_lds_bytes(int nv, size_t elem, int il);
 
 // inverse-dynamics derivatives and the batched SPD solve behind d ydd / d (q, qd, tau) (deriv_kernels.hip)
 // states per group of the interleaved derivative workspace ([group][entry][kDerivGroup]) = wavefronts per workgroup of the
