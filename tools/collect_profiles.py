@@ -32,6 +32,11 @@ if os.path.exists(fl):
     doc["kernel_sources_sha"] = kernel_sources_sha()
     json.dump(doc, open(fl, "w"), indent=1)
 cp("traffic_calibration.txt", "traffic_calibration.txt")
+cp("bench/manifold_derivatives.txt", "manifold_derivatives.txt")
+cp("strong_scaling_proxy.txt", "strong_scaling_proxy.txt")
+cp("gate_f32_oracle.txt", "gate_f32_oracle.txt")
+cp("stress_random_models.txt", "stress_random_models.txt")
+cp("tello_acc.txt", "tello_acc_f32_vs_float_oracle.txt")
 cp("prof/traffic.txt", "pmc_traffic_raw.txt")
 for tag, name in (("pmc_mit_aba32", "mit_aba32"), ("pmc_mit_rnea32", "mit_rnea32"), ("pmc_tello_aba32", "tello_aba32"),
                   ("pmc_jvrc1_aba32", "jvrc1_aba32"), ("pmc_minicheetah_aba64", "minicheetah_aba64"), ("pmc_derivs", "derivatives")):

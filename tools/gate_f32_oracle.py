@@ -53,7 +53,7 @@ for name, build, cfg in (("tello_with_arms", tello_with_arms, 3), ("four_bar", N
     print(f"accepted sample ({sample_acc.size}): kernel fp32 max {e_k32[~is_rej].max():.2e}   oracle fp32 max {e_o32[~is_rej].max():.2e}")
     sev = np.maximum(gm[idx] / 50.0, kc[idx] / 1000.0)
     sev = np.maximum(sev, np.abs(q[idx][:, -plan.nq:]).max(axis=1) / 1e9)
-    print("states outside round 3's gate by severity = max(gain / 50, cond / 1000) (|q| >= 32 rad counted in its own row; the gate now ends at severity 5):")
+    print("states outside round 3's gate by severity = max(gain / 50, cond / 1000) (|q| >= 32 rad counted in its own row; the gate now ends at severity 3):")
     print(f"{'bucket':>22s} {'n':>7s} {'kernel f32 max':>15s} {'oracle f32 max':>15s} {'kernel>1e-3':>12s} {'oracle>1e-3':>12s} {'kernel>1e-3 & oracle<=1e-3':>28s}")
     qbig = np.zeros(idx.size, bool)
     from generalized_rbda_amd.states import parse_clusters

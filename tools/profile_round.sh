@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_derivs -- python3 $ROOT/tools/time_derivs.py jvrc1_humanoid 131072 > $OUT/derivs_under_rocprof.txt 2> $OUT/stats_derivs.log
 : > $OUT/traffic.txt
 for spec in "aba 32 mit_humanoid 262144" "rnea 32 mit_humanoid 262144" "aba 32 tello 1048576" "rnea 32 tello 1048576" \
-            "aba 64 mini_cheetah 65536" "aba 32 jvrc1_humanoid 1048576" "aba 64 mit_humanoid 262144"; do
+            "aba 64 mini_cheetah 65536" "aba 32 jvrc1_humanoid 1048576" "aba 64 mit_humanoid 262144" "aba 32 four_bar 1048576" "aba 32 six_bar 1048576"; do
   set -- $spec
   tag=$1_$2_$3
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -16,9 +16,12 @@ PMC_TO=1 bash tools/pmc_run.sh $R/pmc_mit_rnea32 rnea 32 > /dev/null 2>&1
 PMC_TO=1 PMC_MODEL=tello PMC_BATCH=1048576 bash tools/pmc_run.sh $R/pmc_tello_aba32 aba 32 > /dev/null 2>&1
 PMC_TO=1 PMC_MODEL=jvrc1_humanoid PMC_BATCH=1048576 bash tools/pmc_run.sh $R/pmc_jvrc1_aba32 aba 32 > /dev/null 2>&1
 PMC_FROM=5 PMC_TO=6 PMC_MODEL=mini_cheetah PMC_BATCH=65536 bash tools/pmc_run.sh $R/pmc_minicheetah_aba64 aba 64 > /dev/null 2>&1
+PMC_TO=4 PMC_MODEL=four_bar PMC_BATCH=1048576 bash tools/pmc_run.sh $R/pmc_four_bar_aba32 aba 32 > /dev/null 2>&1
+PMC_TO=4 PMC_MODEL=six_bar PMC_BATCH=1048576 bash tools/pmc_run.sh $R/pmc_six_bar_aba32 aba 32 > /dev/null 2>&1
 python3 tools/pmc_flops.py $OUT/pmc_flops.json mit_humanoid:aba:f32:262144:$OUT/pmc_mit_aba32/summary.txt \
     mit_humanoid:rnea:f32:262144:$OUT/pmc_mit_rnea32/summary.txt tello:aba:f32:1048576:$OUT/pmc_tello_aba32/summary.txt \
-    jvrc1_humanoid:aba:f32:1048576:$OUT/pmc_jvrc1_aba32/summary.txt mini_cheetah:aba:f64:65536:$OUT/pmc_minicheetah_aba64/summary.txt > /dev/null
+    jvrc1_humanoid:aba:f32:1048576:$OUT/pmc_jvrc1_aba32/summary.txt mini_cheetah:aba:f64:65536:$OUT/pmc_minicheetah_aba64/summary.txt \
+    four_bar:aba:f32:1048576:$OUT/pmc_four_bar_aba32/summary.txt six_bar:aba:f32:1048576:$OUT/pmc_six_bar_aba32/summary.txt > /dev/null
 # counter calibration on known byte counts
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -40,4 +43,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         print(f"  {c:11s} {k:16s} {m:12.0f} KiB   counted / moved = {m / 1048576:.3f}")
 PY
 bash $ROOT/tools/pmc_derivs.sh $R/pmc_derivs > /dev/null 2>&1
+cd $ROOT
+python3 tools/strong_scaling_proxy.py > $OUT/strong_scaling_proxy.txt 2>/dev/null
+python3 tools/gate_f32_oracle.py 1048576 > $OUT/gate_f32_oracle.txt 2>/dev/null
+python3 tools/stress_random_models.py 250 > $OUT/stress_random_models.txt 2>/dev/null
+python3 tools/tello_acc2.py generalized_rbda_amd/libgrbda_hip.so 2>/dev/null | tr "\n" " " > $OUT/tello_acc.txt
 cat $OUT/traffic_calibration.txt
