@@ -674,6 +674,9 @@ template <class T>
 int aux_setup(const grbda_plan *p, size_t B, int device, void *stream, DevPlan<T> &d, T **scratch, int *grid,
               size_t *lds_bytes)
 {
+    // (the auxiliary kernels walk the cluster tables with per-lane arrays sized by kMaxClusterBodies / kMaxClusterDof)
+    if (p->host.big_clusters)
+        return set_err(GRBDA_EUNSUPPORTED, "only forward / inverse dynamics and the mass matrix are covered for clusters beyond the structured kernels' limits");
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     d = make_dev_plan<T>(p, *t, false, false);
@@ -764,6 +767,8 @@ int state_convert(const grbda_plan *p, const uint8_t *pos_sp, const uint8_t *vel
     if (!p) return set_err(GRBDA_EINVAL, "null plan");
     GRBDA_CALL_SCOPE(p);
     if (!q_in || (qd && !qd_in)) return set_err(GRBDA_EINVAL, "null argument");
+    if (p->host.big_clusters)
+        return set_err(GRBDA_EUNSUPPORTED, "state conversion is not covered for clusters beyond the structured kernels' limits");
     StateFlags F;
     int in_nq = 0, in_nv = 0;
     if (int rc = state_widths(p, pos_sp, vel_sp, &F, &in_nq, &in_nv)) return rc;
@@ -1417,6 +1422,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     if (int rc = ensure_device(p, device, &t)) return rc;
     const grbda_plan *sp = p->span;
     if (int rc = ensure_device(sp, device, &ts)) return rc;
+    const bool big = p->host.big_clusters;
     const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
     const size_t nq_s = sp->host.nq, nv_s = sp->host.nv, nn_s = nv_s * nv_s;
     const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : 3 * nn_s + 2 * nn);
@@ -1444,12 +1450,12 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
         // inverse dynamics: qdd_s = G ydd + g; forward dynamics: qdd_s = g (the bias of the spanning tree with the constraint's own acceleration)
         e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
                                           p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, rnea ? x + b0 * nv : nullptr, q_s, qd_s, qdd_s, cpl, nb,
-                                          static_cast<int>(grid), hs);
+                                          static_cast<int>(grid), hs, big);
         if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         if (int rc = run<T>(sp, true, q_s, qd_s, qdd_s, nullptr, x_s, nb, device, stream)) return rc;
         if (rnea) {
             e = launch_manifold_apply<T>(d, p->host.n_clusters, t->span_v, t->crow, static_cast<int>(nv_s), p->n_cpl_rows, 0, x_s, nullptr, nullptr,
-                                         cpl, out + b0 * nv, nb, static_cast<int>(grid), hs);
+                                         cpl, out + b0 * nv, nb, static_cast<int>(grid), hs, big);
             if (e != hipSuccess) return hip_err(e, "manifold apply launch");
             continue;
         }
@@ -1461,7 +1467,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
                                  nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, kWave);
         if (e != hipSuccess) return hip_err(e, "spanning derivative launch");
         e = launch_manifold_project<T>(d, p->host.n_clusters, t->span_v, t->crow, t->deriv_related, ts->deriv_related, static_cast<int>(nv_s),
-                                       p->n_cpl_rows, 1, nullptr, nullptr, Hs, nullptr, cpl, nullptr, nullptr, Hw, nb, static_cast<int>(grid), hs, 1);
+                                       p->n_cpl_rows, 1, nullptr, nullptr, Hs, nullptr, cpl, nullptr, nullptr, Hw, nb, static_cast<int>(grid), hs, 1, big);
         if (e != hipSuccess) return hip_err(e, "manifold projection launch");
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), sizeof(T), 0);
         size_t per_cu = lds ? (160u * 1024u) / lds : 16;
@@ -1477,7 +1483,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
                                                  static_cast<int>(g3), hs, 1);
         if (e != hipSuccess) return hip_err(e, "spd solve launch");
         e = launch_manifold_apply<T>(d, p->host.n_clusters, t->span_v, t->crow, static_cast<int>(nv_s), p->n_cpl_rows, 1, x_s, x + b0 * nv, Hinv, cpl,
-                                     out + b0 * nv, nb, static_cast<int>(grid), hs);
+                                     out + b0 * nv, nb, static_cast<int>(grid), hs, big);
         if (e != hipSuccess) return hip_err(e, "manifold apply launch");
     }
     return GRBDA_OK;
@@ -1504,6 +1510,9 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
     const size_t nq_s = sp->host.nq, nv_s = sp->host.nv, nn_s = nv_s * nv_s;
     const bool need_d = dq || dqd;
+    const bool big = p->host.big_clusters;
+    if (big && need_d)
+        return set_err(GRBDA_EUNSUPPORTED, "derivatives with respect to q and qd are not covered for clusters beyond the structured kernels' limits");
     const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
     const bool solve = need_d || dtau;
     const int il = (need_d && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
@@ -1541,7 +1550,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         if (grid > n_tiles) grid = n_tiles;
         e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
                                           p->n_cpl_rows, need_d ? 1 : 0, qc, qdc, yddc, q_s, qd_s, need_d ? qdd_s : nullptr, cpl, nb,
-                                          static_cast<int>(grid), hs);
+                                          static_cast<int>(grid), hs, big);
         if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         if (!need_d && (e = hipMemsetAsync(qd_s, 0, chunk * nv_s * sizeof(T), hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
         if (need_d)
@@ -1561,7 +1570,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         T *H = !solve ? Hout + b0 * nn : ((dtau && !(il > 1 && (B % kDerivGroup) != 0)) ? dtau + b0 * nn : Hw);
         e = launch_manifold_project<T>(d, p->host.n_clusters, t->span_v, t->crow, t->deriv_related, ts->deriv_related, static_cast<int>(nv_s),
                                        p->n_cpl_rows, need_d ? 0 : 1, Aq, Av, Hs, tau_s, cpl, need_d ? Dq : nullptr, need_d ? Dqd : nullptr, H,
-                                       nb, static_cast<int>(grid), hs, solve ? il : 1);
+                                       nb, static_cast<int>(grid), hs, solve ? il : 1, big);
         if (e != hipSuccess) return hip_err(e, "manifold projection launch");
         if (!solve) {
             // packed lower rows -> the full symmetric matrix, in place
@@ -1901,7 +1910,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
                     for (int c = 0; c < p->host.n_clusters; c++) {
                         const ClusterRec &cr = p->host.lay64.clusters[c];
                         p->crow[c] = rows;
-                        if (cr.kind == CK_LOOP) rows += cr.k * cr.n * (4 + cr.n);
+                        if (cr.kind == CK_LOOP) rows += cr.k * (p->host.big_clusters ? cr.n : cr.n * (4 + cr.n));  // (manifold_kernels.hip, cpl_stride)
                     }
                     p->n_cpl_rows = rows;
                 } else {

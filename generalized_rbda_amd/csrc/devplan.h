@@ -179,14 +179,16 @@ size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
 template <class T>
 hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
                                       int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
-                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream);
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, bool big = false);
 template <class T>
 hipError_t launch_manifold_apply(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, int nv_s, int n_cpl_rows, int mode,
-                                 const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream);
+                                 const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream,
+                                 bool big = false);
 template <class T>
 hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
                                    const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
-                                   const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave);
+                                   const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave,
+                                   bool big = false);
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
 hipError_t set_max_dynamic_lds_deriv();
 hipError_t spd_bad_pivots(unsigned long long *count, int reset);

@@ -55,9 +55,36 @@ template <class T> __device__ __forceinline__ void sc_of(Du<T> x, Du<T> &s, Du<T
     c = Du<T>(cs, -sn * x.d);
 }
 
-constexpr int kMB = kMaxClusterBodies;  // 8
+// Array bounds of the per-lane work areas: KB bodies and KN independent coordinates per cluster are template parameters of
+// everything below.  <kMaxClusterBodies, kMaxClusterDof> (8, 4) is what the structured kernels cover and what the derivative
+// parts are compiled for; <kBigClusterBodies, kBigClusterDof> serves clusters beyond those limits (plan.h, HostPlan::big_clusters
+// -- the reference's parallel-chain benchmark family, Benchmarking/src/pinocchioHelpers.cpp:355-410): forward / inverse dynamics
+// and the mass matrix only, G kept in the coupling slab instead of registers, private arrays in scratch memory -- slow, correct.
 constexpr int kMR = 3;                  // constraint rows
-constexpr int kMN = kMaxClusterDof;     // 4
+// rows of the coupling slab per body of an implicit cluster with n independent coordinates: everything the derivatives need,
+// or G alone for the clusters beyond the structured kernels' limits (capi.cpp sizes crow / n_cpl_rows with the same rule)
+template <int KB>
+__device__ __forceinline__ int cpl_stride(int n)
+{
+    return KB > kMaxClusterBodies ? n : n * (4 + n);
+}
+// G (k x n) of the implicit cluster at hand: registers, or -- big clusters -- the slab rows it is handed on in anyway
+template <class T, int KB, int KN, bool SLAB = (KB > kMaxClusterBodies)>
+struct GStore {
+    T g[SLAB ? 1 : KB][SLAB ? 1 : KN];
+    T *cc;
+    int stride;
+    __device__ __forceinline__ T get(int i, int a) const
+    {
+        if constexpr (SLAB) return cc[(size_t)(i * stride + a) * kWave];
+        else return g[i][a];
+    }
+    __device__ __forceinline__ void set(int i, int a, T v)
+    {
+        if constexpr (SLAB) cc[(size_t)(i * stride + a) * kWave] = v;
+        else g[i][a] = v;
+    }
+};
 
 template <class S>
 __device__ __forceinline__ void cross_s(const S (&a)[3], const S (&b)[3], S (&o)[3])
@@ -69,9 +96,9 @@ __device__ __forceinline__ void cross_s(const S (&a)[3], const S (&b)[3], S (&o)
 
 // ---- URDF+ position loops: K (want_K) or kappa = Kdot qd (otherwise), in the scalar type S ------------------------------
 // sn / cs: sine and cosine of the k spanning angles; qd: the k spanning rates
-template <class T, class S>
+template <class T, class S, int KB>
 __device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
-                                   const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][kMB], S (&kap)[kMR])
+                                   const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][KB], S (&kap)[kMR])
 {
     cptr<int32_t> lp = loops;
     int row0 = 0;
@@ -83,7 +110,7 @@ __device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const C
             cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
             const int len = side == 0 ? np : ns;
             const T sgn = side == 0 ? T(1) : T(-1);
-            S E[9], r[3], A[kMB][3], O[kMB][3];
+            S E[9], r[3], A[KB][3], O[KB][3];
 #pragma unroll
             for (int i = 0; i < 9; i++) E[i] = S(i % 4 == 0 ? T(1) : T(0));
 #pragma unroll
@@ -178,9 +205,9 @@ __device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const C
 
 // ---- trig-polynomial phi (plan.cpp: ints [n_args, per row: n_terms, per term: n_factors, (type, argument)...], constants
 // [per distinct argument w[k], b][per term coef]) ---------------------------------------------------------------------------
-template <class T, class S>
+template <class T, class S, int KB>
 __device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32_t> prog, const S *q, const S *qd, bool want_K,
-                                 S (&K)[kMR][kMB], S (&kap)[kMR])
+                                 S (&K)[kMR][KB], S (&kap)[kMR])
 {
     const int k = c.k;
     cptr<int32_t> ip = prog;
@@ -189,9 +216,9 @@ __device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32
     cptr<T> cp = ap + n_args * (k + 1);
     for (int r = 0; r < c.rows; r++) {
         const int nt = *ip++;
-        S Krow[kMB], kd = S(T(0));
+        S Krow[KB], kd = S(T(0));
 #pragma unroll
-        for (int j = 0; j < kMB; j++) Krow[j] = S(T(0));
+        for (int j = 0; j < KB; j++) Krow[j] = S(T(0));
         for (int t = 0; t < nt; t++) {
             const int nf = *ip++;
             const T coef = *cp++;
@@ -245,19 +272,19 @@ __device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32
 }
 
 // K or kappa of an implicit cluster at the spanning state (q, qd), scalar type S
-template <class T, class S>
+template <class T, class S, int KB>
 __device__ void constraint_eval(cptr<T> consts, cptr<BodyRec> bodies, cptr<int32_t> cints, const ClusterRec &c, const S *q, const S *qd,
-                                bool want_K, S (&K)[kMR][kMB], S (&kap)[kMR])
+                                bool want_K, S (&K)[kMR][KB], S (&kap)[kMR])
 {
     cptr<int32_t> ip = cints + c.iofs;
     const int hdr0 = ip[0], n_ind = ip[1];
     cptr<int32_t> payload = ip + 3 + n_ind + c.rows;
     if (c.cons_type == 0) {
-        S sn[kMB], cs[kMB];
+        S sn[KB], cs[KB];
         for (int j = 0; j < c.k; j++) sc_of(q[j], sn[j], cs[j]);
-        loop_position_eval<T, S>(consts, bodies, c, payload, hdr0, sn, cs, qd, want_K, K, kap);
+        loop_position_eval<T, S, KB>(consts, bodies, c, payload, hdr0, sn, cs, qd, want_K, K, kap);
     } else {
-        trig_poly_eval_s<T, S>(consts, c, payload, q, qd, want_K, K, kap);
+        trig_poly_eval_s<T, S, KB>(consts, c, payload, q, qd, want_K, K, kap);
     }
 }
 
@@ -294,7 +321,7 @@ __device__ __forceinline__ void inv_rows(int R, const T (&A)[kMR][kMR], T (&Ai)[
 //       [G row n][(G_a' yd)_i, a < n][(G_a' ydd + d g / d y_a)_i][(d g / d yd_a)_i][G_a'[i][b], a-major]
 // span_q / span_v: first spanning position / velocity index of every body; want_d = 0: G rows only (mass matrix)
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int KB, int KN>
 __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_q_,
                                                                      const int32_t *__restrict__ span_v_, const int32_t *__restrict__ crow_,
                                                                      int nq_s, int nv_s, int n_cpl_rows, int want_d,
@@ -353,40 +380,45 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
             cptr<int32_t> ip = cints + cr.iofs;
             const int n_ind = ip[1], rows = cr.rows;
             cptr<int32_t> ind = ip + 2, dep = ip + 3 + n_ind;
-            T qv[kMB], yd[kMN], yddv[kMN];
-            for (int j = 0; j < kMB; j++) qv[j] = j < k ? qs[cr.q_index + j] : T(0);
-            for (int a = 0; a < kMN; a++) {
+            T qv[KB], yd[KN], yddv[KN];
+            for (int j = 0; j < KB; j++) qv[j] = j < k ? qs[cr.q_index + j] : T(0);
+            for (int a = 0; a < KN; a++) {
                 yd[a] = a < n ? qds[cr.v_index + a] : T(0);
                 yddv[a] = (a < n && ydds) ? ydds[cr.v_index + a] : T(0);
             }
-            T K[kMR][kMB], kap[kMR], zero[kMB];
+            T K[kMR][KB], kap[kMR], zero[KB];
             for (int r = 0; r < kMR; r++) {
                 kap[r] = 0;
-                for (int j = 0; j < kMB; j++) K[r][j] = 0;
+                for (int j = 0; j < KB; j++) K[r][j] = 0;
             }
-            for (int j = 0; j < kMB; j++) zero[j] = 0;
-            constraint_eval<T, T>(consts, bodies, cints, cr, qv, zero, true, K, kap);
-            T Kd[kMR][kMR], Kdi[kMR][kMR], G[kMB][kMN], qdv[kMB], gv[kMB];
+            for (int j = 0; j < KB; j++) zero[j] = 0;
+            constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, zero, true, K, kap);
+            T Kd[kMR][kMR], Kdi[kMR][kMR], qdv[KB], gv[KB];
+            const int stride = cpl_stride<KB>(n);
+            T *cc = cp + (size_t)crow[c] * kWave;
+            GStore<T, KB, KN> G;
+            G.cc = cc;
+            G.stride = stride;
             for (int r = 0; r < kMR; r++)
                 for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
             inv_rows(rows, Kd, Kdi);
-            for (int i = 0; i < kMB; i++) {
+            for (int i = 0; i < k; i++) {
                 gv[i] = 0;
-                for (int a = 0; a < kMN; a++) G[i][a] = 0;
+                for (int a = 0; a < n; a++) G.set(i, a, T(0));
             }
-            for (int a = 0; a < n; a++) G[ind[a]][a] = 1;
+            for (int a = 0; a < n; a++) G.set(ind[a], a, T(1));
             for (int r = 0; r < rows; r++)
                 for (int a = 0; a < n; a++) {
                     T s = 0;
                     for (int j = 0; j < rows; j++) s += Kdi[r][j] * K[j][ind[a]];
-                    G[dep[r]][a] = -s;
+                    G.set(dep[r], a, -s);
                 }
             for (int i = 0; i < k; i++) {
                 T s = 0;
-                for (int a = 0; a < n; a++) s += G[i][a] * yd[a];
+                for (int a = 0; a < n; a++) s += G.get(i, a) * yd[a];
                 qdv[i] = s;
             }
-            constraint_eval<T, T>(consts, bodies, cints, cr, qv, qdv, false, K, kap);  // (K is not touched: want_K false)
+            constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, qdv, false, K, kap);  // (K is not touched: want_K false)
             for (int r = 0; r < rows; r++) {
                 T s = 0;
                 for (int j = 0; j < rows; j++) s += Kdi[r][j] * kap[j];
@@ -398,51 +430,51 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                     ov[span_v[cr.first_body + i]] = qdv[i];
                     if (oa) {
                         T s = gv[i];
-                        for (int a = 0; a < n; a++) s += G[i][a] * yddv[a];
+                        for (int a = 0; a < n; a++) s += G.get(i, a) * yddv[a];
                         oa[span_v[cr.first_body + i]] = s;
                     }
                 }
             }
-            const int stride = n * (4 + n);
-            T *cc = cp + (size_t)crow[c] * kWave;
-            for (int i = 0; i < k; i++)
-                for (int a = 0; a < n; a++) cc[(size_t)(i * stride + a) * kWave] = G[i][a];
-            if (!want_d) continue;
+            if constexpr (KB <= kMaxClusterBodies) {
+                for (int i = 0; i < k; i++)
+                    for (int a = 0; a < n; a++) cc[(size_t)(i * stride + a) * kWave] = G.g[i][a];
+            }
+            if (!want_d || KB > kMaxClusterBodies) continue;
             // ---- first-order parts along every independent coordinate ----
             for (int i = 0; i < k; i++)
                 for (int j = n; j < stride; j++) cc[(size_t)(i * stride + j) * kWave] = 0;
             for (int a = 0; a < n; a++) {
-                Du<T> qD[kMB], qdD[kMB], KD[kMR][kMB], kapD[kMR];
-                for (int j = 0; j < kMB; j++) {
-                    qD[j] = Du<T>(qv[j], j < k ? G[j][a] : T(0));
+                Du<T> qD[KB], qdD[KB], KD[kMR][KB], kapD[kMR];
+                for (int j = 0; j < KB; j++) {
+                    qD[j] = Du<T>(qv[j], j < k ? G.get(j, a) : T(0));
                     qdD[j] = Du<T>(T(0));
                 }
                 for (int r = 0; r < kMR; r++) {
                     kapD[r] = Du<T>(T(0));
-                    for (int j = 0; j < kMB; j++) KD[r][j] = Du<T>(T(0));
+                    for (int j = 0; j < KB; j++) KD[r][j] = Du<T>(T(0));
                 }
-                constraint_eval<T, Du<T>>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD);
+                constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD);
                 // G' (dependent rows) = -Kd^-1 K' G ;  d g / d yd_a = -2 Kd^-1 K' qd_s
-                T Gp[kMR][kMN], KpQd[kMR], qdp[kMB];
+                T Gp[kMR][KN], KpQd[kMR], qdp[KB];
                 for (int r = 0; r < rows; r++) {
                     T s = 0;
                     for (int j = 0; j < k; j++) s += KD[r][j].d * qdv[j];
                     KpQd[r] = s;
                 }
-                for (int j = 0; j < kMB; j++) qdp[j] = 0;
+                for (int j = 0; j < KB; j++) qdp[j] = 0;
                 for (int r = 0; r < rows; r++)
                     for (int b2 = 0; b2 < n; b2++) {
                         T s = 0;
                         for (int r2 = 0; r2 < rows; r2++) {
                             T kg = 0;  // (K' G)[r2][b2]
-                            for (int j = 0; j < k; j++) kg += KD[r2][j].d * G[j][b2];
+                            for (int j = 0; j < k; j++) kg += KD[r2][j].d * G.get(j, b2);
                             s += Kdi[r][r2] * kg;
                         }
                         Gp[r][b2] = -s;
                         qdp[dep[r]] += -s * yd[b2];
                     }
-                for (int j = 0; j < kMB; j++) qdD[j] = Du<T>(j < k ? qdv[j] : T(0), qdp[j]);
-                constraint_eval<T, Du<T>>(consts, bodies, cints, cr, qD, qdD, false, KD, kapD);  // (KD is not touched)
+                for (int j = 0; j < KB; j++) qdD[j] = Du<T>(j < k ? qdv[j] : T(0), qdp[j]);
+                constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, false, KD, kapD);  // (KD is not touched)
                 for (int r = 0; r < rows; r++) {
                     const int i = dep[r];
                     T gy = 0, gyd = 0, ay = 0, by = 0;
@@ -475,7 +507,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
 //   outputs Dq, Dqd, H in the layout spd_solve reads for the model's own nv (packed runs / packed lower rows, interleaved by IL)
 // mode 0: all three; mode 1: H only (Aq, Av, tau_s unused)
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, int IL>
+template <class T, int IL, int KB, int KN>
 __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_v_,
                                                                   const int32_t *__restrict__ crow_, const uint64_t *__restrict__ rel_,
                                                                   const uint64_t *__restrict__ rel_s_, int nv_s, int n_cpl_rows, int mode,
@@ -508,13 +540,13 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
         for (int cJ = 0; cJ < n_clusters; cJ++) {
             const ClusterRec J = load_rec(clusters + cJ);
             const int nJ = J.kind == CK_FREE ? 6 : J.n, kJ = J.kind == CK_FREE ? 6 : J.k;
-            const int strideJ = J.kind == CK_LOOP ? J.n * (4 + J.n) : 0;
+            const int strideJ = J.kind == CK_LOOP ? cpl_stride<KB>(J.n) : 0;
             const T *cJp = cp + (size_t)(J.kind == CK_LOOP ? crow[cJ] : 0) * kWave;
             for (int a = 0; a < nJ; a++) {
                 // column data over the spanning coordinates of cluster J: G e_a, G_a' yd, G_a' ydd + dg/dy_a, dg/dyd_a
-                T gJ[kMB], ayJ[kMB], byJ[kMB], bvJ[kMB];
-                int svJ[kMB];
-                for (int s = 0; s < kMB; s++) {
+                T gJ[KB], ayJ[KB], byJ[KB], bvJ[KB];
+                int svJ[KB];
+                for (int s = 0; s < KB; s++) {
                     gJ[s] = ayJ[s] = byJ[s] = bvJ[s] = 0;
                     svJ[s] = 0;
                     if (s >= kJ) continue;
@@ -539,10 +571,10 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
                     const ClusterRec I = load_rec(clusters + cI);
                     if (!((rel[I.v_index] >> J.v_index) & 1)) continue;  // clusters on different branches: structural zeros
                     const int nI = I.kind == CK_FREE ? 6 : I.n, kI = I.kind == CK_FREE ? 6 : I.k;
-                    const int strideI = I.kind == CK_LOOP ? I.n * (4 + I.n) : 0;
+                    const int strideI = I.kind == CK_LOOP ? cpl_stride<KB>(I.n) : 0;
                     const T *cIp = cp + (size_t)(I.kind == CK_LOOP ? crow[cI] : 0) * kWave;
-                    T oq[kMN + 2], ov[kMN + 2], oh[kMN + 2];
-                    for (int b2 = 0; b2 < kMN + 2; b2++) oq[b2] = ov[b2] = oh[b2] = 0;
+                    T oq[KN + 2], ov[KN + 2], oh[KN + 2];
+                    for (int b2 = 0; b2 < KN + 2; b2++) oq[b2] = ov[b2] = oh[b2] = 0;
                     for (int ri = 0; ri < kI; ri++) {
                         const int r = I.kind == CK_FREE ? span_v[I.first_body] + ri : span_v[I.first_body + ri];
                         const uint64_t rr = rel_s[r];
@@ -594,7 +626,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
 //   mode 0 (inverse dynamics):  out = G^T x_s                                   x_s = tau_s(q_s, G yd, G ydd + g)
 //   mode 1 (forward dynamics):  out = Hinv (tau - G^T x_s)                      x_s = C_s + H_s g,  Hinv = (G^T H_s G)^-1 [B][nv][nv]
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int KB>
 __global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_v_,
                                                                 const int32_t *__restrict__ crow_, int nv_s, int n_cpl_rows, int mode,
                                                                 const T *__restrict__ x_s, const T *__restrict__ tau,
@@ -617,7 +649,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP,
         for (int c = 0; c < n_clusters; c++) {
             const ClusterRec cr = load_rec(clusters + c);
             const int n = cr.kind == CK_FREE ? 6 : cr.n, k = cr.kind == CK_FREE ? 6 : cr.k;
-            const int stride = cr.kind == CK_LOOP ? cr.n * (4 + cr.n) : 0;
+            const int stride = cr.kind == CK_LOOP ? cpl_stride<KB>(cr.n) : 0;
             const T *cc = cp + (size_t)(cr.kind == CK_LOOP ? crow[c] : 0) * kWave;
             for (int a = 0; a < n; a++) {
                 T s = 0;
@@ -646,52 +678,70 @@ __global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP,
         }
     }
 }
+// `big`: the plan has clusters beyond kMaxClusterBodies / kMaxClusterDof (HostPlan::big_clusters): the wide variants, G-only slab
 template <class T>
 hipError_t launch_manifold_apply(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, int nv_s, int n_cpl_rows, int mode,
-                                 const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream)
+                                 const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream, bool big)
 {
-    hipLaunchKernelGGL((manifold_apply_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, nv_s, n_cpl_rows, mode, x_s,
-                       tau, Hinv, cpl, out, B);
+    if (big)
+        hipLaunchKernelGGL((manifold_apply_kernel<T, kBigClusterBodies>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, nv_s,
+                           n_cpl_rows, mode, x_s, tau, Hinv, cpl, out, B);
+    else
+        hipLaunchKernelGGL((manifold_apply_kernel<T, kMaxClusterBodies>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, nv_s,
+                           n_cpl_rows, mode, x_s, tau, Hinv, cpl, out, B);
     return hipGetLastError();
 }
 template hipError_t launch_manifold_apply<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, int, int, int, const float *,
-                                                 const float *, const float *, const float *, float *, size_t, int, hipStream_t);
+                                                 const float *, const float *, const float *, float *, size_t, int, hipStream_t, bool);
 template hipError_t launch_manifold_apply<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, int, int, int, const double *,
-                                                  const double *, const double *, const double *, double *, size_t, int, hipStream_t);
+                                                  const double *, const double *, const double *, double *, size_t, int, hipStream_t, bool);
 
 template <class T>
 hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
                                       int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
-                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream)
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, bool big)
 {
-    hipLaunchKernelGGL((manifold_constraint_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_q, span_v, crow, nq_s, nv_s,
-                       n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
+    if (big) {
+        if (want_d) return hipErrorInvalidValue;  // (the wide variant carries no derivative parts)
+        hipLaunchKernelGGL((manifold_constraint_kernel<T, kBigClusterBodies, kBigClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
+                           span_q, span_v, crow, nq_s, nv_s, n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
+    } else {
+        hipLaunchKernelGGL((manifold_constraint_kernel<T, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
+                           span_q, span_v, crow, nq_s, nv_s, n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
+    }
     return hipGetLastError();
 }
 template <class T>
 hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
                                    const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
-                                   const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave)
+                                   const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave,
+                                   bool big)
 {
-    if (interleave == kDerivGroup)
-        hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, rel, rel_s,
-                           nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
-    else
-        hipLaunchKernelGGL((manifold_project_kernel<T, 1>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_v, crow, rel, rel_s, nv_s,
-                           n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
+    if (big) {
+        if (mode != 1 || interleave != 1) return hipErrorInvalidValue;  // (H only, state-major)
+        hipLaunchKernelGGL((manifold_project_kernel<T, 1, kBigClusterBodies, kBigClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
+                           span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
+    } else if (interleave == kDerivGroup) {
+        hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P,
+                           n_clusters, span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
+    } else {
+        hipLaunchKernelGGL((manifold_project_kernel<T, 1, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
+                           span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
+    }
     return hipGetLastError();
 }
 template hipError_t launch_manifold_constraint<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const int32_t *, int, int, int,
                                                       int, const float *, const float *, const float *, float *, float *, float *, float *,
-                                                      size_t, int, hipStream_t);
+                                                      size_t, int, hipStream_t, bool);
 template hipError_t launch_manifold_constraint<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const int32_t *, int, int,
                                                        int, int, const double *, const double *, const double *, double *, double *, double *,
-                                                       double *, size_t, int, hipStream_t);
+                                                       double *, size_t, int, hipStream_t, bool);
 template hipError_t launch_manifold_project<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const uint64_t *,
                                                    const uint64_t *, int, int, int, const float *, const float *, const float *, const float *,
-                                                   const float *, float *, float *, float *, size_t, int, hipStream_t, int);
+                                                   const float *, float *, float *, float *, size_t, int, hipStream_t, int, bool);
 template hipError_t launch_manifold_project<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const uint64_t *,
                                                     const uint64_t *, int, int, int, const double *, const double *, const double *,
-                                                    const double *, const double *, double *, double *, double *, size_t, int, hipStream_t, int);
+                                                    const double *, const double *, double *, double *, double *, size_t, int, hipStream_t, int,
+                                                    bool);
 
 }  // namespace grbda_hip

@@ -103,8 +103,16 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         b_end += cl.n_bodies;
         q_end += cl.n_pos;
         v_end += cl.n_vel;
-        if (cl.n_bodies > kMaxClusterBodies)
+        // clusters beyond the structured kernels' limits (kMaxClusterBodies, kMaxClusterDof) go through the spanning tree:
+        // HostPlan::big_clusters, manifold_kernels.hip's wide variants
+        const bool no_big = std::getenv("GRBDA_NO_PROJECTION") != nullptr;
+        if (cl.n_bodies > (no_big ? kMaxClusterBodies : kBigClusterBodies))
             return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d bodies exceed the kernel limit", c, cl.n_bodies);
+        const int max_dof = no_big ? kMaxClusterDof : kBigClusterDof;
+        if (cl.constraint_type != GRBDA_CONSTRAINT_FREE && (cl.n_bodies > kMaxClusterBodies || cl.n_vel > kMaxClusterDof)) {
+            P.projection_only = true;
+            P.big_clusters = true;
+        }
 
         ClusterRec &cr = clusters[c];
         cr.first_body = cl.first_body;
@@ -123,7 +131,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             if (cl.n_pos != npos) return fail(msg, cap, GRBDA_EINVAL, "cluster %d: free joint position count", c);
             cr.kind = CK_FREE;
         } else if (cl.constraint_type == GRBDA_CONSTRAINT_STATIC) {
-            if (cl.n_vel < 1 || cl.n_vel > kMaxClusterDof)
+            if (cl.n_vel < 1 || cl.n_vel > max_dof)
                 return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d DoF exceed the kernel limit", c, cl.n_vel);
             if (cl.n_span_vel != cl.n_bodies || cl.n_span_pos != cl.n_bodies || cl.n_pos != cl.n_vel)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: static cluster must have one revolute joint per body", c);
@@ -131,7 +139,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: G payload missing", c);
             cr.kind = CK_STATIC;
         } else if (cl.constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION || cl.constraint_type == GRBDA_CONSTRAINT_TRIG_POLY) {
-            if (cl.n_vel < 1 || cl.n_vel > kMaxClusterDof)
+            if (cl.n_vel < 1 || cl.n_vel > max_dof)
                 return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d DoF exceed the kernel limit", c, cl.n_vel);
             if (cl.n_span_vel != cl.n_bodies || cl.n_span_pos != cl.n_bodies || cl.n_pos != cl.n_bodies)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop cluster must have one revolute joint per body", c);
@@ -186,7 +194,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     for (int b = 0; b < nb; b++)
         if (bodies[b].parent >= 0) bodies[bodies[b].parent].has_child = 1;
     for (int b = 0; b < nb; b++)
-        if (bodies[b].has_child) clusters[m.bodies[b].cluster].child_mask |= 1 << m.bodies[b].sub_index;
+        if (bodies[b].has_child && m.bodies[b].sub_index < 31) clusters[m.bodies[b].cluster].child_mask |= 1 << m.bodies[b].sub_index;
 
     // ---- canonical joint axes -------------------------------------------------------------------
     // The model is re-expressed so that every revolute joint turns about the z axis of its body frame

@@ -45,6 +45,9 @@ enum ClusterKind : int32_t {
 
 constexpr int kMaxClusterDof = 4;     // n of a non-free cluster handled in registers
 constexpr int kMaxClusterBodies = 8;  // k
+// clusters beyond those two limits run through the spanning tree only (HostPlan::big_clusters; manifold_kernels.hip's wide variants)
+constexpr int kBigClusterBodies = 48;
+constexpr int kBigClusterDof = 48;
 constexpr int kWave = 64;
 constexpr int32_t kSlotGlobal = 1 << 30;
 
@@ -438,6 +441,7 @@ struct HostPlan {
     // run through the SPANNING TREE and the per-state G instead -- H = G^T H_s G, ydd = H^-1 (tau - G^T (C_s + H_s g)), the
     // reference's own cross-check (RigidBodyTreeDynamics.cpp:86-97) -- capi.cpp projection_run; no sweep programs are built.
     bool projection_only = false;
+    bool big_clusters = false;  // a cluster exceeds kMaxClusterBodies / kMaxClusterDof: spanning-tree route, forward / inverse dynamics and H only
     double gravity[6] = {0, 0, 0, 0, 0, -9.81};
     std::vector<Step> aba_steps;
     std::vector<Step> rnea_steps;

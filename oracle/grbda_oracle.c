@@ -20,11 +20,19 @@ typedef grbda_real real;  /* working precision; the model description stays doub
 #include <stdlib.h>
 #include <string.h>
 
+/* (_build/libgrbda_oracle_big.so is this file with -DMAXK=48 -DMAXN=48: the checker of the clusters beyond the HIP kernels'
+ * structured limits -- the per-cluster workspace below grows with (6 MAXK)^2, so the default build stays small) */
+#ifndef MAXK
 #define MAXK 8            /* bodies per cluster */
+#endif
 #define MAXD (6 * MAXK)   /* motion-subspace dimension of a cluster */
+#ifndef MAXN
 #define MAXN 8            /* independent velocities per cluster */
+#endif
 #define MAXSP (MAXK + 6)  /* spanning positions per cluster */
+#ifndef MAXROWS
 #define MAXROWS 8         /* constraint rows per cluster */
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* small dense helpers (row-major)                                                            */

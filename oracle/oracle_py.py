@@ -14,15 +14,32 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_LIB = os.path.join(_HERE, "_build", "libgrbda_oracle.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libgrbda_codegen_ref.so")
 
+BIG_LIB = os.path.join(_HERE, "_build", "libgrbda_oracle_big.so")  # the same source with MAXK = MAXN = 48 (oracle/Makefile)
+
 _lib = None
+_lib_big = None
 
 
 def build():
     subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
 
 
-def lib():
-    global _lib
+def lib(big=False):
+    """big: the build with room for clusters of up to 48 bodies / 48 independent coordinates (tests of the spanning-tree
+    route for clusters beyond the HIP kernels' structured limits)."""
+    global _lib, _lib_big
+    if big:
+        if _lib_big is None:
+            if not os.path.exists(BIG_LIB):
+                build()
+            L = ctypes.CDLL(BIG_LIB)
+            for name in ("grbda_oracle_forward_dynamics", "grbda_oracle_inverse_dynamics",
+                         "grbda_oracle_forward_dynamics_projection"):
+                getattr(L, name).argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]
+            L.grbda_oracle_cluster_constraint.argtypes = [c_void_p, c_size_t, c_int] + [c_void_p] * 7
+            L.grbda_oracle_project_positions.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]
+            _lib_big = L
+        return _lib_big
     if _lib is None:
         if not os.path.exists(ORACLE_LIB):
             build()
@@ -54,16 +71,16 @@ def _run(fn, blob, q, qd, x, f_ext=None):
     return out
 
 
-def forward_dynamics(blob, q, qd, tau, f_ext=None):
-    return _run(lib().grbda_oracle_forward_dynamics, blob, q, qd, tau, f_ext)
+def forward_dynamics(blob, q, qd, tau, f_ext=None, big=False):
+    return _run(lib(big).grbda_oracle_forward_dynamics, blob, q, qd, tau, f_ext)
 
 
-def inverse_dynamics(blob, q, qd, ydd, f_ext=None):
-    return _run(lib().grbda_oracle_inverse_dynamics, blob, q, qd, ydd, f_ext)
+def inverse_dynamics(blob, q, qd, ydd, f_ext=None, big=False):
+    return _run(lib(big).grbda_oracle_inverse_dynamics, blob, q, qd, ydd, f_ext)
 
 
-def forward_dynamics_projection(blob, q, qd, tau, f_ext=None):
-    return _run(lib().grbda_oracle_forward_dynamics_projection, blob, q, qd, tau, f_ext)
+def forward_dynamics_projection(blob, q, qd, tau, f_ext=None, big=False):
+    return _run(lib(big).grbda_oracle_forward_dynamics_projection, blob, q, qd, tau, f_ext)
 
 
 def forward_dynamics_mt(blob, q, qd, tau, n_threads):
@@ -119,7 +136,7 @@ def body_poses(blob, q, n_bodies):
     return out
 
 
-def spanning_state(blob, q, qd):
+def spanning_state(blob, q, qd, big=False):
     """(q_span[B, sum n_span_pos], qd_span[B, sum n_span_vel], gmax[B], kcond[B]) -- toSpanningTreeState of every cluster."""
     import struct
     q, qd = _f64(q), _f64(qd)
@@ -129,7 +146,7 @@ def spanning_state(blob, q, qd):
     nsv = sum(struct.unpack_from("<16i", blob, off + 64 * c)[8] for c in range(nc))
     B = q.shape[0]
     qs, vs, gm, kc = np.zeros((B, nsp)), np.zeros((B, nsv)), np.zeros(B), np.zeros(B)
-    L = lib()
+    L = lib(big)
     L.grbda_oracle_spanning_state.argtypes = [c_void_p, c_size_t] + [c_void_p] * 6 + [c_size_t]
     rc = L.grbda_oracle_spanning_state(blob, len(blob), q.ctypes.data, qd.ctypes.data, qs.ctypes.data, vs.ctypes.data,
                                        gm.ctypes.data, kc.ctypes.data, B)
@@ -138,10 +155,10 @@ def spanning_state(blob, q, qd):
     return qs, vs, gm, kc
 
 
-def project_positions(blob, q, max_iter=50):
+def project_positions(blob, q, max_iter=50, big=False):
     q = _f64(q).copy()
     ok = np.zeros(q.shape[0], dtype=np.int32)
-    rc = lib().grbda_oracle_project_positions(blob, len(blob), q.ctypes.data, q.shape[0], max_iter, ok.ctypes.data)
+    rc = lib(big).grbda_oracle_project_positions(blob, len(blob), q.ctypes.data, q.shape[0], max_iter, ok.ctypes.data)
     if rc:
         raise RuntimeError(f"oracle error {rc}")
     return q, ok.astype(bool)

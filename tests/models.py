@@ -203,14 +203,16 @@ def chain_test_tree(seed, n_limbs=4, ori_repr="quaternion", rotors=True, deep_pa
 ROBOT_MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "robot-models")
 
 
-def valid_states(blob, B, config_index=0, max_cond=None):
+def valid_states(blob, B, config_index=0, max_cond=None, big=False, scale=1.0):
     """random_states + (for implicit-loop clusters) Newton projection of the dependent positions onto
     phi(q) = 0 with the oracle, rejecting states that do not converge (GenericJoint.cpp:289-385) or that fail the
     conditioning gate of generalized_rbda_amd/states.py (evaluated on the ORACLE's constraint Jacobian here).
     max_cond: a tighter bound on the condition number of K_d, for the tests that compare DERIVATIVES with differences taken along
     re-projected states: a state that satisfies phi to 1e-12 sits 1e-12 / sigma_min(K_d) off the manifold, and d G / d y changes by
     ~1 / sigma_min^3 per unit of that distance -- at cond 1400 the analytic derivative AT the state and the difference quotient ALONG
-    the manifold differ by per cents although both are exact (measured on four_bar.urdf next to its flat pose)."""
+    the manifold differ by per cents although both are exact (measured on four_bar.urdf next to its flat pose).
+    big: the oracle build with room for clusters of 48 bodies; scale: shrinks the drawn positions (long closed chains close only near
+    their reference configuration)."""
     import oracle_py as O
     from generalized_rbda_amd.states import accept, parse_clusters, random_states
 
@@ -220,8 +222,9 @@ def valid_states(blob, B, config_index=0, max_cond=None):
     have, attempt = 0, 0
     while have < B:
         q, qd, tau = random_states(blob, max(2 * B, 16), config_index + 7919 * attempt)
-        q, ok = O.project_positions(blob, q)
-        gmax, kcond = O.spanning_state(blob, q, qd)[2:]
+        q *= scale
+        q, ok = O.project_positions(blob, q, big=big)
+        gmax, kcond = O.spanning_state(blob, q, qd, big=big)[2:]
         ok &= accept(blob, q, gmax, kcond)
         if max_cond is not None:
             ok &= kcond < max_cond

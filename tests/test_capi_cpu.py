@@ -151,3 +151,44 @@ def test_chain_program_covers_the_headline_models():
         assert info.chain_aba_f32 == 1 and info.n_chain_generic >= 1, name
     for name, blob in z.items():
         assert G.Plan(blob).info().chain_aba_f32 == 1, name
+
+
+def test_parallel_chain_generator_reproduces_the_reference_files(tmp_path):
+    """tests/parallel_chains.py writes the reference's parallel-chain family for any (depth, loop size); for the two files of that
+    family kept under tests/golden/robot-models (the reference's own depth-10 models) it gives the same model description."""
+    from models import ROBOT_MODELS
+    from parallel_chains import parallel_chain_urdf
+
+    for implicit, loop, name in ((False, 16, "parallel_chain_exp_d10_l16"), (True, 17, "parallel_chain_imp_d10_l17")):
+        path = tmp_path / (name + ".urdf")
+        path.write_text(parallel_chain_urdf(10, loop, implicit))
+        assert G.urdf_to_blob(str(path)) == G.urdf_to_blob(os.path.join(ROBOT_MODELS, name + ".urdf"))
+
+
+@pytest.mark.parametrize("implicit,depth,loop", [(False, 10, 16), (True, 10, 17), (False, 20, 30), (True, 20, 31)])
+def test_clusters_beyond_the_structured_limits_compile_to_the_spanning_tree_route(tmp_path, monkeypatch, implicit, depth, loop):
+    """Clusters of more than 8 bodies / 4 independent coordinates (asked for since round 1; the reference's parallel-chain benchmark
+    family reaches 41 bodies) compile to a plan on the spanning-tree route (HostPlan::big_clusters).  The checker for them is the
+    oracle built with room for 48 bodies per cluster; its cluster recursion agrees with its own Projection-method restatement and
+    inverts its inverse dynamics."""
+    import oracle_py as O
+    from models import valid_states
+    from parallel_chains import parallel_chain_urdf
+
+    path = tmp_path / "pc.urdf"
+    path.write_text(parallel_chain_urdf(depth, loop, implicit))
+    plan = G.Plan.from_urdf(str(path))
+    assert plan.info().spanning_tree_route == 1
+    assert plan.n_bodies == 2 * depth + (1 if implicit else 0) and plan.nv == 2 * depth - 1
+    blob = plan.blob
+    q, qd, tau = valid_states(blob, 12, config_index=5, big=True, scale=0.5)
+    a = O.forward_dynamics(blob, q, qd, tau, big=True)
+    b = O.forward_dynamics_projection(blob, q, qd, tau, big=True)
+    assert np.abs(a - b).max() / (1 + np.abs(a).max()) < 5e-8
+    assert np.abs(O.inverse_dynamics(blob, q, qd, a, big=True) - tau).max() / (1 + np.abs(a).max()) < 5e-8
+    with pytest.raises(RuntimeError):  # (the default build of the checker has no room for them)
+        O.forward_dynamics(blob, q, qd, tau)
+    monkeypatch.setenv("GRBDA_NO_PROJECTION", "1")  # (A/B switch: the old refusal)
+    with pytest.raises(G.GrbdaError) as e:
+        G.Plan(blob)
+    assert e.value.code == -2 and "exceed the kernel limit" in str(e.value)

@@ -1017,3 +1017,48 @@ def test_cluster_on_two_parent_bodies_spanning_tree_route(gpu):
             assert np.abs(got - col).max() / (1 + np.abs(col).max()) < 2e-5
             col_t = O.forward_dynamics(blob, q[b:b + 1], qd[b:b + 1], tau[b:b + 1] + e[k])[0] - ref[b]
             assert np.abs(d["dtau"][b, :, k].cpu().numpy() - col_t).max() / (1 + np.abs(col_t).max()) < 1e-8
+
+
+BIG_CHAINS = [  # (implicit, depth, loop size): the reference's parallel-chain family beyond 8 bodies / 4 DoF per cluster
+    (False, 10, 12), (False, 10, 16), (False, 20, 24), (False, 20, 30),
+    (True, 10, 13), (True, 10, 17), (True, 20, 25), (True, 20, 31),
+]
+
+
+@pytest.mark.parametrize("implicit,depth,loop", BIG_CHAINS)
+def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu, tmp_path, implicit, depth, loop):
+    """Clusters of 12 .. 31 bodies with 11 .. 29 independent coordinates (the reference's parallel-chain benchmark family,
+    Benchmarking/urdfs/parallel_chains; sizes from pinocchioHelpers.cpp:355-410): forward and inverse dynamics and the mass matrix
+    through the spanning tree (HostPlan::big_clusters, manifold_kernels.hip's wide variants) against the oracle built with room for
+    48 bodies per cluster (oracle/_build/libgrbda_oracle_big.so) -- fp64 1e-9, fp32 1e-3 of the largest entry (1e-2 for the chains of
+    depth 20: forward dynamics through a dense 39 x 39 solve in fp32 on chains twenty links long; measured 1.4e-3)."""
+    import torch
+    from parallel_chains import parallel_chain_urdf
+
+    path = tmp_path / "pc.urdf"
+    path.write_text(parallel_chain_urdf(depth, loop, implicit))
+    plan = G.Plan.from_urdf(str(path))
+    info = plan.info()
+    assert info.spanning_tree_route == 1
+    blob = plan.blob
+    B, nv = 130, plan.nv
+    q, qd, tau = valid_states(blob, B, config_index=17, big=True, scale=0.5, max_cond=50 if implicit else None)
+    ref = O.forward_dynamics(blob, q, qd, tau, big=True)
+    ref_id = O.inverse_dynamics(blob, q, qd, tau, big=True)
+    for dt, tol in ((torch.float64, 1e-9), (torch.float32, 1e-3 if depth <= 10 else 1e-2)):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+        ydd = plan.forward_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
+        tid = plan.inverse_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
+        assert np.abs(ydd - ref).max() / (1 + np.abs(ref).max()) < tol
+        assert np.abs(tid - ref_id).max() / (1 + np.abs(ref_id).max()) < (tol if dt == torch.float64 else 1e-3)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    H = plan.mass_matrix(t(q[:32])).cpu().numpy()
+    e = np.eye(nv)
+    z = np.zeros_like(qd[:32])
+    C = O.inverse_dynamics(blob, q[:32], z, z, big=True)
+    for k in range(nv):
+        col = O.inverse_dynamics(blob, q[:32], z, np.tile(e[k], (32, 1)), big=True) - C
+        assert np.abs(H[:, :, k] - col).max() < 1e-9 * (1 + np.abs(col).max())
+    # what the route does not cover says so
+    with pytest.raises(Exception):
+        plan.fd_dq(t(q[:4]), t(qd[:4]), t(tau[:4]))
