@@ -463,8 +463,8 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     const int w = sizeof(T) == 8 ? 2 : (wide ? 1 : 0);
     const int kid = sizeof(T) == 8 ? 1 : 0;
     const ChainProgram &cp = w == 2 ? h.chain64 : (wide ? h.chain32w : h.chain32);
-    const size_t waves_per_cu = wide ? 16 : static_cast<size_t>(p->waves_per_cu[kid]);
-    const size_t lds_budget = wide ? 10240 : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
+    const size_t waves_per_cu = wide ? static_cast<size_t>(4 * kChainWideWps) : static_cast<size_t>(p->waves_per_cu[kid]);
+    const size_t lds_budget = wide ? static_cast<size_t>(kChainWideLdsBytes) : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
     ChainDev<T> d;
     d.segs = t.chain_segs[w];
     d.links = t.chain_links[w];
@@ -542,8 +542,8 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     d.n_glb_slots = rp.n_glb;
     d.ori_repr = h.ori_repr;
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
-    const size_t waves_per_cu = wide ? 16 : static_cast<size_t>(p->waves_per_cu[kid]);  // the ABA launch shape: 8 wavefronts per CU
-    const size_t lds_budget = wide ? 10240 : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
+    const size_t waves_per_cu = wide ? static_cast<size_t>(4 * kChainWideWps) : static_cast<size_t>(p->waves_per_cu[kid]);  // the ABA launch shape: 8 wavefronts per CU
+    const size_t lds_budget = wide ? static_cast<size_t>(kChainWideLdsBytes) : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
     size_t grid = static_cast<size_t>(t.n_cu) * waves_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     size_t lds_bytes = static_cast<size_t>(rp.n_lds) * kWave * sizeof(T);
@@ -1724,7 +1724,7 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
                               gen1_waves_per_simd<T>(cp.gens[0].n));
                 return buf;
             case ABA_LM: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s>", tn); return buf;
-            case ABA_CHAIN_WIDE: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, 4, 0>", tn); return buf;
+            case ABA_CHAIN_WIDE: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, 0>", tn, kChainWideWps); return buf;
             case ABA_CHAIN:
                 std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, 2, %d>", tn, !cp.gens.empty() ? 2 : (!cp.diffs.empty() ? 1 : 0));
                 return buf;
@@ -1881,7 +1881,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     lds.aba64 = p->lds_bytes_per_wave[1] / (8 * kWave);
     lds.rnea32 = p->lds_bytes_per_wave[2] / (4 * kWave);
     lds.rnea64 = p->lds_bytes_per_wave[3] / (8 * kWave);
-    lds.chain32w = 10240 / (4 * kWave);
+    lds.chain32w = kChainWideLdsBytes / (4 * kWave);
     // profiling aid (results are wrong when set): GRBDA_DEBUG_SWEEPS is a bit mask of the ABA sweeps to
     // keep -- 1 forward, 2 backward, 4 acceleration -- so that the cost of each sweep can be ablated
 #ifdef GRBDA_EXP

@@ -2113,7 +2113,7 @@ hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const
     }
     if constexpr (sizeof(T) == 4) {
         if (four_waves_per_simd) {
-            hipLaunchKernelGGL((aba_chain_kernel<T, 4, 0>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+            hipLaunchKernelGGL((aba_chain_kernel<T, kChainWideWps, 0>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
             return hipGetLastError();
         }
     }

@@ -192,8 +192,18 @@ struct PartStore {
 // was bound by that (round 3, calibrated FETCH_SIZE / WRITE_SIZE).  Interleaving four states makes every store a run of
 // 16-byte pieces, a quarter of the open lines (measured 2.2 -> 1.45 ms per 131 072 states at four wavefronts per CU;
 // factors 8, 16 and 64 add 2-4 % more and cost the solve its cooperative 4-wavefront copy).
+// (experiment builds: -DGRBDA_EXP_DERIV_WPS=2 asks for two wavefronts per SIMD, -DGRBDA_EXP_PART_LDS keeps the carried composites in LDS
+// for fp32 too)
+#ifndef GRBDA_EXP_DERIV_WPS
+#define GRBDA_EXP_DERIV_WPS 1
+#endif
+#ifdef GRBDA_EXP_PART_LDS
+constexpr bool kPartLdsF32 = true;
+#else
+constexpr bool kPartLdsF32 = false;
+#endif
 template <class T, int NMAX, int IL>
-__global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
+__global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(DevPlan<T> DP, const DerivBody *__restrict__ db_, int n_clusters, int n_rows,
                                                               const T *__restrict__ q, const T *__restrict__ qd,
                                                               const T *__restrict__ ydd, T *__restrict__ Dq, T *__restrict__ Dqd,
                                                               T *__restrict__ H, size_t B, T *__restrict__ scratch)
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(kWave, 1) void rnea_deriv_kernel(DevPlan<T> DP, con
             }
         }
         // ---- pass 2, leaf side first ----
-        PartStore<T, sizeof(T) == 8> part;  // what the in-cluster roots of a cluster hand to the parent body: one read-modify-write per cluster, or
+        PartStore<T, sizeof(T) == 8 || kPartLdsF32> part;  // what the in-cluster roots of a cluster hand to the parent body: one read-modify-write per cluster, or
                      // no memory traffic at all along chains (DerivBody::carry_out: it stays here for the next cluster)
         part.lds = reinterpret_cast<T *>(deriv_smem) + lane;
 #pragma unroll
@@ -723,7 +733,7 @@ template <class T, int IL>
 static hipError_t launch_rnea_deriv_il(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q,
                                        const T *qd, const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream)
 {
-    const size_t part_lds = sizeof(T) == 8 ? 63 * kWave * sizeof(T) : 0;  // PartStore
+    const size_t part_lds = (sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0;  // PartStore
     if (n_max <= 1)
         hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, IL>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
@@ -746,7 +756,7 @@ hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clu
     if (interleave == kWave && n_max <= 1) {
         // tile-interleaved results [tile][entry][lane]: what a one-state-per-lane consumer reads as coalesced rows (the
         // spanning-tree pass of manifold_kernels.hip; single-body clusters only)
-        const size_t part_lds = sizeof(T) == 8 ? 63 * kWave * sizeof(T) : 0;
+        const size_t part_lds = (sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0;
         hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, kWave>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
         return hipGetLastError();

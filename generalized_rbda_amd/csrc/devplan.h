@@ -6,6 +6,14 @@
 
 namespace grbda_hip {
 
+// wavefronts per SIMD of the "wide" fp32 chain kernel (GRBDA_CHAIN_WIDE=1; experiment builds: -DGRBDA_EXP_WIDE_WPS=3)
+#ifndef GRBDA_EXP_WIDE_WPS
+#define GRBDA_EXP_WIDE_WPS 4
+#endif
+constexpr int kChainWideWps = GRBDA_EXP_WIDE_WPS;
+constexpr int kChainWideLdsBytes = (160 * 1024 / (4 * kChainWideWps)) / 256 * 256;  // per wavefront, whole rows of 64 floats
+
+
 template <class T>
 struct DevPlan {
     const Step *steps;

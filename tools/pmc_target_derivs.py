@@ -4,6 +4,8 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, ROOT)
 import torch
 import generalized_rbda_amd as G
+if os.environ.get("GRBDA_LIB"):
+    G.LIB_PATH = os.path.abspath(os.environ["GRBDA_LIB"])
 from generalized_rbda_amd.states import random_states
 plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models/jvrc1_humanoid.urdf"))
 B = int(os.environ.get("PMC_BATCH", "65536"))
