@@ -114,8 +114,9 @@ def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor"
                                               belt_ratios_3=rng.uniform(1, 2, 3))
             link_names += names
         else:  # generic static: k bodies in a random in-cluster tree, random coupling G
-            k = int(rng.integers(2, 6))
-            n = int(rng.integers(1, min(k, 4) + 1))
+            # ("generic_big": beyond the structured kernels' 8 bodies / 4 coordinates -- the spanning-tree route)
+            k = int(rng.integers(9, 21)) if kind == "generic_big" else int(rng.integers(2, 6))
+            n = int(rng.integers(5, min(k, 12) + 1)) if kind == "generic_big" else int(rng.integers(1, min(k, 4) + 1))
             names = [f"g{c}_{i}" for i in range(k)]
             for i, nm in enumerate(names):
                 par = parent if i == 0 or rng.random() < 0.4 else names[rng.integers(i)]
@@ -127,7 +128,7 @@ def random_cluster_tree(seed, n_clusters=8, floating=True, kinds=("rev", "rotor"
             for j, i in enumerate(ind):
                 G[i, j] = 1.0
             for r_, i in enumerate(dep):
-                w = rng.uniform(-3, 3, n)
+                w = rng.uniform(-3, 3, n) if kind != "generic_big" else rng.uniform(-1, 1, n) * (rng.random(n) < 0.4)
                 G[i] = w
                 K[r_, i] = -1.0
                 for j, ii in enumerate(ind):

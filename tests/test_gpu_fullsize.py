@@ -197,3 +197,34 @@ def test_full_size_derivatives_on_the_constraint_manifold(workload, B, gpu):
         got = d["dq"][int(i)].double().cpu().numpy()
         worst = max(worst, np.abs(got - ref).max() / (1.0 + np.abs(ref).max()))
     assert worst < TOL32, f"dq vs oracle differences on the manifold: {worst:.2e}"
+
+
+@pytest.mark.parametrize("name,implicit", [("parallel_chain_exp_d10_l16", False), ("parallel_chain_imp_d10_l17", True)])
+def test_big_cluster_models_at_size_round_trip(name, implicit, gpu):
+    """The reference's own depth-10 parallel-chain files (a cluster of 16 bodies / 15 DoF, of 17 bodies / 15 DoF with a planar
+    loop) through the spanning-tree route at 65 536 + 37 states: ID(FD(tau)) == tau in fp64 over the whole batch, fp32
+    against fp64, and the oracle built for 48 bodies per cluster on a strided sample."""
+    import torch
+    from models import valid_states
+
+    plan = G.Plan.from_urdf(os.path.join(ROBOT_MODELS, name + ".urdf"))
+    assert plan.info().spanning_tree_route == 1
+    blob = plan.blob
+    B = 65536 + 37
+    base = valid_states(blob, 4096, config_index=9, big=True, scale=0.5, max_cond=50 if implicit else None)
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, 4096, B)
+    # distinct states: the drawn positions with fresh velocities and torques per state
+    q = base[0][pick]
+    qd, tau = rng.uniform(-1, 1, (B, plan.nv)), rng.uniform(-1, 1, (B, plan.nv))
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+    q64, qd64, tau64 = t(q, torch.float64), t(qd, torch.float64), t(tau, torch.float64)
+    ydd = plan.forward_dynamics(q64, qd64, tau64)
+    back = plan.inverse_dynamics(q64, qd64, ydd)
+    scale = 1.0 + float(ydd.abs().max())
+    assert float((back - tau64).abs().max()) / scale < 1e-9
+    ydd32 = plan.forward_dynamics(t(q, torch.float32), t(qd, torch.float32), t(tau, torch.float32)).double()
+    assert float(((ydd32 - ydd).abs().amax(dim=1) / (1.0 + ydd.abs().amax(dim=1))).max()) < TOL32
+    idx = sample_indices(B, 512)
+    ref = O.forward_dynamics(blob, q[idx], qd[idx], tau[idx], big=True)
+    assert rel_err(ydd.cpu().numpy()[idx], ref) < TOL64

@@ -1030,8 +1030,9 @@ def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu
     """Clusters of 12 .. 31 bodies with 11 .. 29 independent coordinates (the reference's parallel-chain benchmark family,
     Benchmarking/urdfs/parallel_chains; sizes from pinocchioHelpers.cpp:355-410): forward and inverse dynamics and the mass matrix
     through the spanning tree (HostPlan::big_clusters, manifold_kernels.hip's wide variants) against the oracle built with room for
-    48 bodies per cluster (oracle/_build/libgrbda_oracle_big.so) -- fp64 1e-9, fp32 1e-3 of the largest entry (1e-2 for the chains of
-    depth 20: forward dynamics through a dense 39 x 39 solve in fp32 on chains twenty links long; measured 1.4e-3)."""
+    48 bodies per cluster (oracle/_build/libgrbda_oracle_big.so) -- fp64 1e-9; fp32 inverse dynamics 1e-3 of the largest entry, fp32
+    forward dynamics 1e-5: the fp32 entry point of such plans computes through the fp64 route (a dense fp32 solve over chains twenty
+    links long measured 1.4e-3 here and 1e-2 over 65 536 states)."""
     import torch
     from parallel_chains import parallel_chain_urdf
 
@@ -1045,7 +1046,7 @@ def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu
     q, qd, tau = valid_states(blob, B, config_index=17, big=True, scale=0.5, max_cond=50 if implicit else None)
     ref = O.forward_dynamics(blob, q, qd, tau, big=True)
     ref_id = O.inverse_dynamics(blob, q, qd, tau, big=True)
-    for dt, tol in ((torch.float64, 1e-9), (torch.float32, 1e-3 if depth <= 10 else 1e-2)):
+    for dt, tol in ((torch.float64, 1e-9), (torch.float32, 1e-5)):
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
         ydd = plan.forward_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
         tid = plan.inverse_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
@@ -1062,3 +1063,31 @@ def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu
     # what the route does not cover says so
     with pytest.raises(Exception):
         plan.fd_dq(t(q[:4]), t(qd[:4]), t(tau[:4]))
+
+
+@pytest.mark.parametrize("seed,floating", [(31, True), (32, False), (33, True), (34, False)])
+def test_random_trees_with_big_explicit_clusters(gpu, seed, floating):
+    """Random cluster trees that contain Generic clusters of 9 .. 20 bodies with 5 .. 12 independent coordinates (random in-cluster
+    trees, random sparse coupling G, child clusters on any of their bodies) next to ordinary ones: the spanning-tree route of
+    DESIGN 7c against the oracle built for 48 bodies per cluster."""
+    import torch
+    from models import random_cluster_tree
+
+    model = random_cluster_tree(seed, 4, floating=floating, kinds=("generic_big", "rev", "generic_big", "rotor"))
+    blob = model.serialize()
+    plan = G.Plan(blob)
+    assert plan.info().spanning_tree_route == 1 and plan.nv <= 64
+    B, nv = 96, plan.nv
+    q, qd, tau = random_states(blob, B, config_index=seed)
+    ref = O.forward_dynamics(blob, q, qd, tau, big=True)
+    ref_id = O.inverse_dynamics(blob, q, qd, tau, big=True)
+    for dt, tol in ((torch.float64, 1e-9), (torch.float32, 2e-3)):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+        ydd = plan.forward_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
+        tid = plan.inverse_dynamics(t(q), t(qd), t(tau)).double().cpu().numpy()
+        assert np.abs(ydd - ref).max() / (1 + np.abs(ref).max()) < tol
+        assert np.abs(tid - ref_id).max() / (1 + np.abs(ref_id).max()) < tol
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    Hinv = plan.fd_dtau(t(q[:16])).cpu().numpy()
+    H = plan.mass_matrix(t(q[:16])).cpu().numpy()
+    assert np.abs(np.einsum("bij,bjk->bik", H, Hinv) - np.eye(nv)).max() < 1e-8
