@@ -39,7 +39,8 @@ cp("stress_random_models.txt", "stress_random_models.txt")
 cp("tello_acc.txt", "tello_acc_f32_vs_float_oracle.txt")
 cp("prof/traffic.txt", "pmc_traffic_raw.txt")
 for tag, name in (("pmc_mit_aba32", "mit_aba32"), ("pmc_mit_rnea32", "mit_rnea32"), ("pmc_tello_aba32", "tello_aba32"),
-                  ("pmc_jvrc1_aba32", "jvrc1_aba32"), ("pmc_minicheetah_aba64", "minicheetah_aba64"), ("pmc_derivs", "derivatives")):
+                  ("pmc_jvrc1_aba32", "jvrc1_aba32"), ("pmc_minicheetah_aba64", "minicheetah_aba64"), ("pmc_derivs", "derivatives"),
+                  ("pmc_four_bar_aba32", "four_bar_aba32"), ("pmc_six_bar_aba32", "six_bar_aba32")):
     cp(f"{tag}/summary.txt", f"rocprofv3_pmc_{name}.txt")
 
 # HBM-side traffic per launch: FETCH_SIZE counts half of the bytes read, WRITE_SIZE the bytes written (traffic_calibration.txt)
