@@ -130,6 +130,8 @@ struct grbda_plan {
     bool no_analytic = false;  // GRBDA_NO_ANALYTIC=1: derivatives by the unit-vector / central-difference batches only
     bool solve_f64 = false;    // GRBDA_SOLVE_F64=1: the SPD solve of the f32 derivative entry points computes in f64
     bool no_latency_mode = false;  // GRBDA_NO_LATENCY_MODE=1: small batches keep the one-wavefront-per-tile kernel
+    int crba_waves = 16;       // GRBDA_CRBA_WAVES_PER_CU: grid of the composite-rigid-body kernel (fp32: 99 registers, four wavefronts per SIMD:
+                               // JVRC-1 mass matrix 1.95 -> 1.81 ms per 262 144 states against eight per CU; fp64 is capped at eight)
     int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 3)
     bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
@@ -1331,7 +1333,8 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
         // composite-rigid-body kernel (crba_kernels.hip): one launch instead of nv + 1 inverse-dynamics evaluations
         DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
         const size_t n_tiles = (B + kWave - 1) / kWave;
-        size_t grid = static_cast<size_t>(t->n_cu) * 8;
+        const size_t crba_waves = static_cast<size_t>(sizeof(T) == 4 ? p->crba_waves : std::min(p->crba_waves, 8));  // (fp64: 256 registers, two per SIMD)
+        size_t grid = static_cast<size_t>(t->n_cu) * crba_waves;
         if (grid > n_tiles) grid = n_tiles;
         void *scratch = nullptr;
         if (int rc = ensure_scratch(p, device, stream, grid * static_cast<size_t>(p->host.crba.n_rows) * kWave * sizeof(T) + 256, &scratch))
@@ -1349,7 +1352,7 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
                 const size_t b0 = part == 0 ? 0 : Bg, nbp = part == 0 ? Bg : B - Bg;
                 if (nbp == 0) continue;
                 const int ilp = part == 0 ? il : 1;
-                size_t gp = static_cast<size_t>(t->n_cu) * 8;
+                size_t gp = static_cast<size_t>(t->n_cu) * crba_waves;
                 if (gp > (nbp + kWave - 1) / kWave) gp = (nbp + kWave - 1) / kWave;
                 e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, out + b0 * static_cast<size_t>(nv) * nv, nbp,
                                    static_cast<T *>(scratch), static_cast<int>(gp), hs, true, ilp);
@@ -1906,6 +1909,8 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->rnea_narrow = env_int("GRBDA_RNEA_NARROW", 0) != 0;
     p->no_analytic = env_int("GRBDA_NO_ANALYTIC", 0) != 0;
     p->solve_f64 = env_int("GRBDA_SOLVE_F64", 0) != 0;
+    p->crba_waves = env_int("GRBDA_CRBA_WAVES_PER_CU", 16);
+    if (p->crba_waves < 1 || p->crba_waves > 16) p->crba_waves = 16;
     p->deriv_waves = env_int("GRBDA_DERIV_WAVES_PER_CU", 0);
     if (p->deriv_waves < 0) p->deriv_waves = 0;
     p->no_efpa = env_int("GRBDA_NO_EFPA", 0) != 0;
