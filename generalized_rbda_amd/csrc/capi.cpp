@@ -1435,8 +1435,10 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     const bool big = p->host.big_clusters;
     const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
     const size_t nq_s = sp->host.nq, nv_s = sp->host.nv, nn_s = nv_s * nv_s;
-    const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : 3 * nn_s + 2 * nn);
-    size_t chunk = (1024ull << 20) / (per_state * sizeof(T));
+    // (forward dynamics: H_s alone of the spanning recursion's three matrices is stored)
+    const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : nn_s + 2 * nn);
+    // (plans with big clusters: 40-50 KB per state; a chunk that leaves most SIMDs without a tile costs more than the memory)
+    size_t chunk = ((big ? 4096ull : 1024ull) << 20) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     const size_t b_round = (B + kWave - 1) / kWave * kWave;
@@ -1446,7 +1448,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     T *w = static_cast<T *>(wptr);
     auto take = [&](size_t per) { T *r = w; w += chunk * per; return r; };
     T *q_s = take(nq_s), *qd_s = take(nv_s), *qdd_s = take(nv_s), *x_s = take(nv_s), *cpl = take(p->n_cpl_rows);
-    T *Aq = rnea ? nullptr : take(nn_s), *Av = rnea ? nullptr : take(nn_s), *Hs = rnea ? nullptr : take(nn_s);
+    T *Aq = nullptr, *Av = nullptr, *Hs = rnea ? nullptr : take(nn_s);
     T *Hw = rnea ? nullptr : take(nn), *Hinv = rnea ? nullptr : take(nn);
     hipStream_t hs = static_cast<hipStream_t>(stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
@@ -1504,7 +1506,7 @@ int projection_run_f32_through_f64(const grbda_plan *p, bool rnea, const float *
 {
     const size_t nq = p->host.nq, nv = p->host.nv;
     const size_t per_state = nq + 3 * nv;
-    size_t chunk = (64u << 20) / (per_state * sizeof(double));
+    size_t chunk = (256u << 20) / (per_state * sizeof(double));
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     void *cvt = nullptr;
@@ -1598,8 +1600,8 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             void *scratch = nullptr;
             if (int rc = ensure_scratch(sp, device, stream, g2 * static_cast<size_t>(sp->host.deriv.n_rows) * kWave * sizeof(T) + 256, &scratch))
                 return rc;
-            e = launch_rnea_deriv<T>(ds, ts->deriv_bodies, sp->host.n_clusters, sp->host.deriv.n_rows, sp->host.deriv.n_max, q_s, qd_s, qdd_s, Aq,
-                                     Av, Hs, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, kWave);
+            e = launch_rnea_deriv<T>(ds, ts->deriv_bodies, sp->host.n_clusters, sp->host.deriv.n_rows, sp->host.deriv.n_max, q_s, qd_s, qdd_s,
+                                     need_d ? Aq : nullptr, need_d ? Av : nullptr, Hs, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, kWave);
             if (e != hipSuccess) return hip_err(e, "spanning derivative launch");
         }
         // the projected H goes to the caller's array when no solve follows, or (state-major layouts, whole groups) to d/dtau
@@ -1949,6 +1951,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
                         const ClusterRec &cr = p->host.lay64.clusters[c];
                         p->crow[c] = rows;
                         if (cr.kind == CK_LOOP) rows += cr.k * (p->host.big_clusters ? cr.n : cr.n * (4 + cr.n));  // (manifold_kernels.hip, cpl_stride)
+                        else if (cr.kind == CK_STATIC && p->host.big_clusters) rows += cr.k * cr.n;  // (wide plans keep every cluster's G rows in the slab)
                     }
                     p->n_cpl_rows = rows;
                 } else {

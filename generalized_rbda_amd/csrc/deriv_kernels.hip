@@ -232,11 +232,13 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
         // 6.6 ms on JVRC-1); spd_solve_kernel reads column c as entry c of the runs r >= c, and the second half of run c.
         // (interleaved: state r sits at sub-position r % IL of group r / IL; groups are IL * nv^2 entries apart)
         const size_t grp_of = st / IL, sub_of = st % IL;
-        T *Dqs = Dq + grp_of * (size_t)nv * nv * IL + sub_of, *Dqds = Dqd + grp_of * (size_t)nv * nv * IL + sub_of;
+        T *Dqs = Dq ? Dq + grp_of * (size_t)nv * nv * IL + sub_of : nullptr, *Dqds = Dqd ? Dqd + grp_of * (size_t)nv * nv * IL + sub_of : nullptr;
         // the joint-space inertia matrix falls out of the same composites: H[k][j] = S_j . (Ic_k S_k) for j ancestor of or
         // equal to k (the CRBA in the common frame); the rows of its lower triangle, back to back, when the caller wants it
         T *Hs = H ? H + grp_of * (size_t)nv * nv * IL + sub_of : nullptr;
+        // (Dq == Dqd == nullptr: the caller wants H alone -- the spanning-tree route of capi.cpp's projection_run)
         auto put = [&](T *P, int r, int c, T v) {
+            if (!P) return;
             if (c <= r) P[(size_t)(r * r + c) * IL] = v;
             else P[(size_t)(c * c + c + 1 + r) * IL] = v;
         };

@@ -367,6 +367,9 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                         a += G[j] * qs[cr.q_index + j];
                         v += G[j] * qds[cr.v_index + j];
                         if (ydds) w += G[j] * ydds[cr.v_index + j];
+                        // (wide variant: the projection and the apply kernels read every cluster's G from the slab -- coalesced vector
+                        // loads that pipeline, where table lookups on the scalar unit would serialise their inner loops)
+                        if constexpr (KB > kMaxClusterBodies) cp[(size_t)(crow[c] + i * n + j) * kWave] = G[j];
                     }
                     if (live) {
                         oq[span_q[cr.first_body + i]] = a;
@@ -622,6 +625,83 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Kernel 2w: H = G^T H_s G for plans with clusters beyond the structured limits (mode 1 of kernel 2, state-major packed rows).
+// The general kernel's column work areas would be private arrays of 48 entries here -- scratch memory, and a dependent
+// read-modify-write of scratch per multiply-add (measured: 16.5 ms per 65 536 states of the reference's 16-body parallel chain,
+// 87 % of that model's forward dynamics).  Per column a of cluster J and row cluster I this kernel first forms (H_s G e_a) on the
+// bodies of I with scalar accumulators and parks the k_I values in LDS ([body][lane]), then contracts them with the rows of G_I:
+// every accumulator a register, every load a coalesced row of the tile-interleaved H_s or of the coupling slab, G of explicit
+// clusters from the constant tables on the scalar unit.
+// ---------------------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char manifold_smem[];
+template <class T>
+__global__ __launch_bounds__(kWave, 4) void manifold_project_wide_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_v_,
+                                                                       const int32_t *__restrict__ crow_, const uint64_t *__restrict__ rel_,
+                                                                       const uint64_t *__restrict__ rel_s_, int nv_s, int n_cpl_rows,
+                                                                       const T *__restrict__ Hs, const T *__restrict__ cpl,
+                                                                       T *__restrict__ H, size_t B)
+{
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<int32_t> span_v = (cptr<int32_t>)span_v_, crow = (cptr<int32_t>)crow_;
+    cptr<uint64_t> rel = (cptr<uint64_t>)rel_, rel_s = (cptr<uint64_t>)rel_s_;
+    const int lane = threadIdx.x, nv = DP.nv;
+    const size_t nn_s = (size_t)nv_s * nv_s, nn = (size_t)nv * nv;
+    T *park = reinterpret_cast<T *>(manifold_smem) + lane;  // park[i * kWave]: (H_s G e_a) on body i of the row cluster
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    auto sym = [](int r, int c) -> size_t { return r >= c ? (size_t)(r * (r + 1) / 2 + c) : (size_t)(c * (c + 1) / 2 + r); };
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r0 = tile * kWave + lane;
+        const bool live = r0 < B;
+        const size_t st = live ? r0 : B - 1;
+        const T *hs = Hs + tile * nn_s * kWave + lane;
+        const T *cp = cpl + (tile * (size_t)n_cpl_rows) * kWave + lane;
+        T *Hout = H + st * nn;
+        // entry (i, a) of a cluster's G: the unit matrix of a free base, or a row of the coupling slab (explicit clusters too in wide plans)
+        auto Gval = [&](const ClusterRec &C, int c0, int i, int a) -> T {
+            if (C.kind == CK_FREE) return i == a ? T(1) : T(0);
+            return cp[(size_t)(c0 + i * C.n + a) * kWave];
+        };
+        for (int cJ = 0; cJ < n_clusters; cJ++) {
+            const ClusterRec J = load_rec(clusters + cJ);
+            const int nJ = J.kind == CK_FREE ? 6 : J.n, kJ = J.kind == CK_FREE ? 6 : J.k;
+            const int svJ = span_v[J.first_body], rowJ = J.kind == CK_FREE ? 0 : crow[cJ];  // (a cluster's bodies are consecutive spanning coordinates)
+            for (int a = 0; a < nJ; a++) {
+                const int vJ = J.v_index + a;
+                for (int cI = cJ; cI < n_clusters; cI++) {  // (the lower triangle: rows at or after the column's cluster)
+                    const ClusterRec I = load_rec(clusters + cI);
+                    if (!((rel[I.v_index] >> J.v_index) & 1)) continue;  // clusters on different branches: structural zeros
+                    const int nI = I.kind == CK_FREE ? 6 : I.n, kI = I.kind == CK_FREE ? 6 : I.k;
+                    const int svI = span_v[I.first_body], rowI = I.kind == CK_FREE ? 0 : crow[cI];
+                    for (int ri = 0; ri < kI; ri++) {
+                        const int r = svI + ri;
+                        const uint64_t rr = rel_s[r];
+                        T acc = 0;
+#pragma unroll 8
+                        for (int s = 0; s < kJ; s++) {
+                            const int sv = svJ + s;
+                            // (the load is unconditional -- a structural zero of H_s is allocated, never written, and discarded by the
+                            // select -- so that the unrolled loop keeps eight pairs of loads in flight instead of branching per entry)
+                            const T hv = hs[sym(r, sv) * kWave];
+                            const T h = ((rr >> sv) & 1) ? hv : T(0);
+                            acc += h * Gval(J, rowJ, s, a);
+                        }
+                        park[ri * kWave] = acc;
+                    }
+                    for (int b2 = 0; b2 < nI; b2++) {
+                        const int vI = I.v_index + b2;
+                        if (vJ > vI) continue;
+                        T acc = 0;
+#pragma unroll 8
+                        for (int ri = 0; ri < kI; ri++) acc += Gval(I, rowI, ri, b2) * park[ri * kWave];
+                        if (live) Hout[sym(vI, vJ)] = acc;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Kernel 3: between the independent coordinates and the spanning tree, one state per lane (capi.cpp, projection_run).
 //   mode 0 (inverse dynamics):  out = G^T x_s                                   x_s = tau_s(q_s, G yd, G ydd + g)
 //   mode 1 (forward dynamics):  out = Hinv (tau - G^T x_s)                      x_s = C_s + H_s g,  Hinv = (G^T H_s G)^-1 [B][nv][nv]
@@ -657,7 +737,11 @@ __global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP,
                     T g;
                     int sv;
                     if (cr.kind == CK_FREE) { g = i == a ? T(1) : T(0); sv = span_v[cr.first_body] + i; }
-                    else if (cr.kind == CK_STATIC) { g = consts[load_rec(bodies + (cr.first_body + i)).cofs + kBodyConstFixed + a]; sv = span_v[cr.first_body + i]; }
+                    else if (cr.kind == CK_STATIC) {
+                        if constexpr (KB > kMaxClusterBodies) g = cp[(size_t)(crow[c] + i * cr.n + a) * kWave];  // (wide plans: G rows in the slab)
+                        else g = consts[load_rec(bodies + (cr.first_body + i)).cofs + kBodyConstFixed + a];
+                        sv = span_v[cr.first_body + i];
+                    }
                     else { g = cc[(size_t)(i * stride + a) * kWave]; sv = span_v[cr.first_body + i]; }
                     s += g * xs[sv];
                 }
@@ -719,8 +803,17 @@ hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const in
 {
     if (big) {
         if (mode != 1 || interleave != 1) return hipErrorInvalidValue;  // (H only, state-major)
-        hipLaunchKernelGGL((manifold_project_kernel<T, 1, kBigClusterBodies, kBigClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
-                           span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
+        // (bound by the latency of its coalesced loads -- the tile's H_s and coupling rows come from HBM: as many wavefronts as the LDS holds,
+        // up to four per SIMD; the caller's grid is for one per SIMD)
+        const size_t lds = kBigClusterBodies * kWave * sizeof(T);
+        size_t per_cu = (160u * 1024u) / lds;
+        if (per_cu > 16) per_cu = 16;
+        size_t g = static_cast<size_t>(grid) / 4 * per_cu;
+        const size_t n_tiles = (B + kWave - 1) / kWave;
+        if (g > n_tiles) g = n_tiles;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL((manifold_project_wide_kernel<T>), dim3(static_cast<unsigned>(g)), dim3(kWave), lds, stream, P, n_clusters, span_v, crow, rel,
+                           rel_s, nv_s, n_cpl_rows, Hs, cpl, H, B);
     } else if (interleave == kDerivGroup) {
         hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P,
                            n_clusters, span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);

@@ -10,7 +10,8 @@ from models import valid_states
 from parallel_chains import parallel_chain_urdf
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for implicit, depth, loop in ((False, 10, 4), (False, 10, 12), (False, 10, 16), (False, 20, 30), (True, 10, 5), (True, 10, 13), (True, 10, 17), (True, 20, 31)):
+ONLY = os.environ.get("BIG_ONLY")  # e.g. "1,20,31": one model (implicit flag, depth, loop size)
+for implicit, depth, loop in ([tuple(int(x) for x in ONLY.split(","))] if ONLY else []) or ((False, 10, 4), (False, 10, 12), (False, 10, 16), (False, 20, 30), (True, 10, 5), (True, 10, 13), (True, 10, 17), (True, 20, 31)):
     with tempfile.NamedTemporaryFile("w", suffix=".urdf", delete=False) as f:
         f.write(parallel_chain_urdf(depth, loop, implicit))
     plan = G.Plan.from_urdf(f.name)
