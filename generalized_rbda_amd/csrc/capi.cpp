@@ -122,6 +122,10 @@ struct grbda_plan {
     // register-bound to 8 per CU and prefers 6 with more LDS)
     int lds_bytes_per_wave[4] = {20480, 20480, 10240, 26624};
     int waves_per_cu[4] = {8, 8, 16, 6};
+    // fp64 forward dynamics OFF the plain chain kernels -- the cluster interpreter, and chain programs with generic segments (one wavefront
+    // per SIMD, 428 registers, chain_kernels.hip) -- runs best at one wavefront per SIMD (measured on the zoo, 131 072 states: interpreter
+    // 0.71-0.94 -> 0.46-0.66 ms; generic chain kernel even); GRBDA_WAVES_PER_CU / _ABA64 set it like the others
+    int waves_per_cu_f64_wide_regs = 4;
     bool no_split = false;
     bool no_chain = false;  // GRBDA_NO_CHAIN=1: keep the general interpreter (A/B runs, tests of the general kernels)
     int chain_debug = 0;
@@ -465,7 +469,8 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     const int w = sizeof(T) == 8 ? 2 : (wide ? 1 : 0);
     const int kid = sizeof(T) == 8 ? 1 : 0;
     const ChainProgram &cp = w == 2 ? h.chain64 : (wide ? h.chain32w : h.chain32);
-    const size_t waves_per_cu = wide ? static_cast<size_t>(4 * kChainWideWps) : static_cast<size_t>(p->waves_per_cu[kid]);
+    const size_t waves_per_cu = wide ? static_cast<size_t>(4 * kChainWideWps)
+                                     : static_cast<size_t>((sizeof(T) == 8 && !cp.gens.empty()) ? p->waves_per_cu_f64_wide_regs : p->waves_per_cu[kid]);
     const size_t lds_budget = wide ? static_cast<size_t>(kChainWideLdsBytes) : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
     ChainDev<T> d;
     d.segs = t.chain_segs[w];
@@ -599,7 +604,8 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     d.fext = f_ext;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     const int kid = (rnea ? 2 : 0) + (sizeof(T) == 8 ? 1 : 0);
-    size_t grid = static_cast<size_t>(t->n_cu) * static_cast<size_t>(p->waves_per_cu[kid]);
+    const size_t waves_per_cu = static_cast<size_t>(kid == 1 ? p->waves_per_cu_f64_wide_regs : p->waves_per_cu[kid]);
+    size_t grid = static_cast<size_t>(t->n_cu) * waves_per_cu;
     if (grid > n_tiles) grid = n_tiles;
     const size_t n_glb = static_cast<size_t>(d.n_glb_slots) + static_cast<size_t>(d.nq + 2 * d.nv);  // + staged inputs
     const size_t scratch_bytes = grid * n_glb * kWave * sizeof(T) + 256;
@@ -614,7 +620,7 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     d.lds_bytes = static_cast<int>(lds_bytes);
     // a CU holds 160 KiB of LDS: never launch more persistent wavefronts than can be resident at once
     const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
-    if (fit >= 1 && fit < static_cast<size_t>(p->waves_per_cu[kid])) {
+    if (fit >= 1 && fit < waves_per_cu) {
         const size_t g2 = static_cast<size_t>(t->n_cu) * fit;
         if (grid > g2) grid = g2;
     }
@@ -1764,7 +1770,8 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
             case ABA_LM: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s>", tn); return buf;
             case ABA_CHAIN_WIDE: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, 0>", tn, kChainWideWps); return buf;
             case ABA_CHAIN:
-                std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, 2, %d>", tn, !cp.gens.empty() ? 2 : (!cp.diffs.empty() ? 1 : 0));
+                std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, %d>", tn, (sizeof(T) == 8 && !cp.gens.empty()) ? 1 : 2,
+                              !cp.gens.empty() ? 2 : (!cp.diffs.empty() ? 1 : 0));
                 return buf;
             default: break;
         }
@@ -1895,6 +1902,11 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
         int w = env_int("GRBDA_WAVES_PER_CU", p->waves_per_cu[k]);
         w = env_int((std::string("GRBDA_WAVES_PER_CU") + suffix[k]).c_str(), w);
         p->waves_per_cu[k] = w < 1 ? 1 : (w > 32 ? 32 : w);
+    }
+    {
+        int w = env_int("GRBDA_WAVES_PER_CU", p->waves_per_cu_f64_wide_regs);
+        w = env_int("GRBDA_WAVES_PER_CU_ABA64", w);
+        p->waves_per_cu_f64_wide_regs = w < 1 ? 1 : (w > 32 ? 32 : w);
     }
     p->no_split = env_int("GRBDA_NO_SPLIT", 0) != 0;
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;

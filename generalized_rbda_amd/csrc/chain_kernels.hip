@@ -2137,7 +2137,16 @@ template <class T>
 hipError_t launch_aba_chain_gen(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                                 size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((aba_chain_kernel<T, 2, 2>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    // fp64: ONE wavefront per SIMD.  At two the kernel spills 1 377 registers (768 B of scratch per lane); with 512 registers it needs 428 and
+    // none -- teleop_arm 0.526 -> 0.247 ms, planar leg linkage 0.199 -> 0.108, a tree of triple clusters 0.703 -> 0.307 per 262 144 states
+    // (tools/ab_gen64.py; -DGRBDA_EXP_GEN64_WPS=2 rebuilds the old shape)
+#ifndef GRBDA_EXP_GEN64_WPS
+#define GRBDA_EXP_GEN64_WPS 1
+#endif
+    if constexpr (sizeof(T) == 8)
+        hipLaunchKernelGGL((aba_chain_kernel<T, GRBDA_EXP_GEN64_WPS, 2>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    else
+        hipLaunchKernelGGL((aba_chain_kernel<T, 2, 2>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
 template hipError_t launch_aba_chain_gen<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
