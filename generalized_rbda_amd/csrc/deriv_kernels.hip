@@ -353,6 +353,9 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
         PartStore<T, sizeof(T) == 8 || kPartLdsF32> part;  // what the in-cluster roots of a cluster hand to the parent body: one read-modify-write per cluster, or
                      // no memory traffic at all along chains (DerivBody::carry_out: it stays here for the next cluster)
         part.lds = reinterpret_cast<T *>(deriv_smem) + lane;
+        // fp32: LDS cache of the [S | Sd | Pdd] rows of the current root path, block l = the ancestor l bodies below the base
+        // (plan.h, kDerivAncLevels; behind the composites when an experiment build keeps those in LDS too)
+        T *anc_cache = reinterpret_cast<T *>(deriv_smem) + (kPartLdsF32 ? 63 * kWave : 0) + lane;
 #pragma unroll
         for (int j = 0; j < 63; j++) part.set(j, T(0));
         for (int c = n_clusters - 1; c >= 0; c--) {
@@ -684,7 +687,24 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                     const DerivBody xb = load_rec(db + jj);
                     cptr<T> Cj = consts + bb.cofs;
                     T anc[18], Sj[6], Sdj[6], Pddj[6];
-                    R.ld(xb.anc_row, anc);
+                    if constexpr (sizeof(T) == 4) {
+                        // (wave-uniform: the block's validity was worked out by the plan compiler, DerivBody::walk_resident)
+                        if (xb.anc_lds >= 0) {
+                            T *blk = anc_cache + xb.anc_lds * 18 * kWave;
+                            if ((xf.walk_resident >> xb.anc_lds) & 1) {
+#pragma unroll
+                                for (int i2 = 0; i2 < 18; i2++) anc[i2] = blk[i2 * kWave];
+                            } else {
+                                R.ld(xb.anc_row, anc);
+#pragma unroll
+                                for (int i2 = 0; i2 < 18; i2++) blk[i2 * kWave] = anc[i2];
+                            }
+                        } else {
+                            R.ld(xb.anc_row, anc);
+                        }
+                    } else {
+                        R.ld(xb.anc_row, anc);
+                    }
 #pragma unroll
                     for (int i2 = 0; i2 < 6; i2++) {
                         Sj[i2] = anc[i2];
@@ -735,7 +755,8 @@ template <class T, int IL>
 static hipError_t launch_rnea_deriv_il(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q,
                                        const T *qd, const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream)
 {
-    const size_t part_lds = (sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0;  // PartStore
+    const size_t part_lds = ((sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0)   // PartStore
+                            + (sizeof(T) == 4 ? kDerivAncLevels * 18 * kWave * sizeof(T) : 0);  // fp32: ancestor-row cache
     if (n_max <= 1)
         hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, IL>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
@@ -758,7 +779,7 @@ hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clu
     if (interleave == kWave && n_max <= 1) {
         // tile-interleaved results [tile][entry][lane]: what a one-state-per-lane consumer reads as coalesced rows (the
         // spanning-tree pass of manifold_kernels.hip; single-body clusters only)
-        const size_t part_lds = (sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0;
+        const size_t part_lds = ((sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0) + (sizeof(T) == 4 ? kDerivAncLevels * 18 * kWave * sizeof(T) : 0);
         hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, kWave>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
         return hipGetLastError();

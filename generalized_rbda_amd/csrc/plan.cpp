@@ -2068,7 +2068,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             if (cr.kind == CK_LOOP) DV.ok = false;
             if (cr.kind == CK_FREE && cr.first_body != 0) DV.ok = false;
         }
-        DV.bodies.assign(nb, DerivBody{0, -1, -1, -1, 0, 0, 0, -1});
+        DV.bodies.assign(nb, DerivBody{0, -1, -1, -1, 0, 0, 0, -1, -1, 0});
         int rows = 0;
         for (int b = 0; b < nb; b++) {
             DV.bodies[b].cluster = m.bodies[b].cluster;
@@ -2082,6 +2082,30 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         }
         for (const ClusterRec &cr : clusters)
             if (cr.kind != CK_FREE) DV.n_max = std::max(DV.n_max, cr.n);
+        {
+            // LDS cache of the ancestor rows (plan.h, kDerivAncLevels): the walk of cluster c visits the body-tree ancestors of its
+            // parent body up to the base; simulate the blocks over the kernel's processing order (last cluster first)
+            std::vector<int> level(nb, 0);
+            for (int b = 0; b < nb; b++) {
+                const int pb = bodies[b].parent;
+                level[b] = (pb >= 0 && bodies[pb].jtype != GRBDA_JOINT_FREE) ? level[pb] + 1 : 0;
+                if (DV.bodies[b].anc_row >= 0 && level[b] < kDerivAncLevels) DV.bodies[b].anc_lds = level[b];
+            }
+            int owner[kDerivAncLevels];
+            for (int &o : owner) o = -1;
+            for (int c = nc - 1; c >= 0; c--) {
+                const ClusterRec &cr = clusters[c];
+                if (cr.kind == CK_FREE) continue;
+                int mask = 0;
+                for (int b = cr.parent_body; b >= 0 && bodies[b].jtype != GRBDA_JOINT_FREE; b = bodies[b].parent) {
+                    const int l = DV.bodies[b].anc_lds;
+                    if (l < 0) continue;
+                    if (owner[l] == b) mask |= 1 << l;
+                    else owner[l] = b;
+                }
+                DV.bodies[cr.first_body].walk_resident = mask;
+            }
+        }
         // register hand-over along chains: a cluster that is the only contributor to its parent body, directly before that
         // body's cluster in the processing order, leaves its composites in registers; the receiving body (no in-cluster
         // children) is processed first in its cluster

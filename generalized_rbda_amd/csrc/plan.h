@@ -405,7 +405,11 @@ struct CrbaProgram {
 };
 
 // inverse-dynamics derivatives (deriv_kernels.hip): per body, where its per-state rows live in the wave's slab
-struct DerivBody {     // 8 ints
+// rnea_deriv_kernel (fp32) keeps the [S | Sd | Pdd] rows of the current root path in LDS: a body `level` bodies below the base (or the
+// ground) owns block `level` of kDerivAncLevels; deeper bodies stay in the slab.  Which blocks are valid when a cluster walks up its
+// ancestors is known at plan time (the clusters are processed in a fixed order): DerivBody::walk_resident.
+constexpr int kDerivAncLevels = 8;
+struct DerivBody {     // 10 ints
     int32_t cluster;
     int32_t kin_row;    // bodies with children: 24 rows [E 9][p 3][v 6][a 6], transform from / motion in the common frame F; else -1
     int32_t anc_row;    // revolute bodies with children: 18 rows [S 6][Sd 6][Pdd 6]; else -1
@@ -415,6 +419,8 @@ struct DerivBody {     // 8 ints
     int32_t carry_out;  // (first body of a cluster) the cluster is the only contributor to its parent body and that body's
                         // cluster is processed next: the composites stay in registers instead of going through the slab
     int32_t carry_body; // (first body of a cluster) the body that receives them (processed first in its cluster), or -1
+    int32_t anc_lds;    // bodies with an anc_row: their block of the LDS cache (their depth below the base), or -1: slab only
+    int32_t walk_resident;  // (first body of a cluster) bit l: block l holds the cluster's ancestor at that depth when its walk starts
 };
 struct DerivProgram {
     bool ok = false;  // explicit (constant G) clusters
