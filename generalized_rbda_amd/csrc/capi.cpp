@@ -62,6 +62,7 @@ struct DeviceTables {
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
+    int32_t *related_table = nullptr;   // HostPlan::related_table (plans of the wide route with more than 64 velocities)
     int32_t *span_q = nullptr, *span_v = nullptr, *crow = nullptr;  // grbda_plan::span_q / span_v / crow
     // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w)
     RneaSeg *rchain_segs[3] = {nullptr, nullptr, nullptr};
@@ -238,6 +239,9 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     }
     if (!h.deriv.related.empty() &&
         (e = up(h.deriv.related.data(), h.deriv.related.size() * sizeof(uint64_t), (void **)&t.deriv_related)) != hipSuccess)
+        return hip_err(e, "plan upload");
+    if (!h.related_table.empty() &&
+        (e = up(h.related_table.data(), h.related_table.size() * sizeof(int32_t), (void **)&t.related_table)) != hipSuccess)
         return hip_err(e, "plan upload");
     for (int w = 0; w < 5; w++) {
         const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : h.chain64p)));
@@ -1433,7 +1437,8 @@ bool analytic_covers(const grbda_plan *p)
 template <class T>
 int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int device, void *stream)
 {
-    if (!p->span) return set_err(GRBDA_EUNSUPPORTED, "the model needs the spanning-tree route, which covers at most 64 spanning velocities");
+    if (!p->span)
+        return set_err(GRBDA_EUNSUPPORTED, "the model needs the spanning-tree route, which covers at most 64 spanning velocities (128 for plans with big clusters)");
     DeviceTables *t = nullptr, *ts = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const grbda_plan *sp = p->span;
@@ -1442,7 +1447,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     const size_t nq = p->host.nq, nv = p->host.nv, nn = nv * nv;
     const size_t nq_s = sp->host.nq, nv_s = sp->host.nv, nn_s = nv_s * nv_s;
     // (forward dynamics: H_s alone of the spanning recursion's three matrices is stored)
-    const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : nn_s + 2 * nn);
+    const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : nn_s + 2 * nn);  // (wide: nn + nv would do)
     // (plans with big clusters: 40-50 KB per state; a chunk that leaves most SIMDs without a tile costs more than the memory)
     size_t chunk = ((big ? 4096ull : 1024ull) << 20) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
@@ -1455,7 +1460,10 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     auto take = [&](size_t per) { T *r = w; w += chunk * per; return r; };
     T *q_s = take(nq_s), *qd_s = take(nv_s), *qdd_s = take(nv_s), *x_s = take(nv_s), *cpl = take(p->n_cpl_rows);
     T *Aq = nullptr, *Av = nullptr, *Hs = rnea ? nullptr : take(nn_s);
-    T *Hw = rnea ? nullptr : take(nn), *Hinv = rnea ? nullptr : take(nn);
+    // (more than 64 velocities: related-coordinate TABLES instead of one-word masks, and the workgroup-per-state solve on the one right-hand
+    // side instead of H^-1 -- manifold_kernels.hip, kernels 2w and 4)
+    const bool wide_nv = nv > static_cast<size_t>(kWave) || nv_s > static_cast<size_t>(kWave);
+    T *Hw = rnea ? nullptr : take(nn), *Hinv = rnea ? nullptr : take(wide_nv ? nv : nn);
     hipStream_t hs = static_cast<hipStream_t>(stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
     DevPlan<T> ds = make_dev_plan<T>(sp, *ts, false, false);
@@ -1484,6 +1492,18 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
         e = launch_rnea_deriv<T>(ds, ts->deriv_bodies, sp->host.n_clusters, sp->host.deriv.n_rows, sp->host.deriv.n_max, q_s, qd_s, qdd_s, Aq, Av, Hs,
                                  nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, kWave);
         if (e != hipSuccess) return hip_err(e, "spanning derivative launch");
+        if (wide_nv) {
+            if (!t->related_table || !ts->related_table) return set_err(GRBDA_EUNSUPPORTED, "more than 64 velocities on a plan without big clusters");
+            e = launch_manifold_project_wide<T>(d, p->host.n_clusters, t->span_v, t->crow, nullptr, nullptr, t->related_table, ts->related_table,
+                                                static_cast<int>(nv_s), p->n_cpl_rows, Hs, cpl, Hw, nb, static_cast<int>(grid), hs);
+            if (e != hipSuccess) return hip_err(e, "manifold projection launch");
+            e = launch_manifold_apply<T>(d, p->host.n_clusters, t->span_v, t->crow, static_cast<int>(nv_s), p->n_cpl_rows, 2, x_s, x + b0 * nv, nullptr,
+                                         cpl, Hinv, nb, static_cast<int>(grid), hs, big);
+            if (e != hipSuccess) return hip_err(e, "manifold apply launch");
+            e = launch_spd_wide_solve<T>(Hw, t->related_table, Hinv, out + b0 * nv, static_cast<int>(nv), nb, t->n_cu, hs);
+            if (e != hipSuccess) return hip_err(e, "wide solve launch");
+            continue;
+        }
         e = launch_manifold_project<T>(d, p->host.n_clusters, t->span_v, t->crow, t->deriv_related, ts->deriv_related, static_cast<int>(nv_s),
                                        p->n_cpl_rows, 1, nullptr, nullptr, Hs, nullptr, cpl, nullptr, nullptr, Hw, nb, static_cast<int>(grid), hs, 1, big);
         if (e != hipSuccess) return hip_err(e, "manifold projection launch");
@@ -1539,7 +1559,8 @@ int projection_run_f32_through_f64(const grbda_plan *p, bool rnea, const float *
 template <class T>
 bool manifold_covers(const grbda_plan *p)
 {
-    return p->span && !p->no_manifold && !p->no_analytic && p->host.nv <= kWave && p->host.deriv.related.size() == static_cast<size_t>(p->host.nv);
+    return p->span && !p->no_manifold && !p->no_analytic && p->host.nv <= kWave && p->span->host.nv <= kWave &&
+           p->host.deriv.related.size() == static_cast<size_t>(p->host.nv);
 }
 template <class T>
 int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, T *dq, T *dqd, T *dtau, T *Hout, size_t B, int device,
@@ -1885,6 +1906,27 @@ const char *grbda_strerror(int code)
 }
 const char *grbda_last_error(void) { return g_last_error.c_str(); }
 
+// nv x nv, 1 where two velocity coordinates lie on one root path (same cluster, or one cluster an ancestor of the other): what
+// DerivProgram::related holds as one 64-bit word per coordinate, for plans beyond 64 coordinates (manifold_kernels.hip, kernels 2w and 4)
+static void build_related_table(HostPlan &h)
+{
+    const std::vector<ClusterRec> &cl = h.lay64.clusters;
+    const int nc = static_cast<int>(cl.size()), nv = h.nv;
+    std::vector<int> body_cluster(h.n_bodies, 0), parent(nc, -1);
+    for (int c = 0; c < nc; c++)
+        for (int i = 0; i < cl[c].k; i++) body_cluster[cl[c].first_body + i] = c;
+    for (int c = 0; c < nc; c++) parent[c] = cl[c].parent_body >= 0 ? body_cluster[cl[c].parent_body] : -1;
+    auto dof = [&](int c) { return cl[c].kind == CK_FREE ? 6 : cl[c].n; };
+    h.related_table.assign(static_cast<size_t>(nv) * nv, 0);
+    for (int c = 0; c < nc; c++)
+        for (int a = c; a >= 0; a = parent[a])
+            for (int i = 0; i < dof(c); i++)
+                for (int j = 0; j < dof(a); j++) {
+                    h.related_table[static_cast<size_t>(cl[c].v_index + i) * nv + cl[a].v_index + j] = 1;
+                    h.related_table[static_cast<size_t>(cl[a].v_index + j) * nv + cl[c].v_index + i] = 1;
+                }
+}
+
 int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
 {
     if (!out) return set_err(GRBDA_EINVAL, "null out pointer");
@@ -1947,15 +1989,20 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->no_manifold = env_int("GRBDA_NO_MANIFOLD", 0) != 0;
     bool implicit = false;
     for (const ClusterRec &cr : p->host.lay64.clusters) implicit = implicit || cr.kind == CK_LOOP;
-    if ((implicit || p->host.projection_only) && p->host.nv <= kWave) {
+    // (plans with big clusters: up to 128 velocities -- tables instead of the one-word masks, build_related_table)
+    if ((implicit || p->host.projection_only) && p->host.nv <= (p->host.big_clusters ? 2 * kWave : kWave)) {
         // the spanning-tree model for the derivatives on the constraint manifold (at most 64 spanning velocities: the masks of
         // DerivProgram::related)
         std::vector<unsigned char> sb;
         if (make_spanning_blob(blob, bytes, sb, p->span_q, p->span_v, msg, sizeof msg) == 0) {
             grbda_plan *sp = nullptr;
             if (grbda_plan_from_blob(sb.data(), sb.size(), &sp) == GRBDA_OK) {
-                if (sp->host.nv <= kWave && sp->host.deriv.ok) {
+                if (sp->host.nv <= (p->host.big_clusters ? 2 * kWave : kWave) && sp->host.deriv.ok) {
                     p->span = sp;
+                    if (p->host.nv > kWave || sp->host.nv > kWave) {
+                        build_related_table(p->host);
+                        build_related_table(sp->host);
+                    }
                     std::memcpy(sp->host.gravity, p->host.gravity, sizeof sp->host.gravity);
                     p->crow.assign(p->host.n_clusters, 0);
                     int rows = 0;
@@ -2010,7 +2057,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
         for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }

@@ -197,6 +197,13 @@ hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const in
                                    const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
                                    const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave,
                                    bool big = false);
+// (plans with clusters beyond the structured limits: H only, one-word masks or nv x nv tables; the solve for up to 128 velocities)
+template <class T>
+hipError_t launch_manifold_project_wide(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
+                                        const uint64_t *rel_s, const int32_t *relt, const int32_t *relt_s, int nv_s, int n_cpl_rows, const T *Hs,
+                                        const T *cpl, T *H, size_t B, int grid, hipStream_t stream);
+template <class T>
+hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream);
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
 hipError_t set_max_dynamic_lds_deriv();
 hipError_t spd_bad_pivots(unsigned long long *count, int reset);

@@ -637,10 +637,14 @@ extern __shared__ __attribute__((aligned(16))) unsigned char manifold_smem[];
 template <class T>
 __global__ __launch_bounds__(kWave, 4) void manifold_project_wide_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_v_,
                                                                        const int32_t *__restrict__ crow_, const uint64_t *__restrict__ rel_,
-                                                                       const uint64_t *__restrict__ rel_s_, int nv_s, int n_cpl_rows,
+                                                                       const uint64_t *__restrict__ rel_s_, const int32_t *__restrict__ relt_,
+                                                                       const int32_t *__restrict__ relt_s_, int nv_s, int n_cpl_rows,
                                                                        const T *__restrict__ Hs, const T *__restrict__ cpl,
                                                                        T *__restrict__ H, size_t B)
 {
+    // relt / relt_s (plans with more than 64 velocities): nv x nv and nv_s x nv_s tables instead of the one-word masks
+    cptr<int32_t> relt = (cptr<int32_t>)relt_, relt_s = (cptr<int32_t>)relt_s_;
+    const bool tables = relt_ != nullptr;
     cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
     cptr<int32_t> span_v = (cptr<int32_t>)span_v_, crow = (cptr<int32_t>)crow_;
     cptr<uint64_t> rel = (cptr<uint64_t>)rel_, rel_s = (cptr<uint64_t>)rel_s_;
@@ -669,12 +673,12 @@ __global__ __launch_bounds__(kWave, 4) void manifold_project_wide_kernel(DevPlan
                 const int vJ = J.v_index + a;
                 for (int cI = cJ; cI < n_clusters; cI++) {  // (the lower triangle: rows at or after the column's cluster)
                     const ClusterRec I = load_rec(clusters + cI);
-                    if (!((rel[I.v_index] >> J.v_index) & 1)) continue;  // clusters on different branches: structural zeros
+                    if (tables ? relt[I.v_index * nv + J.v_index] == 0 : !((rel[I.v_index] >> J.v_index) & 1)) continue;  // different branches: structural zeros
                     const int nI = I.kind == CK_FREE ? 6 : I.n, kI = I.kind == CK_FREE ? 6 : I.k;
                     const int svI = span_v[I.first_body], rowI = I.kind == CK_FREE ? 0 : crow[cI];
                     for (int ri = 0; ri < kI; ri++) {
                         const int r = svI + ri;
-                        const uint64_t rr = rel_s[r];
+                        const uint64_t rr = tables ? 0 : rel_s[r];
                         T acc = 0;
 #pragma unroll 8
                         for (int s = 0; s < kJ; s++) {
@@ -682,7 +686,8 @@ __global__ __launch_bounds__(kWave, 4) void manifold_project_wide_kernel(DevPlan
                             // (the load is unconditional -- a structural zero of H_s is allocated, never written, and discarded by the
                             // select -- so that the unrolled loop keeps eight pairs of loads in flight instead of branching per entry)
                             const T hv = hs[sym(r, sv) * kWave];
-                            const T h = ((rr >> sv) & 1) ? hv : T(0);
+                            const bool on = tables ? relt_s[r * nv_s + sv] != 0 : ((rr >> sv) & 1) != 0;
+                            const T h = on ? hv : T(0);
                             acc += h * Gval(J, rowJ, s, a);
                         }
                         park[ri * kWave] = acc;
@@ -705,6 +710,7 @@ __global__ __launch_bounds__(kWave, 4) void manifold_project_wide_kernel(DevPlan
 // Kernel 3: between the independent coordinates and the spanning tree, one state per lane (capi.cpp, projection_run).
 //   mode 0 (inverse dynamics):  out = G^T x_s                                   x_s = tau_s(q_s, G yd, G ydd + g)
 //   mode 1 (forward dynamics):  out = Hinv (tau - G^T x_s)                      x_s = C_s + H_s g,  Hinv = (G^T H_s G)^-1 [B][nv][nv]
+//   mode 2:                      out = tau - G^T x_s
 // ---------------------------------------------------------------------------------------------------------------
 template <class T, int KB>
 __global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP, int n_clusters, const int32_t *__restrict__ span_v_,
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP,
         const size_t st = live ? r0 : B - 1;
         const T *xs = x_s + st * (size_t)nv_s;
         const T *cp = cpl + (tile * (size_t)n_cpl_rows) * kWave + lane;
-        T rhs[kWave];
+        T rhs[2 * kWave];  // (up to 128 velocities on the wide route)
         for (int c = 0; c < n_clusters; c++) {
             const ClusterRec cr = load_rec(clusters + c);
             const int n = cr.kind == CK_FREE ? 6 : cr.n, k = cr.kind == CK_FREE ? 6 : cr.k;
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_apply_kernel(DevPlan<T> DP,
         }
         if (!live) continue;
         T *o = out + st * (size_t)nv;
-        if (mode == 0) {
+        if (mode == 0 || mode == 2) {  // (mode 2: tau - G^T x_s, the right-hand side of the wide route's own solve)
             for (int i = 0; i < nv; i++) o[i] = rhs[i];
         } else {
             const T *Hi = Hinv + st * (size_t)nv * nv;
@@ -796,6 +802,112 @@ hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const
     return hipGetLastError();
 }
 template <class T>
+hipError_t launch_manifold_project_wide(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
+                                        const uint64_t *rel_s, const int32_t *relt, const int32_t *relt_s, int nv_s, int n_cpl_rows, const T *Hs,
+                                        const T *cpl, T *H, size_t B, int grid, hipStream_t stream)
+{
+    // (bound by the latency of its coalesced loads -- the tile's H_s and coupling rows come from HBM: as many wavefronts as the LDS holds,
+    // up to four per SIMD; the caller's grid is for one per SIMD)
+    const size_t lds = kBigClusterBodies * kWave * sizeof(T);
+    size_t per_cu = (160u * 1024u) / lds;
+    if (per_cu > 16) per_cu = 16;
+    size_t g = static_cast<size_t>(grid) / 4 * per_cu;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    if (g > n_tiles) g = n_tiles;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((manifold_project_wide_kernel<T>), dim3(static_cast<unsigned>(g)), dim3(kWave), lds, stream, P, n_clusters, span_v, crow, rel,
+                       rel_s, relt, relt_s, nv_s, n_cpl_rows, Hs, cpl, H, B);
+    return hipGetLastError();
+}
+template hipError_t launch_manifold_project_wide<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const uint64_t *,
+                                                        const uint64_t *, const int32_t *, const int32_t *, int, int, const float *, const float *,
+                                                        float *, size_t, int, hipStream_t);
+template hipError_t launch_manifold_project_wide<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const uint64_t *,
+                                                         const uint64_t *, const int32_t *, const int32_t *, int, int, const double *,
+                                                         const double *, double *, size_t, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel 4: y = H^-1 b for up to 128 velocities, one state per WORKGROUP of four wavefronts (the wide route beyond the 64 coordinates of
+// deriv_kernels.hip's row-per-lane solves).  H: packed lower rows [B][nv^2] as kernel 2w leaves them, structural zeros (never
+// written) masked by the nv x nv table; the factor L (H = L L^T) replaces it in LDS, then two substitutions on the one right-hand side.
+// Slow and plain: a column at a time, barriers between the steps.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(4 * kWave) void spd_wide_solve_kernel(const T *__restrict__ H, const int32_t *__restrict__ relt, const T *__restrict__ rhs,
+                                                                 T *__restrict__ out, int nv, size_t B, unsigned long long *bad_count)
+{
+    T *L = reinterpret_cast<T *>(manifold_smem);          // packed lower rows: L[i (i + 1) / 2 + j]
+    T *x = L + (size_t)nv * (nv + 1) / 2;                 // right-hand side, then the solution
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const size_t nn = (size_t)nv * nv;
+    for (size_t s = blockIdx.x; s < B; s += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < nv * (nv + 1) / 2; e += nt) {
+            // entry e = (i, j): i = the largest row with i (i + 1) / 2 <= e
+            int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= e) i++;
+            while (i * (i + 1) / 2 > e) i--;
+            const int j = e - i * (i + 1) / 2;
+            L[e] = relt[i * nv + j] ? H[s * nn + e] : T(0);
+        }
+        for (int i = tid; i < nv; i += nt) x[i] = rhs[s * (size_t)nv + i];
+        __syncthreads();
+        bool bad = false;
+        for (int k = 0; k < nv; k++) {
+            const int kk = k * (k + 1) / 2 + k;
+            const T d = L[kk];
+            bad = bad || !(d > T(0));
+            const T r = T(1) / __builtin_sqrt((double)d);
+            __syncthreads();  // every thread has read the pivot
+            if (tid == 0) L[kk] = (T)__builtin_sqrt((double)d);
+            for (int i = k + 1 + tid; i < nv; i += nt) L[i * (i + 1) / 2 + k] *= r;
+            __syncthreads();
+            for (int i = k + 1 + (tid >> 4); i < nv; i += nt >> 4) {
+                const T lik = L[i * (i + 1) / 2 + k];
+                for (int j = k + 1 + (tid & 15); j <= i; j += 16) L[i * (i + 1) / 2 + j] -= lik * L[j * (j + 1) / 2 + k];
+            }
+            __syncthreads();
+        }
+        if (bad && tid == 0 && bad_count) atomicAdd(bad_count, 1ull);
+        for (int k = 0; k < nv; k++) {  // L y = b
+            if (tid == 0) x[k] /= L[k * (k + 1) / 2 + k];
+            __syncthreads();
+            const T yk = x[k];
+            for (int i = k + 1 + tid; i < nv; i += nt) x[i] -= L[i * (i + 1) / 2 + k] * yk;
+            __syncthreads();
+        }
+        for (int k = nv - 1; k >= 0; k--) {  // L^T x = y
+            if (tid == 0) x[k] /= L[k * (k + 1) / 2 + k];
+            __syncthreads();
+            const T xk = x[k];
+            for (int i = tid; i < k; i += nt) x[i] -= L[k * (k + 1) / 2 + i] * xk;
+            __syncthreads();
+        }
+        for (int i = tid; i < nv; i += nt) out[s * (size_t)nv + i] = x[i];
+    }
+}
+template <class T>
+hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream)
+{
+    const size_t lds = ((size_t)nv * (nv + 1) / 2 + nv) * sizeof(T);
+    size_t per_cu = (160u * 1024u) / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) return hipErrorInvalidValue;
+    size_t g = static_cast<size_t>(n_cu) * per_cu;
+    if (g > B) g = B;
+    const void *fn = reinterpret_cast<const void *>(&spd_wide_solve_kernel<T>);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((spd_wide_solve_kernel<T>), dim3(static_cast<unsigned>(g)), dim3(4 * kWave), lds, stream, H, relt, rhs, out, nv, B,
+                       static_cast<unsigned long long *>(nullptr));
+    return hipGetLastError();
+}
+template hipError_t launch_spd_wide_solve<float>(const float *, const int32_t *, const float *, float *, int, size_t, int, hipStream_t);
+template hipError_t launch_spd_wide_solve<double>(const double *, const int32_t *, const double *, double *, int, size_t, int, hipStream_t);
+
+template <class T>
 hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,
                                    const uint64_t *rel_s, int nv_s, int n_cpl_rows, int mode, const T *Aq, const T *Av, const T *Hs,
                                    const T *tau_s, const T *cpl, T *Dq, T *Dqd, T *H, size_t B, int grid, hipStream_t stream, int interleave,
@@ -803,17 +915,7 @@ hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const in
 {
     if (big) {
         if (mode != 1 || interleave != 1) return hipErrorInvalidValue;  // (H only, state-major)
-        // (bound by the latency of its coalesced loads -- the tile's H_s and coupling rows come from HBM: as many wavefronts as the LDS holds,
-        // up to four per SIMD; the caller's grid is for one per SIMD)
-        const size_t lds = kBigClusterBodies * kWave * sizeof(T);
-        size_t per_cu = (160u * 1024u) / lds;
-        if (per_cu > 16) per_cu = 16;
-        size_t g = static_cast<size_t>(grid) / 4 * per_cu;
-        const size_t n_tiles = (B + kWave - 1) / kWave;
-        if (g > n_tiles) g = n_tiles;
-        if (g < 1) g = 1;
-        hipLaunchKernelGGL((manifold_project_wide_kernel<T>), dim3(static_cast<unsigned>(g)), dim3(kWave), lds, stream, P, n_clusters, span_v, crow, rel,
-                           rel_s, nv_s, n_cpl_rows, Hs, cpl, H, B);
+        return launch_manifold_project_wide<T>(P, n_clusters, span_v, crow, rel, rel_s, nullptr, nullptr, nv_s, n_cpl_rows, Hs, cpl, H, B, grid, stream);
     } else if (interleave == kDerivGroup) {
         hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P,
                            n_clusters, span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);

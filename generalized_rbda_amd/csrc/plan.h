@@ -448,6 +448,9 @@ struct HostPlan {
     // reference's own cross-check (RigidBodyTreeDynamics.cpp:86-97) -- capi.cpp projection_run; no sweep programs are built.
     bool projection_only = false;
     bool big_clusters = false;  // a cluster exceeds kMaxClusterBodies / kMaxClusterDof: spanning-tree route, forward / inverse dynamics and H only
+    // (plans of that route with more than 64 velocities -- and their spanning plans -- where the one-word masks of DerivProgram::related
+    // end: capi.cpp, build_related_table) nv x nv, 1 where two coordinates lie on one root path
+    std::vector<int32_t> related_table;
     double gravity[6] = {0, 0, 0, 0, 0, -9.81};
     std::vector<Step> aba_steps;
     std::vector<Step> rnea_steps;

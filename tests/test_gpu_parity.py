@@ -1022,6 +1022,7 @@ def test_cluster_on_two_parent_bodies_spanning_tree_route(gpu):
 BIG_CHAINS = [  # (implicit, depth, loop size): the reference's parallel-chain family beyond 8 bodies / 4 DoF per cluster
     (False, 10, 12), (False, 10, 16), (False, 20, 24), (False, 20, 30),
     (True, 10, 13), (True, 10, 17), (True, 20, 25), (True, 20, 31),
+    (False, 40, 40), (True, 40, 41),  # 79 velocities: beyond the one-word masks (tables, workgroup-per-state solve)
 ]
 
 
@@ -1043,7 +1044,7 @@ def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu
     assert info.spanning_tree_route == 1
     blob = plan.blob
     B, nv = 130, plan.nv
-    q, qd, tau = valid_states(blob, B, config_index=17, big=True, scale=0.5, max_cond=50 if implicit else None)
+    q, qd, tau = valid_states(blob, B, config_index=17, big=True, scale=0.5 if depth < 40 else 0.25, max_cond=50 if implicit else None)
     ref = O.forward_dynamics(blob, q, qd, tau, big=True)
     ref_id = O.inverse_dynamics(blob, q, qd, tau, big=True)
     for dt, tol in ((torch.float64, 1e-9), (torch.float32, 1e-5)):
@@ -1060,9 +1061,10 @@ def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu
     for k in range(nv):
         col = O.inverse_dynamics(blob, q[:32], z, np.tile(e[k], (32, 1)), big=True) - C
         assert np.abs(H[:, :, k] - col).max() < 1e-9 * (1 + np.abs(col).max())
-    # what the route does not cover says so
-    with pytest.raises(Exception):
-        plan.fd_dq(t(q[:4]), t(qd[:4]), t(tau[:4]))
+    # what the route does not cover says so (up to 64 velocities; beyond, the difference batches of capi.cpp take over for explicit clusters)
+    if nv <= 64:
+        with pytest.raises(Exception):
+            plan.fd_dq(t(q[:4]), t(qd[:4]), t(tau[:4]))
 
 
 @pytest.mark.parametrize("seed,floating", [(31, True), (32, False), (33, True), (34, False)])

@@ -11,12 +11,12 @@ from parallel_chains import parallel_chain_urdf
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ONLY = os.environ.get("BIG_ONLY")  # e.g. "1,20,31": one model (implicit flag, depth, loop size)
-for implicit, depth, loop in ([tuple(int(x) for x in ONLY.split(","))] if ONLY else []) or ((False, 10, 4), (False, 10, 12), (False, 10, 16), (False, 20, 30), (True, 10, 5), (True, 10, 13), (True, 10, 17), (True, 20, 31)):
+for implicit, depth, loop in ([tuple(int(x) for x in ONLY.split(","))] if ONLY else []) or ((False, 10, 4), (False, 10, 12), (False, 10, 16), (False, 20, 30), (True, 10, 5), (True, 10, 13), (True, 10, 17), (True, 20, 31), (False, 40, 40), (True, 40, 41)):
     with tempfile.NamedTemporaryFile("w", suffix=".urdf", delete=False) as f:
         f.write(parallel_chain_urdf(depth, loop, implicit))
     plan = G.Plan.from_urdf(f.name)
     os.unlink(f.name)
-    q, qd, tau = valid_states(plan.blob, 512, config_index=3, big=True, scale=0.5)
+    q, qd, tau = valid_states(plan.blob, 512, config_index=3, big=True, scale=0.5 if depth < 40 else 0.25)
     rep = (B + 511) // 512
     q, qd, tau = (np.tile(a, (rep, 1))[:B] for a in (q, qd, tau))
     for dt in (torch.float32, torch.float64):
