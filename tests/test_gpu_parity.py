@@ -1093,3 +1093,32 @@ def test_random_trees_with_big_explicit_clusters(gpu, seed, floating):
     Hinv = plan.fd_dtau(t(q[:16])).cpu().numpy()
     H = plan.mass_matrix(t(q[:16])).cpu().numpy()
     assert np.abs(np.einsum("bij,bjk->bik", H, Hinv) - np.eye(nv)).max() < 1e-8
+
+
+FAMILY = [(False, d, l) for d, ls in ((5, (2, 4, 6, 8, 10)), (10, (2, 4, 8, 12, 16)), (20, (2, 6, 12, 20, 30)), (40, (2, 8, 16, 28, 40))) for l in ls] + \
+         [(True, d, l) for d, ls in ((5, (3, 5, 7, 9, 11)), (10, (3, 5, 9, 13, 17)), (20, (3, 7, 13, 21, 31)), (40, (3, 9, 17, 29, 41))) for l in ls]
+
+
+@pytest.mark.parametrize("implicit,depth,loop", FAMILY, ids=[f"{'imp' if f[0] else 'exp'}-d{f[1]}-l{f[2]}" for f in FAMILY])
+def test_every_model_of_the_reference_parallel_chain_family(gpu, tmp_path, implicit, depth, loop):
+    """All 40 (depth, loop size) pairs of the reference's parallel-chain benchmark (Benchmarking/urdfs/make_parallel_chain_urdfs.sh;
+    pinocchioHelpers.cpp:355-410): forward and inverse dynamics in fp64 against the oracle, whichever route the plan takes -- the
+    structured kernels up to 8 bodies / 4 DoF per cluster (at depth 40: 79 DoF), the spanning tree beyond."""
+    import torch
+    from parallel_chains import parallel_chain_urdf
+
+    path = tmp_path / "pc.urdf"
+    path.write_text(parallel_chain_urdf(depth, loop, implicit))
+    plan = G.Plan.from_urdf(str(path))
+    m = loop // 2
+    big = (loop > 8) or (loop - (2 if implicit else 1) > 4)
+    assert plan.info().spanning_tree_route == (1 if big else 0)
+    blob = plan.blob
+    q, qd, tau = valid_states(blob, 70, config_index=23, big=True, scale=0.5 if depth < 40 else 0.25, max_cond=50 if implicit else None)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    ref = O.forward_dynamics(blob, q, qd, tau, big=True)
+    ref_id = O.inverse_dynamics(blob, q, qd, tau, big=True)
+    ydd = plan.forward_dynamics(t(q), t(qd), t(tau)).cpu().numpy()
+    tid = plan.inverse_dynamics(t(q), t(qd), t(tau)).cpu().numpy()
+    assert np.abs(ydd - ref).max() / (1 + np.abs(ref).max()) < 1e-9
+    assert np.abs(tid - ref_id).max() / (1 + np.abs(ref_id).max()) < 1e-9
