@@ -1576,8 +1576,9 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const size_t nq_s = sp->host.nq, nv_s = sp->host.nv, nn_s = nv_s * nv_s;
     const bool need_d = dq || dqd;
     const bool big = p->host.big_clusters;
-    if (big && need_d)
-        return set_err(GRBDA_EUNSUPPORTED, "derivatives with respect to q and qd are not covered for clusters beyond the structured kernels' limits");
+    // (clusters beyond the structured limits: no analytic d/dq, d/dqd -- the callers' difference batches take over: forward dynamics
+    // differences for explicit clusters; implicit ones would need the Newton re-projection, which refuses such plans)
+    if (big && need_d) return 1;
     const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
     const bool solve = need_d || dtau;
     const int il = (need_d && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;

@@ -1061,10 +1061,18 @@ def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu
     for k in range(nv):
         col = O.inverse_dynamics(blob, q[:32], z, np.tile(e[k], (32, 1)), big=True) - C
         assert np.abs(H[:, :, k] - col).max() < 1e-9 * (1 + np.abs(col).max())
-    # what the route does not cover says so (up to 64 velocities; beyond, the difference batches of capi.cpp take over for explicit clusters)
-    if nv <= 64:
+    # derivatives with respect to q: not analytic for such clusters -- difference batches of the forward dynamics for explicit clusters
+    # (against oracle differences), a loud refusal for implicit ones (their differences need the Newton re-projection)
+    if implicit:
         with pytest.raises(Exception):
             plan.fd_dq(t(q[:4]), t(qd[:4]), t(tau[:4]))
+    elif depth <= 10:
+        J = plan.fd_dq(t(q[:2]), t(qd[:2]), t(tau[:2])).cpu().numpy()
+        h = 1e-6
+        for k in (0, nv // 2, nv - 1):
+            dq_ = np.zeros_like(q[:2]); dq_[:, k] = h
+            col = (O.forward_dynamics(blob, q[:2] + dq_, qd[:2], tau[:2], big=True) - O.forward_dynamics(blob, q[:2] - dq_, qd[:2], tau[:2], big=True)) / (2 * h)
+            assert np.abs(J[:, :, k] - col).max() / (1 + np.abs(col).max()) < 2e-5
 
 
 @pytest.mark.parametrize("seed,floating", [(31, True), (32, False), (33, True), (34, False)])
