@@ -577,9 +577,9 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
 }
 
 template <class T>
-int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int device, void *stream);
-int projection_run_f32_through_f64(const grbda_plan *p, bool rnea, const float *q, const float *qd, const float *x, float *out, size_t B, int device,
-                                   void *stream);
+int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, const T *f_ext, T *out, size_t B, int device, void *stream);
+int projection_run_f32_through_f64(const grbda_plan *p, bool rnea, const float *q, const float *qd, const float *x, const float *f_ext, float *out,
+                                   size_t B, int device, void *stream);
 
 template <class T>
 int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, const T *f_ext, T *out, size_t B,
@@ -590,13 +590,13 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     if (!p || !q || !qd || !x || !out) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
     if (p->host.projection_only) {
-        if (f_ext) return set_err(GRBDA_EUNSUPPORTED, "external forces are not supported for models on the spanning-tree route");
+        // (external forces: world-frame wrenches on the BODIES, which the spanning model shares with this one -- they enter its inverse dynamics)
         if constexpr (sizeof(T) == 4) {
             // clusters beyond the structured limits: a dense solve over chains tens of links long loses cond(H) x 6e-8 in fp32 (measured
             // 1e-2 on the reference's depth-10 parallel chains); the route is slow anyway, so fp32 callers get the fp64 route's result
-            if (p->host.big_clusters && !rnea) return projection_run_f32_through_f64(p, rnea, q, qd, x, out, B, device, stream);
+            if (p->host.big_clusters && !rnea) return projection_run_f32_through_f64(p, rnea, q, qd, x, f_ext, out, B, device, stream);
         }
-        return projection_run<T>(p, rnea, q, qd, x, out, B, device, stream);
+        return projection_run<T>(p, rnea, q, qd, x, f_ext, out, B, device, stream);
     }
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
@@ -1435,7 +1435,7 @@ bool analytic_covers(const grbda_plan *p)
 // Forward / inverse dynamics through the spanning tree (HostPlan::projection_only; the reference's Projection-method cross-check,
 // RigidBodyTreeDynamics.cpp:86-97):  tau = G^T ID_s(q_s, G yd, G ydd + g);  ydd = (G^T H_s G)^-1 (tau - G^T ID_s(q_s, G yd, g)).
 template <class T>
-int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, T *out, size_t B, int device, void *stream)
+int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, const T *f_ext, T *out, size_t B, int device, void *stream)
 {
     if (!p->span)
         return set_err(GRBDA_EUNSUPPORTED, "the model needs the spanning-tree route, which covers at most 64 spanning velocities (128 for plans with big clusters)");
@@ -1478,7 +1478,8 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
                                           p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, rnea ? x + b0 * nv : nullptr, q_s, qd_s, qdd_s, cpl, nb,
                                           static_cast<int>(grid), hs, big);
         if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
-        if (int rc = run<T>(sp, true, q_s, qd_s, qdd_s, nullptr, x_s, nb, device, stream)) return rc;
+        if (int rc = run<T>(sp, true, q_s, qd_s, qdd_s, f_ext ? f_ext + b0 * static_cast<size_t>(p->host.n_bodies) * 6 : nullptr, x_s, nb, device, stream))
+            return rc;
         if (rnea) {
             e = launch_manifold_apply<T>(d, p->host.n_clusters, t->span_v, t->crow, static_cast<int>(nv_s), p->n_cpl_rows, 0, x_s, nullptr, nullptr,
                                          cpl, out + b0 * nv, nb, static_cast<int>(grid), hs, big);
@@ -1527,17 +1528,17 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     return GRBDA_OK;
 }
 
-int projection_run_f32_through_f64(const grbda_plan *p, bool rnea, const float *q, const float *qd, const float *x, float *out, size_t B, int device,
-                                   void *stream)
+int projection_run_f32_through_f64(const grbda_plan *p, bool rnea, const float *q, const float *qd, const float *x, const float *f_ext, float *out,
+                                   size_t B, int device, void *stream)
 {
-    const size_t nq = p->host.nq, nv = p->host.nv;
-    const size_t per_state = nq + 3 * nv;
+    const size_t nq = p->host.nq, nv = p->host.nv, nfe = f_ext ? static_cast<size_t>(p->host.n_bodies) * 6 : 0;
+    const size_t per_state = nq + 3 * nv + nfe;
     size_t chunk = (256u << 20) / (per_state * sizeof(double));
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     void *cvt = nullptr;
     if (int rc = ensure_work(p, p->work_cvt, device, stream, chunk * per_state * sizeof(double) + 256, &cvt)) return rc;
-    double *q64 = static_cast<double *>(cvt), *qd64 = q64 + chunk * nq, *x64 = qd64 + chunk * nv, *o64 = x64 + chunk * nv;
+    double *q64 = static_cast<double *>(cvt), *qd64 = q64 + chunk * nq, *x64 = qd64 + chunk * nv, *o64 = x64 + chunk * nv, *fe64 = o64 + chunk * nv;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     auto blocks = [](size_t n) { return static_cast<int>((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535); };
     for (size_t b0 = 0; b0 < B; b0 += chunk) {
@@ -1545,7 +1546,8 @@ int projection_run_f32_through_f64(const grbda_plan *p, bool rnea, const float *
         hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks(nb * nq)), dim3(256), 0, hs, q + b0 * nq, q64, nb * nq);
         hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks(nb * nv)), dim3(256), 0, hs, qd + b0 * nv, qd64, nb * nv);
         hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks(nb * nv)), dim3(256), 0, hs, x + b0 * nv, x64, nb * nv);
-        if (int rc = projection_run<double>(p, rnea, q64, qd64, x64, o64, nb, device, stream)) return rc;
+        if (f_ext) hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks(nb * nfe)), dim3(256), 0, hs, f_ext + b0 * nfe, fe64, nb * nfe);
+        if (int rc = projection_run<double>(p, rnea, q64, qd64, x64, f_ext ? fe64 : nullptr, o64, nb, device, stream)) return rc;
         hipLaunchKernelGGL((convert_kernel<double, float>), dim3(blocks(nb * nv)), dim3(256), 0, hs, o64, out + b0 * nv, nb * nv);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_err(e, "convert launch");

@@ -15,7 +15,7 @@ import oracle_py as O
 import generalized_rbda_amd as G
 from generalized_rbda_amd import modeldesc as md
 from generalized_rbda_amd.states import random_states
-from models import random_inertia, random_xtree, valid_states, zoo
+from models import ROBOT_MODELS, random_inertia, random_xtree, valid_states, zoo
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -1130,3 +1130,53 @@ def test_every_model_of_the_reference_parallel_chain_family(gpu, tmp_path, impli
     tid = plan.inverse_dynamics(t(q), t(qd), t(tau)).cpu().numpy()
     assert np.abs(ydd - ref).max() / (1 + np.abs(ref).max()) < 1e-9
     assert np.abs(tid - ref_id).max() / (1 + np.abs(ref_id).max()) < 1e-9
+
+
+@pytest.mark.parametrize("which", ["two_parent", "exp_d10_l16", "imp_d10_l17"])
+def test_external_forces_and_test_force_on_the_spanning_tree_route(gpu, which):
+    """Plans on the spanning-tree route (a cluster on two parent bodies; clusters of 16 / 17 bodies) take world-frame external forces --
+    the spanning model shares their bodies, so the forces enter ITS inverse dynamics -- and with them the contact-side entry points that
+    are built on forced forward dynamics: applyTestForce (ClusterTreeDynamics.cpp:194-233) against the oracle's forced dynamics."""
+    import torch
+    from test_capi_cpu import two_parent_model
+
+    big = which != "two_parent"
+    if which == "two_parent":
+        blob = two_parent_model().serialize()
+        plan = G.Plan(blob)
+        q, qd, tau = random_states(blob, 70, config_index=4)
+    else:
+        name = {"exp_d10_l16": "parallel_chain_exp_d10_l16", "imp_d10_l17": "parallel_chain_imp_d10_l17"}[which]
+        plan = G.Plan.from_urdf(os.path.join(ROBOT_MODELS, name + ".urdf"))
+        blob = plan.blob
+        q, qd, tau = valid_states(blob, 70, config_index=4, big=True, scale=0.5, max_cond=50)
+    assert plan.info().spanning_tree_route == 1
+    B, nb, nv = q.shape[0], plan.n_bodies, plan.nv
+    fext = np.random.default_rng(6).uniform(-1, 1, (B, nb, 6))
+    t = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+    ref = O.forward_dynamics(blob, q, qd, tau, fext, big=big)
+    ref_t = O.inverse_dynamics(blob, q, qd, tau, fext, big=big)
+    assert rel_err(O.forward_dynamics(blob, q, qd, tau, big=big), ref) > 1e-3  # (the forces matter)
+    for dt, tol in ((torch.float64, TOL64), (torch.float32, TOL32)):
+        got = plan.forward_dynamics(t(q, dt), t(qd, dt), t(tau, dt), f_ext=t(fext, dt)).double().cpu().numpy()
+        got_t = plan.inverse_dynamics(t(q, dt), t(qd, dt), t(tau, dt), f_ext=t(fext, dt)).double().cpu().numpy()
+        assert np.abs(got - ref).max() / (1 + np.abs(ref).max()) < tol
+        assert np.abs(got_t - ref_t).max() / (1 + np.abs(ref_t).max()) < tol
+    # applyTestForce at a point of the last body
+    Bt = 6
+    force = np.random.default_rng(7).uniform(-1, 1, (Bt, 3))
+    offset = np.array([0.05, -0.02, 0.1])
+    body = nb - 1
+    lam, ds = plan.apply_test_force(t(q[:Bt]), body, offset, t(force))
+    lam, ds = lam.cpu().numpy(), ds.cpu().numpy()
+    Xa = plan.body_poses(t(q[:Bt])).cpu().numpy()[:, body]
+    E, r = Xa[:, :9].reshape(Bt, 3, 3), Xa[:, 9:]
+    pt = r + np.einsum("bji,j->bi", E, offset)
+    fe = np.zeros((Bt, nb, 6))
+    fe[:, body, :3] = np.cross(pt, force)
+    fe[:, body, 3:] = force
+    zero = np.zeros((Bt, nv))
+    ds_ref = O.forward_dynamics(blob, q[:Bt], zero, zero, fe, big=big) - O.forward_dynamics(blob, q[:Bt], zero, zero, big=big)
+    jtf = O.inverse_dynamics(blob, q[:Bt], zero, zero, big=big) - O.inverse_dynamics(blob, q[:Bt], zero, zero, fe, big=big)
+    assert np.abs(ds - ds_ref).max() / (1 + np.abs(ds_ref).max()) < 1e-8
+    assert np.abs(lam.reshape(-1) - np.einsum("bi,bi->b", jtf, ds_ref)).max() / (1 + np.abs(lam).max()) < 1e-8
