@@ -102,8 +102,10 @@ typedef struct {
     int n_chain_differentials;          /* implicit two-rotor differential clusters inside the f32 chain program */
     int latency_mode_f32, latency_mode_f64; /* 1: batches of at most one tile per SIMD run a tile on two wavefronts (plan.h, ChainProgram::n_waves) */
     int n_chain_generic;                /* generic clusters inside the f32 chain program (plan.h, ChainGen): URDF+ position loops, triple / Generic clusters */
-    int spanning_tree_route;            /* 1: a cluster attaches to several bodies of its parent cluster -- every entry point runs through the
-                                           spanning tree and the per-state G (H = G^T H_s G; capi.cpp projection_run), no sweep programs */
+    int spanning_tree_route;            /* 1: a cluster attaches to several bodies of its parent cluster, or has more than 8 bodies / 4 independent
+                                           coordinates (up to 48 / 48; models up to 128 velocities) -- forward / inverse dynamics (with external
+                                           forces), mass matrix and d ydd / d tau run through the spanning tree and the per-state G
+                                           (H = G^T H_s G; capi.cpp projection_run), no sweep programs; INTEGRATION.md 3 lists what the route refuses */
 } grbda_plan_info_t;
 int grbda_plan_info(const grbda_plan *plan, grbda_plan_info_t *info);
 
