@@ -1587,7 +1587,8 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     // workspace per state: spanning state (q_s, qd_s, qdd_s, tau_s), zeros for a missing qd, coupling rows, the three spanning
     // matrices, the three projected matrices, ydd
     const size_t per_state = nq_s + 3 * nv_s + nv + static_cast<size_t>(p->n_cpl_rows) + 3 * nn_s + 3 * nn + nv;
-    size_t chunk = (1024ull << 20) / (per_state * sizeof(T));
+    // (4 GiB: TelloWithArms takes 33 KB per state, and a 1 GiB chunk -- 32 768 states, 512 tiles -- left half of the SIMDs without one)
+    size_t chunk = (4096ull << 20) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     const size_t b_round = (B + kWave - 1) / kWave * kWave;

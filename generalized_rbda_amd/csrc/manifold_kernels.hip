@@ -916,11 +916,18 @@ hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const in
     if (big) {
         if (mode != 1 || interleave != 1) return hipErrorInvalidValue;  // (H only, state-major)
         return launch_manifold_project_wide<T>(P, n_clusters, span_v, crow, rel, rel_s, nullptr, nullptr, nv_s, n_cpl_rows, Hs, cpl, H, B, grid, stream);
-    } else if (interleave == kDerivGroup) {
-        hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P,
+    }
+    // (101 registers in fp32, 189 in fp64, and every load a coalesced row that comes from HBM: four / two wavefronts per SIMD hide what one
+    // cannot -- the caller's grid is for one per SIMD)
+    size_t g = static_cast<size_t>(grid) * (sizeof(T) == 4 ? 4 : 2);
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    if (g > n_tiles) g = n_tiles;
+    if (g < 1) g = 1;
+    if (interleave == kDerivGroup) {
+        hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup, kMaxClusterBodies, kMaxClusterDof>), dim3(static_cast<unsigned>(g)), dim3(kWave), 0, stream, P,
                            n_clusters, span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
     } else {
-        hipLaunchKernelGGL((manifold_project_kernel<T, 1, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
+        hipLaunchKernelGGL((manifold_project_kernel<T, 1, kMaxClusterBodies, kMaxClusterDof>), dim3(static_cast<unsigned>(g)), dim3(kWave), 0, stream, P, n_clusters,
                            span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
     }
     return hipGetLastError();
