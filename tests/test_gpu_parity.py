@@ -1180,3 +1180,31 @@ def test_external_forces_and_test_force_on_the_spanning_tree_route(gpu, which):
     jtf = O.inverse_dynamics(blob, q[:Bt], zero, zero, big=big) - O.inverse_dynamics(blob, q[:Bt], zero, zero, fe, big=big)
     assert np.abs(ds - ds_ref).max() / (1 + np.abs(ds_ref).max()) < 1e-8
     assert np.abs(lam.reshape(-1) - np.einsum("bi,bi->b", jtf, ds_ref)).max() / (1 + np.abs(lam).max()) < 1e-8
+    # inverse operational-space inertia of two frames (the unit-wrench route: 6 m + 1 forced dynamics per state), as
+    # test_inverse_osim_by_force_propagation builds it from the oracle
+    frames = [nb - 1, nb // 2]
+    offs = np.random.default_rng(8).uniform(-0.2, 0.2, size=(2, 3))
+    Linv, J = plan.inv_osim(t(q[:Bt]), frames, offs, with_jacobian=True)
+    Linv, J = Linv.cpu().numpy(), J.cpu().numpy()
+    Xall = plan.body_poses(t(q[:Bt])).cpu().numpy()
+    tau0 = O.inverse_dynamics(blob, q[:Bt], zero, zero, big=big)
+    J_ref = np.zeros((Bt, 12, nv))
+    for c, (bd, off) in enumerate(zip(frames, offs)):
+        E, r = Xall[:, bd, :9].reshape(Bt, 3, 3), Xall[:, bd, 9:]
+        pt = r + np.einsum("bji,j->bi", E, off)
+        for k in range(6):
+            e = E[:, k % 3, :]
+            fe = np.zeros((Bt, nb, 6))
+            if k < 3:
+                fe[:, bd, :3] = e
+            else:
+                fe[:, bd, :3] = np.cross(pt, e)
+                fe[:, bd, 3:] = e
+            J_ref[:, 6 * c + k] = tau0 - O.inverse_dynamics(blob, q[:Bt], zero, zero, fe, big=big)
+    Hm = np.zeros((Bt, nv, nv))
+    for j in range(nv):
+        ej = np.zeros((Bt, nv)); ej[:, j] = 1
+        Hm[:, :, j] = O.inverse_dynamics(blob, q[:Bt], zero, ej, big=big) - tau0
+    L_ref = np.einsum("bik,bkl,bjl->bij", J_ref, np.linalg.inv(Hm), J_ref)
+    assert np.abs(J - J_ref).max() / (1 + np.abs(J_ref).max()) < 1e-8
+    assert np.abs(Linv - L_ref).max() / (1 + np.abs(L_ref).max()) < 1e-7
