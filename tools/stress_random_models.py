@@ -16,7 +16,7 @@ rel = lambda a, b: float(np.abs(a - b).max() / (1.0 + np.abs(b).max()))
 bad = 0
 shapes = {}
 for seed in range(1000, 1000 + n):
-    for kind in ("chain", "tree_float", "tree_fixed", "chain_fixed_like"):
+    for kind in ("chain", "tree_float", "tree_fixed", "chain_fixed_like", "tree_big"):
         if kind == "chain":
             m = chain_test_tree(seed, n_limbs=1 + seed % 5, ori_repr="rpy" if seed % 4 == 0 else "quaternion", rotors=seed % 3 != 0,
                                 deep_pairs=seed % 2 == 1)
@@ -24,6 +24,8 @@ for seed in range(1000, 1000 + n):
             m = random_cluster_tree(seed, n_clusters=3 + seed % 9, floating=True, ori_repr="rpy" if seed % 7 == 0 else "quaternion")
         elif kind == "tree_fixed":
             m = random_cluster_tree(seed, n_clusters=2 + seed % 8, floating=False)
+        elif kind == "tree_big":  # Generic clusters of 9-20 bodies / 5-12 coordinates among ordinary ones: the spanning-tree route
+            m = random_cluster_tree(seed, n_clusters=2 + seed % 3, floating=seed % 2 == 0, kinds=("generic_big", "rev", "rotor", "generic_big", "generic"))
         else:
             m = random_cluster_tree(seed, n_clusters=2 + seed % 10, floating=False, kinds=("rev", "axirotor", "rotor"))
         blob = m.serialize()
@@ -33,12 +35,24 @@ for seed in range(1000, 1000 + n):
         key = (kind, info.chain_aba_f32, info.chain_rnea_f32, info.analytic_derivatives, "diffs>0" if info.n_chain_differentials else "")
         shapes[key] = shapes.get(key, 0) + 1
         B = 70
-        q, qd, tau = valid_states(blob, B, config_index=seed)
+        big = kind == "tree_big"  # (the oracle build with room for 48 bodies per cluster)
+        if big and plan.nv > 64:
+            continue
+        q, qd, tau = valid_states(blob, B, config_index=seed, big=big)
         errs = {}
         for dt, tol in ((torch.float64, 1e-9), (torch.float32, 1e-3)):
             c = (lambda a: a) if dt == torch.float64 else (lambda a: a.astype(np.float32).astype(np.float64))
-            errs[f"aba{dt}"] = (rel(plan.forward_dynamics(t(q, dt), t(qd, dt), t(tau, dt)).double().cpu().numpy(), O.forward_dynamics(blob, c(q), c(qd), c(tau))), tol)
-            errs[f"rnea{dt}"] = (rel(plan.inverse_dynamics(t(q, dt), t(qd, dt), t(tau, dt)).double().cpu().numpy(), O.inverse_dynamics(blob, c(q), c(qd), c(tau))), tol)
+            errs[f"aba{dt}"] = (rel(plan.forward_dynamics(t(q, dt), t(qd, dt), t(tau, dt)).double().cpu().numpy(), O.forward_dynamics(blob, c(q), c(qd), c(tau), big=big)), tol)
+            errs[f"rnea{dt}"] = (rel(plan.inverse_dynamics(t(q, dt), t(qd, dt), t(tau, dt)).double().cpu().numpy(), O.inverse_dynamics(blob, c(q), c(qd), c(tau), big=big)), tol)
+        if big:
+            H64 = plan.mass_matrix(t(q[:8])).cpu().numpy()
+            Hinv = plan.fd_dtau(t(q[:8])).cpu().numpy()
+            errs["H Hinv"] = (float(np.abs(np.einsum("bij,bjk->bik", H64, Hinv) - np.eye(plan.nv)).max()), 1e-7)
+            fails = {k: v for k, v in errs.items() if not (v[0] < v[1])}
+            if fails:
+                bad += 1
+                print("FAIL", kind, seed, {k: f"{v[0]:.2e}" for k, v in fails.items()}, "info", key, flush=True)
+            continue
         d = plan.fd_derivatives(t(q[:6]), t(qd[:6]), t(tau[:6]))
         os.environ["GRBDA_NO_ANALYTIC"] = "1"; os.environ["GRBDA_NO_EFPA"] = "1"
         slow = G.Plan(blob)
@@ -68,7 +82,7 @@ for seed in range(1000, 1000 + n):
         if fails:
             bad += 1
             print("FAIL", kind, seed, {k: f"{v[0]:.2e}" for k, v in fails.items()}, "info", key, flush=True)
-print("models", 4 * n, "failures", bad)
+print("models", sum(shapes.values()), "failures", bad)
 for k, v in sorted(shapes.items()):
     print("  (kind, chain_aba_f32, chain_rnea_f32, analytic, explicit pairs as differentials):", k, "x", v)
 sys.exit(1 if bad else 0)
