@@ -743,6 +743,36 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
     GRBDA_CALL_SCOPE(p);
     if (!p || !q || !qd || !ydd || !qdd_span) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
+    if (p->host.big_clusters) {
+        // clusters beyond the structured limits: qd_s = G yd, qdd_s = G ydd + g from the wide constraint kernel of the spanning-tree route
+        // (manifold_kernels.hip), whose spanning coordinates are the bodies in order -- the layout of this entry point
+        if (!p->span) return set_err(GRBDA_EUNSUPPORTED, "the model needs the spanning-tree route, which covers at most 128 velocities");
+        DeviceTables *t = nullptr;
+        if (int rc = ensure_device(p, device, &t)) return rc;
+        const size_t nq = p->host.nq, nv = p->host.nv, nq_s = p->span->host.nq, nv_s = p->span->host.nv;
+        if (static_cast<size_t>(span_count(p)) != nv_s) return set_err(GRBDA_EUNSUPPORTED, "spanning layout mismatch");
+        const size_t per_state = nq_s + nv_s + static_cast<size_t>(p->n_cpl_rows);
+        size_t chunk = (1024ull << 20) / (per_state * sizeof(T));
+        chunk &= ~static_cast<size_t>(kWave - 1);
+        if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
+        const size_t b_round = (B + kWave - 1) / kWave * kWave;
+        if (chunk > b_round) chunk = b_round;
+        void *wptr = nullptr;
+        if (int rc = ensure_work(p, p->work_proj, device, stream, chunk * per_state * sizeof(T) + 256, &wptr)) return rc;
+        T *q_s = static_cast<T *>(wptr), *v_tmp = q_s + chunk * nq_s, *cpl = v_tmp + chunk * nv_s;
+        DevPlan<T> dp = make_dev_plan<T>(p, *t, false, false);
+        for (size_t b0 = 0; b0 < B; b0 += chunk) {
+            const size_t nb = B - b0 < chunk ? B - b0 : chunk;
+            size_t g = static_cast<size_t>(t->n_cu) * 4;
+            if (g > (nb + kWave - 1) / kWave) g = (nb + kWave - 1) / kWave;
+            hipError_t e = launch_manifold_constraint<T>(dp, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s),
+                                                         static_cast<int>(nv_s), p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, ydd + b0 * nv, q_s,
+                                                         qd_span ? qd_span + b0 * nv_s : v_tmp, qdd_span + b0 * nv_s, cpl, nb, static_cast<int>(g),
+                                                         static_cast<hipStream_t>(stream), true);
+            if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
+        }
+        return GRBDA_OK;
+    }
     DevPlan<T> d;
     T *scratch = nullptr;
     int grid = 0;
@@ -828,6 +858,8 @@ int twists(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *V, siz
     GRBDA_CALL_SCOPE(p);
     if (!q || !qd || !ydd || !V) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
+    if (p->host.big_clusters)
+        return set_err(GRBDA_EUNSUPPORTED, "body twists are not covered for clusters beyond the structured kernels' limits (spanning rates are: grbda_spanning_*)");
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const size_t ns = static_cast<size_t>(span_count(p));

@@ -116,11 +116,11 @@ def forward_dynamics_mt_f32(blob, q, qd, tau, n_threads):
     return out
 
 
-def cluster_constraint(blob, cluster, q, qd, nsv, n, rows):
+def cluster_constraint(blob, cluster, q, qd, nsv, n, rows, big=False):
     q, qd = _f64(q), _f64(qd)
     G, g = np.zeros((nsv, n)), np.zeros(nsv)
     K, k, phi = np.zeros((rows, nsv)), np.zeros(rows), np.zeros(rows)
-    rc = lib().grbda_oracle_cluster_constraint(blob, len(blob), cluster, q.ctypes.data, qd.ctypes.data, G.ctypes.data,
+    rc = lib(big).grbda_oracle_cluster_constraint(blob, len(blob), cluster, q.ctypes.data, qd.ctypes.data, G.ctypes.data,
                                                g.ctypes.data, K.ctypes.data, k.ctypes.data, phi.ctypes.data)
     if rc:
         raise RuntimeError(f"oracle error {rc}")

@@ -1180,6 +1180,24 @@ def test_external_forces_and_test_force_on_the_spanning_tree_route(gpu, which):
     jtf = O.inverse_dynamics(blob, q[:Bt], zero, zero, big=big) - O.inverse_dynamics(blob, q[:Bt], zero, zero, fe, big=big)
     assert np.abs(ds - ds_ref).max() / (1 + np.abs(ds_ref).max()) < 1e-8
     assert np.abs(lam.reshape(-1) - np.einsum("bi,bi->b", jtf, ds_ref)).max() / (1 + np.abs(lam).max()) < 1e-8
+    # spanning recovery qd_s = G yd, qdd_s = G ydd + g (big clusters: the wide constraint kernel): rates against the oracle's, the
+    # acceleration's G against the rates' by linearity, g of the big cluster against the oracle's constraint evaluation
+    vs, as0 = (x.cpu().numpy() for x in plan.spanning(t(q), t(qd), t(np.zeros_like(qd))))
+    _, as1 = (x.cpu().numpy() for x in plan.spanning(t(q), t(qd), t(qd)))
+    vs_ref = O.spanning_state(blob, q, qd, big=big)[1]
+    assert np.abs(vs - vs_ref).max() / (1 + np.abs(vs_ref).max()) < 1e-10
+    assert np.abs((as1 - as0) - vs).max() / (1 + np.abs(vs).max()) < 1e-10
+    from generalized_rbda_amd.states import parse_clusters
+    at = 0
+    for ci, c in enumerate(parse_clusters(blob)["clusters"]):
+        (pc, fb, k, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = c
+        if ctype >= 2:
+            for b in range(4):
+                g_ref = O.cluster_constraint(blob, ci, q[b], qd[b], nsv, nvel, rows, big=big)[1]
+                assert np.abs(as0[b, at:at + nsv] - g_ref).max() / (1 + np.abs(g_ref).max()) < 1e-9
+        else:
+            assert np.abs(as0[:, at:at + nsv]).max() == 0
+        at += nsv
     # inverse operational-space inertia of two frames (the unit-wrench route: 6 m + 1 forced dynamics per state), as
     # test_inverse_osim_by_force_propagation builds it from the oracle
     frames = [nb - 1, nb // 2]
