@@ -858,8 +858,6 @@ int twists(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *V, siz
     GRBDA_CALL_SCOPE(p);
     if (!q || !qd || !ydd || !V) return set_err(GRBDA_EINVAL, "null argument");
     if (B == 0) return GRBDA_OK;
-    if (p->host.big_clusters)
-        return set_err(GRBDA_EUNSUPPORTED, "body twists are not covered for clusters beyond the structured kernels' limits (spanning rates are: grbda_spanning_*)");
     DeviceTables *t = nullptr;
     if (int rc = ensure_device(p, device, &t)) return rc;
     const size_t ns = static_cast<size_t>(span_count(p));

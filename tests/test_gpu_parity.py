@@ -1226,3 +1226,21 @@ def test_external_forces_and_test_force_on_the_spanning_tree_route(gpu, which):
     L_ref = np.einsum("bik,bkl,bjl->bij", J_ref, np.linalg.inv(Hm), J_ref)
     assert np.abs(J - J_ref).max() / (1 + np.abs(J_ref).max()) < 1e-8
     assert np.abs(Linv - L_ref).max() / (1 + np.abs(L_ref).max()) < 1e-7
+    # body twists (spanning rates from the wide constraint kernel, then the tree walk): velocities against J qd of the frames' bodies,
+    # accelerations against central differences of the velocities along the motion (explicit clusters: y moves with yd, ydd)
+    _, J0 = plan.inv_osim(t(q[:Bt]), frames, np.zeros((2, 3)), with_jacobian=True)
+    J0 = J0.cpu().numpy().reshape(Bt, 2, 6, nv)
+    ydd = ref[:Bt] * 0 + np.random.default_rng(9).uniform(-1, 1, (Bt, nv))
+    V = plan.body_twists(t(q[:Bt]), t(qd[:Bt]), t(ydd)).cpu().numpy()
+    assert np.abs(np.einsum("bnij,bj->bni", J0, qd[:Bt]) - V[:, frames, :6]).max() / (1 + np.abs(V[:, frames, :6]).max()) < 1e-9
+    V32 = plan.body_twists(t(q[:Bt], torch.float32), t(qd[:Bt], torch.float32), t(ydd, torch.float32)).double().cpu().numpy()
+    assert np.abs(V32 - V).max() / (1 + np.abs(V).max()) < TOL32
+    if which != "imp_d10_l17":
+        h = 1e-5
+        Vp = plan.body_twists(t(q[:Bt] + h * qd[:Bt] + 0.5 * h * h * ydd), t(qd[:Bt] + h * ydd), t(ydd)).cpu().numpy()
+        Vm = plan.body_twists(t(q[:Bt] - h * qd[:Bt] + 0.5 * h * h * ydd), t(qd[:Bt] - h * ydd), t(ydd)).cpu().numpy()
+        a_fd = (Vp[:, :, :6] - Vm[:, :, :6]) / (2 * h)
+        Ew = Xall[:, :, :9].reshape(Bt, nb, 3, 3)
+        a_ref = V[:, :, 6:].copy()
+        a_ref[:, :, 3:] -= np.einsum("bnij,j->bni", Ew, -np.asarray(plan.get_gravity(), dtype=np.float64)[-3:])
+        assert np.abs(a_fd - a_ref).max() / (1 + np.abs(a_ref).max()) < 2e-6
