@@ -725,6 +725,16 @@ int project(const grbda_plan *p, T *q, int32_t *ok, size_t B, int max_iter, doub
     GRBDA_CALL_SCOPE(p);
     if (!p || !q || max_iter < 0) return set_err(GRBDA_EINVAL, "bad argument");
     if (B == 0) return GRBDA_OK;
+    if (p->host.big_clusters) {  // (clusters beyond the structured limits: the wide Newton kernel of manifold_kernels.hip)
+        DeviceTables *t = nullptr;
+        if (int rc = ensure_device(p, device, &t)) return rc;
+        DevPlan<T> dp = make_dev_plan<T>(p, *t, false, false);
+        size_t g = static_cast<size_t>(t->n_cu) * 4;
+        if (g > (B + kWave - 1) / kWave) g = (B + kWave - 1) / kWave;
+        hipError_t e = launch_manifold_newton<T>(dp, p->host.n_clusters, q, ok, B, max_iter, static_cast<T>(tol), static_cast<int>(g),
+                                                 static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? GRBDA_OK : hip_err(e, "projection launch");
+    }
     DevPlan<T> d;
     T *scratch = nullptr;
     int grid = 0;

@@ -98,8 +98,9 @@ __device__ __forceinline__ void cross_s(const S (&a)[3], const S (&b)[3], S (&o)
 // sn / cs: sine and cosine of the k spanning angles; qd: the k spanning rates
 template <class T, class S, int KB>
 __device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
-                                   const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][KB], S (&kap)[kMR])
+                                   const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][KB], S (&kap)[kMR], S *phi = nullptr)
 {
+    // phi (with want_K): the constraint values -- predecessor point minus successor point along the constrained axes
     cptr<int32_t> lp = loops;
     int row0 = 0;
     for (int l = 0; l < n_loops; l++) {
@@ -146,6 +147,10 @@ __device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const C
 #pragma unroll
             for (int i = 0; i < 3; i++) p[i] = r[i] + E[i] * og[9] + E[3 + i] * og[10] + E[6 + i] * og[11];
             if (want_K) {
+                if (phi) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) acc[i] += sgn * p[i];
+                }
                 for (int t = 0; t < len; t++) {
                     const S a[3] = {A[t][0], A[t][1], A[t][2]}, d[3] = {p[0] - O[t][0], p[1] - O[t][1], p[2] - O[t][2]};
                     S J[3];
@@ -196,6 +201,7 @@ __device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const C
         for (int ax = 0; ax < 3; ax++)
             if (mask & (1 << ax)) {
                 if (!want_K) kap[row] = acc[ax];
+                else if (phi) phi[row] = acc[ax];
                 row++;
             }
         row0 = row;
@@ -825,6 +831,81 @@ template hipError_t launch_manifold_project_wide<float>(const DevPlan<float> &, 
 template hipError_t launch_manifold_project_wide<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const uint64_t *,
                                                          const uint64_t *, const int32_t *, const int32_t *, int, int, const double *,
                                                          const double *, double *, size_t, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel 5: Newton projection of the dependent spanning positions of URDF+ position-loop clusters onto phi(q) = 0, in place, for plans
+// with clusters beyond the structured limits (the structured plans use kernels.hip's project_kernel): GenericJoint.cpp:289-385 --
+// q_dep <- q_dep - K_d^-1 phi until |phi|_2 < tol or max_iter steps; ok[b] = every cluster converged.  One state per lane.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void manifold_newton_kernel(DevPlan<T> DP, int n_clusters, T *__restrict__ q, int32_t *__restrict__ ok,
+                                                                 size_t B, int max_iter, T tol)
+{
+    constexpr int KB = kBigClusterBodies;
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
+    cptr<T> consts = (cptr<T>)DP.consts;
+    cptr<int32_t> cints = (cptr<int32_t>)DP.cints;
+    const int lane = threadIdx.x, nq = DP.nq;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r0 = tile * kWave + lane;
+        const bool live = r0 < B;
+        T *qs = q + (live ? r0 : B - 1) * (size_t)nq;
+        bool good = true;
+        for (int c = 0; c < n_clusters; c++) {
+            const ClusterRec cr = load_rec(clusters + c);
+            if (cr.kind != CK_LOOP) continue;
+            if (cr.cons_type != 0) { good = false; continue; }  // (trig-polynomial constraints: structured plans only)
+            cptr<int32_t> ip = cints + cr.iofs;
+            const int hdr0 = ip[0], n_ind = ip[1], rows = cr.rows, k = cr.k;
+            cptr<int32_t> dep = ip + 3 + n_ind;
+            cptr<int32_t> payload = ip + 3 + n_ind + rows;
+            T qv[KB], sn[KB], cs[KB], zero[KB];
+            for (int j = 0; j < KB; j++) {
+                qv[j] = j < k ? qs[cr.q_index + j] : T(0);
+                zero[j] = 0;
+            }
+            T nrm = T(1e30);
+            for (int it = 0; it <= max_iter; it++) {
+                T K[kMR][KB], kap[kMR], phi[kMR];
+                for (int r = 0; r < kMR; r++) {
+                    kap[r] = phi[r] = 0;
+                    for (int j = 0; j < KB; j++) K[r][j] = 0;
+                }
+                for (int j = 0; j < k; j++) sincos_precise(qv[j], &sn[j], &cs[j]);
+                loop_position_eval<T, T, KB>(consts, bodies, cr, payload, hdr0, sn, cs, zero, true, K, kap, phi);
+                nrm = 0;
+                for (int r = 0; r < rows; r++) nrm += phi[r] * phi[r];
+                nrm = (T)__builtin_sqrt((double)nrm);
+                // (all lanes iterate together: a lane that has converged keeps its coordinates)
+                const bool done = nrm < tol;
+                if (__builtin_amdgcn_ballot_w64(!done) == 0 || it == max_iter) break;
+                T Kd[kMR][kMR], Kdi[kMR][kMR];
+                for (int r = 0; r < kMR; r++)
+                    for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
+                inv_rows(rows, Kd, Kdi);
+                for (int r = 0; r < rows; r++) {
+                    T s = 0;
+                    for (int j = 0; j < rows; j++) s += Kdi[r][j] * phi[j];
+                    if (!done) qv[dep[r]] -= s;
+                }
+            }
+            good = good && (nrm < tol);
+            if (live)
+                for (int r = 0; r < rows; r++) qs[cr.q_index + dep[r]] = qv[dep[r]];
+        }
+        if (ok && live) ok[r0] = good ? 1 : 0;
+    }
+}
+template <class T>
+hipError_t launch_manifold_newton(const DevPlan<T> &P, int n_clusters, T *q, int32_t *ok, size_t B, int max_iter, T tol, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((manifold_newton_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, q, ok, B, max_iter, tol);
+    return hipGetLastError();
+}
+template hipError_t launch_manifold_newton<float>(const DevPlan<float> &, int, float *, int32_t *, size_t, int, float, int, hipStream_t);
+template hipError_t launch_manifold_newton<double>(const DevPlan<double> &, int, double *, int32_t *, size_t, int, double, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel 4: y = H^-1 b for up to 128 velocities, one state per WORKGROUP of four wavefronts (the wide route beyond the 64 coordinates of

