@@ -1729,14 +1729,11 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const bool wide0 = sizeof(T) == 4 && p->solve_f64;
     const int n_rhs = (dq ? 1 : 0) + (dqd ? 1 : 0);
     // (d / d tau alone: the CRBA kernel writes the same interleaved H and the matrix-core solve inverts it)
-    // (fp64 on the interleaved workspace: built and measured in round 4, NOT the default -- the row-per-lane fp64 solve reads an interleaved block
-    // strided, and what the recursion gains the solve loses twice over on JVRC-1: 29.3 against 21.5 ms per 262 144 states; MIT Humanoid 7.7 against
-    // 8.4.  GRBDA_DERIV_F64_INTERLEAVED=1 selects it for A/B runs; profiles/r4_derivative_recursion_experiments.txt)
-    const bool il64 = sizeof(T) == 8 && nv <= static_cast<size_t>(kWave) && env_int("GRBDA_DERIV_F64_INTERLEAVED", 0) != 0;
-    const int il = (il64 || (!wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs))) ? kDerivGroup : 1;
-    // (only an INTERLEAVED H block can reach past the caller's array: the state-major layouts always build H in place; the fp64 solve
-    // writes its state-major H^-1 while other states of the group still read the interleaved H, so that H stays in the workspace)
-    const bool h_in_place = dtau && (il == 1 || (!il64 && (B % kDerivGroup) == 0));
+    // (fp64 stays state-major: its interleaved workspace was built and measured in round 4 -- MIT Humanoid 8 % faster, JVRC-1 36 % slower, the
+    // row-per-lane fp64 solve reads an interleaved block strided; profiles/r4_derivative_recursion_experiments.txt -- and removed again)
+    const int il = (!wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
+    // (only an INTERLEAVED H block can reach past the caller's array: the state-major layouts always build H in place)
+    const bool h_in_place = dtau && (il == 1 || (B % kDerivGroup) == 0);
     const size_t per_state = (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
     size_t chunk = (2048ull << 20) / (per_state ? per_state * sizeof(T) : 1);
     chunk &= ~static_cast<size_t>(kWave - 1);  // whole tiles, whole groups of the interleaved workspace
@@ -1807,7 +1804,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             if (wide) e = launch_spd_solve<float, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, 1);
             else e = launch_spd_solve<float, float>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, sil);
         } else {
-            e = launch_spd_solve<double, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, sil);
+            e = launch_spd_solve<double, double>(H, hp, r1, r2, o3, o1, o2, rel, nvi, nb, g3i, hs, 1);
         }
         if (e != hipSuccess) return hip_err(e, "spd solve launch");
     }

@@ -772,8 +772,10 @@ template <class T>
 hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
                              const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream, int interleave)
 {
-    if (interleave == kDerivGroup)
-        return launch_rnea_deriv_il<T, kDerivGroup>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
+    if constexpr (sizeof(T) == 4) {
+        if (interleave == kDerivGroup)
+            return launch_rnea_deriv_il<T, kDerivGroup>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
+    }
     if (interleave == kWave && n_max <= 1) {
         // tile-interleaved results [tile][entry][lane]: what a one-state-per-lane consumer reads as coalesced rows (the
         // spanning-tree pass of manifold_kernels.hip; single-body clusters only)
@@ -859,9 +861,8 @@ template <class TIO, class TC, int NV, int KC>
 __global__ __launch_bounds__(kWave)
 __attribute__((amdgpu_waves_per_eu((KC == 2 || (sizeof(TC) == 8 && NV <= 48)) ? 2 : 1, KC == 2 ? 2 : 8)))
 void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2,
-                      const uint64_t *__restrict__ related, int nv, size_t B, int il)
+                      const uint64_t *__restrict__ related, int nv, size_t B)
 {
-    // il: interleave factor of the INPUTS (H, P1, P2: [group of il states][entry][il], rnea_deriv_kernel / crba_kernel); results state-major
     constexpr int V = 16 / (int)sizeof(TC);
     typedef TC Vec __attribute__((ext_vector_type(V)));
     typedef TC XV __attribute__((ext_vector_type(KC)));
@@ -882,11 +883,6 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
     auto read_row = [&](const TIO *row, int n, TIO(&out)[NV]) {
         constexpr int W = 16 / (int)sizeof(TIO);
         typedef TIO VIO __attribute__((ext_vector_type(W)));
-        if (il != 1) {  // (interleaved inputs: entry i of the run at row[i * il])
-#pragma unroll
-            for (int i = 0; i < NV; i++) out[i] = i < n ? row[(size_t)i * il] : TIO(0);
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < NV; i += W) {
             if (i + W <= n) {
@@ -908,9 +904,7 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
             // h_packed: rows of the lower triangle back to back, as rnea_deriv_kernel writes them)
             const size_t lrow = lane < nv ? lane : 0;
             TIO hrow[NV];
-            // (state s of an interleaved workspace: sub-position s % il of group s / il, entries il apart)
-            const size_t sbase = (s / il) * nn * il + s % il;
-            read_row(H + sbase + (h_packed ? lrow * (lrow + 1) / 2 : lrow * nv) * il, nv, hrow);
+            read_row(H + s * nn + (h_packed ? lrow * (lrow + 1) / 2 : lrow * nv), nv, hrow);
 #pragma unroll
             for (int j = 0; j < NV; j++)
                 Lr[j] = (lane < nv && j < nv) ? ((j <= lane && ((rel_mine >> j) & 1)) ? (TC)hrow[j] : TC(0)) : (lane == j ? TC(1) : TC(0));
@@ -947,9 +941,8 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
                 dst[u] = nullptr;
                 jc[u] = 0;
                 scale[u] = 1;
-                const size_t sb = (s / il) * nn * il + s % il;
-                if (col < n1) { src[u] = P1 + sb; dst[u] = X1 + s * nn; jc[u] = col; scale[u] = -1; }
-                else if (col < n1 + n2) { src[u] = P2 + sb; dst[u] = X2 + s * nn; jc[u] = col - n1; scale[u] = -1; }
+                if (col < n1) { src[u] = P1 + s * nn; dst[u] = X1 + s * nn; jc[u] = col; scale[u] = -1; }
+                else if (col < n1 + n2) { src[u] = P2 + s * nn; dst[u] = X2 + s * nn; jc[u] = col - n1; scale[u] = -1; }
                 else if (col < n1 + n2 + n3) { dst[u] = Hinv + s * nn; jc[u] = col - n1 - n2; }
                 // column c of a packed right-hand side (rnea_deriv_kernel): the entries on and below the diagonal sit at
                 // r^2 + c of the runs r >= c (across lanes: consecutive addresses), the ones above it are the second half of
@@ -957,11 +950,11 @@ void spd_solve_kernel(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, 
                 const uint64_t rel = related ? related[jc[u]] : ~uint64_t(0);
                 if (src[u]) {
                     TIO urow[NV];
-                    read_row(src[u] + ((size_t)jc[u] * jc[u] + jc[u] + 1) * il, nv - 1, urow);
+                    read_row(src[u] + (size_t)jc[u] * jc[u] + jc[u] + 1, nv - 1, urow);
 #pragma unroll
                     for (int i = 0; i < NV; i++) {
                         const size_t r = i < nv ? i : 0;
-                        const TIO v = src[u][(r * r + (jc[u] <= (int)r ? jc[u] : 0)) * il];
+                        const TIO v = src[u][r * r + (jc[u] <= (int)r ? jc[u] : 0)];
                         x[i][u] = (i < nv && ((rel >> i) & 1)) ? (TC)(i < jc[u] ? urow[i] : v) : TC(0);
                     }
                 } else {
@@ -1357,7 +1350,7 @@ static hipError_t launch_spd_mfma(const float *H, int h_packed, int h_il, const 
 
 template <class TIO, class TC, int NV>
 static hipError_t launch_spd_solve_n(const TIO *H, int h_packed, const TIO *P1, const TIO *P2, TIO *Hinv, TIO *X1, TIO *X2,
-                                     const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream, int il = 1)
+                                     const uint64_t *related, int nv, size_t B, int grid, hipStream_t stream)
 {
     // two columns per lane: f32 arithmetic and more than one pass of 64 columns (register budget: 4 NV values per lane)
     const int ncols = (P1 ? nv : 0) + (P2 ? nv : 0) + (Hinv ? nv : 0);
@@ -1365,12 +1358,12 @@ static hipError_t launch_spd_solve_n(const TIO *H, int h_packed, const TIO *P1, 
     if constexpr (sizeof(TC) == 4 && NV == 40) {  // (measured: it pays for JVRC-1's 114 columns only)
         if (kc_env != 1 && (ncols > kWave || kc_env == 2)) {
             hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 2>), dim3(grid), dim3(kWave), 0, stream, H, h_packed, P1, P2, Hinv, X1, X2,
-                               related, nv, B, il);
+                               related, nv, B);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((spd_solve_kernel<TIO, TC, NV, 1>), dim3(grid), dim3(kWave), 0, stream, H, h_packed, P1, P2, Hinv, X1, X2, related, nv,
-                       B, il);
+                       B);
     return hipGetLastError();
 }
 // interleave: layout of H, P1, P2 -- 1 state-major, kDerivGroup the interleaved workspace of rnea_deriv_kernel (matrix-core kernel only)
@@ -1457,16 +1450,13 @@ hipError_t launch_spd_solve(const TIO *H, int h_packed, const TIO *P1, const TIO
         if (spd_solve_on_mfma(4, nv, (P1 ? 1 : 0) + (P2 ? 1 : 0)))
             return launch_spd_mfma(H, h_packed, interleave, P1, P2, interleave, Hinv, X1, X2, related, nv, B, grid, stream);
     }
-    // (the row-per-lane kernel reads interleaved inputs too -- the fp64 route since round 4; its results are state-major, so an interleaved
-    // H must not share memory with H^-1: capi.cpp keeps it in the workspace)
-    if (interleave != 1 && (reinterpret_cast<const void *>(H) == reinterpret_cast<const void *>(Hinv) || !h_packed)) return hipErrorInvalidValue;
-    const int il = interleave;
-    if (nv <= 16) return launch_spd_solve_n<TIO, TC, 16>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream, il);
-    if (nv <= 24) return launch_spd_solve_n<TIO, TC, 24>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream, il);
-    if (nv <= 32) return launch_spd_solve_n<TIO, TC, 32>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream, il);
-    if (nv <= 40) return launch_spd_solve_n<TIO, TC, 40>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream, il);
-    if (nv <= 48) return launch_spd_solve_n<TIO, TC, 48>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream, il);
-    if (nv <= 64) return launch_spd_solve_n<TIO, TC, 64>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream, il);
+    if (interleave != 1) return hipErrorInvalidValue;
+    if (nv <= 16) return launch_spd_solve_n<TIO, TC, 16>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 24) return launch_spd_solve_n<TIO, TC, 24>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 32) return launch_spd_solve_n<TIO, TC, 32>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 40) return launch_spd_solve_n<TIO, TC, 40>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 48) return launch_spd_solve_n<TIO, TC, 48>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
+    if (nv <= 64) return launch_spd_solve_n<TIO, TC, 64>(H, h_packed, P1, P2, Hinv, X1, X2, related, nv, B, grid, stream);
     return hipErrorInvalidValue;
 }
 template hipError_t launch_spd_solve<float, float>(const float *, int, const float *, const float *, float *, float *, float *, const uint64_t *,
