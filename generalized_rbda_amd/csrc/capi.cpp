@@ -826,12 +826,20 @@ int state_convert(const grbda_plan *p, const uint8_t *pos_sp, const uint8_t *vel
     if (!p) return set_err(GRBDA_EINVAL, "null plan");
     GRBDA_CALL_SCOPE(p);
     if (!q_in || (qd && !qd_in)) return set_err(GRBDA_EINVAL, "null argument");
-    if (p->host.big_clusters)
-        return set_err(GRBDA_EUNSUPPORTED, "state conversion is not covered for clusters beyond the structured kernels' limits");
     StateFlags F;
     int in_nq = 0, in_nv = 0;
     if (int rc = state_widths(p, pos_sp, vel_sp, &F, &in_nq, &in_nv)) return rc;
     if (B == 0) return GRBDA_OK;
+    if (p->host.big_clusters) {  // (clusters beyond the structured limits: the same rules in manifold_kernels.hip's wide state kernel)
+        DeviceTables *t = nullptr;
+        if (int rc = ensure_device(p, device, &t)) return rc;
+        DevPlan<T> dp = make_dev_plan<T>(p, *t, false, false);
+        size_t g = static_cast<size_t>(t->n_cu) * 4;
+        if (g > (B + kWave - 1) / kWave) g = (B + kWave - 1) / kWave;
+        hipError_t e = launch_manifold_state<T>(dp, p->host.n_clusters, F, q_in, qd_in, in_nq, in_nv, q, qd, status, cond, B, static_cast<T>(tol),
+                                                static_cast<int>(g), static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? GRBDA_OK : hip_err(e, "state conversion launch");
+    }
     DevPlan<T> d;
     T *scratch = nullptr;
     int grid = 0;

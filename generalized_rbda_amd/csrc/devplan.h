@@ -203,6 +203,9 @@ hipError_t launch_manifold_project_wide(const DevPlan<T> &P, int n_clusters, con
                                         const uint64_t *rel_s, const int32_t *relt, const int32_t *relt_s, int nv_s, int n_cpl_rows, const T *Hs,
                                         const T *cpl, T *H, size_t B, int grid, hipStream_t stream);
 template <class T>
+hipError_t launch_manifold_state(const DevPlan<T> &P, int n_clusters, const StateFlags &F, const T *q_in, const T *qd_in, int in_nq, int in_nv,
+                                 T *q_out, T *qd_out, int32_t *status, T *cond, size_t B, T tol, int grid, hipStream_t stream);
+template <class T>
 hipError_t launch_manifold_newton(const DevPlan<T> &P, int n_clusters, T *q, int32_t *ok, size_t B, int max_iter, T tol, int grid, hipStream_t stream);
 template <class T>
 hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream);

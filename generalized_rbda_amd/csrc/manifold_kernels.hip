@@ -908,6 +908,162 @@ template hipError_t launch_manifold_newton<float>(const DevPlan<float> &, int, f
 template hipError_t launch_manifold_newton<double>(const DevPlan<double> &, int, double *, int32_t *, size_t, int, double, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------------------
+// Kernel 6: state input in the reference's conventions for plans with clusters beyond the structured limits -- the rules of kernels.hip's
+// state_kernel (ClusterJoints::Base::toSpanningTreeState, ClusterJoint.cpp:22-71; LoopConstraint.cpp:15-26): per cluster the caller's
+// positions / velocities are independent or SPANNING coordinates (flags F); explicit clusters: y = G+ q_span, yd = G+ qd_span, spanning
+// velocities valid iff |K qd_span| < tol; implicit (position-loop) clusters: spanning positions, valid iff |phi(q)| < tol, spanning
+// velocities valid iff |K qd_span| < tol and yd = their independent entries.  status[b] = 0 or (1 position / 2 velocity) + 256 cluster of
+// the first failure; cond[b] = (max |Kd^-1 Ki|, max |Kd|_F |Kd^-1|_F) over the implicit clusters.  One state per lane.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kWave, 1) void manifold_state_kernel(DevPlan<T> DP, int n_clusters, StateFlags F, const T *__restrict__ q_in,
+                                                                const T *__restrict__ qd_in, int in_nq, int in_nv, T *__restrict__ q_out,
+                                                                T *__restrict__ qd_out, int32_t *__restrict__ status, T *__restrict__ cond,
+                                                                size_t B, T tol)
+{
+    constexpr int KB = kBigClusterBodies;
+    cptr<ClusterRec> clusters = (cptr<ClusterRec>)DP.clusters;
+    cptr<BodyRec> bodies = (cptr<BodyRec>)DP.bodies;
+    cptr<T> consts = (cptr<T>)DP.consts;
+    cptr<int32_t> cints = (cptr<int32_t>)DP.cints;
+    const int lane = threadIdx.x, nq = DP.nq, nv = DP.nv;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t r0 = tile * kWave + lane;
+        const bool write = r0 < B;
+        const size_t row = write ? r0 : B - 1;
+        const T *qi = q_in + row * (size_t)in_nq;
+        const T *vi = qd_in ? qd_in + row * (size_t)in_nv : nullptr;
+        T *qo = q_out ? q_out + row * (size_t)nq : nullptr;
+        T *vo = qd_out ? qd_out + row * (size_t)nv : nullptr;
+        int st = 0;
+        T gm = 0, kc = 0;
+        for (int ci = 0; ci < n_clusters; ci++) {
+            const ClusterRec c = load_rec(clusters + ci);
+            const bool ps = (F.pos[ci >> 6] >> (ci & 63)) & 1, vs = (F.vel[ci >> 6] >> (ci & 63)) & 1;
+            T *qoc = qo ? qo + c.q_index : nullptr, *voc = vo ? vo + c.v_index : nullptr;
+            if (c.kind == CK_FREE) {
+                const int npos = DP.ori_repr == 0 ? 7 : 6;
+                if (qoc && write)
+                    for (int j = 0; j < npos; j++) qoc[j] = qi[j];
+                if (vi && voc && write)
+                    for (int j = 0; j < 6; j++) voc[j] = vi[j];
+                qi += npos;
+                if (vi) vi += 6;
+            } else if (c.kind == CK_LOOP) {
+                const int k = c.k, n = c.n, rows = c.rows;
+                cptr<int32_t> ip = cints + c.iofs;
+                const int hdr0 = ip[0], n_ind = ip[1];
+                cptr<int32_t> ind = ip + 2, dep = ip + 3 + n_ind, payload = ip + 3 + n_ind + rows;
+                T sn[KB], cs[KB], zero[KB], K[kMR][KB], kap[kMR], phi[kMR];
+                for (int j = 0; j < KB; j++) zero[j] = 0;
+                for (int r = 0; r < kMR; r++) {
+                    kap[r] = phi[r] = 0;
+                    for (int j = 0; j < KB; j++) K[r][j] = 0;
+                }
+                for (int i = 0; i < k; i++) {
+                    const T v = qi[i];
+                    sincos_precise(v, &sn[i], &cs[i]);
+                    if (qoc && write) qoc[i] = v;
+                }
+                if (c.cons_type == 0) loop_position_eval<T, T, KB>(consts, bodies, c, payload, hdr0, sn, cs, zero, true, K, kap, phi);
+                else if (st == 0) st = 1 + 256 * ci;  // (trig-polynomial constraints: structured plans only)
+                T n2 = 0;
+                for (int r = 0; r < rows; r++) n2 += phi[r] * phi[r];
+                if (!((T)__builtin_sqrt((double)n2) < tol) && st == 0) st = 1 + 256 * ci;
+                if (vi) {
+                    if (vs) {
+                        T s2 = 0;
+                        for (int r = 0; r < rows; r++) {
+                            T sacc = 0;
+                            for (int i = 0; i < k; i++) sacc += K[r][i] * vi[i];
+                            s2 += sacc * sacc;
+                        }
+                        if (!((T)__builtin_sqrt((double)s2) < tol) && st == 0) st = 2 + 256 * ci;
+                    }
+                    for (int a = 0; a < n; a++) {
+                        const T v = vi[vs ? ind[a] : a];
+                        if (voc && write) voc[a] = v;
+                    }
+                }
+                T Kd[kMR][kMR], Kdi[kMR][kMR];
+                for (int r = 0; r < kMR; r++)
+                    for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
+                inv_rows(rows, Kd, Kdi);
+                T f1 = 0, f2 = 0;
+                for (int r = 0; r < rows; r++)
+                    for (int j = 0; j < rows; j++) {
+                        f1 += Kd[r][j] * Kd[r][j];
+                        f2 += Kdi[r][j] * Kdi[r][j];
+                    }
+                const T cn = (T)__builtin_sqrt((double)(f1 * f2));
+                kc = (cn > kc || cn != cn) ? cn : kc;
+                for (int r = 0; r < rows; r++)
+                    for (int a = 0; a < n; a++) {
+                        T x = 0;
+                        for (int j = 0; j < rows; j++) x += Kdi[r][j] * K[j][ind[a]];
+                        x = x < 0 ? -x : x;
+                        gm = (x > gm || x != x) ? x : gm;  // (NaN of a singular Kd sticks)
+                    }
+                qi += k;
+                if (vi) vi += vs ? k : n;
+            } else {  // explicit: consts[dofs] = K (rows x k), then G+ (n x k)  (plan.cpp)
+                cptr<T> Kc = consts + c.dofs;
+                cptr<T> Gp = Kc + c.rows * c.k;
+                for (int a = 0; a < c.n; a++) {
+                    T y = 0;
+                    if (ps) {
+                        for (int i = 0; i < c.k; i++) y += Gp[a * c.k + i] * qi[i];
+                    } else {
+                        y = qi[a];
+                    }
+                    if (qoc && write) qoc[a] = y;
+                }
+                qi += ps ? c.k : c.n;
+                if (vi) {
+                    if (vs) {
+                        T s2 = 0;
+                        for (int rr = 0; rr < c.rows; rr++) {
+                            T sacc = 0;
+                            for (int i = 0; i < c.k; i++) sacc += Kc[rr * c.k + i] * vi[i];
+                            s2 += sacc * sacc;
+                        }
+                        if (!((T)__builtin_sqrt((double)s2) < tol) && st == 0) st = 2 + 256 * ci;
+                    }
+                    for (int a = 0; a < c.n; a++) {
+                        T y = 0;
+                        if (vs) {
+                            for (int i = 0; i < c.k; i++) y += Gp[a * c.k + i] * vi[i];
+                        } else {
+                            y = vi[a];
+                        }
+                        if (voc && write) voc[a] = y;
+                    }
+                    vi += vs ? c.k : c.n;
+                }
+            }
+        }
+        if (status && write) status[r0] = st;
+        if (cond && write) {
+            cond[2 * r0] = gm;
+            cond[2 * r0 + 1] = kc;
+        }
+    }
+}
+template <class T>
+hipError_t launch_manifold_state(const DevPlan<T> &P, int n_clusters, const StateFlags &F, const T *q_in, const T *qd_in, int in_nq, int in_nv,
+                                 T *q_out, T *qd_out, int32_t *status, T *cond, size_t B, T tol, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((manifold_state_kernel<T>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, F, q_in, qd_in, in_nq, in_nv, q_out, qd_out,
+                       status, cond, B, tol);
+    return hipGetLastError();
+}
+template hipError_t launch_manifold_state<float>(const DevPlan<float> &, int, const StateFlags &, const float *, const float *, int, int, float *,
+                                                 float *, int32_t *, float *, size_t, float, int, hipStream_t);
+template hipError_t launch_manifold_state<double>(const DevPlan<double> &, int, const StateFlags &, const double *, const double *, int, int,
+                                                  double *, double *, int32_t *, double *, size_t, double, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
 // Kernel 4: y = H^-1 b for up to 128 velocities, one state per WORKGROUP of four wavefronts (the wide route beyond the 64 coordinates of
 // deriv_kernels.hip's row-per-lane solves).  H: packed lower rows [B][nv^2] as kernel 2w leaves them, structural zeros (never
 // written) masked by the nv x nv table; the factor L (H = L L^T) replaces it in LDS, then two substitutions on the one right-hand side.

@@ -306,10 +306,83 @@ static int spanningStates()
     return diff < 1e-9 && threw ? 0 : 1;
 }
 
+// The same through a model of the reference's parallel-chain benchmark family (Benchmarking/urdfs/parallel_chains; here one cluster of 12
+// bodies / 11 independent coordinates): the class API, setState(ModelState) with spanning joint states -- the call the reference's
+// benchmark makes (pinocchioBenchmark.cpp:160-168) --, forward dynamics, ID(FD(tau)) = tau.  Such clusters run through the spanning tree
+// (DESIGN 7c); the facade must not notice.
+static int bigClusterStates(const std::string &urdf)
+{
+    // the explicit parallel chain of depth 6 and loop size 12, hand-built as the reference's URDF+ parser would cluster it: twelve bodies in
+    // ONE Generic cluster (joint_2_6 coupled to joint_1_6 with ratio 1: eleven independent coordinates), through the class API; `urdf`
+    // (the reference's own depth-10 file) is only read to check that the URDF route gives a model of the expected size
+    using namespace ClusterJoints;
+    {
+        ClusterTreeModel<double> u;
+        u.buildModelFromURDF(urdf);
+        if (u.getNumBodies() != 20 || u.getNumDegreesOfFreedom() != 19) return 1;
+    }
+    const int depth = 6, k = 2 * depth, n = k - 1;
+    const Mat3<double> I3 = Mat3<double>::Identity();
+    Mat3<double> Ic = Mat3<double>::Zero();
+    Ic(0, 0) = 0.01; Ic(1, 1) = 0.1; Ic(2, 2) = 0.01;
+    const SpatialInertia<double> link(0.25, Vec3<double>{0., 0.5, 0.}, Ic);
+    ClusterTreeModel<double> m;
+    std::vector<Body<double>> bodies;
+    std::vector<JointPtr<double>> joints;
+    for (int i = 1; i <= depth; i++)
+        for (int chain = 1; chain <= 2; chain++) {
+            const std::string name = "link_" + std::to_string(chain) + "_" + std::to_string(i);
+            const std::string parent = i == 1 ? "ground" : "link_" + std::to_string(chain) + "_" + std::to_string(i - 1);
+            const Vec3<double> r = i == 1 ? Vec3<double>::Zero() : Vec3<double>{0., 1., 0.};
+            bodies.push_back(m.registerBody(name, link, parent, spatial::Transform<double>(I3, r)));
+            joints.emplace_back(new Joints::Revolute<double>(ori::CoordinateAxis::Z, "joint_" + std::to_string(chain) + "_" + std::to_string(i)));
+        }
+    // independent: every joint but the last one of chain 2 (body index k - 1), which follows the last one of chain 1 (k - 2)
+    DMat<double> G = DMat<double>::Zero(k, n), K = DMat<double>::Zero(1, k);
+    for (int i = 0; i < n; i++) G(i, i) = 1.0;
+    G(k - 1, k - 2) = 1.0;
+    K(0, k - 2) = 1.0;
+    K(0, k - 1) = -1.0;
+    m.appendRegisteredBodiesAsCluster<Generic<double>>("loop", bodies, joints, std::make_shared<LoopConstraint::Static<double>>(G, K));
+    const int nv = m.getNumDegreesOfFreedom();
+    int biggest = 0;
+    for (const auto &cluster : m.clusters()) biggest = std::max(biggest, static_cast<int>(cluster->bodies_.size()));
+    const DVec<double> tau = DVec<double>::Random(nv);
+    ModelState<double> independent, spanning;
+    for (const auto &cluster : m.clusters()) {
+        const auto &joint = cluster->joint_;
+        DVec<double> y = DVec<double>::Random(joint->numPositions());
+        const DVec<double> yd = DVec<double>::Random(joint->numVelocities());
+        for (int j = 0; j < static_cast<int>(y.size()); j++) y[j] *= 0.5;
+        const DMat<double> &G = joint->G();
+        DVec<double> qs = DVec<double>::Zero(G.rows()), vs = DVec<double>::Zero(G.rows());
+        for (int i = 0; i < G.rows(); i++)
+            for (int j = 0; j < G.cols(); j++) {
+                qs[i] += G(i, j) * y[j];
+                vs[i] += G(i, j) * yd[j];
+            }
+        independent.emplace_back(JointCoordinate<double>(y, false), JointCoordinate<double>(yd, false));
+        spanning.emplace_back(JointCoordinate<double>(qs, true), JointCoordinate<double>(vs, true));
+    }
+    m.setState(independent);
+    const DVec<double> a = m.forwardDynamics(tau);
+    const DVec<double> back = m.inverseDynamics(a);
+    m.setState(spanning);
+    const DVec<double> b = m.forwardDynamics(tau);
+    const double diff = (a - b).norm(), rt = (back - tau).norm();
+    std::printf("big cluster (%d bodies, model nv %d): spanning vs independent |dydd| = %.3e, |ID(FD(tau)) - tau| = %.3e\n", biggest, nv, diff, rt);
+    return biggest > 8 && diff < 1e-9 && rt < 1e-8 ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "";
     try {
+        if (mode == "--big" && argc > 2) {
+            const int rc = bigClusterStates(argv[2]);
+            std::printf(rc ? "FAILED\n" : "OK\n");
+            return rc;
+        }
         if (mode == "--dump" && argc > 2) {
             const std::string dir = argv[2];
             { ClusterTreeModel<double> m; buildRevoluteChainWithRotor<2>(m); dump(dir + "/rev2.grbd", m.serialize()); }

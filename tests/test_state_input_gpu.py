@@ -90,3 +90,47 @@ def test_constraint_gain_matches_oracle(name, gpu):
     assert int(status.abs().sum().item()) == 0
     assert np.abs(gmax.cpu().numpy() - gm).max() <= 1e-8 * (1 + gm.max())
     assert (np.abs(kcond.cpu().numpy() - kc) / kc).max() <= 1e-7
+
+
+@pytest.mark.parametrize("name,implicit_model", [("parallel_chain_exp_d10_l16", False), ("parallel_chain_imp_d10_l17", True)])
+def test_state_input_of_plans_with_big_clusters(name, implicit_model, gpu):
+    """The same conventions for the reference's depth-10 parallel chains (a cluster of 16 / 17 bodies: the wide state kernel of
+    manifold_kernels.hip) -- what ClusterTreeModel::setState(ModelState) of the facade goes through for such models: spanning,
+    engine and mixed inputs give the engine's state back, invalid spanning velocities / positions get the reference's status codes,
+    and the conditioning measures match the oracle's."""
+    import os
+    import torch
+    from models import ROBOT_MODELS
+
+    plan = G.Plan.from_urdf(os.path.join(ROBOT_MODELS, name + ".urdf"))
+    blob = plan.blob
+    m = parse_clusters(blob)
+    q, qd, tau = valid_states(blob, 70, config_index=11, big=True, scale=0.5, max_cond=50)
+    qs, vs, gm, kc = O.spanning_state(blob, q, qd, big=True)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=gpu)
+    implicit = [cl[9] in (C_LOOP_POSITION, C_TRIG_POLY) for cl in m["clusters"]]
+    nc = len(m["clusters"])
+    for pos_sp, vel_sp in (([True] * nc, [True] * nc), (implicit, [False] * nc),
+                           ([imp or c % 2 == 0 for c, imp in enumerate(implicit)], [c % 3 != 0 for c in range(nc)])):
+        q_in, qd_in = _rows(m, q, qd, qs, vs, pos_sp, vel_sp)
+        assert plan.state_input_dims(pos_sp, vel_sp) == (q_in.shape[1], qd_in.shape[1])
+        q2, qd2, status = plan.state_to_independent(t(q_in), t(qd_in), pos_sp, vel_sp, tol=1e-8)
+        assert int(status.abs().sum().item()) == 0
+        assert np.abs(q2.cpu().numpy() - q).max() < 1e-12 and np.abs(qd2.cpu().numpy() - qd).max() < 1e-11
+    c = 0  # the big cluster comes first (both chains hang off the ground)
+    assert m["clusters"][c][2] >= 16
+    q_in, qd_in = _rows(m, q, qd, qs, vs, [True] * nc, [True] * nc)
+    bad = qd_in.copy()
+    bad[3, 0] += 1e-3
+    _, _, status = plan.state_to_independent(t(q_in), t(bad), [True] * nc, [True] * nc)
+    st = status.cpu().numpy()
+    assert st[3] == 2 + 256 * c and (np.delete(st, 3) == 0).all()
+    if implicit_model:
+        bad = q_in.copy()
+        bad[1, m["clusters"][c][7] - 1] += 1e-3
+        _, _, status = plan.state_to_independent(t(bad), t(qd_in), [True] * nc, [True] * nc)
+        assert status.cpu().numpy()[1] == 1 + 256 * c
+        gmax, kcond, status = plan.constraint_gain(t(q))
+        assert int(status.abs().sum().item()) == 0
+        assert np.abs(gmax.cpu().numpy() - gm).max() <= 1e-8 * (1 + gm.max())
+        assert (np.abs(kcond.cpu().numpy() - kc) / kc).max() <= 1e-7
