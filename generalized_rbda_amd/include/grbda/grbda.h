@@ -672,6 +672,20 @@ public:
         }
     }
 };
+// A cluster joint of a model read from URDF+: sizes, single joints and loop constraint as the reader formed them (ClusterTreeParsing.cpp:
+// 232-440) -- what clusters()[i]->joint_ is for such a model (numPositions(), numVelocities(), G(), K(), randomJointState()).
+template <typename Scalar = double>
+class Described : public Base<Scalar> {
+public:
+    Described(int n_bodies, int n_positions, int n_velocities, const std::vector<JointPtr<Scalar>> &joints,
+              std::shared_ptr<LoopConstraint::Base<Scalar>> loop_constraint)
+        : Base<Scalar>(n_bodies, n_positions, n_velocities)
+    {
+        this->single_joints_ = joints;
+        this->ordered_joints_ = joints;
+        this->loop_constraint_ = loop_constraint;
+    }
+};
 // ClusterJoints::FourBar (FourBarJoint.h:57-77)
 template <typename Scalar = double>
 class FourBar : public Generic<Scalar> {
@@ -746,10 +760,91 @@ public:
                            4u * static_cast<size_t>(h->n_ints + (h->n_ints & 1)) + 8u * static_cast<size_t>(h->n_doubles);
         const char *names = reinterpret_cast<const char *>(urdf_blob_.data()) + off;
         const char *end = names + h->n_name_bytes;
+        std::vector<std::string> body_names, cluster_names;
         for (int b = 0; b < h->n_bodies && names < end; b++) {
             const std::string nm(names);
             body_name_to_body_index_[nm] = b;
+            body_names.push_back(nm);
             names += nm.size() + 1;
+        }
+        for (int c = 0; c < h->n_clusters && names < end; c++) {
+            cluster_names.emplace_back(names);
+            names += cluster_names.back().size() + 1;
+        }
+        // bodies() / clusters() of the model as read (the reference's callers walk them: joint sizes, G, random joint states --
+        // Benchmarking/src/pinocchioBenchmark.cpp:150-168).  The dynamics keep running on the description itself.
+        const auto *db = reinterpret_cast<const grbda_desc_body *>(urdf_blob_.data() + sizeof(grbda_desc_header));
+        const auto *dc = reinterpret_cast<const grbda_desc_cluster *>(db + h->n_bodies);
+        const auto *ints = reinterpret_cast<const int32_t *>(dc + h->n_clusters);
+        const auto *dbls = reinterpret_cast<const double *>(ints + (h->n_ints + (h->n_ints & 1)));
+        bodies_.clear();
+        cluster_nodes_.clear();
+        body_index_to_cluster_index_.clear();
+        for (int b = 0; b < h->n_bodies; b++) {
+            Body<Scalar> body;
+            body.index_ = b;
+            body.name_ = b < static_cast<int>(body_names.size()) ? body_names[b] : "body_" + std::to_string(b);
+            body.parent_index_ = db[b].parent;
+            Mat3<Scalar> E;
+            Vec3<Scalar> r;
+            for (int i = 0; i < 3; i++) {
+                r[i] = static_cast<Scalar>(db[b].Xtree_r[i]);
+                for (int j = 0; j < 3; j++) E(i, j) = static_cast<Scalar>(db[b].Xtree_E[3 * i + j]);
+            }
+            body.Xtree_ = spatial::Transform<Scalar>(E, r);
+            Mat6<Scalar> I;
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) I(i, j) = static_cast<Scalar>(db[b].inertia[6 * i + j]);
+            body.inertia_ = SpatialInertia<Scalar>(I);
+            body.sub_index_within_cluster_ = db[b].sub_index;
+            int anc = db[b].parent;
+            const int first = dc[db[b].cluster].first_body;
+            while (anc >= first) anc = db[anc].parent;
+            body.cluster_ancestor_index_ = anc;
+            body.cluster_ancestor_sub_index_within_cluster_ = anc >= 0 ? db[anc].sub_index : 0;
+            bodies_.push_back(body);
+            body_index_to_cluster_index_[b] = db[b].cluster;
+        }
+        for (int c = 0; c < h->n_clusters; c++) {
+            const grbda_desc_cluster &cl = dc[c];
+            auto node = std::make_shared<ClusterTreeNode<Scalar>>();
+            node->index_ = c;
+            node->name_ = c < static_cast<int>(cluster_names.size()) ? cluster_names[c] : "cluster_" + std::to_string(c);
+            std::vector<JointPtr<Scalar>> joints;
+            for (int i = 0; i < cl.n_bodies; i++) {
+                const grbda_desc_body &bd = db[cl.first_body + i];
+                node->bodies_.push_back(bodies_[cl.first_body + i]);
+                if (bd.joint_type == GRBDA_JOINT_FREE) joints.emplace_back(new Joints::Free<Scalar, OriTpl>());
+                else joints.emplace_back(new Joints::Revolute<Scalar>(static_cast<ori::CoordinateAxis>(bd.axis)));
+            }
+            std::shared_ptr<LoopConstraint::Base<Scalar>> lc;
+            if (cl.constraint_type == GRBDA_CONSTRAINT_FREE) {
+                lc = std::make_shared<LoopConstraint::Free<Scalar>>();
+            } else if (cl.constraint_type == GRBDA_CONSTRAINT_STATIC) {
+                const int k = cl.n_span_vel, n = cl.n_vel, rows = cl.n_constraint_rows;
+                DMat<Scalar> Gm = DMat<Scalar>::Zero(k, n), Km = DMat<Scalar>::Zero(rows, k);
+                for (int i = 0; i < k; i++)
+                    for (int j = 0; j < n; j++) Gm(i, j) = static_cast<Scalar>(dbls[cl.dbl_offset + i * n + j]);
+                if (cl.n_dbl >= k * n + rows * k)
+                    for (int i = 0; i < rows; i++)
+                        for (int j = 0; j < k; j++) Km(i, j) = static_cast<Scalar>(dbls[cl.dbl_offset + k * n + i * k + j]);
+                lc = std::make_shared<LoopConstraint::Static<Scalar>>(Gm, Km);
+            } else {  // implicit: the description's payload (G and K depend on the state)
+                lc = std::make_shared<LoopConstraint::Base<Scalar>>();
+                lc->kind = cl.constraint_type;
+                lc->rows = cl.n_constraint_rows;
+                lc->ints.assign(ints + cl.int_offset, ints + cl.int_offset + cl.n_int);
+                lc->dbls.assign(dbls + cl.dbl_offset, dbls + cl.dbl_offset + cl.n_dbl);
+                const int32_t *flags = cl.constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION ? lc->ints.data() + 1 : lc->ints.data();
+                for (int i = 0; i < cl.n_bodies; i++) lc->independent.push_back(flags[i] != 0);
+            }
+            node->joint_ = std::make_shared<ClusterJoints::Described<Scalar>>(cl.n_bodies, cl.n_pos, cl.n_vel, joints, lc);
+            node->parent_index_ = cl.parent_cluster;
+            node->position_index_ = cl.q_index;
+            node->num_positions_ = cl.n_pos;
+            node->velocity_index_ = cl.v_index;
+            node->num_velocities_ = cl.n_vel;
+            cluster_nodes_.push_back(node);
         }
     }
 

@@ -317,9 +317,40 @@ static int bigClusterStates(const std::string &urdf)
     // (the reference's own depth-10 file) is only read to check that the URDF route gives a model of the expected size
     using namespace ClusterJoints;
     {
+        // the URDF route: clusters() of the model as read -- sizes, G of the 16-body cluster, random joint states as the reference's
+        // benchmark draws them, spanning against independent joint states
         ClusterTreeModel<double> u;
         u.buildModelFromURDF(urdf);
-        if (u.getNumBodies() != 20 || u.getNumDegreesOfFreedom() != 19) return 1;
+        if (u.getNumBodies() != 20 || u.getNumDegreesOfFreedom() != 19 || u.clusters().size() != 5 || u.bodies().size() != 20) return 1;
+        int np = 0, nvv = 0, big = 0;
+        ModelState<double> ind, span;
+        for (const auto &cluster : u.clusters()) {
+            const auto &joint = cluster->joint_;
+            np += joint->numPositions();
+            nvv += joint->numVelocities();
+            big = std::max(big, static_cast<int>(cluster->bodies_.size()));
+            JointState<double> js = joint->randomJointState();
+            for (int j = 0; j < static_cast<int>(js.position.size()); j++) js.position[j] *= 0.5;
+            const DMat<double> &G = joint->G();
+            if (G.rows() != static_cast<int>(cluster->bodies_.size()) || G.cols() != joint->numVelocities()) return 1;
+            DVec<double> qs = DVec<double>::Zero(G.rows()), vs = DVec<double>::Zero(G.rows());
+            for (int i = 0; i < G.rows(); i++)
+                for (int j = 0; j < G.cols(); j++) {
+                    qs[i] += G(i, j) * js.position[j];
+                    vs[i] += G(i, j) * js.velocity[j];
+                }
+            ind.push_back(js);
+            span.emplace_back(JointCoordinate<double>(qs, true), JointCoordinate<double>(vs, true));
+        }
+        if (np != u.getNumPositions() || nvv != 19 || big != 16 || u.body("link_2_8").parent_index_ != u.body("link_2_7").index_) return 1;
+        const DVec<double> tau_u = DVec<double>::Random(19);
+        u.setState(ind);
+        const DVec<double> a_u = u.forwardDynamics(tau_u);
+        u.setState(span);
+        const DVec<double> b_u = u.forwardDynamics(tau_u);
+        std::printf("URDF-built parallel chain: clusters() %zu, biggest %d bodies, spanning vs independent |dydd| = %.3e\n", u.clusters().size(), big,
+                    (a_u - b_u).norm());
+        if (!((a_u - b_u).norm() < 1e-9)) return 1;
     }
     const int depth = 6, k = 2 * depth, n = k - 1;
     const Mat3<double> I3 = Mat3<double>::Identity();
