@@ -34,7 +34,7 @@ C_ABI_SYMBOLS = [
     "grbda_mass_matrix_host_f64", "grbda_fd_derivatives_host_f64",
     "grbda_body_twists_f64", "grbda_body_twists_f32", "grbda_body_twists_host_f64",
     "grbda_state_input_dims", "grbda_state_to_independent_f64", "grbda_state_to_independent_f32",
-    "grbda_state_to_independent_host_f64", "grbda_spd_bad_pivots", "grbda_kernel_name",
+    "grbda_state_to_independent_host_f64", "grbda_spd_bad_pivots", "grbda_kernel_name", "grbda_project_positions_host_f64",
 ]
 
 

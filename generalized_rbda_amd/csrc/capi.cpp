@@ -2537,6 +2537,23 @@ int grbda_project_positions_f32(const grbda_plan *p, float *q, int32_t *ok, size
 {
     return project<float>(p, q, ok, B, max_iter, tol, device, stream);
 }
+int grbda_project_positions_host_f64(const grbda_plan *p, double *q, int32_t *ok, size_t B, int max_iter, double tol, int device)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    if (!q) return set_err(GRBDA_EINVAL, "null argument");
+    if (B == 0) return GRBDA_OK;
+    DeviceTables *t = nullptr;
+    if (int rc = ensure_device(p, device, &t)) return rc;
+    const size_t nq = p->host.nq;
+    DevBuf dq, dok;
+    int rc;
+    if ((rc = dq.alloc(B * nq * 8)) || (rc = dok.alloc(B * sizeof(int32_t))) || (rc = dq.put(q, B * nq * 8))) return rc;
+    if ((rc = project<double>(p, static_cast<double *>(dq.p), static_cast<int32_t *>(dok.p), B, max_iter, tol, device, nullptr))) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(GRBDA_EHIP, "kernel execution");
+    if ((rc = dq.get(q, B * nq * 8))) return rc;
+    return ok ? dok.get(ok, B * sizeof(int32_t)) : GRBDA_OK;
+}
 int grbda_state_input_dims(const grbda_plan *p, const uint8_t *pos_is_spanning, const uint8_t *vel_is_spanning, int *in_nq, int *in_nv)
 {
     if (!p) return set_err(GRBDA_EINVAL, "null plan");

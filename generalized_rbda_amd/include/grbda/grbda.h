@@ -20,6 +20,7 @@
 #include <array>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -529,7 +530,7 @@ public:
     std::shared_ptr<LoopConstraint::Base<Scalar>> cloneLoopConstraint() const { return loop_constraint_; }
     const std::vector<JointPtr<Scalar>> &singleJoints() const { return single_joints_; }
     // ClusterJoint.cpp:73-80
-    JointState<double> randomJointState() const
+    virtual JointState<double> randomJointState() const
     {
         return JointState<double>(JointCoordinate<double>(DVec<double>::Random(num_positions_), false),
                                   JointCoordinate<double>(DVec<double>::Random(num_velocities_), false));
@@ -685,6 +686,14 @@ public:
         this->ordered_joints_ = joints;
         this->loop_constraint_ = loop_constraint;
     }
+    // implicit clusters: spanning positions on the constraint manifold (GenericJoint.cpp:289-361: independent coordinates U(-1, 1), a
+    // dependent guess U(-0.1, 0.1), Newton, up to 45 draws) -- the model that read the description installs the root finder
+    std::function<JointCoordinate<double>()> find_roots_for_phi_;
+    JointState<double> randomJointState() const override
+    {
+        if (!find_roots_for_phi_) return Base<Scalar>::randomJointState();
+        return JointState<double>(find_roots_for_phi_(), JointCoordinate<double>(DVec<double>::Random(this->num_velocities_), false));
+    }
 };
 // ClusterJoints::FourBar (FourBarJoint.h:57-77)
 template <typename Scalar = double>
@@ -838,7 +847,29 @@ public:
                 const int32_t *flags = cl.constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION ? lc->ints.data() + 1 : lc->ints.data();
                 for (int i = 0; i < cl.n_bodies; i++) lc->independent.push_back(flags[i] != 0);
             }
-            node->joint_ = std::make_shared<ClusterJoints::Described<Scalar>>(cl.n_bodies, cl.n_pos, cl.n_vel, joints, lc);
+            auto described = std::make_shared<ClusterJoints::Described<Scalar>>(cl.n_bodies, cl.n_pos, cl.n_vel, joints, lc);
+            if (cl.constraint_type != GRBDA_CONSTRAINT_FREE && cl.constraint_type != GRBDA_CONSTRAINT_STATIC) {
+                const int q0 = cl.q_index, k = cl.n_bodies, nq_all = h->nq;
+                const std::vector<bool> indep = lc->independent;
+                described->find_roots_for_phi_ = [this, q0, k, nq_all, indep]() {
+                    // the other clusters rest at zero (a free base at the identity quaternion): constraints never couple clusters
+                    for (int attempt = 0; attempt < 45; attempt++) {
+                        std::vector<double> q(nq_all, 0.0);
+                        if (OriTpl::desc_id == GRBDA_ORI_QUATERNION && nq_all >= 7 && !cluster_nodes_.empty() &&
+                            cluster_nodes_.front()->num_velocities_ == 6 && cluster_nodes_.front()->num_positions_ == 7)
+                            q[3] = 1.0;
+                        const DVec<double> r = DVec<double>::Random(k);
+                        for (int i = 0; i < k; i++) q[q0 + i] = indep[i] ? r[i] : 0.1 * r[i];
+                        int32_t ok = 0;
+                        check(grbda_project_positions_host_f64(plan(), q.data(), &ok, 1, 50, 1e-8, 0));
+                        // (ok covers every implicit cluster of the model: the others sit at zero, which is on their manifold for the
+                        // linkages of the reference's URDFs; a model where it is not keeps drawing and then reports the failure)
+                        if (ok) return JointCoordinate<double>(DVec<double>(q.begin() + q0, q.begin() + q0 + k), true);
+                    }
+                    throw std::runtime_error("Failed to find valid roots for implicit loop constraint");
+                };
+            }
+            node->joint_ = described;
             node->parent_index_ = cl.parent_cluster;
             node->position_index_ = cl.q_index;
             node->num_positions_ = cl.n_pos;

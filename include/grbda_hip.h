@@ -220,6 +220,10 @@ int grbda_project_positions_f64(const grbda_plan *plan, double *q, int32_t *ok, 
                                 int device, void *stream);
 int grbda_project_positions_f32(const grbda_plan *plan, float *q, int32_t *ok, size_t B, int max_iter, double tol,
                                 int device, void *stream);
+/* The same with HOST arrays (copied to the device and back; synchronises): what the C++ facade's randomJointState() of an implicit
+ * cluster of a URDF-built model runs (GenericJoint.cpp:289-348: independent coordinates U(-1, 1), dependent guess U(-0.1, 0.1), Newton,
+ * at most 45 draws). */
+int grbda_project_positions_host_f64(const grbda_plan *plan, double *q, int32_t *ok, size_t B, int max_iter, double tol, int device);
 
 /* State input in the reference's conventions: ClusterJoints::Base::toSpanningTreeState (ClusterJoint.cpp:22-71) behind
  * ClusterTreeModel::setState(const ModelState&) (ClusterTreeModel.cpp:256-276).  Every JointState of a ModelState flags

@@ -410,7 +410,33 @@ int main(int argc, char **argv)
     const std::string mode = argc > 1 ? argv[1] : "";
     try {
         if (mode == "--big" && argc > 2) {
-            const int rc = bigClusterStates(argv[2]);
+            int rc = bigClusterStates(argv[2]);
+            if (argc > 3) {
+                // the implicit family: random joint states of every cluster as the reference's benchmark draws them (the 17-body loop
+                // cluster: spanning positions on the constraint manifold through the library's Newton projection), setState, dynamics
+                ClusterTreeModel<double> u;
+                u.buildModelFromURDF(argv[3]);
+                double worst = 0;
+                for (int rep = 0; rep < 3; rep++) {
+                    ModelState<double> state;
+                    int spanning = 0;
+                    for (const auto &cluster : u.clusters()) {
+                        state.push_back(cluster->joint_->randomJointState());
+                        if (state.back().position.isSpanning()) {
+                            spanning++;
+                            for (int j = 0; j < static_cast<int>(state.back().position.size()); j++)
+                                if (!std::isfinite(state.back().position[j])) rc |= 1;
+                        }
+                    }
+                    if (spanning != 1) rc |= 1;
+                    u.setState(state);
+                    const DVec<double> tau = DVec<double>::Random(u.getNumDegreesOfFreedom());
+                    const DVec<double> ydd = u.forwardDynamics(tau);
+                    worst = std::fmax(worst, (u.inverseDynamics(ydd) - tau).norm() / (1.0 + ydd.norm()));
+                }
+                std::printf("URDF-built implicit parallel chain: random model states, |ID(FD(tau)) - tau| = %.3e\n", worst);
+                if (!(worst < 1e-8)) rc |= 1;
+            }
             std::printf(rc ? "FAILED\n" : "OK\n");
             return rc;
         }

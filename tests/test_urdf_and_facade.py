@@ -193,5 +193,6 @@ def test_cpp_facade_runs_a_model_with_a_big_cluster(facade_binary):
     """The reference's depth-10 explicit parallel chain (a cluster of 16 bodies) through the C++ facade: buildModelFromURDF,
     setState(ModelState) with spanning joint states, forwardDynamics / inverseDynamics -- what the reference's own benchmark does with
     this model family (Benchmarking/src/pinocchioBenchmark.cpp:160-168)."""
-    r = subprocess.run([facade_binary, "--big", os.path.join(MODELS, "parallel_chain_exp_d10_l16.urdf")], capture_output=True, text=True)
+    r = subprocess.run([facade_binary, "--big", os.path.join(MODELS, "parallel_chain_exp_d10_l16.urdf"),
+                        os.path.join(MODELS, "parallel_chain_imp_d10_l17.urdf")], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
