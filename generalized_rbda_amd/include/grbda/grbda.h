@@ -529,9 +529,13 @@ public:
     const DMat<Scalar> &K() const { return loop_constraint_->K(); }
     std::shared_ptr<LoopConstraint::Base<Scalar>> cloneLoopConstraint() const { return loop_constraint_; }
     const std::vector<JointPtr<Scalar>> &singleJoints() const { return single_joints_; }
-    // ClusterJoint.cpp:73-80
+    // ClusterJoint.cpp:73-80; implicit clusters (GenericJoint.cpp:289-361): spanning positions on the constraint manifold -- independent
+    // coordinates U(-1, 1), a dependent guess U(-0.1, 0.1), Newton, up to 45 draws; the model the cluster belongs to installs the root finder
+    std::function<JointCoordinate<double>()> find_roots_for_phi_;
     virtual JointState<double> randomJointState() const
     {
+        if (find_roots_for_phi_)
+            return JointState<double>(find_roots_for_phi_(), JointCoordinate<double>(DVec<double>::Random(num_velocities_), false));
         return JointState<double>(JointCoordinate<double>(DVec<double>::Random(num_positions_), false),
                                   JointCoordinate<double>(DVec<double>::Random(num_velocities_), false));
     }
@@ -685,14 +689,6 @@ public:
         this->single_joints_ = joints;
         this->ordered_joints_ = joints;
         this->loop_constraint_ = loop_constraint;
-    }
-    // implicit clusters: spanning positions on the constraint manifold (GenericJoint.cpp:289-361: independent coordinates U(-1, 1), a
-    // dependent guess U(-0.1, 0.1), Newton, up to 45 draws) -- the model that read the description installs the root finder
-    std::function<JointCoordinate<double>()> find_roots_for_phi_;
-    JointState<double> randomJointState() const override
-    {
-        if (!find_roots_for_phi_) return Base<Scalar>::randomJointState();
-        return JointState<double>(find_roots_for_phi_(), JointCoordinate<double>(DVec<double>::Random(this->num_velocities_), false));
     }
 };
 // ClusterJoints::FourBar (FourBarJoint.h:57-77)
@@ -848,27 +844,8 @@ public:
                 for (int i = 0; i < cl.n_bodies; i++) lc->independent.push_back(flags[i] != 0);
             }
             auto described = std::make_shared<ClusterJoints::Described<Scalar>>(cl.n_bodies, cl.n_pos, cl.n_vel, joints, lc);
-            if (cl.constraint_type != GRBDA_CONSTRAINT_FREE && cl.constraint_type != GRBDA_CONSTRAINT_STATIC) {
-                const int q0 = cl.q_index, k = cl.n_bodies, nq_all = h->nq;
-                const std::vector<bool> indep = lc->independent;
-                described->find_roots_for_phi_ = [this, q0, k, nq_all, indep]() {
-                    // the other clusters rest at zero (a free base at the identity quaternion): constraints never couple clusters
-                    for (int attempt = 0; attempt < 45; attempt++) {
-                        std::vector<double> q(nq_all, 0.0);
-                        if (OriTpl::desc_id == GRBDA_ORI_QUATERNION && nq_all >= 7 && !cluster_nodes_.empty() &&
-                            cluster_nodes_.front()->num_velocities_ == 6 && cluster_nodes_.front()->num_positions_ == 7)
-                            q[3] = 1.0;
-                        const DVec<double> r = DVec<double>::Random(k);
-                        for (int i = 0; i < k; i++) q[q0 + i] = indep[i] ? r[i] : 0.1 * r[i];
-                        int32_t ok = 0;
-                        check(grbda_project_positions_host_f64(plan(), q.data(), &ok, 1, 50, 1e-8, 0));
-                        // (ok covers every implicit cluster of the model: the others sit at zero, which is on their manifold for the
-                        // linkages of the reference's URDFs; a model where it is not keeps drawing and then reports the failure)
-                        if (ok) return JointCoordinate<double>(DVec<double>(q.begin() + q0, q.begin() + q0 + k), true);
-                    }
-                    throw std::runtime_error("Failed to find valid roots for implicit loop constraint");
-                };
-            }
+            if (cl.constraint_type != GRBDA_CONSTRAINT_FREE && cl.constraint_type != GRBDA_CONSTRAINT_STATIC)
+                described->find_roots_for_phi_ = rootFinder(cl.q_index, cl.n_bodies, lc->independent);
             node->joint_ = described;
             node->parent_index_ = cl.parent_cluster;
             node->position_index_ = cl.q_index;
@@ -877,6 +854,34 @@ public:
             node->num_velocities_ = cl.n_vel;
             cluster_nodes_.push_back(node);
         }
+    }
+
+    // The root finder behind randomJointState() of an implicit cluster (GenericJoint.cpp:289-361): the cluster's spanning positions at
+    // [q0, q0 + k) of the model's position vector.  Every implicit cluster of the model is drawn (independent coordinates U(-1, 1), dependent
+    // guess U(-0.1, 0.1)) and projected by the library's Newton kernel in one call -- its verdict covers the whole state --, the explicit ones
+    // rest at zero; up to 45 draws, then the reference's error.
+    std::function<JointCoordinate<double>()> rootFinder(int q0, int k, const std::vector<bool> &independent)
+    {
+        return [this, q0, k, independent]() {
+            const int nq_all = this->position_index_;
+            for (int attempt = 0; attempt < 45; attempt++) {
+                std::vector<double> q(nq_all, 0.0);
+                for (const auto &node : cluster_nodes_) {
+                    const auto lc = node->joint_->cloneLoopConstraint();
+                    if (lc->kind == GRBDA_CONSTRAINT_FREE) {
+                        if (node->num_positions_ == 7) q[node->position_index_ + 3] = 1.0;  // the identity quaternion
+                    } else if (!lc->isExplicit()) {
+                        const DVec<double> r = DVec<double>::Random(node->num_positions_);
+                        for (int i = 0; i < node->num_positions_; i++)
+                            q[node->position_index_ + i] = (i < static_cast<int>(lc->independent.size()) && lc->independent[i]) ? r[i] : 0.1 * r[i];
+                    }
+                }
+                int32_t ok = 0;
+                check(grbda_project_positions_host_f64(plan(), q.data(), &ok, 1, 50, 1e-8, 0));
+                if (ok) return JointCoordinate<double>(DVec<double>(q.begin() + q0, q.begin() + q0 + k), true);
+            }
+            throw std::runtime_error("Failed to find valid roots for implicit loop constraint");
+        };
     }
 
     // ClusterTreeModel.cpp:10-32
@@ -947,6 +952,10 @@ public:
         }
         node->parent_index_ = parent_cluster;
         for (const auto &b : node->bodies_) body_index_to_cluster_index_[b.index_] = node->index_;
+        {
+            const auto lc = joint->cloneLoopConstraint();
+            if (lc && !lc->isExplicit()) joint->find_roots_for_phi_ = rootFinder(node->position_index_, joint->numPositions(), lc->independent);
+        }
         cluster_nodes_.push_back(node);
         this->position_index_ += joint->numPositions();
         this->velocity_index_ += joint->numVelocities();

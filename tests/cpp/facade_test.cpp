@@ -261,6 +261,16 @@ static int fourBar()
         // one degree of freedom: H ydd + C = tau with the scalar mass "matrix"
         worst = std::fmax(worst, std::fabs(m.getMassMatrix()(0, 0) * ydd[0] + m.getBiasForceVector()[0] - tau[0]));
     }
+    // random joint states of the implicit cluster (GenericJoint.cpp:289-361): spanning positions on the constraint manifold, accepted by
+    // setState(ModelState) (an invalid spanning position would throw)
+    for (int rep = 0; rep < 3; rep++) {
+        const JointState<double> js = m.cluster(0)->joint_->randomJointState();
+        if (!js.position.isSpanning() || js.position.size() != 3 || js.velocity.size() != 1) return 1;
+        m.setState(ModelState<double>{js});
+        DVec<double> tau(1);
+        tau[0] = 0.3;
+        worst = std::fmax(worst, (m.inverseDynamics(m.forwardDynamics(tau)) - tau).norm());
+    }
     std::printf("FourBar (parallelogram): nq=3 nv=1 |ID(FD(tau)) - tau| = %.3e\n", worst);
     return worst < 5e-8 ? 0 : 1;
 }
