@@ -63,6 +63,69 @@ namespace grbda_hip {
 
 #include "devmath.h"
 
+// optional in-kernel cycle accounting of the chain kernel (make expc NAME=cprof DEFS=-DGRBDA_CHAIN_PROFILE, tools/chain_prof.py;
+// never in the shipped library): s_memtime deltas per tile phase and segment type, summed over wavefronts
+#ifdef GRBDA_CHAIN_PROFILE
+__device__ unsigned long long grbda_chain_prof[128];
+#define CPROF_T0() unsigned long long cprof_t = __builtin_amdgcn_s_memtime(), cprof_acc = 0, cprof_cnt = 0
+// lane i keeps bucket i (no memory traffic inside the tile loop); CPROF_END adds the lanes' buckets to the global table
+#define CPROF_ADD(i, n)                                                                   \
+    do {                                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                     \
+        if (lane == (i)) {                                                                \
+            cprof_acc += now_ - cprof_t;                                                  \
+            cprof_cnt += (unsigned long long)(n);                                         \
+        }                                                                                 \
+        cprof_t = now_;                                                                   \
+    } while (0)
+#define CPROF_END()                                                                       \
+    do {                                                                                  \
+        if (lane < 32) {                                                                  \
+            atomicAdd(&grbda_chain_prof[lane], cprof_acc);                                \
+            atomicAdd(&grbda_chain_prof[32 + lane], cprof_cnt);                           \
+        }                                                                                 \
+        atomicAdd(&grbda_chain_prof[64 + lane], M.pacc);                                  \
+    } while (0)
+// marks inside a run's link loop: issue-time stamps (ordered behind the value `dep`), summed per interval into lane buckets 32.. of
+// a second per-lane accumulator that lives in ChainMem (M.pacc)
+#define CMARK(k, dep)                                                                     \
+    do {                                                                                  \
+        asm volatile("" ::"v"(dep) : "memory");                                           \
+        cm_[k] = __builtin_amdgcn_s_memtime();                                            \
+    } while (0)
+#define CMARK_DECL(n) unsigned long long cm_[n]
+#define CMARK_SUM(base, n)                                                                \
+    do {                                                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ + 1 < (n); k_++)                            \
+            if (M.lane == (base) + k_) M.pacc += cm_[k_ + 1] - cm_[k_];                   \
+    } while (0)
+#else
+#define CPROF_T0()
+#define CPROF_ADD(i, n)
+#define CPROF_END()
+#define CMARK(k, dep)
+#define CMARK_DECL(n)
+#define CMARK_SUM(base, n)
+#endif
+
+// Every load the wavefront has in flight has landed (vmcnt(0) of the gfx9 s_waitcnt encoding, the other counters untouched).  Placed in
+// the PREHEADER of the run loops: the first link's inputs are fetched there, and without it the compiler's wait-count pass must
+// assume at the top of EVERY iteration that those loads are still in flight with nothing issued behind them -- it then waits
+// vmcnt(0) at the loop top, which drains the [K | y0] stores of the link before (backward run) or the block just requested for the
+// next link (acceleration run: the prefetch bought nothing).  With the loads of the preheader retired the waits inside the loops
+// count exactly (vmcnt(7) behind seven stores).
+// which runs use the restructured link loops (A/B switch): 1 forward run in chunks, 2 branch-free backward run, 4 acceleration run in chunks
+#ifndef GRBDA_CHUNK_MASK
+#define GRBDA_CHUNK_MASK 7
+#endif
+#ifndef GRBDA_DRAIN_MASK
+#define GRBDA_DRAIN_MASK 0
+#endif
+#define PREHEADER_DRAIN(bit)                                                \
+    do {                                                                    \
+        if constexpr ((GRBDA_DRAIN_MASK) & (bit)) __builtin_amdgcn_s_waitcnt(0x0F70); \
+    } while (0)
+
 template <class T>
 struct ChainTables {
     cptr<ChainSeg> segs;
@@ -139,6 +202,9 @@ struct ChainMem {
     __device__ __forceinline__ T q(int j) const { return row_ld(in_q_u, j); }
     __device__ __forceinline__ T qd(int j) const { return row_ld(in_qd_u, j); }
     __device__ __forceinline__ T x(int j) const { return row_ld(in_x_u, j); }
+#ifdef GRBDA_CHAIN_PROFILE
+    mutable unsigned long long pacc;
+#endif
     int out_row;  // >= 0: the result rows [coordinate][lane] live in LDS from this row on (ChainProgram::out_lds); -1: in the slab
     // a result row read back (the differential's forward segment leaves a partial torque its backward segment completes)
     __device__ __forceinline__ T got(int j) const
@@ -146,7 +212,18 @@ struct ChainMem {
         return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b);
     }
     // (forward dynamics: rows in LDS or in the slab)
-    __device__ __forceinline__ void put_f(int j, T v) const { out_f[j * kWave + lane] = v; }
+    // (forward dynamics: rows in LDS or in the slab; a wave-uniform branch, so that the store is a DS or a GLOBAL instruction: a
+    // flat store counts on both memory counters and turns every later wait of the run into vmcnt(0) lgkmcnt(0).  The fp64 kernels
+    // that spill keep the flat store: the branch cost them 40 % in round 3.)
+    __device__ __forceinline__ void put_f(int j, T v) const
+    {
+        if constexpr (sizeof(T) == 4) {
+            if (out_row >= 0) reinterpret_cast<T *>(grbda_smem)[(out_row + j) * kWave + lane] = v;
+            else put(j, v);
+        } else {
+            out_f[j * kWave + lane] = v;
+        }
+    }
     // the result rows through ONE generic pointer (flat stores reach LDS and the slab alike): no branch per store
     T *out_f;
     __device__ __forceinline__ void set_out(int row)
@@ -313,7 +390,10 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
     // the inputs of the next link travel (global slab rows, L2 latency) while the current link is computed
     ChainLink l = load_rec(P.links + sg.first);
     T qi = M.q(l.q_index), qdi_in = M.qd(l.v_index);
+    PREHEADER_DRAIN(1);
     for (int i = 0; i < sg.count; i++) {
+        CMARK_DECL(6);
+        CMARK(0, vp[0]);
         const bool more = i + 1 < sg.count;
         const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
         T qn = 0, qdn = 0;
@@ -324,9 +404,13 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
         cptr<T> C = P.consts + l.cofs;
         const T g0 = C[kBodyConstFixed];
         T blk[8], v[6];
-        sincos_t(g0 * qi, &blk[0], &blk[1]);
+        const T ang = g0 * qi;
+        CMARK(1, ang);
+        sincos_t(ang, &blk[0], &blk[1]);
+        CMARK(2, blk[0]);
         link_down(perm_if<T>(GRBDA_PERM_LINK, l.perm), blk[0], blk[1], C, vp, v);
         v[2] += g0 * qdi_in;
+        CMARK(3, v[2]);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             blk[2 + j] = v[j];
@@ -334,9 +418,61 @@ __device__ __forceinline__ void run_fwd(const ChainTables<T> &P, const ChainMem<
         }
         if constexpr (SVG) M.acc_st(l.lds_sv, blk);
         else M.lds_st(l.lds_sv, blk);
+        CMARK(4, v[0]);
         l = ln;
         qi = qn;
         qdi_in = qdn;
+        CMARK(5, qi);
+        CMARK_SUM(0, 6);
+    }
+}
+
+// The same run with the slab rows of FOUR links requested at once (kChunk): a link of the forward run is ~60 instructions, far
+// shorter than the L2 / Infinity Cache round trip of its two input rows, so the one-link-ahead prefetch of run_fwd exposes most of
+// that latency at every link (profiles/r5_chain_phase_profile.txt: ~780 cycles per link at the loop top); here it is exposed once
+// per chunk.  Runs of the URDF robots are 3-7 links long.
+constexpr int kChunk = 4;
+template <class T>
+__device__ __forceinline__ void run_fwd_c(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
+{
+    T vp[6];
+    for (int base = 0; base < sg.count; base += kChunk) {
+        const int n = sg.count - base;
+        ChainLink L[kChunk];
+        T qv[kChunk], qdv[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) {
+            if (u < n) {
+                L[u] = load_rec(P.links + (sg.first + base + u));
+                qv[u] = M.q(L[u].q_index);
+                qdv[u] = M.qd(L[u].v_index);
+            }
+        }
+        if (base == 0) {
+            if (L[0].lds_pv != -1) {
+                M.lds_ld(L[0].lds_pv, vp);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) vp[j] = 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) {
+            if (u < n) {
+                cptr<T> C = P.consts + L[u].cofs;
+                const T g0 = C[kBodyConstFixed];
+                T blk[8], v[6];
+                sincos_t(g0 * qv[u], &blk[0], &blk[1]);
+                link_down(perm_if<T>(GRBDA_PERM_LINK, L[u].perm), blk[0], blk[1], C, vp, v);
+                v[2] += g0 * qdv[u];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    blk[2 + j] = v[j];
+                    vp[j] = v[j];
+                }
+                M.lds_st(L[u].lds_sv, blk);
+            }
+        }
     }
 }
 
@@ -985,7 +1121,10 @@ __device__ __forceinline__ void diff_acc(const ChainTables<T> &P, const ChainMem
 // Per link the rotor comes in three kinds (a wave-uniform branch on the link record, so one run may mix them): none;
 // axisymmetric (q = 0, plan constants); general leaf rotor evaluated at its own angle, whose X^T I X joins the hand-over
 // like a second body of the cluster.
-template <class T, bool OSIM, bool SVG>
+// ROT (ChainSeg::rot_kind, plan.cpp): 1 -- every link of the run carries an axisymmetric rotor, 2 -- none carries a rotor: the link body
+// is then ONE basic block (no wave-uniform branch on the rotor kind), so the rotor's constants and the parent velocity are fetched with
+// the link's own at the top of the iteration and its arithmetic is scheduled between the link's; 0 -- mixed, the branches stay.
+template <class T, bool OSIM, bool SVG, int ROT = 0>
 __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
 {
     T IAc[21], psic[6];  // what the link below handed up (register hand-over inside the run)
@@ -1010,7 +1149,10 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
     T yd = M.qd(l.v_index), tau_in = M.x(l.v_index), y_in = M.q(l.q_index);
     T blk[8];  // [sin, cos, v 6] of the current link; SVG: in the global slab, fetched one link ahead
     if constexpr (SVG) M.acc_ld(l.lds_sv, blk);
+    PREHEADER_DRAIN(2);
     for (int i = 0; i < sg.count; i++) {
+        CMARK_DECL(8);
+        CMARK(0, IAc[0]);
         const bool more = i + 1 < sg.count;
         const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
         T ydn = 0, taun = 0, yn = 0;
@@ -1035,6 +1177,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         for (int j = 0; j < 6; j++) v[j] = blk[2 + j];
         T chat[6];
         vxz(v, qdi, chat);
+        CMARK(1, chat[0]);
 
         T IA[21], psi[6];
         bias_force(Ic, v, psi);
@@ -1048,6 +1191,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         const T bj = psi[2] + h[0] * chat[0] + h[1] * chat[1] + h[3] * chat[3] + h[4] * chat[4];
         T u = tau_in - g0 * bj;
         T D = h[2] * g0 * g0;
+        CMARK(2, u);
         T F[6];
         {
             T t[6];
@@ -1058,7 +1202,8 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         }
 #pragma unroll
         for (int r = 0; r < 6; r++) F[r] *= g0;
-        if (l.rofs >= 0 && l.rpre < 0) {
+        CMARK(3, F[0]);
+        if (ROT == 0 && l.rofs >= 0 && l.rpre < 0) {
             cptr<T> Cr = P.consts + l.rofs;
             cptr<T> Ir = Cr + 12;
             const T gr = Cr[kBodyConstFixed];
@@ -1094,12 +1239,17 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
             for (int j = 0; j < 21; j++) IAc[j] += Br[j];
         }
-        if (l.rofs >= 0 && l.rpre >= 0) {
+        if (ROT == 1 || (ROT == 0 && l.rofs >= 0 && l.rpre >= 0)) {
             cptr<T> Cr = P.consts + l.rofs;
             cptr<T> Rp = P.consts + l.rpre;  // [X0^T h (6)][h_z]
             const T gr = Cr[kBodyConstFixed];
             T vp[6];
-            if (l.lds_pv != -1) {
+            if constexpr (ROT == 1 && !SVG) {  // branch-free: a run that starts on the ground reads row 0 and discards it
+                const bool gnd = l.lds_pv == -1;
+                M.lds_ld(gnd ? 0 : l.lds_pv, vp);
+#pragma unroll
+                for (int j = 0; j < 6; j++) vp[j] = gnd ? T(0) : vp[j];
+            } else if (l.lds_pv != -1) {
                 if constexpr (SVG) M.acc_ld(l.lds_pv, vp);
                 else M.lds_ld(l.lds_pv, vp);
             } else {
@@ -1115,6 +1265,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
 #pragma unroll
             for (int j = 0; j < 6; j++) psic[j] += tp[j];
         }
+        CMARK(4, psic[0]);
         const T Dinv = rcp_t(D);
         T kb[7];  // [K 6][y0]: what the acceleration run needs (it recomputes sin / cos from q: two slab rows less per link)
 #pragma unroll
@@ -1125,12 +1276,14 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
             const T ex[3] = {blk[0], blk[1], Dinv};
             M.glb_st(l.glb_k + 7, ex);
         }
+        CMARK(5, kb[6]);
 #pragma unroll
         for (int r = 0; r < 6; r++) {
             psic[r] += F[r] * kb[6];
 #pragma unroll
             for (int cc = r; cc < 6; cc++) IAc[sidx(r, cc)] -= F[r] * kb[cc];
         }
+        CMARK(6, IAc[0]);
         l = ln;
         yd = ydn;
         tau_in = taun;
@@ -1141,6 +1294,8 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
                 for (int j = 0; j < 8; j++) blk[j] = blkn[j];
             }
         }
+        CMARK(7, yd);
+        CMARK_SUM(8, 8);
     }
     // hand the chain's projected inertia / bias to the body it hangs off
     if (sg.lds_acc_out != -1) {
@@ -1187,9 +1342,12 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
     T kb[7];
     M.glb_ld(l.glb_k, kb);
     T yd = M.qd(l.v_index), yq = l.has_child ? M.q(l.q_index) : T(0);
+    PREHEADER_DRAIN(4);
     for (int i = 0; i < sg.count; i++) {
         // the next link's record, [K | y0] block and inputs travel while this link is computed (the joint angle only for
         // links with children: the others need no transform here)
+        CMARK_DECL(5);
+        CMARK(0, ap[0]);
         const bool more = i + 1 < sg.count;
         const ChainLink ln = load_rec(P.links + (sg.first + (more ? i + 1 : i)));
         T kn[7], ydn = 0, yqn = 0;
@@ -1201,7 +1359,9 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
         T ydd = kb[6];
 #pragma unroll
         for (int r = 0; r < 6; r++) ydd -= kb[r] * ap[r];
+        CMARK(1, ydd);
         M.put_f(l.v_index, ydd);
+        CMARK(2, ydd);
         if (l.has_child) {
             cptr<T> C = P.consts + l.cofs;
             const T g0 = C[kBodyConstFixed];
@@ -1229,12 +1389,93 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
                 ap[j] = a[j];
             }
         }
+        CMARK(3, ap[0]);
         if (more) {
             l = ln;
             yd = ydn;
             yq = yqn;
 #pragma unroll
             for (int j = 0; j < 7; j++) kb[j] = kn[j];
+        }
+        CMARK(4, kb[0]);
+        CMARK_SUM(20, 5);
+    }
+}
+
+// The acceleration run with the [K | y0] blocks and input rows of FOUR links requested at once (see run_fwd_c): the blocks were
+// written by the backward sweep tens of microseconds earlier and come back from the Infinity Cache (~1 300 cycles measured at the loop
+// top of run_acc, where the block of the NEXT link was requested and -- the compiler's wait-count pass merges the loop's entry states --
+// waited for at once); a link of this run is 20-150 instructions.
+template <class T>
+__device__ __forceinline__ void run_acc_c(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
+{
+    T vp[6], ap[6];
+    for (int base = 0; base < sg.count; base += kChunk) {
+        const int n = sg.count - base;
+        ChainLink L[kChunk];
+        T kb[kChunk][7], yd[kChunk], yq[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) {
+            if (u < n) {
+                L[u] = load_rec(P.links + (sg.first + base + u));
+                M.glb_ld(L[u].glb_k, kb[u]);
+                yd[u] = M.qd(L[u].v_index);
+                yq[u] = L[u].has_child ? M.q(L[u].q_index) : T(0);
+            }
+        }
+        if (base == 0) {
+            if (sg.lds_pva >= 0) {
+                T va[12];
+                M.lds_ld(sg.lds_pva, va);
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    vp[j] = va[j];
+                    ap[j] = va[6 + j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    vp[j] = 0;
+                    ap[j] = P.a_root[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) {
+            if (u < n) {
+                const ChainLink &l = L[u];
+                T ydd = kb[u][6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) ydd -= kb[u][r] * ap[r];
+                M.put_f(l.v_index, ydd);
+                if (l.has_child) {
+                    cptr<T> C = P.consts + l.cofs;
+                    const T g0 = C[kBodyConstFixed];
+                    const T qdi = g0 * yd[u];
+                    T v[6], a[6], chat[6], sn, cs;
+                    sincos_t(g0 * yq[u], &sn, &cs);
+                    link_down2(perm_if<T>(GRBDA_PERM_ACC, l.perm), sn, cs, C, vp, ap, v, a);
+                    v[2] += qdi;
+                    vxz(v, qdi, chat);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) a[j] += chat[j];
+                    a[2] += g0 * ydd;
+                    if (l.lds_va >= 0) {
+                        T va[12];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            va[j] = v[j];
+                            va[6 + j] = a[j];
+                        }
+                        M.lds_st(l.lds_va, va);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        vp[j] = v[j];
+                        ap[j] = a[j];
+                    }
+                }
+            }
         }
     }
 }
@@ -1503,27 +1744,41 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.set_out(DP.out_lds);
+#ifdef GRBDA_CHAIN_PROFILE
+    M.pacc = 0;
+#endif
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
+    CPROF_T0();
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
         // (DP.debug: profiling aid of tools/chain_ablate.py -- bit 0 skips the prologue, bit 1 the segments, bit 2 the
         // epilogue; results are then meaningless)
         if (!(dbg & 1)) stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        CPROF_ADD(0, 1);
         for (int s = 0; s < ((dbg & 2) ? 0 : P.n_segs); s++) {
             const ChainSeg sg = load_rec(P.segs + s);
+            // (ablation builds: bits 5 / 6 / 7 skip the forward / backward / acceleration segments of every kind)
+            if ((dbg & 32) && (sg.op == SEG_RUN_FWD || sg.op == SEG_FREE_FWD)) continue;
+            if ((dbg & 64) && (sg.op == SEG_RUN_BWD || sg.op == SEG_FREE_BWD)) continue;
+            if ((dbg & 128) && (sg.op == SEG_RUN_ACC || sg.op == SEG_FREE_ACC || sg.op == SEG_PAIR_ACC)) continue;
             switch (sg.op) {
                 case SEG_RUN_FWD:
                     if (DP.sv_global) run_fwd<T, true>(P, M, sg);
+                    else if constexpr ((GRBDA_CHUNK_MASK) & 1) run_fwd_c(P, M, sg);
                     else run_fwd<T, false>(P, M, sg);
                     break;
                 case SEG_RUN_BWD: {
                     if (DP.sv_global) run_bwd<T, false, true>(P, M, sg);
+                    else if (((GRBDA_CHUNK_MASK) & 2) && sg.rot_kind == 1) run_bwd<T, false, false, 1>(P, M, sg);
                     else run_bwd<T, false, false>(P, M, sg);
                     break;
                 }
-                case SEG_RUN_ACC: run_acc(P, M, sg); break;
+                case SEG_RUN_ACC:
+                    if constexpr ((GRBDA_CHUNK_MASK) & 4) run_acc_c(P, M, sg);
+                    else run_acc(P, M, sg);
+                    break;
                 case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
                 case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
                 case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first)); break;
@@ -1547,12 +1802,16 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                     break;
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
+            CPROF_ADD((sg.op == SEG_RUN_BWD && sg.head == HEAD_PAIR) ? 20 : 2 + sg.op,
+                      sg.op == SEG_RUN_FWD || sg.op == SEG_RUN_BWD || sg.op == SEG_RUN_ACC ? sg.count : 1);
         }
         if (!(dbg & 4)) {
             if (M.out_row >= 0) write_outputs_lds<T>(M.out_row, ydd, tile, rows_valid, P.nv, lane);
             else write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
         }
+        CPROF_ADD(1, 1);
     }
+    CPROF_END();
 }
 
 
@@ -2652,6 +2911,18 @@ template hipError_t launch_rnea_chain<float>(const RneaChainDev<float> &, const 
                                              float *, int, size_t, hipStream_t);
 template hipError_t launch_rnea_chain<double>(const RneaChainDev<double> &, const double *, const double *, const double *, double *,
                                               size_t, double *, int, size_t, hipStream_t);
+#endif
+
+#if defined(GRBDA_CHAIN_PROFILE) && GRBDA_CHAIN_UNIT == 0
+extern "C" int grbda_debug_chain_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(grbda_chain_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[128] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(grbda_chain_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 
 static hipError_t set_max_dynamic_lds(const void *const *kernels, int n)

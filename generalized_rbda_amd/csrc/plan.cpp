@@ -1963,7 +1963,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     ChainSeg &sg = CP.segs[r.seg];
                     sg.first = static_cast<int>(CP.links.size());
                     sg.count = static_cast<int>(r.cl.size());
-                    for (int c : r.cl) CP.links.push_back(link_of[c]);
+                    bool all_axi = true, none = true;
+                    for (int c : r.cl) {
+                        CP.links.push_back(link_of[c]);
+                        all_axi = all_axi && link_of[c].rofs >= 0 && link_of[c].rpre >= 0;
+                        none = none && link_of[c].rofs < 0;
+                    }
+                    sg.rot_kind = all_axi ? 1 : (none ? 2 : 0);
                 }
                 for (size_t id = 0; id < chains.size(); id++) {
                     const Chain &ch = chains[id];

@@ -310,7 +310,9 @@ struct ChainSeg {       // 16 ints
     int32_t acc_first;      // 1: this segment is the first writer of that slot
     int32_t lds_pva;        // SEG_RUN_ACC: [v 6][a 6] of the body the chain hangs off, -1: ground (v = 0, a = a_root)
     int32_t owner;          // latency-mode programs: the wavefront of the workgroup that runs this segment (base segments: 0)
-    int32_t reserved[7];
+    int32_t rot_kind;       // runs: 1 -- every link carries an axisymmetric rotor (rofs >= 0, rpre >= 0), 2 -- no link carries a rotor,
+                            // 0 -- mixed: the backward run picks a branch-free link body for 1 (chain_kernels.hip, run_bwd<.., ROT>)
+    int32_t reserved[6];
 };
 
 struct ChainFree {      // 16 ints
