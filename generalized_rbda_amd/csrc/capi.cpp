@@ -456,6 +456,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.ori_repr = h.ori_repr;
             d.debug = 0;
             d.sv_global = 0;
+            d.fuse = d.stage_lds_v = d.stage_v_index = 0;
             d.out_lds = lp.out_lds;
             d.lds_bytes = static_cast<int>(lds_lm);
             for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
@@ -496,6 +497,21 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     d.debug = p->chain_debug;
     d.sv_global = cp.sv_global ? 1 : 0;
     d.out_lds = cp.out_lds;
+    d.fuse = d.stage_lds_v = d.stage_v_index = 0;
+    {   // the floating base's segments that only move data through the slab (devplan.h, ChainDev::fuse)
+        int n_free_bwd = 0, at_bwd = -1;
+        for (size_t s = 0; s < cp.segs.size(); s++)
+            if (cp.segs[s].op == SEG_FREE_BWD) { n_free_bwd++; at_bwd = static_cast<int>(s); }
+        if (!cp.segs.empty() && cp.segs[0].op == SEG_FREE_FWD && n_free_bwd == 1 && cp.frees[cp.segs[0].first].lds_v >= 0) {
+            d.fuse |= 1;
+            d.stage_lds_v = cp.frees[cp.segs[0].first].lds_v;
+            d.stage_v_index = cp.frees[cp.segs[0].first].v_index;
+        }
+        if (n_free_bwd == 1 && at_bwd + 1 < static_cast<int>(cp.segs.size()) && cp.segs[at_bwd + 1].op == SEG_FREE_ACC &&
+            cp.segs[at_bwd + 1].first == cp.segs[at_bwd].first)
+            d.fuse |= 2;
+        if (env_int("GRBDA_NO_FREE_FUSE", 0)) d.fuse = 0;
+    }
     for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;
     size_t grid = static_cast<size_t>(t.n_cu) * waves_per_cu;
@@ -507,6 +523,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     if (lds_bytes < stage_one) lds_bytes = stage_one;
     if (lds_bytes < stage_all && stage_all <= lds_budget) lds_bytes = stage_all;
     d.lds_bytes = static_cast<int>(lds_bytes);
+    if (lds_bytes < stage_all) d.fuse &= ~1;  // (the prologue stages one array at a time: the velocities are gone when it returns)
     const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
     if (fit >= 1 && fit < waves_per_cu) {
         const size_t g2 = static_cast<size_t>(t.n_cu) * fit;
@@ -1187,6 +1204,7 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     d.debug = 0;
     d.sv_global = cp.sv_global ? 1 : 0;
     d.out_lds = -1;  // (the force-propagation kernel keeps its result rows in the slab)
+    d.fuse = d.stage_lds_v = d.stage_v_index = 0;
     // (gravity enters the acceleration sweep only, which runs in applyTestForce mode alone -- there without it)
     for (int i = 0; i < 6; i++) d.a_root[i] = tf_force ? T(0) : static_cast<T>(-h.gravity[i]);
     const size_t n_tiles = (B + kWave - 1) / kWave;

@@ -1493,8 +1493,10 @@ __device__ __forceinline__ void free_fwd(const ChainTables<T> &P, const ChainMem
     M.lds_st(f.lds_v, v);
 }
 
+template <class T>
+__device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, const T (&y0)[6]);
 template <class T, bool OSIM>
-__device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
+__device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, bool fuse_acc = false)
 {
     cptr<T> Ic = P.consts + f.cofs + 12;
     cptr<T> Ib = P.consts + f.iofs;
@@ -1530,6 +1532,12 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
     Chol<T, 6> ch;
     ch.factor(D);
     ch.solve(u);
+    if constexpr (!OSIM) {
+        if (fuse_acc) {  // (every LDS read of this segment is behind us: the rows free_acc writes may alias the accumulators)
+            free_acc_core(P, M, f, u);
+            return;
+        }
+    }
     M.glb_st(f.glb_y0, u);
     if constexpr (OSIM) {  // Cholesky factor of the base's articulated inertia: [L lower triangle 21][1 / diag 6]
         T ex[27];
@@ -1543,11 +1551,11 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
     }
 }
 
+// (y0 in registers: the tail of free_bwd when the two segments are fused, ChainDev::fuse)
 template <class T>
-__device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
+__device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, const T (&y0)[6])
 {
-    T y0[6], o[4], E[9], r[3], g[6], ag[6];
-    M.glb_ld(f.glb_y0, y0);
+    T o[4], E[9], r[3], g[6], ag[6];
     const int nori = P.ori_repr == 0 ? 4 : 3;
 #pragma unroll
     for (int j = 0; j < 4; j++) o[j] = j < nori ? M.q(f.q_index + 3 + j) : T(0);
@@ -1569,6 +1577,13 @@ __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem
         }
         M.lds_st(f.lds_va, va);
     }
+}
+template <class T>
+__device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
+{
+    T y0[6];
+    M.glb_ld(f.glb_y0, y0);
+    free_acc_core(P, M, f, y0);
 }
 
 #include "gen_segments.h"
@@ -1756,6 +1771,14 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
         // (DP.debug: profiling aid of tools/chain_ablate.py -- bit 0 skips the prologue, bit 1 the segments, bit 2 the
         // epilogue; results are then meaningless)
         if (!(dbg & 1)) stage_inputs(q, qd, tau, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+        if (DP.fuse & 1) {  // the floating base's velocity: from the lane's row of the staged block (still there) to its LDS slot
+            const T *mine = reinterpret_cast<const T *>(grbda_smem) + (kWave * P.nq + lane * P.nv + DP.stage_v_index);
+            T v[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) v[j] = mine[j];
+            wave_lds_fence();
+            M.lds_st(DP.stage_lds_v, v);
+        }
         CPROF_ADD(0, 1);
         for (int s = 0; s < ((dbg & 2) ? 0 : P.n_segs); s++) {
             const ChainSeg sg = load_rec(P.segs + s);
@@ -1780,8 +1803,10 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                     else run_acc(P, M, sg);
                     break;
                 case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
-                case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
-                case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_FREE_FWD:
+                    if (!((DP.fuse & 1) && s == 0)) free_fwd(P, M, load_rec(P.frees + sg.first));
+                    break;
+                case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first), (DP.fuse & 2) != 0); break;
                 case SEG_DIFF_FWD:
                     if constexpr (DIFF) diff_fwd(P, M, load_rec(P.diffs + sg.first));
                     break;
@@ -1800,7 +1825,9 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
                 case SEG_GEN_ACC:
                     if constexpr (GEN) gen_segment<T, 2>(P, M, load_rec(P.gens + sg.first));
                     break;
-                default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
+                default:
+                    if (!(DP.fuse & 2)) free_acc(P, M, load_rec(P.frees + sg.first));
+                    break;
             }
             CPROF_ADD((sg.op == SEG_RUN_BWD && sg.head == HEAD_PAIR) ? 20 : 2 + sg.op,
                       sg.op == SEG_RUN_FWD || sg.op == SEG_RUN_BWD || sg.op == SEG_RUN_ACC ? sg.count : 1);

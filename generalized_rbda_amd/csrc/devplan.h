@@ -85,6 +85,11 @@ struct ChainDev {
     int debug;   // GRBDA_CHAIN_DEBUG: phase ablation for profiling (chain_kernels.hip)
     int sv_global;  // ChainProgram::sv_global
     int out_lds;    // ChainProgram::out_lds
+    // aba_chain_kernel only (capi.cpp, run_chain): bit 0 -- the program starts with the floating base's forward segment, whose whole work is
+    // "own velocity to LDS slot stage_lds_v": the tile prologue does it from the staged block (no slab round trip) and the segment is
+    // skipped; bit 1 -- the base's acceleration segment follows its backward segment directly: the backward segment finishes it with y0
+    // in registers (no slab round trip) and the acceleration segment is skipped
+    int fuse, stage_lds_v, stage_v_index;
     T a_root[6];
 };
 template <class T>
