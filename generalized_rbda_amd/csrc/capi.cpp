@@ -62,6 +62,7 @@ struct DeviceTables {
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
+    int32_t *tree_tab = nullptr;        // DerivProgram::tree (TreeSolveProgram::tab)
     int32_t *related_table = nullptr;   // HostPlan::related_table (plans of the wide route with more than 64 velocities)
     int32_t *span_q = nullptr, *span_v = nullptr, *crow = nullptr;  // grbda_plan::span_q / span_v / crow
     // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w)
@@ -242,6 +243,9 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         return hip_err(e, "plan upload");
     if (!h.related_table.empty() &&
         (e = up(h.related_table.data(), h.related_table.size() * sizeof(int32_t), (void **)&t.related_table)) != hipSuccess)
+        return hip_err(e, "plan upload");
+    if (h.deriv.tree.ok &&
+        (e = up(h.deriv.tree.tab.data(), h.deriv.tree.tab.size() * sizeof(int32_t), (void **)&t.tree_tab)) != hipSuccess)
         return hip_err(e, "plan upload");
     for (int w = 0; w < 5; w++) {
         const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : h.chain64p)));
@@ -1734,6 +1738,16 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     return GRBDA_OK;
 }
 
+// the branch-sparse solve covers plans whose expanded coordinate tree fits its register stack (plan.h, TreeSolveProgram; n <= 40)
+template <class T>
+static bool tree_solve_usable(const grbda_plan *p, const DeviceTables &t)
+{
+    const TreeSolveProgram &tp = p->host.deriv.tree;
+    if (!tp.ok || !t.tree_tab || !t.deriv_related || tp.n > 40) return false;
+    if (sizeof(T) == 4 && p->solve_f64) return false;
+    return env_int("GRBDA_NO_TREE_SOLVE", 0) == 0;
+}
+
 template <class T>
 int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, T *dq, T *dqd, T *dtau, size_t B, int device,
                     void *stream)
@@ -1811,6 +1825,33 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
                                static_cast<int>(grid), hs, true, il);
             if (e != hipSuccess) return hip_err(e, "crba launch");
         }
+        T *o1 = dq ? dq + b0 * nn : nullptr, *o2 = dqd ? dqd + b0 * nn : nullptr, *o3 = dtau ? dtau + b0 * nn : nullptr;
+        const T *r1 = dq ? Dq : nullptr, *r2 = dqd ? Dqd : nullptr;
+        // the branch-sparse L^T L solve (tree_solve.h): eight states per wavefront
+        if (tree_solve_usable<T>(p, *t)) {
+            const TreeSolveProgram &tp = p->host.deriv.tree;
+            TreeSolveDev td;
+            td.tab = t->tree_tab; td.related = t->deriv_related; td.n = tp.n; td.nl = tp.nl;
+            td.o_rec = tp.o_rec; td.o_ancn = tp.o_ancn; td.o_ancro = tp.o_ancro; td.o_ancp = tp.o_ancp; td.o_hidx = tp.o_hidx;
+            TreeSolveIO<T> io;
+            std::memset(&io, 0, sizeof io);
+            io.H = H;
+            io.il = il;
+            int nm = 0;  // (the identity last: with all three asked, the two packed right-hand sides share the first pass)
+            if (dq) { io.kind[nm] = 1; io.src[nm] = r1; io.dst[nm] = o1; nm++; }
+            if (dqd) { io.kind[nm] = 2; io.src[nm] = r2; io.dst[nm] = o2; nm++; }
+            if (dtau) { io.kind[nm] = 0; io.src[nm] = nullptr; io.dst[nm] = o3; nm++; }
+            const size_t lds_t = tree_solve_lds_bytes(tp.n, tp.nl, sizeof(T));
+            size_t wpc = sizeof(T) == 4 ? 8 : 4;
+            if (lds_t && wpc > (160u * 1024u) / lds_t) wpc = (160u * 1024u) / lds_t;
+            if (wpc < 1) wpc = 1;
+            size_t gt = static_cast<size_t>(t->n_cu) * wpc;
+            const size_t tiles8 = (nb + 7) / 8;
+            if (gt > tiles8) gt = tiles8;
+            e = launch_tree_solve<T>(td, io, nm, nb, static_cast<int>(gt), hs);
+            if (e != hipSuccess) return hip_err(e, "tree solve launch");
+            continue;
+        }
         // one wavefront per state; as many as the LDS of a CU holds
         const bool wide = sizeof(T) == 4 && p->solve_f64;
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), wide ? 8 : sizeof(T), (dq ? 1 : 0) + (dqd ? 1 : 0));
@@ -1821,8 +1862,6 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
         const size_t units = mfma ? (nb + kDerivGroup - 1) / kDerivGroup : nb;
         if (g3 > units) g3 = units;
-        T *o1 = dq ? dq + b0 * nn : nullptr, *o2 = dqd ? dqd + b0 * nn : nullptr, *o3 = dtau ? dtau + b0 * nn : nullptr;
-        const T *r1 = dq ? Dq : nullptr, *r2 = dqd ? Dqd : nullptr;
         const uint64_t *rel = t->deriv_related;
         const int nvi = static_cast<int>(nv), g3i = static_cast<int>(g3), hp = 1;
         const int sil = il;
@@ -2129,7 +2168,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.tree_tab);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
         for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }

@@ -215,6 +215,24 @@ hipError_t launch_manifold_newton(const DevPlan<T> &P, int n_clusters, T *q, int
 template <class T>
 hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream);
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
+// branch-sparse L^T L solve (tree_solve.h): eight states per wavefront, the right-hand sides as IO.kind says (0 identity, 1 / 2 packed runs)
+struct TreeSolveDev {
+    const int32_t *tab;
+    const uint64_t *related;
+    int n, nl;
+    int o_rec, o_ancn, o_ancro, o_ancp, o_hidx;
+};
+template <class T>
+struct TreeSolveIO {
+    const T *H;        // packed lower-triangle rows (layout `il`)
+    const T *src[3];   // kind 1 / 2: packed runs of dID/dq, dID/dqd (layout `il`); kind 0 (identity): unused
+    T *dst[3];         // [state][n][n]
+    int kind[3];
+    int il;
+};
+template <class T>
+hipError_t launch_tree_solve(const TreeSolveDev &P, const TreeSolveIO<T> &IO, int n_mat, size_t B, int grid, hipStream_t stream);
+size_t tree_solve_lds_bytes(int n, int nl, size_t elem);
 hipError_t set_max_dynamic_lds_deriv();
 hipError_t spd_bad_pivots(unsigned long long *count, int reset);
 
