@@ -1745,7 +1745,8 @@ static bool tree_solve_usable(const grbda_plan *p, const DeviceTables &t)
     const TreeSolveProgram &tp = p->host.deriv.tree;
     if (!tp.ok || !t.tree_tab || !t.deriv_related || tp.n > 40) return false;
     if (sizeof(T) == 4 && p->solve_f64) return false;
-    return env_int("GRBDA_NO_TREE_SOLVE", 0) == 0;
+    // opt-in: measured SLOWER than the matrix-core solve on every model tried (profiles/r5_tree_solve_experiment.txt)
+    return env_int("GRBDA_TREE_SOLVE", 0) != 0;
 }
 
 template <class T>

@@ -73,12 +73,11 @@ __device__ __forceinline__ void tree_sweeps(const TreeSolveDev &P, const TreeSol
                 if (kind[m] == 0) {
                     b[m * NS + s] = c == j ? T(1) : T(0);
                 } else {
-                    // (the load is unconditional, from entry 0 where the entry is a structural zero: a load under a lane mask is a
-                    // block of its own with its own wait, ten round trips per row instead of one)
+                    // (loads under the lane mask: unconditional loads from a dummy entry were measured SLOWER, 43.6 -> 53.1 ms per million
+                    // JVRC-1 states for all three matrices)
                     const bool on = cok[s] && ((relj >> c) & 1);
                     const int e = c <= j ? j * j + c : c * c + c + 1 + j;
-                    const T v = Ss[m][(size_t)(on ? e : 0) * il];
-                    b[m * NS + s] = on ? -v : T(0);
+                    b[m * NS + s] = on ? -Ss[m][(size_t)e * il] : T(0);
                 }
             }
     };
@@ -156,10 +155,7 @@ __device__ __forceinline__ void tree_sweeps(const TreeSolveDev &P, const TreeSol
 #pragma unroll
             for (int m = 0; m < NM; m++)
 #pragma unroll
-                for (int s = 0; s < NS; s++) {
-                    const T v = Ds[m][(size_t)i * n + (cok[s] ? col[s] : 0)];
-                    x[m * NS + s] = (live && cok[s]) ? v : T(0);
-                }
+                for (int s = 0; s < NS; s++) x[m * NS + s] = (live && cok[s]) ? Ds[m][(size_t)i * n + col[s]] : T(0);
         };
         TsRec rc = load_rec(recs + 0), rn = load_rec(recs + (n > 1 ? 1 : 0));
         T xc[NC];
