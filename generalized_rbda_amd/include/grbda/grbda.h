@@ -25,6 +25,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -1249,6 +1250,35 @@ public:
     void inverseDynamicsBatch(const double *q, const double *qd, const double *ydd, double *tau, size_t B, int device = 0)
     {
         check(grbda_rnea_host_f64(plan(), q, qd, ydd, nullptr, tau, B, device));
+    }
+    // The same on DEVICE arrays of the model's Scalar (SURVEY 8b's batched surface: ClusterTreeModel<float> runs grbda_aba_f32 /
+    // grbda_rnea_f32 -- BASELINE's headline precision -- ClusterTreeModel<double> the _f64 entry points): row-major q[B][nq], qd[B][nv],
+    // tau[B][nv] -> ydd[B][nv], all resident on `device`; the call only enqueues on `stream` (a hipStream_t, passed as void * so that
+    // this header needs no HIP header; nullptr = the default stream) and returns.  f_ext: nullptr or [B][n_bodies][6] world-frame
+    // forces (TreeModel::setExternalForces).  Reference members: ClusterTreeModel.h:158-159 over ClusterTreeDynamics.cpp:85-191 /
+    // TreeModel.cpp:173-212.
+    void forwardDynamicsBatch(const Scalar *q, const Scalar *qd, const Scalar *tau, Scalar *ydd, size_t B, int device, void *stream,
+                              const Scalar *f_ext = nullptr)
+    {
+        static_assert(std::is_same<Scalar, float>::value || std::is_same<Scalar, double>::value, "device batches are float or double");
+        if constexpr (std::is_same<Scalar, float>::value) check(grbda_aba_f32(plan(), q, qd, tau, f_ext, ydd, B, device, stream));
+        else check(grbda_aba_f64(plan(), q, qd, tau, f_ext, ydd, B, device, stream));
+    }
+    void inverseDynamicsBatch(const Scalar *q, const Scalar *qd, const Scalar *ydd, Scalar *tau, size_t B, int device, void *stream,
+                              const Scalar *f_ext = nullptr)
+    {
+        static_assert(std::is_same<Scalar, float>::value || std::is_same<Scalar, double>::value, "device batches are float or double");
+        if constexpr (std::is_same<Scalar, float>::value) check(grbda_rnea_f32(plan(), q, qd, ydd, f_ext, tau, B, device, stream));
+        else check(grbda_rnea_f64(plan(), q, qd, ydd, f_ext, tau, B, device, stream));
+    }
+    // d ydd / d q, d qd, d tau on device arrays, each [B][nv][nv] row-major, any of them may be null (grbda_fd_derivatives_f32 / _f64)
+    void forwardDynamicsDerivativesBatch(const Scalar *q, const Scalar *qd, const Scalar *tau, Scalar *dydd_dq, Scalar *dydd_dqd,
+                                         Scalar *dydd_dtau, size_t B, int device, void *stream)
+    {
+        static_assert(std::is_same<Scalar, float>::value || std::is_same<Scalar, double>::value, "device batches are float or double");
+        if constexpr (std::is_same<Scalar, float>::value)
+            check(grbda_fd_derivatives_f32(plan(), q, qd, tau, dydd_dq, dydd_dqd, dydd_dtau, B, device, stream));
+        else check(grbda_fd_derivatives_f64(plan(), q, qd, tau, dydd_dq, dydd_dqd, dydd_dtau, B, device, stream));
     }
     // the immutable compiled plan, for the device-pointer C ABI (grbda_aba_f32 / _f64, grbda_rnea_*)
     const grbda_plan *plan()

@@ -12,6 +12,12 @@
 
 #include "grbda/Dynamics/ClusterTreeModel.h"
 
+// (device-array mode only: the HIP runtime API for allocation and copies, compiled by g++ -- no device code in this file)
+#ifdef FACADE_TEST_WITH_HIP
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#endif
+
 using namespace grbda;
 
 template <size_t N>
@@ -74,6 +80,71 @@ void buildRevolutePairChainWithRotor(ClusterTreeModel<double> &model)
         parent_name = "link-B-" + s;
     }
 }
+
+#ifdef FACADE_TEST_WITH_HIP
+// ClusterTreeModel<Scalar>::forwardDynamicsBatch / inverseDynamicsBatch on DEVICE arrays of the model's Scalar: the float model runs
+// grbda_aba_f32 / grbda_rnea_f32, the double model the _f64 entry points; float against double to 1e-3 (BASELINE's fp32 tolerance),
+// double device arrays against the host-array overload exactly, ID(FD(tau)) = tau on the device in both precisions.
+template <class S>
+static int deviceBatch(const std::string &urdf, const std::vector<double> &q, const std::vector<double> &qd, const std::vector<double> &tau,
+                       size_t B, std::vector<double> &ydd_out, double id_tol)
+{
+    ClusterTreeModel<S> m(urdf);
+    const size_t nq = m.getNumPositions(), nv = m.getNumDegreesOfFreedom();
+    std::vector<S> hq(q.begin(), q.end()), hqd(qd.begin(), qd.end()), htau(tau.begin(), tau.end()), hydd(B * nv), hback(B * nv);
+    S *dq = nullptr, *dqd = nullptr, *dtau = nullptr, *dydd = nullptr, *dback = nullptr;
+    hipStream_t stream = nullptr;
+    if (hipSetDevice(0) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) return 1;
+    if (hipMalloc((void **)&dq, B * nq * sizeof(S)) != hipSuccess || hipMalloc((void **)&dqd, B * nv * sizeof(S)) != hipSuccess ||
+        hipMalloc((void **)&dtau, B * nv * sizeof(S)) != hipSuccess || hipMalloc((void **)&dydd, B * nv * sizeof(S)) != hipSuccess ||
+        hipMalloc((void **)&dback, B * nv * sizeof(S)) != hipSuccess)
+        return 1;
+    (void)hipMemcpy(dq, hq.data(), B * nq * sizeof(S), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dqd, hqd.data(), B * nv * sizeof(S), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dtau, htau.data(), B * nv * sizeof(S), hipMemcpyHostToDevice);
+    m.forwardDynamicsBatch(dq, dqd, dtau, dydd, B, 0, stream);
+    m.inverseDynamicsBatch(dq, dqd, dydd, dback, B, 0, stream);
+    if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+    (void)hipMemcpy(hydd.data(), dydd, B * nv * sizeof(S), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hback.data(), dback, B * nv * sizeof(S), hipMemcpyDeviceToHost);
+    (void)hipFree(dq); (void)hipFree(dqd); (void)hipFree(dtau); (void)hipFree(dydd); (void)hipFree(dback);
+    (void)hipStreamDestroy(stream);
+    ydd_out.assign(hydd.begin(), hydd.end());
+    double worst = 0;
+    for (size_t i = 0; i < B * nv; i++) worst = std::max(worst, std::fabs(static_cast<double>(hback[i]) - tau[i]) / (1.0 + std::fabs(tau[i])));
+    std::printf("  %s device batch of %zu states: max |ID(FD(tau)) - tau| / (1 + |tau|) = %.3g\n", sizeof(S) == 4 ? "float " : "double", B, worst);
+    return worst < id_tol ? 0 : 1;
+}
+
+static int deviceArrays(const std::string &urdf)
+{
+    ClusterTreeModel<double> md(urdf);
+    const size_t B = 4099, nq = md.getNumPositions(), nv = md.getNumDegreesOfFreedom();
+    std::vector<double> q(B * nq), qd(B * nv), tau(B * nv);
+    unsigned long long sd = 0x9E3779B97F4A7C15ull;
+    auto uni = [&]() { sd = sd * 6364136223846793005ull + 1442695040888963407ull; return (double)(sd >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
+    for (size_t s = 0; s < B; s++) {
+        for (size_t j = 0; j < nq; j++) q[s * nq + j] = uni();
+        if (nq == nv + 1) {  // floating base: a unit quaternion in the last four of its seven positions (Joint.h:61-68)
+            double nrm = 0;
+            for (int j = 3; j < 7; j++) nrm += q[s * nq + j] * q[s * nq + j];
+            for (int j = 3; j < 7; j++) q[s * nq + j] /= std::sqrt(nrm);
+        }
+        for (size_t j = 0; j < nv; j++) { qd[s * nv + j] = uni(); tau[s * nv + j] = uni(); }
+    }
+    std::vector<double> y32, y64, yhost(B * nv);
+    int rc = deviceBatch<float>(urdf, q, qd, tau, B, y32, 5e-3) | deviceBatch<double>(urdf, q, qd, tau, B, y64, 1e-8);
+    md.forwardDynamicsBatch(q.data(), qd.data(), tau.data(), yhost.data(), B);  // host-array overload of the same model
+    double d_host = 0, d_f32 = 0, scale = 0;
+    for (size_t i = 0; i < B * nv; i++) scale = std::max(scale, std::fabs(y64[i]));
+    for (size_t i = 0; i < B * nv; i++) {
+        d_host = std::max(d_host, std::fabs(y64[i] - yhost[i]));
+        d_f32 = std::max(d_f32, std::fabs(y32[i] - y64[i]) / (1.0 + std::fabs(y64[i])));
+    }
+    std::printf("  double device vs host overload: %.3g;  float vs double: %.3g relative (1 + |ydd|), max |ydd| %.3g\n", d_host, d_f32, scale);
+    return rc | (d_host == 0.0 ? 0 : 1) | (d_f32 < 1e-3 ? 0 : 1);
+}
+#endif
 
 static void dump(const std::string &path, const std::vector<unsigned char> &blob)
 {
@@ -499,10 +570,17 @@ int main(int argc, char **argv)
             std::printf(rc ? "FAILED\n" : "OK\n");
             return rc;
         }
+#ifdef FACADE_TEST_WITH_HIP
+        if (mode == "--device" && argc > 2) {
+            const int rc = deviceArrays(argv[2]);
+            std::printf(rc ? "FAILED\n" : "OK\n");
+            return rc;
+        }
+#endif
     } catch (const std::exception &e) {
         std::printf("exception: %s\n", e.what());
         return 2;
     }
-    std::printf("usage: facade_test --dump <dir> | --run <urdf>\n");
+    std::printf("usage: facade_test --dump <dir> | --run <urdf> | --device <urdf>\n");
     return 2;
 }

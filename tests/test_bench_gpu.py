@@ -28,7 +28,8 @@ def test_bench_line_is_verified_and_carries_roofline_and_cpu_baseline(gpu):
     assert line["verified"] is True and line["verify_states"] >= 1000
     assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["dtype"] == "f32"
     r = line["roofline"]
-    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
+    assert r["bound"] == "valu_issue" and r["bound_contract"] == "hbm" and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["single_thread"] > 0 and c["passes"] >= 5
 
@@ -48,3 +49,20 @@ def test_bench_multi_rank_path_on_one_rank(gpu):
     # (the two figures come from separate timed loops of 6 steps each; either can catch a stall of the box, so they are
     # not compared -- that assertion failed once in 30 runs with the compute-only loop 5 x slower than usual)
     assert line["value"] > 0
+
+
+def test_bench_weak_run_carries_the_strong_split_of_config_4(gpu):
+    """N > 1 weak runs append a `strong` sub-record: BASELINE config 4's ONE batch of 1 048 576 TelloWithArms states split over the ranks.
+    Here the multi-rank path is forced on one rank (the whole batch on it)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1",
+           "LOCAL_RANK": "0"}
+    line = _run(env, "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--replays", "3")
+    assert line["verified"] is True and line["scaling"] == "weak"
+    st = line["strong"]
+    assert st["scaling"] == "strong" and st["batch_global"] == 1048576 and st["batch_per_gpu"] == 1048576 and st["n_gpus"] == 1
+    assert st["verified"] is True and st["value"] > 0 and st["ms_per_step"] > 0

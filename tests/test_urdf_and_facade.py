@@ -188,6 +188,31 @@ def test_cpp_facade_runs_dynamics_on_the_gpu(facade_binary):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.fixture(scope="module")
+def facade_binary_hip(tmp_path_factory):
+    """the same test program with its device-array mode: the HIP runtime API (allocation, copies) compiled by g++"""
+    out = tmp_path_factory.mktemp("facade_hip") / "facade_test_hip"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-DFACADE_TEST_WITH_HIP", "-I/opt/rocm/include",
+                    "-I" + os.path.join(ROOT, "generalized_rbda_amd", "include"),
+                    os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-o", str(out),
+                    "-L" + os.path.join(ROOT, "generalized_rbda_amd"), "-lgrbda_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + os.path.join(ROOT, "generalized_rbda_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return str(out)
+
+
+@pytest.mark.gpu
+def test_cpp_facade_float_and_double_models_on_device_arrays(facade_binary_hip):
+    """SURVEY 8b's batched surface: ClusterTreeModel<float> / <double>::forwardDynamicsBatch, inverseDynamicsBatch on DEVICE arrays of the
+    model's Scalar with a stream (float -> grbda_aba_f32, the headline precision): float matches double to 1e-3, the double device arrays
+    match the host-array overload exactly, ID(FD(tau)) = tau in both."""
+    r = subprocess.run([facade_binary_hip, "--device", os.path.join(MODELS, "mit_humanoid.urdf")], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_facade_device_mode_compiles(facade_binary_hip):
+    assert os.path.exists(facade_binary_hip)
+
+
 @pytest.mark.gpu
 def test_cpp_facade_runs_a_model_with_a_big_cluster(facade_binary):
     """The reference's depth-10 explicit parallel chain (a cluster of 16 bodies) through the C++ facade: buildModelFromURDF,
