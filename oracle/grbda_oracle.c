@@ -15,7 +15,8 @@
 
 typedef grbda_real real;  /* working precision; the model description stays double (md_copy) */
 
-#include <math.h>
+#include <tgmath.h>  /* type-generic sin / cos / sqrt / fabs: the working precision is a build parameter (grbda_oracle.h) */
+#undef I             /* (tgmath.h brings complex.h and its imaginary unit: `I` is an inertia here) */
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1223,7 +1224,7 @@ int grbda_oracle_project_positions(const void *blob, size_t bytes, real *q, size
                 nrm = 0;
                 for (int r = 0; r < rows; r++) nrm += w->phi[r] * w->phi[r];
                 nrm = sqrt(nrm);
-                if (nrm < 1e-12 || it == max_iter) break;
+                if (nrm < (sizeof(real) > 8 ? (real)1e-17 : (real)1e-12) || it == max_iter) break;
                 real Kd[MAXROWS * MAXROWS], dq[MAXROWS];
                 for (int r = 0; r < rows; r++) {
                     for (int j = 0; j < nd; j++) Kd[r * nd + j] = w->K[r * nsv + dep[j]];

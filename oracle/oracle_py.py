@@ -164,6 +164,46 @@ def project_positions(blob, q, max_iter=50, big=False):
     return q, ok.astype(bool)
 
 
+# ---- the same restatement in x87 extended precision (_build/libgrbda_oracle_ld.so): tests only ----------
+_lib_ld = None
+LD = np.longdouble
+
+
+def _ld():
+    global _lib_ld
+    if _lib_ld is None:
+        path = os.path.join(_HERE, "_build", "libgrbda_oracle_ld.so")
+        if not os.path.exists(path):
+            build()
+        assert np.finfo(LD).nmant >= 63, "numpy's longdouble is not the x87 extended type on this machine"
+        L = ctypes.CDLL(path)
+        L.grbda_oracle_forward_dynamics.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]
+        L.grbda_oracle_project_positions.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]
+        _lib_ld = L
+    return _lib_ld
+
+
+def forward_dynamics_ld(blob, q, qd, tau):
+    """forward dynamics in long double (eps 1.1e-19): arrays of np.longdouble in and out"""
+    q, qd, tau = (np.ascontiguousarray(a, dtype=LD) for a in (q, qd, tau))
+    out = np.empty_like(tau)
+    rc = _ld().grbda_oracle_forward_dynamics(blob, len(blob), q.ctypes.data, qd.ctypes.data, tau.ctypes.data, None, out.ctypes.data,
+                                             q.shape[0])
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    return out
+
+
+def project_positions_ld(blob, q, max_iter=60):
+    """Newton projection of the dependent positions of implicit clusters in long double, to |phi| < 1e-17"""
+    q = np.ascontiguousarray(q, dtype=LD).copy()
+    ok = np.zeros(q.shape[0], dtype=np.int32)
+    rc = _ld().grbda_oracle_project_positions(blob, len(blob), q.ctypes.data, q.shape[0], max_iter, ok.ctypes.data)
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    return q, ok.astype(bool)
+
+
 # ---- the reference's own closed-form codegen (oracle/_ref) -------------------------------------------
 _REF_FUNCS = {
     ("rev", 2, "FD"): ("RevWithRotors2DofFwdDyn", 2), ("rev", 2, "ID"): ("RevWithRotors2DofInvDyn", 2),

@@ -7,6 +7,7 @@ operation order; fp32 errors are normalised by the per-state vector norm as the 
 comparisons are (testRigidBodyDynamicsAlgos.cpp:9,208-232 use norms of differences)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -464,6 +465,46 @@ def test_position_derivative_matches_oracle_differences(name, gpu):
     c32 = lambda a: a.astype(np.float32).astype(np.float64)
     J_of_32 = plan.fd_dq(t(c32(q)), t(c32(qd)), t(c32(tau)), step=h).cpu().numpy()
     assert np.abs(J32 - J_of_32).max() / scale < (1e-3 if implicit else 2e-4)
+
+
+@pytest.mark.parametrize("name", ["urdf_four_bar", "urdf_planar_leg_linkage"])
+def test_manifold_dq_against_extended_precision_differences(name, gpu):
+    """d ydd / d q of implicit clusters NEAR SINGULAR POSES, without a conditioning filter: the analytic route through the spanning tree
+    (manifold_kernels.hip, fp64) against a third, independent evaluation -- the oracle compiled in x87 extended precision
+    (oracle/_build/libgrbda_oracle_ld.so), central differences along an independent position with the dependent ones re-projected to
+    |phi| < 1e-17, Richardson-extrapolated (h = 1e-7, h / 2).  States with cond(K_d) from 1 to 1e4, a dozen per decade.  Tolerance law per
+    state: 1e-11 cond^3 + 1e-9 relative to 1 + |J|_max (measured: ~1e-12 cond^3, profiles/r5_manifold_derivatives_third_evaluation.txt); the
+    difference batches (GRBDA_NO_MANIFOLD=1) are 10-100 x further from the reference in every decade, which is what
+    profiles/r4_manifold_derivatives.txt's 22 % was.  Yardstick: testRigidBodyDynamicsAlgosDerivatives.cpp:271-383."""
+    import torch
+    from generalized_rbda_amd.states import parse_clusters, random_states
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from manifold_third_eval import reference_dq
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    assert plan.info().analytic_derivatives == 1
+    m = parse_clusters(blob)
+    q, qd, tau = random_states(blob, 60000, config_index=5)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    tq = t(q)
+    ok = plan.project_positions(tq).cpu().numpy()
+    q, qd, tau = tq.cpu().numpy()[ok], qd[ok], tau[ok]
+    kcond = O.spanning_state(blob, q, qd)[3]
+    n_checked, worst_ratio = 0, 0.0
+    for lo, hi in ((1, 10), (10, 100), (100, 1e3), (1e3, 1e4)):
+        idx = np.flatnonzero((kcond >= lo) & (kcond < hi))[:12]
+        assert idx.size >= (6 if hi <= 1e3 else 1), f"no states with cond(K_d) in [{lo}, {hi})"
+        for i in idx:
+            J_ref, q0 = reference_dq(blob, m, q[i], qd[i], tau[i], 1e-7)
+            J = plan.fd_dq(t(q0[None]), t(qd[i][None]), t(tau[i][None])).cpu().numpy()[0]
+            err = np.abs(J - J_ref).max() / (1.0 + np.abs(J_ref).max())
+            tol = 1e-11 * kcond[i] ** 3 + 1e-9
+            worst_ratio = max(worst_ratio, err / tol)
+            assert err < tol, f"cond(K_d) {kcond[i]:.3g}: analytic vs extended-precision differences {err:.2e} (law {tol:.2e})"
+            n_checked += 1
+    assert n_checked >= 30
 
 
 @pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "urdf_jvrc1_humanoid", "tree_mixed_fixed", "tree_pair_float",

@@ -80,3 +80,25 @@ def test_oracle_single_precision_build_tracks_the_checker():
         assert np.isfinite(b).all()
         err = np.abs(a - b).max(axis=1) / (1.0 + np.abs(a).max(axis=1))
         assert np.quantile(err, 0.99) < 1e-4
+
+
+def test_extended_precision_build_of_the_oracle_agrees_with_the_fp64_checker():
+    """oracle/_build/libgrbda_oracle_ld.so is the same source in x87 extended precision (the third evaluation of d ydd / d q near singular
+    poses, tests/test_gpu_parity.py): on the golden-vector models it reproduces the fp64 checker to fp64 rounding, and its Newton
+    projection of an implicit cluster lands closer to the manifold than fp64 can."""
+    import generalized_rbda_amd.modeldesc as md
+    from generalized_rbda_amd.states import random_states
+    from models import zoo
+
+    blob = md.revolute_pair_chain_with_rotor(4).serialize()
+    q, qd, tau = random_states(blob, 16, 0)
+    a = O.forward_dynamics(blob, q, qd, tau)
+    b = O.forward_dynamics_ld(blob, q, qd, tau)
+    assert b.dtype == np.longdouble and np.abs(a - b.astype(np.float64)).max() / (1 + np.abs(a).max()) < 1e-12
+    fb = zoo()["urdf_four_bar"]
+    q, qd, tau = random_states(fb, 64, 5)
+    q64, ok64 = O.project_positions(fb, q)
+    qld, okld = O.project_positions_ld(fb, q64)
+    both = ok64 & okld
+    assert both.sum() >= 32
+    assert np.abs(qld.astype(np.float64)[both] - q64[both]).max() < 1e-9   # the same branch of the manifold, refined
