@@ -114,9 +114,10 @@ __device__ unsigned long long grbda_chain_prof[128];
 // vmcnt(0) at the loop top, which drains the [K | y0] stores of the link before (backward run) or the block just requested for the
 // next link (acceleration run: the prefetch bought nothing).  With the loads of the preheader retired the waits inside the loops
 // count exactly (vmcnt(7) behind seven stores).
-// which runs use the restructured link loops (A/B switch): 1 forward run in chunks, 2 branch-free backward run, 4 acceleration run in chunks
+// which runs use the restructured link loops (A/B switch): 1 forward run in chunks, 2 branch-free backward run, 4 acceleration run in chunks,
+// 8 the chunked runs in two phases (parent-independent work of four links first, the recursion on register operands after)
 #ifndef GRBDA_CHUNK_MASK
-#define GRBDA_CHUNK_MASK 7
+#define GRBDA_CHUNK_MASK 15
 #endif
 #ifndef GRBDA_DRAIN_MASK
 #define GRBDA_DRAIN_MASK 0
@@ -435,18 +436,24 @@ constexpr int kChunk = 4;
 template <class T>
 __device__ __forceinline__ void run_fwd_c(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
 {
+    // Two phases per chunk (GRBDA_CHUNK_MASK bit 3): A -- everything of a link that does not depend on its parent (constants, sin / cos,
+    // E = Rz(q) Et, the offset r, the joint rate), four links side by side: the scalar loads of all four are in flight together and the
+    // arithmetic of one link fills the waits of another; B -- the recursion proper, v_i = X_i v_(i-1) + z qd_i, on REGISTER operands only
+    // (no constant fetched on the critical path: the phase profile showed ~780 of a link's ~1 500 cycles in serialized scalar waits).
+    constexpr bool TWO_PHASE = ((GRBDA_CHUNK_MASK) & 8) != 0;
     T vp[6];
     for (int base = 0; base < sg.count; base += kChunk) {
         const int n = sg.count - base;
+        // (ONE basic block: the four records -- positions past the end of the run repeat its last link -- then every slab row; a branch per
+        // link made a block of its own of every record, each with its own scalar wait: ~740 cycles per link in the phase profile)
         ChainLink L[kChunk];
         T qv[kChunk], qdv[kChunk];
 #pragma unroll
+        for (int u = 0; u < kChunk; u++) L[u] = load_rec(P.links + (sg.first + base + (u < n ? u : n - 1)));
+#pragma unroll
         for (int u = 0; u < kChunk; u++) {
-            if (u < n) {
-                L[u] = load_rec(P.links + (sg.first + base + u));
-                qv[u] = M.q(L[u].q_index);
-                qdv[u] = M.qd(L[u].v_index);
-            }
+            qv[u] = M.q(L[u].q_index);
+            qdv[u] = M.qd(L[u].v_index);
         }
         if (base == 0) {
             if (L[0].lds_pv != -1) {
@@ -456,21 +463,53 @@ __device__ __forceinline__ void run_fwd_c(const ChainTables<T> &P, const ChainMe
                 for (int j = 0; j < 6; j++) vp[j] = 0;
             }
         }
+        if constexpr (TWO_PHASE) {
+            T E[kChunk][9], r[kChunk][3], sc[kChunk][2], gq[kChunk];
 #pragma unroll
-        for (int u = 0; u < kChunk; u++) {
-            if (u < n) {
-                cptr<T> C = P.consts + L[u].cofs;
-                const T g0 = C[kBodyConstFixed];
-                T blk[8], v[6];
-                sincos_t(g0 * qv[u], &blk[0], &blk[1]);
-                link_down(perm_if<T>(GRBDA_PERM_LINK, L[u].perm), blk[0], blk[1], C, vp, v);
-                v[2] += g0 * qdv[u];
+            for (int u = 0; u < kChunk; u++) {
+                if (u < n) {
+                    cptr<T> C = P.consts + L[u].cofs;
+                    const T g0 = C[kBodyConstFixed];
+                    sincos_t(g0 * qv[u], &sc[u][0], &sc[u][1]);
+                    rotate_z(sc[u][0], sc[u][1], C, E[u]);
 #pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    blk[2 + j] = v[j];
-                    vp[j] = v[j];
+                    for (int j = 0; j < 3; j++) r[u][j] = C[9 + j];
+                    gq[u] = g0 * qdv[u];
                 }
-                M.lds_st(L[u].lds_sv, blk);
+            }
+#pragma unroll
+            for (int u = 0; u < kChunk; u++) {
+                if (u < n) {
+                    T blk[8], v[6];
+                    xmotion(E[u], r[u], vp, v);
+                    v[2] += gq[u];
+                    blk[0] = sc[u][0];
+                    blk[1] = sc[u][1];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        blk[2 + j] = v[j];
+                        vp[j] = v[j];
+                    }
+                    M.lds_st(L[u].lds_sv, blk);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kChunk; u++) {
+                if (u < n) {
+                    cptr<T> C = P.consts + L[u].cofs;
+                    const T g0 = C[kBodyConstFixed];
+                    T blk[8], v[6];
+                    sincos_t(g0 * qv[u], &blk[0], &blk[1]);
+                    link_down(perm_if<T>(GRBDA_PERM_LINK, L[u].perm), blk[0], blk[1], C, vp, v);
+                    v[2] += g0 * qdv[u];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        blk[2 + j] = v[j];
+                        vp[j] = v[j];
+                    }
+                    M.lds_st(L[u].lds_sv, blk);
+                }
             }
         }
     }
@@ -1409,20 +1448,27 @@ __device__ __forceinline__ void run_acc(const ChainTables<T> &P, const ChainMem<
 template <class T>
 __device__ __forceinline__ void run_acc_c(const ChainTables<T> &P, const ChainMem<T> &M, const ChainSeg &sg)
 {
+    // (two phases per chunk as in run_fwd_c: the recursion a_i = X_i a_(i-1) + c_i + z g0 ydd_i with ydd_i = y0_i - K_i a_(i-1) runs on
+    // register operands prepared for all four links beforehand)
+    constexpr bool TWO_PHASE = ((GRBDA_CHUNK_MASK) & 8) != 0;
     T vp[6], ap[6];
     for (int base = 0; base < sg.count; base += kChunk) {
         const int n = sg.count - base;
+        CMARK_DECL(5);
+        CMARK(0, ap[0]);
+        // (one basic block, see run_fwd_c; the input rows are requested BEFORE the [K | y0] blocks, so that phase A -- which needs only
+        // them -- runs while the blocks are still on their way from the Infinity Cache)
         ChainLink L[kChunk];
         T kb[kChunk][7], yd[kChunk], yq[kChunk];
 #pragma unroll
+        for (int u = 0; u < kChunk; u++) L[u] = load_rec(P.links + (sg.first + base + (u < n ? u : n - 1)));
+#pragma unroll
         for (int u = 0; u < kChunk; u++) {
-            if (u < n) {
-                L[u] = load_rec(P.links + (sg.first + base + u));
-                M.glb_ld(L[u].glb_k, kb[u]);
-                yd[u] = M.qd(L[u].v_index);
-                yq[u] = L[u].has_child ? M.q(L[u].q_index) : T(0);
-            }
+            yd[u] = M.qd(L[u].v_index);
+            yq[u] = M.q(L[u].q_index);
         }
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) M.glb_ld(L[u].glb_k, kb[u]);
         if (base == 0) {
             if (sg.lds_pva >= 0) {
                 T va[12];
@@ -1440,26 +1486,57 @@ __device__ __forceinline__ void run_acc_c(const ChainTables<T> &P, const ChainMe
                 }
             }
         }
+        CMARK(1, ap[0]);
+        CMARK(2, ap[0]);
+        T E[kChunk][9], r[kChunk][3], g0v[kChunk], qdi[kChunk];
+        if constexpr (TWO_PHASE) {
+#pragma unroll
+            for (int u = 0; u < kChunk; u++) {
+                if (u < n && L[u].has_child) {
+                    cptr<T> C = P.consts + L[u].cofs;
+                    const T g0 = C[kBodyConstFixed];
+                    T sn, cs;
+                    sincos_t(g0 * yq[u], &sn, &cs);
+                    rotate_z(sn, cs, C, E[u]);
+#pragma unroll
+                    for (int j = 0; j < 3; j++) r[u][j] = C[9 + j];
+                    g0v[u] = g0;
+                    qdi[u] = g0 * yd[u];
+                }
+            }
+        }
+        CMARK(3, ap[1]);
 #pragma unroll
         for (int u = 0; u < kChunk; u++) {
             if (u < n) {
                 const ChainLink &l = L[u];
                 T ydd = kb[u][6];
 #pragma unroll
-                for (int r = 0; r < 6; r++) ydd -= kb[u][r] * ap[r];
+                for (int rr = 0; rr < 6; rr++) ydd -= kb[u][rr] * ap[rr];
                 M.put_f(l.v_index, ydd);
                 if (l.has_child) {
-                    cptr<T> C = P.consts + l.cofs;
-                    const T g0 = C[kBodyConstFixed];
-                    const T qdi = g0 * yd[u];
-                    T v[6], a[6], chat[6], sn, cs;
-                    sincos_t(g0 * yq[u], &sn, &cs);
-                    link_down2(perm_if<T>(GRBDA_PERM_ACC, l.perm), sn, cs, C, vp, ap, v, a);
-                    v[2] += qdi;
-                    vxz(v, qdi, chat);
+                    T v[6], a[6], chat[6];
+                    if constexpr (TWO_PHASE) {
+                        xmotion(E[u], r[u], vp, v);
+                        xmotion(E[u], r[u], ap, a);
+                        v[2] += qdi[u];
+                        vxz(v, qdi[u], chat);
 #pragma unroll
-                    for (int j = 0; j < 6; j++) a[j] += chat[j];
-                    a[2] += g0 * ydd;
+                        for (int j = 0; j < 6; j++) a[j] += chat[j];
+                        a[2] += g0v[u] * ydd;
+                    } else {
+                        cptr<T> C = P.consts + l.cofs;
+                        const T g0 = C[kBodyConstFixed];
+                        const T qd1 = g0 * yd[u];
+                        T sn, cs;
+                        sincos_t(g0 * yq[u], &sn, &cs);
+                        link_down2(perm_if<T>(GRBDA_PERM_ACC, l.perm), sn, cs, C, vp, ap, v, a);
+                        v[2] += qd1;
+                        vxz(v, qd1, chat);
+#pragma unroll
+                        for (int j = 0; j < 6; j++) a[j] += chat[j];
+                        a[2] += g0 * ydd;
+                    }
                     if (l.lds_va >= 0) {
                         T va[12];
 #pragma unroll
@@ -1477,6 +1554,8 @@ __device__ __forceinline__ void run_acc_c(const ChainTables<T> &P, const ChainMe
                 }
             }
         }
+        CMARK(4, ap[0]);
+        CMARK_SUM(20, 5);
     }
 }
 
@@ -1765,6 +1844,13 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
 
     const size_t n_tiles = (B + kWave - 1) / kWave;
     CPROF_T0();
+#ifdef GRBDA_EXP
+    // experiment: the wavefronts in the odd slots of their SIMD start late by (debug >> 8) x 127 x 64 clocks, so that the two wavefronts of a
+    // SIMD do not stage their inputs (an HBM burst of the whole grid) and run their latency-bound phases at the same moment
+    if ((dbg >> 8) && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {  // HW_REG_HW_ID (4), offset 0, size 4: WAVE_ID
+        for (int i = 0; i < (dbg >> 8); i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;

@@ -39,6 +39,8 @@ print(f"  total {tot/n/tiles:.0f} ticks per tile")
 marks = {"run fwd": (0, ["top: next record, prefetch issue, g0 (scalar waits)", "sin / cos", "transform (constants + math)", "LDS store", "copies (vm wait)"], 3),
          "run bwd": (8, ["top: record, prefetch issue, LDS blk, chat", "bias force, IA sum, u, D", "link_up (transform)", "rotor", "rcp, K store", "rank-1 update", "copies (vm wait)"], None),
          "run acc": (20, ["top: record, prefetch issue, ydd", "put", "child transform", "copies (vm wait)"], 7)}
+if os.environ.get("CPROF_CHUNKED"):
+    marks["run acc"] = (20, ["chunk: records + loads issued + parent (v, a)", "wait for the first [K | y0] block", "phase A (constants, sin / cos, E)", "phase B (recursion, all links of the chunk)"], 7)
 nb = buf[32 + 4] + buf[32 + 20]
 for nm, (base, labels, cnt_bucket) in marks.items():
     links = (buf[32 + cnt_bucket] if cnt_bucket is not None else nb) / n / tiles
