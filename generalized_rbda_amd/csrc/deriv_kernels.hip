@@ -34,6 +34,42 @@ namespace grbda_hip {
 
 #include "devmath.h"
 
+// optional in-kernel cycle accounting of the derivative recursion (make expd NAME=dprof DEFS=-DGRBDA_DERIV_PROFILE, tools/deriv_prof.py;
+// never in the shipped library): s_memtime deltas per phase, lane i keeps bucket i, summed over wavefronts at the end
+#ifdef GRBDA_DERIV_PROFILE
+__device__ unsigned long long grbda_deriv_prof[64];
+#define DPROF_T0() unsigned long long dprof_t = __builtin_amdgcn_s_memtime(), dprof_acc = 0, dprof_cnt = 0
+#define DPROF_ADD(i)                                                                      \
+    do {                                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                     \
+        if (lane == (i)) {                                                                \
+            dprof_acc += now_ - dprof_t;                                                  \
+            dprof_cnt += 1;                                                               \
+        }                                                                                 \
+        dprof_t = now_;                                                                   \
+    } while (0)
+#define DPROF_END()                                                                       \
+    do {                                                                                  \
+        if (lane < 32) {                                                                  \
+            atomicAdd(&grbda_deriv_prof[lane], dprof_acc);                                \
+            atomicAdd(&grbda_deriv_prof[32 + lane], dprof_cnt);                           \
+        }                                                                                 \
+    } while (0)
+extern "C" int grbda_debug_deriv_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(grbda_deriv_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(grbda_deriv_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define DPROF_T0()
+#define DPROF_ADD(i)
+#define DPROF_END()
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // spatial helpers in the common frame
 // ---------------------------------------------------------------------------------------------------------------
@@ -216,6 +252,7 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
     Rows<T> R;
     R.p = scratch + (size_t)blockIdx.x * (size_t)n_rows * kWave + lane;
     const size_t n_tiles = (B + kWave - 1) / kWave;
+    DPROF_T0();
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t r = tile * kWave + lane;
         const size_t st = r < B ? r : B - 1;  // lanes past the end redo the last state and do not store
@@ -260,6 +297,10 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
         for (int j = 0; j < 9; j++) Rb[j] = Tb[j] = (j % 4 == 0) ? T(1) : T(0);
         const bool rpy = DP.ori_repr == 1;
         // ---- pass 1, root side first: kinematics in F of every body that has children ----
+        int last_gb = -1;
+        T last_kin[24];
+#pragma unroll
+        for (int j = 0; j < 24; j++) last_kin[j] = 0;
         for (int c = 0; c < n_clusters; c++) {
             const ClusterRec cr = load_rec(clusters + c);
             if (cr.kind == CK_FREE) {
@@ -294,6 +335,9 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                 }
                 const DerivBody x = load_rec(db + cr.first_body);
                 if (x.kin_row >= 0) R.st(x.kin_row, kin);
+                last_gb = cr.first_body;
+#pragma unroll
+                for (int j = 0; j < 24; j++) last_kin[j] = kin[j];
                 continue;
             }
             for (int i = 0; i < cr.k; i++) {
@@ -310,7 +354,12 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                     qddi += g * ydds[cr.v_index + a2];
                 }
                 T kp[24];
-                if (b.parent >= 0) {
+                if (b.parent >= 0 && b.parent == last_gb) {
+                    // (along a chain the parent is the body before: its kinematics are still in registers -- without this every body
+                    // waits for the store -> load round trip of its parent's slab row: ~10 k cycles per body in the phase profile)
+#pragma unroll
+                    for (int j = 0; j < 24; j++) kp[j] = last_kin[j];
+                } else if (b.parent >= 0) {
                     const DerivBody xp = load_rec(db + b.parent);
                     R.ld(xp.kin_row, kp);
                 } else {
@@ -347,8 +396,12 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                 }
                 R.st(x.kin_row, kin);
                 R.st(x.anc_row, anc);
+                last_gb = gb;
+#pragma unroll
+                for (int j = 0; j < 24; j++) last_kin[j] = kin[j];
             }
         }
+        DPROF_ADD(0);   // pass 1
         // ---- pass 2, leaf side first ----
         PartStore<T, sizeof(T) == 8 || kPartLdsF32> part;  // what the in-cluster roots of a cluster hand to the parent body: one read-modify-write per cluster, or
                      // no memory traffic at all along chains (DerivBody::carry_out: it stays here for the next cluster)
@@ -410,6 +463,7 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                         }
                     }
                 }
+                DPROF_ADD(4);   // base cluster
                 continue;
             }
             const int n = cr.n;
@@ -524,6 +578,7 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
 #pragma unroll
                     for (int j = 0; j < 6; j++) Fc[j] += acc[57 + j];
                 }
+                DPROF_ADD(1);   // body: records, kinematics (loads or recomputed), composites
                 // descendant-side vectors of this joint (Pd = Sd for a revolute joint)
                 T t1[6], t2[6], t3[6], t4[6];
                 mtv6(Bc, S, t1);
@@ -618,6 +673,7 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                     for (int j = 0; j < 6; j++) part.set(57 + j, part.get(57 + j) + Fc[j]);
                 }
             }
+            DPROF_ADD(2);   // body: joint terms, in-cluster ancestors, hand-over
             if (cr.parent_body >= 0 && !xf.carry_out) {
                 const DerivBody xp = load_rec(db + cr.parent_body);
                 T out[63];
@@ -642,6 +698,7 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                             put_h(cr.v_index + a2, cr.v_index + b2, Ch[a2][b2]);
                         }
             }
+            DPROF_ADD(3);   // accumulator row of the parent body, the cluster's own entries stored
             // ---- up the ancestors outside the cluster, block by block ----
 #ifdef GRBDA_EXP_NO_WALK
             int j = -1;
@@ -744,11 +801,15 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                             }
                 }
                 j = next;
+                DPROF_ADD(5);   // one ancestor cluster of the walk (rows, dot products, stores)
             }
+            DPROF_ADD(6);   // walk: the base's columns, loop exit
         }
+        DPROF_ADD(7);
         // entries between clusters on different branches are structural zeros: never written, and never read by the solve
         // (DerivProgram::related)
     }
+    DPROF_END();
 }
 
 template <class T, int IL>
