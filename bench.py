@@ -56,7 +56,8 @@ def kernel_sources_sha():
 
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "generalized_rbda_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+    # (device code AND the host code that picks kernels, waves per CU, chunking and the plan layout: capi.cpp, plan.cpp)
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -476,7 +477,7 @@ def main():
     # (only counters taken on THESE kernel sources: a file records the sha of the sources it was measured on)
     sha = kernel_sources_sha()
     traffic, traffic_src, stale = None, None, []
-    for fname in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):
+    for fname in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fname)) as f:
                 doc = json.load(f)
@@ -494,7 +495,7 @@ def main():
     # executed floating-point operations per evaluation from the committed instruction counters of the same launch
     # configuration (2 x FMA + ADD + MUL + TRANS, x 64 lanes / batch), beside the plan compiler's operation model
     flops_pmc, flops_pmc_src = None, None
-    for fname in ("r4_pmc_flops.json", "r3_pmc_flops.json"):
+    for fname in ("r5_pmc_flops.json", "r4_pmc_flops.json", "r3_pmc_flops.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fname)) as f:
                 doc = json.load(f)

@@ -304,6 +304,24 @@ int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, 
 
 // The per-(device, stream) work slab of the derived quantities, grown on demand under the same rule as ensure_scratch: never
 // while the stream captures (a graph captured earlier holds the old address).
+// Upper bound of a work-slab request of the chunked pipelines (derivatives, projection): what the call site asks for (1-4 GiB, sized so that a
+// million states go through in a few chunks), cut to a quarter of the memory that is FREE on the device right now (never below 256 MiB) and to
+// GRBDA_WORK_MAX_MB when that is set.  The slabs are kept per (device, stream) until grbda_plan_free and never shrink, so several streams or
+// plans could otherwise pin tens of GiB unnoticed (advisor, round 4).
+static size_t work_budget(size_t want)
+{
+    size_t cap = want;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+        size_t quarter = free_b / 4;
+        if (quarter < (256ull << 20)) quarter = 256ull << 20;
+        if (cap > quarter) cap = quarter;
+    }
+    const int mb = env_int("GRBDA_WORK_MAX_MB", 0);
+    if (mb > 0 && cap > (static_cast<size_t>(mb) << 20)) cap = static_cast<size_t>(mb) << 20;
+    return cap;
+}
+
 int ensure_work(const grbda_plan *p, std::map<std::pair<int, void *>, Scratch> &pool, int device, void *stream, size_t bytes, void **out)
 {
     std::lock_guard<std::recursive_mutex> lk(p->mu);
@@ -783,7 +801,7 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
         const size_t nq = p->host.nq, nv = p->host.nv, nq_s = p->span->host.nq, nv_s = p->span->host.nv;
         if (static_cast<size_t>(span_count(p)) != nv_s) return set_err(GRBDA_EUNSUPPORTED, "spanning layout mismatch");
         const size_t per_state = nq_s + nv_s + static_cast<size_t>(p->n_cpl_rows);
-        size_t chunk = (1024ull << 20) / (per_state * sizeof(T));
+        size_t chunk = work_budget(1024ull << 20) / (per_state * sizeof(T));
         chunk &= ~static_cast<size_t>(kWave - 1);
         if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
         const size_t b_round = (B + kWave - 1) / kWave * kWave;
@@ -1519,7 +1537,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     // (forward dynamics: H_s alone of the spanning recursion's three matrices is stored)
     const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : nn_s + 2 * nn);  // (wide: nn + nv would do)
     // (plans with big clusters: 40-50 KB per state; a chunk that leaves most SIMDs without a tile costs more than the memory)
-    size_t chunk = ((big ? 4096ull : 1024ull) << 20) / (per_state * sizeof(T));
+    size_t chunk = work_budget((big ? 4096ull : 1024ull) << 20) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     const size_t b_round = (B + kWave - 1) / kWave * kWave;
@@ -1571,7 +1589,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
             e = launch_manifold_apply<T>(d, p->host.n_clusters, t->span_v, t->crow, static_cast<int>(nv_s), p->n_cpl_rows, 2, x_s, x + b0 * nv, nullptr,
                                          cpl, Hinv, nb, static_cast<int>(grid), hs, big);
             if (e != hipSuccess) return hip_err(e, "manifold apply launch");
-            e = launch_spd_wide_solve<T>(Hw, t->related_table, Hinv, out + b0 * nv, static_cast<int>(nv), nb, t->n_cu, hs);
+            e = launch_spd_wide_solve<T>(Hw, t->related_table, Hinv, out + b0 * nv, static_cast<int>(nv), nb, t->n_cu, hs, spd_bad_count_address());
             if (e != hipSuccess) return hip_err(e, "wide solve launch");
             continue;
         }
@@ -1658,7 +1676,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     // matrices, the three projected matrices, ydd
     const size_t per_state = nq_s + 3 * nv_s + nv + static_cast<size_t>(p->n_cpl_rows) + 3 * nn_s + 3 * nn + nv;
     // (4 GiB: TelloWithArms takes 33 KB per state, and a 1 GiB chunk -- 32 768 states, 512 tiles -- left half of the SIMDs without one)
-    size_t chunk = (4096ull << 20) / (per_state * sizeof(T));
+    size_t chunk = work_budget(4096ull << 20) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     const size_t b_round = (B + kWave - 1) / kWave * kWave;
@@ -1776,7 +1794,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     // (only an INTERLEAVED H block can reach past the caller's array: the state-major layouts always build H in place)
     const bool h_in_place = dtau && (il == 1 || (B % kDerivGroup) == 0);
     const size_t per_state = (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
-    size_t chunk = (2048ull << 20) / (per_state ? per_state * sizeof(T) : 1);
+    size_t chunk = work_budget(2048ull << 20) / (per_state ? per_state * sizeof(T) : 1);
     chunk &= ~static_cast<size_t>(kWave - 1);  // whole tiles, whole groups of the interleaved workspace
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     if (chunk > B) chunk = (B + kDerivGroup - 1) / kDerivGroup * kDerivGroup;  // (the last group of the workspace is allocated whole)

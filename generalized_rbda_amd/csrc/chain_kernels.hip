@@ -1573,7 +1573,10 @@ __device__ __forceinline__ void free_fwd(const ChainTables<T> &P, const ChainMem
 }
 
 template <class T>
-__device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, const T (&y0)[6]);
+__device__ __forceinline__ void free_acc_inputs(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, T (&o)[4], T (&r)[3]);
+template <class T>
+__device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, const T (&y0)[6],
+                                              const T (&o)[4], const T (&r)[3], const T (&vb)[6]);
 template <class T, bool OSIM>
 __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, bool fuse_acc = false)
 {
@@ -1582,6 +1585,10 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
     T v[6], psi[6], IA[21];
 #pragma unroll
     for (int j = 0; j < 6; j++) v[j] = M.qd(f.v_index + j);
+    T o_[4] = {0, 0, 0, 0}, r_[3] = {0, 0, 0};
+    if constexpr (!OSIM) {
+        if (fuse_acc) free_acc_inputs(P, M, f, o_, r_);
+    }
     bias_force(Ic, v, psi);
     if (f.lds_acc != -1) {
         T acc[27];
@@ -1613,7 +1620,7 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
     ch.solve(u);
     if constexpr (!OSIM) {
         if (fuse_acc) {  // (every LDS read of this segment is behind us: the rows free_acc writes may alias the accumulators)
-            free_acc_core(P, M, f, u);
+            free_acc_core(P, M, f, u, o_, r_, v);
             return;
         }
     }
@@ -1630,17 +1637,23 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
     }
 }
 
-// (y0 in registers: the tail of free_bwd when the two segments are fused, ChainDev::fuse)
+// (y0 in registers: the tail of free_bwd when the two segments are fused, ChainDev::fuse; the base's seven positions are requested by
+// free_acc_inputs -- in the fused segment at its very start, next to the backward segment's own rows: one wait instead of two)
 template <class T>
-__device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, const T (&y0)[6])
+__device__ __forceinline__ void free_acc_inputs(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, T (&o)[4], T (&r)[3])
 {
-    T o[4], E[9], r[3], g[6], ag[6];
     const int nori = P.ori_repr == 0 ? 4 : 3;
 #pragma unroll
     for (int j = 0; j < 4; j++) o[j] = j < nori ? M.q(f.q_index + 3 + j) : T(0);
-    free_rotation(P.ori_repr, o, E);
 #pragma unroll
     for (int j = 0; j < 3; j++) r[j] = M.q(f.q_index + j);
+}
+template <class T>
+__device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f, const T (&y0)[6],
+                                              const T (&o)[4], const T (&r)[3], const T (&vb)[6])
+{
+    T E[9], g[6], ag[6];
+    free_rotation(P.ori_repr, o, E);
 #pragma unroll
     for (int j = 0; j < 6; j++) g[j] = P.a_root[j];
     xmotion(E, r, g, ag);
@@ -1651,7 +1664,7 @@ __device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const Cha
         T va[12];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            va[j] = M.qd(f.v_index + j);
+            va[j] = vb[j];
             va[6 + j] = y0[j];
         }
         M.lds_st(f.lds_va, va);
@@ -1660,9 +1673,12 @@ __device__ __forceinline__ void free_acc_core(const ChainTables<T> &P, const Cha
 template <class T>
 __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem<T> &M, const ChainFree &f)
 {
-    T y0[6];
+    T y0[6], o[4], r[3], vb[6];
     M.glb_ld(f.glb_y0, y0);
-    free_acc_core(P, M, f, y0);
+    free_acc_inputs(P, M, f, o, r);
+#pragma unroll
+    for (int j = 0; j < 6; j++) vb[j] = M.qd(f.v_index + j);
+    free_acc_core(P, M, f, y0, o, r, vb);
 }
 
 #include "gen_segments.h"

@@ -895,6 +895,11 @@ __device__ __forceinline__ double lane_value(double x, int l)
 // that a caller can ASK (grbda_spd_bad_pivots, include/grbda_hip.h) instead of scanning nv^2 numbers per state.
 __device__ unsigned long long grbda_spd_bad_count = 0;
 #include "tree_solve.h"
+unsigned long long *spd_bad_count_address()
+{
+    void *p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(grbda_spd_bad_count)) == hipSuccess ? static_cast<unsigned long long *>(p) : nullptr;
+}
 hipError_t spd_bad_pivots(unsigned long long *count, int reset)
 {
     hipError_t e = hipDeviceSynchronize();

@@ -213,7 +213,11 @@ hipError_t launch_manifold_state(const DevPlan<T> &P, int n_clusters, const Stat
 template <class T>
 hipError_t launch_manifold_newton(const DevPlan<T> &P, int n_clusters, T *q, int32_t *ok, size_t B, int max_iter, T tol, int grid, hipStream_t stream);
 template <class T>
-hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream);
+hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream,
+                                 unsigned long long *bad_count);
+// device address of the bad-pivot counter of the SPD solves (deriv_kernels.hip; nullptr when it cannot be resolved): the solve of the wide
+// route (manifold_kernels.hip, another translation unit) counts into the same word
+unsigned long long *spd_bad_count_address();
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
 // branch-sparse L^T L solve (tree_solve.h): eight states per wavefront, the right-hand sides as IO.kind says (0 identity, 1 / 2 packed runs)
 struct TreeSolveDev {

@@ -817,7 +817,9 @@ hipError_t launch_manifold_project_wide(const DevPlan<T> &P, int n_clusters, con
     const size_t lds = kBigClusterBodies * kWave * sizeof(T);
     size_t per_cu = (160u * 1024u) / lds;
     if (per_cu > 16) per_cu = 16;
-    size_t g = static_cast<size_t>(grid) / 4 * per_cu;
+    // (the caller's grid is four wavefronts per CU, or the number of tiles when that is smaller: round UP to whole CUs -- grid / 4 was zero
+    // for batches of fewer than four tiles, and every tile of such a batch ran on one wavefront)
+    size_t g = (static_cast<size_t>(grid) + 3) / 4 * per_cu;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     if (g > n_tiles) g = n_tiles;
     if (g < 1) g = 1;
@@ -1124,7 +1126,8 @@ __global__ __launch_bounds__(4 * kWave) void spd_wide_solve_kernel(const T *__re
     }
 }
 template <class T>
-hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream)
+hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, T *out, int nv, size_t B, int n_cu, hipStream_t stream,
+                                 unsigned long long *bad_count)
 {
     const size_t lds = ((size_t)nv * (nv + 1) / 2 + nv) * sizeof(T);
     size_t per_cu = (160u * 1024u) / lds;
@@ -1138,11 +1141,13 @@ hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, 
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((spd_wide_solve_kernel<T>), dim3(static_cast<unsigned>(g)), dim3(4 * kWave), lds, stream, H, relt, rhs, out, nv, B,
-                       static_cast<unsigned long long *>(nullptr));
+                       bad_count);
     return hipGetLastError();
 }
-template hipError_t launch_spd_wide_solve<float>(const float *, const int32_t *, const float *, float *, int, size_t, int, hipStream_t);
-template hipError_t launch_spd_wide_solve<double>(const double *, const int32_t *, const double *, double *, int, size_t, int, hipStream_t);
+template hipError_t launch_spd_wide_solve<float>(const float *, const int32_t *, const float *, float *, int, size_t, int, hipStream_t,
+                                                 unsigned long long *);
+template hipError_t launch_spd_wide_solve<double>(const double *, const int32_t *, const double *, double *, int, size_t, int, hipStream_t,
+                                                  unsigned long long *);
 
 template <class T>
 hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, const uint64_t *rel,

@@ -7,6 +7,11 @@ sys.path.insert(0, ROOT)
 from bench import kernel_sources_sha  # the counters are valid for these device sources only (bench.py refuses others)
 rnd, src = sys.argv[1], sys.argv[2]
 P = os.path.join(ROOT, "profiles")
+# the sha the run recorded on the GPU box (tools/round_profiles.sh); a run without one is stamped with the current sources
+_sha_file = os.path.join(src, "kernel_sources_sha.txt")
+measured_sha = open(_sha_file).read().strip() if os.path.exists(_sha_file) else kernel_sources_sha()
+if measured_sha != kernel_sources_sha():
+    print(f"WARNING: counters were measured on kernel sources {measured_sha}, the tree is at {kernel_sources_sha()}: bench.py will refuse them")
 
 
 def cp(rel, name):
@@ -29,7 +34,7 @@ cp("pmc_flops.json", "pmc_flops.json")
 fl = os.path.join(P, f"{rnd}_pmc_flops.json")
 if os.path.exists(fl):
     doc = json.load(open(fl))
-    doc["kernel_sources_sha"] = kernel_sources_sha()
+    doc["kernel_sources_sha"] = measured_sha
     json.dump(doc, open(fl, "w"), indent=1)
 cp("traffic_calibration.txt", "traffic_calibration.txt")
 cp("bench/manifold_derivatives.txt", "manifold_derivatives.txt")
@@ -58,5 +63,5 @@ if os.path.exists(raw):
                         "bytes_per_launch": total, "bytes_per_state": round(total / batch, 1), "kernel": kern})
     old = os.path.join(P, f"{rnd}_pmc_traffic.json")
     comment = json.load(open(old))["_comment"] if os.path.exists(old) else "bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
-    json.dump({"_comment": comment, "kernel_sources_sha": kernel_sources_sha(), "entries": entries}, open(old, "w"), indent=1)
+    json.dump({"_comment": comment, "kernel_sources_sha": measured_sha, "entries": entries}, open(old, "w"), indent=1)
     print(f"{rnd}_pmc_traffic.json  <-  prof/traffic.txt ({len(entries)} entries)")

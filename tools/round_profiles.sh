@@ -8,6 +8,9 @@ R=${1:-r3}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd $ROOT
+# the sha of the kernel sources the counters below are MEASURED on (tools/collect_profiles.py stamps the JSON files with this value, not
+# with the sources at collection time)
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from bench import kernel_sources_sha; print(kernel_sources_sha())" > $OUT/kernel_sources_sha.txt
 bash tools/bench_all.sh $R/bench > $OUT/bench_all.log 2>&1
 bash tools/profile_round.sh $R/prof > $OUT/profile_round.log 2>&1
 # instruction counters: the sets with the floating-point instruction classes (1: f32, 5-6: f64) and the cycle counters (3-4)
