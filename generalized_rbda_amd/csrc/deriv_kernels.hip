@@ -233,6 +233,23 @@ struct PartStore {
 #ifndef GRBDA_EXP_DERIV_WPS
 #define GRBDA_EXP_DERIV_WPS 1
 #endif
+// (experiment builds: -DGRBDA_EXP_ANC_LEVELS=n keeps n levels of the ancestor-row cache in LDS instead of kDerivAncLevels -- the cache is 4.6 KB per
+// level and wavefront, 36.9 KB at eight levels: FOUR wavefronts per CU whatever the register count)
+// Round 5: the cache is OFF by default (0 levels) -- with it or without it the kernel takes the same time (28.0 against 28.7 ms per million
+// JVRC-1 states, profiles/r5_deriv_recursion_experiments.txt) -- and its LDS holds the tile's staged inputs instead (kStageInputsF32).
+#ifndef GRBDA_EXP_ANC_LEVELS
+#define GRBDA_EXP_ANC_LEVELS 0
+#endif
+// fp32: the tile's q / qd / ydd blocks are copied to LDS once (coalesced LDS-DMA, as the chain kernels stage theirs) and every body reads its
+// coordinates from the lane's own row there.  Read straight from the caller's arrays they are 4-byte accesses 150 bytes apart: 64 cache
+// lines per load instruction, three loads per body in pass 1 and again per leaf body in pass 2 -- the counters showed 27 KB fetched per state
+// for a kernel whose slab rows account for 12 (profiles/r5_rocprofv3_pmc_derivatives.txt; the kernel moves 4.5 TB/s at the fabric).
+#ifndef GRBDA_EXP_NO_STAGE
+constexpr bool kStageInputsF32 = true;
+#else
+constexpr bool kStageInputsF32 = false;
+#endif
+constexpr int kAncLevelsLds = GRBDA_EXP_ANC_LEVELS;
 #ifdef GRBDA_EXP_PART_LDS
 constexpr bool kPartLdsF32 = true;
 #else
@@ -262,6 +279,24 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
         const bool live = r < B;
 #endif
         const T *qs = q + st * (size_t)nq, *qds = qd + st * (size_t)nv, *ydds = ydd + st * (size_t)nv;
+        if constexpr (sizeof(T) == 4 && kStageInputsF32) {
+            // (lanes past the end of the batch read the last valid row, as they redo the last state)
+            const size_t left = B - tile * kWave;
+            const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+            const unsigned in0 = (unsigned)((kPartLdsF32 ? 63 * kWave : 0) + kAncLevelsLds * 18 * kWave) * (unsigned)sizeof(T);
+            const unsigned bq = (unsigned)(kWave * nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * nv) * (unsigned)sizeof(T);
+            wave_lds_fence();  // the previous tile's reads of the block are done
+            stage_issue(q, tile, rows_valid, nq, in0, lane);
+            stage_issue(qd, tile, rows_valid, nv, in0 + bq, lane);
+            stage_issue(ydd, tile, rows_valid, nv, in0 + bq + bv, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            const int my = lane < rows_valid ? lane : rows_valid - 1;
+            const T *blk = reinterpret_cast<const T *>(deriv_smem + in0);
+            qs = blk + my * nq;
+            qds = blk + kWave * nq + my * nv;
+            ydds = blk + kWave * (nq + nv) + my * nv;
+        }
         // output layout, per state and matrix nv^2 entries: coordinate r owns the run [r^2, (r + 1)^2): first d tau_r / d x_c
         // for c = 0 .. r, then d tau_c / d x_r for c = 0 .. r-1.  Every store of a coordinate's pass (its own cluster, then
         // ancestor by ancestor) lands in that coordinate's run, so a cache line is completed by consecutive instructions
@@ -746,7 +781,7 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                     T anc[18], Sj[6], Sdj[6], Pddj[6];
                     if constexpr (sizeof(T) == 4) {
                         // (wave-uniform: the block's validity was worked out by the plan compiler, DerivBody::walk_resident)
-                        if (xb.anc_lds >= 0) {
+                        if (xb.anc_lds >= 0 && xb.anc_lds < kAncLevelsLds) {
                             T *blk = anc_cache + xb.anc_lds * 18 * kWave;
                             if ((xf.walk_resident >> xb.anc_lds) & 1) {
 #pragma unroll
@@ -817,7 +852,8 @@ static hipError_t launch_rnea_deriv_il(const DevPlan<T> &P, const DerivBody *db,
                                        const T *qd, const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream)
 {
     const size_t part_lds = ((sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0)   // PartStore
-                            + (sizeof(T) == 4 ? kDerivAncLevels * 18 * kWave * sizeof(T) : 0);  // fp32: ancestor-row cache
+                            + (sizeof(T) == 4 ? kAncLevelsLds * 18 * kWave * sizeof(T) : 0)  // fp32: ancestor-row cache
+                            + ((sizeof(T) == 4 && kStageInputsF32) ? static_cast<size_t>(kWave) * (P.nq + 2 * P.nv) * sizeof(T) : 0);  // staged inputs
     if (n_max <= 1)
         hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, IL>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
@@ -840,7 +876,8 @@ hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clu
     if (interleave == kWave && n_max <= 1) {
         // tile-interleaved results [tile][entry][lane]: what a one-state-per-lane consumer reads as coalesced rows (the
         // spanning-tree pass of manifold_kernels.hip; single-body clusters only)
-        const size_t part_lds = ((sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0) + (sizeof(T) == 4 ? kDerivAncLevels * 18 * kWave * sizeof(T) : 0);
+        const size_t part_lds = ((sizeof(T) == 8 || kPartLdsF32) ? 63 * kWave * sizeof(T) : 0) + (sizeof(T) == 4 ? kAncLevelsLds * 18 * kWave * sizeof(T) : 0) +
+                                ((sizeof(T) == 4 && kStageInputsF32) ? static_cast<size_t>(kWave) * (P.nq + 2 * P.nv) * sizeof(T) : 0);
         hipLaunchKernelGGL((rnea_deriv_kernel<T, 1, kWave>), dim3(grid), dim3(kWave), part_lds, stream, P, db, n_clusters, n_rows, q, qd, ydd, Dq,
                            Dqd, H, B, scratch);
         return hipGetLastError();
