@@ -467,6 +467,36 @@ def test_position_derivative_matches_oracle_differences(name, gpu):
     assert np.abs(J32 - J_of_32).max() / scale < (1e-3 if implicit else 2e-4)
 
 
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "urdf_jvrc1_humanoid", "tree_mixed_fixed", "rev_rotor_chain_4"])
+def test_branch_sparse_solve_matches_the_matrix_core_solve(name, gpu, monkeypatch):
+    """The opt-in branch-sparse solve (csrc/tree_solve.h: the reference's H = L^T L over the expanded parent array, Factorization.cpp:9-36;
+    GRBDA_TREE_SOLVE=1) against the default route (dense Cholesky + matrix-core GEMMs) on the same states: all three derivative matrices,
+    fp64 to 1e-9 and fp32 to 2e-4 of the matrix scale; 133 states (tiles of eight states, a ragged one)."""
+    import torch
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    if not plan.info().analytic_derivatives:
+        pytest.skip("explicit models only")
+    q, qd, tau = valid_states(blob, 133, config_index=17)
+    for dt, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+        monkeypatch.delenv("GRBDA_TREE_SOLVE", raising=False)
+        ref = plan.fd_derivatives(t(q), t(qd), t(tau))
+        ref_tau = plan.fd_dtau(t(q))
+        monkeypatch.setenv("GRBDA_TREE_SOLVE", "1")
+        got = plan.fd_derivatives(t(q), t(qd), t(tau))
+        got_tau = plan.fd_dtau(t(q))
+        got_dq = plan.fd_dq(t(q), t(qd), t(tau))
+        monkeypatch.delenv("GRBDA_TREE_SOLVE", raising=False)
+        for k in ("dq", "dqd", "dtau"):
+            a, b = got[k].double(), ref[k].double()
+            assert torch.isfinite(a).all()
+            assert float((a - b).abs().max() / (1.0 + b.abs().max())) < tol, (k, str(dt))
+        assert float((got_tau.double() - ref_tau.double()).abs().max() / (1.0 + ref_tau.abs().max())) < tol
+        assert float((got_dq.double() - ref["dq"].double()).abs().max() / (1.0 + ref["dq"].abs().max())) < tol
+
+
 @pytest.mark.parametrize("name", ["urdf_four_bar", "urdf_planar_leg_linkage"])
 def test_manifold_dq_against_extended_precision_differences(name, gpu):
     """d ydd / d q of implicit clusters NEAR SINGULAR POSES, without a conditioning filter: the analytic route through the spanning tree
