@@ -858,13 +858,15 @@ public:
     }
 
     // The root finder behind randomJointState() of an implicit cluster (GenericJoint.cpp:289-361): the cluster's spanning positions at
-    // [q0, q0 + k) of the model's position vector.  Every implicit cluster of the model is drawn (independent coordinates U(-1, 1), dependent
-    // guess U(-0.1, 0.1)) and projected by the library's Newton kernel in one call -- its verdict covers the whole state --, the explicit ones
-    // rest at zero; up to 45 draws, then the reference's error.
-    std::function<JointCoordinate<double>()> rootFinder(int q0, int k, const std::vector<bool> &independent)
+    // [q0, q0 + k) of the model's position vector.  The REQUESTED cluster is drawn (independent coordinates U(-1, 1), dependent guess
+    // U(-0.1, 0.1)) and projected by the library's Newton kernel; the other implicit clusters rest at the last state the kernel accepted (its
+    // verdict covers the whole state, so a cluster that is hard to converge must not spend the budget of the others -- the reference solves
+    // per cluster) and are drawn only while no such state exists; the explicit ones rest at zero.  Up to 45 draws, then the reference's error.
+    std::function<JointCoordinate<double>()> rootFinder(int q0, int k, const std::vector<bool> &)
     {
-        return [this, q0, k, independent]() {
+        return [this, q0, k]() {
             const int nq_all = this->position_index_;
+            const bool cached = static_cast<int>(valid_q_cache_.size()) == nq_all;
             for (int attempt = 0; attempt < 45; attempt++) {
                 std::vector<double> q(nq_all, 0.0);
                 for (const auto &node : cluster_nodes_) {
@@ -872,6 +874,10 @@ public:
                     if (lc->kind == GRBDA_CONSTRAINT_FREE) {
                         if (node->num_positions_ == 7) q[node->position_index_ + 3] = 1.0;  // the identity quaternion
                     } else if (!lc->isExplicit()) {
+                        if (cached && node->position_index_ != q0) {
+                            for (int i = 0; i < node->num_positions_; i++) q[node->position_index_ + i] = valid_q_cache_[node->position_index_ + i];
+                            continue;
+                        }
                         const DVec<double> r = DVec<double>::Random(node->num_positions_);
                         for (int i = 0; i < node->num_positions_; i++)
                             q[node->position_index_ + i] = (i < static_cast<int>(lc->independent.size()) && lc->independent[i]) ? r[i] : 0.1 * r[i];
@@ -879,7 +885,10 @@ public:
                 }
                 int32_t ok = 0;
                 check(grbda_project_positions_host_f64(plan(), q.data(), &ok, 1, 50, 1e-8, 0));
-                if (ok) return JointCoordinate<double>(DVec<double>(q.begin() + q0, q.begin() + q0 + k), true);
+                if (ok) {
+                    valid_q_cache_ = q;
+                    return JointCoordinate<double>(DVec<double>(q.begin() + q0, q.begin() + q0 + k), true);
+                }
             }
             throw std::runtime_error("Failed to find valid roots for implicit loop constraint");
         };
@@ -1479,6 +1488,7 @@ private:
     bool from_urdf_ = false;
     int n_bodies_urdf_ = 0;
     grbda_plan *plan_ = nullptr;
+    std::vector<double> valid_q_cache_;  // the last full position vector the Newton projection accepted (rootFinder)
 };
 
 }  // namespace grbda
