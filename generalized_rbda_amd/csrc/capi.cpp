@@ -135,6 +135,8 @@ struct grbda_plan {
     bool rnea_narrow = false;  // GRBDA_RNEA_NARROW=1: the inverse-dynamics chain kernel stays at two wavefronts per SIMD
     bool no_analytic = false;  // GRBDA_NO_ANALYTIC=1: derivatives by the unit-vector / central-difference batches only
     bool solve_f64 = false;    // GRBDA_SOLVE_F64=1: the SPD solve of the f32 derivative entry points computes in f64
+    int gen1_tiles_per_wave = 0;   // GRBDA_GEN1_TILES_PER_WAVE > 0: grid = tiles / this (the dispatcher balances the workgroups)
+    int gen1_waves_cap = 0;        // GRBDA_GEN1_WAVES_PER_CU > 0: wavefronts per CU of the single-cluster kernels (experiments)
     bool no_latency_mode = false;  // GRBDA_NO_LATENCY_MODE=1: small batches keep the one-wavefront-per-tile kernel
     int crba_waves = 16;       // GRBDA_CRBA_WAVES_PER_CU: grid of the composite-rigid-body kernel (fp32: 99 registers, four wavefronts per SIMD:
                                // JVRC-1 mass matrix 1.95 -> 1.81 ms per 262 144 states against eight per CU; fp64 is capped at eight)
@@ -392,12 +394,18 @@ size_t lm_lds_bytes(const grbda_plan *p)
     const size_t lds_lm = static_cast<size_t>(lp.n_lds) * kWave * sizeof(T);
     return lds_lm < stage_all ? stage_all : lds_lm;
 }
+// the single-cluster kernels prefetch a state's positions into min(n + 3, 8) registers (implicit cluster: one per body) or n (explicit)
+static bool gen1_positions_fit(int nq, const ChainGen &g)
+{
+    const int room = g.kind ? std::min(g.n + 3, kMaxClusterBodies) : g.n;
+    return nq <= room && g.n <= 4;
+}
 template <class T>
 size_t gen1_lds_bytes(const grbda_plan *p)
 {
     const HostPlan &h = p->host;
     const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
-    return static_cast<size_t>(sp.n_lds) * kWave * sizeof(T) + 2 * static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
+    return static_cast<size_t>(sp.n_lds) * kWave * sizeof(T) + static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
 }
 template <class T>
 AbaPath choose_aba(const grbda_plan *p, int n_cu, size_t B, bool f_ext)
@@ -406,7 +414,7 @@ AbaPath choose_aba(const grbda_plan *p, int n_cu, size_t B, bool f_ext)
     if (f_ext || !chain_covers<T>(p)) return ABA_INTERPRETER;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
-    if (sp.ok && sp.single_gen && !p->chain_debug && gen1_lds_bytes<T>(p) <= 65536) return ABA_GEN1;
+    if (sp.ok && sp.single_gen && !p->chain_debug && gen1_lds_bytes<T>(p) <= 65536 && gen1_positions_fit(h.nq, sp.gens[0])) return ABA_GEN1;
     const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
     if (lp.ok && !p->no_latency_mode && !p->chain_debug && n_tiles <= static_cast<size_t>(n_cu) * 4 && n_tiles > 0 && lm_lds_bytes<T>(p) <= 40960)
         return ABA_LM;
@@ -426,7 +434,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
         const int w1 = sizeof(T) == 8 ? 2 : 0;
         const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
         const size_t work = static_cast<size_t>(sp.n_lds) * kWave * sizeof(T);
-        const size_t lds_total = gen1_lds_bytes<T>(p);  // work area + two input buffers
+        const size_t lds_total = gen1_lds_bytes<T>(p);  // work area + the staged input rows
         if (path == ABA_GEN1) {
             ChainDev<T> d;
             std::memset(&d, 0, sizeof d);
@@ -442,9 +450,11 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.lds_bytes = static_cast<int>(work);
             for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
             size_t per_cu = static_cast<size_t>(gen1_waves_per_simd<T>(sp.gens[0].n)) * 4;
-            const size_t fit = (160u * 1024u) / lds_total;
+            const size_t fit = lds_workgroups_per_cu(lds_total);
             if (fit < per_cu) per_cu = fit;
+            if (p->gen1_waves_cap > 0 && static_cast<size_t>(p->gen1_waves_cap) < per_cu) per_cu = static_cast<size_t>(p->gen1_waves_cap);
             size_t grid = static_cast<size_t>(t.n_cu) * per_cu;
+            if (p->gen1_tiles_per_wave > 0) grid = (n_tiles0 + p->gen1_tiles_per_wave - 1) / p->gen1_tiles_per_wave;
             if (grid > n_tiles0) grid = n_tiles0;
             hipError_t e = launch_aba_gen1<T>(d, sp.gens[0].n, sp.gens[0].kind != 0, q, qd, tau, ydd, B, static_cast<int>(grid), lds_total,
                                               static_cast<hipStream_t>(stream));
@@ -546,7 +556,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     if (lds_bytes < stage_all && stage_all <= lds_budget) lds_bytes = stage_all;
     d.lds_bytes = static_cast<int>(lds_bytes);
     if (lds_bytes < stage_all) d.fuse &= ~1;  // (the prologue stages one array at a time: the velocities are gone when it returns)
-    const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
+    const size_t fit = lds_workgroups_per_cu(lds_bytes);
     if (fit >= 1 && fit < waves_per_cu) {
         const size_t g2 = static_cast<size_t>(t.n_cu) * fit;
         if (grid > g2) grid = g2;
@@ -557,6 +567,20 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     hipError_t e = launch_aba_chain<T>(d, q, qd, tau, ydd, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
                                            static_cast<hipStream_t>(stream), wide);
     return e == hipSuccess ? GRBDA_OK : hip_err(e, "aba chain launch");
+}
+
+template <class T>
+size_t rnea_gen1_lds_bytes(const grbda_plan *p)
+{
+    const HostPlan &h = p->host;
+    const RneaChainProgram &rp = sizeof(T) == 8 ? h.rchain64 : h.rchain32;
+    return static_cast<size_t>(rp.n_lds) * kWave * sizeof(T) + static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
+}
+template <class T>
+bool rnea_gen1_usable(const grbda_plan *p)
+{
+    const RneaChainProgram &rp = sizeof(T) == 8 ? p->host.rchain64 : p->host.rchain32;
+    return rp.ok && rp.single_gen && !p->chain_debug && rnea_gen1_lds_bytes<T>(p) <= 65536 && gen1_positions_fit(p->host.nq, rp.gens[0]);
 }
 
 template <class T>
@@ -574,6 +598,31 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
                       n_tiles > static_cast<size_t>(t.n_cu) * 8;
     const int w = wide ? 2 : kid;
     const RneaChainProgram &rp = wide ? h.rchain32w : (kid ? h.rchain64 : h.rchain32);
+    if (rnea_gen1_usable<T>(p)) {  // single-cluster programs: the fused, slab-free kernel (chain_kernels.hip, rnea_gen1_kernel)
+        RneaChainDev<T> d;
+        std::memset(&d, 0, sizeof d);
+        d.gens = t.rchain_gens[kid];
+        d.gbodies = t.rchain_gbodies[kid];
+        d.n_gens = 1;
+        d.cints = t.cints;
+        d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
+        d.nq = h.nq;
+        d.nv = h.nv;
+        d.ori_repr = h.ori_repr;
+        d.lds_bytes = static_cast<int>(static_cast<size_t>(rp.n_lds) * kWave * sizeof(T));
+        for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+        const size_t lds_total = rnea_gen1_lds_bytes<T>(p);  // work area + the staged input rows
+        size_t per_cu = static_cast<size_t>(rnea_gen1_waves_per_simd<T>(rp.gens[0].n)) * 4;
+        const size_t fit = lds_workgroups_per_cu(lds_total);
+        if (fit < per_cu) per_cu = fit;
+        if (p->gen1_waves_cap > 0 && static_cast<size_t>(p->gen1_waves_cap) < per_cu) per_cu = static_cast<size_t>(p->gen1_waves_cap);
+        size_t grid = static_cast<size_t>(t.n_cu) * per_cu;
+        if (p->gen1_tiles_per_wave > 0) grid = (n_tiles + p->gen1_tiles_per_wave - 1) / p->gen1_tiles_per_wave;
+        if (grid > n_tiles) grid = n_tiles;
+        hipError_t e = launch_rnea_gen1<T>(d, rp.gens[0].n, rp.gens[0].kind != 0, q, qd, ydd, tau, B, static_cast<int>(grid), lds_total,
+                                           static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? GRBDA_OK : hip_err(e, "rnea single-cluster launch");
+    }
     RneaChainDev<T> d;
     d.segs = t.rchain_segs[w];
     d.links = t.rchain_links[w];
@@ -602,7 +651,7 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
     if (lds_bytes < stage_one) lds_bytes = stage_one;
     if (lds_bytes < stage_all && stage_all <= lds_budget) lds_bytes = stage_all;
     d.lds_bytes = static_cast<int>(lds_bytes);
-    const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
+    const size_t fit = lds_workgroups_per_cu(lds_bytes);
     if (fit >= 1 && fit < waves_per_cu) {
         const size_t g2 = static_cast<size_t>(t.n_cu) * fit;
         if (grid > g2) grid = g2;
@@ -662,7 +711,7 @@ int run(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T *x, con
     if (lds_bytes < stage_all && stage_all <= static_cast<size_t>(p->lds_bytes_per_wave[kid])) lds_bytes = stage_all;
     d.lds_bytes = static_cast<int>(lds_bytes);
     // a CU holds 160 KiB of LDS: never launch more persistent wavefronts than can be resident at once
-    const size_t fit = lds_bytes ? (160u * 1024u) / lds_bytes : 32;
+    const size_t fit = lds_workgroups_per_cu(lds_bytes);
     if (fit >= 1 && fit < waves_per_cu) {
         const size_t g2 = static_cast<size_t>(t->n_cu) * fit;
         if (grid > g2) grid = g2;
@@ -1597,7 +1646,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
                                        p->n_cpl_rows, 1, nullptr, nullptr, Hs, nullptr, cpl, nullptr, nullptr, Hw, nb, static_cast<int>(grid), hs, 1, big);
         if (e != hipSuccess) return hip_err(e, "manifold projection launch");
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), sizeof(T), 0);
-        size_t per_cu = lds ? (160u * 1024u) / lds : 16;
+        size_t per_cu = lds ? lds_workgroups_per_cu(lds) : 16;
         if (per_cu > 16) per_cu = 16;
         if (per_cu < 1) per_cu = 1;
         size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
@@ -1738,7 +1787,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             continue;
         }
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), sizeof(T), n_rhs);
-        size_t per_cu = lds ? (160u * 1024u) / lds : 16;
+        size_t per_cu = lds ? lds_workgroups_per_cu(lds) : 16;
         const bool mfma = need_d && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs);
         if (per_cu > (mfma ? 2u : 16u)) per_cu = mfma ? 2 : 16;
         if (per_cu < 1) per_cu = 1;
@@ -1862,7 +1911,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             if (dtau) { io.kind[nm] = 0; io.src[nm] = nullptr; io.dst[nm] = o3; nm++; }
             const size_t lds_t = tree_solve_lds_bytes(tp.n, tp.nl, sizeof(T));
             size_t wpc = sizeof(T) == 4 ? 8 : 4;
-            if (lds_t && wpc > (160u * 1024u) / lds_t) wpc = (160u * 1024u) / lds_t;
+            if (lds_t && wpc > lds_workgroups_per_cu(lds_t)) wpc = lds_workgroups_per_cu(lds_t);
             if (wpc < 1) wpc = 1;
             size_t gt = static_cast<size_t>(t->n_cu) * wpc;
             const size_t tiles8 = (nb + 7) / 8;
@@ -1874,7 +1923,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         // one wavefront per state; as many as the LDS of a CU holds
         const bool wide = sizeof(T) == 4 && p->solve_f64;
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), wide ? 8 : sizeof(T), (dq ? 1 : 0) + (dqd ? 1 : 0));
-        size_t per_cu = lds ? (160u * 1024u) / lds : 16;
+        size_t per_cu = lds ? lds_workgroups_per_cu(lds) : 16;
         const bool mfma = !wide && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs);
         if (per_cu > (mfma ? 2u : 16u)) per_cu = mfma ? 2 : 16;  // (matrix-core kernel: workgroups of four wavefronts, two wavefronts per SIMD)
         if (per_cu < 1) per_cu = 1;
@@ -1934,6 +1983,11 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
     const bool chain = !p->no_chain && (sizeof(T) == 8 ? h.rchain64.ok : h.rchain32.ok);
     if (chain) {
         const RneaChainProgram &rp = sizeof(T) == 8 ? h.rchain64 : h.rchain32;
+        if (rnea_gen1_usable<T>(p)) {
+            std::snprintf(buf, sizeof buf, "grbda_hip::rnea_gen1_kernel<%s, %d, %s, %d>", tn, rp.gens[0].n, rp.gens[0].kind ? "true" : "false",
+                          rnea_gen1_waves_per_simd<T>(rp.gens[0].n));
+            return buf;
+        }
         std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_kernel<%s, %d, %s>", tn, !rp.gens.empty() ? 2 : (rp.diffs.empty() ? 0 : 1), rp.n_glb > 0 ? "true" : "false");
         return buf;
     }
@@ -2083,6 +2137,8 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->no_split = env_int("GRBDA_NO_SPLIT", 0) != 0;
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;
     p->no_latency_mode = env_int("GRBDA_NO_LATENCY_MODE", 0) != 0;
+    p->gen1_waves_cap = env_int("GRBDA_GEN1_WAVES_PER_CU", 0);
+    p->gen1_tiles_per_wave = env_int("GRBDA_GEN1_TILES_PER_WAVE", 0);
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
 #ifdef GRBDA_EXP
     // ablation switches of tools/chain_ablate.py: results are WRONG when set, so the product library does not read them -- only

@@ -1688,24 +1688,82 @@ __device__ __forceinline__ void free_acc(const ChainTables<T> &P, const ChainMem
 // Single-cluster programs (ChainProgram::single_gen): ONE generic cluster on the ground and nothing else -- the URDF+ loop
 // mechanisms of BASELINE config 5 (four_bar.urdf, six_bar.urdf), a triple cluster on a bench.  The whole forward dynamics is the
 // cluster's downward pass, its upward pass and ydd = y0 - K a_root, so the kernel is specialised on (n, implicit?) at compile time
-// and touches no slab at all: the tile's inputs stay in LDS as the asynchronous copy left them (row-major [state][column] blocks,
-// every lane reads its own row), results go straight to the caller's array.  With 3-5 input columns per state the tile is bound by
-// the latency of its few dependent memory round trips, not by instructions: small register footprints (N = 1: four wavefronts
-// per SIMD) and no global round trip inside the tile are what count.
+// and touches no slab at all; results go straight to the caller's array.
 // ---------------------------------------------------------------------------------------------------------------
+// The tile is bound by the latency of its dependent LDS round trips and by instruction issue, so what counts is how many wavefronts
+// the LDS of a CU holds: the inputs of the NEXT tile travel into registers while this one computes (every lane loads its own row:
+// the tile's rows are one contiguous block, every byte of every cache line is used) and are written to ONE set of LDS rows
+// [column][lane] at the top of their tile -- half the staging area of a double-buffered asynchronous copy, which is a wavefront
+// more per CU on six_bar (devplan.h, lds_workgroups_per_cu).
 template <class T>
-struct ChainMemL : ChainMem<T> {
-    int in_q, in_qd, in_x;  // element offsets of the staged blocks in LDS
-    int ncq, ncv;
+struct ChainMemC : ChainMem<T> {
+    int in_q, in_qd, in_x;  // first LDS rows of the staged blocks ([column][lane])
     T *out_g;               // this lane's result row (nullptr: a lane beyond the batch)
-    __device__ __forceinline__ T q(int j) const { return reinterpret_cast<const T *>(grbda_smem)[in_q + this->lane * ncq + j]; }
-    __device__ __forceinline__ T qd(int j) const { return reinterpret_cast<const T *>(grbda_smem)[in_qd + this->lane * ncv + j]; }
-    __device__ __forceinline__ T x(int j) const { return reinterpret_cast<const T *>(grbda_smem)[in_x + this->lane * ncv + j]; }
-    __device__ __forceinline__ void put_f(int j, T v) const
+    __device__ __forceinline__ T q(int j) const { return reinterpret_cast<const T *>(grbda_smem)[(in_q + j) * kWave + this->lane]; }
+    __device__ __forceinline__ T qd(int j) const { return reinterpret_cast<const T *>(grbda_smem)[(in_qd + j) * kWave + this->lane]; }
+    __device__ __forceinline__ T x(int j) const { return reinterpret_cast<const T *>(grbda_smem)[(in_x + j) * kWave + this->lane]; }
+    __device__ __forceinline__ void put(int j, T v) const
     {
         if (out_g) out_g[j] = v;
     }
+    __device__ __forceinline__ void put_f(int j, T v) const { put(j, v); }
 };
+
+// the tile loop of the single-cluster kernels: BODY(M) is the tile's work (forward or inverse dynamics of the cluster)
+template <class T, int N, bool LOOP, class BODY>
+__device__ __forceinline__ void gen1_tiles(int work_bytes, int nq, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ x,
+                                           T *__restrict__ out, size_t B, BODY body)
+{
+    const int lane = threadIdx.x;
+    ChainMemC<T> M;
+    M.lane = lane;
+    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
+    M.gmul = 1;
+    M.amask = ~0;
+    M.glb_u = nullptr;
+    M.in_q_u = M.in_qd_u = M.in_x_u = nullptr;
+    M.out_u = nullptr;
+    M.out_row = -1;
+    M.out_f = nullptr;
+    // LDS: [work area][q rows | qd rows | tau / ydd rows]   (nv = N: the cluster is the whole model)
+    M.in_q = work_bytes / (int)(kWave * sizeof(T));
+    M.in_qd = M.in_q + nq;
+    M.in_x = M.in_qd + N;
+    // implicit clusters: spanning positions, one per body; k = n + rows with at most three constraint rows (capi.cpp checks nq)
+    constexpr int NQ = LOOP ? (N + 3 < kMaxClusterBodies ? N + 3 : kMaxClusterBodies) : N;
+    T rq[NQ], rv[N], rx[N];
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    auto fetch = [&](size_t tile) {
+        size_t row = tile * kWave + lane;
+        if (row >= B) row = B - 1;  // (lanes beyond the batch work on the last state; nothing of theirs is stored)
+#pragma unroll
+        for (int j = 0; j < NQ; j++)
+            if (j < nq) rq[j] = q[row * (size_t)nq + j];
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            rv[a] = qd[row * (size_t)N + a];
+            rx[a] = x[row * (size_t)N + a];
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NQ; j++) rq[j] = 0;
+    if ((size_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+#pragma unroll
+        for (int j = 0; j < NQ; j++)
+            if (j < nq) reinterpret_cast<T *>(grbda_smem)[(M.in_q + j) * kWave + lane] = rq[j];
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            reinterpret_cast<T *>(grbda_smem)[(M.in_qd + a) * kWave + lane] = rv[a];
+            reinterpret_cast<T *>(grbda_smem)[(M.in_x + a) * kWave + lane] = rx[a];
+        }
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        M.out_g = lane < rows_valid ? out + (tile * kWave + lane) * (size_t)N : nullptr;
+        body(M);
+    }
+}
 
 template <class T, int N, bool LOOP, int WPS>
 __global__ __launch_bounds__(kWave, WPS) void aba_gen1_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
@@ -1728,48 +1786,10 @@ __global__ __launch_bounds__(kWave, WPS) void aba_gen1_kernel(ChainDev<T> DP, co
 #pragma unroll
     for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
     const ChainGen g = load_rec(P.gens);
-    const int lane = threadIdx.x;
-    ChainMemL<T> M;
-    M.lane = lane;
-    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
-    M.gmul = 1;
-    M.amask = ~0;
-    M.glb_u = nullptr;
-    M.in_q_u = M.in_qd_u = M.in_x_u = nullptr;
-    M.out_u = nullptr;
-    M.out_row = -1;
-    M.out_f = nullptr;
-    // LDS: [work area: DP.lds_bytes][2 x (q block | qd block | tau block)]: the next tile's inputs are copied while this one computes
-    const unsigned off0 = (unsigned)DP.lds_bytes;
-    const unsigned bq = (unsigned)(kWave * P.nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * P.nv) * (unsigned)sizeof(T);
-    const unsigned blk = bq + 2 * bv;
-    M.ncq = P.nq;
-    M.ncv = P.nv;
-    const size_t n_tiles = (B + kWave - 1) / kWave;
-    auto issue = [&](size_t tile, unsigned off) {
-        const size_t left = B - tile * kWave;
-        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
-        stage_issue(q, tile, rows_valid, P.nq, off, lane);
-        stage_issue(qd, tile, rows_valid, P.nv, off + bq, lane);
-        stage_issue(tau, tile, rows_valid, P.nv, off + bq + bv, lane);
-    };
-    unsigned par = 0;
-    if ((size_t)blockIdx.x < n_tiles) issue(blockIdx.x, off0);
-    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const size_t left = B - tile * kWave;
-        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_fence();  // this tile's inputs are in LDS; the previous tile's reads of the other buffer are done
-        const unsigned off = off0 + par * blk;
-        if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x, off0 + (par ^ 1u) * blk);
-        M.in_q = (int)(off / sizeof(T));
-        M.in_qd = (int)((off + bq) / sizeof(T));
-        M.in_x = (int)((off + bq + bv) / sizeof(T));
-        M.out_g = lane < rows_valid ? ydd + (tile * kWave + lane) * (size_t)P.nv : nullptr;
+    gen1_tiles<T, N, LOOP>(DP.lds_bytes, P.nq, q, qd, tau, ydd, B, [&](const ChainMemC<T> &M) {
         gen_down<T, N, LOOP>(P, M, g, g.lds_w, true, false);
         gen_up<T, N, LOOP, true>(P, M, g);
-        par ^= 1u;
-    }
+    });
 }
 
 template <class T, int N, bool LOOP>
@@ -3022,6 +3042,75 @@ template hipError_t launch_rnea_chain_gen<float>(const RneaChainDev<float> &, co
                                                  float *, int, size_t, hipStream_t);
 template hipError_t launch_rnea_chain_gen<double>(const RneaChainDev<double> &, const double *, const double *, const double *, double *,
                                                   size_t, double *, int, size_t, hipStream_t);
+
+// Single-cluster programs (RneaChainProgram::single_gen): the inverse dynamics of ONE generic cluster on the ground, the counterpart of
+// aba_gen1_kernel -- TreeModel::recursiveNewtonEulerAlgorithm (src/Dynamics/TreeModel.cpp:173-212) of a model whose only cluster is a
+// loop mechanism (four_bar.urdf, six_bar.urdf).  Specialised on (n, implicit?) at compile time; no slab, no segment loop; the tile loop
+// and the input staging of aba_gen1_kernel (gen1_tiles).  ONE LDS object (plan.cpp: [sin, cos][forces | the constraint's scratch]
+// [kept block]) keeps the work area at the forward dynamics' size.
+template <class T, int N, bool LOOP, int WPS>
+__global__ __launch_bounds__(kWave, WPS) void rnea_gen1_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd,
+                                                             const T *__restrict__ ydd, T *__restrict__ tau, size_t B)
+{
+    RneaTables<T> P;
+    P.segs = nullptr;
+    P.links = nullptr;
+    P.pairs = nullptr;
+    P.frees = nullptr;
+    P.diffs = nullptr;
+    P.gens = (cptr<ChainGen>)DP.gens;
+    P.gbodies = (cptr<ChainGenBody>)DP.gbodies;
+    P.cints = (cptr<int32_t>)DP.cints;
+    P.consts = (cptr<T>)DP.consts;
+    P.n_segs = 0;
+    P.nq = DP.nq;
+    P.nv = DP.nv;
+    P.ori_repr = DP.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
+    const ChainGen g = load_rec(P.gens);
+    gen1_tiles<T, N, LOOP>(DP.lds_bytes, P.nq, q, qd, ydd, tau, B, [&](const ChainMemC<T> &M) {
+        gen_rnea_fwd<T, N, LOOP>(P, M, g);
+        gen_rnea_bwd<T, N, LOOP, false>(P, M, g);
+    });
+}
+
+template <class T>
+int rnea_gen1_waves_per_simd(int n)
+{
+    (void)n;
+    return sizeof(T) == 4 ? 4 : 2;  // (the LDS of a CU holds fewer than that for every cluster with a constraint)
+}
+template int rnea_gen1_waves_per_simd<float>(int);
+template int rnea_gen1_waves_per_simd<double>(int);
+template <class T, int N, bool LOOP>
+static hipError_t launch_rgen1(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, int grid, size_t lds_bytes,
+                               hipStream_t stream)
+{
+    // wavefronts per SIMD the register footprint allows (checked against the code object: no scratch)
+    constexpr int WPS = sizeof(T) == 4 ? 4 : 2;
+    hipLaunchKernelGGL((rnea_gen1_kernel<T, N, LOOP, WPS>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, ydd, tau, B);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_rnea_gen1(const RneaChainDev<T> &P, int n, int implicit, const T *q, const T *qd, const T *ydd, T *tau, size_t B, int grid,
+                            size_t lds_bytes, hipStream_t stream)
+{
+    if (implicit) {
+        if (n == 1) return launch_rgen1<T, 1, true>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+        if (n == 2) return launch_rgen1<T, 2, true>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+        if (n == 3) return launch_rgen1<T, 3, true>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+        return launch_rgen1<T, 4, true>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+    }
+    if (n == 1) return launch_rgen1<T, 1, false>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+    if (n == 2) return launch_rgen1<T, 2, false>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+    if (n == 3) return launch_rgen1<T, 3, false>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+    return launch_rgen1<T, 4, false>(P, q, qd, ydd, tau, B, grid, lds_bytes, stream);
+}
+template hipError_t launch_rnea_gen1<float>(const RneaChainDev<float> &, int, int, const float *, const float *, const float *, float *, size_t,
+                                            int, size_t, hipStream_t);
+template hipError_t launch_rnea_gen1<double>(const RneaChainDev<double> &, int, int, const double *, const double *, const double *, double *,
+                                             size_t, int, size_t, hipStream_t);
 #endif
 template <class T>
 hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,

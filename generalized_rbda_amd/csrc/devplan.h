@@ -1,5 +1,6 @@
 // devplan.h -- kernel argument block and launcher declarations shared by kernels.hip and capi.cpp
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "plan.h"
@@ -11,6 +12,20 @@ namespace grbda_hip {
 #define GRBDA_EXP_WIDE_WPS 4
 #endif
 constexpr int kChainWideWps = GRBDA_EXP_WIDE_WPS;
+// wavefronts (one-wavefront workgroups) whose dynamic LDS fits a CU: gfx950 hands out its 160 KiB in granules of 1 280 bytes, so a
+// kernel asking for 13 312 bytes holds 11 workgroups per CU, not 12 -- and a persistent grid sized for 12 leaves every twelfth
+// workgroup waiting for a slot until another has finished ALL its tiles (measured: four_bar forward dynamics 0.103 ms at 12 per CU,
+// 0.074 ms at 10; profiles/r5_single_cluster_kernels.txt)
+inline size_t lds_workgroups_per_cu(size_t lds_bytes)
+{
+    if (lds_bytes == 0) return 32;
+    static const size_t granule = [] {  // (GRBDA_LDS_GRANULE=1: the naive quotient, for A/B runs)
+        const char *e = std::getenv("GRBDA_LDS_GRANULE");
+        const long v = e ? std::atol(e) : 0;
+        return static_cast<size_t>(v > 0 ? v : 1280);
+    }();
+    return (160u * 1024u) / ((lds_bytes + granule - 1) / granule * granule);
+}
 constexpr int kChainWideLdsBytes = (160 * 1024 / (4 * kChainWideWps)) / 256 * 256;  // per wavefront, whole rows of 64 floats
 
 
@@ -101,7 +116,7 @@ hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, co
                                size_t lds_bytes, hipStream_t stream);
 hipError_t set_max_dynamic_lds_chain();
 // single-cluster programs (ChainProgram::single_gen; chain_kernels.hip, aba_gen1_kernel): P.lds_bytes = the work area, lds_bytes = work
-// area + two sets of the three staged input blocks
+// area + nq + 2 nv rows of staged inputs
 template <class T>
 hipError_t launch_aba_gen1(const ChainDev<T> &P, int n, int implicit, const T *q, const T *qd, const T *tau, T *ydd, size_t B, int grid,
                            size_t lds_bytes, hipStream_t stream);
@@ -131,6 +146,14 @@ struct RneaChainDev {
 template <class T>
 hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
                              size_t lds_bytes, hipStream_t stream);
+
+// single-cluster programs (RneaChainProgram::single_gen; chain_kernels.hip, rnea_gen1_kernel): P.lds_bytes = the work area, lds_bytes =
+// work area + nq + 2 nv rows of staged inputs
+template <class T>
+hipError_t launch_rnea_gen1(const RneaChainDev<T> &P, int n, int implicit, const T *q, const T *qd, const T *ydd, T *tau, size_t B, int grid,
+                            size_t lds_bytes, hipStream_t stream);
+template <class T>
+int rnea_gen1_waves_per_simd(int n);
 
 // inverse operational-space inertia by force propagation along the contacts' ancestor paths (chain_kernels.hip,
 // osim_chain_kernel).  Built per call on the host (capi.cpp) and passed by value.

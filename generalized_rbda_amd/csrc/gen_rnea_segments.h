@@ -4,9 +4,12 @@
 // namespace grbda_hip, after gen_segments.h and the run / pair / differential segments of the inverse dynamics.
 // Field use of the shared records in THIS program: ChainGen::lds_w = work area of the forward segment ([sin, cos] x k | [v 6][a 6] of
 // the bodies with in-cluster children -- ChainGenBody::acc_w = offset of a body's own pair, up_w = of its in-cluster parent's; the
-// constraint evaluation's scratch aliases them), glb_k = the blocks [f 6][sin, cos] x k the forward segment
+// constraint evaluation's scratch aliases them; up_w = -1 and lam = the body right before: the pair comes over in registers), glb_k =
+// the blocks [f 6][sin, cos] x k the forward segment
 // leaves for the backward one (child segments add their forces into the f part), lds_acc_out = force slot of the parent body,
 // lds_pva = its [v 6][a 6]; ChainGenBody::lds_va = [v 6][a 6] of a body with child clusters.
+// ChainGen::reserved[1] = 1: the cluster is the whole model (plan.cpp): ONE LDS object [sin, cos 2k][f 6 x k][pairs][kept block], the
+// backward segment reads [sin, cos] from the work area and the constraint's scratch lies over the forces and pairs.
 #pragma once
 
 // forward segment: kinematics, the constraint of an implicit cluster, body forces f = I a + v x* I v
@@ -41,7 +44,11 @@ __device__ __forceinline__ void gen_rnea_fwd(const TB &P, const MM &M, const Cha
         M.lds_st(sc0 + 2 * i, sc);
     }
     if constexpr (LOOP) gen_constraint<T, N>(P, M, g, sc0, v0, yd);
-    T vp[6], ap[6];
+    const bool solo = g.reserved[1] != 0;
+    const int fstride = solo ? 6 : 8;
+    T vp[6], ap[6], vl[6], al[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) vl[j] = al[j] = 0;
     if (g.lds_pva >= 0) {
         T va[12];
         M.lds_ld(g.lds_pva, va);
@@ -68,12 +75,14 @@ __device__ __forceinline__ void gen_rnea_fwd(const TB &P, const MM &M, const Cha
         M.lds_ld(sc0 + 2 * i, sc);
         rotate_z(sc[0], sc[1], C, E);
         if (b.lam >= 0) {
-            T val[12], vl[6], al[6];
-            M.lds_ld(g.lds_w + b.up_w, val);
+            if (b.up_w >= 0) {  // (else: the body right before, whose pair is in vl / al)
+                T val[12];
+                M.lds_ld(g.lds_w + b.up_w, val);
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                vl[j] = val[j];
-                al[j] = val[6 + j];
+                for (int j = 0; j < 6; j++) {
+                    vl[j] = val[j];
+                    al[j] = val[6 + j];
+                }
             }
             xmotion(E, C + 9, vl, v);
             xmotion(E, C + 9, al, a6);
@@ -95,13 +104,15 @@ __device__ __forceinline__ void gen_rnea_fwd(const TB &P, const MM &M, const Cha
             }
             M.lds_st(g.lds_w + b.acc_w, val);
         }
-        T f[6], blk[8];
+        T f[6];
         body_force_c(C + 12, v, a6, f);
+        M.lds_st(g.glb_k + fstride * i, f);
+        if (!solo) M.lds_st(g.glb_k + 8 * i + 6, sc);
 #pragma unroll
-        for (int j = 0; j < 6; j++) blk[j] = f[j];
-        blk[6] = sc[0];
-        blk[7] = sc[1];
-        M.lds_st(g.glb_k + 8 * i, blk);
+        for (int j = 0; j < 6; j++) {
+            vl[j] = v[j];
+            al[j] = a6[j];
+        }
         if (b.lds_va >= 0) {
             T va[12];
 #pragma unroll
@@ -124,24 +135,25 @@ __device__ __forceinline__ void gen_rnea_bwd(const TB &P, const MM &M, const Cha
         yd[a] = M.qd(g.v_index + a);
         tau[a] = 0;
     }
+    const bool solo = g.reserved[1] != 0;
+    const int fstride = solo ? 6 : 8;
     for (int i = g.k - 1; i >= 0; i--) {
         const ChainGenBody b = load_rec(P.gbodies + (g.first + i));
         cptr<T> C = P.consts + b.cofs;
-        T Gr[N], gi, qdi, blk[8], f[6], fp[6], E[9];
+        T Gr[N], gi, qdi, sc[2], f[6], fp[6], E[9];
         gen_coupling<T, N, LOOP>(P, M, g, b, C, yd, Gr, gi, qdi);
-        M.lds_ld(g.glb_k + 8 * i, blk);
-#pragma unroll
-        for (int j = 0; j < 6; j++) f[j] = blk[j];
+        M.lds_ld(g.glb_k + fstride * i, f);
+        M.lds_ld(solo ? g.lds_w + 2 * i : g.glb_k + 8 * i + 6, sc);
 #pragma unroll
         for (int a = 0; a < N; a++) tau[a] += Gr[a] * f[2];
-        rotate_z(blk[6], blk[7], C, E);
+        rotate_z(sc[0], sc[1], C, E);
         xforce_inv(E, C + 9, f, fp);
         if (b.lam >= 0) {
             T fl[6];
-            M.lds_ld(g.glb_k + 8 * b.lam, fl);
+            M.lds_ld(g.glb_k + fstride * b.lam, fl);
 #pragma unroll
             for (int j = 0; j < 6; j++) fl[j] += fp[j];
-            M.lds_st(g.glb_k + 8 * b.lam, fl);
+            M.lds_st(g.glb_k + fstride * b.lam, fl);
         } else if (g.lds_acc_out != -1) {
             add6<T, GLB>(M, g.lds_acc_out, fp);
         }

@@ -815,7 +815,7 @@ hipError_t launch_manifold_project_wide(const DevPlan<T> &P, int n_clusters, con
     // (bound by the latency of its coalesced loads -- the tile's H_s and coupling rows come from HBM: as many wavefronts as the LDS holds,
     // up to four per SIMD; the caller's grid is for one per SIMD)
     const size_t lds = kBigClusterBodies * kWave * sizeof(T);
-    size_t per_cu = (160u * 1024u) / lds;
+    size_t per_cu = lds_workgroups_per_cu(lds);
     if (per_cu > 16) per_cu = 16;
     // (the caller's grid is four wavefronts per CU, or the number of tiles when that is smaller: round UP to whole CUs -- grid / 4 was zero
     // for batches of fewer than four tiles, and every tile of such a batch ran on one wavefront)
@@ -1130,7 +1130,7 @@ hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, 
                                  unsigned long long *bad_count)
 {
     const size_t lds = ((size_t)nv * (nv + 1) / 2 + nv) * sizeof(T);
-    size_t per_cu = (160u * 1024u) / lds;
+    size_t per_cu = lds_workgroups_per_cu(lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) return hipErrorInvalidValue;
     size_t g = static_cast<size_t>(n_cu) * per_cu;

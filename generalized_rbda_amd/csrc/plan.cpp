@@ -1619,13 +1619,20 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         rg[c].need_acc = 0;
                         rgb[c] = gbody_of[c];
                         for (ChainGenBody &b : rgb[c]) b.lds_acc = b.lds_va = b.pva = b.lds_v = b.acc_w = b.up_w = -1;
-                        {   // [v 6][a 6] of the bodies with in-cluster children, behind the [sin, cos] rows of the work area
+                        {   // [v 6][a 6] of the bodies with in-cluster children that do not come right after them (a body right
+                            // after its parent takes the pair over in registers: up_w stays -1), behind the [sin, cos] rows of the
+                            // work area
                             int w = 2 * rg[c].k;
-                            for (ChainGenBody &b : rgb[c])
-                                if (b.lam >= 0 && rgb[c][b.lam].acc_w < 0) { rgb[c][b.lam].acc_w = w; w += 12; }
-                            for (ChainGenBody &b : rgb[c])
-                                if (b.lam >= 0) b.up_w = rgb[c][b.lam].acc_w;
+                            for (size_t i = 0; i < rgb[c].size(); i++) {
+                                ChainGenBody &b = rgb[c][i];
+                                if (b.lam >= 0 && b.lam != static_cast<int>(i) - 1 && rgb[c][b.lam].acc_w < 0) { rgb[c][b.lam].acc_w = w; w += 12; }
+                            }
+                            for (size_t i = 0; i < rgb[c].size(); i++) {
+                                ChainGenBody &b = rgb[c][i];
+                                if (b.lam >= 0 && b.lam != static_cast<int>(i) - 1) b.up_w = rgb[c][b.lam].acc_w;
+                            }
                             rg[c].reserved[0] = w - 2 * rg[c].k;  // slots of those pairs
+                            rg[c].reserved[1] = 0;                // (1: the single-cluster layout below)
                         }
                     } else if (is_diff(c)) {
                         RneaDiff &d = rd[c];
@@ -1649,6 +1656,21 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         const int c = ch.cl[0];
                         ChainGen &g = rg[c];
                         const int k = g.k;
+                        if (chains.size() == 1 && nc == 1 && !g.has_parent) {
+                            // the cluster is the whole model (rnea_gen1_kernel): ONE object, [sin, cos 2k][f 6k][v | a pairs] with the
+                            // constraint's scratch over the forces and pairs (it is done before the first force is written), then
+                            // the kept block; the backward segment reads [sin, cos] where the forward one left them
+                            const int pairs = g.reserved[0];
+                            const int mid = std::max(6 * k + pairs, gen_scratch[c]);
+                            for (ChainGenBody &b : rgb[c]) {
+                                if (b.acc_w >= 0) b.acc_w += 6 * k;
+                                if (b.up_w >= 0) b.up_w += 6 * k;
+                            }
+                            g.reserved[1] = 1;
+                            g.reserved[2] = 2 * k + mid;  // offset of the kept block
+                            robjs.push_back({&g.lds_w, 2 * k + mid + (g.kind ? g.rows * (g.n + 2) : 0), 0, rt_fwd[id], rt_bwd[id], -1, 1, 1});
+                            continue;
+                        }
                         robjs.push_back({&g.lds_w, 2 * k + std::max(g.reserved[0], gen_scratch[c]), 0, rt_fwd[id], rt_fwd[id], -1, 1, 1});
                         robjs.push_back({&g.glb_k, 8 * k, 0, rt_fwd[id], rt_bwd[id], -1, 1, 1});
                         if (g.kind) robjs.push_back({&g.keep, g.rows * (g.n + 2), 0, rt_fwd[id], rt_bwd[id], -1, 1, 1});
@@ -1708,6 +1730,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         if (cls[c] == 7) return rgb[c][b - clusters[c].first_body].lds_va;
                         return cls[c] == 0 ? rf[c].lds_va : rl[c].lds_va;
                     };
+                    for (int c = 0; c < nc; c++)
+                        if (cls[c] == 7 && rg[c].reserved[1]) {
+                            rg[c].glb_k = rg[c].lds_w + 2 * rg[c].k;
+                            rg[c].keep = rg[c].kind ? rg[c].lds_w + rg[c].reserved[2] : -1;
+                        }
                     for (int c = 0; c < nc; c++) {
                         const int pb = clusters[c].parent_body;
                         if (cls[c] == 7) { rg[c].lds_pva = va_slot_of_body2(pb); rg[c].lds_acc_out = f_slot_of_body(pb); }
@@ -1757,6 +1784,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     R.n_glb = rn_glb;
                 }
                 R.ok = rok;
+                R.single_gen = rok && R.gens.size() == 1 && R.segs.size() == 2 && R.links.empty() && R.pairs.empty() && R.frees.empty() &&
+                               R.diffs.empty() && !R.gens[0].has_parent && R.n_glb == 0 && !std::getenv("GRBDA_NO_GEN1");
                 if (!rok) { R.segs.clear(); R.links.clear(); R.pairs.clear(); R.frees.clear(); R.diffs.clear(); R.gens.clear(); R.gbodies.clear(); }
             }
             // ---- LDS objects and their live ranges ----

@@ -370,6 +370,7 @@ struct RneaChainProgram {
     std::vector<ChainGenBody> gbodies;   // gen_rnea_segments.h
     int n_lds = 0;
     int n_glb = 0;  // > 0: some link blocks live in the wave's global slab (their slot numbers carry kSlotGlobal)
+    bool single_gen = false;  // the whole model is ONE generic cluster on the ground: rnea_gen1_kernel (no slab, fused sweeps)
 };
 
 struct ChainProgram {

@@ -995,6 +995,42 @@ def test_latency_mode_matches_the_one_wavefront_kernel(name, gpu, monkeypatch):
     assert rel_err(got, O.forward_dynamics(blob, q, qd, tau)) < TOL64
 
 
+@pytest.mark.parametrize("name", ["urdf_four_bar", "urdf_six_bar", "rev_triple_rotor_chain_3"])
+def test_single_cluster_kernels_match_the_chain_kernels(name, gpu, monkeypatch):
+    """A model that is ONE generic cluster on the ground (the URDF+ loop mechanisms of BASELINE config 5, a triple with rotors on a
+    bench) runs the fused kernels aba_gen1_kernel / rnea_gen1_kernel: no slab, inputs prefetched into registers, for the inverse
+    dynamics one LDS object whose force blocks the constraint's scratch overlays.  Same device functions and operations per state as
+    the generic segments of the chain kernels (GRBDA_NO_GEN1=1), so the results agree to rounding; several tiles per wavefront and
+    a ragged last tile are in; the oracle as everywhere."""
+    import torch
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    monkeypatch.setenv("GRBDA_NO_GEN1", "1")
+    plain = G.Plan(blob)
+    monkeypatch.delenv("GRBDA_NO_GEN1")
+    for dt, tn in ((torch.float32, "f32"), (torch.float64, "f64")):
+        assert "aba_gen1_kernel" in plan.kernel_name("aba", tn, 4096) and "rnea_gen1_kernel" in plan.kernel_name("rnea", tn, 4096)
+        assert "gen1" not in plain.kernel_name("aba", tn, 4096) and "gen1" not in plain.kernel_name("rnea", tn, 4096)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    big = 64 * 20 * n_cu * 2 + 37  # more tiles than any launch shape has wavefronts: every wavefront loops
+    for B in (1, 65, 1000, big):
+        q, qd, tau = valid_states(blob, min(B, 3000), config_index=91)
+        rep = (B + q.shape[0] - 1) // q.shape[0]
+        q, qd, tau = (np.tile(a, (rep, 1))[:B] for a in (q, qd, tau))
+        for dt in (torch.float32, torch.float64):
+            t = lambda a: torch.as_tensor(a, dtype=dt, device=gpu)
+            for fn in ("forward_dynamics", "inverse_dynamics"):
+                a = getattr(plan, fn)(t(q), t(qd), t(tau))
+                b = getattr(plain, fn)(t(q), t(qd), t(tau))
+                torch.cuda.synchronize()
+                err = ((a - b).abs().amax(dim=1) / (1.0 + b.abs().amax(dim=1))).max().item()
+                assert err < (2e-4 if dt == torch.float32 else 1e-11), f"{fn} B={B} {dt}: {err:.2e}"
+    q, qd, tau = valid_states(blob, 300, config_index=92)
+    assert rel_err(run_gpu(plan, "aba", q, qd, tau, torch.float64, gpu), O.forward_dynamics(blob, q, qd, tau)) < TOL64
+    assert rel_err(run_gpu(plan, "rnea", q, qd, tau, torch.float64, gpu), O.inverse_dynamics(blob, q, qd, tau)) < TOL64
+
+
 @pytest.mark.parametrize("name", ["tello_with_arms", "tello", "urdf_four_bar", "urdf_six_bar", "urdf_planar_leg_linkage"])
 def test_ungated_implicit_states_fp64(name, gpu):
     """north_star's fp64 tolerance (1e-6 relative) on EVERY valid input of the implicit models: states drawn with the

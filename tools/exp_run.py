@@ -16,7 +16,7 @@ def one(path):
             plan = G.Plan.from_model(tello_with_arms())
         else:
             plan = G.Plan.from_urdf(os.path.join(ROOT, "tests/golden/robot-models", urdf + ".urdf"))
-        B = 262144
+        B = int(os.environ.get("EXP_B", "262144"))
         q, qd, tau = random_states(plan.blob, B, 2)
         if urdf == "tello":  # valid spanning positions: Newton projection on the device, failures replaced
             import numpy as np
