@@ -312,7 +312,8 @@ int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, 
 // plans could otherwise pin tens of GiB unnoticed (advisor, round 4).
 static size_t work_budget(size_t want)
 {
-    size_t cap = want;
+    const int want_mb = env_int("GRBDA_WORK_WANT_MB", 0);  // (experiments: another chunk size)
+    size_t cap = want_mb > 0 ? static_cast<size_t>(want_mb) << 20 : want;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
         size_t quarter = free_b / 4;
@@ -1724,8 +1725,9 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     // workspace per state: spanning state (q_s, qd_s, qdd_s, tau_s), zeros for a missing qd, coupling rows, the three spanning
     // matrices, the three projected matrices, ydd
     const size_t per_state = nq_s + 3 * nv_s + nv + static_cast<size_t>(p->n_cpl_rows) + 3 * nn_s + 3 * nn + nv;
-    // (4 GiB: TelloWithArms takes 33 KB per state, and a 1 GiB chunk -- 32 768 states, 512 tiles -- left half of the SIMDs without one)
-    size_t chunk = work_budget(4096ull << 20) / (per_state * sizeof(T));
+    // (16 GiB, cut to a quarter of the free memory: TelloWithArms takes 33 KB per state; a 4 GiB chunk -- 131 072 states, 2 048 tiles -- left half
+    // of the projection kernel's wavefront slots empty: 13.3 -> 10.8 ms per 262 144 states, 55 -> 44 ms per 1 048 576)
+    size_t chunk = work_budget(16384ull << 20) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     const size_t b_round = (B + kWave - 1) / kWave * kWave;

@@ -96,9 +96,34 @@ __device__ __forceinline__ void cross_s(const S (&a)[3], const S (&b)[3], S (&o)
 
 // ---- URDF+ position loops: K (want_K) or kappa = Kdot qd (otherwise), in the scalar type S ------------------------------
 // sn / cs: sine and cosine of the k spanning angles; qd: the k spanning rates
+// wave-uniform index into a private array WITHOUT taking the array to scratch memory: compare-and-select over the (few) entries
+template <class S, int N>
+__device__ __forceinline__ S pick(const S (&a)[N], int idx)
+{
+    // (every entry read unconditionally, then selects on VALUES: "if (idx == j) r = a[j]" is folded into one load at a selected
+    // address, which is exactly the dynamic index this avoids)
+    S r = a[0];
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+        const S e = a[j];
+        r = idx == j ? e : r;
+    }
+    return r;
+}
+template <class S, int N>
+__device__ __forceinline__ void place(S (&a)[N], int idx, S v)
+{
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const S e = a[j];
+        a[j] = idx == j ? v : e;
+    }
+}
+
+// (clusters beyond the structured limits: runtime loops over private arrays of 48 entries -- scratch memory, slow, correct)
 template <class T, class S, int KB>
-__device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
-                                   const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][KB], S (&kap)[kMR], S *phi = nullptr)
+__device__ void loop_position_eval_dyn(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
+                                       const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][KB], S (&kap)[kMR], S *phi = nullptr)
 {
     // phi (with want_K): the constraint values -- predecessor point minus successor point along the constrained axes
     cptr<int32_t> lp = loops;
@@ -209,18 +234,213 @@ __device__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const C
     }
 }
 
+// the structured clusters (at most kMaxClusterBodies bodies): every loop unrolled to its bound, every array in registers
+template <class T, class S, int KB>
+__device__ __forceinline__ void loop_position_eval_reg(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops,
+                                                       int n_loops, const S (&sn)[KB], const S (&cs)[KB], const S (&qd)[KB], bool want_K,
+                                                       S (&K)[kMR][KB], S (&kap)[kMR], S *phi)
+{
+    cptr<int32_t> lp = loops;
+    int row0 = 0;
+    for (int l = 0; l < n_loops; l++) {
+        const int np = lp[0], ns = lp[1 + np], mask = lp[2 + np + ns];
+        cptr<T> org = consts + c.dofs + 24 * l;
+        S acc[3] = {S(T(0)), S(T(0)), S(T(0))};
+        for (int side = 0; side < 2; side++) {
+            cptr<int32_t> subs = side == 0 ? lp + 1 : lp + 2 + np;
+            const int len = side == 0 ? np : ns;
+            const T sgn = side == 0 ? T(1) : T(-1);
+            S E[9], r[3], A[KB][3], O[KB][3];
+#pragma unroll
+            for (int i = 0; i < 9; i++) E[i] = S(i % 4 == 0 ? T(1) : T(0));
+#pragma unroll
+            for (int i = 0; i < 3; i++) r[i] = S(T(0));
+#pragma unroll
+            for (int t = 0; t < KB; t++) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) A[t][i] = O[t][i] = S(T(0));
+                if (t < len) {
+                    const int sub = subs[t];
+                    const BodyRec b = load_rec(bodies + (c.first_body + sub));
+                    cptr<T> C = consts + b.cofs;
+                    S Eb[9], En[9];
+                    const S s = pick(sn, sub), co = pick(cs, sub);
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {  // Rz(q) Et (canonical joint axes, plan.cpp)
+                        Eb[j] = co * C[j] + s * C[3 + j];
+                        Eb[3 + j] = co * C[3 + j] - s * C[j];
+                        Eb[6 + j] = S(C[6 + j]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; i++) r[i] += E[i] * C[9] + E[3 + i] * C[10] + E[6 + i] * C[11];
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) En[3 * i + j] = Eb[3 * i] * E[j] + Eb[3 * i + 1] * E[3 + j] + Eb[3 * i + 2] * E[6 + j];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) E[i] = En[i];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        A[t][i] = E[6 + i];
+                        O[t][i] = r[i];
+                    }
+                }
+            }
+            S p[3];
+            cptr<T> og = org + 12 * side;
+#pragma unroll
+            for (int i = 0; i < 3; i++) p[i] = r[i] + E[i] * og[9] + E[3 + i] * og[10] + E[6 + i] * og[11];
+            if (want_K) {
+                if (phi) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) acc[i] += sgn * p[i];
+                }
+#pragma unroll
+                for (int t = 0; t < KB; t++) {
+                    if (t >= len) continue;
+                    const S a[3] = {A[t][0], A[t][1], A[t][2]}, d[3] = {p[0] - O[t][0], p[1] - O[t][1], p[2] - O[t][2]};
+                    S J[3];
+                    cross_s(a, d, J);
+                    int row = row0;
+                    const int sub = subs[t];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++)
+                        if (mask & (1 << ax)) {
+#pragma unroll
+                            for (int rr = 0; rr < kMR; rr++) place(K[rr], rr == row ? sub : -1, sgn * J[ax]);
+                            row++;
+                        }
+                }
+            } else {
+                S w[3], al[3], ao[3], op[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) w[i] = al[i] = ao[i] = op[i] = S(T(0));
+#pragma unroll
+                for (int t = 0; t <= KB; t++) {
+                    if (t > len) continue;
+                    S a[3], o[3], qd_t = S(T(0));
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        a[i] = S(T(0));
+                        o[i] = p[i];
+                    }
+                    if constexpr (true) {
+                        if (t < KB && t < len) {
+#pragma unroll
+                            for (int i = 0; i < 3; i++) {
+                                a[i] = A[t < KB ? t : 0][i];
+                                o[i] = O[t < KB ? t : 0][i];
+                            }
+                            qd_t = pick(qd, subs[t]);
+                        }
+                    }
+                    const S d[3] = {o[0] - op[0], o[1] - op[1], o[2] - op[2]};
+                    S wd[3], wwd[3], ad[3];
+                    cross_s(w, d, wd);
+                    cross_s(w, wd, wwd);
+                    cross_s(al, d, ad);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        ao[i] += ad[i] + wwd[i];
+                        op[i] = o[i];
+                    }
+                    const S aq[3] = {a[0] * qd_t, a[1] * qd_t, a[2] * qd_t};
+                    S waq[3];
+                    cross_s(w, aq, waq);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        al[i] += waq[i];
+                        w[i] += aq[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) acc[i] += sgn * ao[i];
+            }
+        }
+        int row = row0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+            if (mask & (1 << ax)) {
+                if (!want_K) place(kap, row, acc[ax]);
+                else if (phi) phi[row] = acc[ax];
+                row++;
+            }
+        row0 = row;
+        lp += 3 + np + ns;
+    }
+}
+
+template <class T, class S, int KB>
+__device__ __forceinline__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
+                                                   const S (&sn)[KB], const S (&cs)[KB], const S (&qd)[KB], bool want_K, S (&K)[kMR][KB],
+                                                   S (&kap)[kMR], S *phi = nullptr)
+{
+    if constexpr (KB > kMaxClusterBodies) loop_position_eval_dyn<T, S, KB>(consts, bodies, c, loops, n_loops, sn, cs, qd, want_K, K, kap, phi);
+    else loop_position_eval_reg<T, S, KB>(consts, bodies, c, loops, n_loops, sn, cs, qd, want_K, K, kap, phi);
+}
+
 // ---- trig-polynomial phi (plan.cpp: ints [n_args, per row: n_terms, per term: n_factors, (type, argument)...], constants
 // [per distinct argument w[k], b][per term coef]) ---------------------------------------------------------------------------
+// The DISTINCT arguments a = w . q + b are evaluated once per call -- the Tello hip differential has 4 in the 30 factors of its two
+// rows, and sincos_precise is what an evaluation costs -- and parked in LDS ([slot][lane]: the factors pick them by a wave-uniform
+// index that a private array would take to scratch memory).  tl: this lane's column of the work area (kTrigLdsSlots rows of T), or
+// nullptr / more than kTrigArgsLds arguments: every factor evaluates its own.  fresh = false: [a, sin, cos] of the previous call
+// with the same q are still there (the kappa pass after the K pass), only the rates a' = w . qd are new.
+constexpr int kTrigArgsLds = 8;
+constexpr int kTrigLdsSlots = kTrigArgsLds * 4 * 2;  // [a, a', sin, cos] per argument, two numbers each when they are duals
+template <class T>
+__device__ __forceinline__ void tl_put(T *tl, int slot, T v) { tl[(size_t)(2 * slot) * kWave] = v; }
+template <class T>
+__device__ __forceinline__ void tl_put(T *tl, int slot, Du<T> v)
+{
+    tl[(size_t)(2 * slot) * kWave] = v.v;
+    tl[(size_t)(2 * slot + 1) * kWave] = v.d;
+}
+template <class T>
+__device__ __forceinline__ void tl_get(const T *tl, int slot, T &v) { v = tl[(size_t)(2 * slot) * kWave]; }
+template <class T>
+__device__ __forceinline__ void tl_get(const T *tl, int slot, Du<T> &v)
+{
+    v.v = tl[(size_t)(2 * slot) * kWave];
+    v.d = tl[(size_t)(2 * slot + 1) * kWave];
+}
+
 template <class T, class S, int KB>
-__device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32_t> prog, const S *q, const S *qd, bool want_K,
-                                 S (&K)[kMR][KB], S (&kap)[kMR])
+__device__ __forceinline__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32_t> prog, const S (&q)[KB], const S (&qd)[KB],
+                                                 bool want_K, S (&K)[kMR][KB], S (&kap)[kMR], T *tl = nullptr, bool fresh = true)
 {
     const int k = c.k;
     cptr<int32_t> ip = prog;
     const int n_args = *ip++;
     cptr<T> ap = consts + c.dofs;
     cptr<T> cp = ap + n_args * (k + 1);
-    for (int r = 0; r < c.rows; r++) {
+    const bool cached = tl != nullptr && n_args <= kTrigArgsLds;
+    if (cached) {
+        for (int arg = 0; arg < n_args; arg++) {
+            cptr<T> w = ap + arg * (k + 1);
+            if (fresh) {
+                S a = S(w[k]);
+#pragma unroll
+                for (int j = 0; j < KB; j++)
+                    if (j < k) a += q[j] * w[j];
+                S sn, cs;
+                sc_of(a, sn, cs);
+                tl_put(tl, 4 * arg, a);
+                tl_put(tl, 4 * arg + 2, sn);
+                tl_put(tl, 4 * arg + 3, cs);
+            }
+            if (!want_K) {
+                S adot = S(T(0));
+#pragma unroll
+                for (int j = 0; j < KB; j++)
+                    if (j < k) adot += qd[j] * w[j];
+                tl_put(tl, 4 * arg + 1, adot);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kMR; r++) {
+        if (r >= c.rows) break;
         const int nt = *ip++;
         S Krow[KB], kd = S(T(0));
 #pragma unroll
@@ -230,6 +450,7 @@ __device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32
             const T coef = *cp++;
             S f0[4], f1[4], f2[4], ad[4];
             cptr<T> wv[4];
+#pragma unroll
             for (int f = 0; f < 4; f++) {
                 f0[f] = S(T(1)); f1[f] = S(T(0)); f2[f] = S(T(0)); ad[f] = S(T(0));
                 wv[f] = ap;
@@ -238,30 +459,47 @@ __device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32
                     ip += 2;
                     cptr<T> w = ap + arg * (k + 1);
                     wv[f] = w;
-                    S a = S(w[k]), adot = S(T(0));
-                    for (int j = 0; j < k; j++) {
-                        a += q[j] * w[j];
-                        adot += qd[j] * w[j];
+                    S a, adot = S(T(0)), sn, cs;
+                    if (cached) {
+                        tl_get(tl, 4 * arg, a);
+                        if (!want_K) tl_get(tl, 4 * arg + 1, adot);
+                        tl_get(tl, 4 * arg + 2, sn);
+                        tl_get(tl, 4 * arg + 3, cs);
+                    } else {
+                        a = S(w[k]);
+#pragma unroll
+                        for (int j = 0; j < KB; j++)
+                            if (j < k) {
+                                a += q[j] * w[j];
+                                adot += qd[j] * w[j];
+                            }
+                        sc_of(a, sn, cs);
                     }
                     ad[f] = adot;
-                    S sn, cs;
-                    sc_of(a, sn, cs);
                     if (type == 1) { f0[f] = sn; f1[f] = cs; f2[f] = -sn; }
                     else if (type == 2) { f0[f] = cs; f1[f] = -sn; f2[f] = -cs; }
                     else { f0[f] = a; f1[f] = S(T(1)); f2[f] = S(T(0)); }
                 }
             }
-            for (int f = 0; f < nf; f++) {
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                if (f >= nf) continue;
                 S others = S(coef);
+#pragma unroll
                 for (int h = 0; h < 4; h++)
                     if (h != f) others = others * f0[h];
                 if (want_K) {
-                    for (int j = 0; j < k; j++) Krow[j] += others * f1[f] * wv[f][j];
+                    const S of1 = others * f1[f];
+#pragma unroll
+                    for (int j = 0; j < KB; j++)
+                        if (j < k) Krow[j] += of1 * wv[f][j];
                 } else {
                     kd += others * f2[f] * ad[f] * ad[f];
-                    for (int h = 0; h < nf; h++)
-                        if (h != f) {
+#pragma unroll
+                    for (int h = 0; h < 4; h++)
+                        if (h != f && h < nf) {
                             S rest = S(coef);
+#pragma unroll
                             for (int m2 = 0; m2 < 4; m2++)
                                 if (m2 != f && m2 != h) rest = rest * f0[m2];
                             kd += rest * f1[f] * ad[f] * f1[h] * ad[h];
@@ -270,7 +508,9 @@ __device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32
             }
         }
         if (want_K) {
-            for (int j = 0; j < k; j++) K[r][j] = Krow[j];
+#pragma unroll
+            for (int j = 0; j < KB; j++)
+                if (j < k) K[r][j] = Krow[j];
         } else {
             kap[r] = kd;
         }
@@ -279,18 +519,28 @@ __device__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32
 
 // K or kappa of an implicit cluster at the spanning state (q, qd), scalar type S
 template <class T, class S, int KB>
-__device__ void constraint_eval(cptr<T> consts, cptr<BodyRec> bodies, cptr<int32_t> cints, const ClusterRec &c, const S *q, const S *qd,
-                                bool want_K, S (&K)[kMR][KB], S (&kap)[kMR])
+__device__ __forceinline__ void constraint_eval(cptr<T> consts, cptr<BodyRec> bodies, cptr<int32_t> cints, const ClusterRec &c,
+                                                const S (&q)[KB], const S (&qd)[KB], bool want_K, S (&K)[kMR][KB], S (&kap)[kMR],
+                                                T *tl = nullptr, bool fresh = true)
 {
     cptr<int32_t> ip = cints + c.iofs;
     const int hdr0 = ip[0], n_ind = ip[1];
     cptr<int32_t> payload = ip + 3 + n_ind + c.rows;
     if (c.cons_type == 0) {
         S sn[KB], cs[KB];
-        for (int j = 0; j < c.k; j++) sc_of(q[j], sn[j], cs[j]);
+        if constexpr (KB > kMaxClusterBodies) {
+            for (int j = 0; j < c.k; j++) sc_of(q[j], sn[j], cs[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < KB; j++) {
+                sn[j] = S(T(0));
+                cs[j] = S(T(1));
+                if (j < c.k) sc_of(q[j], sn[j], cs[j]);
+            }
+        }
         loop_position_eval<T, S, KB>(consts, bodies, c, payload, hdr0, sn, cs, qd, want_K, K, kap);
     } else {
-        trig_poly_eval_s<T, S, KB>(consts, c, payload, q, qd, want_K, K, kap);
+        trig_poly_eval_s<T, S, KB>(consts, c, payload, q, qd, want_K, K, kap, tl, fresh);
     }
 }
 
@@ -321,6 +571,191 @@ __device__ __forceinline__ void inv_rows(int R, const T (&A)[kMR][kMR], T (&Ai)[
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// One implicit cluster of at most kMaxClusterBodies bodies / kMaxClusterDof independent coordinates in kernel 1: spanning state, G, g
+// and -- want_d -- their first-order parts along every independent coordinate (the formulas at the top of this file).  Every loop runs
+// to its compile-time bound under a wave-uniform guard and the dependent / independent coordinate numbers go through pick / place,
+// so that K, G and the dual work areas stay in registers (the runtime loops this replaces kept 1.2 KB per lane in scratch memory
+// and every multiply-add of the small solves was a dependent scratch round trip).
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<BodyRec> bodies, cptr<int32_t> cints, cptr<int32_t> span_q,
+                                                          cptr<int32_t> span_v, const ClusterRec &cr, const T *qs, const T *qds, const T *ydds,
+                                                          T *oq, T *ov, T *oa, T *cc, bool live, int want_d, T *tl)
+{
+    constexpr int KB = kMaxClusterBodies, KN = kMaxClusterDof;
+    const int k = cr.k, n = cr.n, rows = cr.rows;
+    cptr<int32_t> ip = cints + cr.iofs;
+    const int n_ind = ip[1];
+    int ind[KN], dep[kMR];
+#pragma unroll
+    for (int a = 0; a < KN; a++) ind[a] = a < n ? ip[2 + a] : -1;
+#pragma unroll
+    for (int r = 0; r < kMR; r++) dep[r] = r < rows ? ip[3 + n_ind + r] : -1;
+    T qv[KB], yd[KN], yddv[KN];
+#pragma unroll
+    for (int j = 0; j < KB; j++) qv[j] = j < k ? qs[cr.q_index + j] : T(0);
+#pragma unroll
+    for (int a = 0; a < KN; a++) {
+        yd[a] = a < n ? qds[cr.v_index + a] : T(0);
+        yddv[a] = (a < n && ydds) ? ydds[cr.v_index + a] : T(0);
+    }
+    T K[kMR][KB], kap[kMR], zero[KB];
+#pragma unroll
+    for (int r = 0; r < kMR; r++) {
+        kap[r] = 0;
+#pragma unroll
+        for (int j = 0; j < KB; j++) K[r][j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < KB; j++) zero[j] = 0;
+    constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, zero, true, K, kap, tl, true);
+    T Kd[kMR][kMR], Kdi[kMR][kMR], qdv[KB], gv[KB], G[KB][KN];
+#pragma unroll
+    for (int r = 0; r < kMR; r++)
+#pragma unroll
+        for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? pick(K[r], dep[j]) : T(r == j);
+    inv_rows(rows, Kd, Kdi);
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        gv[i] = 0;
+#pragma unroll
+        for (int a = 0; a < KN; a++) G[i][a] = (a < n && i == ind[a]) ? T(1) : T(0);
+    }
+#pragma unroll
+    for (int r = 0; r < kMR; r++)
+#pragma unroll
+        for (int a = 0; a < KN; a++) {
+            if (r >= rows || a >= n) continue;
+            T sum = 0;
+#pragma unroll
+            for (int j = 0; j < kMR; j++)
+                if (j < rows) sum += Kdi[r][j] * pick(K[j], ind[a]);
+#pragma unroll
+            for (int i = 0; i < KB; i++) G[i][a] = i == dep[r] ? -sum : G[i][a];
+        }
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        T sum = 0;
+#pragma unroll
+        for (int a = 0; a < KN; a++) sum += G[i][a] * yd[a];
+        qdv[i] = sum;
+    }
+    constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, qdv, false, K, kap, tl, false);  // (K is not touched: want_K false)
+#pragma unroll
+    for (int r = 0; r < kMR; r++) {
+        if (r >= rows) continue;
+        T sum = 0;
+#pragma unroll
+        for (int j = 0; j < kMR; j++)
+            if (j < rows) sum += Kdi[r][j] * kap[j];
+        place(gv, dep[r], -sum);
+    }
+    const int stride = cpl_stride<KB>(n);
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        if (i >= k) continue;
+        if (live) {
+            oq[span_q[cr.first_body + i]] = qv[i];
+            ov[span_v[cr.first_body + i]] = qdv[i];
+            if (oa) {
+                T sum = gv[i];
+#pragma unroll
+                for (int a = 0; a < KN; a++) sum += G[i][a] * yddv[a];
+                oa[span_v[cr.first_body + i]] = sum;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < KN; a++)
+            if (a < n) cc[(size_t)(i * stride + a) * kWave] = G[i][a];
+    }
+    if (!want_d) return;
+    // ---- first-order parts along every independent coordinate ----
+    for (int i = 0; i < k; i++)
+        for (int j = n; j < stride; j++) cc[(size_t)(i * stride + j) * kWave] = 0;
+    for (int a = 0; a < n; a++) {
+        Du<T> qD[KB], qdD[KB], KD[kMR][KB], kapD[kMR];
+#pragma unroll
+        for (int j = 0; j < KB; j++) {
+            qD[j] = Du<T>(qv[j], pick(G[j], a));
+            qdD[j] = Du<T>(T(0));
+        }
+#pragma unroll
+        for (int r = 0; r < kMR; r++) {
+            kapD[r] = Du<T>(T(0));
+#pragma unroll
+            for (int j = 0; j < KB; j++) KD[r][j] = Du<T>(T(0));
+        }
+        constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD, tl, true);
+        // G' (dependent rows) = -Kd^-1 K' G ;  d g / d yd_a = -2 Kd^-1 K' qd_s
+        T Gp[kMR][KN], KpQd[kMR], qdp[KB], KpG[kMR][KN];
+#pragma unroll
+        for (int r = 0; r < kMR; r++) {
+            T sum = 0;
+#pragma unroll
+            for (int j = 0; j < KB; j++) sum += KD[r][j].d * qdv[j];
+            KpQd[r] = sum;
+#pragma unroll
+            for (int b2 = 0; b2 < KN; b2++) {
+                T kg = 0;  // (K' G)[r][b2]
+#pragma unroll
+                for (int j = 0; j < KB; j++) kg += KD[r][j].d * G[j][b2];
+                KpG[r][b2] = kg;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KB; j++) qdp[j] = 0;
+#pragma unroll
+        for (int r = 0; r < kMR; r++)
+#pragma unroll
+            for (int b2 = 0; b2 < KN; b2++) {
+                Gp[r][b2] = 0;
+                if (r >= rows || b2 >= n) continue;
+                T sum = 0;
+#pragma unroll
+                for (int r2 = 0; r2 < kMR; r2++)
+                    if (r2 < rows) sum += Kdi[r][r2] * KpG[r2][b2];
+                Gp[r][b2] = -sum;
+#pragma unroll
+                for (int i = 0; i < KB; i++) qdp[i] += i == dep[r] ? -sum * yd[b2] : T(0);
+            }
+#pragma unroll
+        for (int j = 0; j < KB; j++) qdD[j] = Du<T>(qdv[j], qdp[j]);
+        constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, false, KD, kapD, tl, false);  // (KD is not touched)
+        T gdep[kMR];
+#pragma unroll
+        for (int j = 0; j < kMR; j++) gdep[j] = j < rows ? pick(gv, dep[j]) : T(0);
+#pragma unroll
+        for (int r = 0; r < kMR; r++) {
+            if (r >= rows) continue;
+            const int i = dep[r];
+            T gy = 0, gyd = 0, ay = 0, by = 0;
+#pragma unroll
+            for (int r2 = 0; r2 < kMR; r2++) {
+                if (r2 >= rows) continue;
+                T kdg = 0;  // (K'_d g_dep)[r2]
+#pragma unroll
+                for (int j = 0; j < kMR; j++)
+                    if (j < rows) kdg += pick(KD[r2], dep[j]).d * gdep[j];
+                gy += Kdi[r][r2] * (kapD[r2].d + kdg);
+                gyd += Kdi[r][r2] * KpQd[r2];
+            }
+            gy = -gy;
+            gyd = T(-2) * gyd;
+#pragma unroll
+            for (int b2 = 0; b2 < KN; b2++) {
+                if (b2 >= n) continue;
+                ay += Gp[r][b2] * yd[b2];
+                by += Gp[r][b2] * yddv[b2];
+                cc[(size_t)(i * stride + 4 * n + a * n + b2) * kWave] = Gp[r][b2];
+            }
+            cc[(size_t)(i * stride + n + a) * kWave] = ay;
+            cc[(size_t)(i * stride + 2 * n + a) * kWave] = by + gy;
+            cc[(size_t)(i * stride + 3 * n + a) * kWave] = gyd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Kernel 1: spanning state and coupling of every cluster, one state per lane.
 //   q_s [B][nq_s], qd_s / qdd_s [B][nv_s]: the state of the spanning model (row-major: what its kernels take)
 //   cpl [tile][row][lane]: per implicit cluster, from row crow[c], per body i (stride n (4 + n)):
@@ -341,6 +776,8 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
     cptr<int32_t> cints = (cptr<int32_t>)DP.cints;
     cptr<int32_t> span_q = (cptr<int32_t>)span_q_, span_v = (cptr<int32_t>)span_v_, crow = (cptr<int32_t>)crow_;
     const int lane = threadIdx.x, nq = DP.nq, nv = DP.nv;
+    __shared__ T trig_lds[kTrigLdsSlots * kWave];  // (one wavefront per workgroup: trig_poly_eval_s)
+    T *tl = trig_lds + lane;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t r0 = tile * kWave + lane;
@@ -386,6 +823,12 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                 continue;
             }
             // ---- implicit cluster ----
+            if constexpr (KB <= kMaxClusterBodies) {
+                manifold_implicit_cluster<T>(consts, bodies, cints, span_q, span_v, cr, qs, qds, ydds, oq, ov, oa, cp + (size_t)crow[c] * kWave, live,
+                                             want_d, tl);
+                continue;
+            }
+            // (clusters beyond the structured limits: runtime loops, G in the coupling slab, no derivative parts)
             cptr<int32_t> ip = cints + cr.iofs;
             const int n_ind = ip[1], rows = cr.rows;
             cptr<int32_t> ind = ip + 2, dep = ip + 3 + n_ind;
@@ -401,7 +844,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                 for (int j = 0; j < KB; j++) K[r][j] = 0;
             }
             for (int j = 0; j < KB; j++) zero[j] = 0;
-            constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, zero, true, K, kap);
+            constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, zero, true, K, kap, tl, true);
             T Kd[kMR][kMR], Kdi[kMR][kMR], qdv[KB], gv[KB];
             const int stride = cpl_stride<KB>(n);
             T *cc = cp + (size_t)crow[c] * kWave;
@@ -427,7 +870,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                 for (int a = 0; a < n; a++) s += G.get(i, a) * yd[a];
                 qdv[i] = s;
             }
-            constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, qdv, false, K, kap);  // (K is not touched: want_K false)
+            constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, qdv, false, K, kap, tl, false);  // (K is not touched: want_K false)
             for (int r = 0; r < rows; r++) {
                 T s = 0;
                 for (int j = 0; j < rows; j++) s += Kdi[r][j] * kap[j];
@@ -462,7 +905,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                     kapD[r] = Du<T>(T(0));
                     for (int j = 0; j < KB; j++) KD[r][j] = Du<T>(T(0));
                 }
-                constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD);
+                constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD, tl, true);
                 // G' (dependent rows) = -Kd^-1 K' G ;  d g / d yd_a = -2 Kd^-1 K' qd_s
                 T Gp[kMR][KN], KpQd[kMR], qdp[KB];
                 for (int r = 0; r < rows; r++) {
@@ -483,7 +926,7 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                         qdp[dep[r]] += -s * yd[b2];
                     }
                 for (int j = 0; j < KB; j++) qdD[j] = Du<T>(j < k ? qdv[j] : T(0), qdp[j]);
-                constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, false, KD, kapD);  // (KD is not touched)
+                constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, false, KD, kapD, tl, false);  // (KD is not touched)
                 for (int r = 0; r < rows; r++) {
                     const int i = dep[r];
                     T gy = 0, gyd = 0, ay = 0, by = 0;
