@@ -113,3 +113,9 @@ asan:
 	    -DGRBDA_ASAN_DRIVER -I include -I generalized_rbda_amd/include tools/asan_driver.cpp $(CSRC)/plan.cpp $(CSRC)/urdf.cpp \
 	    -x c oracle/grbda_oracle.c -x none -lm -lpthread -o build/asan/asan_driver
 .PHONY: asan
+
+# experiment builds of the manifold kernels: make expm NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
+expm: $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+	@mkdir -p build/exp
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/manifold_kernels.hip -o build/exp/manifold_$(NAME).o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/manifold_$(NAME).o $^

@@ -150,6 +150,7 @@ struct grbda_plan {
     ~grbda_plan() { if (span) grbda_plan_free(span); }
     std::vector<int32_t> span_q, span_v, crow;
     int n_cpl_rows = 0;
+    int constraint_shape = 0;  // manifold_kernels.hip, launch_manifold_constraint: 0 structured, 1 beyond the limits, 2 at most 4 bodies / 2 coordinates
     bool no_manifold = false;  // GRBDA_NO_MANIFOLD=1: implicit models keep the difference batches (A/B runs)
 };
 
@@ -867,7 +868,7 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
             hipError_t e = launch_manifold_constraint<T>(dp, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s),
                                                          static_cast<int>(nv_s), p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, ydd + b0 * nv, q_s,
                                                          qd_span ? qd_span + b0 * nv_s : v_tmp, qdd_span + b0 * nv_s, cpl, nb, static_cast<int>(g),
-                                                         static_cast<hipStream_t>(stream), true);
+                                                         static_cast<hipStream_t>(stream), 1);
             if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         }
         return GRBDA_OK;
@@ -1614,7 +1615,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
         // inverse dynamics: qdd_s = G ydd + g; forward dynamics: qdd_s = g (the bias of the spanning tree with the constraint's own acceleration)
         e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
                                           p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, rnea ? x + b0 * nv : nullptr, q_s, qd_s, qdd_s, cpl, nb,
-                                          static_cast<int>(grid), hs, big);
+                                          static_cast<int>(grid), hs, p->constraint_shape);
         if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         if (int rc = run<T>(sp, true, q_s, qd_s, qdd_s, f_ext ? f_ext + b0 * static_cast<size_t>(p->host.n_bodies) * 6 : nullptr, x_s, nb, device, stream))
             return rc;
@@ -1758,7 +1759,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         if (grid > n_tiles) grid = n_tiles;
         e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
                                           p->n_cpl_rows, need_d ? 1 : 0, qc, qdc, yddc, q_s, qd_s, need_d ? qdd_s : nullptr, cpl, nb,
-                                          static_cast<int>(grid), hs, big);
+                                          static_cast<int>(grid), hs, p->constraint_shape);
         if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         if (!need_d && (e = hipMemsetAsync(qd_s, 0, chunk * nv_s * sizeof(T), hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
         if (need_d)
@@ -2201,6 +2202,13 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
                         else if (cr.kind == CK_STATIC && p->host.big_clusters) rows += cr.k * cr.n;  // (wide plans keep every cluster's G rows in the slab)
                     }
                     p->n_cpl_rows = rows;
+                    // (every implicit cluster within 4 bodies / 2 independent coordinates: the constraint kernel's half-size build)
+                    bool small = !p->host.big_clusters;
+                    for (int c = 0; c < p->host.n_clusters; c++) {
+                        const ClusterRec &cr = p->host.lay64.clusters[c];
+                        if (cr.kind == CK_LOOP && (cr.k > 4 || cr.n > 2)) small = false;
+                    }
+                    p->constraint_shape = p->host.big_clusters ? 1 : (small && !env_int("GRBDA_NO_SMALL_CONSTRAINT", 0) ? 2 : 0);
                 } else {
                     grbda_plan_free(sp);
                 }

@@ -215,7 +215,7 @@ size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
 template <class T>
 hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
                                       int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
-                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, bool big = false);
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, int shape = false);
 template <class T>
 hipError_t launch_manifold_apply(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, int nv_s, int n_cpl_rows, int mode,
                                  const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream,

@@ -577,12 +577,11 @@ __device__ __forceinline__ void inv_rows(int R, const T (&A)[kMR][kMR], T (&Ai)[
 // so that K, G and the dual work areas stay in registers (the runtime loops this replaces kept 1.2 KB per lane in scratch memory
 // and every multiply-add of the small solves was a dependent scratch round trip).
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int KB, int KN>
 __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<BodyRec> bodies, cptr<int32_t> cints, cptr<int32_t> span_q,
                                                           cptr<int32_t> span_v, const ClusterRec &cr, const T *qs, const T *qds, const T *ydds,
                                                           T *oq, T *ov, T *oa, T *cc, bool live, int want_d, T *tl)
 {
-    constexpr int KB = kMaxClusterBodies, KN = kMaxClusterDof;
     const int k = cr.k, n = cr.n, rows = cr.rows;
     cptr<int32_t> ip = cints + cr.iofs;
     const int n_ind = ip[1];
@@ -650,7 +649,7 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
             if (j < rows) sum += Kdi[r][j] * kap[j];
         place(gv, dep[r], -sum);
     }
-    const int stride = cpl_stride<KB>(n);
+    const int stride = cpl_stride<kMaxClusterBodies>(n);
 #pragma unroll
     for (int i = 0; i < KB; i++) {
         if (i >= k) continue;
@@ -824,8 +823,8 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
             }
             // ---- implicit cluster ----
             if constexpr (KB <= kMaxClusterBodies) {
-                manifold_implicit_cluster<T>(consts, bodies, cints, span_q, span_v, cr, qs, qds, ydds, oq, ov, oa, cp + (size_t)crow[c] * kWave, live,
-                                             want_d, tl);
+                manifold_implicit_cluster<T, KB, KN>(consts, bodies, cints, span_q, span_v, cr, qs, qds, ydds, oq, ov, oa, cp + (size_t)crow[c] * kWave,
+                                                     live, want_d, tl);
                 continue;
             }
             // (clusters beyond the structured limits: runtime loops, G in the coupling slab, no derivative parts)
@@ -989,11 +988,92 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
         T *Hout = H + grp * nn * IL + sub;
         auto packed = [](int r, int c) -> size_t { return c <= r ? (size_t)(r * r + c) : (size_t)(c * c + c + 1 + r); };
         auto sym = [](int r, int c) -> size_t { return r >= c ? (size_t)(r * (r + 1) / 2 + c) : (size_t)(c * (c + 1) / 2 + r); };
-        for (int cJ = 0; cJ < n_clusters; cJ++) {
+        // (gridDim.y > 1: the column clusters are dealt out over the workgroups of a tile -- batches with fewer tiles than wavefront slots)
+        for (int cJ = blockIdx.y; cJ < n_clusters; cJ += gridDim.y) {
             const ClusterRec J = load_rec(clusters + cJ);
             const int nJ = J.kind == CK_FREE ? 6 : J.n, kJ = J.kind == CK_FREE ? 6 : J.k;
             const int strideJ = J.kind == CK_LOOP ? cpl_stride<KB>(J.n) : 0;
             const T *cJp = cp + (size_t)(J.kind == CK_LOOP ? crow[cJ] : 0) * kWave;
+            if (J.kind == CK_FREE) {
+                // The floating base's columns: G e_a is a unit vector, so a column of the projected matrices is a column of the spanning
+                // ones contracted with G_I^T -- and every cluster is related to the base.  All FC columns at once: each entry of A_q / A_v / H_s
+                // in the base's columns is read ONCE (column by column it was the same rows of G_I against one entry at a time, six passes).
+#ifdef GRBDA_EXP_FC
+                constexpr int FC = GRBDA_EXP_FC;
+#else
+                constexpr int FC = 3;  // (six at once: 197 registers in fp32, two wavefronts per SIMD instead of three, 7 % slower)
+#endif
+                const int sv0 = span_v[J.first_body];
+                for (int a0 = 0; a0 < 6; a0 += FC) {
+                    for (int cI = 0; cI < n_clusters; cI++) {
+                        const ClusterRec I = load_rec(clusters + cI);
+                        if (!((rel[I.v_index] >> J.v_index) & 1)) continue;
+                        const int nI = I.kind == CK_FREE ? 6 : I.n, kI = I.kind == CK_FREE ? 6 : I.k;
+                        const int strideI = I.kind == CK_LOOP ? cpl_stride<KB>(I.n) : 0;
+                        const T *cIp = cp + (size_t)(I.kind == CK_LOOP ? crow[cI] : 0) * kWave;
+                        T oq[KN][FC], ov[KN][FC], oh[KN][FC];
+#pragma unroll
+                        for (int b2 = 0; b2 < KN; b2++)
+#pragma unroll
+                            for (int a = 0; a < FC; a++) oq[b2][a] = ov[b2][a] = oh[b2][a] = 0;
+                        for (int ri = 0; ri < kI; ri++) {
+                            const int r = I.kind == CK_FREE ? span_v[I.first_body] + ri : span_v[I.first_body + ri];
+                            const uint64_t rr = rel_s[r];
+                            T x[FC], y[FC], h[FC];
+#pragma unroll
+                            for (int a = 0; a < FC; a++) {
+                                const int sv = sv0 + a0 + a;
+                                const bool on = (rr >> sv) & 1;
+                                h[a] = on ? hs[sym(r, sv) * kWave] : T(0);
+                                x[a] = (on && mode == 0) ? aq[packed(r, sv) * kWave] : T(0);
+                                y[a] = (on && mode == 0) ? av[packed(r, sv) * kWave] : T(0);
+                            }
+                            if (I.kind == CK_FREE) {  // (the base against itself: G_I is the identity too)
+                                if (live) {
+#pragma unroll
+                                    for (int a = 0; a < FC; a++) {
+                                        const int vI = I.v_index + ri, vJ = J.v_index + a0 + a;
+                                        if (mode == 0) {
+                                            Dqs[packed(vI, vJ) * IL] = x[a];
+                                            Dqds[packed(vI, vJ) * IL] = y[a];
+                                        }
+                                        if (vJ <= vI) Hout[sym(vI, vJ) * IL] = h[a];
+                                    }
+                                }
+                                continue;
+                            }
+                            cptr<T> gS = consts + (I.kind == CK_STATIC ? load_rec(bodies + (I.first_body + ri)).cofs + kBodyConstFixed : 0);
+#pragma unroll
+                            for (int b2 = 0; b2 < KN; b2++) {
+                                if (b2 >= nI) continue;
+                                const T g = I.kind == CK_STATIC ? gS[b2] : cIp[(size_t)(ri * strideI + b2) * kWave];
+#pragma unroll
+                                for (int a = 0; a < FC; a++) {
+                                    oq[b2][a] += g * x[a];
+                                    ov[b2][a] += g * y[a];
+                                    oh[b2][a] += g * h[a];
+                                }
+                            }
+                        }
+                        if (live && I.kind != CK_FREE) {
+#pragma unroll
+                            for (int b2 = 0; b2 < KN; b2++) {
+                                if (b2 >= nI) continue;
+#pragma unroll
+                                for (int a = 0; a < FC; a++) {
+                                    const int vI = I.v_index + b2, vJ = J.v_index + a0 + a;
+                                    if (mode == 0) {
+                                        Dqs[packed(vI, vJ) * IL] = oq[b2][a];
+                                        Dqds[packed(vI, vJ) * IL] = ov[b2][a];
+                                    }
+                                    if (vJ <= vI) Hout[sym(vI, vJ) * IL] = oh[b2][a];
+                                }
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
             for (int a = 0; a < nJ; a++) {
                 // column data over the spanning coordinates of cluster J: G e_a, G_a' yd, G_a' ydd + dg/dy_a, dg/dyd_a
                 T gJ[KB], ayJ[KB], byJ[KB], bvJ[KB];
@@ -1238,8 +1318,20 @@ template hipError_t launch_manifold_apply<double>(const DevPlan<double> &, int, 
 template <class T>
 hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
                                       int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
-                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, bool big)
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, int shape)
 {
+    // shape 0: clusters of up to kMaxClusterBodies bodies / kMaxClusterDof independent coordinates; 1: beyond (runtime loops, no derivative
+    // parts); 2: every implicit cluster has at most 4 bodies and 2 independent coordinates (the Tello differentials): the same code with
+    // half the unrolled work areas
+    const bool big = shape == 1;
+    if (shape == 2) {
+        // (fp32: 216 registers, two wavefronts per SIMD -- the caller's grid is for one)
+        const size_t n_tiles = (B + kWave - 1) / kWave;
+        if (sizeof(T) == 4 && static_cast<size_t>(grid) * 2 <= n_tiles) grid *= 2;
+        hipLaunchKernelGGL((manifold_constraint_kernel<T, 4, 2>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_q, span_v, crow, nq_s, nv_s,
+                           n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
+        return hipGetLastError();
+    }
     if (big) {
         if (want_d) return hipErrorInvalidValue;  // (the wide variant carries no derivative parts)
         hipLaunchKernelGGL((manifold_constraint_kernel<T, kBigClusterBodies, kBigClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
@@ -1606,23 +1698,27 @@ hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const in
     // cannot -- the caller's grid is for one per SIMD)
     size_t g = static_cast<size_t>(grid) * (sizeof(T) == 4 ? 4 : 2);
     const size_t n_tiles = (B + kWave - 1) / kWave;
+    // fewer than two tiles per wavefront slot: the column clusters of a tile go to workgroups of their own (TelloWithArms, 262 144 states:
+    // 4 096 tiles on 4 096 slots, every wavefront a chain of ~60 k dependent loads)
+    const unsigned gy = (n_tiles < 2 * g && n_clusters > 1) ? static_cast<unsigned>(n_clusters) : 1u;
     if (g > n_tiles) g = n_tiles;
     if (g < 1) g = 1;
+    const dim3 gr(static_cast<unsigned>(g), gy);
     if (interleave == kDerivGroup) {
-        hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup, kMaxClusterBodies, kMaxClusterDof>), dim3(static_cast<unsigned>(g)), dim3(kWave), 0, stream, P,
+        hipLaunchKernelGGL((manifold_project_kernel<T, kDerivGroup, kMaxClusterBodies, kMaxClusterDof>), gr, dim3(kWave), 0, stream, P,
                            n_clusters, span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
     } else {
-        hipLaunchKernelGGL((manifold_project_kernel<T, 1, kMaxClusterBodies, kMaxClusterDof>), dim3(static_cast<unsigned>(g)), dim3(kWave), 0, stream, P, n_clusters,
+        hipLaunchKernelGGL((manifold_project_kernel<T, 1, kMaxClusterBodies, kMaxClusterDof>), gr, dim3(kWave), 0, stream, P, n_clusters,
                            span_v, crow, rel, rel_s, nv_s, n_cpl_rows, mode, Aq, Av, Hs, tau_s, cpl, Dq, Dqd, H, B);
     }
     return hipGetLastError();
 }
 template hipError_t launch_manifold_constraint<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const int32_t *, int, int, int,
                                                       int, const float *, const float *, const float *, float *, float *, float *, float *,
-                                                      size_t, int, hipStream_t, bool);
+                                                      size_t, int, hipStream_t, int);
 template hipError_t launch_manifold_constraint<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const int32_t *, int, int,
                                                        int, int, const double *, const double *, const double *, double *, double *, double *,
-                                                       double *, size_t, int, hipStream_t, bool);
+                                                       double *, size_t, int, hipStream_t, int);
 template hipError_t launch_manifold_project<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const uint64_t *,
                                                    const uint64_t *, int, int, int, const float *, const float *, const float *, const float *,
                                                    const float *, float *, float *, float *, size_t, int, hipStream_t, int, bool);
