@@ -540,7 +540,7 @@ def main():
                      "kernel": kernel_name,
                      "kernel_ms": kernel_ms, "bytes_per_eval": bytes_per_eval,
                      "note": "`achieved`/`frac` price the ALGORITHMIC bytes as the contract asks; `frac_traffic` prices the "
-                             "HBM-side bytes rocprofv3 counted; what binds is per-wavefront latency -- dependent VALU issue (~10 cycles, tools/pk_rate.hip) and scalar / LDS / slab waits at two wavefronts per SIMD -- not bytes and not the VALU instruction count (see valu; DESIGN.md 4)",
+                             "HBM-side bytes rocprofv3 counted; what binds is instruction issue -- two wavefronts per SIMD run at ~85 % of the rate this instruction mix (dependent VALU chains, scalar / LDS / slab waits) issues at, profiles/r5_chain_phase_profile.txt -- not bytes and not flops (see valu; DESIGN.md 4)",
                      "valu": {"flops_model": flops, "flops_pmc": flops_pmc, "flops_pmc_source": flops_pmc_src,
                               "flops_per_eval": flops_pmc if flops_pmc is not None else flops,
                               "achieved_tflops": kernel_evals_per_s * (flops_pmc if flops_pmc is not None else flops) / 1e12,
