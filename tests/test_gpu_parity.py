@@ -497,6 +497,30 @@ def test_branch_sparse_solve_matches_the_matrix_core_solve(name, gpu, monkeypatc
         assert float((got_dq.double() - ref["dq"].double()).abs().max() / (1.0 + ref["dq"].abs().max())) < tol
 
 
+@pytest.mark.parametrize("name", ["urdf_four_bar", "tello_with_arms", "tello"])
+def test_constraint_kernel_builds_agree(name, gpu, monkeypatch):
+    """Models whose implicit clusters all have at most 4 bodies / 2 independent coordinates run manifold_constraint_kernel<T, 4, 2> (half the
+    unrolled work areas, two wavefronts per SIMD in fp32); GRBDA_NO_SMALL_CONSTRAINT=1 keeps the <T, 8, 4> build every other model uses.  Same
+    formulas, same operation order per entry: all three derivative matrices and the mass matrix agree to rounding, on a batch with several chunks
+    of column-cluster workgroups and a ragged tile."""
+    import torch
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    monkeypatch.setenv("GRBDA_NO_SMALL_CONSTRAINT", "1")
+    plain = G.Plan(blob)
+    monkeypatch.delenv("GRBDA_NO_SMALL_CONSTRAINT")
+    q, qd, tau = valid_states(blob, 777, config_index=33)
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=gpu)
+        a, b = plan.fd_derivatives(t(q), t(qd), t(tau)), plain.fd_derivatives(t(q), t(qd), t(tau))
+        for k in ("dq", "dqd", "dtau"):
+            assert torch.isfinite(a[k]).all()
+            assert float((a[k].double() - b[k].double()).abs().max() / (1.0 + b[k].double().abs().max())) < tol, (k, str(dt))
+        Ha, Hb = plan.mass_matrix(t(q)).double(), plain.mass_matrix(t(q)).double()
+        assert float((Ha - Hb).abs().max() / (1.0 + Hb.abs().max())) < tol
+
+
 @pytest.mark.parametrize("name", ["urdf_four_bar", "urdf_planar_leg_linkage"])
 def test_manifold_dq_against_extended_precision_differences(name, gpu):
     """d ydd / d q of implicit clusters NEAR SINGULAR POSES, without a conditioning filter: the analytic route through the spanning tree
