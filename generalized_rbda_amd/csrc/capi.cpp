@@ -1506,7 +1506,8 @@ int derived(const grbda_plan *p, int mode, const T *q, const T *qd, const T *tau
                 e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, out + b0 * static_cast<size_t>(nv) * nv, nbp,
                                    static_cast<T *>(scratch), static_cast<int>(gp), hs, true, ilp);
                 if (e != hipSuccess) return hip_err(e, "crba launch");
-                size_t g2 = static_cast<size_t>(t->n_cu) * 16;
+                // (a persistent grid: no more workgroups than the LDS of a CU holds at once -- 12 of JVRC-1's 12.4 KB blocks, not 16)
+                size_t g2 = static_cast<size_t>(t->n_cu) * std::min<size_t>(16, lds_workgroups_per_cu(unpack_symmetric_lds_bytes(nv, sizeof(T), ilp) + 512));
                 if (g2 > nbp / ilp) g2 = nbp / ilp;
                 e = launch_unpack_symmetric<T>(out + b0 * static_cast<size_t>(nv) * nv, t->deriv_related, nv, nbp, static_cast<int>(g2), hs, ilp);
                 if (e != hipSuccess) return hip_err(e, "unpack launch");
@@ -1783,7 +1784,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         if (e != hipSuccess) return hip_err(e, "manifold projection launch");
         if (!solve) {
             // packed lower rows -> the full symmetric matrix, in place
-            size_t g4 = static_cast<size_t>(t->n_cu) * 16;
+            size_t g4 = static_cast<size_t>(t->n_cu) * std::min<size_t>(16, lds_workgroups_per_cu(unpack_symmetric_lds_bytes(static_cast<int>(nv), sizeof(T), 1) + 512));
             if (g4 > nb) g4 = nb;
             e = launch_unpack_symmetric<T>(H, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g4), hs, 1);
             if (e != hipSuccess) return hip_err(e, "unpack launch");
@@ -1792,7 +1793,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), sizeof(T), n_rhs);
         size_t per_cu = lds ? lds_workgroups_per_cu(lds) : 16;
         const bool mfma = need_d && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs);
-        if (per_cu > (mfma ? 2u : 16u)) per_cu = mfma ? 2 : 16;
+        if (per_cu > (mfma ? static_cast<size_t>(spd_mfma_workgroups_per_cu(static_cast<int>(nv))) : 16u)) per_cu = mfma ? spd_mfma_workgroups_per_cu(static_cast<int>(nv)) : 16;
         if (per_cu < 1) per_cu = 1;
         size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
         const size_t units = mfma ? (nb + kDerivGroup - 1) / kDerivGroup : nb;
@@ -1928,7 +1929,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         const size_t lds = spd_solve_lds_bytes(static_cast<int>(nv), wide ? 8 : sizeof(T), (dq ? 1 : 0) + (dqd ? 1 : 0));
         size_t per_cu = lds ? lds_workgroups_per_cu(lds) : 16;
         const bool mfma = !wide && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs);
-        if (per_cu > (mfma ? 2u : 16u)) per_cu = mfma ? 2 : 16;  // (matrix-core kernel: workgroups of four wavefronts, two wavefronts per SIMD)
+        if (per_cu > (mfma ? static_cast<size_t>(spd_mfma_workgroups_per_cu(static_cast<int>(nv))) : 16u)) per_cu = mfma ? spd_mfma_workgroups_per_cu(static_cast<int>(nv)) : 16;  // (matrix-core kernel: workgroups of four wavefronts)
         if (per_cu < 1) per_cu = 1;
         size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
         const size_t units = mfma ? (nb + kDerivGroup - 1) / kDerivGroup : nb;

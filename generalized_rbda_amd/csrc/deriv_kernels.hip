@@ -912,6 +912,14 @@ static size_t spd_mfma_lds_bytes(int nv, int n_rhs)
     // per WORKGROUP of kDerivGroup wavefronts; the H block is staged where the right-hand sides go
     return static_cast<size_t>(kDerivGroup) * (static_cast<size_t>(nvb) * ws + static_cast<size_t>(n_rhs > 1 ? n_rhs : 1) * nv * nv) * 4;
 }
+// wavefronts per SIMD (= workgroups per CU) of the matrix-core solve for nv <= 24: the kernel is bound by the issue of mostly dependent
+// instruction chains, which a third wavefront fills in -- MIT Humanoid all three matrices 3.03 -> 2.75 ms per 262 144 states, Mini Cheetah
+// 0.675 -> 0.614 per 65 536; a fourth costs spills (3.03); nv > 24 needs the registers (246 .. 256) and the LDS of two
+// (experiment builds: -DGRBDA_EXP_MF_WAVES24=2|4)
+#ifndef GRBDA_EXP_MF_WAVES24
+#define GRBDA_EXP_MF_WAVES24 3
+#endif
+int spd_mfma_workgroups_per_cu(int nv) { return nv <= 24 ? GRBDA_EXP_MF_WAVES24 : 2; }  // (= wavefronts per SIMD: workgroups of four)
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs)
 {
     static const bool valu = [] { const char *e = std::getenv("GRBDA_SOLVE_VALU"); return e && std::atoi(e) != 0; }();
@@ -1153,7 +1161,8 @@ __device__ unsigned long long mf_prof[8];
 #endif
 
 template <int NVV>
-__global__ __launch_bounds__(kWave * kDerivGroup) __attribute__((amdgpu_waves_per_eu(NVV > 48 ? 1 : 2, 2)))
+__global__ __launch_bounds__(kWave * kDerivGroup)
+    __attribute__((amdgpu_waves_per_eu(NVV > 48 ? 1 : (NVV <= 24 ? GRBDA_EXP_MF_WAVES24 : 2), NVV <= 24 ? GRBDA_EXP_MF_WAVES24 : 2)))
 void spd_mfma_kernel(const float *H, int h_packed, int h_il, const float *P1, const float *P2, int p_il, float *Hinv, float *X1, float *X2,
                      const uint64_t *__restrict__ related, int nv, size_t B)
 {

@@ -241,6 +241,7 @@ hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, 
 // device address of the bad-pivot counter of the SPD solves (deriv_kernels.hip; nullptr when it cannot be resolved): the solve of the wide
 // route (manifold_kernels.hip, another translation unit) counts into the same word
 unsigned long long *spd_bad_count_address();
+int spd_mfma_workgroups_per_cu(int nv);
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
 // branch-sparse L^T L solve (tree_solve.h): eight states per wavefront, the right-hand sides as IO.kind says (0 identity, 1 / 2 packed runs)
 struct TreeSolveDev {

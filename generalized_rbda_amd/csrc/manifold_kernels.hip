@@ -1074,52 +1074,71 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
                 }
                 continue;
             }
-            for (int a = 0; a < nJ; a++) {
+            // (J is a static or an implicit cluster here: the base's columns went above.)  NC columns at a time: the entries of A_q / A_v / H_s of
+            // a cluster pair are read once per NC columns of J
+#ifdef GRBDA_EXP_NC
+            constexpr int NC = GRBDA_EXP_NC;
+#else
+            constexpr int NC = sizeof(T) == 4 ? 2 : 1;  // (fp64 with two: 234 registers + scratch, one wavefront per SIMD)
+#endif
+            for (int a0 = 0; a0 < nJ; a0 += NC) {
                 // column data over the spanning coordinates of cluster J: G e_a, G_a' yd, G_a' ydd + dg/dy_a, dg/dyd_a
-                T gJ[KB], ayJ[KB], byJ[KB], bvJ[KB];
+                T gJ[KB][NC], ayJ[KB][NC], byJ[KB][NC], bvJ[KB][NC];
                 int svJ[KB];
                 for (int s = 0; s < KB; s++) {
-                    gJ[s] = ayJ[s] = byJ[s] = bvJ[s] = 0;
+#pragma unroll
+                    for (int u = 0; u < NC; u++) gJ[s][u] = ayJ[s][u] = byJ[s][u] = bvJ[s][u] = 0;
                     svJ[s] = 0;
                     if (s >= kJ) continue;
-                    if (J.kind == CK_FREE) {
-                        svJ[s] = span_v[J.first_body] + s;
-                        gJ[s] = s == a ? T(1) : T(0);
-                    } else if (J.kind == CK_STATIC) {
-                        svJ[s] = span_v[J.first_body + s];
-                        gJ[s] = consts[load_rec(bodies + (J.first_body + s)).cofs + kBodyConstFixed + a];
-                    } else {
-                        svJ[s] = span_v[J.first_body + s];
-                        gJ[s] = cJp[(size_t)(s * strideJ + a) * kWave];
-                        if (mode == 0) {
-                            ayJ[s] = cJp[(size_t)(s * strideJ + J.n + a) * kWave];
-                            byJ[s] = cJp[(size_t)(s * strideJ + 2 * J.n + a) * kWave];
-                            bvJ[s] = cJp[(size_t)(s * strideJ + 3 * J.n + a) * kWave];
+                    svJ[s] = span_v[J.first_body + s];
+#pragma unroll
+                    for (int u = 0; u < NC; u++) {
+                        const int a = a0 + u;
+                        if (a >= nJ) continue;
+                        if (J.kind == CK_STATIC) {
+                            gJ[s][u] = consts[load_rec(bodies + (J.first_body + s)).cofs + kBodyConstFixed + a];
+                        } else {
+                            gJ[s][u] = cJp[(size_t)(s * strideJ + a) * kWave];
+                            if (mode == 0) {
+                                ayJ[s][u] = cJp[(size_t)(s * strideJ + J.n + a) * kWave];
+                                byJ[s][u] = cJp[(size_t)(s * strideJ + 2 * J.n + a) * kWave];
+                                bvJ[s][u] = cJp[(size_t)(s * strideJ + 3 * J.n + a) * kWave];
+                            }
                         }
                     }
                 }
-                const int vJ = J.v_index + a;
                 for (int cI = 0; cI < n_clusters; cI++) {
                     const ClusterRec I = load_rec(clusters + cI);
                     if (!((rel[I.v_index] >> J.v_index) & 1)) continue;  // clusters on different branches: structural zeros
                     const int nI = I.kind == CK_FREE ? 6 : I.n, kI = I.kind == CK_FREE ? 6 : I.k;
                     const int strideI = I.kind == CK_LOOP ? cpl_stride<KB>(I.n) : 0;
                     const T *cIp = cp + (size_t)(I.kind == CK_LOOP ? crow[cI] : 0) * kWave;
-                    T oq[KN + 2], ov[KN + 2], oh[KN + 2];
-                    for (int b2 = 0; b2 < KN + 2; b2++) oq[b2] = ov[b2] = oh[b2] = 0;
+                    T oq[KN + 2][NC], ov[KN + 2][NC], oh[KN + 2][NC];
+                    for (int b2 = 0; b2 < KN + 2; b2++)
+#pragma unroll
+                        for (int u = 0; u < NC; u++) oq[b2][u] = ov[b2][u] = oh[b2][u] = 0;
                     for (int ri = 0; ri < kI; ri++) {
                         const int r = I.kind == CK_FREE ? span_v[I.first_body] + ri : span_v[I.first_body + ri];
                         const uint64_t rr = rel_s[r];
-                        T colq = 0, colv = 0, colh = 0;
+                        T colq[NC], colv[NC], colh[NC];
+#pragma unroll
+                        for (int u = 0; u < NC; u++) colq[u] = colv[u] = colh[u] = 0;
                         for (int s = 0; s < kJ; s++) {
                             const int sv = svJ[s];
                             if (!((rr >> sv) & 1)) continue;
                             const T h = hs[sym(r, sv) * kWave];
-                            colh += h * gJ[s];
+                            T x = 0, y = 0;
                             if (mode == 0) {
-                                const T x = aq[packed(r, sv) * kWave], y = av[packed(r, sv) * kWave];
-                                colq += x * gJ[s] + y * ayJ[s] + h * byJ[s];
-                                colv += y * gJ[s] + h * bvJ[s];
+                                x = aq[packed(r, sv) * kWave];
+                                y = av[packed(r, sv) * kWave];
+                            }
+#pragma unroll
+                            for (int u = 0; u < NC; u++) {
+                                colh[u] += h * gJ[s][u];
+                                if (mode == 0) {
+                                    colq[u] += x * gJ[s][u] + y * ayJ[s][u] + h * byJ[s][u];
+                                    colv[u] += y * gJ[s][u] + h * bvJ[s][u];
+                                }
                             }
                         }
                         for (int b2 = 0; b2 < nI; b2++) {
@@ -1127,24 +1146,35 @@ __global__ __launch_bounds__(kWave, 1) void manifold_project_kernel(DevPlan<T> D
                             if (I.kind == CK_FREE) g = ri == b2 ? T(1) : T(0);
                             else if (I.kind == CK_STATIC) g = consts[load_rec(bodies + (I.first_body + ri)).cofs + kBodyConstFixed + b2];
                             else g = cIp[(size_t)(ri * strideI + b2) * kWave];
-                            oq[b2] += g * colq;
-                            ov[b2] += g * colv;
-                            oh[b2] += g * colh;
+#pragma unroll
+                            for (int u = 0; u < NC; u++) {
+                                oq[b2][u] += g * colq[u];
+                                ov[b2][u] += g * colv[u];
+                                oh[b2][u] += g * colh[u];
+                            }
                         }
                         // (d G^T / d y_a) tau_s: own cluster only, dependent bodies carry the rows of G_a'
                         if (mode == 0 && cI == cJ && I.kind == CK_LOOP) {
                             const T tr = ts[r];
-                            for (int b2 = 0; b2 < nI; b2++) oq[b2] += cIp[(size_t)(ri * strideI + 4 * I.n + a * I.n + b2) * kWave] * tr;
+                            for (int b2 = 0; b2 < nI; b2++)
+#pragma unroll
+                                for (int u = 0; u < NC; u++)
+                                    if (a0 + u < nJ) oq[b2][u] += cIp[(size_t)(ri * strideI + 4 * I.n + (a0 + u) * I.n + b2) * kWave] * tr;
                         }
                     }
                     if (live) {
                         for (int b2 = 0; b2 < nI; b2++) {
                             const int vI = I.v_index + b2;
-                            if (mode == 0) {
-                                Dqs[packed(vI, vJ) * IL] = oq[b2];
-                                Dqds[packed(vI, vJ) * IL] = ov[b2];
+#pragma unroll
+                            for (int u = 0; u < NC; u++) {
+                                if (a0 + u >= nJ) continue;
+                                const int vJ = J.v_index + a0 + u;
+                                if (mode == 0) {
+                                    Dqs[packed(vI, vJ) * IL] = oq[b2][u];
+                                    Dqds[packed(vI, vJ) * IL] = ov[b2][u];
+                                }
+                                if (vJ <= vI) Hout[sym(vI, vJ) * IL] = oh[b2][u];
                             }
-                            if (vJ <= vI) Hout[sym(vI, vJ) * IL] = oh[b2];
                         }
                     }
                 }
