@@ -155,6 +155,190 @@ def verify_sample(blob, q, qd, x, out, algo, dtype_name, n=1024):
             "verify_max_rel_err": float(err.max()), "verify_states_over_tol": int((err >= tol).sum()), "verify_tol": tol}
 
 
+def load_plan(G, workload):
+    """the plan of a WORKLOADS entry (TelloWithArms is hand-built: its URDF carries no constraints)"""
+    urdf = WORKLOADS[workload][0]
+    if workload == "tello":
+        from generalized_rbda_amd.robots import tello_with_arms
+
+        return G.Plan.from_model(tello_with_arms())
+    return G.Plan.from_urdf(os.path.join(ROOT, "tests", "golden", "robot-models", urdf))
+
+
+def committed_counters(sha, workload, algo, dtype_name, B):
+    """(traffic bytes per launch, source, flops per eval, source) from the PMC files committed under profiles/ -- only counters
+    taken on THESE kernel sources (a file records the sha of the sources it was measured on; others are refused, not printed
+    next to a fresh time)"""
+    traffic, traffic_src, stale = None, None, []
+    for fname in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                doc = json.load(f)
+            if doc.get("kernel_sources_sha") != sha:
+                stale.append(fname)
+                continue
+            for e in doc["entries"]:
+                if traffic is None and (e["workload"], e["algo"], e["dtype"], e["batch"]) == (workload, algo, dtype_name, B):
+                    traffic = e["bytes_per_launch"]
+                    traffic_src = f"rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/{fname} (kernel sources {sha})"
+        except (OSError, KeyError, ValueError):
+            pass
+    if traffic is None and stale:
+        traffic_src = f"no counters for kernel sources {sha}: {', '.join('profiles/' + x for x in stale)} were taken on other sources (refused)"
+    flops_pmc, flops_pmc_src = None, None
+    for fname in ("r6_pmc_flops.json", "r5_pmc_flops.json", "r4_pmc_flops.json", "r3_pmc_flops.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                doc = json.load(f)
+            if doc.get("kernel_sources_sha") != sha:
+                continue
+            for e in doc["entries"]:
+                if flops_pmc is None and (e["workload"], e["algo"], e["dtype"]) == (workload, algo, dtype_name):
+                    flops_pmc, flops_pmc_src = e["flops_per_eval"], f"profiles/{fname}: " + e["source"]
+        except (OSError, KeyError, ValueError):
+            pass
+    return traffic, traffic_src, flops_pmc, flops_pmc_src
+
+
+def verify_derivatives(plan, q, qd, tau, d, dtype_name, n=24):
+    """d ydd / d (q, qd, tau) of a strided sample against differences of the ORACLE's forward dynamics along the reference's
+    tangent step (the reference's own yardstick, testRigidBodyDynamicsAlgosDerivatives.cpp:309-380): d tau exact (affine),
+    d qd exact (quadratic), d q central differences with h = 1e-6."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    from generalized_rbda_amd.states import parse_clusters, tangent_step
+
+    blob, nv, B = plan.blob, plan.nv, q.shape[0]
+    idx = np.unique(np.concatenate([[0, min(63, B - 1), min(64, B - 1)], np.linspace(0, B - 1, num=min(n, B), dtype=np.int64), [B - 1]]))
+    c = (lambda a: a.astype(np.float32).astype(np.float64)) if dtype_name == "f32" else (lambda a: a)
+    qs, qds, ts = c(q[idx]), c(qd[idx]), c(tau[idx])
+    m = parse_clusters(blob)
+    threads = os.cpu_count() or 1
+    fd = lambda a, b, x: O.forward_dynamics_mt(blob, a, b, x, threads)
+    h, ns = 1e-6, idx.size
+    ref = {k: np.empty((ns, nv, nv)) for k in d}
+    f0 = fd(qs, qds, ts)
+    for k in range(nv):
+        e = np.zeros(nv)
+        e[k] = 1.0
+        if "dq" in d:
+            qp = np.stack([tangent_step(m, qs[i], k, +h) for i in range(ns)])
+            qm = np.stack([tangent_step(m, qs[i], k, -h) for i in range(ns)])
+            ref["dq"][:, :, k] = (fd(qp, qds, ts) - fd(qm, qds, ts)) / (2 * h)
+        if "dqd" in d:
+            ref["dqd"][:, :, k] = (fd(qs, qds + e, ts) - fd(qs, qds - e, ts)) / 2.0
+        if "dtau" in d:
+            ref["dtau"][:, :, k] = fd(qs, qds, ts + e) - f0
+    tol = 1e-3 if dtype_name == "f32" else 2e-5  # (fp64: the central differences themselves, the reference's 2e-5)
+    worst, finite = 0.0, True
+    sel = torch.as_tensor(idx, device=next(iter(d.values())).device)
+    for k in d:
+        got = d[k][sel].double().cpu().numpy()
+        finite = finite and bool(np.isfinite(got).all())
+        worst = max(worst, float((np.abs(got - ref[k]).max(axis=(1, 2)) / (1.0 + np.abs(ref[k]).max(axis=(1, 2)))).max()))
+    return {"verified": bool(finite and worst < tol), "verify_states": int(ns), "verify_max_rel_err": worst, "verify_tol": tol}
+
+
+# The BASELINE configs beside the headline one, each as a compact sub-record of the default single-GPU line (`configs`): the
+# driver's run is the only measurement anyone but the builder takes, so every config is in it.
+CONFIG_RECORDS = [
+    # (BASELINE config, workload, algo, dtype, batch)
+    (1, "revolute_rotor_chain", "aba", "f64", 1024),
+    (2, "mini_cheetah", "aba", "f64", 65536),
+    (3, "mit_humanoid", "rnea", "f32", 262144),
+    (4, "tello", "aba", "f32", 1048576),
+    (4, "tello", "rnea", "f32", 1048576),
+    (5, "jvrc1_humanoid", "aba", "f32", 1048576),
+    (5, "jvrc1_humanoid", "fd_derivatives", "f32", 1048576),
+    (5, "four_bar", "aba", "f32", 1048576),
+    (5, "six_bar", "aba", "f32", 1048576),
+]
+
+
+def config_records(G, dev, steps, sha, only=None):
+    """one sub-record per CONFIG_RECORDS row: K launches bracketed by synchronize (median of 3 repetitions), the kernel's own
+    duration from hipEvents (grbda_time_kernel), a strided sample against the oracle after the timed region"""
+    import numpy as np
+    import torch
+
+    from generalized_rbda_amd.states import valid_random_states_device
+
+    out_recs, cache = [], {}
+    for cfg_no, workload, algo, dtype_name, B in CONFIG_RECORDS:
+        if only and workload not in only:
+            continue
+        rec = {"config": cfg_no, "workload": workload, "algo": algo, "dtype": dtype_name, "batch": B}
+        try:
+            if workload not in cache:
+                cache.clear()  # (one workload's inputs at a time: a million-state batch in fp64 on the host is ~1 GB)
+                plan = load_plan(G, workload)
+                cache[workload] = (plan,) + tuple(valid_random_states_device(plan, B, WORKLOADS[workload][3], dev)[:3])
+            plan, q, qd, x = cache[workload]
+            tdt = torch.float32 if dtype_name == "f32" else torch.float64
+            elem = 4 if dtype_name == "f32" else 8
+            tq, tqd, tx = (torch.as_tensor(a, dtype=tdt, device=dev) for a in (q, qd, x))
+            info = plan.info()
+            if algo == "fd_derivatives":
+                # all three matrices of d ydd / d (q, qd, tau): ms per batch (the bar of this row is quoted in ms per 1 048 576 states)
+                d = plan.fd_derivatives(tq, tqd, tx)
+                torch.cuda.synchronize()
+                reps = []
+                for _ in range(3):
+                    del d
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    d = plan.fd_derivatives(tq, tqd, tx)
+                    torch.cuda.synchronize()
+                    reps.append(time.perf_counter() - t0)
+                ms = sorted(reps)[1] * 1e3
+                result_bytes = (3 * plan.nv * plan.nv + plan.nq + 2 * plan.nv) * elem
+                rec.update({"ms": ms, "evals_per_s": B / (ms * 1e-3), "ms_min": min(reps) * 1e3, "ms_max": max(reps) * 1e3,
+                            "what": "d ydd / d q, d qd, d tau (three [B, nv, nv] arrays) in one call, analytic",
+                            "kernel": "aba + rnea_deriv_kernel + spd solve (deriv_kernels.hip), chunked",
+                            "roofline": {"bound": "hbm", "bytes_per_eval": result_bytes, "achieved": B / (ms * 1e-3) * result_bytes / 1e9,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / (ms * 1e-3) * result_bytes / 1e9 / HBM_PEAK_GBS},
+                            "valu": None})
+                rec.update(verify_derivatives(plan, q, qd, x, d, dtype_name))
+                del d
+            else:
+                run = plan.forward_dynamics if algo == "aba" else plan.inverse_dynamics
+                out = torch.empty((B, plan.nv), dtype=tdt, device=dev)
+                for _ in range(3):
+                    run(tq, tqd, tx, out=out)
+                torch.cuda.synchronize()
+                reps = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        run(tq, tqd, tx, out=out)
+                    torch.cuda.synchronize()
+                    reps.append((time.perf_counter() - t0) / steps)
+                ms = sorted(reps)[1] * 1e3
+                kernel_ms = plan.time_kernel(algo, tq, tqd, tx, out, iters=max(5, min(steps, 50)))
+                bytes_per_eval = (plan.nq + 3 * plan.nv) * elem
+                _, _, flops_pmc, _ = committed_counters(sha, workload, algo, dtype_name, B)
+                flops = flops_pmc if flops_pmc is not None else (info.flops_aba if algo == "aba" else info.flops_rnea)
+                k_rate = B / (kernel_ms * 1e-3)
+                rec.update({"ms": ms, "evals_per_s": B / (ms * 1e-3), "kernel_ms": kernel_ms, "steps": steps,
+                            "kernel": plan.kernel_name(algo, dtype_name, B, dev.index or 0),
+                            "roofline": {"bound": "hbm", "bytes_per_eval": bytes_per_eval, "achieved": k_rate * bytes_per_eval / 1e9,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_rate * bytes_per_eval / 1e9 / HBM_PEAK_GBS},
+                            "valu": {"flops_per_eval": flops, "flops_source": "pmc" if flops_pmc is not None else "plan model",
+                                     "achieved_tflops": k_rate * flops / 1e12, "peak_tflops": VALU_PEAK_TFLOPS[dtype_name],
+                                     "frac": k_rate * flops / 1e12 / VALU_PEAK_TFLOPS[dtype_name]}})
+                rec.update(verify_sample(plan.blob, q, qd, x, out, algo, dtype_name))
+                del out
+            del tq, tqd, tx
+        except Exception as e:  # noqa: BLE001 -- a failing sub-record must not take the headline line with it
+            rec.update({"error": f"{type(e).__name__}: {e}", "verified": False})
+        out_recs.append(rec)
+    return out_recs
+
+
 def strong_split_record(G, dist, rank, world, dev, steps, replays, warmup):
     """BASELINE config 4 as it is named: ONE global batch of 1 048 576 TelloWithArms states split over the ranks (contiguous slabs,
     plan replicated, no data-path collective).  Timed like the main line: K steps (one hipGraph replay when it captures), bracketed by
@@ -169,15 +353,11 @@ def strong_split_record(G, dist, rank, world, dev, steps, replays, warmup):
 
     _, B_global, dtype_name, cfg = WORKLOADS["tello"]
     plan = G.Plan.from_model(tello_with_arms())
-    if rank == 0:
-        q, qd, x, _ = valid_random_states_device(plan, B_global, cfg, dev)
-    else:
-        q, qd, x = np.empty((B_global, plan.nq)), np.empty((B_global, plan.nv)), np.empty((B_global, plan.nv))
-    if world > 1:
-        for a in (q, qd, x):
-            tb = torch.as_tensor(a, dtype=torch.float64, device=dev)
-            dist.broadcast(tb, src=0)
-            a[...] = tb.cpu().numpy()
+    # every rank draws the SAME global batch itself (counter-based RNG, one seed; the Newton projection of the dependent
+    # coordinates runs on its own GPU) and keeps its contiguous slab: no broadcast of a gigabyte of fp64 states through rank 0
+    # and no extra barriers in the headline run.  Bounded: at most 20 steps, 3 repetitions.
+    steps, replays = min(steps, 20), min(replays, 3)
+    q, qd, x, _ = valid_random_states_device(plan, B_global, cfg, dev)
     lo, hi = shard_range(B_global, rank, world)
     tdt = torch.float32
     tq, tqd, tx = (torch.as_tensor(a[lo:hi], dtype=tdt, device=dev) for a in (q, qd, x))
@@ -270,6 +450,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's batch per GPU; strong: the workload's batch split over the GPUs")
     ap.add_argument("--replays", type=int, default=7, help="repetitions of the K timed steps (median reported)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` sub-records (the other BASELINE configs)")
+    ap.add_argument("--configs", default="", help="comma-separated workloads to keep in `configs` (default: all)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -329,12 +511,7 @@ def main():
     if args.dtype:
         dtype_name = args.dtype
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
-    if args.workload == "tello":
-        from generalized_rbda_amd.robots import tello_with_arms
-
-        plan = G.Plan.from_model(tello_with_arms())
-    else:
-        plan = G.Plan.from_urdf(os.path.join(ROOT, "tests", "golden", "robot-models", urdf))
+    plan = load_plan(G, args.workload)
     blob = plan.blob
     info = plan.info()
 
@@ -459,7 +636,7 @@ def main():
     strong = None
     if dist is not None and args.scaling == "weak" and args.workload == "mit_humanoid" and args.algo == "aba" and \
             os.environ.get("BENCH_NO_STRONG") != "1":
-        strong = strong_split_record(G, dist, rank, world, dev, args.steps, min(args.replays, 5), args.warmup)
+        strong = strong_split_record(G, dist, rank, world, dev, args.steps, args.replays, args.warmup)
 
     if rank != 0:
         if dist is not None:
@@ -476,36 +653,7 @@ def main():
     # measured HBM-side traffic of the same launch configuration, if a PMC run is committed (profiles/)
     # (only counters taken on THESE kernel sources: a file records the sha of the sources it was measured on)
     sha = kernel_sources_sha()
-    traffic, traffic_src, stale = None, None, []
-    for fname in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", fname)) as f:
-                doc = json.load(f)
-            if doc.get("kernel_sources_sha") != sha:
-                stale.append(fname)
-                continue
-            for e in doc["entries"]:
-                if traffic is None and (e["workload"], e["algo"], e["dtype"], e["batch"]) == (args.workload, args.algo, dtype_name, B):
-                    traffic = e["bytes_per_launch"]
-                    traffic_src = f"rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/{fname} (kernel sources {sha})"
-        except (OSError, KeyError, ValueError):
-            pass
-    if traffic is None and stale:
-        traffic_src = f"no counters for kernel sources {sha}: {', '.join('profiles/' + x for x in stale)} were taken on other sources (refused)"
-    # executed floating-point operations per evaluation from the committed instruction counters of the same launch
-    # configuration (2 x FMA + ADD + MUL + TRANS, x 64 lanes / batch), beside the plan compiler's operation model
-    flops_pmc, flops_pmc_src = None, None
-    for fname in ("r5_pmc_flops.json", "r4_pmc_flops.json", "r3_pmc_flops.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", fname)) as f:
-                doc = json.load(f)
-            if doc.get("kernel_sources_sha") != sha:
-                continue
-            for e in doc["entries"]:
-                if flops_pmc is None and (e["workload"], e["algo"], e["dtype"]) == (args.workload, args.algo, dtype_name):
-                    flops_pmc, flops_pmc_src = e["flops_per_eval"], f"profiles/{fname}: " + e["source"]
-        except (OSError, KeyError, ValueError):
-            pass
+    traffic, traffic_src, flops_pmc, flops_pmc_src = committed_counters(sha, args.workload, args.algo, dtype_name, B)
     from generalized_rbda_amd.states import parse_clusters
 
     general = any(c[9] >= 2 for c in parse_clusters(blob)["clusters"])
@@ -530,10 +678,11 @@ def main():
         "config": {"workload": f"{urdf} cluster-{'ABA' if args.algo == 'aba' else 'RNEA'}, {B} random states per GPU",
                    "batch_per_gpu": B, "batch_global": total_states, "nq": plan.nq, "nv": plan.nv, "n_bodies": plan.n_bodies,
                    "n_clusters": plan.n_clusters, "parallelism": f"batch-sharded x{world}, plan replicated"},
-        # `bound`: the resource the measurements say binds the kernel (per-wavefront latency: dependent VALU issue and scalar / LDS / slab
-        # waits at two wavefronts per SIMD -- profiles/r5_chain_phase_profile.txt); `achieved` / `peak` / `frac` stay the HBM figures of the
-        # ALGORITHMIC bytes the contract asks for (`bound_contract`), the VALU figures are under `valu`
-        "roofline": {"bound": "valu_issue", "bound_contract": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `bound` names the resource `achieved` / `peak` / `frac` are figures OF: the HBM roofline of the ALGORITHMIC bytes, as the
+        # contract asks.  `binding_measured` names the resource the measurements say binds the kernel (per-wavefront latency: dependent
+        # VALU issue and scalar / LDS / slab waits at two wavefronts per SIMD -- profiles/r5_chain_phase_profile.txt); its figures are
+        # under `valu`
+        "roofline": {"bound": "hbm", "binding_measured": "valu_issue", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_per_eval * B,
                      "frac_traffic": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -565,6 +714,10 @@ def main():
                                       "step i overlaps the kernel of step i + 1"}
     if strong is not None:
         line["strong"] = strong
+    if world == 1 and dist is None and not args.no_configs and args.workload == "mit_humanoid" and args.algo == "aba":
+        del tq, tqd, tx, out
+        line["configs"] = config_records(G, dev, max(5, min(args.steps, 20)), sha,
+                                         only=set(args.configs.split(",")) if args.configs else None)
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(blob, q, qd, x)
     elif world == 1:

@@ -112,6 +112,38 @@ def random_states(blob: bytes, B: int, config_index: int = 0, dtype=np.float64):
     return q.astype(dtype), qd.astype(dtype), tau.astype(dtype)
 
 
+def tangent_step(m, q: np.ndarray, k: int, d: float) -> np.ndarray:
+    """One state q after the reference's tangent step d along velocity coordinate k (TestHelpers::plus,
+    UnitTests/testHelpers.hpp:50-112) -- the step the reference's derivative tests difference along, and therefore the
+    coordinates d ydd / d q is expressed in.  `m` = parse_clusters(blob).  Free base: positions [pos 3, quat 4 scalar first],
+    velocities [angular 3, linear 3]: an angular step multiplies the quaternion by (0, d) / 2, a linear step moves the position
+    by R^T d; a roll-pitch-yaw base and every other coordinate take plain q + d.  Explicit models only (an implicit cluster's
+    dependent positions must be re-projected by the caller)."""
+    q = np.array(q, dtype=np.float64, copy=True)
+    for c in m["clusters"]:
+        (pc, fb, kk, qi, npos, vi, nvel, nsp, nsv, ctype, rows, io, ni, do, nd, _) = c
+        if not (vi <= k < vi + nvel):
+            continue
+        a = k - vi
+        if ctype == C_FREE and m["ori"] == ORI_QUATERNION:
+            e0, e1, e2, e3 = quat = q[qi + 3: qi + 7].copy()
+            # quaternionToRotationMatrix (OrientationTools.h:251-269) returns the transpose of this matrix; R^T is the matrix itself
+            Rt = np.array([[1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2)],
+                           [2 * (e1 * e2 + e0 * e3), 1 - 2 * (e1 * e1 + e3 * e3), 2 * (e2 * e3 - e0 * e1)],
+                           [2 * (e1 * e3 - e0 * e2), 2 * (e2 * e3 + e0 * e1), 1 - 2 * (e1 * e1 + e2 * e2)]])
+            dv = np.zeros(3)
+            if a < 3:
+                dv[a] = d
+                w, v = quat[0], quat[1:]
+                q[qi + 3: qi + 7] = quat + 0.5 * np.concatenate([[-v @ dv], w * dv + np.cross(v, dv)])
+            else:
+                dv[a - 3] = d
+                q[qi: qi + 3] += Rt @ dv
+        else:
+            q[qi + a] += d
+    return q
+
+
 def accept(blob: bytes, q: np.ndarray, gmax: np.ndarray, kcond: np.ndarray) -> np.ndarray:
     """The conditioning gate (module docstring): bool[B].  gmax[B] = max |K_d^-1 K_i| and kcond[B] = max |K_d|_F |K_d^-1|_F
     over the implicit clusters, from the product (``Plan.constraint_gain``) or from the oracle
