@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("GRBDA_HIP_LIB") or os.path.join(_HERE, "libgrbda_hip.
 # every entry point include/grbda_hip.h declares
 C_ABI_SYMBOLS = [
     "grbda_strerror", "grbda_last_error", "grbda_plan_from_blob", "grbda_plan_from_urdf", "grbda_urdf_to_blob",
-    "grbda_plan_free", "grbda_plan_dims", "grbda_plan_set_gravity", "grbda_plan_get_gravity", "grbda_plan_blob",
+    "grbda_plan_free", "grbda_plan_release_work", "grbda_plan_dims", "grbda_plan_set_gravity", "grbda_plan_get_gravity", "grbda_plan_blob",
     "grbda_plan_info", "grbda_aba_f64", "grbda_aba_f32", "grbda_rnea_f64", "grbda_rnea_f32",
     "grbda_aba_host_f64", "grbda_rnea_host_f64", "grbda_time_kernel", "grbda_device_count",
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
@@ -83,6 +83,7 @@ def lib() -> ctypes.CDLL:
     L.grbda_urdf_to_blob.argtypes = [POINTER(c_char_p), c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]
     L.grbda_plan_free.argtypes = [c_void_p]
     L.grbda_plan_free.restype = None
+    L.grbda_plan_release_work.argtypes = [c_void_p, POINTER(ctypes.c_ulonglong)]
     L.grbda_plan_dims.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     L.grbda_plan_set_gravity.argtypes = [c_void_p, POINTER(c_double)]
     L.grbda_plan_get_gravity.argtypes = [c_void_p, POINTER(c_double)]
@@ -194,6 +195,13 @@ class Plan:
         arr = (c_double * 3)()
         _check(lib().grbda_plan_get_gravity(self._h, arr))
         return list(arr)
+
+    def release_work(self) -> int:
+        """Frees the work buffers the chunked pipelines keep per (device, stream) between calls (grbda_plan_release_work);
+        returns the bytes handed back."""
+        n = ctypes.c_ulonglong(0)
+        _check(lib().grbda_plan_release_work(self._h, byref(n)))
+        return int(n.value)
 
     def info(self) -> PlanInfo:
         info = PlanInfo()

@@ -63,6 +63,8 @@ struct DeviceTables {
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
     int32_t *tree_tab = nullptr;        // DerivProgram::tree (TreeSolveProgram::tab)
+    MinvBody *minv_bodies = nullptr;    // DerivProgram::minv (plan.h, MinvProgram): record offsets per body ...
+    int32_t *minv_coltab = nullptr;     // ... and the column programs of minv_mfma_kernel
     int32_t *related_table = nullptr;   // HostPlan::related_table (plans of the wide route with more than 64 velocities)
     int32_t *span_q = nullptr, *span_v = nullptr, *crow = nullptr;  // grbda_plan::span_q / span_v / crow
     // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w)
@@ -141,6 +143,8 @@ struct grbda_plan {
     int crba_waves = 16;       // GRBDA_CRBA_WAVES_PER_CU: grid of the composite-rigid-body kernel (fp32: 99 registers, four wavefronts per SIMD:
                                // JVRC-1 mass matrix 1.95 -> 1.81 ms per 262 144 states against eight per CU; fp64 is capped at eight)
     int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 3)
+    bool no_minv = false;      // GRBDA_NO_MINV=1: the derivative pipeline keeps the dense factorisation of H (A/B runs)
+    int minv_wpc = 0;          // GRBDA_MINV_WPC: upper limit of the workgroups per CU of minv_mfma_kernel (0: what registers and LDS hold)
     bool no_efpa = false;  // GRBDA_NO_EFPA=1: inverse OSIM through unit wrenches and the ABA / RNEA kernels  // GRBDA_NO_CRBA=1: mass matrix through nv + 1 inverse-dynamics evaluations (the path of loop models)
     bool chain_wide = false;  // GRBDA_CHAIN_WIDE=1: chain kernel at four wavefronts per SIMD for batches that fill them
     // Models with implicit clusters: the spanning-tree model as a plan of its own (plan.cpp, make_spanning_blob) -- the analytic
@@ -250,6 +254,10 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     if (h.deriv.tree.ok &&
         (e = up(h.deriv.tree.tab.data(), h.deriv.tree.tab.size() * sizeof(int32_t), (void **)&t.tree_tab)) != hipSuccess)
         return hip_err(e, "plan upload");
+    if (h.deriv.ok && h.deriv.minv.ok &&
+        ((e = up(h.deriv.minv.bodies.data(), h.deriv.minv.bodies.size() * sizeof(MinvBody), (void **)&t.minv_bodies)) != hipSuccess ||
+         (e = up(h.deriv.minv.coltab.data(), h.deriv.minv.coltab.size() * sizeof(int32_t), (void **)&t.minv_coltab)) != hipSuccess))
+        return hip_err(e, "plan upload");
     for (int w = 0; w < 5; w++) {
         const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : h.chain64p)));
         if (!cp.ok) continue;
@@ -274,6 +282,7 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     t.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = set_max_dynamic_lds()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     if ((e = set_max_dynamic_lds_deriv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
+    if ((e = set_max_dynamic_lds_minv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     auto ins = p->dev.emplace(device, t);
     *out = &ins.first->second;
     return 0;
@@ -307,19 +316,32 @@ int ensure_scratch(const grbda_plan *p, int device, void *stream, size_t bytes, 
 
 // The per-(device, stream) work slab of the derived quantities, grown on demand under the same rule as ensure_scratch: never
 // while the stream captures (a graph captured earlier holds the old address).
-// Upper bound of a work-slab request of the chunked pipelines (derivatives, projection): what the call site asks for (1-4 GiB, sized so that a
-// million states go through in a few chunks), cut to a quarter of the memory that is FREE on the device right now (never below 256 MiB) and to
-// GRBDA_WORK_MAX_MB when that is set.  The slabs are kept per (device, stream) until grbda_plan_free and never shrink, so several streams or
-// plans could otherwise pin tens of GiB unnoticed (advisor, round 4).
-static size_t work_budget(size_t want)
+// Upper bound of a work-slab request of the chunked pipelines (derivatives, projection): what the call site asks for (1-16 GiB, sized so that a
+// million states go through in a few chunks), cut to GRBDA_WORK_MAX_MB when that is set and to
+//     max(the slab this (device, stream) already holds, a quarter of the memory that is FREE on the device right now, 256 MiB)
+// so that (a) a call never shrinks below what it already owns -- the chunk, and with it the timing, of a repeated call is reproducible whatever
+// else has been allocated since -- and (b) a stream that is being CAPTURED derives its chunk from the held slab alone (no hipMemGetInfo, no
+// growth: INTEGRATION.md's rule "run the largest batch once on the stream before capturing" then always suffices).  The slabs are kept per
+// (device, stream) and never shrink by themselves; grbda_plan_release_work() hands them back.
+static size_t work_budget(const grbda_plan *p, const std::map<std::pair<int, void *>, Scratch> &pool, int device, void *stream, size_t want)
 {
     const int want_mb = env_int("GRBDA_WORK_WANT_MB", 0);  // (experiments: another chunk size)
     size_t cap = want_mb > 0 ? static_cast<size_t>(want_mb) << 20 : want;
+    size_t held = 0;
+    {
+        std::lock_guard<std::recursive_mutex> lk(p->mu);
+        const auto it = pool.find({device, stream});
+        if (it != pool.end()) held = it->second.bytes > 256 ? it->second.bytes - 256 : 0;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (capturing && held > 0) return cap < held ? cap : held;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
-        size_t quarter = free_b / 4;
-        if (quarter < (256ull << 20)) quarter = 256ull << 20;
-        if (cap > quarter) cap = quarter;
+    if (!capturing && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+        size_t limit = free_b / 4;
+        if (limit < (256ull << 20)) limit = 256ull << 20;
+        if (limit < held) limit = held;
+        if (cap > limit) cap = limit;
     }
     const int mb = env_int("GRBDA_WORK_MAX_MB", 0);
     if (mb > 0 && cap > (static_cast<size_t>(mb) << 20)) cap = static_cast<size_t>(mb) << 20;
@@ -852,7 +874,7 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
         const size_t nq = p->host.nq, nv = p->host.nv, nq_s = p->span->host.nq, nv_s = p->span->host.nv;
         if (static_cast<size_t>(span_count(p)) != nv_s) return set_err(GRBDA_EUNSUPPORTED, "spanning layout mismatch");
         const size_t per_state = nq_s + nv_s + static_cast<size_t>(p->n_cpl_rows);
-        size_t chunk = work_budget(1024ull << 20) / (per_state * sizeof(T));
+        size_t chunk = work_budget(p, p->work_proj, device, stream, 1024ull << 20) / (per_state * sizeof(T));
         chunk &= ~static_cast<size_t>(kWave - 1);
         if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
         const size_t b_round = (B + kWave - 1) / kWave * kWave;
@@ -1589,7 +1611,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
     // (forward dynamics: H_s alone of the spanning recursion's three matrices is stored)
     const size_t per_state = nq_s + 3 * nv_s + static_cast<size_t>(p->n_cpl_rows) + (rnea ? 0 : nn_s + 2 * nn);  // (wide: nn + nv would do)
     // (plans with big clusters: 40-50 KB per state; a chunk that leaves most SIMDs without a tile costs more than the memory)
-    size_t chunk = work_budget((big ? 4096ull : 1024ull) << 20) / (per_state * sizeof(T));
+    size_t chunk = work_budget(p, p->work_proj, device, stream, (big ? 4096ull : 1024ull) << 20) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     const size_t b_round = (B + kWave - 1) / kWave * kWave;
@@ -1729,7 +1751,8 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const size_t per_state = nq_s + 3 * nv_s + nv + static_cast<size_t>(p->n_cpl_rows) + 3 * nn_s + 3 * nn + nv;
     // (16 GiB, cut to a quarter of the free memory: TelloWithArms takes 33 KB per state; a 4 GiB chunk -- 131 072 states, 2 048 tiles -- left half
     // of the projection kernel's wavefront slots empty: 13.3 -> 10.8 ms per 262 144 states, 55 -> 44 ms per 1 048 576)
-    size_t chunk = work_budget(16384ull << 20) / (per_state * sizeof(T));
+    // (up to 16 GiB -- but no more than the batch itself needs: a small batch does not pin a large slab)
+    size_t chunk = work_budget(p, p->work, device, stream, std::min<size_t>(16384ull << 20, ((B + kWave - 1) / kWave * kWave) * per_state * sizeof(T) + (1u << 20))) / (per_state * sizeof(T));
     chunk &= ~static_cast<size_t>(kWave - 1);
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     const size_t b_round = (B + kWave - 1) / kWave * kWave;
@@ -1843,13 +1866,26 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     // (d / d tau alone: the CRBA kernel writes the same interleaved H and the matrix-core solve inverts it)
     // (fp64 stays state-major: its interleaved workspace was built and measured in round 4 -- MIT Humanoid 8 % faster, JVRC-1 36 % slower, the
     // row-per-lane fp64 solve reads an interleaved block strided; profiles/r4_derivative_recursion_experiments.txt -- and removed again)
-    const int il = (!wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1;
+    // H^-1 = W^T W from the articulated-body quantities (minv_kernels.hip): no H, no dense factorisation; f32 and f64 alike on the
+    // matrix cores, both workspaces interleaved by groups of kDerivGroup states.  GRBDA_NO_MINV=1 keeps the factorisation route (A/B runs)
+    const MinvProgram &mv = p->host.deriv.minv;
+    const bool minv = mv.ok && t->minv_bodies && t->minv_coltab && !wide0 && !p->no_minv &&
+                      minv_solve_lds_bytes(static_cast<int>(nv), n_rhs, mv.n_entries, sizeof(T)) <= 160u * 1024u;
+    const int il = minv ? kDerivGroup : ((!wide0 && spd_solve_on_mfma(sizeof(T), static_cast<int>(nv), n_rhs)) ? kDerivGroup : 1);
     // (only an INTERLEAVED H block can reach past the caller's array: the state-major layouts always build H in place)
-    const bool h_in_place = dtau && (il == 1 || (B % kDerivGroup) == 0);
-    const size_t per_state = (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
-    size_t chunk = work_budget(2048ull << 20) / (per_state ? per_state * sizeof(T) : 1);
+    const bool h_in_place = !minv && dtau && (il == 1 || (B % kDerivGroup) == 0);
+    const size_t per_state = minv ? static_cast<size_t>(mv.n_entries) + (need_d ? 2 * nn + nv : 0)
+                                  : (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
+    size_t chunk = work_budget(p, p->work, device, stream, 4096ull << 20) / (per_state ? per_state * sizeof(T) : 1);
     chunk &= ~static_cast<size_t>(kWave - 1);  // whole tiles, whole groups of the interleaved workspace
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
+    {
+        // whole ROUNDS of the one-state-per-lane kernels: a chunk of 2.4 rounds of wavefront slots takes as long as 3 (measured: 159 488-state
+        // chunks of JVRC-1, 2 492 tiles on 1 024 slots of the recursion and 2 048 of the factor kernel / the ABA: 19 % and 40 % of the
+        // slots idle in the last round).  n_cu * 8 wavefronts = one round at two per SIMD, two rounds of the recursion's four per CU.
+        const size_t round = static_cast<size_t>(t->n_cu) * 8 * kWave;
+        if (chunk >= round) chunk = chunk / round * round;
+    }
     if (chunk > B) chunk = (B + kDerivGroup - 1) / kDerivGroup * kDerivGroup;  // (the last group of the workspace is allocated whole)
     // f32 with the matrix-core solve: the recursion writes H, dID/dq, dID/dqd interleaved by groups of kDerivGroup states
     // (deriv_kernels.hip); every other combination keeps the state-major layout (il, above)
@@ -1862,8 +1898,9 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         wnext += chunk * nn;
         return r;
     };
-    T *wH = take(!h_in_place), *Dq = take(need_d), *Dqd = take(need_d);
+    T *wH = take(!minv && !h_in_place), *Dq = take(need_d), *Dqd = take(need_d);
     T *ydd = wnext;
+    T *recs = minv ? ydd + (need_d ? chunk * nv : 0) : nullptr;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
     for (size_t b0 = 0; b0 < B; b0 += chunk) {
@@ -1879,10 +1916,10 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             if (int rc = run<T>(p, false, q + b0 * nq, qd + b0 * nv, tau + b0 * nv, nullptr, ydd, nb, device, stream)) return rc;
         size_t grid = static_cast<size_t>(t->n_cu) * 8;
         if (grid > n_tiles) grid = n_tiles;
-        const size_t rows = std::max(p->host.crba.n_rows, need_d ? p->host.deriv.n_rows : 0);
+        const size_t rows = std::max(p->host.crba.n_rows, (need_d || minv) ? p->host.deriv.n_rows : 0);  // (the factor kernel of the minv route uses the recursion's rows)
         // (state-major results: three wavefronts per CU -- a fourth only adds open cache lines; interleaved: one per SIMD)
         const size_t deriv_waves = p->deriv_waves ? static_cast<size_t>(p->deriv_waves) : (il > 1 ? 4 : 3);
-        const size_t slabs = std::max(grid, static_cast<size_t>(t->n_cu) * deriv_waves);
+        const size_t slabs = std::max(grid, static_cast<size_t>(t->n_cu) * deriv_waves);  // (the factor kernel of the minv route runs n_cu * 8 wavefronts, as `grid`)
         void *scratch = nullptr;
         if (int rc = ensure_scratch(p, device, stream, slabs * rows * kWave * sizeof(T) + 256, &scratch)) return rc;
         if (need_d) {
@@ -1890,15 +1927,32 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             size_t g2 = static_cast<size_t>(t->n_cu) * deriv_waves;
             if (g2 > n_tiles) g2 = n_tiles;
             e = launch_rnea_deriv<T>(d, t->deriv_bodies, p->host.n_clusters, p->host.deriv.n_rows, p->host.deriv.n_max, q + b0 * nq,
-                                     qd + b0 * nv, ydd, Dq, Dqd, H, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, il);
+                                     qd + b0 * nv, ydd, Dq, Dqd, minv ? nullptr : H, nb, static_cast<T *>(scratch), static_cast<int>(g2), hs, il);
             if (e != hipSuccess) return hip_err(e, "rnea derivative launch");
-        } else {
+        } else if (!minv) {
             e = launch_crba<T>(d, t->crba_bodies, p->host.n_clusters, p->host.crba.n_rows, q + b0 * nq, H, nb, static_cast<T *>(scratch),
                                static_cast<int>(grid), hs, true, il);
             if (e != hipSuccess) return hip_err(e, "crba launch");
         }
         T *o1 = dq ? dq + b0 * nn : nullptr, *o2 = dqd ? dqd + b0 * nn : nullptr, *o3 = dtau ? dtau + b0 * nn : nullptr;
         const T *r1 = dq ? Dq : nullptr, *r2 = dqd ? Dqd : nullptr;
+        if (minv) {
+            // articulated-inertia recursion -> record blocks (one state per lane, two wavefronts per SIMD), then the walk and the two
+            // products on the matrix cores (one state per wavefront)
+            e = launch_abi_factor<T>(d, t->deriv_bodies, t->minv_bodies, p->host.n_clusters, p->host.deriv.n_rows, p->host.deriv.n_max,
+                                     mv.n_entries, q + b0 * nq, recs, nb, static_cast<T *>(scratch), static_cast<int>(grid), hs, kDerivGroup,
+                                     spd_bad_count_address());
+            if (e != hipSuccess) return hip_err(e, "articulated-inertia factor launch");
+            size_t per_cu = static_cast<size_t>(minv_workgroups_per_cu<T>(static_cast<int>(nv), p->host.deriv.n_max, n_rhs, mv.n_entries));
+            if (p->minv_wpc > 0 && per_cu > static_cast<size_t>(p->minv_wpc)) per_cu = static_cast<size_t>(p->minv_wpc);
+            size_t g3 = static_cast<size_t>(t->n_cu) * per_cu;
+            const size_t units = (nb + kDerivGroup - 1) / kDerivGroup;
+            if (g3 > units) g3 = units;
+            e = launch_minv_solve<T>(recs, mv.n_entries, kDerivGroup, t->minv_coltab, mv.max_depth, mv.base_off, p->host.deriv.n_max, r1, r2,
+                                     kDerivGroup, o3, o1, o2, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
+            if (e != hipSuccess) return hip_err(e, "minv solve launch");
+            continue;
+        }
         // the branch-sparse L^T L solve (tree_solve.h): eight states per wavefront
         if (tree_solve_usable<T>(p, *t)) {
             const TreeSolveProgram &tp = p->host.deriv.tree;
@@ -2139,6 +2193,8 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
         p->waves_per_cu_f64_wide_regs = w < 1 ? 1 : (w > 32 ? 32 : w);
     }
     p->no_split = env_int("GRBDA_NO_SPLIT", 0) != 0;
+    p->no_minv = env_int("GRBDA_NO_MINV", 0) != 0;
+    p->minv_wpc = env_int("GRBDA_MINV_WPC", 0);
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;
     p->no_latency_mode = env_int("GRBDA_NO_LATENCY_MODE", 0) != 0;
     p->gen1_waves_cap = env_int("GRBDA_GEN1_WAVES_PER_CU", 0);
@@ -2254,7 +2310,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.tree_tab);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.tree_tab); (void)hipFree(t.minv_bodies); (void)hipFree(t.minv_coltab);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
         for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
@@ -2266,6 +2322,34 @@ void grbda_plan_free(grbda_plan *p)
             if (kv.second.ptr) (void)hipFree(kv.second.ptr);
         }
     delete p;
+}
+
+int grbda_plan_release_work(grbda_plan *p, unsigned long long *bytes_released)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    GRBDA_CALL_SCOPE(p);
+    unsigned long long total = 0;
+    for (auto *m : {&p->work, &p->work_cvt, &p->work_proj})
+        for (auto &kv : *m) {
+            if (!kv.second.ptr) continue;
+            hipError_t e = hipSetDevice(kv.first.first);
+            if (e != hipSuccess) return hip_err(e, "hipSetDevice");
+            // a stream that is capturing must not lose a buffer its graph refers to, and hipFree would wait for the capture
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (kv.first.second && hipStreamIsCapturing(static_cast<hipStream_t>(kv.first.second), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return set_err(GRBDA_EINVAL, "a stream of this plan is capturing: its work buffer cannot be released now");
+            if ((e = hipFree(kv.second.ptr)) != hipSuccess) return hip_err(e, "hipFree");  // (waits for the work enqueued on it)
+            total += kv.second.bytes;
+            kv.second.ptr = nullptr;
+            kv.second.bytes = 0;
+        }
+    if (p->span) {
+        unsigned long long more = 0;
+        if (const int rc = grbda_plan_release_work(p->span, &more)) return rc;
+        total += more;
+    }
+    if (bytes_released) *bytes_released = total;
+    return GRBDA_OK;
 }
 
 int grbda_plan_dims(const grbda_plan *p, int *nq, int *nv, int *n_bodies, int *n_clusters)

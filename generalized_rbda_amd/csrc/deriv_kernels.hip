@@ -869,10 +869,9 @@ template <class T>
 hipError_t launch_rnea_deriv(const DevPlan<T> &P, const DerivBody *db, int n_clusters, int n_rows, int n_max, const T *q, const T *qd,
                              const T *ydd, T *Dq, T *Dqd, T *H, size_t B, T *scratch, int grid, hipStream_t stream, int interleave)
 {
-    if constexpr (sizeof(T) == 4) {
-        if (interleave == kDerivGroup)
-            return launch_rnea_deriv_il<T, kDerivGroup>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
-    }
+    // (f64: the minv route of capi.cpp -- minv_kernels.hip reads the interleaved blocks through LDS)
+    if (interleave == kDerivGroup)
+        return launch_rnea_deriv_il<T, kDerivGroup>(P, db, n_clusters, n_rows, n_max, q, qd, ydd, Dq, Dqd, H, B, scratch, grid, stream);
     if (interleave == kWave && n_max <= 1) {
         // tile-interleaved results [tile][entry][lane]: what a one-state-per-lane consumer reads as coalesced rows (the
         // spanning-tree pass of manifold_kernels.hip; single-body clusters only)

@@ -262,6 +262,21 @@ template <class T>
 hipError_t launch_tree_solve(const TreeSolveDev &P, const TreeSolveIO<T> &IO, int n_mat, size_t B, int grid, hipStream_t stream);
 size_t tree_solve_lds_bytes(int n, int nl, size_t elem);
 hipError_t set_max_dynamic_lds_deriv();
+// H^-1 = W^T W from the articulated-body quantities (minv_kernels.hip; plan.h, MinvProgram): the record blocks (one state per lane, the
+// slab rows and processing order of rnea_deriv_kernel), then the walk + the two products on the matrix cores (one state per wavefront;
+// records and right-hand sides interleaved by groups of kDerivGroup states)
+template <class T>
+hipError_t launch_abi_factor(const DevPlan<T> &P, const DerivBody *db, const MinvBody *mb, int n_clusters, int n_rows, int n_max, int n_entries,
+                             const T *q, T *rec, size_t B, T *scratch, int grid, hipStream_t stream, int interleave,
+                             unsigned long long *bad_count);
+template <class T>
+hipError_t launch_minv_solve(const T *rec, int n_entries, int r_il, const int32_t *coltab, int max_depth, int base_off, int n_max, const T *P1,
+                             const T *P2, int p_il, T *Hinv, T *X1, T *X2, const uint64_t *related, int nv, size_t B, int grid,
+                             hipStream_t stream);
+size_t minv_solve_lds_bytes(int nv, int n_rhs, int n_entries, size_t elem);
+template <class T>
+int minv_workgroups_per_cu(int nv, int n_max, int n_rhs, int n_entries);  // (registers of the instantiation and LDS granules; needs the current device)
+hipError_t set_max_dynamic_lds_minv();
 hipError_t spd_bad_pivots(unsigned long long *count, int reset);
 
 }  // namespace grbda_hip

@@ -2203,6 +2203,66 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             build_tree_solve(DV.related, P.nv, DV.tree);
         }
+        // ---- H^-1 = W^T W from the articulated-body quantities (plan.h, MinvProgram; minv_kernels.hip) ----
+        {
+            MinvProgram &MV = DV.minv;
+            MV = MinvProgram();
+            MV.ok = DV.ok && P.nv <= 64;
+            MV.bodies.assign(nb, MinvBody{-1, -1});
+            int off = 0;
+            std::vector<int> c_off(nc, -1);
+            for (int c = 0; c < nc && MV.ok; c++) {
+                const ClusterRec &cr = clusters[c];
+                if (cr.kind == CK_FREE) {
+                    MV.base_off = off;
+                    MV.bodies[cr.first_body].clus_off = off;
+                    c_off[c] = off;
+                    off += 21;
+                    continue;
+                }
+                if (cr.n > kMaxClusterDof) { MV.ok = false; break; }
+                const int blk = 6 * cr.n + cr.n * (cr.n + 1) / 2;
+                c_off[c] = off;
+                MV.bodies[cr.first_body].clus_off = off;
+                bool any = false;
+                for (int i = 0; i < cr.k; i++) {
+                    const int b = cr.first_body + i;
+                    bool carries = false;
+                    for (int c2 = 0; c2 < nc; c2++) carries = carries || clusters[c2].parent_body == b;
+                    if (carries) {
+                        MV.bodies[b].blk_off = off;
+                        off += blk + 6 * cr.n;
+                        any = true;
+                    }
+                }
+                if (!any) off += blk;
+            }
+            MV.n_entries = off;
+            if (off >= 65536) MV.ok = false;
+            MV.coltab.assign(static_cast<size_t>(64) * kMinvColInts, 0);
+            for (int c = 0; c < nc && MV.ok; c++) {
+                const ClusterRec &cr = clusters[c];
+                const bool is_free = cr.kind == CK_FREE;
+                for (int e = 0; e < cr.n; e++) {
+                    int32_t *col = &MV.coltab[static_cast<size_t>(cr.v_index + e) * kMinvColInts];
+                    col[0] = is_free ? 0 : c_off[c] + 6 * e;
+                    col[1] = is_free ? c_off[c] : c_off[c] + 6 * cr.n;
+                    int depth = 0, pb = cr.parent_body;
+                    bool at_base = false;
+                    while (pb >= 0) {
+                        const int a = m.bodies[pb].cluster;
+                        if (clusters[a].kind == CK_FREE) { at_base = true; break; }
+                        if (depth >= kMinvMaxDepth || MV.bodies[pb].blk_off < 0) { MV.ok = false; break; }
+                        col[3 + depth] = static_cast<int32_t>(static_cast<uint32_t>(MV.bodies[pb].blk_off) | (static_cast<uint32_t>(clusters[a].n) << 16) |
+                                                              (static_cast<uint32_t>(clusters[a].v_index) << 20) | (1u << 31));
+                        depth++;
+                        pb = clusters[a].parent_body;
+                    }
+                    MV.max_depth = std::max(MV.max_depth, depth);
+                    col[2] = cr.n | (e << 4) | (cr.v_index << 8) | ((at_base ? 1 : 0) << 20) | (1 << 21);
+                }
+            }
+        }
     }
 
     // ---- operation count (mul + add, as executed by kernels.hip) --------------------------------

@@ -443,8 +443,39 @@ struct TreeSolveProgram {
 };
 bool build_tree_solve(const std::vector<uint64_t> &related, int nv, TreeSolveProgram &out);
 
+// H^-1 from the articulated-body quantities (minv_kernels.hip).  The cluster ABA's own factorisation of the joint-space inertia,
+//   H^-1 = W^T W,   W = D^-1/2 (1 - psi):   row block of cluster a, column j (j in a or below it)
+// (Rodriguez / Jain's innovations factorisation; what Carpentier's computeMinverse sweeps), replaces the dense Cholesky factorisation and the
+// inversion of its factor in the derivative pipeline.  abi_factor_kernel (one state per lane) runs the articulated-inertia recursion in the common
+// frame F of the derivative recursion and writes, per state, a RECORD BLOCK of n_entries scalars:
+//   per non-free cluster c (n coordinates) one BLOCK per body that carries child clusters (one block when none does):
+//       [K = F D^-1 (6 x n, column by column: force at the parent body per unit sigma)][L^-1 (D = L L^T; packed lower triangle, row-major)]
+//       [S_ab (6 x n, column by column): motion of that body per unit cluster coordinate]        (K and L^-1 repeat in every block of c)
+//   floating base at base_off:  L^-1 of its articulated inertia (packed lower triangle, 21)
+// so that one offset names everything a step of the walk needs.
+// minv_mfma_kernel (one state per wavefront, lane = column j) walks column j up its root path -- f = K_c e_j; at every ancestor cluster a
+// (attached through body b): sigma = S_ab^T f, W[a rows][j] = -L_a^-1 sigma, f -= K_a sigma -- and multiplies on the matrix cores.
+// coltab (uploaded as it is): per lane j < 64, kMinvColInts int32:
+//   [0] offset of column e of K_c   [1] offset of L_c^-1   [2] n | e << 4 | v_index << 8 | ends_at_base << 20 | valid << 21
+//   [3 + t] (t < kMinvMaxDepth): step t of the path, leaf side first:  block offset | n << 16 | v_index << 20 | valid << 31
+constexpr int kMinvMaxDepth = 16;
+constexpr int kMinvColInts = 3 + kMinvMaxDepth;
+struct MinvBody {      // 2 ints per body
+    int32_t blk_off;   // bodies that carry child clusters: offset of their block [K | L^-1 | S_ab]; else -1
+    int32_t clus_off;  // (first body of a non-free cluster) offset of the cluster's first block; (base) offset of its L^-1; else -1
+};
+struct MinvProgram {
+    bool ok = false;
+    int n_entries = 0;   // scalars per state
+    int base_off = -1;   // floating base: offset of its L^-1 (21 scalars)
+    int max_depth = 0;   // longest path (ancestor clusters of a column, the base not counted)
+    std::vector<MinvBody> bodies;
+    std::vector<int32_t> coltab;   // [64][kMinvColInts]
+};
+
 struct DerivProgram {
     bool ok = false;  // explicit (constant G) clusters
+    MinvProgram minv;
     TreeSolveProgram tree;
     std::vector<DerivBody> bodies;
     int n_rows = 0;

@@ -67,6 +67,14 @@ int grbda_urdf_to_blob(const char *const *paths, int n_paths, int ori_repr, void
 
 void grbda_plan_free(grbda_plan *plan);
 
+/* Hands the work buffers of the chunked pipelines (derivatives, mass matrix / derivatives on the constraint manifold, position
+ * projection) back to the device allocator.  They are kept per (device, stream) between calls -- up to a few GiB after a
+ * million-state derivative call (16 GiB on the manifold route) -- and otherwise live until grbda_plan_free; the next call that
+ * needs one allocates it again.  Waits for the work enqueued on them; refused (GRBDA_EINVAL) while one of the plan's streams is
+ * capturing.  *bytes_released (may be NULL): what was freed.  No counterpart in the reference: its temporaries are Eigen
+ * objects of one state (ClusterTreeModel.h:150-170). */
+int grbda_plan_release_work(grbda_plan *plan, unsigned long long *bytes_released);
+
 /* getNumPositions / getNumDegreesOfFreedom / getNumBodies / clusters().size()
  * (TreeModel.h:25-26, ClusterTreeModel.h:98,113); any out pointer may be NULL */
 int grbda_plan_dims(const grbda_plan *plan, int *nq, int *nv, int *n_bodies, int *n_clusters);

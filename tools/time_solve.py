@@ -37,3 +37,17 @@ try:
     print("s_memtime ticks per state (all three):", "  ".join(f"{n}={buf[i] / B:.0f} ({100 * buf[i] / tot:.0f}%)" for i, n in enumerate(names)), " total", tot / B)
 except AttributeError:
     pass
+
+try:
+    import ctypes
+    L = G.lib()
+    L.grbda_debug_mv_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = (ctypes.c_ulonglong * 8)()
+    L.grbda_debug_mv_prof(buf, 1)
+    plan.fd_derivatives(tq, tqd, tt); torch.cuda.synchronize()
+    L.grbda_debug_mv_prof(buf, 0)
+    names = ["record copy + tile clear + wait", "walk", "barrier + rhs copy issue + GEMM1", "copy wait + H^-1 to LDS and out", "barrier", "GEMM2", "result stores"]
+    tot = sum(buf[:7])
+    print("minv_mfma_kernel, s_memtime ticks per state (all three):", "  ".join(f"{n}={buf[i] / B:.0f} ({100 * buf[i] / tot:.0f}%)" for i, n in enumerate(names)), " total", tot / B)
+except AttributeError:
+    pass
