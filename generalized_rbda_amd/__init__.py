@@ -26,6 +26,7 @@ C_ABI_SYMBOLS = [
     "grbda_bias_f64", "grbda_bias_f32", "grbda_mass_matrix_f64", "grbda_mass_matrix_f32",
     "grbda_fd_dtau_f64", "grbda_fd_dtau_f32", "grbda_fd_dqd_f64", "grbda_fd_dqd_f32",
     "grbda_aba_sharded_f32", "grbda_aba_sharded_f64", "grbda_rnea_sharded_f32", "grbda_rnea_sharded_f64",
+    "grbda_aba_sharded_dev_f32", "grbda_aba_sharded_dev_f64", "grbda_rnea_sharded_dev_f32", "grbda_rnea_sharded_dev_f64",
     "grbda_debug_dump_plan", "grbda_body_poses_host_f64", "grbda_apply_test_force_host_f64",
     "grbda_inv_osim_host_f64", "grbda_fd_dq_f64", "grbda_fd_dq_f32", "grbda_body_poses_f64", "grbda_body_poses_f32",
     "grbda_apply_test_force_f64", "grbda_apply_test_force_f32", "grbda_inv_osim_f64", "grbda_inv_osim_f32",
@@ -84,6 +85,8 @@ def lib() -> ctypes.CDLL:
     L.grbda_plan_free.argtypes = [c_void_p]
     L.grbda_plan_free.restype = None
     L.grbda_plan_release_work.argtypes = [c_void_p, POINTER(ctypes.c_ulonglong)]
+    for name in ("grbda_aba_sharded_dev_f32", "grbda_aba_sharded_dev_f64", "grbda_rnea_sharded_dev_f32", "grbda_rnea_sharded_dev_f64"):
+        getattr(L, name).argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.grbda_plan_dims.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     L.grbda_plan_set_gravity.argtypes = [c_void_p, POINTER(c_double)]
     L.grbda_plan_get_gravity.argtypes = [c_void_p, POINTER(c_double)]
@@ -526,6 +529,42 @@ class Plan:
                                        q.data_ptr(), qd.data_ptr(), x.data_ptr(), out.data_ptr(), q.shape[0],
                                        q.device.index or 0, c_void_p(s.cuda_stream), iters, byref(ms)))
         return ms.value
+
+    def sharded_device(self, which: str, qs, qds, xs, outs=None, gathered=None, streams=None):
+        """grbda_{aba,rnea}_sharded_dev_*: shard g = the device tensors qs[g], qds[g], xs[g] on THEIR device (one process, several
+        devices), launched on streams[g] (default: each device's current stream).  outs: per-shard output tensors (made when
+        None and no `gathered`); gathered: a [sum B, nv] tensor on the first shard's device that receives every slab over the
+        peer links.  Enqueues only.  Returns (outs, gathered)."""
+        import torch
+
+        n = len(qs)
+        if n < 1 or len(qds) != n or len(xs) != n:
+            raise ValueError("one q, qd, x tensor per shard")
+        dt = qs[0].dtype
+        for g in range(n):
+            self._floating(qs[g], qds[g], xs[g])
+            if qs[g].dtype != dt or qs[g].shape[1:] != (self.nq,) or qds[g].shape != (qs[g].shape[0], self.nv) or xs[g].shape != qds[g].shape:
+                raise ValueError(f"shard {g}: expected q[B,{self.nq}], qd[B,{self.nv}], x[B,{self.nv}] of one dtype")
+        qs, qds, xs = [t.contiguous() for t in qs], [t.contiguous() for t in qds], [t.contiguous() for t in xs]
+        Bs = [int(t.shape[0]) for t in qs]
+        if outs is None and gathered is None:
+            outs = [torch.empty((Bs[g], self.nv), dtype=dt, device=qs[g].device) for g in range(n)]
+        if gathered is not None and outs is None:
+            # shards on the gather device write straight into their place; the others need a slab of their own
+            outs = [None if qs[g].device == gathered.device else torch.empty((Bs[g], self.nv), dtype=dt, device=qs[g].device) for g in range(n)]
+        if gathered is not None and (gathered.shape != (sum(Bs), self.nv) or gathered.dtype != dt or not gathered.is_contiguous()
+                                     or gathered.device != qs[0].device):
+            raise ValueError("gathered must be a contiguous [sum B, nv] tensor of the shards' dtype on the first shard's device")
+        if streams is None:
+            streams = [torch.cuda.current_stream(t.device) for t in qs]
+        P = ctypes.c_void_p
+        arr = lambda ts: (P * n)(*[None if t is None else t.data_ptr() for t in ts])
+        devs = (c_int * n)(*[t.device.index or 0 for t in qs])
+        Bc = (ctypes.c_size_t * n)(*Bs)
+        st = (P * n)(*[s.cuda_stream for s in streams])
+        fn = getattr(lib(), f"grbda_{which}_sharded_dev_{'f32' if dt == torch.float32 else 'f64'}")
+        _check(fn(self._h, n, devs, arr(qs), arr(qds), arr(xs), arr(outs), Bc, st, None if gathered is None else gathered.data_ptr()))
+        return outs, gathered
 
     def sharded_host(self, which: str, q, qd, x, n_gpus: int):
         """Host numpy arrays (float32 or float64), batch split over devices 0 .. n_gpus-1 in this process."""

@@ -76,6 +76,7 @@ struct DeviceTables {
     ChainGen *rchain_gens[3] = {nullptr, nullptr, nullptr};
     ChainGenBody *rchain_gbodies[3] = {nullptr, nullptr, nullptr};
     int n_cu = 0;
+    unsigned long long *bad_count = nullptr;  // this device's counter of states with a pivot that is not positive (deriv_kernels.hip)
 };
 struct Scratch {
     void *ptr = nullptr;
@@ -283,6 +284,7 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
     if ((e = set_max_dynamic_lds()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     if ((e = set_max_dynamic_lds_deriv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
     if ((e = set_max_dynamic_lds_minv()) != hipSuccess) return hip_err(e, "hipFuncSetAttribute");
+    t.bad_count = spd_bad_count_address();
     auto ins = p->dev.emplace(device, t);
     *out = &ins.first->second;
     return 0;
@@ -373,6 +375,7 @@ DevPlan<T> make_dev_plan(const grbda_plan *p, const DeviceTables &t, bool rnea, 
 {
     DevPlan<T> d;
     const HostPlan &h = p->host;
+    d.bad_count = t.bad_count;
     d.steps = rnea ? t.rnea_steps : t.aba_steps;
     d.n_steps = static_cast<int>(rnea ? h.rnea_steps.size() : h.aba_steps.size());
     int w = (sizeof(T) == 4 ? 0 : 1) + (fext ? 2 : 0);
@@ -462,6 +465,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
         if (path == ABA_GEN1) {
             ChainDev<T> d;
             std::memset(&d, 0, sizeof d);
+            d.bad_count = t.bad_count;
             d.gens = t.chain_gens[w1];
             d.gbodies = t.chain_gbodies[w1];
             d.n_gens = 1;
@@ -494,6 +498,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
         if (path == ABA_LM) {
             const int w = sizeof(T) == 8 ? 4 : 3;
             ChainDev<T> d;
+            d.bad_count = t.bad_count;
             d.segs = t.chain_segs[w];
             d.links = t.chain_links[w];
             d.pairs = t.chain_pairs[w];
@@ -508,7 +513,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.n_segs = static_cast<int>(lp.segs.size());
             d.nq = h.nq;
             d.nv = h.nv;
-            d.n_glb_slots = lp.n_glb;
+            d.n_glb_slots = lp.n_glb + 1;  // (+ the row that carries wavefront 1's bad-pivot mask to wavefront 0, aba_chain_lm_kernel)
             d.ori_repr = h.ori_repr;
             d.debug = 0;
             d.sv_global = 0;
@@ -517,7 +522,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.lds_bytes = static_cast<int>(lds_lm);
             for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
             const size_t grid = n_tiles0;  // (<= 4 workgroups per CU: all resident)
-            const size_t n_rows = static_cast<size_t>(lp.n_glb) + static_cast<size_t>(d.nq + 2 * d.nv);
+            const size_t n_rows = static_cast<size_t>(d.n_glb_slots) + static_cast<size_t>(d.nq + 2 * d.nv);
             void *scratch = nullptr;
             if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(T) + 256, &scratch)) return rc;
             hipError_t e = launch_aba_chain_lm<T>(d, q, qd, tau, ydd, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_lm,
@@ -534,6 +539,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
                                      : static_cast<size_t>((sizeof(T) == 8 && !cp.gens.empty()) ? p->waves_per_cu_f64_wide_regs : p->waves_per_cu[kid]);
     const size_t lds_budget = wide ? static_cast<size_t>(kChainWideLdsBytes) : static_cast<size_t>(p->lds_bytes_per_wave[kid]);
     ChainDev<T> d;
+    d.bad_count = t.bad_count;
     d.segs = t.chain_segs[w];
     d.links = t.chain_links[w];
     d.pairs = t.chain_pairs[w];
@@ -1280,6 +1286,7 @@ int inv_osim_chain(const grbda_plan *p, const T *q, int n_contacts, const int *b
     A.w_base = cp.n_glb;
     A.w_stride = 6 * max_rows;
     ChainDev<T> d;
+    d.bad_count = t->bad_count;
     d.segs = t->chain_segs[w];
     d.links = t->chain_links[w];
     d.pairs = t->chain_pairs[w];
@@ -1941,7 +1948,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             // products on the matrix cores (one state per wavefront)
             e = launch_abi_factor<T>(d, t->deriv_bodies, t->minv_bodies, p->host.n_clusters, p->host.deriv.n_rows, p->host.deriv.n_max,
                                      mv.n_entries, q + b0 * nq, recs, nb, static_cast<T *>(scratch), static_cast<int>(grid), hs, kDerivGroup,
-                                     spd_bad_count_address());
+                                     t->bad_count);
             if (e != hipSuccess) return hip_err(e, "articulated-inertia factor launch");
             size_t per_cu = static_cast<size_t>(minv_workgroups_per_cu<T>(static_cast<int>(nv), p->host.deriv.n_max, n_rhs, mv.n_entries));
             if (p->minv_wpc > 0 && per_cu > static_cast<size_t>(p->minv_wpc)) per_cu = static_cast<size_t>(p->minv_wpc);
@@ -2117,6 +2124,74 @@ int run_sharded(const grbda_plan *p, bool rnea, const T *q, const T *qd, const T
         (void)hipStreamDestroy(S.s);
     }
     return rc;
+}
+
+// ---- one process, several devices, DEVICE-resident shards: launch every shard on its own device / stream, optionally gather the
+// result slabs on the first device over the peer links (hipMemcpyPeerAsync: xGMI, no host hop).  Enqueues only.
+template <class T>
+int run_sharded_dev(const grbda_plan *p, bool rnea, int n_gpus, const int *devices, const T *const *q, const T *const *qd, const T *const *x,
+                    T *const *out, const size_t *B, void *const *streams, T *gathered)
+{
+    if (!p) return set_err(GRBDA_EINVAL, "null plan");
+    if (n_gpus < 1 || !q || !qd || !x || !B || (!out && !gathered)) return set_err(GRBDA_EINVAL, "null argument or n_gpus < 1");
+    GRBDA_CALL_SCOPE(p);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return set_err(GRBDA_ENODEVICE, "no HIP device available (there is no CPU fallback)");
+    const size_t nv = p->host.nv;
+    for (int g = 0; g < n_gpus; g++) {
+        const int dev = devices ? devices[g] : g;
+        if (dev < 0 || dev >= count) return set_err(GRBDA_EINVAL, "device index out of range");
+        for (int h = 0; h < g; h++)
+            if ((devices ? devices[h] : h) == dev && (streams ? streams[h] : nullptr) == (streams ? streams[g] : nullptr) && B[g] && B[h])
+                return set_err(GRBDA_EINVAL, "two shards on one (device, stream): they would share one scratch slab -- give them distinct streams");
+        if (B[g] && (!q[g] || !qd[g] || !x[g] || (!gathered && (!out || !out[g])))) return set_err(GRBDA_EINVAL, "null shard pointer");
+    }
+    const int dev0 = devices ? devices[0] : 0;
+    void *const s0 = streams ? streams[0] : nullptr;
+    size_t off = 0;
+    hipError_t e = hipSuccess;
+    for (int g = 0; g < n_gpus; g++) {
+        const int dev = devices ? devices[g] : g;
+        void *const sg = streams ? streams[g] : nullptr;
+        const size_t nb = B[g];
+        if (nb == 0) continue;
+        // a shard on the gather device computes straight into its place of the gathered array
+        T *dst = gathered ? gathered + off * nv : nullptr;
+        T *o = (out && out[g]) ? out[g] : nullptr;
+        if (gathered && dev == dev0 && !o) o = dst;
+        if (!o) return set_err(GRBDA_EINVAL, "a shard on another device than the gather device needs its own output slab (out[g])");
+        if (const int rc = run<T>(p, rnea, q[g], qd[g], x[g], nullptr, o, nb, dev, sg)) return rc;
+        if (gathered && o != dst) {
+            if ((e = hipSetDevice(dev)) != hipSuccess) return hip_err(e, "hipSetDevice");
+            if (dev != dev0) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dev, dev0) == hipSuccess && can) {
+                    e = hipDeviceEnablePeerAccess(dev0, 0);  // (direct over the link; without it the runtime stages the copy)
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                    (void)hipGetLastError();
+                }
+                e = hipMemcpyPeerAsync(dst, dev0, o, dev, nb * nv * sizeof(T), static_cast<hipStream_t>(sg));
+            } else {
+                e = hipMemcpyAsync(dst, o, nb * nv * sizeof(T), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(sg));
+            }
+            if (e != hipSuccess) return hip_err(e, "gather copy");
+        }
+        // the first shard's stream is the join point: work enqueued on it after this call sees every slab of `gathered`
+        if (gathered && (dev != dev0 || sg != s0)) {
+            hipEvent_t ev = nullptr;
+            if ((e = hipSetDevice(dev)) != hipSuccess || (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess ||
+                (e = hipEventRecord(ev, static_cast<hipStream_t>(sg))) != hipSuccess)
+                return hip_err(e, "gather event");
+            if ((e = hipSetDevice(dev0)) != hipSuccess || (e = hipStreamWaitEvent(static_cast<hipStream_t>(s0), ev, 0)) != hipSuccess) {
+                (void)hipEventDestroy(ev);
+                return hip_err(e, "gather join");
+            }
+            (void)hipEventDestroy(ev);  // (released by the runtime once the recorded work has completed)
+        }
+        off += nb;
+    }
+    return GRBDA_OK;
 }
 
 // ---- host-pointer convenience for the contact-side entry points (single-state facade calls) ----------------------
@@ -2625,6 +2700,26 @@ int grbda_rnea_sharded_f32(const grbda_plan *p, const float *q, const float *qd,
                            int n_gpus)
 {
     return run_sharded<float>(p, true, q, qd, ydd, tau, B, n_gpus);
+}
+int grbda_aba_sharded_dev_f32(const grbda_plan *p, int n_gpus, const int *devices, const float *const *q, const float *const *qd,
+                              const float *const *tau, float *const *ydd, const size_t *B, void *const *streams, float *gathered)
+{
+    return run_sharded_dev<float>(p, false, n_gpus, devices, q, qd, tau, ydd, B, streams, gathered);
+}
+int grbda_aba_sharded_dev_f64(const grbda_plan *p, int n_gpus, const int *devices, const double *const *q, const double *const *qd,
+                              const double *const *tau, double *const *ydd, const size_t *B, void *const *streams, double *gathered)
+{
+    return run_sharded_dev<double>(p, false, n_gpus, devices, q, qd, tau, ydd, B, streams, gathered);
+}
+int grbda_rnea_sharded_dev_f32(const grbda_plan *p, int n_gpus, const int *devices, const float *const *q, const float *const *qd,
+                               const float *const *ydd, float *const *tau, const size_t *B, void *const *streams, float *gathered)
+{
+    return run_sharded_dev<float>(p, true, n_gpus, devices, q, qd, ydd, tau, B, streams, gathered);
+}
+int grbda_rnea_sharded_dev_f64(const grbda_plan *p, int n_gpus, const int *devices, const double *const *q, const double *const *qd,
+                               const double *const *ydd, double *const *tau, const size_t *B, void *const *streams, double *gathered)
+{
+    return run_sharded_dev<double>(p, true, n_gpus, devices, q, qd, ydd, tau, B, streams, gathered);
 }
 int grbda_rnea_sharded_f64(const grbda_plan *p, const double *q, const double *qd, const double *ydd, double *tau, size_t B,
                            int n_gpus)

@@ -150,6 +150,24 @@ struct ChainMem {
     T *out_u;
     int lane;
     unsigned lane_b;  // lane * sizeof(T): the byte offset every slab access adds to its wave-uniform row address
+    // lanes of this tile whose D = S^T IA S had a pivot that is not positive (or not a number): the reference's ColPivHouseholderQR
+    // (ClusterTreeNode.cpp:33-37) returns a least-squares answer there, the Cholesky factorisations here return NaN / Inf -- and the
+    // state is COUNTED (grbda_spd_bad_pivots, the counter of the derivative solves).  A wave-uniform mask on the scalar unit: one
+    // v_cmp that writes an SGPR pair and one s_or per pivot.
+    mutable unsigned long long bad;
+#ifdef GRBDA_EXP_NO_PIVOT  // (A/B builds: make variant VFLAGS=-DGRBDA_EXP_NO_PIVOT)
+    __device__ __forceinline__ void pivot(T) const {}
+#else
+    __device__ __forceinline__ void pivot(T d) const { bad |= __builtin_amdgcn_ballot_w64(!(d > T(0))); }
+#endif
+    // (end of a tile: `valid` = ballot of the lanes that hold a state of the batch)
+    __device__ __forceinline__ void flush_bad(unsigned long long *counter, int rows_valid) const
+    {
+        const unsigned long long live = rows_valid >= kWave ? ~0ull : ((1ull << rows_valid) - 1ull);
+        const unsigned long long b = bad & live;
+        if (b && counter && lane == 0) atomicAdd(counter, (unsigned long long)__builtin_popcountll(b));
+        bad = 0;
+    }
     int gmul;  // 1; 0 under GRBDA_CHAIN_DEBUG bit 3: every global slot aliases row 0 (same instructions, no slab traffic)
     int amask; // ~0; kSlotGlobal under GRBDA_CHAIN_DEBUG bit 4: the slots that overflowed the LDS alias row 0, the [K | y0] blocks stay
 
@@ -647,6 +665,8 @@ __device__ __forceinline__ void pair_bwd_k(const ChainTables<T> &P, const ChainM
     // ---- D^-1 (2 x 2, SPD), K = D^-1 F^T, y0 = D^-1 u ----
     // D = L L^T and triangular solves (see diff_bwd: the adjugate / determinant form cancels when D is nearly rank one)
     const T r00 = rsqrt_t(D00), l10 = D01 * r00, r11 = rsqrt_t(D11 - l10 * l10);
+    M.pivot(D00);
+    M.pivot(D11 - l10 * l10);
     const T i00 = r00 * r00 + (l10 * r00 * r11) * (l10 * r00 * r11), i01 = -(l10 * r00) * r11 * r11, i11 = r11 * r11;
     T blk[14];  // [K row 0 (6)][K row 1 (6)][y0 (2)]
     auto solve2 = [&](T b0, T b1, T &x0, T &x1) {
@@ -1053,6 +1073,8 @@ __device__ __forceinline__ void diff_bwd(const ChainTables<T> &P, const ChainMem
     // compiled in float on 60 000 gated TelloWithArms states (tools/tello_acc2.py, profiles/r4_tello_acc_variants.txt): max error of
     // ydd 1.07e-4 with the determinant, 2.1e-5 with the factorisation, 1.9e-5 for the dense float restatement itself.
     const T r00 = rsqrt_t(D00), l10 = D01 * r00, r11 = rsqrt_t(D11 - l10 * l10);
+    M.pivot(D00);
+    M.pivot(D11 - l10 * l10);
     const T i00 = r00 * r00 + (l10 * r00 * r11) * (l10 * r00 * r11), i01 = -(l10 * r00) * r11 * r11, i11 = r11 * r11;
     T blk[14];
     auto solve2 = [&](T b0, T b1, T &x0, T &x1) {
@@ -1306,6 +1328,7 @@ __device__ __forceinline__ void run_bwd(const ChainTables<T> &P, const ChainMem<
         }
         CMARK(4, psic[0]);
         const T Dinv = rcp_t(D);
+        M.pivot(D);
         T kb[7];  // [K 6][y0]: what the acceleration run needs (it recomputes sin / cos from q: two slab rows less per link)
 #pragma unroll
         for (int r = 0; r < 6; r++) kb[r] = F[r] * Dinv;
@@ -1617,6 +1640,8 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
     }
     Chol<T, 6> ch;
     ch.factor(D);
+#pragma unroll
+    for (int i = 0; i < 6; i++) M.pivot(ch.inv[i] < T(1e30) ? ch.inv[i] : T(0));  // (1 / sqrt(pivot): Inf for 0, NaN below it)
     ch.solve(u);
     if constexpr (!OSIM) {
         if (fuse_acc) {  // (every LDS read of this segment is behind us: the rows free_acc writes may alias the accumulators)
@@ -1712,10 +1737,11 @@ struct ChainMemC : ChainMem<T> {
 // the tile loop of the single-cluster kernels: BODY(M) is the tile's work (forward or inverse dynamics of the cluster)
 template <class T, int N, bool LOOP, class BODY>
 __device__ __forceinline__ void gen1_tiles(int work_bytes, int nq, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ x,
-                                           T *__restrict__ out, size_t B, BODY body)
+                                           T *__restrict__ out, size_t B, unsigned long long *bad_count, BODY body)
 {
     const int lane = threadIdx.x;
     ChainMemC<T> M;
+    M.bad = 0;
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
@@ -1762,6 +1788,7 @@ __device__ __forceinline__ void gen1_tiles(int work_bytes, int nq, const T *__re
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
         M.out_g = lane < rows_valid ? out + (tile * kWave + lane) * (size_t)N : nullptr;
         body(M);
+        M.flush_bad(bad_count, rows_valid);
     }
 }
 
@@ -1786,7 +1813,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_gen1_kernel(ChainDev<T> DP, co
 #pragma unroll
     for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
     const ChainGen g = load_rec(P.gens);
-    gen1_tiles<T, N, LOOP>(DP.lds_bytes, P.nq, q, qd, tau, ydd, B, [&](const ChainMemC<T> &M) {
+    gen1_tiles<T, N, LOOP>(DP.lds_bytes, P.nq, q, qd, tau, ydd, B, DP.bad_count, [&](const ChainMemC<T> &M) {
         gen_down<T, N, LOOP>(P, M, g, g.lds_w, true, false);
         gen_up<T, N, LOOP, true>(P, M, g);
     });
@@ -1874,6 +1901,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.set_out(DP.out_lds);
+    M.bad = 0;
 #ifdef GRBDA_CHAIN_PROFILE
     M.pacc = 0;
 #endif
@@ -1958,6 +1986,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
             if (M.out_row >= 0) write_outputs_lds<T>(M.out_row, ydd, tile, rows_valid, P.nv, lane);
             else write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
         }
+        M.flush_bad(DP.bad_count, rows_valid);
         CPROF_ADD(1, 1);
     }
     CPROF_END();
@@ -1999,7 +2028,11 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
+    // (the LAST slab row -- the launch adds one to the program's rows -- carries wavefront 1's mask of bad pivots to wavefront 0: the
+    // tile's 40 KiB of LDS are four workgroups per CU exactly, there is no word to spare)
+    unsigned long long &lm_bad = *reinterpret_cast<unsigned long long *>(slab + (size_t)(DP.n_glb_slots - 1 + P.nq + 2 * P.nv) * kWave);
     ChainMem<T> M;
+    M.bad = 0;
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
@@ -2054,10 +2087,16 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
+        // (a state with a bad pivot is counted once: wavefront 1 hands its mask to wavefront 0)
+        if (wave == 1 && lane == 0) lm_bad = M.bad;
         __syncthreads();  // every result row is in the slab (or in LDS: ChainProgram::out_lds)
         if (wave == 0) {
             if (M.out_row >= 0) write_outputs_lds<T>(M.out_row, ydd, tile, rows_valid, P.nv, lane);
             else write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+            M.bad |= lm_bad;
+            M.flush_bad(DP.bad_count, rows_valid);
+        } else {
+            M.bad = 0;
         }
         // LDS and the slab are free for the next tile once wavefront 0 has READ the result rows (its own output stores may still
         // be in flight)
@@ -2137,6 +2176,7 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     const int n_rows_wave = DP.n_glb_slots + P.nq + 2 * P.nv;  // DP.n_glb_slots includes the W blocks (capi.cpp)
     T *slab = scratch + (size_t)blockIdx.x * (size_t)n_rows_wave * kWave;
     ChainMem<T> M;
+    M.bad = 0;
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
@@ -2984,6 +3024,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     // wave slab: [nq + 2 nv input / result rows][n_glb_slots rows]
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(P.nq + 2 * P.nv + DP.n_glb_slots) * kWave;
     ChainMem<T> M;
+    M.bad = 0;
     M.lane = lane;
     M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
     M.gmul = 1;
@@ -3069,7 +3110,7 @@ __global__ __launch_bounds__(kWave, WPS) void rnea_gen1_kernel(RneaChainDev<T> D
 #pragma unroll
     for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
     const ChainGen g = load_rec(P.gens);
-    gen1_tiles<T, N, LOOP>(DP.lds_bytes, P.nq, q, qd, ydd, tau, B, [&](const ChainMemC<T> &M) {
+    gen1_tiles<T, N, LOOP>(DP.lds_bytes, P.nq, q, qd, ydd, tau, B, nullptr, [&](const ChainMemC<T> &M) {
         gen_rnea_fwd<T, N, LOOP>(P, M, g);
         gen_rnea_bwd<T, N, LOOP, false>(P, M, g);
     });

@@ -46,6 +46,7 @@ struct DevPlan {
     int split;     // the layout keeps [K | y0] blocks in the global slab and everything else in LDS (Slots<T, true>)
     int n_bodies;
     const T *fext; // [B][n_bodies][6] world-frame spatial forces or nullptr (TreeModel::setExternalForces)
+    unsigned long long *bad_count;  // aba_kernel: per-device counter of states with a pivot of D that is not positive (grbda_spd_bad_pivots)
     T a_root[6];  // -gravity (ClusterTreeDynamics.cpp:147)
 };
 
@@ -105,6 +106,8 @@ struct ChainDev {
     // skipped; bit 1 -- the base's acceleration segment follows its backward segment directly: the backward segment finishes it with y0
     // in registers (no slab round trip) and the acceleration segment is skipped
     int fuse, stage_lds_v, stage_v_index;
+    // per-device counter of states whose D = S^T IA S had a pivot that is not positive (grbda_spd_bad_pivots; deriv_kernels.hip owns the word)
+    unsigned long long *bad_count;
     T a_root[6];
 };
 template <class T>

@@ -641,6 +641,8 @@ __device__ __forceinline__ void gen_up(const TB &P, const MM &M, const ChainGen 
     // D^-1 u', K = D^-1 F^T
     Chol<T, N> ch;
     ch.factor(D);
+#pragma unroll
+    for (int a = 0; a < N; a++) M.pivot(ch.inv[a] < T(1e30) ? ch.inv[a] : T(0));  // (1 / sqrt(pivot): Inf for 0, NaN below it)
     ch.solve(u);
     T blk[7 * N];
 #pragma unroll

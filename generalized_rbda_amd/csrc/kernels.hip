@@ -118,6 +118,16 @@ struct Slots {
     T *glb;  // wave's global slab (uniform: the per-lane part of an address is a 32-bit offset, which
              // keeps the 64-bit address arithmetic to one vector add per object)
     int lane;
+    // lanes of this tile whose D = S^T IA S had a pivot that is not positive (chain_kernels.hip, ChainMem::bad: the same counting)
+    mutable unsigned long long bad = 0;
+    __device__ __forceinline__ void pivot(T d) const { bad |= __builtin_amdgcn_ballot_w64(!(d > T(0))); }
+    __device__ __forceinline__ void flush_bad(unsigned long long *counter, int rows_valid) const
+    {
+        const unsigned long long live = rows_valid >= kWave ? ~0ull : ((1ull << rows_valid) - 1ull);
+        const unsigned long long b = bad & live;
+        if (b && counter && lane == 0) atomicAdd(counter, (unsigned long long)__builtin_popcountll(b));
+        bad = 0;
+    }
 
     __device__ __forceinline__ T lds_get(int s) const { return reinterpret_cast<T *>(grbda_smem)[s * kWave + lane]; }
     __device__ __forceinline__ void lds_put(int s, T x) const { reinterpret_cast<T *>(grbda_smem)[s * kWave + lane] = x; }
@@ -1066,6 +1076,8 @@ __device__ __forceinline__ void aba_bwd_static(const Tables<T> &P, const SL &S, 
     // D^-1 u', K = D^-1 F^T
     Chol<T, N> ch;
     ch.factor(D);
+#pragma unroll
+    for (int a = 0; a < N; a++) S.pivot(ch.inv[a] < T(1e30) ? ch.inv[a] : T(0));  // (1 / sqrt(pivot): Inf for 0, NaN below it)
     ch.solve(u);
     T K[6 * N];
 #pragma unroll
@@ -1156,6 +1168,8 @@ __device__ __forceinline__ void aba_bwd_free(const Tables<T> &P, const SL &S, co
     }
     Chol<T, 6> ch;
     ch.factor(D);
+#pragma unroll
+    for (int i = 0; i < 6; i++) S.pivot(ch.inv[i] < T(1e30) ? ch.inv[i] : T(0));
     ch.solve(u);
     S.stK(c.slot_y0, u);
 }
@@ -1288,6 +1302,7 @@ __device__ __forceinline__ void aba_bwd_rev(const Tables<T> &P, const SL &S, con
 
     // ---- D^-1 u', K = D^-1 F^T (n = 1) ----
     const T Dinv = rcp_t(D);
+    S.pivot(D);
     const T y0 = u * Dinv;
     T K[6];
 #pragma unroll
@@ -1878,6 +1893,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_kernel(DevPlan<T> DP, const T 
             }
         }
         write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
+        S.flush_bad(DP.bad_count, rows_valid);
         PROF_ADD(18);  // tile epilogue
     }
 #ifdef GRBDA_PROFILE

@@ -354,6 +354,29 @@ int grbda_rnea_sharded_f32(const grbda_plan *plan, const float *q, const float *
 int grbda_rnea_sharded_f64(const grbda_plan *plan, const double *q, const double *qd, const double *ydd, double *tau,
                            size_t B, int n_gpus);
 
+/* The same split for shards that are ALREADY RESIDENT on their devices ("batches of independent states shard
+ * trivially across the GPUs of one node with a gather of results only"; the reference has no counterpart -- one
+ * ClusterTreeModel::forwardDynamics call is one state on one core, ClusterTreeDynamics.cpp:85-152).  One process, n_gpus
+ * shards: shard g = B[g] states in DEVICE arrays q[g], qd[g], tau[g] on device devices[g] (devices == NULL: 0 .. n_gpus-1),
+ * launched on streams[g] (streams == NULL or a NULL entry: that device's default stream; two shards on one device need
+ * distinct streams).  The plan is replicated per device on first use; there is no data-path collective.
+ *   gathered == NULL: every shard writes ydd[g] (its own device); nothing else happens.
+ *   gathered != NULL: a DEVICE array [sum B][nv] on devices[0]; the slab of shard g lands at row offset B[0] + .. + B[g-1] by
+ *     hipMemcpyPeerAsync on streams[g] (peer access is enabled where the devices allow it: the copy then crosses xGMI with no
+ *     host hop); a shard on devices[0] computes straight into its place when ydd is NULL or ydd[g] is NULL.  Shards on other
+ *     devices need their own output slab ydd[g].  streams[0] is made to wait for every shard's copy (events), so work enqueued
+ *     on streams[0] after the call sees the whole gathered array.
+ * Enqueues only, like every device-pointer entry point: no synchronisation, no host copies.  GRBDA_EINVAL for null / out of
+ * range arguments, GRBDA_ENODEVICE without a HIP device. */
+int grbda_aba_sharded_dev_f32(const grbda_plan *plan, int n_gpus, const int *devices, const float *const *q, const float *const *qd,
+                              const float *const *tau, float *const *ydd, const size_t *B, void *const *streams, float *gathered);
+int grbda_aba_sharded_dev_f64(const grbda_plan *plan, int n_gpus, const int *devices, const double *const *q, const double *const *qd,
+                              const double *const *tau, double *const *ydd, const size_t *B, void *const *streams, double *gathered);
+int grbda_rnea_sharded_dev_f32(const grbda_plan *plan, int n_gpus, const int *devices, const float *const *q, const float *const *qd,
+                               const float *const *ydd, float *const *tau, const size_t *B, void *const *streams, float *gathered);
+int grbda_rnea_sharded_dev_f64(const grbda_plan *plan, int n_gpus, const int *devices, const double *const *q, const double *const *qd,
+                               const double *const *ydd, double *const *tau, const size_t *B, void *const *streams, double *gathered);
+
 /* ---- measurement hook -------------------------------------------------------------------------- */
 /* Average duration in milliseconds of `iters` back-to-back launches of the ABA (kind 0) or RNEA
  * (kind 1) kernel, measured with hipEvents recorded on `stream` around the launches (the stream

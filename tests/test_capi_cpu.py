@@ -103,6 +103,30 @@ def test_no_cpu_fallback():
     assert e.value.code == -3
 
 
+def test_device_resident_sharded_entry_points_check_their_arguments():
+    """grbda_{aba,rnea}_sharded_dev_*: argument checking happens before anything touches a device (null plan, n_gpus < 1, null
+    pointer arrays -> GRBDA_EINVAL = -1); with well-formed arguments and no HIP device the answer is GRBDA_ENODEVICE = -3."""
+    import ctypes
+
+    L = G.lib()
+    p = G.Plan(md.revolute_chain_with_rotor(2).serialize())
+    P = ctypes.c_void_p
+    one = (P * 1)(0x1000)   # (never dereferenced on these paths)
+    Bs = (ctypes.c_size_t * 1)(4)
+    for name in ("grbda_aba_sharded_dev_f32", "grbda_aba_sharded_dev_f64", "grbda_rnea_sharded_dev_f32", "grbda_rnea_sharded_dev_f64"):
+        fn = getattr(L, name)
+        assert fn(None, 1, None, one, one, one, one, Bs, None, None) == -1            # null plan
+        assert fn(p._h, 0, None, one, one, one, one, Bs, None, None) == -1            # n_gpus < 1
+        assert fn(p._h, 1, None, None, one, one, one, Bs, None, None) == -1           # null q array
+        assert fn(p._h, 1, None, one, one, one, None, Bs, None, None) == -1           # neither per-shard outputs nor a gathered array
+        assert fn(p._h, 1, None, one, one, one, one, None, None, None) == -1          # null batch sizes
+        if G.device_count() == 0:
+            assert fn(p._h, 1, None, one, one, one, one, Bs, None, None) == -3        # no device: no CPU fallback
+        else:
+            bad_dev = (ctypes.c_int * 1)(G.device_count())
+            assert fn(p._h, 1, bad_dev, one, one, one, one, Bs, None, None) == -1     # device index out of range
+
+
 def test_model_builder_rejects_invalid_topology():
     m = md.ClusterTreeModel()
     I = md.spatial_inertia(1.0, [0, 0, 0], np.eye(3))

@@ -54,6 +54,70 @@ def test_aba_and_rnea_fp64_match_oracle(name, blob, gpu):
         assert rel_err(got_t, ref_t) < TOL64, f"RNEA B={B}"
 
 
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "urdf_jvrc1_humanoid"])
+@pytest.mark.parametrize("scale", [0.7, 1.3])
+def test_non_unit_quaternion_is_used_as_it_is(name, scale, gpu):
+    """The reference does not normalise the base quaternion: quaternionToRotationMatrix (OrientationTools.h:251-269) builds its
+    matrix from whatever four numbers the state holds, and a quaternion of length 1.3 gives a scaled, non-orthogonal "rotation" that
+    the dynamics then carry through.  Parity means doing the same: forward / inverse dynamics (and the mass matrix) of states
+    whose quaternion is scaled, against the oracle, in both precisions -- every kernel that builds the base rotation (chain
+    programs, latency mode at this batch size, interpreter) follows the formula, none normalises."""
+    import torch
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    q, qd, tau = valid_states(blob, 300, config_index=61)
+    q = q.copy()
+    q[:, 3:7] *= scale   # (floating base first: position 3, quaternion 4)
+    assert abs(np.linalg.norm(q[0, 3:7]) - scale) < 1e-9
+    ref, ref_t = O.forward_dynamics(blob, q, qd, tau), O.inverse_dynamics(blob, q, qd, tau)
+    assert rel_err(run_gpu(plan, "aba", q, qd, tau, torch.float64, gpu), ref) < TOL64
+    assert rel_err(run_gpu(plan, "rnea", q, qd, tau, torch.float64, gpu), ref_t) < TOL64
+    c32 = lambda a: a.astype(np.float32).astype(np.float64)
+    q32, qd32, tau32 = c32(q), c32(qd), c32(tau)
+    assert rel_err(run_gpu(plan, "aba", q32, qd32, tau32, torch.float32, gpu), O.forward_dynamics(blob, q32, qd32, tau32)) < TOL32
+    assert rel_err(run_gpu(plan, "rnea", q32, qd32, tau32, torch.float32, gpu), O.inverse_dynamics(blob, q32, qd32, tau32)) < TOL32
+    # and the unit-quaternion result is NOT what comes out (the scaling is not silently removed)
+    qn = q.copy()
+    qn[:, 3:7] /= scale
+    assert rel_err(O.forward_dynamics(blob, qn, qd, tau), ref) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["urdf_mit_humanoid", "urdf_jvrc1_humanoid", "rev_rotor_chain_4", "tree_triple_fixed"])
+def test_fp32_joint_angles_of_a_hundred_radians(name, gpu):
+    """Explicit models with joint angles drawn from +-100 rad (wound joints).  fp64 keeps 1e-9.  In fp32 the yardstick is the
+    oracle compiled in `float` (the dense restatement of the reference, oracle/_build/libgrbda_oracle_f32.so) on the same
+    fp32-rounded inputs: a single-precision angle of magnitude a carries ~6e-8 a of absolute error through any sine, and a
+    NON-axisymmetric geared rotor multiplies the joint angle by its gear ratio first (RevoluteTripleWithRotor here: up to 8 x 100
+    rad, where one ulp of the product is 6e-5 rad) -- there single precision itself leaves 1e-3 (measured: the float restatement
+    1.4e-3, the kernels 5.4e-3 on the worst of 2 000 states), and the kernels must stay within 5 x the float restatement's own error;
+    everywhere else they stay below the path's 1e-3 outright."""
+    import torch
+    from generalized_rbda_amd.states import parse_clusters
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    q, qd, tau = valid_states(blob, 2000, config_index=62)
+    rng = np.random.default_rng(62)
+    q = q.copy()
+    for c in parse_clusters(blob)["clusters"]:
+        (pc, fb, k, qi, npos, vi, nvel, nsp, nsv, ctype, *_rest) = c
+        if ctype != 1:   # (not the free base)
+            q[:, qi: qi + npos] = rng.uniform(-100.0, 100.0, (q.shape[0], npos))
+    c32 = lambda a: a.astype(np.float32).astype(np.float64)
+    q32, qd32, tau32 = c32(q), c32(qd), c32(tau)
+    ref, ref_t = O.forward_dynamics(blob, q32, qd32, tau32), O.inverse_dynamics(blob, q32, qd32, tau32)
+    assert rel_err(run_gpu(plan, "aba", q32, qd32, tau32, torch.float64, gpu), ref) < TOL64
+    assert rel_err(run_gpu(plan, "rnea", q32, qd32, tau32, torch.float64, gpu), ref_t) < TOL64
+    e_float = rel_err(O.forward_dynamics_mt_f32(blob, q32, qd32, tau32, 4), ref)
+    e_aba = rel_err(run_gpu(plan, "aba", q32, qd32, tau32, torch.float32, gpu), ref)
+    e_rnea = rel_err(run_gpu(plan, "rnea", q32, qd32, tau32, torch.float32, gpu), ref_t)
+    assert e_aba < max(TOL32, 5.0 * e_float), (e_aba, e_float)
+    assert e_rnea < TOL32, e_rnea
+    if name != "tree_triple_fixed":
+        assert e_aba < TOL32, (e_aba, e_float)
+
+
 @pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
 def test_aba_and_rnea_fp32_match_oracle(name, blob, gpu):
     import torch
@@ -986,6 +1050,57 @@ def test_sharded_host_entry_points(gpu):
         plan.sharded_host("aba", q, qd, tau, n + 1)
 
 
+@pytest.mark.parametrize("dtype_name", ["f32", "f64"])
+def test_device_resident_sharded_entry_points(dtype_name, gpu):
+    """grbda_{aba,rnea}_sharded_dev_* (SURVEY 8e): shards already in HBM, one process.  With ONE shard the results are bit for
+    bit those of grbda_aba_* / grbda_rnea_* (the same launch); with the batch cut into three shards on distinct streams (of as many
+    devices as the box has, wrapping around) and gathered on the first device -- peer copies over the links between devices, a
+    device-to-device copy on one -- the gathered array is bit for bit the unsharded result, and work enqueued on the first
+    stream after the call sees all of it."""
+    import torch
+
+    blob = zoo()["urdf_mit_humanoid"]
+    plan = G.Plan(blob)
+    B = 5000 + 37
+    q, qd, x = random_states(blob, B, 12)
+    dt = torch.float32 if dtype_name == "f32" else torch.float64
+    n_dev = G.device_count()
+    t = lambda a, d=0: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=torch.device("cuda", d))
+    for which, plain in (("aba", plan.forward_dynamics), ("rnea", plan.inverse_dynamics)):
+        want = plain(t(q), t(qd), t(x))
+        outs, _ = plan.sharded_device(which, [t(q)], [t(qd)], [t(x)])
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], want)
+        # one shard, gathered: the shard computes straight into the gathered array
+        gathered = torch.full((B, plan.nv), float("nan"), dtype=dt, device=torch.device("cuda", 0))
+        plan.sharded_device(which, [t(q)], [t(qd)], [t(x)], gathered=gathered)
+        torch.cuda.synchronize()
+        assert torch.equal(gathered, want)
+        # three ragged shards, each on its own stream, gathered on device 0
+        cuts = [0, 1700, 1700 + 64, B]
+        devs = [g % n_dev for g in range(3)]
+        qs = [t(q[cuts[g]:cuts[g + 1]], devs[g]) for g in range(3)]
+        qds = [t(qd[cuts[g]:cuts[g + 1]], devs[g]) for g in range(3)]
+        xs = [t(x[cuts[g]:cuts[g + 1]], devs[g]) for g in range(3)]
+        streams = [torch.cuda.Stream(device=torch.device("cuda", d)) for d in devs]
+        for g in range(3):
+            streams[g].wait_stream(torch.cuda.current_stream(torch.device("cuda", devs[g])))
+        gathered = torch.full((B, plan.nv), float("nan"), dtype=dt, device=torch.device("cuda", 0))
+        outs = [torch.empty((cuts[g + 1] - cuts[g], plan.nv), dtype=dt, device=torch.device("cuda", devs[g])) for g in range(3)]
+        plan.sharded_device(which, qs, qds, xs, outs=outs, gathered=gathered, streams=streams)
+        with torch.cuda.stream(streams[0]):
+            seen = gathered.clone()   # enqueued on the first stream AFTER the call: must see every slab
+        for s_ in streams:
+            s_.synchronize()
+        assert torch.equal(seen, want) and torch.equal(gathered, want)
+        for g in range(3):
+            assert torch.equal(outs[g].to("cuda:0"), want[cuts[g]:cuts[g + 1]])
+    # two shards on one (device, stream) would share a scratch slab: refused
+    with pytest.raises(G.GrbdaError):
+        s_ = torch.cuda.current_stream()
+        plan.sharded_device("aba", [t(q[:64]), t(q[64:128])], [t(qd[:64]), t(qd[64:128])], [t(x[:64]), t(x[64:128])], streams=[s_, s_])
+
+
 @pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_rotor_float", "chain_tree_b", "urdf_mini_cheetah_rpy"])
 def test_latency_mode_matches_the_one_wavefront_kernel(name, gpu, monkeypatch):
     """Batches of at most one tile per SIMD run a tile on a workgroup of two wavefronts that split the limbs below the
@@ -1102,10 +1217,54 @@ def test_singular_mass_matrix_is_counted(gpu):
         Hinv = plan.fd_dtau(q.to(dt))
         assert G.spd_bad_pivots(0, reset=True) == B
         assert not torch.isfinite(Hinv).all()
+    # the forward dynamics itself counts them too: D = S^T IA S of the massless link is 0, where the reference's
+    # ColPivHouseholderQR (ClusterTreeNode.cpp:33-37) would return a least-squares answer the Cholesky factorisations here return
+    # NaN / Inf -- every ABA kernel (chain programs, latency mode, single-cluster programs, the interpreter) reports the state
+    qd = torch.as_tensor(rng.uniform(-1, 1, (B, 2)), dtype=torch.float64, device=gpu)
+    tau = torch.as_tensor(rng.uniform(-1, 1, (B, 2)), dtype=torch.float64, device=gpu)
+    for dt in (torch.float64, torch.float32):
+        ydd = plan.forward_dynamics(q.to(dt), qd.to(dt), tau.to(dt))
+        assert G.spd_bad_pivots(0, reset=True) == B
+        assert not torch.isfinite(ydd).all()
     good = G.Plan(zoo()["urdf_mini_cheetah"])
-    qg, _, _ = valid_states(good.blob, 70, config_index=3)
+    qg, qdg, taug = valid_states(good.blob, 70, config_index=3)
     good.fd_dtau(torch.as_tensor(qg, dtype=torch.float32, device=gpu))
+    t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=gpu)
+    good.forward_dynamics(t32(qg), t32(qdg), t32(taug))
     assert G.spd_bad_pivots(0, reset=True) == 0
+
+
+@pytest.mark.parametrize("route", ["chain", "interpreter", "latency"])
+def test_bad_pivots_of_the_forward_dynamics_are_counted_on_every_kernel(route, gpu, monkeypatch):
+    """A floating-base robot with one massless, inertia-less distal link: its D is 0 in every state.  The chain program, the
+    general interpreter (GRBDA_NO_CHAIN=1) and the latency mode (small batch: a tile per workgroup of two wavefronts, whose
+    masks are united before counting) each report every state exactly once."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    m = md.ClusterTreeModel(gravity=(0.0, 0.0, -9.81))
+    m.appendBody("base", random_inertia(rng), "ground", joint="free")
+    m.appendBody("a0", random_inertia(rng), "base", *random_xtree(rng), joint="revolute", axis="z")
+    m.appendBody("a1", md.spatial_inertia(0.0, np.zeros(3), np.zeros((3, 3))), "a0", *random_xtree(rng), joint="revolute", axis="y")
+    m.appendBody("b0", random_inertia(rng), "base", *random_xtree(rng), joint="revolute", axis="x")
+    if route == "interpreter":
+        monkeypatch.setenv("GRBDA_NO_CHAIN", "1")
+    plan = G.Plan(m.serialize())
+    B = 64 * 3 + 5 if route == "latency" else 64 * 2100 + 5
+    q, qd, tau = random_states(plan.blob, B, 21)
+    G.spd_bad_pivots(0, reset=True)
+    for dt in (torch.float32, torch.float64):
+        t = lambda a: torch.as_tensor(a, dtype=dt, device=gpu)
+        name = plan.kernel_name("aba", "f32" if dt == torch.float32 else "f64", B)
+        if route == "latency":
+            assert "lm_kernel" in name, name
+        elif route == "interpreter":
+            assert "aba_kernel" in name, name
+        else:
+            assert "aba_chain_kernel" in name, name
+        ydd = plan.forward_dynamics(t(q), t(qd), t(tau))
+        assert G.spd_bad_pivots(0, reset=True) == B
+        assert not torch.isfinite(ydd).all()
 
 
 def test_cluster_on_two_parent_bodies_spanning_tree_route(gpu):
