@@ -143,6 +143,12 @@ struct ChainTables {
 };
 
 // LDS slots [slot][lane]; global slab rows [slot][lane]; the tile's inputs as coordinate-major slab rows
+// Slab rows through a buffer descriptor instead of pointers: an experiment switch (make variant VFLAGS=-DGRBDA_SLAB_BUFFER=1), OFF in
+// the product.  Measured in one run on one box (profiles/r6_slab_buffer_ab.txt): MIT Humanoid fp32 ABA 0.1427 -> 0.1449 ms, inverse
+// dynamics 0.0809 -> 0.0815, JVRC-1 even, TelloWithArms 0.848 -> 0.824 (-3 %), Mini Cheetah fp64 in latency mode 0.0657 -> 0.0778 (+18 %).
+#ifndef GRBDA_SLAB_BUFFER
+#define GRBDA_SLAB_BUFFER 0
+#endif
 template <class T>
 struct ChainMem {
     T *glb_u;           // wave's global slots (after the input rows): wave-uniform base
@@ -185,21 +191,68 @@ struct ChainMem {
 #pragma unroll
         for (int i = 0; i < N; i++) p[i * kWave] = x[i];
     }
-    // (row base: wave-uniform, so the 64-bit address arithmetic stays on the scalar unit; the lane enters as a 32-bit offset
-    // that is the same register for every access of the kernel, the row number as an immediate)
+    // The wave's slab [input rows | global slots] through ONE buffer descriptor (GRBDA_SLAB_BUFFER=1): a row access is buffer_load /
+    // buffer_store with the lane's byte offset in the VGPR that every access of the kernel shares, the row's byte offset in an SGPR
+    // (one 32-bit shift) and the element's row inside the block as the instruction's immediate -- 32-bit address arithmetic only,
+    // where the pointer form makes the compiler form 64-bit row addresses (s_mov + s_lshl_b64 and, where the row number is a loop
+    // variable, a v_lshl_add_u64 per access: 554 -> 363 of them in the headline kernel's text).  It did not pay (see the switch).
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned glb_b, q_b, qd_b, x_b, out_b;  // byte offsets of the regions inside the slab
+    static constexpr unsigned kRowBytes = kWave * (unsigned)sizeof(T);
+    __device__ __forceinline__ void set_slab(T *slab, int n_rows_total, int nq, int nv)
+    {
+        rs = __builtin_amdgcn_make_buffer_rsrc(slab, /*stride*/ 0, (int)((unsigned)n_rows_total * kRowBytes), 0x00020000);
+        q_b = 0;
+        qd_b = (unsigned)nq * kRowBytes;
+        x_b = (unsigned)(nq + nv) * kRowBytes;
+        out_b = x_b;
+        glb_b = (unsigned)(nq + 2 * nv) * kRowBytes;
+    }
+    // element at row byte offset `so` (wave-uniform) + `imm` (a constant: folds into the instruction) of this lane
+    __device__ __forceinline__ T bld(unsigned so, int imm) const
+    {
+        if constexpr (sizeof(T) == 4) {
+            return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_b + imm, (int)so, 0));
+        } else {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_b + imm, (int)so, 0);
+            return __builtin_bit_cast(T, v);
+        }
+    }
+    __device__ __forceinline__ void bst(unsigned so, int imm, T v) const
+    {
+        if constexpr (sizeof(T) == 4) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)lane_b + imm, (int)so, 0);
+        } else {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rs, (int)lane_b + imm, (int)so, 0);
+        }
+    }
     template <int N>
     __device__ __forceinline__ void glb_ld(int s, T (&x)[N]) const
     {
+#if GRBDA_SLAB_BUFFER
+        const unsigned so = glb_b + (unsigned)((s & ~kSlotGlobal) * gmul) * kRowBytes;
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = bld(so, i * (int)kRowBytes);
+#else
         const char *p = reinterpret_cast<const char *>(glb_u + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave));
 #pragma unroll
         for (int i = 0; i < N; i++) x[i] = *reinterpret_cast<const T *>(p + i * (kWave * (int)sizeof(T)) + (size_t)lane_b);
+#endif
     }
     template <int N>
     __device__ __forceinline__ void glb_st(int s, const T (&x)[N]) const
     {
+#if GRBDA_SLAB_BUFFER
+        const unsigned so = glb_b + (unsigned)((s & ~kSlotGlobal) * gmul) * kRowBytes;
+#pragma unroll
+        for (int i = 0; i < N; i++) bst(so, i * (int)kRowBytes, x[i]);
+#else
         char *p = reinterpret_cast<char *>(glb_u + (size_t)(unsigned)((s & ~kSlotGlobal) * gmul * kWave));
 #pragma unroll
         for (int i = 0; i < N; i++) *reinterpret_cast<T *>(p + i * (kWave * (int)sizeof(T)) + (size_t)lane_b) = x[i];
+#endif
     }
     // accumulators of branching bodies: LDS, or the global slab when the plan could not fit them (rare accesses)
     template <int N>
@@ -218,9 +271,15 @@ struct ChainMem {
     {
         return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b);
     }
+#if GRBDA_SLAB_BUFFER
+    __device__ __forceinline__ T q(int j) const { return bld(q_b + (unsigned)j * kRowBytes, 0); }
+    __device__ __forceinline__ T qd(int j) const { return bld(qd_b + (unsigned)j * kRowBytes, 0); }
+    __device__ __forceinline__ T x(int j) const { return bld(x_b + (unsigned)j * kRowBytes, 0); }
+#else
     __device__ __forceinline__ T q(int j) const { return row_ld(in_q_u, j); }
     __device__ __forceinline__ T qd(int j) const { return row_ld(in_qd_u, j); }
     __device__ __forceinline__ T x(int j) const { return row_ld(in_x_u, j); }
+#endif
 #ifdef GRBDA_CHAIN_PROFILE
     mutable unsigned long long pacc;
 #endif
@@ -228,7 +287,11 @@ struct ChainMem {
     // a result row read back (the differential's forward segment leaves a partial torque its backward segment completes)
     __device__ __forceinline__ T got(int j) const
     {
+#if GRBDA_SLAB_BUFFER
+        return bld(out_b + (unsigned)j * kRowBytes, 0);
+#else
         return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b);
+#endif
     }
     // (forward dynamics: rows in LDS or in the slab)
     // (forward dynamics: rows in LDS or in the slab; a wave-uniform branch, so that the store is a DS or a GLOBAL instruction: a
@@ -252,7 +315,11 @@ struct ChainMem {
     }
     __device__ __forceinline__ void put(int j, T v) const
     {
+#if GRBDA_SLAB_BUFFER
+        bst(out_b + (unsigned)j * kRowBytes, 0, v);
+#else
         *reinterpret_cast<T *>(reinterpret_cast<char *>(out_u + (size_t)(unsigned)(j * kWave)) + (size_t)lane_b) = v;
+#endif
     }
 };
 
@@ -1749,6 +1816,7 @@ __device__ __forceinline__ void gen1_tiles(int work_bytes, int nq, const T *__re
     M.glb_u = nullptr;
     M.in_q_u = M.in_qd_u = M.in_x_u = nullptr;
     M.out_u = nullptr;
+    M.set_slab(nullptr, 0, 0, 0);  // (the single-cluster kernels touch no slab)
     M.out_row = -1;
     M.out_f = nullptr;
     // LDS: [work area][q rows | qd rows | tau / ydd rows]   (nv = N: the cluster is the whole model)
@@ -1900,6 +1968,7 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_slab(slab, DP.n_glb_slots + P.nq + 2 * P.nv, P.nq, P.nv);
     M.set_out(DP.out_lds);
     M.bad = 0;
 #ifdef GRBDA_CHAIN_PROFILE
@@ -2042,6 +2111,7 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_slab(slab, DP.n_glb_slots + P.nq + 2 * P.nv, P.nq, P.nv);
     M.set_out(DP.out_lds);
     const unsigned bq = (unsigned)(kWave * P.nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * P.nv) * (unsigned)sizeof(T);
 
@@ -2186,6 +2256,7 @@ __global__ __launch_bounds__(kWave, 1) void osim_chain_kernel(ChainDev<T> DP, Os
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_slab(slab, DP.n_glb_slots + P.nq + 2 * P.nv, P.nq, P.nv);
     M.set_out(-1);
     const int m = A.n_contacts, nv = P.nv;
     const size_t n_tiles = (B + kWave - 1) / kWave;
@@ -3035,6 +3106,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     M.in_qd_u = slab + (size_t)P.nq * kWave;
     M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
     M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_slab(slab, DP.n_glb_slots + P.nq + 2 * P.nv, P.nq, P.nv);
     M.set_out(-1);
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
