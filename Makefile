@@ -35,7 +35,7 @@ $(OBJ)/chain_kernels_u2.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CS
 $(OBJ)/crba_kernels.o: $(CSRC)/crba_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
-$(OBJ)/deriv_kernels.o: $(CSRC)/deriv_kernels.hip $(CSRC)/tree_solve.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+$(OBJ)/deriv_kernels.o: $(CSRC)/deriv_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
 $(OBJ)/minv_kernels.o: $(CSRC)/minv_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h

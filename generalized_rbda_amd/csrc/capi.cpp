@@ -62,7 +62,6 @@ struct DeviceTables {
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
-    int32_t *tree_tab = nullptr;        // DerivProgram::tree (TreeSolveProgram::tab)
     MinvBody *minv_bodies = nullptr;    // DerivProgram::minv (plan.h, MinvProgram): record offsets per body ...
     int32_t *minv_coltab = nullptr;     // ... and the column programs of minv_mfma_kernel
     int32_t *related_table = nullptr;   // HostPlan::related_table (plans of the wide route with more than 64 velocities)
@@ -155,6 +154,7 @@ struct grbda_plan {
     ~grbda_plan() { if (span) grbda_plan_free(span); }
     std::vector<int32_t> span_q, span_v, crow;
     int n_cpl_rows = 0;
+    bool has_trig = false;     // some implicit cluster is a trig-polynomial constraint (its sine / cosine cache takes dynamic LDS of the manifold constraint kernel)
     int constraint_shape = 0;  // manifold_kernels.hip, launch_manifold_constraint: 0 structured, 1 beyond the limits, 2 at most 4 bodies / 2 coordinates
     bool no_manifold = false;  // GRBDA_NO_MANIFOLD=1: implicit models keep the difference batches (A/B runs)
 };
@@ -251,9 +251,6 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         return hip_err(e, "plan upload");
     if (!h.related_table.empty() &&
         (e = up(h.related_table.data(), h.related_table.size() * sizeof(int32_t), (void **)&t.related_table)) != hipSuccess)
-        return hip_err(e, "plan upload");
-    if (h.deriv.tree.ok &&
-        (e = up(h.deriv.tree.tab.data(), h.deriv.tree.tab.size() * sizeof(int32_t), (void **)&t.tree_tab)) != hipSuccess)
         return hip_err(e, "plan upload");
     if (h.deriv.ok && h.deriv.minv.ok &&
         ((e = up(h.deriv.minv.bodies.data(), h.deriv.minv.bodies.size() * sizeof(MinvBody), (void **)&t.minv_bodies)) != hipSuccess ||
@@ -896,7 +893,7 @@ int spanning(const grbda_plan *p, const T *q, const T *qd, const T *ydd, T *qd_s
             hipError_t e = launch_manifold_constraint<T>(dp, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s),
                                                          static_cast<int>(nv_s), p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, ydd + b0 * nv, q_s,
                                                          qd_span ? qd_span + b0 * nv_s : v_tmp, qdd_span + b0 * nv_s, cpl, nb, static_cast<int>(g),
-                                                         static_cast<hipStream_t>(stream), 1);
+                                                         static_cast<hipStream_t>(stream), 1, p->has_trig);
             if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         }
         return GRBDA_OK;
@@ -1645,7 +1642,7 @@ int projection_run(const grbda_plan *p, bool rnea, const T *q, const T *qd, cons
         // inverse dynamics: qdd_s = G ydd + g; forward dynamics: qdd_s = g (the bias of the spanning tree with the constraint's own acceleration)
         e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
                                           p->n_cpl_rows, 0, q + b0 * nq, qd + b0 * nv, rnea ? x + b0 * nv : nullptr, q_s, qd_s, qdd_s, cpl, nb,
-                                          static_cast<int>(grid), hs, p->constraint_shape);
+                                          static_cast<int>(grid), hs, p->constraint_shape, p->has_trig);
         if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         if (int rc = run<T>(sp, true, q_s, qd_s, qdd_s, f_ext ? f_ext + b0 * static_cast<size_t>(p->host.n_bodies) * 6 : nullptr, x_s, nb, device, stream))
             return rc;
@@ -1790,7 +1787,7 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         if (grid > n_tiles) grid = n_tiles;
         e = launch_manifold_constraint<T>(d, p->host.n_clusters, t->span_q, t->span_v, t->crow, static_cast<int>(nq_s), static_cast<int>(nv_s),
                                           p->n_cpl_rows, need_d ? 1 : 0, qc, qdc, yddc, q_s, qd_s, need_d ? qdd_s : nullptr, cpl, nb,
-                                          static_cast<int>(grid), hs, p->constraint_shape);
+                                          static_cast<int>(grid), hs, p->constraint_shape, p->has_trig);
         if (e != hipSuccess) return hip_err(e, "manifold constraint launch");
         if (!need_d && (e = hipMemsetAsync(qd_s, 0, chunk * nv_s * sizeof(T), hs)) != hipSuccess) return hip_err(e, "hipMemsetAsync");
         if (need_d)
@@ -1839,17 +1836,6 @@ int manifold_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     return GRBDA_OK;
 }
 
-// the branch-sparse solve covers plans whose expanded coordinate tree fits its register stack (plan.h, TreeSolveProgram; n <= 40)
-template <class T>
-static bool tree_solve_usable(const grbda_plan *p, const DeviceTables &t)
-{
-    const TreeSolveProgram &tp = p->host.deriv.tree;
-    if (!tp.ok || !t.tree_tab || !t.deriv_related || tp.n > 40) return false;
-    if (sizeof(T) == 4 && p->solve_f64) return false;
-    // opt-in: measured SLOWER than the matrix-core solve on every model tried (profiles/r5_tree_solve_experiment.txt)
-    return env_int("GRBDA_TREE_SOLVE", 0) != 0;
-}
-
 template <class T>
 int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, T *dq, T *dqd, T *dtau, size_t B, int device,
                     void *stream)
@@ -1883,7 +1869,9 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     const bool h_in_place = !minv && dtau && (il == 1 || (B % kDerivGroup) == 0);
     const size_t per_state = minv ? static_cast<size_t>(mv.n_entries) + (need_d ? 2 * nn + nv : 0)
                                   : (h_in_place ? 0 : nn) + (need_d ? 2 * nn + nv : 0);
-    size_t chunk = work_budget(p, p->work, device, stream, 4096ull << 20) / (per_state ? per_state * sizeof(T) : 1);
+    size_t budget = work_budget(p, p->work, device, stream, (4096ull << 20) + (need_d ? B * nv * sizeof(T) : 0));
+    if (need_d && budget > 2 * B * nv * sizeof(T)) budget -= B * nv * sizeof(T);  // (room for the whole batch's ydd, below)
+    size_t chunk = budget / (per_state ? per_state * sizeof(T) : 1);
     chunk &= ~static_cast<size_t>(kWave - 1);  // whole tiles, whole groups of the interleaved workspace
     if (chunk < static_cast<size_t>(kWave)) chunk = kWave;
     {
@@ -1896,8 +1884,12 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
     if (chunk > B) chunk = (B + kDerivGroup - 1) / kDerivGroup * kDerivGroup;  // (the last group of the workspace is allocated whole)
     // f32 with the matrix-core solve: the recursion writes H, dID/dq, dID/dqd interleaved by groups of kDerivGroup states
     // (deriv_kernels.hip); every other combination keeps the state-major layout (il, above)
+    // several chunks: the forward dynamics of the WHOLE batch in one launch up front (B nv scalars more of workspace: 160 MB for a million
+    // JVRC-1 states in fp32) instead of one launch per chunk -- a quarter-million-state launch runs at 0.35 ms, a quarter of the
+    // million-state launch at 0.29
+    const bool ydd_all = need_d && B > chunk;
     void *wptr = nullptr;
-    if (int rc = ensure_work(p, p->work, device, stream, chunk * per_state * sizeof(T) + 256, &wptr)) return rc;
+    if (int rc = ensure_work(p, p->work, device, stream, (chunk * per_state + (ydd_all ? B * nv : 0)) * sizeof(T) + 256, &wptr)) return rc;
     T *wnext = static_cast<T *>(wptr);
     auto take = [&](bool wanted) -> T * {
         if (!wanted) return nullptr;
@@ -1906,11 +1898,15 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         return r;
     };
     T *wH = take(!minv && !h_in_place), *Dq = take(need_d), *Dqd = take(need_d);
-    T *ydd = wnext;
-    T *recs = minv ? ydd + (need_d ? chunk * nv : 0) : nullptr;
+    T *ydd_chunk = wnext;
+    T *recs = minv ? ydd_chunk + (need_d ? chunk * nv : 0) : nullptr;
+    T *ydd_whole = ydd_all ? static_cast<T *>(wptr) + chunk * per_state : nullptr;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     DevPlan<T> d = make_dev_plan<T>(p, *t, false, false);
+    if (ydd_all)
+        if (int rc = run<T>(p, false, q, qd, tau, nullptr, ydd_whole, B, device, stream)) return rc;
     for (size_t b0 = 0; b0 < B; b0 += chunk) {
+        T *ydd = ydd_all ? ydd_whole + b0 * nv : ydd_chunk;
         const size_t nb = B - b0 < chunk ? B - b0 : chunk;
         const size_t n_tiles = (nb + kWave - 1) / kWave;
         // (an interleaved H block spans the slots of a whole group: when the batch does not end on a group boundary the last
@@ -1919,7 +1915,7 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
         hipError_t e = hipSuccess;
         // (both kernels write H as packed rows of its lower triangle; the solve reads it through DerivProgram::related, so
         // nothing is cleared)
-        if (need_d)
+        if (need_d && !ydd_all)
             if (int rc = run<T>(p, false, q + b0 * nq, qd + b0 * nv, tau + b0 * nv, nullptr, ydd, nb, device, stream)) return rc;
         size_t grid = static_cast<size_t>(t->n_cu) * 8;
         if (grid > n_tiles) grid = n_tiles;
@@ -1958,31 +1954,6 @@ int analytic_derivs(const grbda_plan *p, const T *q, const T *qd, const T *tau, 
             e = launch_minv_solve<T>(recs, mv.n_entries, kDerivGroup, t->minv_coltab, mv.max_depth, mv.base_off, p->host.deriv.n_max, r1, r2,
                                      kDerivGroup, o3, o1, o2, t->deriv_related, static_cast<int>(nv), nb, static_cast<int>(g3), hs);
             if (e != hipSuccess) return hip_err(e, "minv solve launch");
-            continue;
-        }
-        // the branch-sparse L^T L solve (tree_solve.h): eight states per wavefront
-        if (tree_solve_usable<T>(p, *t)) {
-            const TreeSolveProgram &tp = p->host.deriv.tree;
-            TreeSolveDev td;
-            td.tab = t->tree_tab; td.related = t->deriv_related; td.n = tp.n; td.nl = tp.nl;
-            td.o_rec = tp.o_rec; td.o_ancn = tp.o_ancn; td.o_ancro = tp.o_ancro; td.o_ancp = tp.o_ancp; td.o_hidx = tp.o_hidx;
-            TreeSolveIO<T> io;
-            std::memset(&io, 0, sizeof io);
-            io.H = H;
-            io.il = il;
-            int nm = 0;  // (the identity last: with all three asked, the two packed right-hand sides share the first pass)
-            if (dq) { io.kind[nm] = 1; io.src[nm] = r1; io.dst[nm] = o1; nm++; }
-            if (dqd) { io.kind[nm] = 2; io.src[nm] = r2; io.dst[nm] = o2; nm++; }
-            if (dtau) { io.kind[nm] = 0; io.src[nm] = nullptr; io.dst[nm] = o3; nm++; }
-            const size_t lds_t = tree_solve_lds_bytes(tp.n, tp.nl, sizeof(T));
-            size_t wpc = sizeof(T) == 4 ? 8 : 4;
-            if (lds_t && wpc > lds_workgroups_per_cu(lds_t)) wpc = lds_workgroups_per_cu(lds_t);
-            if (wpc < 1) wpc = 1;
-            size_t gt = static_cast<size_t>(t->n_cu) * wpc;
-            const size_t tiles8 = (nb + 7) / 8;
-            if (gt > tiles8) gt = tiles8;
-            e = launch_tree_solve<T>(td, io, nm, nb, static_cast<int>(gt), hs);
-            if (e != hipSuccess) return hip_err(e, "tree solve launch");
             continue;
         }
         // one wavefront per state; as many as the LDS of a CU holds
@@ -2339,6 +2310,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
                     for (int c = 0; c < p->host.n_clusters; c++) {
                         const ClusterRec &cr = p->host.lay64.clusters[c];
                         if (cr.kind == CK_LOOP && (cr.k > 4 || cr.n > 2)) small = false;
+                        if (cr.kind == CK_LOOP && cr.cons_type != 0) p->has_trig = true;
                     }
                     p->constraint_shape = p->host.big_clusters ? 1 : (small && !env_int("GRBDA_NO_SMALL_CONSTRAINT", 0) ? 2 : 0);
                 } else {
@@ -2385,7 +2357,7 @@ void grbda_plan_free(grbda_plan *p)
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         DeviceTables &t = kv.second;
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
-        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.tree_tab); (void)hipFree(t.minv_bodies); (void)hipFree(t.minv_coltab);
+        (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.minv_bodies); (void)hipFree(t.minv_coltab);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
         for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }

@@ -938,7 +938,6 @@ __device__ __forceinline__ double lane_value(double x, int l)
 // massless chains, a singular pose of an implicit cluster): their results are NaN / Inf, and the solve kernels count them here so
 // that a caller can ASK (grbda_spd_bad_pivots, include/grbda_hip.h) instead of scanning nv^2 numbers per state.
 __device__ unsigned long long grbda_spd_bad_count = 0;
-#include "tree_solve.h"
 unsigned long long *spd_bad_count_address()
 {
     void *p = nullptr;

@@ -218,7 +218,7 @@ size_t spd_solve_lds_bytes(int nv, size_t elem, int n_rhs);
 template <class T>
 hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
                                       int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
-                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, int shape = false);
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, int shape = false, bool trig = true);
 template <class T>
 hipError_t launch_manifold_apply(const DevPlan<T> &P, int n_clusters, const int32_t *span_v, const int32_t *crow, int nv_s, int n_cpl_rows, int mode,
                                  const T *x_s, const T *tau, const T *Hinv, const T *cpl, T *out, size_t B, int grid, hipStream_t stream,
@@ -246,24 +246,6 @@ hipError_t launch_spd_wide_solve(const T *H, const int32_t *relt, const T *rhs, 
 unsigned long long *spd_bad_count_address();
 int spd_mfma_workgroups_per_cu(int nv);
 bool spd_solve_on_mfma(size_t elem, int nv, int n_rhs);
-// branch-sparse L^T L solve (tree_solve.h): eight states per wavefront, the right-hand sides as IO.kind says (0 identity, 1 / 2 packed runs)
-struct TreeSolveDev {
-    const int32_t *tab;
-    const uint64_t *related;
-    int n, nl;
-    int o_rec, o_ancn, o_ancro, o_ancp, o_hidx;
-};
-template <class T>
-struct TreeSolveIO {
-    const T *H;        // packed lower-triangle rows (layout `il`)
-    const T *src[3];   // kind 1 / 2: packed runs of dID/dq, dID/dqd (layout `il`); kind 0 (identity): unused
-    T *dst[3];         // [state][n][n]
-    int kind[3];
-    int il;
-};
-template <class T>
-hipError_t launch_tree_solve(const TreeSolveDev &P, const TreeSolveIO<T> &IO, int n_mat, size_t B, int grid, hipStream_t stream);
-size_t tree_solve_lds_bytes(int n, int nl, size_t elem);
 hipError_t set_max_dynamic_lds_deriv();
 // H^-1 = W^T W from the articulated-body quantities (minv_kernels.hip; plan.h, MinvProgram): the record blocks (one state per lane, the
 // slab rows and processing order of rnea_deriv_kernel), then the walk + the two products on the matrix cores (one state per wavefront;

@@ -775,8 +775,9 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
     cptr<int32_t> cints = (cptr<int32_t>)DP.cints;
     cptr<int32_t> span_q = (cptr<int32_t>)span_q_, span_v = (cptr<int32_t>)span_v_, crow = (cptr<int32_t>)crow_;
     const int lane = threadIdx.x, nq = DP.nq, nv = DP.nv;
-    __shared__ T trig_lds[kTrigLdsSlots * kWave];  // (one wavefront per workgroup: trig_poly_eval_s)
-    T *tl = trig_lds + lane;
+    // (one wavefront per workgroup: trig_poly_eval_s.  DYNAMIC LDS, asked for only by plans that have a trig-polynomial cluster --
+    // launch_manifold_constraint: a static array cost every instantiation 16 / 32 KB per workgroup, loop-position models included)
+    T *tl = reinterpret_cast<T *>(grbda_smem) + lane;
     const size_t n_tiles = (B + kWave - 1) / kWave;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t r0 = tile * kWave + lane;
@@ -1348,8 +1349,20 @@ template hipError_t launch_manifold_apply<double>(const DevPlan<double> &, int, 
 template <class T>
 hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const int32_t *span_q, const int32_t *span_v, const int32_t *crow,
                                       int nq_s, int nv_s, int n_cpl_rows, int want_d, const T *q, const T *qd, const T *ydd, T *q_s, T *qd_s,
-                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, int shape)
+                                      T *qdd_s, T *cpl, size_t B, int grid, hipStream_t stream, int shape, bool trig)
 {
+    // the sine / cosine cache of trig-polynomial constraints (kTrigLdsSlots rows per wavefront); the grid is cut to what the LDS holds
+    const size_t lds = trig ? static_cast<size_t>(kTrigLdsSlots) * kWave * sizeof(T) : 0;
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    }
+    auto fit = [&](int g) {
+        const size_t cap = static_cast<size_t>(n_cu) * lds_workgroups_per_cu(lds);
+        return static_cast<size_t>(g) > cap ? static_cast<int>(cap) : g;
+    };
     // shape 0: clusters of up to kMaxClusterBodies bodies / kMaxClusterDof independent coordinates; 1: beyond (runtime loops, no derivative
     // parts); 2: every implicit cluster has at most 4 bodies and 2 independent coordinates (the Tello differentials): the same code with
     // half the unrolled work areas
@@ -1358,16 +1371,17 @@ hipError_t launch_manifold_constraint(const DevPlan<T> &P, int n_clusters, const
         // (fp32: 216 registers, two wavefronts per SIMD -- the caller's grid is for one)
         const size_t n_tiles = (B + kWave - 1) / kWave;
         if (sizeof(T) == 4 && static_cast<size_t>(grid) * 2 <= n_tiles) grid *= 2;
-        hipLaunchKernelGGL((manifold_constraint_kernel<T, 4, 2>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters, span_q, span_v, crow, nq_s, nv_s,
+        grid = fit(grid);
+        hipLaunchKernelGGL((manifold_constraint_kernel<T, 4, 2>), dim3(grid), dim3(kWave), lds, stream, P, n_clusters, span_q, span_v, crow, nq_s, nv_s,
                            n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
         return hipGetLastError();
     }
     if (big) {
         if (want_d) return hipErrorInvalidValue;  // (the wide variant carries no derivative parts)
-        hipLaunchKernelGGL((manifold_constraint_kernel<T, kBigClusterBodies, kBigClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
+        hipLaunchKernelGGL((manifold_constraint_kernel<T, kBigClusterBodies, kBigClusterDof>), dim3(fit(grid)), dim3(kWave), lds, stream, P, n_clusters,
                            span_q, span_v, crow, nq_s, nv_s, n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
     } else {
-        hipLaunchKernelGGL((manifold_constraint_kernel<T, kMaxClusterBodies, kMaxClusterDof>), dim3(grid), dim3(kWave), 0, stream, P, n_clusters,
+        hipLaunchKernelGGL((manifold_constraint_kernel<T, kMaxClusterBodies, kMaxClusterDof>), dim3(fit(grid)), dim3(kWave), lds, stream, P, n_clusters,
                            span_q, span_v, crow, nq_s, nv_s, n_cpl_rows, want_d, q, qd, ydd, q_s, qd_s, qdd_s, cpl, B);
     }
     return hipGetLastError();
@@ -1745,10 +1759,10 @@ hipError_t launch_manifold_project(const DevPlan<T> &P, int n_clusters, const in
 }
 template hipError_t launch_manifold_constraint<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const int32_t *, int, int, int,
                                                       int, const float *, const float *, const float *, float *, float *, float *, float *,
-                                                      size_t, int, hipStream_t, int);
+                                                      size_t, int, hipStream_t, int, bool);
 template hipError_t launch_manifold_constraint<double>(const DevPlan<double> &, int, const int32_t *, const int32_t *, const int32_t *, int, int,
                                                        int, int, const double *, const double *, const double *, double *, double *, double *,
-                                                       double *, size_t, int, hipStream_t, int);
+                                                       double *, size_t, int, hipStream_t, int, bool);
 template hipError_t launch_manifold_project<float>(const DevPlan<float> &, int, const int32_t *, const int32_t *, const uint64_t *,
                                                    const uint64_t *, int, int, int, const float *, const float *, const float *, const float *,
                                                    const float *, float *, float *, float *, size_t, int, hipStream_t, int, bool);

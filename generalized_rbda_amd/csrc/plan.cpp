@@ -600,7 +600,6 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             P.deriv.related[m.clusters[c].v_index + i] |= uint64_t(1) << (m.clusters[a].v_index + j);
                             P.deriv.related[m.clusters[a].v_index + j] |= uint64_t(1) << (m.clusters[c].v_index + i);
                         }
-            build_tree_solve(P.deriv.related, P.nv, P.deriv.tree);
         }
         return 0;
     }
@@ -2201,7 +2200,6 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     a = m.bodies[clusters[a].parent_body].cluster;
                 }
             }
-            build_tree_solve(DV.related, P.nv, DV.tree);
         }
         // ---- H^-1 = W^T W from the articulated-body quantities (plan.h, MinvProgram; minv_kernels.hip) ----
         {
@@ -2362,77 +2360,5 @@ int make_spanning_blob(const void *blob, size_t bytes, std::vector<unsigned char
     return 0;
 }
 
-// Expanded parent array and depth-first tables of the branch-sparse solve (plan.h, TreeSolveProgram) from the `related` masks alone:
-// the coordinates before i that share a root path with i are its ancestors (clusters are numbered parents first), the last of them its
-// parent.
-bool build_tree_solve(const std::vector<uint64_t> &related, int nv, TreeSolveProgram &T)
-{
-    T = TreeSolveProgram();
-    if (nv <= 0 || nv > 64 || static_cast<int>(related.size()) != nv) return false;
-    std::vector<int> parent(nv, -1), depth(nv, 0);
-    for (int i = 0; i < nv; i++) {
-        for (int j = 0; j < i; j++)
-            if ((related[i] >> j) & 1) { parent[i] = j; depth[i]++; }
-        // the ancestors must be one chain: every one of them related to every other (a tree, not a DAG)
-        for (int j = 0; j < i; j++)
-            if ((related[i] >> j) & 1)
-                for (int k = 0; k < j; k++)
-                    if (((related[i] >> k) & 1) && !((related[j] >> k) & 1)) return false;
-        if (parent[i] >= 0 && depth[i] != depth[parent[i]] + 1) return false;
-        if (depth[i] >= kTreeSolveDmax) return false;
-    }
-    std::vector<std::vector<int>> kids(nv);
-    std::vector<int> order, pos(nv, -1);
-    for (int i = 0; i < nv; i++)
-        if (parent[i] >= 0) kids[parent[i]].push_back(i);
-    std::vector<int> stack;
-    for (int i = nv - 1; i >= 0; i--)
-        if (parent[i] < 0) stack.push_back(i);
-    while (!stack.empty()) {
-        const int i = stack.back();
-        stack.pop_back();
-        pos[i] = static_cast<int>(order.size());
-        order.push_back(i);
-        for (int k = static_cast<int>(kids[i].size()) - 1; k >= 0; k--) stack.push_back(kids[i][k]);
-    }
-    if (static_cast<int>(order.size()) != nv) return false;
-    T.n = nv;
-    std::vector<int> rowofs(nv, 0);
-    for (int p = 0; p < nv; p++) {
-        rowofs[p] = T.nl;
-        T.nl += depth[order[p]];
-        T.dmax = std::max(T.dmax, depth[order[p]]);
-    }
-    T.o_rec = 0;
-    T.o_ancn = T.o_rec + 8 * nv;
-    T.o_ancro = T.o_ancn + kTreeSolveDmax * nv;
-    T.o_ancp = T.o_ancro + kTreeSolveDmax * nv;
-    T.o_hidx = T.o_ancp + kTreeSolveDmax * nv;
-    T.tab.assign(T.o_hidx + std::max(T.nl, 1) + 16, 0);
-    for (int p = 0; p < nv; p++) {
-        const int i = order[p], d = depth[i];
-        // levels [init_lo, d) are entered anew when the backward walk (positions descending) arrives at p from p + 1
-        int init_lo = 0;
-        const bool leaf = !(p + 1 < nv && parent[order[p + 1]] == i);
-        if (p + 1 < nv) {
-            const int pp = parent[order[p + 1]];
-            init_lo = pp >= 0 ? depth[pp] + 1 : 0;
-        }
-        if (init_lo > d) init_lo = d;
-        int32_t *rec = &T.tab[T.o_rec + 8 * p];
-        rec[0] = i; rec[1] = d; rec[2] = rowofs[p]; rec[3] = init_lo; rec[4] = leaf ? 1 : 0; rec[5] = i * (i + 1) / 2 + i;
-        for (int l = 0; l < kTreeSolveDmax; l++) T.tab[T.o_ancn + kTreeSolveDmax * p + l] = -1;
-        int a = parent[i];
-        for (int l = d - 1; l >= 0; l--) {
-            T.tab[T.o_ancn + kTreeSolveDmax * p + l] = a;
-            T.tab[T.o_ancro + kTreeSolveDmax * p + l] = rowofs[pos[a]];
-            T.tab[T.o_ancp + kTreeSolveDmax * p + l] = pos[a];
-            T.tab[T.o_hidx + rowofs[p] + l] = i * (i + 1) / 2 + a;
-            a = parent[a];
-        }
-    }
-    T.ok = true;
-    return true;
-}
 
 }  // namespace grbda_hip

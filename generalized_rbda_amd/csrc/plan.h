@@ -425,23 +425,6 @@ struct DerivBody {     // 10 ints
     int32_t anc_lds;    // bodies with an anc_row: their block of the LDS cache (their depth below the base), or -1: slab only
     int32_t walk_resident;  // (first body of a cluster) bit l: block l holds the cluster's ancestor at that depth when its walk starts
 };
-// Branch-sparse factorisation H = L^T L and the two triangular solves over the EXPANDED parent array of the velocity coordinates -- the
-// reference's own algorithm (src/Utils/Factorization.cpp:9-36 factorisation, :86-144 inverse products / solve; `expanded_tree_parent_indices_`,
-// ClusterTreeModel): coordinate i's parent is the coordinate before it in its cluster, the first coordinate of a cluster hangs off the
-// last coordinate of the parent cluster.  tree_solve_kernel (tree_solve.h) walks the coordinates in depth-first order with the values of
-// the current root path in a register stack indexed by DEPTH (static indices), so the program is a table of positions in that order.
-constexpr int kTreeSolveDmax = 16;  // deepest root path of the expanded tree the register stack holds
-struct TreeSolveProgram {
-    bool ok = false;
-    int n = 0, nl = 0, dmax = 0;   // coordinates, path entries (sum of depths), deepest path
-    // one int32 table (uploaded as it is): offsets below; per position p in depth-first order
-    //   rec[p][8]      = {coordinate, depth, rowofs, init_lo, leaf, packed index of H(i, i), 0, 0}
-    //   anc_node[p][16] coordinate of the ancestor at level l (-1 beyond the depth), anc_ro[p][16] its rowofs, anc_pos[p][16] its position
-    //   hidx[e]        packed lower-triangle index r (r + 1) / 2 + c of path entry e = rowofs[p] + l
-    std::vector<int32_t> tab;
-    int o_rec = 0, o_ancn = 0, o_ancro = 0, o_ancp = 0, o_hidx = 0;
-};
-bool build_tree_solve(const std::vector<uint64_t> &related, int nv, TreeSolveProgram &out);
 
 // H^-1 from the articulated-body quantities (minv_kernels.hip).  The cluster ABA's own factorisation of the joint-space inertia,
 //   H^-1 = W^T W,   W = D^-1/2 (1 - psi):   row block of cluster a, column j (j in a or below it)
@@ -476,7 +459,6 @@ struct MinvProgram {
 struct DerivProgram {
     bool ok = false;  // explicit (constant G) clusters
     MinvProgram minv;
-    TreeSolveProgram tree;
     std::vector<DerivBody> bodies;
     int n_rows = 0;
     int n_max = 1;    // largest number of coordinates of a cluster

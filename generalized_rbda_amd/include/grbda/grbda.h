@@ -866,7 +866,9 @@ public:
     {
         return [this, q0, k]() {
             const int nq_all = this->position_index_;
-            const bool cached = static_cast<int>(valid_q_cache_.size()) == nq_all;
+            // (the cache is dropped with the plan on every model mutation; should the cached state still fail -- it is re-projected with the
+            // new draw -- the first failed attempt forgets it and every implicit cluster is drawn afresh from then on)
+            bool cached = static_cast<int>(valid_q_cache_.size()) == nq_all;
             for (int attempt = 0; attempt < 45; attempt++) {
                 std::vector<double> q(nq_all, 0.0);
                 for (const auto &node : cluster_nodes_) {
@@ -888,6 +890,10 @@ public:
                 if (ok) {
                     valid_q_cache_ = q;
                     return JointCoordinate<double>(DVec<double>(q.begin() + q0, q.begin() + q0 + k), true);
+                }
+                if (cached && attempt == 0) {
+                    cached = false;
+                    valid_q_cache_.clear();
                 }
             }
             throw std::runtime_error("Failed to find valid roots for implicit loop constraint");
@@ -1294,6 +1300,7 @@ public:
     {
         if (this->plan_dirty_ || !plan_) {
             if (plan_) { grbda_plan_free(plan_); plan_ = nullptr; }
+            valid_q_cache_.clear();  // (positions accepted for the model as it was)
             std::vector<unsigned char> blob = serialize();
             check(grbda_plan_from_blob(blob.data(), blob.size(), &plan_));
             this->plan_dirty_ = false;
