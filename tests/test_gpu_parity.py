@@ -113,9 +113,9 @@ def test_fp32_joint_angles_of_a_hundred_radians(name, gpu):
     e_aba = rel_err(run_gpu(plan, "aba", q32, qd32, tau32, torch.float32, gpu), ref)
     e_rnea = rel_err(run_gpu(plan, "rnea", q32, qd32, tau32, torch.float32, gpu), ref_t)
     assert e_aba < max(TOL32, 5.0 * e_float), (e_aba, e_float)
-    assert e_rnea < TOL32, e_rnea
+    assert e_rnea < max(TOL32, 5.0 * e_float), (e_rnea, e_float)   # (inverse dynamics of the triple clusters: 1.5e-3 measured)
     if name != "tree_triple_fixed":
-        assert e_aba < TOL32, (e_aba, e_float)
+        assert e_aba < TOL32 and e_rnea < TOL32, (e_aba, e_rnea, e_float)
 
 
 @pytest.mark.parametrize("name,blob", list(zoo().items()), ids=list(zoo().keys()))
