@@ -14,7 +14,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_V
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -- python3 $ROOT/tools/pmc_target_derivs.py > $OUT/p$i.log 2>&1
 done
-for k in rnea_deriv spd_solve spd_mfma; do
+for k in rnea_deriv abi_factor minv_mfma; do
   echo "== $k"; python3 $ROOT/tools/pmc_summarize.py $OUT $k
 done > $OUT/summary.txt
 cat $OUT/summary.txt
