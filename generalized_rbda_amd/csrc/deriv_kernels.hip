@@ -584,7 +584,7 @@ __global__ __launch_bounds__(kWave, GRBDA_EXP_DERIV_WPS) void rnea_deriv_kernel(
                 }
                 // body inertia, force and B in F; composites
                 T Ic[21], Bc[36], Fc[6], h[6];
-                congruence(E, p3, C + 12, Ic);
+                congruence_rigid(E, p3, C + 12, Ic);
                 symv(Ic, v, h);
                 {
                     T Ia[6], vh[6];

@@ -179,6 +179,43 @@ __device__ __forceinline__ void congruence(const T (&E)[9], R3 r, const A21 &A, 
         }
 }
 
+// The same congruence for a RIGID-BODY inertia A = [[Ibar, h^], [h^T, m 1]] (what SpatialInertia holds: mass, first moment h = m c, rotational
+// inertia about the origin) under a proper rotation E:  E^T h^ E = (E^T h)^,  a^ b^ = b a^T - (a . b) 1,  so with h' = E^T h and g = h' + m r
+//   B22 = m 1,   B12 = g^,   B11 = E^T Ibar E - (r h'^T + h' r^T + m r r^T) + (2 h' . r + m r . r) 1
+// -- ~100 multiply-adds instead of ~260: one symmetric 3 x 3 rotation instead of two and a general one.  Used by the derivative
+// recursion and the articulated-inertia factor kernel (every E there is a product of joint rotations and axis permutations; the plan compiler
+// refuses them for a model whose body inertias do not have this structure: plan.cpp, DerivProgram::ok).
+template <class T, class R3, class A21>
+__device__ __forceinline__ void congruence_rigid(const T (&E)[9], R3 r, const A21 &A, T (&B)[21])
+{
+    T A11[9], R11[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) A11[3 * i + j] = A[sidx(i, j)];
+    rot3_sym(E, A11, R11);
+    // h^ = [[0, -h2, h1], [h2, 0, -h0], [-h1, h0, 0]] is the upper right block
+    const T h0 = A[sidx(2, 4)], h1 = A[sidx(0, 5)], h2 = A[sidx(1, 3)], m = A[sidx(3, 3)];
+    T hp[3], g[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        hp[j] = E[j] * h0 + E[3 + j] * h1 + E[6 + j] * h2;  // E^T h
+        g[j] = hp[j] + m * r[j];
+    }
+    const T s = T(2) * (hp[0] * r[0] + hp[1] * r[1] + hp[2] * r[2]) + m * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            B[sidx(i, j)] = R11[3 * i + j] - (r[i] * hp[j] + hp[i] * r[j] + m * r[i] * r[j]) + (i == j ? s : T(0));
+            B[sidx(3 + i, 3 + j)] = i == j ? m : T(0);
+        }
+    // B12 = g^
+    B[sidx(0, 3)] = 0;      B[sidx(0, 4)] = -g[2];  B[sidx(0, 5)] = g[1];
+    B[sidx(1, 3)] = g[2];   B[sidx(1, 4)] = 0;      B[sidx(1, 5)] = -g[0];
+    B[sidx(2, 3)] = -g[1];  B[sidx(2, 4)] = g[0];   B[sidx(2, 5)] = 0;
+}
+
 // y = A x for packed symmetric A
 template <class T>
 __device__ __forceinline__ void symv(const T (&A)[21], const T (&x)[6], T (&y)[6])

@@ -46,6 +46,20 @@ __device__ __forceinline__ void minv_kin(cptr<T> C, bool axisym, T qi, const T (
     S[4] = kin[11] * S[0] - kin[9] * S[2];
     S[5] = kin[9] * S[1] - kin[10] * S[0];
 }
+// the PARENT's [E | p] from a revolute body's own: the step above undone (E_p = E_l^T E, p_p = p - E_p^T r)
+template <class T>
+__device__ __forceinline__ void minv_kin_up(cptr<T> C, bool axisym, T qi, const T (&kin)[12], T (&kp)[12])
+{
+    T sn = 0, cs = 1, El[9];
+    if (!axisym) sincos_t(qi, &sn, &cs);
+    rotate_z(sn, cs, C, El);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) kp[3 * r + c] = El[r] * kin[c] + El[3 + r] * kin[3 + c] + El[6 + r] * kin[6 + c];
+#pragma unroll
+    for (int i = 0; i < 3; i++) kp[9 + i] = kin[9 + i] - (kp[i] * C[9] + kp[3 + i] * C[10] + kp[6 + i] * C[11]);
+}
 template <class T>
 __device__ __forceinline__ void axis_of(const T (&kin)[12], T (&S)[6])
 {
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
 #pragma unroll
                 for (int j = 0; j < 12; j++) kin[j] = (j < 9 && j % 4 == 0) ? T(1) : T(0);
                 const DerivBody x = load_rec(db + cr.first_body);
-                if (x.kin_row >= 0) {
+                if (x.kin_row >= 0 && load_rec(mb + cr.first_body).keep) {
 #pragma unroll
                     for (int j = 0; j < 12; j++) slab[(size_t)(x.kin_row + j) * kWave] = kin[j];
                 }
@@ -146,8 +160,10 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
                 }
                 T kin[12], S[6];
                 minv_kin(C, false, qi, kp, kin, S);
+                if (load_rec(mb + gb).keep) {  // (only the rows somebody loads: plan.h, MinvBody::keep)
 #pragma unroll
-                for (int j = 0; j < 12; j++) slab[(size_t)(x.kin_row + j) * kWave] = kin[j];
+                    for (int j = 0; j < 12; j++) slab[(size_t)(x.kin_row + j) * kWave] = kin[j];
+                }
                 last_gb = gb;
 #pragma unroll
                 for (int j = 0; j < 12; j++) last_kin[j] = kin[j];
@@ -155,8 +171,11 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
         }
         // ---- pass 2, leaf side first: articulated inertias, D, K, L^-1 ----
         T part[21];  // articulated inertia the in-cluster roots of a cluster hand to the parent body (registers along chains)
+        T kin_carry[12];  // ... and, beside it, the kinematics of that parent body: the next cluster derives ITS parent's from them
 #pragma unroll
         for (int j = 0; j < 21; j++) part[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) kin_carry[j] = 0;
         for (int c = n_clusters - 1; c >= 0; c--) {
             const ClusterRec cr = load_rec(clusters + c);
             if (cr.kind == CK_FREE) {
@@ -209,6 +228,20 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
 #pragma unroll
                 for (int j = 0; j < 21; j++) part[j] = 0;
             }
+            // kinematics of the cluster's parent body: undone from the carried body's along a chain, loaded otherwise
+            T kin_pb[12];
+            if (first_i >= 0) {
+                const BodyRec bc = load_rec(bodies + (cr.first_body + first_i));
+                cptr<T> Cc = consts + bc.cofs;
+                T qc = 0;
+                for (int a2 = 0; a2 < n; a2++) qc += Cc[kBodyConstFixed + a2] * qs[cr.q_index + a2];
+                minv_kin_up(Cc, bc.axisym != 0, qc, kin_carry, kin_pb);
+            } else if (cr.parent_body >= 0) {
+                ld12(load_rec(db + cr.parent_body).kin_row, kin_pb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 12; j++) kin_pb[j] = (j < 9 && j % 4 == 0) ? T(1) : T(0);
+            }
 #pragma unroll
             for (int a2 = 0; a2 < NMAX; a2++) {
 #pragma unroll
@@ -232,8 +265,9 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
 #pragma unroll
                 for (int a2 = 0; a2 < NMAX; a2++) Gi[a2] = a2 < n ? C[kBodyConstFixed + a2] : T(0);
                 T kin[12], S[6];
-                if (x.kin_row >= 0) {
-                    ld12(x.kin_row, kin);
+                if (step < 0) {  // the body a child cluster handed its inertia to: its kinematics came along
+#pragma unroll
+                    for (int j = 0; j < 12; j++) kin[j] = kin_carry[j];
                     axis_of(kin, S);
                 } else {
                     T qi = 0;
@@ -241,12 +275,11 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
                     for (int a2 = 0; a2 < NMAX; a2++)
                         if (a2 < n) qi += Gi[a2] * qs[cr.q_index + a2];
                     T kp[12];
-                    if (b.parent >= 0) {
-                        const DerivBody xp = load_rec(db + b.parent);
-                        ld12(xp.kin_row, kp);
+                    if (b.lam >= 0) {  // in-cluster parent: its row is kept
+                        ld12(load_rec(db + b.lam).kin_row, kp);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 12; j++) kp[j] = (j < 9 && j % 4 == 0) ? T(1) : T(0);
+                        for (int j = 0; j < 12; j++) kp[j] = kin_pb[j];
                     }
                     minv_kin(C, b.axisym != 0, qi, kp, kin, S);
                 }
@@ -257,7 +290,7 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
                     for (int j = 0; j < 9; j++) E[j] = kin[j];
 #pragma unroll
                     for (int j = 0; j < 3; j++) p3[j] = kin[9 + j];
-                    congruence(E, p3, C + 12, IA);
+                    congruence_rigid(E, p3, C + 12, IA);
                 }
                 if (step < 0) {
 #pragma unroll
@@ -416,6 +449,9 @@ __global__ __launch_bounds__(kWave, 2) void abi_factor_kernel(DevPlan<T> DP, con
                     }
 #pragma unroll
                     for (int j = 0; j < 21; j++) slab[(size_t)(xp.acc_row + j) * kWave] = part[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 12; j++) kin_carry[j] = kin_pb[j];
                 }
             }
         }

@@ -2103,6 +2103,20 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             if (cr.kind == CK_LOOP) DV.ok = false;
             if (cr.kind == CK_FREE && cr.first_body != 0) DV.ok = false;
         }
+        // the recursion transforms body inertias with the rigid-body congruence (devmath.h, congruence_rigid): [[Ibar, h^], [h^T, m 1]] -- what a
+        // SpatialInertia of the reference holds (SpatialInertia.h: mass, centre of mass, rotational inertia); a description with any other
+        // symmetric 6 x 6 keeps the difference batches
+        for (int b = 0; b < nb && DV.ok; b++) {
+            const double *I = m.bodies[b].inertia;
+            double scale = 0;
+            for (int i = 0; i < 36; i++) scale = std::max(scale, std::fabs(I[i]));
+            const double tol = 1e-10 * (scale + 1e-300), mass = I[3 * 6 + 3];
+            for (int i = 0; i < 3 && DV.ok; i++)
+                for (int j = 0; j < 3; j++) {
+                    if (std::fabs(I[(3 + i) * 6 + 3 + j] - (i == j ? mass : 0.0)) > tol) DV.ok = false;   // lower right: m 1
+                    if (std::fabs(I[i * 6 + 3 + j] + I[j * 6 + 3 + i]) > tol) DV.ok = false;               // upper right: skew
+                }
+        }
         DV.bodies.assign(nb, DerivBody{0, -1, -1, -1, 0, 0, 0, -1, -1, 0});
         int rows = 0;
         for (int b = 0; b < nb; b++) {
@@ -2206,7 +2220,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             MinvProgram &MV = DV.minv;
             MV = MinvProgram();
             MV.ok = DV.ok && P.nv <= 64;
-            MV.bodies.assign(nb, MinvBody{-1, -1});
+            MV.bodies.assign(nb, MinvBody{-1, -1, 0});
             int off = 0;
             std::vector<int> c_off(nc, -1);
             for (int c = 0; c < nc && MV.ok; c++) {
@@ -2237,6 +2251,27 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             }
             MV.n_entries = off;
             if (off >= 65536) MV.ok = false;
+            // which kinematics rows the factor kernel really stores (plan.h, MinvBody::keep): simulate its two passes
+            {
+                int last = -1;  // pass 1, clusters root side first, bodies with children: the parent comes from registers when it was the body before
+                for (int c = 0; c < nc; c++) {
+                    const ClusterRec &cr = clusters[c];
+                    if (cr.kind == CK_FREE) { last = cr.first_body; continue; }
+                    for (int i = 0; i < cr.k; i++) {
+                        const int b = cr.first_body + i;
+                        if (!bodies[b].has_child) continue;
+                        if (bodies[b].parent >= 0 && bodies[b].parent != last) MV.bodies[bodies[b].parent].keep = 1;
+                        last = b;
+                    }
+                }
+                for (int b = 0; b < nb; b++)
+                    if (bodies[b].lam >= 0) MV.bodies[bodies[b].lam].keep = 1;  // in-cluster parents: their children and the ancestor loops load them
+                for (int c = 0; c < nc; c++) {  // pass 2: clusters without a carried hand-over load their parent body's row
+                    const ClusterRec &cr = clusters[c];
+                    if (cr.kind == CK_FREE || cr.parent_body < 0) continue;
+                    if (DV.bodies[cr.first_body].carry_body < 0) MV.bodies[cr.parent_body].keep = 1;
+                }
+            }
             MV.coltab.assign(static_cast<size_t>(64) * kMinvColInts, 0);
             for (int c = 0; c < nc && MV.ok; c++) {
                 const ClusterRec &cr = clusters[c];

@@ -443,9 +443,14 @@ struct DerivBody {     // 10 ints
 //   [3 + t] (t < kMinvMaxDepth): step t of the path, leaf side first:  block offset | n << 16 | v_index << 20 | valid << 31
 constexpr int kMinvMaxDepth = 16;
 constexpr int kMinvColInts = 3 + kMinvMaxDepth;
-struct MinvBody {      // 2 ints per body
+struct MinvBody {      // 3 ints per body
     int32_t blk_off;   // bodies that carry child clusters: offset of their block [K | L^-1 | S_ab]; else -1
     int32_t clus_off;  // (first body of a non-free cluster) offset of the cluster's first block; (base) offset of its L^-1; else -1
+    // abi_factor_kernel stores the kinematics [E | p] of this body in its slab row (pass 1) because somebody LOADS them: a body of pass 1
+    // whose parent is not the body processed right before it, an in-cluster child, or -- pass 2 -- a cluster that receives no carried
+    // hand-over from a child cluster.  Along chains nobody does: pass 2 derives a parent's kinematics from its child's
+    // (E_p = E_l^T E_i, p_p = p_i - E_p^T r) and the row is never written (JVRC-1: 11 of 33 rows stay).
+    int32_t keep;
 };
 struct MinvProgram {
     bool ok = false;
