@@ -249,10 +249,12 @@ CONFIG_RECORDS = [
     (1, "revolute_rotor_chain", "aba", "f64", 1024),
     (2, "mini_cheetah", "aba", "f64", 65536),
     (3, "mit_humanoid", "rnea", "f32", 262144),
+    (3, "mit_humanoid", "fd_derivatives", "f32", 262144),
     (4, "tello", "aba", "f32", 1048576),
     (4, "tello", "rnea", "f32", 1048576),
     (5, "jvrc1_humanoid", "aba", "f32", 1048576),
     (5, "jvrc1_humanoid", "fd_derivatives", "f32", 1048576),
+    (5, "jvrc1_humanoid", "fd_derivatives", "f64", 1048576),
     (5, "four_bar", "aba", "f32", 1048576),
     (5, "six_bar", "aba", "f32", 1048576),
 ]

@@ -34,9 +34,11 @@ def test_bench_line_is_verified_and_carries_roofline_and_cpu_baseline(gpu):
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["single_thread"] > 0 and c["passes"] >= 5
     # every other BASELINE config rides in the same line as a compact sub-record
-    recs = {(x["workload"], x["algo"]): x for x in line["configs"]}
-    for key in [("revolute_rotor_chain", "aba"), ("mini_cheetah", "aba"), ("mit_humanoid", "rnea"), ("tello", "aba"), ("tello", "rnea"),
-                ("jvrc1_humanoid", "aba"), ("jvrc1_humanoid", "fd_derivatives"), ("four_bar", "aba"), ("six_bar", "aba")]:
+    recs = {(x["workload"], x["algo"], x["dtype"]): x for x in line["configs"]}
+    for key in [("revolute_rotor_chain", "aba", "f64"), ("mini_cheetah", "aba", "f64"), ("mit_humanoid", "rnea", "f32"), ("tello", "aba", "f32"),
+                ("tello", "rnea", "f32"), ("jvrc1_humanoid", "aba", "f32"), ("jvrc1_humanoid", "fd_derivatives", "f32"),
+                ("jvrc1_humanoid", "fd_derivatives", "f64"), ("mit_humanoid", "fd_derivatives", "f32"), ("four_bar", "aba", "f32"),
+                ("six_bar", "aba", "f32")]:
         x = recs[key]
         assert "error" not in x, x
         assert x["verified"] is True and x["ms"] > 0 and x["evals_per_s"] > 0 and 0 < x["roofline"]["frac"] < 1, x
