@@ -60,7 +60,12 @@ template <class T> __device__ __forceinline__ void sc_of(Du<T> x, Du<T> &s, Du<T
 // parts are compiled for; <kBigClusterBodies, kBigClusterDof> serves clusters beyond those limits (plan.h, HostPlan::big_clusters
 // -- the reference's parallel-chain benchmark family, Benchmarking/src/pinocchioHelpers.cpp:355-410): forward / inverse dynamics
 // and the mass matrix only, G kept in the coupling slab instead of registers, private arrays in scratch memory -- slow, correct.
-constexpr int kMR = 3;                  // constraint rows
+// constraint rows of an implicit cluster: 3 in the structured kernels (registers, closed-form inverses of K_d), kMaxConstraintRows = 6 in the wide
+// ones (runtime loops over private arrays, K_d by elimination with partial pivoting): clusters with 4 - 6 rows -- two planar loops that share
+// bodies, a spatial loop beside a planar one; the reference inverts a K_d of any size, GenericJoint.cpp:57-90 -- take the spanning-tree route
+// like the clusters beyond 8 bodies / 4 coordinates (plan.cpp)
+template <int KB>
+constexpr int kMRof = KB > kMaxClusterBodies ? kMaxConstraintRows : 3;
 // rows of the coupling slab per body of an implicit cluster with n independent coordinates: everything the derivatives need,
 // or G alone for the clusters beyond the structured kernels' limits (capi.cpp sizes crow / n_cpl_rows with the same rule)
 template <int KB>
@@ -123,7 +128,7 @@ __device__ __forceinline__ void place(S (&a)[N], int idx, S v)
 // (clusters beyond the structured limits: runtime loops over private arrays of 48 entries -- scratch memory, slow, correct)
 template <class T, class S, int KB>
 __device__ void loop_position_eval_dyn(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
-                                       const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMR][KB], S (&kap)[kMR], S *phi = nullptr)
+                                       const S *sn, const S *cs, const S *qd, bool want_K, S (&K)[kMRof<KB>][KB], S (&kap)[kMRof<KB>], S *phi = nullptr)
 {
     // phi (with want_K): the constraint values -- predecessor point minus successor point along the constrained axes
     cptr<int32_t> lp = loops;
@@ -238,7 +243,7 @@ __device__ void loop_position_eval_dyn(cptr<T> consts, cptr<BodyRec> bodies, con
 template <class T, class S, int KB>
 __device__ __forceinline__ void loop_position_eval_reg(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops,
                                                        int n_loops, const S (&sn)[KB], const S (&cs)[KB], const S (&qd)[KB], bool want_K,
-                                                       S (&K)[kMR][KB], S (&kap)[kMR], S *phi)
+                                                       S (&K)[kMRof<KB>][KB], S (&kap)[kMRof<KB>], S *phi)
 {
     cptr<int32_t> lp = loops;
     int row0 = 0;
@@ -307,7 +312,7 @@ __device__ __forceinline__ void loop_position_eval_reg(cptr<T> consts, cptr<Body
                     for (int ax = 0; ax < 3; ax++)
                         if (mask & (1 << ax)) {
 #pragma unroll
-                            for (int rr = 0; rr < kMR; rr++) place(K[rr], rr == row ? sub : -1, sgn * J[ax]);
+                            for (int rr = 0; rr < kMRof<KB>; rr++) place(K[rr], rr == row ? sub : -1, sgn * J[ax]);
                             row++;
                         }
                 }
@@ -372,8 +377,8 @@ __device__ __forceinline__ void loop_position_eval_reg(cptr<T> consts, cptr<Body
 
 template <class T, class S, int KB>
 __device__ __forceinline__ void loop_position_eval(cptr<T> consts, cptr<BodyRec> bodies, const ClusterRec &c, cptr<int32_t> loops, int n_loops,
-                                                   const S (&sn)[KB], const S (&cs)[KB], const S (&qd)[KB], bool want_K, S (&K)[kMR][KB],
-                                                   S (&kap)[kMR], S *phi = nullptr)
+                                                   const S (&sn)[KB], const S (&cs)[KB], const S (&qd)[KB], bool want_K, S (&K)[kMRof<KB>][KB],
+                                                   S (&kap)[kMRof<KB>], S *phi = nullptr)
 {
     if constexpr (KB > kMaxClusterBodies) loop_position_eval_dyn<T, S, KB>(consts, bodies, c, loops, n_loops, sn, cs, qd, want_K, K, kap, phi);
     else loop_position_eval_reg<T, S, KB>(consts, bodies, c, loops, n_loops, sn, cs, qd, want_K, K, kap, phi);
@@ -407,7 +412,7 @@ __device__ __forceinline__ void tl_get(const T *tl, int slot, Du<T> &v)
 
 template <class T, class S, int KB>
 __device__ __forceinline__ void trig_poly_eval_s(cptr<T> consts, const ClusterRec &c, cptr<int32_t> prog, const S (&q)[KB], const S (&qd)[KB],
-                                                 bool want_K, S (&K)[kMR][KB], S (&kap)[kMR], T *tl = nullptr, bool fresh = true)
+                                                 bool want_K, S (&K)[kMRof<KB>][KB], S (&kap)[kMRof<KB>], T *tl = nullptr, bool fresh = true)
 {
     const int k = c.k;
     cptr<int32_t> ip = prog;
@@ -439,7 +444,7 @@ __device__ __forceinline__ void trig_poly_eval_s(cptr<T> consts, const ClusterRe
         }
     }
 #pragma unroll
-    for (int r = 0; r < kMR; r++) {
+    for (int r = 0; r < kMRof<KB>; r++) {
         if (r >= c.rows) break;
         const int nt = *ip++;
         S Krow[KB], kd = S(T(0));
@@ -520,7 +525,7 @@ __device__ __forceinline__ void trig_poly_eval_s(cptr<T> consts, const ClusterRe
 // K or kappa of an implicit cluster at the spanning state (q, qd), scalar type S
 template <class T, class S, int KB>
 __device__ __forceinline__ void constraint_eval(cptr<T> consts, cptr<BodyRec> bodies, cptr<int32_t> cints, const ClusterRec &c,
-                                                const S (&q)[KB], const S (&qd)[KB], bool want_K, S (&K)[kMR][KB], S (&kap)[kMR],
+                                                const S (&q)[KB], const S (&qd)[KB], bool want_K, S (&K)[kMRof<KB>][KB], S (&kap)[kMRof<KB>],
                                                 T *tl = nullptr, bool fresh = true)
 {
     cptr<int32_t> ip = cints + c.iofs;
@@ -544,18 +549,18 @@ __device__ __forceinline__ void constraint_eval(cptr<T> consts, cptr<BodyRec> bo
     }
 }
 
-template <class T>
-__device__ __forceinline__ void inv_rows(int R, const T (&A)[kMR][kMR], T (&Ai)[kMR][kMR])
+template <class T, int M>
+__device__ __forceinline__ void inv_rows(int R, const T (&A)[M][M], T (&Ai)[M][M])
 {
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) Ai[i][j] = 0;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++) Ai[i][j] = 0;
     if (R == 1) {
         Ai[0][0] = T(1) / A[0][0];
     } else if (R == 2) {
         const T id = T(1) / (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
         Ai[0][0] = A[1][1] * id; Ai[0][1] = -A[0][1] * id;
         Ai[1][0] = -A[1][0] * id; Ai[1][1] = A[0][0] * id;
-    } else {
+    } else if (R == 3) {
         const T c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
         const T c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
         const T c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
@@ -567,6 +572,41 @@ __device__ __forceinline__ void inv_rows(int R, const T (&A)[kMR][kMR], T (&Ai)[
         Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id;
         Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id;
         Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id;
+    } else if constexpr (M > 3) {
+        // 4 .. M rows: Gauss-Jordan elimination with partial pivoting on [A | 1] (the wide kernels only: runtime loops over private arrays).
+        // A singular K_d leaves Inf / NaN behind, as the closed forms do.
+        T W[M][M];
+        for (int i = 0; i < R; i++)
+            for (int j = 0; j < R; j++) {
+                W[i][j] = A[i][j];
+                Ai[i][j] = i == j ? T(1) : T(0);
+            }
+        for (int c = 0; c < R; c++) {
+            int piv = c;
+            T best = W[c][c] < 0 ? -W[c][c] : W[c][c];
+            for (int i = c + 1; i < R; i++) {
+                const T a = W[i][c] < 0 ? -W[i][c] : W[i][c];
+                if (a > best) { best = a; piv = i; }
+            }
+            if (piv != c)
+                for (int j = 0; j < R; j++) {
+                    const T t1 = W[c][j]; W[c][j] = W[piv][j]; W[piv][j] = t1;
+                    const T t2 = Ai[c][j]; Ai[c][j] = Ai[piv][j]; Ai[piv][j] = t2;
+                }
+            const T ip = T(1) / W[c][c];
+            for (int j = 0; j < R; j++) {
+                W[c][j] *= ip;
+                Ai[c][j] *= ip;
+            }
+            for (int i = 0; i < R; i++) {
+                if (i == c) continue;
+                const T f = W[i][c];
+                for (int j = 0; j < R; j++) {
+                    W[i][j] -= f * W[c][j];
+                    Ai[i][j] -= f * Ai[c][j];
+                }
+            }
+        }
     }
 }
 
@@ -585,11 +625,11 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
     const int k = cr.k, n = cr.n, rows = cr.rows;
     cptr<int32_t> ip = cints + cr.iofs;
     const int n_ind = ip[1];
-    int ind[KN], dep[kMR];
+    int ind[KN], dep[kMRof<KB>];
 #pragma unroll
     for (int a = 0; a < KN; a++) ind[a] = a < n ? ip[2 + a] : -1;
 #pragma unroll
-    for (int r = 0; r < kMR; r++) dep[r] = r < rows ? ip[3 + n_ind + r] : -1;
+    for (int r = 0; r < kMRof<KB>; r++) dep[r] = r < rows ? ip[3 + n_ind + r] : -1;
     T qv[KB], yd[KN], yddv[KN];
 #pragma unroll
     for (int j = 0; j < KB; j++) qv[j] = j < k ? qs[cr.q_index + j] : T(0);
@@ -598,9 +638,9 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
         yd[a] = a < n ? qds[cr.v_index + a] : T(0);
         yddv[a] = (a < n && ydds) ? ydds[cr.v_index + a] : T(0);
     }
-    T K[kMR][KB], kap[kMR], zero[KB];
+    T K[kMRof<KB>][KB], kap[kMRof<KB>], zero[KB];
 #pragma unroll
-    for (int r = 0; r < kMR; r++) {
+    for (int r = 0; r < kMRof<KB>; r++) {
         kap[r] = 0;
 #pragma unroll
         for (int j = 0; j < KB; j++) K[r][j] = 0;
@@ -608,11 +648,11 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
 #pragma unroll
     for (int j = 0; j < KB; j++) zero[j] = 0;
     constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, zero, true, K, kap, tl, true);
-    T Kd[kMR][kMR], Kdi[kMR][kMR], qdv[KB], gv[KB], G[KB][KN];
+    T Kd[kMRof<KB>][kMRof<KB>], Kdi[kMRof<KB>][kMRof<KB>], qdv[KB], gv[KB], G[KB][KN];
 #pragma unroll
-    for (int r = 0; r < kMR; r++)
+    for (int r = 0; r < kMRof<KB>; r++)
 #pragma unroll
-        for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? pick(K[r], dep[j]) : T(r == j);
+        for (int j = 0; j < kMRof<KB>; j++) Kd[r][j] = (r < rows && j < rows) ? pick(K[r], dep[j]) : T(r == j);
     inv_rows(rows, Kd, Kdi);
 #pragma unroll
     for (int i = 0; i < KB; i++) {
@@ -621,13 +661,13 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
         for (int a = 0; a < KN; a++) G[i][a] = (a < n && i == ind[a]) ? T(1) : T(0);
     }
 #pragma unroll
-    for (int r = 0; r < kMR; r++)
+    for (int r = 0; r < kMRof<KB>; r++)
 #pragma unroll
         for (int a = 0; a < KN; a++) {
             if (r >= rows || a >= n) continue;
             T sum = 0;
 #pragma unroll
-            for (int j = 0; j < kMR; j++)
+            for (int j = 0; j < kMRof<KB>; j++)
                 if (j < rows) sum += Kdi[r][j] * pick(K[j], ind[a]);
 #pragma unroll
             for (int i = 0; i < KB; i++) G[i][a] = i == dep[r] ? -sum : G[i][a];
@@ -641,11 +681,11 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
     }
     constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, qdv, false, K, kap, tl, false);  // (K is not touched: want_K false)
 #pragma unroll
-    for (int r = 0; r < kMR; r++) {
+    for (int r = 0; r < kMRof<KB>; r++) {
         if (r >= rows) continue;
         T sum = 0;
 #pragma unroll
-        for (int j = 0; j < kMR; j++)
+        for (int j = 0; j < kMRof<KB>; j++)
             if (j < rows) sum += Kdi[r][j] * kap[j];
         place(gv, dep[r], -sum);
     }
@@ -672,23 +712,23 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
     for (int i = 0; i < k; i++)
         for (int j = n; j < stride; j++) cc[(size_t)(i * stride + j) * kWave] = 0;
     for (int a = 0; a < n; a++) {
-        Du<T> qD[KB], qdD[KB], KD[kMR][KB], kapD[kMR];
+        Du<T> qD[KB], qdD[KB], KD[kMRof<KB>][KB], kapD[kMRof<KB>];
 #pragma unroll
         for (int j = 0; j < KB; j++) {
             qD[j] = Du<T>(qv[j], pick(G[j], a));
             qdD[j] = Du<T>(T(0));
         }
 #pragma unroll
-        for (int r = 0; r < kMR; r++) {
+        for (int r = 0; r < kMRof<KB>; r++) {
             kapD[r] = Du<T>(T(0));
 #pragma unroll
             for (int j = 0; j < KB; j++) KD[r][j] = Du<T>(T(0));
         }
         constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD, tl, true);
         // G' (dependent rows) = -Kd^-1 K' G ;  d g / d yd_a = -2 Kd^-1 K' qd_s
-        T Gp[kMR][KN], KpQd[kMR], qdp[KB], KpG[kMR][KN];
+        T Gp[kMRof<KB>][KN], KpQd[kMRof<KB>], qdp[KB], KpG[kMRof<KB>][KN];
 #pragma unroll
-        for (int r = 0; r < kMR; r++) {
+        for (int r = 0; r < kMRof<KB>; r++) {
             T sum = 0;
 #pragma unroll
             for (int j = 0; j < KB; j++) sum += KD[r][j].d * qdv[j];
@@ -704,14 +744,14 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
 #pragma unroll
         for (int j = 0; j < KB; j++) qdp[j] = 0;
 #pragma unroll
-        for (int r = 0; r < kMR; r++)
+        for (int r = 0; r < kMRof<KB>; r++)
 #pragma unroll
             for (int b2 = 0; b2 < KN; b2++) {
                 Gp[r][b2] = 0;
                 if (r >= rows || b2 >= n) continue;
                 T sum = 0;
 #pragma unroll
-                for (int r2 = 0; r2 < kMR; r2++)
+                for (int r2 = 0; r2 < kMRof<KB>; r2++)
                     if (r2 < rows) sum += Kdi[r][r2] * KpG[r2][b2];
                 Gp[r][b2] = -sum;
 #pragma unroll
@@ -720,20 +760,20 @@ __device__ __forceinline__ void manifold_implicit_cluster(cptr<T> consts, cptr<B
 #pragma unroll
         for (int j = 0; j < KB; j++) qdD[j] = Du<T>(qdv[j], qdp[j]);
         constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, false, KD, kapD, tl, false);  // (KD is not touched)
-        T gdep[kMR];
+        T gdep[kMRof<KB>];
 #pragma unroll
-        for (int j = 0; j < kMR; j++) gdep[j] = j < rows ? pick(gv, dep[j]) : T(0);
+        for (int j = 0; j < kMRof<KB>; j++) gdep[j] = j < rows ? pick(gv, dep[j]) : T(0);
 #pragma unroll
-        for (int r = 0; r < kMR; r++) {
+        for (int r = 0; r < kMRof<KB>; r++) {
             if (r >= rows) continue;
             const int i = dep[r];
             T gy = 0, gyd = 0, ay = 0, by = 0;
 #pragma unroll
-            for (int r2 = 0; r2 < kMR; r2++) {
+            for (int r2 = 0; r2 < kMRof<KB>; r2++) {
                 if (r2 >= rows) continue;
                 T kdg = 0;  // (K'_d g_dep)[r2]
 #pragma unroll
-                for (int j = 0; j < kMR; j++)
+                for (int j = 0; j < kMRof<KB>; j++)
                     if (j < rows) kdg += pick(KD[r2], dep[j]).d * gdep[j];
                 gy += Kdi[r][r2] * (kapD[r2].d + kdg);
                 gyd += Kdi[r][r2] * KpQd[r2];
@@ -838,21 +878,21 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
                 yd[a] = a < n ? qds[cr.v_index + a] : T(0);
                 yddv[a] = (a < n && ydds) ? ydds[cr.v_index + a] : T(0);
             }
-            T K[kMR][KB], kap[kMR], zero[KB];
-            for (int r = 0; r < kMR; r++) {
+            T K[kMRof<KB>][KB], kap[kMRof<KB>], zero[KB];
+            for (int r = 0; r < kMRof<KB>; r++) {
                 kap[r] = 0;
                 for (int j = 0; j < KB; j++) K[r][j] = 0;
             }
             for (int j = 0; j < KB; j++) zero[j] = 0;
             constraint_eval<T, T, KB>(consts, bodies, cints, cr, qv, zero, true, K, kap, tl, true);
-            T Kd[kMR][kMR], Kdi[kMR][kMR], qdv[KB], gv[KB];
+            T Kd[kMRof<KB>][kMRof<KB>], Kdi[kMRof<KB>][kMRof<KB>], qdv[KB], gv[KB];
             const int stride = cpl_stride<KB>(n);
             T *cc = cp + (size_t)crow[c] * kWave;
             GStore<T, KB, KN> G;
             G.cc = cc;
             G.stride = stride;
-            for (int r = 0; r < kMR; r++)
-                for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
+            for (int r = 0; r < kMRof<KB>; r++)
+                for (int j = 0; j < kMRof<KB>; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
             inv_rows(rows, Kd, Kdi);
             for (int i = 0; i < k; i++) {
                 gv[i] = 0;
@@ -896,18 +936,18 @@ __global__ __launch_bounds__(kWave, 1) void manifold_constraint_kernel(DevPlan<T
             for (int i = 0; i < k; i++)
                 for (int j = n; j < stride; j++) cc[(size_t)(i * stride + j) * kWave] = 0;
             for (int a = 0; a < n; a++) {
-                Du<T> qD[KB], qdD[KB], KD[kMR][KB], kapD[kMR];
+                Du<T> qD[KB], qdD[KB], KD[kMRof<KB>][KB], kapD[kMRof<KB>];
                 for (int j = 0; j < KB; j++) {
                     qD[j] = Du<T>(qv[j], j < k ? G.get(j, a) : T(0));
                     qdD[j] = Du<T>(T(0));
                 }
-                for (int r = 0; r < kMR; r++) {
+                for (int r = 0; r < kMRof<KB>; r++) {
                     kapD[r] = Du<T>(T(0));
                     for (int j = 0; j < KB; j++) KD[r][j] = Du<T>(T(0));
                 }
                 constraint_eval<T, Du<T>, KB>(consts, bodies, cints, cr, qD, qdD, true, KD, kapD, tl, true);
                 // G' (dependent rows) = -Kd^-1 K' G ;  d g / d yd_a = -2 Kd^-1 K' qd_s
-                T Gp[kMR][KN], KpQd[kMR], qdp[KB];
+                T Gp[kMRof<KB>][KN], KpQd[kMRof<KB>], qdp[KB];
                 for (int r = 0; r < rows; r++) {
                     T s = 0;
                     for (int j = 0; j < k; j++) s += KD[r][j].d * qdv[j];
@@ -1449,8 +1489,8 @@ __global__ __launch_bounds__(kWave, 1) void manifold_newton_kernel(DevPlan<T> DP
             }
             T nrm = T(1e30);
             for (int it = 0; it <= max_iter; it++) {
-                T K[kMR][KB], kap[kMR], phi[kMR];
-                for (int r = 0; r < kMR; r++) {
+                T K[kMRof<KB>][KB], kap[kMRof<KB>], phi[kMRof<KB>];
+                for (int r = 0; r < kMRof<KB>; r++) {
                     kap[r] = phi[r] = 0;
                     for (int j = 0; j < KB; j++) K[r][j] = 0;
                 }
@@ -1462,9 +1502,9 @@ __global__ __launch_bounds__(kWave, 1) void manifold_newton_kernel(DevPlan<T> DP
                 // (all lanes iterate together: a lane that has converged keeps its coordinates)
                 const bool done = nrm < tol;
                 if (__builtin_amdgcn_ballot_w64(!done) == 0 || it == max_iter) break;
-                T Kd[kMR][kMR], Kdi[kMR][kMR];
-                for (int r = 0; r < kMR; r++)
-                    for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
+                T Kd[kMRof<KB>][kMRof<KB>], Kdi[kMRof<KB>][kMRof<KB>];
+                for (int r = 0; r < kMRof<KB>; r++)
+                    for (int j = 0; j < kMRof<KB>; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
                 inv_rows(rows, Kd, Kdi);
                 for (int r = 0; r < rows; r++) {
                     T s = 0;
@@ -1536,9 +1576,9 @@ __global__ __launch_bounds__(kWave, 1) void manifold_state_kernel(DevPlan<T> DP,
                 cptr<int32_t> ip = cints + c.iofs;
                 const int hdr0 = ip[0], n_ind = ip[1];
                 cptr<int32_t> ind = ip + 2, dep = ip + 3 + n_ind, payload = ip + 3 + n_ind + rows;
-                T sn[KB], cs[KB], zero[KB], K[kMR][KB], kap[kMR], phi[kMR];
+                T sn[KB], cs[KB], zero[KB], K[kMRof<KB>][KB], kap[kMRof<KB>], phi[kMRof<KB>];
                 for (int j = 0; j < KB; j++) zero[j] = 0;
-                for (int r = 0; r < kMR; r++) {
+                for (int r = 0; r < kMRof<KB>; r++) {
                     kap[r] = phi[r] = 0;
                     for (int j = 0; j < KB; j++) K[r][j] = 0;
                 }
@@ -1567,9 +1607,9 @@ __global__ __launch_bounds__(kWave, 1) void manifold_state_kernel(DevPlan<T> DP,
                         if (voc && write) voc[a] = v;
                     }
                 }
-                T Kd[kMR][kMR], Kdi[kMR][kMR];
-                for (int r = 0; r < kMR; r++)
-                    for (int j = 0; j < kMR; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
+                T Kd[kMRof<KB>][kMRof<KB>], Kdi[kMRof<KB>][kMRof<KB>];
+                for (int r = 0; r < kMRof<KB>; r++)
+                    for (int j = 0; j < kMRof<KB>; j++) Kd[r][j] = (r < rows && j < rows) ? K[r][dep[j]] : T(r == j);
                 inv_rows(rows, Kd, Kdi);
                 T f1 = 0, f2 = 0;
                 for (int r = 0; r < rows; r++)

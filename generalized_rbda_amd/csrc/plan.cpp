@@ -45,9 +45,9 @@ struct Blob {
     const double *dbls;
 };
 
-int fail(char *msg, size_t cap, int code, const char *fmt, int a = 0, int b = 0)
+int fail(char *msg, size_t cap, int code, const char *fmt, int a = 0, int b = 0, int c = 0)
 {
-    if (msg && cap) std::snprintf(msg, cap, fmt, a, b);
+    if (msg && cap) std::snprintf(msg, cap, fmt, a, b, c);
     return code;
 }
 
@@ -143,8 +143,16 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d DoF exceed the kernel limit", c, cl.n_vel);
             if (cl.n_span_vel != cl.n_bodies || cl.n_span_pos != cl.n_bodies || cl.n_pos != cl.n_bodies)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop cluster must have one revolute joint per body", c);
-            if (cl.n_constraint_rows < 1 || cl.n_constraint_rows > 3 || cl.n_constraint_rows != cl.n_bodies - cl.n_vel)
-                return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d constraint rows (1..3 supported)", c, cl.n_constraint_rows);
+            // 1 - 3 rows: the structured kernels (closed-form inverses of K_d).  4 - kMaxConstraintRows rows of URDF+ position loops -- two planar
+            // loops that share bodies, a spatial loop beside a planar one; the reference inverts a K_d of any size, GenericJoint.cpp:57-90 --:
+            // the spanning-tree route with the wide kernels (K_d by elimination), like clusters beyond 8 bodies / 4 coordinates
+            const int max_rows = (cl.constraint_type == GRBDA_CONSTRAINT_LOOP_POSITION && !no_big) ? kMaxConstraintRows : 3;
+            if (cl.n_constraint_rows < 1 || cl.n_constraint_rows > max_rows || cl.n_constraint_rows != cl.n_bodies - cl.n_vel)
+                return fail(msg, cap, GRBDA_EUNSUPPORTED, "cluster %d: %d constraint rows (1..%d supported)", c, cl.n_constraint_rows, max_rows);
+            if (cl.n_constraint_rows > 3) {
+                P.projection_only = true;
+                P.big_clusters = true;
+            }
             if (cl.int_offset < 0 || cl.int_offset + cl.n_int > m.h->n_ints || cl.n_int < cl.n_bodies)
                 return fail(msg, cap, GRBDA_EINVAL, "cluster %d: loop payload missing", c);
             cr.kind = CK_LOOP;

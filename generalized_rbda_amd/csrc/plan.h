@@ -45,6 +45,7 @@ enum ClusterKind : int32_t {
 
 constexpr int kMaxClusterDof = 4;     // n of a non-free cluster handled in registers
 constexpr int kMaxClusterBodies = 8;  // k
+constexpr int kMaxConstraintRows = 6; // rows of an implicit cluster: 1 - 3 in the structured kernels, 4 - 6 through the spanning tree (wide kernels)
 // clusters beyond those two limits run through the spanning tree only (HostPlan::big_clusters; manifold_kernels.hip's wide variants)
 constexpr int kBigClusterBodies = 48;
 constexpr int kBigClusterDof = 48;

@@ -220,11 +220,14 @@ def valid_states(blob, B, config_index=0, max_cond=None, big=False, scale=1.0):
     if not any(c[9] >= 2 for c in parse_clusters(blob)["clusters"]):
         return random_states(blob, B, config_index)
     qs, qds, taus = [], [], []
+    loop_clusters = [c for c in parse_clusters(blob)["clusters"] if c[9] == 2]
     have, attempt = 0, 0
     while have < B:
         q, qd, tau = random_states(blob, max(2 * B, 16), config_index + 7919 * attempt)
         q *= scale
         q, ok = O.project_positions(blob, q, big=big)
+        for c in loop_clusters:  # revolute loops: Newton from a far guess may land whole turns away -- the same pose, wrapped
+            q[:, c[3]:c[3] + c[4]] = np.remainder(q[:, c[3]:c[3] + c[4]] + np.pi, 2 * np.pi) - np.pi
         gmax, kcond = O.spanning_state(blob, q, qd, big=big)[2:]
         ok &= accept(blob, q, gmax, kcond)
         if max_cond is not None:

@@ -214,7 +214,8 @@ def test_full_size_derivatives_on_the_constraint_manifold(workload, B, gpu):
     assert worst < TOL32, f"dq vs oracle differences on the manifold: {worst:.2e}"
 
 
-@pytest.mark.parametrize("name,implicit", [("parallel_chain_exp_d10_l16", False), ("parallel_chain_imp_d10_l17", True)])
+@pytest.mark.parametrize("name,implicit", [("parallel_chain_exp_d10_l16", False), ("parallel_chain_imp_d10_l17", True),
+                                           ("three_loop_linkage", True)])  # (the last: 7 bodies, SIX constraint rows)
 def test_big_cluster_models_at_size_round_trip(name, implicit, gpu):
     """The reference's own depth-10 parallel-chain files (a cluster of 16 bodies / 15 DoF, of 17 bodies / 15 DoF with a planar
     loop) through the spanning-tree route at 65 536 + 37 states: ID(FD(tau)) == tau in fp64 over the whole batch, fp32

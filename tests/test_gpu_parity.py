@@ -1457,24 +1457,24 @@ def test_every_model_of_the_reference_parallel_chain_family(gpu, tmp_path, impli
     assert np.abs(tid - ref_id).max() / (1 + np.abs(ref_id).max()) < 1e-9
 
 
-@pytest.mark.parametrize("which", ["two_parent", "exp_d10_l16", "imp_d10_l17"])
+@pytest.mark.parametrize("which", ["two_parent", "exp_d10_l16", "imp_d10_l17", "three_loop_linkage"])
 def test_external_forces_and_test_force_on_the_spanning_tree_route(gpu, which):
-    """Plans on the spanning-tree route (a cluster on two parent bodies; clusters of 16 / 17 bodies) take world-frame external forces --
+    """Plans on the spanning-tree route (a cluster on two parent bodies; clusters of 16 / 17 bodies; a cluster with six constraint rows) take world-frame external forces --
     the spanning model shares their bodies, so the forces enter ITS inverse dynamics -- and with them the contact-side entry points that
     are built on forced forward dynamics: applyTestForce (ClusterTreeDynamics.cpp:194-233) against the oracle's forced dynamics."""
     import torch
     from test_capi_cpu import two_parent_model
 
-    big = which != "two_parent"
+    big = which in ("exp_d10_l16", "imp_d10_l17")
     if which == "two_parent":
         blob = two_parent_model().serialize()
         plan = G.Plan(blob)
         q, qd, tau = random_states(blob, 70, config_index=4)
     else:
-        name = {"exp_d10_l16": "parallel_chain_exp_d10_l16", "imp_d10_l17": "parallel_chain_imp_d10_l17"}[which]
+        name = {"exp_d10_l16": "parallel_chain_exp_d10_l16", "imp_d10_l17": "parallel_chain_imp_d10_l17"}.get(which, which)
         plan = G.Plan.from_urdf(os.path.join(ROBOT_MODELS, name + ".urdf"))
         blob = plan.blob
-        q, qd, tau = valid_states(blob, 70, config_index=4, big=True, scale=0.5, max_cond=50)
+        q, qd, tau = valid_states(blob, 70, config_index=4, big=big, scale=0.5 if big else 1.0, max_cond=50)
     assert plan.info().spanning_tree_route == 1
     B, nb, nv = q.shape[0], plan.n_bodies, plan.nv
     fext = np.random.default_rng(6).uniform(-1, 1, (B, nb, 6))
@@ -1560,7 +1560,7 @@ def test_external_forces_and_test_force_on_the_spanning_tree_route(gpu, which):
     assert np.abs(np.einsum("bnij,bj->bni", J0, qd[:Bt]) - V[:, frames, :6]).max() / (1 + np.abs(V[:, frames, :6]).max()) < 1e-9
     V32 = plan.body_twists(t(q[:Bt], torch.float32), t(qd[:Bt], torch.float32), t(ydd, torch.float32)).double().cpu().numpy()
     assert np.abs(V32 - V).max() / (1 + np.abs(V).max()) < TOL32
-    if which != "imp_d10_l17":
+    if which not in ("imp_d10_l17", "three_loop_linkage"):
         h = 1e-5
         Vp = plan.body_twists(t(q[:Bt] + h * qd[:Bt] + 0.5 * h * h * ydd), t(qd[:Bt] + h * ydd), t(ydd)).cpu().numpy()
         Vm = plan.body_twists(t(q[:Bt] - h * qd[:Bt] + 0.5 * h * h * ydd), t(qd[:Bt] - h * ydd), t(ydd)).cpu().numpy()
