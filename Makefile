@@ -32,6 +32,10 @@ $(OBJ)/chain_kernels_u1.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CS
 $(OBJ)/chain_kernels_u2.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/gen_rnea_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -DGRBDA_CHAIN_UNIT=2 $(U2FLAGS) -c $< -o $@
+# fourth unit: the latency-mode kernel with four wavefronts per tile (its [K | y0] blocks are LDS objects: GRBDA_KLDS)
+$(OBJ)/chain_kernels_u3.o: $(CSRC)/chain_kernels.hip $(CSRC)/gen_segments.h $(CSRC)/gen_rnea_segments.h $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) -DGRBDA_CHAIN_UNIT=3 -c $< -o $@
 $(OBJ)/crba_kernels.o: $(CSRC)/crba_kernels.hip $(CSRC)/plan.h $(CSRC)/devplan.h $(CSRC)/devmath.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) -c $< -o $@
@@ -62,14 +66,14 @@ U1FLAGS ?=
 U2FLAGS ?=
 # (VFLAGS=-DGRBDA_EXP also compiles the ablation switches GRBDA_CHAIN_DEBUG / GRBDA_DEBUG_SWEEPS into the variant: the product
 # library ignores them)
-variant: $(OBJ)/chain_kernels_u2.o $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/plan.o $(OBJ)/urdf.o
+variant: $(OBJ)/chain_kernels_u2.o $(OBJ)/chain_kernels_u3.o $(OBJ)/kernels.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	@mkdir -p build/variants
 	$(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/capi.cpp -o build/variants/capi_$(VARIANT).o
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_$(VARIANT).o
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(VFLAGS) -DGRBDA_CHAIN_UNIT=1 $(U1FLAGS) -c $(CSRC)/chain_kernels.hip -o build/variants/chain_kernels_u1_$(VARIANT).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/libgrbda_hip_$(VARIANT).so build/variants/chain_kernels_$(VARIANT).o build/variants/chain_kernels_u1_$(VARIANT).o build/variants/capi_$(VARIANT).o $^
 
-$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
+$(LIB): $(OBJ)/kernels.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/chain_kernels_u3.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 oracle:
@@ -90,19 +94,19 @@ prof: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/ch
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/libgrbda_hip_prof.so build/prof/kernels.o $^
 
 # experiment builds: make exp NAME=foo DEFS="-DGRBDA_EXP_FOO" -> build/exp/libgrbda_foo.so
-exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o
+exp: $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/chain_kernels_u3.o $(OBJ)/crba_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/kernels.hip -o build/exp/kernels_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/kernels_$(NAME).o $^
 
 # experiment builds of the derivative kernels: make expd NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expd: $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expd: $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/chain_kernels_u3.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/deriv_kernels.hip -o build/exp/deriv_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/deriv_$(NAME).o $^
 
 # experiment builds of the chain kernels: make expc NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expc: $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/deriv_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expc: $(OBJ)/minv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/chain_kernels_u3.o $(OBJ)/deriv_kernels.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(CHAINFLAGS) $(DEFS) -c $(CSRC)/chain_kernels.hip -o build/exp/chain_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/chain_$(NAME).o $^
@@ -118,13 +122,13 @@ asan:
 .PHONY: asan
 
 # experiment builds of the manifold kernels: make expm NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expm: $(OBJ)/minv_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expm: $(OBJ)/minv_kernels.o $(OBJ)/deriv_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/chain_kernels_u3.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/manifold_kernels.hip -o build/exp/manifold_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/manifold_$(NAME).o $^
 
 # experiment builds of the minv kernels: make expv NAME=foo DEFS="-D..." -> build/exp/libgrbda_foo.so
-expv: $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
+expv: $(OBJ)/deriv_kernels.o $(OBJ)/manifold_kernels.o $(OBJ)/capi.o $(OBJ)/plan.o $(OBJ)/urdf.o $(OBJ)/chain_kernels.o $(OBJ)/chain_kernels_u1.o $(OBJ)/chain_kernels_u2.o $(OBJ)/chain_kernels_u3.o $(OBJ)/crba_kernels.o $(OBJ)/kernels.o
 	@mkdir -p build/exp
 	$(HIPCC) $(HIPFLAGS) $(KERNFLAGS) $(DEFS) -c $(CSRC)/minv_kernels.hip -o build/exp/minv_$(NAME).o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/exp/libgrbda_$(NAME).so build/exp/minv_$(NAME).o $^

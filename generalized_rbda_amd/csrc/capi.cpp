@@ -51,14 +51,15 @@ struct DeviceTables {
     float *consts32 = nullptr;
     // chain program of the f32 fast path (plan.h, ChainProgram)
     // [0] f32, two wavefronts per SIMD (HostPlan::chain32), [1] f32, four (chain32w), [2] f64 (chain64)
-    // chain programs: 0 f32, 1 f32 at four wavefronts per SIMD, 2 f64, 3 / 4 latency mode f32 / f64 (ChainProgram::n_waves = 2)
-    ChainSeg *chain_segs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainLink *chain_links[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainPair *chain_pairs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainFree *chain_frees[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainDiff *chain_diffs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainGen *chain_gens[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainGenBody *chain_gbodies[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // chain programs: 0 f32, 1 f32 at four wavefronts per SIMD, 2 f64, 3 / 4 latency mode f32 / f64 (ChainProgram::n_waves = 2),
+    // 5 latency mode f32 with four wavefronts per tile
+    ChainSeg *chain_segs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainLink *chain_links[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainPair *chain_pairs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainFree *chain_frees[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainDiff *chain_diffs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGen *chain_gens[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGenBody *chain_gbodies[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
@@ -140,6 +141,7 @@ struct grbda_plan {
     int gen1_tiles_per_wave = 0;   // GRBDA_GEN1_TILES_PER_WAVE > 0: grid = tiles / this (the dispatcher balances the workgroups)
     int gen1_waves_cap = 0;        // GRBDA_GEN1_WAVES_PER_CU > 0: wavefronts per CU of the single-cluster kernels (experiments)
     bool no_latency_mode = false;  // GRBDA_NO_LATENCY_MODE=1: small batches keep the one-wavefront-per-tile kernel
+    int lm_waves = 0;              // GRBDA_LM_WAVES=2: latency mode never takes four wavefronts per tile (A/B runs)
     int crba_waves = 16;       // GRBDA_CRBA_WAVES_PER_CU: grid of the composite-rigid-body kernel (fp32: 99 registers, four wavefronts per SIMD:
                                // JVRC-1 mass matrix 1.95 -> 1.81 ms per 262 144 states against eight per CU; fp64 is capped at eight)
     int deriv_waves = 0;       // GRBDA_DERIV_WAVES_PER_CU: grid of the inverse-dynamics derivative kernel (0: 3)
@@ -256,8 +258,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         ((e = up(h.deriv.minv.bodies.data(), h.deriv.minv.bodies.size() * sizeof(MinvBody), (void **)&t.minv_bodies)) != hipSuccess ||
          (e = up(h.deriv.minv.coltab.data(), h.deriv.minv.coltab.size() * sizeof(int32_t), (void **)&t.minv_coltab)) != hipSuccess))
         return hip_err(e, "plan upload");
-    for (int w = 0; w < 5; w++) {
-        const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : h.chain64p)));
+    for (int w = 0; w < 6; w++) {
+        const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : (w == 4 ? h.chain64p : h.chain32q))));
         if (!cp.ok) continue;
         if ((e = up(cp.segs.data(), cp.segs.size() * sizeof(ChainSeg), (void **)&t.chain_segs[w])) != hipSuccess ||
             (e = up(cp.links.data(), cp.links.size() * sizeof(ChainLink), (void **)&t.chain_links[w])) != hipSuccess ||
@@ -408,12 +410,12 @@ bool chain_covers(const grbda_plan *p)
 
 // which forward-dynamics kernel a batch of B states runs on a device with n_cu compute units: ONE definition, used by the launch
 // path below and by grbda_kernel_name (bench.py prints the name next to the roofline figures)
-enum AbaPath { ABA_GEN1, ABA_LM, ABA_CHAIN_WIDE, ABA_CHAIN, ABA_INTERPRETER };
+enum AbaPath { ABA_GEN1, ABA_LM, ABA_LM4, ABA_CHAIN_WIDE, ABA_CHAIN, ABA_INTERPRETER };
 template <class T>
-size_t lm_lds_bytes(const grbda_plan *p)
+size_t lm_lds_bytes(const grbda_plan *p, int n_waves = 2)
 {
     const HostPlan &h = p->host;
-    const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
+    const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : (n_waves == 4 ? h.chain32q : h.chain32p);
     const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
     const size_t lds_lm = static_cast<size_t>(lp.n_lds) * kWave * sizeof(T);
     return lds_lm < stage_all ? stage_all : lds_lm;
@@ -440,6 +442,10 @@ AbaPath choose_aba(const grbda_plan *p, int n_cu, size_t B, bool f_ext)
     const ChainProgram &sp = sizeof(T) == 8 ? h.chain64 : h.chain32;
     if (sp.ok && sp.single_gen && !p->chain_debug && gen1_lds_bytes<T>(p) <= 65536 && gen1_positions_fit(h.nq, sp.gens[0])) return ABA_GEN1;
     const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
+    // four wavefronts per tile while that still leaves at most two wavefronts per SIMD (two tiles per CU); GRBDA_LM_WAVES=2 keeps two
+    if (sizeof(T) == 4 && h.chain32q.ok && !p->no_latency_mode && !p->chain_debug && p->lm_waves != 2 && n_tiles > 0 &&
+        n_tiles <= static_cast<size_t>(n_cu) * 2 && lm_lds_bytes<T>(p, 4) <= 81920)
+        return ABA_LM4;
     if (lp.ok && !p->no_latency_mode && !p->chain_debug && n_tiles <= static_cast<size_t>(n_cu) * 4 && n_tiles > 0 && lm_lds_bytes<T>(p) <= 40960)
         return ABA_LM;
     const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && h.chain32w.gens.empty() && p->chain_wide &&
@@ -490,10 +496,11 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     // to a workgroup of two wavefronts that split its limbs (chain_kernels.hip, aba_chain_lm_kernel).  GRBDA_NO_LATENCY_MODE=1
     // keeps the ordinary kernel (A/B runs); results agree to rounding (the base sums one partial inertia per wavefront).
     {
-        const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
-        const size_t lds_lm = lm_lds_bytes<T>(p);
-        if (path == ABA_LM) {
-            const int w = sizeof(T) == 8 ? 4 : 3;
+        const int lm_waves = path == ABA_LM4 ? 4 : 2;
+        const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : (lm_waves == 4 ? h.chain32q : h.chain32p);
+        const size_t lds_lm = lm_lds_bytes<T>(p, lm_waves);
+        if (path == ABA_LM || path == ABA_LM4) {
+            const int w = sizeof(T) == 8 ? 4 : (lm_waves == 4 ? 5 : 3);
             ChainDev<T> d;
             d.bad_count = t.bad_count;
             d.segs = t.chain_segs[w];
@@ -510,7 +517,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.n_segs = static_cast<int>(lp.segs.size());
             d.nq = h.nq;
             d.nv = h.nv;
-            d.n_glb_slots = lp.n_glb + 1;  // (+ the row that carries wavefront 1's bad-pivot mask to wavefront 0, aba_chain_lm_kernel)
+            d.n_glb_slots = lp.n_glb + 1;  // (+ the row that carries the other wavefronts' bad-pivot masks to wavefront 0, aba_chain_lm_kernel)
             d.ori_repr = h.ori_repr;
             d.debug = 0;
             d.sv_global = 0;
@@ -523,7 +530,7 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             void *scratch = nullptr;
             if (int rc = ensure_scratch(p, device, stream, grid * n_rows * kWave * sizeof(T) + 256, &scratch)) return rc;
             hipError_t e = launch_aba_chain_lm<T>(d, q, qd, tau, ydd, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_lm,
-                                                  static_cast<hipStream_t>(stream));
+                                                  static_cast<hipStream_t>(stream), lm_waves);
             return e == hipSuccess ? GRBDA_OK : hip_err(e, "aba chain launch (latency mode)");
         }
     }
@@ -2003,7 +2010,8 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
                 std::snprintf(buf, sizeof buf, "grbda_hip::aba_gen1_kernel<%s, %d, %s, %d>", tn, cp.gens[0].n, cp.gens[0].kind ? "true" : "false",
                               gen1_waves_per_simd<T>(cp.gens[0].n));
                 return buf;
-            case ABA_LM: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s>", tn); return buf;
+            case ABA_LM: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 2>", tn); return buf;
+            case ABA_LM4: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 4>", tn); return buf;
             case ABA_CHAIN_WIDE: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, 0>", tn, kChainWideWps); return buf;
             case ABA_CHAIN:
                 std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, %d>", tn, (sizeof(T) == 8 && !cp.gens.empty()) ? 1 : 2,
@@ -2243,6 +2251,7 @@ int grbda_plan_from_blob(const void *blob, size_t bytes, grbda_plan **out)
     p->minv_wpc = env_int("GRBDA_MINV_WPC", 0);
     p->no_chain = env_int("GRBDA_NO_CHAIN", 0) != 0;
     p->no_latency_mode = env_int("GRBDA_NO_LATENCY_MODE", 0) != 0;
+    p->lm_waves = env_int("GRBDA_LM_WAVES", 0);
     p->gen1_waves_cap = env_int("GRBDA_GEN1_WAVES_PER_CU", 0);
     p->gen1_tiles_per_wave = env_int("GRBDA_GEN1_TILES_PER_WAVE", 0);
     p->chain_wide = env_int("GRBDA_CHAIN_WIDE", 0) != 0;
@@ -2360,7 +2369,7 @@ void grbda_plan_free(grbda_plan *p)
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.minv_bodies); (void)hipFree(t.minv_coltab);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
-        for (int w = 0; w < 5; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
+        for (int w = 0; w < 6; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work, &p->work_cvt, &p->work_proj})

@@ -20,9 +20,9 @@
 // (kernels.hip); the plan compiler decides (ChainProgram::ok).  The same file holds the inverse dynamics on the chains
 // (rnea_chain_kernel) and the force-propagation kernel of the contact side (osim_chain_kernel).
 //
-// Three translation units are built from this file (Makefile).  GRBDA_CHAIN_UNIT == 2 carries the kernels of programs with
+// Four translation units are built from this file (Makefile; unit 3: see GRBDA_KLDS below).  GRBDA_CHAIN_UNIT == 2 carries the kernels of programs with
 // generic clusters (gen_segments.h: aba_chain_kernel<T, 2, 2>), GRBDA_CHAIN_UNIT == 1 carries the two fp64 kernels with the deepest
-// register pressure -- aba_chain_lm_kernel<double> and aba_chain_kernel<double, 2, true> (the program with differentials); unit 0
+// register pressure -- aba_chain_lm_kernel<double, 2> and aba_chain_kernel<double, 2, true> (the program with differentials); unit 0
 // is everything else.  Both fp64 kernels spill, and how much depends on what else the compiler sees in the unit: measured in
 // one run against the single-unit build (tools/ab3.sh), Mini Cheetah fp64 at 65 536 states 0.0727 -> 0.0664 ms and TelloWithArms
 // fp64 3.60 -> 2.61 ms, every other kernel unchanged.  (Scheduler strategies were tried on top -- make variant
@@ -34,6 +34,10 @@
 #ifndef GRBDA_CHAIN_UNIT
 #define GRBDA_CHAIN_UNIT 0
 #endif
+// GRBDA_CHAIN_UNIT == 3 carries ONE kernel, aba_chain_lm_kernel<float, 4> (latency mode with four wavefronts per tile), whose "slab" blocks
+// [K | y0] are LDS objects (ChainMem::glb_ld / glb_st below): a unit of its own, so that the slot test exists in no other kernel's text (as a
+// member flag that every other kernel sets to false it still moved TelloWithArms' kernel to 68 bytes of scratch).
+#define GRBDA_KLDS (GRBDA_CHAIN_UNIT == 3)
 // Which code paths use the permutation-structured transforms of devmath.h (rzp_*).  The defaults are what the same-run A/B
 // (tools/ab3.sh, library variants of `make variant VFLAGS=-DGRBDA_PERM_...`) kept: links, general rotors and pairs of the fp32
 // forward dynamics (JVRC-1 1.234 -> 1.178 ms per 2^20 states, TelloWithArms 0.801 -> 0.789, MIT Humanoid unchanged at 0.1495 --
@@ -228,9 +232,17 @@ struct ChainMem {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rs, (int)lane_b + imm, (int)so, 0);
         }
     }
+    // GRBDA_KLDS (unit 3, aba_chain_lm_kernel<float, 4>): the program's "slab" blocks [K | y0] are LDS objects unless their slot number
+    // carries kSlotGlobal (ChainProgram::n_waves = 4, plan.cpp)
     template <int N>
     __device__ __forceinline__ void glb_ld(int s, T (&x)[N]) const
     {
+#if GRBDA_KLDS
+        if (!(s & kSlotGlobal)) {
+            lds_ld(s, x);
+            return;
+        }
+#endif
 #if GRBDA_SLAB_BUFFER
         const unsigned so = glb_b + (unsigned)((s & ~kSlotGlobal) * gmul) * kRowBytes;
 #pragma unroll
@@ -244,6 +256,12 @@ struct ChainMem {
     template <int N>
     __device__ __forceinline__ void glb_st(int s, const T (&x)[N]) const
     {
+#if GRBDA_KLDS
+        if (!(s & kSlotGlobal)) {
+            lds_st(s, x);
+            return;
+        }
+#endif
 #if GRBDA_SLAB_BUFFER
         const unsigned so = glb_b + (unsigned)((s & ~kSlotGlobal) * gmul) * kRowBytes;
 #pragma unroll
@@ -1687,12 +1705,19 @@ __device__ __forceinline__ void free_bwd(const ChainTables<T> &P, const ChainMem
         for (int j = 0; j < 21; j++) IA[j] = Ib[j] + acc[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) psi[j] += acc[21 + j];
-        if (f.lds_acc2 != -1) {  // latency-mode programs: what the second wavefront's limbs handed up
-            M.acc_ld(f.lds_acc2, acc);
+        if (f.lds_acc2 != -1) {  // latency-mode programs: what the other wavefronts' limbs handed up (dealt out in order: 2, 3, 4)
+            auto add = [&](int slot) {
+                M.acc_ld(slot, acc);
 #pragma unroll
-            for (int j = 0; j < 21; j++) IA[j] += acc[j];
+                for (int j = 0; j < 21; j++) IA[j] += acc[j];
 #pragma unroll
-            for (int j = 0; j < 6; j++) psi[j] += acc[21 + j];
+                for (int j = 0; j < 6; j++) psi[j] += acc[21 + j];
+            };
+            add(f.lds_acc2);
+            if (f.lds_acc3 != -1) {
+                add(f.lds_acc3);
+                if (f.lds_acc4 != -1) add(f.lds_acc4);
+            }
         }
     } else {
 #pragma unroll
@@ -2074,8 +2099,10 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
 // Same device functions and operations per state as aba_chain_kernel; the limbs' inertias reach the base as one partial sum per
 // wavefront, so results agree with it to rounding (tests/test_gpu_parity.py, test_latency_mode_matches_the_one_wavefront_kernel).
 // ---------------------------------------------------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// NW = 4 (fp32, batches of at most two tiles per CU -- where two wavefronts per tile leave every SIMD with one): the limbs go to four
+// wavefronts, the base keeps one accumulator per wavefront (ChainFree::lds_acc .. lds_acc4), q / qd / tau are staged by wavefronts 0 / 1 / 2.
+template <class T, int NW>
+__global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ tau,
                          T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
 {
@@ -2099,7 +2126,7 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     T *slab = scratch + (size_t)blockIdx.x * (size_t)(DP.n_glb_slots + P.nq + 2 * P.nv) * kWave;
     // (the LAST slab row -- the launch adds one to the program's rows -- carries wavefront 1's mask of bad pivots to wavefront 0: the
     // tile's 40 KiB of LDS are four workgroups per CU exactly, there is no word to spare)
-    unsigned long long &lm_bad = *reinterpret_cast<unsigned long long *>(slab + (size_t)(DP.n_glb_slots - 1 + P.nq + 2 * P.nv) * kWave);
+    unsigned long long *lm_bad = reinterpret_cast<unsigned long long *>(slab + (size_t)(DP.n_glb_slots - 1 + P.nq + 2 * P.nv) * kWave);
     ChainMem<T> M;
     M.bad = 0;
     M.lane = lane;
@@ -2125,15 +2152,21 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_lds_fence();
             stage_transpose(P.nq, 0u, slab, lane);
-        } else {
+        } else if (NW == 2) {
             stage_issue(qd, tile, rows_valid, P.nv, bq, lane);
             stage_issue(tau, tile, rows_valid, P.nv, bq + bv, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_lds_fence();
             stage_transpose(P.nv, bq, slab + (size_t)P.nq * kWave, lane);
             stage_transpose(P.nv, bq + bv, slab + (size_t)(P.nq + P.nv) * kWave, lane);
+        } else if (wave < 3) {  // wavefront 1: qd, wavefront 2: tau
+            const unsigned at = wave == 1 ? bq : bq + bv;
+            stage_issue(wave == 1 ? qd : tau, tile, rows_valid, P.nv, at, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            stage_transpose(P.nv, at, slab + (size_t)(wave == 1 ? P.nq : P.nq + P.nv) * kWave, lane);
         }
-        __syncthreads();  // (drains the slab stores of both wavefronts: the rows are visible to either)
+        __syncthreads();  // (drains the slab stores of every wavefront: the rows are visible to all)
         for (int s = 0; s < P.n_segs; s++) {
             const ChainSeg sg = load_rec(P.segs + s);
             if (sg.op == SEG_BARRIER) {
@@ -2157,13 +2190,14 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
-        // (a state with a bad pivot is counted once: wavefront 1 hands its mask to wavefront 0)
-        if (wave == 1 && lane == 0) lm_bad = M.bad;
+        // (a state with a bad pivot is counted once: the other wavefronts hand their masks to wavefront 0)
+        if (wave != 0 && lane == 0) lm_bad[wave - 1] = M.bad;
         __syncthreads();  // every result row is in the slab (or in LDS: ChainProgram::out_lds)
         if (wave == 0) {
             if (M.out_row >= 0) write_outputs_lds<T>(M.out_row, ydd, tile, rows_valid, P.nv, lane);
             else write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, ydd, tile, rows_valid, P.nv, lane);
-            M.bad |= lm_bad;
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) M.bad |= lm_bad[w2 - 1];
             M.flush_bad(DP.bad_count, rows_valid);
         } else {
             M.bad = 0;
@@ -2176,19 +2210,33 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     }
 }
 
+hipError_t launch_aba_chain_lm4(const ChainDev<float> &P, const float *q, const float *qd, const float *tau, float *ydd, size_t B, float *scratch,
+                                int grid, size_t lds_bytes, hipStream_t stream);
 template <class T>
 hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
-                               size_t lds_bytes, hipStream_t stream)
+                               size_t lds_bytes, hipStream_t stream, int n_waves)
 {
-    hipLaunchKernelGGL((aba_chain_lm_kernel<T>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    if constexpr (sizeof(T) == 4) {
+        if (n_waves == 4) return launch_aba_chain_lm4(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream);  // (unit 3)
+    }
+    if (n_waves != 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((aba_chain_lm_kernel<T, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
+#if GRBDA_CHAIN_UNIT == 3
+hipError_t launch_aba_chain_lm4(const ChainDev<float> &P, const float *q, const float *qd, const float *tau, float *ydd, size_t B, float *scratch,
+                                int grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((aba_chain_lm_kernel<float, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    return hipGetLastError();
+}
+#endif
 #if GRBDA_CHAIN_UNIT == 0
 template hipError_t launch_aba_chain_lm<float>(const ChainDev<float> &, const float *, const float *, const float *, float *, size_t,
-                                               float *, int, size_t, hipStream_t);
+                                               float *, int, size_t, hipStream_t, int);
 #elif GRBDA_CHAIN_UNIT == 1
 template hipError_t launch_aba_chain_lm<double>(const ChainDev<double> &, const double *, const double *, const double *, double *,
-                                                size_t, double *, int, size_t, hipStream_t);
+                                                size_t, double *, int, size_t, hipStream_t, int);
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2651,7 +2699,7 @@ hipError_t launch_aba_chain_diff_f64(const ChainDev<double> &P, const double *q,
     hipLaunchKernelGGL((aba_chain_kernel<double, 2, 1>), dim3(grid), dim3(kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
-#else
+#elif GRBDA_CHAIN_UNIT == 2
 template <class T>
 hipError_t launch_aba_chain_gen(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                                 size_t lds_bytes, hipStream_t stream)
@@ -3266,6 +3314,7 @@ static hipError_t set_max_dynamic_lds(const void *const *kernels, int n)
 }
 hipError_t set_max_dynamic_lds_chain_unit1();
 hipError_t set_max_dynamic_lds_chain_unit2();
+hipError_t set_max_dynamic_lds_chain_unit3();
 #if GRBDA_CHAIN_UNIT == 0
 hipError_t set_max_dynamic_lds_chain()
 {
@@ -3278,18 +3327,26 @@ hipError_t set_max_dynamic_lds_chain()
         reinterpret_cast<const void *>(&rnea_chain_kernel<float, 0, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, 1, true>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, 0, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, 1, true>),
         reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>),
-        reinterpret_cast<const void *>(&aba_chain_lm_kernel<float>)};
+        reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2>)};
     const hipError_t e = set_max_dynamic_lds(kernels, static_cast<int>(sizeof(kernels) / sizeof(kernels[0])));
     if (e != hipSuccess) return e;
     const hipError_t e1 = set_max_dynamic_lds_chain_unit1();
-    return e1 != hipSuccess ? e1 : set_max_dynamic_lds_chain_unit2();
+    if (e1 != hipSuccess) return e1;
+    const hipError_t e2 = set_max_dynamic_lds_chain_unit2();
+    return e2 != hipSuccess ? e2 : set_max_dynamic_lds_chain_unit3();
 }
 #elif GRBDA_CHAIN_UNIT == 1
 hipError_t set_max_dynamic_lds_chain_unit1()
 {
     const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_kernel<double, 2, 1>),
-                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<double>)};
+                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<double, 2>)};
     return set_max_dynamic_lds(kernels, 2);
+}
+#elif GRBDA_CHAIN_UNIT == 3
+hipError_t set_max_dynamic_lds_chain_unit3()
+{
+    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4>)};
+    return set_max_dynamic_lds(kernels, 1);
 }
 #else
 hipError_t set_max_dynamic_lds_chain_unit2()

@@ -113,10 +113,10 @@ struct ChainDev {
 template <class T>
 hipError_t launch_aba_chain(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                             size_t lds_bytes, hipStream_t stream, bool four_waves_per_simd);
-// latency mode: a tile per workgroup of two wavefronts (chain_kernels.hip, aba_chain_lm_kernel)
+// latency mode: a tile per workgroup of n_waves = 2 (or, fp32, 4) wavefronts (chain_kernels.hip, aba_chain_lm_kernel)
 template <class T>
 hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
-                               size_t lds_bytes, hipStream_t stream);
+                               size_t lds_bytes, hipStream_t stream, int n_waves);
 hipError_t set_max_dynamic_lds_chain();
 // single-cluster programs (ChainProgram::single_gen; chain_kernels.hip, aba_gen1_kernel): P.lds_bytes = the work area, lds_bytes = work
 // area + nq + 2 nv rows of staged inputs

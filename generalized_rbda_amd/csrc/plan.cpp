@@ -708,6 +708,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         // everything by the barriers) and the phase it lives in (0: forward / backward runs, 1: acceleration runs).  Limbs of
         // different wavefronts run concurrently inside a phase: their objects never share slots, whatever the segment order says.
         int owner = -1, phase = 0;
+        int span = 0;  // 1: alive in BOTH phases (the [K | y0] blocks of a limb: written by its backward run, read by its acceleration run)
     };
     // returns false when an object that must live in LDS does not fit the budget
     // mode 0: placement order (priority, birth); 1: longest-lived first; 2: largest first (allocate_packed below)
@@ -736,7 +737,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::vector<std::pair<int, int>> busy;
             for (int pi : placed) {
                 const Obj &p = objs[pi];
-                const bool concurrent = p.owner >= 0 && o.owner >= 0 && p.owner != o.owner && p.phase == o.phase;
+                const bool concurrent = p.owner >= 0 && o.owner >= 0 && p.owner != o.owner && (p.phase == o.phase || p.span || o.span);
                 if (!concurrent && (p.death < o.birth || o.death < p.birth)) continue;
                 const int off = global ? (p.slot & ~kSlotGlobal) : p.slot - lds_base;
                 busy.push_back({off, off + p.size});
@@ -1239,6 +1240,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::vector<Obj> objs;
             int n_glb = 0;
             auto glb = [&](int size) { const int at = n_glb; n_glb += size; return at | kSlotGlobal; };
+            // four wavefronts per tile (at most two tiles per CU, 80 KiB of LDS each): the [K | y0] blocks and the base's accumulators are LDS
+            // objects like everything else (what does not fit overflows to the slab): two such tiles per CU otherwise keep ~100 KB of slab
+            // each in flight, 6.5 MB per XCD against 4 MB of L2 (measured: MIT Humanoid, 512 tiles, 0.0388 -> 0.0332 ms with the
+            // accumulators alone)
+            const bool k_lds = n_waves == 4;
             for (int c = 0; c < nc; c++) {
                 const ClusterRec &cr = clusters[c];
                 if (cls[c] == 0) {
@@ -1246,8 +1252,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     f = ChainFree();
                     const BodyRec &br = bodies[cr.first_body];
                     f.q_index = cr.q_index; f.v_index = cr.v_index; f.cofs = br.cofs; f.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
-                    f.lds_v = f.lds_acc = f.lds_va = f.lds_acc2 = -1;
-                    f.glb_y0 = glb(33);  // [y0 6] (+ OSIM pass: Cholesky factor of the base's articulated inertia, L 21 + 1/diag 6)
+                    f.lds_v = f.lds_acc = f.lds_va = f.lds_acc2 = f.lds_acc3 = f.lds_acc4 = -1;
+                    f.glb_y0 = k_lds ? -1 : glb(33);  // [y0 6] (+ OSIM pass: Cholesky factor of the base's articulated inertia, L 21 + 1/diag 6)
                 } else if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) {
                     ChainLink &l = link_of[c];
                     l = ChainLink();
@@ -1258,7 +1264,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     l.iofs = br.xofs >= 0 ? br.xofs : br.cofs + 12;
                     l.has_child = br.has_child;
                     l.lds_sv = l.lds_pv = l.lds_va = -1;
-                    l.glb_k = glb(10);  // [K 6][y0][sin][cos] (+ OSIM pass: 1 / D)
+                    l.glb_k = k_lds ? -1 : glb(10);  // [K 6][y0][sin][cos] (+ OSIM pass: 1 / D)
                     l.perm = cyclic_shift(P.consts, br.cofs);
                     l.rperm = l.rofs >= 0 && l.rpre < 0 ? cyclic_shift(P.consts, l.rofs) : -1;
                     if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: cluster %d class %d perm %d rotor perm %d\n", c, cls[c], l.perm, l.rperm);
@@ -1360,7 +1366,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     g.has_fwd = kids_here ? 1 : 0;
                     gen_w_size[c] = w;
                 } else {
-                    pair_of[c].glb_k = glb(21);  // [K 12][y0 2] (+ OSIM pass: D^-1 (3), sin / cos of the two links (4))
+                    pair_of[c].glb_k = k_lds ? -1 : glb(21);  // [K 12][y0 2] (+ OSIM pass: D^-1 (3), sin / cos of the two links (4))
                     pair_of[c].rpre[0] = rotor_constants(pair_rotors[c][0]);
                     pair_of[c].rpre[1] = rotor_constants(pair_rotors[c][1]);
                     pair_of[c].lds_pv = pair_of[c].lds_pva = -1;
@@ -1492,7 +1498,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     if (cls[c] == 0) { n_free++; base = c; }
                 bool any_diff = false;
                 for (const Chain &ch : chains) any_diff = any_diff || ch.diff || ch.gen;
-                if (n_free != 1 || !ground_chains.empty() || any_diff || free_chains[base].size() < 2) {
+                if (n_free != 1 || !ground_chains.empty() || any_diff || static_cast<int>(free_chains[base].size()) < n_waves || n_waves > 4) {
                     ok = false;
                 } else {
                     std::function<int(int)> weight = [&](int id) {
@@ -1815,15 +1821,20 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 } else {
                     // one accumulator per wavefront, in the global slab (two read-modify-writes per limb; LDS is what limits
                     // how many tiles a CU holds in this mode)
-                    for (int o = 0; o < n_waves && o < 2; o++) {
+                    int32_t *const acc_of[4] = {&f.lds_acc, &f.lds_acc2, &f.lds_acc3, &f.lds_acc4};
+                    for (int o = 0; o < n_waves && o < 4; o++) {
                         int fb = 1 << 30;
                         for (int id : free_chains[c])
                             if (owner_of[id] == o) fb = std::min(fb, ct[id].bwd);
                         if (fb == 1 << 30) continue;
-                        objs.push_back({o == 0 ? &f.lds_acc : &f.lds_acc2, 27, 1, B0(fb) + 1, B0(t_free_bwd[c]), -1, 2});
+                        // (in LDS the accumulator is alive from the base's forward segment on: the limbs of the other wavefronts run
+                        // concurrently, whatever the order of the segments in the program says)
+                        const bool acc_lds = k_lds;
+                        objs.push_back({acc_of[o], 27, 1, acc_lds ? B0(t_free_fwd[c]) : B0(fb) + 1, B0(t_free_bwd[c]), -1, acc_lds ? 1 : 2});
                     }
                 }
                 objs.push_back({&f.lds_va, 12, 0, B0(t_free_acc[c]), D1(last_acc), -1, 1});
+                if (k_lds) objs.push_back({&f.glb_y0, 6, 2, B0(t_free_bwd[c]), D1(t_free_acc[c]), -1, 0});
             }
             int t_acc_phase = 1 << 30;  // first acceleration segment: objects born from there on live in phase 1
             for (int c = 0; c < nc; c++)
@@ -1878,6 +1889,16 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     continue;
                 }
                 for (int c : ch.cl) objs.push_back({&link_of[c].lds_sv, 8, 0, B0(ct[id].fwd), D1(ct[id].bwd), -1, 1});
+                if (k_lds) {
+                    for (int c : ch.cl) {
+                        objs.push_back({&link_of[c].glb_k, 7, 2, B0(ct[id].bwd), D1(ct[id].acc), -1, 0});
+                        objs.back().span = 1;
+                    }
+                    if (ch.pair >= 0) {
+                        objs.push_back({&pair_of[ch.pair].glb_k, 14, 2, B0(ct[id].bwd), D1(ct[id].pair_acc), -1, 0});
+                        objs.back().span = 1;
+                    }
+                }
                 const int tipc = ch.cl.back();
                 if (!ch.kid_chains.empty()) {
                     int first_bwd = 1 << 30, last_acc = ct[id].acc;
@@ -1958,7 +1979,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         }
                     }
                 }
-                if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: result rows at LDS row %d (nv %d, %d rows in use of %d)\n", CP.out_lds, P.nv, n_lds, lds_budget);
+                if (std::getenv("GRBDA_DEBUG_CHAIN")) std::fprintf(stderr, "chain: result rows at LDS row %d (nv %d, %d rows in use of %d; %d slab rows, %d wavefronts per tile)\n", CP.out_lds, P.nv, n_lds, lds_budget, n_glb, CP.n_waves);
                 CP.n_lds = n_lds;
                 CP.n_glb = n_glb;
                 // parent velocity / (v, a) slots
@@ -1981,7 +2002,9 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     const int c = m.bodies[b].cluster;
                     if (is_diff(c)) return diff_of[c].lds_acc;
                     if (cls[c] == 7) return gbody_of[c][b - clusters[c].first_body].lds_acc;
-                    return cls[c] == 0 ? (lm && owner == 1 ? free_of[c].lds_acc2 : free_of[c].lds_acc) : acc_slot[c];
+                    if (cls[c] != 0) return acc_slot[c];
+                    const ChainFree &f = free_of[c];
+                    return !lm || owner == 0 ? f.lds_acc : (owner == 1 ? f.lds_acc2 : (owner == 2 ? f.lds_acc3 : f.lds_acc4));
                 };
                 for (int c = 0; c < nc; c++) {
                     const int pb = clusters[c].parent_body;
@@ -2079,6 +2102,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     // latency mode serves batches of at most one tile per SIMD, i.e. four tiles per CU: 40 KiB of LDS per tile
     build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2);
     build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);
+    // four wavefronts per tile: batches of at most two tiles per CU (one wavefront per SIMD in the two-wavefront mode), 80 KiB each
+    build_chain(P.chain32q, 81920 / (4 * kWave), nullptr, 0, 4);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
     {

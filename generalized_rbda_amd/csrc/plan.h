@@ -323,7 +323,8 @@ struct ChainFree {      // 16 ints
     int32_t glb_y0;     // [y0 6]
     int32_t lds_va;     // acceleration sweep: own [v 6][a 6], -1 when no children
     int32_t lds_acc2;   // latency-mode programs: the accumulator the SECOND wavefront's limbs add into (-1: none)
-    int32_t reserved[7];
+    int32_t lds_acc3, lds_acc4;  // ... the third's and the fourth's (ChainProgram::n_waves = 4)
+    int32_t reserved[5];
 };
 
 // ---- inverse dynamics on the same chains (chain_kernels.hip, rnea_chain_kernel) ------------------------------------
@@ -387,8 +388,8 @@ struct ChainProgram {
     int n_lds = 0, n_glb = 0;        // slots
     int out_lds = -1;                // first of the nv LDS rows the acceleration sweep writes its results to (-1: slab rows)
     bool sv_global = false;          // the [sin, cos, v] blocks of the links live in the global slab (chains too long for LDS)
-    // Latency mode (n_waves = 2): a tile is run by a WORKGROUP of two wavefronts -- the limbs below the floating base are
-    // dealt to the two, the base's own segments run on wavefront 0, SEG_BARRIER segments order the hand-overs (base velocity
+    // Latency mode (n_waves = 2 or 4): a tile is run by a WORKGROUP of n_waves wavefronts -- the limbs below the floating base are
+    // dealt out to them, the base's own segments run on wavefront 0, SEG_BARRIER segments order the hand-overs (base velocity
     // -> limbs, limb accumulators -> base, base acceleration -> limbs).  For batches that do not fill the chip (fewer tiles
     // than SIMDs: BASELINE config 2) this halves the instruction stream a SIMD sees per tile.  LDS objects of limbs that run
     // on different wavefronts never share slots (separate pools); the base's accumulators live in the global slab.
@@ -504,6 +505,7 @@ struct HostPlan {
     ChainProgram chain32w;    // the same laid out for four wavefronts per SIMD (half the LDS per wavefront)
     ChainProgram chain64;     // f64 ABA (slots are twice as large: the LDS budget holds half as many)
     ChainProgram chain32p, chain64p;  // latency mode: two wavefronts per tile (ChainProgram::n_waves)
+    ChainProgram chain32q;            // latency mode, four wavefronts per tile (batches of at most two tiles per CU, fp32)
     CrbaProgram crba;
     DerivProgram deriv;
     RneaChainProgram rchain32, rchain64;  // inverse dynamics on the chains

@@ -1119,7 +1119,17 @@ def test_latency_mode_matches_the_one_wavefront_kernel(name, gpu, monkeypatch):
     plain = G.Plan(blob)
     monkeypatch.delenv("GRBDA_NO_LATENCY_MODE")
     assert plain.info().latency_mode_f32 == 0
-    for B in (1, 64, 65, 1000, 65536):
+    # fp32 batches of at most two tiles per CU take FOUR wavefronts per tile when the base carries four limbs or more (one accumulator per
+    # wavefront at the base); GRBDA_LM_WAVES=2 keeps two -- all three kernels are compared
+    monkeypatch.setenv("GRBDA_LM_WAVES", "2")
+    two = G.Plan(blob)
+    monkeypatch.delenv("GRBDA_LM_WAVES")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    if name.startswith("urdf_"):  # (four legs; two legs and two arms)
+        assert "lm_kernel<float, 4>" in plan.kernel_name("aba", "f32", 64 * 2 * n_cu)
+    assert "lm_kernel<float, 2>" in plan.kernel_name("aba", "f32", 64 * 2 * n_cu + 1)
+    assert "lm_kernel<float, 2>" in two.kernel_name("aba", "f32", 1000)
+    for B in (1, 64, 65, 1000, 64 * 2 * n_cu, 65536):
         q, qd, tau = random_states(blob, B, config_index=77)
         for dt in (torch.float32, torch.float64):
             if dt == torch.float64 and not info.latency_mode_f64:
@@ -1127,9 +1137,11 @@ def test_latency_mode_matches_the_one_wavefront_kernel(name, gpu, monkeypatch):
             t = lambda a: torch.as_tensor(a, dtype=dt, device=gpu)
             a = plan.forward_dynamics(t(q), t(qd), t(tau))
             b = plain.forward_dynamics(t(q), t(qd), t(tau))
+            c = two.forward_dynamics(t(q), t(qd), t(tau))
             torch.cuda.synchronize()
-            err = ((a - b).abs().amax(dim=1) / (1.0 + b.abs().amax(dim=1))).max().item()
-            assert err < (2e-5 if dt == torch.float32 else 1e-12), f"B={B} {dt}: {err:.2e}"
+            for x in (a, c):
+                err = ((x - b).abs().amax(dim=1) / (1.0 + b.abs().amax(dim=1))).max().item()
+                assert err < (2e-5 if dt == torch.float32 else 1e-12), f"B={B} {dt}: {err:.2e}"
     q, qd, tau = random_states(blob, 300, config_index=78)
     got = run_gpu(plan, "aba", q, qd, tau, torch.float64, gpu)
     assert rel_err(got, O.forward_dynamics(blob, q, qd, tau)) < TOL64

@@ -1,0 +1,28 @@
+"""Latency mode with four against two wavefronts per tile (GRBDA_LM_WAVES=2) against the one-wavefront kernel (GRBDA_NO_LATENCY_MODE=1):
+kernel ms of the fp32 forward dynamics at small batches.   usage: python tools/lm_waves_ab.py [model ...]"""
+import os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import generalized_rbda_amd as G
+from generalized_rbda_amd.states import random_states
+
+for model in (sys.argv[1:] or ["mit_humanoid", "mini_cheetah"]):
+    path = os.path.join(ROOT, "tests/golden/robot-models", model + ".urdf")
+    plans = {}
+    for label, env in (("four", {}), ("two", {"GRBDA_LM_WAVES": "2"}), ("one", {"GRBDA_NO_LATENCY_MODE": "1"})):
+        os.environ.update(env)
+        plans[label] = G.Plan.from_urdf(path)
+        for k in env:
+            del os.environ[k]
+    for B in (64, 4096, 8192, 16384, 24576, 32768):
+        q, qd, tau = random_states(plans["four"].blob, B, 2)
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda:0")
+        tq, tqd, tt = t(q), t(qd), t(tau)
+        out = torch.empty((B, plans["four"].nv), dtype=torch.float32, device="cuda:0")
+        row = []
+        for label, plan in plans.items():
+            plan.time_kernel("aba", tq, tqd, tt, out, iters=5)
+            ms = min(plan.time_kernel("aba", tq, tqd, tt, out, iters=30) for _ in range(3))
+            row.append(f"{label} {ms:.4f} ms ({plan.kernel_name('aba', 'f32', B).split('::')[-1]})")
+        print(f"{model:14s} B {B:6d} tiles {(B + 63) // 64:4d}  " + "  ".join(row), flush=True)
