@@ -34,9 +34,9 @@
 #ifndef GRBDA_CHAIN_UNIT
 #define GRBDA_CHAIN_UNIT 0
 #endif
-// GRBDA_CHAIN_UNIT == 3 carries ONE kernel, aba_chain_lm_kernel<float, 4> (latency mode with four wavefronts per tile), whose "slab" blocks
-// [K | y0] are LDS objects (ChainMem::glb_ld / glb_st below): a unit of its own, so that the slot test exists in no other kernel's text (as a
-// member flag that every other kernel sets to false it still moved TelloWithArms' kernel to 68 bytes of scratch).
+// GRBDA_CHAIN_UNIT == 3 carries the fp32 latency-mode kernels aba_chain_lm_kernel<float, 2 / 4>, whose "slab" blocks [K | y0] are LDS
+// objects (ChainMem::glb_ld / glb_st below): a unit of its own, so that the slot test exists in no other kernel's text (as a member flag
+// that every other kernel sets to false it still moved TelloWithArms' kernel to 68 bytes of scratch).
 #define GRBDA_KLDS (GRBDA_CHAIN_UNIT == 3)
 // Which code paths use the permutation-structured transforms of devmath.h (rzp_*).  The defaults are what the same-run A/B
 // (tools/ab3.sh, library variants of `make variant VFLAGS=-DGRBDA_PERM_...`) kept: links, general rotors and pairs of the fp32
@@ -232,8 +232,8 @@ struct ChainMem {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rs, (int)lane_b + imm, (int)so, 0);
         }
     }
-    // GRBDA_KLDS (unit 3, aba_chain_lm_kernel<float, 4>): the program's "slab" blocks [K | y0] are LDS objects unless their slot number
-    // carries kSlotGlobal (ChainProgram::n_waves = 4, plan.cpp)
+    // GRBDA_KLDS (unit 3, aba_chain_lm_kernel<float, NW>): the program's "slab" blocks [K | y0] are LDS objects unless their slot number
+    // carries kSlotGlobal (plan.cpp, build_chain's k_lds)
     template <int N>
     __device__ __forceinline__ void glb_ld(int s, T (&x)[N]) const
     {
@@ -2211,23 +2211,26 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
 }
 
 hipError_t launch_aba_chain_lm4(const ChainDev<float> &P, const float *q, const float *qd, const float *tau, float *ydd, size_t B, float *scratch,
-                                int grid, size_t lds_bytes, hipStream_t stream);
+                                int grid, size_t lds_bytes, hipStream_t stream, int n_waves);
 template <class T>
 hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                                size_t lds_bytes, hipStream_t stream, int n_waves)
 {
     if constexpr (sizeof(T) == 4) {
-        if (n_waves == 4) return launch_aba_chain_lm4(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream);  // (unit 3)
+        return launch_aba_chain_lm4(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream, n_waves);  // (unit 3)
+    } else {
+        if (n_waves != 2) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((aba_chain_lm_kernel<T, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+        return hipGetLastError();
     }
-    if (n_waves != 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((aba_chain_lm_kernel<T, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
-    return hipGetLastError();
 }
 #if GRBDA_CHAIN_UNIT == 3
 hipError_t launch_aba_chain_lm4(const ChainDev<float> &P, const float *q, const float *qd, const float *tau, float *ydd, size_t B, float *scratch,
-                                int grid, size_t lds_bytes, hipStream_t stream)
+                                int grid, size_t lds_bytes, hipStream_t stream, int n_waves)
 {
-    hipLaunchKernelGGL((aba_chain_lm_kernel<float, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    if (n_waves == 4) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    else if (n_waves == 2) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 #endif
@@ -3326,8 +3329,7 @@ hipError_t set_max_dynamic_lds_chain()
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, 0, false>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, 1, false>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<float, 0, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<float, 1, true>),
         reinterpret_cast<const void *>(&rnea_chain_kernel<double, 0, true>), reinterpret_cast<const void *>(&rnea_chain_kernel<double, 1, true>),
-        reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>),
-        reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2>)};
+        reinterpret_cast<const void *>(&osim_chain_kernel<float>), reinterpret_cast<const void *>(&osim_chain_kernel<double>)};
     const hipError_t e = set_max_dynamic_lds(kernels, static_cast<int>(sizeof(kernels) / sizeof(kernels[0])));
     if (e != hipSuccess) return e;
     const hipError_t e1 = set_max_dynamic_lds_chain_unit1();
@@ -3345,8 +3347,8 @@ hipError_t set_max_dynamic_lds_chain_unit1()
 #elif GRBDA_CHAIN_UNIT == 3
 hipError_t set_max_dynamic_lds_chain_unit3()
 {
-    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4>)};
-    return set_max_dynamic_lds(kernels, 1);
+    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4>)};
+    return set_max_dynamic_lds(kernels, 2);
 }
 #else
 hipError_t set_max_dynamic_lds_chain_unit2()

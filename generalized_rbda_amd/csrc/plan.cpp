@@ -718,6 +718,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         std::vector<int> order(objs.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = static_cast<int>(i);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            // (prio >= 10: extras that take what LDS the others leave, in every order -- the [K | y0] blocks of latency-mode programs)
+            const bool xa = objs[a].prio >= 10, xb = objs[b].prio >= 10;
+            if (xa != xb) return xb;
+            if (xa && objs[a].prio != objs[b].prio) return objs[a].prio < objs[b].prio;
             if (mode == 1) {
                 const int la = objs[a].death - objs[a].birth, lb = objs[b].death - objs[b].birth;
                 if (la != lb) return la > lb;
@@ -1109,7 +1113,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         diff_shape[c] = ds;
     }
 
-    auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget, int n_waves = 1) {
+    auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget, int n_waves = 1, bool k_lds = false) {
         CP = ChainProgram();
         CP.n_waves = n_waves;
         const bool lm = n_waves > 1;  // latency mode (plan.h, ChainProgram::n_waves)
@@ -1240,11 +1244,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             std::vector<Obj> objs;
             int n_glb = 0;
             auto glb = [&](int size) { const int at = n_glb; n_glb += size; return at | kSlotGlobal; };
-            // four wavefronts per tile (at most two tiles per CU, 80 KiB of LDS each): the [K | y0] blocks and the base's accumulators are LDS
-            // objects like everything else (what does not fit overflows to the slab): two such tiles per CU otherwise keep ~100 KB of slab
-            // each in flight, 6.5 MB per XCD against 4 MB of L2 (measured: MIT Humanoid, 512 tiles, 0.0388 -> 0.0332 ms with the
-            // accumulators alone)
-            const bool k_lds = n_waves == 4;
+            // k_lds (the fp32 latency-mode programs; their kernels are built with GRBDA_KLDS): the [K | y0] blocks and the base's accumulators
+            // are LDS objects like everything else, and what does not fit overflows to the slab.  Two four-wavefront tiles per CU otherwise keep
+            // ~100 KB of slab each in flight, 6.5 MB per XCD against 4 MB of L2 (measured: MIT Humanoid, 512 tiles, 0.0388 -> 0.0332 ms
+            // with the accumulators alone, 0.0297 with the blocks)
             for (int c = 0; c < nc; c++) {
                 const ClusterRec &cr = clusters[c];
                 if (cls[c] == 0) {
@@ -1830,11 +1833,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         // (in LDS the accumulator is alive from the base's forward segment on: the limbs of the other wavefronts run
                         // concurrently, whatever the order of the segments in the program says)
                         const bool acc_lds = k_lds;
-                        objs.push_back({acc_of[o], 27, 1, acc_lds ? B0(t_free_fwd[c]) : B0(fb) + 1, B0(t_free_bwd[c]), -1, acc_lds ? 1 : 2});
+                        objs.push_back({acc_of[o], 27, acc_lds ? 10 : 1, acc_lds ? B0(t_free_fwd[c]) : B0(fb) + 1, B0(t_free_bwd[c]), -1, acc_lds ? 0 : 2});
                     }
                 }
                 objs.push_back({&f.lds_va, 12, 0, B0(t_free_acc[c]), D1(last_acc), -1, 1});
-                if (k_lds) objs.push_back({&f.glb_y0, 6, 2, B0(t_free_bwd[c]), D1(t_free_acc[c]), -1, 0});
+                if (k_lds) objs.push_back({&f.glb_y0, 6, 11, B0(t_free_bwd[c]), D1(t_free_acc[c]), -1, 0});
             }
             int t_acc_phase = 1 << 30;  // first acceleration segment: objects born from there on live in phase 1
             for (int c = 0; c < nc; c++)
@@ -1891,11 +1894,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 for (int c : ch.cl) objs.push_back({&link_of[c].lds_sv, 8, 0, B0(ct[id].fwd), D1(ct[id].bwd), -1, 1});
                 if (k_lds) {
                     for (int c : ch.cl) {
-                        objs.push_back({&link_of[c].glb_k, 7, 2, B0(ct[id].bwd), D1(ct[id].acc), -1, 0});
+                        objs.push_back({&link_of[c].glb_k, 7, 11, B0(ct[id].bwd), D1(ct[id].acc), -1, 0});
                         objs.back().span = 1;
                     }
                     if (ch.pair >= 0) {
-                        objs.push_back({&pair_of[ch.pair].glb_k, 14, 2, B0(ct[id].bwd), D1(ct[id].pair_acc), -1, 0});
+                        objs.push_back({&pair_of[ch.pair].glb_k, 14, 11, B0(ct[id].bwd), D1(ct[id].pair_acc), -1, 0});
                         objs.back().span = 1;
                     }
                 }
@@ -2100,10 +2103,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         if (!P.rchain64.ok) build_chain(scratch_cp, 2 * lds.aba64, &P.rchain64, 2 * lds.aba64);
     }
     // latency mode serves batches of at most one tile per SIMD, i.e. four tiles per CU: 40 KiB of LDS per tile
-    build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2);
+    build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2, std::getenv("GRBDA_LM2_SLAB") == nullptr);  // (A/B switch: blocks in the slab)
     build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);
     // four wavefronts per tile: batches of at most two tiles per CU (one wavefront per SIMD in the two-wavefront mode), 80 KiB each
-    build_chain(P.chain32q, 81920 / (4 * kWave), nullptr, 0, 4);
+    build_chain(P.chain32q, 81920 / (4 * kWave), nullptr, 0, 4, true);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
     {

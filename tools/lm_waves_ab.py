@@ -10,12 +10,13 @@ from generalized_rbda_amd.states import random_states
 for model in (sys.argv[1:] or ["mit_humanoid", "mini_cheetah"]):
     path = os.path.join(ROOT, "tests/golden/robot-models", model + ".urdf")
     plans = {}
-    for label, env in (("four", {}), ("two", {"GRBDA_LM_WAVES": "2"}), ("one", {"GRBDA_NO_LATENCY_MODE": "1"})):
+    for label, env in (("four", {}), ("two", {"GRBDA_LM_WAVES": "2"}), ("two, blocks in the slab", {"GRBDA_LM_WAVES": "2", "GRBDA_LM2_SLAB": "1"}),
+                       ("one", {"GRBDA_NO_LATENCY_MODE": "1"})):
         os.environ.update(env)
         plans[label] = G.Plan.from_urdf(path)
         for k in env:
             del os.environ[k]
-    for B in (64, 4096, 8192, 16384, 24576, 32768):
+    for B in (64, 16384, 32768, 49152, 65536):
         q, qd, tau = random_states(plans["four"].blob, B, 2)
         t = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda:0")
         tq, tqd, tt = t(q), t(qd), t(tau)
@@ -24,5 +25,5 @@ for model in (sys.argv[1:] or ["mit_humanoid", "mini_cheetah"]):
         for label, plan in plans.items():
             plan.time_kernel("aba", tq, tqd, tt, out, iters=5)
             ms = min(plan.time_kernel("aba", tq, tqd, tt, out, iters=30) for _ in range(3))
-            row.append(f"{label} {ms:.4f} ms ({plan.kernel_name('aba', 'f32', B).split('::')[-1]})")
+            row.append(f"{label} {ms:.4f} ms ({plan.kernel_name('aba', 'f32', B).split('::')[-1].replace('aba_chain_', '')})")
         print(f"{model:14s} B {B:6d} tiles {(B + 63) // 64:4d}  " + "  ".join(row), flush=True)
