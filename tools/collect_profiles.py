@@ -39,6 +39,7 @@ if os.path.exists(fl):
 cp("traffic_calibration.txt", "traffic_calibration.txt")
 cp("bench/manifold_derivatives.txt", "manifold_derivatives.txt")
 cp("strong_scaling_proxy.txt", "strong_scaling_proxy.txt")
+cp("latency_mode_waves.txt", "latency_mode_waves_raw.txt")
 cp("gate_f32_oracle.txt", "gate_f32_oracle.txt")
 cp("stress_random_models.txt", "stress_random_models.txt")
 cp("tello_acc.txt", "tello_acc_f32_vs_float_oracle.txt")

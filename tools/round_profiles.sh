@@ -48,6 +48,7 @@ PY
 bash $ROOT/tools/pmc_derivs.sh $R/pmc_derivs > /dev/null 2>&1
 cd $ROOT
 python3 tools/strong_scaling_proxy.py > $OUT/strong_scaling_proxy.txt 2>/dev/null
+python3 tools/lm_waves_ab.py mit_humanoid mini_cheetah > $OUT/latency_mode_waves.txt 2>/dev/null
 python3 tools/gate_f32_oracle.py 1048576 > $OUT/gate_f32_oracle.txt 2>/dev/null
 python3 tools/stress_random_models.py 250 > $OUT/stress_random_models.txt 2>/dev/null
 python3 tools/tello_acc2.py generalized_rbda_amd/libgrbda_hip.so 2>/dev/null | tr "\n" " " > $OUT/tello_acc.txt
