@@ -54,6 +54,26 @@ def test_aba_and_rnea_fp64_match_oracle(name, blob, gpu):
         assert rel_err(got_t, ref_t) < TOL64, f"RNEA B={B}"
 
 
+@pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "urdf_jvrc1_humanoid", "tello_with_arms", "urdf_six_bar", "rev_rotor_chain_4"])
+def test_componentwise_parity_fp64(name, gpu):
+    """The other tests of this file measure a state's error norm-wise (rel_err: the largest component error against the largest component).
+    Here every COMPONENT of the forward / inverse dynamics is held against the oracle on its own: |a_i - b_i| <= 1e-9 (|b_i| + 1e-3 |b|_inf)
+    -- small accelerations next to large ones (a distal joint against the base) keep six digits of their own, not only of the state's norm.
+    fp64, 2 000 states per model (both chain kernels and latency mode: the batch is below one tile per SIMD); the floor 1e-3 |b|_inf is what
+    cancellation in a sum of terms of the state's scale leaves to a component that happens to be near zero."""
+    import torch
+
+    blob = zoo()[name]
+    plan = G.Plan(blob)
+    q, qd, tau = valid_states(blob, 2000, config_index=63)
+    for which, fn in (("aba", O.forward_dynamics), ("rnea", O.inverse_dynamics)):
+        ref = fn(blob, q, qd, tau)
+        got = run_gpu(plan, which, q, qd, tau, torch.float64, gpu)
+        bound = 1e-9 * (np.abs(ref) + 1e-3 * np.abs(ref).max(axis=1, keepdims=True))
+        worst = float((np.abs(got - ref) / bound).max())
+        assert worst < 1.0, f"{which}: worst component at {worst:.2f} of its bound"
+
+
 @pytest.mark.parametrize("name", ["urdf_mini_cheetah", "urdf_mit_humanoid", "tree_mixed_float", "urdf_jvrc1_humanoid"])
 @pytest.mark.parametrize("scale", [0.7, 1.3])
 def test_non_unit_quaternion_is_used_as_it_is(name, scale, gpu):
