@@ -507,8 +507,8 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
             d.links = t.chain_links[w];
             d.pairs = t.chain_pairs[w];
             d.frees = t.chain_frees[w];
-            d.diffs = nullptr;
-            d.n_diffs = 0;
+            d.diffs = lp.diffs.empty() ? nullptr : t.chain_diffs[w];  // (fp32 programs only: plan.cpp)
+            d.n_diffs = static_cast<int>(lp.diffs.size());
             d.gens = nullptr;
             d.gbodies = nullptr;
             d.n_gens = 0;
@@ -2010,8 +2010,12 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
                 std::snprintf(buf, sizeof buf, "grbda_hip::aba_gen1_kernel<%s, %d, %s, %d>", tn, cp.gens[0].n, cp.gens[0].kind ? "true" : "false",
                               gen1_waves_per_simd<T>(cp.gens[0].n));
                 return buf;
-            case ABA_LM: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 2>", tn); return buf;
-            case ABA_LM4: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 4>", tn); return buf;
+            case ABA_LM: {
+                const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
+                std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 2%s>", tn, lp.diffs.empty() ? "" : ", true");
+                return buf;
+            }
+            case ABA_LM4: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 4%s>", tn, h.chain32q.diffs.empty() ? "" : ", true"); return buf;
             case ABA_CHAIN_WIDE: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, 0>", tn, kChainWideWps); return buf;
             case ABA_CHAIN:
                 std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, %d>", tn, (sizeof(T) == 8 && !cp.gens.empty()) ? 1 : 2,

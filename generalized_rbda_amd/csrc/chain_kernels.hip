@@ -2101,7 +2101,8 @@ __global__ __launch_bounds__(kWave, WPS) void aba_chain_kernel(ChainDev<T> DP, c
 // ---------------------------------------------------------------------------------------------------------------
 // NW = 4 (fp32, batches of at most two tiles per CU -- where two wavefronts per tile leave every SIMD with one): the limbs go to four
 // wavefronts, the base keeps one accumulator per wavefront (ChainFree::lds_acc .. lds_acc4), q / qd / tau are staged by wavefronts 0 / 1 / 2.
-template <class T, int NW>
+// DIFF: the program has differential segments (TelloWithArms; fp32 only).
+template <class T, int NW, bool DIFF = false>
 __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ tau,
                          T *__restrict__ ydd, size_t B, T *__restrict__ scratch)
@@ -2111,10 +2112,10 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
     P.links = (cptr<ChainLink>)DP.links;
     P.pairs = (cptr<ChainPair>)DP.pairs;
     P.frees = (cptr<ChainFree>)DP.frees;
-    P.diffs = nullptr;
+    P.diffs = DIFF ? (cptr<ChainDiff>)DP.diffs : nullptr;
     P.gens = nullptr;
     P.gbodies = nullptr;
-    P.cints = nullptr;
+    P.cints = DIFF ? (cptr<int32_t>)DP.cints : nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -2187,6 +2188,15 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
                 case SEG_PAIR_ACC: pair_acc(P, M, load_rec(P.pairs + sg.first)); break;
                 case SEG_FREE_FWD: free_fwd(P, M, load_rec(P.frees + sg.first)); break;
                 case SEG_FREE_BWD: free_bwd<T, false>(P, M, load_rec(P.frees + sg.first)); break;
+                case SEG_DIFF_FWD:
+                    if constexpr (DIFF) diff_fwd(P, M, load_rec(P.diffs + sg.first));
+                    break;
+                case SEG_DIFF_BWD:
+                    if constexpr (DIFF) diff_bwd<T, false>(P, M, load_rec(P.diffs + sg.first));
+                    break;
+                case SEG_DIFF_ACC:
+                    if constexpr (DIFF) diff_acc(P, M, load_rec(P.diffs + sg.first));
+                    break;
                 default: free_acc(P, M, load_rec(P.frees + sg.first)); break;
             }
         }
@@ -2228,7 +2238,10 @@ hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, co
 hipError_t launch_aba_chain_lm4(const ChainDev<float> &P, const float *q, const float *qd, const float *tau, float *ydd, size_t B, float *scratch,
                                 int grid, size_t lds_bytes, hipStream_t stream, int n_waves)
 {
-    if (n_waves == 4) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    const bool diff = P.n_diffs > 0;
+    if (n_waves == 4 && diff) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 4, true>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    else if (n_waves == 4) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
+    else if (n_waves == 2 && diff) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 2, true>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     else if (n_waves == 2) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     else return hipErrorInvalidValue;
     return hipGetLastError();
@@ -3347,8 +3360,9 @@ hipError_t set_max_dynamic_lds_chain_unit1()
 #elif GRBDA_CHAIN_UNIT == 3
 hipError_t set_max_dynamic_lds_chain_unit3()
 {
-    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4>)};
-    return set_max_dynamic_lds(kernels, 2);
+    const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4>),
+                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2, true>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4, true>)};
+    return set_max_dynamic_lds(kernels, 4);
 }
 #else
 hipError_t set_max_dynamic_lds_chain_unit2()

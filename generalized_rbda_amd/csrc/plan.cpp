@@ -1494,18 +1494,18 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             ct.assign(chains.size(), SegTimes());
             owner_of.assign(chains.size(), 0);
             if (lm) {
-                // one floating base with at least two limbs, nothing on the ground, no differential segments (their work space
-                // and per-state G rows are not sized for concurrent limbs); the limbs are dealt to the wavefronts by link count
+                // one floating base with at least n_waves limbs, nothing on the ground, no generic segments; differential segments only in the
+                // programs whose kernels carry them (k_lds: the fp32 latency-mode kernels); the limbs are dealt to the wavefronts by link count
                 int n_free = 0, base = -1;
                 for (int c = 0; c < nc; c++)
                     if (cls[c] == 0) { n_free++; base = c; }
                 bool any_diff = false;
-                for (const Chain &ch : chains) any_diff = any_diff || ch.diff || ch.gen;
+                for (const Chain &ch : chains) any_diff = any_diff || (ch.diff && !k_lds) || ch.gen;
                 if (n_free != 1 || !ground_chains.empty() || any_diff || static_cast<int>(free_chains[base].size()) < n_waves || n_waves > 4) {
                     ok = false;
                 } else {
                     std::function<int(int)> weight = [&](int id) {
-                        int w = static_cast<int>(chains[id].cl.size()) + (chains[id].pair >= 0 ? 2 : 0);
+                        int w = chains[id].diff ? 4 : static_cast<int>(chains[id].cl.size()) + (chains[id].pair >= 0 ? 2 : 0);  // (a differential: two links, two rotors, the constraint)
                         for (int k : chains[id].kid_chains) w += weight(k);
                         return w;
                     };
@@ -2013,7 +2013,13 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     const int pb = clusters[c].parent_body;
                     if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) link_of[c].lds_pv = v_slot_of_body(pb);
                     if (cls[c] == 3) { pair_of[c].lds_pv = v_slot_of_body(pb); pair_of[c].lds_pva = va_slot_of_body(pb); }
-                    if (is_diff(c)) { diff_of[c].lds_pv = v_slot_of_body(pb); diff_of[c].lds_pva = va_slot_of_body(pb); diff_of[c].lds_acc_out = acc_slot_of_body(pb); }
+                    if (is_diff(c)) {
+                        // (a differential directly on the floating base of a latency-mode program adds into its wavefront's accumulator)
+                        int own = 0;
+                        for (size_t id2 = 0; id2 < chains.size(); id2++)
+                            if (chains[id2].diff && chains[id2].cl[0] == c) own = owner_of[id2];
+                        diff_of[c].lds_pv = v_slot_of_body(pb); diff_of[c].lds_pva = va_slot_of_body(pb); diff_of[c].lds_acc_out = acc_slot_of_body(pb, own);
+                    }
                     if (cls[c] == 7) {
                         ChainGen &g = gen_of[c];
                         g.lds_pv = v_slot_of_body(pb); g.lds_pva = va_slot_of_body(pb); g.lds_acc_out = acc_slot_of_body(pb);
