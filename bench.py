@@ -257,10 +257,14 @@ CONFIG_RECORDS = [
     (5, "jvrc1_humanoid", "fd_derivatives", "f64", 1048576),
     (5, "four_bar", "aba", "f32", 1048576),
     (5, "six_bar", "aba", "f32", 1048576),
+    # one GPU's share of an 8-way STRONG split of configs 3 and 4 (SURVEY 8e's 0.9 is about these batches): the step of a rank is its kernel on B / 8 states,
+    # so `split_efficiency` = t(B) / (8 t(B / 8)) with t(B) from this same line is what an 8-GPU node would show (tools/strong_scaling_proxy.py)
+    (3, "mit_humanoid", "aba", "f32", 32768, 8),
+    (4, "tello", "aba", "f32", 131072, 8),
 ]
 
 
-def config_records(G, dev, steps, sha, only=None):
+def config_records(G, dev, steps, sha, only=None, headline_kernel_ms=None):
     """one sub-record per CONFIG_RECORDS row: K launches bracketed by synchronize (median of 3 repetitions), the kernel's own
     duration from hipEvents (grbda_time_kernel), a strided sample against the oracle after the timed region"""
     import numpy as np
@@ -269,16 +273,21 @@ def config_records(G, dev, steps, sha, only=None):
     from generalized_rbda_amd.states import valid_random_states_device
 
     out_recs, cache = [], {}
-    for cfg_no, workload, algo, dtype_name, B in CONFIG_RECORDS:
+    for row in CONFIG_RECORDS:
+        cfg_no, workload, algo, dtype_name, B = row[:5]
+        split = row[5] if len(row) > 5 else None
         if only and workload not in only:
             continue
         rec = {"config": cfg_no, "workload": workload, "algo": algo, "dtype": dtype_name, "batch": B}
+        if split:
+            rec["split"] = split
         try:
             if workload not in cache:
                 cache.clear()  # (one workload's inputs at a time: a million-state batch in fp64 on the host is ~1 GB)
                 plan = load_plan(G, workload)
                 cache[workload] = (plan,) + tuple(valid_random_states_device(plan, B, WORKLOADS[workload][3], dev)[:3])
             plan, q, qd, x = cache[workload]
+            q, qd, x = q[:B], qd[:B], x[:B]  # (a split record takes the head of its workload's batch)
             tdt = torch.float32 if dtype_name == "f32" else torch.float64
             elem = 4 if dtype_name == "f32" else 8
             tq, tqd, tx = (torch.as_tensor(a, dtype=tdt, device=dev) for a in (q, qd, x))
@@ -338,6 +347,16 @@ def config_records(G, dev, steps, sha, only=None):
         except Exception as e:  # noqa: BLE001 -- a failing sub-record must not take the headline line with it
             rec.update({"error": f"{type(e).__name__}: {e}", "verified": False})
         out_recs.append(rec)
+    # the strong-split shares: efficiency of the N-way split from the kernel times of THIS run (the headline's for config 3)
+    for rec in out_recs:
+        if not rec.get("split") or "kernel_ms" not in rec:
+            continue
+        full = [r for r in out_recs if r is not rec and r.get("workload") == rec["workload"] and r.get("algo") == rec["algo"] and
+                r.get("dtype") == rec["dtype"] and r.get("batch") == rec["batch"] * rec["split"] and "kernel_ms" in r]
+        full_ms = full[0]["kernel_ms"] if full else (headline_kernel_ms if rec["workload"] == "mit_humanoid" and rec["algo"] == "aba" else None)
+        if full_ms:
+            rec["full_batch_kernel_ms"] = full_ms
+            rec["split_efficiency"] = full_ms / (rec["split"] * rec["kernel_ms"])
     return out_recs
 
 
@@ -719,7 +738,7 @@ def main():
     if world == 1 and dist is None and not args.no_configs and args.workload == "mit_humanoid" and args.algo == "aba":
         del tq, tqd, tx, out
         line["configs"] = config_records(G, dev, max(5, min(args.steps, 20)), sha,
-                                         only=set(args.configs.split(",")) if args.configs else None)
+                                         only=set(args.configs.split(",")) if args.configs else None, headline_kernel_ms=kernel_ms)
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(blob, q, qd, x)
     elif world == 1:

@@ -34,7 +34,7 @@ def test_bench_line_is_verified_and_carries_roofline_and_cpu_baseline(gpu):
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["single_thread"] > 0 and c["passes"] >= 5
     # every other BASELINE config rides in the same line as a compact sub-record
-    recs = {(x["workload"], x["algo"], x["dtype"]): x for x in line["configs"]}
+    recs = {(x["workload"], x["algo"], x["dtype"]): x for x in line["configs"] if not x.get("split")}
     for key in [("revolute_rotor_chain", "aba", "f64"), ("mini_cheetah", "aba", "f64"), ("mit_humanoid", "rnea", "f32"), ("tello", "aba", "f32"),
                 ("tello", "rnea", "f32"), ("jvrc1_humanoid", "aba", "f32"), ("jvrc1_humanoid", "fd_derivatives", "f32"),
                 ("jvrc1_humanoid", "fd_derivatives", "f64"), ("mit_humanoid", "fd_derivatives", "f32"), ("four_bar", "aba", "f32"),
@@ -43,6 +43,13 @@ def test_bench_line_is_verified_and_carries_roofline_and_cpu_baseline(gpu):
         assert "error" not in x, x
         assert x["verified"] is True and x["ms"] > 0 and x["evals_per_s"] > 0 and 0 < x["roofline"]["frac"] < 1, x
         assert x["kernel"]
+    # one GPU's share of the 8-way strong split of configs 3 and 4, with the efficiency that split would have
+    shares = {x["workload"]: x for x in line["configs"] if x.get("split") == 8}
+    assert set(shares) == {"mit_humanoid", "tello"}
+    for x in shares.values():
+        assert "error" not in x, x
+        assert x["verified"] is True and 0.2 < x["split_efficiency"] < 1.2 and x["batch"] * 8 in (262144, 1048576), x
+    assert "lm_kernel<float, 4" in shares["mit_humanoid"]["kernel"]
 
 
 def test_bench_multi_rank_path_on_one_rank(gpu):
