@@ -3177,7 +3177,11 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
         const size_t left = B - tile * kWave;
         const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
         stage_inputs(q, qd, ydd, tile, rows_valid, P.nq, P.nv, slab, lane, DP.lds_bytes);
+#ifdef GRBDA_EXP_RNEA_NO_SEGS  // (ablation build, results wrong: the tile's staging and epilogue alone -- profiles/r6_rnea_occupancy.txt)
+        for (int s = 0; s < 0; s++) {
+#else
         for (int s = 0; s < P.n_segs; s++) {
+#endif
             const RneaSeg sg = load_rec(P.segs + s);
             switch (sg.op) {
                 case RSEG_RUN_FWD: rnea_run_fwd<T, GLB>(P, M, sg); break;
