@@ -1,3 +1,5 @@
+"""TelloWithArms forward dynamics (fp32) in latency mode against the one-wavefront kernel: kernel ms by batch size (lm: the library's choice; two: GRBDA_LM_WAVES=2;
+one: GRBDA_NO_LATENCY_MODE=1).   usage: python tools/tello_lm.py"""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", ".")
 sys.path.insert(0, ROOT)
