@@ -52,14 +52,14 @@ struct DeviceTables {
     // chain program of the f32 fast path (plan.h, ChainProgram)
     // [0] f32, two wavefronts per SIMD (HostPlan::chain32), [1] f32, four (chain32w), [2] f64 (chain64)
     // chain programs: 0 f32, 1 f32 at four wavefronts per SIMD, 2 f64, 3 / 4 latency mode f32 / f64 (ChainProgram::n_waves = 2),
-    // 5 latency mode f32 with four wavefronts per tile
-    ChainSeg *chain_segs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainLink *chain_links[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainPair *chain_pairs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainFree *chain_frees[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainDiff *chain_diffs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainGen *chain_gens[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChainGenBody *chain_gbodies[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // 5 / 6 latency mode f32 / f64 with four wavefronts per tile
+    ChainSeg *chain_segs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainLink *chain_links[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainPair *chain_pairs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainFree *chain_frees[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainDiff *chain_diffs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGen *chain_gens[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGenBody *chain_gbodies[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     CrbaBody *crba_bodies = nullptr;
     DerivBody *deriv_bodies = nullptr;
     uint64_t *deriv_related = nullptr;  // DerivProgram::related
@@ -258,8 +258,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
         ((e = up(h.deriv.minv.bodies.data(), h.deriv.minv.bodies.size() * sizeof(MinvBody), (void **)&t.minv_bodies)) != hipSuccess ||
          (e = up(h.deriv.minv.coltab.data(), h.deriv.minv.coltab.size() * sizeof(int32_t), (void **)&t.minv_coltab)) != hipSuccess))
         return hip_err(e, "plan upload");
-    for (int w = 0; w < 6; w++) {
-        const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : (w == 4 ? h.chain64p : h.chain32q))));
+    for (int w = 0; w < 7; w++) {
+        const ChainProgram &cp = w == 0 ? h.chain32 : (w == 1 ? h.chain32w : (w == 2 ? h.chain64 : (w == 3 ? h.chain32p : (w == 4 ? h.chain64p : (w == 5 ? h.chain32q : h.chain64q)))));
         if (!cp.ok) continue;
         if ((e = up(cp.segs.data(), cp.segs.size() * sizeof(ChainSeg), (void **)&t.chain_segs[w])) != hipSuccess ||
             (e = up(cp.links.data(), cp.links.size() * sizeof(ChainLink), (void **)&t.chain_links[w])) != hipSuccess ||
@@ -415,7 +415,7 @@ template <class T>
 size_t lm_lds_bytes(const grbda_plan *p, int n_waves = 2)
 {
     const HostPlan &h = p->host;
-    const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : (n_waves == 4 ? h.chain32q : h.chain32p);
+    const ChainProgram &lp = n_waves == 4 ? (sizeof(T) == 8 ? h.chain64q : h.chain32q) : (sizeof(T) == 8 ? h.chain64p : h.chain32p);
     const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
     const size_t lds_lm = static_cast<size_t>(lp.n_lds) * kWave * sizeof(T);
     return lds_lm < stage_all ? stage_all : lds_lm;
@@ -443,7 +443,7 @@ AbaPath choose_aba(const grbda_plan *p, int n_cu, size_t B, bool f_ext)
     if (sp.ok && sp.single_gen && !p->chain_debug && gen1_lds_bytes<T>(p) <= 65536 && gen1_positions_fit(h.nq, sp.gens[0])) return ABA_GEN1;
     const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
     // four wavefronts per tile while that still leaves at most two wavefronts per SIMD (two tiles per CU); GRBDA_LM_WAVES=2 keeps two
-    if (sizeof(T) == 4 && h.chain32q.ok && !p->no_latency_mode && !p->chain_debug && p->lm_waves != 2 && n_tiles > 0 &&
+    if ((sizeof(T) == 8 ? h.chain64q.ok : h.chain32q.ok) && !p->no_latency_mode && !p->chain_debug && p->lm_waves != 2 && n_tiles > 0 &&
         n_tiles <= static_cast<size_t>(n_cu) * 2 && lm_lds_bytes<T>(p, 4) <= 81920)
         return ABA_LM4;
     if (lp.ok && !p->no_latency_mode && !p->chain_debug && n_tiles <= static_cast<size_t>(n_cu) * 4 && n_tiles > 0 && lm_lds_bytes<T>(p) <= 40960)
@@ -497,10 +497,10 @@ int run_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *q
     // keeps the ordinary kernel (A/B runs); results agree to rounding (the base sums one partial inertia per wavefront).
     {
         const int lm_waves = path == ABA_LM4 ? 4 : 2;
-        const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : (lm_waves == 4 ? h.chain32q : h.chain32p);
+        const ChainProgram &lp = lm_waves == 4 ? (sizeof(T) == 8 ? h.chain64q : h.chain32q) : (sizeof(T) == 8 ? h.chain64p : h.chain32p);
         const size_t lds_lm = lm_lds_bytes<T>(p, lm_waves);
         if (path == ABA_LM || path == ABA_LM4) {
-            const int w = sizeof(T) == 8 ? 4 : (lm_waves == 4 ? 5 : 3);
+            const int w = lm_waves == 4 ? (sizeof(T) == 8 ? 6 : 5) : (sizeof(T) == 8 ? 4 : 3);
             ChainDev<T> d;
             d.bad_count = t.bad_count;
             d.segs = t.chain_segs[w];
@@ -2015,7 +2015,9 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
                 std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 2%s>", tn, lp.diffs.empty() ? "" : ", true");
                 return buf;
             }
-            case ABA_LM4: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 4%s>", tn, h.chain32q.diffs.empty() ? "" : ", true"); return buf;
+            case ABA_LM4:
+                std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_lm_kernel<%s, 4%s>", tn, (sizeof(T) == 8 ? h.chain64q : h.chain32q).diffs.empty() ? "" : ", true");
+                return buf;
             case ABA_CHAIN_WIDE: std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, 0>", tn, kChainWideWps); return buf;
             case ABA_CHAIN:
                 std::snprintf(buf, sizeof buf, "grbda_hip::aba_chain_kernel<%s, %d, %d>", tn, (sizeof(T) == 8 && !cp.gens.empty()) ? 1 : 2,
@@ -2373,7 +2375,7 @@ void grbda_plan_free(grbda_plan *p)
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.minv_bodies); (void)hipFree(t.minv_coltab);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
         for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
-        for (int w = 0; w < 6; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
+        for (int w = 0; w < 7; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }
     for (auto *m : {&p->scratch, &p->work, &p->work_cvt, &p->work_proj})

@@ -34,7 +34,7 @@
 #ifndef GRBDA_CHAIN_UNIT
 #define GRBDA_CHAIN_UNIT 0
 #endif
-// GRBDA_CHAIN_UNIT == 3 carries the fp32 latency-mode kernels aba_chain_lm_kernel<float, 2 / 4>, whose "slab" blocks [K | y0] are LDS
+// GRBDA_CHAIN_UNIT == 3 carries the fp32 latency-mode kernels aba_chain_lm_kernel<float, 2 / 4> and the fp64 one with four wavefronts per tile, whose "slab" blocks [K | y0] are LDS
 // objects (ChainMem::glb_ld / glb_st below): a unit of its own, so that the slot test exists in no other kernel's text (as a member flag
 // that every other kernel sets to false it still moved TelloWithArms' kernel to 68 bytes of scratch).
 #define GRBDA_KLDS (GRBDA_CHAIN_UNIT == 3)
@@ -2222,6 +2222,8 @@ void aba_chain_lm_kernel(ChainDev<T> DP, const T *__restrict__ q, const T *__res
 
 hipError_t launch_aba_chain_lm4(const ChainDev<float> &P, const float *q, const float *qd, const float *tau, float *ydd, size_t B, float *scratch,
                                 int grid, size_t lds_bytes, hipStream_t stream, int n_waves);
+hipError_t launch_aba_chain_lm4_f64(const ChainDev<double> &P, const double *q, const double *qd, const double *tau, double *ydd, size_t B,
+                                    double *scratch, int grid, size_t lds_bytes, hipStream_t stream);
 template <class T>
 hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, const T *tau, T *ydd, size_t B, T *scratch, int grid,
                                size_t lds_bytes, hipStream_t stream, int n_waves)
@@ -2229,6 +2231,7 @@ hipError_t launch_aba_chain_lm(const ChainDev<T> &P, const T *q, const T *qd, co
     if constexpr (sizeof(T) == 4) {
         return launch_aba_chain_lm4(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream, n_waves);  // (unit 3)
     } else {
+        if (n_waves == 4) return launch_aba_chain_lm4_f64(P, q, qd, tau, ydd, B, scratch, grid, lds_bytes, stream);  // (unit 3: blocks in LDS)
         if (n_waves != 2) return hipErrorInvalidValue;
         hipLaunchKernelGGL((aba_chain_lm_kernel<T, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
         return hipGetLastError();
@@ -2244,6 +2247,12 @@ hipError_t launch_aba_chain_lm4(const ChainDev<float> &P, const float *q, const 
     else if (n_waves == 2 && diff) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 2, true>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     else if (n_waves == 2) hipLaunchKernelGGL((aba_chain_lm_kernel<float, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_aba_chain_lm4_f64(const ChainDev<double> &P, const double *q, const double *qd, const double *tau, double *ydd, size_t B,
+                                    double *scratch, int grid, size_t lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL((aba_chain_lm_kernel<double, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, tau, ydd, B, scratch);
     return hipGetLastError();
 }
 #endif
@@ -3365,8 +3374,9 @@ hipError_t set_max_dynamic_lds_chain_unit1()
 hipError_t set_max_dynamic_lds_chain_unit3()
 {
     const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4>),
-                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2, true>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4, true>)};
-    return set_max_dynamic_lds(kernels, 4);
+                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2, true>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4, true>),
+                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<double, 4>)};
+    return set_max_dynamic_lds(kernels, 5);
 }
 #else
 hipError_t set_max_dynamic_lds_chain_unit2()

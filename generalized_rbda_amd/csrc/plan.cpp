@@ -2113,6 +2113,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
     build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);
     // four wavefronts per tile: batches of at most two tiles per CU (one wavefront per SIMD in the two-wavefront mode), 80 KiB each
     build_chain(P.chain32q, 81920 / (4 * kWave), nullptr, 0, 4, true);
+    build_chain(P.chain64q, 81920 / (8 * kWave), nullptr, 0, 4, true);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
     {

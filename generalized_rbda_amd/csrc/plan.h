@@ -505,7 +505,7 @@ struct HostPlan {
     ChainProgram chain32w;    // the same laid out for four wavefronts per SIMD (half the LDS per wavefront)
     ChainProgram chain64;     // f64 ABA (slots are twice as large: the LDS budget holds half as many)
     ChainProgram chain32p, chain64p;  // latency mode: two wavefronts per tile (ChainProgram::n_waves)
-    ChainProgram chain32q;            // latency mode, four wavefronts per tile (batches of at most two tiles per CU, fp32)
+    ChainProgram chain32q, chain64q;  // latency mode, four wavefronts per tile (batches of at most two tiles per CU)
     CrbaProgram crba;
     DerivProgram deriv;
     RneaChainProgram rchain32, rchain64;  // inverse dynamics on the chains
