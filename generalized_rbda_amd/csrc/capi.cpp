@@ -443,10 +443,13 @@ AbaPath choose_aba(const grbda_plan *p, int n_cu, size_t B, bool f_ext)
     if (sp.ok && sp.single_gen && !p->chain_debug && gen1_lds_bytes<T>(p) <= 65536 && gen1_positions_fit(h.nq, sp.gens[0])) return ABA_GEN1;
     const ChainProgram &lp = sizeof(T) == 8 ? h.chain64p : h.chain32p;
     // four wavefronts per tile while that still leaves at most two wavefronts per SIMD (two tiles per CU); GRBDA_LM_WAVES=2 keeps two
-    if ((sizeof(T) == 8 ? h.chain64q.ok : h.chain32q.ok) && !p->no_latency_mode && !p->chain_debug && p->lm_waves != 2 && n_tiles > 0 &&
+    // (only the fp32 latency-mode kernels carry the differential segments: plan.cpp builds no fp64 program with them)
+    const ChainProgram &lq = sizeof(T) == 8 ? h.chain64q : h.chain32q;
+    if (lq.ok && (sizeof(T) == 4 || lq.diffs.empty()) && !p->no_latency_mode && !p->chain_debug && p->lm_waves != 2 && n_tiles > 0 &&
         n_tiles <= static_cast<size_t>(n_cu) * 2 && lm_lds_bytes<T>(p, 4) <= 81920)
         return ABA_LM4;
-    if (lp.ok && !p->no_latency_mode && !p->chain_debug && n_tiles <= static_cast<size_t>(n_cu) * 4 && n_tiles > 0 && lm_lds_bytes<T>(p) <= 40960)
+    if (lp.ok && (sizeof(T) == 4 || lp.diffs.empty()) && !p->no_latency_mode && !p->chain_debug && n_tiles <= static_cast<size_t>(n_cu) * 4 && n_tiles > 0 &&
+        lm_lds_bytes<T>(p) <= 40960)
         return ABA_LM;
     const bool wide = sizeof(T) == 4 && h.chain32w.ok && h.chain32w.diffs.empty() && h.chain32w.gens.empty() && p->chain_wide &&
                       (!h.chain32.ok || n_tiles > static_cast<size_t>(n_cu) * 8);

@@ -1113,7 +1113,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         diff_shape[c] = ds;
     }
 
-    auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget, int n_waves = 1, bool k_lds = false) {
+    auto build_chain = [&](ChainProgram &CP, int lds_budget, RneaChainProgram *RP, int rnea_budget, int n_waves = 1, bool k_lds = false, bool lm_diffs = false) {
         CP = ChainProgram();
         CP.n_waves = n_waves;
         const bool lm = n_waves > 1;  // latency mode (plan.h, ChainProgram::n_waves)
@@ -1495,12 +1495,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
             owner_of.assign(chains.size(), 0);
             if (lm) {
                 // one floating base with at least n_waves limbs, nothing on the ground, no generic segments; differential segments only in the
-                // programs whose kernels carry them (k_lds: the fp32 latency-mode kernels); the limbs are dealt to the wavefronts by link count
+                // programs whose kernels carry them (lm_diffs: the fp32 latency-mode kernels); the limbs are dealt to the wavefronts by link count
                 int n_free = 0, base = -1;
                 for (int c = 0; c < nc; c++)
                     if (cls[c] == 0) { n_free++; base = c; }
                 bool any_diff = false;
-                for (const Chain &ch : chains) any_diff = any_diff || (ch.diff && !k_lds) || ch.gen;
+                for (const Chain &ch : chains) any_diff = any_diff || (ch.diff && !lm_diffs) || ch.gen;
                 if (n_free != 1 || !ground_chains.empty() || any_diff || static_cast<int>(free_chains[base].size()) < n_waves || n_waves > 4) {
                     ok = false;
                 } else {
@@ -2109,10 +2109,10 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         if (!P.rchain64.ok) build_chain(scratch_cp, 2 * lds.aba64, &P.rchain64, 2 * lds.aba64);
     }
     // latency mode serves batches of at most one tile per SIMD, i.e. four tiles per CU: 40 KiB of LDS per tile
-    build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2, std::getenv("GRBDA_LM2_SLAB") == nullptr);  // (A/B switch: blocks in the slab)
+    build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2, std::getenv("GRBDA_LM2_SLAB") == nullptr, true);  // (A/B switch: blocks in the slab)
     build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);
     // four wavefronts per tile: batches of at most two tiles per CU (one wavefront per SIMD in the two-wavefront mode), 80 KiB each
-    build_chain(P.chain32q, 81920 / (4 * kWave), nullptr, 0, 4, true);
+    build_chain(P.chain32q, 81920 / (4 * kWave), nullptr, 0, 4, true, true);
     build_chain(P.chain64q, 81920 / (8 * kWave), nullptr, 0, 4, true);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
