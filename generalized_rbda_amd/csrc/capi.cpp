@@ -67,14 +67,15 @@ struct DeviceTables {
     int32_t *minv_coltab = nullptr;     // ... and the column programs of minv_mfma_kernel
     int32_t *related_table = nullptr;   // HostPlan::related_table (plans of the wide route with more than 64 velocities)
     int32_t *span_q = nullptr, *span_v = nullptr, *crow = nullptr;  // grbda_plan::span_q / span_v / crow
-    // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w)
-    RneaSeg *rchain_segs[3] = {nullptr, nullptr, nullptr};
-    RneaLink *rchain_links[3] = {nullptr, nullptr, nullptr};
-    RneaPair *rchain_pairs[3] = {nullptr, nullptr, nullptr};
-    RneaFree *rchain_frees[3] = {nullptr, nullptr, nullptr};
-    RneaDiff *rchain_diffs[3] = {nullptr, nullptr, nullptr};
-    ChainGen *rchain_gens[3] = {nullptr, nullptr, nullptr};
-    ChainGenBody *rchain_gbodies[3] = {nullptr, nullptr, nullptr};
+    // inverse dynamics on the chains: [0] f32 (HostPlan::rchain32), [1] f64, [2] f32 at four wavefronts per SIMD (rchain32w),
+    // [3] / [4] latency mode f32 / f64 with two wavefronts per tile (rchain32p / rchain64p), [5] / [6] with four (rchain32q / rchain64q)
+    RneaSeg *rchain_segs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    RneaLink *rchain_links[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    RneaPair *rchain_pairs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    RneaFree *rchain_frees[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    RneaDiff *rchain_diffs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGen *rchain_gens[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ChainGenBody *rchain_gbodies[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cu = 0;
     unsigned long long *bad_count = nullptr;  // this device's counter of states with a pivot that is not positive (deriv_kernels.hip)
 };
@@ -229,8 +230,8 @@ int ensure_device(const grbda_plan *p, int device, DeviceTables **out)
             (e = up(L.acc_k.data(), L.acc_k.size() * sizeof(int32_t), (void **)&t.acc_k[w])) != hipSuccess)
             return hip_err(e, "plan upload");
     }
-    for (int w = 0; w < 3; w++) {
-        const RneaChainProgram &rp = w == 0 ? h.rchain32 : (w == 1 ? h.rchain64 : h.rchain32w);
+    for (int w = 0; w < 7; w++) {
+        const RneaChainProgram &rp = w == 0 ? h.rchain32 : (w == 1 ? h.rchain64 : (w == 2 ? h.rchain32w : (w == 3 ? h.rchain32p : (w == 4 ? h.rchain64p : (w == 5 ? h.rchain32q : h.rchain64q)))));
         if (!rp.ok) continue;
         if ((e = up(rp.segs.data(), rp.segs.size() * sizeof(RneaSeg), (void **)&t.rchain_segs[w])) != hipSuccess ||
             (e = up(rp.links.data(), rp.links.size() * sizeof(RneaLink), (void **)&t.rchain_links[w])) != hipSuccess ||
@@ -620,6 +621,25 @@ bool rnea_gen1_usable(const grbda_plan *p)
     return rp.ok && rp.single_gen && !p->chain_debug && rnea_gen1_lds_bytes<T>(p) <= 65536 && gen1_positions_fit(p->host.nq, rp.gens[0]);
 }
 
+// latency mode of the inverse dynamics: wavefronts per tile for a batch of B states (0: the one-wavefront kernels); ONE definition, used by the launch path
+// and by grbda_kernel_name
+template <class T>
+int choose_rnea_lm(const grbda_plan *p, int n_cu, size_t B)
+{
+    const HostPlan &h = p->host;
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    if (p->no_latency_mode || p->no_chain || n_tiles == 0) return 0;
+    const bool kid = sizeof(T) == 8;
+    const RneaChainProgram &r4 = kid ? h.rchain64q : h.rchain32q, &r2 = kid ? h.rchain64p : h.rchain32p;
+    const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
+    if (r4.ok && r4.n_waves == 4 && p->lm_waves != 2 && n_tiles <= static_cast<size_t>(n_cu) * 2 &&
+        std::max(static_cast<size_t>(r4.n_lds) * kWave * sizeof(T), stage_all) <= 81920)
+        return 4;
+    if (r2.ok && r2.n_waves == 2 && n_tiles <= static_cast<size_t>(n_cu) * 4 && std::max(static_cast<size_t>(r2.n_lds) * kWave * sizeof(T), stage_all) <= 40960)
+        return 2;
+    return 0;
+}
+
 template <class T>
 int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const T *qd, const T *ydd, T *tau, size_t B, int device,
                    void *stream)
@@ -635,6 +655,38 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
                       n_tiles > static_cast<size_t>(t.n_cu) * 8;
     const int w = wide ? 2 : kid;
     const RneaChainProgram &rp = wide ? h.rchain32w : (kid ? h.rchain64 : h.rchain32);
+    // Latency mode (as the forward dynamics': batches of at most one tile per SIMD go to workgroups of two wavefronts per tile, of at most two tiles per CU to
+    // workgroups of four when the base carries four limbs; chain_kernels.hip, rnea_chain_lm_kernel).  GRBDA_NO_LATENCY_MODE=1 / GRBDA_LM_WAVES=2 as there.
+    {
+        const RneaChainProgram &r4 = kid ? h.rchain64q : h.rchain32q, &r2 = kid ? h.rchain64p : h.rchain32p;
+        const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
+        const int lm_waves = choose_rnea_lm<T>(p, t.n_cu, B);
+        const bool use4 = lm_waves == 4, use2 = lm_waves == 2;
+        if (use4 || use2) {
+            const RneaChainProgram &lp = use4 ? r4 : r2;
+            const int wi = use4 ? (kid ? 6 : 5) : (kid ? 4 : 3);
+            RneaChainDev<T> d;
+            std::memset(&d, 0, sizeof d);
+            d.segs = t.rchain_segs[wi];
+            d.links = t.rchain_links[wi];
+            d.pairs = t.rchain_pairs[wi];
+            d.frees = t.rchain_frees[wi];
+            d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
+            d.n_segs = static_cast<int>(lp.segs.size());
+            d.nq = h.nq;
+            d.nv = h.nv;
+            d.ori_repr = h.ori_repr;
+            for (int i = 0; i < 6; i++) d.a_root[i] = static_cast<T>(-h.gravity[i]);
+            const size_t lds_bytes = std::max(static_cast<size_t>(lp.n_lds) * kWave * sizeof(T), stage_all);
+            d.lds_bytes = static_cast<int>(lds_bytes);
+            const size_t grid = n_tiles;  // (all resident)
+            void *scratch = nullptr;
+            if (int rc = ensure_scratch(p, device, stream, grid * static_cast<size_t>(h.nq + 2 * h.nv) * kWave * sizeof(T) + 256, &scratch)) return rc;
+            hipError_t e = launch_rnea_chain_lm<T>(d, q, qd, ydd, tau, B, static_cast<T *>(scratch), static_cast<int>(grid), lds_bytes,
+                                                   static_cast<hipStream_t>(stream), use4 ? 4 : 2);
+            return e == hipSuccess ? GRBDA_OK : hip_err(e, "rnea chain launch (latency mode)");
+        }
+    }
     if (rnea_gen1_usable<T>(p)) {  // single-cluster programs: the fused, slab-free kernel (chain_kernels.hip, rnea_gen1_kernel)
         RneaChainDev<T> d;
         std::memset(&d, 0, sizeof d);
@@ -2041,6 +2093,10 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
                           rnea_gen1_waves_per_simd<T>(rp.gens[0].n));
             return buf;
         }
+        if (const int lmw = choose_rnea_lm<T>(p, n_cu, B)) {
+            std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_lm_kernel<%s, %d>", tn, lmw);
+            return buf;
+        }
         std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_kernel<%s, %d, %s>", tn, !rp.gens.empty() ? 2 : (rp.diffs.empty() ? 0 : 1), rp.n_glb > 0 ? "true" : "false");
         return buf;
     }
@@ -2377,7 +2433,7 @@ void grbda_plan_free(grbda_plan *p)
         (void)hipFree(t.aba_steps); (void)hipFree(t.rnea_steps); (void)hipFree(t.consts64); (void)hipFree(t.consts32);
         (void)hipFree(t.cints); (void)hipFree(t.dq_map); (void)hipFree(t.crba_bodies); (void)hipFree(t.deriv_bodies); (void)hipFree(t.deriv_related); (void)hipFree(t.related_table); (void)hipFree(t.minv_bodies); (void)hipFree(t.minv_coltab);
         (void)hipFree(t.span_q); (void)hipFree(t.span_v); (void)hipFree(t.crow);
-        for (int w = 0; w < 3; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
+        for (int w = 0; w < 7; w++) { (void)hipFree(t.rchain_segs[w]); (void)hipFree(t.rchain_links[w]); (void)hipFree(t.rchain_pairs[w]); (void)hipFree(t.rchain_frees[w]); (void)hipFree(t.rchain_diffs[w]); (void)hipFree(t.rchain_gens[w]); (void)hipFree(t.rchain_gbodies[w]); }
         for (int w = 0; w < 7; w++) { (void)hipFree(t.chain_segs[w]); (void)hipFree(t.chain_links[w]); (void)hipFree(t.chain_pairs[w]); (void)hipFree(t.chain_frees[w]); (void)hipFree(t.chain_diffs[w]); (void)hipFree(t.chain_gens[w]); (void)hipFree(t.chain_gbodies[w]); }
         for (int w = 0; w < kLayouts; w++) { (void)hipFree(t.acc_k[w]); (void)hipFree(t.clusters[w]); (void)hipFree(t.rnea_clusters[w]); (void)hipFree(t.bodies[w]); (void)hipFree(t.rnea_bodies[w]); }
     }

@@ -3216,6 +3216,141 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
     }
 }
 
+#if GRBDA_CHAIN_UNIT == 3
+// ---------------------------------------------------------------------------------------------------------------
+// Latency mode of the inverse dynamics (plan.h, RneaChainProgram::n_waves = 2 or 4): as aba_chain_lm_kernel, a tile of 64 states on a workgroup of NW
+// wavefronts.  The base's forward segment runs on wavefront 0, a barrier, the limbs on their wavefronts (RneaSeg::owner; every wavefront adds its limbs'
+// forces into a block of its own, RneaFree::lds_f .. lds_f4), a barrier, the base's backward segment on wavefront 0.  Links and leaf pairs; every block
+// in LDS (40 / 80 KiB per tile).  Same device functions and operations per state as rnea_chain_kernel; the limbs' forces reach the base as one partial sum
+// per wavefront.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T, int NW>
+__global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void rnea_chain_lm_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
+                          T *__restrict__ scratch)
+{
+    RneaTables<T> P;
+    P.segs = (cptr<RneaSeg>)DP.segs;
+    P.links = (cptr<RneaLink>)DP.links;
+    P.pairs = (cptr<RneaPair>)DP.pairs;
+    P.frees = (cptr<RneaFree>)DP.frees;
+    P.diffs = nullptr;
+    P.gens = nullptr;
+    P.gbodies = nullptr;
+    P.cints = nullptr;
+    P.consts = (cptr<T>)DP.consts;
+    P.n_segs = DP.n_segs;
+    P.nq = DP.nq;
+    P.nv = DP.nv;
+    P.ori_repr = DP.ori_repr;
+#pragma unroll
+    for (int i = 0; i < 6; i++) P.a_root[i] = DP.a_root[i];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    T *slab = scratch + (size_t)blockIdx.x * (size_t)(P.nq + 2 * P.nv) * kWave;
+    ChainMem<T> M;
+    M.bad = 0;
+    M.lane = lane;
+    M.lane_b = (unsigned)lane * (unsigned)sizeof(T);
+    M.gmul = 1;
+    M.amask = ~0;
+    M.glb_u = slab + (size_t)(P.nq + 2 * P.nv) * kWave;
+    M.in_q_u = slab;
+    M.in_qd_u = slab + (size_t)P.nq * kWave;
+    M.in_x_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.out_u = slab + (size_t)(P.nq + P.nv) * kWave;
+    M.set_slab(slab, P.nq + 2 * P.nv, P.nq, P.nv);
+    M.set_out(-1);
+    const unsigned bq = (unsigned)(kWave * P.nq) * (unsigned)sizeof(T), bv = (unsigned)(kWave * P.nv) * (unsigned)sizeof(T);
+    const size_t n_tiles = (B + kWave - 1) / kWave;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t left = B - tile * kWave;
+        const int rows_valid = left < (size_t)kWave ? (int)left : kWave;
+        // prologue: the arrays are staged by different wavefronts through their own parts of LDS (capi.cpp sizes LDS for all three at once)
+        if (wave == 0) {
+            stage_issue(q, tile, rows_valid, P.nq, 0u, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            stage_transpose(P.nq, 0u, slab, lane);
+        } else if (NW == 2) {
+            stage_issue(qd, tile, rows_valid, P.nv, bq, lane);
+            stage_issue(ydd, tile, rows_valid, P.nv, bq + bv, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            stage_transpose(P.nv, bq, slab + (size_t)P.nq * kWave, lane);
+            stage_transpose(P.nv, bq + bv, slab + (size_t)(P.nq + P.nv) * kWave, lane);
+        } else if (wave < 3) {
+            const unsigned at = wave == 1 ? bq : bq + bv;
+            stage_issue(wave == 1 ? qd : ydd, tile, rows_valid, P.nv, at, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            stage_transpose(P.nv, at, slab + (size_t)(wave == 1 ? P.nq : P.nq + P.nv) * kWave, lane);
+        }
+        __syncthreads();  // (drains the slab stores: the rows are visible to every wavefront; the staging area is free)
+        for (int s = 0; s < P.n_segs; s++) {
+            const RneaSeg sg = load_rec(P.segs + s);
+            if (sg.op == RSEG_BARRIER) {  // LDS hand-over
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                continue;
+            }
+            if (sg.owner != wave) continue;
+            switch (sg.op) {
+                case RSEG_RUN_FWD: rnea_run_fwd<T, false>(P, M, sg); break;
+                case RSEG_RUN_BWD: rnea_run_bwd<T, false>(P, M, sg); break;
+                case RSEG_PAIR: rnea_pair<T, false>(P, M, load_rec(P.pairs + sg.first)); break;
+                case RSEG_FREE_FWD: {
+                    const RneaFree f = load_rec(P.frees + sg.first);
+                    rnea_free_fwd(P, M, f);
+                    const T zero[6] = {0, 0, 0, 0, 0, 0};  // the force blocks the other wavefronts' limbs add into
+                    if (f.lds_f2 != -1) M.lds_st(f.lds_f2, zero);
+                    if (f.lds_f3 != -1) M.lds_st(f.lds_f3, zero);
+                    if (f.lds_f4 != -1) M.lds_st(f.lds_f4, zero);
+                    break;
+                }
+                default: {
+                    const RneaFree f = load_rec(P.frees + sg.first);
+                    if (f.lds_f2 != -1) {
+                        T x[6];
+                        M.lds_ld(f.lds_f2, x);
+                        add6<T, false>(M, f.lds_f, x);
+                        if (f.lds_f3 != -1) {
+                            M.lds_ld(f.lds_f3, x);
+                            add6<T, false>(M, f.lds_f, x);
+                            if (f.lds_f4 != -1) {
+                                M.lds_ld(f.lds_f4, x);
+                                add6<T, false>(M, f.lds_f, x);
+                            }
+                        }
+                    }
+                    rnea_free_bwd(P, M, f);
+                    break;
+                }
+            }
+        }
+        __syncthreads();  // every torque row is in the slab
+        if (wave == 0) write_outputs(slab + (size_t)(P.nq + P.nv) * kWave, tau, tile, rows_valid, P.nv, lane);
+        // LDS and the slab are free for the next tile once wavefront 0 has read the torque rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+template <class T>
+hipError_t launch_rnea_chain_lm(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid, size_t lds_bytes,
+                                hipStream_t stream, int n_waves)
+{
+    if (n_waves == 4) hipLaunchKernelGGL((rnea_chain_lm_kernel<T, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else if (n_waves == 2) hipLaunchKernelGGL((rnea_chain_lm_kernel<T, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+template hipError_t launch_rnea_chain_lm<float>(const RneaChainDev<float> &, const float *, const float *, const float *, float *, size_t, float *, int, size_t,
+                                                hipStream_t, int);
+template hipError_t launch_rnea_chain_lm<double>(const RneaChainDev<double> &, const double *, const double *, const double *, double *, size_t, double *, int,
+                                                 size_t, hipStream_t, int);
+#endif
+
 template <class T>
 hipError_t launch_rnea_chain_gen(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
                                  size_t lds_bytes, hipStream_t stream);
@@ -3375,8 +3510,10 @@ hipError_t set_max_dynamic_lds_chain_unit3()
 {
     const void *const kernels[] = {reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4>),
                                    reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2, true>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4, true>),
-                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<double, 4>)};
-    return set_max_dynamic_lds(kernels, 5);
+                                   reinterpret_cast<const void *>(&aba_chain_lm_kernel<double, 4>),
+                                   reinterpret_cast<const void *>(&rnea_chain_lm_kernel<float, 2>), reinterpret_cast<const void *>(&rnea_chain_lm_kernel<float, 4>),
+                                   reinterpret_cast<const void *>(&rnea_chain_lm_kernel<double, 2>), reinterpret_cast<const void *>(&rnea_chain_lm_kernel<double, 4>)};
+    return set_max_dynamic_lds(kernels, 9);
 }
 #else
 hipError_t set_max_dynamic_lds_chain_unit2()

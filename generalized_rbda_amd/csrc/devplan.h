@@ -149,6 +149,10 @@ struct RneaChainDev {
 template <class T>
 hipError_t launch_rnea_chain(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid,
                              size_t lds_bytes, hipStream_t stream);
+// latency mode: a tile per workgroup of n_waves = 2 or 4 wavefronts (chain_kernels.hip, rnea_chain_lm_kernel)
+template <class T>
+hipError_t launch_rnea_chain_lm(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid, size_t lds_bytes,
+                                hipStream_t stream, int n_waves);
 
 // single-cluster programs (RneaChainProgram::single_gen; chain_kernels.hip, rnea_gen1_kernel): P.lds_bytes = the work area, lds_bytes =
 // work area + nq + 2 nv rows of staged inputs

@@ -1575,9 +1575,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 std::vector<RRun> rruns;
                 std::vector<int> rt_fwd(chains.size(), -1), rt_bwd(chains.size(), -1), rt_pair(chains.size(), -1);
                 std::vector<int> rt_free_fwd(nc, -1), rt_free_bwd(nc, -1);
-                auto rpush = [&](int op) { RneaSeg sg = RneaSeg(); sg.op = op; sg.lds_pva = sg.lds_pf = -1; R.segs.push_back(sg); return static_cast<int>(R.segs.size()) - 1; };
+                int r_owner = 0;
+                auto rpush = [&](int op) { RneaSeg sg = RneaSeg(); sg.op = op; sg.lds_pva = sg.lds_pf = -1; sg.owner = r_owner; R.segs.push_back(sg); return static_cast<int>(R.segs.size()) - 1; };
+                const bool rlm = lm && ok;  // (the limbs were dealt out above: owner_of)
                 std::function<int(int)> remit = [&](int id) -> int {  // returns the last forward-type segment of the subtree
                     const Chain ch = chains[id];
+                    r_owner = rlm ? owner_of[id] : 0;
                     if (ch.diff || ch.gen) {
                         int last = rt_fwd[id] = rpush(ch.gen ? RSEG_GEN_FWD : RSEG_DIFF_FWD);
                         for (int k : ch.kid_chains) last = std::max(last, remit(k));
@@ -1589,6 +1592,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     int last = rt_fwd[id];
                     if (ch.pair >= 0) last = rt_pair[id] = rpush(RSEG_PAIR);
                     for (int k : ch.kid_chains) last = std::max(last, remit(k));
+                    r_owner = rlm ? owner_of[id] : 0;
                     rt_bwd[id] = rpush(RSEG_RUN_BWD);
                     std::vector<int> rev(ch.cl.rbegin(), ch.cl.rend());
                     rruns.push_back({rt_bwd[id], rev});
@@ -1598,8 +1602,12 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 for (int id : ground_chains) remit(id);
                 for (int c = 0; c < nc; c++) {
                     if (cls[c] != 0) continue;
+                    r_owner = 0;
                     rt_free_fwd[c] = rpush(RSEG_FREE_FWD);
+                    if (rlm) rpush(RSEG_BARRIER);  // the base's [v | a] and its force rows are in LDS: the limbs may start
                     for (int id : free_chains[c]) remit(id);
+                    r_owner = 0;
+                    if (rlm) rpush(RSEG_BARRIER);  // every limb has added its force
                     rt_free_bwd[c] = rpush(RSEG_FREE_BWD);
                 }
                 // last segment that reads the [v, a] of a chain's tip: the forward runs / pair of its kid chains
@@ -1615,11 +1623,15 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         RneaFree &f = rf[c];
                         f = RneaFree();
                         f.q_index = cr.q_index; f.v_index = cr.v_index; f.cofs = bodies[cr.first_body].cofs;
-                        f.lds_va = f.lds_f = -1;
+                        f.lds_va = f.lds_f = f.lds_f2 = f.lds_f3 = f.lds_f4 = -1;
                         int last = rt_free_fwd[c];
                         for (int id : free_chains[c]) last = std::max(last, rt_fwd[id]);
                         if (!free_chains[c].empty()) robjs.push_back({&f.lds_va, 12, 0, rt_free_fwd[c], last, -1, 1});
                         robjs.push_back({&f.lds_f, 6, 0, rt_free_fwd[c], rt_free_bwd[c], -1, 1});
+                        if (rlm) {  // one force row block per wavefront: no two wavefronts read-modify-write the same rows
+                            int32_t *const extra[3] = {&f.lds_f2, &f.lds_f3, &f.lds_f4};
+                            for (int o = 1; o < n_waves && o < 4; o++) robjs.push_back({extra[o - 1], 6, 0, rt_free_fwd[c], rt_free_bwd[c], -1, 1});
+                        }
                     } else if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) {
                         RneaLink &l = rl[c];
                         l = RneaLink();
@@ -1668,6 +1680,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 }
                 for (size_t id = 0; id < chains.size(); id++) {
                     const Chain &ch = chains[id];
+                    struct RTag {  // on leaving the iteration: latency-mode programs tag the chain's objects with its wavefront (limbs of different
+                                   // wavefronts run concurrently: their objects never share rows, whatever the segment order says)
+                        std::vector<Obj> &v; size_t from; int owner; bool on;
+                        ~RTag() { if (on) for (size_t i = from; i < v.size(); i++) v[i].owner = owner; }
+                    } rtag{robjs, robjs.size(), rlm ? owner_of[id] : -1, rlm};
                     if (ch.gen) {
                         const int c = ch.cl[0];
                         ChainGen &g = rg[c];
@@ -1714,7 +1731,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                 }
                 int rn_lds = 0, rn_glb = 0;
                 bool rok = allocate_packed(robjs, rnea_budget, rn_lds, rn_glb);
-                if (!rok) {
+                if (!rok && !lm) {
                     // second try: the links' [f | sin, cos | rotor torque] blocks take what LDS the other objects leave
                     // and otherwise go to the wave's global slab
                     for (Obj &o : robjs)
@@ -1732,13 +1749,22 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                             d.lds_w = d.lds_blk;
                             d.lds_va = chains[id].kid_chains.empty() ? -1 : d.lds_blk + 14;
                         }
-                    auto f_slot_of_body = [&](int b) -> int {
+                    auto f_slot_of_body = [&](int b, int owner = 0) -> int {
                         if (b < 0) return -1;  // ground
                         const int c = m.bodies[b].cluster;
                         if (is_diff(c)) return rd[c].lds_blk;
                         if (cls[c] == 7) return rg[c].glb_k + 8 * (b - clusters[c].first_body);
-                        return cls[c] == 0 ? rf[c].lds_f : rl[c].lds_blk;
+                        if (cls[c] != 0) return rl[c].lds_blk;
+                        const RneaFree &f = rf[c];
+                        return !rlm || owner == 0 ? f.lds_f : (owner == 1 ? f.lds_f2 : (owner == 2 ? f.lds_f3 : f.lds_f4));
                     };
+                    // (latency mode: the wavefront of the chain a cluster belongs to)
+                    std::vector<int> owner_of_cluster(nc, 0);
+                    if (rlm)
+                        for (size_t id2 = 0; id2 < chains.size(); id2++) {
+                            for (int c2 : chains[id2].cl) owner_of_cluster[c2] = owner_of[id2];
+                            if (chains[id2].pair >= 0) owner_of_cluster[chains[id2].pair] = owner_of[id2];
+                        }
                     auto va_slot_of_body2 = [&](int b) -> int {
                         if (b < 0) return -1;
                         const int c = m.bodies[b].cluster;
@@ -1754,8 +1780,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     for (int c = 0; c < nc; c++) {
                         const int pb = clusters[c].parent_body;
                         if (cls[c] == 7) { rg[c].lds_pva = va_slot_of_body2(pb); rg[c].lds_acc_out = f_slot_of_body(pb); }
-                        if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) rl[c].lds_pf = f_slot_of_body(pb);
-                        if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb); }
+                        if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) rl[c].lds_pf = f_slot_of_body(pb, owner_of_cluster[c]);
+                        if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb, owner_of_cluster[c]); }
                         if (is_diff(c)) { rd[c].lds_pva = va_slot_of_body2(pb); rd[c].lds_pf = f_slot_of_body(pb); }
                     }
                     for (const RRun &r : rruns) {
@@ -1768,7 +1794,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         const Chain &ch = chains[id];
                         const int pb = clusters[ch.cl.front()].parent_body;
                         R.segs[rt_fwd[id]].lds_pva = va_slot_of_body2(pb);
-                        R.segs[rt_bwd[id]].lds_pf = f_slot_of_body(pb);
+                        R.segs[rt_bwd[id]].lds_pf = f_slot_of_body(pb, rlm ? owner_of[id] : 0);
                         if (ch.diff) {
                             R.segs[rt_fwd[id]].first = R.segs[rt_bwd[id]].first = static_cast<int>(R.diffs.size());
                             R.diffs.push_back(rd[ch.cl[0]]);
@@ -1798,6 +1824,8 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     }
                     R.n_lds = rn_lds;
                     R.n_glb = rn_glb;
+                    R.n_waves = rlm ? n_waves : 1;
+                    if (lm && (!rlm || !R.diffs.empty() || !R.gens.empty())) rok = false;  // (latency mode: links and leaf pairs below one floating base)
                 }
                 R.ok = rok;
                 R.single_gen = rok && R.gens.size() == 1 && R.segs.size() == 2 && R.links.empty() && R.pairs.empty() && R.frees.empty() &&
@@ -2109,11 +2137,11 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
         if (!P.rchain64.ok) build_chain(scratch_cp, 2 * lds.aba64, &P.rchain64, 2 * lds.aba64);
     }
     // latency mode serves batches of at most one tile per SIMD, i.e. four tiles per CU: 40 KiB of LDS per tile
-    build_chain(P.chain32p, 40960 / (4 * kWave), nullptr, 0, 2, std::getenv("GRBDA_LM2_SLAB") == nullptr, true);  // (A/B switch: blocks in the slab)
-    build_chain(P.chain64p, 40960 / (8 * kWave), nullptr, 0, 2);
+    build_chain(P.chain32p, 40960 / (4 * kWave), &P.rchain32p, 40960 / (4 * kWave), 2, std::getenv("GRBDA_LM2_SLAB") == nullptr, true);  // (A/B switch: blocks in the slab)
+    build_chain(P.chain64p, 40960 / (8 * kWave), &P.rchain64p, 40960 / (8 * kWave), 2);
     // four wavefronts per tile: batches of at most two tiles per CU (one wavefront per SIMD in the two-wavefront mode), 80 KiB each
-    build_chain(P.chain32q, 81920 / (4 * kWave), nullptr, 0, 4, true, true);
-    build_chain(P.chain64q, 81920 / (8 * kWave), nullptr, 0, 4, true);
+    build_chain(P.chain32q, 81920 / (4 * kWave), &P.rchain32q, 81920 / (4 * kWave), 4, true, true);
+    build_chain(P.chain64q, 81920 / (8 * kWave), &P.rchain64q, 81920 / (8 * kWave), 4, true);
 
     // ---- composite-rigid-body program (crba_kernels.hip) ----------------------------------------------------------
     {

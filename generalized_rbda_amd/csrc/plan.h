@@ -331,7 +331,8 @@ struct ChainFree {      // 16 ints
 // forward run: v, a, body force f = I a + v x* I v of every link, the rotor's torque and its force on the parent body;
 // backward run: tau = S^T f, f_parent += X^T f.  A leaf pair cluster is finished in one segment of the forward pass.
 enum RneaChainOp : int32_t { RSEG_FREE_FWD = 0, RSEG_RUN_FWD = 1, RSEG_PAIR = 2, RSEG_RUN_BWD = 3, RSEG_FREE_BWD = 4,
-                             RSEG_DIFF_FWD = 5, RSEG_DIFF_BWD = 6, RSEG_GEN_FWD = 7, RSEG_GEN_BWD = 8 };
+                             RSEG_DIFF_FWD = 5, RSEG_DIFF_BWD = 6, RSEG_GEN_FWD = 7, RSEG_GEN_BWD = 8,
+                             RSEG_BARRIER = 9 };  // latency-mode programs (RneaChainProgram::n_waves > 1): every wavefront of the workgroup meets here
 struct RneaLink {       // 16 ints
     int32_t q_index, v_index;
     int32_t cofs, rofs;     // link / rotor constants (rofs -1: plain revolute cluster)
@@ -353,13 +354,14 @@ struct RneaSeg {        // 8 ints
     int32_t op, first, count;
     int32_t lds_pva;        // RSEG_RUN_FWD: [v][a] of the body the chain hangs off, -1: ground
     int32_t lds_pf;         // RSEG_RUN_BWD: force slot of that body, -1: ground
-    int32_t reserved[3];
+    int32_t owner;          // latency-mode programs: the wavefront of the workgroup that runs this segment (the base's segments: 0)
+    int32_t reserved[2];
 };
 struct RneaFree {       // 8 ints
     int32_t q_index, v_index, cofs;
     int32_t lds_va;         // own [v][a], -1 when no children
     int32_t lds_f;          // own force (children add theirs)
-    int32_t reserved[3];
+    int32_t lds_f2, lds_f3, lds_f4;  // latency-mode programs: what the limbs of the second .. fourth wavefront add into (-1: none)
 };
 struct RneaChainProgram {
     bool ok = false;
@@ -373,6 +375,9 @@ struct RneaChainProgram {
     int n_lds = 0;
     int n_glb = 0;  // > 0: some link blocks live in the wave's global slab (their slot numbers carry kSlotGlobal)
     bool single_gen = false;  // the whole model is ONE generic cluster on the ground: rnea_gen1_kernel (no slab, fused sweeps)
+    // Latency mode (n_waves = 2 or 4, as ChainProgram::n_waves): the limbs below the floating base are dealt to the wavefronts of a workgroup (RneaSeg::owner), the base's
+    // forward segment runs first on wavefront 0, its backward segment last; two RSEG_BARRIER segments order the hand-overs.  Links and leaf pairs only.
+    int n_waves = 1;
 };
 
 struct ChainProgram {
@@ -510,6 +515,7 @@ struct HostPlan {
     DerivProgram deriv;
     RneaChainProgram rchain32, rchain64;  // inverse dynamics on the chains
     RneaChainProgram rchain32w;           // f32 laid out for four wavefronts per SIMD (half the LDS per wavefront)
+    RneaChainProgram rchain32p, rchain64p, rchain32q, rchain64q;  // latency mode: two / four wavefronts per tile (RneaChainProgram::n_waves)
     // statistics for DESIGN.md / bench.py
     double flops_aba = 0, flops_rnea = 0;
 };
