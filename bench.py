@@ -260,6 +260,7 @@ CONFIG_RECORDS = [
     # one GPU's share of an 8-way STRONG split of configs 3 and 4 (SURVEY 8e's 0.9 is about these batches): the step of a rank is its kernel on B / 8 states,
     # so `split_efficiency` = t(B) / (8 t(B / 8)) with t(B) from this same line is what an 8-GPU node would show (tools/strong_scaling_proxy.py)
     (3, "mit_humanoid", "aba", "f32", 32768, 8),
+    (3, "mit_humanoid", "rnea", "f32", 32768, 8),
     (4, "tello", "aba", "f32", 131072, 8),
 ]
 

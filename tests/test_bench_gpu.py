@@ -44,8 +44,10 @@ def test_bench_line_is_verified_and_carries_roofline_and_cpu_baseline(gpu):
         assert x["verified"] is True and x["ms"] > 0 and x["evals_per_s"] > 0 and 0 < x["roofline"]["frac"] < 1, x
         assert x["kernel"]
     # one GPU's share of the 8-way strong split of configs 3 and 4, with the efficiency that split would have
-    shares = {x["workload"]: x for x in line["configs"] if x.get("split") == 8}
+    shares = {x["workload"]: x for x in line["configs"] if x.get("split") == 8 and x["algo"] == "aba"}
     assert set(shares) == {"mit_humanoid", "tello"}
+    rnea_share = [x for x in line["configs"] if x.get("split") == 8 and x["algo"] == "rnea"]
+    assert len(rnea_share) == 1 and rnea_share[0]["verified"] is True and "rnea_chain_lm_kernel<float, 4>" in rnea_share[0]["kernel"]
     for x in shares.values():
         assert "error" not in x, x
         assert x["verified"] is True and 0.2 < x["split_efficiency"] < 1.2 and x["batch"] * 8 in (262144, 1048576), x
