@@ -632,10 +632,10 @@ int choose_rnea_lm(const grbda_plan *p, int n_cu, size_t B)
     const bool kid = sizeof(T) == 8;
     const RneaChainProgram &r4 = kid ? h.rchain64q : h.rchain32q, &r2 = kid ? h.rchain64p : h.rchain32p;
     const size_t stage_all = static_cast<size_t>(kWave) * static_cast<size_t>(h.nq + 2 * h.nv) * sizeof(T);
-    if (r4.ok && r4.n_waves == 4 && p->lm_waves != 2 && n_tiles <= static_cast<size_t>(n_cu) * 2 &&
+    if (r4.ok && r4.n_waves == 4 && (!kid || r4.diffs.empty()) && p->lm_waves != 2 && n_tiles <= static_cast<size_t>(n_cu) * 2 &&
         std::max(static_cast<size_t>(r4.n_lds) * kWave * sizeof(T), stage_all) <= 81920)
         return 4;
-    if (r2.ok && r2.n_waves == 2 && n_tiles <= static_cast<size_t>(n_cu) * 4 && std::max(static_cast<size_t>(r2.n_lds) * kWave * sizeof(T), stage_all) <= 40960)
+    if (r2.ok && r2.n_waves == 2 && (!kid || r2.diffs.empty()) && n_tiles <= static_cast<size_t>(n_cu) * 4 && std::max(static_cast<size_t>(r2.n_lds) * kWave * sizeof(T), stage_all) <= 40960)
         return 2;
     return 0;
 }
@@ -671,6 +671,9 @@ int run_rnea_chain(const grbda_plan *p, const DeviceTables &t, const T *q, const
             d.links = t.rchain_links[wi];
             d.pairs = t.rchain_pairs[wi];
             d.frees = t.rchain_frees[wi];
+            d.diffs = lp.diffs.empty() ? nullptr : t.rchain_diffs[wi];  // (fp32 programs only)
+            d.n_diffs = static_cast<int>(lp.diffs.size());
+            d.cints = t.cints;
             d.consts = sizeof(T) == 4 ? reinterpret_cast<const T *>(t.consts32) : reinterpret_cast<const T *>(t.consts64);
             d.n_segs = static_cast<int>(lp.segs.size());
             d.nq = h.nq;
@@ -2094,7 +2097,8 @@ static std::string kernel_name_of(const grbda_plan *p, int kind, int n_cu, size_
             return buf;
         }
         if (const int lmw = choose_rnea_lm<T>(p, n_cu, B)) {
-            std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_lm_kernel<%s, %d>", tn, lmw);
+            const RneaChainProgram &lr = lmw == 4 ? (sizeof(T) == 8 ? h.rchain64q : h.rchain32q) : (sizeof(T) == 8 ? h.rchain64p : h.rchain32p);
+            std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_lm_kernel<%s, %d%s>", tn, lmw, lr.diffs.empty() ? "" : ", true");
             return buf;
         }
         std::snprintf(buf, sizeof buf, "grbda_hip::rnea_chain_kernel<%s, %d, %s>", tn, !rp.gens.empty() ? 2 : (rp.diffs.empty() ? 0 : 1), rp.n_glb > 0 ? "true" : "false");

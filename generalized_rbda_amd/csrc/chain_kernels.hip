@@ -3224,7 +3224,7 @@ __global__ __launch_bounds__(kWave, 2) void rnea_chain_kernel(RneaChainDev<T> DP
 // in LDS (40 / 80 KiB per tile).  Same device functions and operations per state as rnea_chain_kernel; the limbs' forces reach the base as one partial sum
 // per wavefront.
 // ---------------------------------------------------------------------------------------------------------------
-template <class T, int NW>
+template <class T, int NW, bool DIFF = false>
 __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rnea_chain_lm_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *__restrict__ qd, const T *__restrict__ ydd, T *__restrict__ tau, size_t B,
                           T *__restrict__ scratch)
@@ -3234,10 +3234,10 @@ void rnea_chain_lm_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *
     P.links = (cptr<RneaLink>)DP.links;
     P.pairs = (cptr<RneaPair>)DP.pairs;
     P.frees = (cptr<RneaFree>)DP.frees;
-    P.diffs = nullptr;
+    P.diffs = DIFF ? (cptr<RneaDiff>)DP.diffs : nullptr;
     P.gens = nullptr;
     P.gbodies = nullptr;
-    P.cints = nullptr;
+    P.cints = DIFF ? (cptr<int32_t>)DP.cints : nullptr;
     P.consts = (cptr<T>)DP.consts;
     P.n_segs = DP.n_segs;
     P.nq = DP.nq;
@@ -3299,6 +3299,12 @@ void rnea_chain_lm_kernel(RneaChainDev<T> DP, const T *__restrict__ q, const T *
                 case RSEG_RUN_FWD: rnea_run_fwd<T, false>(P, M, sg); break;
                 case RSEG_RUN_BWD: rnea_run_bwd<T, false>(P, M, sg); break;
                 case RSEG_PAIR: rnea_pair<T, false>(P, M, load_rec(P.pairs + sg.first)); break;
+                case RSEG_DIFF_FWD:
+                    if constexpr (DIFF) rnea_diff_fwd<T, false>(P, M, load_rec(P.diffs + sg.first));
+                    break;
+                case RSEG_DIFF_BWD:
+                    if constexpr (DIFF) rnea_diff_bwd<T, false>(P, M, load_rec(P.diffs + sg.first));
+                    break;
                 case RSEG_FREE_FWD: {
                     const RneaFree f = load_rec(P.frees + sg.first);
                     rnea_free_fwd(P, M, f);
@@ -3340,6 +3346,15 @@ template <class T>
 hipError_t launch_rnea_chain_lm(const RneaChainDev<T> &P, const T *q, const T *qd, const T *ydd, T *tau, size_t B, T *scratch, int grid, size_t lds_bytes,
                                 hipStream_t stream, int n_waves)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (P.n_diffs > 0) {  // (fp32 programs only: plan.cpp)
+            if (n_waves == 4) hipLaunchKernelGGL((rnea_chain_lm_kernel<T, 4, true>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+            else if (n_waves == 2) hipLaunchKernelGGL((rnea_chain_lm_kernel<T, 2, true>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
+    if (P.n_diffs > 0) return hipErrorInvalidValue;
     if (n_waves == 4) hipLaunchKernelGGL((rnea_chain_lm_kernel<T, 4>), dim3(grid), dim3(4 * kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     else if (n_waves == 2) hipLaunchKernelGGL((rnea_chain_lm_kernel<T, 2>), dim3(grid), dim3(2 * kWave), lds_bytes, stream, P, q, qd, ydd, tau, B, scratch);
     else return hipErrorInvalidValue;
@@ -3512,8 +3527,9 @@ hipError_t set_max_dynamic_lds_chain_unit3()
                                    reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 2, true>), reinterpret_cast<const void *>(&aba_chain_lm_kernel<float, 4, true>),
                                    reinterpret_cast<const void *>(&aba_chain_lm_kernel<double, 4>),
                                    reinterpret_cast<const void *>(&rnea_chain_lm_kernel<float, 2>), reinterpret_cast<const void *>(&rnea_chain_lm_kernel<float, 4>),
-                                   reinterpret_cast<const void *>(&rnea_chain_lm_kernel<double, 2>), reinterpret_cast<const void *>(&rnea_chain_lm_kernel<double, 4>)};
-    return set_max_dynamic_lds(kernels, 9);
+                                   reinterpret_cast<const void *>(&rnea_chain_lm_kernel<double, 2>), reinterpret_cast<const void *>(&rnea_chain_lm_kernel<double, 4>),
+                                   reinterpret_cast<const void *>(&rnea_chain_lm_kernel<float, 2, true>), reinterpret_cast<const void *>(&rnea_chain_lm_kernel<float, 4, true>)};
+    return set_max_dynamic_lds(kernels, 11);
 }
 #else
 hipError_t set_max_dynamic_lds_chain_unit2()

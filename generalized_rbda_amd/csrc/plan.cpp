@@ -1762,7 +1762,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     std::vector<int> owner_of_cluster(nc, 0);
                     if (rlm)
                         for (size_t id2 = 0; id2 < chains.size(); id2++) {
-                            for (int c2 : chains[id2].cl) owner_of_cluster[c2] = owner_of[id2];
+                            for (int c2 : chains[id2].cl) owner_of_cluster[c2] = owner_of[id2];  // (a differential is a chain of its one cluster)
                             if (chains[id2].pair >= 0) owner_of_cluster[chains[id2].pair] = owner_of[id2];
                         }
                     auto va_slot_of_body2 = [&](int b) -> int {
@@ -1782,7 +1782,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                         if (cls[c] == 7) { rg[c].lds_pva = va_slot_of_body2(pb); rg[c].lds_acc_out = f_slot_of_body(pb); }
                         if (cls[c] == 1 || cls[c] == 2 || cls[c] == 4) rl[c].lds_pf = f_slot_of_body(pb, owner_of_cluster[c]);
                         if (cls[c] == 3) { rp[c].lds_pva = va_slot_of_body2(pb); rp[c].lds_pf = f_slot_of_body(pb, owner_of_cluster[c]); }
-                        if (is_diff(c)) { rd[c].lds_pva = va_slot_of_body2(pb); rd[c].lds_pf = f_slot_of_body(pb); }
+                        if (is_diff(c)) { rd[c].lds_pva = va_slot_of_body2(pb); rd[c].lds_pf = f_slot_of_body(pb, owner_of_cluster[c]); }
                     }
                     for (const RRun &r : rruns) {
                         RneaSeg &sg = R.segs[r.seg];
@@ -1825,7 +1825,7 @@ int compile_plan(const void *blob, size_t bytes, const LdsBudget &lds, int sweep
                     R.n_lds = rn_lds;
                     R.n_glb = rn_glb;
                     R.n_waves = rlm ? n_waves : 1;
-                    if (lm && (!rlm || !R.diffs.empty() || !R.gens.empty())) rok = false;  // (latency mode: links and leaf pairs below one floating base)
+                    if (lm && (!rlm || (!R.diffs.empty() && !lm_diffs) || !R.gens.empty())) rok = false;  // (latency mode: links, leaf pairs and -- fp32 -- differentials below one floating base)
                 }
                 R.ok = rok;
                 R.single_gen = rok && R.gens.size() == 1 && R.segs.size() == 2 && R.links.empty() && R.pairs.empty() && R.frees.empty() &&
